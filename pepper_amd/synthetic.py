@@ -1,0 +1,172 @@
+"""Deterministic synthetic checkpoints and summary tensors (numpy only, no torch RNG).
+
+There is no network in the build environment, so neither the released PEPPER
+checkpoints nor real HG003 summaries exist here.  Everything that needs weights or
+inputs (tests, golden-vector generation, ``bench.py``, ``smoke()``) draws them from
+the recipes below so that the container that generated ``tests/golden/*`` and the GPU
+box see bit-identical tensors without shipping 47 MB of weights.
+
+Weight layout follows the reference state_dicts:
+  variant: /root/reference/pepper_variant/modules/python/models/simple_model.py:23-46
+  polish : /root/reference/pepper/modules/python/models/simple_model.py:12-21
+Checkpoint dict keys follow
+  /root/reference/pepper_variant/modules/python/models/train_distributed.py:36-42
+  ({'model_state_dict', 'hidden_size', 'gru_layers', 'epochs', ...}).
+Synthetic summary distributions follow SURVEY.md section 8(d) (V-syn / P-syn).
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+# ---- shapes of the two model families -------------------------------------------------
+VARIANT_FEATURES = 26      # ImageSizeOptions.IMAGE_HEIGHT   (pepper_variant Options.py:6)
+VARIANT_WINDOW = 33        # CANDIDATE_WINDOW_SIZE + 1        (pepper_variant Options.py:8)
+VARIANT_LSTM_HIDDEN = 256  # hard-coded lstm_1/2_hidden_size  (simple_model.py:15-16)
+VARIANT_LINEAR = 512
+VARIANT_CLASSES = 3        # TOTAL_TYPE_LABELS
+
+POLISH_FEATURES = 10       # pepper Options.py:2
+POLISH_HIDDEN = 128        # TrainOptions.HIDDEN_SIZE (pepper Options.py:19)
+POLISH_CLASSES = 5
+POLISH_SEQ = 1000
+POLISH_WINDOW = 100
+POLISH_JUMP = 50
+
+VSYN_SEED = 20260926
+PSYN_SEED = 20260927
+
+
+def _uniform(rng, shape, bound):
+    return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+
+def variant_param_shapes(image_features=VARIANT_FEATURES, gru_layers=1,
+                         num_classes_type=VARIANT_CLASSES, window=VARIANT_WINDOW):
+    """(name, shape, init_bound) in the reference's state_dict order."""
+    H = VARIANT_LSTM_HIDDEN
+    out = []
+    for mod, in0 in (("encoder", image_features), ("decoder", 2 * H)):
+        for layer in range(gru_layers):
+            in_sz = in0 if layer == 0 else 2 * H
+            for suffix in ("", "_reverse"):
+                k = 1.0 / np.sqrt(H)
+                out.append((f"{mod}.weight_ih_l{layer}{suffix}", (4 * H, in_sz), k))
+                out.append((f"{mod}.weight_hh_l{layer}{suffix}", (4 * H, H), k))
+                out.append((f"{mod}.bias_ih_l{layer}{suffix}", (4 * H,), k))
+                out.append((f"{mod}.bias_hh_l{layer}{suffix}", (4 * H,), k))
+    L = VARIANT_LINEAR
+    dims = [("linear_1", 2 * H * window, L), ("linear_2", L, L), ("linear_3", L, L),
+            ("linear_4", L, L), ("linear_5", L, L), ("output_layer_type", L, num_classes_type)]
+    for name, fin, fout in dims:
+        k = 1.0 / np.sqrt(fin)
+        out.append((f"{name}.weight", (fout, fin), k))
+        out.append((f"{name}.bias", (fout,), k))
+    return out
+
+
+def polish_param_shapes(image_features=POLISH_FEATURES, gru_layers=1, hidden=POLISH_HIDDEN,
+                        num_classes=POLISH_CLASSES):
+    H = hidden
+    out = []
+    for mod, in0 in (("gru_encoder", image_features), ("gru_decoder", 2 * H)):
+        for layer in range(gru_layers):
+            in_sz = in0 if layer == 0 else 2 * H
+            for suffix in ("", "_reverse"):
+                k = 1.0 / np.sqrt(H)
+                out.append((f"{mod}.weight_ih_l{layer}{suffix}", (3 * H, in_sz), k))
+                out.append((f"{mod}.weight_hh_l{layer}{suffix}", (3 * H, H), k))
+                out.append((f"{mod}.bias_ih_l{layer}{suffix}", (3 * H,), k))
+                out.append((f"{mod}.bias_hh_l{layer}{suffix}", (3 * H,), k))
+    k = 1.0 / np.sqrt(2 * H)
+    out.append(("dense1.weight", (num_classes, 2 * H), k))
+    out.append(("dense1.bias", (num_classes,), k))
+    return out
+
+
+def _state_dict(shapes, seed, gain):
+    sd = OrderedDict()
+    for idx, (name, shape, bound) in enumerate(shapes):
+        rng = np.random.default_rng([seed, idx])
+        sd[name] = _uniform(rng, shape, bound * gain)
+    return sd
+
+
+def variant_state_dict(seed=0, gain=1.0, **kw):
+    """numpy state_dict of the variant model (PyTorch-default init bounds x ``gain``).
+
+    gain=1 resembles a freshly initialised network (outputs near 1/3 each); gain>1
+    saturates gates and spreads the softmax, which is the harder parity case.
+    """
+    return _state_dict(variant_param_shapes(**kw), seed, gain)
+
+
+def polish_state_dict(seed=0, gain=1.0, **kw):
+    return _state_dict(polish_param_shapes(**kw), seed, gain)
+
+
+def checkpoint_dict(state_dict, hidden_size, gru_layers=1, epochs=1, module_prefix=False):
+    """Reference checkpoint schema (torch tensors are made by the caller)."""
+    sd = OrderedDict((("module." + k if module_prefix else k), v) for k, v in state_dict.items())
+    return {"model_state_dict": sd, "hidden_size": hidden_size, "gru_layers": gru_layers,
+            "epochs": epochs}
+
+
+# ---- synthetic summaries ----------------------------------------------------------------
+def variant_windows(n, seed=VSYN_SEED, window=VARIANT_WINDOW, features=VARIANT_FEATURES):
+    """V-syn: int8 [n, 33, 26] candidate windows with a summary-like value distribution.
+
+    Column meaning: /root/reference/pepper_variant/modules/cpp/region_summary.h:23-48.
+    Counts are stored negated by the encoder (region_summary.cpp:381-430); the centre
+    row carries the candidate-specific overwrite (region_summary.cpp:848-905).
+    """
+    rng = np.random.default_rng(seed)
+    x = np.zeros((n, window, features), dtype=np.int16)
+    x[:, :, 0] = rng.integers(1, 6, size=(n, window))
+    for col in (4, 15):
+        x[:, :, col] = -np.clip(rng.poisson(30, size=(n, window)), 0, 125)
+    base_cols = list(range(8, 15)) + list(range(19, 26))
+    sparse = rng.random(size=(n, window, len(base_cols))) < 0.10
+    vals = -np.clip(rng.poisson(3, size=(n, window, len(base_cols))), 0, 125)
+    x[:, :, base_cols] = np.where(sparse, vals, 0)
+    mid = window // 2
+    kind = rng.integers(0, 3, size=n)  # 0 SNP, 1 INS, 2 DEL
+    rows = np.arange(n)
+    alt = rng.integers(1, 5, size=n)
+    length = np.clip(rng.geometric(0.4, size=n), 1, 60)
+    fwd = np.clip(rng.poisson(6, size=n), 0, 125)
+    rev = np.clip(rng.poisson(6, size=n), 0, 125)
+    snp, ins, dele = kind == 0, kind == 1, kind == 2
+    x[rows[snp], mid, 1] = alt[snp]
+    x[rows[snp], mid, 5] = fwd[snp]
+    x[rows[snp], mid, 16] = rev[snp]
+    x[rows[snp], mid, 7 + alt[snp]] = fwd[snp]       # negated base column -> positive
+    x[rows[snp], mid, 18 + alt[snp]] = rev[snp]
+    x[rows[ins], mid, 2] = length[ins]
+    x[rows[ins], mid, 6] = fwd[ins]
+    x[rows[ins], mid, 17] = rev[ins]
+    x[rows[ins], mid, 12] = fwd[ins]
+    x[rows[ins], mid, 23] = rev[ins]
+    x[rows[dele], mid, 3] = length[dele]
+    x[rows[dele], mid, 7] = fwd[dele]
+    x[rows[dele], mid, 18] = rev[dele]
+    x[rows[dele], mid, 13] = fwd[dele]
+    x[rows[dele], mid, 24] = rev[dele]
+    return x.astype(np.int8)
+
+
+def polish_chunks(n, seed=PSYN_SEED, seq=POLISH_SEQ, features=POLISH_FEATURES):
+    """P-syn: uint8 [n, 1000, 10] chunks; each row a composition summing to <= 254.
+
+    Row semantics: /root/reference/pepper/modules/src/pileup_summary/summary_generator.cpp:274-306
+    (count / coverage * 254, truncated).  2 % of chunks get zero-padded tails as produced by
+    chunk_images (/root/reference/pepper/modules/python/AlignmentSummarizer.py:18-56).
+    """
+    rng = np.random.default_rng(seed)
+    alpha = np.array([4, 1, 1, 1, 4, 1, 1, 1, 0.3, 0.3]) * 0.25
+    frac = rng.dirichlet(alpha, size=(n, seq))
+    img = np.floor(frac * 254.0).astype(np.uint8)
+    padded = rng.random(n) < 0.02
+    tail = rng.integers(1, seq // 2, size=n)
+    for i in np.nonzero(padded)[0]:
+        img[i, seq - tail[i]:, :] = 0
+    return img
