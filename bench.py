@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Throughput benchmark of the RNN inference hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model variant|polish]
+
+A "step" is one pass of the hot path over one resident batch of synthetic summaries per GPU
+(variant: 16384 candidate windows int8 [.,33,26] = 32 reference batches of 512; polish: 2048
+chunks uint8 [.,1000,10] = 19 windows each).  Inputs are in HBM before the timed region; the
+timed region is bracketed by barrier + synchronize on both sides and the maximum over ranks is
+reported.  Rank 0 prints one JSON line (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from pepper_amd import _lib, synthetic  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+VARIANT_FLOP_PER_WINDOW = 2 * 80_664_064      # SURVEY.md 8(a) A8 / BASELINE.md section 2
+POLISH_FLOP_PER_WINDOW = 2 * 40_217_600       # per 100-step window (A12)
+POLISH_WINDOWS_PER_CHUNK = 19
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", choices=["variant", "polish"], default="variant")
+    ap.add_argument("--per-gpu", type=int, default=0, help="windows (variant) / chunks (polish) per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def dist_setup(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+        local = 0
+    return world, rank, local
+
+
+def broadcast_state_dict(make_sd, shapes, world, rank, dev):
+    """Rank 0 owns the checkpoint; everyone else receives one packed fp32 blob over RCCL
+    (the only collective on the path: SURVEY.md 8(e))."""
+    if world == 1:
+        return make_sd()
+    import torch.distributed as dist
+    total = sum(int(np.prod(s)) for _, s, _ in shapes)
+    blob = torch.empty(total, dtype=torch.float32, device=dev)
+    if rank == 0:
+        sd = make_sd()
+        blob.copy_(torch.from_numpy(np.concatenate([sd[n].ravel() for n, _, _ in shapes])))
+    dist.broadcast(blob, src=0)
+    host = blob.cpu().numpy()
+    out, off = {}, 0
+    for n, s, _ in shapes:
+        k = int(np.prod(s))
+        out[n] = host[off:off + k].reshape(s)
+        off += k
+    return out
+
+
+def cpu_baseline(model_kind, seconds):
+    """The torch.nn port of the reference forward (oracle/torch_port.py) on the host cores."""
+    from oracle import torch_port
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    if model_kind == "variant":
+        sd = synthetic.variant_state_dict(seed=0)
+        model = torch_port.load_numpy_state_dict(torch_port.VariantPort(), sd)
+        x = torch.from_numpy(synthetic.variant_windows(512, seed=1)).float()
+        run = lambda: model(x)
+        units, unit = 512, "windows/s"
+        sample = "batch 512 x [33,26] V-syn windows, torch.nn CPU forward, all host cores"
+    else:
+        sd = synthetic.polish_state_dict(seed=0)
+        model = torch_port.load_numpy_state_dict(torch_port.PolishPort(), sd)
+        img = synthetic.polish_chunks(128, seed=1)
+        run = lambda: torch_port.polish_predict_chunks(model, img, 128)
+        units, unit = 128 * POLISH_WINDOWS_PER_CHUNK, "windows/s"
+        sample = "batch 128 chunks x [1000,10] P-syn (19 windows each), torch.nn CPU loop, all host cores"
+    with torch.no_grad():
+        run()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds or n < 2:
+            run()
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": units * n / dt, "unit": unit, "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} x ({sample}) in {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world, rank, local = dist_setup(args)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    dev = torch.device("cuda", local)
+    lib = _lib.load()
+    import ctypes
+    stream = torch.cuda.Stream(device=dev)
+
+    if args.model == "variant":
+        per = args.per_gpu or 16384
+        sd = broadcast_state_dict(lambda: synthetic.variant_state_dict(seed=0),
+                                  synthetic.variant_param_shapes(), world, rank, dev)
+        cfg = _lib.VariantConfig(26, 33, 1, 3, local, per)
+        names, data, numel, n, keep = _lib.marshal_state_dict(sd)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.pa_variant_create(ctypes.byref(cfg), names, data, numel, n,
+                                         ctypes.c_void_p(stream.cuda_stream), ctypes.byref(handle)))
+        x = torch.from_numpy(synthetic.variant_windows(per, seed=synthetic.VSYN_SEED + rank)).to(dev)
+        out = torch.empty((per, 3), dtype=torch.float32, device=dev)
+
+        def step():
+            _lib.check(lib.pa_variant_forward_device(handle, x.data_ptr(), per, out.data_ptr(), None))
+        windows_per_unit, flop_per_window = 1, VARIANT_FLOP_PER_WINDOW
+        workload = ("V-syn: int8 [N,33,26] candidate windows, variant bi-LSTM(26->256)x2 + MLP head, "
+                    "F=26 H=256 L=1 (BASELINE configs[1] shapes)")
+    else:
+        per = args.per_gpu or 2048
+        sd = broadcast_state_dict(lambda: synthetic.polish_state_dict(seed=0),
+                                  synthetic.polish_param_shapes(), world, rank, dev)
+        cfg = _lib.PolishConfig(10, 128, 1, 5, 1000, 100, 50, 50, local, per)
+        names, data, numel, n, keep = _lib.marshal_state_dict(sd)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.pa_polish_create(ctypes.byref(cfg), names, data, numel, n,
+                                        ctypes.c_void_p(stream.cuda_stream), ctypes.byref(handle)))
+        x = torch.from_numpy(synthetic.polish_chunks(per, seed=synthetic.PSYN_SEED + rank)).to(dev)
+        lab = torch.empty((per, 1000), dtype=torch.uint8, device=dev)
+        ph = torch.empty((per, 1000), dtype=torch.uint8, device=dev)
+
+        def step():
+            _lib.check(lib.pa_polish_predict_device(handle, x.data_ptr(), per, lab.data_ptr(),
+                                                    ph.data_ptr(), None))
+        windows_per_unit, flop_per_window = POLISH_WINDOWS_PER_CHUNK, POLISH_FLOP_PER_WINDOW
+        workload = ("P-syn: uint8 [N,1000,10] chunks, polish bi-GRU(10->128)x2 + dense, 19 windows of "
+                    "100 steps with hidden carry (BASELINE configs[4] shapes)")
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    torch.cuda.synchronize(dev)
+    for _ in range(args.warmup):
+        step()
+    _lib.check(lib.pa_synchronize(handle))
+    _lib.check(lib.pa_profile_enable(handle, 1))
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _lib.check(lib.pa_synchronize(handle))
+    torch.cuda.synchronize(dev)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    prof = _lib.profile_dict(handle)
+    _lib.check(lib.pa_profile_enable(handle, 0))
+
+    if rank == 0:
+        windows = world * args.steps * per * windows_per_unit
+        value = windows / dt
+        kern = {}
+        for label, p in prof.items():
+            avg_ms = p["ms"] / max(1, p["launches"])
+            tf = (p["flops"] / max(1, p["launches"])) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            kern[label] = {"launches_per_step": p["launches"] / args.steps, "avg_ms": round(avg_ms, 4),
+                           "share": 0.0, "tflops": round(tf, 2)}
+        tot = sum(p["ms"] for p in prof.values()) or 1.0
+        for label, p in prof.items():
+            kern[label]["share"] = round(p["ms"] / tot, 4)
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        d = prof[dom]
+        ach = (d["flops"] / d["launches"]) / (d["ms"] / d["launches"] * 1e-3) / 1e12
+        line = {
+            "metric": "inference windows/sec (whole node)",
+            "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "per_gpu_per_step": per,
+                       "units": "windows" if args.model == "variant" else "chunks (x19 windows)",
+                       "reference_hdf5_batch": 512 if args.model == "variant" else 128,
+                       "weights": "seeded random init (pepper_amd.synthetic), fp32",
+                       "parallelism": f"region-shard x{world}, RCCL weight broadcast only"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None},
+            "end_to_end_tflops": value * flop_per_window / 1e12,
+            "end_to_end_frac_of_f32_mfma_peak": value * flop_per_window / 1e12 / F32_MFMA_PEAK_TFLOPS / world,
+            "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.model, args.cpu_seconds)
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+
+    if args.model == "variant":
+        lib.pa_variant_destroy(handle)
+    else:
+        lib.pa_polish_destroy(handle)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+/* pepper_amd C ABI -- MI355X (gfx950) drop-in for PEPPER's RNN inference hot path.
+ *
+ * Plain C, opaque handles, int return codes (0 = PA_OK), caller-owned buffers, one HIP stream
+ * per handle, no global state besides a thread-local error string.  A handle is
+ * thread-compatible, not thread-safe.  Device pointers are ordinary HIP device allocations
+ * (e.g. torch.Tensor.data_ptr() of a CUDA/ROCm tensor); no torch types cross this boundary.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * kishwarshafin/pepper repository root).
+ */
+#ifndef PEPPER_AMD_H
+#define PEPPER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_OK 0
+#define PA_ERR_INVALID 1   /* bad argument / missing or mis-shaped tensor */
+#define PA_ERR_HIP 2       /* HIP runtime error (message in pa_last_error) */
+#define PA_ERR_NO_DEVICE 3 /* no gfx950 device visible */
+
+/* Thread-local message describing the last non-zero return on this thread. */
+const char* pa_last_error(void);
+/* "pepper_amd <version> gfx950"; lets a binding check it loaded the right library. */
+const char* pa_version(void);
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int pa_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Variant model  (bi-LSTM x2 + 5 x (Linear + SELU) + Linear + Softmax)
+ * replaces: pepper_variant/modules/python/models/simple_model.py:6-82  (class TransducerGRU)
+ *           and its construction from a checkpoint,
+ *           pepper_variant/modules/python/models/ModelHander.py:18-44
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pa_variant_model pa_variant_model;
+
+typedef struct {
+    int32_t image_features;   /* ImageSizeOptions.IMAGE_HEIGHT = 26 (Options.py:6)             */
+    int32_t window;           /* CANDIDATE_WINDOW_SIZE + 1 = 33 (Options.py:8)                 */
+    int32_t gru_layers;       /* checkpoint['gru_layers'] -> nn.LSTM(num_layers)               */
+    int32_t num_classes_type; /* TOTAL_TYPE_LABELS = 3 (Options.py:11)                         */
+    int32_t device;           /* HIP device ordinal                                            */
+    int32_t max_chunk;        /* windows per device pass (0 = default 16384)                   */
+} pa_variant_config;
+
+/* Build a model from a state_dict given as parallel arrays: names[i] is the reference
+ * state_dict key ("encoder.weight_ih_l0", ..., "output_layer_type.bias"; a leading "module."
+ * is stripped as ModelHander.py:35-39 does), data[i] a HOST pointer to numel[i] float32 values
+ * in PyTorch's row-major layout.  Missing keys or wrong sizes fail with PA_ERR_INVALID
+ * (load_state_dict(strict=True) semantics).  hip_stream: a hipStream_t to run on, or NULL to
+ * create a private stream. */
+int pa_variant_create(const pa_variant_config* cfg, const char* const* names,
+                      const float* const* data, const int64_t* numel, int32_t n_tensors,
+                      void* hip_stream, pa_variant_model** out);
+void pa_variant_destroy(pa_variant_model* m);
+
+/* forward(x, train_mode=False): images int8 [n, window, image_features] (the dtype the images
+ * HDF5 stores: pepper_variant/modules/python/DataStore.py:68) -> probs float32 [n, classes].
+ * logits (pre-softmax, = forward(x, train_mode=True)) may be NULL.  All pointers are DEVICE
+ * pointers; the call is asynchronous on the handle's stream.
+ * replaces: simple_model.py:48-82 as called by predict_distributed_gpu.py:58-65. */
+int pa_variant_forward_device(pa_variant_model* m, const int8_t* images, int64_t n, float* probs,
+                              float* logits);
+/* Same with float32 images (the reference feeds FloatTensor; values need not be integral). */
+int pa_variant_forward_device_f32(pa_variant_model* m, const float* images, int64_t n,
+                                  float* probs, float* logits);
+/* Same with HOST pointers: H2D copy of the packed int8 windows, forward, D2H copy of the
+ * results, synchronous.  replaces predict_distributed_gpu.py:60-67 (.cuda() ... .cpu()). */
+int pa_variant_forward_host(pa_variant_model* m, const int8_t* images, int64_t n, float* probs,
+                            float* logits);
+
+/* ------------------------------------------------------------------------------------------
+ * Polish model  (bi-GRU x2 + Linear, sliding windows with hidden-state carry)
+ * replaces: pepper/modules/python/models/simple_model.py:5-42 (class TransducerGRU)
+ *           pepper/modules/python/models/predict_distributed_cpu.py:43-90 (window loop)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pa_polish_model pa_polish_model;
+
+typedef struct {
+    int32_t image_features; /* ImageSizeOptions.IMAGE_HEIGHT = 10 (pepper Options.py:2)        */
+    int32_t hidden_size;    /* checkpoint['hidden_size'] (TrainOptions.HIDDEN_SIZE = 128)      */
+    int32_t gru_layers;     /* checkpoint['gru_layers']                                        */
+    int32_t num_classes;    /* TOTAL_LABELS = 5                                                */
+    int32_t seq_length;     /* SEQ_LENGTH = 1000                                               */
+    int32_t window;         /* TrainOptions.TRAIN_WINDOW = 100                                 */
+    int32_t jump;           /* TrainOptions.WINDOW_JUMP = 50                                   */
+    int32_t overlap;        /* SEQ_OVERLAP = 50                                                */
+    int32_t device;
+    int32_t max_chunk;      /* chunks per device pass (0 = default 8192)                       */
+} pa_polish_config;
+
+int pa_polish_create(const pa_polish_config* cfg, const char* const* names,
+                     const float* const* data, const int64_t* numel, int32_t n_tensors,
+                     void* hip_stream, pa_polish_model** out);
+void pa_polish_destroy(pa_polish_model* m);
+
+/* One module forward: x float32 [n, T, image_features], hidden float32 [n, 2*layers, H] ->
+ * logits float32 [n, T, classes], hidden_out [n, 2*layers, H].  DEVICE pointers.
+ * replaces: pepper simple_model.py:27-42 (forward(x, hidden)). */
+int pa_polish_forward_device(pa_polish_model* m, const float* x, const float* hidden, int64_t n,
+                             int32_t T, float* logits, float* hidden_out);
+
+/* Whole-chunk prediction: images uint8 [n, seq_length, image_features] -> labels uint8
+ * [n, seq_length], phred uint8 [n, seq_length]; acc (float32 [n, seq_length, classes], the
+ * overlap-added softmax) may be NULL.  DEVICE pointers, asynchronous.
+ * replaces: predict_distributed_cpu.py:43-93 (zero hidden, 19 windows, softmax accumulate,
+ * max, phred) producing what DataStorePredict.py:70-76 stores as bases / phred_score. */
+int pa_polish_predict_device(pa_polish_model* m, const uint8_t* images, int64_t n, uint8_t* labels,
+                             uint8_t* phred, float* acc);
+int pa_polish_predict_host(pa_polish_model* m, const uint8_t* images, int64_t n, uint8_t* labels,
+                           uint8_t* phred, float* acc);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel timing with HIP events recorded on the handle's own stream (what bench.py's
+ * roofline block is computed from).  `model` is a pa_variant_model* or pa_polish_model*.
+ * ------------------------------------------------------------------------------------------ */
+int pa_profile_enable(void* model, int32_t on);          /* also clears collected samples      */
+int pa_profile_count(void* model);                       /* distinct kernel labels so far      */
+int pa_profile_get(void* model, int32_t idx, char* label, int32_t label_cap, double* total_ms,
+                   int64_t* launches, double* flops);    /* synchronises the stream            */
+/* Block until everything queued on the handle's stream has finished. */
+int pa_synchronize(void* model);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEPPER_AMD_H */

@@ -1,0 +1,704 @@
+// C ABI of pepper_amd (see include/pepper_amd.h): model handles, weight packing, workspace,
+// the two forward pipelines and the HIP-event profiler.  Host-side C++ only; kernels live in
+// gemm.hip / rnn.hip / head.hip.
+#include "../../include/pepper_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(PA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+constexpr int MT = 64;  // batch padding of the recurrent kernels (rnn.hip)
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return PA_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess)
+            return fail(PA_ERR_HIP, "hipMalloc(" + std::to_string(need) + " B): " + hipGetErrorString(e));
+        bytes = need;
+        return PA_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    float* f() const { return static_cast<float*>(p); }
+};
+
+struct ProfSample {
+    int label;
+    hipEvent_t start, stop;
+    double flops;
+};
+
+struct ModelBase {
+    uint32_t magic = 0x50414d44;  // 'PAMD'
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    std::vector<std::string> labels;
+    std::vector<double> total_ms, total_flops;
+    std::vector<int64_t> launches;
+    std::vector<ProfSample> pending;
+    std::vector<DevBuf*> owned;  // weights + workspace, freed by the destructor
+
+    int label_id(const char* name) {
+        for (size_t i = 0; i < labels.size(); ++i)
+            if (labels[i] == name) return (int)i;
+        labels.push_back(name);
+        total_ms.push_back(0.0);
+        total_flops.push_back(0.0);
+        launches.push_back(0);
+        return (int)labels.size() - 1;
+    }
+    int drain() {
+        if (pending.empty()) return PA_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (auto& s : pending) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, s.start, s.stop));
+            total_ms[s.label] += ms;
+            total_flops[s.label] += s.flops;
+            launches[s.label] += 1;
+            (void)hipEventDestroy(s.start);
+            (void)hipEventDestroy(s.stop);
+        }
+        pending.clear();
+        return PA_OK;
+    }
+    virtual ~ModelBase() {
+        for (auto& s : pending) {
+            (void)hipEventDestroy(s.start);
+            (void)hipEventDestroy(s.stop);
+        }
+        for (DevBuf* b : owned) {
+            b->release();
+            delete b;
+        }
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+    DevBuf* new_buf() {
+        owned.push_back(new DevBuf());
+        return owned.back();
+    }
+};
+
+// RAII bracket: records two events around a launch when profiling is on.
+struct Timed {
+    ModelBase* m;
+    ProfSample s{};
+    bool on;
+    Timed(ModelBase* m_, const char* label, double flops) : m(m_), on(m_->profiling) {
+        if (!on) return;
+        s.label = m->label_id(label);
+        s.flops = flops;
+        if (hipEventCreate(&s.start) != hipSuccess || hipEventCreate(&s.stop) != hipSuccess) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(s.start, m->stream);
+    }
+    ~Timed() {
+        if (!on) return;
+        (void)hipEventRecord(s.stop, m->stream);
+        m->pending.push_back(s);
+    }
+};
+
+// ---- state_dict lookup -----------------------------------------------------------------------
+struct StateDict {
+    std::map<std::string, std::pair<const float*, int64_t>> t;
+    StateDict(const char* const* names, const float* const* data, const int64_t* numel, int n) {
+        for (int i = 0; i < n; ++i) {
+            std::string k = names[i];
+            if (k.rfind("module.", 0) == 0) k = k.substr(7);  // ModelHander.py:35-39
+            t[k] = {data[i], numel[i]};
+        }
+    }
+    const float* get(const std::string& key, int64_t expect, std::string& err) const {
+        auto it = t.find(key);
+        if (it == t.end()) {
+            err = "state_dict is missing key '" + key + "'";
+            return nullptr;
+        }
+        if (it->second.second != expect) {
+            err = "state_dict['" + key + "'] has " + std::to_string(it->second.second) +
+                  " elements, expected " + std::to_string(expect);
+            return nullptr;
+        }
+        if (it->second.first == nullptr) {
+            err = "state_dict['" + key + "'] is a null pointer";
+            return nullptr;
+        }
+        return it->second.first;
+    }
+};
+
+int upload(DevBuf* b, const std::vector<float>& host) {
+    if (int rc = b->ensure(host.size() * sizeof(float))) return rc;
+    HIP_TRY(hipMemcpy(b->p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PA_OK;
+}
+
+// W_hh [G*H, H] of both directions -> fragment order [dir][G*H/32][H/8][64][4] (rnn.hip):
+// lane l of n-tile nt, k-block kb holds W[nt*32 + (l&31)][kb*8 + 4*(l>>5) + e], e = 0..3.
+void pack_rec_weights(const float* const w[2], int G, int H, std::vector<float>& out) {
+    const int NTt = G * H / 32, KB = H / 8;
+    out.resize((size_t)2 * NTt * KB * 64 * 4);
+    for (int d = 0; d < 2; ++d)
+        for (int nt = 0; nt < NTt; ++nt)
+            for (int kb = 0; kb < KB; ++kb)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 4; ++e)
+                        out[((((size_t)d * NTt + nt) * KB + kb) * 64 + l) * 4 + e] =
+                            w[d][(size_t)(nt * 32 + (l & 31)) * H + kb * 8 + 4 * (l >> 5) + e];
+}
+
+// One bidirectional recurrent layer's device weights.
+struct RecLayer {
+    int K = 0, Kp = 0;         // input width and its zero-padded row length
+    DevBuf *w_ih = nullptr;    // [2*G*H, Kp]   rows: dir*G*H + gate*H + unit
+    DevBuf *b_in = nullptr;    // [2*G*H]       LSTM: b_ih + b_hh; GRU: b_ih + (b_hr, b_hz, 0)
+    DevBuf *w_hh = nullptr;    // packed
+    DevBuf *b_hn = nullptr;    // GRU only: [2*H]
+};
+
+int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix, int layer, int G,
+                    int H, int K, RecLayer& out) {
+    const char* sfx[2] = {"", "_reverse"};
+    const float *wih[2], *whh[2], *bih[2], *bhh[2];
+    std::string err;
+    for (int d = 0; d < 2; ++d) {
+        const std::string l = "_l" + std::to_string(layer) + sfx[d];
+        wih[d] = sd.get(prefix + ".weight_ih" + l, (int64_t)G * H * K, err);
+        whh[d] = wih[d] ? sd.get(prefix + ".weight_hh" + l, (int64_t)G * H * H, err) : nullptr;
+        bih[d] = whh[d] ? sd.get(prefix + ".bias_ih" + l, (int64_t)G * H, err) : nullptr;
+        bhh[d] = bih[d] ? sd.get(prefix + ".bias_hh" + l, (int64_t)G * H, err) : nullptr;
+        if (!bhh[d]) return fail(PA_ERR_INVALID, err);
+    }
+    out.K = K;
+    out.Kp = (int)round_up(K, 4);
+    std::vector<float> w((size_t)2 * G * H * out.Kp, 0.0f), b((size_t)2 * G * H), bn((size_t)2 * H, 0.0f);
+    for (int d = 0; d < 2; ++d)
+        for (int n = 0; n < G * H; ++n) {
+            std::memcpy(&w[((size_t)d * G * H + n) * out.Kp], &wih[d][(size_t)n * K], K * sizeof(float));
+            float bv = bih[d][n];
+            if (G == 4 || n < 2 * H) bv += bhh[d][n];   // GRU keeps b_hn out of the r-gated term
+            b[(size_t)d * G * H + n] = bv;
+        }
+    if (G == 3)
+        for (int d = 0; d < 2; ++d)
+            for (int j = 0; j < H; ++j) bn[(size_t)d * H + j] = bhh[d][2 * H + j];
+    std::vector<float> packed;
+    pack_rec_weights(whh, G, H, packed);
+    out.w_ih = m->new_buf();
+    out.b_in = m->new_buf();
+    out.w_hh = m->new_buf();
+    if (int rc = upload(out.w_ih, w)) return rc;
+    if (int rc = upload(out.b_in, b)) return rc;
+    if (int rc = upload(out.w_hh, packed)) return rc;
+    if (G == 3) {
+        out.b_hn = m->new_buf();
+        if (int rc = upload(out.b_hn, bn)) return rc;
+    }
+    return PA_OK;
+}
+
+struct Linear {
+    int in = 0, out = 0;
+    DevBuf *w = nullptr, *b = nullptr;
+};
+
+int build_linear(ModelBase* m, const StateDict& sd, const std::string& name, int in, int out, Linear& l) {
+    std::string err;
+    const float* w = sd.get(name + ".weight", (int64_t)in * out, err);
+    const float* b = w ? sd.get(name + ".bias", out, err) : nullptr;
+    if (!b) return fail(PA_ERR_INVALID, err);
+    l.in = in;
+    l.out = out;
+    l.w = m->new_buf();
+    l.b = m->new_buf();
+    if (int rc = upload(l.w, std::vector<float>(w, w + (size_t)in * out))) return rc;
+    return upload(l.b, std::vector<float>(b, b + out));
+}
+
+int init_base(ModelBase* m, int device, void* hip_stream) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(PA_ERR_NO_DEVICE, "no HIP device visible: the pepper_amd product path has no CPU fallback");
+    if (device < 0 || device >= count)
+        return fail(PA_ERR_INVALID, "device ordinal " + std::to_string(device) + " out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(PA_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    m->device = device;
+    if (hip_stream) {
+        m->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        m->own_stream = true;
+    }
+    return PA_OK;
+}
+
+#define LAUNCH_TRY(m, label, flops, call)                                                     \
+    do {                                                                                       \
+        hipError_t e_;                                                                         \
+        {                                                                                      \
+            Timed t_(m, label, flops);                                                         \
+            e_ = (call);                                                                       \
+        }                                                                                      \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(PA_ERR_HIP, std::string(label) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+}  // namespace
+
+// ================================================================================================
+// Variant model
+// ================================================================================================
+struct pa_variant_model : ModelBase {
+    pa_variant_config cfg{};
+    int H = 256, L1 = 512;
+    std::vector<RecLayer> rec;   // encoder layers then decoder layers
+    Linear lin[5], out;
+    DevBuf *xp, *ya, *yb, *l1, *l2, *stage_in, *stage_p, *stage_l;
+};
+
+extern "C" {
+
+const char* pa_last_error(void) { return g_err.c_str(); }
+const char* pa_version(void) { return "pepper_amd 0.1.0 gfx950"; }
+int pa_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int pa_variant_create(const pa_variant_config* cfg, const char* const* names, const float* const* data,
+                      const int64_t* numel, int32_t n_tensors, void* hip_stream, pa_variant_model** out) {
+    if (!cfg || !names || !data || !numel || !out) return fail(PA_ERR_INVALID, "null argument");
+    if (cfg->image_features <= 0 || cfg->window <= 0 || cfg->gru_layers <= 0 ||
+        cfg->num_classes_type <= 0 || cfg->num_classes_type > 8)
+        return fail(PA_ERR_INVALID, "bad pa_variant_config");
+    auto* m = new pa_variant_model();
+    m->cfg = *cfg;
+    if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 16384;
+    int rc = init_base(m, cfg->device, hip_stream);
+    StateDict sd(names, data, numel, n_tensors);
+    const int H = m->H;
+    for (int mod = 0; mod < 2 && rc == PA_OK; ++mod)
+        for (int layer = 0; layer < cfg->gru_layers && rc == PA_OK; ++layer) {
+            const int K = (mod == 0 && layer == 0) ? cfg->image_features : 2 * H;
+            m->rec.emplace_back();
+            rc = build_rec_layer(m, sd, mod == 0 ? "encoder" : "decoder", layer, 4, H, K, m->rec.back());
+        }
+    const char* lin_names[5] = {"linear_1", "linear_2", "linear_3", "linear_4", "linear_5"};
+    for (int i = 0; i < 5 && rc == PA_OK; ++i)
+        rc = build_linear(m, sd, lin_names[i], i == 0 ? 2 * H * cfg->window : m->L1, m->L1, m->lin[i]);
+    if (rc == PA_OK) rc = build_linear(m, sd, "output_layer_type", m->L1, cfg->num_classes_type, m->out);
+    if (rc != PA_OK) {
+        delete m;
+        return rc;
+    }
+    m->xp = m->new_buf(); m->ya = m->new_buf(); m->yb = m->new_buf();
+    m->l1 = m->new_buf(); m->l2 = m->new_buf();
+    m->stage_in = m->new_buf(); m->stage_p = m->new_buf(); m->stage_l = m->new_buf();
+    *out = m;
+    return PA_OK;
+}
+
+void pa_variant_destroy(pa_variant_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    delete m;
+}
+
+static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* images, int64_t n,
+                                 float* probs, float* logits) {
+    const int T = m->cfg.window, F = m->cfg.image_features, H = m->H, C = m->cfg.num_classes_type;
+    const int64_t np = round_up(n, MT);
+    const int NX = 2 * 4 * H;  // both directions' gate pre-activations
+    if (int rc = m->xp->ensure((size_t)np * T * NX * sizeof(float))) return rc;
+    if (int rc = m->ya->ensure((size_t)np * T * 2 * H * sizeof(float))) return rc;
+    if (m->rec.size() > 1)
+        if (int rc = m->yb->ensure((size_t)np * T * 2 * H * sizeof(float))) return rc;
+    if (int rc = m->l1->ensure((size_t)n * m->L1 * sizeof(float))) return rc;
+    if (int rc = m->l2->ensure((size_t)n * m->L1 * sizeof(float))) return rc;
+
+    const void* cur = images;
+    int cur_kind = a_kind, cur_ld = F;
+    float* ybuf[2] = {m->ya->f(), m->yb->f()};
+    int which = 0;
+    const int M = (int)(n * T);
+    for (size_t li = 0; li < m->rec.size(); ++li) {
+        const RecLayer& r = m->rec[li];
+        LAUNCH_TRY(m, li == 0 ? "gemm_inproj_i8" : "gemm_inproj", 2.0 * M * NX * r.K,
+                   pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
+                                      NX, M, NX, r.K, 0, 0, 0, m->stream));
+        float* y = ybuf[which];
+        LAUNCH_TRY(m, "lstm_rec", 2.0 * n * T * (4.0 * H) * H * 2,
+                   pa::launch_lstm_rec(H, m->xp->f(), NX, r.w_hh->f(), y, 2 * H, (int)n, T, m->stream));
+        cur = y;
+        cur_kind = pa::A_F32;
+        cur_ld = 2 * H;
+        which ^= 1;
+    }
+    // flatten(start_dim=1, end_dim=2): [n, T, 2H] rows are already contiguous -> [n, T*2H]
+    const int K1 = T * 2 * H;
+    LAUNCH_TRY(m, "gemm_linear_1", 2.0 * n * m->L1 * K1,
+               pa::launch_gemm_nt(pa::A_F32, cur, K1, m->lin[0].w->f(), K1, m->lin[0].b->f(), m->l1->f(),
+                                  m->L1, (int)n, m->L1, K1, 1, 0, 0, m->stream));
+    float* a = m->l1->f();
+    float* b = m->l2->f();
+    for (int i = 1; i < 5; ++i) {
+        LAUNCH_TRY(m, "gemm_linear_2to5", 2.0 * n * m->L1 * m->L1,
+                   pa::launch_gemm_nt(pa::A_F32, a, m->L1, m->lin[i].w->f(), m->L1, m->lin[i].b->f(), b,
+                                      m->L1, (int)n, m->L1, m->L1, 1, 0, 0, m->stream));
+        std::swap(a, b);
+    }
+    LAUNCH_TRY(m, "head_softmax", 2.0 * n * m->L1 * C,
+               pa::launch_dense_small(0, a, m->L1, m->out.w->f(), m->out.b->f(), probs, logits, (int)n,
+                                      m->L1, C, 1, 1, 0, m->stream));
+    return PA_OK;
+}
+
+static int variant_forward(pa_variant_model* m, int a_kind, const void* images, size_t elem, int64_t n,
+                           float* probs, float* logits) {
+    if (!m || m->magic != 0x50414d44) return fail(PA_ERR_INVALID, "bad model handle");
+    if (n < 0 || (n > 0 && (!images || !probs))) return fail(PA_ERR_INVALID, "null buffer");
+    HIP_TRY(hipSetDevice(m->device));
+    const int64_t per = (int64_t)m->cfg.window * m->cfg.image_features;
+    const int C = m->cfg.num_classes_type;
+    for (int64_t off = 0; off < n; off += m->cfg.max_chunk) {
+        const int64_t c = std::min<int64_t>(m->cfg.max_chunk, n - off);
+        const char* img = static_cast<const char*>(images) + (size_t)off * per * elem;
+        if (int rc = variant_forward_chunk(m, a_kind, img, c, probs + off * C,
+                                           logits ? logits + off * C : nullptr))
+            return rc;
+    }
+    return PA_OK;
+}
+
+int pa_variant_forward_device(pa_variant_model* m, const int8_t* images, int64_t n, float* probs,
+                              float* logits) {
+    return variant_forward(m, pa::A_I8, images, 1, n, probs, logits);
+}
+
+int pa_variant_forward_device_f32(pa_variant_model* m, const float* images, int64_t n, float* probs,
+                                  float* logits) {
+    return variant_forward(m, pa::A_F32_SCALAR, images, 4, n, probs, logits);
+}
+
+int pa_variant_forward_host(pa_variant_model* m, const int8_t* images, int64_t n, float* probs,
+                            float* logits) {
+    if (!m || m->magic != 0x50414d44) return fail(PA_ERR_INVALID, "bad model handle");
+    if (n < 0 || (n > 0 && (!images || !probs))) return fail(PA_ERR_INVALID, "null buffer");
+    if (n == 0) return PA_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t per = (size_t)m->cfg.window * m->cfg.image_features;
+    const int C = m->cfg.num_classes_type;
+    if (int rc = m->stage_in->ensure((size_t)n * per)) return rc;
+    if (int rc = m->stage_p->ensure((size_t)n * C * sizeof(float))) return rc;
+    if (logits)
+        if (int rc = m->stage_l->ensure((size_t)n * C * sizeof(float))) return rc;
+    HIP_TRY(hipMemcpyAsync(m->stage_in->p, images, (size_t)n * per, hipMemcpyHostToDevice, m->stream));
+    if (int rc = variant_forward(m, pa::A_I8, m->stage_in->p, 1, n, m->stage_p->f(),
+                                 logits ? m->stage_l->f() : nullptr))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(probs, m->stage_p->p, (size_t)n * C * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    if (logits)
+        HIP_TRY(hipMemcpyAsync(logits, m->stage_l->p, (size_t)n * C * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return PA_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// Polish model
+// ================================================================================================
+struct pa_polish_model : ModelBase {
+    pa_polish_config cfg{};
+    std::vector<RecLayer> enc, dec;
+    Linear dense;
+    DevBuf *xp, *y1, *y2, *hid_a, *hid_b, *acc, *stage_in, *stage_lab, *stage_ph, *stage_acc;
+};
+
+// One module forward on n (<= padded workspace) sequences of T steps.
+//   x_kind/x/x_ld/x_rpb/x_bstride describe the first layer's input rows (see launch_gemm_nt);
+//   hidden_in may be null (zeros); hidden_out receives the decoder's final states.
+static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld, int x_rpb,
+                         int64_t x_bstride, const float* hidden_in, float* hidden_out, int64_t n, int T,
+                         float** y_last) {
+    const int H = m->cfg.hidden_size, L = m->cfg.gru_layers, NX = 2 * 3 * H, ldh = 2 * L * H;
+    const int M = (int)(n * T);
+    const void* cur = x;
+    int cur_kind = x_kind, cur_ld = x_ld, cur_rpb = x_rpb;
+    int64_t cur_bs = x_bstride;
+    float* ybuf[2] = {m->y1->f(), m->y2->f()};
+    int which = 0;
+    // encoder: h0 = hidden_in, h_n -> hid_a ; decoder: h0 = hid_a, h_n -> hidden_out
+    for (int stage = 0; stage < 2; ++stage) {
+        std::vector<RecLayer>& layers = stage == 0 ? m->enc : m->dec;
+        const float* h0 = stage == 0 ? hidden_in : m->hid_a->f();
+        float* hn = stage == 0 ? m->hid_a->f() : hidden_out;
+        for (int l = 0; l < L; ++l) {
+            const RecLayer& r = layers[l];
+            LAUNCH_TRY(m, (stage == 0 && l == 0) ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
+                       pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
+                                          NX, M, NX, r.K, 0, cur_rpb, cur_bs, m->stream));
+            float* y = ybuf[which];
+            LAUNCH_TRY(m, "gru_rec", 2.0 * n * T * (3.0 * H) * H * 2,
+                       pa::launch_gru_rec(H, m->xp->f(), NX, r.w_hh->f(), r.b_hn->f(),
+                                          h0 ? h0 + (size_t)l * 2 * H : nullptr, ldh,
+                                          hn ? hn + (size_t)l * 2 * H : nullptr, ldh, y, 2 * H, (int)n, T,
+                                          m->stream));
+            cur = y;
+            cur_kind = pa::A_F32;
+            cur_ld = 2 * H;
+            cur_rpb = 0;
+            cur_bs = 0;
+            which ^= 1;
+        }
+    }
+    *y_last = const_cast<float*>(static_cast<const float*>(cur));
+    return PA_OK;
+}
+
+static int polish_ensure(pa_polish_model* m, int64_t n, int T) {
+    const int H = m->cfg.hidden_size, L = m->cfg.gru_layers;
+    const int64_t np = round_up(n, MT);
+    if (int rc = m->xp->ensure((size_t)np * T * 6 * H * sizeof(float))) return rc;
+    if (int rc = m->y1->ensure((size_t)np * T * 2 * H * sizeof(float))) return rc;
+    if (int rc = m->y2->ensure((size_t)np * T * 2 * H * sizeof(float))) return rc;
+    if (int rc = m->hid_a->ensure((size_t)np * 2 * L * H * sizeof(float))) return rc;
+    if (int rc = m->hid_b->ensure((size_t)np * 2 * L * H * sizeof(float))) return rc;
+    return PA_OK;
+}
+
+extern "C" {
+
+int pa_polish_create(const pa_polish_config* cfg, const char* const* names, const float* const* data,
+                     const int64_t* numel, int32_t n_tensors, void* hip_stream, pa_polish_model** out) {
+    if (!cfg || !names || !data || !numel || !out) return fail(PA_ERR_INVALID, "null argument");
+    if (cfg->image_features <= 0 || cfg->gru_layers <= 0 || cfg->num_classes <= 0 || cfg->num_classes > 8 ||
+        (cfg->hidden_size != 128 && cfg->hidden_size != 256) || cfg->seq_length <= 0 || cfg->window <= 0 ||
+        cfg->jump <= 0 || cfg->window > cfg->seq_length || cfg->overlap < 0 || 2 * cfg->overlap > cfg->seq_length)
+        return fail(PA_ERR_INVALID, "bad pa_polish_config (hidden_size must be 128 or 256)");
+    auto* m = new pa_polish_model();
+    m->cfg = *cfg;
+    if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 8192;
+    int rc = init_base(m, cfg->device, hip_stream);
+    StateDict sd(names, data, numel, n_tensors);
+    const int H = cfg->hidden_size;
+    for (int stage = 0; stage < 2 && rc == PA_OK; ++stage)
+        for (int l = 0; l < cfg->gru_layers && rc == PA_OK; ++l) {
+            auto& vec = stage == 0 ? m->enc : m->dec;
+            vec.emplace_back();
+            const int K = (stage == 0 && l == 0) ? cfg->image_features : 2 * H;
+            rc = build_rec_layer(m, sd, stage == 0 ? "gru_encoder" : "gru_decoder", l, 3, H, K, vec.back());
+        }
+    if (rc == PA_OK) rc = build_linear(m, sd, "dense1", 2 * H, cfg->num_classes, m->dense);
+    if (rc != PA_OK) {
+        delete m;
+        return rc;
+    }
+    m->xp = m->new_buf(); m->y1 = m->new_buf(); m->y2 = m->new_buf();
+    m->hid_a = m->new_buf(); m->hid_b = m->new_buf(); m->acc = m->new_buf();
+    m->stage_in = m->new_buf(); m->stage_lab = m->new_buf(); m->stage_ph = m->new_buf();
+    m->stage_acc = m->new_buf();
+    *out = m;
+    return PA_OK;
+}
+
+void pa_polish_destroy(pa_polish_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    delete m;
+}
+
+int pa_polish_forward_device(pa_polish_model* m, const float* x, const float* hidden, int64_t n, int32_t T,
+                             float* logits, float* hidden_out) {
+    if (!m || m->magic != 0x50414d44) return fail(PA_ERR_INVALID, "bad model handle");
+    if (n < 0 || T <= 0 || (n > 0 && (!x || !logits))) return fail(PA_ERR_INVALID, "bad argument");
+    if (n == 0) return PA_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const int H = m->cfg.hidden_size, L = m->cfg.gru_layers, F = m->cfg.image_features, C = m->cfg.num_classes;
+    const size_t hbytes = (size_t)2 * L * H * sizeof(float);
+    for (int64_t off = 0; off < n; off += m->cfg.max_chunk) {
+        const int64_t c = std::min<int64_t>(m->cfg.max_chunk, n - off);
+        if (int rc = polish_ensure(m, c, T)) return rc;
+        // user hidden buffers are exactly [c, 2L, H]; the kernels want MT-padded rows -> stage
+        const float* hin = nullptr;
+        if (hidden) {
+            HIP_TRY(hipMemcpyAsync(m->hid_b->p, hidden + (size_t)off * 2 * L * H, c * hbytes,
+                                   hipMemcpyDeviceToDevice, m->stream));
+            hin = m->hid_b->f();
+        }
+        float* y = nullptr;
+        if (int rc = polish_window(m, pa::A_F32_SCALAR, x + (size_t)off * T * F, F, 0, 0, hin, m->hid_b->f(), c,
+                                   T, &y))
+            return rc;
+        LAUNCH_TRY(m, "dense_logits", 2.0 * c * T * 2 * H * C,
+                   pa::launch_dense_small(2, y, 2 * H, m->dense.w->f(), m->dense.b->f(),
+                                          logits + (size_t)off * T * C, nullptr, (int)(c * T), 2 * H, C, 1, 1, 0,
+                                          m->stream));
+        if (hidden_out)
+            HIP_TRY(hipMemcpyAsync(hidden_out + (size_t)off * 2 * L * H, m->hid_b->p, c * hbytes,
+                                   hipMemcpyDeviceToDevice, m->stream));
+    }
+    return PA_OK;
+}
+
+int pa_polish_predict_device(pa_polish_model* m, const uint8_t* images, int64_t n, uint8_t* labels,
+                             uint8_t* phred, float* acc_out) {
+    if (!m || m->magic != 0x50414d44) return fail(PA_ERR_INVALID, "bad model handle");
+    if (n < 0 || (n > 0 && (!images || !labels || !phred))) return fail(PA_ERR_INVALID, "null buffer");
+    if (n == 0) return PA_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const int H = m->cfg.hidden_size, F = m->cfg.image_features, C = m->cfg.num_classes;
+    const int S = m->cfg.seq_length, T = m->cfg.window;
+    for (int64_t off = 0; off < n; off += m->cfg.max_chunk) {
+        const int64_t c = std::min<int64_t>(m->cfg.max_chunk, n - off);
+        if (int rc = polish_ensure(m, c, T)) return rc;
+        float* acc = acc_out ? acc_out + (size_t)off * S * C : nullptr;
+        if (!acc) {
+            if (int rc = m->acc->ensure((size_t)c * S * C * sizeof(float))) return rc;
+            acc = m->acc->f();
+        }
+        HIP_TRY(hipMemsetAsync(acc, 0, (size_t)c * S * C * sizeof(float), m->stream));
+        const uint8_t* img = images + (size_t)off * S * F;
+        bool first = true;
+        // predict_distributed_cpu.py:50-53: i = 0, jump, ... while i + window <= seq_length
+        for (int i = 0; i + T <= S; i += m->cfg.jump) {
+            float* y = nullptr;
+            if (int rc = polish_window(m, pa::A_U8, img + (size_t)i * F, F, T, (int64_t)S * F,
+                                       first ? nullptr : m->hid_b->f(), m->hid_b->f(), c, T, &y))
+                return rc;
+            first = false;
+            LAUNCH_TRY(m, "dense_softmax_acc", 2.0 * c * T * 2 * H * C,
+                       pa::launch_dense_small(1, y, 2 * H, m->dense.w->f(), m->dense.b->f(), acc, nullptr,
+                                              (int)(c * T), 2 * H, C, T, S, i, m->stream));
+        }
+        LAUNCH_TRY(m, "polish_finalize", 0.0,
+                   pa::launch_polish_finalize(acc, labels + (size_t)off * S, phred + (size_t)off * S, c, S, C,
+                                              m->cfg.overlap, m->stream));
+    }
+    return PA_OK;
+}
+
+int pa_polish_predict_host(pa_polish_model* m, const uint8_t* images, int64_t n, uint8_t* labels,
+                           uint8_t* phred, float* acc) {
+    if (!m || m->magic != 0x50414d44) return fail(PA_ERR_INVALID, "bad model handle");
+    if (n < 0 || (n > 0 && (!images || !labels || !phred))) return fail(PA_ERR_INVALID, "null buffer");
+    if (n == 0) return PA_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t S = m->cfg.seq_length, F = m->cfg.image_features, C = m->cfg.num_classes;
+    if (int rc = m->stage_in->ensure((size_t)n * S * F)) return rc;
+    if (int rc = m->stage_lab->ensure((size_t)n * S)) return rc;
+    if (int rc = m->stage_ph->ensure((size_t)n * S)) return rc;
+    if (acc)
+        if (int rc = m->stage_acc->ensure((size_t)n * S * C * sizeof(float))) return rc;
+    HIP_TRY(hipMemcpyAsync(m->stage_in->p, images, (size_t)n * S * F, hipMemcpyHostToDevice, m->stream));
+    if (int rc = pa_polish_predict_device(m, static_cast<const uint8_t*>(m->stage_in->p), n,
+                                          static_cast<uint8_t*>(m->stage_lab->p),
+                                          static_cast<uint8_t*>(m->stage_ph->p), acc ? m->stage_acc->f() : nullptr))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(labels, m->stage_lab->p, (size_t)n * S, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(phred, m->stage_ph->p, (size_t)n * S, hipMemcpyDeviceToHost, m->stream));
+    if (acc)
+        HIP_TRY(hipMemcpyAsync(acc, m->stage_acc->p, (size_t)n * S * C * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return PA_OK;
+}
+
+// ---- profiler / sync -----------------------------------------------------------------------------
+static ModelBase* as_base(void* model) {
+    // Both handle structs derive from ModelBase as their only (polymorphic) base, so a handle's
+    // address is its ModelBase address; the magic word guards against foreign pointers.
+    auto* b = reinterpret_cast<ModelBase*>(model);
+    if (!model || b->magic != 0x50414d44) return nullptr;
+    return b;
+}
+
+int pa_profile_enable(void* model, int32_t on) {
+    ModelBase* b = as_base(model);
+    if (!b) return fail(PA_ERR_INVALID, "bad model handle");
+    if (int rc = b->drain()) return rc;
+    b->profiling = on != 0;
+    b->labels.clear();
+    b->total_ms.clear();
+    b->total_flops.clear();
+    b->launches.clear();
+    return PA_OK;
+}
+
+int pa_profile_count(void* model) {
+    ModelBase* b = as_base(model);
+    if (!b) return -1;
+    if (b->drain() != PA_OK) return -1;
+    return (int)b->labels.size();
+}
+
+int pa_profile_get(void* model, int32_t idx, char* label, int32_t label_cap, double* total_ms,
+                   int64_t* launches, double* flops) {
+    ModelBase* b = as_base(model);
+    if (!b) return fail(PA_ERR_INVALID, "bad model handle");
+    if (int rc = b->drain()) return rc;
+    if (idx < 0 || idx >= (int)b->labels.size()) return fail(PA_ERR_INVALID, "profile index out of range");
+    if (label && label_cap > 0) {
+        std::strncpy(label, b->labels[idx].c_str(), label_cap - 1);
+        label[label_cap - 1] = 0;
+    }
+    if (total_ms) *total_ms = b->total_ms[idx];
+    if (launches) *launches = b->launches[idx];
+    if (flops) *flops = b->total_flops[idx];
+    return PA_OK;
+}
+
+int pa_synchronize(void* model) {
+    ModelBase* b = as_base(model);
+    if (!b) return fail(PA_ERR_INVALID, "bad model handle");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return PA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Shared device helpers for the pepper_amd gfx950 kernels.
+//
+// All dense contractions use v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate): the parity
+// bar is 1e-4 on softmax outputs after 66 dependent recurrent steps and a K=16896
+// reduction, so operands stay exact f32 (157.3 TFLOP/s dense peak on MI355X).
+//
+// Fragment conventions used everywhere (wave = 64 lanes, lane l):
+//   A operand: one f32 = A[i = l & 31][k = l >> 5]
+//   B operand: one f32 = B[k = l >> 5][j = l & 31]
+//   C/D      : 16 f32,  reg r -> row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col l & 31
+// A "k-block" is 8 consecutive k: lane l holds k = 8*kb + 4*(l>>5) + s for s = 0..3 in one
+// 16-byte register quad, so 4 MFMAs consume one ds_read_b128 / global_load_dwordx4 per operand.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define PA_DEV __device__ __forceinline__
+
+PA_DEV f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+PA_DEV int crow32(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+PA_DEV float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// torch.nn.SELU constants (torch/nn/functional.py selu; alpha, scale as published)
+PA_DEV float selu_f(float x) {
+    const float alpha = 1.6732632423543772848170429916717f;
+    const float scale = 1.0507009873554804934193349852946f;
+    return scale * (x > 0.0f ? x : alpha * expm1f(x));
+}
+
+// Bijective XCD-aware remap of a 1-D grid: workgroup b runs on XCD b % 8 (observed, speed
+// only); give every XCD a contiguous run of logical tiles so neighbours share L2 lines.
+PA_DEV int xcd_swizzle(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

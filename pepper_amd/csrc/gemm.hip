@@ -1,0 +1,203 @@
+// C[M,N] = act(A[M,K] * W[N,K]^T + bias[N])  -- "NT" GEMM on v_mfma_f32_32x32x2_f32.
+//
+// Used for every input projection of the recurrent layers (torch.nn.LSTM/GRU's W_ih x + b,
+// reference call sites pepper_variant/.../simple_model.py:51,54 and pepper/.../simple_model.py:30,32)
+// and for the variant MLP head's Linear+SELU layers (simple_model.py:58-75).
+//
+// Tile: 128x128x32 per 256-thread workgroup, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA
+// tiles (64 accumulator VGPRs).  Both operands are K-contiguous (PyTorch weight layout is
+// [out,in]), staged global -> registers -> LDS with one barrier per k-tile (loads for tile
+// k+1 are issued before the MFMAs of tile k and written to the other LDS buffer after them).
+// LDS rows are padded to 36 floats: ds_read_b128 fragment reads are bank-conflict free
+// (row stride 144 B -> 16 distinct 16-B slots per 16-lane group).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
+
+template <int AT> struct AType { typedef float type; };
+template <> struct AType<pa::A_I8> { typedef int8_t type; };
+template <> struct AType<pa::A_U8> { typedef uint8_t type; };
+
+// Load 4 consecutive k of one row (row == nullptr -> out of range -> zeros).
+template <int AT>
+PA_DEV void load_a4(const typename AType<AT>::type* __restrict__ row, int k, int K, float (&out)[4]) {
+    if constexpr (AT == pa::A_F32) {
+        // requires 16-byte aligned rows and K % 4 == 0 or zero-padded rows (checked on the host)
+        if (row != nullptr && k < K) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + k);
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        } else {
+            out[0] = out[1] = out[2] = out[3] = 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            out[e] = (row != nullptr && k + e < K) ? (float)row[k + e] : 0.0f;
+    }
+}
+
+template <int AT, int ACT>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const typename AType<AT>::type* __restrict__ A, int lda,
+                                                      const float* __restrict__ W, int ldw,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ C, int ldc,
+                                                      int M, int N, int K, int tiles_n, int nwg,
+                                                      int a_rpb, int64_t a_bstride) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BM * LDT];
+    float* As = lds;                    // [2][BM][LDT]
+    float* Bs = lds + 2 * BM * LDT;     // [2][BN][LDT]
+
+    const int tile = xcd_swizzle(blockIdx.x, nwg);
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int li = lane & 31, hf = lane >> 5;
+
+    // staging role: 8 threads cover one 128-byte row segment, 32 rows per pass, 4 passes
+    const int kq = tid & 7, r0 = tid >> 3;
+
+    float ra[4][4], rb[4][4];
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const int nk = (K + BK - 1) / BK;
+
+    // Row pointers are fixed per thread for the whole k loop.  A rows may be remapped: logical
+    // row m = (batch m / a_rpb, step m % a_rpb) -> A + batch * a_bstride + step * lda, which lets
+    // one window of a longer [B, S, F] tensor be projected without a gather copy.
+    const typename AType<AT>::type* arow[4];
+    const float* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + 32 * i, n = n0 + r0 + 32 * i;
+        if (m < M) {
+            const size_t off = a_rpb > 0 ? (size_t)(m / a_rpb) * a_bstride + (size_t)(m % a_rpb) * lda
+                                         : (size_t)m * lda;
+            arow[i] = A + off;
+        } else {
+            arow[i] = nullptr;
+        }
+        wrow[i] = n < N ? W + (size_t)n * ldw : nullptr;
+    }
+
+    auto gload = [&](int kt) {
+        const int k = kt * BK + kq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            load_a4<AT>(arow[i], k, K, ra[i]);
+            load_a4<pa::A_F32>(wrow[i], k, K, rb[i]);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 va = {ra[i][0], ra[i][1], ra[i][2], ra[i][3]};
+            f32x4 vb = {rb[i][0], rb[i][1], rb[i][2], rb[i][3]};
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + r0 + 32 * i) * LDT + kq * 4]) = va;
+            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + r0 + 32 * i) * LDT + kq * 4]) = vb;
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* Ab = As + (buf * BM + wm * 64 + li) * LDT + hf * 4;
+        const float* Bb = Bs + (buf * BN + wn * 64 + li) * LDT + hf * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a[2], b[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const f32x4*>(Ab + m * 32 * LDT + kk * 8);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const f32x4*>(Bb + n * 32 * LDT + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma32(a[m][s], b[n][s], acc[m][n]);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = n0 + wn * 64 + n * 32 + li;
+        const float bv = (bias != nullptr && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + m * 32 + crow32(r, lane);
+                if (row < M && col < N) {
+                    float v = acc[m][n][r] + bv;
+                    if (ACT == 1) v = selu_f(v);
+                    C[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int AT>
+hipError_t launch_typed(const typename AType<AT>::type* A, int lda, const float* W, int ldw, const float* bias, float* C,
+                        int ldc, int M, int N, int K, int act, int a_rpb, int64_t a_bstride,
+                        hipStream_t stream) {
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    if (nwg == 0) return hipSuccess;
+    if (act == 1)
+        hipLaunchKernelGGL((gemm_nt_kernel<AT, 1>), dim3(nwg), dim3(256), 0, stream, A, lda, W, ldw,
+                           bias, C, ldc, M, N, K, tiles_n, nwg, a_rpb, a_bstride);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<AT, 0>), dim3(nwg), dim3(256), 0, stream, A, lda, W, ldw,
+                           bias, C, ldc, M, N, K, tiles_n, nwg, a_rpb, a_bstride);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+namespace pa {
+
+hipError_t launch_gemm_nt(int a_type, const void* A, int lda, const float* W, int ldw,
+                          const float* bias, float* C, int ldc, int M, int N, int K, int act,
+                          int a_rpb, int64_t a_bstride, hipStream_t stream) {
+    // W rows are read 4 floats at a time: they must be 16-byte aligned and zero-padded to a
+    // multiple of 4 columns (ldw >= round_up(K, 4)); the packer in api.hip guarantees this.
+    const bool w_ok = !(ldw & 3) && !((uintptr_t)W & 15) && ldw >= ((K + 3) & ~3);
+    switch (a_type) {
+        case A_F32:
+            if (!w_ok || (lda & 3) || (K & 3) || (a_bstride & 3) || ((uintptr_t)A & 15))
+                return hipErrorInvalidValue;
+            return launch_typed<A_F32>((const float*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, stream);
+        case A_F32_SCALAR:  // unaligned / K % 4 != 0 float rows (e.g. [B,33,26] float images)
+            if (!w_ok) return hipErrorInvalidValue;
+            return launch_typed<A_F32_SCALAR>((const float*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, stream);
+        case A_I8:
+            if (!w_ok) return hipErrorInvalidValue;
+            return launch_typed<A_I8>((const int8_t*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, stream);
+        case A_U8:
+            if (!w_ok) return hipErrorInvalidValue;
+            return launch_typed<A_U8>((const uint8_t*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, stream);
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace pa

@@ -1,0 +1,131 @@
+// Classification heads: a C-class (C <= 8) Linear on top of the last hidden layer, with the
+// softmax done by wavefront-level reductions (one 64-lane wave per row, butterfly __shfl_xor).
+//
+//  * variant:  output_layer_type (512 -> 3) + Softmax(dim=1)
+//        /root/reference/pepper_variant/modules/python/models/simple_model.py:76-82
+//  * polish :  dense1 (256 -> 5), then per window softmax(dim=2) zero-padded to the chunk and
+//              added into the [B,1000,5] accumulator
+//        /root/reference/pepper/modules/python/models/simple_model.py:34
+//        /root/reference/pepper/modules/python/models/predict_distributed_cpu.py:62-81
+//  * polish finalize: max over classes -> label, phred = -10 log10(1 - value / counts)
+//        /root/reference/pepper/modules/python/models/predict_distributed_cpu.py:83-90
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int MAXC = 8;
+
+PA_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// MODE 0: write probs (and optionally logits) [B,C].
+// MODE 1: accumulate softmax into acc[(row / T) * S + off + row % T][C]   (polish overlap-add)
+// MODE 2: write logits only [B,C]
+template <int MODE>
+__global__ __launch_bounds__(256) void dense_small_kernel(const float* __restrict__ X, int ldx,
+                                                          const float* __restrict__ W,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ out0,
+                                                          float* __restrict__ out1, int rows, int K,
+                                                          int C, int T, int S, int off) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float part[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) part[c] = 0.0f;
+    const float* x = X + (size_t)row * ldx;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(W + (size_t)c * K + k);
+                part[c] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+            }
+    }
+    float logit[MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        logit[c] = c < C ? wave_sum(part[c]) + bias[c] : -INFINITY;
+        mx = fmaxf(mx, logit[c]);
+    }
+    float den = 0.0f, e[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        e[c] = c < C ? expf(logit[c] - mx) : 0.0f;
+        den += e[c];
+    }
+    // lanes 0..C-1 each own one class (select without dynamic register indexing)
+    float my_logit = 0.0f, my_e = 0.0f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane == c) { my_logit = logit[c]; my_e = e[c]; }
+    if (lane < C) {
+        const float p = my_e / den;
+        if (MODE == 0) {
+            out0[(size_t)row * C + lane] = p;
+            if (out1 != nullptr) out1[(size_t)row * C + lane] = my_logit;
+        } else if (MODE == 1) {
+            const size_t dst = ((size_t)(row / T) * S + off + row % T) * C + lane;
+            out0[dst] += p;
+        } else {
+            out0[(size_t)row * C + lane] = my_logit;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void polish_finalize_kernel(const float* __restrict__ acc,
+                                                              uint8_t* __restrict__ labels,
+                                                              uint8_t* __restrict__ phred,
+                                                              size_t total, int S, int C, int overlap) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const float* a = acc + idx * C;
+    float best = a[0];
+    int lab = 0;
+    for (int c = 1; c < C; ++c)
+        if (a[c] > best) { best = a[c]; lab = c; }   // first maximum wins, as torch.max on CPU
+    const int p = (int)(idx % S);
+    const float counts = (p < overlap || p >= S - overlap) ? 1.0f : 2.0f;
+    float ph = -10.0f * log10f(1.0f - best / counts);
+    if (isinf(ph)) ph = 100.0f;
+    labels[idx] = (uint8_t)lab;
+    // numpy float32 -> uint8 cast: truncation; NaN / negative are undefined there, map to 0
+    phred[idx] = (ph >= 0.0f && ph < 256.0f) ? (uint8_t)ph : (uint8_t)0;
+}
+
+}  // namespace
+
+namespace pa {
+
+hipError_t launch_dense_small(int mode, const float* X, int ldx, const float* W, const float* bias,
+                              float* out0, float* out1, int rows, int K, int C, int T, int S, int off,
+                              hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    if (C > MAXC || (K & 3) || (ldx & 3)) return hipErrorInvalidValue;
+    const dim3 grid((rows + 3) / 4), block(256);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((dense_small_kernel<0>), grid, block, 0, stream, X, ldx, W, bias, out0, out1, rows, K, C, T, S, off); break;
+        case 1: hipLaunchKernelGGL((dense_small_kernel<1>), grid, block, 0, stream, X, ldx, W, bias, out0, out1, rows, K, C, T, S, off); break;
+        case 2: hipLaunchKernelGGL((dense_small_kernel<2>), grid, block, 0, stream, X, ldx, W, bias, out0, out1, rows, K, C, T, S, off); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_polish_finalize(const float* acc, uint8_t* labels, uint8_t* phred, int64_t B, int S,
+                                  int C, int overlap, hipStream_t stream) {
+    const size_t total = (size_t)B * S;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(polish_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       stream, acc, labels, phred, total, S, C, overlap);
+    return hipGetLastError();
+}
+
+}  // namespace pa

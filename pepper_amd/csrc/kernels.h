@@ -1,0 +1,31 @@
+// Internal launcher declarations shared between the kernel translation units and api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pa {
+
+enum AKind { A_F32 = 0, A_I8 = 1, A_U8 = 2, A_F32_SCALAR = 3 };
+
+// gemm.hip: C[M,N] = act(A[M,K] W[N,K]^T + bias); act 0 = identity, 1 = SELU.
+// a_rpb > 0 remaps logical row m to A + (m / a_rpb) * a_bstride + (m % a_rpb) * lda.
+hipError_t launch_gemm_nt(int a_type, const void* A, int lda, const float* W, int ldw,
+                          const float* bias, float* C, int ldc, int M, int N, int K, int act,
+                          int a_rpb, int64_t a_bstride, hipStream_t stream);
+
+// rnn.hip: Xp [Bpad*T, ldx], Y [Bpad*T, ldy]; Bpad = B rounded up to 64 rows (workspace buffers).
+// Packed recurrent weights: [dir][G*H/32][H/8][64 lanes][4] (see pack_rec_weights in api.hip).
+hipError_t launch_lstm_rec(int H, const float* Xp, int ldx, const float* Wp, float* Y, int ldy,
+                           int B, int T, hipStream_t stream);
+hipError_t launch_gru_rec(int H, const float* Xp, int ldx, const float* Wp, const float* bhn,
+                          const float* h0, int ldh0, float* hn, int ldhn, float* Y, int ldy,
+                          int B, int T, hipStream_t stream);
+
+// head.hip
+hipError_t launch_dense_small(int mode, const float* X, int ldx, const float* W, const float* bias,
+                              float* out0, float* out1, int rows, int K, int C, int T, int S, int off,
+                              hipStream_t stream);
+hipError_t launch_polish_finalize(const float* acc, uint8_t* labels, uint8_t* phred, int64_t B, int S,
+                                  int C, int overlap, hipStream_t stream);
+
+}  // namespace pa

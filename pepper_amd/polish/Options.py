@@ -1,0 +1,17 @@
+"""Constants of the polish inference path (reference: /root/reference/pepper/modules/python/Options.py:1-20)."""
+
+
+class ImageSizeOptions(object):
+    IMAGE_HEIGHT = 10
+    IMAGE_CHANNELS = 1
+    SEQ_LENGTH = 1000
+    SEQ_OVERLAP = 50
+    LABEL_LENGTH = SEQ_LENGTH
+    TOTAL_LABELS = 5
+
+
+class TrainOptions(object):
+    TRAIN_WINDOW = 100
+    WINDOW_JUMP = 50
+    GRU_LAYERS = 1
+    HIDDEN_SIZE = 128

@@ -1,0 +1,124 @@
+"""HIP-backed counterpart of the polish ``TransducerGRU``.
+
+Mirrors /root/reference/pepper/modules/python/models/simple_model.py:5-48:
+``forward(x, hidden) -> (logits [B,T,5], hidden [B,2L,H])`` with the encoder->decoder->next-window
+hidden hand-off, plus ``predict_chunks`` = the whole sliding-window loop of
+/root/reference/pepper/modules/python/models/predict_distributed_cpu.py:43-90 on the device.
+"""
+import ctypes
+
+import torch
+
+from pepper_amd import _lib
+from pepper_amd.polish.Options import ImageSizeOptions, TrainOptions
+
+
+class TransducerGRU(object):
+    def __init__(self, image_channels, image_features, gru_layers, hidden_size, num_classes,
+                 bidirectional=True, device=None, max_chunk=0):
+        if not bidirectional:
+            raise ValueError("the reference inference path only instantiates bidirectional=True")
+        self.image_features = image_features
+        self.hidden_size = hidden_size
+        self.num_layers = gru_layers
+        self.num_classes = num_classes
+        self.max_chunk = max_chunk
+        self.device = torch.cuda.current_device() if device is None and torch.cuda.is_available() else (device or 0)
+        self._handle = None
+        self._stream = None
+
+    def load_state_dict(self, state_dict, strict=True):
+        lib = _lib.load()
+        self.close()
+        cfg = _lib.PolishConfig(self.image_features, self.hidden_size, self.num_layers, self.num_classes,
+                                ImageSizeOptions.SEQ_LENGTH, TrainOptions.TRAIN_WINDOW,
+                                TrainOptions.WINDOW_JUMP, ImageSizeOptions.SEQ_OVERLAP, self.device,
+                                self.max_chunk)
+        names, data, numel, n, keep = _lib.marshal_state_dict(state_dict)
+        self._stream = torch.cuda.Stream(device=self.device)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.pa_polish_create(ctypes.byref(cfg), names, data, numel, n,
+                                        ctypes.c_void_p(self._stream.cuda_stream), ctypes.byref(handle)))
+        self._handle = handle
+        return self
+
+    def eval(self):
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def cpu(self):
+        return self
+
+    def close(self):
+        if self._handle is not None:
+            _lib.load().pa_polish_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if self._handle is None:
+            raise _lib.PepperAmdError("TransducerGRU has no weights: call load_state_dict first")
+        return self._handle
+
+    def init_hidden(self, batch_size, num_layers, bidirectional=True):
+        return torch.zeros(batch_size, (2 if bidirectional else 1) * num_layers, self.hidden_size)
+
+    def __call__(self, x, hidden):
+        return self.forward(x, hidden)
+
+    def _enter(self, dev):
+        cur = torch.cuda.current_stream(dev)
+        self._stream.wait_stream(cur)
+        return cur
+
+    def _leave(self, cur, tensors):
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self._stream)
+        cur.wait_stream(self._stream)
+
+    def forward(self, x, hidden):
+        lib = _lib.load()
+        x = torch.as_tensor(x)
+        on_cpu = not x.is_cuda
+        dev = torch.device("cuda", self.device)
+        x = x.to(dev, torch.float32).contiguous()
+        hidden = torch.as_tensor(hidden).to(dev, torch.float32).contiguous()
+        n, T = x.shape[0], x.shape[1]
+        if x.shape[2] != self.image_features or tuple(hidden.shape) != (n, 2 * self.num_layers, self.hidden_size):
+            raise ValueError("bad x / hidden shape")
+        logits = torch.empty((n, T, self.num_classes), dtype=torch.float32, device=dev)
+        hidden_out = torch.empty_like(hidden)
+        cur = self._enter(dev)
+        _lib.check(lib.pa_polish_forward_device(self.handle, x.data_ptr(), hidden.data_ptr(), n, T,
+                                                logits.data_ptr(), hidden_out.data_ptr()))
+        self._leave(cur, (x, hidden, logits, hidden_out))
+        return (logits.cpu(), hidden_out.cpu()) if on_cpu else (logits, hidden_out)
+
+    def predict_chunks(self, images, return_acc=False):
+        """images uint8 [B,1000,10] -> (labels uint8 [B,1000], phred uint8 [B,1000][, acc])."""
+        lib = _lib.load()
+        images = torch.as_tensor(images)
+        on_cpu = not images.is_cuda
+        dev = torch.device("cuda", self.device)
+        if images.dtype != torch.uint8:
+            raise ValueError("polish images are uint8 (pepper DataStore.py:60)")
+        images = images.to(dev).contiguous()
+        n, S = images.shape[0], images.shape[1]
+        labels = torch.empty((n, S), dtype=torch.uint8, device=dev)
+        phred = torch.empty((n, S), dtype=torch.uint8, device=dev)
+        acc = torch.empty((n, S, self.num_classes), dtype=torch.float32, device=dev) if return_acc else None
+        cur = self._enter(dev)
+        _lib.check(lib.pa_polish_predict_device(self.handle, images.data_ptr(), n, labels.data_ptr(),
+                                                phred.data_ptr(), acc.data_ptr() if acc is not None else None))
+        self._leave(cur, (images, labels, phred, acc))
+        out = (labels, phred) + ((acc,) if return_acc else ())
+        return tuple(t.cpu() for t in out) if on_cpu else out

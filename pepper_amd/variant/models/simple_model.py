@@ -1,0 +1,102 @@
+"""HIP-backed counterpart of the variant ``TransducerGRU``.
+
+Mirrors /root/reference/pepper_variant/modules/python/models/simple_model.py:6-87: same
+constructor arguments, same state_dict keys/shapes, ``forward(x, train_mode=False)`` returning
+softmax probabilities [B,3] (logits when ``train_mode``).  All arithmetic runs in
+libpepper_amd.so on the GPU; torch is used only for device memory and stream ordering.
+"""
+import ctypes
+
+import torch
+
+from pepper_amd import _lib
+from pepper_amd.variant.Options import ImageSizeOptions
+
+
+class TransducerGRU(object):
+    def __init__(self, image_features, gru_layers, hidden_size, num_classes, num_classes_type,
+                 bidirectional=True, device=None, max_chunk=0):
+        if not bidirectional:
+            raise ValueError("the reference inference path only instantiates bidirectional=True")
+        self.image_features = image_features
+        self.hidden_size = hidden_size          # kept for parity; layer widths are fixed at 256/512
+        self.bidirectional = bidirectional
+        self.num_layers = gru_layers
+        self.num_classes = num_classes
+        self.num_classes_type = num_classes_type
+        self.window = ImageSizeOptions.CANDIDATE_WINDOW_SIZE + 1
+        self.max_chunk = max_chunk
+        self.device = torch.cuda.current_device() if device is None and torch.cuda.is_available() else (device or 0)
+        self._handle = None
+        self._stream = None
+        self.training = False
+
+    # ---- nn.Module-like surface used by predict() ------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        lib = _lib.load()
+        self.close()
+        cfg = _lib.VariantConfig(self.image_features, self.window, self.num_layers,
+                                 self.num_classes_type, self.device, self.max_chunk)
+        names, data, numel, n, keep = _lib.marshal_state_dict(state_dict)
+        self._stream = torch.cuda.Stream(device=self.device)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.pa_variant_create(ctypes.byref(cfg), names, data, numel, n,
+                                         ctypes.c_void_p(self._stream.cuda_stream), ctypes.byref(handle)))
+        self._handle = handle
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def cpu(self):
+        return self
+
+    def close(self):
+        if self._handle is not None:
+            _lib.load().pa_variant_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if self._handle is None:
+            raise _lib.PepperAmdError("TransducerGRU has no weights: call load_state_dict first")
+        return self._handle
+
+    def __call__(self, x, train_mode=False):
+        return self.forward(x, train_mode)
+
+    def forward(self, x, train_mode=False):
+        """x: [B, 33, 26] int8 (as stored in the images HDF5) or float tensor, CPU or GPU."""
+        lib = _lib.load()
+        x = torch.as_tensor(x)
+        if x.dim() != 3 or x.shape[1] != self.window or x.shape[2] != self.image_features:
+            raise ValueError(f"expected [B,{self.window},{self.image_features}], got {tuple(x.shape)}")
+        on_cpu = not x.is_cuda
+        dev = torch.device("cuda", self.device)
+        if x.dtype not in (torch.int8, torch.float32):
+            x = x.to(torch.float32)
+        x = x.to(dev).contiguous()
+        n = x.shape[0]
+        probs = torch.empty((n, self.num_classes_type), dtype=torch.float32, device=dev)
+        logits = torch.empty_like(probs) if train_mode else None
+        cur = torch.cuda.current_stream(dev)
+        self._stream.wait_stream(cur)
+        fn = lib.pa_variant_forward_device if x.dtype == torch.int8 else lib.pa_variant_forward_device_f32
+        _lib.check(fn(self.handle, x.data_ptr(), n, probs.data_ptr(),
+                      logits.data_ptr() if logits is not None else None))
+        for t in (x, probs, logits):
+            if t is not None:
+                t.record_stream(self._stream)
+        cur.wait_stream(self._stream)
+        out = logits if train_mode else probs
+        return out.cpu() if on_cpu else out

@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the library builds, loads and exports every symbol
+include/pepper_amd.h declares; the product package never touches the oracle."""
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pepper_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    header = open(os.path.join(REPO, "include", "pepper_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 17
+    from pepper_amd import _lib
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_version_and_error_string(lib):
+    assert lib.pa_version().decode().startswith("pepper_amd")
+    assert lib.pa_last_error() is not None
+
+
+def test_no_gpu_means_loud_failure(lib):
+    """Without a device the product path must raise, never fall back to a CPU implementation."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ctypes
+    from pepper_amd import _lib, synthetic
+    cfg = _lib.VariantConfig(26, 33, 1, 3, 0, 0)
+    names, data, numel, n, keep = _lib.marshal_state_dict(synthetic.variant_state_dict(seed=1))
+    handle = ctypes.c_void_p()
+    rc = lib.pa_variant_create(ctypes.byref(cfg), names, data, numel, n, None, ctypes.byref(handle))
+    assert rc != 0
+    assert b"no HIP device" in lib.pa_last_error() or b"hip" in lib.pa_last_error().lower()
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, "pepper_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(root, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "oracle/" in text.replace("oracle/ ", ""):
+                    if "never route through oracle/" in text and not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M):
+                        continue
+                    bad.append(os.path.join(root, f))
+    assert not bad, bad

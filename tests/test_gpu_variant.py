@@ -1,0 +1,136 @@
+"""GPU parity of the variant model: HIP path (through the C ABI) vs golden vectors from the
+reference classes and vs the oracle on seeded inputs.  Tolerance: 1e-4 on probabilities and
+logits (BASELINE.json north_star)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import models_np
+from pepper_amd import _lib, synthetic
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+class NativeVariant:
+    """Thin test harness over the raw C ABI (host-pointer entry points)."""
+
+    def __init__(self, sd, gru_layers=1, max_chunk=0):
+        self.lib = _lib.load()
+        cfg = _lib.VariantConfig(26, 33, gru_layers, 3, 0, max_chunk)
+        names, data, numel, n, keep = _lib.marshal_state_dict(sd)
+        self.h = ctypes.c_void_p()
+        _lib.check(self.lib.pa_variant_create(ctypes.byref(cfg), names, data, numel, n, None,
+                                              ctypes.byref(self.h)))
+
+    def forward(self, images):
+        images = np.ascontiguousarray(images, dtype=np.int8)
+        n = images.shape[0]
+        probs = np.empty((n, 3), np.float32)
+        logits = np.empty((n, 3), np.float32)
+        _lib.check(self.lib.pa_variant_forward_host(self.h, images.ctypes.data, n, probs.ctypes.data,
+                                                    logits.ctypes.data))
+        return probs, logits
+
+    def close(self):
+        self.lib.pa_variant_destroy(self.h)
+
+
+def _golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("tag", ["g1", "g3"])
+def test_variant_matches_reference_golden(golden_dir, tag):
+    g = _golden(golden_dir, f"variant_{tag}.npz")
+    sd = synthetic.variant_state_dict(seed=int(g["seed"]), gain=float(g["gain"]))
+    m = NativeVariant(sd)
+    probs, logits = m.forward(g["images"])
+    m.close()
+    assert np.abs(probs - g["probs"]).max() < TOL
+    assert np.abs(logits - g["logits"]).max() < TOL * max(1.0, np.abs(g["logits"]).max())
+    assert (probs.argmax(1) == g["probs"].argmax(1)).all()
+
+
+def test_variant_two_layer_golden(golden_dir):
+    g = _golden(golden_dir, "variant_l2.npz")
+    sd = synthetic.variant_state_dict(seed=int(g["seed"]), gain=float(g["gain"]), gru_layers=2)
+    m = NativeVariant(sd, gru_layers=2)
+    probs, _ = m.forward(g["images"])
+    m.close()
+    assert np.abs(probs - g["probs"]).max() < TOL
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 130, 515])
+def test_variant_ragged_batches_vs_oracle(n):
+    sd = synthetic.variant_state_dict(seed=5, gain=2.0)
+    x = synthetic.variant_windows(n, seed=77 + n)
+    m = NativeVariant(sd)
+    probs, logits = m.forward(x)
+    m.close()
+    ref, inter = models_np.variant_forward(sd, x, return_intermediates=True)
+    assert np.abs(probs - ref).max() < TOL
+    assert np.abs(logits - inter["logits"]).max() < TOL * max(1.0, np.abs(inter["logits"]).max())
+    assert np.abs(probs.sum(1) - 1).max() < 1e-5
+
+
+def test_variant_empty_batch():
+    m = NativeVariant(synthetic.variant_state_dict(seed=5))
+    probs = np.empty((0, 3), np.float32)
+    _lib.check(m.lib.pa_variant_forward_host(m.h, None, 0, probs.ctypes.data, None))
+    m.close()
+
+
+def test_variant_chunking_and_order_invariance():
+    """Size-independent properties: device chunking must not change results; windows are
+    independent, so permuting the batch permutes the output bit-exactly."""
+    sd = synthetic.variant_state_dict(seed=6, gain=2.0)
+    x = synthetic.variant_windows(1000, seed=3)
+    whole = NativeVariant(sd)
+    p0, _ = whole.forward(x)
+    perm = np.random.default_rng(0).permutation(len(x))
+    p1, _ = whole.forward(x[perm])
+    whole.close()
+    chunked = NativeVariant(sd, max_chunk=192)
+    p2, _ = chunked.forward(x)
+    chunked.close()
+    assert np.abs(p0 - p2).max() < 1e-6
+    assert np.abs(p0[perm] - p1).max() < 1e-6
+
+
+def test_variant_missing_key_fails_loudly():
+    sd = synthetic.variant_state_dict(seed=5)
+    del sd["linear_3.bias"]
+    with pytest.raises(_lib.PepperAmdError, match="linear_3.bias"):
+        NativeVariant(sd)
+
+
+def test_module_wrapper_and_checkpoint_loader(tmp_path):
+    """TransducerGRU / ModelHandler mirror: module.-prefixed checkpoint, int8 and float inputs,
+    CUDA and CPU tensors, train_mode logits."""
+    from pepper_amd.variant.models.ModelHander import ModelHandler
+    sd = synthetic.variant_state_dict(seed=8, gain=2.0)
+    ckpt = synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128,
+                                     module_prefix=True)
+    path = str(tmp_path / "model.pkl")
+    torch.save(ckpt, path)
+    model, hidden_size, gru_layers, epochs = ModelHandler.load_simple_model_for_training(path, 26, 28, 3)
+    assert (hidden_size, gru_layers, epochs) == (128, 1, 1)
+    x = synthetic.variant_windows(70, seed=9)
+    ref, inter = models_np.variant_forward(sd, x, return_intermediates=True)
+    xi = torch.from_numpy(x)
+    out_cpu = model.eval()(xi.type(torch.FloatTensor), False)
+    assert not out_cpu.is_cuda and np.abs(out_cpu.numpy() - ref).max() < TOL
+    out_gpu = model(xi.cuda(), False)
+    assert out_gpu.is_cuda and np.abs(out_gpu.cpu().numpy() - ref).max() < TOL
+    out_f = model(xi.float().cuda(), False)
+    assert np.abs(out_f.cpu().numpy() - out_gpu.cpu().numpy()).max() < 1e-6
+    lg = model(xi.cuda(), True)
+    assert np.abs(lg.cpu().numpy() - inter["logits"]).max() < TOL * max(1.0, np.abs(inter["logits"]).max())
+    # non-integral float input exercises the f32 loader for real
+    xf = xi.float() * 0.37
+    ref_f = models_np.variant_forward(sd, xf.numpy())
+    assert np.abs(model(xf.cuda()).cpu().numpy() - ref_f).max() < TOL
