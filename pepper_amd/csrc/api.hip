@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -186,8 +187,28 @@ void pack_rec_weights(const float* const w[2], int G, int H, std::vector<float>&
                             w[d][(size_t)(nt * 32 + (l & 31)) * H + kb * 8 + 4 * (l >> 5) + e];
 }
 
+// Fused first layer (rnn.hip lstm_rec_pp_kernel<H, 32>): per direction [W_hh | W_ih | 0] with
+// K = H + 32 columns, in the same fragment order as pack_rec_weights.
+void pack_fused_weights(const float* const whh[2], const float* const wih[2], int G, int H, int F, int KX,
+                        std::vector<float>& out) {
+    const int KT = H + KX, NTt = G * H / 32, KB = KT / 8;
+    out.assign((size_t)2 * NTt * KB * 64 * 4, 0.0f);
+    for (int d = 0; d < 2; ++d)
+        for (int nt = 0; nt < NTt; ++nt)
+            for (int kb = 0; kb < KB; ++kb)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = nt * 32 + (l & 31), k = kb * 8 + 4 * (l >> 5) + e;
+                        float v = 0.0f;
+                        if (k < H) v = whh[d][(size_t)n * H + k];
+                        else if (k - H < F) v = wih[d][(size_t)n * F + (k - H)];
+                        out[((((size_t)d * NTt + nt) * KB + kb) * 64 + l) * 4 + e] = v;
+                    }
+}
+
 // One bidirectional recurrent layer's device weights.
 struct RecLayer {
+    DevBuf *w_cat = nullptr;   // LSTM first layer only: fused [W_hh | W_ih] fragments
     int K = 0, Kp = 0;         // input width and its zero-padded row length
     DevBuf *w_ih = nullptr;    // [2*G*H, Kp]   rows: dir*G*H + gate*H + unit
     DevBuf *b_in = nullptr;    // [2*G*H]       LSTM: b_ih + b_hh; GRU: b_ih + (b_hr, b_hz, 0)
@@ -232,6 +253,12 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
     if (G == 3) {
         out.b_hn = m->new_buf();
         if (int rc = upload(out.b_hn, bn)) return rc;
+    }
+    if (G == 4 && H == 256 && K <= 32) {
+        std::vector<float> cat;
+        pack_fused_weights(whh, wih, G, H, K, 32, cat);
+        out.w_cat = m->new_buf();
+        if (int rc = upload(out.w_cat, cat)) return rc;
     }
     return PA_OK;
 }
@@ -294,6 +321,7 @@ int init_base(ModelBase* m, int device, void* hip_stream) {
 struct pa_variant_model : ModelBase {
     pa_variant_config cfg{};
     int H = 256, L1 = 512;
+    bool fuse_input = true;      // PA_FUSE_INPUT=0 falls back to GEMM + Xp for A/B measurements
     std::vector<RecLayer> rec;   // encoder layers then decoder layers
     Linear lin[5], out;
     DevBuf *xp, *ya, *yb, *l1, *l2, *stage_in, *stage_p, *stage_l;
@@ -318,6 +346,7 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     auto* m = new pa_variant_model();
     m->cfg = *cfg;
     if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 16384;
+    if (const char* e = getenv("PA_FUSE_INPUT")) m->fuse_input = e[0] != '0';
     int rc = init_base(m, cfg->device, hip_stream);
     StateDict sd(names, data, numel, n_tensors);
     const int H = m->H;
@@ -368,12 +397,19 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     const int M = (int)(n * T);
     for (size_t li = 0; li < m->rec.size(); ++li) {
         const RecLayer& r = m->rec[li];
-        LAUNCH_TRY(m, li == 0 ? "gemm_inproj_i8" : "gemm_inproj", 2.0 * M * NX * r.K,
-                   pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
-                                      NX, M, NX, r.K, 0, 0, 0, m->stream));
         float* y = ybuf[which];
-        LAUNCH_TRY(m, "lstm_rec", 2.0 * n * T * (4.0 * H) * H * 2,
-                   pa::launch_lstm_rec(H, m->xp->f(), NX, r.w_hh->f(), y, 2 * H, (int)n, T, m->stream));
+        if (li == 0 && cur_kind == pa::A_I8 && r.w_cat != nullptr && m->fuse_input) {
+            // int8 summaries straight into the recurrent kernel: no Xp round trip (rnn.hip)
+            LAUNCH_TRY(m, "lstm_rec_fused_in", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
+                       pa::launch_lstm_rec_fused(H, static_cast<const int8_t*>(cur), r.K, r.b_in->f(),
+                                                 r.w_cat->f(), y, 2 * H, (int)n, T, m->stream));
+        } else {
+            LAUNCH_TRY(m, li == 0 ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
+                       pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
+                                          NX, M, NX, r.K, 0, 0, 0, m->stream));
+            LAUNCH_TRY(m, "lstm_rec", 2.0 * n * T * (4.0 * H) * H * 2,
+                       pa::launch_lstm_rec(H, m->xp->f(), NX, r.w_hh->f(), y, 2 * H, (int)n, T, m->stream));
+        }
         cur = y;
         cur_kind = pa::A_F32;
         cur_ld = 2 * H;

@@ -27,6 +27,16 @@ PA_DEV int crow32(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >
 
 PA_DEV float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Branch-free gate nonlinearities on v_exp_f32 / v_rcp_f32 (both ~1 ulp).  Absolute error is
+// ~1e-7 (cancellation in tanh near 0 included), far inside the 1e-4 parity budget; the libm
+// expf/tanhf expand to range-split code with exec-mask branches in the recurrent hot loop.
+PA_DEV float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+PA_DEV float fast_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
 // torch.nn.SELU constants (torch/nn/functional.py selu; alpha, scale as published)
 PA_DEV float selu_f(float x) {
     const float alpha = 1.6732632423543772848170429916717f;

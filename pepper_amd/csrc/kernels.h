@@ -17,6 +17,10 @@ hipError_t launch_gemm_nt(int a_type, const void* A, int lda, const float* W, in
 // Packed recurrent weights: [dir][G*H/32][H/8][64 lanes][4] (see pack_rec_weights in api.hip).
 hipError_t launch_lstm_rec(int H, const float* Xp, int ldx, const float* Wp, float* Y, int ldy,
                            int B, int T, hipStream_t stream);
+// Fused first layer: int8 X [B, T, F] (F <= 32) and Wcat = [W_hh | W_ih zero-padded to 32] packed
+// with K = H + 32; bias = b_ih + b_hh [2*4H].
+hipError_t launch_lstm_rec_fused(int H, const int8_t* X, int F, const float* bias, const float* Wcat,
+                                 float* Y, int ldy, int B, int T, hipStream_t stream);
 hipError_t launch_gru_rec(int H, const float* Xp, int ldx, const float* Wp, const float* bhn,
                           const float* h0, int ldh0, float* hn, int ldhn, float* Y, int ldy,
                           int B, int T, hipStream_t stream);

@@ -127,7 +127,9 @@ def test_module_wrapper_and_checkpoint_loader(tmp_path):
     out_gpu = model(xi.cuda(), False)
     assert out_gpu.is_cuda and np.abs(out_gpu.cpu().numpy() - ref).max() < TOL
     out_f = model(xi.float().cuda(), False)
-    assert np.abs(out_f.cpu().numpy() - out_gpu.cpu().numpy()).max() < 1e-6
+    # int8 input runs the fused kernel, float input the GEMM + Xp path: same math, different
+    # accumulation order
+    assert np.abs(out_f.cpu().numpy() - out_gpu.cpu().numpy()).max() < 2e-5
     lg = model(xi.cuda(), True)
     assert np.abs(lg.cpu().numpy() - inter["logits"]).max() < TOL * max(1.0, np.abs(inter["logits"]).max())
     # non-integral float input exercises the f32 loader for real
