@@ -7,7 +7,7 @@
 // Tile: 128x128x32 per 256-thread workgroup, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA
 // tiles (64 accumulator VGPRs).  Both operands are K-contiguous (PyTorch weight layout is
 // [out,in]), staged global -> registers -> LDS with one barrier per k-tile (loads for tile
-// k+1 are issued before the MFMAs of tile k and written to the other LDS buffer after them).
+// k+2 are issued, and tile k+1 is written to the other LDS buffer, before the MFMAs of tile k).
 // LDS rows are padded to 36 floats: ds_read_b128 fragment reads are bank-conflict free
 // (row stride 144 B -> 16 distinct 16-B slots per 16-lane group).
 #include "common.h"
@@ -21,12 +21,14 @@ template <int AT> struct AType { typedef float type; };
 template <> struct AType<pa::A_I8> { typedef int8_t type; };
 template <> struct AType<pa::A_U8> { typedef uint8_t type; };
 
-// Load 4 consecutive k of one row (row == nullptr -> out of range -> zeros).
-template <int AT>
+// Load 4 consecutive k of one row.  Rows beyond M/N are clamped to the last valid row by the
+// caller (their results are never stored), so only the K tail needs predication; KFULL (K % 32
+// == 0) removes even that and the loop carries no exec-mask branches.
+template <int AT, bool KFULL>
 PA_DEV void load_a4(const typename AType<AT>::type* __restrict__ row, int k, int K, float (&out)[4]) {
     if constexpr (AT == pa::A_F32) {
         // requires 16-byte aligned rows and K % 4 == 0 or zero-padded rows (checked on the host)
-        if (row != nullptr && k < K) {
+        if (KFULL || k < K) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(row + k);
             out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
         } else {
@@ -35,17 +37,21 @@ PA_DEV void load_a4(const typename AType<AT>::type* __restrict__ row, int k, int
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            out[e] = (row != nullptr && k + e < K) ? (float)row[k + e] : 0.0f;
+            out[e] = (KFULL || k + e < K) ? (float)row[k + e] : 0.0f;
     }
 }
 
-template <int AT, int ACT>
+template <int AT, int ACT, bool KFULL>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const typename AType<AT>::type* __restrict__ A, int lda,
                                                       const float* __restrict__ W, int ldw,
                                                       const float* __restrict__ bias,
                                                       float* __restrict__ C, int ldc,
                                                       int M, int N, int K, int tiles_n, int nwg,
-                                                      int a_rpb, int64_t a_bstride) {
+                                                      int a_rpb, int64_t a_bstride, int tune) {
+    // The two co-resident workgroups of a CU share each SIMD's matrix pipe; with equal priority
+    // they fall into lockstep and stall at their barriers together.  A static priority split
+    // lets one run ahead so their bubbles interleave (MI355X_MICROARCH "Two waves per SIMD").
+    if ((tune & 1) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BM * LDT];
     float* As = lds;                    // [2][BM][LDT]
     float* Bs = lds + 2 * BM * LDT;     // [2][BN][LDT]
@@ -81,22 +87,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const typename AType<AT>::
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + r0 + 32 * i, n = n0 + r0 + 32 * i;
-        if (m < M) {
-            const size_t off = a_rpb > 0 ? (size_t)(m / a_rpb) * a_bstride + (size_t)(m % a_rpb) * lda
-                                         : (size_t)m * lda;
-            arow[i] = A + off;
-        } else {
-            arow[i] = nullptr;
-        }
-        wrow[i] = n < N ? W + (size_t)n * ldw : nullptr;
+        const int mc = m < M ? m : M - 1, nc = n < N ? n : N - 1;   // clamp: tail rows are not stored
+        const size_t off = a_rpb > 0 ? (size_t)(mc / a_rpb) * a_bstride + (size_t)(mc % a_rpb) * lda
+                                     : (size_t)mc * lda;
+        arow[i] = A + off;
+        wrow[i] = W + (size_t)nc * ldw;
     }
 
     auto gload = [&](int kt) {
         const int k = kt * BK + kq * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            load_a4<AT>(arow[i], k, K, ra[i]);
-            load_a4<pa::A_F32>(wrow[i], k, K, rb[i]);
+            load_a4<AT, KFULL>(arow[i], k, K, ra[i]);
+            load_a4<pa::A_F32, KFULL>(wrow[i], k, K, rb[i]);
         }
     };
     auto lstore = [&](int buf) {
@@ -109,31 +112,54 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const typename AType<AT>::
         }
     };
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const float* Ab = As + (buf * BM + wm * 64 + li) * LDT + hf * 4;
-        const float* Bb = Bs + (buf * BN + wn * 64 + li) * LDT + hf * 4;
+    // Software pipeline, one barrier per k-tile, with every LDS fragment read issued one
+    // half-tile (32 MFMAs = 2048 pipe cycles) ahead of its use:
+    //   iteration kt:  read H1(kt) | write tile kt+1 to the other buffer | request tile kt+2 |
+    //                  MFMA H0(kt) | barrier | read H0(kt+1) | MFMA H1(kt)
+    // H0/H1 = k-blocks {0,1} / {2,3} of the 32-wide tile.  sched_barrier(0) pins the order the
+    // compiler would otherwise collapse into read-then-immediately-wait.
+    f32x4 fa[2][2][2], fb[2][2][2];   // [half parity][kk in half][m or n]
+    auto read_half = [&](int buf, int half, f32x4 (&a)[2][2], f32x4 (&b)[2][2]) {
+        const float* Ab = As + (buf * BM + wm * 64 + li) * LDT + hf * 4 + half * 16;
+        const float* Bb = Bs + (buf * BN + wn * 64 + li) * LDT + hf * 4 + half * 16;
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a[2], b[2];
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const f32x4*>(Ab + m * 32 * LDT + kk * 8);
+            for (int m = 0; m < 2; ++m) a[kk][m] = *reinterpret_cast<const f32x4*>(Ab + m * 32 * LDT + kk * 8);
 #pragma unroll
-            for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const f32x4*>(Bb + n * 32 * LDT + kk * 8);
+            for (int n = 0; n < 2; ++n) b[kk][n] = *reinterpret_cast<const f32x4*>(Bb + n * 32 * LDT + kk * 8);
+        }
+    };
+    auto mma_half = [&](const f32x4 (&a)[2][2], const f32x4 (&b)[2][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma32(a[m][s], b[n][s], acc[m][n]);
-        }
+                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma32(a[kk][m][s], b[kk][n][s], acc[m][n]);
+    };
+
+    gload(0);
+    lstore(0);
+    if (nk > 1) gload(1);
+    __syncthreads();
+    read_half(0, 0, fa[0], fb[0]);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        read_half(buf, 1, fa[1], fb[1]);
         if (kt + 1 < nk) lstore(buf ^ 1);
+        if (kt + 2 < nk) gload(kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        if (kt + 1 < nk) read_half(buf ^ 1, 0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
 #pragma unroll
@@ -162,12 +188,16 @@ hipError_t launch_typed(const typename AType<AT>::type* A, int lda, const float*
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int nwg = tiles_m * tiles_n;
     if (nwg == 0) return hipSuccess;
-    if (act == 1)
-        hipLaunchKernelGGL((gemm_nt_kernel<AT, 1>), dim3(nwg), dim3(256), 0, stream, A, lda, W, ldw,
-                           bias, C, ldc, M, N, K, tiles_n, nwg, a_rpb, a_bstride);
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<AT, 0>), dim3(nwg), dim3(256), 0, stream, A, lda, W, ldw,
-                           bias, C, ldc, M, N, K, tiles_n, nwg, a_rpb, a_bstride);
+#define PA_GEMM_LAUNCH(ACT_, KF_)                                                                   \
+    hipLaunchKernelGGL((gemm_nt_kernel<AT, ACT_, KF_>), dim3(nwg), dim3(256), 0, stream, A, lda, W, ldw, \
+                       bias, C, ldc, M, N, K, tiles_n, nwg, a_rpb, a_bstride, pa::tune_flags())
+    const bool kfull = (K % BK) == 0;
+    if (act == 1) {
+        if (kfull) PA_GEMM_LAUNCH(1, true); else PA_GEMM_LAUNCH(1, false);
+    } else {
+        if (kfull) PA_GEMM_LAUNCH(0, true); else PA_GEMM_LAUNCH(0, false);
+    }
+#undef PA_GEMM_LAUNCH
     return hipGetLastError();
 }
 

@@ -7,6 +7,9 @@ namespace pa {
 
 enum AKind { A_F32 = 0, A_I8 = 1, A_U8 = 2, A_F32_SCALAR = 3 };
 
+// experiment switches from $PA_TUNE (bit 0: GEMM priority split, bit 1: MFMA-phase priority)
+int tune_flags();
+
 // gemm.hip: C[M,N] = act(A[M,K] W[N,K]^T + bias); act 0 = identity, 1 = SELU.
 // a_rpb > 0 remaps logical row m to A + (m / a_rpb) * a_bstride + (m % a_rpb) * lda.
 hipError_t launch_gemm_nt(int a_type, const void* A, int lda, const float* W, int ldw,

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_pp_kernel(const float
                                                                      const float* __restrict__ bias,
                                                                      const float* __restrict__ Wp,
                                                                      float* __restrict__ Y, int ldy,
-                                                                     int B, int T) {
+                                                                     int B, int T, int tune) {
     constexpr int KT = H + KX, LDH = KT + 4, KB = KT / 8, NT = H / 32, NW = H / 32;
     static_assert(KB % 2 == 0, "k-blocks are consumed in pairs");
     extern __shared__ __attribute__((aligned(16))) float hs[];  // [MT][LDH] = [h | x | pad], then c
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_pp_kernel(const float
         if ((i & 1) == grp) {
             // ---------------- MFMA phase of step (i - grp) / 2 ----------------
             if (((i - grp) >> 1) < T) {
+                if (tune & 2) __builtin_amdgcn_s_setprio(1);   // feed the matrix pipe first
                 // double buffer at k-block granularity: the 8 weight fragments + the A fragment of
                 // k-block kb+1 are in flight while the 32 MFMAs (2048 pipe cycles) of kb issue
                 f32x4 bw[2][2][4], af[2];
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_pp_kernel(const float
                                     acc[ut][g] = mfma32(af[p][s], bw[p][ut][g][s], acc[ut][g]);
                     }
                 }
+                if (tune & 2) __builtin_amdgcn_s_setprio(0);
             }
         } else {
             // ---------------- gate phase of step (i - 1 - grp) / 2 ----------------
@@ -419,6 +421,14 @@ inline int rec_grid(int B) {
 
 namespace pa {
 
+int tune_flags() {
+    static const int v = [] {
+        const char* e = getenv("PA_TUNE");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 hipError_t launch_lstm_rec(int H, const float* Xp, int ldx, const float* Wp, float* Y, int ldy,
                            int B, int T, hipStream_t stream) {
     if (B <= 0) return hipSuccess;
@@ -430,7 +440,7 @@ hipError_t launch_lstm_rec(int H, const float* Xp, int ldx, const float* Wp, flo
     if (H == 256 && use_pp) {
         const size_t lds = ((size_t)MT * (256 + 4) + 8 * 2 * 16 * 64) * sizeof(float);  // h + c
         hipLaunchKernelGGL((lstm_rec_pp_kernel<256, 0>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
-                           (const int8_t*)nullptr, 0, (const float*)nullptr, Wp, Y, ldy, B, T);
+                           (const int8_t*)nullptr, 0, (const float*)nullptr, Wp, Y, ldy, B, T, tune_flags());
     } else if (H == 256) {
         const size_t lds = (size_t)MT * (256 + 4) * sizeof(float);
         hipLaunchKernelGGL((lstm_rec_kernel<256>), dim3(grid), dim3(512), lds, stream, Xp, ldx, Wp, Y,
@@ -452,7 +462,7 @@ hipError_t launch_lstm_rec_fused(int H, const int8_t* X, int F, const float* bia
     const int grid = rec_grid(B);
     const size_t lds = ((size_t)MT * (256 + 32 + 4) + 8 * 2 * 16 * 64) * sizeof(float);  // [h|x] + c
     hipLaunchKernelGGL((lstm_rec_pp_kernel<256, 32>), dim3(grid), dim3(512), lds, stream,
-                       (const float*)nullptr, 0, X, F, bias, Wcat, Y, ldy, B, T);
+                       (const float*)nullptr, 0, X, F, bias, Wcat, Y, ldy, B, T, tune_flags());
     return hipGetLastError();
 }
 
