@@ -1,0 +1,79 @@
+/* pepper_amd_io C ABI -- the minimal HDF5 surface PEPPER's inference path touches.
+ *
+ * The reference reads and writes its step hand-off files through h5py:
+ *   images       pepper_variant/modules/python/DataStore.py:54-71  (write_summary)
+ *                pepper_variant/modules/python/models/dataloader_predict.py:45-79 (bulk reads)
+ *   predictions  pepper_variant/modules/python/DataStorePredict.py:49-67 (write_prediction)
+ *   polish       pepper/modules/python/DataStore.py:53-67, pepper/modules/python/DataStorePredict.py:49-76,
+ *                pepper/modules/python/models/dataloader_predict.py:49-60
+ * h5py is not installed for the torch-ROCm interpreter of this image, so the same libhdf5 C
+ * calls are made directly (HDF5 1.10, /opt/conda/lib/libhdf5.so.103).  Datasets are written the
+ * way `file[path] = ndarray` does it: contiguous, no chunking, no compression, intermediate
+ * groups created on demand.
+ */
+#ifndef PEPPER_AMD_IO_H
+#define PEPPER_AMD_IO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pa_h5 pa_h5;
+
+/* element type codes for numeric datasets */
+#define PA_H5_I8 0
+#define PA_H5_U8 1
+#define PA_H5_I16 2
+#define PA_H5_I32 3
+#define PA_H5_I64 4
+#define PA_H5_F32 5
+#define PA_H5_F64 6
+#define PA_H5_U16 7
+#define PA_H5_U32 8
+#define PA_H5_U64 9
+
+/* dataset classes reported by pa_h5_info */
+#define PA_H5_CLASS_INT 0
+#define PA_H5_CLASS_FLOAT 1
+#define PA_H5_CLASS_FIXED_STRING 2
+#define PA_H5_CLASS_VLEN_STRING 3
+#define PA_H5_CLASS_OTHER 4
+
+const char* pa_h5_last_error(void);
+
+/* mode: 0 = read-only, 1 = create/truncate ('w'), 2 = read-write existing ('r+') */
+int pa_h5_open(const char* path, int32_t mode, pa_h5** out);
+int pa_h5_close(pa_h5* f);
+int pa_h5_flush(pa_h5* f);
+
+/* 1 if `path` names an existing link (group or dataset), 0 if not, <0 on error */
+int pa_h5_exists(pa_h5* f, const char* path);
+/* child names of a group, NUL-separated, in HDF5's name order (= h5py's keys() order).
+ * Returns 0 and sets *needed; call again with a buffer of that size if cap was too small. */
+int pa_h5_list(pa_h5* f, const char* group, char* buf, int64_t cap, int64_t* needed, int64_t* count);
+
+/* rank (<= 8), dims, class, element size in bytes (string width for fixed strings), signedness */
+int pa_h5_info(pa_h5* f, const char* path, int32_t* rank, int64_t* dims, int32_t* cls, int32_t* elem_size,
+               int32_t* is_signed);
+
+/* whole-dataset numeric read with conversion to `type_code`; nbytes must equal the full size */
+int pa_h5_read(pa_h5* f, const char* path, int32_t type_code, void* out, int64_t nbytes);
+/* create + write a numeric dataset (rank 0 = scalar) */
+int pa_h5_write(pa_h5* f, const char* path, int32_t type_code, int32_t rank, const int64_t* dims,
+                const void* data);
+
+/* all strings of a (fixed or variable length) string dataset, NUL-separated, row-major order */
+int pa_h5_read_strings(pa_h5* f, const char* path, char* buf, int64_t cap, int64_t* needed);
+/* numpy dtype 'S<width>' dataset: `data` holds prod(dims) fields of `width` bytes, NUL padded */
+int pa_h5_write_fixed_strings(pa_h5* f, const char* path, int32_t rank, const int64_t* dims, int32_t width,
+                              const char* data);
+/* h5py special_dtype(vlen=str) dataset (variable-length UTF-8) */
+int pa_h5_write_vlen_strings(pa_h5* f, const char* path, int32_t rank, const int64_t* dims,
+                             const char* const* strings);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEPPER_AMD_IO_H */

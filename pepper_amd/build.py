@@ -21,6 +21,31 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+IO_LIB = os.path.join(CSRC, "libpepper_amd_io.so")
+HDF5_PREFIX = os.environ.get("PEPPER_AMD_HDF5_PREFIX", "/opt/conda")
+
+
+def build_io(force=False, verbose=False):
+    """g++ build of the HDF5 I/O helper (include/pepper_amd_io.h) against libhdf5 1.10.
+
+    h5py is not installed for this image's torch interpreter; libhdf5 + headers live under
+    /opt/conda (override with PEPPER_AMD_HDF5_PREFIX)."""
+    src = os.path.join(CSRC, "hdf5io.cpp")
+    hdr = os.path.join(CSRC, "..", "..", "include", "pepper_amd_io.h")
+    if not force and os.path.exists(IO_LIB) and os.path.getmtime(IO_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return IO_LIB
+    inc, lib = os.path.join(HDF5_PREFIX, "include"), os.path.join(HDF5_PREFIX, "lib")
+    if not os.path.exists(os.path.join(inc, "hdf5.h")):
+        raise RuntimeError(f"hdf5.h not found under {inc}: set PEPPER_AMD_HDF5_PREFIX")
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", IO_LIB + ".tmp", src, f"-I{inc}", f"-L{lib}",
+           "-lhdf5", f"-Wl,-rpath,{lib}"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(IO_LIB + ".tmp", IO_LIB)
+    return IO_LIB
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -42,3 +67,4 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_io(force=True, verbose=True))

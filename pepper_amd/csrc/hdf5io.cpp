@@ -1,0 +1,296 @@
+// Minimal HDF5 reader/writer behind include/pepper_amd_io.h (libhdf5 1.10 C API).
+// Host-only C++ (g++), linked against /opt/conda/lib/libhdf5.so.103.
+#include "../../include/pepper_amd_io.h"
+
+#include <hdf5.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg) {
+    g_err = msg;
+    return -1;
+}
+
+hid_t native_type(int code) {
+    switch (code) {
+        case PA_H5_I8: return H5T_NATIVE_INT8;
+        case PA_H5_U8: return H5T_NATIVE_UINT8;
+        case PA_H5_I16: return H5T_NATIVE_INT16;
+        case PA_H5_I32: return H5T_NATIVE_INT32;
+        case PA_H5_I64: return H5T_NATIVE_INT64;
+        case PA_H5_F32: return H5T_NATIVE_FLOAT;
+        case PA_H5_F64: return H5T_NATIVE_DOUBLE;
+        case PA_H5_U16: return H5T_NATIVE_UINT16;
+        case PA_H5_U32: return H5T_NATIVE_UINT32;
+        case PA_H5_U64: return H5T_NATIVE_UINT64;
+        default: return -1;
+    }
+}
+
+int64_t type_bytes(int code) {
+    switch (code) {
+        case PA_H5_I8: case PA_H5_U8: return 1;
+        case PA_H5_I16: case PA_H5_U16: return 2;
+        case PA_H5_I32: case PA_H5_U32: case PA_H5_F32: return 4;
+        default: return 8;
+    }
+}
+
+struct Quiet {  // silence HDF5's automatic error stack printing for probing calls
+    H5E_auto2_t fn;
+    void* data;
+    Quiet() {
+        H5Eget_auto2(H5E_DEFAULT, &fn, &data);
+        H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);
+    }
+    ~Quiet() { H5Eset_auto2(H5E_DEFAULT, fn, data); }
+};
+
+hid_t make_space(int rank, const int64_t* dims) {
+    if (rank == 0) return H5Screate(H5S_SCALAR);
+    hsize_t d[8];
+    for (int i = 0; i < rank; ++i) d[i] = (hsize_t)dims[i];
+    return H5Screate_simple(rank, d, nullptr);
+}
+
+}  // namespace
+
+struct pa_h5 {
+    hid_t file = -1;
+    hid_t lcpl = -1;  // create intermediate groups, as h5py's file[path] = data does
+};
+
+extern "C" {
+
+const char* pa_h5_last_error(void) { return g_err.c_str(); }
+
+int pa_h5_open(const char* path, int32_t mode, pa_h5** out) {
+    if (!path || !out) return fail("null argument");
+    Quiet q;
+    hid_t f = -1;
+    if (mode == 0) f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+    else if (mode == 1) f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+    else if (mode == 2) f = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
+    else return fail("bad mode");
+    if (f < 0) return fail(std::string("cannot open HDF5 file '") + path + "'");
+    auto* h = new pa_h5();
+    h->file = f;
+    h->lcpl = H5Pcreate(H5P_LINK_CREATE);
+    H5Pset_create_intermediate_group(h->lcpl, 1);
+    *out = h;
+    return 0;
+}
+
+int pa_h5_close(pa_h5* f) {
+    if (!f) return 0;
+    if (f->lcpl >= 0) H5Pclose(f->lcpl);
+    int rc = 0;
+    if (f->file >= 0 && H5Fclose(f->file) < 0) rc = fail("H5Fclose failed");
+    delete f;
+    return rc;
+}
+
+int pa_h5_flush(pa_h5* f) {
+    if (!f) return fail("null file");
+    return H5Fflush(f->file, H5F_SCOPE_GLOBAL) < 0 ? fail("H5Fflush failed") : 0;
+}
+
+int pa_h5_exists(pa_h5* f, const char* path) {
+    if (!f || !path) return fail("null argument");
+    Quiet q;
+    // H5Lexists needs every intermediate link to exist: walk the components
+    std::string p(path), cur;
+    size_t i = 0;
+    while (i < p.size()) {
+        size_t j = p.find('/', i);
+        if (j == std::string::npos) j = p.size();
+        if (j > i) {
+            cur += (cur.empty() ? "" : "/") + p.substr(i, j - i);
+            htri_t e = H5Lexists(f->file, cur.c_str(), H5P_DEFAULT);
+            if (e < 0) return fail("H5Lexists failed");
+            if (e == 0) return 0;
+        }
+        i = j + 1;
+    }
+    return 1;
+}
+
+static herr_t list_cb(hid_t, const char* name, const H5L_info_t*, void* op) {
+    static_cast<std::vector<std::string>*>(op)->push_back(name);
+    return 0;
+}
+
+int pa_h5_list(pa_h5* f, const char* group, char* buf, int64_t cap, int64_t* needed, int64_t* count) {
+    if (!f || !group || !needed) return fail("null argument");
+    Quiet q;
+    hid_t g = H5Gopen2(f->file, group, H5P_DEFAULT);
+    if (g < 0) return fail(std::string("no such group '") + group + "'");
+    std::vector<std::string> names;
+    hsize_t idx = 0;
+    herr_t rc = H5Literate(g, H5_INDEX_NAME, H5_ITER_INC, &idx, list_cb, &names);
+    H5Gclose(g);
+    if (rc < 0) return fail("H5Literate failed");
+    int64_t total = 0;
+    for (auto& n : names) total += (int64_t)n.size() + 1;
+    *needed = total;
+    if (count) *count = (int64_t)names.size();
+    if (buf && cap >= total) {
+        char* p = buf;
+        for (auto& n : names) {
+            std::memcpy(p, n.c_str(), n.size() + 1);
+            p += n.size() + 1;
+        }
+    }
+    return 0;
+}
+
+int pa_h5_info(pa_h5* f, const char* path, int32_t* rank, int64_t* dims, int32_t* cls, int32_t* elem_size,
+               int32_t* is_signed) {
+    if (!f || !path) return fail("null argument");
+    Quiet q;
+    hid_t d = H5Dopen2(f->file, path, H5P_DEFAULT);
+    if (d < 0) return fail(std::string("no such dataset '") + path + "'");
+    hid_t sp = H5Dget_space(d), ty = H5Dget_type(d);
+    const int r = H5Sget_simple_extent_ndims(sp);
+    int rc = 0;
+    if (r < 0 || r > 8) rc = fail("unsupported rank");
+    else {
+        hsize_t hd[8] = {0};
+        if (r > 0) H5Sget_simple_extent_dims(sp, hd, nullptr);
+        if (rank) *rank = r;
+        if (dims) for (int i = 0; i < r; ++i) dims[i] = (int64_t)hd[i];
+        const H5T_class_t c = H5Tget_class(ty);
+        int32_t k = PA_H5_CLASS_OTHER, sgn = 0;
+        if (c == H5T_INTEGER) { k = PA_H5_CLASS_INT; sgn = H5Tget_sign(ty) == H5T_SGN_2; }
+        else if (c == H5T_FLOAT) { k = PA_H5_CLASS_FLOAT; sgn = 1; }
+        else if (c == H5T_STRING) k = H5Tis_variable_str(ty) > 0 ? PA_H5_CLASS_VLEN_STRING : PA_H5_CLASS_FIXED_STRING;
+        if (cls) *cls = k;
+        if (is_signed) *is_signed = sgn;
+        if (elem_size) *elem_size = k == PA_H5_CLASS_VLEN_STRING ? 0 : (int32_t)H5Tget_size(ty);
+    }
+    H5Tclose(ty);
+    H5Sclose(sp);
+    H5Dclose(d);
+    return rc;
+}
+
+int pa_h5_read(pa_h5* f, const char* path, int32_t type_code, void* out, int64_t nbytes) {
+    if (!f || !path || (!out && nbytes > 0)) return fail("null argument");
+    const hid_t mt = native_type(type_code);
+    if (mt < 0) return fail("bad type code");
+    Quiet q;
+    hid_t d = H5Dopen2(f->file, path, H5P_DEFAULT);
+    if (d < 0) return fail(std::string("no such dataset '") + path + "'");
+    hid_t sp = H5Dget_space(d);
+    const hssize_t n = H5Sget_simple_extent_npoints(sp);
+    int rc = 0;
+    if (n < 0 || (int64_t)n * type_bytes(type_code) != nbytes)
+        rc = fail(std::string("size mismatch reading '") + path + "'");
+    else if (n > 0 && H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, out) < 0)
+        rc = fail(std::string("H5Dread failed for '") + path + "'");
+    H5Sclose(sp);
+    H5Dclose(d);
+    return rc;
+}
+
+static int write_dataset(pa_h5* f, const char* path, hid_t file_type, hid_t mem_type, int32_t rank,
+                         const int64_t* dims, const void* data) {
+    if (rank < 0 || rank > 8) return fail("unsupported rank");
+    Quiet q;
+    hid_t sp = make_space(rank, dims);
+    if (sp < 0) return fail("cannot create dataspace");
+    hid_t d = H5Dcreate2(f->file, path, file_type, sp, f->lcpl, H5P_DEFAULT, H5P_DEFAULT);
+    int rc = 0;
+    if (d < 0) rc = fail(std::string("cannot create dataset '") + path + "' (already exists?)");
+    else {
+        const hssize_t n = H5Sget_simple_extent_npoints(sp);
+        if (n > 0 && data && H5Dwrite(d, mem_type, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0)
+            rc = fail(std::string("H5Dwrite failed for '") + path + "'");
+        H5Dclose(d);
+    }
+    H5Sclose(sp);
+    return rc;
+}
+
+int pa_h5_write(pa_h5* f, const char* path, int32_t type_code, int32_t rank, const int64_t* dims,
+                const void* data) {
+    if (!f || !path) return fail("null argument");
+    const hid_t t = native_type(type_code);
+    if (t < 0) return fail("bad type code");
+    return write_dataset(f, path, t, t, rank, dims, data);
+}
+
+int pa_h5_read_strings(pa_h5* f, const char* path, char* buf, int64_t cap, int64_t* needed) {
+    if (!f || !path || !needed) return fail("null argument");
+    Quiet q;
+    hid_t d = H5Dopen2(f->file, path, H5P_DEFAULT);
+    if (d < 0) return fail(std::string("no such dataset '") + path + "'");
+    hid_t sp = H5Dget_space(d), ty = H5Dget_type(d);
+    const hssize_t n = H5Sget_simple_extent_npoints(sp);
+    int rc = 0;
+    std::string out;
+    if (H5Tget_class(ty) != H5T_STRING || n < 0) rc = fail(std::string("'") + path + "' is not a string dataset");
+    else if (H5Tis_variable_str(ty) > 0) {
+        std::vector<char*> ptrs((size_t)n, nullptr);
+        hid_t mt = H5Tcopy(H5T_C_S1);
+        H5Tset_size(mt, H5T_VARIABLE);
+        H5Tset_cset(mt, H5Tget_cset(ty));
+        if (n > 0 && H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, ptrs.data()) < 0) rc = fail("H5Dread (vlen) failed");
+        else {
+            for (hssize_t i = 0; i < n; ++i) {
+                if (ptrs[i]) out.append(ptrs[i]);
+                out.push_back('\0');
+            }
+            if (n > 0) H5Dvlen_reclaim(mt, sp, H5P_DEFAULT, ptrs.data());
+        }
+        H5Tclose(mt);
+    } else {
+        const size_t w = H5Tget_size(ty);
+        std::vector<char> raw((size_t)n * w + 1, 0);
+        if (n > 0 && H5Dread(d, ty, H5S_ALL, H5S_ALL, H5P_DEFAULT, raw.data()) < 0) rc = fail("H5Dread (fixed) failed");
+        else
+            for (hssize_t i = 0; i < n; ++i) {
+                const char* s = raw.data() + (size_t)i * w;
+                out.append(s, strnlen(s, w));
+                out.push_back('\0');
+            }
+    }
+    if (rc == 0) {
+        *needed = (int64_t)out.size();
+        if (buf && cap >= (int64_t)out.size()) std::memcpy(buf, out.data(), out.size());
+    }
+    H5Tclose(ty);
+    H5Sclose(sp);
+    H5Dclose(d);
+    return rc;
+}
+
+int pa_h5_write_fixed_strings(pa_h5* f, const char* path, int32_t rank, const int64_t* dims, int32_t width,
+                              const char* data) {
+    if (!f || !path || width <= 0) return fail("bad argument");
+    hid_t t = H5Tcopy(H5T_C_S1);
+    H5Tset_size(t, (size_t)width);
+    H5Tset_strpad(t, H5T_STR_NULLPAD);   // numpy 'S' -> h5py: fixed width, null padded
+    const int rc = write_dataset(f, path, t, t, rank, dims, data);
+    H5Tclose(t);
+    return rc;
+}
+
+int pa_h5_write_vlen_strings(pa_h5* f, const char* path, int32_t rank, const int64_t* dims,
+                             const char* const* strings) {
+    if (!f || !path) return fail("bad argument");
+    hid_t t = H5Tcopy(H5T_C_S1);
+    H5Tset_size(t, H5T_VARIABLE);
+    H5Tset_cset(t, H5T_CSET_UTF8);       // h5py special_dtype(vlen=str)
+    const int rc = write_dataset(f, path, t, t, rank, dims, strings);
+    H5Tclose(t);
+    return rc;
+}
+
+}  // extern "C"

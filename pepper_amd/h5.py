@@ -1,0 +1,163 @@
+"""h5py-shaped facade over libpepper_amd_io.so (include/pepper_amd_io.h).
+
+Only what PEPPER's inference path uses: open, list a group, whole-dataset reads, and
+`file[path] = ndarray`-style writes (numeric, numpy 'S' fixed strings, vlen str), with the byte
+layout h5py produces for the reference's DataStore classes.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpepper_amd_io.so")
+
+_CODES = {np.dtype(np.int8): 0, np.dtype(np.uint8): 1, np.dtype(np.int16): 2, np.dtype(np.int32): 3,
+          np.dtype(np.int64): 4, np.dtype(np.float32): 5, np.dtype(np.float64): 6, np.dtype(np.uint16): 7,
+          np.dtype(np.uint32): 8, np.dtype(np.uint64): 9}
+CLASS_INT, CLASS_FLOAT, CLASS_FIXED, CLASS_VLEN = 0, 1, 2, 3
+
+c_void_p, c_int32, c_int64, c_char_p = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_char_p
+P64 = ctypes.POINTER(c_int64)
+P32 = ctypes.POINTER(c_int32)
+
+SYMBOLS = [
+    ("pa_h5_last_error", c_char_p, []),
+    ("pa_h5_open", ctypes.c_int, [c_char_p, c_int32, ctypes.POINTER(c_void_p)]),
+    ("pa_h5_close", ctypes.c_int, [c_void_p]),
+    ("pa_h5_flush", ctypes.c_int, [c_void_p]),
+    ("pa_h5_exists", ctypes.c_int, [c_void_p, c_char_p]),
+    ("pa_h5_list", ctypes.c_int, [c_void_p, c_char_p, c_void_p, c_int64, P64, P64]),
+    ("pa_h5_info", ctypes.c_int, [c_void_p, c_char_p, P32, P64, P32, P32, P32]),
+    ("pa_h5_read", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_int64]),
+    ("pa_h5_write", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, P64, c_void_p]),
+    ("pa_h5_read_strings", ctypes.c_int, [c_void_p, c_char_p, c_void_p, c_int64, P64]),
+    ("pa_h5_write_fixed_strings", ctypes.c_int, [c_void_p, c_char_p, c_int32, P64, c_int32, c_void_p]),
+    ("pa_h5_write_vlen_strings", ctypes.c_int, [c_void_p, c_char_p, c_int32, P64, ctypes.POINTER(c_char_p)]),
+]
+
+_lib = None
+
+
+class H5Error(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            from pepper_amd import build
+            build.build_io()
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = restype, argtypes
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise H5Error(load().pa_h5_last_error().decode())
+    return rc
+
+
+class File(object):
+    """with File(path, 'r'|'w'|'r+') as f:  f.keys(group), f[path] (read), f[path] = array (create)."""
+
+    def __init__(self, path, mode="r"):
+        self._lib = load()
+        self._h = c_void_p()
+        code = {"r": 0, "w": 1, "r+": 2, "a": 2 if os.path.exists(path) else 1}[mode]
+        _check(self._lib.pa_h5_open(os.fsencode(path), code, ctypes.byref(self._h)))
+        self.filename, self.mode = path, mode
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, None
+            _check(self._lib.pa_h5_close(h))
+
+    def flush(self):
+        _check(self._lib.pa_h5_flush(self._h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __contains__(self, path):
+        return _check(self._lib.pa_h5_exists(self._h, path.encode())) == 1
+
+    def keys(self, group="/"):
+        needed, count = c_int64(), c_int64()
+        _check(self._lib.pa_h5_list(self._h, group.encode(), None, 0, ctypes.byref(needed), ctypes.byref(count)))
+        if count.value == 0:
+            return []
+        buf = ctypes.create_string_buffer(needed.value)
+        _check(self._lib.pa_h5_list(self._h, group.encode(), buf, needed.value, ctypes.byref(needed), ctypes.byref(count)))
+        return [s.decode() for s in buf.raw[:needed.value].split(b"\0")[:count.value]]
+
+    def info(self, path):
+        rank, cls, size, sgn = c_int32(), c_int32(), c_int32(), c_int32()
+        dims = (c_int64 * 8)()
+        _check(self._lib.pa_h5_info(self._h, path.encode(), ctypes.byref(rank), dims, ctypes.byref(cls),
+                                    ctypes.byref(size), ctypes.byref(sgn)))
+        return tuple(dims[:rank.value]), cls.value, size.value, bool(sgn.value)
+
+    def __getitem__(self, path):
+        """Whole-dataset read (the reference only ever does dataset[()])."""
+        shape, cls, size, sgn = self.info(path)
+        if cls in (CLASS_FIXED, CLASS_VLEN):
+            needed = c_int64()
+            _check(self._lib.pa_h5_read_strings(self._h, path.encode(), None, 0, ctypes.byref(needed)))
+            buf = ctypes.create_string_buffer(max(1, needed.value))
+            _check(self._lib.pa_h5_read_strings(self._h, path.encode(), buf, needed.value, ctypes.byref(needed)))
+            n = int(np.prod(shape)) if shape else 1
+            parts = buf.raw[:needed.value].split(b"\0")[:n]
+            if cls == CLASS_FIXED:
+                arr = np.array(parts, dtype=f"S{max(1, size)}")
+            else:
+                arr = np.empty(n, dtype=object)
+                arr[:] = [p.decode("utf-8") for p in parts]   # h5py 2.x returns str for vlen strings
+            return arr.reshape(shape) if shape else arr[0]
+        if cls == CLASS_FLOAT:
+            dt = np.dtype(np.float32 if size == 4 else np.float64)
+        elif cls == CLASS_INT:
+            dt = np.dtype({1: "i1", 2: "i2", 4: "i4", 8: "i8"}[size] if sgn else {1: "u1", 2: "u2", 4: "u4", 8: "u8"}[size])
+        else:
+            raise H5Error(f"unsupported dataset class for '{path}'")
+        out = np.empty(shape, dtype=dt)
+        _check(self._lib.pa_h5_read(self._h, path.encode(), _CODES[dt], out.ctypes.data, out.nbytes))
+        return out if shape else out[()]
+
+    def __setitem__(self, path, value):
+        """Create a contiguous dataset like h5py's file[path] = value."""
+        if isinstance(value, str):
+            value = np.array(value, dtype=object)
+        if isinstance(value, bytes):
+            value = np.array(value, dtype="S")
+        arr = np.asarray(value)
+        shape = arr.shape                     # np.ascontiguousarray would promote 0-d to 1-d
+        arr = np.ascontiguousarray(arr).reshape(shape)
+        dims = (c_int64 * max(1, arr.ndim))(*arr.shape)
+        if arr.dtype.kind == "S":
+            _check(self._lib.pa_h5_write_fixed_strings(self._h, path.encode(), arr.ndim, dims, arr.dtype.itemsize,
+                                                       arr.ctypes.data))
+        elif arr.dtype.kind in ("O", "U"):
+            flat = [(s if isinstance(s, bytes) else str(s).encode("utf-8")) for s in arr.ravel().tolist()]
+            ptrs = (c_char_p * max(1, len(flat)))(*flat)
+            _check(self._lib.pa_h5_write_vlen_strings(self._h, path.encode(), arr.ndim, dims, ptrs))
+        else:
+            if arr.dtype == np.bool_:
+                arr = arr.astype(np.uint8).reshape(shape)
+            if arr.dtype not in _CODES:
+                raise H5Error(f"unsupported dtype {arr.dtype} for '{path}'")
+            _check(self._lib.pa_h5_write(self._h, path.encode(), _CODES[arr.dtype], arr.ndim, dims, arr.ctypes.data))

@@ -1,0 +1,56 @@
+"""Multi-GPU plumbing of the hot path: region/file sharding needs no data-path collective; the
+only exchange is one broadcast of the packed weight blob from the rank that read the checkpoint
+(SURVEY.md 8(e)).  Backend-agnostic on purpose: "nccl" (= RCCL over xGMI) on the GPU box, "gloo"
+in the CPU tests.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def load_checkpoint_state(model_path):
+    """Reference checkpoint schema (train_distributed.py:36-42), 'module.' prefixes stripped
+    (ModelHander.py:35-39).  -> (OrderedDict name -> float32 tensor, meta dict)."""
+    ckpt = torch.load(model_path, map_location='cpu')
+    state = OrderedDict()
+    for k, v in ckpt['model_state_dict'].items():
+        state[k[7:] if k[0:7] == 'module.' else k] = v.detach().to(torch.float32).contiguous()
+    meta = {"hidden_size": int(ckpt['hidden_size']), "gru_layers": int(ckpt['gru_layers']),
+            "epochs": int(ckpt.get('epochs', 0))}
+    return state, meta
+
+
+def broadcast_checkpoint(model_path, src=0, device=None, group=None):
+    """Rank `src` reads the checkpoint; every rank returns (state_dict, meta).
+
+    Two messages: a small object broadcast with the tensor names/shapes + meta, then ONE flat
+    float32 blob (variant 47.4 MB, polish 1.62 MB) -- on RCCL a single xGMI broadcast.
+    """
+    rank = dist.get_rank(group)
+    if rank == src:
+        state, meta = load_checkpoint_state(model_path)
+        header = [([(k, tuple(v.shape)) for k, v in state.items()], meta)]
+    else:
+        state, header = None, [None]
+    dist.broadcast_object_list(header, src=src, group=group)
+    layout, meta = header[0]
+    total = int(sum(int(np.prod(s)) if len(s) else 1 for _, s in layout))
+    dev = device if device is not None else torch.device("cpu")
+    blob = torch.empty(total, dtype=torch.float32, device=dev)
+    if rank == src:
+        blob.copy_(torch.cat([v.reshape(-1) for v in state.values()]))
+    dist.broadcast(blob, src=src, group=group)
+    host = blob.cpu()
+    out, off = OrderedDict(), 0
+    for name, shape in layout:
+        n = int(np.prod(shape)) if len(shape) else 1
+        out[name] = host[off:off + n].reshape(shape).clone()
+        off += n
+    return out, meta
+
+
+def shard_round_robin(items, world, rank):
+    """items[i] goes to rank i % world (RunInference.py:104-110, call_consensus.py:93-97)."""
+    return [x for i, x in enumerate(items) if i % world == rank]

@@ -1,0 +1,39 @@
+"""Polish images HDF5 store.  Mirrors /root/reference/pepper/modules/python/DataStore.py:6-67:
+summaries/<name>/{image u8 [1000,10], label u8 [1000], position, index, contig, region_start,
+region_end, chunk_id} (position = list of (pos, idx) pairs -> int64 [1000,2] through h5py)."""
+import numpy as np
+
+from pepper_amd import h5
+
+
+class DataStore(object):
+    _summary_path_ = 'summaries'
+
+    def __init__(self, filename, mode='r'):
+        self.filename = filename
+        self.mode = mode
+        self.file_handler = None
+        self._written = set()
+
+    def __enter__(self):
+        self.file_handler = h5.File(self.filename, self.mode)
+        return self
+
+    def __exit__(self, *args):
+        self.file_handler.close()
+
+    def write_summary(self, region, image, label, position, index, chunk_id, summary_name):
+        contig_name, region_start, region_end = region
+        if summary_name in self._written:
+            return
+        self._written.add(summary_name)
+        base = '{}/{}/'.format(self._summary_path_, summary_name)
+        fh = self.file_handler
+        fh[base + 'image'] = np.asarray(image, dtype=np.float64).astype(np.uint8)
+        fh[base + 'label'] = np.asarray(label, dtype=np.uint8)
+        fh[base + 'position'] = np.asarray(position)
+        fh[base + 'index'] = np.asarray(index)
+        fh[base + 'contig'] = contig_name
+        fh[base + 'region_start'] = region_start
+        fh[base + 'region_end'] = region_end
+        fh[base + 'chunk_id'] = chunk_id

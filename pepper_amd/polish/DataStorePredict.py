@@ -1,0 +1,50 @@
+"""Polish predictions HDF5 store.  Mirrors /root/reference/pepper/modules/python/DataStorePredict.py:6-76:
+predictions/<contig>/<contig>-<start>-<end>/{contig_start, contig_end} and
+predictions/<contig>/<contig>-<start>-<end>/<chunk_id>/{position, index, bases u8, phred_score u8}."""
+import numpy as np
+
+from pepper_amd import h5
+
+
+def _item(v):
+    return v.item() if hasattr(v, "item") else v
+
+
+class DataStore(object):
+    _prediction_path_ = 'predictions'
+
+    def __init__(self, filename, mode='r'):
+        self.filename = filename
+        self.mode = mode
+        self.file_handler = h5.File(self.filename, self.mode)
+        self._predictions = set()
+        self._contigs = set()
+
+    def close(self):
+        self.file_handler.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args):
+        self.close()
+
+    def write_prediction(self, contig, contig_start, contig_end, chunk_id, position, index, predicted_bases,
+                         phred_score):
+        if isinstance(contig, bytes):
+            contig = contig.decode('UTF-8')
+        chunk_name_prefix = str(contig) + "-" + str(_item(contig_start)) + "-" + str(_item(contig_end))
+        chunk_name_suffix = str(_item(chunk_id))
+        name = contig + chunk_name_prefix + chunk_name_suffix
+        fh = self.file_handler
+        if chunk_name_prefix not in self._contigs:
+            self._contigs.add(chunk_name_prefix)
+            fh['{}/{}/{}/{}'.format(self._prediction_path_, contig, chunk_name_prefix, 'contig_start')] = _item(contig_start)
+            fh['{}/{}/{}/{}'.format(self._prediction_path_, contig, chunk_name_prefix, 'contig_end')] = _item(contig_end)
+        if name not in self._predictions:
+            self._predictions.add(name)
+            base = '{}/{}/{}/{}/'.format(self._prediction_path_, contig, chunk_name_prefix, chunk_name_suffix)
+            fh[base + 'position'] = np.asarray(position)
+            fh[base + 'index'] = np.asarray(index)
+            fh[base + 'bases'] = np.asarray(predicted_bases).astype(np.uint8)
+            fh[base + 'phred_score'] = np.asarray(phred_score).astype(np.uint8)

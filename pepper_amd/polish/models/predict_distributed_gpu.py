@@ -1,0 +1,86 @@
+"""Polish GPU prediction driver with the reference's entry points.
+
+Mirrors /root/reference/pepper/modules/python/models/predict_distributed_gpu.py:24-166:
+  predict(input_filepath, file_chunks, output_filepath, model_path, batch_size, num_workers, rank, device_id)
+  predict_distributed_gpu(filepath, file_chunks, output_filepath, model_path, batch_size, device_ids, num_workers)
+One process per GPU over file shards, output <output_filepath>pepper_prediction_<rank>.hdf.  The
+whole window loop (19 windows, hidden carry, softmax overlap-add, max, phred) runs on the device;
+labels/phred follow the reference's CPU path -- the reference's GPU path overwrites base_values
+with base_labels before the phred formula (predict_distributed_gpu.py:103), which is not reproduced.
+"""
+import os
+import sys
+from datetime import datetime
+
+import torch
+
+from pepper_amd.polish.DataStorePredict import DataStore
+from pepper_amd.polish.Options import ImageSizeOptions
+from pepper_amd.polish.models.ModelHander import ModelHandler
+from pepper_amd.polish.models.dataloader_predict import SequenceDataset
+
+
+def _log(msg):
+    sys.stderr.write("[" + str(datetime.now().strftime('%m-%d-%Y %H:%M:%S')) + "] " + msg + "\n")
+    sys.stderr.flush()
+
+
+def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size, num_workers, rank, device_id,
+            model=None):
+    torch.cuda.set_device(device_id)
+    if model is None:
+        model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model_for_training(
+            model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS, image_features=ImageSizeOptions.IMAGE_HEIGHT,
+            seq_len=ImageSizeOptions.SEQ_LENGTH, num_classes=ImageSizeOptions.TOTAL_LABELS)
+    model.eval()
+    output_filename = output_filepath + "pepper_prediction_" + str(rank) + ".hdf"
+    prediction_data_file = DataStore(output_filename, mode='w')
+    input_data = SequenceDataset(input_filepath, file_chunks)
+    done = 0
+    try:
+        for contig, contig_start, contig_end, chunk_id, images, position, index in input_data.batches(batch_size):
+            labels, phred = model.predict_chunks(torch.from_numpy(images))
+            labels, phred = labels.numpy(), phred.numpy()
+            for i in range(len(contig)):
+                prediction_data_file.write_prediction(contig[i], contig_start[i], contig_end[i], chunk_id[i],
+                                                      position[i], index[i], labels[i], phred[i])
+            done += 1
+            if rank == 0:
+                _log("INFO: BATCHES PROCESSED " + str(done) + ".")
+    finally:
+        input_data.close()
+        prediction_data_file.close()
+    return rank
+
+
+def _setup(rank, device_ids, args, all_input_files, port):
+    import torch.distributed as dist
+    from pepper_amd.parallel import broadcast_checkpoint
+    filepath, output_filepath, model_path, batch_size, num_workers = args
+    device = device_ids[rank]
+    torch.cuda.set_device(device)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group("nccl", rank=rank, world_size=len(device_ids), device_id=torch.device("cuda", device))
+    try:
+        state, meta = broadcast_checkpoint(model_path if rank == 0 else None, src=0,
+                                           device=torch.device("cuda", device))
+        model = ModelHandler.get_new_gru_model(ImageSizeOptions.IMAGE_CHANNELS, ImageSizeOptions.IMAGE_HEIGHT,
+                                               meta["gru_layers"], meta["hidden_size"], ImageSizeOptions.TOTAL_LABELS)
+        model.load_state_dict(state)
+        predict(filepath, all_input_files[rank] if rank < len(all_input_files) else [], output_filepath, model_path,
+                batch_size, num_workers, rank, device, model=model)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def predict_distributed_gpu(filepath, file_chunks, output_filepath, model_path, batch_size, device_ids, num_workers):
+    """One model per GPU over the given file chunks (reference signature)."""
+    if len(device_ids) == 1:
+        return predict(filepath, file_chunks[0] if file_chunks else [], output_filepath, model_path, batch_size,
+                       num_workers, 0, device_ids[0])
+    import torch.multiprocessing as mp
+    port = int(os.environ.get("PEPPER_AMD_MASTER_PORT", "29542"))
+    args = (filepath, output_filepath, model_path, batch_size, num_workers)
+    mp.spawn(_setup, args=(device_ids, args, file_chunks, port), nprocs=len(device_ids), join=True)

@@ -1,0 +1,44 @@
+"""Predictions HDF5 store (the output layout downstream candidate finding reads).
+
+Mirrors /root/reference/pepper_variant/modules/python/DataStorePredict.py:6-67 (class DataStore,
+write_prediction): predictions/batch_<n>/{contigs 'S', positions i32, depths u8, candidates
+vlen-str, candidate_frequency u8, base_prediction float64 [B,3]} -- `np.float` in the reference
+is float64; the type_prediction dataset is commented out there and is not written here either.
+"""
+import numpy as np
+
+from pepper_amd import h5
+
+
+class DataStore(object):
+    _prediction_path_ = 'predictions'
+
+    def __init__(self, filename, mode='r'):
+        self.filename = filename
+        self.mode = mode
+        self.file_handler = h5.File(self.filename, self.mode)
+        self._written = set()
+
+    def close(self):
+        self.file_handler.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args):
+        self.close()
+
+    def write_prediction(self, batch_no, contigs, positions, depths, candidates, candidate_frequencies,
+                         base_predictions):
+        name = "batch_" + str(batch_no)
+        if name in self._written:
+            return
+        self._written.add(name)
+        base = '{}/{}/'.format(self._prediction_path_, name)
+        fh = self.file_handler
+        fh[base + "contigs"] = np.array(contigs, dtype='S')
+        fh[base + "positions"] = np.asarray(positions, dtype=np.int32)
+        fh[base + "depths"] = np.asarray(depths, dtype=np.uint8)
+        fh[base + "candidates"] = np.asarray(candidates, dtype=object)
+        fh[base + "candidate_frequency"] = np.asarray(candidate_frequencies, dtype=np.uint8)
+        fh[base + "base_prediction"] = np.asarray(base_predictions, dtype=np.float64)

@@ -1,0 +1,81 @@
+"""GPU prediction driver with the reference's entry points.
+
+Mirrors /root/reference/pepper_variant/modules/python/models/predict_distributed_gpu.py:19-87:
+  predict(options, input_filepath, input_files, output_filepath, threads)
+  predict_distributed_gpu(options, filepath, input_files, output_filepath, threads_per_caller)
+Same inputs (a checkpoint path in options.model_path, images HDF5 files), same output file
+(<output_filepath>pepper_prediction.hdf with predictions/batch_<n> groups of options.batch_size
+candidates, batch numbering continuing across files).  Differences, all deliberate:
+  * the forward runs in libpepper_amd.so on one MI355X per process (no DataParallel, which
+    re-replicates 47 MB of weights every forward: SURVEY.md 8(a) A8); a whole file's windows go
+    to the device as packed int8 in large chunks while the HDF5 groups keep the reference's
+    batch_size granularity;
+  * multi-GPU = one process per GPU over file shards (RunInference.distributed_gpu); rank r > 0
+    or world > 1 writes pepper_prediction_<r>.hdf, which the downstream reader already globs
+    (FindCandidates.py:151-166);
+  * failures raise instead of being logged and swallowed.
+"""
+import sys
+from datetime import datetime
+
+import torch
+
+from pepper_amd.variant.DataStorePredict import DataStore
+from pepper_amd.variant.Options import ImageSizeOptions
+from pepper_amd.variant.models.ModelHander import ModelHandler
+from pepper_amd.variant.models.dataloader_predict import SequenceDataset
+
+
+def _log(msg):
+    sys.stderr.write("[" + str(datetime.now().strftime('%m-%d-%Y %H:%M:%S')) + "] " + msg + "\n")
+    sys.stderr.flush()
+
+
+def predict(options, input_filepath, input_files, output_filepath, threads, rank=None, device=None,
+            model=None):
+    if getattr(options, "use_hp_info", False):
+        raise NotImplementedError("--use_hp_info inference is non-functional in the reference at this "
+                                  "commit (SURVEY.md 2.1 V13) and is not provided")
+    if device is None:
+        device = torch.cuda.current_device()
+    torch.cuda.set_device(device)
+    if model is None:
+        model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model_for_training(
+            options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT,
+            num_classes=ImageSizeOptions.TOTAL_LABELS, num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)
+    model.eval()
+    suffix = "" if rank is None else "_" + str(rank)
+    output_filename = output_filepath + "pepper_prediction" + suffix + ".hdf"
+    prediction_data_file = DataStore(output_filename, mode='w')
+    torch.set_num_threads(max(1, int(threads)))
+    _log("INFO: TOTAL FILES: " + str(len(input_files)) + ".")
+
+    batch_completed = 0
+    total_windows = 0
+    try:
+        for file_id, input_file in enumerate(input_files):
+            input_data = SequenceDataset(input_filepath, input_file)
+            n = len(input_data)
+            if n:
+                # one packed int8 H2D copy per file, one device pass; float32 probs come back
+                images = torch.from_numpy(input_data.all_images)
+                probs = model(images, False).numpy()
+                offset = 0
+                for contigs, positions, depths, candidates, freqs, _ in input_data.batches(options.batch_size):
+                    b = len(positions)
+                    prediction_data_file.write_prediction(
+                        batch_completed, [c.decode('UTF-8') for c in contigs], positions, depths, candidates,
+                        freqs, probs[offset:offset + b])
+                    offset += b
+                    batch_completed += 1
+            total_windows += n
+            _log("INFO: FILES COMPLETED: " + str(file_id + 1) + "/" + str(len(input_files)) + ".")
+    finally:
+        prediction_data_file.close()
+    return batch_completed, total_windows
+
+
+def predict_distributed_gpu(options, filepath, input_files, output_filepath, threads_per_caller, rank=None,
+                            device=None):
+    """Create the prediction table of an image set using a trained model (reference signature)."""
+    return predict(options, filepath, input_files, output_filepath, threads_per_caller, rank=rank, device=device)

@@ -1,0 +1,60 @@
+"""N>1 path on CPU: world_size-2 gloo process group exercising the only collective of the hot path
+(weight broadcast) and the reference's file sharding rule."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pepper_amd import synthetic
+from pepper_amd.parallel import broadcast_checkpoint, shard_round_robin
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ckpt_path, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        state, meta = broadcast_checkpoint(ckpt_path if rank == 0 else None, src=0)
+        files = [f"img_{i}.hdf5" for i in range(7)]
+        mine = shard_round_robin(files, world, rank)
+        torch.save({"state": state, "meta": meta, "files": mine}, os.path.join(out_dir, f"r{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weight_broadcast_and_sharding_world2(tmp_path):
+    sd = synthetic.polish_state_dict(seed=3)
+    ckpt = synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128,
+                                     gru_layers=1, epochs=7, module_prefix=True)
+    path = str(tmp_path / "model.pkl")
+    torch.save(ckpt, path)
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), path, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(str(tmp_path / f"r{r}.pt"), weights_only=False) for r in range(world)]
+    for g in got:
+        assert g["meta"] == {"hidden_size": 128, "gru_layers": 1, "epochs": 7}
+        assert list(g["state"].keys()) == list(sd.keys())          # 'module.' stripped, order kept
+        for k, v in sd.items():
+            assert np.array_equal(g["state"][k].numpy(), v), k
+    assert got[0]["files"] == ["img_0.hdf5", "img_2.hdf5", "img_4.hdf5", "img_6.hdf5"]
+    assert got[1]["files"] == ["img_1.hdf5", "img_3.hdf5", "img_5.hdf5"]
+
+
+def test_shard_files_matches_reference_rule():
+    from pepper_amd.variant.RunInference import shard_files
+    files = [f"f{i}" for i in range(5)]
+    assert shard_files(files, 2) == [["f0", "f2", "f4"], ["f1", "f3"]]
+    assert shard_files(files[:1], 4) == [["f0"]]                    # empty chunks dropped
+    assert shard_files([], 4) == []

@@ -1,0 +1,138 @@
+"""HDF5 layouts: files written by pepper_amd's stores must be structurally and
+numerically identical to files written by the REFERENCE's DataStore classes (golden fixtures made
+by tests/golden/make_golden_hdf5.py), and the reader must read the reference's files."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from pepper_amd import h5
+
+
+def dump(path):
+    """{dataset path: (shape, class, elem size, signed, values)} via pepper_amd.h5."""
+    out = {}
+    with h5.File(path, "r") as f:
+        def walk(g):
+            for name in f.keys(g):
+                p = (g.rstrip("/") + "/" + name) if g != "/" else name
+                try:
+                    shape, cls, size, sgn = f.info(p)
+                except h5.H5Error:
+                    walk(p)
+                    continue
+                out[p] = (shape, cls, size, sgn, f[p])
+        walk("/")
+    return out
+
+
+def assert_same_tree(a, b):
+    assert sorted(a) == sorted(b)
+    for k in a:
+        sa, ca, za, ga, va = a[k]
+        sb, cb, zb, gb, vb = b[k]
+        assert (sa, ca, za, ga) == (sb, cb, zb, gb), k
+        assert np.array_equal(np.asarray(va), np.asarray(vb)), k
+
+
+def test_variant_images_reader_and_writer(golden_dir, tmp_path):
+    from pepper_amd.variant.DataStore import DataStore
+    from pepper_amd.variant.models.dataloader_predict import SequenceDataset
+    ref = os.path.join(golden_dir, "variant_images_ref.hdf5")
+    inp = np.load(os.path.join(golden_dir, "variant_images_inputs.npz"), allow_pickle=True)
+    names = sorted({k.split("__")[0] for k in inp.files})
+    mine = str(tmp_path / "mine.hdf5")
+    with DataStore(mine, "w") as ds:
+        for n in names:
+            g = {k.split("__")[1]: inp[k] for k in inp.files if k.startswith(n + "__")}
+            ds.write_summary(n, g["contigs"].tolist(), g["positions"].tolist(), g["depths"].tolist(),
+                             g["candidates"].tolist(), g["candidate_frequency"].tolist(), g["images"].tolist(),
+                             [0] * len(g["contigs"]), [0] * len(g["contigs"]), False)
+    assert_same_tree(dump(ref), dump(mine))
+    # int8 wrap of unclamped columns, as numpy 1.22 did it
+    d = dump(ref)
+    img = d["summaries/chr20_1000_2000/images"][4]
+    assert img.dtype == np.int8 and img[0, 16, 4] == 126 and img[0, 16, 8] == -116
+    # dataset view of the reference-written file
+    data = SequenceDataset(golden_dir, ref)
+    assert len(data) == 8
+    contig, pos, depth, cand, freq, image = data[0]
+    assert contig == "chr20" and image.shape == (33, 26) and cand[0] == "1A" and freq.shape == (1,)
+    batch = SequenceDataset.my_collate([data[i] for i in range(3)])
+    assert batch[5].shape == (3, 33, 26) and batch[5].dtype.is_floating_point
+    blocks = list(data.batches(5))
+    assert [len(b[1]) for b in blocks] == [5, 3]
+
+
+def test_variant_predictions_writer(golden_dir, tmp_path):
+    from pepper_amd.variant.DataStorePredict import DataStore
+    from pepper_amd.variant.models.dataloader_predict import SequenceDataset
+    ref = os.path.join(golden_dir, "variant_predictions_ref.hdf")
+    probs = np.load(os.path.join(golden_dir, "variant_predictions_inputs.npz"))
+    data = SequenceDataset(golden_dir, os.path.join(golden_dir, "variant_images_ref.hdf5"), )
+    mine = str(tmp_path / "pred.hdf")
+    with DataStore(mine, "w") as ds:
+        # group order in the images file = name order; batch 0 = first group (5), batch 1 = second (3)
+        off = 0
+        for b, n in enumerate((5, 3)):
+            sl = slice(off, off + n)
+            ds.write_prediction(b, [c.decode() for c in data.all_contigs[sl]], data.all_positions[sl],
+                                data.all_depths[sl], data.all_candidates[sl], data.all_candidate_frequency[sl],
+                                probs[f"probs_{b}"])
+            off += n
+    assert_same_tree(dump(ref), dump(mine))
+    assert dump(mine)["predictions/batch_0/base_prediction"][4].dtype == np.float64
+
+
+def test_polish_stores(golden_dir, tmp_path):
+    from pepper_amd.polish.DataStore import DataStore
+    from pepper_amd.polish.DataStorePredict import DataStore as DataStorePredict
+    from pepper_amd.polish.models.dataloader_predict import SequenceDataset
+    ref = os.path.join(golden_dir, "polish_images_ref.hdf")
+    inp = np.load(os.path.join(golden_dir, "polish_images_inputs.npz"))
+    mine = str(tmp_path / "img.hdf")
+    with DataStore(mine, "w") as ds:
+        for cid in range(2):
+            name = f"contig_1_1000_2000_{cid}"
+            ds.write_summary(("contig_1", 1000, 2000), inp[name + "__image"].tolist(), [0] * 1000,
+                             [tuple(p) for p in inp[name + "__position"].tolist()], list(range(1000)), cid, name)
+    assert_same_tree(dump(ref), dump(mine))
+    data = SequenceDataset(golden_dir, [ref])
+    assert len(data) == 2
+    contig, start, end, chunk_id, image, position, index = data[1]
+    assert contig == "contig_1" and (start, end, chunk_id) == (1000, 2000, 1)
+    assert image.shape == (1000, 10) and image.dtype == np.uint8 and tuple(position[950]) == (-1, -1)
+    data.close()
+
+    pref = os.path.join(golden_dir, "polish_predictions_ref.hdf")
+    pin = np.load(os.path.join(golden_dir, "polish_predictions_inputs.npz"))
+    pmine = str(tmp_path / "pred.hdf")
+    with DataStorePredict(pmine, "w") as ds:
+        for cid in range(2):
+            ds.write_prediction("contig_1", np.int64(1000), np.int64(2000), np.int64(cid),
+                                np.array([(1000 + i, 0) for i in range(1000)]), np.arange(1000),
+                                pin[f"bases_{cid}"], pin[f"phred_{cid}"])
+    assert_same_tree(dump(pref), dump(pmine))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/conda/bin/python3.9"), reason="needs the image's h5py interpreter")
+def test_h5py_sees_same_types(golden_dir, tmp_path):
+    """Independent check with real h5py: dtype strings of our files equal the reference's."""
+    from pepper_amd.variant.DataStorePredict import DataStore
+    mine = str(tmp_path / "pred.hdf")
+    with DataStore(mine, "w") as ds:
+        ds.write_prediction(0, ["chr20"] * 2, [1, 2], [3, 4], np.array([["1A"], ["2ACG"]], dtype=object),
+                            np.array([[5], [6]], np.uint8), np.zeros((2, 3), np.float32))
+    script = ("import h5py,sys\n"
+              "def d(p):\n"
+              "    f=h5py.File(p,'r'); o={}\n"
+              "    f.visititems(lambda n,x: o.__setitem__(n.split('/')[-1], (str(x.dtype), x.chunks, x.compression)) "
+              "if isinstance(x,h5py.Dataset) else None)\n"
+              "    return o\n"
+              "a=d(sys.argv[1]); b=d(sys.argv[2])\n"
+              "assert all(a[k]==b[k] for k in a), (a,b)\nprint('same')\n")
+    r = subprocess.run(["/opt/conda/bin/python3.9", "-c", script, mine,
+                        os.path.join(golden_dir, "variant_predictions_ref.hdf")], capture_output=True, text=True)
+    assert r.returncode == 0 and "same" in r.stdout, r.stderr
