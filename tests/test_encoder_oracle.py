@@ -1,0 +1,115 @@
+"""The oracle's variant-encoder restatement (oracle/pileup_oracle.cpp) against the REFERENCE's own
+C++ (oracle/_ref, built from /root/reference where present) and against committed golden vectors
+that the reference build produced.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import pileup_utils as pu
+
+
+def _same(a, b):
+    assert a["candidates"] == b["candidates"]
+    for k in ("positions", "depths", "candidate_frequency", "images"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def _case(seed, depth=40, region=2500, flank=100, **kw):
+    rng = np.random.default_rng(seed)
+    ref_offset = 10_000
+    L = region + 2 * flank
+    ref = pu.random_reference(rng, L + 1, n_frac=kw.pop("n_frac", 0.0), lower_frac=kw.pop("lower_frac", 0.0))
+    sites = {}
+    for p in rng.choice(np.arange(ref_offset + flank + 20, ref_offset + flank + region - 20), size=12, replace=False):
+        rb = ref[p - ref_offset].upper()
+        sites[int(p)] = (rng.choice([c for c in "ACGT" if c != rb]), float(rng.choice([0.15, 0.5, 1.0])))
+    indels = {}
+    lo, hi = ref_offset + flank + 20, ref_offset + flank + region - 90
+    for p in rng.choice(np.arange(lo, hi), size=10, replace=False):
+        if int(p) in sites:
+            continue
+        frac = float(rng.choice([0.2, 0.5, 0.9]))
+        if rng.random() < 0.5:
+            n = int(rng.choice([1, 2, 5, 17, 59, 60, 61, 64]))
+            indels[int(p)] = ("I", "".join(rng.choice(list("ACGT"), size=n)), frac)
+        else:
+            indels[int(p)] = ("D", int(rng.choice([1, 2, 4, 12, 20, 40, 59, 60, 61])), frac)
+    if region < 1000:
+        indels = dict(list(indels.items())[:3])
+    reads = pu.simulate_reads(rng, ref, ref_offset, n_reads=int(depth * L / 500), snp_sites=sites,
+                              indel_sites=indels, **kw)
+    pile = pu.FlatPileup(ref_offset, ref_offset + L - 1, ref, reads)
+    params = pu.make_params(ref_offset + flank, ref_offset + flank + region)
+    return pile, params
+
+
+CASES = {
+    "plain": dict(seed=1),
+    "eqx_cigars": dict(seed=2, eqx=True),
+    "ref_skip_pad_fallthrough": dict(seed=3, skip_rate=0.004),
+    "long_indels_61_cap": dict(seed=4, long_indel_rate=0.15, ins_rate=0.02, del_rate=0.02),
+    "deep_over_125": dict(seed=5, depth=330, region=600),
+    "lowercase_reference": dict(seed=6, lower_frac=0.2),
+    "low_quality_heavy": dict(seed=7, low_q_rate=0.5),
+    "indel_heavy": dict(seed=8, ins_rate=0.05, del_rate=0.05),
+}
+
+
+@pytest.fixture(scope="module")
+def libs():
+    return pu.load_restatement(), pu.load_reference_encoder()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_restatement_equals_reference_build(libs, name):
+    oracle, ref = libs
+    if ref is None:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    pile, params = _case(**CASES[name])
+    a = pu.run_variant(oracle, pile, params)
+    b = pu.run_variant(ref, pile, params, reference_impl=True)
+    assert len(b["candidates"]) > 0
+    _same(a, b)
+
+
+def test_restatement_threshold_variants(libs):
+    oracle, ref = libs
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    pile, _ = _case(seed=11, ins_rate=0.03, del_rate=0.03)
+    lo, hi = pile.region_start + 100, pile.region_end - 100
+    for over in (dict(skip_indels=1), dict(min_snp_baseq=10, min_indel_baseq=10), dict(candidate_support_threshold=5),
+                 dict(snp_freq_threshold=0.4, snp_candidate_freq_threshold=0.4), dict(min_coverage_threshold=60)):
+        params = pu.make_params(lo, hi, **over)
+        _same(pu.run_variant(oracle, pile, params), pu.run_variant(ref, pile, params, reference_impl=True))
+    # candidate region narrower than the pileup, and touching the region edges (zero-padded windows)
+    params = pu.make_params(pile.region_start, pile.region_end)
+    _same(pu.run_variant(oracle, pile, params), pu.run_variant(ref, pile, params, reference_impl=True))
+
+
+def test_restatement_against_committed_golden(libs, golden_dir):
+    """Golden vectors made by the reference build (tests/golden/make_golden_encoder.py): this is the
+    check that still runs where /root/reference does not exist."""
+    oracle, _ = libs
+    for name in sorted(CASES)[:4]:
+        g = np.load(os.path.join(golden_dir, f"encoder_variant_{name}.npz"), allow_pickle=False)
+        pile, params = _case(**CASES[name])
+        a = pu.run_variant(oracle, pile, params)
+        assert a["candidates"] == [s for s in str(g["candidates"]).split("\n") if s]
+        assert np.array_equal(a["positions"], g["positions"])
+        assert np.array_equal(a["depths"], g["depths"])
+        assert np.array_equal(a["candidate_frequency"], g["candidate_frequency"])
+        assert np.array_equal(a["images"].astype(np.int16), g["images"])
+
+
+def test_empty_and_uncovered_region(libs):
+    oracle, ref = libs
+    rng = np.random.default_rng(0)
+    refseq = pu.random_reference(rng, 501)
+    pile = pu.FlatPileup(1000, 1499, refseq, [])
+    params = pu.make_params(1000, 1499)
+    a = pu.run_variant(oracle, pile, params)
+    assert a["candidates"] == [] and a["images"].shape == (0, 33, 26)
+    if ref is not None:
+        assert pu.run_variant(ref, pile, params, reference_impl=True)["candidates"] == []
