@@ -53,6 +53,14 @@ SYMBOLS = [
     ("pa_profile_get", ctypes.c_int, [c_void_p, c_int32, c_char_p, c_int32, ctypes.POINTER(c_double),
                                       ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
     ("pa_synchronize", ctypes.c_int, [c_void_p]),
+    # include/pepper_amd_encoder.h (struct pointers passed as void*; typed structs live in
+    # pepper_amd/variant/PEPPER_VARIANT.py)
+    ("pa_encoder_create", ctypes.c_int, [c_int32, c_void_p, ctypes.POINTER(c_void_p)]),
+    ("pa_encoder_destroy", None, [c_void_p]),
+    ("pa_encoder_generate_summary", ctypes.c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64)]),
+    ("pa_encoder_get_results", ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_int64, ctypes.POINTER(c_int64)]),
+    ("pa_encoder_device_images", c_void_p, [c_void_p]),
 ]
 
 _lib = None

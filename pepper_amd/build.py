@@ -10,8 +10,9 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpepper_amd.so")
-SOURCES = ["api.hip", "gemm.hip", "rnn.hip", "head.hip"]
-HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "pepper_amd.h")]
+SOURCES = ["api.hip", "gemm.hip", "rnn.hip", "head.hip", "encoder.hip"]
+HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "pepper_amd.h"),
+           os.path.join("..", "..", "include", "pepper_amd_encoder.h")]
 
 
 def _hipcc():

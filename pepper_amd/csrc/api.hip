@@ -16,13 +16,19 @@
 #include "kernels.h"
 
 namespace {
-
 thread_local std::string g_err;
+}
 
-int fail(int code, const std::string& msg) {
+namespace pa {
+int set_error(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+}  // namespace pa
+
+namespace {
+
+int fail(int code, const std::string& msg) { return pa::set_error(code, msg); }
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \

@@ -1,0 +1,551 @@
+// Variant summary encoder (include/pepper_amd_encoder.h): pileup -> candidate images.
+//
+// Split of the reference's RegionalSummaryGenerator::generate_summary
+// (/root/reference/pepper_variant/modules/cpp/region_summary.cpp:337-916):
+//   host  : one pass over CIGAR *ops* (not bases) per read -> match / deletion segments for the
+//           GPU, plus everything that needs strings: insert / delete allele keys, their ordered
+//           per-site maps and the sparse matrix updates they imply (:431-555);
+//   GPU   : pileup_count_kernel    per-base walk of the match segments: coverage, strand coverage,
+//                                  base columns, SNP counts and SNP allele tallies (:366-428), and the
+//                                  '*' columns of deleted bases (:541-551)            [atomics, HBM bound]
+//           apply_events_kernel    the host's sparse updates
+//           site_threshold_kernel  per-position fractions vs thresholds in fp64, clamp of columns
+//                                  11..24 (:634-654), compaction of passing sites
+//           gather_windows_kernel  33 x 26 window copy + candidate-specific overwrite (:828-905),
+//                                  int32 image_matrix and the int8 wrap DataStore.py:68 applies
+//   host  : candidate enumeration in the reference's std::set order with its filters (:669-712).
+// The matrix lives on the device as int32 [L+1][32]: columns 0..25 = the image, 26 coverage,
+// 27 snp_count, 28 insert_count, 29 delete_count (128-byte rows).
+#include "../../include/pepper_amd_encoder.h"
+#include "../../include/pepper_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+enum { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP_P = 6, OP_EQ = 7, OP_X = 8 };
+constexpr int MAXC = 125, ROW = 32, C_COV = 26, C_SNP = 27, C_INS = 28, C_DEL = 29;
+constexpr uint32_t SEG_REV = 1, SEG_DEL = 2, SEG_ANCHOR = 4;
+
+struct Seg {          // a run of consecutive reference positions touched by one CIGAR op
+    int64_t seq0;     // offset of the first base in the concatenated seq / qual arrays
+    int32_t idx0;     // first row (pos - region_start)
+    int32_t n;        // rows
+    uint32_t flags;   // SEG_REV | SEG_DEL | SEG_ANCHOR (last base anchors an indel: no strand coverage)
+    int32_t pad;
+};
+struct Event { int32_t row, col, delta, pad; };
+struct SiteRec { int32_t idx, cov, flags, fwd[4], rev[4]; };
+struct CandDesc {
+    int32_t idx, type;        // row of the candidate site; 1 SNP, 2 insert, 3 delete
+    int32_t vcol, vval;       // columns 1/2/3 <- alt base code / allele length
+    int32_t fwd, rev;         // strand allele depths (<= 125) for columns 5..7 / 16..18
+    int32_t neg_f, neg_r;     // columns negated on the centre row (-1: none)
+    int32_t last;             // delete: last spill row of the window (else -1)
+    int32_t star_f, star_r;   // delete: '*' columns negated on spill rows
+    int32_t pad;
+};
+
+__host__ __device__ inline bool is_acgt(char c) {
+    c &= ~0x20;
+    return c == 'A' || c == 'C' || c == 'G' || c == 'T';
+}
+__host__ __device__ inline int up(char c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
+// column of `symbol` for a strand, -1 if the reference base is not A/C/G/T (region_summary.cpp:201-230)
+__host__ __device__ inline int symbol_column(char ref_base, char symbol, bool reverse) {
+    if (!is_acgt(ref_base)) return -1;
+    const int first = reverse ? 19 : 8;
+    switch (up(symbol)) {
+        case 'A': return first;
+        case 'C': return first + 1;
+        case 'G': return first + 2;
+        case 'T': return first + 3;
+        case 'I': return first + 4;
+        case 'D': return first + 5;
+        default: return first + 6;
+    }
+}
+__host__ __device__ inline int base_code(char c) {
+    switch (up(c)) {
+        case 'A': return 1;
+        case 'C': return 2;
+        case 'G': return 3;
+        case 'T': return 4;
+        default: return 5;
+    }
+}
+
+__global__ __launch_bounds__(256) void init_matrix_kernel(int* __restrict__ mat, const char* __restrict__ ref,
+                                                          int64_t ref_len, int L) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i > L) return;
+    int4* row = reinterpret_cast<int4*>(mat + (size_t)i * ROW);
+#pragma unroll
+    for (int k = 0; k < ROW / 4; ++k) row[k] = make_int4(0, 0, 0, 0);
+    if (i < L) mat[(size_t)i * ROW] = base_code(i < ref_len ? ref[i] : 'N');
+}
+
+// One thread per segment (ONT match runs between indels are ~10-30 bases); the matrix updates are
+// int32 atomics -- a position is hit ~depth times in total, spread over the launch.
+__global__ __launch_bounds__(256) void pileup_count_kernel(const Seg* __restrict__ segs, int nseg,
+                                                           const char* __restrict__ seq,
+                                                           const uint8_t* __restrict__ qual,
+                                                           const char* __restrict__ ref, int64_t ref_len,
+                                                           int* __restrict__ mat, int* __restrict__ snp_tab,
+                                                           int* __restrict__ ovf_count, int4* __restrict__ ovf,
+                                                           int ovf_cap, double min_snp_q) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= nseg) return;
+    const Seg sg = segs[s];
+    const bool rev = sg.flags & SEG_REV;
+    if (sg.flags & SEG_DEL) {
+        for (int i = 0; i < sg.n; ++i) {
+            const int idx = sg.idx0 + i;
+            const int col = symbol_column(idx < ref_len ? ref[idx] : 'N', '*', rev);
+            if (col >= 0) atomicSub(&mat[(size_t)idx * ROW + col], 1);
+        }
+        return;
+    }
+    for (int i = 0; i < sg.n; ++i) {
+        if (!((double)qual[sg.seq0 + i] >= min_snp_q)) continue;
+        const int idx = sg.idx0 + i;
+        const char base = seq[sg.seq0 + i];
+        const char rb = idx < ref_len ? ref[idx] : 'N';
+        int* row = mat + (size_t)idx * ROW;
+        atomicAdd(&row[C_COV], 1);
+        if (!((sg.flags & SEG_ANCHOR) && i == sg.n - 1)) atomicSub(&row[rev ? 15 : 4], 1);
+        const int col = symbol_column(rb, base, rev);
+        if (col >= 0) atomicSub(&row[col], 1);
+        if (rb != base) {                       // case-sensitive, as the reference compares
+            atomicAdd(&row[C_SNP], 1);
+            const int k = base == 'A' ? 0 : base == 'C' ? 1 : base == 'G' ? 2 : base == 'T' ? 3 : -1;
+            if (k >= 0) {
+                atomicAdd(&snp_tab[((size_t)idx * 2 + (rev ? 1 : 0)) * 4 + k], 1);
+            } else {                            // rare alphabet (N, IUPAC, lower case): exact key kept on host
+                const int slot = atomicAdd(ovf_count, 1);
+                if (slot < ovf_cap) ovf[slot] = make_int4(idx, (int)(unsigned char)base, rev ? 1 : 0, 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void apply_events_kernel(const Event* __restrict__ ev, int n, int* __restrict__ mat) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&mat[(size_t)ev[i].row * ROW + ev[i].col], ev[i].delta);
+}
+
+__global__ __launch_bounds__(256) void site_threshold_kernel(int* __restrict__ mat, const int* __restrict__ snp_tab, int L,
+                                                             int64_t region_start, int64_t cand_start, int64_t cand_end,
+                                                             double snp_thr, double ins_thr, double del_thr,
+                                                             double min_cov, int* __restrict__ site_count,
+                                                             SiteRec* __restrict__ sites, int site_cap) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L) return;
+    int* row = mat + (size_t)idx * ROW;
+    const int cov = row[C_COV];
+    const double c = cov > 1 ? (double)cov : 1.0;
+    const bool s = (double)row[C_SNP] / c >= snp_thr;
+    const bool n = (double)row[C_INS] / c >= ins_thr;
+    const bool d = (double)row[C_DEL] / c >= del_thr;
+    const int64_t pos = region_start + idx;
+    if ((s || n || d) && pos >= cand_start && pos <= cand_end && (double)cov >= min_cov) {
+        const int slot = atomicAdd(site_count, 1);
+        if (slot < site_cap) {
+            SiteRec r;
+            r.idx = idx;
+            r.cov = cov;
+            r.flags = (s ? 1 : 0) | (n ? 2 : 0) | (d ? 4 : 0);
+            for (int k = 0; k < 4; ++k) {
+                r.fwd[k] = snp_tab[((size_t)idx * 2 + 0) * 4 + k];
+                r.rev[k] = snp_tab[((size_t)idx * 2 + 1) * 4 + k];
+            }
+            sites[slot] = r;
+        }
+    }
+    for (int col = 11; col < 25; ++col) row[col] = max(-MAXC, min(MAXC, row[col]));
+}
+
+// one 64-lane workgroup per candidate: 33 x 26 = 858 cells
+__global__ __launch_bounds__(64) void gather_windows_kernel(const int* __restrict__ mat, const CandDesc* __restrict__ cands,
+                                                            int L, int W, int F, int mid, int* __restrict__ out32,
+                                                            int8_t* __restrict__ out8) {
+    const CandDesc cd = cands[blockIdx.x];
+    const size_t base = (size_t)blockIdx.x * W * F;
+    for (int e = threadIdx.x; e < W * F; e += 64) {
+        const int r = e / F, f = e - r * F;
+        const int row = cd.idx - mid + r;
+        int v = (row >= 0 && row <= L && f < 26) ? mat[(size_t)row * ROW + f] : 0;
+        if (r == mid) {
+            if (f == cd.vcol) v = cd.vval;
+            else if (f == cd.type + 4) v = cd.fwd;        // 5 / 6 / 7
+            else if (f == cd.type + 15) v = cd.rev;       // 16 / 17 / 18
+            else if (f == cd.neg_f || f == cd.neg_r) v = -v;
+        } else if (r > mid && r <= cd.last) {
+            if (f == 3) v = cd.vval;
+            else if (f == 7) v = cd.fwd;
+            else if (f == 18) v = cd.rev;
+            else if (f == cd.star_f || f == cd.star_r) v = -v;
+        }
+        out32[base + e] = v;
+        out8[base + e] = (int8_t)v;                        // two's-complement wrap, as numpy 1.22's int8 cast
+    }
+}
+
+struct DBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    bool ensure(size_t need) {
+        if (need <= bytes) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        const size_t grow = need + need / 4 + 256;
+        if (hipMalloc(&p, grow) != hipSuccess) return false;
+        bytes = grow;
+        return true;
+    }
+    ~DBuf() { if (p) (void)hipFree(p); }
+};
+
+struct Tally { int total = 0, fwd = 0, rev = 0; };
+
+}  // namespace
+
+struct pa_encoder {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DBuf d_seq, d_qual, d_ref, d_segs, d_events, d_mat, d_snp, d_ovf, d_counters, d_sites, d_cands, d_img32, d_img8;
+    // results of the last call
+    int64_t n = 0;
+    int W = 33, F = 26;
+    std::vector<int64_t> positions;
+    std::vector<int32_t> depths, freqs;
+    std::string names;
+};
+
+#define ENC_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return pa::set_error(PA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define ENC_ALLOC(buf, bytes_)                                                                          \
+    do {                                                                                                \
+        if (!(buf).ensure(bytes_)) return pa::set_error(PA_ERR_HIP, "hipMalloc failed in encoder workspace"); \
+    } while (0)
+
+extern "C" {
+
+int pa_encoder_create(int32_t device, void* hip_stream, pa_encoder** out) {
+    if (!out) return pa::set_error(PA_ERR_INVALID, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return pa::set_error(PA_ERR_NO_DEVICE, "no HIP device visible: the pepper_amd encoder has no CPU fallback");
+    if (device < 0 || device >= count) return pa::set_error(PA_ERR_INVALID, "device ordinal out of range");
+    ENC_HIP(hipSetDevice(device));
+    auto* e = new pa_encoder();
+    e->device = device;
+    if (hip_stream) e->stream = static_cast<hipStream_t>(hip_stream);
+    else {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete e;
+            return pa::set_error(PA_ERR_HIP, "hipStreamCreate failed");
+        }
+        e->own_stream = true;
+    }
+    *out = e;
+    return PA_OK;
+}
+
+void pa_encoder_destroy(pa_encoder* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summary_params* q, int64_t* n_candidates) {
+    if (!e || !p || !q || !n_candidates) return pa::set_error(PA_ERR_INVALID, "null argument");
+    if (p->region_end < p->region_start || p->region_end - p->region_start > (int64_t)1 << 28)
+        return pa::set_error(PA_ERR_INVALID, "bad region");
+    if (q->feature_size < 26 || q->candidate_window_size < 2 || q->candidate_window_size > 254)
+        return pa::set_error(PA_ERR_INVALID, "feature_size must be >= 26 and 2 <= candidate_window_size <= 254");
+    ENC_HIP(hipSetDevice(e->device));
+    const int64_t start = p->region_start, end = p->region_end;
+    const int L = (int)(end - start + 1);
+    const int W = q->candidate_window_size + 1, F = q->feature_size, mid = q->candidate_window_size / 2;
+    e->W = W;
+    e->F = F;
+    e->n = 0;
+    e->positions.clear();
+    e->depths.clear();
+    e->freqs.clear();
+    e->names.clear();
+    auto refc = [&](int64_t idx) { return idx >= 0 && idx < p->reference_len ? p->reference[idx] : 'N'; };
+
+    // ---- host pass over CIGAR ops -----------------------------------------------------------
+    std::vector<Seg> segs;
+    std::vector<Event> events;
+    std::map<int32_t, std::map<std::string, Tally>> indels;   // site -> ordered allele keys ("2..." < "3...")
+    auto vote = [&](int32_t idx, const std::string& key, bool rev) {
+        Tally& t = indels[idx][key];
+        t.total += 1;
+        (rev ? t.rev : t.fwd) += 1;
+    };
+    const int64_t total_bases = p->n_reads > 0 ? p->seq_offset[p->n_reads] : 0;
+    for (int32_t r = 0; r < p->n_reads; ++r) {
+        if (p->read_mapq[r] <= 0) continue;
+        const bool rev = p->read_reverse[r] != 0;
+        const int64_t s0 = p->seq_offset[r], read_len = p->seq_offset[r + 1] - s0;
+        const char* seq = p->seq + s0;
+        const uint8_t* ql = p->qual + s0;
+        const int64_t c0 = p->cigar_offset[r], c1 = p->cigar_offset[r + 1];
+        int64_t ri = 0, pos = p->read_pos[r];
+        for (int64_t c = c0; c < c1; ++c) {
+            if (pos > end) break;
+            const int op = p->cigar_op[c];
+            const int64_t len = p->cigar_len[c];
+            if (op == OP_M || op == OP_EQ || op == OP_X) {
+                const int64_t lo = std::max(pos, start), hi = std::min(pos + len - 1, end);   // touched positions
+                if (lo <= hi) {
+                    if (ri + (hi - pos) >= read_len)
+                        return pa::set_error(PA_ERR_INVALID, "CIGAR of read " + std::to_string(r) + " runs past its sequence");
+                    Seg sg;
+                    sg.seq0 = s0 + ri + (lo - pos);
+                    sg.idx0 = (int32_t)(lo - start);
+                    sg.n = (int32_t)(hi - lo + 1);
+                    sg.flags = rev ? SEG_REV : 0;
+                    sg.pad = 0;
+                    const bool last_in = (hi == pos + len - 1);
+                    if (last_in && c != c1 - 1) {
+                        const int nop = p->cigar_op[c + 1];
+                        if (nop == OP_I || nop == OP_D) sg.flags |= SEG_ANCHOR;
+                    }
+                    segs.push_back(sg);
+                }
+                ri += len;
+                pos += len;
+            } else if (op == OP_I) {
+                const int64_t anchor = pos - 1;
+                if (anchor >= start && anchor <= end && ri - 1 >= 0) {
+                    const int32_t idx = (int32_t)(anchor - start);
+                    const int64_t n = len + 1;
+                    const int64_t avail = std::max<int64_t>(0, std::min<int64_t>(n, read_len - (ri - 1)));
+                    double qsum = 0;
+                    for (int64_t k = ri - 1; k < ri - 1 + n; ++k) qsum += k < read_len ? ql[k] : 0;
+                    const bool passes = qsum >= q->min_indel_baseq * (double)n;
+                    if (passes && (double)ql[ri - 1] < q->min_snp_baseq) events.push_back({idx, C_COV, 1, 0});
+                    if (avail + 1 <= 61 && passes) {
+                        const int col = symbol_column(refc(idx), 'I', rev);
+                        if (col >= 0) events.push_back({idx, col, -1, 0});
+                        events.push_back({idx, C_INS, 1, 0});
+                        vote(idx, "2" + std::string(seq + (ri - 1), (size_t)avail), rev);
+                    }
+                }
+                ri += len;
+            } else if (op == OP_D) {
+                const int64_t anchor = pos - 1;
+                if (anchor >= start && anchor <= end) {
+                    const int32_t idx = (int32_t)(anchor - start);
+                    const int col = symbol_column(refc(idx), 'D', rev);
+                    if (col >= 0) events.push_back({idx, col, -1, 0});
+                    const int64_t avail = std::max<int64_t>(0, std::min<int64_t>(len + 1, p->reference_len - idx));
+                    if (avail + 1 <= 61) {
+                        events.push_back({idx, C_DEL, 1, 0});
+                        vote(idx, "3" + std::string(p->reference + idx, (size_t)avail), rev);
+                    }
+                }
+                const int64_t lo = std::max(pos, start), hi = std::min(pos + len - 1, end);
+                if (lo <= hi) segs.push_back({0, (int32_t)(lo - start), (int32_t)(hi - lo + 1), (rev ? SEG_REV : 0) | SEG_DEL, 0});
+                pos += len;
+            } else if (op == OP_N || op == OP_P) {
+                pos += len;
+                ri += len;      // the reference falls through into the soft-clip case (region_summary.cpp:556-561)
+            } else if (op == OP_S) {
+                ri += len;
+            }
+        }
+    }
+
+    // ---- device: counts -----------------------------------------------------------------------
+    const int ovf_cap = 1 << 16;
+    const int site_cap = L;
+    ENC_ALLOC(e->d_seq, (size_t)total_bases + 16);
+    ENC_ALLOC(e->d_qual, (size_t)total_bases + 16);
+    ENC_ALLOC(e->d_ref, (size_t)p->reference_len + 16);
+    ENC_ALLOC(e->d_segs, segs.size() * sizeof(Seg) + 16);
+    ENC_ALLOC(e->d_events, events.size() * sizeof(Event) + 16);
+    ENC_ALLOC(e->d_mat, (size_t)(L + 1) * ROW * sizeof(int));
+    ENC_ALLOC(e->d_snp, (size_t)L * 8 * sizeof(int));
+    ENC_ALLOC(e->d_ovf, (size_t)ovf_cap * sizeof(int4));
+    ENC_ALLOC(e->d_counters, 64);
+    ENC_ALLOC(e->d_sites, (size_t)site_cap * sizeof(SiteRec));
+    hipStream_t st = e->stream;
+    if (total_bases > 0) {
+        ENC_HIP(hipMemcpyAsync(e->d_seq.p, p->seq, (size_t)total_bases, hipMemcpyHostToDevice, st));
+        ENC_HIP(hipMemcpyAsync(e->d_qual.p, p->qual, (size_t)total_bases, hipMemcpyHostToDevice, st));
+    }
+    if (p->reference_len > 0)
+        ENC_HIP(hipMemcpyAsync(e->d_ref.p, p->reference, (size_t)p->reference_len, hipMemcpyHostToDevice, st));
+    if (!segs.empty())
+        ENC_HIP(hipMemcpyAsync(e->d_segs.p, segs.data(), segs.size() * sizeof(Seg), hipMemcpyHostToDevice, st));
+    if (!events.empty())
+        ENC_HIP(hipMemcpyAsync(e->d_events.p, events.data(), events.size() * sizeof(Event), hipMemcpyHostToDevice, st));
+    ENC_HIP(hipMemsetAsync(e->d_snp.p, 0, (size_t)L * 8 * sizeof(int), st));
+    ENC_HIP(hipMemsetAsync(e->d_counters.p, 0, 64, st));
+    int* mat = static_cast<int*>(e->d_mat.p);
+    int* counters = static_cast<int*>(e->d_counters.p);
+    hipLaunchKernelGGL(init_matrix_kernel, dim3((L + 1 + 255) / 256), dim3(256), 0, st, mat,
+                       static_cast<const char*>(e->d_ref.p), p->reference_len, L);
+    if (!segs.empty())
+        hipLaunchKernelGGL(pileup_count_kernel, dim3(((int)segs.size() + 255) / 256), dim3(256), 0, st,
+                           static_cast<const Seg*>(e->d_segs.p), (int)segs.size(), static_cast<const char*>(e->d_seq.p),
+                           static_cast<const uint8_t*>(e->d_qual.p), static_cast<const char*>(e->d_ref.p),
+                           p->reference_len, mat, static_cast<int*>(e->d_snp.p), counters,
+                           static_cast<int4*>(e->d_ovf.p), ovf_cap, q->min_snp_baseq);
+    if (!events.empty())
+        hipLaunchKernelGGL(apply_events_kernel, dim3(((int)events.size() + 255) / 256), dim3(256), 0, st,
+                           static_cast<const Event*>(e->d_events.p), (int)events.size(), mat);
+    hipLaunchKernelGGL(site_threshold_kernel, dim3((L + 255) / 256), dim3(256), 0, st, mat,
+                       static_cast<const int*>(e->d_snp.p), L, start, q->candidate_region_start,
+                       q->candidate_region_end, q->snp_freq_threshold, q->insert_freq_threshold,
+                       q->delete_freq_threshold, q->min_coverage_threshold, counters + 1,
+                       static_cast<SiteRec*>(e->d_sites.p), site_cap);
+    ENC_HIP(hipGetLastError());
+    int host_counters[2] = {0, 0};
+    ENC_HIP(hipMemcpyAsync(host_counters, counters, sizeof(host_counters), hipMemcpyDeviceToHost, st));
+    ENC_HIP(hipStreamSynchronize(st));
+    const int n_ovf = host_counters[0], n_sites = std::min(host_counters[1], site_cap);
+    if (n_ovf > ovf_cap)
+        return pa::set_error(PA_ERR_INVALID, "more than 65536 mismatching bases outside ACGT in one region");
+    std::vector<SiteRec> sites((size_t)n_sites);
+    std::vector<int4> ovf((size_t)n_ovf);
+    if (n_sites) ENC_HIP(hipMemcpyAsync(sites.data(), e->d_sites.p, sites.size() * sizeof(SiteRec), hipMemcpyDeviceToHost, st));
+    if (n_ovf) ENC_HIP(hipMemcpyAsync(ovf.data(), e->d_ovf.p, ovf.size() * sizeof(int4), hipMemcpyDeviceToHost, st));
+    ENC_HIP(hipStreamSynchronize(st));
+    std::sort(sites.begin(), sites.end(), [](const SiteRec& a, const SiteRec& b) { return a.idx < b.idx; });
+    std::map<int32_t, std::map<char, Tally>> rare;       // SNP alleles outside ACGT
+    for (const int4& o : ovf) {
+        Tally& t = rare[o.x][(char)o.y];
+        t.total += 1;
+        (o.z ? t.rev : t.fwd) += 1;
+    }
+
+    // ---- host: candidates in the reference's order (std::set<string> per site) -------------------
+    std::vector<CandDesc> cands;
+    for (const SiteRec& s : sites) {
+        const int depth = std::min(s.cov, MAXC);
+        const char rb = refc(s.idx);
+        auto accept = [&](char type, const Tally& t) {
+            const double freq = (double)t.total / std::max(1.0, (double)depth);
+            if ((double)t.total < q->candidate_support_threshold) return false;
+            if (type != '1' && freq < q->indel_candidate_freq_threshold) return false;
+            if (type == '1' && freq < q->snp_candidate_freq_threshold) return false;
+            if (type != '1' && q->skip_indels) return false;
+            if ((type == '1' && !(s.flags & 1)) || (type == '2' && !(s.flags & 2)) || (type == '3' && !(s.flags & 4)))
+                return false;
+            return true;
+        };
+        auto emit = [&](const std::string& key, const Tally& t, const CandDesc& d) {
+            cands.push_back(d);
+            e->positions.push_back(start + s.idx);
+            e->depths.push_back(depth);
+            e->freqs.push_back(std::min(t.total, MAXC));
+            e->names += key;
+            e->names.push_back('\0');
+        };
+        // SNP alleles: "1" + base, ordered by the raw base character
+        std::map<char, Tally> snps;
+        const char acgt[4] = {'A', 'C', 'G', 'T'};
+        for (int k = 0; k < 4; ++k)
+            if (s.fwd[k] + s.rev[k] > 0) snps[acgt[k]] = Tally{s.fwd[k] + s.rev[k], s.fwd[k], s.rev[k]};
+        const auto rit = rare.find(s.idx);
+        if (rit != rare.end())
+            for (const auto& kv : rit->second) {
+                Tally& t = snps[kv.first];
+                t.total += kv.second.total;
+                t.fwd += kv.second.fwd;
+                t.rev += kv.second.rev;
+            }
+        for (const auto& kv : snps) {
+            if (!accept('1', kv.second)) continue;
+            CandDesc d{};
+            d.idx = s.idx; d.type = 1; d.vcol = 1; d.vval = base_code(kv.first);
+            d.fwd = std::min(kv.second.fwd, MAXC); d.rev = std::min(kv.second.rev, MAXC);
+            d.neg_f = symbol_column(rb, kv.first, false); d.neg_r = symbol_column(rb, kv.first, true);
+            d.last = -1; d.star_f = d.star_r = -1;
+            emit(std::string("1") + kv.first, kv.second, d);
+        }
+        const auto iit = indels.find(s.idx);
+        if (iit == indels.end()) continue;
+        for (const auto& kv : iit->second) {
+            const char type = kv.first[0];
+            if (!accept(type, kv.second)) continue;
+            CandDesc d{};
+            d.idx = s.idx; d.type = type - '0';
+            d.fwd = std::min(kv.second.fwd, MAXC); d.rev = std::min(kv.second.rev, MAXC);
+            const int alen = (int)kv.first.size() - 1;
+            d.vval = std::min(alen, MAXC);
+            d.star_f = d.star_r = -1;
+            if (type == '2') {
+                d.vcol = 2; d.last = -1;
+                d.neg_f = symbol_column(rb, 'I', false); d.neg_r = symbol_column(rb, 'I', true);
+            } else {
+                d.vcol = 3; d.last = std::min(mid + alen - 1, q->candidate_window_size - 1);
+                d.neg_f = symbol_column(rb, 'D', false); d.neg_r = symbol_column(rb, 'D', true);
+                d.star_f = symbol_column(rb, '*', false); d.star_r = symbol_column(rb, '*', true);
+            }
+            emit(kv.first, kv.second, d);
+        }
+    }
+
+    // ---- device: window gather ----------------------------------------------------------------------
+    e->n = (int64_t)cands.size();
+    *n_candidates = e->n;
+    if (e->n > 0) {
+        ENC_ALLOC(e->d_cands, cands.size() * sizeof(CandDesc));
+        ENC_ALLOC(e->d_img32, (size_t)e->n * W * F * sizeof(int));
+        ENC_ALLOC(e->d_img8, (size_t)e->n * W * F);
+        ENC_HIP(hipMemcpyAsync(e->d_cands.p, cands.data(), cands.size() * sizeof(CandDesc), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)e->n), dim3(64), 0, st, mat,
+                           static_cast<const CandDesc*>(e->d_cands.p), L, W, F, mid, static_cast<int*>(e->d_img32.p),
+                           static_cast<int8_t*>(e->d_img8.p));
+        ENC_HIP(hipGetLastError());
+        ENC_HIP(hipStreamSynchronize(st));
+    }
+    return PA_OK;
+}
+
+int pa_encoder_get_results(pa_encoder* e, int64_t* positions, int32_t* depths, int32_t* candidate_frequency,
+                           int32_t* images_i32, int8_t* images_i8, char* candidates, int64_t candidates_cap,
+                           int64_t* candidates_needed) {
+    if (!e) return pa::set_error(PA_ERR_INVALID, "null encoder");
+    ENC_HIP(hipSetDevice(e->device));
+    const size_t n = (size_t)e->n;
+    if (positions) std::copy(e->positions.begin(), e->positions.end(), positions);
+    if (depths) std::copy(e->depths.begin(), e->depths.end(), depths);
+    if (candidate_frequency) std::copy(e->freqs.begin(), e->freqs.end(), candidate_frequency);
+    if (candidates_needed) *candidates_needed = (int64_t)e->names.size();
+    if (candidates && candidates_cap >= (int64_t)e->names.size()) std::memcpy(candidates, e->names.data(), e->names.size());
+    if (n > 0 && images_i32)
+        ENC_HIP(hipMemcpyAsync(images_i32, e->d_img32.p, n * e->W * e->F * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if (n > 0 && images_i8)
+        ENC_HIP(hipMemcpyAsync(images_i8, e->d_img8.p, n * e->W * e->F, hipMemcpyDeviceToHost, e->stream));
+    ENC_HIP(hipStreamSynchronize(e->stream));
+    return PA_OK;
+}
+
+const int8_t* pa_encoder_device_images(pa_encoder* e) {
+    return (e && e->n > 0) ? static_cast<const int8_t*>(e->d_img8.p) : nullptr;
+}
+
+}  // extern "C"

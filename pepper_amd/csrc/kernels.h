@@ -3,7 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace pa {
+
+// records the thread-local message returned by pa_last_error(); returns `code`
+int set_error(int code, const std::string& msg);
 
 enum AKind { A_F32 = 0, A_I8 = 1, A_U8 = 2, A_F32_SCALAR = 3 };
 

@@ -47,9 +47,10 @@ class DataStore(object):
         fh[base + "contigs"] = np.array(contigs, dtype='S')
         fh[base + "positions"] = np.asarray(positions, dtype=np.int64).astype(np.int32)
         fh[base + "depths"] = wrap_uint8(depths)
-        fh[base + "candidates"] = np.array(all_candidates, dtype=object)
+        fh[base + "candidates"] = np.asarray(all_candidates, dtype=object)
         fh[base + "candidate_frequency"] = wrap_uint8(all_candidate_frequency)
-        fh[base + "images"] = wrap_int8(all_images)
+        img = np.asarray(all_images)
+        fh[base + "images"] = img if img.dtype == np.int8 else wrap_int8(all_images)
         if train_mode:
             fh[base + "base_labels"] = wrap_uint8(all_base_labels)
             fh[base + "type_label"] = wrap_uint8(all_type_label)

@@ -1,0 +1,194 @@
+"""Python shim with the names of the reference's pybind11 module for the summary encoder.
+
+Mirrors the part of `from pepper_variant.build import PEPPER_VARIANT` that image generation uses
+(/root/reference/pepper_variant/modules/cpp/pybind_api.h:55-62 RegionalSummaryGenerator, :73-101
+CandidateImageSummary, :187-221 CigarOp / type_read_flags / type_read; call site
+/root/reference/pepper_variant/modules/python/AlignmentSummarizer.py:220-238).  Reads may be any
+objects with the type_read attributes (pos, flags.is_reverse, sequence, cigar_tuples[.cigar_op,
+.cigar_len], mapping_quality, base_qualities); they are flattened once and encoded by
+libpepper_amd.so (include/pepper_amd_encoder.h).  `generate_summary_arrays` returns the bulk
+struct-of-arrays form (images already int8-packed on the device) for callers that do not need
+per-candidate Python objects.
+"""
+import ctypes
+
+import numpy as np
+
+from pepper_amd import _lib
+
+
+class CigarOp(object):
+    def __init__(self, cigar_op=-1, cigar_len=0):
+        self.cigar_op = cigar_op
+        self.cigar_len = cigar_len
+
+
+class type_read_flags(object):
+    def __init__(self):
+        for name in ("is_paired", "is_proper_pair", "is_unmapped", "is_mate_unmapped", "is_reverse",
+                     "is_mate_is_reverse", "is_read1", "is_read2", "is_secondary", "is_qc_failed",
+                     "is_duplicate", "is_supplementary"):
+            setattr(self, name, False)
+
+
+class type_read(object):
+    def __init__(self):
+        self.pos = 0
+        self.pos_end = 0
+        self.query_name = ""
+        self.read_id = 0
+        self.flags = type_read_flags()
+        self.hp_tag = 0
+        self.sequence = ""
+        self.cigar_tuples = []
+        self.mapping_quality = 0
+        self.base_qualities = []
+        self.bad_indicies = []
+
+    def set_read_id(self, read_id):
+        self.read_id = read_id
+
+    def __lt__(self, other):
+        return (self.pos, self.pos_end) < (other.pos, other.pos_end)
+
+
+class CandidateImageSummary(object):
+    def __init__(self, contig="", position=0, depth=0, candidates=None, candidate_frequency=None,
+                 image_matrix=None, base_label=0, type_label=0):
+        self.contig = contig
+        self.position = position
+        self.depth = depth
+        self.candidates = candidates if candidates is not None else []
+        self.candidate_frequency = candidate_frequency if candidate_frequency is not None else []
+        self.image_matrix = image_matrix if image_matrix is not None else []
+        self.base_label = base_label
+        self.type_label = type_label
+
+    def __getstate__(self):
+        return (self.contig, self.position, self.depth, self.candidates, self.candidate_frequency,
+                self.image_matrix, self.base_label, self.type_label)
+
+    def __setstate__(self, t):
+        if len(t) != 8:
+            raise RuntimeError("Invalid state!")
+        (self.contig, self.position, self.depth, self.candidates, self.candidate_frequency,
+         self.image_matrix, self.base_label, self.type_label) = t
+
+
+class _Pileup(ctypes.Structure):
+    _fields_ = [("region_start", ctypes.c_int64), ("region_end", ctypes.c_int64),
+                ("reference", ctypes.c_char_p), ("reference_len", ctypes.c_int64), ("n_reads", ctypes.c_int32),
+                ("read_pos", ctypes.c_void_p), ("read_reverse", ctypes.c_void_p), ("read_mapq", ctypes.c_void_p),
+                ("seq_offset", ctypes.c_void_p), ("seq", ctypes.c_void_p), ("qual", ctypes.c_void_p),
+                ("cigar_offset", ctypes.c_void_p), ("cigar_op", ctypes.c_void_p), ("cigar_len", ctypes.c_void_p)]
+
+
+class _Params(ctypes.Structure):
+    _fields_ = [("min_snp_baseq", ctypes.c_double), ("min_indel_baseq", ctypes.c_double),
+                ("snp_freq_threshold", ctypes.c_double), ("insert_freq_threshold", ctypes.c_double),
+                ("delete_freq_threshold", ctypes.c_double), ("min_coverage_threshold", ctypes.c_double),
+                ("snp_candidate_freq_threshold", ctypes.c_double),
+                ("indel_candidate_freq_threshold", ctypes.c_double),
+                ("candidate_support_threshold", ctypes.c_double), ("skip_indels", ctypes.c_int32),
+                ("candidate_region_start", ctypes.c_int64), ("candidate_region_end", ctypes.c_int64),
+                ("candidate_window_size", ctypes.c_int32), ("feature_size", ctypes.c_int32)]
+
+
+_encoders = {}
+
+
+def _encoder(device):
+    """One native encoder (stream + workspace) per device per process, created on first use."""
+    lib = _lib.load()
+    if device not in _encoders:
+        h = ctypes.c_void_p()
+        _lib.check(lib.pa_encoder_create(device, None, ctypes.byref(h)))
+        _encoders[device] = h
+    return lib, _encoders[device]
+
+
+def flatten_reads(reads):
+    """type_read-like objects -> the flat arrays of pa_pileup."""
+    n = len(reads)
+    read_pos = np.fromiter((r.pos for r in reads), np.int64, n)
+    read_reverse = np.fromiter((1 if r.flags.is_reverse else 0 for r in reads), np.uint8, n)
+    read_mapq = np.fromiter((r.mapping_quality for r in reads), np.int32, n)
+    seq_offset = np.zeros(n + 1, np.int64)
+    cigar_offset = np.zeros(n + 1, np.int64)
+    np.cumsum([len(r.sequence) for r in reads], out=seq_offset[1:])
+    np.cumsum([len(r.cigar_tuples) for r in reads], out=cigar_offset[1:])
+    seq = np.frombuffer(("".join(r.sequence for r in reads)).encode("latin-1") + b"\0", np.uint8)
+    qual = np.zeros(int(seq_offset[-1]) + 1, np.uint8)
+    for i, r in enumerate(reads):
+        qual[seq_offset[i]:seq_offset[i + 1]] = np.clip(np.asarray(r.base_qualities, np.int64), 0, 255)
+    cigar_op = np.fromiter((c.cigar_op for r in reads for c in r.cigar_tuples), np.int32, int(cigar_offset[-1]))
+    cigar_len = np.fromiter((c.cigar_len for r in reads for c in r.cigar_tuples), np.int32, int(cigar_offset[-1]))
+    return dict(read_pos=read_pos, read_reverse=read_reverse, read_mapq=read_mapq, seq_offset=seq_offset,
+                seq=seq, qual=qual, cigar_offset=cigar_offset, cigar_op=np.append(cigar_op, 0).astype(np.int32),
+                cigar_len=np.append(cigar_len, 0).astype(np.int32), n_reads=n)
+
+
+class RegionalSummaryGenerator(object):
+    def __init__(self, contig, region_start, region_end, reference_sequence, device=0):
+        self.contig = contig
+        self.ref_start = int(region_start)
+        self.ref_end = int(region_end)
+        self.reference_sequence = reference_sequence
+        self.device = device
+        # GENERATE_INDELS == false in the reference (region_summary.h:50): no insert columns
+        self.total_observered_insert_bases = 0
+
+    def generate_max_insert_summary(self, reads):
+        """Axes of the region.  With GENERATE_INDELS false every max_observed_insert entry is 0, so
+        positions[i] = ref_start + i and index[i] = 0 (region_summary.cpp:19-96); nothing to compute."""
+        return None
+
+    def generate_summary_arrays(self, reads, min_snp_baseq, min_indel_baseq, snp_freq_threshold,
+                                insert_freq_threshold, delete_freq_threshold, min_coverage_threshold,
+                                snp_candidate_freq_threshold, indel_candidate_freq_threshold,
+                                candidate_support_threshold, skip_indels, candidate_region_start,
+                                candidate_region_end, candidate_window_size, feature_size, train_mode=False,
+                                want_int32=False):
+        if train_mode:
+            raise NotImplementedError("train_mode label generation (truth VCF haplotypes) is outside the inference path")
+        flat = reads if isinstance(reads, dict) else flatten_reads(reads)
+        lib, enc = _encoder(self.device)
+        ref = self.reference_sequence.encode("latin-1") if isinstance(self.reference_sequence, str) else bytes(self.reference_sequence)
+        p = _Pileup(self.ref_start, self.ref_end, ref, len(ref), flat["n_reads"],
+                    flat["read_pos"].ctypes.data, flat["read_reverse"].ctypes.data, flat["read_mapq"].ctypes.data,
+                    flat["seq_offset"].ctypes.data, flat["seq"].ctypes.data, flat["qual"].ctypes.data,
+                    flat["cigar_offset"].ctypes.data, flat["cigar_op"].ctypes.data, flat["cigar_len"].ctypes.data)
+        q = _Params(min_snp_baseq, min_indel_baseq, snp_freq_threshold, insert_freq_threshold,
+                    delete_freq_threshold, min_coverage_threshold, snp_candidate_freq_threshold,
+                    indel_candidate_freq_threshold, candidate_support_threshold, 1 if skip_indels else 0,
+                    int(candidate_region_start), int(candidate_region_end), int(candidate_window_size),
+                    int(feature_size))
+        n = ctypes.c_int64()
+        _lib.check(lib.pa_encoder_generate_summary(enc, ctypes.cast(ctypes.pointer(p), ctypes.c_void_p),
+                                                   ctypes.cast(ctypes.pointer(q), ctypes.c_void_p), ctypes.byref(n)))
+        n = n.value
+        W, F = candidate_window_size + 1, feature_size
+        positions = np.zeros(n, np.int64)
+        depths = np.zeros(n, np.int32)
+        freqs = np.zeros(n, np.int32)
+        img8 = np.zeros((n, W, F), np.int8)
+        img32 = np.zeros((n, W, F), np.int32) if want_int32 else None
+        needed = ctypes.c_int64()
+        _lib.check(lib.pa_encoder_get_results(enc, None, None, None, None, None, None, 0, ctypes.byref(needed)))
+        names = ctypes.create_string_buffer(max(1, needed.value))
+        _lib.check(lib.pa_encoder_get_results(enc, positions.ctypes.data, depths.ctypes.data, freqs.ctypes.data,
+                                              img32.ctypes.data if want_int32 else None, img8.ctypes.data,
+                                              ctypes.cast(names, ctypes.c_void_p), needed.value, ctypes.byref(needed)))
+        cands = [s.decode("latin-1") for s in names.raw[:needed.value].split(b"\0")[:n]]
+        return dict(positions=positions, depths=depths, candidate_frequency=freqs, images=img8, images_int32=img32,
+                    candidates=cands)
+
+    def generate_summary(self, reads, *args):
+        """-> list[CandidateImageSummary], as the pybind method (region_summary.h:191-206)."""
+        out = self.generate_summary_arrays(reads, *args, want_int32=True)
+        res = []
+        for i in range(len(out["candidates"])):
+            res.append(CandidateImageSummary(self.contig, int(out["positions"][i]), int(out["depths"][i]),
+                                             [out["candidates"][i]], [int(out["candidate_frequency"][i])],
+                                             out["images_int32"][i].tolist(), 0, 0))
+        return res

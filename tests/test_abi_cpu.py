@@ -15,16 +15,33 @@ def lib():
     return _lib.load()
 
 
+def _declared(*headers):
+    out = set()
+    for h in headers:
+        text = open(os.path.join(REPO, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", text))
+    return out
+
+
 def test_header_symbols_are_exported(lib):
-    header = open(os.path.join(REPO, "include", "pepper_amd.h")).read()
-    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) >= 17
+    declared = _declared("pepper_amd.h", "pepper_amd_encoder.h")
+    assert len(declared) >= 22
     from pepper_amd import _lib
     bound = {name for name, _, _ in _lib.SYMBOLS}
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def test_io_header_symbols_are_exported():
+    from pepper_amd import h5
+    io = h5.load()
+    declared = _declared("pepper_amd_io.h")
+    bound = {name for name, _, _ in h5.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert hasattr(io, name), name
 
 
 def test_version_and_error_string(lib):

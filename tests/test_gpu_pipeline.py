@@ -90,3 +90,107 @@ def test_call_consensus_end_to_end(tmp_path):
             assert (got_b == labels[cid]).mean() > 0.999
             assert (got_p == phred[cid]).mean() > 0.99
             assert f[base + f"{cid}/position"].shape == (1000, 2)
+
+
+class _FakeFasta(object):
+    def __init__(self, contigs):
+        self.contigs = contigs
+
+    def get_chromosome_names(self):
+        return list(self.contigs)
+
+    def get_chromosome_sequence_length(self, name):
+        return len(self.contigs[name])
+
+    def get_reference_sequence(self, name, start, end):
+        return self.contigs[name][start:end]
+
+
+class _FakeBam(object):
+    """get_reads without htslib's region clipping (that belongs to the out-of-scope BAM reader)."""
+
+    def __init__(self, reads_by_contig):
+        self.reads = reads_by_contig
+
+    def get_chromosome_sequence_names(self):
+        return list(self.reads)
+
+    def get_reads(self, name, start, end, include_supplementary, min_mapq, min_baseq):
+        out = []
+        for r in self.reads[name]:
+            ref_len = sum(n for o, n in r["cigar"] if o in (0, 2, 3, 6, 7, 8))
+            if r["pos"] <= end and r["pos"] + ref_len >= start and r["mapq"] >= min_mapq:
+                out.append(_as_read(r))
+        return out
+
+
+def test_images_to_predictions_plumbing(tmp_path):
+    """BASELINE configs[0] plumbing on synthetic reads: pileup -> GPU encoder -> images HDF5 ->
+    GPU inference -> predictions HDF5, against the oracle encoder + oracle model."""
+    import pileup_utils as pu
+    from test_gpu_encoder import R
+    from pepper_amd.variant.ImageGenerationUI import ImageGenerationUtils
+    from pepper_amd.variant.RunInference import run_inference
+    rng = np.random.default_rng(2024)
+    ref = pu.random_reference(rng, 6000)
+    sites = {int(p): ("ACGT"[(("ACGT".index(ref[p]) + 1) % 4)], 0.5) for p in rng.choice(np.arange(300, 5700), 25, replace=False)}
+    indels = {1111: ("I", "ACG", 0.6), 2222: ("D", 4, 0.7), 3333: ("D", 40, 0.5)}
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=500, read_len=(300, 900), snp_sites=sites, indel_sites=indels)
+    options = SimpleNamespace(
+        bam="fake.bam", fasta="fake.fa", region="chr20:0-5999", region_size=2000, threads=2, train_mode=False,
+        use_hp_info=False, image_output_directory=str(tmp_path / "images"), include_supplementary=False,
+        min_mapq=1, min_snp_baseq=1, min_indel_baseq=1, snp_frequency=0.10, insert_frequency=0.15,
+        delete_frequency=0.15, min_coverage_threshold=3, snp_candidate_frequency_threshold=0.10,
+        indel_candidate_frequency_threshold=0.12, candidate_support_threshold=2, skip_indels=False,
+        downsample_rate=1.0,
+        bam_handler_factory=lambda path: _FakeBam({"chr20": reads}),
+        fasta_handler_factory=lambda path: _FakeFasta({"chr20": ref}))
+    ImageGenerationUtils.generate_images(options)
+    files = sorted(os.listdir(options.image_output_directory))
+    assert len(files) == 2 and all(f.endswith(".hdf5") for f in files)
+
+    # oracle side: same intervals, same read selection, oracle encoder
+    oracle = pu.load_restatement()
+    want = {}
+    for (start, end) in ((0, 2000), (2000, 4000), (4000, 5999)):
+        rs, re_ = max(0, start - 100), end + 100
+        sel = [d for d in reads if d["pos"] <= re_ and d["pos"] + sum(n for o, n in d["cigar"] if o in (0, 2, 3, 6, 7, 8)) >= rs and d["mapq"] >= 1]
+        pile = pu.FlatPileup(rs, re_, ref[rs:re_ + 1], sel)
+        want[f"chr20_{start}_{end}"] = pu.run_variant(oracle, pile, pu.make_params(start, end))
+    got_imgs = {}
+    for fn in files:
+        with h5.File(os.path.join(options.image_output_directory, fn)) as f:
+            for name in f.keys("summaries"):
+                got_imgs[name] = (f[f"summaries/{name}/images"], f[f"summaries/{name}/positions"],
+                                  f[f"summaries/{name}/candidates"][:, 0].tolist())
+    assert sorted(got_imgs) == sorted(k for k, v in want.items() if len(v["candidates"]))
+    total = 0
+    for name, (img, pos, cand) in got_imgs.items():
+        w = want[name]
+        assert cand == w["candidates"] and pos.tolist() == w["positions"].tolist()
+        assert np.array_equal(img, w["images"].astype(np.int64).astype(np.int8))
+        total += len(cand)
+    assert total > 20
+
+    sd = synthetic.variant_state_dict(seed=43, gain=2.0)
+    model_path = str(tmp_path / "model.pkl")
+    torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
+    opts = SimpleNamespace(model_path=model_path, batch_size=512, num_workers=0, use_hp_info=False, gpu=True,
+                           device_ids="0", callers_per_gpu=4, threads=8, quantized=False, dry=False)
+    run_inference(opts, options.image_output_directory, str(tmp_path / "pred"))
+    with h5.File(str(tmp_path / "pred" / "pepper_prediction.hdf")) as f:
+        got = np.concatenate([f[f"predictions/{b}/base_prediction"] for b in
+                              sorted(f.keys("predictions"), key=lambda s: int(s.split("_")[1]))])
+    # run_inference reads the image files in sorted order and their groups in name order
+    ordered = []
+    for fn in files:
+        with h5.File(os.path.join(options.image_output_directory, fn)) as f:
+            for name in f.keys("summaries"):
+                ordered.append(f[f"summaries/{name}/images"])
+    ref_probs = models_np.variant_forward(sd, np.concatenate(ordered))
+    assert got.shape == ref_probs.shape and np.abs(got - ref_probs).max() < 1e-4
+
+
+def _as_read(d):
+    from test_gpu_encoder import R
+    return R(d)
