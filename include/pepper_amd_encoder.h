@@ -73,6 +73,20 @@ int pa_encoder_get_results(pa_encoder* e, int64_t* positions, int32_t* depths, i
  * next call) so inference can consume them without a host round trip. */
 const int8_t* pa_encoder_device_images(pa_encoder* e);
 
+/* ------------------------------------------------------------------------------------------
+ * Polish summary encoder
+ * replaces: PEPPER.SummaryGenerator(ref_seq, chr, start, end).generate_summary(reads, start, end)
+ *   -> .image (uint8 rows of 10 features), .genomic_pos ((position, insert index) per row)
+ *   pepper/modules/headers/pybind_api.h:18-25; pepper/modules/src/pileup_summary/summary_generator.cpp:
+ *   16-32 (feature index), 47-121 (per-read walk), 274-306 (pixels), 370-393 (row order).
+ * pileup->region_start/end = the constructor's ref_start/ref_end; start_pos/end_pos = the
+ * arguments of generate_summary (identical in the reference's caller, AlignmentSummarizer.py:340-347).
+ * ------------------------------------------------------------------------------------------ */
+int pa_polish_encoder_generate_summary(pa_encoder* e, const pa_pileup* pileup, int64_t start_pos,
+                                       int64_t end_pos, int64_t* n_rows);
+/* HOST pointers: image uint8 [n_rows, 10], positions int64 [n_rows, 2]; either may be NULL. */
+int pa_polish_encoder_get_results(pa_encoder* e, uint8_t* image, int64_t* positions);
+
 #ifdef __cplusplus
 }
 #endif

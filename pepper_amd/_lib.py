@@ -61,6 +61,9 @@ SYMBOLS = [
     ("pa_encoder_get_results", ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_int64, ctypes.POINTER(c_int64)]),
     ("pa_encoder_device_images", c_void_p, [c_void_p]),
+    ("pa_polish_encoder_generate_summary", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int64,
+                                                          ctypes.POINTER(c_int64)]),
+    ("pa_polish_encoder_get_results", ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
 ]
 
 _lib = None

@@ -1,0 +1,82 @@
+"""Polish region -> 1000-row image chunks (inference branch).
+
+Mirrors /root/reference/pepper/modules/python/AlignmentSummarizer.py:18-56 (chunk_images) and
+:296-358 (read fetch, reservoir sampling to 1500 reads, reference fetch, SummaryGenerator,
+chunking).  SSW re-alignment (`realignment_flag`) is a separate striped Smith-Waterman stage
+upstream of the encoder and is out of scope: reads are encoded as given.
+"""
+import numpy as np
+
+from pepper_amd.polish import PEPPER
+from pepper_amd.polish.Options import ImageSizeOptions
+
+
+class AlingerOptions(object):
+    MAX_READS_IN_REGION = 1500     # pepper Options.py:27-29
+    RANDOM_SEED = 2719747673
+
+
+class AlignmentSummarizer:
+    def __init__(self, bam_handler, fasta_handler, chromosome_name, region_start, region_end):
+        self.bam_handler = bam_handler
+        self.fasta_handler = fasta_handler
+        self.chromosome_name = chromosome_name
+        self.region_start_position = region_start
+        self.region_end_position = region_end
+
+    @staticmethod
+    def chunk_images(summary, chunk_size, chunk_overlap):
+        """Rows -> chunks of chunk_size, the next chunk starting chunk_overlap rows before the end
+        of the previous one; the last chunk is padded with zero rows and (-1, -1) positions."""
+        image = np.asarray(summary.image, dtype=np.uint8).reshape(-1, ImageSizeOptions.IMAGE_HEIGHT)
+        pos = np.asarray(summary.genomic_pos, dtype=np.int64).reshape(-1, 2)
+        total = len(pos)
+        images, labels, positions, chunk_ids = [], [], [], []
+        chunk_start, chunk_id = 0, 0
+        chunk_end = min(total, chunk_size)
+        while True:
+            img = np.zeros((chunk_size, ImageSizeOptions.IMAGE_HEIGHT), np.uint8)
+            p = np.full((chunk_size, 2), -1, np.int64)
+            n = chunk_end - chunk_start
+            img[:n] = image[chunk_start:chunk_end]
+            p[:n] = pos[chunk_start:chunk_end]
+            images.append(img)
+            labels.append(np.zeros(chunk_size, np.uint8))
+            positions.append(p)
+            chunk_ids.append(chunk_id)
+            chunk_id += 1
+            if chunk_end == total:
+                break
+            chunk_start = chunk_end - chunk_overlap
+            chunk_end = min(total, chunk_start + chunk_size)
+        return images, labels, positions, chunk_ids
+
+    def create_summary(self, truth_bam_h1=None, truth_bam_h2=None, train_mode=False, realignment_flag=False):
+        if train_mode:
+            raise NotImplementedError("train_mode image generation is outside the inference path")
+        if realignment_flag:
+            raise NotImplementedError("SSW re-alignment is out of scope (SURVEY.md 2.2 P6)")
+        read_start = max(0, self.region_start_position)
+        read_end = self.region_end_position
+        all_reads = self.bam_handler.get_reads(self.chromosome_name, read_start, read_end, False, 0, 0)
+        total_reads = len(all_reads)
+        if total_reads == 0:
+            return [], [], [], []
+        if total_reads > AlingerOptions.MAX_READS_IN_REGION:
+            random = np.random.RandomState(AlingerOptions.RANDOM_SEED)
+            sample = []
+            for i, read in enumerate(all_reads):
+                if len(sample) < AlingerOptions.MAX_READS_IN_REGION:
+                    sample.append(read)
+                else:
+                    j = random.randint(0, i + 1)
+                    if j < AlingerOptions.MAX_READS_IN_REGION:
+                        sample[j] = read
+            all_reads = sample
+        ref_seq = self.fasta_handler.get_reference_sequence(self.chromosome_name, self.region_start_position,
+                                                            self.region_end_position + 1)
+        summary_generator = PEPPER.SummaryGenerator(ref_seq, self.chromosome_name, self.region_start_position,
+                                                    self.region_end_position)
+        summary_generator.generate_summary(all_reads, self.region_start_position, self.region_end_position)
+        return self.chunk_images(summary_generator, chunk_size=ImageSizeOptions.SEQ_LENGTH,
+                                 chunk_overlap=ImageSizeOptions.SEQ_OVERLAP)

@@ -98,3 +98,42 @@ def test_encoder_object_interface_and_edges():
     # empty pileup
     empty = pu.FlatPileup(5000, 5800, ref, [])
     assert _product(empty, params)["candidates"] == []
+
+
+def test_polish_encoder_matches_oracle():
+    """Polish summary encoder (parity-unpinned oracle: the reference build needs htslib headers):
+    insert columns, deletion-coverage quirk, REF_SKIP/PAD as gaps, 254 scaling truncation."""
+    from pepper_amd.polish.PEPPER import SummaryGenerator
+    oracle = pu.load_restatement()
+    for seed, kw in ((21, {}), (22, dict(ins_rate=0.04, del_rate=0.04)), (23, dict(skip_rate=0.01, eqx=True))):
+        rng = np.random.default_rng(seed)
+        ref = pu.random_reference(rng, 1201)
+        indels = {7300: ("I", "ACGTAC", 0.5), 7600: ("D", 9, 0.6), 7900: ("I", "T", 0.9)}
+        reads = pu.simulate_reads(rng, ref, 7000, 90, read_len=(200, 700), indel_sites=indels, **kw)
+        pile = pu.FlatPileup(7000, 8200, ref, reads)
+        want_img, want_pos = pu.run_polish_oracle(oracle, pile, 7000, 8200)
+        gen = SummaryGenerator(ref, "contig_1", 7000, 8200)
+        gen.generate_summary([R(d) for d in reads], 7000, 8200)
+        assert gen.image.shape == want_img.shape and len(gen.image) > 1201       # insert rows present
+        assert np.array_equal(gen.positions_array, want_pos)
+        assert np.array_equal(gen.image, want_img)
+        assert gen.genomic_pos[0] == (7000, 0)
+
+
+def test_polish_chunker():
+    from pepper_amd.polish.AlignmentSummarizer import AlignmentSummarizer
+
+    class S(object):
+        pass
+    s = S()
+    rows = 2300
+    s.image = (np.arange(rows * 10) % 251).astype(np.uint8).reshape(rows, 10)
+    s.genomic_pos = [(100 + i, 0) for i in range(rows)]
+    images, labels, positions, ids = AlignmentSummarizer.chunk_images(s, 1000, 50)
+    # chunk starts: 0, 950, 1900 ; last chunk holds rows 1900..2299 then padding
+    assert ids == [0, 1, 2] and all(im.shape == (1000, 10) for im in images)
+    assert np.array_equal(images[1][0], s.image[950]) and np.array_equal(images[2][399], s.image[2299])
+    assert (images[2][400:] == 0).all() and tuple(positions[2][400]) == (-1, -1) and tuple(positions[2][399]) == (2399, 0)
+    s.image, s.genomic_pos = s.image[:1000], s.genomic_pos[:1000]
+    images, _, _, ids = AlignmentSummarizer.chunk_images(s, 1000, 50)
+    assert ids == [0]
