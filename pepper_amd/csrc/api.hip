@@ -412,7 +412,7 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
         } else {
             LAUNCH_TRY(m, li == 0 ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
                        pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
-                                          NX, M, NX, r.K, 0, 0, 0, m->stream));
+                                          NX, (int)(np * T), NX, r.K, 0, 0, 0, T, (int)n, m->stream));
             LAUNCH_TRY(m, "lstm_rec", 2.0 * n * T * (4.0 * H) * H * 2,
                        pa::launch_lstm_rec(H, m->xp->f(), NX, r.w_hh->f(), y, 2 * H, (int)n, T, m->stream));
         }
@@ -425,13 +425,13 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     const int K1 = T * 2 * H;
     LAUNCH_TRY(m, "gemm_linear_1", 2.0 * n * m->L1 * K1,
                pa::launch_gemm_nt(pa::A_F32, cur, K1, m->lin[0].w->f(), K1, m->lin[0].b->f(), m->l1->f(),
-                                  m->L1, (int)n, m->L1, K1, 1, 0, 0, m->stream));
+                                  m->L1, (int)n, m->L1, K1, 1, 0, 0, 0, 0, m->stream));
     float* a = m->l1->f();
     float* b = m->l2->f();
     for (int i = 1; i < 5; ++i) {
         LAUNCH_TRY(m, "gemm_linear_2to5", 2.0 * n * m->L1 * m->L1,
                    pa::launch_gemm_nt(pa::A_F32, a, m->L1, m->lin[i].w->f(), m->L1, m->lin[i].b->f(), b,
-                                      m->L1, (int)n, m->L1, m->L1, 1, 0, 0, m->stream));
+                                      m->L1, (int)n, m->L1, m->L1, 1, 0, 0, 0, 0, m->stream));
         std::swap(a, b);
     }
     LAUNCH_TRY(m, "head_softmax", 2.0 * n * m->L1 * C,
@@ -524,7 +524,7 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
             const RecLayer& r = layers[l];
             LAUNCH_TRY(m, (stage == 0 && l == 0) ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
                        pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
-                                          NX, M, NX, r.K, 0, cur_rpb, cur_bs, m->stream));
+                                          NX, (int)(round_up(n, MT) * T), NX, r.K, 0, 0, cur_bs, T, (int)n, m->stream));
             float* y = ybuf[which];
             LAUNCH_TRY(m, "gru_rec", 2.0 * n * T * (3.0 * H) * H * 2,
                        pa::launch_gru_rec(H, m->xp->f(), NX, r.w_hh->f(), r.b_hn->f(),

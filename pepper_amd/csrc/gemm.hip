@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const typename AType<AT>::
                                                       const float* __restrict__ bias,
                                                       float* __restrict__ C, int ldc,
                                                       int M, int N, int K, int tiles_n, int nwg,
-                                                      int a_rpb, int64_t a_bstride, int tune) {
+                                                      int a_rpb, int64_t a_bstride, int tune, int frag_T, int frag_nb) {
     // The two co-resident workgroups of a CU share each SIMD's matrix pipe; with equal priority
     // they fall into lockstep and stall at their barriers together.  A static priority split
     // lets one run ahead so their bubbles interleave (MI355X_MICROARCH "Two waves per SIMD").
@@ -88,8 +88,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const typename AType<AT>::
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + r0 + 32 * i, n = n0 + r0 + 32 * i;
         const int mc = m < M ? m : M - 1, nc = n < N ? n : N - 1;   // clamp: tail rows are not stored
-        const size_t off = a_rpb > 0 ? (size_t)(mc / a_rpb) * a_bstride + (size_t)(mc % a_rpb) * lda
-                                     : (size_t)mc * lda;
+        size_t off;
+        if (frag_T > 0) {
+            // fragment-packed output: logical row m = (32-batch block, step t, batch-in-block) so that
+            // every 32-row MFMA tile is one step of 32 consecutive sequences (what the recurrent
+            // kernel's accumulator tile is); physical A row = batch * T + t, pad batches clamped
+            int b = (mc / (32 * frag_T)) * 32 + (mc & 31);
+            const int t = (mc >> 5) % frag_T;
+            b = b < frag_nb ? b : frag_nb - 1;
+            off = (size_t)b * (a_bstride > 0 ? (size_t)a_bstride : (size_t)frag_T * lda) + (size_t)t * lda;
+        } else {
+            off = a_rpb > 0 ? (size_t)(mc / a_rpb) * a_bstride + (size_t)(mc % a_rpb) * lda : (size_t)mc * lda;
+        }
         arow[i] = A + off;
         wrow[i] = W + (size_t)nc * ldw;
     }
@@ -162,6 +172,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const typename AType<AT>::
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (frag_T > 0) {
+        // C in MFMA fragment order: tile (row/32, col/32) = 4 chunks of [64 lanes][4 regs] floats, so
+        // the producer stores and the consumer (rnn.hip accumulator seed) loads 16 bytes per lane
+        const int ct_n = N >> 5;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = n0 + wn * 64 + n * 32 + li;
+            const float bv = (bias != nullptr && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int rt = (m0 + wm * 64 + m * 32) >> 5, ct = (n0 + wn * 64 + n * 32) >> 5;
+                if ((rt << 5) < M && (ct << 5) < N) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(C + ((size_t)rt * ct_n + ct) * 1024) + lane;
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        f32x4 v = {acc[m][n][4 * qd] + bv, acc[m][n][4 * qd + 1] + bv, acc[m][n][4 * qd + 2] + bv,
+                                   acc[m][n][4 * qd + 3] + bv};
+                        dst[qd * 64] = v;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = n0 + wn * 64 + n * 32 + li;
@@ -183,14 +217,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const typename AType<AT>::
 
 template <int AT>
 hipError_t launch_typed(const typename AType<AT>::type* A, int lda, const float* W, int ldw, const float* bias, float* C,
-                        int ldc, int M, int N, int K, int act, int a_rpb, int64_t a_bstride,
+                        int ldc, int M, int N, int K, int act, int a_rpb, int64_t a_bstride, int frag_T, int frag_nb,
                         hipStream_t stream) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int nwg = tiles_m * tiles_n;
     if (nwg == 0) return hipSuccess;
 #define PA_GEMM_LAUNCH(ACT_, KF_)                                                                   \
     hipLaunchKernelGGL((gemm_nt_kernel<AT, ACT_, KF_>), dim3(nwg), dim3(256), 0, stream, A, lda, W, ldw, \
-                       bias, C, ldc, M, N, K, tiles_n, nwg, a_rpb, a_bstride, pa::tune_flags())
+                       bias, C, ldc, M, N, K, tiles_n, nwg, a_rpb, a_bstride, pa::tune_flags(), frag_T, frag_nb)
     const bool kfull = (K % BK) == 0;
     if (act == 1) {
         if (kfull) PA_GEMM_LAUNCH(1, true); else PA_GEMM_LAUNCH(1, false);
@@ -207,7 +241,8 @@ namespace pa {
 
 hipError_t launch_gemm_nt(int a_type, const void* A, int lda, const float* W, int ldw,
                           const float* bias, float* C, int ldc, int M, int N, int K, int act,
-                          int a_rpb, int64_t a_bstride, hipStream_t stream) {
+                          int a_rpb, int64_t a_bstride, int frag_T, int frag_nb, hipStream_t stream) {
+    if (frag_T > 0 && ((M & 31) || (N & 31) || act != 0)) return hipErrorInvalidValue;
     // W rows are read 4 floats at a time: they must be 16-byte aligned and zero-padded to a
     // multiple of 4 columns (ldw >= round_up(K, 4)); the packer in api.hip guarantees this.
     const bool w_ok = !(ldw & 3) && !((uintptr_t)W & 15) && ldw >= ((K + 3) & ~3);
@@ -215,16 +250,16 @@ hipError_t launch_gemm_nt(int a_type, const void* A, int lda, const float* W, in
         case A_F32:
             if (!w_ok || (lda & 3) || (K & 3) || (a_bstride & 3) || ((uintptr_t)A & 15))
                 return hipErrorInvalidValue;
-            return launch_typed<A_F32>((const float*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, stream);
+            return launch_typed<A_F32>((const float*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, frag_T, frag_nb, stream);
         case A_F32_SCALAR:  // unaligned / K % 4 != 0 float rows (e.g. [B,33,26] float images)
             if (!w_ok) return hipErrorInvalidValue;
-            return launch_typed<A_F32_SCALAR>((const float*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, stream);
+            return launch_typed<A_F32_SCALAR>((const float*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, frag_T, frag_nb, stream);
         case A_I8:
             if (!w_ok) return hipErrorInvalidValue;
-            return launch_typed<A_I8>((const int8_t*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, stream);
+            return launch_typed<A_I8>((const int8_t*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, frag_T, frag_nb, stream);
         case A_U8:
             if (!w_ok) return hipErrorInvalidValue;
-            return launch_typed<A_U8>((const uint8_t*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, stream);
+            return launch_typed<A_U8>((const uint8_t*)A, lda, W, ldw, bias, C, ldc, M, N, K, act, a_rpb, a_bstride, frag_T, frag_nb, stream);
         default:
             return hipErrorInvalidValue;
     }

@@ -17,9 +17,12 @@ int tune_flags();
 
 // gemm.hip: C[M,N] = act(A[M,K] W[N,K]^T + bias); act 0 = identity, 1 = SELU.
 // a_rpb > 0 remaps logical row m to A + (m / a_rpb) * a_bstride + (m % a_rpb) * lda.
+// frag_T > 0 selects the recurrent-seed form: A is [frag_nb, frag_T, K] sequences, M = padded
+// batch * frag_T logical rows ordered (32-batch block, step, batch in block), and C is written in
+// MFMA fragment order [M/32][N/32][4][64 lanes][4] (see rnn.hip), bias folded in.
 hipError_t launch_gemm_nt(int a_type, const void* A, int lda, const float* W, int ldw,
                           const float* bias, float* C, int ldc, int M, int N, int K, int act,
-                          int a_rpb, int64_t a_bstride, hipStream_t stream);
+                          int a_rpb, int64_t a_bstride, int frag_T, int frag_nb, hipStream_t stream);
 
 // rnn.hip: Xp [Bpad*T, ldx], Y [Bpad*T, ldy]; Bpad = B rounded up to 64 rows (workspace buffers).
 // Packed recurrent weights: [dir][G*H/32][H/8][64 lanes][4] (see pack_rec_weights in api.hip).

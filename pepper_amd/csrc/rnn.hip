@@ -31,87 +31,6 @@ PA_DEV void decode_block(int bid, int& dir, int& btile) {
     btile = q * 4 + (xcd & 3);
 }
 
-template <int H>
-__global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_kernel(const float* __restrict__ Xp, int ldx,
-                                                               const float* __restrict__ Wp,
-                                                               float* __restrict__ Y, int ldy, int B,
-                                                               int T) {
-    constexpr int LDH = H + 4, KB = H / 8, NT = H / 32;
-    extern __shared__ __attribute__((aligned(16))) float hs[];  // [MT][LDH]
-
-    int dir, btile;
-    decode_block(blockIdx.x, dir, btile);
-    const int b0 = btile * MT;
-    if (b0 >= B) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, u = tid >> 6;
-    const int li = lane & 31, hf = lane >> 5;
-
-    for (int idx = tid; idx < MT * LDH; idx += blockDim.x) hs[idx] = 0.0f;
-
-    f32x16 c[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[m][r] = 0.0f;
-
-    // Xp / Y are workspace buffers allocated for a batch padded to a multiple of MT rows, so the
-    // tail tile needs no clamping: rows are independent and pad rows are never read back.
-    // row(m, r) = b0 + 4*hf + 32*m + (r & 3) + 8*(r >> 2): per-lane base + wave-uniform deltas.
-    const int col = u * 32 + li;
-    const size_t lrow = (size_t)(b0 + 4 * hf) * T;
-    const float* xl = Xp + lrow * ldx + dir * 4 * H + col;
-    float* yl = Y + lrow * ldy + dir * H + col;
-    float* hl = hs + 4 * hf * LDH + col;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (size_t)dir * (4 * NT) * KB * 64 + lane;
-    __syncthreads();
-
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? T - 1 - step : step;
-        f32x16 acc[2][4];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[m][g][r] = xl[((size_t)(32 * m + (r & 3) + 8 * (r >> 2)) * T + t) * ldx + g * H];
-
-        const float* hrow = hs + li * LDH + hf * 4;
-#pragma unroll 2
-        for (int kb = 0; kb < KB; ++kb) {
-            f32x4 a[2], b[4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const f32x4*>(hrow + m * 32 * LDH + kb * 8);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b[g] = wp[((size_t)(g * NT + u) * KB + kb) * 64];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m][g] = mfma32(a[m][s], b[g][s], acc[m][g]);
-        }
-        __syncthreads();  // every wave has finished reading h_{t-1}
-
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float ig = sigmoid_f(acc[m][0][r]);
-                const float fg = sigmoid_f(acc[m][1][r]);
-                const float gg = tanhf(acc[m][2][r]);
-                const float og = sigmoid_f(acc[m][3][r]);
-                const float cn = fg * c[m][r] + ig * gg;
-                c[m][r] = cn;
-                const float hv = og * tanhf(cn);
-                hl[(32 * m + (r & 3) + 8 * (r >> 2)) * LDH] = hv;
-                yl[((size_t)(32 * m + (r & 3) + 8 * (r >> 2)) * T + t) * ldy] = hv;
-            }
-        __syncthreads();  // h_t visible to every wave
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Ping-pong LSTM step loop (the production variant kernel).
 //
@@ -165,14 +84,15 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_pp_kernel(const float
     // row(r) = b0 + 32*grp + 4*hf + (r & 3) + 8*(r >> 2);  col(ut) = 64*wq + 32*ut + li
     const size_t urow = (size_t)(b0 + 32 * grp) * T;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(KX ? bias + dir * 4 * H + 64 * wq : Xp + urow * ldx + dir * 4 * H + 64 * wq), 0,
+        const_cast<float*>(KX ? bias + dir * 4 * H + 64 * wq
+                              : Xp + (size_t)((b0 >> 5) + grp) * T * (ldx >> 5) * 1024), 0,
         0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs =
         __builtin_amdgcn_make_buffer_rsrc(Y + urow * ldy + dir * H + 64 * wq, 0, 0x7fffffff, 0x00020000);
     // fragment (g, ut, kb) of this wave lives at byte ((g*NT + ut) * KB + kb) * 1024 + lane * 16
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(Wp + ((size_t)dir * (4 * NT) + 2 * wq) * KB * 256), 0, 0x7fffffff, 0x00020000);
-    const unsigned xoff = KX ? li * 4u : ((unsigned)(4 * hf * T) * ldx + li) * 4u;
+    const unsigned xoff = KX ? li * 4u : lane * 16u;
     const unsigned yoff = ((unsigned)(4 * hf * T) * ldy + li) * 4u;
     const unsigned woff = lane * 16u;
     float* hl = hs + (32 * grp + 4 * hf) * LDH + 64 * wq + li;
@@ -190,10 +110,17 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_pp_kernel(const float
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[ut][g][r] = bv;
                 } else {
+                    // Xp is in MFMA fragment order (gemm.hip): tile (step t of this 32-row half,
+                    // column tile) = 4 x 1 KiB chunks, chunk qd = accumulator registers 4qd..4qd+3
+                    const unsigned ct = (unsigned)(dir * (4 * NT) + g * NT + 2 * wq + ut);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned so = ((unsigned)(((r & 3) + 8 * (r >> 2)) * T + t) * ldx + g * H + 32 * ut) * 4u;
-                        acc[ut][g][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff, so, 0));
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const unsigned so = (((unsigned)t * (ldx >> 5) + ct) * 4u + qd) * 1024u;
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
+                        acc[ut][g][4 * qd] = v.x;
+                        acc[ut][g][4 * qd + 1] = v.y;
+                        acc[ut][g][4 * qd + 2] = v.z;
+                        acc[ut][g][4 * qd + 3] = v.w;
                     }
                 }
             }
@@ -213,14 +140,12 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_pp_kernel(const float
             }
         }
     };
-    auto load_kb = [&](int kb, f32x4 (&b)[2][4], f32x4& a) {   // both unit tiles of one k-block
+    // quad q = (k-block q >> 1, unit tile q & 1): the 4 gate fragments one A fragment meets
+    auto load_quad = [&](int q, f32x4 (&b)[4]) {
 #pragma unroll
-        for (int ut = 0; ut < 2; ++ut)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                b[ut][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                         wrs, woff, (unsigned)((g * NT + ut) * KB + kb) * 1024u, 0));
-        a = *reinterpret_cast<const f32x4*>(hrow + kb * 8);
+        for (int g = 0; g < 4; ++g)
+            b[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 wrs, woff, (unsigned)((g * NT + (q & 1)) * KB + (q >> 1)) * 1024u, 0));
     };
 
     __syncthreads();                      // zero fill complete before x is staged on top of it
@@ -233,25 +158,50 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_pp_kernel(const float
             // ---------------- MFMA phase of step (i - grp) / 2 ----------------
             if (((i - grp) >> 1) < T) {
                 if (tune & 2) __builtin_amdgcn_s_setprio(1);   // feed the matrix pipe first
-                // double buffer at k-block granularity: the 8 weight fragments + the A fragment of
-                // k-block kb+1 are in flight while the 32 MFMAs (2048 pipe cycles) of kb issue
-                f32x4 bw[2][2][4], af[2];
-                load_kb(0, bw[0], af[0]);
-                for (int kb = 0; kb < KB; kb += 2) {
+                // 3-deep ring of quads: two quads (2 x 16 MFMAs = 2048 pipe cycles) are in flight
+                // ahead of the one being consumed; the A fragment of the next k-block is read one
+                // quad ahead.  sched_barrier pins the issue order (the scheduler otherwise sinks the
+                // loads next to their use and this lone MFMA-phase wave eats every L2 round trip).
+                constexpr int NQ = 2 * KB;
+                f32x4 ring[3][4], a_cur, a_nxt;
+                load_quad(0, ring[0]);
+                load_quad(1, ring[1]);
+                a_cur = *reinterpret_cast<const f32x4*>(hrow);
+                a_nxt = a_cur;
+                for (int q0 = 0; q0 < NQ; q0 += 6) {
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        if (kb + p + 1 < KB) load_kb(kb + p + 1, bw[p ^ 1], af[p ^ 1]);
-                        // pin the prefetch ahead of this k-block's MFMAs: left alone, the scheduler
-                        // sinks the loads to just before their use and the lone MFMA-phase wave of
-                        // the SIMD stalls on every L2 round trip
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int ut = 0; ut < 2; ++ut)
+                    for (int p = 0; p < 6; ++p) {
+                        const int q = q0 + p;
+                        if (q < NQ) {
+                            if (q + 2 < NQ) load_quad(q + 2, ring[(p + 2) % 3]);
+                            if ((p & 1) == 0 && q + 2 < NQ)
+                                a_nxt = *reinterpret_cast<const f32x4*>(hrow + ((q >> 1) + 1) * 8);
 #pragma unroll
                             for (int s = 0; s < 4; ++s)
 #pragma unroll
                                 for (int g = 0; g < 4; ++g)
-                                    acc[ut][g] = mfma32(af[p][s], bw[p][ut][g][s], acc[ut][g]);
+                                    acc[p & 1][g] = mfma32(a_cur[s], ring[p % 3][g][s], acc[p & 1][g]);
+                            if (p & 1) a_cur = a_nxt;
+                            // Issue order inside the quad: ONE memory instruction per MFMA gap.  A
+                            // VMEM issue costs this wave ~60 cycles; back to back, only the first
+                            // hides in the shadow of the preceding 64-cycle MFMA and the rest stall
+                            // the matrix pipe (measured: 75 % -> MfmaUtil with block issue).
+                            if (q + 2 < NQ) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                                }
+                                if ((p & 1) == 0) {
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+                                } else {
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
                 if (tune & 2) __builtin_amdgcn_s_setprio(0);
@@ -315,16 +265,29 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void gru_rec_kernel(const float* __
     // uses raw buffer descriptors = uniform base + one per-lane offset + uniform soffset
     // (see lstm_rec_pp_kernel).  row(m, r) = b0 + 4*hf + 32*m + (r & 3) + 8*(r >> 2)
     const size_t urow = (size_t)b0 * T;
+    // Xp is in MFMA fragment order (gemm.hip): row tile = (32-batch block, step), 4 x 1 KiB chunks
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(Xp + urow * ldx + dir * 3 * H + u * 32), 0, 0x7fffffff, 0x00020000);
+        const_cast<float*>(Xp + (size_t)(b0 >> 5) * T * (ldx >> 5) * 1024), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs =
         __builtin_amdgcn_make_buffer_rsrc(Y + urow * ldy + dir * H + u * 32, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(Wp + ((size_t)dir * (3 * NT) + u) * KB * 256), 0, 0x7fffffff, 0x00020000);
-    const unsigned xoff = ((unsigned)(4 * hf * T) * ldx + li) * 4u;
+    const unsigned xoff = lane * 16u;
     const unsigned yoff = ((unsigned)(4 * hf * T) * ldy + li) * 4u;
     const unsigned woff = lane * 16u;
     const size_t lb = (size_t)(b0 + 4 * hf);
+    auto load_xp = [&](int m, int t, int g, f32x16& dst) {
+        const unsigned ct = (unsigned)(dir * (3 * NT) + g * NT + u);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const unsigned so = (((unsigned)(m * T + t) * (ldx >> 5) + ct) * 4u + qd) * 1024u;
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
+            dst[4 * qd] = v.x;
+            dst[4 * qd + 1] = v.y;
+            dst[4 * qd + 2] = v.z;
+            dst[4 * qd + 3] = v.w;
+        }
+    };
     float* hl = hs + 4 * hf * LDH + col;
 
     f32x16 hreg[2];
@@ -351,14 +314,12 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void gru_rec_kernel(const float* __
         const int t = dir ? T - 1 - step : step;
         f32x16 acc[2][3];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) {
+            load_xp(m, t, 0, acc[m][0]);
+            load_xp(m, t, 1, acc[m][1]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned so = ((unsigned)((32 * m + (r & 3) + 8 * (r >> 2)) * T + t) * ldx) * 4u;
-                acc[m][0][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff, so, 0));
-                acc[m][1][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff, so + H * 4u, 0));
-                acc[m][2][r] = bn;
-            }
+            for (int r = 0; r < 16; ++r) acc[m][2][r] = bn;
+        }
 
         const float* hrow = hs + li * LDH + hf * 4;
         f32x4 bw[2][3], a[2][2];
@@ -385,12 +346,13 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void gru_rec_kernel(const float* __
         __syncthreads();
 
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) {
+            f32x16 xnv;
+            load_xp(m, t, 2, xnv);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
-                const unsigned so = ((unsigned)(dr * T + t) * ldx + 2 * H) * 4u;
-                const float xn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff, so, 0));
+                const float xn = xnv[r];
                 const float rg = fast_sigmoid(acc[m][0][r]);
                 const float zg = fast_sigmoid(acc[m][1][r]);
                 const float ng = fast_tanh(xn + rg * acc[m][2][r]);
@@ -400,6 +362,7 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void gru_rec_kernel(const float* __
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), yrs, yoff,
                                                       ((unsigned)(dr * T + t) * ldy) * 4u, 0);
             }
+        }
         __syncthreads();
     }
 
@@ -432,26 +395,11 @@ int tune_flags() {
 hipError_t launch_lstm_rec(int H, const float* Xp, int ldx, const float* Wp, float* Y, int ldy,
                            int B, int T, hipStream_t stream) {
     if (B <= 0) return hipSuccess;
+    if (H != 256) return hipErrorInvalidValue;   // the reference hard-codes lstm_*_hidden_size = 256
     const int grid = rec_grid(B);
-    static const bool use_pp = [] {
-        const char* e = getenv("PA_LSTM_PP");
-        return !(e && e[0] == '0');
-    }();
-    if (H == 256 && use_pp) {
-        const size_t lds = ((size_t)MT * (256 + 4) + 8 * 2 * 16 * 64) * sizeof(float);  // h + c
-        hipLaunchKernelGGL((lstm_rec_pp_kernel<256, 0>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
-                           (const int8_t*)nullptr, 0, (const float*)nullptr, Wp, Y, ldy, B, T, tune_flags());
-    } else if (H == 256) {
-        const size_t lds = (size_t)MT * (256 + 4) * sizeof(float);
-        hipLaunchKernelGGL((lstm_rec_kernel<256>), dim3(grid), dim3(512), lds, stream, Xp, ldx, Wp, Y,
-                           ldy, B, T);
-    } else if (H == 128) {
-        const size_t lds = (size_t)MT * (128 + 4) * sizeof(float);
-        hipLaunchKernelGGL((lstm_rec_kernel<128>), dim3(grid), dim3(256), lds, stream, Xp, ldx, Wp, Y,
-                           ldy, B, T);
-    } else {
-        return hipErrorInvalidValue;
-    }
+    const size_t lds = ((size_t)MT * (256 + 4) + 8 * 2 * 16 * 64) * sizeof(float);  // h + c
+    hipLaunchKernelGGL((lstm_rec_pp_kernel<256, 0>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
+                       (const int8_t*)nullptr, 0, (const float*)nullptr, Wp, Y, ldy, B, T, tune_flags());
     return hipGetLastError();
 }
 
