@@ -157,18 +157,43 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const typename AType<AT>::
     __syncthreads();
     read_half(0, 0, fa[0], fb[0]);
 
+    // The loop body is branch free (tail iterations redo harmless loads / LDS writes into buffers
+    // nobody reads) so each half is one scheduling region, and sched_group_barrier spreads its memory
+    // instructions ONE PER MFMA GAP: a VMEM issue costs the wave ~60 cycles, an LDS write ~13; issued
+    // as a block they stall this wave's MFMA stream, and the co-resident workgroup -- running the
+    // same code in lockstep -- does not fill the hole.
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         read_half(buf, 1, fa[1], fb[1]);
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        if (kt + 2 < nk) gload(kt + 2);
-        __builtin_amdgcn_sched_barrier(0);
+        lstore(buf ^ 1);
+        gload(kt + 2 < nk ? kt + 2 : nk - 1);
         mma_half(fa[0], fb[0]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read  (fragments of half 1)
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write (tile kt+1 -> other buffer)
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (tile kt+2)
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        if (kt + 1 < nk) read_half(buf ^ 1, 0, fa[0], fb[0]);
-        __builtin_amdgcn_sched_barrier(0);
+        read_half(buf ^ 1, 0, fa[0], fb[0]);
         mma_half(fa[1], fb[1]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 
