@@ -44,6 +44,15 @@ PA_DEV float selu_f(float x) {
     return scale * (x > 0.0f ? x : alpha * expm1f(x));
 }
 
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  Unlike
+// __syncthreads() it does not drain vmcnt, so global loads / stores issued before it (next-step
+// accumulator seeds, y stores) stay in flight across the barrier.
+PA_DEV void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Bijective XCD-aware remap of a 1-D grid: workgroup b runs on XCD b % 8 (observed, speed
 // only); give every XCD a contiguous run of logical tiles so neighbours share L2 lines.
 PA_DEV int xcd_swizzle(int bid, int nwg) {

@@ -32,30 +32,40 @@ PA_DEV void decode_block(int bid, int& dir, int& btile) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Ping-pong LSTM step loop (the production variant kernel).
+// LSTM step loop (the production variant kernel).
 //
-// The 64 batch rows of a workgroup are split into two independent 32-row halves; waves 0..NW/2-1
-// own half 0, the rest half 1.  Time is cut into intervals separated by one workgroup barrier:
-// in even intervals half 0 runs its MFMA phase (h_{t-1} W_hh^T) while half 1 runs its gate phase
-// (sigmoid/tanh, cell update, h_t -> LDS + HBM, next step's Xp -> accumulators), in odd intervals
-// the roles swap.  Every SIMD hosts one wave of each half, so the matrix pipe always has exactly
-// one wave feeding it and the VALU/memory work of the gate phase is hidden behind it.
-// A wave owns 64 hidden units (two 32-column tiles) x 4 gates for its 32 rows = 8 accumulators.
-// W_hh fragments stream from L2 through a 3-deep register ring (two "quads" of 4 gate fragments
-// in flight ahead of the one being consumed), so the pipe never waits for an L2 round trip.
+// Measured facts that shaped it (s_memtime stamps, tools/phase_timing.py, profiles/r01_*):
+//  * v_mfma_f32_32x32x2_f32 shares the SIMD's FMA datapath with VALU: while one wave streams MFMAs,
+//    the SIMD issues only about ONE other instruction per 64-cycle MFMA slot, whichever wave it
+//    comes from and whatever its priority.  A "ping-pong" split (one half of the rows in its MFMA
+//    phase while the other half does gate math) therefore does not hide the gate phase -- its
+//    ~1.3k instructions stretched to 81k cycles and set the step time.  So all waves run the two
+//    phases in lockstep: MFMA phase (every non-MFMA instruction placed in its own MFMA gap), barrier,
+//    gate phase at the full VALU rate with the matrix pipe idle (~5 % of a step), barrier.
+//  * a VMEM issue costs the issuing wave ~60 cycles: loads are spread one per MFMA gap
+//    (sched_group_barrier), never issued as a block.
+//  * hipcc hoists 64-bit per-lane addresses out of the step loop and spills: all global traffic uses
+//    raw buffer descriptors (uniform base + one lane offset + SGPR soffset).
+//
+// Workgroup = 64 batch rows x one direction, H/32 waves; wave u owns hidden units [32u, 32u+32) for
+// all 4 gates and both 32-row tiles (8 accumulators = 128 VGPRs), so i/f/g/o of one (row, unit) sit
+// in the same lane and register index and the cell update is lane-local.  h_{t-1} lives in LDS (the
+// MFMA A operand, padded rows = conflict-free ds_read_b128), the cell state in LDS (lane-contiguous,
+// touched only in the gate phase).  W_hh fragments stream from L2 through a 3-deep register ring.
 // KX > 0 fuses the layer's input projection: the int8 summary row x_t (F <= KX features, zero
-// padded) is converted to f32 in the gate phase and stored next to h_{t-1} in the same LDS row, so
-// the MFMA phase contracts over K = H + KX against the concatenated [W_hh | W_ih] fragments and
-// the accumulators start from the bias -- no Xp round trip through HBM for the first layer.
+// padded) is converted to f32 in the gate phase and stored next to h in the same LDS row, so the
+// MFMA phase contracts over K = H + KX against the concatenated [W_hh | W_ih] fragments and the
+// accumulators start from the bias -- no Xp round trip through HBM for the first layer.
+// Otherwise Xp (gate pre-activations, MFMA fragment order, written by gemm.hip) seeds the
+// accumulators; its loads are issued from the gate phase, chunk by chunk as registers free up.
 template <int H, int KX>
-__global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_pp_kernel(const float* __restrict__ Xp, int ldx,
-                                                                     const int8_t* __restrict__ Xi, int F,
-                                                                     const float* __restrict__ bias,
-                                                                     const float* __restrict__ Wp,
-                                                                     float* __restrict__ Y, int ldy,
-                                                                     int B, int T, int tune) {
+__global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_kernel(const float* __restrict__ Xp, int ldx,
+                                                                  const int8_t* __restrict__ Xi, int F,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ Wp,
+                                                                  float* __restrict__ Y, int ldy, int B, int T,
+                                                                  unsigned long long* __restrict__ dbg) {
     constexpr int KT = H + KX, LDH = KT + 4, KB = KT / 8, NT = H / 32, NW = H / 32;
-    static_assert(KB % 2 == 0, "k-blocks are consumed in pairs");
     extern __shared__ __attribute__((aligned(16))) float hs[];  // [MT][LDH] = [h | x | pad], then c
 
     int dir, btile;
@@ -64,177 +74,170 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_pp_kernel(const float
     if (b0 >= B) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave / (NW / 2);      // which 32-row half
-    const int wq = wave % (NW / 2);       // owns unit tiles 2*wq, 2*wq+1
+    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's 32-unit tile
     const int li = lane & 31, hf = lane >> 5;
 
-    // cell state lives in LDS ([wave][ut][r][lane], lane-contiguous = conflict free): it is only
-    // touched in the gate phase, and keeping it out of the VGPR file leaves room for the 128
-    // accumulator registers plus the weight prefetch buffers without spilling.
-    float* cs = hs + MT * LDH + wave * (2 * 16 * 64) + lane;
+    float* cs = hs + MT * LDH + u * (2 * 16 * 64) + lane;      // [wave][m][r][lane]
     for (int idx = tid; idx < MT * LDH + NW * 2 * 16 * 64; idx += blockDim.x) hs[idx] = 0.0f;
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][4];   // [row tile][gate]
 
-    // Global traffic goes through raw buffer descriptors: a wave-uniform base (SGPR resource), ONE
-    // 32-bit per-lane byte offset (VGPR) and a wave-uniform byte offset (SGPR soffset) per access,
-    // so the 128 + 32 + 32 addresses of a step cost no VGPRs (hipcc otherwise hoists 64-bit
-    // per-lane addresses out of the step loop and spills hundreds of registers).
-    // row(r) = b0 + 32*grp + 4*hf + (r & 3) + 8*(r >> 2);  col(ut) = 64*wq + 32*ut + li
-    const size_t urow = (size_t)(b0 + 32 * grp) * T;
+    // row(m, r) = b0 + 32*m + 4*hf + (r & 3) + 8*(r >> 2);  col = 32*u + li
+    const size_t urow = (size_t)b0 * T;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(KX ? bias + dir * 4 * H + 64 * wq
-                              : Xp + (size_t)((b0 >> 5) + grp) * T * (ldx >> 5) * 1024), 0,
+        const_cast<float*>(KX ? bias + dir * 4 * H + 32 * u : Xp + (size_t)(b0 >> 5) * T * (ldx >> 5) * 1024), 0,
         0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs =
-        __builtin_amdgcn_make_buffer_rsrc(Y + urow * ldy + dir * H + 64 * wq, 0, 0x7fffffff, 0x00020000);
-    // fragment (g, ut, kb) of this wave lives at byte ((g*NT + ut) * KB + kb) * 1024 + lane * 16
+        __builtin_amdgcn_make_buffer_rsrc(Y + urow * ldy + dir * H + 32 * u, 0, 0x7fffffff, 0x00020000);
+    // fragment (g, kb) of this wave lives at byte ((g*NT + u) * KB + kb) * 1024 + lane * 16
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(Wp + ((size_t)dir * (4 * NT) + 2 * wq) * KB * 256), 0, 0x7fffffff, 0x00020000);
+        const_cast<float*>(Wp + (size_t)dir * (4 * NT) * KB * 256), 0, 0x7fffffff, 0x00020000);
     const unsigned xoff = KX ? li * 4u : lane * 16u;
     const unsigned yoff = ((unsigned)(4 * hf * T) * ldy + li) * 4u;
     const unsigned woff = lane * 16u;
-    float* hl = hs + (32 * grp + 4 * hf) * LDH + 64 * wq + li;
-    const float* hrow = hs + (32 * grp + li) * LDH + hf * 4;
+    float* hl = hs + 4 * hf * LDH + 32 * u + li;
+    const float* hrow = hs + li * LDH + hf * 4;
 
-    // accumulator seed of a step: Xp row (unfused) or the per-column bias (fused)
-    auto load_seed = [&](int t) {
+    // accumulator seed of (row tile m, register chunk qd) for step t
+    auto seed_chunk = [&](int m, int qd, int t) {
 #pragma unroll
-        for (int ut = 0; ut < 2; ++ut)
+        for (int g = 0; g < 4; ++g) {
+            if (KX) {
+                const float bv = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff, (unsigned)(g * H) * 4u, 0));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (KX) {
-                    const float bv = __builtin_bit_cast(
-                        float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff, (unsigned)(g * H + 32 * ut) * 4u, 0));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[ut][g][r] = bv;
-                } else {
-                    // Xp is in MFMA fragment order (gemm.hip): tile (step t of this 32-row half,
-                    // column tile) = 4 x 1 KiB chunks, chunk qd = accumulator registers 4qd..4qd+3
-                    const unsigned ct = (unsigned)(dir * (4 * NT) + g * NT + 2 * wq + ut);
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        const unsigned so = (((unsigned)t * (ldx >> 5) + ct) * 4u + qd) * 1024u;
-                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
-                        acc[ut][g][4 * qd] = v.x;
-                        acc[ut][g][4 * qd + 1] = v.y;
-                        acc[ut][g][4 * qd + 2] = v.z;
-                        acc[ut][g][4 * qd + 3] = v.w;
-                    }
-                }
-            }
-    };
-    // fused only: this half's 32 x KX input slab of time t -> LDS columns [H, H+KX)
-    auto stage_x = [&](int t) {
-        if (KX) {
-            const int gtid = (wave % (NW / 2)) * 64 + lane;
-#pragma unroll
-            for (int k = 0; k < (32 * KX) / (NW / 2 * 64); ++k) {
-                const int e = gtid + k * (NW / 2 * 64);
-                const int row = e / KX, f = e % KX;
-                int brow = b0 + 32 * grp + row;
-                brow = brow < B ? brow : B - 1;
-                const float v = f < F ? (float)Xi[((size_t)brow * T + t) * F + f] : 0.0f;
-                hs[(32 * grp + row) * LDH + H + f] = v;
+                for (int e = 0; e < 4; ++e) acc[m][g][4 * qd + e] = bv;
+            } else {
+                const unsigned ct = (unsigned)(dir * (4 * NT) + g * NT + u);
+                const unsigned so = (((unsigned)(m * T + t) * (ldx >> 5) + ct) * 4u + qd) * 1024u;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
+                acc[m][g][4 * qd] = v.x;
+                acc[m][g][4 * qd + 1] = v.y;
+                acc[m][g][4 * qd + 2] = v.z;
+                acc[m][g][4 * qd + 3] = v.w;
             }
         }
     };
-    // quad q = (k-block q >> 1, unit tile q & 1): the 4 gate fragments one A fragment meets
-    auto load_quad = [&](int q, f32x4 (&b)[4]) {
+    // fused only: the 64 x KX input slab of time t -> LDS columns [H, H+KX); the byte loads are
+    // issued at the start of the gate phase and converted / stored at its end
+    constexpr int XN = KX ? (MT * KX) / (NW * 64) : 1;
+    int xv[XN];
+    auto x_load = [&](int t) {
+        if (KX) {
+#pragma unroll
+            for (int k = 0; k < XN; ++k) {
+                const int e = tid + k * (NW * 64);
+                const int row = e / KX, f = e % KX;
+                int brow = b0 + row;
+                brow = brow < B ? brow : B - 1;
+                xv[k] = f < F ? (int)Xi[((size_t)brow * T + t) * F + f] : 0;
+            }
+        }
+    };
+    auto x_store = [&]() {
+        if (KX) {
+#pragma unroll
+            for (int k = 0; k < XN; ++k) {
+                const int e = tid + k * (NW * 64);
+                hs[(e / KX) * LDH + H + e % KX] = (float)xv[k];
+            }
+        }
+    };
+    struct Frag { f32x4 b[4], a[2]; };
+    auto load_kb = [&](int kb, Frag& fr) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            b[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                 wrs, woff, (unsigned)((g * NT + (q & 1)) * KB + (q >> 1)) * 1024u, 0));
+            fr.b[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                    wrs, woff, (unsigned)((g * NT + u) * KB + kb) * 1024u, 0));
+#pragma unroll
+        for (int m = 0; m < 2; ++m) fr.a[m] = *reinterpret_cast<const f32x4*>(hrow + m * 32 * LDH + kb * 8);
     };
 
     __syncthreads();                      // zero fill complete before x is staged on top of it
-    load_seed(dir ? T - 1 : 0);
-    stage_x(dir ? T - 1 : 0);
+    {
+        const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) seed_chunk(m, qd, t0);
+        x_load(t0);
+        x_store();
+    }
     __syncthreads();
 
-    for (int i = 0; i <= 2 * T; ++i) {
-        if ((i & 1) == grp) {
-            // ---------------- MFMA phase of step (i - grp) / 2 ----------------
-            if (((i - grp) >> 1) < T) {
-                if (tune & 2) __builtin_amdgcn_s_setprio(1);   // feed the matrix pipe first
-                // 3-deep ring of quads: two quads (2 x 16 MFMAs = 2048 pipe cycles) are in flight
-                // ahead of the one being consumed; the A fragment of the next k-block is read one
-                // quad ahead.  sched_barrier pins the issue order (the scheduler otherwise sinks the
-                // loads next to their use and this lone MFMA-phase wave eats every L2 round trip).
-                constexpr int NQ = 2 * KB;
-                f32x4 ring[3][4], a_cur, a_nxt;
-                load_quad(0, ring[0]);
-                load_quad(1, ring[1]);
-                a_cur = *reinterpret_cast<const f32x4*>(hrow);
-                a_nxt = a_cur;
-                for (int q0 = 0; q0 < NQ; q0 += 6) {
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        const bool stamp = dbg != nullptr && blockIdx.x == 8 && lane == 0;
+        if (stamp) dbg[(u * 80 + 2 * step) * 2] = __builtin_amdgcn_s_memtime();
+        // ---------------- MFMA phase: acc += [h | x] * [W_hh | W_ih]^T ----------------
+        {
+            Frag ring[3];
+            load_kb(0, ring[0]);
+            load_kb(1, ring[1]);
+            for (int k0 = 0; k0 < KB; k0 += 3) {
 #pragma unroll
-                    for (int p = 0; p < 6; ++p) {
-                        const int q = q0 + p;
-                        if (q < NQ) {
-                            if (q + 2 < NQ) load_quad(q + 2, ring[(p + 2) % 3]);
-                            if ((p & 1) == 0 && q + 2 < NQ)
-                                a_nxt = *reinterpret_cast<const f32x4*>(hrow + ((q >> 1) + 1) * 8);
+                for (int p = 0; p < 3; ++p) {
+                    const int kb = k0 + p;
+                    if (kb < KB) {
+                        if (kb + 2 < KB) load_kb(kb + 2, ring[(p + 2) % 3]);
 #pragma unroll
-                            for (int s = 0; s < 4; ++s)
+                        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                                for (int g = 0; g < 4; ++g)
-                                    acc[p & 1][g] = mfma32(a_cur[s], ring[p % 3][g][s], acc[p & 1][g]);
-                            if (p & 1) a_cur = a_nxt;
-                            // Issue order inside the quad: ONE memory instruction per MFMA gap.  A
-                            // VMEM issue costs this wave ~60 cycles; back to back, only the first
-                            // hides in the shadow of the preceding 64-cycle MFMA and the rest stall
-                            // the matrix pipe (measured: 75 % -> MfmaUtil with block issue).
-                            if (q + 2 < NQ) {
+                            for (int g = 0; g < 4; ++g)
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-                                }
-                                if ((p & 1) == 0) {
-                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                                    __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
-                                } else {
-                                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-                                }
+                                for (int m = 0; m < 2; ++m)
+                                    acc[m][g] = mfma32(ring[p].a[m][s], ring[p].b[g][s], acc[m][g]);
+                        if (kb + 2 < KB) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
                             }
-                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                }
-                if (tune & 2) __builtin_amdgcn_s_setprio(0);
-            }
-        } else {
-            // ---------------- gate phase of step (i - 1 - grp) / 2 ----------------
-            const int gs = (i - 1 - grp) >> 1;
-            if (i - 1 - grp >= 0 && gs < T) {
-                const int t = dir ? T - 1 - gs : gs;
-#pragma unroll
-                for (int ut = 0; ut < 2; ++ut)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float ig = fast_sigmoid(acc[ut][0][r]);
-                        const float fg = fast_sigmoid(acc[ut][1][r]);
-                        const float gg = fast_tanh(acc[ut][2][r]);
-                        const float og = fast_sigmoid(acc[ut][3][r]);
-                        const float cn = fg * cs[(ut * 16 + r) * 64] + ig * gg;
-                        cs[(ut * 16 + r) * 64] = cn;
-                        const float hv = og * fast_tanh(cn);
-                        const int dr = (r & 3) + 8 * (r >> 2);
-                        hl[dr * LDH + 32 * ut] = hv;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), yrs, yoff,
-                                                              ((unsigned)(dr * T + t) * ldy + 32 * ut) * 4u, 0);
-                    }
-                if (gs + 1 < T) {
-                    const int tn = dir ? T - 2 - gs : gs + 1;
-                    load_seed(tn);
-                    stage_x(tn);
                 }
             }
         }
-        __syncthreads();
+        if (stamp) dbg[(u * 80 + 2 * step) * 2 + 1] = __builtin_amdgcn_s_memtime();
+        lds_barrier();                    // every wave has finished reading h_{t-1}
+        if (stamp) dbg[(u * 80 + 2 * step + 1) * 2] = __builtin_amdgcn_s_memtime();
+
+        // ---------------- gate phase (matrix pipe idle, VALU at full rate) ----------------
+        const int tn = dir ? t - 1 : t + 1;   // next step's time index
+        if (step + 1 < T) x_load(tn);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * qd + e;
+                    const float ig = fast_sigmoid(acc[m][0][r]);
+                    const float fg = fast_sigmoid(acc[m][1][r]);
+                    const float gg = fast_tanh(acc[m][2][r]);
+                    const float og = fast_sigmoid(acc[m][3][r]);
+                    const float cn = fg * cs[(m * 16 + r) * 64] + ig * gg;
+                    cs[(m * 16 + r) * 64] = cn;
+                    const float hv = og * fast_tanh(cn);
+                    const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
+                    hl[dr * LDH] = hv;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), yrs, yoff,
+                                                          ((unsigned)(dr * T + t) * ldy) * 4u, 0);
+                }
+                // these 16 accumulator registers are dead now: refill them with the next step's seed
+                // so the loads fly under the rest of the gate math
+                if (step + 1 < T) seed_chunk(m, qd, tn);
+            }
+        if (step + 1 < T) x_store();
+        if (stamp) dbg[(u * 80 + 2 * step + 1) * 2 + 1] = __builtin_amdgcn_s_memtime();
+        lds_barrier();                    // h_t (and x_{t+1}) visible; seed loads / y stores stay in flight
     }
 }
 
@@ -392,14 +395,27 @@ int tune_flags() {
     return v;
 }
 
+// PA_DEBUG_TIMING=1: a 2 x [8 waves][80 intervals][2] u64 device buffer of s_memtime stamps
+// (first half: last unfused launch, second half: last fused launch), dumped by pa_debug_dump_timing.
+unsigned long long* g_dbg = nullptr;
+unsigned long long* debug_buffer() {
+    static const bool on = [] { const char* e = getenv("PA_DEBUG_TIMING"); return e && e[0] == '1'; }();
+    if (!on) return nullptr;
+    if (!g_dbg) {
+        if (hipMalloc(&g_dbg, 2 * 8 * 80 * 2 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_dbg, 0, 2 * 8 * 80 * 2 * sizeof(unsigned long long));
+    }
+    return g_dbg;
+}
+
 hipError_t launch_lstm_rec(int H, const float* Xp, int ldx, const float* Wp, float* Y, int ldy,
                            int B, int T, hipStream_t stream) {
     if (B <= 0) return hipSuccess;
     if (H != 256) return hipErrorInvalidValue;   // the reference hard-codes lstm_*_hidden_size = 256
     const int grid = rec_grid(B);
     const size_t lds = ((size_t)MT * (256 + 4) + 8 * 2 * 16 * 64) * sizeof(float);  // h + c
-    hipLaunchKernelGGL((lstm_rec_pp_kernel<256, 0>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
-                       (const int8_t*)nullptr, 0, (const float*)nullptr, Wp, Y, ldy, B, T, tune_flags());
+    hipLaunchKernelGGL((lstm_rec_kernel<256, 0>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
+                       (const int8_t*)nullptr, 0, (const float*)nullptr, Wp, Y, ldy, B, T, debug_buffer());
     return hipGetLastError();
 }
 
@@ -409,8 +425,9 @@ hipError_t launch_lstm_rec_fused(int H, const int8_t* X, int F, const float* bia
     if (H != 256 || F <= 0 || F > 32) return hipErrorInvalidValue;
     const int grid = rec_grid(B);
     const size_t lds = ((size_t)MT * (256 + 32 + 4) + 8 * 2 * 16 * 64) * sizeof(float);  // [h|x] + c
-    hipLaunchKernelGGL((lstm_rec_pp_kernel<256, 32>), dim3(grid), dim3(512), lds, stream,
-                       (const float*)nullptr, 0, X, F, bias, Wcat, Y, ldy, B, T, tune_flags());
+    hipLaunchKernelGGL((lstm_rec_kernel<256, 32>), dim3(grid), dim3(512), lds, stream,
+                       (const float*)nullptr, 0, X, F, bias, Wcat, Y, ldy, B, T,
+                       debug_buffer() ? debug_buffer() + 8 * 80 * 2 : nullptr);
     return hipGetLastError();
 }
 
@@ -434,3 +451,8 @@ hipError_t launch_gru_rec(int H, const float* Xp, int ldx, const float* Wp, cons
 }
 
 }  // namespace pa
+
+extern "C" int pa_debug_dump_timing(unsigned long long* host_out) {   // 2 * 8 * 80 * 2 values
+    if (!pa::g_dbg) return 1;
+    return hipMemcpy(host_out, pa::g_dbg, 2 * 8 * 80 * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
