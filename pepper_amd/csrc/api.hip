@@ -37,7 +37,8 @@ int fail(int code, const std::string& msg) { return pa::set_error(code, msg); }
             return fail(PA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
-constexpr int MT = 64;  // batch padding of the recurrent kernels (rnn.hip)
+constexpr int MT = 64;   // batch padding of the LSTM kernel (rnn.hip)
+constexpr int MTP = 128; // batch padding of the GRU kernel (two 64-row groups per workgroup at H = 128)
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
@@ -524,7 +525,7 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
             const RecLayer& r = layers[l];
             LAUNCH_TRY(m, (stage == 0 && l == 0) ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
                        pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
-                                          NX, (int)(round_up(n, MT) * T), NX, r.K, 0, 0, cur_bs, T, (int)n, m->stream));
+                                          NX, (int)(round_up(n, MTP) * T), NX, r.K, 0, 0, cur_bs, T, (int)n, m->stream));
             float* y = ybuf[which];
             LAUNCH_TRY(m, "gru_rec", 2.0 * n * T * (3.0 * H) * H * 2,
                        pa::launch_gru_rec(H, m->xp->f(), NX, r.w_hh->f(), r.b_hn->f(),
@@ -545,7 +546,7 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
 
 static int polish_ensure(pa_polish_model* m, int64_t n, int T) {
     const int H = m->cfg.hidden_size, L = m->cfg.gru_layers;
-    const int64_t np = round_up(n, MT);
+    const int64_t np = round_up(n, MTP);
     if (int rc = m->xp->ensure((size_t)np * T * 6 * H * sizeof(float))) return rc;
     if (int rc = m->y1->ensure((size_t)np * T * 2 * H * sizeof(float))) return rc;
     if (int rc = m->y2->ensure((size_t)np * T * 2 * H * sizeof(float))) return rc;

@@ -242,58 +242,52 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_kernel(const float* _
 }
 
 // GRU: gates r,z,n.  Xp = W_ih x + b_ih (+ b_hr / b_hz folded in for r and z); the n gate keeps
-// W_hn h + b_hn separate because it is multiplied by r (PyTorch GRU definition).
+// W_hn h + b_hn separate because it is multiplied by r (PyTorch GRU definition).  Same lockstep
+// structure as lstm_rec_kernel: always 8 waves = two per SIMD in the same phase; with H = 128 the
+// four unit tiles leave room for two 64-row groups per workgroup (128 batch rows).
 template <int H>
-__global__ __launch_bounds__(H / 32 * 64, 2) void gru_rec_kernel(const float* __restrict__ Xp, int ldx,
-                                                                 const float* __restrict__ Wp,
-                                                                 const float* __restrict__ bhn,
-                                                                 const float* __restrict__ h0, int ldh0,
-                                                                 float* __restrict__ hn, int ldhn,
-                                                                 float* __restrict__ Y, int ldy, int B,
-                                                                 int T) {
-    constexpr int LDH = H + 4, KB = H / 8, NT = H / 32;
-    extern __shared__ __attribute__((aligned(16))) float hs[];  // [MT][LDH]
+__global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict__ Xp, int ldx,
+                                                         const float* __restrict__ Wp,
+                                                         const float* __restrict__ bhn,
+                                                         const float* __restrict__ h0, int ldh0,
+                                                         float* __restrict__ hn, int ldhn,
+                                                         float* __restrict__ Y, int ldy, int B, int T) {
+    constexpr int LDH = H + 4, KB = H / 8, NT = H / 32, RG = 8 / NT, MTG = MT * RG;
+    extern __shared__ __attribute__((aligned(16))) float hs[];  // [MTG][LDH]
 
     int dir, btile;
     decode_block(blockIdx.x, dir, btile);
-    const int b0 = btile * MT;
+    const int b0 = btile * MTG;
     if (b0 >= B) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's 32-unit tile
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u = wave % NT, rg = wave / NT;                   // unit tile, 64-row group
     const int li = lane & 31, hf = lane >> 5;
     const int col = u * 32 + li;
+    const int r0 = b0 + rg * MT;                               // first batch row of this wave
 
-    // all buffers are padded to a multiple of MT batch rows (see lstm_rec_kernel); global traffic
-    // uses raw buffer descriptors = uniform base + one per-lane offset + uniform soffset
-    // (see lstm_rec_pp_kernel).  row(m, r) = b0 + 4*hf + 32*m + (r & 3) + 8*(r >> 2)
-    const size_t urow = (size_t)b0 * T;
-    // Xp is in MFMA fragment order (gemm.hip): row tile = (32-batch block, step), 4 x 1 KiB chunks
+    // all buffers are padded to a multiple of 128 batch rows; row(m, r) = r0 + 32*m + 4*hf + (r&3) + 8*(r>>2)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(Xp + (size_t)(b0 >> 5) * T * (ldx >> 5) * 1024), 0, 0x7fffffff, 0x00020000);
+        const_cast<float*>(Xp + (size_t)(r0 >> 5) * T * (ldx >> 5) * 1024), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs =
-        __builtin_amdgcn_make_buffer_rsrc(Y + urow * ldy + dir * H + u * 32, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)r0 * T * ldy + dir * H + u * 32, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(Wp + ((size_t)dir * (3 * NT) + u) * KB * 256), 0, 0x7fffffff, 0x00020000);
     const unsigned xoff = lane * 16u;
     const unsigned yoff = ((unsigned)(4 * hf * T) * ldy + li) * 4u;
     const unsigned woff = lane * 16u;
-    const size_t lb = (size_t)(b0 + 4 * hf);
-    auto load_xp = [&](int m, int t, int g, f32x16& dst) {
-        const unsigned ct = (unsigned)(dir * (3 * NT) + g * NT + u);
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const unsigned so = (((unsigned)(m * T + t) * (ldx >> 5) + ct) * 4u + qd) * 1024u;
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
-            dst[4 * qd] = v.x;
-            dst[4 * qd + 1] = v.y;
-            dst[4 * qd + 2] = v.z;
-            dst[4 * qd + 3] = v.w;
-        }
-    };
-    float* hl = hs + 4 * hf * LDH + col;
+    const size_t lb = (size_t)(r0 + 4 * hf);
+    float* hl = hs + (rg * MT + 4 * hf) * LDH + col;
+    const float* hrow = hs + (rg * MT + li) * LDH + hf * 4;
 
-    f32x16 hreg[2];
+    auto load_xp4 = [&](int m, int t, int g, int qd) {
+        const unsigned ct = (unsigned)(dir * (3 * NT) + g * NT + u);
+        const unsigned so = (((unsigned)(m * T + t) * (ldx >> 5) + ct) * 4u + qd) * 1024u;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
+    };
+
+    f32x16 hreg[2], acc[2][3];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -304,69 +298,105 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void gru_rec_kernel(const float* __
             hl[dr * LDH] = hv;
         }
     const float bn = bhn[dir * H + col];
+    auto seed_chunk = [&](int m, int qd, int t) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const f32x4 v = load_xp4(m, t, g, qd);
+            acc[m][g][4 * qd] = v.x;
+            acc[m][g][4 * qd + 1] = v.y;
+            acc[m][g][4 * qd + 2] = v.z;
+            acc[m][g][4 * qd + 3] = v.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[m][2][4 * qd + e] = bn;
+    };
+    {
+        const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) seed_chunk(m, qd, t0);
+    }
     __syncthreads();
 
-    auto load_w = [&](int kb, f32x4 (&b)[3]) {
+    struct Frag { f32x4 b[3], a[2]; };
+    auto load_kb = [&](int kb, Frag& fr) {
 #pragma unroll
         for (int g = 0; g < 3; ++g)
-            b[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                 wrs, woff, (unsigned)(g * NT * KB + kb) * 1024u, 0));
+            fr.b[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                    wrs, woff, (unsigned)(g * NT * KB + kb) * 1024u, 0));
+#pragma unroll
+        for (int m = 0; m < 2; ++m) fr.a[m] = *reinterpret_cast<const f32x4*>(hrow + m * 32 * LDH + kb * 8);
     };
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
-        f32x16 acc[2][3];
+        // ---------------- MFMA phase ----------------
+        {
+            Frag ring[3];
+            load_kb(0, ring[0]);
+            load_kb(1, ring[1]);
+            for (int k0 = 0; k0 < KB; k0 += 3) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            load_xp(m, t, 0, acc[m][0]);
-            load_xp(m, t, 1, acc[m][1]);
+                for (int p = 0; p < 3; ++p) {
+                    const int kb = k0 + p;
+                    if (kb < KB) {
+                        if (kb + 2 < KB) load_kb(kb + 2, ring[(p + 2) % 3]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][2][r] = bn;
-        }
-
-        const float* hrow = hs + li * LDH + hf * 4;
-        f32x4 bw[2][3], a[2][2];
-        load_w(0, bw[0]);
+                        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) a[0][m] = *reinterpret_cast<const f32x4*>(hrow + m * 32 * LDH);
-        for (int kb = 0; kb < KB; kb += 2) {
+                            for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                if (kb + p + 1 < KB) {
-                    load_w(kb + p + 1, bw[p ^ 1]);
+                                for (int m = 0; m < 2; ++m)
+                                    acc[m][g] = mfma32(ring[p].a[m][s], ring[p].b[g][s], acc[m][g]);
+                        if (kb + 2 < KB) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        a[p ^ 1][m] = *reinterpret_cast<const f32x4*>(hrow + m * 32 * LDH + (kb + p + 1) * 8);
+                            for (int k = 0; k < 3; ++k) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                            }
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) acc[m][g] = mfma32(a[p][m][s], bw[p][g][s], acc[m][g]);
             }
         }
-        __syncthreads();
+        // x part of the n gate for this step: in flight across the barrier
+        f32x4 xn[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) xn[m][qd] = load_xp4(m, t, 2, qd);
+        lds_barrier();
 
+        // ---------------- gate phase ----------------
+        const int tn = dir ? t - 1 : t + 1;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            f32x16 xnv;
-            load_xp(m, t, 2, xnv);
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
-                const float xn = xnv[r];
-                const float rg = fast_sigmoid(acc[m][0][r]);
-                const float zg = fast_sigmoid(acc[m][1][r]);
-                const float ng = fast_tanh(xn + rg * acc[m][2][r]);
-                const float hv = (1.0f - zg) * ng + zg * hreg[m][r];
-                hreg[m][r] = hv;
-                hl[dr * LDH] = hv;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), yrs, yoff,
-                                                      ((unsigned)(dr * T + t) * ldy) * 4u, 0);
+            for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * qd + e;
+                    const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
+                    const float rgate = fast_sigmoid(acc[m][0][r]);
+                    const float zgate = fast_sigmoid(acc[m][1][r]);
+                    const float ngate = fast_tanh(xn[m][qd][e] + rgate * acc[m][2][r]);
+                    const float hv = (1.0f - zgate) * ngate + zgate * hreg[m][r];
+                    hreg[m][r] = hv;
+                    hl[dr * LDH] = hv;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), yrs, yoff,
+                                                          ((unsigned)(dr * T + t) * ldy) * 4u, 0);
+                }
+                if (step + 1 < T) seed_chunk(m, qd, tn);
             }
-        }
-        __syncthreads();
+        lds_barrier();
     }
 
     if (hn != nullptr) {
@@ -378,8 +408,8 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void gru_rec_kernel(const float* __
     }
 }
 
-inline int rec_grid(int B) {
-    const int nbt = (B + MT - 1) / MT;
+inline int rec_grid(int B, int rows_per_wg = MT) {
+    const int nbt = (B + rows_per_wg - 1) / rows_per_wg;
     return 2 * ((nbt + 3) / 4) * 4;  // both directions, batch tiles padded to the 4-XCD groups
 }
 
@@ -435,14 +465,13 @@ hipError_t launch_gru_rec(int H, const float* Xp, int ldx, const float* Wp, cons
                           const float* h0, int ldh0, float* hn, int ldhn, float* Y, int ldy,
                           int B, int T, hipStream_t stream) {
     if (B <= 0) return hipSuccess;
-    const int grid = rec_grid(B);
-    if (H == 128) {
-        const size_t lds = (size_t)MT * (128 + 4) * sizeof(float);
-        hipLaunchKernelGGL((gru_rec_kernel<128>), dim3(grid), dim3(256), lds, stream, Xp, ldx, Wp, bhn,
-                           h0, ldh0, hn, ldhn, Y, ldy, B, T);
-    } else if (H == 256) {
+    if (H == 128) {        // 128 batch rows per workgroup
+        const size_t lds = (size_t)2 * MT * (128 + 4) * sizeof(float);
+        hipLaunchKernelGGL((gru_rec_kernel<128>), dim3(rec_grid(B, 2 * MT)), dim3(512), lds, stream, Xp, ldx, Wp,
+                           bhn, h0, ldh0, hn, ldhn, Y, ldy, B, T);
+    } else if (H == 256) { // 64 batch rows per workgroup
         const size_t lds = (size_t)MT * (256 + 4) * sizeof(float);
-        hipLaunchKernelGGL((gru_rec_kernel<256>), dim3(grid), dim3(512), lds, stream, Xp, ldx, Wp, bhn,
+        hipLaunchKernelGGL((gru_rec_kernel<256>), dim3(rec_grid(B, MT)), dim3(512), lds, stream, Xp, ldx, Wp, bhn,
                            h0, ldh0, hn, ldhn, Y, ldy, B, T);
     } else {
         return hipErrorInvalidValue;
