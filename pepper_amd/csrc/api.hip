@@ -261,9 +261,9 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
         out.b_hn = m->new_buf();
         if (int rc = upload(out.b_hn, bn)) return rc;
     }
-    if (G == 4 && H == 256 && K <= 32) {
+    if ((G == 4 && H == 256 && K <= 32) || (G == 3 && H == 128 && K <= 16)) {
         std::vector<float> cat;
-        pack_fused_weights(whh, wih, G, H, K, 32, cat);
+        pack_fused_weights(whh, wih, G, H, K, G == 4 ? 32 : 16, cat);
         out.w_cat = m->new_buf();
         if (int rc = upload(out.w_cat, cat)) return rc;
     }
@@ -498,6 +498,7 @@ int pa_variant_forward_host(pa_variant_model* m, const int8_t* images, int64_t n
 // ================================================================================================
 struct pa_polish_model : ModelBase {
     pa_polish_config cfg{};
+    bool fuse_input = true;      // PA_FUSE_INPUT=0 falls back to GEMM + Xp
     std::vector<RecLayer> enc, dec;
     Linear dense;
     DevBuf *xp, *y1, *y2, *hid_a, *hid_b, *acc, *stage_in, *stage_lab, *stage_ph, *stage_acc;
@@ -523,6 +524,22 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
         float* hn = stage == 0 ? m->hid_a->f() : hidden_out;
         for (int l = 0; l < L; ++l) {
             const RecLayer& r = layers[l];
+            if (stage == 0 && l == 0 && cur_kind == pa::A_U8 && r.w_cat != nullptr && m->fuse_input) {
+                float* y = ybuf[which];
+                LAUNCH_TRY(m, "gru_rec_fused_in", 2.0 * n * T * (3.0 * H) * (H + r.K) * 2,
+                           pa::launch_gru_rec_fused(H, static_cast<const uint8_t*>(cur), r.K,
+                                                    cur_bs > 0 ? cur_bs : (int64_t)T * r.K, r.b_in->f(), r.w_cat->f(),
+                                                    r.b_hn->f(), h0 ? h0 + (size_t)l * 2 * H : nullptr, ldh,
+                                                    hn ? hn + (size_t)l * 2 * H : nullptr, ldh, y, 2 * H, (int)n, T,
+                                                    m->stream));
+                cur = y;
+                cur_kind = pa::A_F32;
+                cur_ld = 2 * H;
+                cur_rpb = 0;
+                cur_bs = 0;
+                which ^= 1;
+                continue;
+            }
             LAUNCH_TRY(m, (stage == 0 && l == 0) ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
                        pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
                                           NX, (int)(round_up(n, MTP) * T), NX, r.K, 0, 0, cur_bs, T, (int)n, m->stream));
@@ -567,6 +584,7 @@ int pa_polish_create(const pa_polish_config* cfg, const char* const* names, cons
     auto* m = new pa_polish_model();
     m->cfg = *cfg;
     if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 8192;
+    if (const char* e = getenv("PA_FUSE_INPUT")) m->fuse_input = e[0] != '0';
     int rc = init_base(m, cfg->device, hip_stream);
     StateDict sd(names, data, numel, n_tensors);
     const int H = cfg->hidden_size;

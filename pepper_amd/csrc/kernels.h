@@ -36,6 +36,12 @@ hipError_t launch_gru_rec(int H, const float* Xp, int ldx, const float* Wp, cons
                           const float* h0, int ldh0, float* hn, int ldhn, float* Y, int ldy,
                           int B, int T, hipStream_t stream);
 
+// Fused first GRU layer: uint8 X rows (F <= 16) at X + batch * x_bstride + step * F; Wcat packed
+// with K = H + 16 per gate as [W_h* | W_i*]; bias = b_ih + (b_hr, b_hz, 0) [2*3H]; bhn [2*H].
+hipError_t launch_gru_rec_fused(int H, const uint8_t* X, int F, int64_t x_bstride, const float* bias,
+                                const float* Wcat, const float* bhn, const float* h0, int ldh0, float* hn, int ldhn,
+                                float* Y, int ldy, int B, int T, hipStream_t stream);
+
 // head.hip
 hipError_t launch_dense_small(int mode, const float* X, int ldx, const float* W, const float* bias,
                               float* out0, float* out1, int rows, int K, int C, int T, int S, int off,

@@ -245,14 +245,21 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_kernel(const float* _
 // W_hn h + b_hn separate because it is multiplied by r (PyTorch GRU definition).  Same lockstep
 // structure as lstm_rec_kernel: always 8 waves = two per SIMD in the same phase; with H = 128 the
 // four unit tiles leave room for two 64-row groups per workgroup (128 batch rows).
-template <int H>
+// KX > 0 fuses the first layer's input projection (uint8 summary rows, F <= KX): x_t sits next to h
+// in the LDS row; k-blocks [0, H/8) contract h against (W_hr, W_hz, W_hn), k-blocks [H/8, (H+KX)/8)
+// contract x against (W_ir, W_iz, W_in).  The two halves of the n gate stay in separate
+// accumulators (nh, nx) because r multiplies only the hidden half.
+template <int H, int KX>
 __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict__ Xp, int ldx,
+                                                         const uint8_t* __restrict__ Xi, int F, int64_t xi_bstride,
+                                                         const float* __restrict__ bias,
                                                          const float* __restrict__ Wp,
                                                          const float* __restrict__ bhn,
                                                          const float* __restrict__ h0, int ldh0,
                                                          float* __restrict__ hn, int ldhn,
                                                          float* __restrict__ Y, int ldy, int B, int T) {
-    constexpr int LDH = H + 4, KB = H / 8, NT = H / 32, RG = 8 / NT, MTG = MT * RG;
+    constexpr int KT = H + KX, LDH = KT + 4, KB = KT / 8, KBH = H / 8, NT = H / 32, RG = 8 / NT, MTG = MT * RG;
+    constexpr int NA = KX ? 4 : 3;                             // accumulators per row tile
     extern __shared__ __attribute__((aligned(16))) float hs[];  // [MTG][LDH]
 
     int dir, btile;
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
 
     // all buffers are padded to a multiple of 128 batch rows; row(m, r) = r0 + 32*m + 4*hf + (r&3) + 8*(r>>2)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(Xp + (size_t)(r0 >> 5) * T * (ldx >> 5) * 1024), 0, 0x7fffffff, 0x00020000);
+        const_cast<float*>(KX ? Wp : Xp + (size_t)(r0 >> 5) * T * (ldx >> 5) * 1024), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs =
         __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)r0 * T * ldy + dir * H + u * 32, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -281,13 +288,16 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
     float* hl = hs + (rg * MT + 4 * hf) * LDH + col;
     const float* hrow = hs + (rg * MT + li) * LDH + hf * 4;
 
+    if (KX)   // zero the x / pad columns once (feature columns >= F stay zero)
+        for (int idx = tid; idx < MTG * (LDH - H); idx += 512) hs[(idx / (LDH - H)) * LDH + H + idx % (LDH - H)] = 0.0f;
+
     auto load_xp4 = [&](int m, int t, int g, int qd) {
         const unsigned ct = (unsigned)(dir * (3 * NT) + g * NT + u);
         const unsigned so = (((unsigned)(m * T + t) * (ldx >> 5) + ct) * 4u + qd) * 1024u;
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
     };
 
-    f32x16 hreg[2], acc[2][3];
+    f32x16 hreg[2], acc[2][NA];   // unfused: r, z, nh ; fused: r, z, nh, nx
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -298,24 +308,62 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
             hl[dr * LDH] = hv;
         }
     const float bn = bhn[dir * H + col];
+    const float b_r = KX ? bias[dir * 3 * H + col] : 0.0f, b_z = KX ? bias[dir * 3 * H + H + col] : 0.0f,
+                b_nx = KX ? bias[dir * 3 * H + 2 * H + col] : 0.0f;
     auto seed_chunk = [&](int m, int qd, int t) {
+        if (KX) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const f32x4 v = load_xp4(m, t, g, qd);
-            acc[m][g][4 * qd] = v.x;
-            acc[m][g][4 * qd + 1] = v.y;
-            acc[m][g][4 * qd + 2] = v.z;
-            acc[m][g][4 * qd + 3] = v.w;
+            for (int e = 0; e < 4; ++e) {
+                acc[m][0][4 * qd + e] = b_r;
+                acc[m][1][4 * qd + e] = b_z;
+                acc[m][NA - 1][4 * qd + e] = b_nx;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 v = load_xp4(m, t, g, qd);
+                acc[m][g][4 * qd] = v.x;
+                acc[m][g][4 * qd + 1] = v.y;
+                acc[m][g][4 * qd + 2] = v.z;
+                acc[m][g][4 * qd + 3] = v.w;
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[m][2][4 * qd + e] = bn;
     };
+    // fused: uint8 x slab of step t (MTG rows x KX) -> registers -> LDS columns [H, H+KX)
+    constexpr int XN = KX ? (MTG * KX) / 512 : 1;
+    int xv[XN];
+    auto x_load = [&](int t) {
+        if (KX) {
+#pragma unroll
+            for (int k = 0; k < XN; ++k) {
+                const int e = tid + k * 512;
+                const int row = e / KX, f = e % KX;
+                int brow = b0 + row;
+                brow = brow < B ? brow : B - 1;
+                xv[k] = f < F ? (int)Xi[(size_t)brow * xi_bstride + (size_t)t * F + f] : 0;
+            }
+        }
+    };
+    auto x_store = [&]() {
+        if (KX) {
+#pragma unroll
+            for (int k = 0; k < XN; ++k) {
+                const int e = tid + k * 512;
+                hs[(e / KX) * LDH + H + e % KX] = (float)xv[k];
+            }
+        }
+    };
+    __syncthreads();                      // x / pad columns zeroed before staging on top
     {
         const int t0 = dir ? T - 1 : 0;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) seed_chunk(m, qd, t0);
+        x_load(t0);
+        x_store();
     }
     __syncthreads();
 
@@ -336,47 +384,48 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
             Frag ring[3];
             load_kb(0, ring[0]);
             load_kb(1, ring[1]);
-            for (int k0 = 0; k0 < KB; k0 += 3) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const int kb = k0 + p;
-                    if (kb < KB) {
-                        if (kb + 2 < KB) load_kb(kb + 2, ring[(p + 2) % 3]);
+            for (int kb = 0; kb < KB; ++kb) {     // fully unrolled: the n-gate accumulator switches at KBH
+                const int p = kb % 3;
+                if (kb + 2 < KB) load_kb(kb + 2, ring[(p + 2) % 3]);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                            for (int g = 0; g < 3; ++g)
+                    for (int g = 0; g < 3; ++g)
 #pragma unroll
-                                for (int m = 0; m < 2; ++m)
-                                    acc[m][g] = mfma32(ring[p].a[m][s], ring[p].b[g][s], acc[m][g]);
-                        if (kb + 2 < KB) {
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
-                            }
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                            }
-                            __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
+                        for (int m = 0; m < 2; ++m) {
+                            const int ai = (g == 2 && kb >= KBH) ? NA - 1 : g;
+                            acc[m][ai] = mfma32(ring[p].a[m][s], ring[p].b[g][s], acc[m][ai]);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
+                if (kb + 2 < KB) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
                     }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // x part of the n gate for this step: in flight across the barrier
+        // unfused: x part of the n gate for this step, in flight across the barrier
         f32x4 xn[2][4];
+        if (!KX) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) xn[m][qd] = load_xp4(m, t, 2, qd);
+                for (int qd = 0; qd < 4; ++qd) xn[m][qd] = load_xp4(m, t, 2, qd);
+        }
         lds_barrier();
 
         // ---------------- gate phase ----------------
         const int tn = dir ? t - 1 : t + 1;
+        if (step + 1 < T) x_load(tn);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -387,7 +436,8 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
                     const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
                     const float rgate = fast_sigmoid(acc[m][0][r]);
                     const float zgate = fast_sigmoid(acc[m][1][r]);
-                    const float ngate = fast_tanh(xn[m][qd][e] + rgate * acc[m][2][r]);
+                    const float xnv = KX ? acc[m][NA - 1][r] : xn[m][qd][e];
+                    const float ngate = fast_tanh(xnv + rgate * acc[m][2][r]);
                     const float hv = (1.0f - zgate) * ngate + zgate * hreg[m][r];
                     hreg[m][r] = hv;
                     hl[dr * LDH] = hv;
@@ -396,6 +446,7 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
                 }
                 if (step + 1 < T) seed_chunk(m, qd, tn);
             }
+        if (step + 1 < T) x_store();
         lds_barrier();
     }
 
@@ -467,15 +518,28 @@ hipError_t launch_gru_rec(int H, const float* Xp, int ldx, const float* Wp, cons
     if (B <= 0) return hipSuccess;
     if (H == 128) {        // 128 batch rows per workgroup
         const size_t lds = (size_t)2 * MT * (128 + 4) * sizeof(float);
-        hipLaunchKernelGGL((gru_rec_kernel<128>), dim3(rec_grid(B, 2 * MT)), dim3(512), lds, stream, Xp, ldx, Wp,
-                           bhn, h0, ldh0, hn, ldhn, Y, ldy, B, T);
+        hipLaunchKernelGGL((gru_rec_kernel<128, 0>), dim3(rec_grid(B, 2 * MT)), dim3(512), lds, stream, Xp, ldx,
+                           (const uint8_t*)nullptr, 0, (int64_t)0, (const float*)nullptr, Wp, bhn, h0, ldh0, hn, ldhn,
+                           Y, ldy, B, T);
     } else if (H == 256) { // 64 batch rows per workgroup
         const size_t lds = (size_t)MT * (256 + 4) * sizeof(float);
-        hipLaunchKernelGGL((gru_rec_kernel<256>), dim3(rec_grid(B, MT)), dim3(512), lds, stream, Xp, ldx, Wp, bhn,
-                           h0, ldh0, hn, ldhn, Y, ldy, B, T);
+        hipLaunchKernelGGL((gru_rec_kernel<256, 0>), dim3(rec_grid(B, MT)), dim3(512), lds, stream, Xp, ldx,
+                           (const uint8_t*)nullptr, 0, (int64_t)0, (const float*)nullptr, Wp, bhn, h0, ldh0, hn, ldhn,
+                           Y, ldy, B, T);
     } else {
         return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_rec_fused(int H, const uint8_t* X, int F, int64_t x_bstride, const float* bias,
+                                const float* Wcat, const float* bhn, const float* h0, int ldh0, float* hn, int ldhn,
+                                float* Y, int ldy, int B, int T, hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    if (H != 128 || F <= 0 || F > 16) return hipErrorInvalidValue;
+    const size_t lds = (size_t)2 * MT * (128 + 16 + 4) * sizeof(float);
+    hipLaunchKernelGGL((gru_rec_kernel<128, 16>), dim3(rec_grid(B, 2 * MT)), dim3(512), lds, stream,
+                       (const float*)nullptr, 0, X, F, x_bstride, bias, Wcat, bhn, h0, ldh0, hn, ldhn, Y, ldy, B, T);
     return hipGetLastError();
 }
 
