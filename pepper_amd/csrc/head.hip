@@ -80,6 +80,62 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const float* __restric
     }
 }
 
+// Polish head, bandwidth-shaped: 16 lanes per row, 4 rows per wave; every load instruction moves
+// four 256-byte row segments (coalesced), the class weights live in registers, and the reduction
+// is a 4-step butterfly inside each 16-lane group (5 classes x 4 shuffles per 4 rows instead of
+// 5 x 6 per row).  acc[(row / T) * S + off + row % T][c] += softmax(x W^T + b)[c].
+template <int K>
+__global__ __launch_bounds__(256) void polish_dense_acc_kernel(const float* __restrict__ X, int ldx,
+                                                               const float* __restrict__ W,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ acc, int rows, int C, int T,
+                                                               int S, int off, int rows_per_block) {
+    constexpr int J = K / 64;
+    const int lane = threadIdx.x & 63, l16 = lane & 15, rsel = lane >> 4, wave = threadIdx.x >> 6;
+    f32x4 w[5][J];
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            w[c][j] = c < C ? *reinterpret_cast<const f32x4*>(W + (size_t)c * K + l16 * 4 + 64 * j) : f32x4{0, 0, 0, 0};
+    float b[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) b[c] = c < C ? bias[c] : 0.0f;
+    const int row0 = blockIdx.x * rows_per_block;
+    for (int base = row0 + wave * 4; base < row0 + rows_per_block; base += 16) {
+        const int row = base + rsel;
+        const bool ok = row < rows;
+        const float* x = X + (size_t)(ok ? row : rows - 1) * ldx + l16 * 4;
+        f32x4 xv[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) xv[j] = *reinterpret_cast<const f32x4*>(x + 64 * j);
+        float logit[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            float p = 0.0f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) p += xv[j].x * w[c][j].x + xv[j].y * w[c][j].y + xv[j].z * w[c][j].z + xv[j].w * w[c][j].w;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+            logit[c] = c < C ? p + b[c] : -INFINITY;
+        }
+        float mx = logit[0];
+#pragma unroll
+        for (int c = 1; c < 5; ++c) mx = fmaxf(mx, logit[c]);
+        float e[5], den = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            e[c] = expf(logit[c] - mx);
+            den += e[c];
+        }
+        float mine = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            if (l16 == c) mine = e[c];
+        if (ok && l16 < C) acc[((size_t)(row / T) * S + off + row % T) * C + l16] += mine / den;
+    }
+}
+
 __global__ __launch_bounds__(256) void polish_finalize_kernel(const float* __restrict__ acc,
                                                               uint8_t* __restrict__ labels,
                                                               uint8_t* __restrict__ phred,
@@ -109,6 +165,15 @@ hipError_t launch_dense_small(int mode, const float* X, int ldx, const float* W,
                               hipStream_t stream) {
     if (rows <= 0) return hipSuccess;
     if (C > MAXC || (K & 3) || (ldx & 3)) return hipErrorInvalidValue;
+    if (mode == 1 && C <= 5 && (K == 256 || K == 512)) {
+        const int rpb = 256;   // rows per block: 16 rows in flight, 16 passes
+        const dim3 g((rows + rpb - 1) / rpb), b(256);
+        if (K == 256)
+            hipLaunchKernelGGL((polish_dense_acc_kernel<256>), g, b, 0, stream, X, ldx, W, bias, out0, rows, C, T, S, off, rpb);
+        else
+            hipLaunchKernelGGL((polish_dense_acc_kernel<512>), g, b, 0, stream, X, ldx, W, bias, out0, rows, C, T, S, off, rpb);
+        return hipGetLastError();
+    }
     const dim3 grid((rows + 3) / 4), block(256);
     switch (mode) {
         case 0: hipLaunchKernelGGL((dense_small_kernel<0>), grid, block, 0, stream, X, ldx, W, bias, out0, out1, rows, K, C, T, S, off); break;
