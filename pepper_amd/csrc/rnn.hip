@@ -87,13 +87,10 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_kernel(const float* _
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(KX ? bias + dir * 4 * H + 32 * u : Xp + (size_t)(b0 >> 5) * T * (ldx >> 5) * 1024), 0,
         0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t yrs =
-        __builtin_amdgcn_make_buffer_rsrc(Y + urow * ldy + dir * H + 32 * u, 0, 0x7fffffff, 0x00020000);
     // fragment (g, kb) of this wave lives at byte ((g*NT + u) * KB + kb) * 1024 + lane * 16
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(Wp + (size_t)dir * (4 * NT) * KB * 256), 0, 0x7fffffff, 0x00020000);
     const unsigned xoff = KX ? li * 4u : lane * 16u;
-    const unsigned yoff = ((unsigned)(4 * hf * T) * ldy + li) * 4u;
     const unsigned woff = lane * 16u;
     float* hl = hs + 4 * hf * LDH + 32 * u + li;
     const float* hrow = hs + li * LDH + hf * 4;
@@ -153,6 +150,23 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_kernel(const float* _
         for (int m = 0; m < 2; ++m) fr.a[m] = *reinterpret_cast<const f32x4*>(hrow + m * 32 * LDH + kb * 8);
     };
 
+    // y is written from LDS, not from the gate phase: during the MFMA phase of step s every thread
+    // copies 8 x 16 bytes of h_{s-1} (stable in LDS until the next gate phase) to HBM, one
+    // ds_read_b128 + one 16-byte store per k-block, each in its own MFMA gap -- instead of 32
+    // 4-byte stores per lane inside the gate phase, where every VMEM issue is exposed.
+    constexpr int YC = (MT * H / 4) / (NW * 64);          // float4 per thread (8)
+    constexpr int YROWS = (NW * 64) / (H / 4);            // rows covered per pass
+    const int yc_row = tid / (H / 4), yc_c4 = tid % (H / 4);
+    const float* yc_src = hs + yc_row * LDH + yc_c4 * 4;
+    const __amdgpu_buffer_rsrc_t ycrs =
+        __builtin_amdgcn_make_buffer_rsrc(Y + urow * ldy + dir * H, 0, 0x7fffffff, 0x00020000);
+    const unsigned yc_off = ((unsigned)(yc_row * T) * ldy + yc_c4 * 4) * 4u;
+    auto yc_read = [&](int j) { return *reinterpret_cast<const f32x4*>(yc_src + j * YROWS * LDH); };
+    auto yc_write = [&](int j, int tp, f32x4 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ycrs, yc_off,
+                                               ((unsigned)(j * YROWS * T + tp) * ldy) * 4u, 0);
+    };
+
     __syncthreads();                      // zero fill complete before x is staged on top of it
     {
         const int t0 = dir ? T - 1 : 0;
@@ -174,35 +188,45 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_kernel(const float* _
             Frag ring[3];
             load_kb(0, ring[0]);
             load_kb(1, ring[1]);
-            for (int k0 = 0; k0 < KB; k0 += 3) {
+            // time index of h_{s-1}; step 0 copies the zero state to y[t] (overwritten by the same
+            // lanes one step later), which keeps the loop body branch free
+            const int tp = step > 0 ? (dir ? t + 1 : t - 1) : t;
+            f32x4 ycv = {0, 0, 0, 0};
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const int kb = k0 + p;
-                    if (kb < KB) {
-                        if (kb + 2 < KB) load_kb(kb + 2, ring[(p + 2) % 3]);
+            for (int kb = 0; kb < KB; ++kb) {
+                const int p = kb % 3;
+                if (kb + 2 < KB) load_kb(kb + 2, ring[(p + 2) % 3]);
+                if (kb >= 1 && kb <= YC) yc_write(kb - 1, tp, ycv);
+                if (kb < YC) ycv = yc_read(kb);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g)
+                    for (int g = 0; g < 4; ++g)
 #pragma unroll
-                                for (int m = 0; m < 2; ++m)
-                                    acc[m][g] = mfma32(ring[p].a[m][s], ring[p].b[g][s], acc[m][g]);
-                        if (kb + 2 < KB) {
+                        for (int m = 0; m < 2; ++m)
+                            acc[m][g] = mfma32(ring[p].a[m][s], ring[p].b[g][s], acc[m][g]);
+                if (kb + 2 < KB) {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
-                            }
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                    }
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                            }
-                            __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int q = 0; q < 2; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (A fragment)
+                    }
+                    if (kb <= YC) {                                          // y copy traffic of this k-block
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // 1 VMEM write
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (y copy)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 20, 0);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (stamp) dbg[(u * 80 + 2 * step) * 2 + 1] = __builtin_amdgcn_s_memtime();
@@ -228,8 +252,6 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_kernel(const float* _
                     const float hv = og * fast_tanh(cn);
                     const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
                     hl[dr * LDH] = hv;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), yrs, yoff,
-                                                          ((unsigned)(dr * T + t) * ldy) * 4u, 0);
                 }
                 // these 16 accumulator registers are dead now: refill them with the next step's seed
                 // so the loads fly under the rest of the gate math
@@ -238,6 +260,12 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void lstm_rec_kernel(const float* _
         if (step + 1 < T) x_store();
         if (stamp) dbg[(u * 80 + 2 * step + 1) * 2 + 1] = __builtin_amdgcn_s_memtime();
         lds_barrier();                    // h_t (and x_{t+1}) visible; seed loads / y stores stay in flight
+    }
+    // the last step's h is still only in LDS
+    {
+        const int tl = dir ? 0 : T - 1;
+#pragma unroll
+        for (int j = 0; j < YC; ++j) yc_write(j, tl, yc_read(j));
     }
 }
 
