@@ -47,11 +47,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const typename AType<AT>::
                                                       const float* __restrict__ bias,
                                                       float* __restrict__ C, int ldc,
                                                       int M, int N, int K, int tiles_n, int nwg,
-                                                      int a_rpb, int64_t a_bstride, int tune, int frag_T, int frag_nb) {
-    // The two co-resident workgroups of a CU share each SIMD's matrix pipe; with equal priority
-    // they fall into lockstep and stall at their barriers together.  A static priority split
-    // lets one run ahead so their bubbles interleave (MI355X_MICROARCH "Two waves per SIMD").
-    if ((tune & 1) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
+                                                      int a_rpb, int64_t a_bstride, int frag_T, int frag_nb) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BM * LDT];
     float* As = lds;                    // [2][BM][LDT]
     float* Bs = lds + 2 * BM * LDT;     // [2][BN][LDT]
@@ -249,7 +245,7 @@ hipError_t launch_typed(const typename AType<AT>::type* A, int lda, const float*
     if (nwg == 0) return hipSuccess;
 #define PA_GEMM_LAUNCH(ACT_, KF_)                                                                   \
     hipLaunchKernelGGL((gemm_nt_kernel<AT, ACT_, KF_>), dim3(nwg), dim3(256), 0, stream, A, lda, W, ldw, \
-                       bias, C, ldc, M, N, K, tiles_n, nwg, a_rpb, a_bstride, pa::tune_flags(), frag_T, frag_nb)
+                       bias, C, ldc, M, N, K, tiles_n, nwg, a_rpb, a_bstride, frag_T, frag_nb)
     const bool kfull = (K % BK) == 0;
     if (act == 1) {
         if (kfull) PA_GEMM_LAUNCH(1, true); else PA_GEMM_LAUNCH(1, false);

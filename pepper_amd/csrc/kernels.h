@@ -12,9 +12,6 @@ int set_error(int code, const std::string& msg);
 
 enum AKind { A_F32 = 0, A_I8 = 1, A_U8 = 2, A_F32_SCALAR = 3 };
 
-// experiment switches from $PA_TUNE (bit 0: GEMM priority split, bit 1: MFMA-phase priority)
-int tune_flags();
-
 // gemm.hip: C[M,N] = act(A[M,K] W[N,K]^T + bias); act 0 = identity, 1 = SELU.
 // a_rpb > 0 remaps logical row m to A + (m / a_rpb) * a_bstride + (m % a_rpb) * lda.
 // frag_T > 0 selects the recurrent-seed form: A is [frag_nb, frag_T, K] sequences, M = padded

@@ -305,12 +305,9 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
     // all buffers are padded to a multiple of 128 batch rows; row(m, r) = r0 + 32*m + 4*hf + (r&3) + 8*(r>>2)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(KX ? Wp : Xp + (size_t)(r0 >> 5) * T * (ldx >> 5) * 1024), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t yrs =
-        __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)r0 * T * ldy + dir * H + u * 32, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(Wp + ((size_t)dir * (3 * NT) + u) * KB * 256), 0, 0x7fffffff, 0x00020000);
     const unsigned xoff = lane * 16u;
-    const unsigned yoff = ((unsigned)(4 * hf * T) * ldy + li) * 4u;
     const unsigned woff = lane * 16u;
     const size_t lb = (size_t)(r0 + 4 * hf);
     float* hl = hs + (rg * MT + 4 * hf) * LDH + col;
@@ -395,6 +392,19 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
     }
     __syncthreads();
 
+    // y is written from LDS during the MFMA phase (see lstm_rec_kernel): 8 x 16 bytes per thread
+    constexpr int YC = (MTG * H / 4) / 512, YROWS = 512 / (H / 4);
+    const int yc_row = tid / (H / 4), yc_c4 = tid % (H / 4);
+    const float* yc_src = hs + yc_row * LDH + yc_c4 * 4;
+    const __amdgpu_buffer_rsrc_t ycrs =
+        __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)b0 * T * ldy + dir * H, 0, 0x7fffffff, 0x00020000);
+    const unsigned yc_off = ((unsigned)(yc_row * T) * ldy + yc_c4 * 4) * 4u;
+    auto yc_read = [&](int j) { return *reinterpret_cast<const f32x4*>(yc_src + j * YROWS * LDH); };
+    auto yc_write = [&](int j, int tp, f32x4 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ycrs, yc_off,
+                                               ((unsigned)(j * YROWS * T + tp) * ldy) * 4u, 0);
+    };
+
     struct Frag { f32x4 b[3], a[2]; };
     auto load_kb = [&](int kb, Frag& fr) {
 #pragma unroll
@@ -412,10 +422,15 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
             Frag ring[3];
             load_kb(0, ring[0]);
             load_kb(1, ring[1]);
+            // h_{s-1} -> y; step 0 copies the initial state to y[t] (overwritten one step later)
+            const int tp = step > 0 ? (dir ? t + 1 : t - 1) : t;
+            f32x4 ycv = {0, 0, 0, 0};
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {     // fully unrolled: the n-gate accumulator switches at KBH
                 const int p = kb % 3;
                 if (kb + 2 < KB) load_kb(kb + 2, ring[(p + 2) % 3]);
+                if (kb >= 1 && kb <= YC) yc_write(kb - 1, tp, ycv);
+                if (kb < YC) ycv = yc_read(kb);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -436,7 +451,15 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
+                    if (kb <= YC) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // 1 VMEM write (y copy)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (y copy)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -469,8 +492,6 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
                     const float hv = (1.0f - zgate) * ngate + zgate * hreg[m][r];
                     hreg[m][r] = hv;
                     hl[dr * LDH] = hv;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), yrs, yoff,
-                                                          ((unsigned)(dr * T + t) * ldy) * 4u, 0);
                 }
                 if (step + 1 < T) seed_chunk(m, qd, tn);
             }
@@ -478,6 +499,11 @@ __global__ __launch_bounds__(512, 2) void gru_rec_kernel(const float* __restrict
         lds_barrier();
     }
 
+    {   // the last step's h is still only in LDS
+        const int tl = dir ? 0 : T - 1;
+#pragma unroll
+        for (int j = 0; j < YC; ++j) yc_write(j, tl, yc_read(j));
+    }
     if (hn != nullptr) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -495,14 +521,6 @@ inline int rec_grid(int B, int rows_per_wg = MT) {
 }  // namespace
 
 namespace pa {
-
-int tune_flags() {
-    static const int v = [] {
-        const char* e = getenv("PA_TUNE");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
-}
 
 // PA_DEBUG_TIMING=1: a 2 x [8 waves][80 intervals][2] u64 device buffer of s_memtime stamps
 // (first half: last unfused launch, second half: last fused launch), dumped by pa_debug_dump_timing.
