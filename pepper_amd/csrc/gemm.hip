@@ -52,9 +52,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const typename AType<AT>::
     float* As = lds;                    // [2][BM][LDT]
     float* Bs = lds + 2 * BM * LDT;     // [2][BN][LDT]
 
+    // Tile order inside an XCD's contiguous run: groups of GM row panels, row panel fastest, so the
+    // ~64 tiles resident on an XCD at a time form a GM x 8 block sharing GM A panels and 8 W panels
+    // in that XCD's L2 (n fastest re-streamed all of W for every 4 row panels: 4-9x A over-fetch).
     const int tile = xcd_swizzle(blockIdx.x, nwg);
-    const int m0 = (tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
+    constexpr int GM = 8;
+    const int tiles_m = nwg / tiles_n;
+    const int group = tile / (GM * tiles_n), within = tile - group * (GM * tiles_n);
+    const int gm = min(GM, tiles_m - group * GM);
+    const int m0 = (group * GM + within % gm) * BM;
+    const int n0 = (within / gm) * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
