@@ -64,20 +64,8 @@ def broadcast_state_dict(make_sd, shapes, world, rank, dev):
     (the only collective on the path: SURVEY.md 8(e))."""
     if world == 1:
         return make_sd()
-    import torch.distributed as dist
-    total = sum(int(np.prod(s)) for _, s, _ in shapes)
-    blob = torch.empty(total, dtype=torch.float32, device=dev)
-    if rank == 0:
-        sd = make_sd()
-        blob.copy_(torch.from_numpy(np.concatenate([sd[n].ravel() for n, _, _ in shapes])))
-    dist.broadcast(blob, src=0)
-    host = blob.cpu().numpy()
-    out, off = {}, 0
-    for n, s, _ in shapes:
-        k = int(np.prod(s))
-        out[n] = host[off:off + k].reshape(s)
-        off += k
-    return out
+    from pepper_amd.parallel import broadcast_numpy_state_dict
+    return broadcast_numpy_state_dict(make_sd if rank == 0 else None, shapes, device=dev)
 
 
 def _cpu_runner(model_kind):
@@ -114,7 +102,7 @@ def cpu_baseline_workers(model_kind, seconds):
     """Aggregate of P single-thread workers running concurrently in fresh interpreters."""
     import subprocess
     ncpu = os.cpu_count() or 1
-    procs = max(1, min(128, ncpu // 2))
+    procs = max(1, min(64, ncpu // 2))   # ~0.5 GB RSS each (torch + 47 MB of weights): bounded on purpose
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--model", model_kind, "--cpu-threads", "1",
            "--cpu-seconds", str(seconds)]

@@ -54,3 +54,23 @@ def broadcast_checkpoint(model_path, src=0, device=None, group=None):
 def shard_round_robin(items, world, rank):
     """items[i] goes to rank i % world (RunInference.py:104-110, call_consensus.py:93-97)."""
     return [x for i, x in enumerate(items) if i % world == rank]
+
+
+def broadcast_numpy_state_dict(make_state_dict, shapes, src=0, device=None, group=None):
+    """Synthetic-weights variant of broadcast_checkpoint: only rank `src` calls make_state_dict();
+    `shapes` = [(name, shape, ...)] is known to every rank, so ONE flat fp32 broadcast suffices."""
+    rank = dist.get_rank(group)
+    total = int(sum(int(np.prod(s[1])) for s in shapes))
+    dev = device if device is not None else torch.device("cpu")
+    blob = torch.empty(total, dtype=torch.float32, device=dev)
+    if rank == src:
+        sd = make_state_dict()
+        blob.copy_(torch.from_numpy(np.concatenate([np.asarray(sd[s[0]], np.float32).ravel() for s in shapes])))
+    dist.broadcast(blob, src=src, group=group)
+    host = blob.cpu().numpy()
+    out, off = OrderedDict(), 0
+    for s in shapes:
+        n = int(np.prod(s[1]))
+        out[s[0]] = host[off:off + n].reshape(s[1]).copy()
+        off += n
+    return out

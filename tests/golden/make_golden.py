@@ -110,10 +110,31 @@ def make_polish(tag, seed, gain, n=4):
     print(tag, "labels", labels[1, :12].tolist(), "phred", phred[1, :6].tolist())
 
 
+@torch.no_grad()
+def make_polish_two_layer(tag, seed, gain, n=3):
+    """Module-level forward with gru_layers=2 (hidden [B,4,H]); the reference window loop itself
+    hard-codes TrainOptions.GRU_LAYERS = 1, so only forward(x, hidden) is meaningful for L > 1."""
+    from pepper.modules.python.models.simple_model import TransducerGRU
+    sd = synthetic.polish_state_dict(seed=seed, gain=gain, gru_layers=2)
+    model = TransducerGRU(1, 10, 2, 128, 5, bidirectional=True)
+    model.load_state_dict(to_torch(sd))
+    model.eval()
+    imgs = synthetic.polish_chunks(n, seed=777)[:, :100]
+    rng = np.random.default_rng(5)
+    hidden = rng.uniform(-0.5, 0.5, size=(n, 4, 128)).astype(np.float32)
+    logits, hout = model(torch.from_numpy(imgs).float(), torch.from_numpy(hidden))
+    np.savez_compressed(os.path.join(OUT, f"polish_{tag}.npz"), seed=seed, gain=gain, x=imgs, hidden=hidden,
+                        logits=logits.numpy(), hidden_out=hout.numpy(), gru_layers=2)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "polish_l2":
+        make_polish_two_layer("l2", seed=23, gain=2.0)
+        sys.exit(0)
     torch.set_num_threads(8)
     make_variant("g1", seed=11, gain=1.0)
     make_variant("g3", seed=12, gain=3.0)
     make_variant_two_layer("l2", seed=13, gain=2.0)
     make_polish("g1", seed=21, gain=1.0)
     make_polish("g3", seed=22, gain=3.0)
+    make_polish_two_layer("l2", seed=23, gain=2.0)

@@ -20,6 +20,30 @@ def _free_port():
     return p
 
 
+def _worker_np(rank, world, port, out_dir):
+    from pepper_amd.parallel import broadcast_numpy_state_dict
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes = synthetic.variant_param_shapes()
+        sd = broadcast_numpy_state_dict((lambda: synthetic.variant_state_dict(seed=9)) if rank == 0 else None, shapes)
+        digest = {k: float(np.abs(v).sum()) for k, v in sd.items()}
+        torch.save(digest, os.path.join(out_dir, f"np{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_weight_broadcast_world2(tmp_path):
+    """bench.py's N>1 leg: rank 0 builds the synthetic checkpoint, others get it by one broadcast."""
+    mp.spawn(_worker_np, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want = {k: float(np.abs(v).sum()) for k, v in synthetic.variant_state_dict(seed=9).items()}
+    for r in range(2):
+        got = torch.load(str(tmp_path / f"np{r}.pt"), weights_only=False)
+        assert got == want
+
+
 def _worker(rank, world, port, ckpt_path, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -78,3 +78,14 @@ def test_polish_chunking_and_order_invariance():
     # every accumulated position is a sum of 1 or 2 softmax rows
     s = acc0.numpy().sum(2)
     assert np.abs(s[:, :50] - 1).max() < 1e-5 and np.abs(s[:, 50:950] - 2).max() < 1e-5
+
+
+def test_polish_two_layer_module_forward(golden_dir):
+    """checkpoint['gru_layers'] = 2: hidden is [B, 4, H] in PyTorch's layer-major, direction-minor order."""
+    g = np.load(os.path.join(golden_dir, "polish_l2.npz"))
+    sd = synthetic.polish_state_dict(seed=int(g["seed"]), gain=float(g["gain"]), gru_layers=2)
+    m = _model(sd, gru_layers=2)
+    logits, hidden = m(torch.from_numpy(g["x"]).float(), torch.from_numpy(g["hidden"]))
+    assert np.abs(logits.numpy() - g["logits"]).max() < TOL * max(1.0, np.abs(g["logits"]).max())
+    assert np.abs(hidden.numpy() - g["hidden_out"]).max() < TOL
+    m.close()

@@ -81,3 +81,11 @@ def test_synthetic_inputs_are_deterministic():
     p = synthetic.polish_chunks(2)
     assert p.dtype == np.uint8 and p.shape == (2, 1000, 10)
     assert p.astype(int).sum(axis=2).max() <= 254
+
+
+def test_polish_two_layer_oracle(golden_dir):
+    g = _load(golden_dir, "polish_l2.npz")
+    sd = synthetic.polish_state_dict(seed=int(g["seed"]), gain=float(g["gain"]), gru_layers=2)
+    logits, hidden = models_np.polish_forward(sd, g["x"], g["hidden"], gru_layers=2)
+    assert np.abs(logits - g["logits"]).max() < 2e-5 * max(1.0, np.abs(g["logits"]).max())
+    assert np.abs(hidden - g["hidden_out"]).max() < 2e-5
