@@ -1,0 +1,61 @@
+"""make_images -> run_inference -> find_candidates in one call.
+
+replaces: /root/reference/pepper_variant/modules/python/CallVariant.py:12-109 (`call_variant`).
+Same option names and the same three output locations (images_<run>/, predictions_<run>/, VCFs in
+output_dir).  Input checks raise instead of calling exit(); the BAM/FASTA handlers come from
+`options.bam_handler_factory` / `options.fasta_handler_factory` when given (htslib ingestion is not
+part of this package), otherwise the FASTA is read by
+pepper_amd.variant.fasta and a BAM handler must be supplied.
+"""
+import os
+import sys
+import time
+from datetime import datetime
+
+from pepper_amd.variant.FindCandidates import process_candidates
+from pepper_amd.variant.ImageGenerationUI import ImageGenerationUtils
+from pepper_amd.variant.RunInference import run_inference
+
+
+def _log(message):
+    sys.stderr.write("[" + str(datetime.now().strftime('%m-%d-%Y %H:%M:%S')) + "] INFO: " + message + "\n")
+
+
+def call_variant(options):
+    start_time = time.time()
+    if getattr(options, "bam_handler_factory", None) is None and not os.path.isfile(options.bam):
+        raise FileNotFoundError("ERROR: CAN NOT LOCATE BAM FILE.")
+    if getattr(options, "fasta_handler_factory", None) is None and not os.path.isfile(options.fasta):
+        raise FileNotFoundError("ERROR: CAN NOT LOCATE FASTA FILE.")
+    if not os.path.isfile(options.model_path):
+        raise FileNotFoundError("ERROR: CAN NOT LOCATE MODEL FILE.")
+    if options.threads <= 0:
+        raise ValueError("ERROR: THREAD NEEDS TO BE >=0.")
+    if options.batch_size <= 0:
+        raise ValueError("ERROR: batch_size NEEDS TO BE >0.")
+    if options.num_workers < 0:
+        raise ValueError("ERROR: num_workers NEEDS TO BE >=0.")
+
+    timestr = time.strftime("%m%d%Y_%H%M%S")
+    output_dir = ImageGenerationUtils.handle_output_directory(options.output_dir)
+    image_output_directory = output_dir + "images_" + str(timestr) + "/"
+    prediction_output_directory = output_dir + "predictions_" + str(timestr) + "/"
+    candidate_output_directory = output_dir
+
+    _log("RUN-ID: " + str(timestr))
+    _log("IMAGE OUTPUT: " + str(image_output_directory))
+    _log("STEP 1/3 GENERATING IMAGES:")
+    options.image_output_directory = image_output_directory
+    ImageGenerationUtils.generate_images(options)
+
+    _log("STEP 2/3 RUNNING INFERENCE")
+    _log("OUTPUT: " + str(prediction_output_directory))
+    run_inference(options, image_output_directory, prediction_output_directory)
+
+    _log("STEP 3/3 FINDING CANDIDATES")
+    _log("OUTPUT: " + str(candidate_output_directory))
+    totals = process_candidates(options, prediction_output_directory, candidate_output_directory)
+
+    elapsed = time.time() - start_time
+    _log("TOTAL ELAPSED TIME FOR FINDING CANDIDATES: " + str(int(elapsed / 60)) + " Min " + str(int(elapsed) % 60) + " Sec")
+    return image_output_directory, prediction_output_directory, totals

@@ -1,0 +1,168 @@
+"""BGZF writer/reader and a tabix (.tbi) index builder for position-sorted VCF text.
+
+The reference writes its VCFs through pysam (`VariantFile(..., 'w')` on a `.vcf.gz` name, then
+`pysam.tabix_index(preset="vcf")`: /root/reference/pepper_variant/modules/python/VcfWriter.py:27-46).
+pysam / htslib are not part of this image, so the two container formats are produced here from
+their published specifications (SAM spec section 4.1 "The BGZF compression format", and the tabix
+index layout of the same document family): gzip members of at most 64 KiB with a `BC` extra field
+carrying the compressed block size, terminated by the empty EOF block; `.tbi` = BGZF-compressed
+binning (UCSC scheme, 14-bit leaves, 5 levels) + 16 kb linear index over virtual file offsets.
+"""
+import struct
+import zlib
+
+_BLOCK_DATA = 0xff00            # uncompressed payload per block (htslib's BGZF_BLOCK_SIZE)
+_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _block(data, level=6):
+    comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = comp.compress(data) + comp.flush()
+    bsize = len(body) + 25      # header 18 + trailer 8 - 1
+    head = struct.pack("<4BI2BH2BHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 0x42, 0x43, 2, bsize)
+    return head + body + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
+
+
+class BgzfWriter(object):
+    """Buffered BGZF writer; `tell()` returns the virtual offset of the next byte written."""
+
+    def __init__(self, path):
+        self._fh = open(path, "wb")
+        self._buf = bytearray()
+        self._coffset = 0
+
+    def tell(self):
+        return (self._coffset << 16) | len(self._buf)
+
+    def write(self, data):
+        if isinstance(data, str):
+            data = data.encode()
+        view = memoryview(data)
+        while len(view):
+            room = _BLOCK_DATA - len(self._buf)
+            self._buf += view[:room]
+            view = view[room:]
+            if len(self._buf) >= _BLOCK_DATA:
+                self._flush_block()
+
+    def _flush_block(self):
+        if self._buf:
+            blk = _block(bytes(self._buf))
+            self._fh.write(blk)
+            self._coffset += len(blk)
+            self._buf = bytearray()
+
+    def close(self):
+        if self._fh is None:
+            return
+        self._flush_block()
+        self._fh.write(_EOF)
+        self._fh.close()
+        self._fh = None
+
+
+def read_bgzf(path):
+    """Whole decompressed content (BGZF is a valid multi-member gzip stream)."""
+    out = bytearray()
+    with open(path, "rb") as fh:
+        raw = fh.read()
+    pos = 0
+    while pos < len(raw):
+        d = zlib.decompressobj(31)
+        out += d.decompress(raw[pos:])
+        pos = len(raw) - len(d.unused_data)
+    return bytes(out)
+
+
+def reg2bin(beg, end):
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+class TabixBuilder(object):
+    """Collects (contig, begin0, end0, voffset_begin, voffset_end) of each data line, in file order."""
+
+    def __init__(self):
+        self.names = []
+        self._bins = {}     # tid -> {bin: [[beg, end], ...]}
+        self._lin = {}      # tid -> {window: min voffset}
+        self._tid = {}
+
+    def add(self, contig, beg, end, vbeg, vend):
+        tid = self._tid.get(contig)
+        if tid is None:
+            tid = self._tid[contig] = len(self.names)
+            self.names.append(contig)
+            self._bins[tid], self._lin[tid] = {}, {}
+        end = max(end, beg + 1)
+        chunks = self._bins[tid].setdefault(reg2bin(beg, end), [])
+        if chunks and chunks[-1][1] == vbeg:
+            chunks[-1][1] = vend
+        else:
+            chunks.append([vbeg, vend])
+        lin = self._lin[tid]
+        for w in range(beg >> 14, ((end - 1) >> 14) + 1):
+            if w not in lin:
+                lin[w] = vbeg
+
+    def write(self, path):
+        names = b"".join(n.encode() + b"\0" for n in self.names)
+        out = bytearray(b"TBI\1")
+        # n_ref, format (2 = VCF), col_seq, col_beg, col_end, meta char, skip, l_nm
+        out += struct.pack("<8i", len(self.names), 2, 1, 2, 0, ord("#"), 0, len(names))
+        out += names
+        for tid in range(len(self.names)):
+            bins = self._bins[tid]
+            out += struct.pack("<i", len(bins))
+            for b in sorted(bins):
+                out += struct.pack("<Ii", b, len(bins[b]))
+                for beg, end in bins[b]:
+                    out += struct.pack("<QQ", beg, end)
+            lin = self._lin[tid]
+            n_intv = (max(lin) + 1) if lin else 0
+            out += struct.pack("<i", n_intv)
+            last = 0
+            for w in range(n_intv):
+                last = lin.get(w, last)        # empty windows inherit the previous offset, as htslib fills them
+                out += struct.pack("<Q", last)
+        w = BgzfWriter(path)
+        w.write(bytes(out))
+        w.close()
+
+
+def parse_tbi(path):
+    """Decode a .tbi (used by the tests as a structural check of TabixBuilder)."""
+    raw = read_bgzf(path)
+    if raw[:4] != b"TBI\1":
+        raise ValueError("not a tabix index")
+    n_ref, fmt, col_seq, col_beg, col_end, meta, skip, l_nm = struct.unpack_from("<8i", raw, 4)
+    pos = 36
+    names = [n.decode() for n in raw[pos:pos + l_nm].split(b"\0")[:-1]]
+    pos += l_nm
+    refs = []
+    for _ in range(n_ref):
+        (n_bin,) = struct.unpack_from("<i", raw, pos)
+        pos += 4
+        bins = {}
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", raw, pos)
+            pos += 8
+            bins[b] = [struct.unpack_from("<QQ", raw, pos + 16 * i) for i in range(n_chunk)]
+            pos += 16 * n_chunk
+        (n_intv,) = struct.unpack_from("<i", raw, pos)
+        pos += 4
+        ioff = list(struct.unpack_from("<%dQ" % n_intv, raw, pos))
+        pos += 8 * n_intv
+        refs.append({"bins": bins, "ioff": ioff})
+    return {"names": names, "format": fmt, "cols": (col_seq, col_beg, col_end), "meta": chr(meta), "skip": skip,
+            "refs": refs}

@@ -1,0 +1,266 @@
+"""Candidate finder + VCF writer.  pysam/htslib and the reference's compiled
+module are absent here, so these are hand-derived cases of the rules in
+/root/reference/pepper_variant/modules/python/CandidateFinder.py:356-581 and VcfWriter.py:48-218
+(parity unpinned against the reference run; the expectations below were worked out on paper)."""
+import gzip
+import os
+import types
+
+import numpy as np
+import pytest
+
+from pepper_amd.variant import bgzf
+from pepper_amd.variant.CandidateFinder import find_candidates, repeat_annotation, small_chunk_stitch
+from pepper_amd.variant.DataStorePredict import DataStore
+from pepper_amd.variant.fasta import FASTA_handler
+from pepper_amd.variant.FindCandidates import process_candidates
+
+#       0         1         2         3         4         5         6         7         8
+#       012345678901234567890123456789012345678901234567890123456789012345678901234567890123
+CHR1 = "ACGTACGTAGCTAGCTAGCATCGATCGNTCAGCTAGCTAGTCGATAGCAAAAAATCGATCGATCGTAGCTAGCATCGATCAGCT"
+CHR2 = "GATTACAGATTACAGATTACAGATTACACCCCCCCCGATTACAGATTACA"
+
+
+def options(**kw):
+    o = types.SimpleNamespace(
+        fasta=None, sample_name="SAMPLE", threads=1, allowed_multiallelics=4,
+        snp_p_value=0.1, insert_p_value=0.25, delete_p_value=0.25,
+        snp_p_value_in_lc=0.1, insert_p_value_in_lc=0.3, delete_p_value_in_lc=0.3,
+        snp_q_cutoff=20, indel_q_cutoff=15, snp_q_cutoff_in_lc=20, indel_q_cutoff_in_lc=10,
+        report_snp_above_freq=0, report_indel_above_freq=0)
+    o.__dict__.update(kw)
+    return o
+
+
+@pytest.fixture()
+def fasta(tmp_path):
+    path = tmp_path / "ref.fa"
+    with open(path, "w") as fh:
+        for name, seq in (("chr1", CHR1), ("chr2", CHR2)):
+            fh.write(">" + name + " some description\n")
+            for i in range(0, len(seq), 30):          # wrapped lines, lower case on purpose
+                fh.write(seq[i:i + 30].lower() + "\n")
+    return str(path)
+
+
+def naive_repeat_annotation(sequence):
+    """Definition restated from CandidateFinder.py:279-297 for kmer_size 1 (quadratic)."""
+    out = [1] * len(sequence)
+    for i in range(len(sequence)):
+        count, end = 0, i
+        for j in range(i, len(sequence)):
+            if sequence[j] != sequence[i]:
+                break
+            count += 1
+            end = j + 1
+        for k in range(i, min(len(sequence), end)):
+            out[k] = max(out[k], count)
+    return out
+
+
+def test_repeat_annotation_matches_definition():
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        n = int(rng.integers(0, 24))
+        seq = "".join(rng.choice(list("ACGT"), size=n, p=[0.55, 0.15, 0.15, 0.15]))
+        assert repeat_annotation(seq, 1) == naive_repeat_annotation(seq), seq
+
+
+def test_fasta_handler(fasta):
+    fh = FASTA_handler(fasta)
+    assert fh.get_chromosome_names() == ["chr1", "chr2"]
+    assert fh.get_chromosome_sequence_length("chr1") == len(CHR1)
+    assert fh.get_chromosome_sequence_length("nope") == -1
+    for start, stop in [(0, 1), (0, 30), (29, 31), (25, 70), (59, 61), (0, len(CHR1)), (80, 500), (-5, 3), (10, 10), (12, 3)]:
+        assert fh.get_reference_sequence("chr1", start, stop) == CHR1[max(0, start):max(0, stop)], (start, stop)
+    assert fh.get_reference_sequence("chr2", 28, 36) == "CCCCCCCC"
+    with pytest.raises(KeyError):
+        fh.get_reference_sequence("chrX", 0, 5)
+    # same answers from a .fai on disk
+    with open(fasta + ".fai", "w") as out:
+        off1 = len(">chr1 some description\n")
+        lines1 = (len(CHR1) + 29) // 30
+        off2 = off1 + len(CHR1) + lines1 + len(">chr2 some description\n")
+        out.write("chr1\t%d\t%d\t30\t31\n" % (len(CHR1), off1))
+        out.write("chr2\t%d\t%d\t30\t31\n" % (len(CHR2), off2))
+    fh2 = FASTA_handler(fasta)
+    assert fh2.get_reference_sequence("chr2", 0, 50) == CHR2
+    assert fh2.get_reference_sequence("chr1", 25, 70) == CHR1[25:70]
+
+
+def test_bgzf_and_tabix_roundtrip(tmp_path):
+    path = str(tmp_path / "x.gz")
+    w = bgzf.BgzfWriter(path)
+    rng = np.random.default_rng(1)
+    blob = bytes(rng.integers(0, 256, size=200_000, dtype=np.uint8))   # incompressible, spans 4 blocks
+    offsets = []
+    for i in range(0, len(blob), 777):
+        offsets.append(w.tell())
+        w.write(blob[i:i + 777])
+    w.close()
+    assert gzip.open(path).read() == blob                 # valid multi-member gzip
+    assert bgzf.read_bgzf(path) == blob
+    raw = open(path, "rb").read()
+    assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    # every virtual offset points at the right byte: block start in the file, offset inside the block
+    pos, starts = 0, {}
+    total = 0
+    while pos < len(raw):
+        assert raw[pos:pos + 4] == b"\x1f\x8b\x08\x04" and raw[pos + 12:pos + 14] == b"BC"
+        bsize = int.from_bytes(raw[pos + 16:pos + 18], "little") + 1
+        isize = int.from_bytes(raw[pos + bsize - 4:pos + bsize], "little")
+        assert isize <= 0xff00
+        starts[pos] = total
+        total += isize
+        pos += bsize
+    for k, v in enumerate(offsets):
+        assert starts[v >> 16] + (v & 0xffff) == k * 777
+
+    tb = bgzf.TabixBuilder()
+    tb.add("chr1", 10, 11, 100, 200)
+    tb.add("chr1", 20, 25, 200, 300)          # adjacent chunk in the same bin merges
+    tb.add("chr1", 40000, 40001, 300, 400)    # second 16 kb window
+    tb.add("chr2", 5, 6, 400, 500)
+    tb.write(path + ".tbi")
+    idx = bgzf.parse_tbi(path + ".tbi")
+    assert idx["names"] == ["chr1", "chr2"] and idx["format"] == 2 and idx["cols"] == (1, 2, 0) and idx["meta"] == "#"
+    assert idx["refs"][0]["bins"] == {4681: [(100, 300)], 4683: [(300, 400)]}
+    assert idx["refs"][0]["ioff"] == [100, 100, 300]
+    assert idx["refs"][1]["bins"] == {4681: [(400, 500)]}
+    assert bgzf.reg2bin(0, 1 << 29) == 0 and bgzf.reg2bin(1 << 14, (1 << 14) + 1) == 4682
+
+
+def write_predictions(path, records, batch=4):
+    """records: (contig, position, depth, allele code, support, [p0, p1, p2])."""
+    with DataStore(path, "w") as store:
+        for b, i in enumerate(range(0, len(records), batch)):
+            part = records[i:i + batch]
+            store.write_prediction(b, [r[0] for r in part], [r[1] for r in part], [r[2] for r in part],
+                                   np.array([[r[3]] for r in part], dtype=object),
+                                   np.array([[r[4]] for r in part], dtype=np.uint8),
+                                   np.array([r[5] for r in part], dtype=np.float32))
+
+
+RECORDS = [
+    # het SNP, moderate confidence: QUAL int(-10 log10(1 - float32(0.9))) = 9 -> fails the Q20 cut-off
+    ("chr1", 20, 30, "1A", 12, [0.05, 0.9, 0.05]),
+    # confident hom-alt SNP: 1 - float32(0.999) -> QUAL 30 -> stays in the PEPPER set
+    ("chr1", 31, 40, "1A", 38, [0.0005, 0.0005, 0.999]),
+    # reference base N: skipped
+    ("chr1", 27, 40, "1A", 20, [0.0, 1.0, 0.0]),
+    # allele with a non-ACGT base: skipped
+    ("chr1", 33, 40, "1N", 20, [0.0, 1.0, 0.0]),
+    # hom-ref call above the SNP p-value: reported as refCall for re-genotyping
+    ("chr1", 35, 50, "1C", 9, [0.8, 0.15, 0.05]),
+    # hom-ref call below the p-value: dropped
+    ("chr1", 36, 50, "1G", 3, [0.95, 0.03, 0.02]),
+    # two SNP alleles at one site (separate records) + a duplicate of the first
+    ("chr1", 40, 60, "1A", 25, [0.01, 0.98, 0.01]),
+    ("chr1", 40, 60, "1G", 22, [0.02, 0.97, 0.01]),
+    ("chr1", 40, 60, "1A", 25, [0.3, 0.4, 0.3]),
+    # deletion of GA after anchor C(41): REF CGA ALT C, het, not in repeat (runs near 41 are short)
+    ("chr1", 41, 44, "3CGA", 20, [0.001, 0.9985, 0.0005]),
+    # insertion inside the A6 homopolymer (chr1:48-53): in_lc thresholds; 0.28 < 0.3 -> dropped
+    ("chr1", 50, 30, "2AAT", 8, [0.72, 0.28, 0.0]),
+    # same place, 0.35 >= 0.3 -> kept, hom-ref -> refCall, REP=1
+    ("chr1", 51, 30, "2AAG", 9, [0.65, 0.35, 0.0]),
+    # SNP + deletion at one site on chr2: REF padded to the deletion's REF
+    ("chr2", 3, 20, "1C", 8, [0.1, 0.85, 0.05]),
+    ("chr2", 3, 20, "3TAC", 10, [0.05, 0.9, 0.05]),
+]
+
+
+def read_vcf(path):
+    text = bgzf.read_bgzf(path).decode()
+    lines = text.splitlines()
+    return [l for l in lines if l.startswith("#")], [l.split("\t") for l in lines if not l.startswith("#")]
+
+
+def test_selection_rules(fasta, tmp_path):
+    pred = str(tmp_path / "pred.hdf")
+    write_predictions(pred, RECORDS)
+    opt = options(fasta=fasta)
+    pairs = [(pred, "batch_%d" % b) for b in range((len(RECORDS) + 3) // 4)]
+    margin, calling = small_chunk_stitch(opt, pairs)
+    # margin list: SNP alleles at sites whose own record is not hom-ref
+    assert [(m[0], m[1], m[4], m[5]) for m in margin] == [
+        ("chr1", 20, ["A"], [0, 1]), ("chr1", 31, ["A"], [1, 1]), ("chr1", 40, ["A"], [0, 1]),
+        ("chr1", 40, ["G"], [0, 1]), ("chr1", 40, ["A"], [0, 1]), ("chr2", 3, ["C"], [0, 1])]
+    got = [(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[11]) for c in calling]
+    assert got == [
+        ("chr1", 20, 21, "T", ["A"], [0, 1], 30, [12], False),
+        ("chr1", 31, 32, "G", ["A"], [1, 1], 40, [38], False),
+        ("chr1", 35, 36, "G", ["C"], [0, 0], 50, [9], False),
+        ("chr1", 40, 41, "T", ["A"], [0, 1], 60, [25], False),
+        ("chr1", 40, 41, "T", ["G"], [0, 1], 60, [22], False),
+        ("chr1", 40, 41, "T", ["A"], [0, 1], 60, [25], False),
+        ("chr1", 41, 44, "CGA", ["C"], [0, 1], 44, [20], False),
+        ("chr1", 51, 52, "A", ["AAG"], [0, 0], 30, [9], True),
+        ("chr2", 3, 4, "T", ["C"], [0, 1], 20, [8], False),
+        ("chr2", 3, 6, "TAC", ["T"], [0, 1], 20, [10], False),
+    ]
+    assert calling[0][8] == pytest.approx(np.float32(0.9)) and isinstance(calling[0][8], float)
+
+    contigs, phasing_sites, calling_sites = find_candidates(opt, str(tmp_path), pairs)
+    assert contigs == ["chr1", "chr2"]
+    assert [len(calling_sites[k]) for k in sorted(calling_sites)] == [1, 1, 1, 2, 1, 1, 2]   # duplicate (T,A) dropped
+    assert len(phasing_sites[("chr1", 40)]) == 2
+
+    # frequency rescue: a dropped hom-ref SNP comes back when report_snp_above_freq is set
+    opt2 = options(fasta=fasta, report_snp_above_freq=0.05, report_indel_above_freq=0.2)
+    _, calling2 = small_chunk_stitch(opt2, pairs)
+    keys2 = [(c[0], c[1], c[3], c[4]) for c in calling2]
+    assert ("chr1", 36, "C", ["G"]) in keys2                       # 3/50 = 0.06 >= 0.05
+    assert ("chr1", 50, "A", ["AAT"]) in keys2                     # 8/30 >= 0.2
+
+
+def test_vcf_files(fasta, tmp_path):
+    pred_dir = tmp_path / "pred"
+    pred_dir.mkdir()
+    write_predictions(str(pred_dir / "pepper_prediction_0.hdf"), RECORDS[:7])
+    write_predictions(str(pred_dir / "pepper_prediction_1.hdf"), RECORDS[7:])
+    (pred_dir / "notes.txt").write_text("ignored")
+    out_dir = str(tmp_path / "vcf")
+    totals = process_candidates(options(fasta=fasta), str(pred_dir), out_dir)
+    assert totals == (7, 2, 5, 3, 2)
+
+    header, full = read_vcf(os.path.join(out_dir, "PEPPER_VARIANT_FULL.vcf.gz"))
+    assert header[0] == "##fileformat=VCFv4.2"
+    assert header[1] == '##FILTER=<ID=PASS,Description="All filters passed">'
+    assert sum(h.startswith("##FORMAT=<ID=GT,") for h in header) == 1
+    assert header[-3:] == ["##contig=<ID=chr1,length=%d>" % len(CHR1), "##contig=<ID=chr2,length=%d>" % len(CHR2),
+                           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE"]
+    F = "GT:AP:GQ:DP:AD:VAF:REP"
+    assert full == [
+        ["chr1", "21", ".", "T", "A", "9", "PASS", ".", F, "0/1:0.9:9:30:12:0.4:0"],
+        ["chr1", "32", ".", "G", "A", "30", "PASS", ".", F, "1/1:0.999:30:40:38:0.95:0"],
+        ["chr1", "36", ".", "G", "C", "1", "refCall", ".", F, "0/0:0.15:1:50:9:0.18:0"],
+        # two het alleles: sorted by probability (0.98 first) -> GT 1/2; QUAL from the weaker one (0.97 -> 15)
+        ["chr1", "41", ".", "T", "A,G", "15", "PASS", ".", F, "1/2:0.98,0.97:15:60:25,22:0.417,0.367:0"],
+        ["chr1", "42", ".", "CGA", "C", "28", "PASS", ".", F, "0/1:0.9985:28:44:20:0.455:0"],
+        ["chr1", "52", ".", "A", "AAG", "1", "refCall", ".", F, "0/0:0.35:1:30:9:0.3:1"],
+        # SNP padded with the deletion's tail: T>C becomes TAC>CAC; the deletion record sorts first (0.9 > 0.85)
+        ["chr2", "4", ".", "TAC", "T,CAC", "8", "PASS", ".", F, "1/2:0.9,0.85:8:20:10,8:0.5,0.4:0"],
+    ]
+    _, pepper = read_vcf(os.path.join(out_dir, "PEPPER_VARIANT_OUTPUT_PEPPER.vcf.gz"))
+    _, calling = read_vcf(os.path.join(out_dir, "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING.vcf.gz"))
+    _, snps = read_vcf(os.path.join(out_dir, "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_SNPs.vcf.gz"))
+    _, indels = read_vcf(os.path.join(out_dir, "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_INDEL.vcf.gz"))
+    assert [(r[0], r[1]) for r in pepper] == [("chr1", "32"), ("chr1", "42")]
+    assert [(r[0], r[1]) for r in snps] == [("chr1", "21"), ("chr1", "36"), ("chr1", "41")]
+    assert [(r[0], r[1]) for r in indels] == [("chr1", "52"), ("chr2", "4")]
+    assert [(r[0], r[1]) for r in calling] == [("chr1", "21"), ("chr1", "36"), ("chr1", "41"), ("chr1", "52"), ("chr2", "4")]
+    assert all(r in full for r in pepper + calling)
+
+    for name in ("PEPPER_VARIANT_FULL", "PEPPER_VARIANT_OUTPUT_PEPPER", "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING",
+                 "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_SNPs", "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_INDEL"):
+        assert os.path.isfile(os.path.join(out_dir, name + ".vcf.gz.tbi"))
+    idx = bgzf.parse_tbi(os.path.join(out_dir, "PEPPER_VARIANT_FULL.vcf.gz.tbi"))
+    assert idx["names"] == ["chr1", "chr2"]
+    # the first chunk of chr1 starts right after the header, the last one of chr2 ends at the end of the data
+    raw = bgzf.read_bgzf(os.path.join(out_dir, "PEPPER_VARIANT_FULL.vcf.gz"))
+    header_len = sum(len(h) + 1 for h in header)
+    (beg, _), = idx["refs"][0]["bins"][4681]
+    assert beg == header_len                         # single block: virtual offset == uncompressed offset
+    (_, end), = idx["refs"][1]["bins"][4681]
+    assert end == len(raw)

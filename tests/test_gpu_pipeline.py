@@ -194,3 +194,77 @@ def test_images_to_predictions_plumbing(tmp_path):
 def _as_read(d):
     from test_gpu_encoder import R
     return R(d)
+
+
+def test_call_variant_vcf_identity(tmp_path):
+    """BASELINE success criterion ("identical candidate VCF"): pileup -> GPU encoder -> GPU inference
+    -> candidate finder -> VCF through call_variant, against the VCF the candidate finder writes from
+    the ORACLE model's predictions on the oracle encoder's images."""
+    import pileup_utils as pu
+    from pepper_amd.variant import bgzf
+    from pepper_amd.variant.CallVariant import call_variant
+    from pepper_amd.variant.DataStorePredict import DataStore as PredStore
+    from pepper_amd.variant.FindCandidates import process_candidates
+    rng = np.random.default_rng(77)
+    ref = pu.random_reference(rng, 5000)
+    ref = ref[:2500] + "AAAAAAAA" + ref[2508:]            # a homopolymer for the low-complexity rules
+    sites = {int(p): ("ACGT"[(("ACGT".index(ref[p]) + 1) % 4)], 0.5) for p in rng.choice(np.arange(200, 4800), 30, replace=False)}
+    indels = {900: ("I", "TG", 0.6), 1800: ("D", 3, 0.7), 2503: ("I", "A", 0.5), 3700: ("D", 12, 0.5)}
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=450, read_len=(300, 900), snp_sites=sites, indel_sites=indels)
+    sd = synthetic.variant_state_dict(seed=91, gain=2.5)
+    model_path = str(tmp_path / "model.pkl")
+    torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
+    fasta = _FakeFasta({"chr20": ref})
+    options = SimpleNamespace(
+        bam="fake.bam", fasta="fake.fa", region="chr20:0-4999", region_size=2500, threads=1, train_mode=False,
+        use_hp_info=False, include_supplementary=False, output_dir=str(tmp_path / "out"),
+        min_mapq=1, min_snp_baseq=1, min_indel_baseq=1, snp_frequency=0.10, insert_frequency=0.15,
+        delete_frequency=0.15, min_coverage_threshold=3, snp_candidate_frequency_threshold=0.10,
+        indel_candidate_frequency_threshold=0.12, candidate_support_threshold=2, skip_indels=False,
+        downsample_rate=1.0,
+        model_path=model_path, batch_size=256, num_workers=0, gpu=True, device_ids="0", callers_per_gpu=1,
+        quantized=False, dry=False, sample_name="SYN", allowed_multiallelics=4,
+        snp_p_value=0.1, insert_p_value=0.25, delete_p_value=0.25, snp_p_value_in_lc=0.1,
+        insert_p_value_in_lc=0.3, delete_p_value_in_lc=0.3, snp_q_cutoff=20, indel_q_cutoff=15,
+        snp_q_cutoff_in_lc=20, indel_q_cutoff_in_lc=10, report_snp_above_freq=0, report_indel_above_freq=0,
+        bam_handler_factory=lambda path: _FakeBam({"chr20": reads}),
+        fasta_handler_factory=lambda path: fasta)
+    image_dir, pred_dir, totals = call_variant(options)
+    assert totals[0] > 10
+
+    # oracle leg: oracle encoder images -> oracle model -> same candidate finder
+    oracle = pu.load_restatement()
+    contigs, positions, depths, cands, freqs, images = [], [], [], [], [], []
+    for (start, end) in ((0, 2500), (2500, 4999)):
+        rs, re_ = max(0, start - 100), end + 100
+        sel = [d for d in reads if d["pos"] <= re_ and d["pos"] + sum(n for o, n in d["cigar"] if o in (0, 2, 3, 6, 7, 8)) >= rs and d["mapq"] >= 1]
+        res = pu.run_variant(oracle, pu.FlatPileup(rs, re_, ref[rs:re_ + 1], sel), pu.make_params(start, end))
+        n = len(res["candidates"])
+        contigs += ["chr20"] * n
+        positions += res["positions"].tolist()
+        depths += res["depths"].tolist()
+        cands += [[c] for c in res["candidates"]]
+        freqs += [[f] for f in res["candidate_frequency"].tolist()]
+        images.append(res["images"].astype(np.int64).astype(np.int8))
+    probs = models_np.variant_forward(sd, np.concatenate(images))
+    os.makedirs(str(tmp_path / "opred"))
+    with PredStore(str(tmp_path / "opred" / "pepper_prediction.hdf"), "w") as store:
+        store.write_prediction(0, contigs, positions, np.asarray(depths).astype(np.uint8), np.array(cands, dtype=object),
+                               np.asarray(freqs).astype(np.uint8), probs)
+    oracle_totals = process_candidates(options, str(tmp_path / "opred"), str(tmp_path / "ovcf"))
+    assert oracle_totals == totals
+    for name in ("PEPPER_VARIANT_FULL", "PEPPER_VARIANT_OUTPUT_PEPPER", "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING",
+                 "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_SNPs", "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_INDEL"):
+        got = bgzf.read_bgzf(os.path.join(options.output_dir, name + ".vcf.gz")).decode().splitlines()
+        want = bgzf.read_bgzf(os.path.join(str(tmp_path / "ovcf"), name + ".vcf.gz")).decode().splitlines()
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            if g == w:
+                continue
+            # identical call, alleles, genotype, depths; probabilities may differ in the 6th digit
+            gf, wf = g.split("\t"), w.split("\t")
+            assert gf[:5] == wf[:5] and gf[6:9] == wf[6:9], (g, w)
+            gs, ws = gf[9].split(":"), wf[9].split(":")
+            assert gs[0] == ws[0] and gs[3:] == ws[3:], (g, w)
+            assert abs(float(gf[5]) - float(wf[5])) <= 1, (g, w)
+            assert np.allclose([float(v) for v in gs[1].split(",")], [float(v) for v in ws[1].split(",")], atol=2e-5), (g, w)
