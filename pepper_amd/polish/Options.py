@@ -8,6 +8,8 @@ class ImageSizeOptions(object):
     SEQ_OVERLAP = 50
     LABEL_LENGTH = SEQ_LENGTH
     TOTAL_LABELS = 5
+    MIN_SEQUENCE_LENGTH = 1000
+    MIN_IMAGE_OVERLAP = 100
 
 
 class TrainOptions(object):

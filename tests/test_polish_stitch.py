@@ -1,0 +1,101 @@
+"""Polish stitch: the vectorised merge against a literal dictionary
+restatement of /root/reference/pepper/modules/python/Stitch.py:36-128 written here as the checker."""
+import os
+
+import numpy as np
+
+from pepper_amd import h5
+from pepper_amd.polish.DataStorePredict import DataStore
+from pepper_amd.polish.perform_stitch import perform_stitch
+
+DECODE = {1: 'A', 2: 'C', 3: 'G', 4: 'T', 0: ''}
+
+
+def dict_stitch(pred_files, contig, threads=1):
+    """Literal restatement: per piece a dict keyed (pos, idx), later writes overwrite."""
+    keys = []
+    for fn in pred_files:
+        with h5.File(fn) as f:
+            if contig not in f.keys('predictions'):
+                continue
+            for ck in sorted(f.keys('predictions/' + contig)):
+                keys.append((fn, ck, int(f[f'predictions/{contig}/{ck}/contig_start']), int(f[f'predictions/{contig}/{ck}/contig_end'])))
+    keys = sorted(sorted(keys, key=lambda e: e[1]), key=lambda e: (e[2], e[3]))
+    size = max(2, int(len(keys) / threads) + 1)
+    pieces = []
+    for i in range(0, len(keys), size):
+        table = {}
+        for fn, ck, st, en in keys[i:i + size]:
+            with h5.File(fn) as f:
+                for cid in sorted(set(f.keys(f'predictions/{contig}/{ck}')) - {'contig_start', 'contig_end'}):
+                    base = f'predictions/{contig}/{ck}/{cid}/'
+                    for pos, idx, b in zip(f[base + 'position'].tolist(), f[base + 'index'].tolist(), f[base + 'bases'].tolist()):
+                        if st > 0 and pos <= st + 200:
+                            continue
+                        if idx < 0 or pos < 0:
+                            continue
+                        table[(pos, idx)] = b
+        if table:
+            order = sorted(table)
+            pieces.append((order[0][0], order[-1][0], ''.join(DECODE[table[k]] for k in order)))
+    return ''.join(p[2] for p in sorted(pieces, key=lambda e: (e[0], e[1])))
+
+
+def make_region(rng, store, contig, start, end, n_chunks):
+    """Rows (position, insert index) walking the region with occasional insert columns; chunks of 1000
+    rows overlapping by 50, the last one padded with (-1, -1)."""
+    pos, idx = [], []
+    p = start
+    while p < end:
+        pos.append(p)
+        idx.append(0)
+        for k in range(int(rng.integers(0, 3)) if rng.random() < 0.15 else 0):
+            pos.append(p)
+            idx.append(k + 1)
+        p += 1
+    pos, idx = np.array(pos), np.array(idx)
+    cid, at = 0, 0
+    while at < len(pos) and cid < n_chunks:
+        cp, ci = pos[at:at + 1000], idx[at:at + 1000]
+        pad = 1000 - len(cp)
+        cp = np.concatenate([cp, -np.ones(pad, dtype=cp.dtype)])
+        ci = np.concatenate([ci, -np.ones(pad, dtype=ci.dtype)])
+        bases = rng.integers(0, 5, size=1000)
+        store.write_prediction(contig, start, end, cid, cp, ci, bases, rng.integers(0, 60, size=1000))
+        if at + 1000 >= len(pos):
+            break
+        at += 950
+        cid += 1
+
+
+def test_perform_stitch_matches_dictionary_merge(tmp_path):
+    rng = np.random.default_rng(9)
+    pred = tmp_path / "pred"
+    pred.mkdir()
+    files = [str(pred / "pepper_prediction_0.hdf"), str(pred / "pepper_prediction_1.hdf")]
+    with DataStore(files[0], "w") as a, DataStore(files[1], "w") as b:
+        make_region(rng, a, "contig_2", 0, 9000, 12)            # > 10 chunks: ids sort as strings
+        make_region(rng, b, "contig_2", 8900, 12000, 12)        # overlapping neighbour region, other file
+        make_region(rng, a, "contig_2", 11900, 12700, 12)
+        make_region(rng, b, "contig_10", 0, 700, 12)
+        make_region(rng, a, "contig_1", 500, 1800, 12)           # region not starting at 0: head dropped
+    (pred / "readme.txt").write_text("ignored")
+    for threads in (1, 2):
+        out = perform_stitch(str(pred), str(tmp_path / f"out{threads}" / "asm"), threads)
+        assert out.endswith("asm_pepper_polished.fa")
+        lines = open(out).read().splitlines()
+        assert lines[0::2] == [">contig_1", ">contig_2", ">contig_10"]       # natural order
+        for name, seq in zip(lines[0::2], lines[1::2]):
+            want = dict_stitch(files, name[1:], threads)
+            assert len(seq) > 300 and seq == want, name
+
+
+def test_stitch_empty_and_all_gap(tmp_path):
+    pred = tmp_path / "pred"
+    pred.mkdir()
+    with DataStore(str(pred / "p.hdf"), "w") as s:
+        s.write_prediction("c1", 0, 1000, 0, np.arange(1000), np.zeros(1000, dtype=np.int64), np.zeros(1000), np.zeros(1000))
+        s.write_prediction("c2", 0, 10, 0, -np.ones(1000, dtype=np.int64), -np.ones(1000, dtype=np.int64),
+                           np.ones(1000), np.zeros(1000))
+    out = perform_stitch(str(pred), str(tmp_path / "o"), 1)
+    assert open(out).read() == ""             # all-gap consensus and padding-only chunks write nothing
