@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -180,6 +181,18 @@ int upload(DevBuf* b, const std::vector<float>& host) {
     return PA_OK;
 }
 
+// f32 [rows, K] (dense) -> h2 split format on the device (K % 8 == 0); values must fit f16 range
+int upload_h2(DevBuf* b, const float* host, int64_t rows, int K) {
+    for (int64_t i = 0; i < rows * K; ++i)
+        if (!(std::fabs(host[i]) < 65504.0f))
+            return fail(PA_ERR_INVALID, "weight magnitude >= 65504 (or NaN): not representable in the split-f16 GEMM path");
+    std::vector<uint32_t> h((size_t)rows * K);
+    pa::split_h2_host(host, h.data(), rows, K, K, K);
+    if (int rc = b->ensure(h.size() * sizeof(uint32_t))) return rc;
+    HIP_TRY(hipMemcpy(b->p, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return PA_OK;
+}
+
 // W_hh [G*H, H] of both directions -> fragment order [dir][G*H/32][H/8][64][4] (rnn.hip):
 // lane l of n-tile nt, k-block kb holds W[nt*32 + (l&31)][kb*8 + 4*(l>>5) + e], e = 0..3.
 void pack_rec_weights(const float* const w[2], int G, int H, std::vector<float>& out) {
@@ -218,6 +231,7 @@ struct RecLayer {
     DevBuf *w_cat = nullptr;   // LSTM first layer only: fused [W_hh | W_ih] fragments
     int K = 0, Kp = 0;         // input width and its zero-padded row length
     DevBuf *w_ih = nullptr;    // [2*G*H, Kp]   rows: dir*G*H + gate*H + unit
+    DevBuf *w_ih_h2 = nullptr; // the same matrix in the h2 split format (gemm_h2.hip), when K % 32 == 0
     DevBuf *b_in = nullptr;    // [2*G*H]       LSTM: b_ih + b_hh; GRU: b_ih + (b_hr, b_hz, 0)
     DevBuf *w_hh = nullptr;    // packed
     DevBuf *b_hn = nullptr;    // GRU only: [2*H]
@@ -257,6 +271,10 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
     if (int rc = upload(out.w_ih, w)) return rc;
     if (int rc = upload(out.b_in, b)) return rc;
     if (int rc = upload(out.w_hh, packed)) return rc;
+    if (K % 32 == 0) {
+        out.w_ih_h2 = m->new_buf();
+        if (int rc = upload_h2(out.w_ih_h2, w.data(), (int64_t)2 * G * H, K)) return rc;
+    }
     if (G == 3) {
         out.b_hn = m->new_buf();
         if (int rc = upload(out.b_hn, bn)) return rc;
@@ -273,9 +291,11 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
 struct Linear {
     int in = 0, out = 0;
     DevBuf *w = nullptr, *b = nullptr;
+    DevBuf *w_h2 = nullptr;    // h2 split copy for the f16-pipe GEMM (built on request)
 };
 
-int build_linear(ModelBase* m, const StateDict& sd, const std::string& name, int in, int out, Linear& l) {
+int build_linear(ModelBase* m, const StateDict& sd, const std::string& name, int in, int out, Linear& l,
+                 bool with_h2 = false) {
     std::string err;
     const float* w = sd.get(name + ".weight", (int64_t)in * out, err);
     const float* b = w ? sd.get(name + ".bias", out, err) : nullptr;
@@ -285,6 +305,10 @@ int build_linear(ModelBase* m, const StateDict& sd, const std::string& name, int
     l.w = m->new_buf();
     l.b = m->new_buf();
     if (int rc = upload(l.w, std::vector<float>(w, w + (size_t)in * out))) return rc;
+    if (with_h2 && in % 32 == 0) {
+        l.w_h2 = m->new_buf();
+        if (int rc = upload_h2(l.w_h2, w, out, in)) return rc;
+    }
     return upload(l.b, std::vector<float>(b, b + out));
 }
 
@@ -329,6 +353,7 @@ struct pa_variant_model : ModelBase {
     pa_variant_config cfg{};
     int H = 256, L1 = 512;
     bool fuse_input = true;      // PA_FUSE_INPUT=0 falls back to GEMM + Xp for A/B measurements
+    bool split_gemm = true;      // PA_SPLIT_GEMM=0 keeps the big GEMMs on the f32 matrix instructions
     std::vector<RecLayer> rec;   // encoder layers then decoder layers
     Linear lin[5], out;
     DevBuf *xp, *ya, *yb, *l1, *l2, *stage_in, *stage_p, *stage_l;
@@ -354,6 +379,7 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     m->cfg = *cfg;
     if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 16384;
     if (const char* e = getenv("PA_FUSE_INPUT")) m->fuse_input = e[0] != '0';
+    if (const char* e = getenv("PA_SPLIT_GEMM")) m->split_gemm = e[0] != '0';
     int rc = init_base(m, cfg->device, hip_stream);
     StateDict sd(names, data, numel, n_tensors);
     const int H = m->H;
@@ -365,7 +391,7 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
         }
     const char* lin_names[5] = {"linear_1", "linear_2", "linear_3", "linear_4", "linear_5"};
     for (int i = 0; i < 5 && rc == PA_OK; ++i)
-        rc = build_linear(m, sd, lin_names[i], i == 0 ? 2 * H * cfg->window : m->L1, m->L1, m->lin[i]);
+        rc = build_linear(m, sd, lin_names[i], i == 0 ? 2 * H * cfg->window : m->L1, m->L1, m->lin[i], i == 0);
     if (rc == PA_OK) rc = build_linear(m, sd, "output_layer_type", m->L1, cfg->num_classes_type, m->out);
     if (rc != PA_OK) {
         delete m;
@@ -411,9 +437,21 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
                        pa::launch_lstm_rec_fused(H, static_cast<const int8_t*>(cur), r.K, r.b_in->f(),
                                                  r.w_cat->f(), y, 2 * H, (int)n, T, m->stream));
         } else {
-            LAUNCH_TRY(m, li == 0 ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
-                       pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
-                                          NX, (int)(np * T), NX, r.K, 0, 0, 0, T, (int)n, m->stream));
+            if (li > 0 && m->split_gemm && r.w_ih_h2 != nullptr) {
+                // previous layer's y is only read by this projection: split it in place, then the
+                // three-MFMA f16 product (gemm_h2.hip)
+                const size_t a_bytes = (size_t)M * cur_ld * sizeof(float);
+                LAUNCH_TRY(m, "cvt_h2", 0.0,
+                           pa::launch_f32_to_h2(static_cast<const float*>(cur), const_cast<void*>(cur), M, r.K, cur_ld,
+                                                m->stream));
+                LAUNCH_TRY(m, "gemm_h2_inproj", 2.0 * M * NX * r.K,
+                           pa::launch_gemm_h2(cur, cur_ld, a_bytes, r.w_ih_h2->p, r.K, (size_t)NX * r.K * 4, r.b_in->f(),
+                                              m->xp->f(), NX, (int)(np * T), NX, r.K, 0, 0, 0, T, (int)n, m->stream));
+            } else {
+                LAUNCH_TRY(m, li == 0 ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
+                           pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
+                                              NX, (int)(np * T), NX, r.K, 0, 0, 0, T, (int)n, m->stream));
+            }
             LAUNCH_TRY(m, "lstm_rec", 2.0 * n * T * (4.0 * H) * H * 2,
                        pa::launch_lstm_rec(H, m->xp->f(), NX, r.w_hh->f(), y, 2 * H, (int)n, T, m->stream));
         }
@@ -424,9 +462,17 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     }
     // flatten(start_dim=1, end_dim=2): [n, T, 2H] rows are already contiguous -> [n, T*2H]
     const int K1 = T * 2 * H;
-    LAUNCH_TRY(m, "gemm_linear_1", 2.0 * n * m->L1 * K1,
-               pa::launch_gemm_nt(pa::A_F32, cur, K1, m->lin[0].w->f(), K1, m->lin[0].b->f(), m->l1->f(),
-                                  m->L1, (int)n, m->L1, K1, 1, 0, 0, 0, 0, m->stream));
+    if (m->split_gemm && m->lin[0].w_h2 != nullptr && cur_kind == pa::A_F32) {
+        LAUNCH_TRY(m, "cvt_h2", 0.0,
+                   pa::launch_f32_to_h2(static_cast<const float*>(cur), const_cast<void*>(cur), n, K1, K1, m->stream));
+        LAUNCH_TRY(m, "gemm_h2_linear_1", 2.0 * n * m->L1 * K1,
+                   pa::launch_gemm_h2(cur, K1, (size_t)n * K1 * 4, m->lin[0].w_h2->p, K1, (size_t)m->L1 * K1 * 4,
+                                      m->lin[0].b->f(), m->l1->f(), m->L1, (int)n, m->L1, K1, 1, 0, 0, 0, 0, m->stream));
+    } else {
+        LAUNCH_TRY(m, "gemm_linear_1", 2.0 * n * m->L1 * K1,
+                   pa::launch_gemm_nt(pa::A_F32, cur, K1, m->lin[0].w->f(), K1, m->lin[0].b->f(), m->l1->f(),
+                                      m->L1, (int)n, m->L1, K1, 1, 0, 0, 0, 0, m->stream));
+    }
     float* a = m->l1->f();
     float* b = m->l2->f();
     for (int i = 1; i < 5; ++i) {
@@ -499,6 +545,7 @@ int pa_variant_forward_host(pa_variant_model* m, const int8_t* images, int64_t n
 struct pa_polish_model : ModelBase {
     pa_polish_config cfg{};
     bool fuse_input = true;      // PA_FUSE_INPUT=0 falls back to GEMM + Xp
+    bool split_gemm = true;      // PA_SPLIT_GEMM=0 keeps the projections on the f32 matrix instructions
     std::vector<RecLayer> enc, dec;
     Linear dense;
     DevBuf *xp, *y1, *y2, *hid_a, *hid_b, *acc, *stage_in, *stage_lab, *stage_ph, *stage_acc;
@@ -540,9 +587,20 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
                 which ^= 1;
                 continue;
             }
-            LAUNCH_TRY(m, (stage == 0 && l == 0) ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
-                       pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
-                                          NX, (int)(round_up(n, MTP) * T), NX, r.K, 0, 0, cur_bs, T, (int)n, m->stream));
+            if (!(stage == 0 && l == 0) && m->split_gemm && r.w_ih_h2 != nullptr) {
+                // the previous layer's y (workspace, read only here): split in place, f16-pipe GEMM
+                LAUNCH_TRY(m, "cvt_h2", 0.0,
+                           pa::launch_f32_to_h2(static_cast<const float*>(cur), const_cast<void*>(cur), M, r.K, cur_ld,
+                                                m->stream));
+                LAUNCH_TRY(m, "gemm_h2_inproj", 2.0 * M * NX * r.K,
+                           pa::launch_gemm_h2(cur, cur_ld, (size_t)M * cur_ld * 4, r.w_ih_h2->p, r.K, (size_t)NX * r.K * 4,
+                                              r.b_in->f(), m->xp->f(), NX, (int)(round_up(n, MTP) * T), NX, r.K, 0, 0, 0, T,
+                                              (int)n, m->stream));
+            } else {
+                LAUNCH_TRY(m, (stage == 0 && l == 0) ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
+                           pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(), NX,
+                                              (int)(round_up(n, MTP) * T), NX, r.K, 0, 0, cur_bs, T, (int)n, m->stream));
+            }
             float* y = ybuf[which];
             LAUNCH_TRY(m, "gru_rec", 2.0 * n * T * (3.0 * H) * H * 2,
                        pa::launch_gru_rec(H, m->xp->f(), NX, r.w_hh->f(), r.b_hn->f(),
@@ -585,6 +643,7 @@ int pa_polish_create(const pa_polish_config* cfg, const char* const* names, cons
     m->cfg = *cfg;
     if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 8192;
     if (const char* e = getenv("PA_FUSE_INPUT")) m->fuse_input = e[0] != '0';
+    if (const char* e = getenv("PA_SPLIT_GEMM")) m->split_gemm = e[0] != '0';
     int rc = init_base(m, cfg->device, hip_stream);
     StateDict sd(names, data, numel, n_tensors);
     const int H = cfg->hidden_size;

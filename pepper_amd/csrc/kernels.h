@@ -21,6 +21,15 @@ hipError_t launch_gemm_nt(int a_type, const void* A, int lda, const float* W, in
                           const float* bias, float* C, int ldc, int M, int N, int K, int act,
                           int a_rpb, int64_t a_bstride, int frag_T, int frag_nb, hipStream_t stream);
 
+// gemm_h2.hip: the same contraction with both operands in the h2 split format (hi/lo f16 pairs, 4
+// bytes per element, see the file header) on the f16 matrix pipe; K % 32 == 0.  lda/ldw/a_bstride
+// are in elements as for launch_gemm_nt; a_bytes / w_bytes bound the buffer descriptors (< 4 GiB).
+hipError_t launch_gemm_h2(const void* A, int lda, size_t a_bytes, const void* W, int ldw, size_t w_bytes,
+                          const float* bias, float* C, int ldc, int M, int N, int K, int act, int a_rpb,
+                          int64_t a_bstride, int frag_T, int frag_nb, hipStream_t stream);
+hipError_t launch_f32_to_h2(const float* src, void* dst, int64_t rows, int K, int64_t ld, hipStream_t stream);
+void split_h2_host(const float* src, uint32_t* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst);
+
 // rnn.hip: Xp [Bpad*T, ldx], Y [Bpad*T, ldy]; Bpad = B rounded up to 64 rows (workspace buffers).
 // Packed recurrent weights: [dir][G*H/32][H/8][64 lanes][4] (see pack_rec_weights in api.hip).
 hipError_t launch_lstm_rec(int H, const float* Xp, int ldx, const float* Wp, float* Y, int ldy,
