@@ -232,6 +232,8 @@ struct RecLayer {
     int K = 0, Kp = 0;         // input width and its zero-padded row length
     DevBuf *w_ih = nullptr;    // [2*G*H, Kp]   rows: dir*G*H + gate*H + unit
     DevBuf *w_ih_h2 = nullptr; // the same matrix in the h2 split format (gemm_h2.hip), when K % 32 == 0
+    DevBuf *w_hh_h2 = nullptr;  // LSTM H=256: W_hh as h2 fragments (rnn_h2.hip)
+    DevBuf *w_cat_h2 = nullptr; // LSTM first layer: [W_hh | W_ih] as h2 fragments
     DevBuf *b_in = nullptr;    // [2*G*H]       LSTM: b_ih + b_hh; GRU: b_ih + (b_hr, b_hz, 0)
     DevBuf *w_hh = nullptr;    // packed
     DevBuf *b_hn = nullptr;    // GRU only: [2*H]
@@ -278,6 +280,27 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
     if (G == 3) {
         out.b_hn = m->new_buf();
         if (int rc = upload(out.b_hn, bn)) return rc;
+    }
+    if (G == 4 && H == 256) {
+        auto pack_upload = [&](DevBuf*& dst, const float* const wx[2], int KX) -> int {
+            for (int d = 0; d < 2; ++d) {
+                for (int64_t i = 0; i < (int64_t)G * H * H; ++i)
+                    if (!(std::fabs(whh[d][i]) < 65504.0f)) return fail(PA_ERR_INVALID, "recurrent weight not representable in f16 range");
+                if (wx[0])
+                    for (int64_t i = 0; i < (int64_t)G * H * K; ++i)
+                        if (!(std::fabs(wx[d][i]) < 65504.0f)) return fail(PA_ERR_INVALID, "input weight not representable in f16 range");
+            }
+            std::vector<uint32_t> hp(pa::rec_weights_h2_words(G, H, KX));
+            pa::pack_rec_weights_h2(whh, wx, G, H, K, KX, hp.data());
+            dst = m->new_buf();
+            if (int rc = dst->ensure(hp.size() * sizeof(uint32_t))) return rc;
+            HIP_TRY(hipMemcpy(dst->p, hp.data(), hp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            return PA_OK;
+        };
+        const float* const none[2] = {nullptr, nullptr};
+        if (int rc = pack_upload(out.w_hh_h2, none, 0)) return rc;
+        if (K <= 32)
+            if (int rc = pack_upload(out.w_cat_h2, wih, 32)) return rc;
     }
     if ((G == 4 && H == 256 && K <= 32) || (G == 3 && H == 128 && K <= 16)) {
         std::vector<float> cat;
@@ -354,6 +377,7 @@ struct pa_variant_model : ModelBase {
     int H = 256, L1 = 512;
     bool fuse_input = true;      // PA_FUSE_INPUT=0 falls back to GEMM + Xp for A/B measurements
     bool split_gemm = true;      // PA_SPLIT_GEMM=0 keeps the big GEMMs on the f32 matrix instructions
+    bool split_rec = true;       // PA_SPLIT_REC=0 keeps the recurrences on the f32 matrix instructions
     std::vector<RecLayer> rec;   // encoder layers then decoder layers
     Linear lin[5], out;
     DevBuf *xp, *ya, *yb, *l1, *l2, *stage_in, *stage_p, *stage_l;
@@ -380,6 +404,8 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 16384;
     if (const char* e = getenv("PA_FUSE_INPUT")) m->fuse_input = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_GEMM")) m->split_gemm = e[0] != '0';
+    if (const char* e = getenv("PA_SPLIT_REC")) m->split_rec = e[0] != '0';
+    m->split_rec = m->split_rec && m->split_gemm;   // the h2 layer output needs the h2 consumers
     int rc = init_base(m, cfg->device, hip_stream);
     StateDict sd(names, data, numel, n_tensors);
     const int H = m->H;
@@ -425,25 +451,33 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
 
     const void* cur = images;
     int cur_kind = a_kind, cur_ld = F;
+    bool cur_h2 = false;         // cur is a layer output already in the h2 split format
     float* ybuf[2] = {m->ya->f(), m->yb->f()};
     int which = 0;
     const int M = (int)(n * T);
     for (size_t li = 0; li < m->rec.size(); ++li) {
         const RecLayer& r = m->rec[li];
         float* y = ybuf[which];
+        const bool rec_h2 = m->split_rec && r.w_hh_h2 != nullptr;
         if (li == 0 && cur_kind == pa::A_I8 && r.w_cat != nullptr && m->fuse_input) {
-            // int8 summaries straight into the recurrent kernel: no Xp round trip (rnn.hip)
-            LAUNCH_TRY(m, "lstm_rec_fused_in", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
-                       pa::launch_lstm_rec_fused(H, static_cast<const int8_t*>(cur), r.K, r.b_in->f(),
-                                                 r.w_cat->f(), y, 2 * H, (int)n, T, m->stream));
+            // int8 summaries straight into the recurrent kernel: no Xp round trip
+            if (rec_h2 && r.w_cat_h2 != nullptr)
+                LAUNCH_TRY(m, "lstm_rec_h2_fused_in", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
+                           pa::launch_lstm_rec_h2(H, nullptr, 0, static_cast<const int8_t*>(cur), r.K, r.b_in->f(),
+                                                  r.w_cat_h2->p, y, 2 * H, (int)n, T, m->stream));
+            else
+                LAUNCH_TRY(m, "lstm_rec_fused_in", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
+                           pa::launch_lstm_rec_fused(H, static_cast<const int8_t*>(cur), r.K, r.b_in->f(),
+                                                     r.w_cat->f(), y, 2 * H, (int)n, T, m->stream));
         } else {
             if (li > 0 && m->split_gemm && r.w_ih_h2 != nullptr) {
-                // previous layer's y is only read by this projection: split it in place, then the
-                // three-MFMA f16 product (gemm_h2.hip)
+                // the previous layer's y is only read by this projection: if it is still f32, split it
+                // in place; then the three-MFMA f16 product (gemm_h2.hip)
                 const size_t a_bytes = (size_t)M * cur_ld * sizeof(float);
-                LAUNCH_TRY(m, "cvt_h2", 0.0,
-                           pa::launch_f32_to_h2(static_cast<const float*>(cur), const_cast<void*>(cur), M, r.K, cur_ld,
-                                                m->stream));
+                if (!cur_h2)
+                    LAUNCH_TRY(m, "cvt_h2", 0.0,
+                               pa::launch_f32_to_h2(static_cast<const float*>(cur), const_cast<void*>(cur), M, r.K,
+                                                    cur_ld, m->stream));
                 LAUNCH_TRY(m, "gemm_h2_inproj", 2.0 * M * NX * r.K,
                            pa::launch_gemm_h2(cur, cur_ld, a_bytes, r.w_ih_h2->p, r.K, (size_t)NX * r.K * 4, r.b_in->f(),
                                               m->xp->f(), NX, (int)(np * T), NX, r.K, 0, 0, 0, T, (int)n, m->stream));
@@ -452,19 +486,26 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
                            pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
                                               NX, (int)(np * T), NX, r.K, 0, 0, 0, T, (int)n, m->stream));
             }
-            LAUNCH_TRY(m, "lstm_rec", 2.0 * n * T * (4.0 * H) * H * 2,
-                       pa::launch_lstm_rec(H, m->xp->f(), NX, r.w_hh->f(), y, 2 * H, (int)n, T, m->stream));
+            if (rec_h2)
+                LAUNCH_TRY(m, "lstm_rec_h2", 2.0 * n * T * (4.0 * H) * H * 2,
+                           pa::launch_lstm_rec_h2(H, m->xp->f(), NX, nullptr, 0, nullptr, r.w_hh_h2->p, y, 2 * H, (int)n,
+                                                  T, m->stream));
+            else
+                LAUNCH_TRY(m, "lstm_rec", 2.0 * n * T * (4.0 * H) * H * 2,
+                           pa::launch_lstm_rec(H, m->xp->f(), NX, r.w_hh->f(), y, 2 * H, (int)n, T, m->stream));
         }
         cur = y;
         cur_kind = pa::A_F32;
         cur_ld = 2 * H;
+        cur_h2 = rec_h2;
         which ^= 1;
     }
     // flatten(start_dim=1, end_dim=2): [n, T, 2H] rows are already contiguous -> [n, T*2H]
     const int K1 = T * 2 * H;
     if (m->split_gemm && m->lin[0].w_h2 != nullptr && cur_kind == pa::A_F32) {
-        LAUNCH_TRY(m, "cvt_h2", 0.0,
-                   pa::launch_f32_to_h2(static_cast<const float*>(cur), const_cast<void*>(cur), n, K1, K1, m->stream));
+        if (!cur_h2)
+            LAUNCH_TRY(m, "cvt_h2", 0.0,
+                       pa::launch_f32_to_h2(static_cast<const float*>(cur), const_cast<void*>(cur), n, K1, K1, m->stream));
         LAUNCH_TRY(m, "gemm_h2_linear_1", 2.0 * n * m->L1 * K1,
                    pa::launch_gemm_h2(cur, K1, (size_t)n * K1 * 4, m->lin[0].w_h2->p, K1, (size_t)m->L1 * K1 * 4,
                                       m->lin[0].b->f(), m->l1->f(), m->L1, (int)n, m->L1, K1, 1, 0, 0, 0, 0, m->stream));

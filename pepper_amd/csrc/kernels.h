@@ -48,6 +48,16 @@ hipError_t launch_gru_rec_fused(int H, const uint8_t* X, int F, int64_t x_bstrid
                                 const float* Wcat, const float* bhn, const float* h0, int ldh0, float* hn, int ldhn,
                                 float* Y, int ldy, int B, int T, hipStream_t stream);
 
+// rnn_h2.hip: the LSTM step loop on the f16 matrix pipe.  Weights packed by pack_rec_weights_h2
+// (wih = {nullptr, nullptr}, KX = 0 for W_hh alone; KX = 32 for the fused first layer).  X != nullptr
+// selects the fused form (int8 rows [B, T, F], bias [2*4H]); otherwise Xp seeds the accumulators as in
+// launch_lstm_rec.  Y receives the layer output in the h2 split format (ldy in 4-byte elements).
+void pack_rec_weights_h2(const float* const whh[2], const float* const wih[2], int G, int H, int F, int KX,
+                         uint32_t* out);
+size_t rec_weights_h2_words(int G, int H, int KX);
+hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, int F, const float* bias,
+                              const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream);
+
 // head.hip
 hipError_t launch_dense_small(int mode, const float* X, int ldx, const float* W, const float* bias,
                               float* out0, float* out1, int rows, int K, int C, int T, int S, int off,

@@ -1,0 +1,316 @@
+// LSTM step loop on the f16 matrix pipe with split (h2) operands -- the fast form of
+// rnn.hip:lstm_rec_kernel for the variant model's four H = 256 directions
+// (/root/reference/pepper_variant/modules/python/models/simple_model.py:51,54).
+//
+// Same decomposition and lockstep phase structure as the f32 kernel (workgroup = 64 batch rows x one
+// direction, wave u owns hidden units [32u, 32u+32) of all four gates and both row tiles, MFMA phase
+// | barrier | gate phase | barrier), but the contraction h_{t-1} W_hh^T (+ x_t W_ih^T when the input
+// projection is fused) runs as three v_mfma_f32_32x32x16_f16 per 16-wide k step on operands held as
+// f16 hi/lo pairs (gemm_h2.hip describes the format and why it is as accurate as f32):
+//   * h lives in LDS in h2 form (32 bytes per 8 units: 16 B hi, 16 B lo); the gate phase rounds
+//     the new h to (hi, lo), neighbouring lanes swap one half through DPP so each lane still writes
+//     one dword per element;
+//   * y is that LDS image copied out 16 bytes per lane during the MFMA phase, i.e. the layer output
+//     is ALREADY in the h2 format the next projection GEMM / linear_1 consumes -- no conversion pass;
+//   * W_hh (and W_ih for the fused first layer, whose int8 inputs are exact in the hi half) is packed
+//     on the host in per-lane fragment order [gate tile][k step][hi, lo][64 lanes][16 B], streamed
+//     from L2 through a 2-deep register ring.
+// Per step a wave issues 24 MFMAs x 32 cycles per k step instead of 128 x 64: the MFMA phase shrinks
+// ~5x and the weight stream (1 MiB per step per workgroup, same bytes as f32) becomes the thing to
+// watch (~40 B/clk/CU of the ~64 B/clk/CU L2 path).
+#include <cstdlib>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int MT = 64;
+
+PA_DEV f32x16 mfma_h(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+PA_DEV void decode_block(int bid, int& dir, int& btile) {
+    const int xcd = bid & 7, q = bid >> 3;   // XCDs 0-3 forward, 4-7 reverse (rnn.hip)
+    dir = xcd >> 2;
+    btile = q * 4 + (xcd & 3);
+}
+
+// value of lane ^ 1 (quad_perm [1,0,3,2])
+PA_DEV unsigned swap_pair(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
+
+template <int H, int KX>
+__global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
+                                                                     const int8_t* __restrict__ Xi, int F,
+                                                                     const float* __restrict__ bias,
+                                                                     const uint32_t* __restrict__ Wp,
+                                                                     uint32_t* __restrict__ Y, int ldy, int B, int T) {
+    constexpr int KT = H + KX, KS = KT / 16, NT = H / 32, NW = H / 32;
+    constexpr int ROWB = KT * 4 + 16;            // bytes per LDS row: h2 image of [h | x] + 16 pad (odd 16-B count)
+    constexpr int ROWD = ROWB / 4;               // in dwords
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [MT][ROWD] h2 rows, then c (f32)
+    static_assert((ROWB / 16) % 2 == 1, "row stride must be an odd number of 16-byte slots");
+
+    int dir, btile;
+    decode_block(blockIdx.x, dir, btile);
+    const int b0 = btile * MT;
+    if (b0 >= B) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hf = lane >> 5;
+
+    float* cs = reinterpret_cast<float*>(lds + MT * ROWD) + u * (2 * 16 * 64) + lane;     // [wave][m][r][lane]
+    for (int idx = tid; idx < MT * ROWD + NW * 2 * 16 * 64; idx += blockDim.x) lds[idx] = 0u;
+
+    f32x16 acc[2][4];   // [row tile][gate]
+
+    const size_t urow = (size_t)b0 * T;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(KX ? bias + dir * 4 * H + 32 * u : Xp + (size_t)(b0 >> 5) * T * (ldx >> 5) * 1024), 0,
+        0x7fffffff, 0x00020000);
+    // fragment (g, s, hi/lo) of this wave lives at byte (((g*NT + u) * KS + s) * 2 + hl) * 1024 + lane * 16
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(Wp + (size_t)dir * (4 * NT) * KS * 512), 0, 0x7fffffff, 0x00020000);
+    const unsigned xoff = KX ? li * 4u : lane * 16u;
+    const unsigned woff = lane * 16u;
+
+    // accumulator seed of (row tile m, register chunk qd) for step t (identical to rnn.hip)
+    auto seed_chunk = [&](int m, int qd, int t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (KX) {
+                const float bv = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff, (unsigned)(g * H) * 4u, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[m][g][4 * qd + e] = bv;
+            } else {
+                const unsigned ct = (unsigned)(dir * (4 * NT) + g * NT + u);
+                const unsigned so = (((unsigned)(m * T + t) * (ldx >> 5) + ct) * 4u + qd) * 1024u;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
+                acc[m][g][4 * qd] = v.x;
+                acc[m][g][4 * qd + 1] = v.y;
+                acc[m][g][4 * qd + 2] = v.z;
+                acc[m][g][4 * qd + 3] = v.w;
+            }
+        }
+    };
+
+    // fused only: x_t (int8, exact in f16) -> hi halves of LDS columns [H, H+KX); lo halves stay 0.
+    // One thread per pair of features: 64 rows x KX/2 pairs over 512 threads.
+    constexpr int XN = KX ? (MT * KX / 2) / (NW * 64) : 1;
+    unsigned xv[XN];
+    auto x_load = [&](int t) {
+        if (KX) {
+#pragma unroll
+            for (int k = 0; k < XN; ++k) {
+                const int e = tid + k * (NW * 64);
+                const int row = e / (KX / 2), f = (e % (KX / 2)) * 2;
+                int brow = b0 + row;
+                brow = brow < B ? brow : B - 1;
+                const int8_t* src = Xi + ((size_t)brow * T + t) * F;
+                const _Float16 h0 = f < F ? (_Float16)(float)src[f] : (_Float16)0.0f;
+                const _Float16 h1 = f + 1 < F ? (_Float16)(float)src[f + 1] : (_Float16)0.0f;
+                xv[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) |
+                        ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            }
+        }
+    };
+    auto x_store = [&]() {
+        if (KX) {
+#pragma unroll
+            for (int k = 0; k < XN; ++k) {
+                const int e = tid + k * (NW * 64);
+                const int row = e / (KX / 2), f = (e % (KX / 2)) * 2;
+                lds[row * ROWD + ((H + f) >> 3) * 8 + ((f & 7) >> 1)] = xv[k];
+            }
+        }
+    };
+
+    struct Frag { h8 b[4][2], a[2][2]; };     // [gate][hi, lo], [row tile][hi, lo]
+    const uint32_t* arow = lds + li * ROWD + hf * 8;
+    auto load_step = [&](int s, Frag& fr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+                fr.b[g][hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         wrs, woff, (unsigned)(((g * NT + u) * KS + s) * 2 + hl) * 1024u, 0));
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            fr.a[m][0] = *reinterpret_cast<const h8*>(arow + m * 32 * ROWD + s * 16);
+            fr.a[m][1] = *reinterpret_cast<const h8*>(arow + m * 32 * ROWD + s * 16 + 4);
+        }
+    };
+
+    // y copy: the h part of the LDS rows (H * 4 bytes = H/4 16-byte chunks per row) -> Y, as is
+    constexpr int CPR = H / 4;                                // 16-byte chunks per row
+    constexpr int YROWS = (NW * 64) / CPR;                    // rows per pass (8)
+    constexpr int YC = MT / YROWS;                            // passes (8)
+    const int yc_row = tid / CPR, yc_c = tid % CPR;
+    const uint32_t* yc_src = lds + yc_row * ROWD + yc_c * 4;
+    const __amdgpu_buffer_rsrc_t ycrs =
+        __builtin_amdgcn_make_buffer_rsrc(Y + urow * ldy + dir * H, 0, 0x7fffffff, 0x00020000);
+    const unsigned yc_off = ((unsigned)(yc_row * T) * ldy + yc_c * 4) * 4u;
+    auto yc_read = [&](int j) { return *reinterpret_cast<const u32x4*>(yc_src + j * YROWS * ROWD); };
+    auto yc_write = [&](int j, int tp, u32x4 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(v, ycrs, yc_off, ((unsigned)(j * YROWS * T + tp) * ldy) * 4u, 0);
+    };
+
+    // gate-phase h write: element (row, col = 32u + li) -> hi half at row*ROWB + (col/8)*32 + (col%8)*2,
+    // lo half 16 bytes later.  Even lanes write the dword {hi(col), hi(col+1)}, odd lanes {lo(col-1), lo(col)}.
+    const int hcol = 32 * u + li;
+    uint32_t* hl_dst = lds + 4 * hf * ROWD + (hcol >> 3) * 8 + ((li & 1) ? 4 : 0) + ((hcol & 7) >> 1);
+    const bool odd = li & 1;
+
+    __syncthreads();
+    {
+        const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) seed_chunk(m, qd, t0);
+        x_load(t0);
+        x_store();
+    }
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        // ---------------- MFMA phase ----------------
+        {
+            Frag ring[2];
+            load_step(0, ring[0]);
+            const int tp = step > 0 ? (dir ? t + 1 : t - 1) : t;   // time index of h_{s-1} (step 0: zeros, rewritten later)
+            u32x4 ycv = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int p = s & 1;
+                if (s + 1 < KS) load_step(s + 1, ring[p ^ 1]);
+                if (s >= 1 && s <= YC) yc_write(s - 1, tp, ycv);
+                if (s < YC) ycv = yc_read(s);
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            acc[m][g] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0], acc[m][g]);
+                if (s + 1 < KS) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (B fragment)
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (A fragment)
+                    }
+                    if (s <= YC) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // 1 VMEM write (y copy)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (y copy)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        lds_barrier();                    // every wave has finished reading h_{t-1}
+
+        // ---------------- gate phase ----------------
+        const int tn = dir ? t - 1 : t + 1;
+        if (step + 1 < T) x_load(tn);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * qd + e;
+                    const float ig = fast_sigmoid(acc[m][0][r]);
+                    const float fg = fast_sigmoid(acc[m][1][r]);
+                    const float gg = fast_tanh(acc[m][2][r]);
+                    const float og = fast_sigmoid(acc[m][3][r]);
+                    const float cn = fg * cs[(m * 16 + r) * 64] + ig * gg;
+                    cs[(m * 16 + r) * 64] = cn;
+                    const float hv = og * fast_tanh(cn);
+                    const _Float16 hi = (_Float16)hv;
+                    const _Float16 lo = (_Float16)(hv - (float)hi);
+                    const unsigned uhi = __builtin_bit_cast(unsigned short, hi), ulo = __builtin_bit_cast(unsigned short, lo);
+                    const unsigned got = swap_pair(odd ? uhi : ulo);   // even lanes send lo, odd lanes send hi
+                    const unsigned word = odd ? (got | (ulo << 16)) : (uhi | (got << 16));
+                    const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
+                    hl_dst[dr * ROWD] = word;
+                }
+                if (step + 1 < T) seed_chunk(m, qd, tn);
+            }
+        if (step + 1 < T) x_store();
+        lds_barrier();                    // h_t (and x_{t+1}) visible
+    }
+    {
+        const int tl = dir ? 0 : T - 1;
+#pragma unroll
+        for (int j = 0; j < YC; ++j) yc_write(j, tl, yc_read(j));
+    }
+}
+
+inline int rec_grid(int B) {
+    const int nbt = (B + MT - 1) / MT;
+    return 2 * ((nbt + 3) / 4) * 4;
+}
+
+}  // namespace
+
+namespace pa {
+
+// W [G*H, K] per direction (K = H, or H + KX with [W_hh | W_ih | 0]) -> per-lane h2 fragments
+// [dir][G*H/32][K/16][hi, lo][64 lanes][8 halves]; lane l of tile nt, step s holds
+// W[nt*32 + (l&31)][16 s + 8 (l>>5) + e], e = 0..7.
+void pack_rec_weights_h2(const float* const whh[2], const float* const wih[2], int G, int H, int F, int KX,
+                         uint32_t* out) {
+    const int KT = H + KX, NTt = G * H / 32, KS = KT / 16;
+    _Float16* o = reinterpret_cast<_Float16*>(out);
+    for (int d = 0; d < 2; ++d)
+        for (int nt = 0; nt < NTt; ++nt)
+            for (int s = 0; s < KS; ++s)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        const int n = nt * 32 + (l & 31), k = 16 * s + 8 * (l >> 5) + e;
+                        float v = 0.0f;
+                        if (k < H) v = whh[d][(size_t)n * H + k];
+                        else if (wih[0] != nullptr && k - H < F) v = wih[d][(size_t)n * F + (k - H)];
+                        const _Float16 hi = (_Float16)v;
+                        const size_t base = ((((size_t)d * NTt + nt) * KS + s) * 2) * 512 + (size_t)l * 8 + e;
+                        o[base] = hi;
+                        o[base + 512] = (_Float16)(v - (float)hi);
+                    }
+}
+
+size_t rec_weights_h2_words(int G, int H, int KX) { return (size_t)2 * (G * H / 32) * ((H + KX) / 16) * 2 * 256; }
+
+hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, int F, const float* bias,
+                              const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    if (H != 256 || (ldy & 7)) return hipErrorInvalidValue;
+    const int grid = rec_grid(B);
+    if (X != nullptr) {
+        if (F <= 0 || F > 32) return hipErrorInvalidValue;
+        const size_t lds = (size_t)MT * ((256 + 32) * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4;
+        hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
+                           F, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y), ldy, B, T);
+    } else {
+        const size_t lds = (size_t)MT * (256 * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4;
+        hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 0>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
+                           (const int8_t*)nullptr, 0, (const float*)nullptr, static_cast<const uint32_t*>(Wp),
+                           static_cast<uint32_t*>(Y), ldy, B, T);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace pa
