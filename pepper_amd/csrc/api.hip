@@ -502,13 +502,20 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     }
     // flatten(start_dim=1, end_dim=2): [n, T, 2H] rows are already contiguous -> [n, T*2H]
     const int K1 = T * 2 * H;
+    // linear_1 has few output tiles (n/256 x 2) and a long K: slice K so that every CU gets a tile; the
+    // partial sums reuse the Xp workspace (dead after the last recurrent layer)
+    const int tiles1 = (int)((n + 255) / 256) * ((m->L1 + 255) / 256);
+    int splits = 1;
+    while (splits < 8 && tiles1 * splits * 2 <= 256 && (size_t)(splits * 2) * n * m->L1 * sizeof(float) <= m->xp->bytes)
+        splits *= 2;
     if (m->split_gemm && m->lin[0].w_h2 != nullptr && cur_kind == pa::A_F32) {
         if (!cur_h2)
             LAUNCH_TRY(m, "cvt_h2", 0.0,
                        pa::launch_f32_to_h2(static_cast<const float*>(cur), const_cast<void*>(cur), n, K1, K1, m->stream));
         LAUNCH_TRY(m, "gemm_h2_linear_1", 2.0 * n * m->L1 * K1,
                    pa::launch_gemm_h2(cur, K1, (size_t)n * K1 * 4, m->lin[0].w_h2->p, K1, (size_t)m->L1 * K1 * 4,
-                                      m->lin[0].b->f(), m->l1->f(), m->L1, (int)n, m->L1, K1, 1, 0, 0, 0, 0, m->stream));
+                                      m->lin[0].b->f(), m->l1->f(), m->L1, (int)n, m->L1, K1, 1, 0, 0, 0, 0, m->stream,
+                                      splits > 1 ? m->xp->f() : nullptr, splits));
     } else {
         LAUNCH_TRY(m, "gemm_linear_1", 2.0 * n * m->L1 * K1,
                    pa::launch_gemm_nt(pa::A_F32, cur, K1, m->lin[0].w->f(), K1, m->lin[0].b->f(), m->l1->f(),

@@ -25,6 +25,7 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -140,14 +141,19 @@ __global__ __launch_bounds__(256) void gemm_h2_kernel(const uint32_t* __restrict
             for (int n = 0; n < 4; ++n) acc[m][n] = mfma_h(f.a[m][0], f.b[n][0], acc[m][n]);
     };
 
-    const int nk = K / HK;
+    // split-K: gridDim.y slices of the k-tile range; slice y writes its partial sums to C + y * M * ldc
+    // (bias / activation are applied by splitk_finish_kernel)
+    const int nk_all = K / HK;
+    const int kbeg = (int)((long long)nk_all * blockIdx.y / gridDim.y);
+    const int nk = (int)((long long)nk_all * (blockIdx.y + 1) / gridDim.y) - kbeg;
+    C += (size_t)blockIdx.y * M * ldc;
     Frag f0, f1;
 
-    gload_a(0, 0, 8);
-    gload_w(0, 0, 8);
+    gload_a(kbeg, 0, 8);
+    gload_w(kbeg, 0, 8);
     lstore(0);
-    gload_a(nk > 1 ? 1 : 0, 0, 8);
-    gload_w(nk > 1 ? 1 : 0, 0, 8);
+    gload_a(kbeg + (nk > 1 ? 1 : 0), 0, 8);
+    gload_w(kbeg + (nk > 1 ? 1 : 0), 0, 8);
     __syncthreads();
     read_step(0, 0, f0);
     if (EXP & 4) read_step(0, 1, f1);
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm_h2_kernel(const uint32_t* __restrict
     // branch free (tail iterations re-request the last tile and write a buffer nobody reads).
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        const int nxt2 = kt + 2 < nk ? kt + 2 : nk - 1;
+        const int nxt2 = kbeg + (kt + 2 < nk ? kt + 2 : nk - 1);
         if (!(EXP & 4)) read_step(buf, 1, f1);
         if (!(EXP & 2)) lstore(buf ^ 1);
         if (!(EXP & 1)) gload_a(nxt2, 0, 8);
@@ -243,6 +249,24 @@ __global__ __launch_bounds__(256) void gemm_h2_kernel(const uint32_t* __restrict
     }
 }
 
+// C = act(sum of split-K partials + bias); partials [S][M][N] dense, 4 columns per thread.
+template <int ACT>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int S, const float* __restrict__ bias,
+                                                            float* __restrict__ C, int ldc, int M, int N) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = N >> 2;
+    if (idx >= (size_t)M * n4) return;
+    const int row = (int)(idx / n4), c = (int)(idx % n4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)row * N + c);
+    for (int s = 1; s < S; ++s) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(part + ((size_t)s * M + row) * N + c);
+        v += w;
+    }
+    if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + c);
+    if (ACT == 1) { v.x = selu_f(v.x); v.y = selu_f(v.y); v.z = selu_f(v.z); v.w = selu_f(v.w); }
+    *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + c) = v;
+}
+
 // f32 rows -> h2 rows (same strides).  One thread per group of 8 k.
 __global__ __launch_bounds__(256) void f32_to_h2_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst,
                                                         int64_t rows, int K, int64_t ld) {
@@ -294,7 +318,8 @@ hipError_t launch_f32_to_h2(const float* src, void* dst, int64_t rows, int K, in
 
 hipError_t launch_gemm_h2(const void* A, int lda, size_t a_bytes, const void* W, int ldw, size_t w_bytes,
                           const float* bias, float* C, int ldc, int M, int N, int K, int act, int a_rpb,
-                          int64_t a_bstride, int frag_T, int frag_nb, hipStream_t stream) {
+                          int64_t a_bstride, int frag_T, int frag_nb, hipStream_t stream, float* splitk_ws,
+                          int splits) {
     if (frag_T > 0 && ((M & 31) || (N & 31) || act != 0)) return hipErrorInvalidValue;
     if ((K % HK) || (lda & 7) || (ldw & 7) || (a_bstride & 7) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15))
         return hipErrorInvalidValue;
@@ -304,6 +329,19 @@ hipError_t launch_gemm_h2(const void* A, int lda, size_t a_bytes, const void* W,
     if (nwg == 0) return hipSuccess;
     const uint32_t* Au = reinterpret_cast<const uint32_t*>(A);
     const uint32_t* Wu = reinterpret_cast<const uint32_t*>(W);
+    if (splits > 1 && splitk_ws != nullptr && frag_T == 0 && !(N & 3) && K / HK >= splits) {
+        hipLaunchKernelGGL((gemm_h2_kernel<0>), dim3(nwg, splits), dim3(256), 0, stream, Au, lda, (uint32_t)a_bytes, Wu, ldw,
+                           (uint32_t)w_bytes, (const float*)nullptr, splitk_ws, N, M, N, K, tiles_n, nwg, a_rpb, a_bstride,
+                           0, 0);
+        const size_t n4 = (size_t)M * (N >> 2);
+        if (act == 1)
+            hipLaunchKernelGGL((splitk_finish_kernel<1>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
+                               splitk_ws, splits, bias, C, ldc, M, N);
+        else
+            hipLaunchKernelGGL((splitk_finish_kernel<0>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
+                               splitk_ws, splits, bias, C, ldc, M, N);
+        return hipGetLastError();
+    }
     if (g_h2_exp > 0 && g_h2_exp < 8) {
 #define PA_EXP(E_) case E_: hipLaunchKernelGGL((gemm_h2_kernel<0, E_>), dim3(nwg), dim3(256), 0, stream, Au, lda, (uint32_t)a_bytes, Wu, ldw, (uint32_t)w_bytes, bias, C, ldc, M, N, K, tiles_n, nwg, a_rpb, a_bstride, frag_T, frag_nb); break;
         switch (g_h2_exp) { PA_EXP(1) PA_EXP(2) PA_EXP(3) PA_EXP(4) PA_EXP(5) PA_EXP(6) PA_EXP(7) }

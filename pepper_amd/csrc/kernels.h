@@ -26,7 +26,8 @@ hipError_t launch_gemm_nt(int a_type, const void* A, int lda, const float* W, in
 // are in elements as for launch_gemm_nt; a_bytes / w_bytes bound the buffer descriptors (< 4 GiB).
 hipError_t launch_gemm_h2(const void* A, int lda, size_t a_bytes, const void* W, int ldw, size_t w_bytes,
                           const float* bias, float* C, int ldc, int M, int N, int K, int act, int a_rpb,
-                          int64_t a_bstride, int frag_T, int frag_nb, hipStream_t stream);
+                          int64_t a_bstride, int frag_T, int frag_nb, hipStream_t stream,
+                          float* splitk_ws = nullptr, int splits = 1);   // splitk_ws: [splits][M][N] floats
 hipError_t launch_f32_to_h2(const float* src, void* dst, int64_t rows, int K, int64_t ld, hipStream_t stream);
 void split_h2_host(const float* src, uint32_t* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst);
 

@@ -45,11 +45,13 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                                                                      const int8_t* __restrict__ Xi, int F,
                                                                      const float* __restrict__ bias,
                                                                      const uint32_t* __restrict__ Wp,
-                                                                     uint32_t* __restrict__ Y, int ldy, int B, int T) {
+                                                                     uint32_t* __restrict__ Y, int ldy, int B, int T,
+                                                                     unsigned long long* __restrict__ dbg) {
     constexpr int KT = H + KX, KS = KT / 16, NT = H / 32, NW = H / 32;
     constexpr int ROWB = KT * 4 + 16;            // bytes per LDS row: h2 image of [h | x] + 16 pad (odd 16-B count)
     constexpr int ROWD = ROWB / 4;               // in dwords
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [MT][ROWD] h2 rows, then c (f32)
+    static_assert(KS % 2 == 0, "the weight prefetch assumes an even number of k steps");
     static_assert((ROWB / 16) % 2 == 1, "row stride must be an odd number of 16-byte slots");
 
     int dir, btile;
@@ -130,13 +132,15 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 
     struct Frag { h8 b[4][2], a[2][2]; };     // [gate][hi, lo], [row tile][hi, lo]
     const uint32_t* arow = lds + li * ROWD + hf * 8;
-    auto load_step = [&](int s, Frag& fr) {
+    auto load_b = [&](int s, Frag& fr) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl)
                 fr.b[g][hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(
                                                          wrs, woff, (unsigned)(((g * NT + u) * KS + s) * 2 + hl) * 1024u, 0));
+    };
+    auto load_a = [&](int s, Frag& fr) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             fr.a[m][0] = *reinterpret_cast<const h8*>(arow + m * 32 * ROWD + s * 16);
@@ -164,6 +168,9 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     uint32_t* hl_dst = lds + 4 * hf * ROWD + (hcol >> 3) * 8 + ((li & 1) ? 4 : 0) + ((hcol & 7) >> 1);
     const bool odd = li & 1;
 
+    // The weights do not depend on the step: the B fragments of k step 0 are requested during the last
+    // k step of the previous time step and fly under the gate phase (ring[0].b stays live across it).
+    Frag ring[2];
     __syncthreads();
     {
         const int t0 = dir ? T - 1 : 0;
@@ -173,21 +180,24 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
             for (int qd = 0; qd < 4; ++qd) seed_chunk(m, qd, t0);
         x_load(t0);
         x_store();
+        load_b(0, ring[0]);
     }
     __syncthreads();
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
+        const bool stamp = dbg != nullptr && blockIdx.x == 8 && lane == 0;
+        if (stamp) dbg[(u * 80 + 2 * step) * 2] = __builtin_amdgcn_s_memtime();
         // ---------------- MFMA phase ----------------
         {
-            Frag ring[2];
-            load_step(0, ring[0]);
+            load_a(0, ring[0]);
             const int tp = step > 0 ? (dir ? t + 1 : t - 1) : t;   // time index of h_{s-1} (step 0: zeros, rewritten later)
             u32x4 ycv = {0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int p = s & 1;
-                if (s + 1 < KS) load_step(s + 1, ring[p ^ 1]);
+                if (s + 1 < KS) { load_b(s + 1, ring[p ^ 1]); load_a(s + 1, ring[p ^ 1]); }
+                else load_b(0, ring[p ^ 1]);            // KS is even: ring[p ^ 1] == ring[0]
                 if (s >= 1 && s <= YC) yc_write(s - 1, tp, ycv);
                 if (s < YC) ycv = yc_read(s);
 #pragma unroll
@@ -217,13 +227,26 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                     } else {
                         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                     }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // next time step's first B fragments
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (stamp) dbg[(u * 80 + 2 * step) * 2 + 1] = __builtin_amdgcn_s_memtime();
+
         lds_barrier();                    // every wave has finished reading h_{t-1}
+        if (stamp) dbg[(u * 80 + 2 * step + 1) * 2] = __builtin_amdgcn_s_memtime();
 
         // ---------------- gate phase ----------------
+        // (Starting a wave's gate math before the barrier, beside the other wave's MFMAs, was measured:
+        // the VALU / transcendental issue slows that MFMA stream by about what it hides.  The phase is
+        // transcendental-bound: 10 quarter-rate ops per element.)
         const int tn = dir ? t - 1 : t + 1;
         if (step + 1 < T) x_load(tn);
 #pragma unroll
@@ -244,13 +267,12 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                     const _Float16 lo = (_Float16)(hv - (float)hi);
                     const unsigned uhi = __builtin_bit_cast(unsigned short, hi), ulo = __builtin_bit_cast(unsigned short, lo);
                     const unsigned got = swap_pair(odd ? uhi : ulo);   // even lanes send lo, odd lanes send hi
-                    const unsigned word = odd ? (got | (ulo << 16)) : (uhi | (got << 16));
-                    const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
-                    hl_dst[dr * ROWD] = word;
+                    hl_dst[(32 * m + (r & 3) + 8 * (r >> 2)) * ROWD] = odd ? (got | (ulo << 16)) : (uhi | (got << 16));
                 }
                 if (step + 1 < T) seed_chunk(m, qd, tn);
             }
         if (step + 1 < T) x_store();
+        if (stamp) dbg[(u * 80 + 2 * step + 1) * 2 + 1] = __builtin_amdgcn_s_memtime();
         lds_barrier();                    // h_t (and x_{t+1}) visible
     }
     {
@@ -268,6 +290,8 @@ inline int rec_grid(int B) {
 }  // namespace
 
 namespace pa {
+
+unsigned long long* debug_buffer();   // rnn.hip (PA_DEBUG_TIMING=1)
 
 // W [G*H, K] per direction (K = H, or H + KX with [W_hh | W_ih | 0]) -> per-lane h2 fragments
 // [dir][G*H/32][K/16][hi, lo][64 lanes][8 halves]; lane l of tile nt, step s holds
@@ -303,12 +327,13 @@ hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, 
         if (F <= 0 || F > 32) return hipErrorInvalidValue;
         const size_t lds = (size_t)MT * ((256 + 32) * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4;
         hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
-                           F, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y), ldy, B, T);
+                           F, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y), ldy, B, T,
+                           debug_buffer() ? debug_buffer() + 8 * 80 * 2 : nullptr);
     } else {
         const size_t lds = (size_t)MT * (256 * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4;
         hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 0>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
                            (const int8_t*)nullptr, 0, (const float*)nullptr, static_cast<const uint32_t*>(Wp),
-                           static_cast<uint32_t*>(Y), ldy, B, T);
+                           static_cast<uint32_t*>(Y), ldy, B, T, debug_buffer());
     }
     return hipGetLastError();
 }

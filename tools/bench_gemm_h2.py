@@ -8,7 +8,7 @@ from test_gpu_gemm_h2 import run
 
 from pepper_amd import _lib
 rng = np.random.default_rng(0)
-M, N, K = 8192, 8192, 1024
+M, N, K = 4096, 4096, 16384      # one tile per CU, 512 k-tiles: main-loop efficiency only
 A = rng.uniform(-1, 1, size=(M, K)).astype(np.float32)
 W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
 for e in range(8):
