@@ -281,7 +281,8 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
         out.b_hn = m->new_buf();
         if (int rc = upload(out.b_hn, bn)) return rc;
     }
-    if (G == 4 && H == 256) {
+    if ((G == 4 && H == 256) || (G == 3 && H == 128)) {
+        const int KXh2 = G == 4 ? 32 : 16;
         auto pack_upload = [&](DevBuf*& dst, const float* const wx[2], int KX) -> int {
             for (int d = 0; d < 2; ++d) {
                 for (int64_t i = 0; i < (int64_t)G * H * H; ++i)
@@ -299,8 +300,8 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
         };
         const float* const none[2] = {nullptr, nullptr};
         if (int rc = pack_upload(out.w_hh_h2, none, 0)) return rc;
-        if (K <= 32)
-            if (int rc = pack_upload(out.w_cat_h2, wih, 32)) return rc;
+        if (K <= KXh2)
+            if (int rc = pack_upload(out.w_cat_h2, wih, KXh2)) return rc;
     }
     if ((G == 4 && H == 256 && K <= 32) || (G == 3 && H == 128 && K <= 16)) {
         std::vector<float> cat;
@@ -594,6 +595,8 @@ struct pa_polish_model : ModelBase {
     pa_polish_config cfg{};
     bool fuse_input = true;      // PA_FUSE_INPUT=0 falls back to GEMM + Xp
     bool split_gemm = true;      // PA_SPLIT_GEMM=0 keeps the projections on the f32 matrix instructions
+    bool split_rec = true;       // PA_SPLIT_REC=0 keeps the recurrences on the f32 matrix instructions
+    bool y_h2 = false;           // format of the last polish_window output
     std::vector<RecLayer> enc, dec;
     Linear dense;
     DevBuf *xp, *y1, *y2, *hid_a, *hid_b, *acc, *stage_in, *stage_lab, *stage_ph, *stage_acc;
@@ -610,6 +613,7 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
     const void* cur = x;
     int cur_kind = x_kind, cur_ld = x_ld, cur_rpb = x_rpb;
     int64_t cur_bs = x_bstride;
+    bool cur_h2 = false;         // cur is a layer output in the h2 split format
     float* ybuf[2] = {m->y1->f(), m->y2->f()};
     int which = 0;
     // encoder: h0 = hidden_in, h_n -> hid_a ; decoder: h0 = hid_a, h_n -> hidden_out
@@ -619,42 +623,49 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
         float* hn = stage == 0 ? m->hid_a->f() : hidden_out;
         for (int l = 0; l < L; ++l) {
             const RecLayer& r = layers[l];
-            if (stage == 0 && l == 0 && cur_kind == pa::A_U8 && r.w_cat != nullptr && m->fuse_input) {
-                float* y = ybuf[which];
-                LAUNCH_TRY(m, "gru_rec_fused_in", 2.0 * n * T * (3.0 * H) * (H + r.K) * 2,
-                           pa::launch_gru_rec_fused(H, static_cast<const uint8_t*>(cur), r.K,
-                                                    cur_bs > 0 ? cur_bs : (int64_t)T * r.K, r.b_in->f(), r.w_cat->f(),
-                                                    r.b_hn->f(), h0 ? h0 + (size_t)l * 2 * H : nullptr, ldh,
-                                                    hn ? hn + (size_t)l * 2 * H : nullptr, ldh, y, 2 * H, (int)n, T,
-                                                    m->stream));
-                cur = y;
-                cur_kind = pa::A_F32;
-                cur_ld = 2 * H;
-                cur_rpb = 0;
-                cur_bs = 0;
-                which ^= 1;
-                continue;
-            }
-            if (!(stage == 0 && l == 0) && m->split_gemm && r.w_ih_h2 != nullptr) {
-                // the previous layer's y (workspace, read only here): split in place, f16-pipe GEMM
-                LAUNCH_TRY(m, "cvt_h2", 0.0,
-                           pa::launch_f32_to_h2(static_cast<const float*>(cur), const_cast<void*>(cur), M, r.K, cur_ld,
-                                                m->stream));
-                LAUNCH_TRY(m, "gemm_h2_inproj", 2.0 * M * NX * r.K,
-                           pa::launch_gemm_h2(cur, cur_ld, (size_t)M * cur_ld * 4, r.w_ih_h2->p, r.K, (size_t)NX * r.K * 4,
-                                              r.b_in->f(), m->xp->f(), NX, (int)(round_up(n, MTP) * T), NX, r.K, 0, 0, 0, T,
-                                              (int)n, m->stream));
-            } else {
-                LAUNCH_TRY(m, (stage == 0 && l == 0) ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
-                           pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(), NX,
-                                              (int)(round_up(n, MTP) * T), NX, r.K, 0, 0, cur_bs, T, (int)n, m->stream));
-            }
+            const bool rec_h2 = m->split_rec && r.w_hh_h2 != nullptr;
+            const float* h0l = h0 ? h0 + (size_t)l * 2 * H : nullptr;
+            float* hnl = hn ? hn + (size_t)l * 2 * H : nullptr;
             float* y = ybuf[which];
-            LAUNCH_TRY(m, "gru_rec", 2.0 * n * T * (3.0 * H) * H * 2,
-                       pa::launch_gru_rec(H, m->xp->f(), NX, r.w_hh->f(), r.b_hn->f(),
-                                          h0 ? h0 + (size_t)l * 2 * H : nullptr, ldh,
-                                          hn ? hn + (size_t)l * 2 * H : nullptr, ldh, y, 2 * H, (int)n, T,
-                                          m->stream));
+            if (stage == 0 && l == 0 && cur_kind == pa::A_U8 && r.w_cat != nullptr && m->fuse_input) {
+                const int64_t xbs = cur_bs > 0 ? cur_bs : (int64_t)T * r.K;
+                if (rec_h2 && r.w_cat_h2 != nullptr)
+                    LAUNCH_TRY(m, "gru_rec_h2_fused_in", 2.0 * n * T * (3.0 * H) * (H + r.K) * 2,
+                               pa::launch_gru_rec_h2(H, nullptr, 0, static_cast<const uint8_t*>(cur), r.K, xbs, r.b_in->f(),
+                                                     r.w_cat_h2->p, r.b_hn->f(), h0l, ldh, hnl, ldh, y, 2 * H, (int)n, T,
+                                                     m->stream));
+                else
+                    LAUNCH_TRY(m, "gru_rec_fused_in", 2.0 * n * T * (3.0 * H) * (H + r.K) * 2,
+                               pa::launch_gru_rec_fused(H, static_cast<const uint8_t*>(cur), r.K, xbs, r.b_in->f(),
+                                                        r.w_cat->f(), r.b_hn->f(), h0l, ldh, hnl, ldh, y, 2 * H, (int)n, T,
+                                                        m->stream));
+                cur_h2 = rec_h2 && r.w_cat_h2 != nullptr;
+            } else {
+                if (!(stage == 0 && l == 0) && m->split_gemm && r.w_ih_h2 != nullptr) {
+                    // the previous layer's y (workspace, read only here): split in place if needed, f16-pipe GEMM
+                    if (!cur_h2)
+                        LAUNCH_TRY(m, "cvt_h2", 0.0,
+                                   pa::launch_f32_to_h2(static_cast<const float*>(cur), const_cast<void*>(cur), M, r.K,
+                                                        cur_ld, m->stream));
+                    LAUNCH_TRY(m, "gemm_h2_inproj", 2.0 * M * NX * r.K,
+                               pa::launch_gemm_h2(cur, cur_ld, (size_t)M * cur_ld * 4, r.w_ih_h2->p, r.K,
+                                                  (size_t)NX * r.K * 4, r.b_in->f(), m->xp->f(), NX,
+                                                  (int)(round_up(n, MTP) * T), NX, r.K, 0, 0, 0, T, (int)n, m->stream));
+                } else {
+                    LAUNCH_TRY(m, (stage == 0 && l == 0) ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
+                               pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(), NX,
+                                                  (int)(round_up(n, MTP) * T), NX, r.K, 0, 0, cur_bs, T, (int)n, m->stream));
+                }
+                if (rec_h2)
+                    LAUNCH_TRY(m, "gru_rec_h2", 2.0 * n * T * (3.0 * H) * H * 2,
+                               pa::launch_gru_rec_h2(H, m->xp->f(), NX, nullptr, 0, 0, nullptr, r.w_hh_h2->p, r.b_hn->f(),
+                                                     h0l, ldh, hnl, ldh, y, 2 * H, (int)n, T, m->stream));
+                else
+                    LAUNCH_TRY(m, "gru_rec", 2.0 * n * T * (3.0 * H) * H * 2,
+                               pa::launch_gru_rec(H, m->xp->f(), NX, r.w_hh->f(), r.b_hn->f(), h0l, ldh, hnl, ldh, y,
+                                                  2 * H, (int)n, T, m->stream));
+                cur_h2 = rec_h2;
+            }
             cur = y;
             cur_kind = pa::A_F32;
             cur_ld = 2 * H;
@@ -663,6 +674,8 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
             which ^= 1;
         }
     }
+    m->y_h2 = cur_h2;
+    (void)cur_rpb;
     *y_last = const_cast<float*>(static_cast<const float*>(cur));
     return PA_OK;
 }
@@ -692,6 +705,8 @@ int pa_polish_create(const pa_polish_config* cfg, const char* const* names, cons
     if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 8192;
     if (const char* e = getenv("PA_FUSE_INPUT")) m->fuse_input = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_GEMM")) m->split_gemm = e[0] != '0';
+    if (const char* e = getenv("PA_SPLIT_REC")) m->split_rec = e[0] != '0';
+    m->split_rec = m->split_rec && m->split_gemm && cfg->hidden_size == 128;
     int rc = init_base(m, cfg->device, hip_stream);
     StateDict sd(names, data, numel, n_tensors);
     const int H = cfg->hidden_size;
@@ -744,6 +759,8 @@ int pa_polish_forward_device(pa_polish_model* m, const float* x, const float* hi
         if (int rc = polish_window(m, pa::A_F32_SCALAR, x + (size_t)off * T * F, F, 0, 0, hin, m->hid_b->f(), c,
                                    T, &y))
             return rc;
+        if (m->y_h2)
+            LAUNCH_TRY(m, "cvt_f32", 0.0, pa::launch_h2_to_f32(y, c * T, 2 * H, 2 * H, m->stream));
         LAUNCH_TRY(m, "dense_logits", 2.0 * c * T * 2 * H * C,
                    pa::launch_dense_small(2, y, 2 * H, m->dense.w->f(), m->dense.b->f(),
                                           logits + (size_t)off * T * C, nullptr, (int)(c * T), 2 * H, C, 1, 1, 0,
@@ -781,9 +798,17 @@ int pa_polish_predict_device(pa_polish_model* m, const uint8_t* images, int64_t 
                                        first ? nullptr : m->hid_b->f(), m->hid_b->f(), c, T, &y))
                 return rc;
             first = false;
-            LAUNCH_TRY(m, "dense_softmax_acc", 2.0 * c * T * 2 * H * C,
-                       pa::launch_dense_small(1, y, 2 * H, m->dense.w->f(), m->dense.b->f(), acc, nullptr,
-                                              (int)(c * T), 2 * H, C, T, S, i, m->stream));
+            if (m->y_h2 && 2 * H == 256 && C <= 5)
+                LAUNCH_TRY(m, "dense_softmax_acc", 2.0 * c * T * 2 * H * C,
+                           pa::launch_polish_dense_acc_h2(y, 2 * H, m->dense.w->f(), m->dense.b->f(), acc, (int)(c * T),
+                                                          2 * H, C, T, S, i, m->stream));
+            else {
+                if (m->y_h2)
+                    LAUNCH_TRY(m, "cvt_f32", 0.0, pa::launch_h2_to_f32(y, c * T, 2 * H, 2 * H, m->stream));
+                LAUNCH_TRY(m, "dense_softmax_acc", 2.0 * c * T * 2 * H * C,
+                           pa::launch_dense_small(1, y, 2 * H, m->dense.w->f(), m->dense.b->f(), acc, nullptr,
+                                                  (int)(c * T), 2 * H, C, T, S, i, m->stream));
+            }
         }
         LAUNCH_TRY(m, "polish_finalize", 0.0,
                    pa::launch_polish_finalize(acc, labels + (size_t)off * S, phred + (size_t)off * S, c, S, C,

@@ -136,6 +136,86 @@ __global__ __launch_bounds__(256) void polish_dense_acc_kernel(const float* __re
     }
 }
 
+// The same head reading X in the h2 split format written by rnn_h2.hip (x = hi + lo): 16 lanes per
+// row, each lane owns K/128 groups of 8 columns (32 contiguous bytes: 16 B hi, 16 B lo).
+template <int K>
+__global__ __launch_bounds__(256) void polish_dense_acc_h2_kernel(const uint32_t* __restrict__ X, int ldx,
+                                                                  const float* __restrict__ W,
+                                                                  const float* __restrict__ bias,
+                                                                  float* __restrict__ acc, int rows, int C, int T,
+                                                                  int S, int off, int rows_per_block) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    constexpr int J = K / 128;
+    const int lane = threadIdx.x & 63, l16 = lane & 15, rsel = lane >> 4, wave = threadIdx.x >> 6;
+    float w[5][J][8];
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[c][j][e] = c < C ? W[(size_t)c * K + (l16 + 16 * j) * 8 + e] : 0.0f;
+    float b[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) b[c] = c < C ? bias[c] : 0.0f;
+    const int row0 = blockIdx.x * rows_per_block;
+    for (int base = row0 + wave * 4; base < row0 + rows_per_block; base += 16) {
+        const int row = base + rsel;
+        const bool ok = row < rows;
+        const uint32_t* x = X + (size_t)(ok ? row : rows - 1) * ldx;
+        float xv[J][8];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const h8 hi = *reinterpret_cast<const h8*>(x + (l16 + 16 * j) * 8);
+            const h8 lo = *reinterpret_cast<const h8*>(x + (l16 + 16 * j) * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[j][e] = (float)hi[e] + (float)lo[e];
+        }
+        float logit[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            float p = 0.0f;
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) p += xv[j][e] * w[c][j][e];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+            logit[c] = c < C ? p + b[c] : -INFINITY;
+        }
+        float mx = logit[0];
+#pragma unroll
+        for (int c = 1; c < 5; ++c) mx = fmaxf(mx, logit[c]);
+        float e[5], den = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            e[c] = expf(logit[c] - mx);
+            den += e[c];
+        }
+        float mine = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            if (l16 == c) mine = e[c];
+        if (ok && l16 < C) acc[((size_t)(row / T) * S + off + row % T) * C + l16] += mine / den;
+    }
+}
+
+// h2 rows -> f32 rows in place (hi + lo), for callers that want the layer output itself
+__global__ __launch_bounds__(256) void h2_to_f32_kernel(uint32_t* __restrict__ buf, int64_t rows, int K, int64_t ld) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int gpr = K >> 3;
+    if (idx >= rows * gpr) return;
+    const int64_t r = idx / gpr;
+    const int g = (int)(idx - r * gpr);
+    uint32_t* p = buf + r * ld + g * 8;
+    const h8 hi = *reinterpret_cast<const h8*>(p);
+    const h8 lo = *reinterpret_cast<const h8*>(p + 4);
+    f32x4 a = {(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
+    f32x4 b = {(float)hi[4] + (float)lo[4], (float)hi[5] + (float)lo[5], (float)hi[6] + (float)lo[6], (float)hi[7] + (float)lo[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
 __global__ __launch_bounds__(256) void polish_finalize_kernel(const float* __restrict__ acc,
                                                               uint8_t* __restrict__ labels,
                                                               uint8_t* __restrict__ phred,
@@ -181,6 +261,25 @@ hipError_t launch_dense_small(int mode, const float* X, int ldx, const float* W,
         case 2: hipLaunchKernelGGL((dense_small_kernel<2>), grid, block, 0, stream, X, ldx, W, bias, out0, out1, rows, K, C, T, S, off); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_polish_dense_acc_h2(const void* X, int ldx, const float* W, const float* bias, float* acc, int rows,
+                                      int K, int C, int T, int S, int off, hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    if (C > 5 || K != 256 || (ldx & 7)) return hipErrorInvalidValue;
+    const int rpb = 256;
+    hipLaunchKernelGGL((polish_dense_acc_h2_kernel<256>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, stream,
+                       static_cast<const uint32_t*>(X), ldx, W, bias, acc, rows, C, T, S, off, rpb);
+    return hipGetLastError();
+}
+
+hipError_t launch_h2_to_f32(void* buf, int64_t rows, int K, int64_t ld, hipStream_t stream) {
+    if ((K & 7) || (ld & 7)) return hipErrorInvalidValue;
+    const int64_t n = rows * (K >> 3);
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(h2_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<uint32_t*>(buf), rows, K, ld);
     return hipGetLastError();
 }
 

@@ -59,10 +59,19 @@ size_t rec_weights_h2_words(int G, int H, int KX);
 hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, int F, const float* bias,
                               const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream);
 
+// GRU (H = 128) counterpart; arguments as launch_gru_rec / launch_gru_rec_fused, Y in h2 format.
+hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, int F, int64_t x_bstride,
+                             const float* bias, const void* Wp, const float* bhn, const float* h0, int ldh0, float* hn,
+                             int ldhn, void* Y, int ldy, int B, int T, hipStream_t stream);
+
 // head.hip
 hipError_t launch_dense_small(int mode, const float* X, int ldx, const float* W, const float* bias,
                               float* out0, float* out1, int rows, int K, int C, int T, int S, int off,
                               hipStream_t stream);
+// polish head on an h2 layer output (K = 256, C <= 5): acc[(row / T) * S + off + row % T][c] += softmax(...)
+hipError_t launch_polish_dense_acc_h2(const void* X, int ldx, const float* W, const float* bias, float* acc, int rows,
+                                      int K, int C, int T, int S, int off, hipStream_t stream);
+hipError_t launch_h2_to_f32(void* buf, int64_t rows, int K, int64_t ld, hipStream_t stream);
 hipError_t launch_polish_finalize(const float* acc, uint8_t* labels, uint8_t* phred, int64_t B, int S,
                                   int C, int overlap, hipStream_t stream);
 

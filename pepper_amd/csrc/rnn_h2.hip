@@ -282,6 +282,262 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// GRU step loop (polish model, H = 128), same split-operand scheme.  Always 8 waves: four unit tiles
+// x two 64-row groups (128 batch rows per workgroup).  Gates r, z, n with the PyTorch definition
+// n = tanh(W_in x + b_in + r * (W_hn h + b_hn)); the hidden half of the n gate has its own accumulator
+// (and, when the uint8 input projection is fused, so has the input half).  h is carried exactly in f32
+// registers for the z * h_{t-1} term and the final state hand-off; the LDS / y image is its h2 split.
+//   /root/reference/pepper/modules/python/models/simple_model.py:30,32
+template <int H, int KX>
+__global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
+                                                            const uint8_t* __restrict__ Xi, int F, int64_t xi_bstride,
+                                                            const float* __restrict__ bias,
+                                                            const uint32_t* __restrict__ Wp,
+                                                            const float* __restrict__ bhn,
+                                                            const float* __restrict__ h0, int ldh0,
+                                                            float* __restrict__ hn, int ldhn,
+                                                            uint32_t* __restrict__ Y, int ldy, int B, int T) {
+    constexpr int KT = H + KX, KS = KT / 16, KSH = H / 16, NT = H / 32, RG = 8 / NT, MTG = MT * RG;
+    constexpr int NA = KX ? 4 : 3;
+    constexpr int ROWB = KT * 4 + 16, ROWD = ROWB / 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [MTG][ROWD] h2 rows of [h | x]
+    static_assert((ROWB / 16) % 2 == 1, "row stride must be an odd number of 16-byte slots");
+
+    int dir, btile;
+    decode_block(blockIdx.x, dir, btile);
+    const int b0 = btile * MTG;
+    if (b0 >= B) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u = wave % NT, rg = wave / NT;
+    const int li = lane & 31, hf = lane >> 5;
+    const int col = u * 32 + li;
+    const int r0 = b0 + rg * MT;
+
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(KX ? bhn : Xp + (size_t)(r0 >> 5) * T * (ldx >> 5) * 1024), 0, 0x7fffffff, 0x00020000);
+    // fragment (g, s, hi/lo) of this wave: byte (((g*NT + u) * KS + s) * 2 + hl) * 1024 + lane * 16
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(Wp + ((size_t)dir * (3 * NT) + u) * KS * 512), 0, 0x7fffffff, 0x00020000);
+    const unsigned xoff = lane * 16u, woff = lane * 16u;
+    const size_t lb = (size_t)(r0 + 4 * hf);
+    const bool odd = li & 1;
+    uint32_t* hl_dst = lds + (rg * MT + 4 * hf) * ROWD + (col >> 3) * 8 + (odd ? 4 : 0) + ((col & 7) >> 1);
+    const uint32_t* arow = lds + (rg * MT + li) * ROWD + hf * 8;
+
+    for (int idx = tid; idx < MTG * ROWD; idx += 512) lds[idx] = 0u;
+    __syncthreads();
+
+    auto load_xp4 = [&](int m, int t, int g, int qd) {
+        const unsigned ct = (unsigned)(dir * (3 * NT) + g * NT + u);
+        const unsigned so = (((unsigned)(m * T + t) * (ldx >> 5) + ct) * 4u + qd) * 1024u;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
+    };
+    // packed h2 word of one element (see lstm_rec_h2_kernel)
+    auto h2_word = [&](float hv) {
+        const _Float16 hi = (_Float16)hv;
+        const _Float16 lo = (_Float16)(hv - (float)hi);
+        const unsigned uhi = __builtin_bit_cast(unsigned short, hi), ulo = __builtin_bit_cast(unsigned short, lo);
+        const unsigned got = swap_pair(odd ? uhi : ulo);
+        return odd ? (got | (ulo << 16)) : (uhi | (got << 16));
+    };
+
+    f32x16 hreg[2], acc[2][NA];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
+            const float hv = h0 != nullptr ? h0[(lb + dr) * ldh0 + dir * H + col] : 0.0f;
+            hreg[m][r] = hv;
+            hl_dst[dr * ROWD] = h2_word(hv);
+        }
+    const float bn = bhn[dir * H + col];
+    const float b_r = KX ? bias[dir * 3 * H + col] : 0.0f, b_z = KX ? bias[dir * 3 * H + H + col] : 0.0f,
+                b_nx = KX ? bias[dir * 3 * H + 2 * H + col] : 0.0f;
+    auto seed_chunk = [&](int m, int qd, int t) {
+        if (KX) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[m][0][4 * qd + e] = b_r;
+                acc[m][1][4 * qd + e] = b_z;
+                acc[m][NA - 1][4 * qd + e] = b_nx;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 v = load_xp4(m, t, g, qd);
+                acc[m][g][4 * qd] = v.x;
+                acc[m][g][4 * qd + 1] = v.y;
+                acc[m][g][4 * qd + 2] = v.z;
+                acc[m][g][4 * qd + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[m][2][4 * qd + e] = bn;
+    };
+    // fused: uint8 x_t (exact in f16) -> hi halves of columns [H, H+KX); one thread per feature pair
+    constexpr int XN = KX ? (MTG * KX / 2) / 512 : 1;
+    unsigned xv[XN];
+    auto x_load = [&](int t) {
+        if (KX) {
+#pragma unroll
+            for (int k = 0; k < XN; ++k) {
+                const int e = tid + k * 512;
+                const int row = e / (KX / 2), f = (e % (KX / 2)) * 2;
+                int brow = b0 + row;
+                brow = brow < B ? brow : B - 1;
+                const uint8_t* src = Xi + (size_t)brow * xi_bstride + (size_t)t * F;
+                const _Float16 v0 = f < F ? (_Float16)(float)src[f] : (_Float16)0.0f;
+                const _Float16 v1 = f + 1 < F ? (_Float16)(float)src[f + 1] : (_Float16)0.0f;
+                xv[k] = (unsigned)__builtin_bit_cast(unsigned short, v0) | ((unsigned)__builtin_bit_cast(unsigned short, v1) << 16);
+            }
+        }
+    };
+    auto x_store = [&]() {
+        if (KX) {
+#pragma unroll
+            for (int k = 0; k < XN; ++k) {
+                const int e = tid + k * 512;
+                const int row = e / (KX / 2), f = (e % (KX / 2)) * 2;
+                lds[row * ROWD + ((H + f) >> 3) * 8 + ((f & 7) >> 1)] = xv[k];
+            }
+        }
+    };
+    {
+        const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) seed_chunk(m, qd, t0);
+        x_load(t0);
+        x_store();
+    }
+    __syncthreads();
+
+    // y copy: h part of the LDS rows (H/4 16-byte chunks per row), 512 threads
+    constexpr int CPR = H / 4, YROWS = 512 / CPR, YC = MTG / YROWS;   // 32 chunks/row, 16 rows/pass, 8 passes
+    constexpr int YI = YC < KS - 1 ? YC : KS - 1;                      // passes interleaved with the MFMAs
+    const int yc_row = tid / CPR, yc_c = tid % CPR;
+    const uint32_t* yc_src = lds + yc_row * ROWD + yc_c * 4;
+    const __amdgpu_buffer_rsrc_t ycrs =
+        __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)b0 * T * ldy + dir * H, 0, 0x7fffffff, 0x00020000);
+    const unsigned yc_off = ((unsigned)(yc_row * T) * ldy + yc_c * 4) * 4u;
+    auto yc_read = [&](int j) { return *reinterpret_cast<const u32x4*>(yc_src + j * YROWS * ROWD); };
+    auto yc_write = [&](int j, int tp, u32x4 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(v, ycrs, yc_off, ((unsigned)(j * YROWS * T + tp) * ldy) * 4u, 0);
+    };
+
+    struct Frag { h8 b[3][2], a[2][2]; };
+    auto load_step = [&](int s, Frag& fr) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+                fr.b[g][hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         wrs, woff, (unsigned)((g * NT * KS + s) * 2 + hl) * 1024u, 0));
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            fr.a[m][0] = *reinterpret_cast<const h8*>(arow + m * 32 * ROWD + s * 16);
+            fr.a[m][1] = *reinterpret_cast<const h8*>(arow + m * 32 * ROWD + s * 16 + 4);
+        }
+    };
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        const int tp = step > 0 ? (dir ? t + 1 : t - 1) : t;   // time index of h_{s-1} (step 0: h0, rewritten later)
+        // ---------------- MFMA phase ----------------
+        {
+            Frag ring[2];
+            load_step(0, ring[0]);
+            u32x4 ycv = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int p = s & 1;
+                if (s + 1 < KS) load_step(s + 1, ring[p ^ 1]);
+                if (s >= 1 && s <= YI) yc_write(s - 1, tp, ycv);
+                if (s < YI) ycv = yc_read(s);
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const int ai = (g == 2 && s >= KSH) ? NA - 1 : g;
+                            acc[m][ai] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0], acc[m][ai]);
+                        }
+                if (s + 1 < KS) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (B fragment)
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (A fragment)
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);       // y copy store
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // y copy read
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = YI; j < YC; ++j) yc_write(j, tp, yc_read(j));     // passes that did not fit a k step
+        }
+        // unfused: x part of the n gate for this step, in flight across the barrier
+        f32x4 xn[2][4];
+        if (!KX) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) xn[m][qd] = load_xp4(m, t, 2, qd);
+        }
+        lds_barrier();
+
+        // ---------------- gate phase ----------------
+        const int tn = dir ? t - 1 : t + 1;
+        if (step + 1 < T) x_load(tn);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * qd + e;
+                    const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
+                    const float rgate = fast_sigmoid(acc[m][0][r]);
+                    const float zgate = fast_sigmoid(acc[m][1][r]);
+                    const float xnv = KX ? acc[m][NA - 1][r] : xn[m][qd][e];
+                    const float ngate = fast_tanh(xnv + rgate * acc[m][2][r]);
+                    const float hv = (1.0f - zgate) * ngate + zgate * hreg[m][r];
+                    hreg[m][r] = hv;
+                    hl_dst[dr * ROWD] = h2_word(hv);
+                }
+                if (step + 1 < T) seed_chunk(m, qd, tn);
+            }
+        if (step + 1 < T) x_store();
+        lds_barrier();
+    }
+
+    {
+        const int tl = dir ? 0 : T - 1;
+#pragma unroll
+        for (int j = 0; j < YC; ++j) yc_write(j, tl, yc_read(j));
+    }
+    if (hn != nullptr) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                hn[(lb + 32 * m + (r & 3) + 8 * (r >> 2)) * ldhn + dir * H + col] = hreg[m][r];
+    }
+}
+
 inline int rec_grid(int B) {
     const int nbt = (B + MT - 1) / MT;
     return 2 * ((nbt + 3) / 4) * 4;
@@ -334,6 +590,28 @@ hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, 
         hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 0>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
                            (const int8_t*)nullptr, 0, (const float*)nullptr, static_cast<const uint32_t*>(Wp),
                            static_cast<uint32_t*>(Y), ldy, B, T, debug_buffer());
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, int F, int64_t x_bstride,
+                             const float* bias, const void* Wp, const float* bhn, const float* h0, int ldh0, float* hn,
+                             int ldhn, void* Y, int ldy, int B, int T, hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    if (H != 128 || (ldy & 7)) return hipErrorInvalidValue;
+    const int nbt = (B + 2 * MT - 1) / (2 * MT);
+    const int grid = 2 * ((nbt + 3) / 4) * 4;
+    if (X != nullptr) {
+        if (F <= 0 || F > 16) return hipErrorInvalidValue;
+        const size_t lds = (size_t)2 * MT * ((128 + 16) * 4 + 16);
+        hipLaunchKernelGGL((gru_rec_h2_kernel<128, 16>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X, F,
+                           x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
+                           static_cast<uint32_t*>(Y), ldy, B, T);
+    } else {
+        const size_t lds = (size_t)2 * MT * (128 * 4 + 16);
+        hipLaunchKernelGGL((gru_rec_h2_kernel<128, 0>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
+                           (const uint8_t*)nullptr, 0, (int64_t)0, (const float*)nullptr, static_cast<const uint32_t*>(Wp),
+                           bhn, h0, ldh0, hn, ldhn, static_cast<uint32_t*>(Y), ldy, B, T);
     }
     return hipGetLastError();
 }
