@@ -381,6 +381,7 @@ struct pa_variant_model : ModelBase {
     bool split_rec = true;       // PA_SPLIT_REC=0 keeps the recurrences on the f32 matrix instructions
     std::vector<RecLayer> rec;   // encoder layers then decoder layers
     Linear lin[5], out;
+    DevBuf *mlp_w = nullptr, *mlp_b = nullptr;   // linear_2..5 as h2 fragments + their biases (mlp_h2.hip)
     DevBuf *xp, *ya, *yb, *l1, *l2, *stage_in, *stage_p, *stage_l;
 };
 
@@ -420,6 +421,28 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     for (int i = 0; i < 5 && rc == PA_OK; ++i)
         rc = build_linear(m, sd, lin_names[i], i == 0 ? 2 * H * cfg->window : m->L1, m->L1, m->lin[i], i == 0);
     if (rc == PA_OK) rc = build_linear(m, sd, "output_layer_type", m->L1, cfg->num_classes_type, m->out);
+    if (rc == PA_OK && m->split_gemm && m->L1 == 512) {
+        std::string err;
+        const float* w4[4];
+        std::vector<float> b4((size_t)4 * m->L1);
+        bool ok = true;
+        for (int i = 0; i < 4 && ok; ++i) {
+            w4[i] = sd.get(std::string(lin_names[i + 1]) + ".weight", (int64_t)m->L1 * m->L1, err);
+            const float* b = sd.get(std::string(lin_names[i + 1]) + ".bias", m->L1, err);
+            for (int64_t k = 0; k < (int64_t)m->L1 * m->L1; ++k) ok = ok && std::fabs(w4[i][k]) < 65504.0f;
+            std::memcpy(&b4[(size_t)i * m->L1], b, m->L1 * sizeof(float));
+        }
+        if (ok) {   // (weights outside the f16 range keep the f32 GEMM chain)
+            std::vector<uint32_t> packed(pa::mlp_weights_h2_words(4));
+            pa::pack_mlp_weights_h2(w4, 4, packed.data());
+            m->mlp_w = m->new_buf();
+            m->mlp_b = m->new_buf();
+            rc = m->mlp_w->ensure(packed.size() * sizeof(uint32_t));
+            if (rc == PA_OK && hipMemcpy(m->mlp_w->p, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+                rc = fail(PA_ERR_HIP, "upload of the packed MLP weights failed");
+            if (rc == PA_OK) rc = upload(m->mlp_b, b4);
+        }
+    }
     if (rc != PA_OK) {
         delete m;
         return rc;
@@ -521,6 +544,12 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
         LAUNCH_TRY(m, "gemm_linear_1", 2.0 * n * m->L1 * K1,
                    pa::launch_gemm_nt(pa::A_F32, cur, K1, m->lin[0].w->f(), K1, m->lin[0].b->f(), m->l1->f(),
                                       m->L1, (int)n, m->L1, K1, 1, 0, 0, 0, 0, m->stream));
+    }
+    if (m->mlp_w != nullptr && C <= 8) {
+        LAUNCH_TRY(m, "mlp_tail_h2", 2.0 * n * m->L1 * (4.0 * m->L1 + C),
+                   pa::launch_mlp_tail_h2(m->l1->f(), m->L1, m->mlp_w->p, m->mlp_b->f(), 4, m->out.w->f(), m->out.b->f(), C,
+                                          probs, logits, (int)n, m->stream));
+        return PA_OK;
     }
     float* a = m->l1->f();
     float* b = m->l2->f();

@@ -64,6 +64,12 @@ hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, 
                              const float* bias, const void* Wp, const float* bhn, const float* h0, int ldh0, float* hn,
                              int ldhn, void* Y, int ldy, int B, int T, hipStream_t stream);
 
+// mlp_h2.hip: linear_2..5 (512 -> 512, SELU) + output layer + softmax fused, 64 rows per workgroup.
+void pack_mlp_weights_h2(const float* const* W, int NL, uint32_t* out);
+size_t mlp_weights_h2_words(int NL);
+hipError_t launch_mlp_tail_h2(const float* X, int ldx, const void* Wp, const float* bias, int NL, const float* Wout,
+                              const float* bout, int C, float* probs, float* logits, int n, hipStream_t stream);
+
 // head.hip
 hipError_t launch_dense_small(int mode, const float* X, int ldx, const float* W, const float* bias,
                               float* out0, float* out1, int rows, int K, int C, int T, int S, int off,
