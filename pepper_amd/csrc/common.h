@@ -1,15 +1,20 @@
 // Shared device helpers for the pepper_amd gfx950 kernels.
 //
-// All dense contractions use v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate): the parity
-// bar is 1e-4 on softmax outputs after 66 dependent recurrent steps and a K=16896
-// reduction, so operands stay exact f32 (157.3 TFLOP/s dense peak on MI355X).
+// Two families of kernels share these helpers: the f32 ones (gemm.hip, rnn.hip) contract on
+// v_mfma_f32_32x32x2_f32 with exact f32 operands (157.3 TFLOP/s dense peak), the default "h2" ones
+// (gemm_h2.hip, rnn_h2.hip, mlp_h2.hip) on v_mfma_f32_32x32x16_f16 with every operand split into
+// f16 hi/lo halves and three MFMAs per product (f32-level accuracy at 5.3x the rate; format and
+// rationale at the top of gemm_h2.hip).  The parity bar is 1e-4 on softmax outputs after 66
+// dependent recurrent steps and a K=16896 reduction.
 //
-// Fragment conventions used everywhere (wave = 64 lanes, lane l):
+// Fragment conventions of the f32 instruction (wave = 64 lanes, lane l):
 //   A operand: one f32 = A[i = l & 31][k = l >> 5]
 //   B operand: one f32 = B[k = l >> 5][j = l & 31]
 //   C/D      : 16 f32,  reg r -> row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col l & 31
 // A "k-block" is 8 consecutive k: lane l holds k = 8*kb + 4*(l>>5) + s for s = 0..3 in one
 // 16-byte register quad, so 4 MFMAs consume one ds_read_b128 / global_load_dwordx4 per operand.
+// For v_mfma_f32_32x32x16_f16: A operand 8 halves = A[i = l & 31][k = 8*(l>>5) + 0..7], B likewise
+// with j = l & 31; C/D as above.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
