@@ -89,3 +89,25 @@ def test_polish_two_layer_module_forward(golden_dir):
     assert np.abs(logits.numpy() - g["logits"]).max() < TOL * max(1.0, np.abs(g["logits"]).max())
     assert np.abs(hidden.numpy() - g["hidden_out"]).max() < TOL
     m.close()
+
+
+def test_polish_many_chunks_properties():
+    """More chunks than one 128-row workgroup tile and than the device chunk (max_chunk): sample vs the
+    oracle, chunking invariance, chunk-permutation equivariance."""
+    sd = synthetic.polish_state_dict(seed=31, gain=2.0)
+    n = 300
+    imgs = synthetic.polish_chunks(n, seed=99)
+    m = _model(sd)
+    l0, p0, a0 = m.predict_chunks(torch.from_numpy(imgs), return_acc=True)
+    perm = np.random.default_rng(3).permutation(n)
+    l1, p1, a1 = m.predict_chunks(torch.from_numpy(imgs[perm]), return_acc=True)
+    m.close()
+    small = _model(sd, max_chunk=70)
+    l2, p2, a2 = small.predict_chunks(torch.from_numpy(imgs), return_acc=True)
+    small.close()
+    a0, a1, a2 = a0.numpy(), a1.numpy(), a2.numpy()
+    assert np.abs(a0 - a2).max() < 1e-6 and (l0.numpy() == l2.numpy()).all()
+    assert np.abs(a0[perm] - a1).max() < 1e-6
+    pick = [0, 127, 128, 299]
+    rl, rp, inter = models_np.polish_predict_chunks(sd, imgs[pick], 128, return_intermediates=True)
+    assert np.abs(a0[pick] - inter["acc"]).max() < TOL

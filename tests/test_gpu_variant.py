@@ -136,3 +136,28 @@ def test_module_wrapper_and_checkpoint_loader(tmp_path):
     xf = xi.float() * 0.37
     ref_f = models_np.variant_forward(sd, xf.numpy())
     assert np.abs(model(xf.cuda()).cpu().numpy() - ref_f).max() < TOL
+
+
+def test_variant_full_bench_size_properties():
+    """BASELINE-size batch (16384 + ragged tail, two device chunks): (i) a sample of windows against
+    the oracle, (ii) chunking invariance, (iii) row-permutation equivariance, (iv) probabilities sum
+    to one -- the size-independent checks at the size bench.py times."""
+    n = 16384 + 37
+    sd = synthetic.variant_state_dict(seed=15, gain=2.0)
+    x = synthetic.variant_windows(n, seed=2718)
+    m = NativeVariant(sd)                      # default max_chunk 16384 -> chunks of 16384 and 37
+    p0, l0 = m.forward(x)
+    perm = np.random.default_rng(1).permutation(n)
+    p1, _ = m.forward(x[perm])
+    m.close()
+    small = NativeVariant(sd, max_chunk=4096)
+    p2, _ = small.forward(x)
+    small.close()
+    assert np.isfinite(p0).all() and np.abs(p0.sum(1) - 1).max() < 1e-5
+    assert np.abs(p0 - p2).max() < 1e-6
+    assert np.abs(p0[perm] - p1).max() < 1e-6
+    pick = np.random.default_rng(2).choice(n, 192, replace=False)
+    pick[:3] = (0, 16383, n - 1)
+    ref, inter = models_np.variant_forward(sd, x[pick], return_intermediates=True)
+    assert np.abs(p0[pick] - ref).max() < TOL
+    assert np.abs(l0[pick] - inter["logits"]).max() < TOL * max(1.0, np.abs(inter["logits"]).max())
