@@ -232,6 +232,9 @@ struct RecLayer {
     int K = 0, Kp = 0;         // input width and its zero-padded row length
     DevBuf *w_ih = nullptr;    // [2*G*H, Kp]   rows: dir*G*H + gate*H + unit
     DevBuf *w_ih_h2 = nullptr; // the same matrix in the h2 split format (gemm_h2.hip), when K % 32 == 0
+    bool prescaled = false;     // LSTM h2 path: w_ih_s / b_in_s / w_ih_h2 / w_hh_h2 / w_cat_h2 carry the exp2 gate scales
+    DevBuf *w_ih_s = nullptr;   // [2*G*H, Kp] f32, gate-scaled (feeds the f32 GEMM of float / unfused first layers)
+    DevBuf *b_in_s = nullptr;   // [2*G*H] gate-scaled bias
     DevBuf *w_hh_h2 = nullptr;  // LSTM H=256: W_hh as h2 fragments (rnn_h2.hip)
     DevBuf *w_cat_h2 = nullptr; // LSTM first layer: [W_hh | W_ih] as h2 fragments
     DevBuf *b_in = nullptr;    // [2*G*H]       LSTM: b_ih + b_hh; GRU: b_ih + (b_hr, b_hz, 0)
@@ -239,8 +242,10 @@ struct RecLayer {
     DevBuf *b_hn = nullptr;    // GRU only: [2*H]
 };
 
+// prescale (LSTM + split recurrences only): every copy of the weights that feeds rnn_h2.hip is multiplied
+// per gate row by -log2(e) (i, f, o) or +2 log2(e) (g) so the kernel's accumulators are exp2 arguments.
 int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix, int layer, int G,
-                    int H, int K, RecLayer& out) {
+                    int H, int K, RecLayer& out, bool prescale = false) {
     const char* sfx[2] = {"", "_reverse"};
     const float *wih[2], *whh[2], *bih[2], *bhh[2];
     std::string err;
@@ -267,6 +272,32 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
             for (int j = 0; j < H; ++j) bn[(size_t)d * H + j] = bhh[d][2 * H + j];
     std::vector<float> packed;
     pack_rec_weights(whh, G, H, packed);
+    prescale = prescale && G == 4;
+    out.prescaled = prescale;
+    // gate-scaled copies (identical to the originals when !prescale)
+    std::vector<float> ws(w), bs(b), whs[2], wis[2];
+    const float* whh_x[2] = {whh[0], whh[1]};
+    const float* wih_x[2] = {wih[0], wih[1]};
+    if (prescale) {
+        auto gscale = [&](int n) { return (n / H) == 2 ? 2.8853900817779268f : -1.4426950408889634f; };
+        for (int d = 0; d < 2; ++d) {
+            whs[d].assign(whh[d], whh[d] + (size_t)G * H * H);
+            wis[d].assign(wih[d], wih[d] + (size_t)G * H * K);
+            for (int n = 0; n < G * H; ++n) {
+                const float sc = gscale(n);
+                for (int k = 0; k < H; ++k) whs[d][(size_t)n * H + k] *= sc;
+                for (int k = 0; k < K; ++k) wis[d][(size_t)n * K + k] *= sc;
+                for (int k = 0; k < out.Kp; ++k) ws[((size_t)d * G * H + n) * out.Kp + k] *= sc;
+                bs[(size_t)d * G * H + n] *= sc;
+            }
+            whh_x[d] = whs[d].data();
+            wih_x[d] = wis[d].data();
+        }
+        out.w_ih_s = m->new_buf();
+        out.b_in_s = m->new_buf();
+        if (int rc = upload(out.w_ih_s, ws)) return rc;
+        if (int rc = upload(out.b_in_s, bs)) return rc;
+    }
     out.w_ih = m->new_buf();
     out.b_in = m->new_buf();
     out.w_hh = m->new_buf();
@@ -275,7 +306,7 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
     if (int rc = upload(out.w_hh, packed)) return rc;
     if (K % 32 == 0) {
         out.w_ih_h2 = m->new_buf();
-        if (int rc = upload_h2(out.w_ih_h2, w.data(), (int64_t)2 * G * H, K)) return rc;
+        if (int rc = upload_h2(out.w_ih_h2, ws.data(), (int64_t)2 * G * H, K)) return rc;
     }
     if (G == 3) {
         out.b_hn = m->new_buf();
@@ -286,13 +317,13 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
         auto pack_upload = [&](DevBuf*& dst, const float* const wx[2], int KX) -> int {
             for (int d = 0; d < 2; ++d) {
                 for (int64_t i = 0; i < (int64_t)G * H * H; ++i)
-                    if (!(std::fabs(whh[d][i]) < 65504.0f)) return fail(PA_ERR_INVALID, "recurrent weight not representable in f16 range");
+                    if (!(std::fabs(whh_x[d][i]) < 65504.0f)) return fail(PA_ERR_INVALID, "recurrent weight not representable in f16 range");
                 if (wx[0])
                     for (int64_t i = 0; i < (int64_t)G * H * K; ++i)
                         if (!(std::fabs(wx[d][i]) < 65504.0f)) return fail(PA_ERR_INVALID, "input weight not representable in f16 range");
             }
             std::vector<uint32_t> hp(pa::rec_weights_h2_words(G, H, KX));
-            pa::pack_rec_weights_h2(whh, wx, G, H, K, KX, hp.data());
+            pa::pack_rec_weights_h2(whh_x, wx, G, H, K, KX, hp.data());
             dst = m->new_buf();
             if (int rc = dst->ensure(hp.size() * sizeof(uint32_t))) return rc;
             HIP_TRY(hipMemcpy(dst->p, hp.data(), hp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -301,7 +332,7 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
         const float* const none[2] = {nullptr, nullptr};
         if (int rc = pack_upload(out.w_hh_h2, none, 0)) return rc;
         if (K <= KXh2)
-            if (int rc = pack_upload(out.w_cat_h2, wih, KXh2)) return rc;
+            if (int rc = pack_upload(out.w_cat_h2, wih_x, KXh2)) return rc;
     }
     if ((G == 4 && H == 256 && K <= 32) || (G == 3 && H == 128 && K <= 16)) {
         std::vector<float> cat;
@@ -415,7 +446,7 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
         for (int layer = 0; layer < cfg->gru_layers && rc == PA_OK; ++layer) {
             const int K = (mod == 0 && layer == 0) ? cfg->image_features : 2 * H;
             m->rec.emplace_back();
-            rc = build_rec_layer(m, sd, mod == 0 ? "encoder" : "decoder", layer, 4, H, K, m->rec.back());
+            rc = build_rec_layer(m, sd, mod == 0 ? "encoder" : "decoder", layer, 4, H, K, m->rec.back(), m->split_rec);
         }
     const char* lin_names[5] = {"linear_1", "linear_2", "linear_3", "linear_4", "linear_5"};
     for (int i = 0; i < 5 && rc == PA_OK; ++i)
@@ -483,12 +514,15 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
         const RecLayer& r = m->rec[li];
         float* y = ybuf[which];
         const bool rec_h2 = m->split_rec && r.w_hh_h2 != nullptr;
+        // bias / f32 projection weights matching what the recurrent kernel of this layer expects
+        const float* bias_l = (rec_h2 && r.prescaled) ? r.b_in_s->f() : r.b_in->f();
+        const float* wih_l = (rec_h2 && r.prescaled) ? r.w_ih_s->f() : r.w_ih->f();
         if (li == 0 && cur_kind == pa::A_I8 && r.w_cat != nullptr && m->fuse_input) {
             // int8 summaries straight into the recurrent kernel: no Xp round trip
             if (rec_h2 && r.w_cat_h2 != nullptr)
                 LAUNCH_TRY(m, "lstm_rec_h2_fused_in", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
-                           pa::launch_lstm_rec_h2(H, nullptr, 0, static_cast<const int8_t*>(cur), r.K, r.b_in->f(),
-                                                  r.w_cat_h2->p, y, 2 * H, (int)n, T, m->stream));
+                           pa::launch_lstm_rec_h2(H, nullptr, 0, static_cast<const int8_t*>(cur), r.K, bias_l,
+                                                  r.w_cat_h2->p, y, 2 * H, (int)n, T, m->stream, r.prescaled));
             else
                 LAUNCH_TRY(m, "lstm_rec_fused_in", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
                            pa::launch_lstm_rec_fused(H, static_cast<const int8_t*>(cur), r.K, r.b_in->f(),
@@ -503,17 +537,17 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
                                pa::launch_f32_to_h2(static_cast<const float*>(cur), const_cast<void*>(cur), M, r.K,
                                                     cur_ld, m->stream));
                 LAUNCH_TRY(m, "gemm_h2_inproj", 2.0 * M * NX * r.K,
-                           pa::launch_gemm_h2(cur, cur_ld, a_bytes, r.w_ih_h2->p, r.K, (size_t)NX * r.K * 4, r.b_in->f(),
+                           pa::launch_gemm_h2(cur, cur_ld, a_bytes, r.w_ih_h2->p, r.K, (size_t)NX * r.K * 4, bias_l,
                                               m->xp->f(), NX, (int)(np * T), NX, r.K, 0, 0, 0, T, (int)n, m->stream));
             } else {
                 LAUNCH_TRY(m, li == 0 ? "gemm_inproj_in" : "gemm_inproj", 2.0 * M * NX * r.K,
-                           pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(),
+                           pa::launch_gemm_nt(cur_kind, cur, cur_ld, wih_l, r.Kp, bias_l, m->xp->f(),
                                               NX, (int)(np * T), NX, r.K, 0, 0, 0, T, (int)n, m->stream));
             }
             if (rec_h2)
                 LAUNCH_TRY(m, "lstm_rec_h2", 2.0 * n * T * (4.0 * H) * H * 2,
                            pa::launch_lstm_rec_h2(H, m->xp->f(), NX, nullptr, 0, nullptr, r.w_hh_h2->p, y, 2 * H, (int)n,
-                                                  T, m->stream));
+                                                  T, m->stream, r.prescaled));
             else
                 LAUNCH_TRY(m, "lstm_rec", 2.0 * n * T * (4.0 * H) * H * 2,
                            pa::launch_lstm_rec(H, m->xp->f(), NX, r.w_hh->f(), y, 2 * H, (int)n, T, m->stream));

@@ -40,7 +40,9 @@ PA_DEV void decode_block(int bid, int& dir, int& btile) {
 // value of lane ^ 1 (quad_perm [1,0,3,2])
 PA_DEV unsigned swap_pair(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
 
-template <int H, int KX>
+// PRE: the packed weights, the bias and Xp arrive pre-multiplied per gate row by -log2(e) (i, f, o) or
+// +2 log2(e) (g), so the accumulators ARE the exp2 arguments of sigmoid / tanh (api.hip build_rec_layer).
+template <int H, int KX, bool PRE>
 __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
                                                                      const int8_t* __restrict__ Xi, int F,
                                                                      const float* __restrict__ bias,
@@ -254,20 +256,38 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; e += 2) {
+                    // two elements per pass: the plain arithmetic is written on 2-vectors so it can issue as
+                    // packed f32 instructions (the matrix pipe is idle in this phase)
                     const int r = 4 * qd + e;
-                    const float ig = fast_sigmoid(acc[m][0][r]);
-                    const float fg = fast_sigmoid(acc[m][1][r]);
-                    const float gg = fast_tanh(acc[m][2][r]);
-                    const float og = fast_sigmoid(acc[m][3][r]);
-                    const float cn = fg * cs[(m * 16 + r) * 64] + ig * gg;
-                    cs[(m * 16 + r) * 64] = cn;
-                    const float hv = og * fast_tanh(cn);
-                    const _Float16 hi = (_Float16)hv;
-                    const _Float16 lo = (_Float16)(hv - (float)hi);
-                    const unsigned uhi = __builtin_bit_cast(unsigned short, hi), ulo = __builtin_bit_cast(unsigned short, lo);
-                    const unsigned got = swap_pair(odd ? uhi : ulo);   // even lanes send lo, odd lanes send hi
-                    hl_dst[(32 * m + (r & 3) + 8 * (r >> 2)) * ROWD] = odd ? (got | (ulo << 16)) : (uhi | (got << 16));
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 one = {1.0f, 1.0f};
+                    f32x2 ai = {acc[m][0][r], acc[m][0][r + 1]}, af = {acc[m][1][r], acc[m][1][r + 1]},
+                          ag = {acc[m][2][r], acc[m][2][r + 1]}, ao = {acc[m][3][r], acc[m][3][r + 1]};
+                    if (!PRE) {
+                        ai *= -1.4426950408889634f; af *= -1.4426950408889634f;
+                        ag *= 2.8853900817779268f;  ao *= -1.4426950408889634f;
+                    }
+                    auto ex2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; };
+                    auto rcp = [](f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; };
+                    const f32x2 ig = rcp(one + ex2(ai));
+                    const f32x2 fg = rcp(one + ex2(af));
+                    const f32x2 gg = one - 2.0f * rcp(one + ex2(ag));
+                    const f32x2 og = rcp(one + ex2(ao));
+                    const f32x2 cold = {cs[(m * 16 + r) * 64], cs[(m * 16 + r + 1) * 64]};
+                    const f32x2 cn = fg * cold + ig * gg;
+                    cs[(m * 16 + r) * 64] = cn.x;
+                    cs[(m * 16 + r + 1) * 64] = cn.y;
+                    const f32x2 hv2 = og * (one - 2.0f * rcp(one + ex2(cn * 2.8853900817779268f)));
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float hv = k ? hv2.y : hv2.x;
+                        const _Float16 hi = (_Float16)hv;
+                        const _Float16 lo = (_Float16)(hv - (float)hi);
+                        const unsigned uhi = __builtin_bit_cast(unsigned short, hi), ulo = __builtin_bit_cast(unsigned short, lo);
+                        const unsigned got = swap_pair(odd ? uhi : ulo);   // even lanes send lo, odd lanes send hi
+                        hl_dst[(32 * m + ((r + k) & 3) + 8 * ((r + k) >> 2)) * ROWD] = odd ? (got | (ulo << 16)) : (uhi | (got << 16));
+                    }
                 }
                 if (step + 1 < T) seed_chunk(m, qd, tn);
             }
@@ -575,19 +595,25 @@ void pack_rec_weights_h2(const float* const whh[2], const float* const wih[2], i
 size_t rec_weights_h2_words(int G, int H, int KX) { return (size_t)2 * (G * H / 32) * ((H + KX) / 16) * 2 * 256; }
 
 hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, int F, const float* bias,
-                              const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream) {
+                              const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream, bool prescaled) {
     if (B <= 0) return hipSuccess;
     if (H != 256 || (ldy & 7)) return hipErrorInvalidValue;
     const int grid = rec_grid(B);
     if (X != nullptr) {
         if (F <= 0 || F > 32) return hipErrorInvalidValue;
         const size_t lds = (size_t)MT * ((256 + 32) * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4;
-        hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
+        if (prescaled) hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
+                           F, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y), ldy, B, T,
+                           debug_buffer() ? debug_buffer() + 8 * 80 * 2 : nullptr);
+        else hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32, false>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
                            F, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y), ldy, B, T,
                            debug_buffer() ? debug_buffer() + 8 * 80 * 2 : nullptr);
     } else {
         const size_t lds = (size_t)MT * (256 * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4;
-        hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 0>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
+        if (prescaled) hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 0, true>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
+                           (const int8_t*)nullptr, 0, (const float*)nullptr, static_cast<const uint32_t*>(Wp),
+                           static_cast<uint32_t*>(Y), ldy, B, T, debug_buffer());
+        else hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 0, false>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
                            (const int8_t*)nullptr, 0, (const float*)nullptr, static_cast<const uint32_t*>(Wp),
                            static_cast<uint32_t*>(Y), ldy, B, T, debug_buffer());
     }
