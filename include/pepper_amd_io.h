@@ -73,6 +73,41 @@ int pa_h5_write_fixed_strings(pa_h5* f, const char* path, int32_t rank, const in
 int pa_h5_write_vlen_strings(pa_h5* f, const char* path, int32_t rank, const int64_t* dims,
                              const char* const* strings);
 
+/* ------------------------------------------------------------------------------------------
+ * BAM ingestion (pepper_amd/csrc/bamio.cpp; zlib, no htslib)
+ * replaces the pybind surface of PEPPER_VARIANT.BAM_handler:
+ *   BAM_handler(path)                                   bam_handler.cpp:6-28
+ *   .get_chromosome_sequence_names()                    bam_handler.cpp:103-113
+ *   .get_sample_names()                                 bam_handler.cpp:30-54   (from pa_bam_header_text)
+ *   .get_reads(contig, start, stop, include_supplementary, min_mapq, min_baseq)
+ *        -> vector<type_read>                           bam_handler.cpp:115-451 (read.h:52-64)
+ * Reads come back clipped to [start, stop] exactly as the reference clips them, as the flat arrays
+ * of pa_pileup (include/pepper_amd_encoder.h) instead of per-read objects.  A `<path>.bai` (or
+ * `<stem>.bai`) index is used when present; without one the contig is scanned linearly.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pa_bam pa_bam;
+
+const char* pa_bam_last_error(void);
+int pa_bam_open(const char* path, pa_bam** out);
+void pa_bam_close(pa_bam* b);
+int pa_bam_has_index(pa_bam* b);
+int pa_bam_n_targets(pa_bam* b);
+/* name (NUL-terminated, truncated to cap) and length of target i; returns the name length */
+int pa_bam_target(pa_bam* b, int32_t i, char* name, int32_t cap, int64_t* length);
+/* SAM header text; *needed = bytes including the terminator */
+int pa_bam_header_text(pa_bam* b, char* buf, int64_t cap, int64_t* needed);
+/* Run the region query; results stay in the handle until the next call.  Sizes for pa_bam_copy_reads:
+ * n_reads, total bases, total cigar operations, bytes of the NUL-separated query names. */
+int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop, int32_t include_supplementary,
+                     int32_t min_mapq, int32_t min_baseq, int64_t* n_reads, int64_t* seq_bytes, int64_t* n_cigar,
+                     int64_t* name_bytes);
+/* Copy out (any pointer may be NULL): pos / pos_end int64 [n], reverse u8 [n], mapq / flags / hp int32 [n],
+ * seq_offset int64 [n+1], seq char [bases], qual u8 [bases], cigar_offset int64 [n+1], cigar_op / cigar_len
+ * int32 [ops] (BAM operation codes = CIGAR_OPERATIONS, cigar.h:17-27), names char [name_bytes]. */
+int pa_bam_copy_reads(pa_bam* b, int64_t* pos, int64_t* pos_end, uint8_t* reverse, int32_t* mapq, int32_t* flags,
+                      int32_t* hp, int64_t* seq_offset, char* seq, uint8_t* qual, int64_t* cigar_offset,
+                      int32_t* cigar_op, int32_t* cigar_len, char* names);
+
 #ifdef __cplusplus
 }
 #endif

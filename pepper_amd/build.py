@@ -32,14 +32,16 @@ def build_io(force=False, verbose=False):
     h5py is not installed for this image's torch interpreter; libhdf5 + headers live under
     /opt/conda (override with PEPPER_AMD_HDF5_PREFIX)."""
     src = os.path.join(CSRC, "hdf5io.cpp")
+    bam = os.path.join(CSRC, "bamio.cpp")      # BAM reader (zlib) lives in the same host-side library
     hdr = os.path.join(CSRC, "..", "..", "include", "pepper_amd_io.h")
-    if not force and os.path.exists(IO_LIB) and os.path.getmtime(IO_LIB) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    if not force and os.path.exists(IO_LIB) and os.path.getmtime(IO_LIB) >= max(os.path.getmtime(src), os.path.getmtime(bam),
+                                                                              os.path.getmtime(hdr)):
         return IO_LIB
     inc, lib = os.path.join(HDF5_PREFIX, "include"), os.path.join(HDF5_PREFIX, "lib")
     if not os.path.exists(os.path.join(inc, "hdf5.h")):
         raise RuntimeError(f"hdf5.h not found under {inc}: set PEPPER_AMD_HDF5_PREFIX")
-    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", IO_LIB + ".tmp", src, f"-I{inc}", f"-L{lib}",
-           "-lhdf5", f"-Wl,-rpath,{lib}"]
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", IO_LIB + ".tmp", src, bam, f"-I{inc}", f"-L{lib}",
+           "-lhdf5", "-lz", f"-Wl,-rpath,{lib}"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

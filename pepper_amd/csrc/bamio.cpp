@@ -1,0 +1,481 @@
+// BAM ingestion for the image generator: region query + the
+// reference's read clipping, delivered as the flat arrays of pa_pileup (include/pepper_amd_encoder.h).
+//
+// replaces: /root/reference/pepper_variant/modules/cpp/bam_handler.cpp
+//     BAM_handler::BAM_handler            :6-28    open + index + header
+//     get_sample_names                    :30-54   @RG SM values (parsed in pepper_amd/variant/bam.py)
+//     get_chromosome_sequence_names       :103-113
+//     get_reads                           :115-451 region iterator, flag / mapq filters, clipping of every
+//                                                  read to [start, stop], HP tag
+// htslib is not part of this image; the containers are read from their published layouts (SAM/BAM
+// specification sections 4.1 BGZF, 4.2 BAM, 5.2 BAI) with zlib.  PARITY UNPINNED: the reference's reader
+// cannot be built here (htslib), so tests/test_bam_reader.py checks this file against a Python
+// restatement of get_reads' rules on synthetic BAM files written by the test itself.
+//
+// Region semantics: like sam_itr_queryi(idx, tid, start, stop) the candidates are the records of the
+// contig with pos < stop and end > start (end = pos + reference length, at least pos + 1), in file
+// order.  With a .bai the scan starts at the linear-index offset of start's 16 kb window; without one
+// the contig is scanned from its first record (correct, slower).
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pepper_amd_io.h"
+
+namespace {
+
+thread_local std::string g_bam_err;
+int bam_fail(int code, const std::string& msg) {
+    g_bam_err = msg;
+    return code;
+}
+
+struct Bgzf {
+    FILE* fp = nullptr;
+    std::vector<uint8_t> block;      // decompressed current block
+    int64_t block_coffset = -1;      // file offset of the current block
+    int64_t next_coffset = 0;        // file offset of the block after it
+    size_t upos = 0;                 // read position inside `block`
+    bool eof = false;
+
+    bool load_block(int64_t coffset) {
+        if (fseeko(fp, coffset, SEEK_SET) != 0) return false;
+        uint8_t hdr[18];
+        const size_t got = fread(hdr, 1, 18, fp);
+        if (got == 0) { eof = true; block.clear(); upos = 0; block_coffset = coffset; next_coffset = coffset; return true; }
+        if (got != 18 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) return false;
+        const int xlen = hdr[10] | (hdr[11] << 8);
+        // the BC subfield is the first extra field in every BGZF writer; scan anyway
+        std::vector<uint8_t> extra(xlen);
+        std::memcpy(extra.data(), hdr + 12, std::min(6, xlen));
+        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, fp) != (size_t)(xlen - 6)) return false;
+        int bsize = -1;
+        for (int p = 0; p + 4 <= xlen;) {
+            const int slen = extra[p + 2] | (extra[p + 3] << 8);
+            if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = (extra[p + 4] | (extra[p + 5] << 8)) + 1;
+            p += 4 + slen;
+        }
+        if (bsize < 0) return false;
+        const int clen = bsize - 12 - xlen - 8;
+        if (clen < 0) return false;
+        std::vector<uint8_t> comp(clen + 8);
+        if (fread(comp.data(), 1, clen + 8, fp) != (size_t)(clen + 8)) return false;
+        const uint32_t isize = comp[clen + 4] | (comp[clen + 5] << 8) | (comp[clen + 6] << 16) | ((uint32_t)comp[clen + 7] << 24);
+        block.resize(isize);
+        if (isize) {
+            z_stream zs{};
+            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            zs.next_in = comp.data();
+            zs.avail_in = clen;
+            zs.next_out = block.data();
+            zs.avail_out = isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) return false;
+        }
+        block_coffset = coffset;
+        next_coffset = coffset + bsize;
+        upos = 0;
+        eof = false;
+        return true;
+    }
+    bool seek(uint64_t voffset) {
+        const int64_t co = (int64_t)(voffset >> 16);
+        if (co != block_coffset && !load_block(co)) return false;
+        upos = voffset & 0xffff;
+        return upos <= block.size();
+    }
+    // returns bytes read (< n only at end of file)
+    size_t read(void* dst, size_t n) {
+        size_t done = 0;
+        uint8_t* out = static_cast<uint8_t*>(dst);
+        while (done < n) {
+            if (upos >= block.size()) {
+                if (eof) break;
+                if (!load_block(next_coffset)) { eof = true; break; }
+                if (eof) break;
+                if (block.empty()) continue;          // empty block (e.g. the EOF marker)
+            }
+            const size_t take = std::min(n - done, block.size() - upos);
+            std::memcpy(out + done, block.data() + upos, take);
+            upos += take;
+            done += take;
+        }
+        return done;
+    }
+    uint64_t tell() const { return ((uint64_t)block_coffset << 16) | (uint64_t)upos; }
+};
+
+inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint64_t le64(const uint8_t* p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+
+struct ReadSet {
+    std::vector<int64_t> pos, pos_end, seq_offset{0}, cigar_offset{0}, name_offset{0};
+    std::vector<uint8_t> reverse, qual;
+    std::vector<int32_t> mapq, flags, hp, cigar_op, cigar_len;
+    std::string seq, names;
+    void clear() { *this = ReadSet(); }
+};
+
+}  // namespace
+
+struct pa_bam {
+    Bgzf bg;
+    std::string text;
+    std::vector<std::string> names;
+    std::vector<int64_t> lengths;
+    uint64_t first_record = 0;                                 // virtual offset after the header
+    bool has_index = false;
+    std::vector<std::vector<uint64_t>> ioff;                   // linear index per reference
+    std::vector<uint64_t> ref_min;                             // smallest chunk begin per reference (0 = none)
+    ReadSet reads;
+};
+
+namespace {
+
+bool load_bai(pa_bam* b, const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<uint8_t> raw;
+    uint8_t buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) raw.insert(raw.end(), buf, buf + n);
+    fclose(f);
+    if (raw.size() < 8 || std::memcmp(raw.data(), "BAI\1", 4) != 0) return false;
+    size_t p = 4;
+    const uint32_t n_ref = le32(&raw[p]);
+    p += 4;
+    b->ioff.assign(n_ref, {});
+    b->ref_min.assign(n_ref, 0);
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        if (p + 4 > raw.size()) return false;
+        const uint32_t n_bin = le32(&raw[p]);
+        p += 4;
+        for (uint32_t i = 0; i < n_bin; ++i) {
+            if (p + 8 > raw.size()) return false;
+            const uint32_t bin = le32(&raw[p]);
+            const uint32_t n_chunk = le32(&raw[p + 4]);
+            p += 8;
+            if (p + 16ull * n_chunk > raw.size()) return false;
+            if (bin != 37450)                                   // pseudo-bin with metadata
+                for (uint32_t c = 0; c < n_chunk; ++c) {
+                    const uint64_t beg = le64(&raw[p + 16 * c]);
+                    if (b->ref_min[r] == 0 || beg < b->ref_min[r]) b->ref_min[r] = beg;
+                }
+            p += 16ull * n_chunk;
+        }
+        if (p + 4 > raw.size()) return false;
+        const uint32_t n_intv = le32(&raw[p]);
+        p += 4;
+        if (p + 8ull * n_intv > raw.size()) return false;
+        b->ioff[r].resize(n_intv);
+        for (uint32_t i = 0; i < n_intv; ++i) b->ioff[r][i] = le64(&raw[p + 8 * i]);
+        p += 8ull * n_intv;
+    }
+    return true;
+}
+
+const char kSeqNt16[] = "=ACMGRSVTWYHKDBN";
+
+int aux_size(uint8_t t) {
+    switch (t) {
+        case 'A': case 'c': case 'C': return 1;
+        case 's': case 'S': return 2;
+        case 'f': case 'i': case 'I': return 4;
+        default: return -1;
+    }
+}
+
+// HP:<integer> from the auxiliary block (0 when absent or malformed)
+int parse_hp(const uint8_t* s, const uint8_t* end) {
+    int hp = 0;
+    while (end - s >= 4) {
+        const bool is_hp = s[0] == 'H' && s[1] == 'P';
+        const uint8_t type = s[2];
+        s += 3;
+        switch (type) {
+            case 'A': s += 1; break;
+            case 'c': case 'C': case 's': case 'S': case 'i': case 'I': {
+                const int sz = aux_size(type);
+                if (end - s < sz) return hp;
+                if (is_hp) {
+                    switch (type) {
+                        case 'c': hp = (int8_t)s[0]; break;
+                        case 'C': hp = s[0]; break;
+                        case 's': hp = (int16_t)(s[0] | (s[1] << 8)); break;
+                        case 'S': hp = s[0] | (s[1] << 8); break;
+                        default: hp = (int32_t)le32(s); break;
+                    }
+                }
+                s += sz;
+                break;
+            }
+            case 'f': if (end - s < 4) return hp; s += 4; break;
+            case 'Z': case 'H':
+                while (s < end && *s) ++s;
+                if (s >= end) return hp;
+                ++s;
+                break;
+            case 'B': {
+                if (end - s < 5) return hp;
+                const int esz = aux_size(s[0]);
+                if (esz < 0) return hp;
+                const uint32_t cnt = le32(s + 1);
+                s += 5 + (size_t)cnt * esz;
+                break;
+            }
+            default: return hp;
+        }
+    }
+    return hp;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pa_bam_last_error(void) { return g_bam_err.c_str(); }
+
+int pa_bam_open(const char* path, pa_bam** out) {
+    if (!path || !out) return bam_fail(-1, "null argument");
+    auto* b = new pa_bam();
+    b->bg.fp = fopen(path, "rb");
+    if (!b->bg.fp) { delete b; return bam_fail(-2, std::string("INVALID BAM FILE. PLEASE CHECK IF PATH IS CORRECT: ") + path); }
+    uint8_t hdr[8];
+    if (!b->bg.load_block(0) || b->bg.read(hdr, 8) != 8 || std::memcmp(hdr, "BAM\1", 4) != 0) {
+        fclose(b->bg.fp); delete b;
+        return bam_fail(-3, std::string("HEADER ERROR: INVALID BAM FILE: ") + path);
+    }
+    const uint32_t l_text = le32(hdr + 4);
+    b->text.resize(l_text);
+    uint8_t w[4];
+    bool ok = b->bg.read(b->text.data(), l_text) == l_text && b->bg.read(w, 4) == 4;
+    const uint32_t n_ref = ok ? le32(w) : 0;
+    for (uint32_t i = 0; ok && i < n_ref; ++i) {
+        ok = b->bg.read(w, 4) == 4;
+        const uint32_t l_name = ok ? le32(w) : 0;
+        std::string name(l_name, '\0');
+        ok = ok && b->bg.read(name.data(), l_name) == l_name && b->bg.read(w, 4) == 4;
+        if (!name.empty() && name.back() == '\0') name.pop_back();
+        b->names.push_back(name);
+        b->lengths.push_back(ok ? le32(w) : 0);
+    }
+    if (!ok) { fclose(b->bg.fp); delete b; return bam_fail(-3, std::string("HEADER ERROR: truncated BAM header: ") + path); }
+    while (!b->text.empty() && b->text.back() == '\0') b->text.pop_back();
+    b->first_record = b->bg.tell();
+    const std::string p(path);
+    b->has_index = load_bai(b, p + ".bai");
+    if (!b->has_index && p.size() > 4 && p.substr(p.size() - 4) == ".bam") b->has_index = load_bai(b, p.substr(0, p.size() - 4) + ".bai");
+    *out = b;
+    return 0;
+}
+
+void pa_bam_close(pa_bam* b) {
+    if (!b) return;
+    if (b->bg.fp) fclose(b->bg.fp);
+    delete b;
+}
+
+int pa_bam_has_index(pa_bam* b) { return b && b->has_index ? 1 : 0; }
+int pa_bam_n_targets(pa_bam* b) { return b ? (int)b->names.size() : 0; }
+
+int pa_bam_target(pa_bam* b, int32_t i, char* name, int32_t cap, int64_t* length) {
+    if (!b || i < 0 || i >= (int)b->names.size()) return bam_fail(-1, "target index out of range");
+    if (name && cap > 0) {
+        std::strncpy(name, b->names[i].c_str(), cap - 1);
+        name[cap - 1] = '\0';
+    }
+    if (length) *length = b->lengths[i];
+    return (int)b->names[i].size();
+}
+
+int pa_bam_header_text(pa_bam* b, char* buf, int64_t cap, int64_t* needed) {
+    if (!b) return bam_fail(-1, "null handle");
+    if (needed) *needed = (int64_t)b->text.size() + 1;
+    if (buf && cap > (int64_t)b->text.size()) std::memcpy(buf, b->text.c_str(), b->text.size() + 1);
+    return 0;
+}
+
+int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop, int32_t include_supplementary,
+                     int32_t min_mapq, int32_t min_baseq, int64_t* n_reads, int64_t* seq_bytes, int64_t* n_cigar,
+                     int64_t* name_bytes) {
+    (void)min_baseq;   // only feeds type_read.bad_indicies in the reference, which the encoders never read
+    if (!b || !contig) return bam_fail(-1, "null argument");
+    ReadSet& rs = b->reads;
+    rs.clear();
+    int tid = -1;
+    for (size_t i = 0; i < b->names.size(); ++i)
+        if (b->names[i] == contig) tid = (int)i;
+    if (tid < 0) return bam_fail(-4, std::string("contig not in the BAM header: ") + contig);
+
+    uint64_t from = b->first_record;
+    bool nothing = false;
+    if (b->has_index && tid < (int)b->ioff.size()) {
+        const auto& lin = b->ioff[tid];
+        int64_t w = std::max<int64_t>(0, start) >> 14;
+        uint64_t off = 0;
+        if (!lin.empty()) {
+            if (w >= (int64_t)lin.size()) w = (int64_t)lin.size() - 1;
+            for (int64_t k = w; k >= 0 && off == 0; --k) off = lin[k];
+        }
+        if (off == 0) off = b->ref_min[tid];
+        if (off == 0) nothing = true;     // no alignments on this reference
+        from = off;
+    }
+    if (!nothing && !b->bg.seek(from)) return bam_fail(-5, "BGZF seek failed (corrupt file or index)");
+
+    std::vector<uint8_t> rec;
+    while (!nothing) {
+        uint8_t w4[4];
+        if (b->bg.read(w4, 4) != 4) break;
+        const uint32_t block_size = le32(w4);
+        if (block_size < 32) return bam_fail(-6, "corrupt BAM record");
+        rec.resize(block_size);
+        if (b->bg.read(rec.data(), block_size) != block_size) return bam_fail(-6, "truncated BAM record");
+        const int32_t ref_id = (int32_t)le32(&rec[0]);
+        const int32_t pos = (int32_t)le32(&rec[4]);
+        const uint32_t l_read_name = rec[8];
+        const int32_t mapq = rec[9];
+        const uint32_t n_cigar_op = rec[12] | (rec[13] << 8);
+        const uint32_t flag = rec[14] | (rec[15] << 8);
+        const uint32_t l_seq = le32(&rec[16]);
+        if (ref_id != tid) {
+            if (ref_id > tid || ref_id < 0) break;      // sorted file: past the contig (unmapped reads come last)
+            continue;
+        }
+        if (pos >= stop) break;
+        const size_t o_name = 32, o_cigar = o_name + l_read_name, o_seq = o_cigar + 4ull * n_cigar_op,
+                     o_qual = o_seq + (l_seq + 1) / 2, o_aux = o_qual + l_seq;
+        if (o_aux > block_size) return bam_fail(-6, "corrupt BAM record");
+        int64_t ref_len = 0;
+        for (uint32_t k = 0; k < n_cigar_op; ++k) {
+            const uint32_t c = le32(&rec[o_cigar + 4 * k]);
+            const int op = c & 15;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
+        }
+        const int64_t end = pos + std::max<int64_t>(ref_len, 1);
+        if (end <= start) continue;
+
+        // ---- filters of get_reads (:138-151) ----
+        if (flag & (0x200 | 0x400 | 0x100 | 0x4)) continue;        // qc-fail, duplicate, secondary, unmapped
+        if (!include_supplementary && (flag & 0x800)) continue;
+        if (mapq < min_mapq) continue;
+
+        // ---- clip to [start, stop] (:176-303) ----
+        const uint8_t* seqi = &rec[o_seq];
+        const uint8_t* qual = &rec[o_qual];
+        const size_t seq0 = rs.seq.size(), cig0 = rs.cigar_op.size();
+        int64_t pos_start = -1, pos_end = -1, rpos = pos;
+        int64_t ridx = 0;
+        auto push_base = [&](int64_t idx) {
+            char base = kSeqNt16[(seqi[idx >> 1] >> ((~idx & 1) << 2)) & 15];
+            if (base >= 'a' && base <= 'z') base = (char)(base - 32);
+            rs.seq.push_back(base);
+            rs.qual.push_back(qual[idx]);
+        };
+        for (uint32_t k = 0; k < n_cigar_op; ++k) {
+            const uint32_t c = le32(&rec[o_cigar + 4 * k]);
+            const int op = c & 15;
+            const int64_t len = c >> 4;
+            if (rpos > stop) break;
+            int64_t kept = 0;
+            switch (op) {
+                case 0: case 7: case 8: {                   // M, =, X
+                    int64_t skip = 0;
+                    if (rpos < start) {
+                        skip = std::min<int64_t>(start - rpos, len);
+                        ridx += skip;
+                        rpos += skip;
+                    }
+                    for (int64_t i = skip; i < len; ++i) {
+                        if (rpos > stop) break;
+                        if (pos_start == -1) { pos_start = rpos; pos_end = rpos; }
+                        push_base(ridx);
+                        ++kept;
+                        ++pos_end;
+                        ++ridx;
+                        ++rpos;
+                    }
+                    break;
+                }
+                case 4: case 1:                               // S, I: kept only behind an anchored position
+                    if (rpos >= start && rpos <= stop && pos_start != -1) {
+                        for (int64_t i = 0; i < len; ++i) { push_base(ridx); ++ridx; }
+                        kept = len;
+                    } else {
+                        ridx += len;
+                    }
+                    break;
+                case 3: case 2:                               // N, D
+                    if (rpos >= start && rpos <= stop && pos_start != -1) {
+                        for (int64_t i = 0; i < len; ++i) {
+                            if (rpos > stop) break;
+                            ++kept;
+                            ++pos_end;
+                            ++rpos;
+                        }
+                    } else {
+                        rpos += len;
+                    }
+                    break;
+                default:                                      // H, P: nothing
+                    break;
+            }
+            if (kept > 0) {
+                rs.cigar_op.push_back(op);
+                rs.cigar_len.push_back((int32_t)kept);
+            }
+        }
+        if (rs.seq.size() == seq0) {                          // no base inside the region: read dropped (:432)
+            rs.cigar_op.resize(cig0);
+            rs.cigar_len.resize(cig0);
+            continue;
+        }
+        rs.pos.push_back(pos_start);
+        rs.pos_end.push_back(pos_end);
+        rs.reverse.push_back((flag & 0x10) ? 1 : 0);
+        rs.mapq.push_back(mapq);
+        rs.flags.push_back((int32_t)flag);
+        rs.hp.push_back(parse_hp(&rec[o_aux], rec.data() + block_size));
+        rs.seq_offset.push_back((int64_t)rs.seq.size());
+        rs.cigar_offset.push_back((int64_t)rs.cigar_op.size());
+        rs.names.append(reinterpret_cast<const char*>(&rec[o_name]), l_read_name ? l_read_name - 1 : 0);
+        rs.names.push_back('\0');
+        rs.name_offset.push_back((int64_t)rs.names.size());
+    }
+    if (n_reads) *n_reads = (int64_t)rs.pos.size();
+    if (seq_bytes) *seq_bytes = (int64_t)rs.seq.size();
+    if (n_cigar) *n_cigar = (int64_t)rs.cigar_op.size();
+    if (name_bytes) *name_bytes = (int64_t)rs.names.size();
+    return 0;
+}
+
+int pa_bam_copy_reads(pa_bam* b, int64_t* pos, int64_t* pos_end, uint8_t* reverse, int32_t* mapq, int32_t* flags,
+                      int32_t* hp, int64_t* seq_offset, char* seq, uint8_t* qual, int64_t* cigar_offset,
+                      int32_t* cigar_op, int32_t* cigar_len, char* names) {
+    if (!b) return bam_fail(-1, "null handle");
+    const ReadSet& rs = b->reads;
+    const size_t n = rs.pos.size();
+    auto cp = [](void* dst, const void* src, size_t bytes) { if (dst && bytes) std::memcpy(dst, src, bytes); };
+    cp(pos, rs.pos.data(), n * 8);
+    cp(pos_end, rs.pos_end.data(), n * 8);
+    cp(reverse, rs.reverse.data(), n);
+    cp(mapq, rs.mapq.data(), n * 4);
+    cp(flags, rs.flags.data(), n * 4);
+    cp(hp, rs.hp.data(), n * 4);
+    cp(seq_offset, rs.seq_offset.data(), (n + 1) * 8);
+    cp(seq, rs.seq.data(), rs.seq.size());
+    cp(qual, rs.qual.data(), rs.qual.size());
+    cp(cigar_offset, rs.cigar_offset.data(), (n + 1) * 8);
+    cp(cigar_op, rs.cigar_op.data(), rs.cigar_op.size() * 4);
+    cp(cigar_len, rs.cigar_len.data(), rs.cigar_len.size() * 4);
+    cp(names, rs.names.data(), rs.names.size());
+    return 0;
+}
+
+}  // extern "C"

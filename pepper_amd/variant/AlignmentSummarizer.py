@@ -41,18 +41,19 @@ class AlignmentSummarizer:
                                                options.min_snp_baseq)
         total_reads = len(all_reads)
         total_allowed_reads = int(min(AlingerOptions.MAX_READS_IN_REGION, options.downsample_rate * total_reads))
+        flat = hasattr(all_reads, "as_pileup")          # pepper_amd.variant.bam.ReadSet: structure of arrays
         if total_reads > total_allowed_reads:
-            # reservoir sampling exactly as the reference (nucleus utils.reservoir_sample)
+            # reservoir sampling exactly as the reference (nucleus utils.reservoir_sample); on read indices
             random = np.random.RandomState(AlingerOptions.RANDOM_SEED)
             sample = []
-            for i, read in enumerate(all_reads):
+            for i in range(total_reads):
                 if len(sample) < total_allowed_reads:
-                    sample.append(read)
+                    sample.append(i)
                 else:
                     j = random.randint(0, i + 1)
                     if j < total_allowed_reads:
-                        sample[j] = read
-            all_reads = sample
+                        sample[j] = i
+            all_reads = all_reads.take(sample) if flat else [all_reads[i] for i in sample]
         if len(all_reads) == 0:
             return None
         # ref_seq should contain region_end_position base
@@ -60,6 +61,8 @@ class AlignmentSummarizer:
         regional_summary = PEPPER_VARIANT.RegionalSummaryGenerator(self.chromosome_name, region_start, region_end,
                                                                    ref_seq, device=getattr(options, "device", 0))
         regional_summary.generate_max_insert_summary(all_reads)
+        if flat:
+            all_reads = all_reads.as_pileup()
         args = (all_reads, options.min_snp_baseq, options.min_indel_baseq, options.snp_frequency,
                 options.insert_frequency, options.delete_frequency, options.min_coverage_threshold,
                 options.snp_candidate_frequency_threshold, options.indel_candidate_frequency_threshold,

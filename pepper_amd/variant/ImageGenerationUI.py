@@ -28,11 +28,14 @@ def _log(msg):
 
 
 def _handlers(options, bam_path, fasta_path):
+    """Injected factories win (tests, other readers); otherwise the package's own BAM (zlib, bamio.cpp) and
+    indexed-FASTA readers -- htslib is not needed."""
     bf = getattr(options, "bam_handler_factory", None)
     ff = getattr(options, "fasta_handler_factory", None)
-    if bf is None or ff is None:
-        raise RuntimeError("BAM/FASTA ingestion needs htslib, which this build does not wrap (SURVEY.md 8(f) N3): "
-                           "set options.bam_handler_factory / options.fasta_handler_factory")
+    if bf is None:
+        from pepper_amd.variant.bam import BAM_handler as bf
+    if ff is None:
+        from pepper_amd.variant.fasta import FASTA_handler as ff
     return bf(bam_path), ff(fasta_path)
 
 

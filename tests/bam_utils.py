@@ -1,0 +1,147 @@
+"""Test-side BAM tooling: a minimal coordinate-sorted BAM (+ optional BAI) writer built on the package's
+BGZF writer, and a Python restatement of the reference's get_reads clipping rules
+(/root/reference/pepper_variant/modules/cpp/bam_handler.cpp:115-451) used as the checker for
+pepper_amd/csrc/bamio.cpp.  Not product code."""
+import struct
+
+import numpy as np
+
+from pepper_amd.variant.bgzf import BgzfWriter, reg2bin
+
+SEQ_CODE = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+REF_OPS = (0, 2, 3, 7, 8)
+
+
+def ref_length(cigar):
+    return sum(n for op, n in cigar if op in REF_OPS)
+
+
+def encode_record(tid, rec):
+    name = rec.get("name", "r").encode() + b"\0"
+    cigar = rec["cigar"]
+    seq = rec["seq"]
+    l_seq = len(seq)
+    end = rec["pos"] + max(1, ref_length(cigar))
+    body = struct.pack("<iiBBHHHIiii", tid, rec["pos"], len(name), rec.get("mapq", 60), reg2bin(rec["pos"], end),
+                       len(cigar), rec.get("flag", 16 if rec.get("reverse") else 0), l_seq, -1, -1, 0)
+    body += name
+    body += b"".join(struct.pack("<I", (n << 4) | op) for op, n in cigar)
+    packed = bytearray((l_seq + 1) // 2)
+    for i, c in enumerate(seq):
+        packed[i >> 1] |= SEQ_CODE[c] << (4 if i % 2 == 0 else 0)
+    body += bytes(packed)
+    body += bytes(np.asarray(rec["qual"], dtype=np.uint8))
+    body += rec.get("aux", b"")
+    return struct.pack("<i", len(body)) + body
+
+
+def write_bam(path, refs, records_by_tid, header_text="@HD\tVN:1.6\tSO:coordinate\n", with_index=True, flush_every=0):
+    """refs: [(name, length)]; records_by_tid: {tid: [record dicts sorted by pos]}.  Returns nothing; writes
+    `path` and, when with_index, `path + '.bai'`."""
+    w = BgzfWriter(path)
+    text = header_text + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    w.write(b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs)))
+    for name, length in refs:
+        w.write(struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", length))
+    w._flush_block()                 # records start on a block boundary, as samtools writes them
+    index = {}
+    count = 0
+    for tid in sorted(records_by_tid):
+        bins, lin = {}, {}
+        for rec in records_by_tid[tid]:
+            vbeg = w.tell()
+            w.write(encode_record(tid, rec))
+            count += 1
+            if flush_every and count % flush_every == 0:
+                w._flush_block()
+            vend = w.tell()
+            beg, end = rec["pos"], rec["pos"] + max(1, ref_length(rec["cigar"]))
+            chunks = bins.setdefault(reg2bin(beg, end), [])
+            if chunks and chunks[-1][1] == vbeg:
+                chunks[-1][1] = vend
+            else:
+                chunks.append([vbeg, vend])
+            for win in range(beg >> 14, ((end - 1) >> 14) + 1):
+                lin.setdefault(win, vbeg)
+        index[tid] = (bins, lin)
+    w.close()
+    if with_index:
+        out = bytearray(b"BAI\1" + struct.pack("<i", len(refs)))
+        for tid in range(len(refs)):
+            bins, lin = index.get(tid, ({}, {}))
+            out += struct.pack("<i", len(bins))
+            for b in sorted(bins):
+                out += struct.pack("<Ii", b, len(bins[b]))
+                for beg, end in bins[b]:
+                    out += struct.pack("<QQ", beg, end)
+            n_intv = max(lin) + 1 if lin else 0
+            out += struct.pack("<i", n_intv)
+            for win in range(n_intv):
+                out += struct.pack("<Q", lin.get(win, 0))     # 0 = no alignment overlaps this window
+        with open(path + ".bai", "wb") as fh:
+            fh.write(bytes(out))
+
+
+def restated_get_reads(records, start, stop, include_supplementary, min_mapq):
+    """The reference's filters + clipping on record dicts of ONE contig, in file order."""
+    out = []
+    for rec in records:
+        pos, cigar = rec["pos"], rec["cigar"]
+        flag = rec.get("flag", 16 if rec.get("reverse") else 0)
+        end = pos + max(1, ref_length(cigar))
+        if not (pos < stop and end > start):
+            continue
+        if flag & (0x200 | 0x400 | 0x100 | 0x4):
+            continue
+        if not include_supplementary and flag & 0x800:
+            continue
+        if rec.get("mapq", 60) < min_mapq:
+            continue
+        seq, qual = rec["seq"], list(np.asarray(rec["qual"]).tolist())
+        out_seq, out_qual, out_cigar = [], [], []
+        pos_start = pos_end = -1
+        rpos, ridx = pos, 0
+        for op, n in cigar:
+            if rpos > stop:
+                break
+            kept = 0
+            if op in (0, 7, 8):
+                skip = 0
+                if rpos < start:
+                    skip = min(start - rpos, n)
+                    ridx += skip
+                    rpos += skip
+                for _ in range(skip, n):
+                    if rpos > stop:
+                        break
+                    if pos_start == -1:
+                        pos_start = pos_end = rpos
+                    out_seq.append(seq[ridx].upper())
+                    out_qual.append(qual[ridx])
+                    kept += 1
+                    pos_end += 1
+                    ridx += 1
+                    rpos += 1
+            elif op in (4, 1):
+                if start <= rpos <= stop and pos_start != -1:
+                    out_seq.extend(c.upper() for c in seq[ridx:ridx + n])
+                    out_qual.extend(qual[ridx:ridx + n])
+                    kept = n
+                ridx += n
+            elif op in (3, 2):
+                if start <= rpos <= stop and pos_start != -1:
+                    for _ in range(n):
+                        if rpos > stop:
+                            break
+                        kept += 1
+                        pos_end += 1
+                        rpos += 1
+                else:
+                    rpos += n
+            if kept:
+                out_cigar.append((op, kept))
+        if out_seq:
+            out.append(dict(name=rec.get("name", "r"), pos=pos_start, pos_end=pos_end, seq="".join(out_seq), qual=out_qual,
+                            cigar=out_cigar, mapq=rec.get("mapq", 60), reverse=bool(flag & 0x10), flag=flag,
+                            hp=rec.get("hp", 0)))
+    return out

@@ -1,0 +1,110 @@
+"""BAM reader (pepper_amd/csrc/bamio.cpp behind include/pepper_amd_io.h).  htslib and
+therefore the reference's own reader are absent: PARITY UNPINNED.  The checker is a Python restatement of
+bam_handler.cpp:115-451 (tests/bam_utils.py) on BAM files this test writes."""
+import struct
+
+import numpy as np
+import pytest
+
+import bam_utils as bu
+import pileup_utils as pu
+from pepper_amd.variant.bam import BAM_handler, BamError
+
+
+def compare(readset, want):
+    assert len(readset) == len(want)
+    for got, w in zip(readset, want):
+        assert got.query_name == w["name"]
+        assert (got.pos, got.pos_end) == (w["pos"], w["pos_end"])
+        assert got.sequence == w["seq"] and got.base_qualities == w["qual"]
+        assert [(c.cigar_op, c.cigar_len) for c in got.cigar_tuples] == w["cigar"]
+        assert got.mapping_quality == w["mapq"] and got.flags.is_reverse == w["reverse"] and got.hp_tag == w["hp"]
+
+
+def hp_aux(value, kind="C"):
+    fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}[kind]
+    return b"HP" + kind.encode() + struct.pack(fmt, value)
+
+
+@pytest.mark.parametrize("with_index", [True, False])
+def test_random_pileup_regions(tmp_path, with_index):
+    rng = np.random.default_rng(17)
+    ref = pu.random_reference(rng, 60000)
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=900, read_len=(300, 6000), clip_rate=0.4, mapq_zero_rate=0.1)
+    other = pu.simulate_reads(rng, ref[:9000], 0, n_reads=60, read_len=(200, 900))
+    # (the simulator emits read bases for N / P operations to exercise an encoder quirk; BAM records never do)
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    other = [r for r in other if not any(op in (3, 6) for op, _ in r["cigar"])]
+    for i, r in enumerate(reads):
+        r["name"] = "read%d" % i
+        r["flag"] = (16 if r["reverse"] else 0) | int(rng.choice([0, 0, 0, 0, 0x800, 0x100, 0x400, 0x200, 0x4], p=[.8, .04, .04, .02, .04, .02, .02, .01, .01]))
+        if rng.random() < 0.3:
+            r["hp"] = int(rng.integers(1, 3))
+            r["aux"] = b"NMC\x05" + hp_aux(r["hp"], str(rng.choice(list("cCsSiI")))) + b"RGZgroup1\0" + b"XBBs\x02\0\0\0\x01\0\x02\0"
+    for i, r in enumerate(other):
+        r["name"] = "o%d" % i
+    path = str(tmp_path / "x.bam")
+    bu.write_bam(path, [("chrA", 9000), ("chrB", 60000), ("chrC", 100)], {0: other, 1: reads},
+                 header_text="@HD\tVN:1.6\tSO:coordinate\n@RG\tID:g1\tSM:HG003\tPL:ONT\n@RG\tID:g2\tSM:other\n",
+                 with_index=with_index, flush_every=37)
+    bam = BAM_handler(path)
+    assert bam.has_index() == with_index
+    assert bam.get_chromosome_sequence_names() == ["chrA", "chrB", "chrC"]
+    assert [s.sequence_length for s in bam.get_chromosome_sequence_names_with_length()] == [9000, 60000, 100]
+    assert bam.get_sample_names() == {"HG003", "other"}
+    regions = [(0, 60000), (0, 1), (59990, 60000), (16380, 16390), (20000, 20100), (32768, 49152), (100, 2100)]
+    regions += [tuple(sorted(rng.integers(0, 60000, size=2).tolist())) for _ in range(12)]
+    for start, stop in regions:
+        if stop == start:
+            stop += 1
+        for include_supp, min_mapq in ((False, 1), (True, 0), (False, 30)):
+            got = bam.get_reads("chrB", start, stop, include_supp, min_mapq, 1)
+            compare(got, bu.restated_get_reads(reads, start, stop, include_supp, min_mapq))
+    compare(bam.get_reads("chrA", 100, 5000, True, 0, 0), bu.restated_get_reads(other, 100, 5000, True, 0))
+    assert len(bam.get_reads("chrC", 0, 100, True, 0, 0)) == 0
+    with pytest.raises(BamError):
+        bam.get_reads("chrZ", 0, 10, True, 0, 0)
+    bam.close()
+
+
+def test_hand_made_clipping_cases(tmp_path):
+    """Each cigar pattern the clipping loop treats specially, against expectations worked out by hand."""
+    M, I, D, N, S, H, P, EQ, X = range(9)
+    q = lambda n: list(range(10, 10 + n))
+    recs = [
+        # 0: starts left of the window: first M is cut at start; insertion right at the cut is kept (anchored)
+        dict(name="a", pos=90, cigar=[(M, 15), (I, 2), (M, 10)], seq="A" * 15 + "GG" + "C" * 10, qual=q(27)),
+        # 1: begins with soft clip + insertion before any aligned base inside the window: both dropped
+        dict(name="b", pos=100, cigar=[(S, 3), (I, 2), (M, 5)], seq="TTTGGACGTA", qual=q(10)),
+        # 2: deletion running past stop is cut; trailing M past stop dropped
+        dict(name="c", pos=115, cigar=[(EQ, 3), (D, 10), (X, 4)], seq="ACGTTTT", qual=q(7)),
+        # 3: N skips, hard clip ignored, lower-case never happens in BAM (4-bit codes) but N base kept
+        dict(name="d", pos=105, cigar=[(H, 5), (M, 2), (N, 4), (M, 2), (S, 2)], seq="ANGTCC", qual=q(6)),
+        # 4: entirely right of stop by position: not returned; 5: left of start entirely: not returned
+        dict(name="e", pos=121, cigar=[(M, 5)], seq="AAAAA", qual=q(5)),
+    ]
+    left = dict(name="l", pos=50, cigar=[(M, 40)], seq="A" * 40, qual=q(40))
+    path = str(tmp_path / "h.bam")
+    bu.write_bam(path, [("c", 1000)], {0: [left] + recs})
+    bam = BAM_handler(path)
+    got = bam.get_reads("c", 100, 120, False, 0, 0)
+    want = [
+        dict(name="a", pos=100, pos_end=115, seq="A" * 5 + "GG" + "C" * 10, qual=q(27)[10:], cigar=[(M, 5), (I, 2), (M, 10)]),
+        dict(name="b", pos=100, pos_end=105, seq="ACGTA", qual=q(10)[5:], cigar=[(M, 5)]),
+        dict(name="c", pos=115, pos_end=121, seq="ACG", qual=q(7)[:3], cigar=[(EQ, 3), (D, 3)]),
+        dict(name="d", pos=105, pos_end=113, seq="ANGTCC", qual=q(6), cigar=[(M, 2), (N, 4), (M, 2), (S, 2)]),
+    ]
+    for w in want:
+        w.update(mapq=60, reverse=False, hp=0)
+    compare(got, want)
+    # stop is inclusive for bases (pos <= stop) but the iterator is half-open (pos < stop): a read starting AT stop
+    # is not fetched, a read covering stop contributes the base at stop
+    assert [r.query_name for r in bam.get_reads("c", 89, 90, False, 0, 0)] == ["l", "a"][:1]
+    one = bam.get_reads("c", 89, 90, False, 0, 0)[0]
+    assert (one.pos, one.pos_end, one.sequence) == (89, 90, "A")
+    # the structure-of-arrays form feeds the encoder directly; take() reorders consistently
+    flat = got.as_pileup()
+    assert flat["n_reads"] == 4 and flat["seq_offset"].tolist() == [0, 17, 22, 25, 31]
+    sub = got.take([3, 0])
+    assert [r.query_name for r in sub] == ["d", "a"] and sub[1].sequence == want[0]["seq"]
+    assert sub.as_pileup()["cigar_offset"].tolist() == [0, 4, 7]

@@ -253,10 +253,15 @@ def test_call_variant_vcf_identity(tmp_path):
                                np.asarray(freqs).astype(np.uint8), probs)
     oracle_totals = process_candidates(options, str(tmp_path / "opred"), str(tmp_path / "ovcf"))
     assert oracle_totals == totals
+    _assert_same_vcfs(options.output_dir, str(tmp_path / "ovcf"))
+
+
+def _assert_same_vcfs(got_dir, want_dir):
+    from pepper_amd.variant import bgzf
     for name in ("PEPPER_VARIANT_FULL", "PEPPER_VARIANT_OUTPUT_PEPPER", "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING",
                  "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_SNPs", "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_INDEL"):
-        got = bgzf.read_bgzf(os.path.join(options.output_dir, name + ".vcf.gz")).decode().splitlines()
-        want = bgzf.read_bgzf(os.path.join(str(tmp_path / "ovcf"), name + ".vcf.gz")).decode().splitlines()
+        got = bgzf.read_bgzf(os.path.join(got_dir, name + ".vcf.gz")).decode().splitlines()
+        want = bgzf.read_bgzf(os.path.join(want_dir, name + ".vcf.gz")).decode().splitlines()
         assert len(got) == len(want)
         for g, w in zip(got, want):
             if g == w:
@@ -268,3 +273,65 @@ def test_call_variant_vcf_identity(tmp_path):
             assert gs[0] == ws[0] and gs[3:] == ws[3:], (g, w)
             assert abs(float(gf[5]) - float(wf[5])) <= 1, (g, w)
             assert np.allclose([float(v) for v in gs[1].split(",")], [float(v) for v in ws[1].split(",")], atol=2e-5), (g, w)
+
+
+def test_call_variant_from_bam_and_fasta_files(tmp_path):
+    """The whole variant path from files on disk with the package's own readers (no injected handlers):
+    BAM (+ .bai) + FASTA -> clipped reads -> GPU encoder -> GPU inference -> candidate finder -> VCF, against
+    the oracle leg fed with the Python restatement of the reference's read clipping."""
+    import bam_utils as bu
+    import pileup_utils as pu
+    from pepper_amd.variant.CallVariant import call_variant
+    from pepper_amd.variant.DataStorePredict import DataStore as PredStore
+    from pepper_amd.variant.FindCandidates import process_candidates
+    rng = np.random.default_rng(303)
+    ref = pu.random_reference(rng, 4200)
+    sites = {int(p): ("ACGT"[(("ACGT".index(ref[p]) + 2) % 4)], 0.5) for p in rng.choice(np.arange(200, 4000), 24, replace=False)}
+    indels = {700: ("I", "CA", 0.6), 1500: ("D", 2, 0.7), 3100: ("D", 9, 0.5)}
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=380, read_len=(400, 1500), snp_sites=sites, indel_sites=indels)
+    # the simulator follows the encoder's N/P quirk (bases for skipped positions), which no BAM record has
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    for i, r in enumerate(reads):
+        r["name"] = "q%d" % i
+    bam_path, fa_path = str(tmp_path / "in.bam"), str(tmp_path / "ref.fa")
+    bu.write_bam(bam_path, [("chr20", len(ref))], {0: reads}, flush_every=50)
+    with open(fa_path, "w") as fh:
+        fh.write(">chr20\n" + "\n".join(ref[i:i + 60] for i in range(0, len(ref), 60)) + "\n")
+    sd = synthetic.variant_state_dict(seed=92, gain=2.5)
+    model_path = str(tmp_path / "model.pkl")
+    torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
+    options = SimpleNamespace(
+        bam=bam_path, fasta=fa_path, region="chr20:0-4199", region_size=2100, threads=1, train_mode=False,
+        use_hp_info=False, include_supplementary=False, output_dir=str(tmp_path / "out"),
+        min_mapq=1, min_snp_baseq=1, min_indel_baseq=1, snp_frequency=0.10, insert_frequency=0.15,
+        delete_frequency=0.15, min_coverage_threshold=3, snp_candidate_frequency_threshold=0.10,
+        indel_candidate_frequency_threshold=0.12, candidate_support_threshold=2, skip_indels=False,
+        downsample_rate=1.0,
+        model_path=model_path, batch_size=256, num_workers=0, gpu=True, device_ids="0", callers_per_gpu=1,
+        quantized=False, dry=False, sample_name="SYN", allowed_multiallelics=4,
+        snp_p_value=0.1, insert_p_value=0.25, delete_p_value=0.25, snp_p_value_in_lc=0.1,
+        insert_p_value_in_lc=0.3, delete_p_value_in_lc=0.3, snp_q_cutoff=20, indel_q_cutoff=15,
+        snp_q_cutoff_in_lc=20, indel_q_cutoff_in_lc=10, report_snp_above_freq=0, report_indel_above_freq=0)
+    image_dir, pred_dir, totals = call_variant(options)
+    assert totals[0] > 8
+
+    oracle = pu.load_restatement()
+    contigs, positions, depths, cands, freqs, images = [], [], [], [], [], []
+    for (start, end) in ((0, 2100), (2100, 4199)):
+        rs, re_ = max(0, start - 100), end + 100
+        clipped = bu.restated_get_reads(reads, rs, re_, False, 1)
+        res = pu.run_variant(oracle, pu.FlatPileup(rs, re_, ref[rs:re_ + 1], clipped), pu.make_params(start, end))
+        n = len(res["candidates"])
+        contigs += ["chr20"] * n
+        positions += res["positions"].tolist()
+        depths += res["depths"].tolist()
+        cands += [[c] for c in res["candidates"]]
+        freqs += [[f] for f in res["candidate_frequency"].tolist()]
+        images.append(res["images"].astype(np.int64).astype(np.int8))
+    probs = models_np.variant_forward(sd, np.concatenate(images))
+    os.makedirs(str(tmp_path / "opred"))
+    with PredStore(str(tmp_path / "opred" / "pepper_prediction.hdf"), "w") as store:
+        store.write_prediction(0, contigs, positions, np.asarray(depths).astype(np.uint8), np.array(cands, dtype=object),
+                               np.asarray(freqs).astype(np.uint8), probs)
+    assert process_candidates(options, str(tmp_path / "opred"), str(tmp_path / "ovcf")) == totals
+    _assert_same_vcfs(options.output_dir, str(tmp_path / "ovcf"))
