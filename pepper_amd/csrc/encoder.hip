@@ -367,11 +367,14 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
         segs.reserve((size_t)n_ops + 1024);
         events.reserve((size_t)n_ops * 2 + 1024);
     }
-    std::map<int32_t, std::map<std::string, Tally>> indels;   // site -> ordered allele keys ("2..." < "3...")
-    auto vote = [&](int32_t idx, const std::string& key, bool rev) {
-        Tally& t = indels[idx][key];
-        t.total += 1;
-        (rev ? t.rev : t.fwd) += 1;
+    // Indel allele votes are only recorded here (site, type, where the allele's bytes live); the ordered
+    // per-site maps of allele strings the reference keeps for EVERY position (region_summary.cpp:431-555)
+    // are built later and only for the few sites that pass the thresholds -- one string allocation and two
+    // map look-ups per indel event were most of the host time of a region.
+    struct IndelVote { int32_t idx; char type; bool rev; int32_t len; const char* src; };
+    std::vector<IndelVote> votes;
+    auto vote = [&](int32_t idx, char type, const char* src, int64_t len, bool rev) {
+        votes.push_back({idx, type, rev, (int32_t)len, src});
     };
     const int64_t total_bases = p->n_reads > 0 ? p->seq_offset[p->n_reads] : 0;
     for (int32_t r = 0; r < p->n_reads; ++r) {
@@ -423,7 +426,7 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
                         const int col = symbol_column(refc(idx), 'I', rev);
                         if (col >= 0) events.push_back({idx, col, -1, 0});
                         events.push_back({idx, C_INS, 1, 0});
-                        vote(idx, "2" + std::string(seq + (ri - 1), (size_t)avail), rev);
+                        vote(idx, '2', seq + (ri - 1), avail, rev);
                     }
                 }
                 ri += len;
@@ -436,7 +439,7 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
                     const int64_t avail = std::max<int64_t>(0, std::min<int64_t>(len + 1, p->reference_len - idx));
                     if (avail + 1 <= 61) {
                         events.push_back({idx, C_DEL, 1, 0});
-                        vote(idx, "3" + std::string(p->reference + idx, (size_t)avail), rev);
+                        vote(idx, '3', p->reference + idx, avail, rev);
                     }
                 }
                 const int64_t lo = std::max(pos, start), hi = std::min(pos + len - 1, end);
@@ -517,6 +520,16 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
         (o.z ? t.rev : t.fwd) += 1;
     }
 
+    // votes bucketed by site (counting sort, stable: order of arrival does not matter for the tallies)
+    std::vector<int32_t> vote_begin((size_t)L + 2, 0);
+    for (const IndelVote& v : votes) vote_begin[(size_t)v.idx + 1] += 1;
+    for (int i = 0; i <= L; ++i) vote_begin[(size_t)i + 1] += vote_begin[i];
+    std::vector<int32_t> vote_order(votes.size());
+    {
+        std::vector<int32_t> cursor(vote_begin.begin(), vote_begin.end() - 1);
+        for (size_t k = 0; k < votes.size(); ++k) vote_order[(size_t)cursor[votes[k].idx]++] = (int32_t)k;
+    }
+
     // ---- host: candidates in the reference's order (std::set<string> per site) -------------------
     std::vector<CandDesc> cands;
     for (const SiteRec& s : sites) {
@@ -562,9 +575,17 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
             d.last = -1; d.star_f = d.star_r = -1;
             emit(std::string("1") + kv.first, kv.second, d);
         }
-        const auto iit = indels.find(s.idx);
-        if (iit == indels.end()) continue;
-        for (const auto& kv : iit->second) {
+        if (vote_begin[(size_t)s.idx] == vote_begin[(size_t)s.idx + 1]) continue;
+        std::map<std::string, Tally> site_indels;          // ordered allele keys ("2..." < "3...")
+        for (int32_t k = vote_begin[(size_t)s.idx]; k < vote_begin[(size_t)s.idx + 1]; ++k) {
+            const IndelVote& v = votes[(size_t)vote_order[(size_t)k]];
+            std::string key(1, v.type);
+            key.append(v.src, (size_t)v.len);
+            Tally& t = site_indels[key];
+            t.total += 1;
+            (v.rev ? t.rev : t.fwd) += 1;
+        }
+        for (const auto& kv : site_indels) {
             const char type = kv.first[0];
             if (!accept(type, kv.second)) continue;
             CandDesc d{};
