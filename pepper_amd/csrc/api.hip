@@ -435,6 +435,8 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     auto* m = new pa_variant_model();
     m->cfg = *cfg;
     if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 16384;
+    // the h2 GEMM addresses its A operand through a 32-bit buffer descriptor: [n*T, 2H] h2 rows must stay < 4 GiB
+    m->cfg.max_chunk = std::min<int32_t>(m->cfg.max_chunk, (int32_t)((int64_t)0xf0000000 / ((int64_t)cfg->window * 2 * 256 * 4)));
     if (const char* e = getenv("PA_FUSE_INPUT")) m->fuse_input = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_GEMM")) m->split_gemm = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_REC")) m->split_rec = e[0] != '0';
@@ -766,6 +768,7 @@ int pa_polish_create(const pa_polish_config* cfg, const char* const* names, cons
     auto* m = new pa_polish_model();
     m->cfg = *cfg;
     if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 8192;
+    m->cfg.max_chunk = std::min<int32_t>(m->cfg.max_chunk, (int32_t)((int64_t)0xf0000000 / ((int64_t)cfg->window * 2 * cfg->hidden_size * 4)));
     if (const char* e = getenv("PA_FUSE_INPUT")) m->fuse_input = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_GEMM")) m->split_gemm = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_REC")) m->split_rec = e[0] != '0';

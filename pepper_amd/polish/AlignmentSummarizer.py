@@ -51,7 +51,12 @@ class AlignmentSummarizer:
             chunk_end = min(total, chunk_start + chunk_size)
         return images, labels, positions, chunk_ids
 
-    def create_summary(self, truth_bam_h1=None, truth_bam_h2=None, train_mode=False, realignment_flag=False):
+    def create_summary(self, truth_bam_handler=None, train_mode=False, downsample_rate=1.0, realignment_flag=False):
+        """Argument order of the reference (AlignmentSummarizer.py:179).  NOTE: the reference defaults
+        realignment_flag to True -- its image generation re-aligns every read to the draft with striped
+        Smith-Waterman (reads_to_reference_realignment, simple_aligner.cpp + ssw.c) before encoding.  That stage
+        is not provided: pass realignment_flag=False and reads are encoded as
+        aligned in the BAM."""
         if train_mode:
             raise NotImplementedError("train_mode image generation is outside the inference path")
         if realignment_flag:
@@ -62,17 +67,20 @@ class AlignmentSummarizer:
         total_reads = len(all_reads)
         if total_reads == 0:
             return [], [], [], []
+        flat = hasattr(all_reads, "as_pileup")          # pepper_amd.variant.bam.ReadSet (the same get_reads serves both)
         if total_reads > AlingerOptions.MAX_READS_IN_REGION:
             random = np.random.RandomState(AlingerOptions.RANDOM_SEED)
             sample = []
-            for i, read in enumerate(all_reads):
+            for i in range(total_reads):
                 if len(sample) < AlingerOptions.MAX_READS_IN_REGION:
-                    sample.append(read)
+                    sample.append(i)
                 else:
                     j = random.randint(0, i + 1)
                     if j < AlingerOptions.MAX_READS_IN_REGION:
-                        sample[j] = read
-            all_reads = sample
+                        sample[j] = i
+            all_reads = all_reads.take(sample) if flat else [all_reads[i] for i in sample]
+        if flat:
+            all_reads = all_reads.as_pileup()
         ref_seq = self.fasta_handler.get_reference_sequence(self.chromosome_name, self.region_start_position,
                                                             self.region_end_position + 1)
         summary_generator = PEPPER.SummaryGenerator(ref_seq, self.chromosome_name, self.region_start_position,

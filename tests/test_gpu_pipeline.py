@@ -335,3 +335,36 @@ def test_call_variant_from_bam_and_fasta_files(tmp_path):
                                np.asarray(freqs).astype(np.uint8), probs)
     assert process_candidates(options, str(tmp_path / "opred"), str(tmp_path / "ovcf")) == totals
     _assert_same_vcfs(options.output_dir, str(tmp_path / "ovcf"))
+
+
+def test_polish_create_summary_from_bam(tmp_path):
+    """Polish image generation for one region straight from a BAM + FASTA on disk (the same native reader; the
+    reference's get_reads is identical for both tools) against the oracle encoder on restated clipped reads.
+    realignment_flag=False: the reference's default SSW re-alignment stage is not part of this package."""
+    import bam_utils as bu
+    import pileup_utils as pu
+    from pepper_amd.polish.AlignmentSummarizer import AlignmentSummarizer
+    from pepper_amd.variant.bam import BAM_handler
+    from pepper_amd.variant.fasta import FASTA_handler
+    rng = np.random.default_rng(77)
+    ref = pu.random_reference(rng, 3000)
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=260, read_len=(300, 1200), ins_rate=0.02, del_rate=0.02)
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    for i, r in enumerate(reads):
+        r["name"] = "p%d" % i
+    bam_path, fa_path = str(tmp_path / "p.bam"), str(tmp_path / "draft.fa")
+    bu.write_bam(bam_path, [("contig_1", len(ref))], {0: reads})
+    with open(fa_path, "w") as fh:
+        fh.write(">contig_1\n" + ref + "\n")
+    start, end = 900, 2100
+    summ = AlignmentSummarizer(BAM_handler(bam_path), FASTA_handler(fa_path), "contig_1", start, end)
+    images, labels, positions, chunk_ids = summ.create_summary(None, False, 1.0, realignment_flag=False)
+    assert len(images) >= 2 and chunk_ids == list(range(len(images)))
+
+    oracle = pu.load_restatement()
+    clipped = bu.restated_get_reads(reads, start, end, False, 0)
+    img, pos = pu.run_polish_oracle(oracle, pu.FlatPileup(start, end, ref[start:end + 1], clipped), start, end)
+    want = AlignmentSummarizer.chunk_images(SimpleNamespace(image=img, genomic_pos=pos), 1000, 50)
+    assert len(want[0]) == len(images)
+    for got_i, want_i, got_p, want_p in zip(images, want[0], positions, want[2]):
+        assert np.array_equal(got_i, want_i) and np.array_equal(got_p, want_p)
