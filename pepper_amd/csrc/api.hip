@@ -237,6 +237,7 @@ struct RecLayer {
     DevBuf *b_in_s = nullptr;   // [2*G*H] gate-scaled bias
     DevBuf *w_hh_h2 = nullptr;  // LSTM H=256: W_hh as h2 fragments (rnn_h2.hip)
     DevBuf *w_cat_h2 = nullptr; // LSTM first layer: [W_hh | W_ih] as h2 fragments
+    DevBuf *w_cat_dec_h2 = nullptr; // GRU layer fed by an h2 layer output (K = 2H): [W_hh | W_ih] fragments
     DevBuf *b_in = nullptr;    // [2*G*H]       LSTM: b_ih + b_hh; GRU: b_ih + (b_hr, b_hz, 0)
     DevBuf *w_hh = nullptr;    // packed
     DevBuf *b_hn = nullptr;    // GRU only: [2*H]
@@ -333,6 +334,8 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
         if (int rc = pack_upload(out.w_hh_h2, none, 0)) return rc;
         if (K <= KXh2)
             if (int rc = pack_upload(out.w_cat_h2, wih_x, KXh2)) return rc;
+        if (G == 3 && K == 2 * H)
+            if (int rc = pack_upload(out.w_cat_dec_h2, wih_x, K)) return rc;
     }
     if ((G == 4 && H == 256 && K <= 32) || (G == 3 && H == 128 && K <= 16)) {
         std::vector<float> cat;
@@ -661,6 +664,7 @@ struct pa_polish_model : ModelBase {
     bool fuse_input = true;      // PA_FUSE_INPUT=0 falls back to GEMM + Xp
     bool split_gemm = true;      // PA_SPLIT_GEMM=0 keeps the projections on the f32 matrix instructions
     bool split_rec = true;       // PA_SPLIT_REC=0 keeps the recurrences on the f32 matrix instructions
+    bool fuse_dec = true;        // PA_FUSE_DEC=0: decoder projection as a GEMM + Xp instead of inside the step loop
     bool y_h2 = false;           // format of the last polish_window output
     std::vector<RecLayer> enc, dec;
     Linear dense;
@@ -705,6 +709,12 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
                                                         r.w_cat->f(), r.b_hn->f(), h0l, ldh, hnl, ldh, y, 2 * H, (int)n, T,
                                                         m->stream));
                 cur_h2 = rec_h2 && r.w_cat_h2 != nullptr;
+            } else if (rec_h2 && cur_h2 && r.w_cat_dec_h2 != nullptr && cur_rpb == 0 && cur_bs == 0 && m->fuse_dec) {
+                // h2 layer output -> this layer: projection contracted inside the step loop (no GEMM, no Xp)
+                LAUNCH_TRY(m, "gru_dec_h2_fused", 2.0 * n * T * (3.0 * H) * (H + r.K) * 2,
+                           pa::launch_gru_dec_h2(H, cur, cur_ld, r.b_in->f(), r.w_cat_dec_h2->p, r.b_hn->f(), h0l, ldh, hnl,
+                                                 ldh, y, 2 * H, (int)n, T, m->stream));
+                cur_h2 = true;
             } else {
                 if (!(stage == 0 && l == 0) && m->split_gemm && r.w_ih_h2 != nullptr) {
                     // the previous layer's y (workspace, read only here): split in place if needed, f16-pipe GEMM
@@ -773,6 +783,7 @@ int pa_polish_create(const pa_polish_config* cfg, const char* const* names, cons
     if (const char* e = getenv("PA_SPLIT_GEMM")) m->split_gemm = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_REC")) m->split_rec = e[0] != '0';
     m->split_rec = m->split_rec && m->split_gemm && cfg->hidden_size == 128;
+    if (const char* e = getenv("PA_FUSE_DEC")) m->fuse_dec = e[0] != '0';
     int rc = init_base(m, cfg->device, hip_stream);
     StateDict sd(names, data, numel, n_tensors);
     const int H = cfg->hidden_size;

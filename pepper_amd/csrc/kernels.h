@@ -66,6 +66,12 @@ hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, 
                              const float* bias, const void* Wp, const float* bhn, const float* h0, int ldh0, float* hn,
                              int ldhn, void* Y, int ldy, int B, int T, hipStream_t stream);
 
+// GRU layer whose input is an h2 layer output [B*T, 2H]: projection fused into the step loop (weights packed
+// with pack_rec_weights_h2(..., F = 2H, KX = 2H); bias = b_ih + (b_hr, b_hz, 0)).
+hipError_t launch_gru_dec_h2(int H, const void* Xh, int ldxh, const float* bias, const void* Wp, const float* bhn,
+                             const float* h0, int ldh0, float* hn, int ldhn, void* Y, int ldy, int B, int T,
+                             hipStream_t stream);
+
 // mlp_h2.hip: linear_2..5 (512 -> 512, SELU) + output layer + softmax fused, 64 rows per workgroup.
 void pack_mlp_weights_h2(const float* const* W, int NL, uint32_t* out);
 size_t mlp_weights_h2_words(int NL);

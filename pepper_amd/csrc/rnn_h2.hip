@@ -558,6 +558,222 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// GRU decoder layer with its input projection fused (polish model): the layer input x_t is the previous
+// layer's output, already an h2 tensor [B*T, KX] with KX = 2H, so the step contracts [h_{t-1} | x_t]
+// (K = H + KX = 384) against [W_hh | W_ih] and neither the projection GEMM nor its 2.5 GB-per-window Xp
+// round trip exist.  What makes it fit: 64 batch rows per workgroup (LDS rows of 1552 B = 97 KB), four
+// waves = one per SIMD with both row tiles each (so every weight fragment is fetched once per workgroup:
+// 590 KB per step, ~43 B/clk/CU), a 3-deep fragment ring instead of a second wave to cover L2 latency,
+// and the next step's x slab (64 KB) prefetched into registers during the MFMA phase.
+//   /root/reference/pepper/modules/python/models/simple_model.py:32
+template <int H, int KX>
+__global__ __launch_bounds__(256, 1) void gru_dec_h2_kernel(const uint32_t* __restrict__ Xh, int ldxh,
+                                                            const float* __restrict__ bias,
+                                                            const uint32_t* __restrict__ Wp,
+                                                            const float* __restrict__ bhn,
+                                                            const float* __restrict__ h0, int ldh0,
+                                                            float* __restrict__ hn, int ldhn,
+                                                            uint32_t* __restrict__ Y, int ldy, int B, int T) {
+    constexpr int KT = H + KX, KS = KT / 16, KSH = H / 16, NT = H / 32, MTG = MT, NTHR = NT * 64;
+    constexpr int ROWB = KT * 4 + 16, ROWD = ROWB / 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [MTG][ROWD] h2 rows of [h | x]
+    static_assert((ROWB / 16) % 2 == 1, "row stride must be an odd number of 16-byte slots");
+    static_assert(NT == 4, "one wave per SIMD");
+
+    int dir, btile;
+    decode_block(blockIdx.x, dir, btile);
+    const int b0 = btile * MTG;
+    if (b0 >= B) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hf = lane >> 5;
+    const int col = u * 32 + li;
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(Wp + ((size_t)dir * (3 * NT) + u) * KS * 512), 0, 0x7fffffff, 0x00020000);
+    const unsigned woff = lane * 16u;
+    const size_t lb = (size_t)(b0 + 4 * hf);
+    const bool odd = li & 1;
+    uint32_t* hl_dst = lds + 4 * hf * ROWD + (col >> 3) * 8 + (odd ? 4 : 0) + ((col & 7) >> 1);
+    const uint32_t* arow = lds + li * ROWD + hf * 8;
+
+    for (int idx = tid; idx < MTG * ROWD; idx += NTHR) lds[idx] = 0u;
+    __syncthreads();
+
+    auto h2_word = [&](float hv) {
+        const _Float16 hi = (_Float16)hv;
+        const _Float16 lo = (_Float16)(hv - (float)hi);
+        const unsigned uhi = __builtin_bit_cast(unsigned short, hi), ulo = __builtin_bit_cast(unsigned short, lo);
+        const unsigned got = swap_pair(odd ? uhi : ulo);
+        return odd ? (got | (ulo << 16)) : (uhi | (got << 16));
+    };
+
+    f32x16 hreg[2], acc[2][4];     // r, z, n(hidden half), n(input half)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
+            const float hv = h0 != nullptr ? h0[(lb + dr) * ldh0 + dir * H + col] : 0.0f;
+            hreg[m][r] = hv;
+            hl_dst[dr * ROWD] = h2_word(hv);
+        }
+    const float bn = bhn[dir * H + col];
+    const float b_r = bias[dir * 3 * H + col], b_z = bias[dir * 3 * H + H + col], b_nx = bias[dir * 3 * H + 2 * H + col];
+    auto seed_chunk = [&](int m, int qd) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[m][0][4 * qd + e] = b_r;
+            acc[m][1][4 * qd + e] = b_z;
+            acc[m][2][4 * qd + e] = bn;
+            acc[m][3][4 * qd + e] = b_nx;
+        }
+    };
+
+    // x slab of one step: MTG rows x KX*4 bytes, 16 bytes per thread per pass
+    constexpr int XCPR = KX / 4;                       // 16-byte chunks per row (64)
+    constexpr int XROWS = NTHR / XCPR;                 // rows per pass (4)
+    constexpr int XN = MTG / XROWS;                    // passes (16)
+    const int xr = tid / XCPR, xc = tid % XCPR;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(Xh + (size_t)b0 * T * ldxh), 0, 0x7fffffff, 0x00020000);
+    const unsigned x_off = ((unsigned)(xr * T) * ldxh + xc * 4) * 4u;
+    uint32_t* x_dst = lds + xr * ROWD + H + xc * 4;
+    u32x4 xq[XN];
+    auto x_load_one = [&](int j, int t) {
+        // rows beyond B read the workspace padding (finite garbage in rows nobody reads back)
+        xq[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, x_off, ((unsigned)(j * XROWS * T + t) * ldxh) * 4u, 0);
+    };
+    auto x_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < XN; ++j) *reinterpret_cast<u32x4*>(x_dst + j * XROWS * ROWD) = xq[j];
+    };
+    {
+        const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) seed_chunk(m, qd);
+#pragma unroll
+        for (int j = 0; j < XN; ++j) x_load_one(j, t0);
+        x_store();
+    }
+    __syncthreads();
+
+    constexpr int CPR = H / 4, YROWS = NTHR / CPR, YC = MTG / YROWS;   // 32 chunks/row, 8 rows/pass, 8 passes
+    const int yc_row = tid / CPR, yc_c = tid % CPR;
+    const uint32_t* yc_src = lds + yc_row * ROWD + yc_c * 4;
+    const __amdgpu_buffer_rsrc_t ycrs =
+        __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)b0 * T * ldy + dir * H, 0, 0x7fffffff, 0x00020000);
+    const unsigned yc_off = ((unsigned)(yc_row * T) * ldy + yc_c * 4) * 4u;
+    auto yc_read = [&](int j) { return *reinterpret_cast<const u32x4*>(yc_src + j * YROWS * ROWD); };
+    auto yc_write = [&](int j, int tp, u32x4 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(v, ycrs, yc_off, ((unsigned)(j * YROWS * T + tp) * ldy) * 4u, 0);
+    };
+
+    struct Frag { h8 b[3][2], a[2][2]; };
+    auto load_step = [&](int s, Frag& fr) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+                fr.b[g][hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         wrs, woff, (unsigned)((g * NT * KS + s) * 2 + hl) * 1024u, 0));
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            fr.a[m][0] = *reinterpret_cast<const h8*>(arow + m * 32 * ROWD + s * 16);
+            fr.a[m][1] = *reinterpret_cast<const h8*>(arow + m * 32 * ROWD + s * 16 + 4);
+        }
+    };
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        const int tp = step > 0 ? (dir ? t + 1 : t - 1) : t;
+        const int tn = (step + 1 < T) ? (dir ? t - 1 : t + 1) : t;     // last step re-reads its own slab (unused)
+        // ---------------- MFMA phase ----------------
+        {
+            Frag ring[3];
+            load_step(0, ring[0]);
+            load_step(1, ring[1]);
+            u32x4 ycv = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int p = s % 3;
+                if (s + 2 < KS) load_step(s + 2, ring[(p + 2) % 3]);
+                if (s < XN) x_load_one(s, tn);
+                if (s >= 1 && s <= YC) yc_write(s - 1, tp, ycv);
+                if (s < YC) ycv = yc_read(s);
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const int ai = (g == 2 && s >= KSH) ? 3 : g;
+                            acc[m][ai] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0], acc[m][ai]);
+                        }
+                if (s + 2 < KS) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // B fragment
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // A fragment
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // x slab prefetch
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);       // y copy store
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // y copy read
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        lds_barrier();
+
+        // ---------------- gate phase ----------------
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * qd + e;
+                    const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
+                    const float rgate = fast_sigmoid(acc[m][0][r]);
+                    const float zgate = fast_sigmoid(acc[m][1][r]);
+                    const float ngate = fast_tanh(acc[m][3][r] + rgate * acc[m][2][r]);
+                    const float hv = (1.0f - zgate) * ngate + zgate * hreg[m][r];
+                    hreg[m][r] = hv;
+                    hl_dst[dr * ROWD] = h2_word(hv);
+                }
+                seed_chunk(m, qd);
+            }
+        x_store();
+        lds_barrier();
+    }
+
+    {
+        const int tl = dir ? 0 : T - 1;
+#pragma unroll
+        for (int j = 0; j < YC; ++j) yc_write(j, tl, yc_read(j));
+    }
+    if (hn != nullptr) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                hn[(lb + 32 * m + (r & 3) + 8 * (r >> 2)) * ldhn + dir * H + col] = hreg[m][r];
+    }
+}
+
 inline int rec_grid(int B) {
     const int nbt = (B + MT - 1) / MT;
     return 2 * ((nbt + 3) / 4) * 4;
@@ -639,6 +855,18 @@ hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, 
                            (const uint8_t*)nullptr, 0, (int64_t)0, (const float*)nullptr, static_cast<const uint32_t*>(Wp),
                            bhn, h0, ldh0, hn, ldhn, static_cast<uint32_t*>(Y), ldy, B, T);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_dec_h2(int H, const void* Xh, int ldxh, const float* bias, const void* Wp, const float* bhn,
+                             const float* h0, int ldh0, float* hn, int ldhn, void* Y, int ldy, int B, int T,
+                             hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    if (H != 128 || (ldy & 7) || (ldxh & 7)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)MT * ((128 + 256) * 4 + 16);
+    hipLaunchKernelGGL((gru_dec_h2_kernel<128, 256>), dim3(rec_grid(B)), dim3(256), lds, stream,
+                       static_cast<const uint32_t*>(Xh), ldxh, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn,
+                       ldhn, static_cast<uint32_t*>(Y), ldy, B, T);
     return hipGetLastError();
 }
 
