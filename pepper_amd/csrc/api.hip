@@ -237,7 +237,7 @@ struct RecLayer {
     DevBuf *b_in_s = nullptr;   // [2*G*H] gate-scaled bias
     DevBuf *w_hh_h2 = nullptr;  // LSTM H=256: W_hh as h2 fragments (rnn_h2.hip)
     DevBuf *w_cat_h2 = nullptr; // LSTM first layer: [W_hh | W_ih] as h2 fragments
-    DevBuf *w_cat_dec_h2 = nullptr; // GRU layer fed by an h2 layer output (K = 2H): [W_hh | W_ih] fragments
+    DevBuf *w_cat_dec_h2 = nullptr; // layer fed by an h2 layer output (K = 2H): [W_hh | W_ih] fragments
     DevBuf *b_in = nullptr;    // [2*G*H]       LSTM: b_ih + b_hh; GRU: b_ih + (b_hr, b_hz, 0)
     DevBuf *w_hh = nullptr;    // packed
     DevBuf *b_hn = nullptr;    // GRU only: [2*H]
@@ -334,7 +334,7 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
         if (int rc = pack_upload(out.w_hh_h2, none, 0)) return rc;
         if (K <= KXh2)
             if (int rc = pack_upload(out.w_cat_h2, wih_x, KXh2)) return rc;
-        if (G == 3 && K == 2 * H)
+        if (K == 2 * H)
             if (int rc = pack_upload(out.w_cat_dec_h2, wih_x, K)) return rc;
     }
     if ((G == 4 && H == 256 && K <= 32) || (G == 3 && H == 128 && K <= 16)) {
@@ -413,6 +413,7 @@ struct pa_variant_model : ModelBase {
     bool fuse_input = true;      // PA_FUSE_INPUT=0 falls back to GEMM + Xp for A/B measurements
     bool split_gemm = true;      // PA_SPLIT_GEMM=0 keeps the big GEMMs on the f32 matrix instructions
     bool split_rec = true;       // PA_SPLIT_REC=0 keeps the recurrences on the f32 matrix instructions
+    bool fuse_dec = true;        // PA_FUSE_DEC=0: decoder projection as a GEMM + Xp instead of inside the step loop
     std::vector<RecLayer> rec;   // encoder layers then decoder layers
     Linear lin[5], out;
     DevBuf *mlp_w = nullptr, *mlp_b = nullptr;   // linear_2..5 as h2 fragments + their biases (mlp_h2.hip)
@@ -444,6 +445,7 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     if (const char* e = getenv("PA_SPLIT_GEMM")) m->split_gemm = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_REC")) m->split_rec = e[0] != '0';
     m->split_rec = m->split_rec && m->split_gemm;   // the h2 layer output needs the h2 consumers
+    if (const char* e = getenv("PA_FUSE_DEC")) m->fuse_dec = e[0] != '0';
     int rc = init_base(m, cfg->device, hip_stream);
     StateDict sd(names, data, numel, n_tensors);
     const int H = m->H;
@@ -502,7 +504,14 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     const int T = m->cfg.window, F = m->cfg.image_features, H = m->H, C = m->cfg.num_classes_type;
     const int64_t np = round_up(n, MT);
     const int NX = 2 * 4 * H;  // both directions' gate pre-activations
-    if (int rc = m->xp->ensure((size_t)np * T * NX * sizeof(float))) return rc;
+    // Xp (gate pre-activations, 4.4 GB at 16384 windows) is only materialised when some layer's projection is
+    // NOT contracted inside its step loop; otherwise the workspace just holds linear_1's split-K partials
+    bool need_xp = !(a_kind == pa::A_I8 && m->fuse_input && !m->rec.empty() && m->rec[0].w_cat != nullptr);
+    for (size_t li = 1; li < m->rec.size(); ++li)
+        need_xp = need_xp || !(m->split_rec && m->fuse_dec && m->rec[li].w_cat_dec_h2 != nullptr);
+    const size_t xp_bytes = std::max(need_xp ? (size_t)np * T * NX * sizeof(float) : (size_t)0,
+                                     (size_t)8 * n * m->L1 * sizeof(float));
+    if (int rc = m->xp->ensure(xp_bytes)) return rc;
     if (int rc = m->ya->ensure((size_t)np * T * 2 * H * sizeof(float))) return rc;
     if (m->rec.size() > 1)
         if (int rc = m->yb->ensure((size_t)np * T * 2 * H * sizeof(float))) return rc;
@@ -532,6 +541,11 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
                 LAUNCH_TRY(m, "lstm_rec_fused_in", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
                            pa::launch_lstm_rec_fused(H, static_cast<const int8_t*>(cur), r.K, r.b_in->f(),
                                                      r.w_cat->f(), y, 2 * H, (int)n, T, m->stream));
+        } else if (li > 0 && rec_h2 && cur_h2 && r.w_cat_dec_h2 != nullptr && m->fuse_dec) {
+            // h2 layer output -> this layer: projection contracted inside the step loop (no GEMM, no Xp)
+            LAUNCH_TRY(m, "lstm_dec_h2_fused", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
+                       pa::launch_lstm_dec_h2(H, cur, cur_ld, bias_l, r.w_cat_dec_h2->p, y, 2 * H, (int)n, T, m->stream,
+                                              r.prescaled));
         } else {
             if (li > 0 && m->split_gemm && r.w_ih_h2 != nullptr) {
                 // the previous layer's y is only read by this projection: if it is still f32, split it

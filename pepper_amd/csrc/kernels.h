@@ -61,6 +61,10 @@ hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, 
                               const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream,
                               bool prescaled = false);
 
+// LSTM layer fed by an h2 layer output Xh [B*T, 2H]: projection contracted inside the step loop (weights packed
+// with pack_rec_weights_h2(..., F = 2H, KX = 2H); bias = b_ih + b_hh).
+hipError_t launch_lstm_dec_h2(int H, const void* Xh, int ldxh, const float* bias, const void* Wp, void* Y, int ldy, int B,
+                              int T, hipStream_t stream, bool prescaled);
 // GRU (H = 128) counterpart; arguments as launch_gru_rec / launch_gru_rec_fused, Y in h2 format.
 hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, int F, int64_t x_bstride,
                              const float* bias, const void* Wp, const float* bhn, const float* h0, int ldh0, float* hn,

@@ -42,15 +42,27 @@ PA_DEV unsigned swap_pair(unsigned v) { return (unsigned)__builtin_amdgcn_update
 
 // PRE: the packed weights, the bias and Xp arrive pre-multiplied per gate row by -log2(e) (i, f, o) or
 // +2 log2(e) (g), so the accumulators ARE the exp2 arguments of sigmoid / tanh (api.hip build_rec_layer).
-template <int H, int KX, bool PRE>
+// XG (decoder layers): the layer input x_t is the previous layer's output, an h2 tensor Xh [B*T, KX]; its
+// projection is contracted inside the step loop (K = H + KX) with the x operand fragments loaded straight
+// from global memory in MFMA layout (32 contiguous bytes per lane per k step) -- the x slab of a step is
+// 128 KB per workgroup and does not fit in LDS next to h and c.  No projection GEMM, no Xp round trip
+// (4.4 GB written + read per 16384 windows).  The slab of step t+1 is pulled into L2 by one dword "touch"
+// per 64-byte line issued at the end of step t's MFMA phase, so the fragment loads hit L2.
+// Measured (16384 windows): 4.8-4.9 ms against 3.3 (GEMM) + 1.65 (step loop) = 4.95 ms unfused; the same kernel
+// with the x loads removed runs 4.08 ms, i.e. the floor of this form is the 3 MB-per-step weight stream
+// (~47 B/clk/CU, 3/4 of the XCD's L2 bandwidth), and the x fragments (each wave fetches all 64 rows: 8x
+// redundant through L1) cost the other 0.7 ms.
+template <int H, int KX, bool PRE, bool XG = false>
 __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
                                                                      const int8_t* __restrict__ Xi, int F,
                                                                      const float* __restrict__ bias,
                                                                      const uint32_t* __restrict__ Wp,
                                                                      uint32_t* __restrict__ Y, int ldy, int B, int T,
-                                                                     unsigned long long* __restrict__ dbg) {
-    constexpr int KT = H + KX, KS = KT / 16, NT = H / 32, NW = H / 32;
-    constexpr int ROWB = KT * 4 + 16;            // bytes per LDS row: h2 image of [h | x] + 16 pad (odd 16-B count)
+                                                                     unsigned long long* __restrict__ dbg,
+                                                                     const uint32_t* __restrict__ Xh = nullptr, int ldxh = 0) {
+    constexpr int KT = H + KX, KS = KT / 16, KSH = H / 16, NT = H / 32, NW = H / 32;
+    constexpr int KL = XG ? H : KT;              // columns kept in the LDS rows
+    constexpr int ROWB = KL * 4 + 16;            // bytes per LDS row: h2 image of [h | x] + 16 pad (odd 16-B count)
     constexpr int ROWD = ROWB / 4;               // in dwords
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [MT][ROWD] h2 rows, then c (f32)
     static_assert(KS % 2 == 0, "the weight prefetch assumes an even number of k steps");
@@ -103,10 +115,11 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 
     // fused only: x_t (int8, exact in f16) -> hi halves of LDS columns [H, H+KX); lo halves stay 0.
     // One thread per pair of features: 64 rows x KX/2 pairs over 512 threads.
-    constexpr int XN = KX ? (MT * KX / 2) / (NW * 64) : 1;
+    constexpr bool XI8 = KX > 0 && !XG;
+    constexpr int XN = XI8 ? (MT * KX / 2) / (NW * 64) : 1;
     unsigned xv[XN];
     auto x_load = [&](int t) {
-        if (KX) {
+        if (XI8) {
 #pragma unroll
             for (int k = 0; k < XN; ++k) {
                 const int e = tid + k * (NW * 64);
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
         }
     };
     auto x_store = [&]() {
-        if (KX) {
+        if (XI8) {
 #pragma unroll
             for (int k = 0; k < XN; ++k) {
                 const int e = tid + k * (NW * 64);
@@ -130,6 +143,26 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                 lds[row * ROWD + ((H + f) >> 3) * 8 + ((f & 7) >> 1)] = xv[k];
             }
         }
+    };
+    // XG: this lane's x fragments of step t, k step s >= KSH: row (32 m + li), bytes [(2 (s - KSH) + hf) * 32, +32)
+    const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(XG ? Xh + (size_t)b0 * T * ldxh : Wp), 0, 0x7fffffff, 0x00020000);
+    const unsigned xg_off = XG ? ((unsigned)(li * T) * ldxh) * 4u + hf * 32u : 0u;
+    // L2 touch of a whole step slab: 64 rows x KX*4 bytes = KX/16 64-byte lines per row; one dword per line
+    constexpr int TOUCH = XG ? (MT * (KX / 16)) / (NW * 64) : 1;
+    unsigned touched = 0;
+    auto touch_slab = [&](int t) {
+        unsigned acc_t = 0;
+        if (XG) {
+#pragma unroll
+            for (int k = 0; k < TOUCH; ++k) {
+                const int line = tid + k * (NW * 64);
+                const int row = line / (KX / 16), c = line % (KX / 16);
+                acc_t ^= __builtin_amdgcn_raw_buffer_load_b32(xgrs, ((unsigned)(row * T) * ldxh) * 4u + c * 64u,
+                                                               ((unsigned)t * ldxh) * 4u, 0);
+            }
+        }
+        return acc_t;
     };
 
     struct Frag { h8 b[4][2], a[2][2]; };     // [gate][hi, lo], [row tile][hi, lo]
@@ -142,7 +175,16 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                 fr.b[g][hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(
                                                          wrs, woff, (unsigned)(((g * NT + u) * KS + s) * 2 + hl) * 1024u, 0));
     };
-    auto load_a = [&](int s, Frag& fr) {
+    auto load_a = [&](int s, Frag& fr, int t) {
+        if (XG && s >= KSH) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const unsigned so = ((unsigned)(m * 32 * T + t) * ldxh) * 4u + (unsigned)(s - KSH) * 64u;
+                fr.a[m][0] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(xgrs, xg_off, so, 0));
+                fr.a[m][1] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(xgrs, xg_off, so + 16u, 0));
+            }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             fr.a[m][0] = *reinterpret_cast<const h8*>(arow + m * 32 * ROWD + s * 16);
@@ -192,13 +234,13 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
         if (stamp) dbg[(u * 80 + 2 * step) * 2] = __builtin_amdgcn_s_memtime();
         // ---------------- MFMA phase ----------------
         {
-            load_a(0, ring[0]);
+            load_a(0, ring[0], t);
             const int tp = step > 0 ? (dir ? t + 1 : t - 1) : t;   // time index of h_{s-1} (step 0: zeros, rewritten later)
             u32x4 ycv = {0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int p = s & 1;
-                if (s + 1 < KS) { load_b(s + 1, ring[p ^ 1]); load_a(s + 1, ring[p ^ 1]); }
+                if (s + 1 < KS) { load_b(s + 1, ring[p ^ 1]); load_a(s + 1, ring[p ^ 1], t); }
                 else load_b(0, ring[p ^ 1]);            // KS is even: ring[p ^ 1] == ring[0]
                 if (s >= 1 && s <= YC) yc_write(s - 1, tp, ycv);
                 if (s < YC) ycv = yc_read(s);
@@ -209,7 +251,13 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
                             acc[m][g] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0], acc[m][g]);
-                if (s + 1 < KS) {
+                if (XG && s + 1 < KS && s + 1 >= KSH) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (8 B + 4 x fragments)
+                    }
+                } else if (s + 1 < KS) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
@@ -241,6 +289,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
             }
         }
         if (stamp) dbg[(u * 80 + 2 * step) * 2 + 1] = __builtin_amdgcn_s_memtime();
+        if (XG && step + 1 < T) touched ^= touch_slab(dir ? t - 1 : t + 1);   // next step's x slab -> L2, under the gate phase
 
         lds_barrier();                    // every wave has finished reading h_{t-1}
         if (stamp) dbg[(u * 80 + 2 * step + 1) * 2] = __builtin_amdgcn_s_memtime();
@@ -300,6 +349,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 #pragma unroll
         for (int j = 0; j < YC; ++j) yc_write(j, tl, yc_read(j));
     }
+    if (XG && touched == 0x9e3779b9u && dbg != nullptr) dbg[0] = touched;   // keeps the touch loads alive
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -809,6 +859,21 @@ void pack_rec_weights_h2(const float* const whh[2], const float* const wih[2], i
 }
 
 size_t rec_weights_h2_words(int G, int H, int KX) { return (size_t)2 * (G * H / 32) * ((H + KX) / 16) * 2 * 256; }
+
+hipError_t launch_lstm_dec_h2(int H, const void* Xh, int ldxh, const float* bias, const void* Wp, void* Y, int ldy, int B,
+                              int T, hipStream_t stream, bool prescaled) {
+    if (B <= 0) return hipSuccess;
+    if (H != 256 || (ldy & 7) || (ldxh & 7) || ldxh < 512) return hipErrorInvalidValue;
+    const size_t lds = (size_t)MT * (256 * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4;
+    const int grid = rec_grid(B);
+#define PA_DEC(PRE_)                                                                                                   \
+    hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 512, PRE_, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, \
+                       (const int8_t*)nullptr, 0, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y), ldy, B, T, \
+                       debug_buffer(), static_cast<const uint32_t*>(Xh), ldxh)
+    if (prescaled) PA_DEC(true); else PA_DEC(false);
+#undef PA_DEC
+    return hipGetLastError();
+}
 
 hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, int F, const float* bias,
                               const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream, bool prescaled) {
