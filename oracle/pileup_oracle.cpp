@@ -11,9 +11,11 @@
 // Pinning: the variant restatement is checked against the reference's own implementation compiled
 // into oracle/_ref/libref_variant_encoder.so (oracle/Makefile) on randomized and hand-built
 // pileups (tests/test_encoder_oracle.py) and against committed golden vectors produced by it
-// (tests/golden/encoder_variant_*.npz).  The polish reference encoder cannot be built here without
-// stand-in htslib headers (summary_generator.h includes ../dataio/bam_handler.h -> sam.h), so the
-// polish restatement is "parity unpinned": it follows the cited lines but no reference output backs it.
+// (tests/golden/encoder_variant_*.npz).  The polish restatement is pinned the same way against
+// oracle/_ref/libref_polish_encoder.so -- the reference's SummaryGenerator compiled as it lies, with the
+// htslib-backed #include of bam_handler.h dropped and that header's plain read types lifted by sed at build
+// time (oracle/Makefile; no stand-in for htslib is written) -- on six pileup families
+// (tests/test_encoder_oracle.py) and by golden vectors it produced (tests/golden/encoder_polish_*.npz).
 //
 // Reference quirks that are reproduced on purpose (each changes output bytes):
 //  - GENERATE_INDELS == false (region_summary.h:50): no insert columns, row index = pos - ref_start.

@@ -130,6 +130,29 @@ def load_reference_encoder():
     return lib
 
 
+def load_reference_polish_encoder():
+    """oracle/_ref/libref_polish_encoder.so (the reference's own SummaryGenerator), or None if not built."""
+    path = os.path.join(ORACLE_DIR, "_ref", "libref_polish_encoder.so")
+    if not os.path.exists(path):
+        if not os.path.exists("/root/reference"):
+            return None
+        _build_oracle()
+    lib = ctypes.CDLL(path)
+    lib.ref_polish_generate_summary.restype = ctypes.c_int64
+    lib.ref_polish_generate_summary.argtypes = [ctypes.POINTER(Pileup), ctypes.c_int64, ctypes.c_int64,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    return lib
+
+
+def run_polish_reference(lib, pileup, start_pos, end_pos):
+    p = pileup.struct()
+    rows = lib.ref_polish_generate_summary(ctypes.byref(p), start_pos, end_pos, None, None, 0)
+    img = np.zeros((rows, 10), np.uint8)
+    pos = np.zeros((rows, 2), np.int64)
+    lib.ref_polish_generate_summary(ctypes.byref(p), start_pos, end_pos, img.ctypes.data, pos.ctypes.data, rows)
+    return img, pos
+
+
 def run_variant(lib, pileup, params, reference_impl=False):
     res = SummaryResult()
     p = pileup.struct()

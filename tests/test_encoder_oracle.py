@@ -1,6 +1,6 @@
-"""The oracle's variant-encoder restatement (oracle/pileup_oracle.cpp) against the REFERENCE's own
-C++ (oracle/_ref, built from /root/reference where present) and against committed golden vectors
-that the reference build produced.  CPU only."""
+"""The oracle's variant- and polish-encoder restatements (oracle/pileup_oracle.cpp) against the REFERENCE's
+own C++ (oracle/_ref, built from /root/reference where present) and against committed golden vectors
+that the reference builds produced.  CPU only."""
 import os
 
 import numpy as np
@@ -113,3 +113,49 @@ def test_empty_and_uncovered_region(libs):
     assert a["candidates"] == [] and a["images"].shape == (0, 33, 26)
     if ref is not None:
         assert pu.run_variant(ref, pile, params, reference_impl=True)["candidates"] == []
+
+
+# ---- polish SummaryGenerator ------------------------------------------------------------------------
+POLISH_CASES = {
+    "plain": dict(seed=21),
+    "eqx_cigars": dict(seed=22, eqx=True),
+    "indel_heavy": dict(seed=23, ins_rate=0.06, del_rate=0.05),
+    "deep": dict(seed=24, depth=300, region=700),
+    "lowercase_and_n": dict(seed=25, lower_frac=0.2, n_frac=0.02),
+    "long_inserts": dict(seed=26, long_indel_rate=0.2, ins_rate=0.03),
+}
+
+
+def _polish_case(seed, depth=45, region=1800, **kw):
+    """Region [start, end] of a draft contig; reads clipped to it as get_reads would deliver them."""
+    import bam_utils as bu
+    rng = np.random.default_rng(seed)
+    ref_offset = 5_000
+    ref = pu.random_reference(rng, region + 1, n_frac=kw.pop("n_frac", 0.0), lower_frac=kw.pop("lower_frac", 0.0))
+    reads = pu.simulate_reads(rng, ref, ref_offset, n_reads=int(depth * region / 500), **kw)
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    start, end = ref_offset, ref_offset + region
+    clipped = bu.restated_get_reads(reads, start, end, False, 0)
+    return pu.FlatPileup(start, end, ref, clipped), start, end
+
+
+@pytest.mark.parametrize("name", sorted(POLISH_CASES))
+def test_polish_restatement_equals_reference_build(name):
+    ref = pu.load_reference_polish_encoder()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    oracle = pu.load_restatement()
+    pile, start, end = _polish_case(**POLISH_CASES[name])
+    img_o, pos_o = pu.run_polish_oracle(oracle, pile, start, end)
+    img_r, pos_r = pu.run_polish_reference(ref, pile, start, end)
+    assert len(img_r) > 500
+    assert np.array_equal(pos_o, pos_r) and np.array_equal(img_o, img_r)
+
+
+def test_polish_restatement_against_committed_golden(golden_dir):
+    oracle = pu.load_restatement()
+    for name in sorted(POLISH_CASES)[:3]:
+        g = np.load(os.path.join(golden_dir, f"encoder_polish_{name}.npz"), allow_pickle=False)
+        pile, start, end = _polish_case(**POLISH_CASES[name])
+        img, pos = pu.run_polish_oracle(oracle, pile, start, end)
+        assert np.array_equal(img, g["image"]) and np.array_equal(pos, g["positions"])

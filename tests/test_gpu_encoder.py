@@ -101,7 +101,8 @@ def test_encoder_object_interface_and_edges():
 
 
 def test_polish_encoder_matches_oracle():
-    """Polish summary encoder (parity-unpinned oracle: the reference build needs htslib headers):
+    """Polish summary encoder against the oracle restatement (itself pinned to the reference build by
+    tests/test_encoder_oracle.py):
     insert columns, deletion-coverage quirk, REF_SKIP/PAD as gaps, 254 scaling truncation."""
     from pepper_amd.polish.PEPPER import SummaryGenerator
     oracle = pu.load_restatement()
