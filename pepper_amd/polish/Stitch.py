@@ -7,6 +7,7 @@ Vectorised with numpy: per piece the (position, index, label) triples of all its
 are concatenated in the reference's iteration order (chunk ids sorted as strings), filtered
 (position/index >= 0; for regions not starting at 0 positions <= start + 2 * MIN_IMAGE_OVERLAP are
 overlap and dropped), then the last write of every key wins and keys come out sorted.
+Pinned: tests/golden/polish_stitch_ref.fa is the reference's own output on the same prediction arrays.
 """
 import concurrent.futures
 

@@ -99,3 +99,26 @@ def test_stitch_empty_and_all_gap(tmp_path):
                            np.ones(1000), np.zeros(1000))
     out = perform_stitch(str(pred), str(tmp_path / "o"), 1)
     assert open(out).read() == ""             # all-gap consensus and padding-only chunks write nothing
+
+
+def test_stitch_matches_reference_golden(golden_dir, tmp_path):
+    """tests/golden/polish_stitch_ref.fa was written by the REFERENCE's perform_stitch (make_golden_stitch.py) from
+    prediction files holding the arrays of polish_stitch_inputs.npz; the same arrays through pepper_amd's
+    DataStore + perform_stitch must give the same FASTA, byte for byte."""
+    g = np.load(os.path.join(golden_dir, "polish_stitch_inputs.npz"), allow_pickle=False)
+    pred = tmp_path / "pred"
+    pred.mkdir()
+    stores = [DataStore(str(pred / ("pepper_prediction_%d.hdf" % i)), "w") for i in range(2)]
+    for ri in range(int(g["n_regions"])):
+        fi, start, end, n_chunks = (int(v) for v in g["r%d_meta" % ri])
+        contig = str(g["r%d_contig" % ri])
+        for cid in range(n_chunks):
+            stores[fi].write_prediction(contig, start, end, cid, g["r%d_c%d_position" % (ri, cid)],
+                                        g["r%d_c%d_index" % (ri, cid)], g["r%d_c%d_bases" % (ri, cid)],
+                                        g["r%d_c%d_phred" % (ri, cid)])
+    for s in stores:
+        s.close()
+    want = open(os.path.join(golden_dir, "polish_stitch_ref.fa")).read()
+    for threads in (1, 2):
+        out = perform_stitch(str(pred), str(tmp_path / ("o%d" % threads) / "asm"), threads)
+        assert open(out).read() == want
