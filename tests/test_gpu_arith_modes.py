@@ -73,3 +73,37 @@ def test_polish_modes(golden_dir, env_guard):
         assert np.abs(hidden.numpy() - g["hiddens"][0]).max() < TOL, mode
         accs.append(acc)
     assert np.abs(accs[0] - accs[2]).max() < 2e-5 and np.abs(accs[1] - accs[2]).max() < 2e-5
+
+
+@pytest.mark.parametrize("gain", [0.25, 1.0, 4.0, 8.0])
+def test_split_arithmetic_margin_across_weight_scales(gain, env_guard):
+    """The split-f16 path must hold the 1e-4 bar with margin for small weights (lo halves deep in the f16
+    sub-normal range) and for large ones (saturated gates, big pre-activations), on extreme int8 inputs too."""
+    from test_gpu_variant import NativeVariant
+    _set({})
+    sd = synthetic.variant_state_dict(seed=40 + int(gain * 4), gain=gain)
+    x = synthetic.variant_windows(96, seed=123)
+    x[0] = 127
+    x[1] = -128
+    x[2] = 0
+    ref, inter = models_np.variant_forward(sd, x, return_intermediates=True)
+    m = NativeVariant(sd)
+    probs, logits = m.forward(x)
+    m.close()
+    err = np.abs(probs - ref).max()
+    lerr = np.abs(logits - inter["logits"]).max() / max(1.0, np.abs(inter["logits"]).max())
+    assert err < 0.5 * TOL and lerr < 0.5 * TOL, (gain, err, lerr)
+
+    if gain > 4.0:
+        # the polish recurrence (1900 dependent steps with the hidden carry) is chaotic at this weight scale: the
+        # f32 kernels and the numpy oracle themselves disagree by O(1) there, so no arithmetic can be judged on it
+        return
+    psd = synthetic.polish_state_dict(seed=50 + int(gain * 4), gain=gain)
+    imgs = synthetic.polish_chunks(3, seed=5)
+    imgs[0, :200] = 255
+    rl, rp, pinter = models_np.polish_predict_chunks(psd, imgs, 128, return_intermediates=True)
+    from test_gpu_polish import _model
+    pm = _model(psd)
+    _, _, acc = pm.predict_chunks(torch.from_numpy(imgs), return_acc=True)
+    pm.close()
+    assert np.abs(acc.numpy() - pinter["acc"]).max() < 0.5 * TOL, gain
