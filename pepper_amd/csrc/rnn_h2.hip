@@ -43,15 +43,14 @@ PA_DEV unsigned swap_pair(unsigned v) { return (unsigned)__builtin_amdgcn_update
 // PRE: the packed weights, the bias and Xp arrive pre-multiplied per gate row by -log2(e) (i, f, o) or
 // +2 log2(e) (g), so the accumulators ARE the exp2 arguments of sigmoid / tanh (api.hip build_rec_layer).
 // XG (decoder layers): the layer input x_t is the previous layer's output, an h2 tensor Xh [B*T, KX]; its
-// projection is contracted inside the step loop (K = H + KX) with the x operand fragments loaded straight
-// from global memory in MFMA layout (32 contiguous bytes per lane per k step) -- the x slab of a step is
-// 128 KB per workgroup and does not fit in LDS next to h and c.  No projection GEMM, no Xp round trip
-// (4.4 GB written + read per 16384 windows).  The slab of step t+1 is pulled into L2 by one dword "touch"
-// per 64-byte line issued at the end of step t's MFMA phase, so the fragment loads hit L2.
-// Measured (16384 windows): 4.8-4.9 ms against 3.3 (GEMM) + 1.65 (step loop) = 4.95 ms unfused; the same kernel
-// with the x loads removed runs 4.08 ms, i.e. the floor of this form is the 3 MB-per-step weight stream
-// (~47 B/clk/CU, 3/4 of the XCD's L2 bandwidth), and the x fragments (each wave fetches all 64 rows: 8x
-// redundant through L1) cost the other 0.7 ms.
+// projection is contracted inside the step loop (K = H + KX).  No projection GEMM, no Xp round trip (4.4 GB
+// written + read per 16384 windows).  The x slab of a step (64 rows x 2 KB = 128 KB) does not fit in LDS next to
+// h and c, so it streams through a two-slot LDS ring, two k steps (64 rows x 128 B) per slot: every thread
+// loads one 16-byte chunk of iteration j+2 into a staging register while iteration j is contracted, writes it
+// to the free slot, and one LDS barrier per iteration publishes it; all waves then read their x fragments from
+// LDS like they read h.  (First form of this kernel: every wave fetched its x fragments straight from global
+// memory -- 8x redundant through L1, +0.7 ms per 16384 windows, and 4 MB of x per step per XCD pushed the
+// weights out of L2.)
 template <int H, int KX, bool PRE, bool XG = false>
 __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
                                                                      const int8_t* __restrict__ Xi, int F,
@@ -79,6 +78,9 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 
     float* cs = reinterpret_cast<float*>(lds + MT * ROWD) + u * (2 * 16 * 64) + lane;     // [wave][m][r][lane]
     for (int idx = tid; idx < MT * ROWD + NW * 2 * 16 * 64; idx += blockDim.x) lds[idx] = 0u;
+    // XG: x ring after the cell state: 2 slots x [MT rows][XRD dwords] (128 B of x + 16 B pad per row)
+    constexpr int XRD = 36, XSLOT = MT * XRD, NXI = XG ? KX / 32 : 0;   // NXI iterations of two k steps
+    uint32_t* xring = lds + MT * ROWD + NW * 2 * 16 * 64;
 
     f32x16 acc[2][4];   // [row tile][gate]
 
@@ -144,26 +146,16 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
             }
         }
     };
-    // XG: this lane's x fragments of step t, k step s >= KSH: row (32 m + li), bytes [(2 (s - KSH) + hf) * 32, +32)
+    // XG staging: thread -> (row = tid / 8, 16-byte chunk c = tid % 8) of an iteration's 64 x 128 B slab
     const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(XG ? Xh + (size_t)b0 * T * ldxh : Wp), 0, 0x7fffffff, 0x00020000);
-    const unsigned xg_off = XG ? ((unsigned)(li * T) * ldxh) * 4u + hf * 32u : 0u;
-    // L2 touch of a whole step slab: 64 rows x KX*4 bytes = KX/16 64-byte lines per row; one dword per line
-    constexpr int TOUCH = XG ? (MT * (KX / 16)) / (NW * 64) : 1;
-    unsigned touched = 0;
-    auto touch_slab = [&](int t) {
-        unsigned acc_t = 0;
-        if (XG) {
-#pragma unroll
-            for (int k = 0; k < TOUCH; ++k) {
-                const int line = tid + k * (NW * 64);
-                const int row = line / (KX / 16), c = line % (KX / 16);
-                acc_t ^= __builtin_amdgcn_raw_buffer_load_b32(xgrs, ((unsigned)(row * T) * ldxh) * 4u + c * 64u,
-                                                               ((unsigned)t * ldxh) * 4u, 0);
-            }
-        }
-        return acc_t;
+    const unsigned xg_off = XG ? ((unsigned)((tid >> 3) * T) * ldxh) * 4u + (tid & 7) * 16u : 0u;
+    uint32_t* xst_dst = xring + (tid >> 3) * XRD + (tid & 7) * 4;
+    u32x4 xstage[2];
+    auto xg_load = [&](int j, int t) {      // iteration j of step t -> staging register j & 1
+        xstage[j & 1] = __builtin_amdgcn_raw_buffer_load_b128(xgrs, xg_off, ((unsigned)t * ldxh) * 4u + (unsigned)j * 128u, 0);
     };
+    auto xg_store = [&](int j) { *reinterpret_cast<u32x4*>(xst_dst + (j & 1) * XSLOT) = xstage[j & 1]; };
 
     struct Frag { h8 b[4][2], a[2][2]; };     // [gate][hi, lo], [row tile][hi, lo]
     const uint32_t* arow = lds + li * ROWD + hf * 8;
@@ -175,13 +167,14 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                 fr.b[g][hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(
                                                          wrs, woff, (unsigned)(((g * NT + u) * KS + s) * 2 + hl) * 1024u, 0));
     };
-    auto load_a = [&](int s, Frag& fr, int t) {
+    auto load_a = [&](int s, Frag& fr, int) {
         if (XG && s >= KSH) {
+            const int xs = s - KSH;
+            const uint32_t* src = xring + ((xs >> 1) & 1) * XSLOT + li * XRD + ((xs & 1) * 2 + hf) * 8;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const unsigned so = ((unsigned)(m * 32 * T + t) * ldxh) * 4u + (unsigned)(s - KSH) * 64u;
-                fr.a[m][0] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(xgrs, xg_off, so, 0));
-                fr.a[m][1] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(xgrs, xg_off, so + 16u, 0));
+                fr.a[m][0] = *reinterpret_cast<const h8*>(src + m * 32 * XRD);
+                fr.a[m][1] = *reinterpret_cast<const h8*>(src + m * 32 * XRD + 4);
             }
             return;
         }
@@ -240,6 +233,17 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int p = s & 1;
+                if (XG) {
+                    // iteration j = k steps (KSH + 2j, KSH + 2j + 1); its slab is loaded at step 2j + 9 (j = 0, 1: steps
+                    // 0, 1), written to slot j & 1 at step 2j + 13 (j = 0: step 8) and published by the barrier at the
+                    // start of step 2j + 15, the step that pre-reads its first fragments
+                    if (s == 0) xg_load(0, t);
+                    if (s == 1) xg_load(1, t);
+                    if (s >= KSH - 1 && ((s - (KSH - 1)) & 1) == 0 && (s - (KSH - 1)) / 2 < NXI) lds_barrier();
+                    if (s == 8) xg_store(0);
+                    if (s >= 15 && ((s - 13) & 1) == 0 && (s - 13) / 2 < NXI) xg_store((s - 13) / 2);
+                    if (s >= 13 && ((s - 9) & 1) == 0 && (s - 9) / 2 < NXI) xg_load((s - 9) / 2, t);
+                }
                 if (s + 1 < KS) { load_b(s + 1, ring[p ^ 1]); load_a(s + 1, ring[p ^ 1], t); }
                 else load_b(0, ring[p ^ 1]);            // KS is even: ring[p ^ 1] == ring[0]
                 if (s >= 1 && s <= YC) yc_write(s - 1, tp, ycv);
@@ -251,12 +255,22 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
                             acc[m][g] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0], acc[m][g]);
-                if (XG && s + 1 < KS && s + 1 >= KSH) {
+                if (XG && s + 1 < KS && s > YC) {
 #pragma unroll
-                    for (int q = 0; q < 12; ++q) {
+                    for (int q = 0; q < 8; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (8 B + 4 x fragments)
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (B fragment)
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (A fragment: h rows or x ring)
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // x slab chunk -> ring
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // x slab chunk of a later iteration
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 } else if (s + 1 < KS) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -289,7 +303,6 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
             }
         }
         if (stamp) dbg[(u * 80 + 2 * step) * 2 + 1] = __builtin_amdgcn_s_memtime();
-        if (XG && step + 1 < T) touched ^= touch_slab(dir ? t - 1 : t + 1);   // next step's x slab -> L2, under the gate phase
 
         lds_barrier();                    // every wave has finished reading h_{t-1}
         if (stamp) dbg[(u * 80 + 2 * step + 1) * 2] = __builtin_amdgcn_s_memtime();
@@ -349,7 +362,6 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 #pragma unroll
         for (int j = 0; j < YC; ++j) yc_write(j, tl, yc_read(j));
     }
-    if (XG && touched == 0x9e3779b9u && dbg != nullptr) dbg[0] = touched;   // keeps the touch loads alive
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -864,7 +876,7 @@ hipError_t launch_lstm_dec_h2(int H, const void* Xh, int ldxh, const float* bias
                               int T, hipStream_t stream, bool prescaled) {
     if (B <= 0) return hipSuccess;
     if (H != 256 || (ldy & 7) || (ldxh & 7) || ldxh < 512) return hipErrorInvalidValue;
-    const size_t lds = (size_t)MT * (256 * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4;
+    const size_t lds = (size_t)MT * (256 * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4 + (size_t)2 * MT * 36 * 4;   // h + c + x ring
     const int grid = rec_grid(B);
 #define PA_DEC(PRE_)                                                                                                   \
     hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 512, PRE_, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, \
