@@ -371,7 +371,9 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 // (and, when the uint8 input projection is fused, so has the input half).  h is carried exactly in f32
 // registers for the z * h_{t-1} term and the final state hand-off; the LDS / y image is its h2 split.
 //   /root/reference/pepper/modules/python/models/simple_model.py:30,32
-template <int H, int KX>
+// XG: the layer input is an h2 layer output Xh [B*T, KX] streamed through a two-slot LDS ring exactly as in
+// lstm_rec_h2_kernel (two k steps = 128 rows x 128 B per slot, two 16-byte chunks per thread per iteration).
+template <int H, int KX, bool XG = false>
 __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
                                                             const uint8_t* __restrict__ Xi, int F, int64_t xi_bstride,
                                                             const float* __restrict__ bias,
@@ -379,11 +381,15 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
                                                             const float* __restrict__ bhn,
                                                             const float* __restrict__ h0, int ldh0,
                                                             float* __restrict__ hn, int ldhn,
-                                                            uint32_t* __restrict__ Y, int ldy, int B, int T) {
+                                                            uint32_t* __restrict__ Y, int ldy, int B, int T,
+                                                            const uint32_t* __restrict__ Xh = nullptr, int ldxh = 0) {
     constexpr int KT = H + KX, KS = KT / 16, KSH = H / 16, NT = H / 32, RG = 8 / NT, MTG = MT * RG;
     constexpr int NA = KX ? 4 : 3;
-    constexpr int ROWB = KT * 4 + 16, ROWD = ROWB / 4;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [MTG][ROWD] h2 rows of [h | x]
+    constexpr int KL = XG ? H : KT;
+    constexpr int ROWB = KL * 4 + 16, ROWD = ROWB / 4;
+    constexpr int XRD = 36, XSLOT = MTG * XRD, NXI = XG ? KX / 32 : 0;
+    static_assert(!XG || KSH >= 7, "ring schedule needs KSH >= 7");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [MTG][ROWD] h2 rows of [h | x] (+ x ring when XG)
     static_assert((ROWB / 16) % 2 == 1, "row stride must be an odd number of 16-byte slots");
 
     int dir, btile;
@@ -411,6 +417,23 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 
     for (int idx = tid; idx < MTG * ROWD; idx += 512) lds[idx] = 0u;
     __syncthreads();
+    uint32_t* xring = lds + MTG * ROWD;
+    const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(XG ? Xh + (size_t)b0 * T * ldxh : Wp), 0, 0x7fffffff, 0x00020000);
+    // staging: chunk q of thread tid covers row (tid / 8) + 64 q, 16-byte chunk tid % 8
+    const unsigned xg_off = XG ? ((unsigned)((tid >> 3) * T) * ldxh) * 4u + (tid & 7) * 16u : 0u;
+    uint32_t* xst_dst = xring + (tid >> 3) * XRD + (tid & 7) * 4;
+    u32x4 xstage[2][2];
+    auto xg_load = [&](int j, int t) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            xstage[j & 1][q] = __builtin_amdgcn_raw_buffer_load_b128(
+                xgrs, xg_off, ((unsigned)(q * 64 * T + t) * ldxh) * 4u + (unsigned)j * 128u, 0);
+    };
+    auto xg_store = [&](int j) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4*>(xst_dst + (j & 1) * XSLOT + q * 64 * XRD) = xstage[j & 1][q];
+    };
 
     auto load_xp4 = [&](int m, int t, int g, int qd) {
         const unsigned ct = (unsigned)(dir * (3 * NT) + g * NT + u);
@@ -461,10 +484,11 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) acc[m][2][4 * qd + e] = bn;
     };
     // fused: uint8 x_t (exact in f16) -> hi halves of columns [H, H+KX); one thread per feature pair
-    constexpr int XN = KX ? (MTG * KX / 2) / 512 : 1;
+    constexpr bool XU8 = KX > 0 && !XG;
+    constexpr int XN = XU8 ? (MTG * KX / 2) / 512 : 1;
     unsigned xv[XN];
     auto x_load = [&](int t) {
-        if (KX) {
+        if (XU8) {
 #pragma unroll
             for (int k = 0; k < XN; ++k) {
                 const int e = tid + k * 512;
@@ -479,7 +503,7 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
         }
     };
     auto x_store = [&]() {
-        if (KX) {
+        if (XU8) {
 #pragma unroll
             for (int k = 0; k < XN; ++k) {
                 const int e = tid + k * 512;
@@ -520,6 +544,16 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
             for (int hl = 0; hl < 2; ++hl)
                 fr.b[g][hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(
                                                          wrs, woff, (unsigned)((g * NT * KS + s) * 2 + hl) * 1024u, 0));
+        if (XG && s >= KSH) {
+            const int xs = s - KSH;
+            const uint32_t* src = xring + ((xs >> 1) & 1) * XSLOT + (rg * MT + li) * XRD + ((xs & 1) * 2 + hf) * 8;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                fr.a[m][0] = *reinterpret_cast<const h8*>(src + m * 32 * XRD);
+                fr.a[m][1] = *reinterpret_cast<const h8*>(src + m * 32 * XRD + 4);
+            }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             fr.a[m][0] = *reinterpret_cast<const h8*>(arow + m * 32 * ROWD + s * 16);
@@ -538,6 +572,16 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int p = s & 1;
+                if (XG) {
+                    // x ring schedule (see lstm_rec_h2_kernel): iteration j = k steps (KSH + 2j, KSH + 2j + 1) is loaded at
+                    // step KSH - 7 + 2j (j = 0, 1: steps 0, 1), stored at step KSH - 3 + 2j, published by the barrier at the
+                    // start of step KSH - 1 + 2j
+                    if (s == 0) xg_load(0, t);
+                    if (s == 1) xg_load(1, t);
+                    if (s >= KSH - 1 && ((s - (KSH - 1)) & 1) == 0 && (s - (KSH - 1)) / 2 < NXI) lds_barrier();
+                    if (s >= KSH - 3 && ((s - (KSH - 3)) & 1) == 0 && (s - (KSH - 3)) / 2 < NXI) xg_store((s - (KSH - 3)) / 2);
+                    if (s >= KSH - 3 && ((s - (KSH - 7)) & 1) == 0 && (s - (KSH - 7)) / 2 < NXI) xg_load((s - (KSH - 7)) / 2, t);
+                }
                 if (s + 1 < KS) load_step(s + 1, ring[p ^ 1]);
                 if (s >= 1 && s <= YI) yc_write(s - 1, tp, ycv);
                 if (s < YI) ycv = yc_read(s);
@@ -940,6 +984,18 @@ hipError_t launch_gru_dec_h2(int H, const void* Xh, int ldxh, const float* bias,
                              hipStream_t stream) {
     if (B <= 0) return hipSuccess;
     if (H != 128 || (ldy & 7) || (ldxh & 7)) return hipErrorInvalidValue;
+    // default: the 8-wave / 128-row step loop with the x slab streamed through the LDS ring (half the weight
+    // stream per row of gru_dec_h2_kernel's 64-row form, which PA_GRU_DEC_RING=0 selects)
+    static const bool ring = [] { const char* e = getenv("PA_GRU_DEC_RING"); return !e || e[0] != '0'; }();
+    if (ring) {
+        const int nbt = (B + 2 * MT - 1) / (2 * MT);
+        const int grid = 2 * ((nbt + 3) / 4) * 4;
+        const size_t lds = (size_t)2 * MT * (128 * 4 + 16) + (size_t)2 * 2 * MT * 36 * 4;
+        hipLaunchKernelGGL((gru_rec_h2_kernel<128, 256, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0,
+                           (const uint8_t*)nullptr, 0, (int64_t)0, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn,
+                           ldhn, static_cast<uint32_t*>(Y), ldy, B, T, static_cast<const uint32_t*>(Xh), ldxh);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)MT * ((128 + 256) * 4 + 16);
     hipLaunchKernelGGL((gru_dec_h2_kernel<128, 256>), dim3(rec_grid(B)), dim3(256), lds, stream,
                        static_cast<const uint32_t*>(Xh), ldxh, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn,
