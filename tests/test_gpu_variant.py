@@ -161,3 +161,19 @@ def test_variant_full_bench_size_properties():
     ref, inter = models_np.variant_forward(sd, x[pick], return_intermediates=True)
     assert np.abs(p0[pick] - ref).max() < TOL
     assert np.abs(l0[pick] - inter["logits"]).max() < TOL * max(1.0, np.abs(inter["logits"]).max())
+
+
+def test_variant_run_to_run_determinism():
+    """No atomics and a fixed split-K order anywhere on the model path: the same handle (and a fresh one) must return
+    bit-identical results for the same input."""
+    sd = synthetic.variant_state_dict(seed=17, gain=2.0)
+    x = synthetic.variant_windows(3000, seed=31)
+    a = NativeVariant(sd)
+    p0, l0 = a.forward(x)
+    p1, l1 = a.forward(x)
+    a.close()
+    b = NativeVariant(sd)
+    p2, l2 = b.forward(x)
+    b.close()
+    assert np.array_equal(p0, p1) and np.array_equal(l0, l1)
+    assert np.array_equal(p0, p2) and np.array_equal(l0, l2)
