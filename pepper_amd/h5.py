@@ -5,7 +5,9 @@ Only what PEPPER's inference path uses: open, list a group, whole-dataset reads,
 layout h5py produces for the reference's DataStore classes.
 """
 import ctypes
+import functools
 import os
+import threading
 
 import numpy as np
 
@@ -37,6 +39,17 @@ SYMBOLS = [
 ]
 
 _lib = None
+# libhdf5 is not built thread-safe: every call into it is serialised (a reader thread may prefetch the next image file
+# while the main thread writes predictions; the GPU work in between holds no lock)
+_LOCK = threading.RLock()
+
+
+def _locked(fn):
+    @functools.wraps(fn)
+    def wrapper(*a, **kw):
+        with _LOCK:
+            return fn(*a, **kw)
+    return wrapper
 
 
 class H5Error(RuntimeError):
@@ -66,6 +79,7 @@ def _check(rc):
 class File(object):
     """with File(path, 'r'|'w'|'r+') as f:  f.keys(group), f[path] (read), f[path] = array (create)."""
 
+    @_locked
     def __init__(self, path, mode="r"):
         self._lib = load()
         self._h = c_void_p()
@@ -73,11 +87,13 @@ class File(object):
         _check(self._lib.pa_h5_open(os.fsencode(path), code, ctypes.byref(self._h)))
         self.filename, self.mode = path, mode
 
+    @_locked
     def close(self):
         if self._h:
             h, self._h = self._h, None
             _check(self._lib.pa_h5_close(h))
 
+    @_locked
     def flush(self):
         _check(self._lib.pa_h5_flush(self._h))
 
@@ -93,9 +109,11 @@ class File(object):
         except Exception:
             pass
 
+    @_locked
     def __contains__(self, path):
         return _check(self._lib.pa_h5_exists(self._h, path.encode())) == 1
 
+    @_locked
     def keys(self, group="/"):
         needed, count = c_int64(), c_int64()
         _check(self._lib.pa_h5_list(self._h, group.encode(), None, 0, ctypes.byref(needed), ctypes.byref(count)))
@@ -105,6 +123,7 @@ class File(object):
         _check(self._lib.pa_h5_list(self._h, group.encode(), buf, needed.value, ctypes.byref(needed), ctypes.byref(count)))
         return [s.decode() for s in buf.raw[:needed.value].split(b"\0")[:count.value]]
 
+    @_locked
     def info(self, path):
         rank, cls, size, sgn = c_int32(), c_int32(), c_int32(), c_int32()
         dims = (c_int64 * 8)()
@@ -112,6 +131,7 @@ class File(object):
                                     ctypes.byref(size), ctypes.byref(sgn)))
         return tuple(dims[:rank.value]), cls.value, size.value, bool(sgn.value)
 
+    @_locked
     def __getitem__(self, path):
         """Whole-dataset read (the reference only ever does dataset[()])."""
         shape, cls, size, sgn = self.info(path)
@@ -138,6 +158,7 @@ class File(object):
         _check(self._lib.pa_h5_read(self._h, path.encode(), _CODES[dt], out.ctypes.data, out.nbytes))
         return out if shape else out[()]
 
+    @_locked
     def __setitem__(self, path, value):
         """Create a contiguous dataset like h5py's file[path] = value."""
         if isinstance(value, str):

@@ -25,6 +25,9 @@ def _log(msg):
     sys.stderr.flush()
 
 
+DEVICE_CHUNKS = 4096     # chunks per device pass (19 windows of 100 rows each)
+
+
 def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size, num_workers, rank, device_id,
             model=None):
     torch.cuda.set_device(device_id)
@@ -37,8 +40,21 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
     prediction_data_file = DataStore(output_filename, mode='w')
     input_data = SequenceDataset(input_filepath, file_chunks)
     done = 0
+    # batch_size is the reference's DataLoader batch (128 chunks = one workgroup tile per direction here); the device
+    # pass takes up to DEVICE_CHUNKS chunks at once -- outputs are per chunk, so the files do not change -- and the
+    # next block is read (libhdf5 under the h5 lock, GIL released) while the GPU works on this one
+    from concurrent.futures import ThreadPoolExecutor
+    device_batch = max(int(batch_size), DEVICE_CHUNKS)
+    blocks = input_data.batches(device_batch)
+    reader = ThreadPoolExecutor(max_workers=1)
+    pending = reader.submit(next, blocks, None)
     try:
-        for contig, contig_start, contig_end, chunk_id, images, position, index in input_data.batches(batch_size):
+        while True:
+            block = pending.result()
+            if block is None:
+                break
+            pending = reader.submit(next, blocks, None)
+            contig, contig_start, contig_end, chunk_id, images, position, index = block
             labels, phred = model.predict_chunks(torch.from_numpy(images))
             labels, phred = labels.numpy(), phred.numpy()
             for i in range(len(contig)):
@@ -48,6 +64,7 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
             if rank == 0:
                 _log("INFO: BATCHES PROCESSED " + str(done) + ".")
     finally:
+        reader.shutdown(wait=True)
         input_data.close()
         prediction_data_file.close()
     return rank

@@ -52,9 +52,15 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
 
     batch_completed = 0
     total_windows = 0
+    # the next image file is read (libhdf5 through ctypes: the GIL is released) while the GPU works on this one
+    from concurrent.futures import ThreadPoolExecutor
+    reader = ThreadPoolExecutor(max_workers=1)
+    pending = reader.submit(SequenceDataset, input_filepath, input_files[0]) if input_files else None
     try:
         for file_id, input_file in enumerate(input_files):
-            input_data = SequenceDataset(input_filepath, input_file)
+            input_data = pending.result()
+            pending = (reader.submit(SequenceDataset, input_filepath, input_files[file_id + 1])
+                       if file_id + 1 < len(input_files) else None)
             n = len(input_data)
             if n:
                 # one packed int8 H2D copy per file, one device pass; float32 probs come back
@@ -71,6 +77,7 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
             total_windows += n
             _log("INFO: FILES COMPLETED: " + str(file_id + 1) + "/" + str(len(input_files)) + ".")
     finally:
+        reader.shutdown(wait=True)
         prediction_data_file.close()
     return batch_completed, total_windows
 
