@@ -52,10 +52,24 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
 
     batch_completed = 0
     total_windows = 0
-    # the next image file is read (libhdf5 through ctypes: the GIL is released) while the GPU works on this one
+    # three stages in flight: the next image file is being read and the previous file's predictions are being written
+    # (one thread each; libhdf5 calls are serialised by the h5 lock, ctypes releases the GIL) while the GPU works on
+    # the current file.  The writer is a single FIFO worker, so batch_<n> groups are created in order.
     from concurrent.futures import ThreadPoolExecutor
     reader = ThreadPoolExecutor(max_workers=1)
+    writer = ThreadPoolExecutor(max_workers=1)
+    writes = []
     pending = reader.submit(SequenceDataset, input_filepath, input_files[0]) if input_files else None
+
+    def write_file(first_batch, input_data, probs):
+        offset, batch_no = 0, first_batch
+        for contigs, positions, depths, candidates, freqs, _ in input_data.batches(options.batch_size):
+            b = len(positions)
+            prediction_data_file.write_prediction(batch_no, [c.decode('UTF-8') for c in contigs], positions, depths,
+                                                  candidates, freqs, probs[offset:offset + b])
+            offset += b
+            batch_no += 1
+
     try:
         for file_id, input_file in enumerate(input_files):
             input_data = pending.result()
@@ -66,18 +80,17 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
                 # one packed int8 H2D copy per file, one device pass; float32 probs come back
                 images = torch.from_numpy(input_data.all_images)
                 probs = model(images, False).numpy()
-                offset = 0
-                for contigs, positions, depths, candidates, freqs, _ in input_data.batches(options.batch_size):
-                    b = len(positions)
-                    prediction_data_file.write_prediction(
-                        batch_completed, [c.decode('UTF-8') for c in contigs], positions, depths, candidates,
-                        freqs, probs[offset:offset + b])
-                    offset += b
-                    batch_completed += 1
+                writes.append(writer.submit(write_file, batch_completed, input_data, probs))
+                batch_completed += (n + options.batch_size - 1) // options.batch_size
             total_windows += n
+            if len(writes) > 2:
+                writes.pop(0).result()          # surfaces writer errors early, bounds the queue
             _log("INFO: FILES COMPLETED: " + str(file_id + 1) + "/" + str(len(input_files)) + ".")
+        for w in writes:
+            w.result()
     finally:
         reader.shutdown(wait=True)
+        writer.shutdown(wait=True)
         prediction_data_file.close()
     return batch_completed, total_windows
 

@@ -1,0 +1,53 @@
+"""End-to-end rate of the inference step as the reference runs it: image HDF5 files on disk -> run_inference ->
+predictions HDF5 (not the headline bench: includes libhdf5 reads, H2D, D2H and the per-batch prediction writes).
+    python tools/bench_pipeline.py [--files 8] [--windows 65536]"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from pepper_amd import synthetic  # noqa: E402
+from pepper_amd.variant.DataStore import DataStore  # noqa: E402
+from pepper_amd.variant.RunInference import run_inference  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--files", type=int, default=8)
+ap.add_argument("--windows", type=int, default=65536)
+args = ap.parse_args()
+tmp = tempfile.mkdtemp()
+try:
+    img_dir = os.path.join(tmp, "images")
+    os.makedirs(img_dir)
+    t0 = time.perf_counter()
+    for fi in range(args.files):
+        with DataStore(os.path.join(img_dir, "pepper_variants_images_thread_%d.hdf5" % fi), "w") as ds:
+            per = args.windows // 4
+            for gi in range(4):
+                x = synthetic.variant_windows(per, seed=1000 + fi * 4 + gi)
+                ds.write_summary("chr20_%d_%d" % (gi * 100000, (gi + 1) * 100000), ["chr20"] * per,
+                                 np.arange(per) + gi * 100000, np.full(per, 30), np.array([["1A"]] * per, dtype=object),
+                                 np.full((per, 1), 7), x, [0] * per, [0] * per, False)
+    t_write = time.perf_counter() - t0
+    sd = synthetic.variant_state_dict(seed=0)
+    model_path = os.path.join(tmp, "model.pkl")
+    torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
+    opts = SimpleNamespace(model_path=model_path, batch_size=512, num_workers=0, use_hp_info=False, gpu=True, device_ids="0",
+                           callers_per_gpu=4, threads=8, quantized=False, dry=False)
+    t0 = time.perf_counter()
+    run_inference(opts, img_dir, os.path.join(tmp, "pred"))
+    dt = time.perf_counter() - t0
+    n = args.files * (args.windows // 4) * 4
+    size = sum(os.path.getsize(os.path.join(img_dir, f)) for f in os.listdir(img_dir))
+    print(json.dumps({"metric": "run_inference HDF5 -> HDF5, 1 GPU", "windows": n, "image_bytes": size,
+                      "seconds": round(dt, 3), "windows_per_s": round(n / dt), "image_write_seconds": round(t_write, 2)}))
+finally:
+    shutil.rmtree(tmp)
