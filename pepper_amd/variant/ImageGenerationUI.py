@@ -148,8 +148,18 @@ class ImageGenerationUtils:
         all_intervals, total_bases = ImageGenerationUtils.split_intervals(chr_list, fasta_handler, options.region_size)
         _log("INFO: TOTAL CONTIGS: " + str(len(chr_list)) + " TOTAL INTERVALS: " + str(len(all_intervals))
              + " TOTAL BASES: " + str(total_bases))
-        for process_id in range(options.threads):
-            ImageGenerationUtils.generate_image_and_save_to_file(options, all_intervals, None, process_id)
+        # the reference forks options.threads processes; here they are threads of one process sharing the GPU: the
+        # BAM reader, the encoder's host pass and libhdf5 run outside the GIL, each worker has its own BAM / FASTA
+        # handles, encoder workspace and output file (interval i goes to worker i % threads, as in the reference)
+        if options.threads <= 1:
+            ImageGenerationUtils.generate_image_and_save_to_file(options, all_intervals, None, 0)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=options.threads) as pool:
+                futures = [pool.submit(ImageGenerationUtils.generate_image_and_save_to_file, options, all_intervals, None,
+                                       process_id) for process_id in range(options.threads)]
+                for fut in futures:
+                    fut.result()
         _log("INFO: FINISHED IMAGE GENERATION")
         secs = int(time.time() - start_time)
         _log("INFO: TOTAL ELAPSED TIME FOR GENERATING IMAGES: " + str(secs // 60) + " Min " + str(secs % 60) + " Sec")

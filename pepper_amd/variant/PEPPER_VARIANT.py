@@ -98,13 +98,16 @@ _encoders = {}
 
 
 def _encoder(device):
-    """One native encoder (stream + workspace) per device per process, created on first use."""
+    """One native encoder (stream + workspace) per device per THREAD, created on first use: a handle holds the
+    results of its last call, so image-generation worker threads must not share one."""
+    import threading
     lib = _lib.load()
-    if device not in _encoders:
+    key = (device, threading.get_ident())
+    if key not in _encoders:
         h = ctypes.c_void_p()
         _lib.check(lib.pa_encoder_create(device, None, ctypes.byref(h)))
-        _encoders[device] = h
-    return lib, _encoders[device]
+        _encoders[key] = h
+    return lib, _encoders[key]
 
 
 def flatten_reads(reads):
