@@ -42,7 +42,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", choices=["variant", "polish"], default="variant")
+    ap.add_argument("--model", choices=["variant", "polish", "ns-literal"], default="variant",
+                    help="variant = BASELINE configs[1] shapes (the headline); polish = configs[4]; ns-literal = the polish "
+                         "stack at the north_star's literal synthetic shape (100-step windows x 100 features; not a "
+                         "reference shape, reported separately)")
     ap.add_argument("--per-gpu", type=int, default=0, help="windows (variant) / chunks (polish) per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -200,23 +203,32 @@ def main():
                     "F=26 H=256 L=1 (BASELINE configs[1] shapes)")
     else:
         per = args.per_gpu or 16384
-        sd = broadcast_state_dict(lambda: synthetic.polish_state_dict(seed=0),
-                                  synthetic.polish_param_shapes(), world, rank, dev)
-        cfg = _lib.PolishConfig(10, 128, 1, 5, 1000, 100, 50, 50, local, per)
+        feat = 100 if args.model == "ns-literal" else 10
+        sd = broadcast_state_dict(lambda: synthetic.polish_state_dict(seed=0, image_features=feat),
+                                  synthetic.polish_param_shapes(image_features=feat), world, rank, dev)
+        cfg = _lib.PolishConfig(feat, 128, 1, 5, 1000, 100, 50, 50, local, per)
         names, data, numel, n, keep = _lib.marshal_state_dict(sd)
         handle = ctypes.c_void_p()
         _lib.check(lib.pa_polish_create(ctypes.byref(cfg), names, data, numel, n,
                                         ctypes.c_void_p(stream.cuda_stream), ctypes.byref(handle)))
-        x = torch.from_numpy(synthetic.polish_chunks(per, seed=synthetic.PSYN_SEED + rank)).to(dev)
+        if feat == 10:
+            x = torch.from_numpy(synthetic.polish_chunks(per, seed=synthetic.PSYN_SEED + rank)).to(dev)
+        else:   # rows of small counts spread over 100 columns, generated on the device (1.6 GB per 16384 chunks)
+            gen = torch.Generator(device=dev).manual_seed(synthetic.PSYN_SEED + rank)
+            x = torch.poisson(torch.full((per, 1000, feat), 2.5, device=dev), generator=gen).clamp_(0, 254).to(torch.uint8)
         lab = torch.empty((per, 1000), dtype=torch.uint8, device=dev)
         ph = torch.empty((per, 1000), dtype=torch.uint8, device=dev)
 
         def step():
             _lib.check(lib.pa_polish_predict_device(handle, x.data_ptr(), per, lab.data_ptr(),
                                                     ph.data_ptr(), None))
-        windows_per_unit, flop_per_window = POLISH_WINDOWS_PER_CHUNK, POLISH_FLOP_PER_WINDOW
+        windows_per_unit = POLISH_WINDOWS_PER_CHUNK
+        flop_per_window = POLISH_FLOP_PER_WINDOW + 2.0 * 100 * 2 * 384 * (feat - 10)
         workload = ("P-syn: uint8 [N,1000,10] chunks, polish bi-GRU(10->128)x2 + dense, 19 windows of "
-                    "100 steps with hidden carry (BASELINE configs[4] shapes)")
+                    "100 steps with hidden carry (BASELINE configs[4] shapes)") if feat == 10 else (
+                    "NS-literal: uint8 [N,1000,100] chunks = 19 windows of 100 steps x 100 features through the polish "
+                    "bi-GRU(100->128)x2 + dense with hidden carry; the north_star's literal synthetic shape, not a "
+                    "reference shape (SURVEY.md section 0), no CPU baseline")
 
     def barrier():
         if world > 1:
@@ -281,7 +293,7 @@ def main():
             "end_to_end_tflops": value * flop_per_window / 1e12,
             "kernels": kern,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model != "ns-literal":
             # whole-box CPU number = the reference's own scheme (many single-thread workers); the
             # single-process multi-thread figure is kept beside it
             single = cpu_baseline(args.model, args.cpu_seconds)

@@ -314,7 +314,7 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
         if (int rc = upload(out.b_hn, bn)) return rc;
     }
     if ((G == 4 && H == 256) || (G == 3 && H == 128)) {
-        const int KXh2 = G == 4 ? 32 : 16;
+        const int KXh2 = G == 4 ? 32 : std::max(16, pa::gru_fused_input_kx(H, K));
         auto pack_upload = [&](DevBuf*& dst, const float* const wx[2], int KX) -> int {
             for (int d = 0; d < 2; ++d) {
                 for (int64_t i = 0; i < (int64_t)G * H * H; ++i)
@@ -710,9 +710,12 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
             const float* h0l = h0 ? h0 + (size_t)l * 2 * H : nullptr;
             float* hnl = hn ? hn + (size_t)l * 2 * H : nullptr;
             float* y = ybuf[which];
-            if (stage == 0 && l == 0 && cur_kind == pa::A_U8 && r.w_cat != nullptr && m->fuse_input) {
-                const int64_t xbs = cur_bs > 0 ? cur_bs : (int64_t)T * r.K;
-                if (rec_h2 && r.w_cat_h2 != nullptr)
+            const int64_t xbs = cur_bs > 0 ? cur_bs : (int64_t)T * r.K;
+            // wide uint8 inputs (16 < F <= 128) are read as dwords by the step loop: rows must be 4-byte aligned
+            const bool fused_h2_ok = rec_h2 && r.w_cat_h2 != nullptr &&
+                                     (r.K <= 16 || ((xbs & 3) == 0 && (reinterpret_cast<uintptr_t>(cur) & 3) == 0));
+            if (stage == 0 && l == 0 && cur_kind == pa::A_U8 && (r.w_cat != nullptr || fused_h2_ok) && m->fuse_input) {
+                if (fused_h2_ok)
                     LAUNCH_TRY(m, "gru_rec_h2_fused_in", 2.0 * n * T * (3.0 * H) * (H + r.K) * 2,
                                pa::launch_gru_rec_h2(H, nullptr, 0, static_cast<const uint8_t*>(cur), r.K, xbs, r.b_in->f(),
                                                      r.w_cat_h2->p, r.b_hn->f(), h0l, ldh, hnl, ldh, y, 2 * H, (int)n, T,
@@ -722,7 +725,7 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
                                pa::launch_gru_rec_fused(H, static_cast<const uint8_t*>(cur), r.K, xbs, r.b_in->f(),
                                                         r.w_cat->f(), r.b_hn->f(), h0l, ldh, hnl, ldh, y, 2 * H, (int)n, T,
                                                         m->stream));
-                cur_h2 = rec_h2 && r.w_cat_h2 != nullptr;
+                cur_h2 = fused_h2_ok;
             } else if (rec_h2 && cur_h2 && r.w_cat_dec_h2 != nullptr && cur_rpb == 0 && cur_bs == 0 && m->fuse_dec) {
                 // h2 layer output -> this layer: projection contracted inside the step loop (no GEMM, no Xp)
                 LAUNCH_TRY(m, "gru_dec_h2_fused", 2.0 * n * T * (3.0 * H) * (H + r.K) * 2,

@@ -56,6 +56,7 @@ hipError_t launch_gru_rec_fused(int H, const uint8_t* X, int F, int64_t x_bstrid
 void pack_rec_weights_h2(const float* const whh[2], const float* const wih[2], int G, int H, int F, int KX,
                          uint32_t* out);
 size_t rec_weights_h2_words(int G, int H, int KX);
+int gru_fused_input_kx(int H, int F);   // 16 / 128: padded width of the uint8-input step loop; 0: projection as a GEMM
 // prescaled: weights / bias / Xp were multiplied per gate row by the exp2 constants (see rnn_h2.hip).
 hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, int F, const float* bias,
                               const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream,

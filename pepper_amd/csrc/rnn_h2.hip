@@ -483,22 +483,29 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[m][2][4 * qd + e] = bn;
     };
-    // fused: uint8 x_t (exact in f16) -> hi halves of columns [H, H+KX); one thread per feature pair
+    // fused: uint8 x_t (exact in f16) -> hi halves of columns [H, H+KX).  KX = 16: one thread per feature pair,
+    // byte loads.  KX >= 64 (wide summaries; the launcher requires F % 4 == 0 and 4-byte aligned rows): one thread
+    // per four features, one dword load and one 8-byte LDS write each.
     constexpr bool XU8 = KX > 0 && !XG;
-    constexpr int XN = XU8 ? (MTG * KX / 2) / 512 : 1;
+    constexpr int XPT = KX >= 64 ? 4 : 2;                               // features per thread slot
+    constexpr int XN = XU8 ? (MTG * KX / XPT) / 512 : 1;
     unsigned xv[XN];
     auto x_load = [&](int t) {
         if (XU8) {
 #pragma unroll
             for (int k = 0; k < XN; ++k) {
                 const int e = tid + k * 512;
-                const int row = e / (KX / 2), f = (e % (KX / 2)) * 2;
+                const int row = e / (KX / XPT), f = (e % (KX / XPT)) * XPT;
                 int brow = b0 + row;
                 brow = brow < B ? brow : B - 1;
                 const uint8_t* src = Xi + (size_t)brow * xi_bstride + (size_t)t * F;
-                const _Float16 v0 = f < F ? (_Float16)(float)src[f] : (_Float16)0.0f;
-                const _Float16 v1 = f + 1 < F ? (_Float16)(float)src[f + 1] : (_Float16)0.0f;
-                xv[k] = (unsigned)__builtin_bit_cast(unsigned short, v0) | ((unsigned)__builtin_bit_cast(unsigned short, v1) << 16);
+                if (XPT == 4) {
+                    xv[k] = f < F ? *reinterpret_cast<const uint32_t*>(src + f) : 0u;
+                } else {
+                    const _Float16 v0 = f < F ? (_Float16)(float)src[f] : (_Float16)0.0f;
+                    const _Float16 v1 = f + 1 < F ? (_Float16)(float)src[f + 1] : (_Float16)0.0f;
+                    xv[k] = (unsigned)__builtin_bit_cast(unsigned short, v0) | ((unsigned)__builtin_bit_cast(unsigned short, v1) << 16);
+                }
             }
         }
     };
@@ -507,8 +514,18 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < XN; ++k) {
                 const int e = tid + k * 512;
-                const int row = e / (KX / 2), f = (e % (KX / 2)) * 2;
-                lds[row * ROWD + ((H + f) >> 3) * 8 + ((f & 7) >> 1)] = xv[k];
+                const int row = e / (KX / XPT), f = (e % (KX / XPT)) * XPT;
+                uint32_t* dst = lds + row * ROWD + ((H + f) >> 3) * 8 + ((f & 7) >> 1);
+                if (XPT == 4) {
+                    auto half_bits = [](unsigned byte) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(float)byte); };
+                    const unsigned w = xv[k];
+                    u32x2 pk;
+                    pk.x = half_bits(w & 0xffu) | (half_bits((w >> 8) & 0xffu) << 16);
+                    pk.y = half_bits((w >> 16) & 0xffu) | (half_bits(w >> 24) << 16);
+                    *reinterpret_cast<u32x2*>(dst) = pk;
+                } else {
+                    *dst = xv[k];
+                }
             }
         }
     };
@@ -914,6 +931,14 @@ void pack_rec_weights_h2(const float* const whh[2], const float* const wih[2], i
                     }
 }
 
+// Padded input width of the uint8-input GRU step loop for F features (0: not available, the projection runs as a GEMM)
+int gru_fused_input_kx(int H, int F) {
+    if (H != 128 || F <= 0) return 0;
+    if (F <= 16) return 16;
+    if (F <= 128 && (F & 3) == 0) return 128;
+    return 0;
+}
+
 size_t rec_weights_h2_words(int G, int H, int KX) { return (size_t)2 * (G * H / 32) * ((H + KX) / 16) * 2 * 256; }
 
 hipError_t launch_lstm_dec_h2(int H, const void* Xh, int ldxh, const float* bias, const void* Wp, void* Y, int ldy, int B,
@@ -965,11 +990,21 @@ hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, 
     const int nbt = (B + 2 * MT - 1) / (2 * MT);
     const int grid = 2 * ((nbt + 3) / 4) * 4;
     if (X != nullptr) {
-        if (F <= 0 || F > 16) return hipErrorInvalidValue;
-        const size_t lds = (size_t)2 * MT * ((128 + 16) * 4 + 16);
-        hipLaunchKernelGGL((gru_rec_h2_kernel<128, 16>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X, F,
-                           x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
-                           static_cast<uint32_t*>(Y), ldy, B, T);
+        const int KX = gru_fused_input_kx(H, F);
+        if (KX == 16) {
+            const size_t lds = (size_t)2 * MT * ((128 + 16) * 4 + 16);
+            hipLaunchKernelGGL((gru_rec_h2_kernel<128, 16>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
+                               F, x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
+                               static_cast<uint32_t*>(Y), ldy, B, T);
+        } else if (KX == 128) {
+            if ((x_bstride & 3) || (reinterpret_cast<uintptr_t>(X) & 3)) return hipErrorInvalidValue;
+            const size_t lds = (size_t)2 * MT * ((128 + 128) * 4 + 16);
+            hipLaunchKernelGGL((gru_rec_h2_kernel<128, 128>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
+                               F, x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
+                               static_cast<uint32_t*>(Y), ldy, B, T);
+        } else {
+            return hipErrorInvalidValue;
+        }
     } else {
         const size_t lds = (size_t)2 * MT * (128 * 4 + 16);
         hipLaunchKernelGGL((gru_rec_h2_kernel<128, 0>), dim3(grid), dim3(512), lds, stream, Xp, ldx,
