@@ -1,0 +1,107 @@
+"""ORACLE (test infrastructure): ctypes access to the re-alignment restatement (oracle/ssw_oracle.cpp ->
+oracle/libssw_oracle.so) and, where it was built, to the reference's own SSW (oracle/_ref/libref_ssw.so, built by
+oracle/Makefile from the sources under /root/reference).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline may import this module."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_LIB = os.path.join(HERE, "libssw_oracle.so")
+REF_LIB = os.path.join(HERE, "_ref", "libref_ssw.so")
+_i32 = ctypes.c_int32
+_libs = {}
+
+
+def _load(path):
+    if path not in _libs:
+        _libs[path] = ctypes.CDLL(path)
+    return _libs[path]
+
+
+def have_reference():
+    return os.path.exists(REF_LIB)
+
+
+def align(ref, query, cap=1 << 17):
+    """Restatement: (score, ref_begin, ref_end, query_begin, query_end, cigar_text, wide)."""
+    lib = _load(ORACLE_LIB)
+    out = (_i32 * 6)()
+    buf = ctypes.create_string_buffer(cap)
+    rb, qb = ref.encode("latin-1"), query.encode("latin-1")
+    rc = lib.ssw_oracle_align(rb, len(rb), qb, len(qb), out, buf, cap)
+    if rc < 0:
+        raise RuntimeError("ssw_oracle_align failed")
+    return (out[0], out[1], out[2], out[3], out[4], buf.value.decode(), out[5])
+
+
+def align_reference(ref, query, cap=1 << 17):
+    """The reference's SSW build: (score, ref_begin, ref_end, query_begin, query_end, cigar_text)."""
+    lib = _load(REF_LIB)
+    s, rb, re, qb, qe = _i32(), _i32(), _i32(), _i32(), _i32()
+    buf = ctypes.create_string_buffer(cap)
+    r, q = ref.encode("latin-1"), query.encode("latin-1")
+    rc = lib.ref_ssw_align(r, len(r), q, ctypes.byref(s), ctypes.byref(rb), ctypes.byref(re), ctypes.byref(qb),
+                           ctypes.byref(qe), buf, cap)
+    if rc < 0:
+        raise RuntimeError("ref_ssw_align: cigar buffer too small")
+    return (s.value, rb.value, re.value, qb.value, qe.value, buf.value.decode())
+
+
+_OPS = {"=": 7, "X": 8, "I": 1, "D": 2, "S": 4}
+
+
+def parse_cigar(text):
+    """'12=1X3I' -> [(7, 12), (8, 1), (1, 3)] (BAM op codes)."""
+    out, num = [], ""
+    for ch in text:
+        if ch.isdigit():
+            num += ch
+        else:
+            out.append((_OPS[ch], int(num)))
+            num = ""
+    return out
+
+
+def realign_reads(reference, region_start, read_pos, sequences, aligner=align):
+    """Restatement of ReadAligner::align_reads_to_reference (simple_aligner.cpp:66-106) on plain lists:
+    returns [(status, score, pos, pos_end, cigar ops with =/X kept)] with status 1 aligned / 0 kept / -1 dropped."""
+    out = []
+    for pos, seq in zip(read_pos, sequences):
+        if pos < region_start:
+            out.append((-1, 0, pos, -1, []))
+            continue
+        suffix = reference[pos - region_start:]
+        if not suffix or not seq:
+            out.append((0, 0, pos, -1, []))
+            continue
+        res = aligner(suffix, seq)
+        if res[0] > 1:
+            out.append((1, res[0], pos + res[1], pos + res[2], parse_cigar(res[5])))
+        else:
+            out.append((0, res[0], pos, -1, []))
+    return out
+
+
+def simulate_reads(rng, reference, region_start, n_reads, sub=0.04, ins=0.03, dele=0.04, min_len=30):
+    """Noisy reads of a reference window (nanopore-like error mix), clipped like the polish BAM reader clips them."""
+    bases = "ACGT"
+    n = len(reference)
+    pos, seqs = [], []
+    for _ in range(n_reads):
+        a = int(rng.integers(0, max(1, n - min_len)))
+        b = int(rng.integers(min(n, a + min_len), n + 1)) if rng.random() < 0.5 else n
+        out = []
+        for ch in reference[a:b]:
+            u = rng.random()
+            if u < dele:
+                continue
+            if u < dele + sub:
+                ch = bases[int(rng.integers(4))]
+            out.append(ch)
+            while rng.random() < ins:
+                out.append(bases[int(rng.integers(4))])
+        pos.append(region_start + a)
+        seqs.append("".join(out) or "A")
+    return pos, seqs

@@ -46,3 +46,113 @@ class SummaryGenerator(object):
         self.image = image
         self.positions_array = pos
         self.genomic_pos = [tuple(x) for x in pos.tolist()]
+
+
+_realigners = {}
+
+
+def _realigner(device):
+    """One native re-aligner (stream + workspace) per device per thread."""
+    import threading
+    lib = _lib.load()
+    key = (device, threading.get_ident())
+    if key not in _realigners:
+        h = ctypes.c_void_p()
+        _lib.check(lib.pa_realigner_create(device, None, ctypes.byref(h)))
+        _realigners[key] = h
+    return lib, _realigners[key]
+
+
+class ReadAligner(object):
+    """`PEPPER.ReadAligner(ref_start, ref_end, ref_seq).align_reads_to_reference(reads)`
+
+    /root/reference/pepper/modules/src/local_reassembly/simple_aligner.cpp:60-106: every read is aligned (SSW, match 4,
+    mismatch 6, gap open 8, gap extend 2) against the reference suffix that starts at its mapped position; with a score
+    > 1 it gets the new position / end position / CIGAR ('=' and 'X' runs both become MATCH operations, not merged),
+    otherwise it is passed through; reads that start before the region are dropped.  The alignments run on the GPU
+    (include/pepper_amd_realign.h).  `reads` is a ReadSet (pepper_amd.variant.bam) -> ReadSet, or a list of
+    type_read-like objects -> list of type_read.
+    """
+
+    def __init__(self, ref_start, ref_end, ref_seq, device=0):
+        self.region_start = int(ref_start)
+        self.region_end = int(ref_end)
+        self.reference_sequence = ref_seq
+        self.device = device
+
+    def align_arrays(self, read_pos, seq_offset, seq, collapse_eqx=True):
+        """Flat form: per-read status (1 aligned, 0 kept, -1 dropped), score, pos, pos_end, query span and CIGAR arrays."""
+        lib, h = _realigner(self.device)
+        read_pos = np.ascontiguousarray(read_pos, dtype=np.int64)
+        seq_offset = np.ascontiguousarray(seq_offset, dtype=np.int64)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        n = len(read_pos)
+        ref = self.reference_sequence.encode("latin-1") if isinstance(self.reference_sequence, str) else bytes(self.reference_sequence)
+        status, score = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        pos, pos_end = np.zeros(n, np.int64), np.zeros(n, np.int64)
+        qbeg, qend = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        total = ctypes.c_int64()
+        seq_arg = seq if len(seq) else np.zeros(1, np.uint8)
+        _lib.check(lib.pa_realigner_align(h, ref, len(ref), self.region_start, n, read_pos.ctypes.data, seq_offset.ctypes.data,
+                                          seq_arg.ctypes.data, status.ctypes.data, score.ctypes.data, pos.ctypes.data,
+                                          pos_end.ctypes.data, qbeg.ctypes.data, qend.ctypes.data, ctypes.byref(total)))
+        cigar_offset = np.zeros(n + 1, np.int64)
+        cigar_op, cigar_len = np.zeros(max(1, total.value), np.int32), np.zeros(max(1, total.value), np.int32)
+        _lib.check(lib.pa_realigner_copy_cigars(h, int(bool(collapse_eqx)), cigar_offset.ctypes.data, cigar_op.ctypes.data,
+                                                cigar_len.ctypes.data))
+        return dict(status=status, score=score, pos=pos, pos_end=pos_end, query_begin=qbeg, query_end=qend,
+                    cigar_offset=cigar_offset, cigar_op=cigar_op[:total.value], cigar_len=cigar_len[:total.value])
+
+    def align_reads_to_reference(self, reads):
+        from pepper_amd.variant.bam import ReadSet
+        if isinstance(reads, ReadSet):
+            if len(reads) == 0:
+                return reads
+            out = self.align_arrays(reads.pos, reads.seq_offset, reads.seq)
+            status = out["status"]
+            keep = np.nonzero(status >= 0)[0]
+            base = reads if len(keep) == len(reads) else reads.take(keep)
+            st = status[keep]
+            aligned = st == 1
+            pos = np.where(aligned, out["pos"][keep], base.pos)
+            pos_end = np.where(aligned, out["pos_end"][keep], base.pos_end)
+            old_n = base.cigar_offset[1:] - base.cigar_offset[:-1]
+            new_n = (out["cigar_offset"][1:] - out["cigar_offset"][:-1])[keep]
+            counts = np.where(aligned, new_n, old_n)
+            offsets = np.zeros(len(keep) + 1, np.int64)
+            np.cumsum(counts, out=offsets[1:])
+            ops, lens = np.empty(int(offsets[-1]), np.int32), np.empty(int(offsets[-1]), np.int32)
+            for i, k in enumerate(keep.tolist()):
+                a, b = int(offsets[i]), int(offsets[i + 1])
+                if aligned[i]:
+                    s = int(out["cigar_offset"][k])
+                    ops[a:b], lens[a:b] = out["cigar_op"][s:s + b - a], out["cigar_len"][s:s + b - a]
+                else:
+                    s = int(base.cigar_offset[i])
+                    ops[a:b], lens[a:b] = base.cigar_op[s:s + b - a], base.cigar_len[s:s + b - a]
+            return ReadSet(pos, pos_end, base.reverse, base.mapq, base.flags, base.hp, base.seq_offset, base.seq, base.qual,
+                           offsets, ops, lens, base.names)
+        reads = list(reads)
+        if not reads:
+            return []
+        seqs = [r.sequence.encode("latin-1") for r in reads]
+        seq_offset = np.zeros(len(reads) + 1, np.int64)
+        np.cumsum([len(s) for s in seqs], out=seq_offset[1:])
+        out = self.align_arrays([r.pos for r in reads], seq_offset, np.frombuffer(b"".join(seqs), np.uint8))
+        result = []
+        for k, read in enumerate(reads):
+            st = int(out["status"][k])
+            if st < 0:
+                continue
+            if st == 0:
+                result.append(read)
+                continue
+            new = type_read()
+            for name in ("query_name", "read_id", "flags", "hp_tag", "sequence", "mapping_quality", "base_qualities", "bad_indicies"):
+                if hasattr(read, name):
+                    setattr(new, name, getattr(read, name))
+            a, b = int(out["cigar_offset"][k]), int(out["cigar_offset"][k + 1])
+            new.cigar_tuples = [CigarOp(int(o), int(n)) for o, n in zip(out["cigar_op"][a:b], out["cigar_len"][a:b])]
+            new.pos, new.pos_end = int(out["pos"][k]), int(out["pos_end"][k])
+            result.append(new)
+        return result

@@ -1,0 +1,151 @@
+"""GPU parity of the read re-aligner (include/pepper_amd_realign.h) with the restatement of the reference's
+ReadAligner / SSW (oracle/ssw_oracle.cpp, pinned against the reference's own SSW build by
+tests/test_realign_oracle.py): integer work, so every field and every CIGAR operation must be identical."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ssw
+
+pytestmark = pytest.mark.gpu
+BASES = "ACGT"
+
+
+def _rand_seq(rng, n):
+    return "".join(BASES[k] for k in rng.integers(0, 4, n))
+
+
+def _gpu_align(reference, region_start, pos, seqs):
+    from pepper_amd.polish.PEPPER import ReadAligner
+    blob = [s.encode() for s in seqs]
+    off = np.zeros(len(seqs) + 1, np.int64)
+    np.cumsum([len(b) for b in blob], out=off[1:])
+    aligner = ReadAligner(region_start, region_start + len(reference), reference)
+    return aligner.align_arrays(pos, off, np.frombuffer(b"".join(blob), np.uint8), collapse_eqx=False)
+
+
+def _assert_same(out, expect):
+    bad = []
+    for k, (status, score, pos, pos_end, ops) in enumerate(expect):
+        a, b = int(out["cigar_offset"][k]), int(out["cigar_offset"][k + 1])
+        got_ops = list(zip(out["cigar_op"][a:b].tolist(), out["cigar_len"][a:b].tolist()))
+        got = (int(out["status"][k]), int(out["score"][k]) if status >= 0 else 0, int(out["pos"][k]),
+               int(out["pos_end"][k]) if status == 1 else -1, got_ops)
+        want = (status, score, pos, pos_end, [tuple(o) for o in ops])
+        if got != want:
+            bad.append((k, got[:4], want[:4], got_ops[:6], ops[:6]))
+    assert not bad, (len(bad), bad[:3])
+
+
+def test_region_of_simulated_reads():
+    rng = np.random.default_rng(11)
+    reference = _rand_seq(rng, 1120)
+    pos, seqs = ssw.simulate_reads(rng, reference, 5000, 160)
+    hi_pos, hi_seqs = ssw.simulate_reads(rng, reference, 5000, 60, sub=0.1, ins=0.08, dele=0.1)
+    pos += hi_pos
+    seqs += hi_seqs
+    # special reads: before the region (dropped), starting at the last base, unrelated, all N, very short, homopolymers
+    pos += [4990, 5000 + 1119, 5100, 5200, 5300, 5400]
+    seqs += ["ACGTACGT", "A", _rand_seq(rng, 300), "N" * 40, reference[300:307], "A" * 50]
+    out = _gpu_align(reference, 5000, pos, seqs)
+    _assert_same(out, ssw.realign_reads(reference, 5000, pos, seqs))
+    assert (out["status"] == 1).sum() > 200 and (out["status"] == -1).sum() == 1
+
+
+def test_wide_bands_and_long_gaps():
+    """Long insertions / deletions force band doubling past the first workspace (129 slots per row)."""
+    rng = np.random.default_rng(12)
+    reference = _rand_seq(rng, 900)
+    pos, seqs = [], []
+    for k in range(40):
+        a = int(rng.integers(0, 200))
+        seg = reference[a:a + int(rng.integers(300, 700))]
+        cut = int(rng.integers(20, len(seg) - 20))
+        gap = int(rng.integers(40, 260))
+        if k % 2:
+            seq = seg[:cut] + _rand_seq(rng, gap) + seg[cut:]            # long insertion
+        else:
+            seq = seg[:cut] + seg[min(len(seg) - 10, cut + gap):]         # long deletion
+        pos.append(100 + a)
+        seqs.append(seq)
+    out = _gpu_align(reference, 100, pos, seqs)
+    _assert_same(out, ssw.realign_reads(reference, 100, pos, seqs))
+
+
+def test_short_reads_stay_in_narrow_cells():
+    """Scores below 249 never leave the 8-bit segmentation (16 segments); mixed with reads that do."""
+    rng = np.random.default_rng(13)
+    reference = _rand_seq(rng, 400)
+    pos, seqs = [], []
+    for k in range(150):
+        a = int(rng.integers(0, 380))
+        n = int(rng.integers(1, 75))
+        seq = reference[a:a + n]
+        if k % 3 == 0 and len(seq) > 4:
+            seq = seq[:2] + BASES[int(rng.integers(4))] + seq[3:]
+        if k % 7 == 0:
+            seq = seq + _rand_seq(rng, 5)
+        pos.append(a)
+        seqs.append(seq or "C")
+    out = _gpu_align(reference, 0, pos, seqs)
+    _assert_same(out, ssw.realign_reads(reference, 0, pos, seqs))
+
+
+def test_golden_vectors_from_the_reference_build(golden_dir):
+    g = np.load(os.path.join(golden_dir, "realign_cases.npz"), allow_pickle=False)
+    reference = str(g["reference"])
+    pos = g["read_pos"].tolist()
+    seqs = [s for s in str(g["sequences"]).split("|")]
+    out = _gpu_align(reference, int(g["region_start"]), pos, seqs)
+    cig = str(g["cigars"]).split("|")
+    expect = []
+    for k in range(len(pos)):
+        st = int(g["status"][k])
+        expect.append((st, int(g["score"][k]), int(g["new_pos"][k]), int(g["new_pos_end"][k]) if st == 1 else -1,
+                       ssw.parse_cigar(cig[k]) if st == 1 else []))
+    _assert_same(out, expect)
+
+
+def test_readset_and_object_interfaces():
+    from pepper_amd.polish.PEPPER import ReadAligner, type_read, CigarOp
+    from pepper_amd.variant.bam import ReadSet
+    rng = np.random.default_rng(14)
+    reference = _rand_seq(rng, 600)
+    pos, seqs = ssw.simulate_reads(rng, reference, 1000, 30)
+    pos[3] = 990                                     # dropped
+    expect = ssw.realign_reads(reference, 1000, pos, seqs)
+    reads = []
+    for k, (p, s) in enumerate(zip(pos, seqs)):
+        r = type_read()
+        r.pos, r.pos_end, r.sequence, r.query_name = p, p + len(s), s, "r%d" % k
+        r.cigar_tuples = [CigarOp(0, len(s))]
+        r.base_qualities = [20] * len(s)
+        r.mapping_quality = 60
+        reads.append(r)
+    aligner = ReadAligner(1000, 1600, reference)
+    got = aligner.align_reads_to_reference(reads)
+    kept = [e for e in expect if e[0] >= 0]
+    assert len(got) == len(kept) == 29
+    for r, e in zip(got, kept):
+        if e[0] == 1:
+            assert (r.pos, r.pos_end) == (e[2], e[3])
+            assert [(c.cigar_op, c.cigar_len) for c in r.cigar_tuples] == [(0 if o in (7, 8) else o, n) for o, n in e[4]]
+    # structure-of-arrays form
+    blob = [s.encode() for s in seqs]
+    so = np.zeros(len(seqs) + 1, np.int64)
+    np.cumsum([len(b) for b in blob], out=so[1:])
+    n = len(seqs)
+    rs = ReadSet(np.array(pos, np.int64), np.array([p + len(s) for p, s in zip(pos, seqs)], np.int64), np.zeros(n, np.uint8),
+                 np.full(n, 60, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), so,
+                 np.frombuffer(b"".join(blob), np.uint8), np.full(int(so[-1]), 20, np.uint8), np.arange(n + 1, dtype=np.int64),
+                 np.zeros(n, np.int32), np.array([len(s) for s in seqs], np.int32), ["r%d" % k for k in range(n)])
+    out = aligner.align_reads_to_reference(rs)
+    assert len(out) == 29 and out.names[3] == "r4"
+    for i, e in enumerate(kept):
+        a, b = int(out.cigar_offset[i]), int(out.cigar_offset[i + 1])
+        if e[0] == 1:
+            assert (int(out.pos[i]), int(out.pos_end[i])) == (e[2], e[3])
+            assert list(zip(out.cigar_op[a:b].tolist(), out.cigar_len[a:b].tolist())) == [(0 if o in (7, 8) else o, n) for o, n in e[4]]
+        else:
+            assert b - a == 1
