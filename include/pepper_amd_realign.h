@@ -54,6 +54,11 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
 int pa_realigner_copy_cigars(pa_realigner* r, int32_t collapse_eqx, int64_t* cigar_offset, int32_t* cigar_op,
                              int32_t* cigar_len);
 
+/* Device time of the last pa_realigner_align call (HIP events on the handle's stream): the score / end / begin kernel,
+ * the band + trace-back launches, and the number of DP cells (reference suffix length x read length, summed over the
+ * aligned reads) one score pass visits.  Any pointer may be NULL. */
+int pa_realigner_last_timing(pa_realigner* r, double* score_kernel_ms, double* band_kernel_ms, int64_t* cells);
+
 #ifdef __cplusplus
 }
 #endif

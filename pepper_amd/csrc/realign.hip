@@ -125,6 +125,119 @@ __device__ PassOut score_pass(uint32_t* he, const int8_t* __restrict__ ref, int 
     return o;
 }
 
+__device__ __forceinline__ int dpp_up1(int v) {          // lane l <- lane l - 1 (v_mov_b32_dpp wave_shr:1), lane 0 <- 0
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+// The same pass with the lane's strip of R rows resident in registers (reads of up to 64 R rows): per cell 15 vector
+// ops and no LDS traffic; the hand-off to the next lane is three DPP moves (H | segment-local gap chain, exact gap
+// chain, column maximum as one key = value << 12 | 4095 - row so that a plain unsigned max keeps the smallest row).
+template <int R>
+__device__ __noinline__ PassOut score_pass_reg(const int8_t* __restrict__ ref, int first, int step, int count,
+                                               const int8_t* __restrict__ read, int rfirst, int rstep, int m, int lanes,
+                                               int terminate) {
+    const int lane = threadIdx.x;
+    const int L = (m + lanes - 1) / lanes, rows = L * lanes;
+    int H[R], E[R], Q[R], MIS[R], SEG[R];
+    unsigned RINV[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int r = lane * R + k;
+        int q = 10;                                       // beyond the padded read: contributes nothing
+        if (r < m) {
+            q = read[rfirst + r * rstep];
+            if (q >= 4) q = 8;                            // N never matches (not even N)
+        } else if (r < rows) {
+            q = 9;                                        // padding row of the last segment: scores 0 against everything
+        }
+        Q[k] = q;
+        MIS[k] = r < m ? -S_MIS : (r < rows ? 0 : -(1 << 20));
+        SEG[k] = (r >= rows || r % L == 0) ? 0 : -1;      // and-mask of the segment-local chain
+        RINV[k] = (unsigned)(4095 - r);
+        H[k] = 0;
+        E[k] = 0;
+    }
+    int run_max = 0, end_ref = lanes == 16 ? -1 : 0, end_row = -1, stop = 0, overflow = 0, diag_in = 0;
+    int p0 = 0, p1 = 0;
+    unsigned p2 = 0;
+    int rc_next = lane == 0 ? ref[first] : 0;
+    const int steps = count + 63;
+    for (int t = 0; t < steps; ++t) {
+        const int i0 = dpp_up1(p0), i1 = dpp_up1(p1);
+        const unsigned i2 = (unsigned)dpp_up1((int)p2);
+        const int c = t - lane, rc = rc_next;
+        {
+            const int cn = c + 1;
+            rc_next = (cn >= 0 && cn < count) ? ref[first + cn * step] : 0;
+        }
+        if (c >= 0 && c < count) {
+            int dsrc = diag_in, fs = i0 >> 16, ff = i1;
+            unsigned key = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int diag = dsrc + (Q[k] == rc ? S_MATCH : MIS[k]);
+                dsrc = H[k];
+                fs &= SEG[k];
+                const int hs = max3i(diag, E[k], fs), h = max(hs, ff), hsgo = hs - GO;
+                E[k] = max3i(E[k] - GE, hsgo, 0);
+                fs = max3i(fs - GE, hsgo, 0);
+                ff = max3i(ff - GE, hsgo, 0);             // = max(ff - GE, h - GO, 0): ff - GO < ff - GE
+                H[k] = h;
+                key = max(key, ((unsigned)h << 12) | RINV[k]);
+            }
+            diag_in = i0 & 0xffff;
+            p0 = H[R - 1] | (fs << 16);
+            p1 = ff;
+            p2 = max(i2, key);
+            if (lane == 63) {
+                const int cm = (int)(p2 >> 12);
+                if (cm > run_max) {
+                    run_max = cm;
+                    if (lanes == 16 && run_max + BIAS >= 255) { overflow = 1; stop = 1; }
+                    else { end_ref = first + c * step; end_row = 4095 - (int)(p2 & 0xfffu); }
+                }
+                if (!stop && cm == terminate) stop = 1;
+            }
+        }
+        if (bcast63(stop)) break;
+    }
+    PassOut o;
+    o.overflow = bcast63(overflow);
+    const int rm = bcast63(run_max), er = bcast63(end_row);
+    o.score = o.overflow ? 255 : rm;
+    o.ref = bcast63(end_ref);
+    o.read = m - 1;
+    if (rm == 0) { if (m - 1 > 0) o.read = 0; }
+    else if (er < m - 1) o.read = er;
+    return o;
+}
+
+constexpr int REG_ROWS = 64 * 24;          // longest padded read the register-resident pass takes
+
+__device__ PassOut score_pass_any(uint32_t* he, const int8_t* __restrict__ ref, int first, int step, int count,
+                                  const int8_t* __restrict__ read, int rfirst, int rstep, int m, int lanes, int terminate) {
+    const int rows = ((m + lanes - 1) / lanes) * lanes, R = (rows + 63) >> 6;
+#define PA_PASS(N) return score_pass_reg<N>(ref, first, step, count, read, rfirst, rstep, m, lanes, terminate)
+    switch ((R + 1) >> 1) {
+        case 0: case 1: PA_PASS(2);
+        case 2: PA_PASS(4);
+        case 3: PA_PASS(6);
+        case 4: PA_PASS(8);
+        case 5: PA_PASS(10);
+        case 6: PA_PASS(12);
+        case 7: PA_PASS(14);
+        case 8: PA_PASS(16);
+        case 9: PA_PASS(18);
+        case 10: PA_PASS(20);
+        case 11: PA_PASS(22);
+        case 12: PA_PASS(24);
+        default: break;
+    }
+#undef PA_PASS
+    return score_pass(he, ref, first, step, count, read, rfirst, rstep, m, lanes, terminate);
+}
+
 __global__ __launch_bounds__(64) void sw_ends_kernel(Job* __restrict__ jobs, const int8_t* __restrict__ ref,
                                                      const int8_t* __restrict__ seq) {
     extern __shared__ uint32_t he[];
@@ -133,17 +246,23 @@ __global__ __launch_bounds__(64) void sw_ends_kernel(Job* __restrict__ jobs, con
     const int8_t* rf = ref + J.ref_off;
     const int8_t* rd = seq + J.seq_off;
     const int n = J.n, m = J.m;
-    PassOut f = score_pass(he, rf, 0, 1, n, rd, 0, 1, m, 16, -1);
-    int wide = 0;
-    if (f.overflow) {
-        f = score_pass(he, rf, 0, 1, n, rd, 0, 1, m, 8, -1);
-        wide = 1;
-    }
-    int ref_begin = -1, read_begin = -1;
-    if (f.score > 0 && f.ref >= 0) {
-        const PassOut r = score_pass(he, rf, f.ref, -1, f.ref + 1, rd, f.read, -1, f.read + 1, wide ? 8 : 16, f.score);
-        ref_begin = r.ref;
-        read_begin = f.read - r.read;
+    // pass 0: 8-bit segmentation; pass 1: 16-bit segmentation if pass 0 overflowed; pass 2: begin cell (reversed)
+    PassOut f = {0, 0, 0, 0};
+    int wide = 0, ref_begin = -1, read_begin = -1;
+    for (int pass = 0; pass < 3; ++pass) {
+        if (pass == 1 && !f.overflow) continue;
+        if (pass == 2 && !(f.score > 0 && f.ref >= 0)) continue;
+        const bool rev = pass == 2;
+        const PassOut o = score_pass_any(he, rf, rev ? f.ref : 0, rev ? -1 : 1, rev ? f.ref + 1 : n, rd, rev ? f.read : 0,
+                                         rev ? -1 : 1, rev ? f.read + 1 : m, (pass == 1 || (rev && wide)) ? 8 : 16,
+                                         rev ? f.score : -1);
+        if (rev) {
+            ref_begin = o.ref;
+            read_begin = f.read - o.read;
+        } else {
+            f = o;
+            wide = pass;
+        }
     }
     if (threadIdx.x == 0) {
         J.score = f.score; J.wide = wide; J.ref_end = f.ref; J.read_end = f.read;
@@ -156,19 +275,30 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
+// cap: ints per band array (hb, eb, hc); the bytes behind them hold the trace-back steps and the base codes of the
+// aligned windows (2 (m + n) + 2 bytes).  ops_counter: running number of operations written to opsws.
 __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const int8_t* __restrict__ ref,
                                                   const int8_t* __restrict__ seq, uint8_t* __restrict__ dirws,
-                                                  uint8_t* __restrict__ stepws, uint32_t* __restrict__ opsws, int cap) {
+                                                  uint32_t* __restrict__ opsws, unsigned long long* __restrict__ ops_counter,
+                                                  int cap) {
     extern __shared__ int sm[];
     Job& J = jobs[blockIdx.x];
     if (J.state != ST_BAND) return;
     const int lane = threadIdx.x;
     const int n = J.ref_end - J.ref_begin + 1, m = J.read_end - J.read_begin + 1, score = J.score;
-    const int8_t* rf = ref + J.ref_off + J.ref_begin;
-    const int8_t* rd = seq + J.seq_off + J.read_begin;
     int* hb = sm;
     int* eb = sm + cap;
     int* hc = sm + 2 * cap;
+    const int step_cap = m + n + 2;
+    uint8_t* steps = reinterpret_cast<uint8_t*>(sm + 3 * cap);
+    int8_t* lrf = reinterpret_cast<int8_t*>(steps + step_cap);
+    int8_t* lrd = lrf + n;
+    {
+        const int8_t* rf = ref + J.ref_off + J.ref_begin;
+        const int8_t* rd = seq + J.seq_off + J.read_begin;
+        for (int k = lane; k < n; k += 64) lrf[k] = rf[k];
+        for (int k = lane; k < m; k += 64) lrd[k] = rd[k];
+    }
     uint8_t* dir = dirws + J.dir_off;
     int bw = J.bw, stride = 0;
     for (;;) {
@@ -187,7 +317,7 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
             __syncthreads();
             if (lane == 0) { hb[0] = 0; eb[0] = 0; hb[edge] = 0; eb[edge] = 0; hc[0] = 0; }
             __syncthreads();
-            const int qi = rd[i];
+            const int qi = lrd[i];
             int carry_a = NEG, carry_h = 0, carry_f = 0;
             uint8_t* drow = dir + (size_t)i * stride;
             for (int base = 0; base < U; base += 64) {
@@ -198,7 +328,7 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
                     hbe = hb[u + sh];
                     ebe = eb[u + sh];
                     hbd = hb[u + sh - 1];
-                    rj = rf[x + u - 1];
+                    rj = lrf[x + u - 1];
                 }
                 const int t1 = i == 0 ? -GO : hbe - GO, t2 = i == 0 ? -GE : ebe - GE;
                 const int ecur = max(t1, t2), de = t1 > t2;
@@ -225,9 +355,11 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
                     drow[u - 1] = (uint8_t)(de | (df << 1) | (dh << 2));
                     best = max(best, hcur);
                 }
-                carry_a = max(carry_a, bcast63(pm));
-                carry_h = bcast63(hcur);
-                carry_f = bcast63(f);
+                if (base + 64 < U) {
+                    carry_a = max(carry_a, bcast63(pm));
+                    carry_h = bcast63(hcur);
+                    carry_f = bcast63(f);
+                }
             }
             __syncthreads();
             for (int u = 1 + lane; u <= U; u += 64) hb[u] = hc[u];
@@ -242,58 +374,88 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
     }
     __threadfence();
     __syncthreads();
-    if (lane != 0) return;
 
-    // trace back (ssw.c:653-703): state 2 = H, 0 = E (read gap open/extend), 1 = F
-    uint8_t* steps = stepws + J.steps_off;
-    const int step_cap = m + n + 2;
+    // trace back (ssw.c:653-703): state 2 = H, 0 = E, 1 = F.  Runs of diagonal moves are found 64 cells at a time (every
+    // lane probes one cell of the diagonal), gap cells one by one.
     int i = m - 1, j = n - 1, state = 2, ns = 0;
+    bool bad = false;
     while (i > 0) {
-        const int off = j - max(i - bw, 0);
-        if (off < 0 || off >= stride || ns >= step_cap) { J.state = ST_ERR; return; }
-        const int d = dir[(size_t)i * stride + off];
-        const int code = state == 2 ? (d >> 2) : (state == 0 ? ((d & 1) ? 3 : 2) : ((d & 2) ? 5 : 4));
-        int op;
+        int code;
+        if (state == 2) {
+            const int ii = i - lane, jj = j - lane;
+            int probe = 0;
+            if (ii > 0) {
+                const int off = jj - max(ii - bw, 0);
+                if (off >= 0 && off < stride) probe = dir[(size_t)ii * stride + off] >> 2;
+            }
+            const unsigned long long other = __ballot(probe != 1);
+            const int run = other ? (int)__builtin_ctzll(other) : 64;
+            if (run > 0) {
+                if (ns + run > step_cap) { bad = true; break; }
+                if (lane < run) steps[ns + lane] = 0;
+                ns += run; i -= run; j -= run;
+                if (i <= 0) break;
+                if (run == 64) continue;
+            }
+            code = __shfl(probe, run, 64);
+            if (code == 0) { bad = true; break; }
+        } else {
+            const int off = j - max(i - bw, 0);
+            if (off < 0 || off >= stride) { bad = true; break; }
+            const int d = dir[(size_t)i * stride + off];
+            code = state == 0 ? ((d & 1) ? 3 : 2) : ((d & 2) ? 5 : 4);
+        }
+        int op = 0;
         switch (code) {
             case 1: --i; --j; state = 2; op = 0; break;
             case 2: --i; state = 0; op = OP_I; break;
             case 3: --i; state = 2; op = OP_I; break;
             case 4: --j; state = 1; op = OP_D; break;
             case 5: --j; state = 2; op = OP_D; break;
-            default: J.state = ST_ERR; return;
+            default: bad = true; break;
         }
-        steps[ns++] = (uint8_t)op;
+        if (bad || ns >= step_cap) { bad = true; break; }
+        if (lane == 0) steps[ns] = (uint8_t)op;
+        ++ns;
     }
+    __syncthreads();
+    if (lane != 0) return;
+    if (bad) { J.state = ST_ERR; return; }
+
     // operations in alignment order: soft clip, the first cell, the steps backwards, soft clip; aligned pairs are
-    // classified by comparing base codes from the begin cell on (ssw_cpp.cpp:126-207)
-    uint32_t* ops = opsws + J.ops_off;
-    const int8_t* rfull = ref + J.ref_off;
-    const int8_t* rdfull = seq + J.seq_off;
-    int no = 0, cur = -1, len = 0, rp = J.ref_begin, qp = J.read_begin;
-    const int ocap = J.ops_cap;
-    auto put = [&](int op, int l) { if (no < ocap) ops[no] = ((uint32_t)l << 4) | (uint32_t)op; ++no; };
-    auto emit = [&](int op) {
-        if (op == cur) { ++len; return; }
-        if (len) put(cur, len);
-        cur = op; len = 1;
-    };
-    if (J.read_begin > 0) put(OP_S, J.read_begin);
-    for (int s = ns; s >= 0; --s) {
-        const int op = s == ns ? 0 : steps[s];
-        if (op == 0) {
-            emit(rfull[rp] == rdfull[qp] ? OP_EQ : OP_X);
-            ++rp; ++qp;
-        } else if (op == OP_I) {
-            emit(OP_I); ++qp;
-        } else {
-            emit(OP_D); ++rp;
+    // classified by comparing base codes from the begin cell on (ssw_cpp.cpp:126-207).  First walk counts, then the
+    // output range is reserved, then the second walk writes.
+    auto walk = [&](uint32_t* dst) {
+        int no = 0, cur = -1, len = 0, rp = 0, qp = 0;
+        auto put = [&](int op, int l) { if (dst) dst[no] = ((uint32_t)l << 4) | (uint32_t)op; ++no; };
+        auto emit = [&](int op) {
+            if (op == cur) { ++len; return; }
+            if (len) put(cur, len);
+            cur = op; len = 1;
+        };
+        if (J.read_begin > 0) put(OP_S, J.read_begin);
+        for (int s = ns; s >= 0; --s) {
+            const int op = s == ns ? 0 : steps[s];
+            if (op == 0) {
+                emit(lrf[rp] == lrd[qp] ? OP_EQ : OP_X);
+                ++rp; ++qp;
+            } else if (op == OP_I) {
+                emit(OP_I); ++qp;
+            } else {
+                emit(OP_D); ++rp;
+            }
         }
-    }
-    if (len) put(cur, len);
-    if (J.m - J.read_end - 1 > 0) put(OP_S, J.m - J.read_end - 1);
+        if (len) put(cur, len);
+        if (J.m - J.read_end - 1 > 0) put(OP_S, J.m - J.read_end - 1);
+        return no;
+    };
+    const int no = walk(nullptr);
+    const unsigned long long at = atomicAdd(ops_counter, (unsigned long long)no);
+    walk(opsws + at);
+    J.ops_off = (int64_t)at;
     J.n_ops = no;
     J.bw = bw;
-    J.state = no <= ocap ? ST_DONE : ST_ERR;
+    J.state = ST_DONE;
 }
 
 struct DBuf {
@@ -328,10 +490,13 @@ struct pa_realigner {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DBuf d_ref, d_seq, d_jobs, d_dir, d_steps, d_ops;
+    DBuf d_ref, d_seq, d_jobs, d_dir, d_ops, d_counter;
     std::vector<Job> jobs;
     std::vector<uint32_t> ops;
     int64_t total_ops = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};     // around the score kernel, around the band launches
+    double ends_ms = 0.0, band_ms = 0.0;
+    int64_t cells = 0;                                           // DP cells of the score passes of the last call (n x m per read)
 };
 
 #define RA_HIP(expr)                                                                                    \
@@ -363,6 +528,8 @@ int pa_realigner_create(int32_t device, void* hip_stream, pa_realigner** out) {
         }
         r->own_stream = true;
     }
+    for (auto& e : r->ev)
+        if (hipEventCreate(&e) != hipSuccess) { pa_realigner_destroy(r); return pa::set_error(PA_ERR_HIP, "hipEventCreate failed"); }
     *out = r;
     return PA_OK;
 }
@@ -371,6 +538,8 @@ void pa_realigner_destroy(pa_realigner* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     if (r->stream) (void)hipStreamSynchronize(r->stream);
+    for (auto& e : r->ev)
+        if (e) (void)hipEventDestroy(e);
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -386,6 +555,8 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
     RA_HIP(hipSetDevice(r->device));
     r->jobs.assign((size_t)n_reads, Job());
     r->total_ops = 0;
+    r->ends_ms = r->band_ms = 0.0;
+    r->cells = 0;
     *n_cigar_ops = 0;
     if (n_reads == 0) return PA_OK;
 
@@ -410,6 +581,7 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
             return pa::set_error(PA_ERR_INVALID, "read " + std::to_string(k) + " has " + std::to_string(m) +
                                  " bases: the re-aligner handles region-clipped reads up to " + std::to_string(MAX_READ));
         J.state = ST_NEW;
+        r->cells += (int64_t)J.n * J.m;
         max_m = std::max(max_m, J.m);
         any = true;
     }
@@ -441,29 +613,33 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
     const int8_t* dref = static_cast<const int8_t*>(r->d_ref.p);
     const int8_t* dseq = static_cast<const int8_t*>(r->d_seq.p);
     {
+        // LDS only for reads too long for the register-resident pass (one dword per padded row)
         const int rows = ((max_m + 15) / 16) * 16, R = (rows + 63) / 64;
-        hipLaunchKernelGGL(sw_ends_kernel, dim3(n_reads), dim3(64), (size_t)64 * R * 4, r->stream, dj, dref, dseq);
+        const size_t lds = rows > REG_ROWS ? (size_t)64 * R * 4 : 0;
+        RA_HIP(hipEventRecord(r->ev[0], r->stream));
+        hipLaunchKernelGGL(sw_ends_kernel, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq);
         RA_HIP(hipGetLastError());
+        RA_HIP(hipEventRecord(r->ev[1], r->stream));
     }
     RA_HIP(hipMemcpyAsync(r->jobs.data(), dj, sizeof(Job) * (size_t)n_reads, hipMemcpyDeviceToHost, r->stream));
     RA_HIP(hipStreamSynchronize(r->stream));
 
     // band stage: workspace layout, first with rows of at most 129 slots (band half width <= 64), then full rows
-    int64_t ops_total = 0, steps_total = 0;
+    int64_t ops_total = 0;
+    int aux = 0;
     for (Job& J : r->jobs) {
         if (J.state != ST_NEW) continue;
         if (J.score <= 1 || J.ref_begin < 0) { J.state = ST_KEPT; continue; }     // simple_aligner.cpp:85
         const int n2 = J.ref_end - J.ref_begin + 1, m2 = J.read_end - J.read_begin + 1;
         J.state = ST_BAND;
         J.bw = std::abs(n2 - m2) + 1;
-        J.ops_off = ops_total;
         J.ops_cap = n2 + m2 + 4;
         ops_total += J.ops_cap;
-        J.steps_off = steps_total;
-        steps_total += n2 + m2 + 2;
+        aux = std::max(aux, 2 * (n2 + m2) + 2);
     }
     RA_ALLOC(r->d_ops, sizeof(uint32_t) * (size_t)std::max<int64_t>(ops_total, 1));
-    RA_ALLOC(r->d_steps, (size_t)std::max<int64_t>(steps_total, 1));
+    RA_ALLOC(r->d_counter, 8);
+    RA_HIP(hipMemsetAsync(r->d_counter.p, 0, 8, r->stream));
     for (int round = 0; round < 3; ++round) {
         int64_t dir_total = 0;
         int cap = 0, pending = 0;
@@ -480,18 +656,27 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
             ++pending;
         }
         if (!pending) break;
-        if ((size_t)cap * 12 > 150 * 1024) return pa::set_error(PA_ERR_INVALID, "alignment too long for the band stage");
+        const size_t lds = (size_t)cap * 12 + (size_t)aux + 16;
+        if (lds > 150 * 1024) return pa::set_error(PA_ERR_INVALID, "alignment too long for the band stage");
         RA_ALLOC(r->d_dir, (size_t)std::max<int64_t>(dir_total, 1));
         RA_HIP(hipMemcpyAsync(dj, r->jobs.data(), sizeof(Job) * (size_t)n_reads, hipMemcpyHostToDevice, r->stream));
-        if ((size_t)cap * 12 > 64 * 1024)
+        if (lds > 64 * 1024)
             RA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       cap * 12));
-        hipLaunchKernelGGL(band_kernel, dim3(n_reads), dim3(64), (size_t)cap * 12, r->stream, dj, dref, dseq,
-                           static_cast<uint8_t*>(r->d_dir.p), static_cast<uint8_t*>(r->d_steps.p),
-                           static_cast<uint32_t*>(r->d_ops.p), cap);
+                                       (int)lds));
+        RA_HIP(hipEventRecord(r->ev[2], r->stream));
+        hipLaunchKernelGGL(band_kernel, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq,
+                           static_cast<uint8_t*>(r->d_dir.p), static_cast<uint32_t*>(r->d_ops.p),
+                           static_cast<unsigned long long*>(r->d_counter.p), cap);
         RA_HIP(hipGetLastError());
+        RA_HIP(hipEventRecord(r->ev[3], r->stream));
         RA_HIP(hipMemcpyAsync(r->jobs.data(), dj, sizeof(Job) * (size_t)n_reads, hipMemcpyDeviceToHost, r->stream));
         RA_HIP(hipStreamSynchronize(r->stream));
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r->ev[2], r->ev[3]) == hipSuccess) r->band_ms += ms;
+    }
+    {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r->ev[0], r->ev[1]) == hipSuccess) r->ends_ms = ms;
     }
     for (int32_t k = 0; k < n_reads; ++k) {
         const Job& J = r->jobs[(size_t)k];
@@ -499,14 +684,25 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
             return pa::set_error(PA_ERR_INVALID, "read " + std::to_string(k) + ": the band stage did not reach the alignment score "
                                  "(the reference library aborts on such an alignment)");
     }
-    r->ops.resize((size_t)ops_total);
-    if (ops_total)
-        RA_HIP(hipMemcpyAsync(r->ops.data(), r->d_ops.p, sizeof(uint32_t) * (size_t)ops_total, hipMemcpyDeviceToHost, r->stream));
+    unsigned long long written = 0;
+    RA_HIP(hipMemcpyAsync(&written, r->d_counter.p, 8, hipMemcpyDeviceToHost, r->stream));
+    RA_HIP(hipStreamSynchronize(r->stream));
+    r->ops.resize((size_t)written);
+    if (written)
+        RA_HIP(hipMemcpyAsync(r->ops.data(), r->d_ops.p, sizeof(uint32_t) * (size_t)written, hipMemcpyDeviceToHost, r->stream));
     RA_HIP(hipStreamSynchronize(r->stream));
     for (const Job& J : r->jobs)
         if (J.state == ST_DONE) r->total_ops += J.n_ops;
     *n_cigar_ops = r->total_ops;
     finish_outputs();
+    return PA_OK;
+}
+
+int pa_realigner_last_timing(pa_realigner* r, double* score_kernel_ms, double* band_kernel_ms, int64_t* cells) {
+    if (!r) return pa::set_error(PA_ERR_INVALID, "null argument");
+    if (score_kernel_ms) *score_kernel_ms = r->ends_ms;
+    if (band_kernel_ms) *band_kernel_ms = r->band_ms;
+    if (cells) *cells = r->cells;
     return PA_OK;
 }
 

@@ -2,8 +2,8 @@
 
 Mirrors /root/reference/pepper/modules/python/AlignmentSummarizer.py:18-56 (chunk_images) and
 :296-358 (read fetch, reservoir sampling to 1500 reads, reference fetch, SummaryGenerator,
-chunking).  SSW re-alignment (`realignment_flag`) is a separate striped Smith-Waterman stage
-upstream of the encoder and is out of scope: reads are encoded as given.
+chunking) and :159-177 (reads_to_reference_realignment: every read re-aligned to the draft before it is
+summarised, on by default; the alignments run on the GPU, include/pepper_amd_realign.h).
 """
 import numpy as np
 
@@ -12,7 +12,8 @@ from pepper_amd.polish.Options import ImageSizeOptions
 
 
 class AlingerOptions(object):
-    MAX_READS_IN_REGION = 1500     # pepper Options.py:27-29
+    ALIGNMENT_SAFE_BASES = 20      # pepper Options.py:23-29
+    MAX_READS_IN_REGION = 1500
     RANDOM_SEED = 2719747673
 
 
@@ -51,16 +52,21 @@ class AlignmentSummarizer:
             chunk_end = min(total, chunk_start + chunk_size)
         return images, labels, positions, chunk_ids
 
-    def create_summary(self, truth_bam_handler=None, train_mode=False, downsample_rate=1.0, realignment_flag=False):
-        """Argument order of the reference (AlignmentSummarizer.py:179).  NOTE: the reference defaults
-        realignment_flag to True -- its image generation re-aligns every read to the draft with striped
-        Smith-Waterman (reads_to_reference_realignment, simple_aligner.cpp + ssw.c) before encoding.  That stage
-        is not provided: pass realignment_flag=False and reads are encoded as
+    def reads_to_reference_realignment(self, region_start, region_end, reads):
+        """Local re-alignment of the reads to the reference (AlignmentSummarizer.py:159-177)."""
+        if len(reads) == 0:
+            return reads
+        ref_start, ref_end = region_start, region_end + AlingerOptions.ALIGNMENT_SAFE_BASES
+        ref_sequence = self.fasta_handler.get_reference_sequence(self.chromosome_name, ref_start, ref_end)
+        aligner = PEPPER.ReadAligner(ref_start, ref_end, ref_sequence)
+        return aligner.align_reads_to_reference(reads)
+
+    def create_summary(self, truth_bam_handler=None, train_mode=False, downsample_rate=1.0, realignment_flag=True):
+        """Argument order and defaults of the reference (AlignmentSummarizer.py:179): with realignment_flag (the
+        default) every read is re-aligned to the draft before encoding; realignment_flag=False encodes the reads as
         aligned in the BAM."""
         if train_mode:
             raise NotImplementedError("train_mode image generation is outside the inference path")
-        if realignment_flag:
-            raise NotImplementedError("SSW re-alignment is out of scope (SURVEY.md 2.2 P6)")
         read_start = max(0, self.region_start_position)
         read_end = self.region_end_position
         all_reads = self.bam_handler.get_reads(self.chromosome_name, read_start, read_end, False, 0, 0)
@@ -79,6 +85,8 @@ class AlignmentSummarizer:
                     if j < AlingerOptions.MAX_READS_IN_REGION:
                         sample[j] = i
             all_reads = all_reads.take(sample) if flat else [all_reads[i] for i in sample]
+        if realignment_flag:
+            all_reads = self.reads_to_reference_realignment(self.region_start_position, self.region_end_position, all_reads)
         if flat:
             all_reads = all_reads.as_pileup()
         ref_seq = self.fasta_handler.get_reference_sequence(self.chromosome_name, self.region_start_position,

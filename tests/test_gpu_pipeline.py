@@ -339,8 +339,8 @@ def test_call_variant_from_bam_and_fasta_files(tmp_path):
 
 def test_polish_create_summary_from_bam(tmp_path):
     """Polish image generation for one region straight from a BAM + FASTA on disk (the same native reader; the
-    reference's get_reads is identical for both tools) against the oracle encoder on restated clipped reads.
-    realignment_flag=False: the reference's default SSW re-alignment stage is not part of this package."""
+    reference's get_reads is identical for both tools) against the oracle legs on restated clipped reads: without
+    the re-alignment stage, and with it (the reference's default; oracle = SSW restatement + oracle encoder)."""
     import bam_utils as bu
     import pileup_utils as pu
     from pepper_amd.polish.AlignmentSummarizer import AlignmentSummarizer
@@ -367,4 +367,22 @@ def test_polish_create_summary_from_bam(tmp_path):
     want = AlignmentSummarizer.chunk_images(SimpleNamespace(image=img, genomic_pos=pos), 1000, 50)
     assert len(want[0]) == len(images)
     for got_i, want_i, got_p, want_p in zip(images, want[0], positions, want[2]):
+        assert np.array_equal(got_i, want_i) and np.array_equal(got_p, want_p)
+
+    # default call = with re-alignment (AlignmentSummarizer.py:179,328-332)
+    from oracle import ssw
+    images_r, _, positions_r, _ = summ.create_summary(None, False, 1.0)
+    ref_win = ref[start:end + 20]
+    res = ssw.realign_reads(ref_win, start, [r["pos"] for r in clipped], [r["seq"] for r in clipped])
+    realigned = []
+    for r, (st, score, p, pe, ops) in zip(clipped, res):
+        assert st >= 0
+        if st == 1:
+            r = dict(r, pos=p, cigar=[(0 if o in (7, 8) else o, n) for o, n in ops])
+        realigned.append(r)
+    assert sum(st == 1 for st, *_ in res) > 0.9 * len(clipped)
+    img, pos = pu.run_polish_oracle(oracle, pu.FlatPileup(start, end, ref[start:end + 1], realigned), start, end)
+    want = AlignmentSummarizer.chunk_images(SimpleNamespace(image=img, genomic_pos=pos), 1000, 50)
+    assert len(want[0]) == len(images_r)
+    for got_i, want_i, got_p, want_p in zip(images_r, want[0], positions_r, want[2]):
         assert np.array_equal(got_i, want_i) and np.array_equal(got_p, want_p)
