@@ -35,6 +35,7 @@
 #include <string>
 #include <vector>
 
+#include "common.h"
 #include "kernels.h"
 
 namespace {
@@ -54,6 +55,14 @@ struct Job {
     int64_t dir_off, ops_off, steps_off;
     int32_t ops_cap, n_ops;
 };
+
+// base text -> codes in place (ssw_cpp.cpp:10-19: A/a 0, C/c 1, G/g 2, T/t 3, U/u 0, everything else 4)
+__global__ void to_codes_kernel(int8_t* __restrict__ buf, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int c = buf[k] & 0xdf;
+    buf[k] = (int8_t)(c == 'A' || c == 'U' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4);
+}
 
 __device__ __forceinline__ int bcast63(int v) { return __builtin_amdgcn_readlane(v, 63); }
 
@@ -129,6 +138,19 @@ __device__ __forceinline__ int dpp_up1(int v) {          // lane l <- lane l - 1
     return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);
 }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __forceinline__ int dpp_up1_or(int v, int lane0) {      // same, lane 0 <- lane0
+    return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xf, 0xf, false);
+}
+// inclusive prefix maximum across the wavefront on the DPP network (row shifts inside 16-lane rows, then row broadcasts)
+__device__ __forceinline__ int wave_prefix_max(int v, int identity) {
+    v = max(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    v = max(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
 
 // The same pass with the lane's strip of R rows resident in registers (reads of up to 64 R rows): per cell 15 vector
 // ops and no LDS traffic; the hand-off to the next lane is three DPP moves (H | segment-local gap chain, exact gap
@@ -270,13 +292,27 @@ __global__ __launch_bounds__(64) void sw_ends_kernel(Job* __restrict__ jobs, con
     }
 }
 
+// inclusive prefix sum across the wavefront (same DPP pattern as wave_prefix_max)
+__device__ __forceinline__ int wave_prefix_add(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+// One wavefront per workgroup: LDS instructions of a wavefront execute in issue order, so cross-lane hand-offs through
+// LDS only need the compiler to keep the program order.
+__device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory"); }
+
 __device__ __forceinline__ int wave_max(int v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
     return v;
 }
 
-// cap: ints per band array (hb, eb, hc); the bytes behind them hold the trace-back steps and the base codes of the
-// aligned windows (2 (m + n) + 2 bytes).  ops_counter: running number of operations written to opsws.
+// cap: ints per band array (hb, eb, hc); the bytes behind them hold the trace-back steps, the base codes of the
+// aligned windows and the per-step operation classes (3 (m + n) + 4 bytes).  ops_counter: running number of operations written to opsws.
 __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const int8_t* __restrict__ ref,
                                                   const int8_t* __restrict__ seq, uint8_t* __restrict__ dirws,
                                                   uint32_t* __restrict__ opsws, unsigned long long* __restrict__ ops_counter,
@@ -293,6 +329,7 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
     uint8_t* steps = reinterpret_cast<uint8_t*>(sm + 3 * cap);
     int8_t* lrf = reinterpret_cast<int8_t*>(steps + step_cap);
     int8_t* lrd = lrf + n;
+    uint8_t* cls = reinterpret_cast<uint8_t*>(lrd + m);
     {
         const int8_t* rf = ref + J.ref_off + J.ref_begin;
         const int8_t* rd = seq + J.seq_off + J.read_begin;
@@ -314,9 +351,9 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
         for (int i = 0; i < m; ++i) {
             const int x = max(i - bw, 0), xp = max(i - 1 - bw, 0), sh = x - xp;
             const int end = min(n - 1, i + bw), U = end - x + 1, edge = min(end + 1, width - 1);
-            __syncthreads();
+            wave_lds_order();
             if (lane == 0) { hb[0] = 0; eb[0] = 0; hb[edge] = 0; eb[edge] = 0; hc[0] = 0; }
-            __syncthreads();
+            wave_lds_order();
             const int qi = lrd[i];
             int carry_a = NEG, carry_h = 0, carry_f = 0;
             uint8_t* drow = dir + (size_t)i * stride;
@@ -335,23 +372,19 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
                 const int diag = hbd + ((rj == qi && qi < 4) ? S_MATCH : -S_MIS);
                 const int e1 = max(ecur, 0), g = max(e1, diag);
                 // vertical-gap chain of the row: f(u) = max(-GE u, max_{v<u} (g(v) + GE v) - GO - GE (u - 1))
-                int pm = valid ? g + u * GE : NEG;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int v = __shfl_up(pm, o, 64);
-                    if (lane >= o) pm = max(pm, v);
-                }
-                int ex = __shfl_up(pm, 1, 64);
-                ex = lane == 0 ? carry_a : max(ex, carry_a);
+                const int pm = wave_prefix_max(valid ? g + u * GE : NEG, NEG);
+                const int ex = max(dpp_up1_or(pm, NEG), carry_a);
                 const int f = max(-GE * u, ex - GO - (u - 1) * GE);
                 const int f1 = max(f, 0), hcur = max(g, f1);
-                int hl = __shfl_up(hcur, 1, 64), fl = __shfl_up(f, 1, 64);
-                if (lane == 0) { hl = carry_h; fl = carry_f; }
+                const int hl = dpp_up1_or(hcur, carry_h), fl = dpp_up1_or(f, carry_f);
                 const int df = (hl - GO) > (fl - GE);
                 const int gap = max(e1, f1);
                 const int dh = gap <= diag ? 1 : (e1 > f1 ? (de ? 3 : 2) : (df ? 5 : 4));
+                wave_lds_order();                 // every lane has read the previous row's slots of this chunk
                 if (valid) {
                     eb[u] = ecur;
-                    hc[u] = hcur;
+                    if (U <= 64) hb[u] = hcur;      // single chunk: no other chunk still needs the previous row
+                    else hc[u] = hcur;
                     drow[u - 1] = (uint8_t)(de | (df << 1) | (dh << 2));
                     best = max(best, hcur);
                 }
@@ -361,8 +394,9 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
                     carry_f = bcast63(f);
                 }
             }
-            __syncthreads();
-            for (int u = 1 + lane; u <= U; u += 64) hb[u] = hc[u];
+            wave_lds_order();
+            if (U > 64)
+                for (int u = 1 + lane; u <= U; u += 64) hb[u] = hc[u];
         }
         best = wave_max(best);
         if (best >= score) break;
@@ -373,7 +407,6 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
         bw *= 2;
     }
     __threadfence();
-    __syncthreads();
 
     // trace back (ssw.c:653-703): state 2 = H, 0 = E, 1 = F.  Runs of diagonal moves are found 64 cells at a time (every
     // lane probes one cell of the diagonal), gap cells one by one.
@@ -418,44 +451,70 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
         if (lane == 0) steps[ns] = (uint8_t)op;
         ++ns;
     }
-    __syncthreads();
-    if (lane != 0) return;
-    if (bad) { J.state = ST_ERR; return; }
+    wave_lds_order();
+    if (bad) {
+        if (lane == 0) J.state = ST_ERR;
+        return;
+    }
 
-    // operations in alignment order: soft clip, the first cell, the steps backwards, soft clip; aligned pairs are
-    // classified by comparing base codes from the begin cell on (ssw_cpp.cpp:126-207).  First walk counts, then the
-    // output range is reserved, then the second walk writes.
-    auto walk = [&](uint32_t* dst) {
-        int no = 0, cur = -1, len = 0, rp = 0, qp = 0;
-        auto put = [&](int op, int l) { if (dst) dst[no] = ((uint32_t)l << 4) | (uint32_t)op; ++no; };
-        auto emit = [&](int op) {
-            if (op == cur) { ++len; return; }
-            if (len) put(cur, len);
-            cur = op; len = 1;
-        };
-        if (J.read_begin > 0) put(OP_S, J.read_begin);
-        for (int s = ns; s >= 0; --s) {
-            const int op = s == ns ? 0 : steps[s];
-            if (op == 0) {
-                emit(lrf[rp] == lrd[qp] ? OP_EQ : OP_X);
-                ++rp; ++qp;
-            } else if (op == OP_I) {
-                emit(OP_I); ++qp;
-            } else {
-                emit(OP_D); ++rp;
-            }
+    // Operations in alignment order: soft clip, the first cell, the steps backwards, soft clip; aligned pairs are
+    // classified by comparing base codes from the begin cell on (ssw_cpp.cpp:126-207).  Wavefront-parallel: positions
+    // from prefix sums, classes to LDS, run starts counted, output range reserved, runs written, lengths filled in.
+    const int total = ns + 1;                                  // cells of the path, the begin cell first
+    int carry_r = 0, carry_q = 0;
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        const bool valid = t < total;
+        const int op = (!valid || t == 0) ? 0 : steps[ns - t];
+        const int cr = valid && op != OP_I, cq = valid && op != OP_D;
+        const int pr = wave_prefix_add(cr), pq = wave_prefix_add(cq);
+        if (valid) {
+            const int rp = carry_r + pr - cr, qp = carry_q + pq - cq;
+            cls[t] = (uint8_t)(op == 0 ? (lrf[rp] == lrd[qp] ? OP_EQ : OP_X) : op);
         }
-        if (len) put(cur, len);
-        if (J.m - J.read_end - 1 > 0) put(OP_S, J.m - J.read_end - 1);
-        return no;
-    };
-    const int no = walk(nullptr);
-    const unsigned long long at = atomicAdd(ops_counter, (unsigned long long)no);
-    walk(opsws + at);
-    J.ops_off = (int64_t)at;
-    J.n_ops = no;
-    J.bw = bw;
-    J.state = ST_DONE;
+        carry_r += bcast63(pr);
+        carry_q += bcast63(pq);
+    }
+    wave_lds_order();
+    int nruns = 0;
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        const bool start = t < total && (t == 0 || cls[t] != cls[t - 1]);
+        nruns += __popcll(__ballot(start));
+    }
+    const int lead = J.read_begin > 0, trail = J.m - J.read_end - 1 > 0, no = lead + nruns + trail;
+    unsigned long long at = 0;
+    if (lane == 0) at = atomicAdd(ops_counter, (unsigned long long)no);
+    at = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) |
+         (unsigned)__builtin_amdgcn_readfirstlane((int)(at & 0xffffffffu));
+    uint32_t* ops = opsws + at;
+    int carry_s = 0;
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        const int start = t < total && (t == 0 || cls[t] != cls[t - 1]);
+        const int ps = wave_prefix_add(start);
+        if (start) ops[lead + carry_s + ps - 1] = (uint32_t)cls[t] | ((uint32_t)t << 4);     // run start for now
+        carry_s += bcast63(ps);
+    }
+    __threadfence();
+    for (int k0 = 0; k0 < nruns; k0 += 64) {
+        const int k = k0 + lane;
+        uint32_t a = 0, next = (uint32_t)total;
+        if (k < nruns) {
+            a = ops[lead + k];
+            if (k + 1 < nruns) next = ops[lead + k + 1] >> 4;
+        }
+        wave_lds_order();
+        if (k < nruns) ops[lead + k] = (a & 15u) | ((next - (a >> 4)) << 4);
+    }
+    if (lane == 0) {
+        if (lead) ops[0] = (uint32_t)OP_S | ((uint32_t)J.read_begin << 4);
+        if (trail) ops[no - 1] = (uint32_t)OP_S | ((uint32_t)(J.m - J.read_end - 1) << 4);
+        J.ops_off = (int64_t)at;
+        J.n_ops = no;
+        J.bw = bw;
+        J.state = ST_DONE;
+    }
 }
 
 struct DBuf {
@@ -473,16 +532,6 @@ struct DBuf {
     }
     ~DBuf() { if (p) (void)hipFree(p); }
 };
-
-inline int8_t base_code(char c) {                 // ssw_cpp.cpp:10-19
-    switch (c) {
-        case 'A': case 'a': case 'U': case 'u': return 0;   // the table sends U to 0 as well
-        case 'C': case 'c': return 1;
-        case 'G': case 'g': return 2;
-        case 'T': case 't': return 3;
-        default: return 4;
-    }
-}
 
 }  // namespace
 
@@ -599,16 +648,18 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
     };
     if (!any) { finish_outputs(); return PA_OK; }
 
-    // base text -> codes, upload
-    std::vector<int8_t> codes((size_t)reference_len + (size_t)total_seq);
-    for (int64_t k = 0; k < reference_len; ++k) codes[(size_t)k] = base_code(reference[k]);
-    for (int64_t k = 0; k < total_seq; ++k) codes[(size_t)(reference_len + k)] = base_code(seq[k]);
+    // upload the text, turn it into base codes on the device
     RA_ALLOC(r->d_ref, (size_t)reference_len + 64);
     RA_ALLOC(r->d_seq, (size_t)total_seq + 64);
     RA_ALLOC(r->d_jobs, sizeof(Job) * (size_t)n_reads);
-    RA_HIP(hipMemcpyAsync(r->d_ref.p, codes.data(), (size_t)reference_len, hipMemcpyHostToDevice, r->stream));
-    RA_HIP(hipMemcpyAsync(r->d_seq.p, codes.data() + reference_len, (size_t)total_seq, hipMemcpyHostToDevice, r->stream));
+    RA_HIP(hipMemcpyAsync(r->d_ref.p, reference, (size_t)reference_len, hipMemcpyHostToDevice, r->stream));
+    RA_HIP(hipMemcpyAsync(r->d_seq.p, seq, (size_t)total_seq, hipMemcpyHostToDevice, r->stream));
     RA_HIP(hipMemcpyAsync(r->d_jobs.p, r->jobs.data(), sizeof(Job) * (size_t)n_reads, hipMemcpyHostToDevice, r->stream));
+    hipLaunchKernelGGL(to_codes_kernel, dim3((unsigned)((reference_len + 255) / 256)), dim3(256), 0, r->stream,
+                       static_cast<int8_t*>(r->d_ref.p), reference_len);
+    hipLaunchKernelGGL(to_codes_kernel, dim3((unsigned)((total_seq + 255) / 256)), dim3(256), 0, r->stream,
+                       static_cast<int8_t*>(r->d_seq.p), total_seq);
+    RA_HIP(hipGetLastError());
     Job* dj = static_cast<Job*>(r->d_jobs.p);
     const int8_t* dref = static_cast<const int8_t*>(r->d_ref.p);
     const int8_t* dseq = static_cast<const int8_t*>(r->d_seq.p);
@@ -635,7 +686,7 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
         J.bw = std::abs(n2 - m2) + 1;
         J.ops_cap = n2 + m2 + 4;
         ops_total += J.ops_cap;
-        aux = std::max(aux, 2 * (n2 + m2) + 2);
+        aux = std::max(aux, 3 * (n2 + m2) + 4);
     }
     RA_ALLOC(r->d_ops, sizeof(uint32_t) * (size_t)std::max<int64_t>(ops_total, 1));
     RA_ALLOC(r->d_counter, 8);
