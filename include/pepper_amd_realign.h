@@ -59,6 +59,10 @@ int pa_realigner_copy_cigars(pa_realigner* r, int32_t collapse_eqx, int64_t* cig
  * aligned reads) one score pass visits.  Any pointer may be NULL. */
 int pa_realigner_last_timing(pa_realigner* r, double* score_kernel_ms, double* band_kernel_ms, int64_t* cells);
 
+/* Per-read stage times of the last call in 10 ns ticks, ticks4[4 k .. 4 k + 3] = score passes, band DP (all widths),
+ * trace-back, CIGAR emission (tools/realign_stages.py). */
+int pa_realigner_stage_ticks(pa_realigner* r, int32_t* ticks4);
+
 #ifdef __cplusplus
 }
 #endif

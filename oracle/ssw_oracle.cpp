@@ -95,10 +95,12 @@ EndCell score_pass(const std::vector<int8_t>& ref, int first, int step, int coun
 }
 
 struct RawOp { char op; int len; };
+thread_local int g_band_first = 0, g_band_final = 0;     // diagnostics of the last banded_path call
 
 // Banded DP + trace-back over ref[0..n) x read[0..m); returns M/I/D runs in alignment order.
 bool banded_path(const int8_t* ref, const int8_t* read, int n, int m, int score, std::vector<RawOp>& ops) {
     int bw = std::abs(n - m) + 1;
+    g_band_first = bw;
     std::vector<int> hb, eb, hc;
     std::vector<int8_t> dir;
     int width_d = 0;
@@ -142,6 +144,7 @@ bool banded_path(const int8_t* ref, const int8_t* read, int n, int m, int score,
         if (best >= score) break;
         bw *= 2;
     }
+    g_band_final = bw;
     // trace back from the bottom-right corner (ssw.c:653-703)
     int i = m - 1, j = n - 1, run = 0, state = 2;
     char op = 'M', prev = 'M';
@@ -168,6 +171,11 @@ bool banded_path(const int8_t* ref, const int8_t* read, int n, int m, int score,
 }
 
 }  // namespace
+
+extern "C" void ssw_oracle_last_band(int32_t* first, int32_t* final_width) {
+    *first = g_band_first;
+    *final_width = g_band_final;
+}
 
 // out[0..5] = score, ref_begin, ref_end, query_begin, query_end, wide (1: the 16-bit pass produced the result)
 // returns 1 on success (cigar text written), 0 when the library would not have aligned (empty inputs), -1 on error

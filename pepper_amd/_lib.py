@@ -71,6 +71,7 @@ SYMBOLS = [
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           ctypes.POINTER(c_int64)]),
     ("pa_realigner_copy_cigars", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    ("pa_realigner_stage_ticks", ctypes.c_int, [c_void_p, c_void_p]),
     ("pa_realigner_last_timing", ctypes.c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double),
                                                 ctypes.POINTER(c_int64)]),
 ]

@@ -31,6 +31,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,6 +57,7 @@ struct Job {
     int32_t bw, dir_width;         // band half width to try next; row capacity of the direction workspace
     int64_t dir_off, ops_off, steps_off;
     int32_t ops_cap, n_ops;
+    int32_t t_ends, t_dp, t_trace, t_emit;   // stage times of this read in 10 ns ticks (s_memtime), for tools/realign_stages.py
 };
 
 // base text -> codes in place (ssw_cpp.cpp:10-19: A/a 0, C/c 1, G/g 2, T/t 3, U/u 0, everything else 4)
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(64) void sw_ends_kernel(Job* __restrict__ jobs, con
     // pass 0: 8-bit segmentation; pass 1: 16-bit segmentation if pass 0 overflowed; pass 2: begin cell (reversed)
     PassOut f = {0, 0, 0, 0};
     int wide = 0, ref_begin = -1, read_begin = -1;
+    const long long t_start = wall_clock64();
     for (int pass = 0; pass < 3; ++pass) {
         if (pass == 1 && !f.overflow) continue;
         if (pass == 2 && !(f.score > 0 && f.ref >= 0)) continue;
@@ -289,6 +294,7 @@ __global__ __launch_bounds__(64) void sw_ends_kernel(Job* __restrict__ jobs, con
     if (threadIdx.x == 0) {
         J.score = f.score; J.wide = wide; J.ref_end = f.ref; J.read_end = f.read;
         J.ref_begin = ref_begin; J.read_begin = read_begin;
+        J.t_ends = (int32_t)(wall_clock64() - t_start);
     }
 }
 
@@ -311,102 +317,145 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
-// cap: ints per band array (hb, eb, hc); the bytes behind them hold the trace-back steps, the base codes of the
-// aligned windows and the per-step operation classes (3 (m + n) + 4 bytes).  ops_counter: running number of operations written to opsws.
-__global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const int8_t* __restrict__ ref,
-                                                  const int8_t* __restrict__ seq, uint8_t* __restrict__ dirws,
-                                                  uint32_t* __restrict__ opsws, unsigned long long* __restrict__ ops_counter,
-                                                  int cap) {
+// Three wavefronts per read try three consecutive band widths of the doubling sequence at once (the attempts are
+// independent; the narrowest one that reaches the score is the library's); that wavefront alone walks back and writes
+// the operations.  cap: ints per band array (hb, eb, hc; one set per wavefront); the bytes behind them hold the
+// trace-back steps, the base codes of the aligned windows and the per-step operation classes (3 (m + n) + 4 bytes).
+// ops_counter: running number of operations written to opsws.
+constexpr int BAND_WAVES = 3;
+
+__global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__ jobs, const int8_t* __restrict__ ref,
+                                                               const int8_t* __restrict__ seq, uint8_t* __restrict__ dirws,
+                                                               uint32_t* __restrict__ opsws,
+                                                               unsigned long long* __restrict__ ops_counter, int cap) {
     extern __shared__ int sm[];
     Job& J = jobs[blockIdx.x];
     if (J.state != ST_BAND) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = J.ref_end - J.ref_begin + 1, m = J.read_end - J.read_begin + 1, score = J.score;
-    int* hb = sm;
-    int* eb = sm + cap;
-    int* hc = sm + 2 * cap;
+    int* hb = sm + wave * 3 * cap;
+    int* eb = hb + cap;
+    int* hc = hb + 2 * cap;
+    int* sh_best = sm + BAND_WAVES * 3 * cap;                 // [BAND_WAVES] result of each wavefront's attempt
     const int step_cap = m + n + 2;
-    uint8_t* steps = reinterpret_cast<uint8_t*>(sm + 3 * cap);
+    uint8_t* steps = reinterpret_cast<uint8_t*>(sh_best + 4);
     int8_t* lrf = reinterpret_cast<int8_t*>(steps + step_cap);
     int8_t* lrd = lrf + n;
     uint8_t* cls = reinterpret_cast<uint8_t*>(lrd + m);
     {
         const int8_t* rf = ref + J.ref_off + J.ref_begin;
         const int8_t* rd = seq + J.seq_off + J.read_begin;
-        for (int k = lane; k < n; k += 64) lrf[k] = rf[k];
-        for (int k = lane; k < m; k += 64) lrd[k] = rd[k];
+        for (int k = threadIdx.x; k < n; k += 64 * BAND_WAVES) lrf[k] = rf[k];
+        for (int k = threadIdx.x; k < m; k += 64 * BAND_WAVES) lrd[k] = rd[k];
     }
-    uint8_t* dir = dirws + J.dir_off;
-    int bw = J.bw, stride = 0;
-    for (;;) {
+    constexpr int PENDING = -(1 << 30);
+    volatile int* vbest = sh_best;
+    if (threadIdx.x < BAND_WAVES) sh_best[threadIdx.x] = PENDING;
+    __syncthreads();
+    const int base_bw = J.bw, dir_width = J.dir_width;
+    uint8_t* dir = dirws + J.dir_off + (size_t)wave * m * dir_width;
+    int bw = 0, stride = 0;
+    const long long t_start = wall_clock64();
+    for (int round = 0;; ++round) {
+        const int attempt = round * BAND_WAVES + wave;
+        // results: >= 0 banded maximum; -1 the workspace rows are too narrow for this width; -2 the sequence does not
+        // get here (an earlier width already covers the whole matrix: the library would double for ever)
+        int result;
+        bw = attempt < 24 ? base_bw << attempt : INT32_MAX / 8;
         const int width = 2 * bw + 3;
         stride = min(2 * bw + 1, n);
         const int slots = min(width, n + 2) + 1;
-        if (stride > J.dir_width || slots > cap) {
-            if (lane == 0) { J.bw = bw; J.state = ST_WIDER; }
-            return;
-        }
-        for (int k = lane; k < slots; k += 64) { hb[k] = 0; eb[k] = 0; hc[k] = 0; }
-        int best = 0;
-        for (int i = 0; i < m; ++i) {
-            const int x = max(i - bw, 0), xp = max(i - 1 - bw, 0), sh = x - xp;
-            const int end = min(n - 1, i + bw), U = end - x + 1, edge = min(end + 1, width - 1);
-            wave_lds_order();
-            if (lane == 0) { hb[0] = 0; eb[0] = 0; hb[edge] = 0; eb[edge] = 0; hc[0] = 0; }
-            wave_lds_order();
-            const int qi = lrd[i];
-            int carry_a = NEG, carry_h = 0, carry_f = 0;
-            uint8_t* drow = dir + (size_t)i * stride;
-            for (int base = 0; base < U; base += 64) {
-                const int u = 1 + base + lane;
-                const bool valid = u <= U;
-                int hbe = 0, ebe = 0, hbd = 0, rj = 4;
-                if (valid) {
-                    hbe = hb[u + sh];
-                    ebe = eb[u + sh];
-                    hbd = hb[u + sh - 1];
-                    rj = lrf[x + u - 1];
+        if (attempt >= 24 || (attempt > 0 && (base_bw << (attempt - 1)) > n + m)) {
+            result = -2;
+        } else if (stride > dir_width || slots > cap) {
+            result = -1;
+        } else {
+            for (int k = lane; k < slots; k += 64) { hb[k] = 0; eb[k] = 0; hc[k] = 0; }
+            int best = 0;
+            bool overtaken = false;                     // a narrower width of this round has reached the score already
+            for (int i = 0; i < m; ++i) {
+                if (wave > 0 && (i & 7) == 0) {
+                    for (int w = 0; w < wave; ++w) overtaken = overtaken || vbest[w] >= score;
+                    if (overtaken) break;
                 }
-                const int t1 = i == 0 ? -GO : hbe - GO, t2 = i == 0 ? -GE : ebe - GE;
-                const int ecur = max(t1, t2), de = t1 > t2;
-                const int diag = hbd + ((rj == qi && qi < 4) ? S_MATCH : -S_MIS);
-                const int e1 = max(ecur, 0), g = max(e1, diag);
-                // vertical-gap chain of the row: f(u) = max(-GE u, max_{v<u} (g(v) + GE v) - GO - GE (u - 1))
-                const int pm = wave_prefix_max(valid ? g + u * GE : NEG, NEG);
-                const int ex = max(dpp_up1_or(pm, NEG), carry_a);
-                const int f = max(-GE * u, ex - GO - (u - 1) * GE);
-                const int f1 = max(f, 0), hcur = max(g, f1);
-                const int hl = dpp_up1_or(hcur, carry_h), fl = dpp_up1_or(f, carry_f);
-                const int df = (hl - GO) > (fl - GE);
-                const int gap = max(e1, f1);
-                const int dh = gap <= diag ? 1 : (e1 > f1 ? (de ? 3 : 2) : (df ? 5 : 4));
-                wave_lds_order();                 // every lane has read the previous row's slots of this chunk
-                if (valid) {
-                    eb[u] = ecur;
-                    if (U <= 64) hb[u] = hcur;      // single chunk: no other chunk still needs the previous row
-                    else hc[u] = hcur;
-                    drow[u - 1] = (uint8_t)(de | (df << 1) | (dh << 2));
-                    best = max(best, hcur);
+                const int x = max(i - bw, 0), xp = max(i - 1 - bw, 0), sh = x - xp;
+                const int end = min(n - 1, i + bw), U = end - x + 1, edge = min(end + 1, width - 1);
+                wave_lds_order();
+                if (lane == 0) { hb[0] = 0; eb[0] = 0; hb[edge] = 0; eb[edge] = 0; hc[0] = 0; }
+                wave_lds_order();
+                const int qi = lrd[i];
+                int carry_a = NEG, carry_h = 0, carry_f = 0;
+                uint8_t* drow = dir + (size_t)i * stride;
+                for (int base = 0; base < U; base += 64) {
+                    const int u = 1 + base + lane;
+                    const bool valid = u <= U;
+                    int hbe = 0, ebe = 0, hbd = 0, rj = 4;
+                    if (valid) {
+                        hbe = hb[u + sh];
+                        ebe = eb[u + sh];
+                        hbd = hb[u + sh - 1];
+                        rj = lrf[x + u - 1];
+                    }
+                    const int t1 = i == 0 ? -GO : hbe - GO, t2 = i == 0 ? -GE : ebe - GE;
+                    const int ecur = max(t1, t2), de = t1 > t2;
+                    const int diag = hbd + ((rj == qi && qi < 4) ? S_MATCH : -S_MIS);
+                    const int e1 = max(ecur, 0), g = max(e1, diag);
+                    // vertical-gap chain of the row: f(u) = max(-GE u, max_{v<u} (g(v) + GE v) - GO - GE (u - 1))
+                    const int pm = wave_prefix_max(valid ? g + u * GE : NEG, NEG);
+                    const int ex = max(dpp_up1_or(pm, NEG), carry_a);
+                    const int f = max(-GE * u, ex - GO - (u - 1) * GE);
+                    const int f1 = max(f, 0), hcur = max(g, f1);
+                    const int hl = dpp_up1_or(hcur, carry_h), fl = dpp_up1_or(f, carry_f);
+                    const int df = (hl - GO) > (fl - GE);
+                    const int gap = max(e1, f1);
+                    const int dh = gap <= diag ? 1 : (e1 > f1 ? (de ? 3 : 2) : (df ? 5 : 4));
+                    wave_lds_order();                 // every lane has read the previous row's slots of this chunk
+                    if (valid) {
+                        eb[u] = ecur;
+                        if (U <= 64) hb[u] = hcur;      // single chunk: no other chunk still needs the previous row
+                        else hc[u] = hcur;
+                        drow[u - 1] = (uint8_t)(de | (df << 1) | (dh << 2));
+                        best = max(best, hcur);
+                    }
+                    if (base + 64 < U) {
+                        carry_a = max(carry_a, bcast63(pm));
+                        carry_h = bcast63(hcur);
+                        carry_f = bcast63(f);
+                    }
                 }
-                if (base + 64 < U) {
-                    carry_a = max(carry_a, bcast63(pm));
-                    carry_h = bcast63(hcur);
-                    carry_f = bcast63(f);
-                }
+                wave_lds_order();
+                if (U > 64)
+                    for (int u = 1 + lane; u <= U; u += 64) hb[u] = hc[u];
             }
-            wave_lds_order();
-            if (U > 64)
-                for (int u = 1 + lane; u <= U; u += 64) hb[u] = hc[u];
+            result = overtaken ? -3 : wave_max(best);
         }
-        best = wave_max(best);
-        if (best >= score) break;
-        if (bw > n + m) {                       // the library would double for ever here
-            if (lane == 0) J.state = ST_ERR;
+        if (lane == 0) vbest[wave] = result;
+        __syncthreads();
+        int winner = -1, verdict = 0;                 // verdict: 1 wider workspace needed, 2 no width reaches the score
+        int need_bw = 0;
+        for (int w = 0; w < BAND_WAVES; ++w) {
+            const int r = sh_best[w];
+            if (r >= score) { winner = w; break; }
+            if (r == -1) { verdict = 1; need_bw = base_bw << (round * BAND_WAVES + w); break; }
+            if (r == -2) { verdict = 2; break; }
+        }
+        if (verdict) {
+            if (threadIdx.x == 0) {
+                if (verdict == 1) { J.bw = need_bw; J.state = ST_WIDER; }
+                else J.state = ST_ERR;
+            }
             return;
         }
-        bw *= 2;
+        if (winner >= 0) {
+            if (wave != winner) return;
+            break;
+        }
+        __syncthreads();                              // sh_best is rewritten by the next round
+        if (lane == 0) sh_best[wave] = PENDING;
+        __syncthreads();
     }
     __threadfence();
+    const long long t_dp = wall_clock64();
 
     // trace back (ssw.c:653-703): state 2 = H, 0 = E, 1 = F.  Runs of diagonal moves are found 64 cells at a time (every
     // lane probes one cell of the diagonal), gap cells one by one.
@@ -456,6 +505,7 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
         if (lane == 0) J.state = ST_ERR;
         return;
     }
+    const long long t_trace = wall_clock64();
 
     // Operations in alignment order: soft clip, the first cell, the steps backwards, soft clip; aligned pairs are
     // classified by comparing base codes from the begin cell on (ssw_cpp.cpp:126-207).  Wavefront-parallel: positions
@@ -514,6 +564,9 @@ __global__ __launch_bounds__(64) void band_kernel(Job* __restrict__ jobs, const 
         J.n_ops = no;
         J.bw = bw;
         J.state = ST_DONE;
+        J.t_dp = (int32_t)(t_dp - t_start);
+        J.t_trace = (int32_t)(t_trace - t_dp);
+        J.t_emit = (int32_t)(wall_clock64() - t_trace);
     }
 }
 
@@ -602,6 +655,14 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
         return pa::set_error(PA_ERR_INVALID, "null argument");
     if (reference_len > (int64_t)1 << 30) return pa::set_error(PA_ERR_INVALID, "reference window too long");
     RA_HIP(hipSetDevice(r->device));
+    static const bool trace = getenv("PA_REALIGN_TRACE") != nullptr;      // host phase times on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[realign] %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     r->jobs.assign((size_t)n_reads, Job());
     r->total_ops = 0;
     r->ends_ms = r->band_ms = 0.0;
@@ -648,6 +709,7 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
     };
     if (!any) { finish_outputs(); return PA_OK; }
 
+    lap("job table");
     // upload the text, turn it into base codes on the device
     RA_ALLOC(r->d_ref, (size_t)reference_len + 64);
     RA_ALLOC(r->d_seq, (size_t)total_seq + 64);
@@ -672,8 +734,10 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
         RA_HIP(hipGetLastError());
         RA_HIP(hipEventRecord(r->ev[1], r->stream));
     }
+    lap("upload + launch");
     RA_HIP(hipMemcpyAsync(r->jobs.data(), dj, sizeof(Job) * (size_t)n_reads, hipMemcpyDeviceToHost, r->stream));
     RA_HIP(hipStreamSynchronize(r->stream));
+    lap("score kernel");
 
     // band stage: workspace layout, first with rows of at most 129 slots (band half width <= 64), then full rows
     int64_t ops_total = 0;
@@ -701,13 +765,13 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
             J.dir_width = round == 0 ? std::min(n2, 129) : n2;
             if (round == 0 && std::min(2 * J.bw + 1, n2) > J.dir_width) J.dir_width = n2;   // first band already wider
             J.dir_off = dir_total;
-            dir_total += (int64_t)m2 * J.dir_width;
+            dir_total += (int64_t)m2 * J.dir_width * BAND_WAVES;
             const int bw_cap = J.dir_width >= n2 ? INT32_MAX / 4 : (J.dir_width - 1) / 2;
             cap = std::max(cap, (int)std::min<int64_t>(2 * (int64_t)bw_cap + 3, n2 + 2) + 2);
             ++pending;
         }
         if (!pending) break;
-        const size_t lds = (size_t)cap * 12 + (size_t)aux + 16;
+        const size_t lds = (size_t)cap * 12 * BAND_WAVES + (size_t)aux + 64;
         if (lds > 150 * 1024) return pa::set_error(PA_ERR_INVALID, "alignment too long for the band stage");
         RA_ALLOC(r->d_dir, (size_t)std::max<int64_t>(dir_total, 1));
         RA_HIP(hipMemcpyAsync(dj, r->jobs.data(), sizeof(Job) * (size_t)n_reads, hipMemcpyHostToDevice, r->stream));
@@ -715,13 +779,15 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
             RA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds));
         RA_HIP(hipEventRecord(r->ev[2], r->stream));
-        hipLaunchKernelGGL(band_kernel, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq,
+        hipLaunchKernelGGL(band_kernel, dim3(n_reads), dim3(64 * BAND_WAVES), lds, r->stream, dj, dref, dseq,
                            static_cast<uint8_t*>(r->d_dir.p), static_cast<uint32_t*>(r->d_ops.p),
                            static_cast<unsigned long long*>(r->d_counter.p), cap);
         RA_HIP(hipGetLastError());
         RA_HIP(hipEventRecord(r->ev[3], r->stream));
+        lap("band setup");
         RA_HIP(hipMemcpyAsync(r->jobs.data(), dj, sizeof(Job) * (size_t)n_reads, hipMemcpyDeviceToHost, r->stream));
         RA_HIP(hipStreamSynchronize(r->stream));
+        lap("band kernel");
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, r->ev[2], r->ev[3]) == hipSuccess) r->band_ms += ms;
     }
@@ -746,6 +812,7 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
         if (J.state == ST_DONE) r->total_ops += J.n_ops;
     *n_cigar_ops = r->total_ops;
     finish_outputs();
+    lap("results");
     return PA_OK;
 }
 
@@ -754,6 +821,15 @@ int pa_realigner_last_timing(pa_realigner* r, double* score_kernel_ms, double* b
     if (score_kernel_ms) *score_kernel_ms = r->ends_ms;
     if (band_kernel_ms) *band_kernel_ms = r->band_ms;
     if (cells) *cells = r->cells;
+    return PA_OK;
+}
+
+int pa_realigner_stage_ticks(pa_realigner* r, int32_t* ticks4) {
+    if (!r || !ticks4) return pa::set_error(PA_ERR_INVALID, "null argument");
+    for (size_t k = 0; k < r->jobs.size(); ++k) {
+        const Job& J = r->jobs[k];
+        ticks4[4 * k] = J.t_ends; ticks4[4 * k + 1] = J.t_dp; ticks4[4 * k + 2] = J.t_trace; ticks4[4 * k + 3] = J.t_emit;
+    }
     return PA_OK;
 }
 
