@@ -253,10 +253,11 @@ def realign_bench(args):
         "kernels": {"sw_ends_kernel": {"avg_ms": ends / args.steps, "gcups_one_pass_equiv": cells / (ends / args.steps * 1e-3) / 1e9},
                     "band_kernel": {"avg_ms": band / args.steps}},
         "roofline": {"bound": "valu", "kernel": "sw_ends_kernel", "achieved": 2.0 * cells / (ends / args.steps * 1e-3) / 1e9,
-                     "peak": 39321.6 / 30.0, "unit": "G cell updates/s",
-                     "frac": 2.0 * cells / (ends / args.steps * 1e-3) / 1e9 / (39321.6 / 30.0), "traffic": None,
-                     "note": "integer DP on the vector ALUs: peak = 256 CU x 64 lanes x 2.4 GHz int32 ops / ~30 ops per cell; "
-                             "achieved counts the forward and the reverse pass (2 x n x m cells per read)"},
+                     "peak": 39321.6 / 12.5, "unit": "G cell updates/s",
+                     "frac": 2.0 * cells / (ends / args.steps * 1e-3) / 1e9 / (39321.6 / 12.5), "traffic": None,
+                     "note": "integer DP on the vector ALUs, neither HBM nor MFMA bound: peak = 256 CU x 64 lanes x 2.4 GHz "
+                             "int32 instructions / 12.5 instructions per cell (the kernel's ISA); achieved counts the forward "
+                             "and the reverse pass (2 x n x m cells per read; the 8-bit prefix pass is not counted)"},
         "cpu_baseline": {"value": done / cpu_dt, "unit": "reads/s", "cores": 1, "kind": kind,
                          "sample": f"{done} of the same reads through {'the reference SSW build (oracle/_ref)' if kind == 'reference' else 'oracle/ssw_oracle.cpp'}, one thread, {cpu_dt:.1f} s"},
         "speedup_vs_cpu_baseline": (n * args.steps / dt) / (done / cpu_dt)}))
