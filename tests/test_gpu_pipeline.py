@@ -386,3 +386,61 @@ def test_polish_create_summary_from_bam(tmp_path):
     assert len(want[0]) == len(images_r)
     for got_i, want_i, got_p, want_p in zip(images_r, want[0], positions_r, want[2]):
         assert np.array_equal(got_i, want_i) and np.array_equal(got_p, want_p)
+
+
+def test_polish_end_to_end_from_bam(tmp_path):
+    """`polish(bam, draft, out, threads, region, model, ...)`: make_images (BAM reader, GPU re-aligner, GPU encoder) ->
+    call_consensus -> perform_stitch.  Images are compared with the oracle legs region by region (restated clipped reads
+    -> SSW restatement -> oracle encoder -> chunking); the polished FASTA must not depend on the number of workers."""
+    import glob
+    import bam_utils as bu
+    import pileup_utils as pu
+    from oracle import ssw
+    from pepper_amd.polish.AlignmentSummarizer import AlignmentSummarizer
+    from pepper_amd.polish.ImageGenerationUI import UserInterfaceSupport
+    from pepper_amd.polish.polish import polish
+    rng = np.random.default_rng(91)
+    draft = pu.random_reference(rng, 4300)
+    reads = pu.simulate_reads(rng, draft, 0, n_reads=220, read_len=(600, 2500), ins_rate=0.02, del_rate=0.02)
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    for i, r in enumerate(reads):
+        r["name"] = "q%d" % i
+    bam_path, fa_path = str(tmp_path / "reads.bam"), str(tmp_path / "draft.fa")
+    bu.write_bam(bam_path, [("ctg1", len(draft))], {0: reads})
+    with open(fa_path, "w") as fh:
+        fh.write(">ctg1\n" + draft + "\n")
+    sd = synthetic.polish_state_dict(seed=17, gain=2.0)
+    model_path = str(tmp_path / "polish.pkl")
+    torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
+
+    outs = []
+    for threads in (1, 3):
+        out_dir = str(tmp_path / ("run%d" % threads)) + "/"
+        polish(bam_path, fa_path, out_dir, threads, None, model_path, 64, True, "0", 0)
+        fasta = glob.glob(out_dir + "*.fa")
+        assert len(fasta) == 1
+        text = open(fasta[0]).read()
+        assert text.startswith(">ctg1") and 0.5 * len(draft) < len(text.split("\n", 1)[1].replace("\n", "")) < 2 * len(draft)
+        outs.append(text)
+    assert outs[0] == outs[1]
+
+    # images of the single-worker run against the oracle legs
+    _, intervals = UserInterfaceSupport.make_intervals([("ctg1", None)], fa_path)
+    assert intervals[0] == ("ctg1", 0, 1100) and intervals[1] == ("ctg1", 900, 2100) and len(intervals) == 5
+    img_file = glob.glob(str(tmp_path / "run1") + "/images_*/*.hdf")[0]
+    oracle = pu.load_restatement()
+    checked = 0
+    with h5.File(img_file) as f:
+        for (_, start, end) in intervals[:3]:
+            clipped = bu.restated_get_reads(reads, start, end, False, 0)
+            res = ssw.realign_reads(draft[start:end + 20], start, [r["pos"] for r in clipped], [r["seq"] for r in clipped])
+            realigned = [dict(r, pos=p, cigar=[(0 if o in (7, 8) else o, n) for o, n in ops]) if st == 1 else r
+                         for r, (st, score, p, pe, ops) in zip(clipped, res)]
+            img, pos = pu.run_polish_oracle(oracle, pu.FlatPileup(start, end, draft[start:end + 1], realigned), start, end)
+            want = AlignmentSummarizer.chunk_images(SimpleNamespace(image=img, genomic_pos=pos), 1000, 50)
+            for cid, (wi, wp) in enumerate(zip(want[0], want[2])):
+                base = "summaries/ctg1_%d_%d_%d/" % (start, end, cid)
+                assert np.array_equal(f[base + "image"], wi)
+                assert np.array_equal(f[base + "position"], wp[:, 0]) and np.array_equal(f[base + "index"], wp[:, 1])
+                checked += 1
+    assert checked >= 4
