@@ -149,3 +149,30 @@ def test_readset_and_object_interfaces():
             assert list(zip(out.cigar_op[a:b].tolist(), out.cigar_len[a:b].tolist())) == [(0 if o in (7, 8) else o, n) for o, n in e[4]]
         else:
             assert b - a == 1
+
+
+def test_long_reads_take_the_lds_strip_form():
+    """Reads beyond 1536 padded rows do not fit the register-resident strip (24 rows per lane)."""
+    rng = np.random.default_rng(15)
+    reference = _rand_seq(rng, 3200)
+    pos, seqs = ssw.simulate_reads(rng, reference, 0, 10, min_len=1700, full_span=0.6)
+    pos += [100, 0]
+    seqs += [reference[100:1700], reference[:1530]]          # just around the switch
+    assert max(len(s) for s in seqs) > 2500
+    out = _gpu_align(reference, 0, pos, seqs)
+    _assert_same(out, ssw.realign_reads(reference, 0, pos, seqs))
+
+
+def test_degenerate_read_sets():
+    from pepper_amd import _lib
+    reference = "ACGTTGCA" * 20
+    empty = _gpu_align(reference, 10, [], [])
+    assert len(empty["status"]) == 0 and empty["cigar_offset"].tolist() == [0]
+    out = _gpu_align(reference, 10, [3, 9], ["ACGT", "TTGCA"])            # every read starts before the region
+    assert out["status"].tolist() == [-1, -1] and out["cigar_offset"].tolist() == [0, 0, 0]
+    out = _gpu_align(reference, 10, [10 + len(reference)], ["ACGT"])      # starts exactly at the end: nothing to align to
+    assert out["status"].tolist() == [0]
+    with pytest.raises(_lib.PepperAmdError):
+        _gpu_align(reference, 10, [10 + len(reference) + 1], ["ACGT"])    # beyond it: substr() would throw in the reference
+    with pytest.raises(_lib.PepperAmdError):
+        _gpu_align("ACGT" * 2000, 0, [0], ["ACGT" * 1001])                # 4004 bases: above the supported read length
