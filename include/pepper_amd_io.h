@@ -73,6 +73,14 @@ int pa_h5_write_fixed_strings(pa_h5* f, const char* path, int32_t rank, const in
 int pa_h5_write_vlen_strings(pa_h5* f, const char* path, int32_t rank, const int64_t* dims,
                              const char* const* strings);
 
+/* One `predictions/batch_<n>` group of the variant predictions file in a single call (DataStorePredict.py:49-67):
+ * contigs (fixed-width strings, n rows of contig_stride bytes, null padded), positions int32 [n], depths uint8 [n],
+ * candidates vlen utf-8 [n,1] (NUL-terminated strings at cand_blob + cand_offsets[i]), candidate_frequency uint8 [n,1],
+ * base_prediction float64 [n, n_classes] (converted from the float32 device output). */
+int pa_h5_write_prediction_batch(pa_h5* f, const char* group, int32_t n, const char* contigs, int32_t contig_stride,
+                                 const int32_t* positions, const uint8_t* depths, const char* cand_blob,
+                                 const int64_t* cand_offsets, const uint8_t* freqs, const float* probs, int32_t n_classes);
+
 /* ------------------------------------------------------------------------------------------
  * BAM ingestion (pepper_amd/csrc/bamio.cpp; zlib, no htslib)
  * replaces the pybind surface of PEPPER_VARIANT.BAM_handler:

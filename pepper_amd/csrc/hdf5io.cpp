@@ -4,6 +4,7 @@
 
 #include <hdf5.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -290,6 +291,59 @@ int pa_h5_write_vlen_strings(pa_h5* f, const char* path, int32_t rank, const int
     H5Tset_cset(t, H5T_CSET_UTF8);       // h5py special_dtype(vlen=str)
     const int rc = write_dataset(f, path, t, t, rank, dims, strings);
     H5Tclose(t);
+    return rc;
+}
+
+int pa_h5_write_prediction_batch(pa_h5* f, const char* group, int32_t n, const char* contigs, int32_t contig_stride,
+                                 const int32_t* positions, const uint8_t* depths, const char* cand_blob,
+                                 const int64_t* cand_offsets, const uint8_t* freqs, const float* probs, int32_t n_classes) {
+    if (!f || !group || n < 0 || n_classes <= 0 || contig_stride <= 0 ||
+        (n > 0 && (!contigs || !positions || !depths || !cand_blob || !cand_offsets || !freqs || !probs)))
+        return fail("bad argument");
+    Quiet q;
+    hid_t g = H5Gcreate2(f->file, group, f->lcpl, H5P_DEFAULT, H5P_DEFAULT);
+    if (g < 0) return fail(std::string("cannot create group '") + group + "' (already exists?)");
+    int rc = 0;
+    auto put = [&](const char* name, hid_t ft, hid_t mt, int rank, hsize_t d0, hsize_t d1, const void* data) {
+        if (rc) return;
+        hsize_t dims[2] = {d0, d1};
+        hid_t sp = H5Screate_simple(rank, dims, nullptr);
+        hid_t d = H5Dcreate2(g, name, ft, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+        if (d < 0) rc = fail(std::string("cannot create dataset '") + group + "/" + name + "'");
+        else {
+            if (n > 0 && H5Dwrite(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0)
+                rc = fail(std::string("H5Dwrite failed for '") + group + "/" + name + "'");
+            H5Dclose(d);
+        }
+        H5Sclose(sp);
+    };
+    // contigs: fixed-width, null padded, as wide as the longest name of the batch (numpy 'S' array semantics)
+    size_t w = 1;
+    for (int32_t i = 0; i < n; ++i) w = std::max(w, strnlen(contigs + (size_t)i * contig_stride, (size_t)contig_stride));
+    std::vector<char> packed((size_t)n * w + 1, 0);
+    for (int32_t i = 0; i < n; ++i) {
+        const char* src = contigs + (size_t)i * contig_stride;
+        std::memcpy(packed.data() + (size_t)i * w, src, strnlen(src, std::min(w, (size_t)contig_stride)));
+    }
+    hid_t ts = H5Tcopy(H5T_C_S1);
+    H5Tset_size(ts, w);
+    H5Tset_strpad(ts, H5T_STR_NULLPAD);
+    put("contigs", ts, ts, 1, (hsize_t)n, 0, packed.data());
+    H5Tclose(ts);
+    put("positions", H5T_STD_I32LE, H5T_NATIVE_INT32, 1, (hsize_t)n, 0, positions);
+    put("depths", H5T_STD_U8LE, H5T_NATIVE_UINT8, 1, (hsize_t)n, 0, depths);
+    std::vector<const char*> ptrs((size_t)std::max(n, 1), "");
+    for (int32_t i = 0; i < n; ++i) ptrs[(size_t)i] = cand_blob + cand_offsets[i];
+    hid_t tv = H5Tcopy(H5T_C_S1);
+    H5Tset_size(tv, H5T_VARIABLE);
+    H5Tset_cset(tv, H5T_CSET_UTF8);
+    put("candidates", tv, tv, 2, (hsize_t)n, 1, ptrs.data());
+    H5Tclose(tv);
+    put("candidate_frequency", H5T_STD_U8LE, H5T_NATIVE_UINT8, 2, (hsize_t)n, 1, freqs);
+    std::vector<double> p64((size_t)n * n_classes + 1);
+    for (size_t i = 0; i < (size_t)n * n_classes; ++i) p64[i] = (double)probs[i];
+    put("base_prediction", H5T_IEEE_F64LE, H5T_NATIVE_DOUBLE, 2, (hsize_t)n, (hsize_t)n_classes, p64.data());
+    H5Gclose(g);
     return rc;
 }
 

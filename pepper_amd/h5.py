@@ -36,6 +36,8 @@ SYMBOLS = [
     ("pa_h5_read_strings", ctypes.c_int, [c_void_p, c_char_p, c_void_p, c_int64, P64]),
     ("pa_h5_write_fixed_strings", ctypes.c_int, [c_void_p, c_char_p, c_int32, P64, c_int32, c_void_p]),
     ("pa_h5_write_vlen_strings", ctypes.c_int, [c_void_p, c_char_p, c_int32, P64, ctypes.POINTER(c_char_p)]),
+    ("pa_h5_write_prediction_batch", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
+                                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
 ]
 
 _lib = None
@@ -130,6 +132,33 @@ class File(object):
         _check(self._lib.pa_h5_info(self._h, path.encode(), ctypes.byref(rank), dims, ctypes.byref(cls),
                                     ctypes.byref(size), ctypes.byref(sgn)))
         return tuple(dims[:rank.value]), cls.value, size.value, bool(sgn.value)
+
+    @_locked
+    def read_into(self, path, out):
+        """Whole numeric dataset into a caller-provided C-contiguous array of the matching size (e.g. a slice of a pinned
+        staging buffer): no intermediate array."""
+        if out.dtype not in _CODES or not out.flags["C_CONTIGUOUS"]:
+            raise H5Error(f"read_into needs a C-contiguous array of a supported dtype for '{path}'")
+        _check(self._lib.pa_h5_read(self._h, path.encode(), _CODES[out.dtype], out.ctypes.data, out.nbytes))
+        return out
+
+    @_locked
+    def read_strings_raw(self, path):
+        """A string dataset as one bytes object of NUL-terminated entries (no per-element Python objects)."""
+        needed = c_int64()
+        _check(self._lib.pa_h5_read_strings(self._h, path.encode(), None, 0, ctypes.byref(needed)))
+        buf = ctypes.create_string_buffer(max(1, needed.value))
+        _check(self._lib.pa_h5_read_strings(self._h, path.encode(), buf, needed.value, ctypes.byref(needed)))
+        return buf.raw[:needed.value]
+
+    @_locked
+    def write_prediction_batch(self, group, contigs, positions, depths, cand_blob, cand_offsets, freqs, probs):
+        """One predictions/batch_<n> group in one library call (include/pepper_amd_io.h)."""
+        n = len(positions)
+        _check(self._lib.pa_h5_write_prediction_batch(self._h, group.encode(), n, contigs.ctypes.data, contigs.dtype.itemsize,
+                                                      positions.ctypes.data, depths.ctypes.data, cand_blob.ctypes.data,
+                                                      cand_offsets.ctypes.data, freqs.ctypes.data, probs.ctypes.data,
+                                                      probs.shape[1]))
 
     @_locked
     def __getitem__(self, path):

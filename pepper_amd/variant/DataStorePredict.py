@@ -42,3 +42,18 @@ class DataStore(object):
         fh[base + "candidates"] = np.asarray(candidates, dtype=object)
         fh[base + "candidate_frequency"] = np.asarray(candidate_frequencies, dtype=np.uint8)
         fh[base + "base_prediction"] = np.asarray(base_predictions, dtype=np.float64)
+
+    def write_prediction_arrays(self, batch_no, contigs, positions, depths, candidate_blob, candidate_offsets,
+                                candidate_frequencies, base_predictions):
+        """The same group as write_prediction from bulk arrays in one library call: contigs a numpy 'S' array,
+        candidates as NUL-terminated strings at candidate_blob[candidate_offsets[i]:], base_predictions float32 [B,3]
+        (stored as float64, as the reference's np.float)."""
+        name = "batch_" + str(batch_no)
+        if name in self._written:
+            return
+        self._written.add(name)
+        self.file_handler.write_prediction_batch(
+            self._prediction_path_ + "/" + name, np.ascontiguousarray(contigs), np.ascontiguousarray(positions, dtype=np.int32),
+            np.ascontiguousarray(depths, dtype=np.uint8), candidate_blob, np.ascontiguousarray(candidate_offsets, dtype=np.int64),
+            np.ascontiguousarray(candidate_frequencies, dtype=np.uint8), np.ascontiguousarray(base_predictions, dtype=np.float32))
+

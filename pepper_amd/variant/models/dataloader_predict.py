@@ -23,9 +23,14 @@ def get_file_paths_from_directory(directory_path):
 
 
 class SequenceDataset(object):
-    def __init__(self, image_directory, input_file=None, summary_names=None):
+    def __init__(self, image_directory, input_file=None, summary_names=None, image_alloc=None):
+        """image_alloc(n, window, features) -> int8 array [n, window, features] to read the images into (e.g. a reusable
+        pinned staging buffer); default: a fresh numpy array.  Every group's image block is read straight into its slice."""
         input_files = get_file_paths_from_directory(image_directory) if input_file is None else [input_file]
-        contigs, positions, depths, candidates, freqs, images = [], [], [], [], [], []
+        contigs, positions, depths, candidates, freqs = [], [], [], [], []
+        self._all_candidates = None
+        todo = []                                    # (path, group base, rows)
+        shape = None
         for path in input_files:
             with h5.File(path, 'r') as f:
                 if 'summaries' not in f:
@@ -33,30 +38,65 @@ class SequenceDataset(object):
                 names = f.keys('summaries') if summary_names is None else summary_names
                 for name in names:
                     base = 'summaries/' + name + '/'
-                    img = f[base + 'images']
-                    if img.shape[0] == 0:
+                    dims = f.info(base + 'images')[0]
+                    if dims[0] == 0:
                         continue
+                    if shape is None:
+                        shape = tuple(dims[1:])
+                    elif tuple(dims[1:]) != shape:
+                        raise ValueError("image shapes differ between groups: %r vs %r" % (tuple(dims[1:]), shape))
+                    todo.append((path, base, int(dims[0])))
+        images = None
+        if todo:
+            total = sum(rows for _, _, rows in todo)
+            images = (image_alloc(total, *shape) if image_alloc is not None else np.empty((total,) + shape, np.int8))
+            at, current, f = 0, None, None
+            try:
+                for path, base, rows in todo:
+                    if path != current:
+                        if f is not None:
+                            f.close()
+                        f, current = h5.File(path, 'r'), path
+                    f.read_into(base + 'images', images[at:at + rows])
+                    at += rows
                     contigs.append(f[base + 'contigs'])
                     positions.append(f[base + 'positions'])
                     depths.append(f[base + 'depths'])
-                    candidates.append(f[base + 'candidates'])
+                    candidates.append(f.read_strings_raw(base + 'candidates'))
                     freqs.append(f[base + 'candidate_frequency'])
-                    images.append(img)
-        if images:
+            finally:
+                if f is not None:
+                    f.close()
+        if images is not None:
             width = max(c.dtype.itemsize for c in contigs)
             self.all_contigs = np.concatenate([c.astype(f'S{width}') for c in contigs])
             self.all_positions = np.concatenate(positions)
             self.all_depths = np.concatenate(depths)
-            self.all_candidates = np.concatenate(candidates)
+            # candidate strings stay one NUL-separated byte block + start offsets; the object array of the reference's
+            # loader is built only if somebody asks for it (`all_candidates`, `dataset[i]`)
+            self.candidate_blob = np.frombuffer(b"".join(candidates) + b"\0", np.uint8)
+            ends = np.flatnonzero(self.candidate_blob[:-1] == 0)
+            self.candidate_offsets = np.concatenate(([0], ends[:-1] + 1)).astype(np.int64) if len(ends) else np.zeros(0, np.int64)
             self.all_candidate_frequency = np.concatenate(freqs)
-            self.all_images = np.ascontiguousarray(np.concatenate(images))
+            self.all_images = images
         else:
             self.all_contigs = np.zeros((0,), 'S1')
             self.all_positions = np.zeros((0,), np.int32)
             self.all_depths = np.zeros((0,), np.uint8)
-            self.all_candidates = np.zeros((0, 1), object)
+            self.candidate_blob = np.zeros(1, np.uint8)
+            self.candidate_offsets = np.zeros(0, np.int64)
             self.all_candidate_frequency = np.zeros((0, 1), np.uint8)
             self.all_images = np.zeros((0, 33, 26), np.int8)
+
+    @property
+    def all_candidates(self):
+        if self._all_candidates is None:
+            raw = self.candidate_blob.tobytes()
+            parts = raw.split(b"\0")[:len(self.candidate_offsets)]
+            arr = np.empty((len(parts), 1), dtype=object)
+            arr[:, 0] = [p.decode("utf-8") for p in parts]
+            self._all_candidates = arr
+        return self._all_candidates
 
     @staticmethod
     def my_collate(batch):

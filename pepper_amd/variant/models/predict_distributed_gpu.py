@@ -31,6 +31,32 @@ def _log(msg):
     sys.stderr.flush()
 
 
+class _StagingBuffers(object):
+    """Two reusable page-locked int8 buffers for the image blocks: the reader thread fills one from the HDF5 file while
+    the other is on its way to the device, no fresh (page-faulting, pageable) allocation per file."""
+    LIMIT = 4 << 30
+
+    def __init__(self):
+        self.buffers = [None, None]
+        self.turn = 0
+
+    def alloc(self, n, window, features):
+        import numpy as np
+        need = n * window * features
+        if need > self.LIMIT:
+            return np.empty((n, window, features), np.int8)
+        k, self.turn = self.turn, self.turn ^ 1
+        t = self.buffers[k]
+        if t is None or t.numel() < need:
+            t = torch.empty(max(need + need // 8, 1), dtype=torch.int8)
+            try:
+                t = t.pin_memory()
+            except RuntimeError:
+                pass
+            self.buffers[k] = t
+        return t[:need].view(n, window, features).numpy()
+
+
 def predict(options, input_filepath, input_files, output_filepath, threads, rank=None, device=None,
             model=None):
     if getattr(options, "use_hp_info", False):
@@ -59,21 +85,24 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
     reader = ThreadPoolExecutor(max_workers=1)
     writer = ThreadPoolExecutor(max_workers=1)
     writes = []
-    pending = reader.submit(SequenceDataset, input_filepath, input_files[0]) if input_files else None
+    staging = _StagingBuffers()
+    pending = (reader.submit(SequenceDataset, input_filepath, input_files[0], None, staging.alloc) if input_files else None)
 
     def write_file(first_batch, input_data, probs):
-        offset, batch_no = 0, first_batch
-        for contigs, positions, depths, candidates, freqs, _ in input_data.batches(options.batch_size):
-            b = len(positions)
-            prediction_data_file.write_prediction(batch_no, [c.decode('UTF-8') for c in contigs], positions, depths,
-                                                  candidates, freqs, probs[offset:offset + b])
-            offset += b
+        # bulk arrays straight into one library call per batch_<n> group (no per-candidate Python objects)
+        batch_no = first_batch
+        for s in range(0, len(input_data), options.batch_size):
+            e = min(len(input_data), s + options.batch_size)
+            prediction_data_file.write_prediction_arrays(batch_no, input_data.all_contigs[s:e], input_data.all_positions[s:e],
+                                                         input_data.all_depths[s:e], input_data.candidate_blob,
+                                                         input_data.candidate_offsets[s:e],
+                                                         input_data.all_candidate_frequency[s:e], probs[s:e])
             batch_no += 1
 
     try:
         for file_id, input_file in enumerate(input_files):
             input_data = pending.result()
-            pending = (reader.submit(SequenceDataset, input_filepath, input_files[file_id + 1])
+            pending = (reader.submit(SequenceDataset, input_filepath, input_files[file_id + 1], None, staging.alloc)
                        if file_id + 1 < len(input_files) else None)
             n = len(input_data)
             if n:

@@ -136,3 +136,52 @@ def test_h5py_sees_same_types(golden_dir, tmp_path):
     r = subprocess.run(["/opt/conda/bin/python3.9", "-c", script, mine,
                         os.path.join(golden_dir, "variant_predictions_ref.hdf")], capture_output=True, text=True)
     assert r.returncode == 0 and "same" in r.stdout, r.stderr
+
+
+def test_bulk_prediction_writer_and_loader_equal_the_per_dataset_path(tmp_path):
+    """predict() writes each batch_<n> group with one library call from bulk arrays and reads image blocks straight into
+    one (staging) buffer: same files, same loader contents as the per-dataset / per-object path pinned above."""
+    from pepper_amd import synthetic
+    from pepper_amd.variant.DataStore import DataStore
+    from pepper_amd.variant.DataStorePredict import DataStore as PredStore
+    from pepper_amd.variant.models.dataloader_predict import SequenceDataset
+    rng = np.random.default_rng(3)
+    path = str(tmp_path / "pepper_variants_images_thread_0.hdf5")
+    per = [700, 0, 333]
+    with DataStore(path, "w") as ds:
+        for gi, n in enumerate(per):
+            x = synthetic.variant_windows(max(n, 1), seed=50 + gi)[:n]
+            cands = np.array([[["1A", "2ACCT", "3AG", "", "1T"][k % 5]] for k in range(n)], dtype=object).reshape(n, 1)
+            ds.write_summary("chr20_%d_%d" % (gi * 1000, gi * 1000 + 999), [["chr20", "chr20_KI270_random"][gi % 2]] * n,
+                             np.arange(n) + gi * 1000, rng.integers(1, 99, n), cands, rng.integers(0, 120, (n, 1)), x,
+                             [0] * n, [0] * n, False)
+    asked = []
+
+    def alloc(n, window, features):
+        asked.append((n, window, features))
+        return np.full((n + 5, window, features), 99, np.int8)[:n]
+    d = SequenceDataset(str(tmp_path), path, None, alloc)
+    plain = SequenceDataset(str(tmp_path), path)
+    assert asked == [(1033, 33, 26)] and len(d) == 1033
+    assert np.array_equal(d.all_images, plain.all_images) and np.array_equal(d.all_candidates, plain.all_candidates)
+    assert d.all_candidates.shape == (1033, 1) and d.all_candidates[3, 0] == "" and d.all_candidates[701, 0] == "2ACCT"
+    assert d[701][3][0] == "2ACCT" and d[0][0] == "chr20" and d[1000][0] == "chr20"
+    probs = rng.random((1033, 3)).astype(np.float32)
+    old, new = PredStore(str(tmp_path / "old.hdf"), "w"), PredStore(str(tmp_path / "new.hdf"), "w")
+    off = 0
+    for b, (contigs, positions, depths, candidates, freqs, _) in enumerate(d.batches(256)):
+        e = off + len(positions)
+        old.write_prediction(b, [c.decode() for c in contigs], positions, depths, candidates, freqs, probs[off:e])
+        new.write_prediction_arrays(b, d.all_contigs[off:e], d.all_positions[off:e], d.all_depths[off:e], d.candidate_blob,
+                                    d.candidate_offsets[off:e], d.all_candidate_frequency[off:e], probs[off:e])
+        off = e
+    old.close()
+    new.close()
+    with h5.File(str(tmp_path / "old.hdf")) as a, h5.File(str(tmp_path / "new.hdf")) as c:
+        names = a.keys("predictions")
+        assert names == c.keys("predictions") and len(names) == 5
+        for nm in names:
+            for ds_name in ("contigs", "positions", "depths", "candidates", "candidate_frequency", "base_prediction"):
+                p = "predictions/%s/%s" % (nm, ds_name)
+                assert a.info(p) == c.info(p), (p, a.info(p), c.info(p))
+                assert np.array_equal(a[p], c[p]), p
