@@ -81,6 +81,20 @@ int pa_h5_write_prediction_batch(pa_h5* f, const char* group, int32_t n, const c
                                  const int32_t* positions, const uint8_t* depths, const char* cand_blob,
                                  const int64_t* cand_offsets, const uint8_t* freqs, const float* probs, int32_t n_classes);
 
+/* Polish stores, one block of chunks per call (the format keeps one group per 1000-row chunk):
+ * read    summaries/<name>/{image u8 [seq,features], position, index [seq], region_start, region_end, chunk_id, contig}
+ *         for the n NUL-separated group names into caller arrays (pepper/.../DataStore.py:53-67, dataloader_predict.py);
+ * write   predictions/<contig>/<contig>-<start>-<end>/{contig_start, contig_end} where new_region[i] is set and
+ *         .../<chunk_id>/{position, index int64 [seq], bases, phred_score uint8 [seq]} unless skip[i]
+ *         (pepper/.../DataStorePredict.py:49-76). */
+int pa_h5_read_polish_chunks(pa_h5* f, const char* names, int32_t n, int32_t seq_len, int32_t features, uint8_t* images,
+                             int64_t* position, int64_t* index, int64_t* region_start, int64_t* region_end,
+                             int64_t* chunk_id, char* contigs, int32_t contig_stride);
+int pa_h5_write_polish_predictions(pa_h5* f, int32_t n, int32_t seq_len, const char* contigs, int32_t contig_stride,
+                                   const int64_t* contig_start, const int64_t* contig_end, const int64_t* chunk_id,
+                                   const uint8_t* new_region, const uint8_t* skip, const int64_t* position,
+                                   const int64_t* index, const uint8_t* bases, const uint8_t* phred);
+
 /* ------------------------------------------------------------------------------------------
  * BAM ingestion (pepper_amd/csrc/bamio.cpp; zlib, no htslib)
  * replaces the pybind surface of PEPPER_VARIANT.BAM_handler:

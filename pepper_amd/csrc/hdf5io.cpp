@@ -347,4 +347,126 @@ int pa_h5_write_prediction_batch(pa_h5* f, const char* group, int32_t n, const c
     return rc;
 }
 
+// ---- polish stores in bulk: the format keeps one group per 1000-row chunk (8 small datasets in the image file, 4 in the
+// prediction file), so a region-sized device pass touches thousands of datasets; these entry points do the whole block
+// inside the library instead of one Python-level call per dataset.
+
+static int read_numeric(hid_t loc, const char* name, hid_t mem_type, int64_t expect, void* out, const std::string& where) {
+    hid_t d = H5Dopen2(loc, name, H5P_DEFAULT);
+    if (d < 0) return fail("no dataset '" + where + name + "'");
+    hid_t sp = H5Dget_space(d);
+    const hssize_t n = H5Sget_simple_extent_npoints(sp);
+    int rc = 0;
+    if (n != expect) rc = fail("'" + where + name + "' has " + std::to_string((long long)n) + " elements, expected " + std::to_string((long long)expect));
+    else if (H5Dread(d, mem_type, H5S_ALL, H5S_ALL, H5P_DEFAULT, out) < 0) rc = fail("H5Dread failed for '" + where + name + "'");
+    H5Sclose(sp);
+    H5Dclose(d);
+    return rc;
+}
+
+static int read_string_scalar(hid_t loc, const char* name, char* out, int32_t cap, const std::string& where) {
+    hid_t d = H5Dopen2(loc, name, H5P_DEFAULT);
+    if (d < 0) return fail("no dataset '" + where + name + "'");
+    hid_t ty = H5Dget_type(d), sp = H5Dget_space(d);
+    int rc = 0;
+    std::memset(out, 0, (size_t)cap);
+    if (H5Tget_class(ty) != H5T_STRING || H5Sget_simple_extent_npoints(sp) != 1) rc = fail("'" + where + name + "' is not a string scalar");
+    else if (H5Tis_variable_str(ty) > 0) {
+        char* ptr = nullptr;
+        hid_t mt = H5Tcopy(H5T_C_S1);
+        H5Tset_size(mt, H5T_VARIABLE);
+        H5Tset_cset(mt, H5Tget_cset(ty));
+        if (H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, &ptr) < 0) rc = fail("H5Dread failed for '" + where + name + "'");
+        else {
+            if (ptr) {
+                if ((int32_t)strlen(ptr) >= cap) rc = fail("contig name longer than the buffer in '" + where + name + "'");
+                else std::strcpy(out, ptr);
+            }
+            H5Dvlen_reclaim(mt, sp, H5P_DEFAULT, &ptr);
+        }
+        H5Tclose(mt);
+    } else {
+        const size_t w = H5Tget_size(ty);
+        std::vector<char> raw(w + 1, 0);
+        if (H5Dread(d, ty, H5S_ALL, H5S_ALL, H5P_DEFAULT, raw.data()) < 0) rc = fail("H5Dread failed for '" + where + name + "'");
+        else if ((int32_t)strnlen(raw.data(), w) >= cap) rc = fail("contig name longer than the buffer in '" + where + name + "'");
+        else std::memcpy(out, raw.data(), strnlen(raw.data(), w));
+    }
+    H5Sclose(sp);
+    H5Tclose(ty);
+    H5Dclose(d);
+    return rc;
+}
+
+int pa_h5_read_polish_chunks(pa_h5* f, const char* names, int32_t n, int32_t seq_len, int32_t features, uint8_t* images,
+                             int64_t* position, int64_t* index, int64_t* region_start, int64_t* region_end,
+                             int64_t* chunk_id, char* contigs, int32_t contig_stride) {
+    if (!f || n < 0 || seq_len <= 0 || features <= 0 || contig_stride <= 1 ||
+        (n > 0 && (!names || !images || !position || !index || !region_start || !region_end || !chunk_id || !contigs)))
+        return fail("bad argument");
+    Quiet q;
+    const char* name = names;
+    for (int32_t i = 0; i < n; ++i, name += strlen(name) + 1) {
+        const std::string where = std::string("summaries/") + name + "/";
+        hid_t g = H5Gopen2(f->file, where.c_str(), H5P_DEFAULT);
+        if (g < 0) return fail("no group '" + where + "'");
+        int rc = read_numeric(g, "image", H5T_NATIVE_UINT8, (int64_t)seq_len * features, images + (size_t)i * seq_len * features, where);
+        if (!rc) rc = read_numeric(g, "position", H5T_NATIVE_INT64, seq_len, position + (size_t)i * seq_len, where);
+        if (!rc) rc = read_numeric(g, "index", H5T_NATIVE_INT64, seq_len, index + (size_t)i * seq_len, where);
+        if (!rc) rc = read_numeric(g, "region_start", H5T_NATIVE_INT64, 1, region_start + i, where);
+        if (!rc) rc = read_numeric(g, "region_end", H5T_NATIVE_INT64, 1, region_end + i, where);
+        if (!rc) rc = read_numeric(g, "chunk_id", H5T_NATIVE_INT64, 1, chunk_id + i, where);
+        if (!rc) rc = read_string_scalar(g, "contig", contigs + (size_t)i * contig_stride, contig_stride, where);
+        H5Gclose(g);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int pa_h5_write_polish_predictions(pa_h5* f, int32_t n, int32_t seq_len, const char* contigs, int32_t contig_stride,
+                                   const int64_t* contig_start, const int64_t* contig_end, const int64_t* chunk_id,
+                                   const uint8_t* new_region, const uint8_t* skip, const int64_t* position,
+                                   const int64_t* index, const uint8_t* bases, const uint8_t* phred) {
+    if (!f || n < 0 || seq_len <= 0 || contig_stride <= 0 ||
+        (n > 0 && (!contigs || !contig_start || !contig_end || !chunk_id || !new_region || !skip || !position || !index ||
+                   !bases || !phred)))
+        return fail("bad argument");
+    Quiet q;
+    hsize_t dims[1] = {(hsize_t)seq_len};
+    hid_t sp_row = H5Screate_simple(1, dims, nullptr), sp_one = H5Screate(H5S_SCALAR);
+    int rc = 0;
+    auto put = [&](hid_t loc, const char* name, hid_t ft, hid_t mt, hid_t sp, const void* data, const std::string& where) {
+        if (rc) return;
+        hid_t d = H5Dcreate2(loc, name, ft, sp, f->lcpl, H5P_DEFAULT, H5P_DEFAULT);
+        if (d < 0) { rc = fail("cannot create dataset '" + where + "/" + name + "' (already exists?)"); return; }
+        if (H5Dwrite(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0) rc = fail("H5Dwrite failed for '" + where + "/" + name + "'");
+        H5Dclose(d);
+    };
+    for (int32_t i = 0; i < n && !rc; ++i) {
+        const char* c = contigs + (size_t)i * contig_stride;
+        const std::string contig(c, strnlen(c, (size_t)contig_stride));
+        const std::string region = "predictions/" + contig + "/" + contig + "-" + std::to_string((long long)contig_start[i]) + "-" +
+                                   std::to_string((long long)contig_end[i]);
+        if (new_region[i]) {
+            hid_t g = H5Gcreate2(f->file, region.c_str(), f->lcpl, H5P_DEFAULT, H5P_DEFAULT);
+            if (g < 0) { rc = fail("cannot create group '" + region + "'"); break; }
+            put(g, "contig_start", H5T_STD_I64LE, H5T_NATIVE_INT64, sp_one, contig_start + i, region);
+            put(g, "contig_end", H5T_STD_I64LE, H5T_NATIVE_INT64, sp_one, contig_end + i, region);
+            H5Gclose(g);
+        }
+        if (skip[i] || rc) continue;
+        const std::string chunk = region + "/" + std::to_string((long long)chunk_id[i]);
+        hid_t g = H5Gcreate2(f->file, chunk.c_str(), f->lcpl, H5P_DEFAULT, H5P_DEFAULT);
+        if (g < 0) { rc = fail("cannot create group '" + chunk + "'"); break; }
+        put(g, "position", H5T_STD_I64LE, H5T_NATIVE_INT64, sp_row, position + (size_t)i * seq_len, chunk);
+        put(g, "index", H5T_STD_I64LE, H5T_NATIVE_INT64, sp_row, index + (size_t)i * seq_len, chunk);
+        put(g, "bases", H5T_STD_U8LE, H5T_NATIVE_UINT8, sp_row, bases + (size_t)i * seq_len, chunk);
+        put(g, "phred_score", H5T_STD_U8LE, H5T_NATIVE_UINT8, sp_row, phred + (size_t)i * seq_len, chunk);
+        H5Gclose(g);
+    }
+    H5Sclose(sp_row);
+    H5Sclose(sp_one);
+    return rc;
+}
+
 }  // extern "C"

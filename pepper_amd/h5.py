@@ -36,6 +36,8 @@ SYMBOLS = [
     ("pa_h5_read_strings", ctypes.c_int, [c_void_p, c_char_p, c_void_p, c_int64, P64]),
     ("pa_h5_write_fixed_strings", ctypes.c_int, [c_void_p, c_char_p, c_int32, P64, c_int32, c_void_p]),
     ("pa_h5_write_vlen_strings", ctypes.c_int, [c_void_p, c_char_p, c_int32, P64, ctypes.POINTER(c_char_p)]),
+    ("pa_h5_read_polish_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32]),
+    ("pa_h5_write_polish_predictions", ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 9),
     ("pa_h5_write_prediction_batch", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
 ]
@@ -150,6 +152,28 @@ class File(object):
         buf = ctypes.create_string_buffer(max(1, needed.value))
         _check(self._lib.pa_h5_read_strings(self._h, path.encode(), buf, needed.value, ctypes.byref(needed)))
         return buf.raw[:needed.value]
+
+    @_locked
+    def read_polish_chunks(self, names, seq_len, features, contig_width=256):
+        """summaries/<name> groups of a polish image file as bulk arrays (one library call for the block)."""
+        n = len(names)
+        images = np.empty((n, seq_len, features), np.uint8)
+        position, index = np.empty((n, seq_len), np.int64), np.empty((n, seq_len), np.int64)
+        start, end, chunk = np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.int64)
+        contigs = np.zeros(n, dtype=f"S{contig_width}")
+        blob = b"".join(s.encode() + b"\0" for s in names)
+        _check(self._lib.pa_h5_read_polish_chunks(self._h, blob, n, seq_len, features, images.ctypes.data, position.ctypes.data,
+                                                  index.ctypes.data, start.ctypes.data, end.ctypes.data, chunk.ctypes.data,
+                                                  contigs.ctypes.data, contig_width))
+        return contigs, start, end, chunk, images, position, index
+
+    @_locked
+    def write_polish_predictions(self, contigs, start, end, chunk, new_region, skip, position, index, bases, phred):
+        n, seq_len = bases.shape
+        _check(self._lib.pa_h5_write_polish_predictions(self._h, n, seq_len, contigs.ctypes.data, contigs.dtype.itemsize,
+                                                        start.ctypes.data, end.ctypes.data, chunk.ctypes.data,
+                                                        new_region.ctypes.data, skip.ctypes.data, position.ctypes.data,
+                                                        index.ctypes.data, bases.ctypes.data, phred.ctypes.data))
 
     @_locked
     def write_prediction_batch(self, group, contigs, positions, depths, cand_blob, cand_offsets, freqs, probs):

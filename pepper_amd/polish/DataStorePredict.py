@@ -48,3 +48,27 @@ class DataStore(object):
             fh[base + 'index'] = np.asarray(index)
             fh[base + 'bases'] = np.asarray(predicted_bases).astype(np.uint8)
             fh[base + 'phred_score'] = np.asarray(phred_score).astype(np.uint8)
+
+    def write_predictions_block(self, contigs, contig_start, contig_end, chunk_id, position, index, predicted_bases,
+                                phred_score):
+        """write_prediction for a block of chunks in one library call (contigs: numpy 'S' array; the other arguments
+        int64 / uint8 arrays with one row per chunk).  Same groups, datasets and duplicate handling."""
+        n = len(contigs)
+        new_region, skip = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        for i in range(n):
+            contig = contigs[i].decode('UTF-8')
+            prefix = contig + "-" + str(int(contig_start[i])) + "-" + str(int(contig_end[i]))
+            name = contig + prefix + str(int(chunk_id[i]))
+            if prefix not in self._contigs:
+                self._contigs.add(prefix)
+                new_region[i] = 1
+            if name in self._predictions:
+                skip[i] = 1
+            else:
+                self._predictions.add(name)
+        self.file_handler.write_polish_predictions(
+            np.ascontiguousarray(contigs), np.ascontiguousarray(contig_start, dtype=np.int64),
+            np.ascontiguousarray(contig_end, dtype=np.int64), np.ascontiguousarray(chunk_id, dtype=np.int64), new_region, skip,
+            np.ascontiguousarray(position, dtype=np.int64), np.ascontiguousarray(index, dtype=np.int64),
+            np.ascontiguousarray(predicted_bases, dtype=np.uint8), np.ascontiguousarray(phred_score, dtype=np.uint8))
+

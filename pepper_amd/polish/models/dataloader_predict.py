@@ -51,3 +51,16 @@ class SequenceDataset(object):
             yield ([it[0] for it in items], [it[1] for it in items], [it[2] for it in items],
                    [it[3] for it in items], np.stack([it[4] for it in items]).astype(np.uint8),
                    [it[5] for it in items], [it[6] for it in items])
+
+    def blocks(self, batch_size, seq_len, features):
+        """The same stacked blocks as batches(), read by one library call per (file, block): contigs come back as a
+        numpy 'S' array, region bounds / chunk ids / positions / indices as int64 arrays."""
+        s = 0
+        while s < len(self):
+            path = self.all_images[s][0]
+            e = s
+            while e < len(self) and e - s < batch_size and self.all_images[e][0] == path:
+                e += 1
+            yield self._file(path).read_polish_chunks([name for _, name in self.all_images[s:e]], seq_len, features)
+            s = e
+

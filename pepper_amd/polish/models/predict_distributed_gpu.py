@@ -45,9 +45,11 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
     # next block is read (libhdf5 under the h5 lock, GIL released) while the GPU works on this one
     from concurrent.futures import ThreadPoolExecutor
     device_batch = max(int(batch_size), DEVICE_CHUNKS)
-    blocks = input_data.batches(device_batch)
+    blocks = input_data.blocks(device_batch, ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT)
     reader = ThreadPoolExecutor(max_workers=1)
+    writer = ThreadPoolExecutor(max_workers=1)       # single FIFO worker: groups are created in reading order
     pending = reader.submit(next, blocks, None)
+    writes = []
     try:
         while True:
             block = pending.result()
@@ -56,15 +58,18 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
             pending = reader.submit(next, blocks, None)
             contig, contig_start, contig_end, chunk_id, images, position, index = block
             labels, phred = model.predict_chunks(torch.from_numpy(images))
-            labels, phred = labels.numpy(), phred.numpy()
-            for i in range(len(contig)):
-                prediction_data_file.write_prediction(contig[i], contig_start[i], contig_end[i], chunk_id[i],
-                                                      position[i], index[i], labels[i], phred[i])
+            writes.append(writer.submit(prediction_data_file.write_predictions_block, contig, contig_start, contig_end,
+                                        chunk_id, position, index, labels.numpy(), phred.numpy()))
+            if len(writes) > 2:
+                writes.pop(0).result()               # surfaces writer errors early, bounds the queue
             done += 1
             if rank == 0:
                 _log("INFO: BATCHES PROCESSED " + str(done) + ".")
+        for w in writes:
+            w.result()
     finally:
         reader.shutdown(wait=True)
+        writer.shutdown(wait=True)
         input_data.close()
         prediction_data_file.close()
     return rank

@@ -73,8 +73,8 @@ def test_call_consensus_end_to_end(tmp_path):
     chunks = synthetic.polish_chunks(5, seed=900)
     with DataStore(str(img_dir / "pepper_images_thread_0.hdf"), "w") as ds:
         for cid in range(5):
-            pos = [(2000 + i, 0) for i in range(1000)]
-            ds.write_summary(("contig_7", 2000, 3000), chunks[cid].tolist(), [0] * 1000, pos, list(range(1000)), cid,
+            pos = [2000 + i for i in range(1000)]        # position, index = zip(*positions[i]) (ImageGenerationUI.py:198)
+            ds.write_summary(("contig_7", 2000, 3000), chunks[cid].tolist(), [0] * 1000, pos, [i % 2 for i in range(1000)], cid,
                              f"contig_7_2000_3000_{cid}")
     sd = synthetic.polish_state_dict(seed=42, gain=2.0)
     model_path = str(tmp_path / "polish.pkl")
@@ -89,7 +89,8 @@ def test_call_consensus_end_to_end(tmp_path):
             assert got_b.dtype == np.uint8 and got_b.shape == (1000,)
             assert (got_b == labels[cid]).mean() > 0.999
             assert (got_p == phred[cid]).mean() > 0.99
-            assert f[base + f"{cid}/position"].shape == (1000, 2)
+            assert f[base + f"{cid}/position"].tolist() == list(range(2000, 3000))
+            assert f[base + f"{cid}/index"].tolist() == [i % 2 for i in range(1000)]
 
 
 class _FakeFasta(object):

@@ -185,3 +185,59 @@ def test_bulk_prediction_writer_and_loader_equal_the_per_dataset_path(tmp_path):
                 p = "predictions/%s/%s" % (nm, ds_name)
                 assert a.info(p) == c.info(p), (p, a.info(p), c.info(p))
                 assert np.array_equal(a[p], c[p]), p
+
+
+def test_polish_bulk_block_io_equals_the_per_dataset_path(tmp_path):
+    """The polish predict loop reads image chunks and writes predictions a block at a time inside the library."""
+    from pepper_amd import synthetic
+    from pepper_amd.polish.DataStore import DataStore
+    from pepper_amd.polish.DataStorePredict import DataStore as PredStore
+    from pepper_amd.polish.models.dataloader_predict import SequenceDataset
+    n = 37
+    chunks = synthetic.polish_chunks(n, seed=1)
+    path = str(tmp_path / "img.hdf")
+    with DataStore(path, "w") as ds:
+        for c in range(n):
+            region = ("ctg1" if c < 20 else "contig_number_two", (c // 3) * 1000, (c // 3) * 1000 + 1200)
+            ds.write_summary(region, chunks[c], np.zeros(1000, np.uint8), np.arange(1000) + region[1], np.arange(1000) % 3, c % 3,
+                             "%s_%d_%d_%d" % (region[0], region[1], region[2], c % 3))
+    d = SequenceDataset(str(tmp_path), [path])
+    old_blocks, new_blocks = list(d.batches(16)), list(d.blocks(16, 1000, 10))
+    assert [len(b[0]) for b in new_blocks] == [16, 16, 5]
+    for (c0, s0, e0, k0, im0, p0, i0), (c1, s1, e1, k1, im1, p1, i1) in zip(old_blocks, new_blocks):
+        assert [x if isinstance(x, str) else x.decode() for x in c0] == [x.decode() for x in c1]
+        assert list(map(int, s0)) == s1.tolist() and list(map(int, e0)) == e1.tolist() and list(map(int, k0)) == k1.tolist()
+        assert np.array_equal(im0, im1) and np.array_equal(np.stack(p0), p1) and np.array_equal(np.stack(i0), i1)
+    rng = np.random.default_rng(0)
+    labels, phred = rng.integers(0, 5, (n, 1000)).astype(np.uint8), rng.integers(0, 60, (n, 1000)).astype(np.uint8)
+    old, new = PredStore(str(tmp_path / "old.hdf"), "w"), PredStore(str(tmp_path / "new.hdf"), "w")
+    k = 0
+    for (c0, s0, e0, k0, _, p0, i0), (c1, s1, e1, k1, _, p1, i1) in zip(old_blocks, new_blocks):
+        m = len(c1)
+        for i in range(m):
+            old.write_prediction(c0[i], s0[i], e0[i], k0[i], p0[i], i0[i], labels[k + i], phred[k + i])
+        new.write_predictions_block(c1, s1, e1, k1, p1, i1, labels[k:k + m], phred[k:k + m])
+        new.write_predictions_block(c1[:2], s1[:2], e1[:2], k1[:2], p1[:2], i1[:2], labels[k:k + 2], phred[k:k + 2])   # duplicates are skipped
+        k += m
+    old.close()
+    new.close()
+
+    def walk(f, g):
+        out = {}
+        for name in f.keys(g):
+            p = g + "/" + name
+            try:
+                kids = f.keys(p)
+            except h5.H5Error:
+                kids = None
+            if kids:
+                out.update(walk(f, p))
+            else:
+                out[p] = (f.info(p), f[p])
+        return out
+    with h5.File(str(tmp_path / "old.hdf")) as a, h5.File(str(tmp_path / "new.hdf")) as b:
+        wa, wb = walk(a, "predictions"), walk(b, "predictions")
+        assert wa.keys() == wb.keys() and len(wa) == 4 * n + 2 * 14
+        for key in wa:
+            assert wa[key][0] == wb[key][0], (key, wa[key][0], wb[key][0])
+            assert np.array_equal(wa[key][1], wb[key][1]), key
