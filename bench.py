@@ -181,7 +181,7 @@ def realign_bench(args):
     from pepper_amd.polish.PEPPER import ReadAligner
     rng = np.random.default_rng(5)
     reference = "".join("ACGT"[k] for k in rng.integers(0, 4, 1020))
-    pos, seqs = ssw.simulate_reads(rng, reference, 0, args.per_gpu or 1500, sub=0.04, ins=0.03, dele=0.04, min_len=200,
+    pos, seqs = synthetic.simulate_clipped_reads(rng, reference, 0, args.per_gpu or 1500, sub=0.04, ins=0.03, dele=0.04, min_len=200,
                                    full_span=0.85)
     blob = [q.encode() for q in seqs]
     off = np.zeros(len(seqs) + 1, np.int64)

@@ -84,27 +84,7 @@ def realign_reads(reference, region_start, read_pos, sequences, aligner=align):
     return out
 
 
-def simulate_reads(rng, reference, region_start, n_reads, sub=0.04, ins=0.03, dele=0.04, min_len=30, full_span=0.0):
-    """Noisy reads of a reference window (nanopore-like error mix), clipped like the polish BAM reader clips them;
-    a fraction `full_span` of them covers the whole window (long reads over a 1 kb region)."""
-    bases = "ACGT"
-    n = len(reference)
-    pos, seqs = [], []
-    for _ in range(n_reads):
-        a = int(rng.integers(0, max(1, n - min_len)))
-        b = int(rng.integers(min(n, a + min_len), n + 1)) if rng.random() < 0.5 else n
-        if full_span and rng.random() < full_span:
-            a, b = 0, n
-        out = []
-        for ch in reference[a:b]:
-            u = rng.random()
-            if u < dele:
-                continue
-            if u < dele + sub:
-                ch = bases[int(rng.integers(4))]
-            out.append(ch)
-            while rng.random() < ins:
-                out.append(bases[int(rng.integers(4))])
-        pos.append(region_start + a)
-        seqs.append("".join(out) or "A")
-    return pos, seqs
+def simulate_reads(rng, reference, region_start, n_reads, **kw):
+    """Test inputs: pepper_amd.synthetic.simulate_clipped_reads (kept under this name for the tests)."""
+    from pepper_amd.synthetic import simulate_clipped_reads
+    return simulate_clipped_reads(rng, reference, region_start, n_reads, **kw)
