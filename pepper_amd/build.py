@@ -59,7 +59,9 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    # -mf16c on the host side: weight packing converts ~24 M values to f16 hi/lo halves at model creation; without the
+    # F16C conversions clang calls a soft-float routine per value (0.4 s per variant model instead of tens of ms)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Xarch_host", "-mf16c",
            "-Wno-unused-result", "-o", LIB + ".tmp"] + SOURCES
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
