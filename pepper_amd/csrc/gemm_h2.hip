@@ -396,9 +396,10 @@ extern "C" int pa_debug_gemm_h2(const float* A, const float* W, const float* bia
         ok(hipEventElapsedTime(&ms, e0, e1));
         if (ms_out) *ms_out = iters > 0 ? ms / iters : 0.0f;
         ok(hipMemcpy(C, dC, c_elems * 4, hipMemcpyDeviceToHost));
-        hipEventDestroy(e0); hipEventDestroy(e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
     }
-    hipFree(dA); hipFree(dA2); hipFree(dW); hipFree(dB); hipFree(dC);
+    for (void* p : {(void*)dA, (void*)dA2, (void*)dW, (void*)dB, (void*)dC}) (void)hipFree(p);
     if (e != hipSuccess) return pa::set_error((int)e, std::string("pa_debug_gemm_h2: ") + hipGetErrorString(e));
     return 0;
 }
