@@ -43,10 +43,11 @@ def polish_genome_distributed_gpu(image_dir, model_path, batch_size, num_workers
     if total_callers == 0:
         raise RuntimeError("ERROR: NO GPU AVAILABLE BUT GPU MODE IS SET")
     input_files = get_file_paths_from_directory(image_dir)
-    file_chunks = [[] for _ in range(total_callers)]
-    for i in range(len(input_files)):
-        file_chunks[i % total_callers].append(input_files[i])
-    file_chunks = [c for c in file_chunks if c]
+    # the reference deals the files round robin (call_consensus.py:93-97); with more than one GPU they go largest
+    # first onto the least loaded one instead (same rule as pepper_amd.variant.RunInference.shard_files)
+    from pepper_amd.variant.RunInference import shard_files
+    file_chunks = shard_files(input_files, total_callers,
+                              sizes=[os.path.getsize(f) for f in input_files] if total_callers > 1 else None)
     device_ids = device_ids[:max(1, len(file_chunks))]
     _log("INFO: TOTAL THREADS: " + str(len(device_ids)))
     predict_distributed_gpu(image_dir, file_chunks, output_dir, model_path, batch_size, device_ids, num_workers)

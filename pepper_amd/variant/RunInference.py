@@ -40,11 +40,24 @@ def handle_output_directory(output_dir):
     return output_dir
 
 
-def shard_files(input_files, callers):
-    """file_chunks[i % callers].append(input_files[i]); empty chunks dropped (RunInference.py:104-110)."""
+def shard_files(input_files, callers, sizes=None):
+    """Files -> one list per caller, empty lists dropped.  Without sizes: the reference's round robin,
+    file_chunks[i % callers].append(input_files[i]) (RunInference.py:104-110).  With sizes (bytes per file): largest
+    file first onto the least loaded caller -- image files differ by a lot between chromosomes, and a GPU that finishes
+    early just idles; the prediction files are merged by directory listing downstream, so the assignment is free."""
     chunks = [[] for _ in range(callers)]
-    for i, f in enumerate(input_files):
-        chunks[i % callers].append(f)
+    if sizes is None:
+        for i, f in enumerate(input_files):
+            chunks[i % callers].append(f)
+    else:
+        load = [0] * callers
+        for i in sorted(range(len(input_files)), key=lambda k: (-sizes[k], k)):
+            r = min(range(callers), key=lambda c: (load[c], c))
+            chunks[r].append(input_files[i])
+            load[r] += sizes[i]
+        order = {f: i for i, f in enumerate(input_files)}
+        for c in chunks:
+            c.sort(key=order.get)
     return [c for c in chunks if c]
 
 
@@ -89,7 +102,8 @@ def distributed_gpu(options, image_dir, output_dir):
     if len(device_ids) == 0:
         raise RuntimeError("ERROR: NO GPU AVAILABLE BUT GPU MODE IS SET")
     input_files = get_file_paths_from_directory(image_dir)
-    file_chunks = shard_files(input_files, len(device_ids))
+    file_chunks = shard_files(input_files, len(device_ids),
+                              sizes=[os.path.getsize(f) for f in input_files] if len(device_ids) > 1 else None)
     world = max(1, min(len(device_ids), len(file_chunks)))
     threads_per_caller = max(1, int(options.threads / world))
     _log("INFO: TOTAL CALLERS: " + str(world))

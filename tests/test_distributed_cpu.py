@@ -82,3 +82,12 @@ def test_shard_files_matches_reference_rule():
     assert shard_files(files, 2) == [["f0", "f2", "f4"], ["f1", "f3"]]
     assert shard_files(files[:1], 4) == [["f0"]]                    # empty chunks dropped
     assert shard_files([], 4) == []
+    # with file sizes: largest first onto the least loaded caller (whole-genome shards differ by chromosome length)
+    sizes = [248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51]
+    names = ["chr%d" % (i + 1) for i in range(22)]
+    got = shard_files(names, 8, sizes=sizes)
+    loads = [sum(sizes[names.index(f)] for f in chunk) for chunk in got]
+    assert sorted(f for chunk in got for f in chunk) == sorted(names) and len(got) == 8
+    assert max(loads) <= 1.08 * (sum(sizes) / 8)
+    assert max(sum(sizes[i] for i in range(r, 22, 8)) for r in range(8)) > 1.25 * (sum(sizes) / 8)      # round robin would not be
+    assert all(chunk == sorted(chunk, key=names.index) for chunk in got)
