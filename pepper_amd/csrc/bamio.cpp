@@ -22,7 +22,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/pepper_amd_io.h"
@@ -37,17 +40,41 @@ int bam_fail(int code, const std::string& msg) {
 
 struct Bgzf {
     FILE* fp = nullptr;
-    std::vector<uint8_t> block;      // decompressed current block
+    // Decompressed blocks are kept (FIFO, 256 x <= 64 KiB): image generation queries consecutive ~1 kb regions, and every
+    // query re-reads the records of the 16 kb index window in front of it -- with long reads that is the same couple
+    // of megabytes over and over, and inflating them was most of a query's time.
+    typedef std::shared_ptr<std::vector<uint8_t>> Block;
+    struct Cached { Block data; int64_t next; };
+    std::unordered_map<int64_t, Cached> cache;
+    std::deque<int64_t> order;
+    static constexpr size_t kCacheBlocks = 256;
+    Block cur = std::make_shared<std::vector<uint8_t>>();   // decompressed current block
     int64_t block_coffset = -1;      // file offset of the current block
     int64_t next_coffset = 0;        // file offset of the block after it
-    size_t upos = 0;                 // read position inside `block`
+    size_t upos = 0;                 // read position inside the current block
     bool eof = false;
 
     bool load_block(int64_t coffset) {
+        const auto hit = cache.find(coffset);
+        if (hit != cache.end()) {
+            cur = hit->second.data;
+            block_coffset = coffset;
+            next_coffset = hit->second.next;
+            upos = 0;
+            eof = false;
+            return true;
+        }
         if (fseeko(fp, coffset, SEEK_SET) != 0) return false;
         uint8_t hdr[18];
         const size_t got = fread(hdr, 1, 18, fp);
-        if (got == 0) { eof = true; block.clear(); upos = 0; block_coffset = coffset; next_coffset = coffset; return true; }
+        if (got == 0) {
+            eof = true;
+            cur = std::make_shared<std::vector<uint8_t>>();
+            upos = 0;
+            block_coffset = coffset;
+            next_coffset = coffset;
+            return true;
+        }
         if (got != 18 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) return false;
         const int xlen = hdr[10] | (hdr[11] << 8);
         // the BC subfield is the first extra field in every BGZF writer; scan anyway
@@ -66,43 +93,50 @@ struct Bgzf {
         std::vector<uint8_t> comp(clen + 8);
         if (fread(comp.data(), 1, clen + 8, fp) != (size_t)(clen + 8)) return false;
         const uint32_t isize = comp[clen + 4] | (comp[clen + 5] << 8) | (comp[clen + 6] << 16) | ((uint32_t)comp[clen + 7] << 24);
-        block.resize(isize);
+        Block fresh = std::make_shared<std::vector<uint8_t>>(isize);
         if (isize) {
             z_stream zs{};
             if (inflateInit2(&zs, -15) != Z_OK) return false;
             zs.next_in = comp.data();
             zs.avail_in = clen;
-            zs.next_out = block.data();
+            zs.next_out = fresh->data();
             zs.avail_out = isize;
             const int rc = inflate(&zs, Z_FINISH);
             inflateEnd(&zs);
             if (rc != Z_STREAM_END) return false;
         }
+        cur = fresh;
         block_coffset = coffset;
         next_coffset = coffset + bsize;
         upos = 0;
         eof = false;
+        if (order.size() >= kCacheBlocks) {
+            cache.erase(order.front());
+            order.pop_front();
+        }
+        cache[coffset] = Cached{fresh, next_coffset};
+        order.push_back(coffset);
         return true;
     }
     bool seek(uint64_t voffset) {
         const int64_t co = (int64_t)(voffset >> 16);
         if (co != block_coffset && !load_block(co)) return false;
         upos = voffset & 0xffff;
-        return upos <= block.size();
+        return upos <= cur->size();
     }
     // returns bytes read (< n only at end of file)
     size_t read(void* dst, size_t n) {
         size_t done = 0;
         uint8_t* out = static_cast<uint8_t*>(dst);
         while (done < n) {
-            if (upos >= block.size()) {
+            if (upos >= cur->size()) {
                 if (eof) break;
                 if (!load_block(next_coffset)) { eof = true; break; }
                 if (eof) break;
-                if (block.empty()) continue;          // empty block (e.g. the EOF marker)
+                if (cur->empty()) continue;           // empty block (e.g. the EOF marker)
             }
-            const size_t take = std::min(n - done, block.size() - upos);
-            std::memcpy(out + done, block.data() + upos, take);
+            const size_t take = std::min(n - done, cur->size() - upos);
+            std::memcpy(out + done, cur->data() + upos, take);
             upos += take;
             done += take;
         }

@@ -30,7 +30,9 @@ class AlignmentSummarizer:
         """Rows -> chunks of chunk_size, the next chunk starting chunk_overlap rows before the end
         of the previous one; the last chunk is padded with zero rows and (-1, -1) positions."""
         image = np.asarray(summary.image, dtype=np.uint8).reshape(-1, ImageSizeOptions.IMAGE_HEIGHT)
-        pos = np.asarray(summary.genomic_pos, dtype=np.int64).reshape(-1, 2)
+        pos = getattr(summary, "positions_array", None)        # the encoder's bulk form of genomic_pos
+        if pos is None:
+            pos = np.asarray(summary.genomic_pos, dtype=np.int64).reshape(-1, 2)
         total = len(pos)
         images, labels, positions, chunk_ids = [], [], [], []
         chunk_start, chunk_id = 0, 0

@@ -24,9 +24,21 @@ class SummaryGenerator(object):
         self.ref_end = int(ref_end)
         self.device = device
         self.image = np.zeros((0, 10), np.uint8)
-        self.genomic_pos = []
+        self.positions_array = np.zeros((0, 2), np.int64)
+        self._genomic_pos = []
         self.labels = []
         self.bad_label_positions = []
+
+    @property
+    def genomic_pos(self):
+        if self._genomic_pos is None:
+            self._genomic_pos = [tuple(x) for x in self.positions_array.tolist()]
+        return self._genomic_pos
+
+    @genomic_pos.setter
+    def genomic_pos(self, value):
+        self._genomic_pos = value
+        self.positions_array = np.asarray(value, dtype=np.int64).reshape(-1, 2)
 
     def generate_summary(self, reads, start_pos, end_pos):
         flat = reads if isinstance(reads, dict) else flatten_reads(reads)
@@ -44,8 +56,8 @@ class SummaryGenerator(object):
         pos = np.zeros((rows, 2), np.int64)
         _lib.check(lib.pa_polish_encoder_get_results(enc, image.ctypes.data, pos.ctypes.data))
         self.image = image
-        self.positions_array = pos
-        self.genomic_pos = [tuple(x) for x in pos.tolist()]
+        self.positions_array = pos          # [rows, 2] int64; `genomic_pos` (list of tuples) is built on first access
+        self._genomic_pos = None
 
 
 _realigners = {}
