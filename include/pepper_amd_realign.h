@@ -47,6 +47,16 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
                        int32_t* status, int32_t* sw_score, int64_t* new_pos, int64_t* new_pos_end,
                        int32_t* query_begin, int32_t* query_end, int64_t* n_cigar_ops);
 
+/* The same for the reads of several regions in one call (one job table, one pair of launches: a region at ordinary
+ * coverage is a few dozen wavefronts, far from filling the chip): `reference` holds the n_windows window texts back to
+ * back, window w = reference[window_offset[w] .. window_offset[w + 1]) starting at genome position window_start[w];
+ * read k belongs to window read_window[k] (NULL: all reads in window 0).  Outputs as above, in read order. */
+int pa_realigner_align_windows(pa_realigner* r, int32_t n_windows, const char* reference, const int64_t* window_offset,
+                               const int64_t* window_start, int32_t n_reads, const int32_t* read_window,
+                               const int64_t* read_pos, const int64_t* seq_offset, const char* seq, int32_t* status,
+                               int32_t* sw_score, int64_t* new_pos, int64_t* new_pos_end, int32_t* query_begin,
+                               int32_t* query_end, int64_t* n_cigar_ops);
+
 /* CIGARs of the last call: cigar_offset [n_reads + 1] (empty range for reads that were not aligned), operations in
  * BAM codes: 7 '=', 8 'X', 1 'I', 2 'D', 4 'S' (the text of Alignment.cigar_string).  With collapse_eqx != 0 the
  * codes 7 and 8 are returned as 0 (MATCH) without merging neighbouring runs, which is what

@@ -70,6 +70,8 @@ SYMBOLS = [
     ("pa_realigner_align", ctypes.c_int, [c_void_p, c_char_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           ctypes.POINTER(c_int64)]),
+    ("pa_realigner_align_windows", ctypes.c_int, [c_void_p, c_int32, c_char_p, c_void_p, c_void_p, c_int32] + [c_void_p] * 10 +
+                                                  [ctypes.POINTER(c_int64)]),
     ("pa_realigner_copy_cigars", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     ("pa_realigner_stage_ticks", ctypes.c_int, [c_void_p, c_void_p]),
     ("pa_realigner_last_timing", ctypes.c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double),

@@ -650,9 +650,24 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
                        int32_t n_reads, const int64_t* read_pos, const int64_t* seq_offset, const char* seq,
                        int32_t* status, int32_t* sw_score, int64_t* new_pos, int64_t* new_pos_end,
                        int32_t* query_begin, int32_t* query_end, int64_t* n_cigar_ops) {
-    if (!r || !n_cigar_ops || n_reads < 0 || reference_len < 0 || (n_reads > 0 && (!reference || !read_pos || !seq_offset ||
-        !seq || !status || !sw_score || !new_pos || !new_pos_end)))
+    if (reference_len < 0) return pa::set_error(PA_ERR_INVALID, "null argument");
+    const int64_t offsets[2] = {0, reference_len};
+    return pa_realigner_align_windows(r, 1, reference, offsets, &region_start, n_reads, nullptr, read_pos, seq_offset, seq,
+                                      status, sw_score, new_pos, new_pos_end, query_begin, query_end, n_cigar_ops);
+}
+
+int pa_realigner_align_windows(pa_realigner* r, int32_t n_windows, const char* reference, const int64_t* window_offset,
+                               const int64_t* window_start, int32_t n_reads, const int32_t* read_window,
+                               const int64_t* read_pos, const int64_t* seq_offset, const char* seq, int32_t* status,
+                               int32_t* sw_score, int64_t* new_pos, int64_t* new_pos_end, int32_t* query_begin,
+                               int32_t* query_end, int64_t* n_cigar_ops) {
+    if (!r || !n_cigar_ops || n_reads < 0 || n_windows <= 0 || !window_offset || !window_start ||
+        (n_reads > 0 && (!reference || !read_pos || !seq_offset || !seq || !status || !sw_score || !new_pos || !new_pos_end)))
         return pa::set_error(PA_ERR_INVALID, "null argument");
+    for (int32_t w = 0; w < n_windows; ++w)
+        if (window_offset[w + 1] < window_offset[w] || window_offset[0] != 0)
+            return pa::set_error(PA_ERR_INVALID, "window_offset must start at 0 and be monotonic");
+    const int64_t reference_len = window_offset[n_windows];
     if (reference_len > (int64_t)1 << 30) return pa::set_error(PA_ERR_INVALID, "reference window too long");
     RA_HIP(hipSetDevice(r->device));
     static const bool trace = getenv("PA_REALIGN_TRACE") != nullptr;      // host phase times on stderr
@@ -676,16 +691,19 @@ int pa_realigner_align(pa_realigner* r, const char* reference, int64_t reference
     bool any = false;
     for (int32_t k = 0; k < n_reads; ++k) {
         Job& J = r->jobs[(size_t)k];
-        const int64_t m = seq_offset[k + 1] - seq_offset[k], off = read_pos[k] - region_start;
+        const int32_t w = read_window ? read_window[k] : 0;
+        if (w < 0 || w >= n_windows) return pa::set_error(PA_ERR_INVALID, "read " + std::to_string(k) + ": bad window index");
+        const int64_t m = seq_offset[k + 1] - seq_offset[k], off = read_pos[k] - window_start[w];
+        const int64_t window_len = window_offset[w + 1] - window_offset[w];
         if (m < 0) return pa::set_error(PA_ERR_INVALID, "seq_offset is not monotonic");
         J.seq_off = seq_offset[k];
         J.m = (int32_t)std::min<int64_t>(m, INT32_MAX);
         J.ref_begin = J.read_begin = -1;
         if (off < 0) { J.state = ST_DROPPED; continue; }
-        if (off > reference_len)
+        if (off > window_len)
             return pa::set_error(PA_ERR_INVALID, "read " + std::to_string(k) + " starts beyond the reference window");
-        J.ref_off = (int32_t)off;
-        J.n = (int32_t)(reference_len - off);
+        J.ref_off = (int32_t)(window_offset[w] + off);
+        J.n = (int32_t)(window_len - off);
         if (m == 0 || J.n == 0) { J.state = ST_KEPT; continue; }
         if (m > MAX_READ)
             return pa::set_error(PA_ERR_INVALID, "read " + std::to_string(k) + " has " + std::to_string(m) +

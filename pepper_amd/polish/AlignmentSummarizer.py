@@ -63,20 +63,15 @@ class AlignmentSummarizer:
         aligner = PEPPER.ReadAligner(ref_start, ref_end, ref_sequence)
         return aligner.align_reads_to_reference(reads)
 
-    def create_summary(self, truth_bam_handler=None, train_mode=False, downsample_rate=1.0, realignment_flag=True):
-        """Argument order and defaults of the reference (AlignmentSummarizer.py:179): with realignment_flag (the
-        default) every read is re-aligned to the draft before encoding; realignment_flag=False encodes the reads as
-        aligned in the BAM."""
-        if train_mode:
-            raise NotImplementedError("train_mode image generation is outside the inference path")
+    def fetch_reads(self):
+        """Reads of the region as the reference fetches them: region-clipped, at most MAX_READS_IN_REGION of them by
+        reservoir sampling with the reference's seed (AlignmentSummarizer.py:296-326)."""
         read_start = max(0, self.region_start_position)
         read_end = self.region_end_position
         all_reads = self.bam_handler.get_reads(self.chromosome_name, read_start, read_end, False, 0, 0)
         total_reads = len(all_reads)
-        if total_reads == 0:
-            return [], [], [], []
-        flat = hasattr(all_reads, "as_pileup")          # pepper_amd.variant.bam.ReadSet (the same get_reads serves both)
         if total_reads > AlingerOptions.MAX_READS_IN_REGION:
+            flat = hasattr(all_reads, "as_pileup")
             random = np.random.RandomState(AlingerOptions.RANDOM_SEED)
             sample = []
             for i in range(total_reads):
@@ -87,9 +82,13 @@ class AlignmentSummarizer:
                     if j < AlingerOptions.MAX_READS_IN_REGION:
                         sample[j] = i
             all_reads = all_reads.take(sample) if flat else [all_reads[i] for i in sample]
-        if realignment_flag:
-            all_reads = self.reads_to_reference_realignment(self.region_start_position, self.region_end_position, all_reads)
-        if flat:
+        return all_reads
+
+    def summarise(self, all_reads):
+        """Reads (already re-aligned if that stage is on) -> chunked summary (AlignmentSummarizer.py:334-358)."""
+        if len(all_reads) == 0:
+            return [], [], [], []
+        if hasattr(all_reads, "as_pileup"):          # pepper_amd.variant.bam.ReadSet (the same get_reads serves both)
             all_reads = all_reads.as_pileup()
         ref_seq = self.fasta_handler.get_reference_sequence(self.chromosome_name, self.region_start_position,
                                                             self.region_end_position + 1)
@@ -98,3 +97,46 @@ class AlignmentSummarizer:
         summary_generator.generate_summary(all_reads, self.region_start_position, self.region_end_position)
         return self.chunk_images(summary_generator, chunk_size=ImageSizeOptions.SEQ_LENGTH,
                                  chunk_overlap=ImageSizeOptions.SEQ_OVERLAP)
+
+    def create_summary(self, truth_bam_handler=None, train_mode=False, downsample_rate=1.0, realignment_flag=True):
+        """Argument order and defaults of the reference (AlignmentSummarizer.py:179): with realignment_flag (the
+        default) every read is re-aligned to the draft before encoding; realignment_flag=False encodes the reads as
+        aligned in the BAM."""
+        if train_mode:
+            raise NotImplementedError("train_mode image generation is outside the inference path")
+        all_reads = self.fetch_reads()
+        if len(all_reads) == 0:
+            return [], [], [], []
+        if realignment_flag:
+            all_reads = self.reads_to_reference_realignment(self.region_start_position, self.region_end_position, all_reads)
+        return self.summarise(all_reads)
+
+    @staticmethod
+    def create_summaries(summarizers, realignment_flag=True):
+        """create_summary for several regions with ONE re-alignment call on the GPU (a region at ordinary coverage is a
+        few dozen wavefronts; the job table takes the reads of all regions).  Per-region results, in order."""
+        from pepper_amd.variant.bam import ReadSet
+        reads = [s.fetch_reads() for s in summarizers]
+        batchable = realignment_flag and all(isinstance(r, ReadSet) for r in reads)
+        if realignment_flag and not batchable:
+            reads = [s.reads_to_reference_realignment(s.region_start_position, s.region_end_position, r) if len(r) else r
+                     for s, r in zip(summarizers, reads)]
+        elif batchable and any(len(r) for r in reads):
+            windows = []
+            for s in summarizers:
+                ref_end = s.region_end_position + AlingerOptions.ALIGNMENT_SAFE_BASES
+                windows.append((s.region_start_position,
+                                s.fasta_handler.get_reference_sequence(s.chromosome_name, s.region_start_position, ref_end)))
+            counts = [len(r) for r in reads]
+            seq_lens = np.concatenate([r.seq_offset[1:] - r.seq_offset[:-1] for r in reads]) if sum(counts) else np.zeros(0, np.int64)
+            seq_offset = np.zeros(sum(counts) + 1, np.int64)
+            np.cumsum(seq_lens, out=seq_offset[1:])
+            out = PEPPER.align_windows(windows, np.repeat(np.arange(len(reads), dtype=np.int32), counts),
+                                       np.concatenate([r.pos for r in reads]), seq_offset,
+                                       np.concatenate([r.seq[:int(r.seq_offset[-1])] for r in reads]))
+            first, done = 0, []
+            for r in reads:
+                done.append(PEPPER.apply_alignment(r, out, first))
+                first += len(r)
+            reads = done
+        return [s.summarise(r) for s, r in zip(summarizers, reads)]

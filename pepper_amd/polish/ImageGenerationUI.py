@@ -44,8 +44,15 @@ class UserInterfaceView:
                                          end_position)
         return summarizer.create_summary(self.truth_bam_handler, self.train_mode, downsample_rate)
 
+    def parse_regions(self, bounds, downsample_rate):
+        """Several regions of this contig with one re-alignment call on the GPU; per-region results in order."""
+        summarizers = [AlignmentSummarizer(self.bam_handler, self.fasta_handler, self.chromosome_name, a, b) for a, b in bounds]
+        return AlignmentSummarizer.create_summaries(summarizers)
+
 
 class UserInterfaceSupport:
+    REGIONS_PER_CALL = 8          # intervals whose reads share one re-alignment call on the GPU
+
     @staticmethod
     def handle_output_directory(output_directory):
         if output_directory[-1] != "/":
@@ -128,15 +135,27 @@ class UserInterfaceSupport:
         start_time = time.time()
         views = {}
         with DataStore(file_name, 'w') as output_hdf_file:
-            for counter, (chr_name, _start, _end) in enumerate(intervals):
-                img_args = (chr_name, bam_file, draft_file, truth_bam, train_mode, downsample_rate)
-                images, labels, positions, chunk_ids, region = UserInterfaceSupport.single_worker(img_args, _start, _end,
-                                                                                                  views)
-                for i, image in enumerate(images):
-                    position, index = positions[i][:, 0], positions[i][:, 1]
-                    summary_name = str(region[0]) + "_" + str(region[1]) + "_" + str(region[2]) + "_" + str(chunk_ids[i])
-                    output_hdf_file.write_summary(region, image, labels[i], position, index, chunk_ids[i], summary_name)
-                if counter > 0 and counter % 10 == 0 and thread_id == 0:
+            counter = 0
+            while counter < len(intervals):
+                # up to REGIONS_PER_CALL consecutive intervals of one contig share a re-alignment call
+                chr_name = intervals[counter][0]
+                block = [intervals[counter]]
+                while (len(block) < UserInterfaceSupport.REGIONS_PER_CALL and counter + len(block) < len(intervals)
+                       and intervals[counter + len(block)][0] == chr_name):
+                    block.append(intervals[counter + len(block)])
+                key = (chr_name, bam_file, draft_file)
+                if key not in views:
+                    views.clear()           # one contig's handles at a time per worker
+                    views[key] = UserInterfaceView(chr_name, bam_file, draft_file, truth_bam, train_mode)
+                results = views[key].parse_regions([(a, b) for _, a, b in block], downsample_rate)
+                for region, (images, labels, positions, chunk_ids) in zip(block, results):
+                    for i, image in enumerate(images):
+                        position, index = positions[i][:, 0], positions[i][:, 1]
+                        summary_name = str(region[0]) + "_" + str(region[1]) + "_" + str(region[2]) + "_" + str(chunk_ids[i])
+                        output_hdf_file.write_summary(region, image, labels[i], position, index, chunk_ids[i], summary_name)
+                before = counter
+                counter += len(block)
+                if thread_id == 0 and counter // 10 > before // 10:
                     elapsed = int(time.time() - start_time)
                     _log("INFO: [THREAD " + "{:02d}".format(thread_id) + "] " + str(counter) + "/" + str(len(intervals))
                          + " COMPLETE (" + str(int(100 * counter / len(intervals))) + "%) [ELAPSED TIME: "

@@ -75,6 +75,69 @@ def _realigner(device):
     return lib, _realigners[key]
 
 
+def align_windows(windows, read_window, read_pos, seq_offset, seq, device=0, collapse_eqx=True):
+    """Reads of several regions in one call (include/pepper_amd_realign.h, pa_realigner_align_windows).
+    windows: [(ref_start, ref_seq)]; read_window[k] = index of read k's window.  Returns the flat result arrays:
+    status (1 aligned, 0 kept, -1 dropped), score, pos, pos_end, query span and CIGAR arrays."""
+    lib, h = _realigner(device)
+    read_pos = np.ascontiguousarray(read_pos, dtype=np.int64)
+    seq_offset = np.ascontiguousarray(seq_offset, dtype=np.int64)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    read_window = np.ascontiguousarray(read_window, dtype=np.int32)
+    n = len(read_pos)
+    texts = [(w[1].encode("latin-1") if isinstance(w[1], str) else bytes(w[1])) for w in windows]
+    window_offset = np.zeros(len(windows) + 1, np.int64)
+    np.cumsum([len(t) for t in texts], out=window_offset[1:])
+    window_start = np.array([int(w[0]) for w in windows], np.int64)
+    status, score = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    pos, pos_end = np.zeros(n, np.int64), np.zeros(n, np.int64)
+    qbeg, qend = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    total = ctypes.c_int64()
+    seq_arg = seq if len(seq) else np.zeros(1, np.uint8)
+    _lib.check(lib.pa_realigner_align_windows(h, len(windows), b"".join(texts), window_offset.ctypes.data,
+                                              window_start.ctypes.data, n, read_window.ctypes.data, read_pos.ctypes.data,
+                                              seq_offset.ctypes.data, seq_arg.ctypes.data, status.ctypes.data,
+                                              score.ctypes.data, pos.ctypes.data, pos_end.ctypes.data, qbeg.ctypes.data,
+                                              qend.ctypes.data, ctypes.byref(total)))
+    cigar_offset = np.zeros(n + 1, np.int64)
+    cigar_op, cigar_len = np.zeros(max(1, total.value), np.int32), np.zeros(max(1, total.value), np.int32)
+    _lib.check(lib.pa_realigner_copy_cigars(h, int(bool(collapse_eqx)), cigar_offset.ctypes.data, cigar_op.ctypes.data,
+                                            cigar_len.ctypes.data))
+    return dict(status=status, score=score, pos=pos, pos_end=pos_end, query_begin=qbeg, query_end=qend,
+                cigar_offset=cigar_offset, cigar_op=cigar_op[:total.value], cigar_len=cigar_len[:total.value])
+
+
+def apply_alignment(reads, out, first=0):
+    """ReadSet `reads` = reads first .. first + len(reads) of a result of align_windows -> the ReadSet the reference's
+    ReadAligner returns for them: dropped reads removed, aligned reads with the new position / end / CIGAR."""
+    from pepper_amd.variant.bam import ReadSet
+    n = len(reads)
+    if n == 0:
+        return reads
+    status = out["status"][first:first + n]
+    keep = np.nonzero(status >= 0)[0]
+    base = reads if len(keep) == n else reads.take(keep)
+    aligned = status[keep] == 1
+    pos = np.where(aligned, out["pos"][first:first + n][keep], base.pos)
+    pos_end = np.where(aligned, out["pos_end"][first:first + n][keep], base.pos_end)
+    old_n = base.cigar_offset[1:] - base.cigar_offset[:-1]
+    new_off = out["cigar_offset"][first:first + n + 1]
+    counts = np.where(aligned, (new_off[1:] - new_off[:-1])[keep], old_n)
+    offsets = np.zeros(len(keep) + 1, np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    ops, lens = np.empty(int(offsets[-1]), np.int32), np.empty(int(offsets[-1]), np.int32)
+    for i, k in enumerate(keep.tolist()):
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        if aligned[i]:
+            s0 = int(new_off[k])
+            ops[a:b], lens[a:b] = out["cigar_op"][s0:s0 + b - a], out["cigar_len"][s0:s0 + b - a]
+        else:
+            s0 = int(base.cigar_offset[i])
+            ops[a:b], lens[a:b] = base.cigar_op[s0:s0 + b - a], base.cigar_len[s0:s0 + b - a]
+    return ReadSet(pos, pos_end, base.reverse, base.mapq, base.flags, base.hp, base.seq_offset, base.seq, base.qual,
+                   offsets, ops, lens, base.names)
+
+
 class ReadAligner(object):
     """`PEPPER.ReadAligner(ref_start, ref_end, ref_seq).align_reads_to_reference(reads)`
 
@@ -94,56 +157,15 @@ class ReadAligner(object):
 
     def align_arrays(self, read_pos, seq_offset, seq, collapse_eqx=True):
         """Flat form: per-read status (1 aligned, 0 kept, -1 dropped), score, pos, pos_end, query span and CIGAR arrays."""
-        lib, h = _realigner(self.device)
-        read_pos = np.ascontiguousarray(read_pos, dtype=np.int64)
-        seq_offset = np.ascontiguousarray(seq_offset, dtype=np.int64)
-        seq = np.ascontiguousarray(seq, dtype=np.uint8)
-        n = len(read_pos)
-        ref = self.reference_sequence.encode("latin-1") if isinstance(self.reference_sequence, str) else bytes(self.reference_sequence)
-        status, score = np.zeros(n, np.int32), np.zeros(n, np.int32)
-        pos, pos_end = np.zeros(n, np.int64), np.zeros(n, np.int64)
-        qbeg, qend = np.zeros(n, np.int32), np.zeros(n, np.int32)
-        total = ctypes.c_int64()
-        seq_arg = seq if len(seq) else np.zeros(1, np.uint8)
-        _lib.check(lib.pa_realigner_align(h, ref, len(ref), self.region_start, n, read_pos.ctypes.data, seq_offset.ctypes.data,
-                                          seq_arg.ctypes.data, status.ctypes.data, score.ctypes.data, pos.ctypes.data,
-                                          pos_end.ctypes.data, qbeg.ctypes.data, qend.ctypes.data, ctypes.byref(total)))
-        cigar_offset = np.zeros(n + 1, np.int64)
-        cigar_op, cigar_len = np.zeros(max(1, total.value), np.int32), np.zeros(max(1, total.value), np.int32)
-        _lib.check(lib.pa_realigner_copy_cigars(h, int(bool(collapse_eqx)), cigar_offset.ctypes.data, cigar_op.ctypes.data,
-                                                cigar_len.ctypes.data))
-        return dict(status=status, score=score, pos=pos, pos_end=pos_end, query_begin=qbeg, query_end=qend,
-                    cigar_offset=cigar_offset, cigar_op=cigar_op[:total.value], cigar_len=cigar_len[:total.value])
+        return align_windows([(self.region_start, self.reference_sequence)], np.zeros(len(read_pos), np.int32), read_pos,
+                             seq_offset, seq, device=self.device, collapse_eqx=collapse_eqx)
 
     def align_reads_to_reference(self, reads):
         from pepper_amd.variant.bam import ReadSet
         if isinstance(reads, ReadSet):
             if len(reads) == 0:
                 return reads
-            out = self.align_arrays(reads.pos, reads.seq_offset, reads.seq)
-            status = out["status"]
-            keep = np.nonzero(status >= 0)[0]
-            base = reads if len(keep) == len(reads) else reads.take(keep)
-            st = status[keep]
-            aligned = st == 1
-            pos = np.where(aligned, out["pos"][keep], base.pos)
-            pos_end = np.where(aligned, out["pos_end"][keep], base.pos_end)
-            old_n = base.cigar_offset[1:] - base.cigar_offset[:-1]
-            new_n = (out["cigar_offset"][1:] - out["cigar_offset"][:-1])[keep]
-            counts = np.where(aligned, new_n, old_n)
-            offsets = np.zeros(len(keep) + 1, np.int64)
-            np.cumsum(counts, out=offsets[1:])
-            ops, lens = np.empty(int(offsets[-1]), np.int32), np.empty(int(offsets[-1]), np.int32)
-            for i, k in enumerate(keep.tolist()):
-                a, b = int(offsets[i]), int(offsets[i + 1])
-                if aligned[i]:
-                    s = int(out["cigar_offset"][k])
-                    ops[a:b], lens[a:b] = out["cigar_op"][s:s + b - a], out["cigar_len"][s:s + b - a]
-                else:
-                    s = int(base.cigar_offset[i])
-                    ops[a:b], lens[a:b] = base.cigar_op[s:s + b - a], base.cigar_len[s:s + b - a]
-            return ReadSet(pos, pos_end, base.reverse, base.mapq, base.flags, base.hp, base.seq_offset, base.seq, base.qual,
-                           offsets, ops, lens, base.names)
+            return apply_alignment(reads, self.align_arrays(reads.pos, reads.seq_offset, reads.seq))
         reads = list(reads)
         if not reads:
             return []
