@@ -176,3 +176,26 @@ def test_degenerate_read_sets():
         _gpu_align(reference, 10, [10 + len(reference) + 1], ["ACGT"])    # beyond it: substr() would throw in the reference
     with pytest.raises(_lib.PepperAmdError):
         _gpu_align("ACGT" * 2000, 0, [0], ["ACGT" * 1001])                # 4004 bases: above the supported read length
+
+
+def test_several_windows_in_one_call():
+    """pa_realigner_align_windows: reads of three regions (own reference window each) through one job table."""
+    from pepper_amd.polish.PEPPER import align_windows
+    rng = np.random.default_rng(16)
+    windows, pos, seqs, which, expect = [], [], [], [], []
+    for w, (start, width, n_reads) in enumerate([(1000, 700, 25), (90000, 1220, 40), (5, 60, 8)]):
+        text = _rand_seq(rng, width)
+        p, s = ssw.simulate_reads(rng, text, start, n_reads, min_len=min(30, width // 3))
+        if w == 1:
+            p[0] = start - 3                       # dropped: starts before its own window
+        windows.append((start, text))
+        pos += p
+        seqs += s
+        which += [w] * n_reads
+        expect += ssw.realign_reads(text, start, p, s)
+    blob = [s.encode() for s in seqs]
+    off = np.zeros(len(seqs) + 1, np.int64)
+    np.cumsum([len(b) for b in blob], out=off[1:])
+    out = align_windows(windows, which, pos, off, np.frombuffer(b"".join(blob), np.uint8), collapse_eqx=False)
+    _assert_same(out, expect)
+    assert (out["status"] == -1).sum() == 1 and (out["status"] == 1).sum() > 60
