@@ -48,6 +48,10 @@ struct Bgzf {
     std::unordered_map<int64_t, Cached> cache;
     std::deque<int64_t> order;
     static constexpr size_t kCacheBlocks = 256;
+    z_stream zs{};
+    bool zs_ready = false;
+    std::vector<uint8_t> comp;       // compressed bytes of the block being loaded
+    ~Bgzf() { if (zs_ready) inflateEnd(&zs); }
     Block cur = std::make_shared<std::vector<uint8_t>>();   // decompressed current block
     int64_t block_coffset = -1;      // file offset of the current block
     int64_t next_coffset = 0;        // file offset of the block after it
@@ -90,30 +94,38 @@ struct Bgzf {
         if (bsize < 0) return false;
         const int clen = bsize - 12 - xlen - 8;
         if (clen < 0) return false;
-        std::vector<uint8_t> comp(clen + 8);
+        comp.resize((size_t)clen + 8);
         if (fread(comp.data(), 1, clen + 8, fp) != (size_t)(clen + 8)) return false;
         const uint32_t isize = comp[clen + 4] | (comp[clen + 5] << 8) | (comp[clen + 6] << 16) | ((uint32_t)comp[clen + 7] << 24);
-        Block fresh = std::make_shared<std::vector<uint8_t>>(isize);
+        Block fresh;
+        if (order.size() >= kCacheBlocks) {               // evict the oldest block and take over its (already mapped) memory
+            const auto oldest = cache.find(order.front());
+            if (oldest != cache.end()) {
+                if (oldest->second.data.use_count() == 1) fresh = oldest->second.data;
+                cache.erase(oldest);
+            }
+            order.pop_front();
+        }
+        if (!fresh) fresh = std::make_shared<std::vector<uint8_t>>();
+        fresh->resize(isize);
         if (isize) {
-            z_stream zs{};
-            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            if (!zs_ready) {                              // one inflate state per handle, reset per block
+                if (inflateInit2(&zs, -15) != Z_OK) return false;
+                zs_ready = true;
+            } else if (inflateReset(&zs) != Z_OK) {
+                return false;
+            }
             zs.next_in = comp.data();
             zs.avail_in = clen;
             zs.next_out = fresh->data();
             zs.avail_out = isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END) return false;
+            if (inflate(&zs, Z_FINISH) != Z_STREAM_END) return false;
         }
         cur = fresh;
         block_coffset = coffset;
         next_coffset = coffset + bsize;
         upos = 0;
         eof = false;
-        if (order.size() >= kCacheBlocks) {
-            cache.erase(order.front());
-            order.pop_front();
-        }
         cache[coffset] = Cached{fresh, next_coffset};
         order.push_back(coffset);
         return true;
@@ -153,7 +165,11 @@ struct ReadSet {
     std::vector<uint8_t> reverse, qual;
     std::vector<int32_t> mapq, flags, hp, cigar_op, cigar_len;
     std::string seq, names;
-    void clear() { *this = ReadSet(); }
+    void clear() {      // keeps the capacity: the next region's reads land in already-mapped memory
+        pos.clear(); pos_end.clear(); reverse.clear(); qual.clear(); mapq.clear(); flags.clear(); hp.clear();
+        cigar_op.clear(); cigar_len.clear(); seq.clear(); names.clear();
+        seq_offset.assign(1, 0); cigar_offset.assign(1, 0); name_offset.assign(1, 0);
+    }
 };
 
 }  // namespace
@@ -406,11 +422,25 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
         const size_t seq0 = rs.seq.size(), cig0 = rs.cigar_op.size();
         int64_t pos_start = -1, pos_end = -1, rpos = pos;
         int64_t ridx = 0;
-        auto push_base = [&](int64_t idx) {
-            char base = kSeqNt16[(seqi[idx >> 1] >> ((~idx & 1) << 2)) & 15];
-            if (base >= 'a' && base <= 'z') base = (char)(base - 32);
-            rs.seq.push_back(base);
-            rs.qual.push_back(qual[idx]);
+        // room for the whole read once (trimmed below); runs of consecutive read bases are decoded in place:
+        // 4-bit codes -> upper-case letters two at a time, qualities copied
+        rs.seq.resize(seq0 + l_seq);
+        rs.qual.resize(seq0 + l_seq);
+        char* seq_out = &rs.seq[seq0];
+        uint8_t* qual_out = rs.qual.data() + seq0;
+        size_t written = 0;
+        auto push_run = [&](int64_t idx, int64_t count) {
+            char* out = seq_out + written;
+            int64_t i = 0;
+            if ((idx & 1) && count > 0) { out[0] = kSeqNt16[seqi[idx >> 1] & 15]; i = 1; }
+            for (; i + 1 < count; i += 2) {
+                const uint8_t byte = seqi[(idx + i) >> 1];
+                out[i] = kSeqNt16[byte >> 4];
+                out[i + 1] = kSeqNt16[byte & 15];
+            }
+            if (i < count) out[i] = kSeqNt16[seqi[(idx + i) >> 1] >> 4];
+            std::memcpy(qual_out + written, qual + idx, (size_t)count);
+            written += (size_t)count;
         };
         for (uint32_t k = 0; k < n_cigar_op; ++k) {
             const uint32_t c = le32(&rec[o_cigar + 4 * k]);
@@ -426,24 +456,24 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
                         ridx += skip;
                         rpos += skip;
                     }
-                    for (int64_t i = skip; i < len; ++i) {
-                        if (rpos > stop) break;
+                    kept = std::min<int64_t>(len - skip, stop - rpos + 1);   // bases at positions rpos .. stop
+                    if (kept > 0) {
                         if (pos_start == -1) { pos_start = rpos; pos_end = rpos; }
-                        push_base(ridx);
-                        ++kept;
-                        ++pos_end;
-                        ++ridx;
-                        ++rpos;
+                        push_run(ridx, kept);
+                        pos_end += kept;
+                        ridx += kept;
+                        rpos += kept;
+                    } else {
+                        kept = 0;
                     }
                     break;
                 }
                 case 4: case 1:                               // S, I: kept only behind an anchored position
                     if (rpos >= start && rpos <= stop && pos_start != -1) {
-                        for (int64_t i = 0; i < len; ++i) { push_base(ridx); ++ridx; }
+                        push_run(ridx, len);
                         kept = len;
-                    } else {
-                        ridx += len;
                     }
+                    ridx += len;
                     break;
                 case 3: case 2:                               // N, D
                     if (rpos >= start && rpos <= stop && pos_start != -1) {
@@ -465,7 +495,9 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
                 rs.cigar_len.push_back((int32_t)kept);
             }
         }
-        if (rs.seq.size() == seq0) {                          // no base inside the region: read dropped (:432)
+        rs.seq.resize(seq0 + written);
+        rs.qual.resize(seq0 + written);
+        if (written == 0) {                                   // no base inside the region: read dropped (:432)
             rs.cigar_op.resize(cig0);
             rs.cigar_len.resize(cig0);
             continue;
