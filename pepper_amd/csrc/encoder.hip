@@ -22,6 +22,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -358,6 +361,14 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
     e->freqs.clear();
     e->names.clear();
     auto refc = [&](int64_t idx) { return idx >= 0 && idx < p->reference_len ? p->reference[idx] : 'N'; };
+    static const bool trace = getenv("PA_ENCODER_TRACE") != nullptr;      // host phase times on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[encoder] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
 
     // ---- host pass over CIGAR ops -----------------------------------------------------------
     std::vector<Seg> segs;
@@ -463,6 +474,7 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
     ENC_ALLOC(e->d_qual, (size_t)total_bases + 16);
     ENC_ALLOC(e->d_ref, (size_t)p->reference_len + 16);
     ENC_ALLOC(e->d_segs, segs.size() * sizeof(Seg) + 16);
+    lap("cigar pass");
     ENC_ALLOC(e->d_events, events.size() * sizeof(Event) + 16);
     ENC_ALLOC(e->d_mat, (size_t)(L + 1) * ROW * sizeof(int));
     ENC_ALLOC(e->d_snp, (size_t)L * 8 * sizeof(int));
@@ -502,8 +514,10 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
                        static_cast<SiteRec*>(e->d_sites.p), site_cap);
     ENC_HIP(hipGetLastError());
     int host_counters[2] = {0, 0};
+    lap("uploads + launches");
     ENC_HIP(hipMemcpyAsync(host_counters, counters, sizeof(host_counters), hipMemcpyDeviceToHost, st));
     ENC_HIP(hipStreamSynchronize(st));
+    lap("count kernels");
     const int n_ovf = host_counters[0], n_sites = std::min(host_counters[1], site_cap);
     if (n_ovf > ovf_cap)
         return pa::set_error(PA_ERR_INVALID, "more than 65536 mismatching bases outside ACGT in one region");
@@ -606,6 +620,7 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
         }
     }
 
+    lap("candidate enumeration");
     // ---- device: window gather ----------------------------------------------------------------------
     e->n = (int64_t)cands.size();
     *n_candidates = e->n;
@@ -620,6 +635,7 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
         ENC_HIP(hipGetLastError());
         ENC_HIP(hipStreamSynchronize(st));
     }
+    lap("window gather");
     return PA_OK;
 }
 
