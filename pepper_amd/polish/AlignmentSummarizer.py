@@ -14,6 +14,7 @@ from pepper_amd.polish.Options import ImageSizeOptions
 class AlingerOptions(object):
     ALIGNMENT_SAFE_BASES = 20      # pepper Options.py:23-29
     MAX_READS_IN_REGION = 1500
+    MAX_READS_PER_CALL = 3000      # reads of consecutive regions handed to the GPU re-aligner together
     RANDOM_SEED = 2719747673
 
 
@@ -122,21 +123,34 @@ class AlignmentSummarizer:
             reads = [s.reads_to_reference_realignment(s.region_start_position, s.region_end_position, r) if len(r) else r
                      for s, r in zip(summarizers, reads)]
         elif batchable and any(len(r) for r in reads):
-            windows = []
-            for s in summarizers:
-                ref_end = s.region_end_position + AlingerOptions.ALIGNMENT_SAFE_BASES
-                windows.append((s.region_start_position,
-                                s.fasta_handler.get_reference_sequence(s.chromosome_name, s.region_start_position, ref_end)))
-            counts = [len(r) for r in reads]
-            seq_lens = np.concatenate([r.seq_offset[1:] - r.seq_offset[:-1] for r in reads]) if sum(counts) else np.zeros(0, np.int64)
-            seq_offset = np.zeros(sum(counts) + 1, np.int64)
-            np.cumsum(seq_lens, out=seq_offset[1:])
-            out = PEPPER.align_windows(windows, np.repeat(np.arange(len(reads), dtype=np.int32), counts),
-                                       np.concatenate([r.pos for r in reads]), seq_offset,
-                                       np.concatenate([r.seq[:int(r.seq_offset[-1])] for r in reads]))
-            first, done = 0, []
-            for r in reads:
-                done.append(PEPPER.apply_alignment(r, out, first))
-                first += len(r)
+            # one call per run of regions holding up to MAX_READS_PER_CALL reads (the band stage keeps ~0.5 MB of
+            # direction bytes per read on the device; regions at the 1500-read cap go through in smaller groups)
+            done, lo = [], 0
+            while lo < len(reads):
+                hi, total = lo + 1, len(reads[lo])
+                while hi < len(reads) and total + len(reads[hi]) <= AlingerOptions.MAX_READS_PER_CALL:
+                    total += len(reads[hi])
+                    hi += 1
+                group, group_s = reads[lo:hi], summarizers[lo:hi]
+                if total:
+                    windows = []
+                    for s in group_s:
+                        ref_end = s.region_end_position + AlingerOptions.ALIGNMENT_SAFE_BASES
+                        windows.append((s.region_start_position, s.fasta_handler.get_reference_sequence(
+                            s.chromosome_name, s.region_start_position, ref_end)))
+                    counts = [len(r) for r in group]
+                    seq_lens = np.concatenate([r.seq_offset[1:] - r.seq_offset[:-1] for r in group])
+                    seq_offset = np.zeros(total + 1, np.int64)
+                    np.cumsum(seq_lens, out=seq_offset[1:])
+                    out = PEPPER.align_windows(windows, np.repeat(np.arange(len(group), dtype=np.int32), counts),
+                                               np.concatenate([r.pos for r in group]), seq_offset,
+                                               np.concatenate([r.seq[:int(r.seq_offset[-1])] for r in group]))
+                    first = 0
+                    for r in group:
+                        done.append(PEPPER.apply_alignment(r, out, first))
+                        first += len(r)
+                else:
+                    done.extend(group)
+                lo = hi
             reads = done
         return [s.summarise(r) for s, r in zip(summarizers, reads)]
