@@ -95,6 +95,12 @@ int pa_h5_write_polish_predictions(pa_h5* f, int32_t n, int32_t seq_len, const c
                                    const uint8_t* new_region, const uint8_t* skip, const int64_t* position,
                                    const int64_t* index, const uint8_t* bases, const uint8_t* phred);
 
+/* All chunks of one predictions/<contig>/<contig>-<start>-<end> group for the stitcher: sub-groups other than
+ * contig_start / contig_end in string order, their position / index (int64 [seq]) and bases (uint8 [seq]) into rows of the
+ * caller's arrays (max_chunks rows); *n_chunks = number of chunks found (Stitch.py:36-62 reads them one dataset at a time). */
+int pa_h5_read_polish_prediction_region(pa_h5* f, const char* region_path, int32_t seq_len, int32_t max_chunks,
+                                        int64_t* position, int64_t* index, uint8_t* bases, int32_t* n_chunks);
+
 /* ------------------------------------------------------------------------------------------
  * BAM ingestion (pepper_amd/csrc/bamio.cpp; zlib, no htslib)
  * replaces the pybind surface of PEPPER_VARIANT.BAM_handler:

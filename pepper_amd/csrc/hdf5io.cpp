@@ -469,4 +469,37 @@ int pa_h5_write_polish_predictions(pa_h5* f, int32_t n, int32_t seq_len, const c
     return rc;
 }
 
+static herr_t collect_names(hid_t, const char* name, const H5L_info_t*, void* p) {
+    static_cast<std::vector<std::string>*>(p)->push_back(name);
+    return 0;
+}
+
+int pa_h5_read_polish_prediction_region(pa_h5* f, const char* region_path, int32_t seq_len, int32_t max_chunks,
+                                        int64_t* position, int64_t* index, uint8_t* bases, int32_t* n_chunks) {
+    if (!f || !region_path || seq_len <= 0 || max_chunks <= 0 || !position || !index || !bases || !n_chunks)
+        return fail("bad argument");
+    Quiet q;
+    hid_t g = H5Gopen2(f->file, region_path, H5P_DEFAULT);
+    if (g < 0) return fail(std::string("no group '") + region_path + "'");
+    std::vector<std::string> names;
+    H5Literate(g, H5_INDEX_NAME, H5_ITER_NATIVE, nullptr, collect_names, &names);
+    names.erase(std::remove_if(names.begin(), names.end(),
+                               [](const std::string& s) { return s == "contig_start" || s == "contig_end"; }), names.end());
+    std::sort(names.begin(), names.end());            // the order of Python's sorted() on the chunk ids as strings
+    *n_chunks = (int32_t)names.size();
+    int rc = 0;
+    if ((int32_t)names.size() > max_chunks) rc = fail(std::string("more chunks than the buffer holds in '") + region_path + "'");
+    for (size_t i = 0; i < names.size() && !rc; ++i) {
+        hid_t c = H5Gopen2(g, names[i].c_str(), H5P_DEFAULT);
+        const std::string where = std::string(region_path) + "/" + names[i] + "/";
+        if (c < 0) { rc = fail("no group '" + where + "'"); break; }
+        rc = read_numeric(c, "position", H5T_NATIVE_INT64, seq_len, position + i * (size_t)seq_len, where);
+        if (!rc) rc = read_numeric(c, "index", H5T_NATIVE_INT64, seq_len, index + i * (size_t)seq_len, where);
+        if (!rc) rc = read_numeric(c, "bases", H5T_NATIVE_UINT8, seq_len, bases + i * (size_t)seq_len, where);
+        H5Gclose(c);
+    }
+    H5Gclose(g);
+    return rc;
+}
+
 }  // extern "C"

@@ -37,6 +37,8 @@ SYMBOLS = [
     ("pa_h5_write_fixed_strings", ctypes.c_int, [c_void_p, c_char_p, c_int32, P64, c_int32, c_void_p]),
     ("pa_h5_write_vlen_strings", ctypes.c_int, [c_void_p, c_char_p, c_int32, P64, ctypes.POINTER(c_char_p)]),
     ("pa_h5_read_polish_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32]),
+    ("pa_h5_read_polish_prediction_region", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                                           ctypes.POINTER(c_int32)]),
     ("pa_h5_write_polish_predictions", ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 9),
     ("pa_h5_write_prediction_batch", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
@@ -166,6 +168,17 @@ class File(object):
                                                   index.ctypes.data, start.ctypes.data, end.ctypes.data, chunk.ctypes.data,
                                                   contigs.ctypes.data, contig_width))
         return contigs, start, end, chunk, images, position, index
+
+    @_locked
+    def read_polish_prediction_region(self, region_path, seq_len, max_chunks=64):
+        """(position, index, bases) rows of every chunk under one predictions region group, chunk ids in string order."""
+        position, index = np.empty((max_chunks, seq_len), np.int64), np.empty((max_chunks, seq_len), np.int64)
+        bases = np.empty((max_chunks, seq_len), np.uint8)
+        n = c_int32()
+        _check(self._lib.pa_h5_read_polish_prediction_region(self._h, region_path.encode(), seq_len, max_chunks,
+                                                             position.ctypes.data, index.ctypes.data, bases.ctypes.data,
+                                                             ctypes.byref(n)))
+        return position[:n.value], index[:n.value], bases[:n.value]
 
     @_locked
     def write_polish_predictions(self, contigs, start, end, chunk, new_region, skip, position, index, bases, phred):

@@ -28,21 +28,33 @@ def chunks(file_names, threads):
 def small_chunk_stitch(contig, small_chunk_keys):
     buffer_positions = ImageSizeOptions.MIN_IMAGE_OVERLAP * 2
     pos_parts, idx_parts, base_parts = [], [], []
-    for file_name, contig_name, _st, _end in small_chunk_keys:
-        chunk_name = contig_name + '-' + str(_st) + '-' + str(_end)
-        prefix = 'predictions/' + contig + '/' + chunk_name
-        with h5.File(file_name, 'r') as hdf5_file:
-            smaller_chunks = sorted(set(hdf5_file.keys(prefix)) - {'contig_start', 'contig_end'})
-            for chunk in smaller_chunks:
-                positions = np.asarray(hdf5_file[prefix + '/' + chunk + '/position'], dtype=np.int64).reshape(-1)
-                indices = np.asarray(hdf5_file[prefix + '/' + chunk + '/index'], dtype=np.int64).reshape(-1)
-                bases = np.asarray(hdf5_file[prefix + '/' + chunk + '/bases'], dtype=np.int64).reshape(-1)
-                keep = (indices >= 0) & (positions >= 0)
-                if _st > 0:
-                    keep &= positions > _st + buffer_positions
-                pos_parts.append(positions[keep])
-                idx_parts.append(indices[keep])
-                base_parts.append(bases[keep])
+    open_files = {}                       # each prediction file is opened once per call, not once per region
+    try:
+        for file_name, contig_name, _st, _end in small_chunk_keys:
+            chunk_name = contig_name + '-' + str(_st) + '-' + str(_end)
+            prefix = 'predictions/' + contig + '/' + chunk_name
+            hdf5_file = open_files.get(file_name)
+            if hdf5_file is None:
+                hdf5_file = open_files[file_name] = h5.File(file_name, 'r')
+            # every chunk of the region in one library call (chunk ids in string order, as sorted() gives them)
+            try:
+                positions, indices, bases = hdf5_file.read_polish_prediction_region(prefix, ImageSizeOptions.SEQ_LENGTH)
+                positions, indices, bases = positions.reshape(-1), indices.reshape(-1), bases.reshape(-1).astype(np.int64)
+            except h5.H5Error:                  # chunks of another length (not written by this pipeline): one by one
+                parts = [[], [], []]
+                for chunk in sorted(set(hdf5_file.keys(prefix)) - {'contig_start', 'contig_end'}):
+                    for k, name in enumerate(('position', 'index', 'bases')):
+                        parts[k].append(np.asarray(hdf5_file[prefix + '/' + chunk + '/' + name], dtype=np.int64).reshape(-1))
+                positions, indices, bases = (np.concatenate(p) if p else np.zeros(0, np.int64) for p in parts)
+            keep = (indices >= 0) & (positions >= 0)
+            if _st > 0:
+                keep &= positions > _st + buffer_positions
+            pos_parts.append(positions[keep])
+            idx_parts.append(indices[keep])
+            base_parts.append(bases[keep])
+    finally:
+        for f in open_files.values():
+            f.close()
     if not pos_parts:
         return -1, -1, ''
     positions = np.concatenate(pos_parts)
