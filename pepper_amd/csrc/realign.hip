@@ -1,5 +1,5 @@
 // Read re-aligner (include/pepper_amd_realign.h): the polish image generator's local re-alignment of every read
-// against the reference suffix that starts at its mapped position, as HIP kernels -- one wavefront per read.
+// against the reference suffix that starts at its mapped position, as HIP kernels -- one wavefront per read and pass.
 //
 // What is reproduced, stage by stage (the reference calls the SSW library for each read on one host thread:
 // /root/reference/pepper/modules/src/local_reassembly/simple_aligner.cpp:66-106, ssw.c:801-891):
@@ -11,20 +11,22 @@
 //                    vertical-gap chains (segment-local and exact) are carried here, so the scores, the first column
 //                    reaching the maximum and the smallest row inside it are the library's.  8-bit pass first; a running
 //                    maximum >= 249 switches to the 16-bit segmentation (ssw.c:819-824).
-//                    Mapping: lane l owns a strip of consecutive read rows (state in LDS, one dword per row:
-//                    H | E | base code), columns are visited in a skewed pipeline (lane l works on column t - l at
-//                    step t) and the strip's bottom cell, both gap chains and the running column maximum are handed to
-//                    lane l + 1 through the cross-lane network.  Lane 63 sees each column's complete maximum and runs
-//                    the sequential part (first column that raises the maximum, overflow, early stop of the reverse
-//                    pass at the forward score).  Integer DP, no matrix cores: ~25 VALU ops + one LDS read / write
-//                    per cell.
+//                    Mapping: lane l owns a strip of consecutive read rows in registers (score_pass_reg<R>; reads
+//                    beyond 1536 padded rows fall back to one LDS dword per row, score_pass), columns are visited in a
+//                    skewed pipeline (lane l works on column t - l at step t) and the strip's bottom cell, both gap
+//                    chains and the running column maximum are handed to lane l + 1 by three DPP moves.  Lane 63 sees
+//                    each column's complete maximum and runs the sequential part (first column that raises the
+//                    maximum, overflow, early stop of the reverse pass at the forward score).  Integer DP, no matrix
+//                    cores: 12.5 vector instructions per cell.
 //   band_kernel      banded DP between begin and end cell with the library's band slots, its zeroed slot to the right
-//                    of the previous row and its tie rules (ssw.c:571-650), band doubled until the score is reached;
-//                    the row's vertical-gap chain is a max-plus prefix scan across the wavefront; direction bits go to
-//                    a workspace in HBM (1 byte per cell); lane 0 walks them back (ssw.c:653-703) and writes the
-//                    final operations: '=' / 'X' runs from comparing base codes, I, D, soft clips
-//                    (ssw_cpp.cpp:56-207).
-// Host side of the entry points: base text -> codes, job table, workspace sizing between the two kernels.
+//                    of the previous row and its tie rules (ssw.c:571-650); three wavefronts per read try three
+//                    consecutive widths of the doubling sequence at once, the narrowest that reaches the score wins.
+//                    The row's vertical-gap chain is a max-plus prefix scan on the DPP network; direction bits go to a
+//                    workspace in HBM (1 byte per cell); the walk back (ssw.c:653-703) probes 64 cells of the diagonal
+//                    per round trip, and the final operations -- '=' / 'X' runs from comparing base codes, I, D, soft
+//                    clips (ssw_cpp.cpp:56-207) -- are emitted wavefront-parallel into one compacted output.
+// Host side of the entry points: job table over one or several reference windows, workspace sizing between the two
+// kernels (base text -> codes on the device).
 #include "../../include/pepper_amd_realign.h"
 #include "../../include/pepper_amd.h"
 
@@ -55,8 +57,8 @@ struct Job {
     int64_t seq_off;               // read codes
     int32_t score, wide, ref_begin, ref_end, read_begin, read_end;
     int32_t bw, dir_width;         // band half width to try next; row capacity of the direction workspace
-    int64_t dir_off, ops_off, steps_off;
-    int32_t ops_cap, n_ops;
+    int64_t dir_off, ops_off;      // direction workspace of this read; first operation in the compacted output
+    int32_t ops_cap, n_ops;        // worst-case number of operations (sizes the output buffer); operations written
     int32_t t_ends, t_dp, t_trace, t_emit;   // stage times of this read in 10 ns ticks (s_memtime), for tools/realign_stages.py
 };
 
