@@ -51,6 +51,15 @@ def repeat_annotation(sequence, kmer_size=1):
 
 def _parse_list_field(value):
     """"['1A' '2AT']" / "['1A', '2AT']" / "[12 3]" -> ['1A', '2AT'] / ['12', '3'] (:376-383)."""
+    if isinstance(value, np.ndarray) and value.ndim == 1 and value.size < 1000:
+        # what str(array) + the parsing below yields for the rows the pipeline writes (one-dimensional, strings without
+        # blanks / quotes / commas, or integers), without numpy's array printer: 20x less time per candidate
+        if value.dtype.kind in "iu":
+            return [str(v) for v in value.tolist()]
+        if value.dtype.kind in "OU":
+            items = value.tolist()
+            if all(isinstance(v, str) and v and not any(c in v for c in " ,'\"[]\n") for v in items):
+                return items
     text = str(value).strip("][").replace(",", " ")
     return [tok.strip("'") for tok in text.split()]
 
