@@ -101,6 +101,14 @@ int pa_h5_write_polish_predictions(pa_h5* f, int32_t n, int32_t seq_len, const c
 int pa_h5_read_polish_prediction_region(pa_h5* f, const char* region_path, int32_t seq_len, int32_t max_chunks,
                                         int64_t* position, int64_t* index, uint8_t* bases, int32_t* n_chunks);
 
+/* The chunks of one polish region into the image file in one call: summaries/<name>/{image u8 [seq,features], label u8
+ * [seq], position, index int64 [seq], contig (vlen string), region_start, region_end, chunk_id int64}
+ * (pepper/.../DataStore.py:53-67); names = n NUL-separated group names. */
+int pa_h5_write_polish_image_chunks(pa_h5* f, const char* names, int32_t n, int32_t seq_len, int32_t features,
+                                    const char* contig, int64_t region_start, int64_t region_end, const int64_t* chunk_id,
+                                    const uint8_t* images, const uint8_t* labels, const int64_t* position,
+                                    const int64_t* index);
+
 /* ------------------------------------------------------------------------------------------
  * BAM ingestion (pepper_amd/csrc/bamio.cpp; zlib, no htslib)
  * replaces the pybind surface of PEPPER_VARIANT.BAM_handler:

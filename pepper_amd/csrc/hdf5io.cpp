@@ -502,4 +502,47 @@ int pa_h5_read_polish_prediction_region(pa_h5* f, const char* region_path, int32
     return rc;
 }
 
+int pa_h5_write_polish_image_chunks(pa_h5* f, const char* names, int32_t n, int32_t seq_len, int32_t features,
+                                    const char* contig, int64_t region_start, int64_t region_end, const int64_t* chunk_id,
+                                    const uint8_t* images, const uint8_t* labels, const int64_t* position,
+                                    const int64_t* index) {
+    if (!f || n < 0 || seq_len <= 0 || features <= 0 || !contig ||
+        (n > 0 && (!names || !chunk_id || !images || !labels || !position || !index)))
+        return fail("bad argument");
+    Quiet q;
+    hsize_t d2[2] = {(hsize_t)seq_len, (hsize_t)features}, d1[1] = {(hsize_t)seq_len};
+    hid_t sp_img = H5Screate_simple(2, d2, nullptr), sp_row = H5Screate_simple(1, d1, nullptr), sp_one = H5Screate(H5S_SCALAR);
+    hid_t tv = H5Tcopy(H5T_C_S1);
+    H5Tset_size(tv, H5T_VARIABLE);
+    H5Tset_cset(tv, H5T_CSET_UTF8);
+    int rc = 0;
+    auto put = [&](hid_t loc, const char* name, hid_t ft, hid_t mt, hid_t sp, const void* data, const std::string& where) {
+        if (rc) return;
+        hid_t d = H5Dcreate2(loc, name, ft, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+        if (d < 0) { rc = fail("cannot create dataset '" + where + "/" + name + "' (already exists?)"); return; }
+        if (H5Dwrite(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, data) < 0) rc = fail("H5Dwrite failed for '" + where + "/" + name + "'");
+        H5Dclose(d);
+    };
+    const char* name = names;
+    for (int32_t i = 0; i < n && !rc; ++i, name += strlen(name) + 1) {
+        const std::string where = std::string("summaries/") + name;
+        hid_t g = H5Gcreate2(f->file, where.c_str(), f->lcpl, H5P_DEFAULT, H5P_DEFAULT);
+        if (g < 0) { rc = fail("cannot create group '" + where + "' (already exists?)"); break; }
+        put(g, "image", H5T_STD_U8LE, H5T_NATIVE_UINT8, sp_img, images + (size_t)i * seq_len * features, where);
+        put(g, "label", H5T_STD_U8LE, H5T_NATIVE_UINT8, sp_row, labels + (size_t)i * seq_len, where);
+        put(g, "position", H5T_STD_I64LE, H5T_NATIVE_INT64, sp_row, position + (size_t)i * seq_len, where);
+        put(g, "index", H5T_STD_I64LE, H5T_NATIVE_INT64, sp_row, index + (size_t)i * seq_len, where);
+        put(g, "contig", tv, tv, sp_one, &contig, where);
+        put(g, "region_start", H5T_STD_I64LE, H5T_NATIVE_INT64, sp_one, &region_start, where);
+        put(g, "region_end", H5T_STD_I64LE, H5T_NATIVE_INT64, sp_one, &region_end, where);
+        put(g, "chunk_id", H5T_STD_I64LE, H5T_NATIVE_INT64, sp_one, chunk_id + i, where);
+        H5Gclose(g);
+    }
+    H5Tclose(tv);
+    H5Sclose(sp_img);
+    H5Sclose(sp_row);
+    H5Sclose(sp_one);
+    return rc;
+}
+
 }  // extern "C"

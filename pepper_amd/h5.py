@@ -39,6 +39,8 @@ SYMBOLS = [
     ("pa_h5_read_polish_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32]),
     ("pa_h5_read_polish_prediction_region", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                                            ctypes.POINTER(c_int32)]),
+    ("pa_h5_write_polish_image_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32, c_char_p, c_int64, c_int64] +
+                                                       [c_void_p] * 5),
     ("pa_h5_write_polish_predictions", ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 9),
     ("pa_h5_write_prediction_batch", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
@@ -179,6 +181,14 @@ class File(object):
                                                              position.ctypes.data, index.ctypes.data, bases.ctypes.data,
                                                              ctypes.byref(n)))
         return position[:n.value], index[:n.value], bases[:n.value]
+
+    @_locked
+    def write_polish_image_chunks(self, names, contig, region_start, region_end, chunk_id, images, labels, position, index):
+        n, seq_len, features = images.shape
+        blob = b"".join(s.encode() + b"\0" for s in names)
+        _check(self._lib.pa_h5_write_polish_image_chunks(self._h, blob, n, seq_len, features, contig.encode(), int(region_start),
+                                                         int(region_end), chunk_id.ctypes.data, images.ctypes.data,
+                                                         labels.ctypes.data, position.ctypes.data, index.ctypes.data))
 
     @_locked
     def write_polish_predictions(self, contigs, start, end, chunk, new_region, skip, position, index, bases, phred):

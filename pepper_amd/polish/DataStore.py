@@ -37,3 +37,27 @@ class DataStore(object):
         fh[base + 'region_start'] = region_start
         fh[base + 'region_end'] = region_end
         fh[base + 'chunk_id'] = chunk_id
+
+    def write_summaries(self, region, images, labels, positions, chunk_ids):
+        """write_summary for all chunks of one region in one library call: images uint8 [n,1000,10] (or a list of
+        [1000,10] arrays), labels [n,1000], positions int64 [n,1000,2] = (position, index) pairs, chunk ids.  Same groups,
+        datasets and types; chunks whose group name was written before are skipped, as write_summary does."""
+        contig_name, region_start, region_end = region
+        names, keep = [], []
+        for k, chunk_id in enumerate(chunk_ids):
+            name = str(contig_name) + "_" + str(region_start) + "_" + str(region_end) + "_" + str(chunk_id)
+            if name in self._written:
+                continue
+            self._written.add(name)
+            names.append(name)
+            keep.append(k)
+        if not names:
+            return
+        images = np.ascontiguousarray(np.asarray(images)[keep], dtype=np.uint8)
+        labels = np.ascontiguousarray(np.asarray(labels)[keep], dtype=np.uint8)
+        positions = np.asarray(positions)[keep]
+        self.file_handler.write_polish_image_chunks(
+            names, str(contig_name), region_start, region_end, np.asarray(chunk_ids, dtype=np.int64)[keep],
+            images, labels, np.ascontiguousarray(positions[:, :, 0], dtype=np.int64),
+            np.ascontiguousarray(positions[:, :, 1], dtype=np.int64))
+

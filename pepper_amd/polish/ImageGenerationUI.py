@@ -149,10 +149,8 @@ class UserInterfaceSupport:
                     views[key] = UserInterfaceView(chr_name, bam_file, draft_file, truth_bam, train_mode)
                 results = views[key].parse_regions([(a, b) for _, a, b in block], downsample_rate)
                 for region, (images, labels, positions, chunk_ids) in zip(block, results):
-                    for i, image in enumerate(images):
-                        position, index = positions[i][:, 0], positions[i][:, 1]
-                        summary_name = str(region[0]) + "_" + str(region[1]) + "_" + str(region[2]) + "_" + str(chunk_ids[i])
-                        output_hdf_file.write_summary(region, image, labels[i], position, index, chunk_ids[i], summary_name)
+                    if len(images):         # group names <contig>_<start>_<end>_<chunk id>, one library call per region
+                        output_hdf_file.write_summaries(region, images, labels, positions, chunk_ids)
                 before = counter
                 counter += len(block)
                 if thread_id == 0 and counter // 10 > before // 10:

@@ -241,3 +241,26 @@ def test_polish_bulk_block_io_equals_the_per_dataset_path(tmp_path):
         for key in wa:
             assert wa[key][0] == wb[key][0], (key, wa[key][0], wb[key][0])
             assert np.array_equal(wa[key][1], wb[key][1]), key
+
+
+def test_polish_image_chunks_bulk_writer_equals_write_summary(tmp_path):
+    from pepper_amd import synthetic
+    from pepper_amd.polish.DataStore import DataStore
+    chunks = synthetic.polish_chunks(3, seed=4)
+    pos = np.stack([np.stack([np.arange(1000) + 7000 + 950 * c, np.arange(1000) % 4], axis=1) for c in range(3)]).astype(np.int64)
+    pos[2, 600:] = -1
+    labels = np.zeros((3, 1000), np.uint8)
+    region = ("contig_9", 7000, 8200)
+    with DataStore(str(tmp_path / "a.hdf"), "w") as a, DataStore(str(tmp_path / "b.hdf"), "w") as b:
+        for c in range(3):
+            a.write_summary(region, chunks[c], labels[c], pos[c][:, 0], pos[c][:, 1], c, "contig_9_7000_8200_%d" % c)
+        b.write_summaries(region, [chunks[c] for c in range(3)], list(labels), list(pos), [0, 1, 2])
+        b.write_summaries(region, [chunks[0]], [labels[0]], [pos[0]], [0])                 # already written: skipped
+    with h5.File(str(tmp_path / "a.hdf")) as fa, h5.File(str(tmp_path / "b.hdf")) as fb:
+        assert fa.keys("summaries") == fb.keys("summaries") and len(fb.keys("summaries")) == 3
+        for name in fa.keys("summaries"):
+            assert sorted(fa.keys("summaries/" + name)) == sorted(fb.keys("summaries/" + name))
+            for ds_name in fa.keys("summaries/" + name):
+                p = "summaries/%s/%s" % (name, ds_name)
+                assert fa.info(p) == fb.info(p), (p, fa.info(p), fb.info(p))
+                assert np.array_equal(fa[p], fb[p]), p
