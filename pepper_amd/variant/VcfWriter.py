@@ -39,9 +39,10 @@ class _VcfFile(object):
 
     def write(self, record):
         contig, start, ref_len, line = record
-        vbeg = self._out.tell()
-        self._out.write(line)
-        self._index.add(contig, start, start + ref_len, vbeg, self._out.tell())
+        out = self._out
+        vbeg = out.tell()
+        out.write(line)
+        self._index.add(contig, start, start + ref_len, vbeg, out.tell())
 
     def close(self):
         if self._out is not None:
@@ -154,7 +155,7 @@ class VCFWriter:
         ])
         line = "\t".join([str(contig), str(ref_start + 1), ".", alleles[0], ",".join(alleles[1:]), _fmt_float(qual),
                           filt, ".", "GT:AP:GQ:DP:AD:VAF:REP", sample]) + "\n"
-        return (str(contig), ref_start, len(alleles[0]), line)
+        return (str(contig), ref_start, len(alleles[0]), line.encode())     # encoded once, written to up to three files
 
     def write_vcf_records(self, variants_list, options):
         total_variants, total_pepper, total_calling, total_calling_snp, total_calling_indel = 0, 0, 0, 0, 0

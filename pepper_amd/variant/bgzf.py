@@ -37,6 +37,9 @@ class BgzfWriter(object):
     def write(self, data):
         if isinstance(data, str):
             data = data.encode()
+        if len(self._buf) + len(data) < _BLOCK_DATA:     # the common case: one record, no block boundary
+            self._buf += data
+            return
         view = memoryview(data)
         while len(view):
             room = _BLOCK_DATA - len(self._buf)
