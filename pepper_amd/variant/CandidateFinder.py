@@ -69,6 +69,23 @@ def _fasta(options):
     return factory(options.fasta) if factory is not None else FASTA_handler(options.fasta)
 
 
+class _ReferenceWindow(object):
+    """get_reference_sequence for the positions of one prediction batch out of ONE fetch of the span they cover (the
+    batch's candidates sit within a few kb of each other; three seek + read calls per candidate otherwise)."""
+
+    def __init__(self, fasta_handler, contig, lo, hi):
+        self.contig, self.fasta = contig, fasta_handler
+        self.lo = max(0, int(lo))
+        self.text = fasta_handler.get_reference_sequence(contig, self.lo, int(hi)) if hi - lo <= 4000000 else None
+        self.hi = self.lo + len(self.text) if self.text is not None else self.lo
+
+    def get_reference_sequence(self, contig, start, stop):
+        start = max(0, int(start))
+        if self.text is None or contig != self.contig or start < self.lo or stop > self.hi:
+            return self.fasta.get_reference_sequence(contig, start, stop)       # outside the window (or clamped by the contig end)
+        return self.text[start - self.lo:max(start, int(stop)) - self.lo]
+
+
 def _in_repeat(fasta_handler, contig, position):
     """The reference's low-complexity flag: a homopolymer run >= 5 touching [position-5, position+4)
     inside the context ref[position-10, position+10)  (:397-418)."""
@@ -151,18 +168,23 @@ def small_chunk_stitch(options, file_chunks):
             candidate_frequencies = hdf5_file[base + "candidate_frequency"]
             base_predictions = np.asarray(hdf5_file[base + "base_prediction"]).astype(np.float32)
 
+        windows = {}
         for i in range(len(contigs)):
             contig = contigs[i].decode("UTF-8") if isinstance(contigs[i], bytes) else str(contigs[i])
             position = int(positions[i])
+            window = windows.get(contig)
+            if window is None:
+                same = [int(positions[k]) for k in range(len(contigs)) if contigs[k] == contigs[i]]
+                window = windows[contig] = _ReferenceWindow(fasta_handler, contig, min(same) - 16, max(same) + 16)
             depth = int(depths[i])
             alleles = _parse_list_field(candidates[i])
             supports = [int(x) for x in _parse_list_field(candidate_frequencies[i])]
             prediction = [float(v) for v in base_predictions[i]]
 
-            reference_base = fasta_handler.get_reference_sequence(contig, position, position + 1).upper()
+            reference_base = window.get_reference_sequence(contig, position, position + 1).upper()
             if reference_base not in _BASES or len(reference_base) != 1:
                 continue
-            in_repeat = _in_repeat(fasta_handler, contig, position)
+            in_repeat = _in_repeat(window, contig, position)
             margin, calling = _select_site(options, contig, position, depth, alleles, supports, prediction,
                                            reference_base, in_repeat)
             if margin is not None:
