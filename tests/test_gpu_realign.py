@@ -199,3 +199,27 @@ def test_several_windows_in_one_call():
     out = align_windows(windows, which, pos, off, np.frombuffer(b"".join(blob), np.uint8), collapse_eqx=False)
     _assert_same(out, expect)
     assert (out["status"] == -1).sum() == 1 and (out["status"] == 1).sum() > 60
+
+
+def test_low_complexity_sequences():
+    """Tandem repeats, two-letter alphabets and homopolymer runs: many equal-scoring cells, so the end / begin cell
+    choice and every tie rule of the band stage decide the result."""
+    rng = np.random.default_rng(17)
+
+    def lowc(n, kind):
+        if kind == 0:
+            unit = _rand_seq(rng, int(rng.integers(1, 4)))
+            return (unit * (n // len(unit) + 1))[:n]
+        if kind == 1:
+            return "".join(rng.choice(list("AC"), n))
+        out = []
+        while len(out) < n:
+            out += [BASES[int(rng.integers(4))]] * int(rng.integers(1, 12))
+        return "".join(out[:n])
+    for kind in (0, 1, 2):
+        reference = lowc(700, kind)
+        pos, seqs = ssw.simulate_reads(rng, reference, 300, 70, sub=0.03, ins=0.03, dele=0.03, min_len=20)
+        pos += [300, 310, 320]
+        seqs += [lowc(150, kind), reference[10:400], reference[20:30] * 6]
+        out = _gpu_align(reference, 300, pos, seqs)
+        _assert_same(out, ssw.realign_reads(reference, 300, pos, seqs))
