@@ -30,6 +30,13 @@ def _fmt_float(value):
     return "%g" % v
 
 
+def _picklable_options(options):
+    """The option fields the formatter reads, as a plain namespace (the caller's object may hold handles / factories)."""
+    from types import SimpleNamespace
+    names = ("allowed_multiallelics", "snp_q_cutoff", "snp_q_cutoff_in_lc", "indel_q_cutoff", "indel_q_cutoff_in_lc")
+    return SimpleNamespace(**{n: getattr(options, n) for n in names})
+
+
 class _VcfFile(object):
     def __init__(self, path, header_text):
         self.path = path
@@ -157,17 +164,17 @@ class VCFWriter:
                           filt, ".", "GT:AP:GQ:DP:AD:VAF:REP", sample]) + "\n"
         return (str(contig), ref_start, len(alleles[0]), line.encode())     # encoded once, written to up to three files
 
-    def write_vcf_records(self, variants_list, options):
-        total_variants, total_pepper, total_calling, total_calling_snp, total_calling_indel = 0, 0, 0, 0, 0
-        last_position = -1
-        for contig, position in sorted(variants_list):
+    @staticmethod
+    def format_sites(site_candidates, options):
+        """The per-site part of write_vcf_records (:150-218) for a list of sites in order: (record, is_snp,
+        selected_for_variant_calling) per site, or None where the site has no allele.  No state: runs in worker processes."""
+        out = []
+        for candidates in site_candidates:
             contig, ref_start, ref_end, ref_seq, alleles, genotype, depth, variant_allele_support, genotype_probability, \
-                non_alt_predictions, site_in_repeat = self.candidate_list_to_variant(variants_list[(contig, position)], options)
+                non_alt_predictions, site_in_repeat = VCFWriter.candidate_list_to_variant(None, candidates, options)
             if len(alleles) <= 0:
+                out.append(None)
                 continue
-            if ref_start == last_position:     # (sic: compared across contigs too, :150-151)
-                continue
-            last_position = ref_start
             max_alt_len = max(len(ref_seq), max(len(x) for x in alleles))
             alleles = (ref_seq,) + tuple(alleles)
             qual = max(1, int(-10 * math.log10(max(0.000000001, 1.0 - genotype_probability))))
@@ -179,25 +186,53 @@ class VCFWriter:
             failed_variant = qual <= cutoff
             # everything not confidently genotyped goes to the re-genotyping set (:178-182)
             selected_for_variant_calling = genotype == [0, 0] or failed_variant
-
             vafs = [round(ad / max(1, depth), 3) for ad in variant_allele_support]
             rep = "1" if site_in_repeat else "0"
-            record = self._record(contig, ref_start, alleles, qual, 'refCall' if genotype == [0, 0] else 'PASS',
-                                  genotype, non_alt_predictions, qual, depth, variant_allele_support, vafs, rep)
-            self.vcf_file_full.write(record)
-            total_variants += 1
-            if selected_for_variant_calling:
-                if is_snp:
-                    self.vcf_file_variant_calling_snp.write(record)
-                    total_calling_snp += 1
+            record = VCFWriter._record(contig, ref_start, alleles, qual, 'refCall' if genotype == [0, 0] else 'PASS',
+                                       genotype, non_alt_predictions, qual, depth, variant_allele_support, vafs, rep)
+            out.append((record, is_snp, selected_for_variant_calling))
+        return out
+
+    def write_vcf_records(self, variants_list, options):
+        total_variants, total_pepper, total_calling, total_calling_snp, total_calling_indel = 0, 0, 0, 0, 0
+        last_position = -1
+        keys = sorted(variants_list)
+        sites = [variants_list[k] for k in keys]
+        # records are formatted in `threads` worker processes (a pure function of the site); the sequential part -- the
+        # duplicate-start rule and the five compressed, indexed files -- stays here
+        threads = max(1, int(getattr(options, "threads", 1) or 1))
+        block = 4096
+        blocks = [sites[i:i + block] for i in range(0, len(sites), block)]
+        if threads > 1 and len(blocks) > 1:
+            import concurrent.futures
+            plain = _picklable_options(options)
+            with concurrent.futures.ProcessPoolExecutor(max_workers=threads) as executor:
+                formatted_blocks = [f.result() for f in [executor.submit(VCFWriter.format_sites, b, plain) for b in blocks]]
+        else:
+            formatted_blocks = [VCFWriter.format_sites(b, options) for b in blocks]
+        for formatted in formatted_blocks:
+            for item in formatted:
+                if item is None:
+                    continue
+                record, is_snp, selected_for_variant_calling = item
+                ref_start = record[1]
+                if ref_start == last_position:     # (sic: compared across contigs too, :150-151)
+                    continue
+                last_position = ref_start
+                self.vcf_file_full.write(record)
+                total_variants += 1
+                if selected_for_variant_calling:
+                    if is_snp:
+                        self.vcf_file_variant_calling_snp.write(record)
+                        total_calling_snp += 1
+                    else:
+                        self.vcf_file_variant_calling_indel.write(record)
+                        total_calling_indel += 1
+                    self.vcf_file_variant_calling.write(record)
+                    total_calling += 1
                 else:
-                    self.vcf_file_variant_calling_indel.write(record)
-                    total_calling_indel += 1
-                self.vcf_file_variant_calling.write(record)
-                total_calling += 1
-            else:
-                self.vcf_file_pepper.write(record)
-                total_pepper += 1
+                    self.vcf_file_pepper.write(record)
+                    total_pepper += 1
         return total_variants, total_pepper, total_calling, total_calling_snp, total_calling_indel
 
     def get_vcf_header(self, sample_name, contigs):

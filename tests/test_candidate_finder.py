@@ -264,3 +264,39 @@ def test_vcf_files(fasta, tmp_path):
     assert beg == header_len                         # single block: virtual offset == uncompressed offset
     (_, end), = idx["refs"][1]["bins"][4681]
     assert end == len(raw)
+
+
+def test_vcfs_do_not_depend_on_the_number_of_worker_processes(tmp_path):
+    """Selection and record formatting run in `threads` processes; the duplicate-start rule and the writers are
+    sequential: all ten output files are byte-identical for 1 and 3 workers."""
+    import hashlib
+    from pepper_amd.variant.DataStorePredict import DataStore
+    from pepper_amd.variant.FindCandidates import process_candidates
+    rng = np.random.default_rng(8)
+    n, length = 9000, 60000
+    ref = "".join("ACGT"[k] for k in rng.integers(0, 4, length))
+    ref = ref[:3000] + "A" * 12 + ref[3012:]
+    fa = str(tmp_path / "r.fa")
+    with open(fa, "w") as fh:
+        fh.write(">chr20\n" + "\n".join(ref[i:i + 60] for i in range(0, length, 60)) + "\n")
+    (tmp_path / "pred").mkdir()
+    store = DataStore(str(tmp_path / "pred" / "pepper_prediction_0.hdf"), "w")
+    positions = np.sort(rng.choice(np.arange(100, length - 100), n, replace=True)).astype(np.int32)   # repeats: multi-allelic sites
+    for b, s in enumerate(range(0, n, 512)):
+        e = min(n, s + 512)
+        m = e - s
+        cands = []
+        for p in positions[s:e]:
+            r, k = ref[int(p)], int(rng.integers(3))
+            cands.append(["1" + "ACGT"[("ACGT".index(r) + 1 + int(rng.integers(3))) % 4]] if k == 0 else
+                         (["2" + r + "AC"] if k == 1 else ["3" + ref[int(p):int(p) + 3]]))
+        store.write_prediction(b, ["chr20"] * m, positions[s:e], rng.integers(20, 80, m).astype(np.uint8),
+                               np.array(cands, dtype=object), rng.integers(5, 40, (m, 1)).astype(np.uint8),
+                               rng.dirichlet([1.0, 1.0, 1.0], m))
+    store.close()
+    digests = []
+    for threads in (1, 3):
+        out = str(tmp_path / ("out%d" % threads))
+        process_candidates(options(fasta=fa, threads=threads), str(tmp_path / "pred"), out)
+        digests.append({f: hashlib.md5(open(out + "/" + f, "rb").read()).hexdigest() for f in sorted(os.listdir(out))})
+    assert len(digests[0]) == 10 and digests[0] == digests[1]
