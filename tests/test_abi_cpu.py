@@ -63,6 +63,14 @@ def test_no_gpu_means_loud_failure(lib):
     rc = lib.pa_variant_create(ctypes.byref(cfg), names, data, numel, n, None, ctypes.byref(handle))
     assert rc != 0
     assert b"no HIP device" in lib.pa_last_error() or b"hip" in lib.pa_last_error().lower()
+    # the summary encoders and the read re-aligner likewise
+    for create in (lib.pa_encoder_create, lib.pa_realigner_create):
+        handle = ctypes.c_void_p()
+        assert create(0, None, ctypes.byref(handle)) != 0 and not handle.value
+        assert b"no cpu fallback" in lib.pa_last_error().lower()
+    from pepper_amd.polish.PEPPER import ReadAligner
+    with pytest.raises(_lib.PepperAmdError, match="no CPU fallback"):
+        ReadAligner(0, 8, "ACGTACGT").align_arrays([0], [0, 4], [65, 67, 71, 84])
 
 
 def test_product_never_imports_oracle():
