@@ -45,7 +45,7 @@ class _StagingBuffers(object):
         need = n * window * features
         if need > self.LIMIT:
             return np.empty((n, window, features), np.int8)
-        k, self.turn = self.turn, self.turn ^ 1
+        k, self.turn = self.turn, (self.turn + 1) % len(self.buffers)
         t = self.buffers[k]
         if t is None or t.numel() < need:
             t = torch.empty(max(need + need // 8, 1), dtype=torch.int8)
@@ -86,7 +86,15 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
     writer = ThreadPoolExecutor(max_workers=1)
     writes = []
     staging = _StagingBuffers()
-    pending = (reader.submit(SequenceDataset, input_filepath, input_files[0], None, staging.alloc) if input_files else None)
+    # options.num_workers (the reference's DataLoader(num_workers=...), RunInferenceArguments.py:75-82): > 0 reads the image
+    # files in that many loader processes (libhdf5 calls of one process share a lock), 0 in one reader thread
+    loader_workers = max(0, int(getattr(options, "num_workers", 0) or 0))
+    loaded = None
+    if loader_workers > 0 and len(input_files) > 1:
+        from pepper_amd.variant.models.dataloader_predict import LoaderPool
+        loaded = iter(LoaderPool(input_filepath, input_files, loader_workers, staging.alloc))
+    pending = (reader.submit(SequenceDataset, input_filepath, input_files[0], None, staging.alloc)
+               if input_files and loaded is None else None)
 
     def write_file(first_batch, input_data, probs):
         # bulk arrays straight into one library call per batch_<n> group (no per-candidate Python objects)
@@ -101,9 +109,12 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
 
     try:
         for file_id, input_file in enumerate(input_files):
-            input_data = pending.result()
-            pending = (reader.submit(SequenceDataset, input_filepath, input_files[file_id + 1], None, staging.alloc)
-                       if file_id + 1 < len(input_files) else None)
+            if loaded is not None:
+                input_data = next(loaded)
+            else:
+                input_data = pending.result()
+                pending = (reader.submit(SequenceDataset, input_filepath, input_files[file_id + 1], None, staging.alloc)
+                           if file_id + 1 < len(input_files) else None)
             n = len(input_data)
             if n:
                 # one packed int8 H2D copy per file, one device pass; float32 probs come back
@@ -118,6 +129,8 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
         for w in writes:
             w.result()
     finally:
+        if loaded is not None:
+            loaded.close()                  # the generator's finally stops the loader processes
         reader.shutdown(wait=True)
         writer.shutdown(wait=True)
         prediction_data_file.close()

@@ -445,3 +445,4 @@ def test_polish_end_to_end_from_bam(tmp_path):
                 assert np.array_equal(f[base + "position"], wp[:, 0]) and np.array_equal(f[base + "index"], wp[:, 1])
                 checked += 1
     assert checked >= 4
+

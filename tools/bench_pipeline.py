@@ -22,6 +22,7 @@ from pepper_amd.variant.RunInference import run_inference  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--files", type=int, default=8)
 ap.add_argument("--windows", type=int, default=65536)
+ap.add_argument("--workers", type=int, default=0, help="options.num_workers: loader processes (0 = one reader thread)")
 args = ap.parse_args()
 tmp = tempfile.mkdtemp()
 try:
@@ -40,7 +41,7 @@ try:
     sd = synthetic.variant_state_dict(seed=0)
     model_path = os.path.join(tmp, "model.pkl")
     torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
-    opts = SimpleNamespace(model_path=model_path, batch_size=512, num_workers=0, use_hp_info=False, gpu=True, device_ids="0",
+    opts = SimpleNamespace(model_path=model_path, batch_size=512, num_workers=args.workers, use_hp_info=False, gpu=True, device_ids="0",
                            callers_per_gpu=4, threads=8, quantized=False, dry=False)
     t0 = time.perf_counter()
     run_inference(opts, img_dir, os.path.join(tmp, "pred"))
@@ -48,6 +49,6 @@ try:
     n = args.files * (args.windows // 4) * 4
     size = sum(os.path.getsize(os.path.join(img_dir, f)) for f in os.listdir(img_dir))
     print(json.dumps({"metric": "run_inference HDF5 -> HDF5, 1 GPU", "windows": n, "image_bytes": size,
-                      "seconds": round(dt, 3), "windows_per_s": round(n / dt), "image_write_seconds": round(t_write, 2)}))
+                      "loader_processes": args.workers, "seconds": round(dt, 3), "windows_per_s": round(n / dt), "image_write_seconds": round(t_write, 2)}))
 finally:
     shutil.rmtree(tmp)
