@@ -108,3 +108,22 @@ def test_hand_made_clipping_cases(tmp_path):
     sub = got.take([3, 0])
     assert [r.query_name for r in sub] == ["d", "a"] and sub[1].sequence == want[0]["seq"]
     assert sub.as_pileup()["cigar_offset"].tolist() == [0, 4, 7]
+
+
+def test_block_cache_eviction_and_buffer_reuse(tmp_path):
+    """More BGZF blocks than the reader caches (256): region queries in random order keep evicting blocks and reusing
+    their buffers; every answer must still equal the restatement."""
+    rng = np.random.default_rng(23)
+    ref = pu.random_reference(rng, 40000)
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=1400, read_len=(300, 2500), clip_rate=0.2)
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    for i, r in enumerate(reads):
+        r["name"] = "r%d" % i
+    path = str(tmp_path / "many_blocks.bam")
+    bu.write_bam(path, [("ctg", 40000)], {0: reads}, flush_every=2)          # a block every two records: > 500 blocks
+    bam = BAM_handler(path)
+    starts = rng.integers(0, 39000, size=60).tolist() + list(range(0, 39000, 3000)) + list(range(38000, 0, -3500))
+    for start in starts:
+        stop = int(start) + int(rng.integers(50, 3000))
+        compare(bam.get_reads("ctg", int(start), stop, False, 0, 0), bu.restated_get_reads(reads, int(start), stop, False, 0))
+    bam.close()
