@@ -103,3 +103,48 @@ def test_restatement_equals_reference_build_on_low_complexity_sequences():
             assert got[0] == want[0], it
         else:
             assert got[:6] == want, it
+
+
+def test_apply_alignment_assembles_the_read_set():
+    """Host-side assembly of the re-aligner's flat results into a ReadSet (pepper_amd.polish.PEPPER.apply_alignment),
+    fed with the restatement's results instead of the GPU's: dropped reads disappear, aligned reads get the new position /
+    end / CIGAR ('=' and 'X' as MATCH), the others keep what they had; `first` selects a slice of a multi-region result."""
+    from pepper_amd.polish.PEPPER import apply_alignment
+    from pepper_amd.variant.bam import ReadSet
+    rng = np.random.default_rng(4)
+    window = _rand(rng, 500)
+    pos, seqs = ssw.simulate_reads(rng, window, 2000, 14)
+    pos[2] = 1990                                   # dropped
+    seqs[5] = "N" * 25                              # score 0: kept as it was
+    res = ssw.realign_reads(window, 2000, pos, seqs)
+    assert [r[0] for r in res].count(-1) == 1 and [r[0] for r in res].count(0) == 1
+    n = len(seqs)
+    so = np.zeros(n + 1, np.int64)
+    np.cumsum([len(s) for s in seqs], out=so[1:])
+    reads = ReadSet(np.array(pos, np.int64), np.array([p + len(s) for p, s in zip(pos, seqs)], np.int64), np.zeros(n, np.uint8),
+                    np.full(n, 60, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), so,
+                    np.frombuffer("".join(seqs).encode(), np.uint8), np.full(int(so[-1]), 20, np.uint8),
+                    np.arange(n + 1, dtype=np.int64), np.zeros(n, np.int32), np.array([len(s) for s in seqs], np.int32),
+                    ["r%d" % k for k in range(n)])
+    # flat result arrays as align_windows returns them, preceded by three reads of "another region"
+    lead = 3
+    ops_all = [(0 if o in (7, 8) else o, ln) for r in res for (o, ln) in r[4]]
+    counts = [0] * lead + [len(r[4]) for r in res]
+    off = np.zeros(lead + n + 1, np.int64)
+    np.cumsum(counts, out=off[1:])
+    out = dict(status=np.array([1] * lead + [r[0] for r in res], np.int32), score=np.zeros(lead + n, np.int32),
+               pos=np.array([0] * lead + [r[2] for r in res], np.int64), pos_end=np.array([0] * lead + [r[3] for r in res], np.int64),
+               cigar_offset=off, cigar_op=np.array([o for o, _ in ops_all], np.int32), cigar_len=np.array([ln for _, ln in ops_all], np.int32))
+    got = apply_alignment(reads, out, first=lead)
+    kept = [(k, r) for k, r in enumerate(res) if r[0] >= 0]
+    assert len(got) == n - 1 and got.names == ["r%d" % k for k, _ in kept]
+    for i, (k, (st, score, p, pe, ops)) in enumerate(kept):
+        a, b = int(got.cigar_offset[i]), int(got.cigar_offset[i + 1])
+        cigar = list(zip(got.cigar_op[a:b].tolist(), got.cigar_len[a:b].tolist()))
+        s0, s1 = int(got.seq_offset[i]), int(got.seq_offset[i + 1])
+        assert got.seq[s0:s1].tobytes().decode() == seqs[k]
+        if st == 1:
+            assert (int(got.pos[i]), int(got.pos_end[i])) == (p, pe)
+            assert cigar == [(0 if o in (7, 8) else o, ln) for o, ln in ops]
+        else:
+            assert (int(got.pos[i]), int(got.pos_end[i])) == (pos[k], pos[k] + len(seqs[k])) and cigar == [(0, len(seqs[k]))]
