@@ -6,7 +6,7 @@
 // includes htslib (absent from this image) and ends with the htslib-backed BAM_handler class.  The Makefile
 // lifts, verbatim and at build time, (1) the block of plain type definitions of that header (from `using
 // namespace std;` to just before `class BAM_handler`), (2) summary_generator.h minus that one #include line
-// and (3) summary_generator.cpp minus its #include of the header, all into oracle/_ref/ (git-ignored).  No
+// and (3) summary_generator.cpp minus its #include of the header, all into a scratch directory made by mktemp (removed after the compile; oracle/_ref/ keeps only the .so).  No
 // stand-in for any htslib header, type or function is written: the encoder never touches htslib.
 #include <assert.h>
 #include <math.h>
