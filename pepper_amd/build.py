@@ -12,7 +12,8 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpepper_amd.so")
 SOURCES = ["api.hip", "gemm.hip", "gemm_h2.hip", "rnn.hip", "rnn_h2.hip", "mlp_h2.hip", "head.hip", "encoder.hip", "realign.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "pepper_amd.h"),
-           os.path.join("..", "..", "include", "pepper_amd_encoder.h")]
+           os.path.join("..", "..", "include", "pepper_amd_encoder.h"),
+           os.path.join("..", "..", "include", "pepper_amd_realign.h")]
 
 
 def _hipcc():
@@ -34,18 +35,26 @@ def build_io(force=False, verbose=False):
     src = os.path.join(CSRC, "hdf5io.cpp")
     bam = os.path.join(CSRC, "bamio.cpp")      # BAM reader (zlib) lives in the same host-side library
     hdr = os.path.join(CSRC, "..", "..", "include", "pepper_amd_io.h")
-    if not force and os.path.exists(IO_LIB) and os.path.getmtime(IO_LIB) >= max(os.path.getmtime(src), os.path.getmtime(bam),
-                                                                              os.path.getmtime(hdr)):
+    have_src = all(os.path.exists(f) for f in (src, bam, hdr))
+    if os.path.exists(IO_LIB) and (not have_src or (not force and os.path.getmtime(IO_LIB) >= max(
+            os.path.getmtime(src), os.path.getmtime(bam), os.path.getmtime(hdr)))):
         return IO_LIB
     inc, lib = os.path.join(HDF5_PREFIX, "include"), os.path.join(HDF5_PREFIX, "lib")
     if not os.path.exists(os.path.join(inc, "hdf5.h")):
         raise RuntimeError(f"hdf5.h not found under {inc}: set PEPPER_AMD_HDF5_PREFIX")
-    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", IO_LIB + ".tmp", src, bam, f"-I{inc}", f"-L{lib}",
+    # per-process temporary name: loader / writer worker processes that start without a built library may all get
+    # here at once; each links its own file and the rename is atomic
+    tmp = f"{IO_LIB}.{os.getpid()}.tmp"
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", tmp, src, bam, f"-I{inc}", f"-L{lib}",
            "-lhdf5", "-lz", f"-Wl,-rpath,{lib}"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
-    os.replace(IO_LIB + ".tmp", IO_LIB)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, IO_LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return IO_LIB
 
 
@@ -61,12 +70,17 @@ def build(force=False, verbose=False):
         return LIB
     # -mf16c on the host side: weight packing converts ~24 M values to f16 hi/lo halves at model creation; without the
     # F16C conversions clang calls a soft-float routine per value (0.4 s per variant model instead of tens of ms)
+    tmp = f"{LIB}.{os.getpid()}.tmp"
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Xarch_host", "-mf16c",
-           "-Wno-unused-result", "-o", LIB + ".tmp"] + SOURCES
+           "-Wno-unused-result", "-o", tmp] + SOURCES
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, cwd=CSRC, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    try:
+        subprocess.run(cmd, cwd=CSRC, check=True)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 

@@ -57,6 +57,7 @@ struct Bgzf {
     int64_t next_coffset = 0;        // file offset of the block after it
     size_t upos = 0;                 // read position inside the current block
     bool eof = false;
+    bool failed = false;             // a block could not be decoded (bad magic, short block, inflate error): NOT end of file
 
     bool load_block(int64_t coffset) {
         const auto hit = cache.find(coffset);
@@ -143,7 +144,7 @@ struct Bgzf {
         while (done < n) {
             if (upos >= cur->size()) {
                 if (eof) break;
-                if (!load_block(next_coffset)) { eof = true; break; }
+                if (!load_block(next_coffset)) { eof = true; failed = true; break; }
                 if (eof) break;
                 if (cur->empty()) continue;           // empty block (e.g. the EOF marker)
             }
@@ -285,6 +286,45 @@ int parse_hp(const uint8_t* s, const uint8_t* end) {
     return hp;
 }
 
+// CG:B,I -- the real CIGAR of a record with more than 65535 operations (SAM spec 4.2.2: the core field then holds the
+// placeholder <l_seq>S<ref_len>N).  Returns a pointer to the little-endian uint32 array and its length, or nullptr.
+const uint8_t* find_cg(const uint8_t* s, const uint8_t* end, uint32_t* count) {
+    while (end - s >= 4) {
+        const bool is_cg = s[0] == 'C' && s[1] == 'G';
+        const uint8_t type = s[2];
+        s += 3;
+        switch (type) {
+            case 'A': s += 1; break;
+            case 'c': case 'C': case 's': case 'S': case 'i': case 'I': case 'f': {
+                const int sz = aux_size(type);
+                if (end - s < sz) return nullptr;
+                s += sz;
+                break;
+            }
+            case 'Z': case 'H':
+                while (s < end && *s) ++s;
+                if (s >= end) return nullptr;
+                ++s;
+                break;
+            case 'B': {
+                if (end - s < 5) return nullptr;
+                const int esz = aux_size(s[0]);
+                if (esz < 0) return nullptr;
+                const uint32_t cnt = le32(s + 1);
+                if ((uint64_t)(end - s - 5) < (uint64_t)cnt * esz) return nullptr;
+                if (is_cg && s[0] == 'I') {
+                    *count = cnt;
+                    return s + 5;
+                }
+                s += 5 + (size_t)cnt * esz;
+                break;
+            }
+            default: return nullptr;
+        }
+    }
+    return nullptr;
+}
+
 }  // namespace
 
 extern "C" {
@@ -377,16 +417,23 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
         if (off == 0) nothing = true;     // no alignments on this reference
         from = off;
     }
+    b->bg.failed = false;
     if (!nothing && !b->bg.seek(from)) return bam_fail(-5, "BGZF seek failed (corrupt file or index)");
 
     std::vector<uint8_t> rec;
     while (!nothing) {
         uint8_t w4[4];
-        if (b->bg.read(w4, 4) != 4) break;
+        const size_t got4 = b->bg.read(w4, 4);
+        if (b->bg.failed) return bam_fail(-5, "corrupt or truncated BGZF block");
+        if (got4 != 4) {
+            if (got4 != 0) return bam_fail(-6, "truncated BAM record");
+            break;
+        }
         const uint32_t block_size = le32(w4);
         if (block_size < 32) return bam_fail(-6, "corrupt BAM record");
         rec.resize(block_size);
-        if (b->bg.read(rec.data(), block_size) != block_size) return bam_fail(-6, "truncated BAM record");
+        if (b->bg.read(rec.data(), block_size) != block_size)
+            return bam_fail(b->bg.failed ? -5 : -6, b->bg.failed ? "corrupt or truncated BGZF block" : "truncated BAM record");
         const int32_t ref_id = (int32_t)le32(&rec[0]);
         const int32_t pos = (int32_t)le32(&rec[4]);
         const uint32_t l_read_name = rec[8];
@@ -402,9 +449,21 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
         const size_t o_name = 32, o_cigar = o_name + l_read_name, o_seq = o_cigar + 4ull * n_cigar_op,
                      o_qual = o_seq + (l_seq + 1) / 2, o_aux = o_qual + l_seq;
         if (o_aux > block_size) return bam_fail(-6, "corrupt BAM record");
+        // reads with more than 65535 CIGAR operations (ultra-long nanopore reads) keep their CIGAR in the CG:B,I tag and a
+        // placeholder <l_seq>S<ref_len>N in the core field; htslib (the reference's reader) swaps it in transparently
+        const uint8_t* cig = &rec[o_cigar];
+        uint32_t n_cig = n_cigar_op;
+        if (n_cigar_op == 2 && (le32(cig) & 15) == 4 && (le32(cig) >> 4) == l_seq && (le32(cig + 4) & 15) == 3) {
+            uint32_t cnt = 0;
+            const uint8_t* real = find_cg(&rec[o_aux], rec.data() + block_size, &cnt);
+            if (!real)
+                return bam_fail(-6, "BAM record carries the long-CIGAR placeholder (<l_seq>S<ref_len>N) but no CG:B,I tag");
+            cig = real;
+            n_cig = cnt;
+        }
         int64_t ref_len = 0;
-        for (uint32_t k = 0; k < n_cigar_op; ++k) {
-            const uint32_t c = le32(&rec[o_cigar + 4 * k]);
+        for (uint32_t k = 0; k < n_cig; ++k) {
+            const uint32_t c = le32(cig + 4 * k);
             const int op = c & 15;
             if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
         }
@@ -442,8 +501,8 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
             std::memcpy(qual_out + written, qual + idx, (size_t)count);
             written += (size_t)count;
         };
-        for (uint32_t k = 0; k < n_cigar_op; ++k) {
-            const uint32_t c = le32(&rec[o_cigar + 4 * k]);
+        for (uint32_t k = 0; k < n_cig; ++k) {
+            const uint32_t c = le32(cig + 4 * k);
             const int op = c & 15;
             const int64_t len = c >> 4;
             if (rpos > stop) break;

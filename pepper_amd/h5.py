@@ -67,9 +67,10 @@ class H5Error(RuntimeError):
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            from pepper_amd import build
-            build.build_io()
+        # rebuilds when hdf5io.cpp / bamio.cpp / the header are newer than the library (a no-op otherwise, and where the
+        # sources or the compiler are absent the shipped library is used as is)
+        from pepper_amd import build
+        build.build_io()
         lib = ctypes.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(lib, name)

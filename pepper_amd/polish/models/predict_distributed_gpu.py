@@ -75,7 +75,7 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
     return rank
 
 
-def _setup(rank, device_ids, args, all_input_files, port):
+def _setup(rank, device_ids, args, all_input_files, port, backend):
     import torch.distributed as dist
     from pepper_amd.parallel import broadcast_checkpoint
     filepath, output_filepath, model_path, batch_size, num_workers = args
@@ -83,10 +83,13 @@ def _setup(rank, device_ids, args, all_input_files, port):
     torch.cuda.set_device(device)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group("nccl", rank=rank, world_size=len(device_ids), device_id=torch.device("cuda", device))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=len(device_ids), device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=len(device_ids))
     try:
         state, meta = broadcast_checkpoint(model_path if rank == 0 else None, src=0,
-                                           device=torch.device("cuda", device))
+                                           device=torch.device("cuda", device) if backend == "nccl" else None)
         model = ModelHandler.get_new_gru_model(ImageSizeOptions.IMAGE_CHANNELS, ImageSizeOptions.IMAGE_HEIGHT,
                                                meta["gru_layers"], meta["hidden_size"], ImageSizeOptions.TOTAL_LABELS)
         model.load_state_dict(state)
@@ -98,11 +101,17 @@ def _setup(rank, device_ids, args, all_input_files, port):
 
 
 def predict_distributed_gpu(filepath, file_chunks, output_filepath, model_path, batch_size, device_ids, num_workers):
-    """One model per GPU over the given file chunks (reference signature)."""
+    """One model per entry of device_ids over the given file chunks (reference signature).  An ordinal listed twice
+    gets two callers on that GPU (the weight broadcast then runs over gloo: RCCL refuses two ranks per device)."""
+    from pepper_amd.variant.RunInference import dist_backend, free_port, remove_stale_predictions
+    if len(file_chunks) > len(device_ids) and len(device_ids) > 1:
+        raise ValueError("predict_distributed_gpu: %d file chunks for %d devices" % (len(file_chunks), len(device_ids)))
+    remove_stale_predictions(output_filepath)
     if len(device_ids) == 1:
-        return predict(filepath, file_chunks[0] if file_chunks else [], output_filepath, model_path, batch_size,
+        # every file goes to the one device, whatever the caller's chunking was
+        return predict(filepath, [f for chunk in file_chunks for f in chunk], output_filepath, model_path, batch_size,
                        num_workers, 0, device_ids[0])
     import torch.multiprocessing as mp
-    port = int(os.environ.get("PEPPER_AMD_MASTER_PORT", "29542"))
     args = (filepath, output_filepath, model_path, batch_size, num_workers)
-    mp.spawn(_setup, args=(device_ids, args, file_chunks, port), nprocs=len(device_ids), join=True)
+    mp.spawn(_setup, args=(device_ids, args, file_chunks, free_port(), dist_backend(device_ids)), nprocs=len(device_ids),
+             join=True)

@@ -62,14 +62,47 @@ def shard_files(input_files, callers, sizes=None):
 
 
 def resolve_device_ids(options):
+    """One entry per caller: the distinct device ordinals, each repeated options.callers_per_gpu times
+    (RunInference.py:27-60)."""
     if getattr(options, "device_ids", None) is None:
-        return list(range(torch.cuda.device_count()))
-    if isinstance(options.device_ids, str):
-        return sorted(set(int(i) for i in options.device_ids.split(',')))
-    return sorted(set(int(i) for i in options.device_ids))
+        ids = list(range(torch.cuda.device_count()))
+    elif isinstance(options.device_ids, str):
+        ids = sorted(set(int(i) for i in options.device_ids.split(',')))
+    else:
+        ids = sorted(set(int(i) for i in options.device_ids))
+    per_gpu = max(1, int(getattr(options, "callers_per_gpu", 1) or 1))
+    return [d for d in ids for _ in range(per_gpu)]
 
 
-def _worker(rank, world, device_ids, options, image_dir, file_chunks, output_dir, port):
+def free_port():
+    """MASTER_PORT for a spawn: PEPPER_AMD_MASTER_PORT if set, else a port the kernel hands out (two runs on one host
+    must not collide on a fixed number)."""
+    if os.environ.get("PEPPER_AMD_MASTER_PORT"):
+        return int(os.environ["PEPPER_AMD_MASTER_PORT"])
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def dist_backend(device_ids):
+    """"nccl" (= RCCL over xGMI) when every caller has its own GPU.  RCCL refuses two ranks on one device, so with
+    callers_per_gpu > 1 the one weight broadcast goes over gloo on host memory instead (47 MB, once)."""
+    if os.environ.get("PEPPER_AMD_DIST_BACKEND"):
+        return os.environ["PEPPER_AMD_DIST_BACKEND"]
+    return "nccl" if len(set(device_ids)) == len(device_ids) else "gloo"
+
+
+def remove_stale_predictions(output_dir, pattern="pepper_prediction"):
+    """The file names depend on the number of callers (pepper_prediction.hdf vs pepper_prediction_<rank>.hdf) and the
+    next stage globs every *.hdf of the directory (FindCandidates.py:151-166): leftovers of an earlier run with a
+    different GPU count would be mixed into the VCF."""
+    for name in listdir(output_dir):
+        if name.startswith(pattern) and name.endswith(".hdf") and isfile(join(output_dir, name)):
+            os.remove(join(output_dir, name))
+
+
+def _worker(rank, world, device_ids, options, image_dir, file_chunks, output_dir, port, backend):
     import torch.distributed as dist
     from pepper_amd.parallel import broadcast_checkpoint
     from pepper_amd.variant.Options import ImageSizeOptions
@@ -79,10 +112,13 @@ def _worker(rank, world, device_ids, options, image_dir, file_chunks, output_dir
     torch.cuda.set_device(device)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         state, meta = broadcast_checkpoint(options.model_path if rank == 0 else None, src=0,
-                                           device=torch.device("cuda", device))
+                                           device=torch.device("cuda", device) if backend == "nccl" else None)
         model = ModelHandler.get_new_gru_model(ImageSizeOptions.IMAGE_HEIGHT, meta["gru_layers"],
                                                meta["hidden_size"], ImageSizeOptions.TOTAL_LABELS,
                                                ImageSizeOptions.TOTAL_TYPE_LABELS)
@@ -105,6 +141,7 @@ def distributed_gpu(options, image_dir, output_dir):
     file_chunks = shard_files(input_files, len(device_ids),
                               sizes=[os.path.getsize(f) for f in input_files] if len(device_ids) > 1 else None)
     world = max(1, min(len(device_ids), len(file_chunks)))
+    remove_stale_predictions(output_dir)
     threads_per_caller = max(1, int(options.threads / world))
     _log("INFO: TOTAL CALLERS: " + str(world))
     _log("INFO: TOTAL THREADS PER CALLER: " + str(threads_per_caller))
@@ -115,8 +152,8 @@ def distributed_gpu(options, image_dir, output_dir):
                                 device=device_ids[0])
     else:
         import torch.multiprocessing as mp
-        port = int(os.environ.get("PEPPER_AMD_MASTER_PORT", "29541"))
-        mp.spawn(_worker, args=(world, device_ids, options, image_dir, file_chunks, output_dir, port),
+        mp.spawn(_worker, args=(world, device_ids, options, image_dir, file_chunks, output_dir, free_port(),
+                                dist_backend(device_ids[:world])),
                  nprocs=world, join=True)
 
     _log("INFO: PREDICTION GENERATED SUCCESSFULLY.")

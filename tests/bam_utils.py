@@ -23,15 +23,22 @@ def encode_record(tid, rec):
     l_seq = len(seq)
     end = rec["pos"] + max(1, ref_length(cigar))
     body = struct.pack("<iiBBHHHIiii", tid, rec["pos"], len(name), rec.get("mapq", 60), reg2bin(rec["pos"], end),
-                       len(cigar), rec.get("flag", 16 if rec.get("reverse") else 0), l_seq, -1, -1, 0)
+                       2 if rec.get("long_cigar") else len(cigar), rec.get("flag", 16 if rec.get("reverse") else 0), l_seq, -1, -1, 0)
     body += name
-    body += b"".join(struct.pack("<I", (n << 4) | op) for op, n in cigar)
+    if rec.get("long_cigar"):
+        # what writers do for more than 65535 operations (SAM spec 4.2.2), forced here on short records: the core field
+        # holds <l_seq>S<ref_len>N (n_cigar_op = 2) and the real operations travel in the CG:B,I tag
+        body += struct.pack("<II", (l_seq << 4) | 4, (ref_length(cigar) << 4) | 3)
+    else:
+        body += b"".join(struct.pack("<I", (n << 4) | op) for op, n in cigar)
     packed = bytearray((l_seq + 1) // 2)
     for i, c in enumerate(seq):
         packed[i >> 1] |= SEQ_CODE[c] << (4 if i % 2 == 0 else 0)
     body += bytes(packed)
     body += bytes(np.asarray(rec["qual"], dtype=np.uint8))
     body += rec.get("aux", b"")
+    if rec.get("long_cigar") and not rec.get("drop_cg"):
+        body += b"CGBI" + struct.pack("<I", len(cigar)) + b"".join(struct.pack("<I", (n << 4) | op) for op, n in cigar)
     return struct.pack("<i", len(body)) + body
 
 

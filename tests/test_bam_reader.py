@@ -127,3 +127,65 @@ def test_block_cache_eviction_and_buffer_reuse(tmp_path):
         stop = int(start) + int(rng.integers(50, 3000))
         compare(bam.get_reads("ctg", int(start), stop, False, 0, 0), bu.restated_get_reads(reads, int(start), stop, False, 0))
     bam.close()
+
+
+def test_long_cigar_in_cg_tag(tmp_path):
+    """Records whose CIGAR lives in the CG:B,I tag behind the <l_seq>S<ref_len>N placeholder (reads with more than 65535
+    operations; htslib swaps the real CIGAR in transparently): same reads as with the CIGAR in the core field; a
+    placeholder without the tag is an error, not a silently dropped read."""
+    rng = np.random.default_rng(31)
+    ref = pu.random_reference(rng, 20000)
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=120, read_len=(300, 4000), clip_rate=0.3)
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    for i, r in enumerate(reads):
+        r["name"] = "r%d" % i
+        r["long_cigar"] = i % 3 != 1
+        if i % 4 == 0:
+            r["hp"] = 2
+            r["aux"] = hp_aux(2) + b"XBBs\x02\0\0\0\x01\0\x02\0"     # tags in front of CG are walked over
+    path = str(tmp_path / "cg.bam")
+    bu.write_bam(path, [("ctg", 20000)], {0: reads}, flush_every=11)
+    bam = BAM_handler(path)
+    for start, stop in ((0, 20000), (5000, 5100), (9000, 13000), (19990, 20000)):
+        compare(bam.get_reads("ctg", start, stop, False, 0, 0), bu.restated_get_reads(reads, start, stop, False, 0))
+    bam.close()
+    # one real read with more than 65535 operations: 35000 x (1M 1I) + 1M
+    n = 35000
+    big = dict(name="ultra", pos=10, cigar=[(0, 1), (1, 1)] * n + [(0, 1)], seq="AC" * n + "G", qual=[20] * (2 * n + 1),
+               long_cigar=True)
+    path2 = str(tmp_path / "ultra.bam")
+    bu.write_bam(path2, [("ctg", 40000)], {0: [big]})
+    bam = BAM_handler(path2)
+    compare(bam.get_reads("ctg", 100, 30000, False, 0, 0), bu.restated_get_reads([big], 100, 30000, False, 0))
+    bam.close()
+    bad = dict(reads[0], long_cigar=True, drop_cg=True)
+    path3 = str(tmp_path / "nocg.bam")
+    bu.write_bam(path3, [("ctg", 20000)], {0: [bad]})
+    bam = BAM_handler(path3)
+    with pytest.raises(BamError):
+        bam.get_reads("ctg", 0, 20000, False, 0, 0)
+    bam.close()
+
+
+def test_corrupt_block_is_an_error_not_end_of_file(tmp_path):
+    """A damaged BGZF block on a record boundary must fail the query (it used to read as end of file and
+    return a partial read set)."""
+    rng = np.random.default_rng(37)
+    ref = pu.random_reference(rng, 30000)
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=300, read_len=(300, 2000))
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    path = str(tmp_path / "c.bam")
+    bu.write_bam(path, [("ctg", 30000)], {0: reads}, flush_every=5)       # every block ends on a record boundary
+    raw = bytearray(open(path, "rb").read())
+    # walk the blocks and break the magic of one in the middle of the file
+    offs, p = [], 0
+    while p < len(raw):
+        offs.append(p)
+        p += (raw[p + 16] | (raw[p + 17] << 8)) + 1
+    victim = offs[len(offs) // 2]
+    raw[victim] ^= 0xff
+    open(path, "wb").write(bytes(raw))
+    bam = BAM_handler(path)
+    with pytest.raises(BamError):
+        bam.get_reads("ctg", 0, 30000, False, 0, 0)
+    bam.close()
