@@ -1,13 +1,21 @@
 #!/usr/bin/env python
 """Throughput benchmark of the RNN inference hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--model variant|polish]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model variant|polish|ns-literal|realign]
 
-A "step" is one pass of the hot path over one resident batch of synthetic summaries per GPU
-(variant: 16384 candidate windows int8 [.,33,26] = 32 reference batches of 512; polish: 2048
-chunks uint8 [.,1000,10] = 19 windows each).  Inputs are in HBM before the timed region; the
-timed region is bracketed by barrier + synchronize on both sides and the maximum over ranks is
-reported.  Rank 0 prints one JSON line (see DESIGN.md "Measurement").
+What one "step" is (DESIGN.md "Measurement"): one pass of the hot path over one batch of synthetic
+summaries per GPU, as the reference's predict loop runs it -- page-locked host buffer -> H2D of the packed int8 / uint8
+summaries -> forward -> D2H of the results (predict_distributed_gpu.py:58-67 does `.cuda()` ... `.cpu()` per batch) --
+through the C ABI's host entry points, whose device passes (16384 windows / 16384 chunks) overlap the copies of the
+neighbouring passes with the kernels on separate HIP streams.  Variant: 2^18 windows per step, taken round robin from a
+pool of 2^20 distinct V-syn windows per GPU; polish: 32768 chunks (x 19 windows) per step from a pool of 65536 P-syn
+chunks.  `value` = windows of all ranks / max-over-ranks wall time of exactly K steps bracketed by barrier +
+synchronize; the device-resident rate (inputs already in HBM, what round 1 reported) is kept as
+`device_resident` beside it, and `batch512` gives the reference's default batch through one call.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself as N ranks under torch.distributed.run
+(one process per GPU, RCCL); under an external torchrun launch it uses the ranks it is given.  Rank 0 prints ONE JSON
+line.
 """
 import argparse
 import json
@@ -24,23 +32,28 @@ sys.path.insert(0, REPO)
 from pepper_amd import _lib, synthetic  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+F16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense f16/bf16 MFMA peak (never the 2:1 sparsity figure)
 # kernels whose label carries "_h2" evaluate every f32-accurate product as three v_mfma_f32_32x32x16_f16
 # (hi*hi + hi*lo + lo*hi, f32 accumulate): their ceiling in algorithmic (f32-equivalent) FLOP/s is the
-# dense f16 MFMA peak (2.5 PFLOP/s, same guide) divided by three
-H2_MFMA_PEAK_TFLOPS = 2500.0 / 3.0
+# dense f16 MFMA peak divided by three
+H2_MFMA_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3.0
 
 
 def kernel_peak(label):
     return H2_MFMA_PEAK_TFLOPS if "_h2" in label else F32_MFMA_PEAK_TFLOPS
+
+
 VARIANT_FLOP_PER_WINDOW = 2 * 80_664_064      # SURVEY.md 8(a) A8 / BASELINE.md section 2
 POLISH_FLOP_PER_WINDOW = 2 * 40_217_600       # per 100-step window (A12)
 POLISH_WINDOWS_PER_CHUNK = 19
+VARIANT_BYTES_PER_WINDOW = 33 * 26 + 12       # int8 summary in, float32 probabilities out
+POLISH_BYTES_PER_CHUNK = 1000 * 10 + 2000     # uint8 summary in, label + phred bytes out
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", choices=["variant", "polish", "ns-literal", "realign"], default="variant",
                     help="variant = BASELINE configs[1] shapes (the headline); polish = configs[4]; ns-literal = the polish "
@@ -48,27 +61,58 @@ def parse():
                          "reference shape, reported separately); realign = the polish read re-aligner (SSW) on "
                          "regions of 1500 simulated reads, reads/s and DP cell updates/s")
     ap.add_argument("--per-gpu", type=int, default=0, help="windows (variant) / chunks (polish) per GPU per step")
+    ap.add_argument("--pool", type=int, default=0, help="distinct windows / chunks in the page-locked host pool per GPU")
+    ap.add_argument("--resident-only", action="store_true",
+                    help="time the device-resident pass instead of the host-buffer path (kernel profiling under rocprofv3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the device-resident and batch-512 legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=1, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` on its own: become N ranks (the reference spawns its ranks itself too,
+    pepper/modules/python/models/predict_distributed_gpu.py:150-166)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and os.environ.get("PEPPER_AMD_BENCH_SHARE_GPU") != "1":
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {ndev} HIP device(s) visible\n")
+        sys.exit(2)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
 def dist_setup(args):
+    """-> (world, rank, device ordinal, ranks_seen).  ranks_seen comes out of a real all-reduce."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
-    else:
+    if world == 1:
         torch.cuda.set_device(0)
-        local = 0
-    return world, rank, local
+        return 1, 0, 0, 1
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    ndev = torch.cuda.device_count()
+    # PEPPER_AMD_BENCH_SHARE_GPU=1: a plumbing check of the N-rank code path on a box with fewer GPUs (ranks share
+    # devices, gloo instead of RCCL, the line says so); never a scaling number
+    share = os.environ.get("PEPPER_AMD_BENCH_SHARE_GPU") == "1" and ndev < world
+    device = local % ndev if share else local
+    torch.cuda.set_device(device)
+    if share:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        one = torch.ones(1)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        one = torch.ones(1, device=torch.device("cuda", device))
+    dist.all_reduce(one)
+    return world, rank, device, int(one.item())
 
 
 def broadcast_state_dict(make_sd, shapes, world, rank, dev):
@@ -76,8 +120,10 @@ def broadcast_state_dict(make_sd, shapes, world, rank, dev):
     (the only collective on the path: SURVEY.md 8(e))."""
     if world == 1:
         return make_sd()
+    import torch.distributed as dist
     from pepper_amd.parallel import broadcast_numpy_state_dict
-    return broadcast_numpy_state_dict(make_sd if rank == 0 else None, shapes, device=dev)
+    on_gpu = dist.get_backend() == "nccl"
+    return broadcast_numpy_state_dict(make_sd if rank == 0 else None, shapes, device=dev if on_gpu else None)
 
 
 def _cpu_runner(model_kind):
@@ -110,11 +156,28 @@ def cpu_worker(model_kind, threads, seconds):
     print(json.dumps({"windows": units * n, "seconds": dt}))
 
 
+def host_cores():
+    """(physical cores, logical CPUs) of this host."""
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or logical
+    except Exception:
+        physical = max(1, logical // 2)
+    return physical, logical
+
+
 def cpu_baseline_workers(model_kind, seconds):
-    """Aggregate of P single-thread workers running concurrently in fresh interpreters."""
+    """Aggregate of single-thread workers running concurrently in fresh interpreters, ONE PER PHYSICAL CORE (the
+    reference's distributed_cpu scheme on the whole box; each worker holds torch + 47 MB of weights, about 0.5 GB)."""
     import subprocess
-    ncpu = os.cpu_count() or 1
-    procs = max(1, min(64, ncpu // 2))   # ~0.5 GB RSS each (torch + 47 MB of weights): bounded on purpose
+    physical, logical = host_cores()
+    procs = physical
+    try:
+        import psutil
+        procs = max(1, min(procs, int(psutil.virtual_memory().available / (0.8 * 2 ** 30))))
+    except Exception:
+        pass
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--model", model_kind, "--cpu-threads", "1",
            "--cpu-seconds", str(seconds)]
@@ -123,7 +186,7 @@ def cpu_baseline_workers(model_kind, seconds):
     outs = []
     for p in ps:
         try:
-            out, _ = p.communicate(timeout=6 * seconds + 120)
+            out, _ = p.communicate(timeout=6 * seconds + 180)
             outs.append(json.loads(out.strip().splitlines()[-1]))
         except Exception:
             p.kill()
@@ -132,26 +195,26 @@ def cpu_baseline_workers(model_kind, seconds):
         return None
     windows = sum(o["windows"] for o in outs)
     span = max(o["seconds"] for o in outs)
-    return {"value": windows / span, "unit": "windows/s", "cores": len(outs), "kind": "port",
-            "sample": f"{len(outs)} concurrent single-thread workers (the reference's distributed_cpu scheme), "
-                      f"each looping the torch.nn forward for {seconds:.0f} s; aggregate over {span:.1f} s "
-                      f"(wall incl. start-up {wall:.0f} s)"}
+    return {"value": windows / span, "unit": "windows/s", "cores": len(outs), "host_physical_cores": physical,
+            "host_logical_cpus": logical, "kind": "port",
+            "sample": f"{len(outs)} concurrent single-thread workers, one per physical core (the reference's "
+                      f"distributed_cpu scheme), each looping the torch.nn forward for {seconds:.0f} s; aggregate over "
+                      f"{span:.1f} s (wall incl. interpreter start-up {wall:.0f} s)"}
 
 
 def cpu_baseline(model_kind, seconds):
-    """The torch.nn port of the reference forward (oracle/torch_port.py) on the host cores.
+    """The torch.nn port of the reference forward (oracle/torch_port.py) in ONE process on intra-op threads.
 
-    ATen's small-GEMM RNN path collapses when oversubscribed (all 256 hyper-threads of the GPU
-    box: >20 s per batch), so a short sweep picks the best thread count first; the reported
-    `cores` is the thread count actually used for the timed sample.  Total CPU time is bounded.
+    ATen's small-GEMM RNN path collapses when oversubscribed (all hyper-threads of the GPU box: >20 s per batch),
+    so a short sweep up to the physical core count picks the best thread count first; the reported `cores` is the
+    thread count actually used for the timed sample.  Total CPU time is bounded.
     """
-    ncpu = os.cpu_count() or 1
+    physical, logical = host_cores()
     run, units, sample = _cpu_runner(model_kind)
-    unit = "windows/s"
     deadline = time.perf_counter() + 3.0 * seconds      # hard bound on the whole leg
     best_t, best_rate = None, 0.0
     with torch.no_grad():
-        for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        for nt in sorted({min(physical, c) for c in (8, 16, 32, 64, physical)}):
             if time.perf_counter() > deadline - seconds:
                 break
             torch.set_num_threads(nt)
@@ -168,8 +231,41 @@ def cpu_baseline(model_kind, seconds):
             run()
             n += 1
         dt = time.perf_counter() - t0
-    return {"value": units * n / dt, "unit": unit, "cores": best_t, "host_logical_cpus": ncpu,
-            "kind": "port", "sample": f"{n} x ({sample}), {best_t} threads (best of sweep), {dt:.1f} s"}
+    return {"value": units * n / dt, "unit": "windows/s", "cores": best_t, "host_physical_cores": physical,
+            "host_logical_cpus": logical, "kind": "port",
+            "sample": f"{n} x ({sample}), {best_t} threads (best of a sweep up to {physical}), {dt:.1f} s"}
+
+
+# HBM bytes one launch has to move per unit (window / chunk-window) if every operand is touched once: what `traffic` is
+# compared with.  h2 layer outputs are 4 B per element like f32.  Weights (3-35 MB per launch, L2 / MALL resident) are
+# not counted.
+ALGORITHMIC_BYTES_PER_UNIT = {
+    "lstm_rec_h2_fused_in": 33 * 26 + 33 * 512 * 4,            # int8 summary in, encoder output (h2) out
+    "lstm_dec_h2_fused": 2 * 33 * 512 * 4,                     # encoder output in, decoder output out
+    "gemm_h2_linear_1": 33 * 512 * 4 + 512 * 4,                # flattened decoder output in, [512] out
+    "mlp_tail_h2": 512 * 4 + 12,
+    "gru_rec_h2_fused_in": 100 * 10 + 100 * 256 * 4,           # per chunk and window launch
+    "gru_dec_h2_fused": 2 * 100 * 256 * 4,
+    "gru_dec_h2_fused_dense": 100 * 256 * 4 + 100 * 5 * 4 * 2, # encoder output in, accumulator read-modify-write
+    "dense_softmax_acc": 100 * 256 * 4 + 100 * 5 * 4 * 2,
+}
+
+
+def measured_traffic(model_kind, label):
+    """HBM bytes per launch of `label` from the committed PMC passes (profiles/r02_<model>_pmc.json, written by
+    tools/pmc_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this file with --resident-only):
+    FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16-byte-per-lane streaming reads, WRITE_SIZE as
+    reported.  None where no pass is on file."""
+    path = os.path.join(REPO, "profiles", f"r02_{model_kind}_pmc.json")
+    try:
+        with open(path) as fh:
+            table = json.load(fh)
+        k = table["kernels"][label]
+        return {"bytes_per_launch": k["fetch_bytes_corrected"] + k["write_bytes"], "fetch_bytes_corrected": k["fetch_bytes_corrected"],
+                "write_bytes": k["write_bytes"], "units_per_launch": k.get("units_per_launch"),
+                "source": os.path.relpath(path, REPO)}
+    except Exception:
+        return None
 
 
 def realign_bench(args):
@@ -263,6 +359,16 @@ def realign_bench(args):
         "speedup_vs_cpu_baseline": (n * args.steps / dt) / (done / cpu_dt)}))
 
 
+def timed_loop(fn, count, sync):
+    """count calls of fn between two synchronisations -> seconds."""
+    sync()
+    t0 = time.perf_counter()
+    for k in range(count):
+        fn(k)
+    sync()
+    return time.perf_counter() - t0
+
+
 def main():
     args = parse()
     if args.cpu_worker:
@@ -272,87 +378,145 @@ def main():
         torch.cuda.set_device(0)
         realign_bench(args)
         return
-    world, rank, local = dist_setup(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
+    world, rank, device, ranks_seen = dist_setup(args)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", device)
     lib = _lib.load()
     import ctypes
     stream = torch.cuda.Stream(device=dev)
+    variant = args.model == "variant"
 
-    if args.model == "variant":
-        per = args.per_gpu or 16384
+    if variant:
+        chunk = 16384                                   # windows per device pass
+        per = args.per_gpu or (chunk if args.resident_only else 1 << 18)
+        pool_n = max(per, args.pool or (per if args.resident_only else 1 << 20))
         sd = broadcast_state_dict(lambda: synthetic.variant_state_dict(seed=0),
                                   synthetic.variant_param_shapes(), world, rank, dev)
-        cfg = _lib.VariantConfig(26, 33, 1, 3, local, per)
+        cfg = _lib.VariantConfig(26, 33, 1, 3, device, chunk)
         names, data, numel, n, keep = _lib.marshal_state_dict(sd)
         handle = ctypes.c_void_p()
         _lib.check(lib.pa_variant_create(ctypes.byref(cfg), names, data, numel, n,
                                          ctypes.c_void_p(stream.cuda_stream), ctypes.byref(handle)))
-        x = torch.from_numpy(synthetic.variant_windows(per, seed=synthetic.VSYN_SEED + rank)).to(dev)
-        out = torch.empty((per, 3), dtype=torch.float32, device=dev)
-
-        def step():
-            _lib.check(lib.pa_variant_forward_device(handle, x.data_ptr(), per, out.data_ptr(), None))
+        pool_dev = synthetic.variant_windows_device(pool_n, seed=synthetic.VSYN_SEED + rank, device=dev)
+        unit_shape, out_shapes, out_dtype = (33, 26), [(3,)], torch.float32
         windows_per_unit, flop_per_window = 1, VARIANT_FLOP_PER_WINDOW
+        bytes_per_unit = VARIANT_BYTES_PER_WINDOW
         workload = ("V-syn: int8 [N,33,26] candidate windows, variant bi-LSTM(26->256)x2 + MLP head, "
                     "F=26 H=256 L=1 (BASELINE configs[1] shapes)")
+
+        def host_call(x_ptr, count, outs):
+            _lib.check(lib.pa_variant_forward_host(handle, x_ptr, count, outs[0].data_ptr(), None))
+
+        def device_call(x_ptr, count, outs):
+            _lib.check(lib.pa_variant_forward_device(handle, x_ptr, count, outs[0].data_ptr(), None))
     else:
-        per = args.per_gpu or 16384
         feat = 100 if args.model == "ns-literal" else 10
+        chunk = 16384                                   # chunks per device pass (128 rows per workgroup x 2 directions = 256 workgroups)
+        per = args.per_gpu or (chunk if args.resident_only else 32768)
+        pool_n = max(per, args.pool or (per if (args.resident_only or feat != 10) else 65536))
         sd = broadcast_state_dict(lambda: synthetic.polish_state_dict(seed=0, image_features=feat),
                                   synthetic.polish_param_shapes(image_features=feat), world, rank, dev)
-        cfg = _lib.PolishConfig(feat, 128, 1, 5, 1000, 100, 50, 50, local, per)
+        cfg = _lib.PolishConfig(feat, 128, 1, 5, 1000, 100, 50, 50, device, chunk)
         names, data, numel, n, keep = _lib.marshal_state_dict(sd)
         handle = ctypes.c_void_p()
         _lib.check(lib.pa_polish_create(ctypes.byref(cfg), names, data, numel, n,
                                         ctypes.c_void_p(stream.cuda_stream), ctypes.byref(handle)))
         if feat == 10:
-            x = torch.from_numpy(synthetic.polish_chunks(per, seed=synthetic.PSYN_SEED + rank)).to(dev)
+            pool_dev = synthetic.polish_chunks_device(pool_n, seed=synthetic.PSYN_SEED + rank, device=dev)
         else:   # rows of small counts spread over 100 columns, generated on the device (1.6 GB per 16384 chunks)
             gen = torch.Generator(device=dev).manual_seed(synthetic.PSYN_SEED + rank)
-            x = torch.poisson(torch.full((per, 1000, feat), 2.5, device=dev), generator=gen).clamp_(0, 254).to(torch.uint8)
-        lab = torch.empty((per, 1000), dtype=torch.uint8, device=dev)
-        ph = torch.empty((per, 1000), dtype=torch.uint8, device=dev)
-
-        def step():
-            _lib.check(lib.pa_polish_predict_device(handle, x.data_ptr(), per, lab.data_ptr(),
-                                                    ph.data_ptr(), None))
+            pool_dev = torch.poisson(torch.full((pool_n, 1000, feat), 2.5, device=dev), generator=gen).clamp_(0, 254).to(torch.uint8)
+        unit_shape, out_shapes, out_dtype = (1000, feat), [(1000,), (1000,)], torch.uint8
         windows_per_unit = POLISH_WINDOWS_PER_CHUNK
         flop_per_window = POLISH_FLOP_PER_WINDOW + 2.0 * 100 * 2 * 384 * (feat - 10)
+        bytes_per_unit = 1000 * feat + 2000
         workload = ("P-syn: uint8 [N,1000,10] chunks, polish bi-GRU(10->128)x2 + dense, 19 windows of "
                     "100 steps with hidden carry (BASELINE configs[4] shapes)") if feat == 10 else (
                     "NS-literal: uint8 [N,1000,100] chunks = 19 windows of 100 steps x 100 features through the polish "
                     "bi-GRU(100->128)x2 + dense with hidden carry; the north_star's literal synthetic shape, not a "
                     "reference shape (SURVEY.md section 0), no CPU baseline")
 
+        def host_call(x_ptr, count, outs):
+            _lib.check(lib.pa_polish_predict_host(handle, x_ptr, count, outs[0].data_ptr(), outs[1].data_ptr(), None))
+
+        def device_call(x_ptr, count, outs):
+            _lib.check(lib.pa_polish_predict_device(handle, x_ptr, count, outs[0].data_ptr(), outs[1].data_ptr(), None))
+
+    unit_bytes = int(np.prod(unit_shape))
+    torch.cuda.synchronize(dev)
+    if args.resident_only:
+        pool, outs = pool_dev, [torch.empty((per,) + sh, dtype=out_dtype, device=dev) for sh in out_shapes]
+        call = device_call
+    else:
+        # the boundary's host side: a page-locked pool of summaries (what the HDF5 reader fills) and page-locked results
+        pool = torch.empty((pool_n,) + unit_shape, dtype=pool_dev.dtype, pin_memory=True)
+        pool.copy_(pool_dev)
+        outs = [torch.empty((per,) + sh, dtype=out_dtype, pin_memory=True) for sh in out_shapes]
+        call = host_call
+    slots = max(1, pool_n // per)
+
+    def step(k):
+        call(pool.data_ptr() + (k % slots) * per * unit_bytes, per, outs)
+
+    def sync():
+        _lib.check(lib.pa_synchronize(handle))
+        torch.cuda.synchronize(dev)
+
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
-    torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        step()
-    _lib.check(lib.pa_synchronize(handle))
+    for k in range(args.warmup):
+        step(k)
+    sync()
     _lib.check(lib.pa_profile_enable(handle, 1))
     barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    _lib.check(lib.pa_synchronize(handle))
-    torch.cuda.synchronize(dev)
+    for k in range(args.steps):
+        step(args.warmup + k)
+    sync()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        on_gpu = dist.get_backend() == "nccl"
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if on_gpu else None)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     prof = _lib.profile_dict(handle)
     _lib.check(lib.pa_profile_enable(handle, 0))
+
+    extras = {}
+    if rank == 0 and not args.no_extras and not args.resident_only:
+        # (a) the same kernels on inputs already in HBM (round 1's figure): one device pass of `chunk` units, repeated
+        xr = pool_dev[:chunk].contiguous()
+        outs_d = [torch.empty((chunk,) + sh, dtype=out_dtype, device=dev) for sh in out_shapes]
+        reps = max(10, min(60, int(0.5 * per * args.steps / chunk)))
+        device_call(xr.data_ptr(), chunk, outs_d)
+        t = timed_loop(lambda k: device_call(xr.data_ptr(), chunk, outs_d), reps, sync)
+        extras["device_resident"] = {"value": reps * chunk * windows_per_unit / t, "unit": "windows/s",
+                                     "units_per_pass": chunk, "passes": reps, "ms_per_pass": t / reps * 1e3,
+                                     "note": "inputs and outputs in HBM, no copies (round 1's headline definition)"}
+        # (b) the reference's default batch through one call (BASELINE configs[1]: batch = 512 windows; polish: 128 chunks)
+        b = 512 if variant else 128
+        outs_b = [torch.empty((b,) + sh, dtype=out_dtype, pin_memory=True) for sh in out_shapes]
+        host_call(pool.data_ptr(), b, outs_b)
+        nb = 200 if variant else 50
+        th = timed_loop(lambda k: (host_call(pool.data_ptr() + (k % 64) * b * unit_bytes, b, outs_b)), nb, sync)
+        outs_bd = [torch.empty((b,) + sh, dtype=out_dtype, device=dev) for sh in out_shapes]
+        td = timed_loop(lambda k: device_call(pool_dev.data_ptr() + (k % 64) * b * unit_bytes, b, outs_bd), nb, sync)
+        extras["batch512" if variant else "batch128"] = {
+            "units_per_call": b,
+            "host_buffers": {"value": nb * b * windows_per_unit / th, "unit": "windows/s", "ms_per_call": th / nb * 1e3,
+                             "note": "one synchronous call per batch: H2D, forward, D2H, as predict_distributed_gpu.py:58-67 loops"},
+            "device_resident": {"value": nb * b * windows_per_unit / td, "unit": "windows/s", "ms_per_call": td / nb * 1e3,
+                                "note": "calls queued back to back on one stream, inputs in HBM"}}
 
     if rank == 0:
         windows = world * args.steps * per * windows_per_unit
@@ -369,6 +533,8 @@ def main():
         dom = max(prof, key=lambda k: prof[k]["ms"])
         d = prof[dom]
         ach = (d["flops"] / d["launches"]) / (d["ms"] / d["launches"] * 1e-3) / 1e12
+        h2 = "_h2" in dom
+        traffic = measured_traffic(args.model, dom)
         line = {
             "metric": "inference windows/sec (whole node)",
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
@@ -376,21 +542,42 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if not any("_h2" in k for k in prof) else "f32 via f16 hi/lo split operands (3 MFMAs per product), f32 accumulate",
             "data": "synthetic",
-            "config": {"workload": workload, "per_gpu_per_step": per,
-                       "units": "windows" if args.model == "variant" else "chunks (x19 windows)",
-                       "reference_hdf5_batch": 512 if args.model == "variant" else 128,
+            "config": {"workload": workload, "per_gpu_per_step": per, "distinct_units_per_gpu": pool_n,
+                       "units": "windows" if variant else "chunks (x19 windows)",
+                       "device_pass": chunk, "h2d_d2h": "excluded (--resident-only)" if args.resident_only else "included",
+                       "host_path": None if args.resident_only else
+                       "page-locked host pool -> H2D -> forward -> D2H (pa_*_host), copies of neighbouring device passes "
+                       "overlapped with the kernels on separate HIP streams",
+                       "timed_seconds": dt,
+                       "reference_hdf5_batch": 512 if variant else 128,
                        "weights": "seeded random init (pepper_amd.synthetic), fp32",
-                       "parallelism": f"region-shard x{world}, RCCL weight broadcast only"},
+                       "parallelism": f"region-shard x{world}, one weight broadcast, no data-path collective",
+                       "ranks_seen": ranks_seen},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": kernel_peak(dom),
-                         "unit": "TFLOP/s", "frac": ach / kernel_peak(dom), "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / kernel_peak(dom),
+                         "traffic": traffic["bytes_per_launch"] if traffic else None,
+                         "traffic_detail": traffic,
+                         "algorithmic_bytes_per_launch": (ALGORITHMIC_BYTES_PER_UNIT[dom] * min(per, chunk)
+                                                          if dom in ALGORITHMIC_BYTES_PER_UNIT else None),
+                         "issued_tflops": ach * (3 if h2 else 1),
+                         "frac_of_dense_peak_issued": ach * (3 if h2 else 1) / (F16_MFMA_PEAK_TFLOPS if h2 else F32_MFMA_PEAK_TFLOPS),
                          "arithmetic": ("3 x v_mfma_f32_32x32x16_f16 per product (f16 hi/lo split operands, f32 "
-                                        "accumulate); peak = 2.5 PFLOP/s dense f16 / 3") if "_h2" in dom
+                                        "accumulate); peak = 2.5 PFLOP/s dense f16 / 3; `achieved` counts algorithmic "
+                                        "(f32-equivalent) FLOP, `issued_tflops` the machine MFMAs") if h2
                          else "v_mfma_f32_32x32x2_f32"},
             "end_to_end_tflops": value * flop_per_window / 1e12,
+            "hbm_view": {"algorithmic_bytes_per_unit": bytes_per_unit,
+                         "achieved_GBps": value / windows_per_unit * bytes_per_unit / 1e9, "peak_GBps": 8000.0,
+                         "note": "the path is matrix-bound (arithmetic intensity ~1e5 FLOP/B): shown only because north_star asks for it"},
             "kernels": kern,
         }
+        if os.environ.get("PEPPER_AMD_BENCH_SHARE_GPU") == "1" and world > torch.cuda.device_count():
+            line["shared_gpu_plumbing_check"] = True
+        line.update(extras)
+        if "device_resident" in extras:
+            line["host_path_over_device_resident"] = value / extras["device_resident"]["value"]
         if world == 1 and not args.no_cpu_baseline and args.model != "ns-literal":
-            # whole-box CPU number = the reference's own scheme (many single-thread workers); the
+            # whole-box CPU number = the reference's own scheme (single-thread workers, one per physical core); the
             # single-process multi-thread figure is kept beside it
             single = cpu_baseline(args.model, args.cpu_seconds)
             multi = cpu_baseline_workers(args.model, args.cpu_seconds)
@@ -399,7 +586,7 @@ def main():
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))
 
-    if args.model == "variant":
+    if variant:
         lib.pa_variant_destroy(handle)
     else:
         lib.pa_polish_destroy(handle)

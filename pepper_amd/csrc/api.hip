@@ -116,11 +116,46 @@ struct ModelBase {
             b->release();
             delete b;
         }
+        pipe_destroy();
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
     DevBuf* new_buf() {
         owned.push_back(new DevBuf());
         return owned.back();
+    }
+
+    // Host-buffer entry points (pa_*_host): device passes of max_chunk units with the H2D copy of pass i+1 and the D2H
+    // copy of pass i-1 on their own streams beside the kernels of pass i (two staging slots each way).  With page-locked
+    // host buffers nothing blocks the host until the final synchronise; pageable buffers work too (HIP stages them).
+    struct HostPipe {
+        hipStream_t h2d = nullptr, d2h = nullptr;
+        hipEvent_t in_ready[2]{}, in_free[2]{}, out_ready[2]{}, out_free[2]{};
+        bool ready = false;
+    } pipe;
+    int pipe_init() {
+        if (pipe.ready) return PA_OK;
+        HIP_TRY(hipStreamCreateWithFlags(&pipe.h2d, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&pipe.d2h, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipEventCreateWithFlags(&pipe.in_ready[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&pipe.in_free[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&pipe.out_ready[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&pipe.out_free[k], hipEventDisableTiming));
+        }
+        pipe.ready = true;
+        return PA_OK;
+    }
+    void pipe_destroy() {
+        if (!pipe.ready) return;
+        for (int k = 0; k < 2; ++k) {
+            (void)hipEventDestroy(pipe.in_ready[k]);
+            (void)hipEventDestroy(pipe.in_free[k]);
+            (void)hipEventDestroy(pipe.out_ready[k]);
+            (void)hipEventDestroy(pipe.out_free[k]);
+        }
+        (void)hipStreamDestroy(pipe.h2d);
+        (void)hipStreamDestroy(pipe.d2h);
+        pipe.ready = false;
     }
 };
 
@@ -417,7 +452,7 @@ struct pa_variant_model : ModelBase {
     std::vector<RecLayer> rec;   // encoder layers then decoder layers
     Linear lin[5], out;
     DevBuf *mlp_w = nullptr, *mlp_b = nullptr;   // linear_2..5 as h2 fragments + their biases (mlp_h2.hip)
-    DevBuf *xp, *ya, *yb, *l1, *l2, *stage_in, *stage_p, *stage_l;
+    DevBuf *xp, *ya, *yb, *l1, *l2, *stage_in[2], *stage_p[2], *stage_l[2];
 };
 
 extern "C" {
@@ -487,7 +522,9 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     }
     m->xp = m->new_buf(); m->ya = m->new_buf(); m->yb = m->new_buf();
     m->l1 = m->new_buf(); m->l2 = m->new_buf();
-    m->stage_in = m->new_buf(); m->stage_p = m->new_buf(); m->stage_l = m->new_buf();
+    for (int k = 0; k < 2; ++k) {
+        m->stage_in[k] = m->new_buf(); m->stage_p[k] = m->new_buf(); m->stage_l[k] = m->new_buf();
+    }
     *out = m;
     return PA_OK;
 }
@@ -651,19 +688,36 @@ int pa_variant_forward_host(pa_variant_model* m, const int8_t* images, int64_t n
     if (n < 0 || (n > 0 && (!images || !probs))) return fail(PA_ERR_INVALID, "null buffer");
     if (n == 0) return PA_OK;
     HIP_TRY(hipSetDevice(m->device));
+    if (int rc = m->pipe_init()) return rc;
     const size_t per = (size_t)m->cfg.window * m->cfg.image_features;
     const int C = m->cfg.num_classes_type;
-    if (int rc = m->stage_in->ensure((size_t)n * per)) return rc;
-    if (int rc = m->stage_p->ensure((size_t)n * C * sizeof(float))) return rc;
-    if (logits)
-        if (int rc = m->stage_l->ensure((size_t)n * C * sizeof(float))) return rc;
-    HIP_TRY(hipMemcpyAsync(m->stage_in->p, images, (size_t)n * per, hipMemcpyHostToDevice, m->stream));
-    if (int rc = variant_forward(m, pa::A_I8, m->stage_in->p, 1, n, m->stage_p->f(),
-                                 logits ? m->stage_l->f() : nullptr))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(probs, m->stage_p->p, (size_t)n * C * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-    if (logits)
-        HIP_TRY(hipMemcpyAsync(logits, m->stage_l->p, (size_t)n * C * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    const int64_t chunk = m->cfg.max_chunk;
+    auto& pp = m->pipe;
+    int64_t i = 0;
+    for (int64_t off = 0; off < n; off += chunk, ++i) {
+        const int64_t c = std::min<int64_t>(chunk, n - off);
+        const int k = (int)(i & 1);
+        if (int rc = m->stage_in[k]->ensure((size_t)std::min<int64_t>(chunk, n) * per)) return rc;
+        if (int rc = m->stage_p[k]->ensure((size_t)std::min<int64_t>(chunk, n) * C * sizeof(float))) return rc;
+        if (logits)
+            if (int rc = m->stage_l[k]->ensure((size_t)std::min<int64_t>(chunk, n) * C * sizeof(float))) return rc;
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(pp.h2d, pp.in_free[k], 0));      // pass i-2 has consumed this slot
+        HIP_TRY(hipMemcpyAsync(m->stage_in[k]->p, images + (size_t)off * per, (size_t)c * per, hipMemcpyHostToDevice, pp.h2d));
+        HIP_TRY(hipEventRecord(pp.in_ready[k], pp.h2d));
+        HIP_TRY(hipStreamWaitEvent(m->stream, pp.in_ready[k], 0));
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->stream, pp.out_free[k], 0));  // results of pass i-2 have left the slot
+        if (int rc = variant_forward_chunk(m, pa::A_I8, m->stage_in[k]->p, c, m->stage_p[k]->f(),
+                                           logits ? m->stage_l[k]->f() : nullptr))
+            return rc;
+        HIP_TRY(hipEventRecord(pp.in_free[k], m->stream));
+        HIP_TRY(hipEventRecord(pp.out_ready[k], m->stream));
+        HIP_TRY(hipStreamWaitEvent(pp.d2h, pp.out_ready[k], 0));
+        HIP_TRY(hipMemcpyAsync(probs + off * C, m->stage_p[k]->p, (size_t)c * C * sizeof(float), hipMemcpyDeviceToHost, pp.d2h));
+        if (logits)
+            HIP_TRY(hipMemcpyAsync(logits + off * C, m->stage_l[k]->p, (size_t)c * C * sizeof(float), hipMemcpyDeviceToHost, pp.d2h));
+        HIP_TRY(hipEventRecord(pp.out_free[k], pp.d2h));
+    }
+    HIP_TRY(hipStreamSynchronize(pp.d2h));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return PA_OK;
 }
@@ -682,7 +736,7 @@ struct pa_polish_model : ModelBase {
     bool y_h2 = false;           // format of the last polish_window output
     std::vector<RecLayer> enc, dec;
     Linear dense;
-    DevBuf *xp, *y1, *y2, *hid_a, *hid_b, *acc, *stage_in, *stage_lab, *stage_ph, *stage_acc;
+    DevBuf *xp, *y1, *y2, *hid_a, *hid_b, *acc, *stage_in[2], *stage_lab[2], *stage_ph[2], *stage_acc[2];
 };
 
 // One module forward on n (<= padded workspace) sequences of T steps.
@@ -818,8 +872,10 @@ int pa_polish_create(const pa_polish_config* cfg, const char* const* names, cons
     }
     m->xp = m->new_buf(); m->y1 = m->new_buf(); m->y2 = m->new_buf();
     m->hid_a = m->new_buf(); m->hid_b = m->new_buf(); m->acc = m->new_buf();
-    m->stage_in = m->new_buf(); m->stage_lab = m->new_buf(); m->stage_ph = m->new_buf();
-    m->stage_acc = m->new_buf();
+    for (int k = 0; k < 2; ++k) {
+        m->stage_in[k] = m->new_buf(); m->stage_lab[k] = m->new_buf(); m->stage_ph[k] = m->new_buf();
+        m->stage_acc[k] = m->new_buf();
+    }
     *out = m;
     return PA_OK;
 }
@@ -917,21 +973,40 @@ int pa_polish_predict_host(pa_polish_model* m, const uint8_t* images, int64_t n,
     if (n < 0 || (n > 0 && (!images || !labels || !phred))) return fail(PA_ERR_INVALID, "null buffer");
     if (n == 0) return PA_OK;
     HIP_TRY(hipSetDevice(m->device));
+    if (int rc = m->pipe_init()) return rc;
     const size_t S = m->cfg.seq_length, F = m->cfg.image_features, C = m->cfg.num_classes;
-    if (int rc = m->stage_in->ensure((size_t)n * S * F)) return rc;
-    if (int rc = m->stage_lab->ensure((size_t)n * S)) return rc;
-    if (int rc = m->stage_ph->ensure((size_t)n * S)) return rc;
-    if (acc)
-        if (int rc = m->stage_acc->ensure((size_t)n * S * C * sizeof(float))) return rc;
-    HIP_TRY(hipMemcpyAsync(m->stage_in->p, images, (size_t)n * S * F, hipMemcpyHostToDevice, m->stream));
-    if (int rc = pa_polish_predict_device(m, static_cast<const uint8_t*>(m->stage_in->p), n,
-                                          static_cast<uint8_t*>(m->stage_lab->p),
-                                          static_cast<uint8_t*>(m->stage_ph->p), acc ? m->stage_acc->f() : nullptr))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(labels, m->stage_lab->p, (size_t)n * S, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(phred, m->stage_ph->p, (size_t)n * S, hipMemcpyDeviceToHost, m->stream));
-    if (acc)
-        HIP_TRY(hipMemcpyAsync(acc, m->stage_acc->p, (size_t)n * S * C * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    const int64_t chunk = m->cfg.max_chunk;
+    const size_t cap = (size_t)std::min<int64_t>(chunk, n);
+    auto& pp = m->pipe;
+    int64_t i = 0;
+    for (int64_t off = 0; off < n; off += chunk, ++i) {
+        const int64_t c = std::min<int64_t>(chunk, n - off);
+        const int k = (int)(i & 1);
+        if (int rc = m->stage_in[k]->ensure(cap * S * F)) return rc;
+        if (int rc = m->stage_lab[k]->ensure(cap * S)) return rc;
+        if (int rc = m->stage_ph[k]->ensure(cap * S)) return rc;
+        if (acc)
+            if (int rc = m->stage_acc[k]->ensure(cap * S * C * sizeof(float))) return rc;
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(pp.h2d, pp.in_free[k], 0));
+        HIP_TRY(hipMemcpyAsync(m->stage_in[k]->p, images + (size_t)off * S * F, (size_t)c * S * F, hipMemcpyHostToDevice, pp.h2d));
+        HIP_TRY(hipEventRecord(pp.in_ready[k], pp.h2d));
+        HIP_TRY(hipStreamWaitEvent(m->stream, pp.in_ready[k], 0));
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->stream, pp.out_free[k], 0));
+        if (int rc = pa_polish_predict_device(m, static_cast<const uint8_t*>(m->stage_in[k]->p), c,
+                                              static_cast<uint8_t*>(m->stage_lab[k]->p),
+                                              static_cast<uint8_t*>(m->stage_ph[k]->p), acc ? m->stage_acc[k]->f() : nullptr))
+            return rc;
+        HIP_TRY(hipEventRecord(pp.in_free[k], m->stream));
+        HIP_TRY(hipEventRecord(pp.out_ready[k], m->stream));
+        HIP_TRY(hipStreamWaitEvent(pp.d2h, pp.out_ready[k], 0));
+        HIP_TRY(hipMemcpyAsync(labels + (size_t)off * S, m->stage_lab[k]->p, (size_t)c * S, hipMemcpyDeviceToHost, pp.d2h));
+        HIP_TRY(hipMemcpyAsync(phred + (size_t)off * S, m->stage_ph[k]->p, (size_t)c * S, hipMemcpyDeviceToHost, pp.d2h));
+        if (acc)
+            HIP_TRY(hipMemcpyAsync(acc + (size_t)off * S * C, m->stage_acc[k]->p, (size_t)c * S * C * sizeof(float),
+                                   hipMemcpyDeviceToHost, pp.d2h));
+        HIP_TRY(hipEventRecord(pp.out_free[k], pp.d2h));
+    }
+    HIP_TRY(hipStreamSynchronize(pp.d2h));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return PA_OK;
 }

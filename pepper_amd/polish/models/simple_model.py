@@ -111,6 +111,17 @@ class TransducerGRU(object):
         dev = torch.device("cuda", self.device)
         if images.dtype != torch.uint8:
             raise ValueError("polish images are uint8 (pepper DataStore.py:60)")
+        if on_cpu:
+            # host buffers: device passes with the copies of the neighbouring passes beside the kernels
+            from pepper_amd.variant.models.simple_model import _pinned_empty
+            images = images.contiguous()
+            n, S = images.shape[0], images.shape[1]
+            labels = _pinned_empty((n, S), torch.uint8)
+            phred = _pinned_empty((n, S), torch.uint8)
+            acc = _pinned_empty((n, S, self.num_classes), torch.float32) if return_acc else None
+            _lib.check(lib.pa_polish_predict_host(self.handle, images.data_ptr(), n, labels.data_ptr(), phred.data_ptr(),
+                                                  acc.data_ptr() if acc is not None else None))
+            return (labels, phred) + ((acc,) if return_acc else ())
         images = images.to(dev).contiguous()
         n, S = images.shape[0], images.shape[1]
         labels = torch.empty((n, S), dtype=torch.uint8, device=dev)

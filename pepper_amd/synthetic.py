@@ -154,6 +154,66 @@ def variant_windows(n, seed=VSYN_SEED, window=VARIANT_WINDOW, features=VARIANT_F
     return x.astype(np.int8)
 
 
+def variant_windows_device(n, seed=VSYN_SEED, device="cuda", window=VARIANT_WINDOW, features=VARIANT_FEATURES):
+    """V-syn with the distribution of variant_windows(), drawn by torch's generator ON THE DEVICE (bench.py needs 2^20
+    distinct windows per GPU; the numpy recipe above takes two minutes for that on a few host cores).  Same columns,
+    same laws, different bits: fixtures and parity tests keep using the numpy recipe.  -> int8 tensor [n, 33, 26]."""
+    import torch
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+    out = torch.empty((n, window, features), dtype=torch.int8, device=dev)
+    base_cols = torch.tensor(list(range(8, 15)) + list(range(19, 26)), device=dev)
+    mid = window // 2
+    for a in range(0, n, 65536):
+        m = min(65536, n - a)
+        x = torch.zeros((m, window, features), dtype=torch.int16, device=dev)
+        x[:, :, 0] = torch.randint(1, 6, (m, window), generator=g, device=dev, dtype=torch.int16)
+        for col in (4, 15):
+            x[:, :, col] = -torch.poisson(torch.full((m, window), 30.0, device=dev), generator=g).clamp_(0, 125).to(torch.int16)
+        sparse = torch.rand((m, window, 14), generator=g, device=dev) < 0.10
+        vals = -torch.poisson(torch.full((m, window, 14), 3.0, device=dev), generator=g).clamp_(0, 125).to(torch.int16)
+        x[:, :, base_cols] = torch.where(sparse, vals, torch.zeros_like(vals))
+        kind = torch.randint(0, 3, (m,), generator=g, device=dev)
+        alt = torch.randint(1, 5, (m,), generator=g, device=dev)
+        length = torch.empty(m, device=dev).geometric_(0.4, generator=g).clamp_(1, 60).to(torch.int16)
+        fwd = torch.poisson(torch.full((m,), 6.0, device=dev), generator=g).clamp_(0, 125).to(torch.int16)
+        rev = torch.poisson(torch.full((m,), 6.0, device=dev), generator=g).clamp_(0, 125).to(torch.int16)
+        for k, (c_len, c_f, c_r, b_f, b_r) in enumerate(((1, 5, 16, None, None), (2, 6, 17, 12, 23), (3, 7, 18, 13, 24))):
+            rows = torch.nonzero(kind == k).squeeze(1)
+            x[rows, mid, c_len] = alt[rows].to(torch.int16) if k == 0 else length[rows]
+            x[rows, mid, c_f] = fwd[rows]
+            x[rows, mid, c_r] = rev[rows]
+            if k == 0:
+                x[rows, mid, 7 + alt[rows]] = fwd[rows]
+                x[rows, mid, 18 + alt[rows]] = rev[rows]
+            else:
+                x[rows, mid, b_f] = fwd[rows]
+                x[rows, mid, b_r] = rev[rows]
+        out[a:a + m] = x.to(torch.int8)
+    return out
+
+
+def polish_chunks_device(n, seed=PSYN_SEED, device="cuda", seq=POLISH_SEQ, features=POLISH_FEATURES):
+    """P-syn with the distribution of polish_chunks(), drawn on the device.  -> uint8 tensor [n, 1000, 10]."""
+    import torch
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+    alpha = torch.tensor([4, 1, 1, 1, 4, 1, 1, 1, 0.3, 0.3], device=dev) * 0.25
+    out = torch.empty((n, seq, features), dtype=torch.uint8, device=dev)
+    for a in range(0, n, 8192):
+        m = min(8192, n - a)
+        # a Dirichlet draw = normalised Gamma(alpha, 1) draws
+        gam = torch._standard_gamma(alpha.expand(m, seq, features).contiguous(), generator=g)
+        frac = gam / gam.sum(-1, keepdim=True).clamp_min(1e-30)
+        img = torch.floor(frac * 254.0).to(torch.uint8)
+        padded = torch.rand(m, generator=g, device=dev) < 0.02
+        tail = torch.randint(1, seq // 2, (m,), generator=g, device=dev)
+        pos = torch.arange(seq, device=dev).unsqueeze(0)
+        img[(padded.unsqueeze(1) & (pos >= (seq - tail).unsqueeze(1)))] = 0
+        out[a:a + m] = img
+    return out
+
+
 def polish_chunks(n, seed=PSYN_SEED, seq=POLISH_SEQ, features=POLISH_FEATURES):
     """P-syn: uint8 [n, 1000, 10] chunks; each row a composition summing to <= 254.
 

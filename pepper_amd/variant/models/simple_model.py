@@ -13,6 +13,15 @@ from pepper_amd import _lib
 from pepper_amd.variant.Options import ImageSizeOptions
 
 
+def _pinned_empty(shape, dtype):
+    """Page-locked result buffer (the D2H copies of the host entry points are asynchronous only into pinned memory);
+    falls back to pageable memory where pinning is refused."""
+    try:
+        return torch.empty(shape, dtype=dtype, pin_memory=True)
+    except RuntimeError:
+        return torch.empty(shape, dtype=dtype)
+
+
 class TransducerGRU(object):
     def __init__(self, image_features, gru_layers, hidden_size, num_classes, num_classes_type,
                  bidirectional=True, device=None, max_chunk=0):
@@ -83,6 +92,16 @@ class TransducerGRU(object):
             raise ValueError(f"expected [B,{self.window},{self.image_features}], got {tuple(x.shape)}")
         on_cpu = not x.is_cuda
         dev = torch.device("cuda", self.device)
+        if on_cpu and x.dtype == torch.int8:
+            # host buffers (what the predict loop hands over: a file's packed int8 windows, page-locked): device passes
+            # with the H2D copy of the next pass and the D2H copy of the previous one beside the kernels
+            x = x.contiguous()
+            n = x.shape[0]
+            probs = _pinned_empty((n, self.num_classes_type), torch.float32)
+            logits = _pinned_empty((n, self.num_classes_type), torch.float32) if train_mode else None
+            _lib.check(lib.pa_variant_forward_host(self.handle, x.data_ptr(), n, probs.data_ptr(),
+                                                   logits.data_ptr() if logits is not None else None))
+            return logits if train_mode else probs
         if x.dtype not in (torch.int8, torch.float32):
             x = x.to(torch.float32)
         x = x.to(dev).contiguous()
