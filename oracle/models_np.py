@@ -179,3 +179,40 @@ def polish_predict_chunks(sd, images, hidden_size, window=100, jump=50, overlap=
     if return_intermediates:
         return out + ({"acc": acc, "hiddens": np.stack(hiddens, 0), "phred_f32": phred},)
     return out
+
+
+# ---- float64 restatement of the variant forward ------------------------------------------------------------------
+# For stress families of weights (mixed row scales, heavy tails, values near the f16 limit) the float32 restatement
+# above is itself a few 1e-6 away from exact arithmetic; tests that judge an arithmetic scheme on such weights compare
+# against this float64 form of the same equations (same citations as variant_forward).
+def variant_forward_f64(sd, images, gru_layers=1):
+    f8 = np.float64
+    sig = lambda v: 1.0 / (1.0 + np.exp(-np.clip(v, -700.0, 700.0)))   # noqa: E731
+
+    def direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
+        B, T, _ = x.shape
+        H = w_hh.shape[1]
+        h, c = np.zeros((B, H), f8), np.zeros((B, H), f8)
+        y = np.zeros((B, T, H), f8)
+        xp = x @ w_ih.astype(f8).T + (b_ih.astype(f8) + b_hh.astype(f8))
+        whh = w_hh.astype(f8).T
+        for t in (range(T - 1, -1, -1) if reverse else range(T)):
+            g = xp[:, t] + h @ whh
+            c = sig(g[:, H:2 * H]) * c + sig(g[:, :H]) * np.tanh(g[:, 2 * H:3 * H])
+            h = sig(g[:, 3 * H:]) * np.tanh(c)
+            y[:, t] = h
+        return y
+
+    x = np.asarray(images).astype(f8)
+    for prefix in ("encoder", "decoder"):
+        for layer in range(gru_layers):
+            x = np.concatenate([direction(x, sd[f"{prefix}.weight_ih_l{layer}{s}"], sd[f"{prefix}.weight_hh_l{layer}{s}"],
+                                          sd[f"{prefix}.bias_ih_l{layer}{s}"], sd[f"{prefix}.bias_hh_l{layer}{s}"], rev)
+                                for s, rev in (("", False), ("_reverse", True))], axis=2)
+    a = x.reshape(x.shape[0], -1)
+    for name in ("linear_1", "linear_2", "linear_3", "linear_4", "linear_5"):
+        v = a @ sd[f"{name}.weight"].astype(f8).T + sd[f"{name}.bias"].astype(f8)
+        a = float(SELU_SCALE) * np.where(v > 0, v, float(SELU_ALPHA) * np.expm1(np.minimum(v, 0.0)))
+    logits = a @ sd["output_layer_type.weight"].astype(f8).T + sd["output_layer_type.bias"].astype(f8)
+    e = np.exp(logits - logits.max(axis=1, keepdims=True))
+    return e / e.sum(axis=1, keepdims=True), logits

@@ -210,6 +210,28 @@ struct StateDict {
     }
 };
 
+// Largest |w| over the 2-D tensors of a state_dict (names containing "weight").
+// The split-f16 operand format carries an ACTIVATION to 22 bits relative but with an absolute floor of 2^-25 (both halves
+// are f16 numbers; below 6e-5 they are sub-normal): a product a * w therefore carries an absolute error of up to
+// |w| * 3e-8 whatever the size of a.  With |w| of order 1 that is far below the f32 accumulation noise; a checkpoint
+// with entries in the hundreds would turn it into 1e-5 .. 1e-4 of pre-activation error on unsaturated gates (numpy
+// emulation in tests/weight_families.py: 4e-6 relative logit error at |w| = 100, 6e-5 at 500, 4e-3 at 2000).  Models
+// whose largest weight reaches kSplitMaxWeight therefore run on the exact-f32 matrix instructions (the
+// PA_SPLIT_GEMM=0 kernels): slower, same results as the f32 oracle for any weights.
+constexpr float kSplitMaxWeight = 64.0f;
+float state_dict_max_abs_weight(const StateDict& sd) {
+    float m = 0.0f;
+    for (const auto& kv : sd.t) {
+        if (kv.first.find("weight") == std::string::npos || !kv.second.first) continue;
+        const float* p = kv.second.first;
+        for (int64_t i = 0; i < kv.second.second; ++i) {
+            const float a = std::fabs(p[i]);
+            if (!(a <= m)) m = a;      // NaN ends up in m as well
+        }
+    }
+    return m;
+}
+
 int upload(DevBuf* b, const std::vector<float>& host) {
     if (int rc = b->ensure(host.size() * sizeof(float))) return rc;
     HIP_TRY(hipMemcpy(b->p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -281,7 +303,7 @@ struct RecLayer {
 // prescale (LSTM + split recurrences only): every copy of the weights that feeds rnn_h2.hip is multiplied
 // per gate row by -log2(e) (i, f, o) or +2 log2(e) (g) so the kernel's accumulators are exp2 arguments.
 int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix, int layer, int G,
-                    int H, int K, RecLayer& out, bool prescale = false) {
+                    int H, int K, RecLayer& out, bool prescale = false, bool want_h2 = true) {
     const char* sfx[2] = {"", "_reverse"};
     const float *wih[2], *whh[2], *bih[2], *bhh[2];
     std::string err;
@@ -340,7 +362,7 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
     if (int rc = upload(out.w_ih, w)) return rc;
     if (int rc = upload(out.b_in, b)) return rc;
     if (int rc = upload(out.w_hh, packed)) return rc;
-    if (K % 32 == 0) {
+    if (want_h2 && K % 32 == 0) {
         out.w_ih_h2 = m->new_buf();
         if (int rc = upload_h2(out.w_ih_h2, ws.data(), (int64_t)2 * G * H, K)) return rc;
     }
@@ -348,7 +370,7 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
         out.b_hn = m->new_buf();
         if (int rc = upload(out.b_hn, bn)) return rc;
     }
-    if ((G == 4 && H == 256) || (G == 3 && H == 128)) {
+    if (want_h2 && ((G == 4 && H == 256) || (G == 3 && H == 128))) {
         const int KXh2 = G == 4 ? 32 : std::max(16, pa::gru_fused_input_kx(H, K));
         auto pack_upload = [&](DevBuf*& dst, const float* const wx[2], int KX) -> int {
             for (int d = 0; d < 2; ++d) {
@@ -479,20 +501,23 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     if (const char* e = getenv("PA_FUSE_INPUT")) m->fuse_input = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_GEMM")) m->split_gemm = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_REC")) m->split_rec = e[0] != '0';
+    StateDict sd(names, data, numel, n_tensors);
+    if (!(state_dict_max_abs_weight(sd) < kSplitMaxWeight)) m->split_gemm = false;   // see kSplitMaxWeight
     m->split_rec = m->split_rec && m->split_gemm;   // the h2 layer output needs the h2 consumers
     if (const char* e = getenv("PA_FUSE_DEC")) m->fuse_dec = e[0] != '0';
     int rc = init_base(m, cfg->device, hip_stream);
-    StateDict sd(names, data, numel, n_tensors);
     const int H = m->H;
     for (int mod = 0; mod < 2 && rc == PA_OK; ++mod)
         for (int layer = 0; layer < cfg->gru_layers && rc == PA_OK; ++layer) {
             const int K = (mod == 0 && layer == 0) ? cfg->image_features : 2 * H;
             m->rec.emplace_back();
-            rc = build_rec_layer(m, sd, mod == 0 ? "encoder" : "decoder", layer, 4, H, K, m->rec.back(), m->split_rec);
+            rc = build_rec_layer(m, sd, mod == 0 ? "encoder" : "decoder", layer, 4, H, K, m->rec.back(), m->split_rec,
+                                 m->split_gemm);
         }
     const char* lin_names[5] = {"linear_1", "linear_2", "linear_3", "linear_4", "linear_5"};
     for (int i = 0; i < 5 && rc == PA_OK; ++i)
-        rc = build_linear(m, sd, lin_names[i], i == 0 ? 2 * H * cfg->window : m->L1, m->L1, m->lin[i], i == 0);
+        rc = build_linear(m, sd, lin_names[i], i == 0 ? 2 * H * cfg->window : m->L1, m->L1, m->lin[i],
+                          i == 0 && m->split_gemm);
     if (rc == PA_OK) rc = build_linear(m, sd, "output_layer_type", m->L1, cfg->num_classes_type, m->out);
     if (rc == PA_OK && m->split_gemm && m->L1 == 512) {
         std::string err;
@@ -853,17 +878,19 @@ int pa_polish_create(const pa_polish_config* cfg, const char* const* names, cons
     if (const char* e = getenv("PA_FUSE_INPUT")) m->fuse_input = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_GEMM")) m->split_gemm = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_REC")) m->split_rec = e[0] != '0';
+    StateDict sd(names, data, numel, n_tensors);
+    if (!(state_dict_max_abs_weight(sd) < kSplitMaxWeight)) m->split_gemm = false;   // see kSplitMaxWeight
     m->split_rec = m->split_rec && m->split_gemm && cfg->hidden_size == 128;
     if (const char* e = getenv("PA_FUSE_DEC")) m->fuse_dec = e[0] != '0';
     int rc = init_base(m, cfg->device, hip_stream);
-    StateDict sd(names, data, numel, n_tensors);
     const int H = cfg->hidden_size;
     for (int stage = 0; stage < 2 && rc == PA_OK; ++stage)
         for (int l = 0; l < cfg->gru_layers && rc == PA_OK; ++l) {
             auto& vec = stage == 0 ? m->enc : m->dec;
             vec.emplace_back();
             const int K = (stage == 0 && l == 0) ? cfg->image_features : 2 * H;
-            rc = build_rec_layer(m, sd, stage == 0 ? "gru_encoder" : "gru_decoder", l, 3, H, K, vec.back());
+            rc = build_rec_layer(m, sd, stage == 0 ? "gru_encoder" : "gru_decoder", l, 3, H, K, vec.back(), false,
+                                 m->split_gemm);
         }
     if (rc == PA_OK) rc = build_linear(m, sd, "dense1", 2 * H, cfg->num_classes, m->dense);
     if (rc != PA_OK) {

@@ -47,6 +47,22 @@ ONT_PARAMS = dict(min_snp_baseq=1, min_indel_baseq=1, snp_freq_threshold=0.10, i
                   indel_candidate_freq_threshold=0.12, candidate_support_threshold=2, skip_indels=0)
 
 
+# image-generation thresholds of the reference's other presets (pepper_variant/modules/argparse/SetParameters.py:
+# ont_r9_guppy5_sup :20-36 = ONT_PARAMS above with indel_candidate 0.10 -- the tests keep 0.12 from round 1 as one more
+# variant --, ont_r10_q20 :122-146, hifi :176-203, clr :229-256)
+PRESET_PARAMS = {
+    "ont_r10_q20": dict(min_snp_baseq=1, min_indel_baseq=1, snp_freq_threshold=0.10, insert_freq_threshold=0.10,
+                        delete_freq_threshold=0.10, min_coverage_threshold=3, snp_candidate_freq_threshold=0.10,
+                        indel_candidate_freq_threshold=0.10, candidate_support_threshold=2),
+    "hifi": dict(min_snp_baseq=10, min_indel_baseq=10, snp_freq_threshold=0.10, insert_freq_threshold=0.12,
+                 delete_freq_threshold=0.10, min_coverage_threshold=2, snp_candidate_freq_threshold=0.10,
+                 indel_candidate_freq_threshold=0.10, candidate_support_threshold=2),
+    "clr": dict(min_snp_baseq=0, min_indel_baseq=0, snp_freq_threshold=0.10, insert_freq_threshold=0.12,
+                delete_freq_threshold=0.12, min_coverage_threshold=3, snp_candidate_freq_threshold=0.10,
+                indel_candidate_freq_threshold=0.12, candidate_support_threshold=2),
+}
+
+
 class FlatPileup(object):
     """Owns the numpy buffers behind a Pileup struct."""
 

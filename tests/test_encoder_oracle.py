@@ -88,6 +88,45 @@ def test_restatement_threshold_variants(libs):
     _same(pu.run_variant(oracle, pile, params), pu.run_variant(ref, pile, params, reference_impl=True))
 
 
+# pileups on which the base-quality branches of region_summary.cpp:366-454 decide a lot: qualities 2..39 with half of the
+# bases (low_quality_heavy) or a fifth (the others) below the HiFi cut-off of 10, inserts whose quality sum straddles
+# min_indel_baseq * length
+PRESET_CASES = {
+    "low_quality_heavy": dict(seed=31, low_q_rate=0.5, ins_rate=0.03, del_rate=0.03),
+    "indel_heavy": dict(seed=32, ins_rate=0.05, del_rate=0.05, low_q_rate=0.2),
+    "deep": dict(seed=33, depth=200, region=700, low_q_rate=0.3),
+}
+
+
+def preset_case(preset, name):
+    pile, _ = _case(**PRESET_CASES[name])
+    params = pu.make_params(pile.region_start + 100, pile.region_end - 100, **pu.PRESET_PARAMS[preset])
+    return pile, params
+
+
+@pytest.mark.parametrize("preset", sorted(pu.PRESET_PARAMS))
+@pytest.mark.parametrize("name", sorted(PRESET_CASES))
+def test_restatement_under_reference_presets(libs, preset, name):
+    """HiFi / CLR / R10 image-generation thresholds (SetParameters.py:122-256) on quality-sensitive pileups."""
+    oracle, ref = libs
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    pile, params = preset_case(preset, name)
+    a = pu.run_variant(oracle, pile, params)
+    assert len(a["candidates"]) > 0
+    _same(a, pu.run_variant(ref, pile, params, reference_impl=True))
+
+
+def test_presets_change_the_result(libs):
+    """The quality cut-offs are live on these pileups: HiFi (baseq 10) and CLR (baseq 0) give different candidates."""
+    oracle, _ = libs
+    pile, hifi = preset_case("hifi", "low_quality_heavy")
+    _, clr = preset_case("clr", "low_quality_heavy")
+    a, b = pu.run_variant(oracle, pile, hifi), pu.run_variant(oracle, pile, clr)
+    assert a["candidates"] != b["candidates"] or not np.array_equal(a["images"], b["images"])
+    assert not np.array_equal(a["depths"][:20], b["depths"][:20]) or len(a["depths"]) != len(b["depths"])
+
+
 def test_restatement_against_committed_golden(libs, golden_dir):
     """Golden vectors made by the reference build (tests/golden/make_golden_encoder.py): this is the
     check that still runs where /root/reference does not exist."""

@@ -107,3 +107,53 @@ def test_split_arithmetic_margin_across_weight_scales(gain, env_guard):
     _, _, acc = pm.predict_chunks(torch.from_numpy(imgs), return_acc=True)
     pm.close()
     assert np.abs(acc.numpy() - pinter["acc"]).max() < 0.5 * TOL, gain
+
+
+@pytest.mark.parametrize("family", __import__("weight_families").FAMILIES)
+def test_split_arithmetic_on_weight_families(family, env_guard):
+    """Mixed row scales (|w| ~ 1e-4 beside |w| ~ 1), heavy tails, large biases, entries near the f16 limit (these run on
+    the exact-f32 kernels: kSplitMaxWeight in api.hip), and a head whose three scores almost tie: the default path
+    against the float64 restatement, 1e-4 with margin."""
+    import weight_families as wf
+    from test_gpu_variant import NativeVariant
+    _set({})
+    sd = wf.make(family, 70)
+    x = wf.stress_windows(96, 7)
+    p64, l64 = models_np.variant_forward_f64(sd, x)
+    m = NativeVariant(sd)
+    probs, logits = m.forward(x)
+    m.close()
+    assert np.isfinite(probs).all() and np.isfinite(logits).all()
+    perr, lerr = wf.errors(probs, logits, p64, l64)
+    assert perr < 0.5 * TOL and lerr < 0.5 * TOL, (family, perr, lerr)
+    # calls: identical wherever exact arithmetic separates the two best classes by more than 1e-5
+    top = np.sort(p64, axis=1)
+    clear = (top[:, -1] - top[:, -2]) > 1e-5
+    assert (probs.argmax(1)[clear] == p64.argmax(1)[clear]).all()
+    if family == "near_tie_head":
+        assert (top[:, -1] - top[:, -2]).max() < 1e-3      # the construction really produces near ties
+        assert perr < 1e-5, perr
+
+
+def test_large_weights_select_the_exact_f32_kernels(env_guard):
+    """The split-f16 operands have an absolute floor of 2^-25 on activations, i.e. |w| * 3e-8 of error per product:
+    checkpoints whose largest weight reaches 64 run on the exact-f32 matrix instructions instead (api.hip
+    kSplitMaxWeight).  Seen here through the kernel labels the profiler records; results still meet the bar."""
+    import ctypes
+    from pepper_amd import _lib
+    from test_gpu_variant import NativeVariant
+    import weight_families as wf
+    _set({})
+    for big, want_h2 in ((None, True), (3.0e4, False), (7.0e4, False)):
+        sd = synthetic.variant_state_dict(seed=3)
+        if big is not None:
+            sd["decoder.weight_hh_l0"][2 * 256 + 5, 7] = big      # 7e4 would not even fit the f16 hi half
+        m = NativeVariant(sd)
+        _lib.check(m.lib.pa_profile_enable(m.h, 1))
+        x = wf.stress_windows(70, 9)
+        probs, logits = m.forward(x)
+        labels = set(_lib.profile_dict(m.h))
+        m.close()
+        assert any("_h2" in k for k in labels) == want_h2, (big, labels)
+        p64, l64 = models_np.variant_forward_f64(sd, x)
+        assert max(wf.errors(probs, logits, p64, l64)) < 0.5 * TOL, big

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import pileup_utils as pu
-from test_encoder_oracle import CASES, _case
+from test_encoder_oracle import CASES, PRESET_CASES, _case, preset_case
 
 pytestmark = pytest.mark.gpu
 
@@ -52,6 +52,21 @@ def _check(got, want):
 def test_encoder_matches_oracle_and_reference(name):
     oracle, ref = pu.load_restatement(), pu.load_reference_encoder()
     pile, params = _case(**CASES[name])
+    got = _product(pile, params)
+    assert len(got["candidates"]) > 0
+    _check(got, pu.run_variant(oracle, pile, params))
+    if ref is not None:
+        _check(got, pu.run_variant(ref, pile, params, reference_impl=True))
+
+
+@pytest.mark.parametrize("preset", sorted(pu.PRESET_PARAMS))
+@pytest.mark.parametrize("name", sorted(PRESET_CASES))
+def test_encoder_under_reference_presets(preset, name):
+    """BASELINE configs[3] (--hifi) and the CLR / R10 presets through the HIP encoder: min base quality 10 / 0,
+    their frequency and coverage thresholds (SetParameters.py:122-256), on pileups where a fifth to a half of the bases
+    sit below the cut-off so the quality branches of region_summary.cpp:366-454 decide coverage, votes and inserts."""
+    oracle, ref = pu.load_restatement(), pu.load_reference_encoder()
+    pile, params = preset_case(preset, name)
     got = _product(pile, params)
     assert len(got["candidates"]) > 0
     _check(got, pu.run_variant(oracle, pile, params))

@@ -13,7 +13,7 @@ from pepper_amd import h5, synthetic
 pytestmark = pytest.mark.gpu
 
 
-def _variant_images(dirpath, sizes_per_file):
+def _variant_images(dirpath, sizes_per_file, file_stride=0):
     from pepper_amd.variant.DataStore import DataStore
     all_images = []
     seed = 500
@@ -22,7 +22,7 @@ def _variant_images(dirpath, sizes_per_file):
             for gi, n in enumerate(groups):
                 x = synthetic.variant_windows(n, seed=seed)
                 seed += 1
-                start = 100000 * gi
+                start = file_stride * fi + 100000 * gi
                 ds.write_summary(f"chr20_{start}_{start + 100000}", ["chr20"] * n, list(range(start, start + n)),
                                  [30] * n, [[f"1{'ACGT'[i % 4]}"] for i in range(n)], [[7]] * n, x.tolist(),
                                  [0] * n, [0] * n, False)
@@ -41,8 +41,11 @@ def test_run_inference_end_to_end(tmp_path):
     model_path = str(tmp_path / "model.pkl")
     torch.save(ckpt, model_path)
     options = SimpleNamespace(model_path=model_path, batch_size=512, num_workers=0, use_hp_info=False, gpu=True,
-                              device_ids="0", callers_per_gpu=4, threads=8, quantized=False, dry=False)
+                              device_ids="0", callers_per_gpu=1, threads=8, quantized=False, dry=False)
+    out_dir.mkdir()
+    (out_dir / "pepper_prediction_3.hdf").write_bytes(b"left over from a run with four callers")
     run_inference(options, str(img_dir), str(out_dir))
+    assert sorted(os.listdir(out_dir)) == ["pepper_prediction.hdf"]      # stale per-rank files are removed
     out_file = out_dir / "pepper_prediction.hdf"
     assert out_file.exists()
     x_all = np.concatenate([g[2] for g in groups])
@@ -63,6 +66,99 @@ def test_run_inference_end_to_end(tmp_path):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         options.gpu = False
         run_inference(options, str(img_dir), str(out_dir))
+
+
+def _read_predictions(path):
+    """{(contig, position, candidate): probabilities} of one predictions file, plus the batch names in order."""
+    out = {}
+    with h5.File(path) as f:
+        batches = sorted(f.keys("predictions"), key=lambda s: int(s.split("_")[1]))
+        for b in batches:
+            probs = f[f"predictions/{b}/base_prediction"]
+            pos = f[f"predictions/{b}/positions"]
+            cand = f[f"predictions/{b}/candidates"]
+            contigs = f[f"predictions/{b}/contigs"]
+            for i in range(len(pos)):
+                out[(bytes(contigs[i]), int(pos[i]), str(cand[i, 0]))] = np.array(probs[i])
+    return out, batches
+
+
+def test_run_inference_multi_process_and_loader_workers(tmp_path):
+    """The N-caller leg of RunInference.distributed_gpu (mp.spawn, one process per caller, one weight broadcast, file
+    shards, pepper_prediction_<rank>.hdf) with two callers sharing GPU 0 -- callers_per_gpu = 2, the reference's own
+    option (RunInference.py:31-35); the broadcast then runs over gloo because RCCL refuses two ranks on one device --
+    and options.num_workers = 2 (spawned loader processes): both must reproduce the single-process files exactly."""
+    from pepper_amd.variant.RunInference import run_inference
+    img_dir = tmp_path / "images"
+    img_dir.mkdir()
+    _variant_images(str(img_dir), [[600, 40], [300], [77, 3], [150]], file_stride=10_000_000)    # unique positions
+    sd = synthetic.variant_state_dict(seed=43, gain=2.0)
+    model_path = str(tmp_path / "model.pkl")
+    torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128, module_prefix=True),
+               model_path)
+
+    def run(out, **over):
+        opts = dict(model_path=model_path, batch_size=256, num_workers=0, use_hp_info=False, gpu=True, device_ids="0",
+                    callers_per_gpu=1, threads=4, quantized=False, dry=False)
+        opts.update(over)
+        run_inference(SimpleNamespace(**opts), str(img_dir), str(tmp_path / out))
+        return tmp_path / out
+
+    single = run("single")
+    want, want_batches = _read_predictions(str(single / "pepper_prediction.hdf"))
+    assert len(want) == 600 + 40 + 300 + 77 + 3 + 150
+
+    two = run("two", callers_per_gpu=2)
+    assert sorted(os.listdir(two)) == ["pepper_prediction_0.hdf", "pepper_prediction_1.hdf"]
+    got = {}
+    for r in (0, 1):
+        part, batches = _read_predictions(str(two / f"pepper_prediction_{r}.hdf"))
+        assert batches == [f"batch_{i}" for i in range(len(batches))] and len(part) > 0
+        assert not (set(part) & set(got))
+        got.update(part)
+    assert set(got) == set(want)
+    assert all(np.array_equal(got[k], want[k]) for k in want)
+
+    loaders = run("loaders", num_workers=2)
+    got2, batches2 = _read_predictions(str(loaders / "pepper_prediction.hdf"))
+    assert batches2 == want_batches and set(got2) == set(want)
+    assert all(np.array_equal(got2[k], want[k]) for k in want)
+
+
+def test_call_consensus_two_callers_share_gpu(tmp_path):
+    """Polish counterpart: device_ids "0,0" = two processes on GPU 0 (predict_distributed_gpu's mp.spawn leg), files
+    sharded between them; per-chunk outputs equal the one-process run."""
+    from pepper_amd.polish.DataStore import DataStore
+    from pepper_amd.polish.call_consensus import call_consensus
+    img_dir = tmp_path / "images"
+    img_dir.mkdir()
+    chunks = synthetic.polish_chunks(7, seed=901)
+    for fi, ids in enumerate(([0, 1, 2, 3], [4, 5, 6])):
+        with DataStore(str(img_dir / f"pepper_images_thread_{fi}.hdf"), "w") as ds:
+            for cid in ids:
+                ds.write_summary((f"contig_{fi}", 2000, 3000), chunks[cid].tolist(), [0] * 1000, list(range(2000, 3000)),
+                                 [0] * 1000, cid, f"contig_{fi}_2000_3000_{cid}")
+    sd = synthetic.polish_state_dict(seed=44, gain=2.0)
+    model_path = str(tmp_path / "polish.pkl")
+    torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
+    call_consensus(str(img_dir), model_path, 128, 0, str(tmp_path / "one"), "0", True, 4)
+    call_consensus(str(img_dir), model_path, 128, 0, str(tmp_path / "two"), "0,0", True, 4)
+    assert sorted(os.listdir(tmp_path / "two")) == ["pepper_prediction_0.hdf", "pepper_prediction_1.hdf"]
+
+    def read(dirpath):
+        out = {}
+        for name in sorted(os.listdir(dirpath)):
+            with h5.File(str(dirpath / name)) as f:
+                for contig in f.keys("predictions"):
+                    base = f"predictions/{contig}/{contig}-2000-3000"
+                    for cid in f.keys(base):
+                        if cid.isdigit():
+                            out[(contig, int(cid))] = (np.array(f[f"{base}/{cid}/bases"]), np.array(f[f"{base}/{cid}/phred_score"]))
+        return out
+    one, two = read(tmp_path / "one"), read(tmp_path / "two")
+    assert len(one) == 7 and set(one) == set(two)
+    for k in one:
+        assert np.array_equal(one[k][0], two[k][0]) and np.array_equal(one[k][1], two[k][1])
 
 
 def test_call_consensus_end_to_end(tmp_path):

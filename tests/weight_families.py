@@ -1,0 +1,109 @@
+"""Stress families of variant-model weights for the split-f16 arithmetic: the seeded-uniform
+recipe of pepper_amd.synthetic only scales ONE distribution; a trained checkpoint has rows of very different
+magnitude side by side, heavy tails and the odd large bias.  Each family starts from the PyTorch-default init and
+reshapes it; `near_tie_head` makes the three class scores almost equal so that tiny logit errors would flip calls.
+Also a numpy emulation of the product's arithmetic (every contraction as hi*hi + hi*lo + lo*hi on f16 halves) so the
+families can be judged on the CPU before a GPU sees them."""
+import numpy as np
+
+from pepper_amd import synthetic
+
+FAMILIES = ["mixed_row_scales", "heavy_tailed", "large_bias", "near_f16_limit", "near_tie_head"]
+
+
+def make(name, seed):
+    sd = synthetic.variant_state_dict(seed=seed, gain=1.0)
+    rng = np.random.default_rng([seed, 99])
+    shapes = {s[0]: s[2] for s in synthetic.variant_param_shapes()}
+    if name == "mixed_row_scales":
+        # per output row: 1e-3 .. 16 x the default bound for the LSTM matrices (|w| from ~6e-5 to ~1 side by side),
+        # 1e-3 .. 3 x for the dense layers (their fan-in is up to 16896: larger rows only saturate everything)
+        for k, v in sd.items():
+            if v.ndim == 2:
+                top = 1.2 if ("encoder" in k or "decoder" in k) else 0.5
+                v *= (10.0 ** rng.uniform(-3.0, top, size=(v.shape[0], 1))).astype(np.float32)
+    elif name == "heavy_tailed":
+        for k, v in sd.items():
+            if v.ndim == 2:
+                t = rng.standard_t(2.0, size=v.shape) * 0.5
+                sd[k] = (np.clip(t, -40.0, 40.0) * shapes[k]).astype(np.float32)
+    elif name == "large_bias":
+        for k, v in sd.items():
+            if v.ndim == 1:
+                v *= 50.0
+    elif name == "near_f16_limit":
+        # a sprinkle of entries at +-2.0e4 (the LSTM copies are pre-multiplied by up to 2.89 before the f16 split:
+        # 5.8e4 < 65504); everything downstream saturates, nothing may overflow to inf / NaN
+        # (LSTM matrices only: their inputs are bounded -- int8 summaries, h in (-1, 1) -- so the f16 range constrains
+        # the weights alone; dense-layer ACTIVATIONS beyond 65504 are outside the split format)
+        for k, v in sd.items():
+            if v.ndim == 2 and ("encoder" in k or "decoder" in k):
+                hit = rng.random(v.shape) < 5e-4
+                v[hit] = rng.choice([-2.0e4, 2.0e4], size=int(hit.sum())).astype(np.float32)
+    elif name == "near_tie_head":
+        w, b = sd["output_layer_type.weight"], sd["output_layer_type.bias"]
+        w[1] = w[0] * (1.0 + 1e-4)
+        w[2] = w[0] * (1.0 - 2e-4)
+        b[1] = b[0] + 1e-5
+        b[2] = b[0] - 1e-5
+    else:
+        raise KeyError(name)
+    return sd
+
+
+def stress_windows(n, seed):
+    x = synthetic.variant_windows(n, seed=seed)
+    x[0] = 127
+    x[1] = -128
+    x[2] = 0
+    return x
+
+
+# ---- numpy emulation of the split-f16 product ----------------------------------------------------------------------
+def split(v):
+    hi = v.astype(np.float16)
+    lo = (v.astype(np.float32) - hi.astype(np.float32)).astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def mm3(a, w):
+    """a [M,K] f32, w [N,K] f32 -> a w^T with hi*hi + hi*lo + lo*hi (products exact, accumulation not rounded)."""
+    ah, al = split(a)
+    wh, wl = split(w)
+    return (ah @ wh.T + ah @ wl.T + al @ wh.T).astype(np.float32)
+
+
+def variant_forward_emulated(sd, images):
+    f4 = np.float32
+    sig = lambda v: (1.0 / (1.0 + np.exp(-np.clip(v.astype(np.float64), -700, 700)))).astype(f4)   # noqa: E731
+
+    def direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
+        B, T, F = x.shape
+        H = w_hh.shape[1]
+        h, c = np.zeros((B, H), f4), np.zeros((B, H), f4)
+        y = np.zeros((B, T, H), f4)
+        xp = mm3(x.reshape(B * T, F), w_ih).reshape(B, T, 4 * H) + (b_ih + b_hh)
+        for t in (range(T - 1, -1, -1) if reverse else range(T)):
+            g = xp[:, t] + mm3(h, w_hh)
+            c = sig(g[:, H:2 * H]) * c + sig(g[:, :H]) * np.tanh(g[:, 2 * H:3 * H])
+            h = (sig(g[:, 3 * H:]) * np.tanh(c)).astype(f4)
+            y[:, t] = h
+        return y
+
+    x = np.asarray(images).astype(f4)
+    for prefix in ("encoder", "decoder"):
+        x = np.concatenate([direction(x, sd[f"{prefix}.weight_ih_l0{s}"], sd[f"{prefix}.weight_hh_l0{s}"],
+                                      sd[f"{prefix}.bias_ih_l0{s}"], sd[f"{prefix}.bias_hh_l0{s}"], rev)
+                            for s, rev in (("", False), ("_reverse", True))], axis=2)
+    a = x.reshape(x.shape[0], -1)
+    from oracle.models_np import selu, softmax
+    for name in ("linear_1", "linear_2", "linear_3", "linear_4", "linear_5"):
+        a = selu(mm3(a, sd[f"{name}.weight"]) + sd[f"{name}.bias"])
+    logits = (a.astype(np.float64) @ sd["output_layer_type.weight"].astype(np.float64).T + sd["output_layer_type.bias"]).astype(f4)
+    return softmax(logits, axis=1), logits
+
+
+def errors(probs, logits, ref_probs, ref_logits):
+    """(max |dp|, max |dlogit| / max(1, max |logit|))."""
+    return (float(np.abs(probs - ref_probs).max()),
+            float(np.abs(logits - ref_logits).max() / max(1.0, np.abs(ref_logits).max())))
