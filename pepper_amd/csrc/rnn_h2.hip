@@ -23,6 +23,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef PA_NT_DEFAULT
+#define PA_NT_DEFAULT false
+#endif
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -51,7 +55,10 @@ PA_DEV unsigned swap_pair(unsigned v) { return (unsigned)__builtin_amdgcn_update
 // LDS like they read h.  (First form of this kernel: every wave fetched its x fragments straight from global
 // memory -- 8x redundant through L1, +0.7 ms per 16384 windows, and 4 MB of x per step per XCD pushed the
 // weights out of L2.)
-template <int H, int KX, bool PRE, bool XG = false>
+// SAUX: cache policy of the streams that pass through once -- the x slab loads of the XG form and the y stores (2 = nt:
+// the lines are not kept in the XCD's L2, which has to hold this direction's 3 MB of weight fragments that every
+// workgroup re-reads every step; 0 = default policy).
+template <int H, int KX, bool PRE, bool XG = false, int SAUX = 0>
 __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
                                                                      const int8_t* __restrict__ Xi, int F,
                                                                      const float* __restrict__ bias,
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     uint32_t* xst_dst = xring + (tid >> 3) * XRD + (tid & 7) * 4;
     u32x4 xstage[2];
     auto xg_load = [&](int j, int t) {      // iteration j of step t -> staging register j & 1
-        xstage[j & 1] = __builtin_amdgcn_raw_buffer_load_b128(xgrs, xg_off, ((unsigned)t * ldxh) * 4u + (unsigned)j * 128u, 0);
+        xstage[j & 1] = __builtin_amdgcn_raw_buffer_load_b128(xgrs, xg_off, ((unsigned)t * ldxh) * 4u + (unsigned)j * 128u, SAUX);
     };
     auto xg_store = [&](int j) { *reinterpret_cast<u32x4*>(xst_dst + (j & 1) * XSLOT) = xstage[j & 1]; };
 
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     const unsigned yc_off = ((unsigned)(yc_row * T) * ldy + yc_c * 4) * 4u;
     auto yc_read = [&](int j) { return *reinterpret_cast<const u32x4*>(yc_src + j * YROWS * ROWD); };
     auto yc_write = [&](int j, int tp, u32x4 v) {
-        __builtin_amdgcn_raw_buffer_store_b128(v, ycrs, yc_off, ((unsigned)(j * YROWS * T + tp) * ldy) * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, ycrs, yc_off, ((unsigned)(j * YROWS * T + tp) * ldy) * 4u, SAUX);
     };
 
     // gate-phase h write: element (row, col = 32u + li) -> hi half at row*ROWB + (col/8)*32 + (col%8)*2,
@@ -249,12 +256,15 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                 if (s >= 1 && s <= YC) yc_write(s - 1, tp, ycv);
                 if (s < YC) ycv = yc_read(s);
 #pragma unroll
-                for (int term = 0; term < 3; ++term)
+                for (int term = 0; term < 3; ++term) {
+                    // int8 summaries are exact in the hi half: their lo half is identically zero, so is lo(a) * hi(w)
+                    if (XI8 && s >= KSH && term == 0) continue;
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
                             acc[m][g] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0], acc[m][g]);
+                }
                 if (XG && s + 1 < KS && s > YC) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -373,7 +383,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 //   /root/reference/pepper/modules/python/models/simple_model.py:30,32
 // XG: the layer input is an h2 layer output Xh [B*T, KX] streamed through a two-slot LDS ring exactly as in
 // lstm_rec_h2_kernel (two k steps = 128 rows x 128 B per slot, two 16-byte chunks per thread per iteration).
-template <int H, int KX, bool XG = false>
+template <int H, int KX, bool XG = false, int SAUX = 0>
 __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
                                                             const uint8_t* __restrict__ Xi, int F, int64_t xi_bstride,
                                                             const float* __restrict__ bias,
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 2; ++q)
             xstage[j & 1][q] = __builtin_amdgcn_raw_buffer_load_b128(
-                xgrs, xg_off, ((unsigned)(q * 64 * T + t) * ldxh) * 4u + (unsigned)j * 128u, 0);
+                xgrs, xg_off, ((unsigned)(q * 64 * T + t) * ldxh) * 4u + (unsigned)j * 128u, SAUX);
     };
     auto xg_store = [&](int j) {
 #pragma unroll
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
     const unsigned yc_off = ((unsigned)(yc_row * T) * ldy + yc_c * 4) * 4u;
     auto yc_read = [&](int j) { return *reinterpret_cast<const u32x4*>(yc_src + j * YROWS * ROWD); };
     auto yc_write = [&](int j, int tp, u32x4 v) {
-        __builtin_amdgcn_raw_buffer_store_b128(v, ycrs, yc_off, ((unsigned)(j * YROWS * T + tp) * ldy) * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, ycrs, yc_off, ((unsigned)(j * YROWS * T + tp) * ldy) * 4u, SAUX);
     };
 
     struct Frag { h8 b[3][2], a[2][2]; };
@@ -603,7 +613,8 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
                 if (s >= 1 && s <= YI) yc_write(s - 1, tp, ycv);
                 if (s < YI) ycv = yc_read(s);
 #pragma unroll
-                for (int term = 0; term < 3; ++term)
+                for (int term = 0; term < 3; ++term) {
+                    if (XU8 && s >= KSH && term == 0) continue;    // uint8 summaries: lo(a) == 0
 #pragma unroll
                     for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -611,6 +622,7 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
                             const int ai = (g == 2 && s >= KSH) ? NA - 1 : g;
                             acc[m][ai] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0], acc[m][ai]);
                         }
+                }
                 if (s + 1 < KS) {
 #pragma unroll
                     for (int q = 0; q < 6; ++q) {
@@ -897,6 +909,12 @@ __global__ __launch_bounds__(256, 1) void gru_dec_h2_kernel(const uint32_t* __re
     }
 }
 
+// PA_NT=1: nt cache policy on the once-through streams of the step loops (see SAUX)
+inline bool stream_nt() {
+    static const bool on = [] { const char* e = getenv("PA_NT"); return e ? e[0] != '0' : PA_NT_DEFAULT; }();
+    return on;
+}
+
 inline int rec_grid(int B) {
     const int nbt = (B + MT - 1) / MT;
     return 2 * ((nbt + 3) / 4) * 4;
@@ -947,11 +965,12 @@ hipError_t launch_lstm_dec_h2(int H, const void* Xh, int ldxh, const float* bias
     if (H != 256 || (ldy & 7) || (ldxh & 7) || ldxh < 512) return hipErrorInvalidValue;
     const size_t lds = (size_t)MT * (256 * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4 + (size_t)2 * MT * 36 * 4;   // h + c + x ring
     const int grid = rec_grid(B);
-#define PA_DEC(PRE_)                                                                                                   \
-    hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 512, PRE_, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, \
+#define PA_DEC(PRE_, AUX_)                                                                                             \
+    hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 512, PRE_, true, AUX_>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, \
                        (const int8_t*)nullptr, 0, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y), ldy, B, T, \
                        debug_buffer(), static_cast<const uint32_t*>(Xh), ldxh)
-    if (prescaled) PA_DEC(true); else PA_DEC(false);
+    if (stream_nt()) { if (prescaled) PA_DEC(true, 2); else PA_DEC(false, 2); }
+    else { if (prescaled) PA_DEC(true, 0); else PA_DEC(false, 0); }
 #undef PA_DEC
     return hipGetLastError();
 }
@@ -964,7 +983,11 @@ hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, 
     if (X != nullptr) {
         if (F <= 0 || F > 32) return hipErrorInvalidValue;
         const size_t lds = (size_t)MT * ((256 + 32) * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4;
-        if (prescaled) hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
+        if (prescaled && stream_nt())
+            hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32, true, false, 2>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
+                               F, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y), ldy, B, T,
+                               debug_buffer() ? debug_buffer() + 8 * 80 * 2 : nullptr);
+        else if (prescaled) hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
                            F, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y), ldy, B, T,
                            debug_buffer() ? debug_buffer() + 8 * 80 * 2 : nullptr);
         else hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32, false>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,

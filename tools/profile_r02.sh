@@ -14,6 +14,11 @@ PEPPER_AMD_BENCH_SHARE_GPU=1 timeout 300 python bench.py --gpus 2 --steps 4 --wa
 if [ "${SKIP_POLISH:-0}" != "1" ]; then
 timeout 400 python bench.py --model polish --steps 6 --warmup 1 --cpu-seconds 8 > gpurun_out/${TAG}_bench_polish.json 2> gpurun_out/${TAG}_bench_polish.err; tail -c 1200 gpurun_out/${TAG}_bench_polish.json; tail -3 gpurun_out/${TAG}_bench_polish.err
 fi
+# A/B of the nt cache policy on the once-through streams of the step loops (PA_NT), device-resident pass
+for NT in 0 1; do
+PA_NT=$NT timeout 200 python bench.py --resident-only --no-cpu-baseline --steps 12 --warmup 3 > gpurun_out/${TAG}_bench_resident_nt$NT.json 2> gpurun_out/${TAG}_bench_resident_nt$NT.err; tail -c 900 gpurun_out/${TAG}_bench_resident_nt$NT.json
+done
+PA_NT=1 timeout 300 python -m pytest tests/test_gpu_variant.py tests/test_gpu_polish.py -q -m gpu > gpurun_out/${TAG}_gpu_tests_nt1.log 2>&1; tail -2 gpurun_out/${TAG}_gpu_tests_nt1.log
 cd /tmp && export TMPDIR=/tmp
 PROF="python $R/bench.py --resident-only --no-cpu-baseline --steps 6 --warmup 2"
 timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o variant -- $PROF > $R/gpurun_out/${TAG}_stats.log 2>&1
