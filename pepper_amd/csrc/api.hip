@@ -759,17 +759,24 @@ struct pa_polish_model : ModelBase {
     bool split_rec = true;       // PA_SPLIT_REC=0 keeps the recurrences on the f32 matrix instructions
     bool fuse_dec = true;        // PA_FUSE_DEC=0: decoder projection as a GEMM + Xp instead of inside the step loop
     bool y_h2 = false;           // format of the last polish_window output
+    bool fuse_head = true;       // PA_FUSE_HEAD=0: last decoder layer writes y, dense1 + softmax + overlap-add as their own kernel
     std::vector<RecLayer> enc, dec;
     Linear dense;
+    DevBuf *dense_h2 = nullptr;  // dense1 as h2 fragments of the 16x16x32 tile (rnn_h2.hip pack_dense_head_h2)
+    DevBuf *part = nullptr;      // per-direction partial logits of the fused head
     DevBuf *xp, *y1, *y2, *hid_a, *hid_b, *acc, *stage_in[2], *stage_lab[2], *stage_ph[2], *stage_acc[2];
 };
 
 // One module forward on n (<= padded workspace) sequences of T steps.
 //   x_kind/x/x_ld/x_rpb/x_bstride describe the first layer's input rows (see launch_gemm_nt);
 //   hidden_in may be null (zeros); hidden_out receives the decoder's final states.
+// head_fused (in/out): the caller wants softmax-ready logits only; set to true when the last decoder layer ran with
+// dense1 contracted inside its step loop (m->part then holds the partial logits and *y_last is not written).
 static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld, int x_rpb,
                          int64_t x_bstride, const float* hidden_in, float* hidden_out, int64_t n, int T,
-                         float** y_last) {
+                         float** y_last, bool* head_fused = nullptr) {
+    const bool want_head = head_fused && *head_fused;
+    if (head_fused) *head_fused = false;
     const int H = m->cfg.hidden_size, L = m->cfg.gru_layers, NX = 2 * 3 * H, ldh = 2 * L * H;
     const int M = (int)(n * T);
     const void* cur = x;
@@ -805,6 +812,15 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
                                                         r.w_cat->f(), r.b_hn->f(), h0l, ldh, hnl, ldh, y, 2 * H, (int)n, T,
                                                         m->stream));
                 cur_h2 = fused_h2_ok;
+            } else if (want_head && stage == 1 && l == L - 1 && rec_h2 && cur_h2 && r.w_cat_dec_h2 != nullptr && cur_rpb == 0 &&
+                       cur_bs == 0 && m->fuse_dec && m->fuse_head && m->dense_h2 != nullptr && H == 128) {
+                // last layer: projection AND dense1 contracted inside the step loop; no layer output at all
+                if (int rc = m->part->ensure(pa::dense_partials_floats((int)n, T) * sizeof(float))) return rc;
+                LAUNCH_TRY(m, "gru_dec_h2_fused_dense", 2.0 * n * T * ((3.0 * H) * (H + r.K) + m->cfg.num_classes * H) * 2,
+                           pa::launch_gru_dec_h2_dense(H, cur, cur_ld, r.b_in->f(), r.w_cat_dec_h2->p, r.b_hn->f(), h0l, ldh, hnl,
+                                                       ldh, m->dense_h2->p, m->part->f(), (int)n, T, m->stream));
+                *head_fused = true;
+                cur_h2 = true;
             } else if (rec_h2 && cur_h2 && r.w_cat_dec_h2 != nullptr && cur_rpb == 0 && cur_bs == 0 && m->fuse_dec) {
                 // h2 layer output -> this layer: projection contracted inside the step loop (no GEMM, no Xp)
                 LAUNCH_TRY(m, "gru_dec_h2_fused", 2.0 * n * T * (3.0 * H) * (H + r.K) * 2,
@@ -893,10 +909,22 @@ int pa_polish_create(const pa_polish_config* cfg, const char* const* names, cons
                                  m->split_gemm);
         }
     if (rc == PA_OK) rc = build_linear(m, sd, "dense1", 2 * H, cfg->num_classes, m->dense);
+    if (const char* e = getenv("PA_FUSE_HEAD")) m->fuse_head = e[0] != '0';
+    if (rc == PA_OK && m->split_rec && H == 128 && cfg->num_classes <= 5) {
+        std::string err;
+        const float* w = sd.get("dense1.weight", (int64_t)cfg->num_classes * 2 * H, err);
+        std::vector<uint32_t> packed(pa::dense_head_h2_words(H));
+        pa::pack_dense_head_h2(w, cfg->num_classes, H, packed.data());
+        m->dense_h2 = m->new_buf();
+        rc = m->dense_h2->ensure(packed.size() * sizeof(uint32_t));
+        if (rc == PA_OK && hipMemcpy(m->dense_h2->p, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(PA_ERR_HIP, "upload of the packed dense1 fragments failed");
+    }
     if (rc != PA_OK) {
         delete m;
         return rc;
     }
+    m->part = m->new_buf();
     m->xp = m->new_buf(); m->y1 = m->new_buf(); m->y2 = m->new_buf();
     m->hid_a = m->new_buf(); m->hid_b = m->new_buf(); m->acc = m->new_buf();
     for (int k = 0; k < 2; ++k) {
@@ -971,11 +999,15 @@ int pa_polish_predict_device(pa_polish_model* m, const uint8_t* images, int64_t 
         // predict_distributed_cpu.py:50-53: i = 0, jump, ... while i + window <= seq_length
         for (int i = 0; i + T <= S; i += m->cfg.jump) {
             float* y = nullptr;
+            bool head = true;
             if (int rc = polish_window(m, pa::A_U8, img + (size_t)i * F, F, T, (int64_t)S * F,
-                                       first ? nullptr : m->hid_b->f(), m->hid_b->f(), c, T, &y))
+                                       first ? nullptr : m->hid_b->f(), m->hid_b->f(), c, T, &y, &head))
                 return rc;
             first = false;
-            if (m->y_h2 && 2 * H == 256 && C <= 5)
+            if (head)
+                LAUNCH_TRY(m, "head_combine_acc", 0.0,
+                           pa::launch_polish_combine(m->part->f(), m->dense.b->f(), acc, (int)c, T, C, S, i, m->stream));
+            else if (m->y_h2 && 2 * H == 256 && C <= 5)
                 LAUNCH_TRY(m, "dense_softmax_acc", 2.0 * c * T * 2 * H * C,
                            pa::launch_polish_dense_acc_h2(y, 2 * H, m->dense.w->f(), m->dense.b->f(), acc, (int)(c * T),
                                                           2 * H, C, T, S, i, m->stream));

@@ -207,18 +207,24 @@ __global__ __launch_bounds__(256) void gemm_h2_kernel(const uint32_t* __restrict
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    // Everything the epilogue derives from the lane index is computed AFTER the k loop: left alone, hipcc hoists the four
+    // 64-bit bias addresses and the row offsets above the loop, where all 512 registers are taken, and spills them to
+    // scratch (9 VGPRs in round 1's build).  The empty asm makes the lane index opaque at this point.
+    int lane_ep = lane;
+    asm volatile("" : "+v"(lane_ep));
+    const int li_ep = lane_ep & 31;
     if (frag_T > 0) {
         // C in MFMA fragment order (see gemm.hip / rnn.hip): 16-byte stores, bias folded in
         const int ct_n = N >> 5;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const int col = n0 + wn * 128 + n * 32 + li;
+            const int col = n0 + wn * 128 + n * 32 + li_ep;
             const float bv = (bias != nullptr && col < N) ? bias[col] : 0.0f;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int rt = (m0 + wm * 128 + m * 32) >> 5, ct = (n0 + wn * 128 + n * 32) >> 5;
                 if ((rt << 5) < M && (ct << 5) < N) {
-                    f32x4* dst = reinterpret_cast<f32x4*>(C + ((size_t)rt * ct_n + ct) * 1024) + lane;
+                    f32x4* dst = reinterpret_cast<f32x4*>(C + ((size_t)rt * ct_n + ct) * 1024) + lane_ep;
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         f32x4 v = {acc[m][n][4 * qd] + bv, acc[m][n][4 * qd + 1] + bv, acc[m][n][4 * qd + 2] + bv,
@@ -232,13 +238,13 @@ __global__ __launch_bounds__(256) void gemm_h2_kernel(const uint32_t* __restrict
     }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-        const int col = n0 + wn * 128 + n * 32 + li;
+        const int col = n0 + wn * 128 + n * 32 + li_ep;
         const float bv = (bias != nullptr && col < N) ? bias[col] : 0.0f;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 128 + m * 32 + crow32(r, lane);
+                const int row = m0 + wm * 128 + m * 32 + crow32(r, lane_ep);
                 if (row < M && col < N) {
                     float v = acc[m][n][r] + bv;
                     if (ACT == 1) v = selu_f(v);

@@ -199,6 +199,63 @@ __global__ __launch_bounds__(256) void polish_dense_acc_h2_kernel(const uint32_t
     }
 }
 
+// Second half of the fused polish head (first half: gru_rec_h2_kernel<.., DENSE> in rnn_h2.hip).  P holds, per
+// direction, the partial logits of the last decoder layer laid out [dir][batch tile of 128][t][class 5][128 rows];
+// logits = P[0] + P[1] + bias, then softmax over the classes and the overlap-add of
+// predict_distributed_cpu.py:62-81: acc[(b * S + off + t) * C + c] += p.  One block = 16 chunks x all T steps of one
+// batch tile: the [t][c][row] slab is read in 64-byte runs, transposed through LDS, and the accumulator -- T * C
+// consecutive floats per chunk -- is updated with coalesced 4-byte read-modify-writes.
+constexpr int CMB_ROWS = 16, CMB_TILE = 128, CMB_C = 5;
+__global__ __launch_bounds__(256) void polish_combine_kernel(const float* __restrict__ P, const float* __restrict__ bias,
+                                                             float* __restrict__ acc, int B, int T, int C, int S, int off,
+                                                             int nbt) {
+    extern __shared__ float cmb[];                      // [T][CMB_C][CMB_ROWS] logits, then [CMB_ROWS][T * C] probabilities
+    float* lg = cmb;
+    float* pr = cmb + (size_t)T * CMB_C * CMB_ROWS;
+    const int bt = blockIdx.x / (CMB_TILE / CMB_ROWS), slab = blockIdx.x % (CMB_TILE / CMB_ROWS);
+    const int r0 = slab * CMB_ROWS;
+    const size_t dstride = (size_t)nbt * T * CMB_C * CMB_TILE;
+    const float* p0 = P + (size_t)bt * T * CMB_C * CMB_TILE + r0;
+    // phase 1: 16-byte loads, four lanes cover one (t, c) run of 16 rows
+    const int n4 = T * CMB_C * (CMB_ROWS / 4);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const int tc = i >> 2, q = i & 3;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p0 + (size_t)tc * CMB_TILE + 4 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p0 + dstride + (size_t)tc * CMB_TILE + 4 * q);
+        const float bv = bias[tc % CMB_C];
+        f32x4 v = {a.x + b.x + bv, a.y + b.y + bv, a.z + b.z + bv, a.w + b.w + bv};
+        *reinterpret_cast<f32x4*>(lg + tc * CMB_ROWS + 4 * q) = v;
+    }
+    __syncthreads();
+    // phase 2: one (row, t) per thread and pass: softmax over the C classes
+    for (int i = threadIdx.x; i < CMB_ROWS * T; i += 256) {
+        const int row = i % CMB_ROWS, t = i / CMB_ROWS;
+        float l[CMB_C], mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CMB_C; ++c) {
+            l[c] = c < C ? lg[(t * CMB_C + c) * CMB_ROWS + row] : -INFINITY;
+            mx = fmaxf(mx, l[c]);
+        }
+        float e[CMB_C], den = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CMB_C; ++c) {
+            e[c] = c < C ? expf(l[c] - mx) : 0.0f;
+            den += e[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CMB_C; ++c)
+            if (c < C) pr[(size_t)row * T * C + t * C + c] = e[c] / den;
+    }
+    __syncthreads();
+    // phase 3: acc rows of one chunk are T * C consecutive floats
+    const int per = T * C;
+    for (int i = threadIdx.x; i < CMB_ROWS * per; i += 256) {
+        const int row = i / per, e = i - row * per;
+        const int b = bt * CMB_TILE + r0 + row;
+        if (b < B) acc[((size_t)b * S + off) * C + e] += pr[(size_t)row * per + e];
+    }
+}
+
 // h2 rows -> f32 rows in place (hi + lo), for callers that want the layer output itself
 __global__ __launch_bounds__(256) void h2_to_f32_kernel(uint32_t* __restrict__ buf, int64_t rows, int K, int64_t ld) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -271,6 +328,23 @@ hipError_t launch_polish_dense_acc_h2(const void* X, int ldx, const float* W, co
     const int rpb = 256;
     hipLaunchKernelGGL((polish_dense_acc_h2_kernel<256>), dim3((rows + rpb - 1) / rpb), dim3(256), 0, stream,
                        static_cast<const uint32_t*>(X), ldx, W, bias, acc, rows, C, T, S, off, rpb);
+    return hipGetLastError();
+}
+
+hipError_t launch_polish_combine(const float* P, const float* bias, float* acc, int B, int T, int C, int S, int off,
+                                 hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    if (C > CMB_C || T <= 0) return hipErrorInvalidValue;
+    const int nbt = (B + CMB_TILE - 1) / CMB_TILE;
+    const size_t lds = ((size_t)T * CMB_C * CMB_ROWS + (size_t)CMB_ROWS * T * C) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(polish_combine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(polish_combine_kernel, dim3(nbt * (CMB_TILE / CMB_ROWS)), dim3(256), lds, stream, P, bias, acc, B, T, C, S,
+                       off, nbt);
     return hipGetLastError();
 }
 

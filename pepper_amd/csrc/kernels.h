@@ -77,6 +77,19 @@ hipError_t launch_gru_dec_h2(int H, const void* Xh, int ldxh, const float* bias,
                              const float* h0, int ldh0, float* hn, int ldhn, void* Y, int ldy, int B, int T,
                              hipStream_t stream);
 
+// The polish model's last decoder layer with dense1 (2H -> C <= 5 classes) contracted inside the step loop: no layer
+// output at all, per-direction partial logits P[dir][batch tile of 128][T][5][128 rows] f32 instead
+// (dense_partials_floats(B, T) floats).  Wd: pack_dense_head_h2 fragments.  head.hip's launch_polish_combine consumes P.
+void pack_dense_head_h2(const float* W, int C, int H, uint32_t* out);
+size_t dense_head_h2_words(int H);
+size_t dense_partials_floats(int B, int T);
+hipError_t launch_gru_dec_h2_dense(int H, const void* Xh, int ldxh, const float* bias, const void* Wp, const float* bhn,
+                                   const float* h0, int ldh0, float* hn, int ldhn, const void* Wd, float* P, int B, int T,
+                                   hipStream_t stream);
+// head.hip: acc[(b * S + off + t) * C + c] += softmax_c(P[0][..] + P[1][..] + bias) for b < B, t < T
+hipError_t launch_polish_combine(const float* P, const float* bias, float* acc, int B, int T, int C, int S, int off,
+                                 hipStream_t stream);
+
 // mlp_h2.hip: linear_2..5 (512 -> 512, SELU) + output layer + softmax fused, 64 rows per workgroup.
 void pack_mlp_weights_h2(const float* const* W, int NL, uint32_t* out);
 size_t mlp_weights_h2_words(int NL);

@@ -23,8 +23,9 @@
 #include "common.h"
 #include "kernels.h"
 
+// measured r02 (16384 windows, device-resident pass): 2.566 -> 2.596 M windows/s with nt on the once-through streams
 #ifndef PA_NT_DEFAULT
-#define PA_NT_DEFAULT false
+#define PA_NT_DEFAULT true
 #endif
 
 namespace {
@@ -383,7 +384,14 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 //   /root/reference/pepper/modules/python/models/simple_model.py:30,32
 // XG: the layer input is an h2 layer output Xh [B*T, KX] streamed through a two-slot LDS ring exactly as in
 // lstm_rec_h2_kernel (two k steps = 128 rows x 128 B per slot, two 16-byte chunks per thread per iteration).
-template <int H, int KX, bool XG = false, int SAUX = 0>
+// DENSE (with XG; the polish model's last decoder layer): the layer output never leaves the workgroup.  Its only
+// consumer is dense1 (2H -> C classes, /root/reference/pepper/modules/python/models/simple_model.py:34), so while step
+// s+1 contracts, the h_s rows still in LDS are multiplied with this direction's half of dense1's weights on
+// v_mfma_f32_16x16x32_f16 (same three-term split product; wave (u, rg) takes k in [32u, 32u+32) of row group rg: 12 small
+// MFMAs per step), the four k-quarter partials are summed through an LDS scratch behind a barrier the x ring needs
+// anyway, and 5 x 128 floats per step go to P[dir][batch tile][t][class][128 rows] (2.5 KB instead of the 128 KB of y).
+// polish_combine_kernel (head.hip) adds the two directions and the bias, takes the softmax and overlap-adds it.
+template <int H, int KX, bool XG = false, int SAUX = 0, bool DENSE = false>
 __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
                                                             const uint8_t* __restrict__ Xi, int F, int64_t xi_bstride,
                                                             const float* __restrict__ bias,
@@ -392,7 +400,11 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
                                                             const float* __restrict__ h0, int ldh0,
                                                             float* __restrict__ hn, int ldhn,
                                                             uint32_t* __restrict__ Y, int ldy, int B, int T,
-                                                            const uint32_t* __restrict__ Xh = nullptr, int ldxh = 0) {
+                                                            const uint32_t* __restrict__ Xh = nullptr, int ldxh = 0,
+                                                            const uint32_t* __restrict__ Wd = nullptr,
+                                                            float* __restrict__ P = nullptr) {
+    static_assert(!DENSE || (XG && H == 128), "the fused head belongs to the H = 128 layer fed by an h2 layer output");
+    constexpr int DC = 5;                        // classes of the fused head (columns of the 16-wide MFMA tile in use)
     constexpr int KT = H + KX, KS = KT / 16, KSH = H / 16, NT = H / 32, RG = 8 / NT, MTG = MT * RG;
     constexpr int NA = KX ? 4 : 3;
     constexpr int KL = XG ? H : KT;
@@ -428,6 +440,57 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
     for (int idx = tid; idx < MTG * ROWD; idx += 512) lds[idx] = 0u;
     __syncthreads();
     uint32_t* xring = lds + MTG * ROWD;
+    // DENSE: after the ring, this direction's dense1 fragments [k quarter 4][hi, lo][64 lanes][16 B] (8 KB, copied once)
+    // and the partial-logit scratch [k quarter 4][class DC][MTG rows] f32 (10 KB)
+    uint32_t* dw_lds = xring + 2 * XSLOT;
+    float* dsc = reinterpret_cast<float*>(dw_lds + 4 * 2 * 256);
+    if (DENSE) {
+        for (int idx = tid; idx < 4 * 2 * 256; idx += 512) dw_lds[idx] = Wd[(size_t)dir * (4 * 2 * 256) + idx];
+        __syncthreads();
+    }
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        DENSE ? P + ((size_t)dir * ((B + MTG - 1) / MTG) + btile) * T * (DC * MTG) : const_cast<float*>(bhn), 0, 0x7fffffff,
+        0x00020000);
+    auto dense_partials = [&]() {
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const int i16 = lane & 15, kg = lane >> 4;
+        const uint32_t* drow = lds + (rg * MT + i16) * ROWD + (u * 4 + kg) * 8;
+        const h8 bd_hi = *reinterpret_cast<const h8*>(dw_lds + (u * 2 + 0) * 256 + lane * 4);
+        const h8 bd_lo = *reinterpret_cast<const h8*>(dw_lds + (u * 2 + 1) * 256 + lane * 4);
+        h8 ah[4], al[4];
+        f32x4v dacc[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            ah[rt] = *reinterpret_cast<const h8*>(drow + rt * 16 * ROWD);
+            al[rt] = *reinterpret_cast<const h8*>(drow + rt * 16 * ROWD + 4);
+            dacc[rt] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) dacc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt], bd_hi, dacc[rt], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) dacc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bd_lo, dacc[rt], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) dacc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt], bd_hi, dacc[rt], 0, 0, 0);
+        // D: column lane & 15 = class, rows 4 * (lane >> 4) + r of row tile rt
+        if (i16 < DC) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+                *reinterpret_cast<f32x4v*>(dsc + (u * DC + i16) * MTG + rg * MT + rt * 16 + kg * 4) = dacc[rt];
+        }
+    };
+    // behind a barrier: sum the four k quarters, 4-byte stores coalesced over the 128 rows
+    auto dense_store = [&](int tp) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            // value index = class * MTG + row; the second round has 128 values for 512 threads: the surplus threads
+            // repeat the last one (same address, same bits) so the unrolled k step stays free of control flow
+            int v = tid + 512 * k;
+            v = v < DC * MTG ? v : DC * MTG - 1;
+            const float sum = (dsc[v] + dsc[DC * MTG + v]) + (dsc[2 * DC * MTG + v] + dsc[3 * DC * MTG + v]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), prs, (unsigned)v * 4u,
+                                                  (unsigned)tp * (unsigned)(DC * MTG * 4), 0);
+        }
+    };
     const __amdgpu_buffer_rsrc_t xgrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(XG ? Xh + (size_t)b0 * T * ldxh : Wp), 0, 0x7fffffff, 0x00020000);
     // staging: chunk q of thread tid covers row (tid / 8) + 64 q, 16-byte chunk tid % 8
@@ -459,14 +522,26 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
         return odd ? (got | (ulo << 16)) : (uhi | (got << 16));
     };
 
+    // exact f32 h_{t-1} of this lane's 32 elements (the z * h term and the final state).  The forms that sit at the
+    // 256-register limit of two waves per SIMD keep the last HL of them in a per-wave private LDS strip [HL][64 lanes]
+    // instead of registers (the gate phase has LDS slots to spare; same trick as the LSTM's cell state): all of row
+    // tile 1 in the XG forms, half of it in the wide-input form.
+    constexpr int HL = XG ? 16 : (KX >= 64 ? 15 : 0);
+    float* hls = reinterpret_cast<float*>(lds + MTG * ROWD + (XG ? 2 * XSLOT : 0) + (DENSE ? 4 * 2 * 256 + 4 * DC * MTG : 0)) +
+                 wave * (HL * 64) + lane;
     f32x16 hreg[2], acc[2][NA];
+    auto h_get = [&](int m, int r) { return (m == 1 && r >= 16 - HL) ? hls[(r - (16 - HL)) * 64] : hreg[m][r]; };
+    auto h_set = [&](int m, int r, float v) {
+        if (m == 1 && r >= 16 - HL) hls[(r - (16 - HL)) * 64] = v;
+        else hreg[m][r] = v;
+    };
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
             const float hv = h0 != nullptr ? h0[(lb + dr) * ldh0 + dir * H + col] : 0.0f;
-            hreg[m][r] = hv;
+            h_set(m, r, hv);
             hl_dst[dr * ROWD] = h2_word(hv);
         }
     const float bn = bhn[dir * H + col];
@@ -555,8 +630,8 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
     constexpr int YI = YC < KS - 1 ? YC : KS - 1;                      // passes interleaved with the MFMAs
     const int yc_row = tid / CPR, yc_c = tid % CPR;
     const uint32_t* yc_src = lds + yc_row * ROWD + yc_c * 4;
-    const __amdgpu_buffer_rsrc_t ycrs =
-        __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)b0 * T * ldy + dir * H, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ycrs = __builtin_amdgcn_make_buffer_rsrc(
+        DENSE ? const_cast<uint32_t*>(Wp) : Y + (size_t)b0 * T * ldy + dir * H, 0, 0x7fffffff, 0x00020000);
     const unsigned yc_off = ((unsigned)(yc_row * T) * ldy + yc_c * 4) * 4u;
     auto yc_read = [&](int j) { return *reinterpret_cast<const u32x4*>(yc_src + j * YROWS * ROWD); };
     auto yc_write = [&](int j, int tp, u32x4 v) {
@@ -593,6 +668,10 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
         const int tp = step > 0 ? (dir ? t + 1 : t - 1) : t;   // time index of h_{s-1} (step 0: h0, rewritten later)
         // ---------------- MFMA phase ----------------
         {
+            if (DENSE) {
+                dense_partials();                       // head partials of h_{s-1} (step 0: of h0, rewritten by step 1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
             Frag ring[2];
             load_step(0, ring[0]);
             u32x4 ycv = {0, 0, 0, 0};
@@ -606,12 +685,13 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
                     if (s == 0) xg_load(0, t);
                     if (s == 1) xg_load(1, t);
                     if (s >= KSH - 1 && ((s - (KSH - 1)) & 1) == 0 && (s - (KSH - 1)) / 2 < NXI) lds_barrier();
+                    if (DENSE && s == KSH - 1) dense_store(tp);     // the scratch is complete behind that barrier
                     if (s >= KSH - 3 && ((s - (KSH - 3)) & 1) == 0 && (s - (KSH - 3)) / 2 < NXI) xg_store((s - (KSH - 3)) / 2);
                     if (s >= KSH - 3 && ((s - (KSH - 7)) & 1) == 0 && (s - (KSH - 7)) / 2 < NXI) xg_load((s - (KSH - 7)) / 2, t);
                 }
                 if (s + 1 < KS) load_step(s + 1, ring[p ^ 1]);
-                if (s >= 1 && s <= YI) yc_write(s - 1, tp, ycv);
-                if (s < YI) ycv = yc_read(s);
+                if (!DENSE && s >= 1 && s <= YI) yc_write(s - 1, tp, ycv);
+                if (!DENSE && s < YI) ycv = yc_read(s);
 #pragma unroll
                 for (int term = 0; term < 3; ++term) {
                     if (XU8 && s >= KSH && term == 0) continue;    // uint8 summaries: lo(a) == 0
@@ -641,8 +721,10 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (!DENSE) {
 #pragma unroll
-            for (int j = YI; j < YC; ++j) yc_write(j, tp, yc_read(j));     // passes that did not fit a k step
+                for (int j = YI; j < YC; ++j) yc_write(j, tp, yc_read(j));     // passes that did not fit a k step
+            }
         }
         // unfused: x part of the n gate for this step, in flight across the barrier
         f32x4 xn[2][4];
@@ -669,8 +751,8 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
                     const float zgate = fast_sigmoid(acc[m][1][r]);
                     const float xnv = KX ? acc[m][NA - 1][r] : xn[m][qd][e];
                     const float ngate = fast_tanh(xnv + rgate * acc[m][2][r]);
-                    const float hv = (1.0f - zgate) * ngate + zgate * hreg[m][r];
-                    hreg[m][r] = hv;
+                    const float hv = (1.0f - zgate) * ngate + zgate * h_get(m, r);
+                    h_set(m, r, hv);
                     hl_dst[dr * ROWD] = h2_word(hv);
                 }
                 if (step + 1 < T) seed_chunk(m, qd, tn);
@@ -681,15 +763,21 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 
     {
         const int tl = dir ? 0 : T - 1;
+        if (DENSE) {
+            dense_partials();
+            __syncthreads();
+            dense_store(tl);
+        } else {
 #pragma unroll
-        for (int j = 0; j < YC; ++j) yc_write(j, tl, yc_read(j));
+            for (int j = 0; j < YC; ++j) yc_write(j, tl, yc_read(j));
+        }
     }
     if (hn != nullptr) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                hn[(lb + 32 * m + (r & 3) + 8 * (r >> 2)) * ldhn + dir * H + col] = hreg[m][r];
+                hn[(lb + 32 * m + (r & 3) + 8 * (r >> 2)) * ldhn + dir * H + col] = h_get(m, r);
     }
 }
 
@@ -1016,12 +1104,17 @@ hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, 
         const int KX = gru_fused_input_kx(H, F);
         if (KX == 16) {
             const size_t lds = (size_t)2 * MT * ((128 + 16) * 4 + 16);
-            hipLaunchKernelGGL((gru_rec_h2_kernel<128, 16>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
-                               F, x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
-                               static_cast<uint32_t*>(Y), ldy, B, T);
+            if (stream_nt())
+                hipLaunchKernelGGL((gru_rec_h2_kernel<128, 16, false, 2>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
+                                   F, x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
+                                   static_cast<uint32_t*>(Y), ldy, B, T);
+            else
+                hipLaunchKernelGGL((gru_rec_h2_kernel<128, 16>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
+                                   F, x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
+                                   static_cast<uint32_t*>(Y), ldy, B, T);
         } else if (KX == 128) {
             if ((x_bstride & 3) || (reinterpret_cast<uintptr_t>(X) & 3)) return hipErrorInvalidValue;
-            const size_t lds = (size_t)2 * MT * ((128 + 128) * 4 + 16);
+            const size_t lds = (size_t)2 * MT * ((128 + 128) * 4 + 16) + (size_t)8 * 15 * 64 * 4;   // + f32 h strip (160 KB in all)
             hipLaunchKernelGGL((gru_rec_h2_kernel<128, 128>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
                                F, x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
                                static_cast<uint32_t*>(Y), ldy, B, T);
@@ -1037,6 +1130,44 @@ hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, 
     return hipGetLastError();
 }
 
+// dense1 [C, 2H] (C <= 5, H = 128) -> per-direction B fragments of v_mfma_f32_16x16x32_f16 in h2 form:
+// [dir][k quarter 4][hi, lo][64 lanes][8 halves]; lane l holds W[j = l & 15][dir*H + 32 q + 8 (l >> 4) + e] (0 for j >= C).
+void pack_dense_head_h2(const float* W, int C, int H, uint32_t* out) {
+    _Float16* o = reinterpret_cast<_Float16*>(out);
+    for (int d = 0; d < 2; ++d)
+        for (int q = 0; q < H / 32; ++q)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int j = l & 15, k = d * H + 32 * q + 8 * (l >> 4) + e;
+                    const float v = j < C ? W[(size_t)j * 2 * H + k] : 0.0f;
+                    const _Float16 hi = (_Float16)v;
+                    const size_t base = (((size_t)d * (H / 32) + q) * 2) * 512 + (size_t)l * 8 + e;
+                    o[base] = hi;
+                    o[base + 512] = (_Float16)(v - (float)hi);
+                }
+}
+
+size_t dense_head_h2_words(int H) { return (size_t)2 * (H / 32) * 2 * 256; }
+size_t dense_partials_floats(int B, int T) { return (size_t)2 * ((B + 2 * MT - 1) / (2 * MT)) * T * 5 * (2 * MT); }
+
+hipError_t launch_gru_dec_h2_dense(int H, const void* Xh, int ldxh, const float* bias, const void* Wp, const float* bhn,
+                                   const float* h0, int ldh0, float* hn, int ldhn, const void* Wd, float* P, int B, int T,
+                                   hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    if (H != 128 || (ldxh & 7) || !Wd || !P) return hipErrorInvalidValue;
+    const int nbt = (B + 2 * MT - 1) / (2 * MT);
+    const int grid = 2 * ((nbt + 3) / 4) * 4;
+    const size_t lds = (size_t)2 * MT * (128 * 4 + 16) + (size_t)2 * 2 * MT * 36 * 4 + (size_t)4 * 2 * 1024 + (size_t)4 * 5 * 2 * MT * 4 +
+                       (size_t)8 * 16 * 64 * 4;   // h rows + x ring + dense1 fragments + partial-logit scratch + f32 h strip
+#define PA_GDD(AUX_)                                                                                                   \
+    hipLaunchKernelGGL((gru_rec_h2_kernel<128, 256, true, AUX_, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, \
+                       (const uint8_t*)nullptr, 0, (int64_t)0, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn, \
+                       (uint32_t*)nullptr, 8, B, T, static_cast<const uint32_t*>(Xh), ldxh, static_cast<const uint32_t*>(Wd), P)
+    if (stream_nt()) PA_GDD(2); else PA_GDD(0);
+#undef PA_GDD
+    return hipGetLastError();
+}
+
 hipError_t launch_gru_dec_h2(int H, const void* Xh, int ldxh, const float* bias, const void* Wp, const float* bhn,
                              const float* h0, int ldh0, float* hn, int ldhn, void* Y, int ldy, int B, int T,
                              hipStream_t stream) {
@@ -1048,10 +1179,15 @@ hipError_t launch_gru_dec_h2(int H, const void* Xh, int ldxh, const float* bias,
     if (ring) {
         const int nbt = (B + 2 * MT - 1) / (2 * MT);
         const int grid = 2 * ((nbt + 3) / 4) * 4;
-        const size_t lds = (size_t)2 * MT * (128 * 4 + 16) + (size_t)2 * 2 * MT * 36 * 4;
-        hipLaunchKernelGGL((gru_rec_h2_kernel<128, 256, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0,
-                           (const uint8_t*)nullptr, 0, (int64_t)0, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn,
-                           ldhn, static_cast<uint32_t*>(Y), ldy, B, T, static_cast<const uint32_t*>(Xh), ldxh);
+        const size_t lds = (size_t)2 * MT * (128 * 4 + 16) + (size_t)2 * 2 * MT * 36 * 4 + (size_t)8 * 16 * 64 * 4;
+        if (stream_nt())
+            hipLaunchKernelGGL((gru_rec_h2_kernel<128, 256, true, 2>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0,
+                               (const uint8_t*)nullptr, 0, (int64_t)0, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn,
+                               ldhn, static_cast<uint32_t*>(Y), ldy, B, T, static_cast<const uint32_t*>(Xh), ldxh);
+        else
+            hipLaunchKernelGGL((gru_rec_h2_kernel<128, 256, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0,
+                               (const uint8_t*)nullptr, 0, (int64_t)0, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn,
+                               ldhn, static_cast<uint32_t*>(Y), ldy, B, T, static_cast<const uint32_t*>(Xh), ldxh);
         return hipGetLastError();
     }
     const size_t lds = (size_t)MT * ((128 + 256) * 4 + 16);

@@ -111,3 +111,41 @@ def test_polish_many_chunks_properties():
     pick = [0, 127, 128, 299]
     rl, rp, inter = models_np.polish_predict_chunks(sd, imgs[pick], 128, return_intermediates=True)
     assert np.abs(a0[pick] - inter["acc"]).max() < TOL
+
+
+def test_fused_head_equals_the_separate_head():
+    """The default predict path contracts dense1 inside the last decoder layer's step loop (gru_rec_h2_kernel<.., DENSE>
+    + polish_combine_kernel; no layer output in HBM); PA_FUSE_HEAD=0 keeps that layer's output and runs dense1 +
+    softmax + overlap-add as their own kernel.  Same three-term split products in a different summation order: the
+    accumulators agree far inside the bar, ragged tails and more than one 128-row batch tile included."""
+    from pepper_amd import _lib
+    sd = synthetic.polish_state_dict(seed=33, gain=2.0)
+    imgs = synthetic.polish_chunks(261, seed=77)
+    imgs[5, 300:] = 0
+    saved = os.environ.get("PA_FUSE_HEAD")
+    try:
+        os.environ.pop("PA_FUSE_HEAD", None)
+        m = _model(sd)
+        _lib.check(_lib.load().pa_profile_enable(m.handle, 1))
+        l0, p0, a0 = m.predict_chunks(torch.from_numpy(imgs).cuda(), return_acc=True)
+        labels_fused = set(_lib.profile_dict(m.handle))
+        m.close()
+        os.environ["PA_FUSE_HEAD"] = "0"
+        m = _model(sd)
+        _lib.check(_lib.load().pa_profile_enable(m.handle, 1))
+        l1, p1, a1 = m.predict_chunks(torch.from_numpy(imgs).cuda(), return_acc=True)
+        labels_split = set(_lib.profile_dict(m.handle))
+        m.close()
+    finally:
+        if saved is None:
+            os.environ.pop("PA_FUSE_HEAD", None)
+        else:
+            os.environ["PA_FUSE_HEAD"] = saved
+    assert "gru_dec_h2_fused_dense" in labels_fused and "head_combine_acc" in labels_fused, labels_fused
+    assert "gru_dec_h2_fused" in labels_split and "dense_softmax_acc" in labels_split, labels_split
+    a0, a1 = a0.cpu().numpy(), a1.cpu().numpy()
+    assert np.abs(a0 - a1).max() < 5e-6
+    pick = [0, 5, 127, 128, 255, 256, 260]
+    rl, rp, inter = models_np.polish_predict_chunks(sd, imgs[pick], 128, return_intermediates=True)
+    assert np.abs(a0[pick] - inter["acc"]).max() < TOL
+    _check_labels(l0.cpu().numpy()[pick], p0.cpu().numpy()[pick], inter["acc"], rl, rp, inter["phred_f32"])

@@ -1,0 +1,70 @@
+"""Register budget of the shipped HIP kernels, read from the compiler's own metadata (hipcc -save-temps): no kernel may
+spill vector registers inside its matrix loop.  The step loops (rnn_h2.hip), the fused MLP tail, the heads and the
+encoders must not spill at all (gru_rec_h2_kernel<128,256,true> carried 28 spilled VGPRs);
+gemm_h2_kernel's 128x128 wave tile takes all 512 registers and parks eight accumulator registers in scratch for its
+bias epilogue -- allowed only outside the span of its MFMAs.  CPU only: hipcc cross-compiles gfx950."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pepper_amd", "csrc")
+STRICT = ["rnn_h2.hip", "mlp_h2.hip", "head.hip", "encoder.hip"]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _asm(tmp_path, source):
+    if not os.path.exists(_hipcc()):
+        pytest.skip("hipcc not available")
+    out = tmp_path / (source + ".o")
+    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", source, "-o", str(out), "-save-temps=obj"],
+                   cwd=CSRC, check=True, capture_output=True)
+    path = tmp_path / (source.replace(".hip", "") + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+    return path.read_text()
+
+
+def _kernels(asm):
+    """{kernel symbol: (vgpr_count, vgpr_spill_count)} from the .amdhsa metadata block."""
+    out = {}
+    for block in asm.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        out[name] = (int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)),
+                     int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)))
+    return out
+
+
+@pytest.mark.parametrize("source", STRICT)
+def test_no_vector_register_spills(tmp_path, source):
+    kernels = _kernels(_asm(tmp_path, source))
+    assert kernels, source
+    spilled = {k: v for k, v in kernels.items() if v[1] != 0}
+    assert not spilled, spilled
+    if source == "rnn_h2.hip":
+        # the instantiations the polish and variant models launch, by their mangled template arguments
+        for needle in ("gru_rec_h2_kernelILi128ELi256ELb1ELi2ELb1E", "gru_rec_h2_kernelILi128ELi256ELb1ELi2ELb0E",
+                       "gru_rec_h2_kernelILi128ELi16E", "gru_rec_h2_kernelILi128ELi128E",
+                       "lstm_rec_h2_kernelILi256ELi512ELb1ELb1ELi2E", "lstm_rec_h2_kernelILi256ELi32ELb1ELb0ELi2E"):
+            assert any(needle in k for k in kernels), needle
+
+
+def test_gemm_h2_spills_stay_out_of_the_matrix_loop(tmp_path):
+    asm = _asm(tmp_path, "gemm_h2.hip")
+    kernels = _kernels(asm)
+    lines = asm.split("\n")
+    for name, (vgprs, spills) in kernels.items():
+        assert spills <= 9, (name, spills)
+        if spills == 0:
+            continue
+        start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
+        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+        body = lines[start:end]
+        mfma = [i for i, l in enumerate(body) if "v_mfma" in l]
+        scratch = [i for i, l in enumerate(body) if "scratch_" in l]
+        assert mfma and scratch
+        inside = [i for i in scratch if mfma[0] < i < mfma[-1]]
+        assert not inside, (name, len(inside))

@@ -21,16 +21,18 @@ from collections import OrderedDict, defaultdict
 
 # kernel symbol prefix -> label bench.py's profiler uses
 LABELS = [
-    ("lstm_rec_h2_kernel<256, 512, true, true>", "lstm_dec_h2_fused"),
-    ("lstm_rec_h2_kernel<256, 32, true, false>", "lstm_rec_h2_fused_in"),
+    ("lstm_rec_h2_kernel<256, 512, true, true", "lstm_dec_h2_fused"),
+    ("lstm_rec_h2_kernel<256, 32, true, false", "lstm_rec_h2_fused_in"),
     ("gemm_h2_kernel", "gemm_h2_linear_1"),
     ("mlp_tail_h2_kernel", "mlp_tail_h2"),
     ("splitk_finish_kernel", "splitk_finish"),
     ("gru_rec_h2_kernel<128, 16", "gru_rec_h2_fused_in"),
-    ("gru_rec_h2_kernel<128, 256, true, true>", "gru_dec_h2_fused_dense"),
+    ("gru_rec_h2_kernel<128, 256, true, 2, true>", "gru_dec_h2_fused_dense"),
+    ("gru_rec_h2_kernel<128, 256, true, 0, true>", "gru_dec_h2_fused_dense"),
     ("gru_rec_h2_kernel<128, 256", "gru_dec_h2_fused"),
     ("gru_dec_h2_kernel", "gru_dec_h2_fused"),
     ("polish_dense_acc_h2_kernel", "dense_softmax_acc"),
+    ("polish_combine_kernel", "head_combine_acc"),
     ("polish_finalize_kernel", "polish_finalize"),
     ("pileup_count_kernel", "pileup_count"),
     ("apply_events_kernel", "apply_events"),

@@ -32,5 +32,13 @@ timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_fe
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_write_polish -o polish -- $PROFP > $R/gpurun_out/${TAG}_write_polish.log 2>&1
 fi
 cd $R
-find gpurun_out -name "*.db" -size +20M -delete
+# summaries are made here, on the box: the databases carry every loaded code object's symbols and can be tens of MB each
+python tools/pmc_summary.py --model variant --units 16384 --out gpurun_out/${TAG}_variant --command "rocprofv3 --kernel-trace [--stats | --pmc ...] -- $PROF" \
+    gpurun_out/${TAG}_stats gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_mfma > /dev/null
+if [ "${SKIP_POLISH:-0}" != "1" ]; then
+python tools/pmc_summary.py --model polish --units 16384 --out gpurun_out/${TAG}_polish --command "rocprofv3 --kernel-trace [--stats | --pmc ...] -- $PROFP" \
+    gpurun_out/${TAG}_stats_polish gpurun_out/${TAG}_fetch_polish gpurun_out/${TAG}_write_polish > /dev/null
+fi
 ls -la gpurun_out/${TAG}_*/ | head -40
+find gpurun_out -name "*.db" -size +2M -delete
+head -12 gpurun_out/${TAG}_variant_kernel_stats.txt
