@@ -6,7 +6,7 @@ TAG=${TAG:-r02}
 mkdir -p $R/gpurun_out
 cd $R
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-timeout 900 python -m pytest tests -q -m gpu -x > gpurun_out/${TAG}_gpu_tests.log 2>&1; tail -5 gpurun_out/${TAG}_gpu_tests.log
+timeout 900 python -m pytest tests -q -m gpu > gpurun_out/${TAG}_gpu_tests.log 2>&1; tail -15 gpurun_out/${TAG}_gpu_tests.log
 timeout 120 python __graft_entry__.py smoke > gpurun_out/${TAG}_smoke.log 2>&1; tail -1 gpurun_out/${TAG}_smoke.log
 fi
 timeout 500 python bench.py > gpurun_out/${TAG}_bench_variant.json 2> gpurun_out/${TAG}_bench_variant.err; tail -c 1500 gpurun_out/${TAG}_bench_variant.json; tail -3 gpurun_out/${TAG}_bench_variant.err
