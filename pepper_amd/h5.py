@@ -159,11 +159,17 @@ class File(object):
         return buf.raw[:needed.value]
 
     @_locked
-    def read_polish_chunks(self, names, seq_len, features, contig_width=256):
-        """summaries/<name> groups of a polish image file as bulk arrays (one library call for the block)."""
+    def read_polish_chunks(self, names, seq_len, features, contig_width=256, out=None):
+        """summaries/<name> groups of a polish image file as bulk arrays (one library call for the block).
+        out = (images u8 [n, seq, features], position i64 [n, seq], index i64 [n, seq]) to read into caller memory."""
         n = len(names)
-        images = np.empty((n, seq_len, features), np.uint8)
-        position, index = np.empty((n, seq_len), np.int64), np.empty((n, seq_len), np.int64)
+        if out is not None:
+            images, position, index = out
+            assert images.shape == (n, seq_len, features) and images.dtype == np.uint8 and images.flags.c_contiguous
+            assert position.shape == (n, seq_len) and position.dtype == np.int64 and index.shape == (n, seq_len)
+        else:
+            images = np.empty((n, seq_len, features), np.uint8)
+            position, index = np.empty((n, seq_len), np.int64), np.empty((n, seq_len), np.int64)
         start, end, chunk = np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.int64)
         contigs = np.zeros(n, dtype=f"S{contig_width}")
         blob = b"".join(s.encode() + b"\0" for s in names)

@@ -1,0 +1,396 @@
+"""Host side of the predict loops at device speed: reader and writer PROCESSES per lane of image files.
+
+libhdf5 is not thread-safe -- every call of one process goes through one lock -- and the step hand-off formats are made
+of many small groups (variant: six datasets per 512-window batch on the way out; polish: seven datasets per 1000-row
+chunk on the way in and four on the way out), so one process tops out far below one MI355X (r01: variant HDF5 -> HDF5
+1.45 M windows/s against 2.5 M on the device, polish 4.7 k chunks/s against 185 k).  Files shard naturally
+(RunInference.py:104-110, call_consensus.py:93-97), so the image files of a caller are dealt over `lanes`; a lane is
+
+    reader process  --slots-->  the caller's GPU loop  --slots-->  writer process  -> pepper_prediction_<rank>[_<lane>].hdf
+
+Slots are shared-memory segments (multiprocessing.shared_memory) that the GPU process page-locks once
+(hipHostRegister), so a reader's libhdf5 read lands where the H2D copy starts and the D2H copy lands where the writer's
+libhdf5 write starts: no copies in between, no pickling of bulk arrays.  A region's chunks (polish) and a file's batch
+numbering (variant) never span lanes because an image file never does; the next stage globs every *.hdf of the
+directory (FindCandidates.py:151-166, perform_stitch.py:44-72), exactly as it does for the per-GPU / per-thread files the
+reference writes.
+
+Worker processes are spawned (the parent holds a HIP context) and import only numpy + the libhdf5 binding.
+"""
+import os
+import sys
+import traceback
+from multiprocessing import get_context, shared_memory
+
+import numpy as np
+
+ALIGN = 256
+
+
+def _align(n):
+    return (n + ALIGN - 1) // ALIGN * ALIGN
+
+
+def shm_room(nbytes):
+    """Is there room for nbytes of shared memory?  (tmpfs allocates lazily: an over-full /dev/shm ends in SIGBUS)"""
+    try:
+        st = os.statvfs("/dev/shm")
+        return st.f_bavail * st.f_frsize > nbytes + (1 << 30)
+    except OSError:
+        return False
+
+
+def _attach(name):
+    """Attach to a segment the parent owns; the attaching process must not let its resource tracker unlink it."""
+    shm = shared_memory.SharedMemory(name=name)
+    try:
+        from multiprocessing import resource_tracker
+        resource_tracker.unregister(shm._name, "shared_memory")
+    except Exception:
+        pass
+    return shm
+
+
+class Slots(object):
+    """`count` shared segments of `nbytes`, created (and page-locked for the GPU) by the process that runs the device."""
+
+    def __init__(self, count, nbytes, register=True):
+        self.nbytes = int(nbytes)
+        self.segments = [shared_memory.SharedMemory(create=True, size=max(1, self.nbytes)) for _ in range(count)]
+        self.names = [s.name for s in self.segments]
+        self.registered = []
+        if register:
+            try:
+                import torch
+                rt = torch.cuda.cudart()
+                for s in self.segments:
+                    ptr = np.frombuffer(s.buf, np.uint8).ctypes.data
+                    rc = rt.cudaHostRegister(ptr, self.nbytes, 0)
+                    if int(rc) == 0:
+                        self.registered.append(ptr)
+            except Exception:
+                pass      # pageable slots still work, the copies just stage through the runtime
+
+    def view(self, i, offset, shape, dtype):
+        return np.ndarray(shape, dtype, buffer=self.segments[i].buf, offset=offset)
+
+    def close(self):
+        if self.registered:
+            try:
+                import torch
+                rt = torch.cuda.cudart()
+                for ptr in self.registered:
+                    rt.cudaHostUnregister(ptr)
+            except Exception:
+                pass
+            self.registered = []
+        for s in self.segments:
+            try:
+                s.unlink()                  # the name goes first: close() refuses while numpy views are alive
+            except Exception:
+                pass
+            try:
+                s.close()
+            except Exception:
+                pass
+        self.segments = []
+
+
+def deal_files(files, lanes):
+    """Largest file first onto the least loaded lane (files keep their order inside a lane)."""
+    sizes = [os.path.getsize(f) for f in files]
+    load = [0] * lanes
+    out = [[] for _ in range(lanes)]
+    for i in sorted(range(len(files)), key=lambda k: (-sizes[k], k)):
+        lane = min(range(lanes), key=lambda c: (load[c], c))
+        out[lane].append(i)
+        load[lane] += sizes[i]
+    return [[files[i] for i in sorted(idx)] for idx in out if idx]
+
+
+class LaneError(RuntimeError):
+    pass
+
+
+def _close_all(segments):
+    for s in segments:
+        try:
+            s.close()
+        except BufferError:      # a numpy view is still alive; the mapping goes with the process
+            pass
+
+
+def _guarded(fn, lane, result_q, args):
+    """Worker body: an exception travels to the parent as ('error', lane, text) on the result queue."""
+    try:
+        fn(lane, result_q, *args)
+    except BaseException:
+        result_q.put(("error", lane, traceback.format_exc()))
+
+
+# ============================================================================================================
+# polish: summaries/<name> chunk groups -> predictions/<contig>/<contig>-<start>-<end>/<chunk_id>
+# ============================================================================================================
+class PolishLayout(object):
+    """Byte layout of one slot holding a block of up to `block` chunks."""
+
+    def __init__(self, block, seq_len, features):
+        self.block, self.seq_len, self.features = block, seq_len, features
+        self.o_image = 0
+        self.o_position = _align(block * seq_len * features)
+        self.o_index = self.o_position + _align(block * seq_len * 8)
+        self.o_labels = self.o_index + _align(block * seq_len * 8)
+        self.o_phred = self.o_labels + _align(block * seq_len)
+        self.nbytes = self.o_phred + _align(block * seq_len)
+
+    def views(self, buf, n):
+        s, f = self.seq_len, self.features
+        mk = lambda off, shape, dt: np.ndarray(shape, dt, buffer=buf, offset=off)   # noqa: E731
+        return (mk(self.o_image, (n, s, f), np.uint8), mk(self.o_position, (n, s), np.int64), mk(self.o_index, (n, s), np.int64),
+                mk(self.o_labels, (n, s), np.uint8), mk(self.o_phred, (n, s), np.uint8))
+
+
+def _polish_reader(lane, result_q, files, slot_names, layout_args, free_q):
+    from pepper_amd import h5
+    layout = PolishLayout(*layout_args)
+    segs = [_attach(n) for n in slot_names]
+    try:
+        for path in files:
+            with h5.File(path, 'r') as f:
+                if 'summaries' not in f:
+                    continue
+                names = f.keys('summaries')
+                for a in range(0, len(names), layout.block):
+                    part = names[a:a + layout.block]
+                    slot = free_q.get()
+                    image, position, index, _, _ = layout.views(segs[slot].buf, len(part))
+                    contigs, start, end, chunk = f.read_polish_chunks(part, layout.seq_len, layout.features,
+                                                                      out=(image, position, index))[:4]
+                    result_q.put(("block", lane, slot, len(part), (contigs, start, end, chunk)))
+        result_q.put(("read_done", lane))
+    finally:
+        _close_all(segs)
+
+
+def _polish_writer(lane, result_q, output_filename, slot_names, layout_args, write_q, free_q):
+    from pepper_amd.polish.DataStorePredict import DataStore
+    layout = PolishLayout(*layout_args)
+    segs = [_attach(n) for n in slot_names]
+    store = DataStore(output_filename, mode='w')
+    try:
+        while True:
+            item = write_q.get()
+            if item is None:
+                break
+            slot, n, (contigs, start, end, chunk) = item
+            _, position, index, labels, phred = layout.views(segs[slot].buf, n)
+            store.write_predictions_block(contigs, start, end, chunk, position, index, labels, phred)
+            free_q.put(slot)
+        result_q.put(("write_done", lane))
+    finally:
+        store.close()
+        _close_all(segs)
+
+
+def polish_reader(lane, result_q, *args):
+    _guarded(_polish_reader, lane, result_q, args)
+
+
+def polish_writer(lane, result_q, *args):
+    _guarded(_polish_writer, lane, result_q, args)
+
+
+def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1000, features=10, slots_per_lane=3, log=None):
+    """Run the polish predict loop over `files` with `lanes` reader/writer process pairs.
+
+    predict_block(image u8 [n, seq, features], labels u8 [n, seq], phred u8 [n, seq]) runs the device pass on host
+    arrays that live in page-locked shared memory and fills labels / phred.  Output files: `<output_stem>.hdf` for one
+    lane, `<output_stem>_<lane>.hdf` otherwise.  Returns the number of chunks processed."""
+    groups = deal_files(files, max(1, lanes))
+    lanes = len(groups)
+    if lanes == 0:
+        return 0
+    layout = PolishLayout(block, seq_len, features)
+    largs = (block, seq_len, features)
+    ctx = get_context("spawn")
+    slots = [Slots(slots_per_lane, layout.nbytes) for _ in range(lanes)]
+    result_q = ctx.Queue()
+    free_qs = [ctx.Queue() for _ in range(lanes)]
+    write_qs = [ctx.Queue() for _ in range(lanes)]
+    procs = []
+    done = 0
+    try:
+        for k in range(lanes):
+            for s in range(slots_per_lane):
+                free_qs[k].put(s)
+            out = output_stem + ".hdf" if lanes == 1 else "%s_%d.hdf" % (output_stem, k)
+            procs.append(ctx.Process(target=polish_reader, args=(k, result_q, groups[k], slots[k].names, largs, free_qs[k]),
+                                     daemon=True))
+            procs.append(ctx.Process(target=polish_writer, args=(k, result_q, out, slots[k].names, largs, write_qs[k], free_qs[k]),
+                                     daemon=True))
+        for p in procs:
+            p.start()
+        reading, writing = lanes, lanes
+        while writing:
+            msg = result_q.get()
+            kind, lane = msg[0], msg[1]
+            if kind == "error":
+                raise LaneError("lane %d failed:\n%s" % (lane, msg[2]))
+            if kind == "block":
+                _, _, slot, n, meta = msg
+                image, _, _, labels, phred = layout.views(slots[lane].segments[slot].buf, n)
+                predict_block(image, labels, phred)
+                del image, labels, phred
+                write_qs[lane].put((slot, n, meta))
+                done += n
+                if log is not None:
+                    log(done)
+            elif kind == "read_done":
+                reading -= 1
+                write_qs[lane].put(None)
+            elif kind == "write_done":
+                writing -= 1
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for s in slots:
+            s.close()
+    return done
+
+
+# ============================================================================================================
+# variant: summaries/<region> image groups -> predictions/batch_<n>
+# ============================================================================================================
+def _variant_reader(lane, result_q, image_directory, files, slot_names, slot_bytes, free_q):
+    from pepper_amd.variant.models.dataloader_predict import SequenceDataset
+    segs = [_attach(n) for n in slot_names]
+    try:
+        for path in files:
+            slot = free_q.get()
+
+            def alloc(n, window, features, _slot=slot):
+                if n * window * features > slot_bytes:
+                    raise LaneError("%s holds %d windows, more than a staging slot of %d bytes" % (path, n, slot_bytes))
+                return np.ndarray((n, window, features), np.int8, buffer=segs[_slot].buf)
+            data = SequenceDataset(image_directory, path, None, alloc)
+            meta = (data.all_contigs, data.all_positions, data.all_depths, data.candidate_blob, data.candidate_offsets,
+                    data.all_candidate_frequency, tuple(data.all_images.shape))
+            del data
+            result_q.put(("block", lane, slot, meta))
+        result_q.put(("read_done", lane))
+    finally:
+        _close_all(segs)
+
+
+def _variant_writer(lane, result_q, output_filename, batch_size, write_q):
+    from pepper_amd.variant.DataStorePredict import DataStore
+    store = DataStore(output_filename, mode='w')
+    batch_no = 0
+    try:
+        while True:
+            item = write_q.get()
+            if item is None:
+                break
+            contigs, positions, depths, blob, offsets, freqs, probs = item
+            n = len(positions)
+            for s in range(0, n, batch_size):
+                e = min(n, s + batch_size)
+                store.write_prediction_arrays(batch_no, contigs[s:e], positions[s:e], depths[s:e], blob, offsets[s:e],
+                                              freqs[s:e], probs[s:e])
+                batch_no += 1
+        result_q.put(("write_done", lane, batch_no))
+    finally:
+        store.close()
+
+
+def variant_reader(lane, result_q, *args):
+    _guarded(_variant_reader, lane, result_q, args)
+
+
+def variant_writer(lane, result_q, *args):
+    _guarded(_variant_writer, lane, result_q, args)
+
+
+def variant_lanes(image_directory, files, output_stem, forward_block, batch_size, lanes, slots_per_lane=2, log=None):
+    """Run the variant predict loop over `files` with `lanes` reader/writer process pairs.
+
+    forward_block(images int8 [n, window, features]) -> float32 probabilities [n, classes] runs the device pass on a
+    host array in page-locked shared memory.  Output: `<output_stem>.hdf` for one lane, `<output_stem>_<lane>.hdf`
+    otherwise; batch_<n> numbering runs over the files of a lane, as it runs over the files of a caller in the reference
+    (predict_distributed_gpu.py:40-67).  Returns (batches written, windows processed)."""
+    groups = deal_files(files, max(1, lanes))
+    lanes = len(groups)
+    if lanes == 0:
+        return 0, 0
+    slot_bytes = max(os.path.getsize(f) for f in files)       # the image block of a file is smaller than the file
+    ctx = get_context("spawn")
+    slots = [Slots(slots_per_lane, slot_bytes) for _ in range(lanes)]
+    result_q = ctx.Queue()
+    free_qs = [ctx.Queue() for _ in range(lanes)]
+    write_qs = [ctx.Queue() for _ in range(lanes)]
+    procs = []
+    windows = batches = 0
+    try:
+        for k in range(lanes):
+            for s in range(slots_per_lane):
+                free_qs[k].put(s)
+            out = output_stem + ".hdf" if lanes == 1 else "%s_%d.hdf" % (output_stem, k)
+            procs.append(ctx.Process(target=variant_reader, args=(k, result_q, image_directory, groups[k], slots[k].names,
+                                                                   slot_bytes, free_qs[k]), daemon=True))
+            procs.append(ctx.Process(target=variant_writer, args=(k, result_q, out, batch_size, write_qs[k]), daemon=True))
+        for p in procs:
+            p.start()
+        writing = lanes
+        files_done = 0
+        while writing:
+            msg = result_q.get()
+            kind, lane = msg[0], msg[1]
+            if kind == "error":
+                raise LaneError("lane %d failed:\n%s" % (lane, msg[2]))
+            if kind == "block":
+                _, _, slot, meta = msg
+                contigs, positions, depths, blob, offsets, freqs, shape = meta
+                if shape[0]:
+                    images = slots[lane].view(slot, 0, shape, np.int8)
+                    probs = forward_block(images)
+                    del images
+                    write_qs[lane].put((contigs, positions, depths, blob, offsets, freqs, np.asarray(probs)))
+                    windows += shape[0]
+                free_qs[lane].put(slot)               # the forward has consumed the images
+                files_done += 1
+                if log is not None:
+                    log(files_done)
+            elif kind == "read_done":
+                write_qs[lane].put(None)
+            elif kind == "write_done":
+                writing -= 1
+                batches += msg[2]
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for s in slots:
+            s.close()
+    return batches, windows
+
+
+def default_lanes(files, requested, small=64 << 20):
+    """options.num_workers > 0: that many lanes (at most one per file).  0: process lanes only when the job is big
+    enough to pay for spawning them (interpreter start-up is ~0.3 s per process)."""
+    if not files:
+        return 0
+    if requested and requested > 0:
+        return min(int(requested), len(files))
+    total = sum(os.path.getsize(f) for f in files)
+    if total < small or len(files) < 2:
+        return 0
+    return min(len(files), 8)
+
+
+if __name__ == "__main__":
+    sys.exit(0)

@@ -25,7 +25,7 @@ def _log(msg):
     sys.stderr.flush()
 
 
-DEVICE_CHUNKS = 4096     # chunks per device pass (19 windows of 100 rows each)
+DEVICE_CHUNKS = 8192     # chunks per device pass (19 windows of 100 rows each; 128 chunks per workgroup and direction)
 
 
 def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size, num_workers, rank, device_id,
@@ -36,6 +36,19 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
             model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS, image_features=ImageSizeOptions.IMAGE_HEIGHT,
             seq_len=ImageSizeOptions.SEQ_LENGTH, num_classes=ImageSizeOptions.TOTAL_LABELS)
     model.eval()
+    # big jobs (or num_workers > 0, the reference's DataLoader(num_workers=...)): reader and writer processes per lane of
+    # image files around this process's GPU loop; libhdf5's one-lock-per-process is what bounds the loop below
+    from pepper_amd import hostpipe
+    lanes = hostpipe.default_lanes(file_chunks, num_workers)
+    layout = hostpipe.PolishLayout(DEVICE_CHUNKS, ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT)
+    if lanes > 0 and hostpipe.shm_room(2 * lanes * layout.nbytes):
+        def log(done):
+            if rank == 0:
+                _log("INFO: CHUNKS PROCESSED " + str(done) + ".")
+        hostpipe.polish_lanes(file_chunks, output_filepath + "pepper_prediction_" + str(rank), model.predict_chunks_into, lanes,
+                              block=DEVICE_CHUNKS, seq_len=ImageSizeOptions.SEQ_LENGTH, features=ImageSizeOptions.IMAGE_HEIGHT,
+                              slots_per_lane=2, log=log)
+        return rank
     output_filename = output_filepath + "pepper_prediction_" + str(rank) + ".hdf"
     prediction_data_file = DataStore(output_filename, mode='w')
     input_data = SequenceDataset(input_filepath, file_chunks)

@@ -103,6 +103,20 @@ class TransducerGRU(object):
         self._leave(cur, (x, hidden, logits, hidden_out))
         return (logits.cpu(), hidden_out.cpu()) if on_cpu else (logits, hidden_out)
 
+    def predict_chunks_into(self, images, labels, phred):
+        """Host arrays in, host arrays out (numpy uint8, C-contiguous; page-locked memory makes the copies asynchronous):
+        images [B,1000,10] -> labels [B,1000], phred [B,1000] filled in place.  What the lane pipeline calls
+        (pepper_amd/hostpipe.py)."""
+        import numpy as np
+        for a in (images, labels, phred):
+            if a.dtype != np.uint8 or not a.flags.c_contiguous:
+                raise ValueError("predict_chunks_into wants C-contiguous uint8 arrays")
+        n = images.shape[0]
+        if labels.shape != (n, images.shape[1]) or phred.shape != labels.shape:
+            raise ValueError("labels / phred must be [B, seq_length]")
+        _lib.check(_lib.load().pa_polish_predict_host(self.handle, images.ctypes.data, n, labels.ctypes.data,
+                                                      phred.ctypes.data, None))
+
     def predict_chunks(self, images, return_acc=False):
         """images uint8 [B,1000,10] -> (labels uint8 [B,1000], phred uint8 [B,1000][, acc])."""
         lib = _lib.load()

@@ -62,16 +62,16 @@ def shard_files(input_files, callers, sizes=None):
 
 
 def resolve_device_ids(options):
-    """One entry per caller: the distinct device ordinals, each repeated options.callers_per_gpu times
-    (RunInference.py:27-60)."""
+    """One entry per caller (= process).  --device_ids is taken as written, duplicates included: "0,0" puts two callers on
+    GPU 0, as the reference's list does (RunInference.py:41-60).  options.callers_per_gpu is accepted and NOT multiplied
+    in: in the reference it only lengthens the device list handed to one nn.DataParallel process (default 4, sized for
+    11 GB cards); here a caller is a process that fills an MI355X on its own, and four of them time-slicing one GPU
+    would only add context switches."""
     if getattr(options, "device_ids", None) is None:
-        ids = list(range(torch.cuda.device_count()))
-    elif isinstance(options.device_ids, str):
-        ids = sorted(set(int(i) for i in options.device_ids.split(',')))
-    else:
-        ids = sorted(set(int(i) for i in options.device_ids))
-    per_gpu = max(1, int(getattr(options, "callers_per_gpu", 1) or 1))
-    return [d for d in ids for _ in range(per_gpu)]
+        return list(range(torch.cuda.device_count()))
+    if isinstance(options.device_ids, str):
+        return [int(i) for i in options.device_ids.split(',') if i.strip() != ""]
+    return [int(i) for i in options.device_ids]
 
 
 def free_port():
@@ -86,8 +86,8 @@ def free_port():
 
 
 def dist_backend(device_ids):
-    """"nccl" (= RCCL over xGMI) when every caller has its own GPU.  RCCL refuses two ranks on one device, so with
-    callers_per_gpu > 1 the one weight broadcast goes over gloo on host memory instead (47 MB, once)."""
+    """"nccl" (= RCCL over xGMI) when every caller has its own GPU.  RCCL refuses two ranks on one device, so when an
+    ordinal is listed twice the one weight broadcast goes over gloo on host memory instead (47 MB, once)."""
     if os.environ.get("PEPPER_AMD_DIST_BACKEND"):
         return os.environ["PEPPER_AMD_DIST_BACKEND"]
     return "nccl" if len(set(device_ids)) == len(device_ids) else "gloo"

@@ -71,6 +71,16 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
             num_classes=ImageSizeOptions.TOTAL_LABELS, num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)
     model.eval()
     suffix = "" if rank is None else "_" + str(rank)
+    # big jobs (or options.num_workers > 0, the reference's DataLoader(num_workers=...), RunInferenceArguments.py:75-82): reader
+    # and writer processes per lane of image files around this process's GPU loop (libhdf5 has one lock per process)
+    from pepper_amd import hostpipe
+    lanes = hostpipe.default_lanes(input_files, int(getattr(options, "num_workers", 0) or 0))
+    if lanes > 0 and hostpipe.shm_room(2 * lanes * max(__import__("os").path.getsize(f) for f in input_files)):
+        def log(done):
+            _log("INFO: FILES COMPLETED: " + str(done) + "/" + str(len(input_files)) + ".")
+        return hostpipe.variant_lanes(input_filepath, input_files, output_filepath + "pepper_prediction" + suffix,
+                                      lambda images: model(torch.from_numpy(images), False).numpy(), options.batch_size, lanes,
+                                      log=log)
     output_filename = output_filepath + "pepper_prediction" + suffix + ".hdf"
     prediction_data_file = DataStore(output_filename, mode='w')
     torch.set_num_threads(max(1, int(threads)))
@@ -86,13 +96,7 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
     writer = ThreadPoolExecutor(max_workers=1)
     writes = []
     staging = _StagingBuffers()
-    # options.num_workers (the reference's DataLoader(num_workers=...), RunInferenceArguments.py:75-82): > 0 reads the image
-    # files in that many loader processes (libhdf5 calls of one process share a lock), 0 in one reader thread
-    loader_workers = max(0, int(getattr(options, "num_workers", 0) or 0))
     loaded = None
-    if loader_workers > 0 and len(input_files) > 1:
-        from pepper_amd.variant.models.dataloader_predict import LoaderPool
-        loaded = iter(LoaderPool(input_filepath, input_files, loader_workers, staging.alloc))
     pending = (reader.submit(SequenceDataset, input_filepath, input_files[0], None, staging.alloc)
                if input_files and loaded is None else None)
 

@@ -85,8 +85,9 @@ def _read_predictions(path):
 
 def test_run_inference_multi_process_and_loader_workers(tmp_path):
     """The N-caller leg of RunInference.distributed_gpu (mp.spawn, one process per caller, one weight broadcast, file
-    shards, pepper_prediction_<rank>.hdf) with two callers sharing GPU 0 -- callers_per_gpu = 2, the reference's own
-    option (RunInference.py:31-35); the broadcast then runs over gloo because RCCL refuses two ranks on one device --
+    shards, pepper_prediction_<rank>.hdf) with two callers sharing GPU 0 -- --device_ids "0,0", which the reference's
+    list semantics allow (RunInference.py:41-60); the broadcast then runs over gloo because RCCL refuses two ranks on
+    one device --
     and options.num_workers = 2 (spawned loader processes): both must reproduce the single-process files exactly."""
     from pepper_amd.variant.RunInference import run_inference
     img_dir = tmp_path / "images"
@@ -108,7 +109,7 @@ def test_run_inference_multi_process_and_loader_workers(tmp_path):
     want, want_batches = _read_predictions(str(single / "pepper_prediction.hdf"))
     assert len(want) == 600 + 40 + 300 + 77 + 3 + 150
 
-    two = run("two", callers_per_gpu=2)
+    two = run("two", device_ids="0,0", callers_per_gpu=4)        # callers_per_gpu is not multiplied in
     assert sorted(os.listdir(two)) == ["pepper_prediction_0.hdf", "pepper_prediction_1.hdf"]
     got = {}
     for r in (0, 1):
