@@ -122,103 +122,3 @@ class SequenceDataset(object):
             e = min(len(self), s + batch_size)
             yield (self.all_contigs[s:e], self.all_positions[s:e], self.all_depths[s:e],
                    self.all_candidates[s:e], self.all_candidate_frequency[s:e], self.all_images[s:e])
-
-
-# ---- image files read in worker processes (options.num_workers, the reference's DataLoader(num_workers=...)) ----------
-# libhdf5 is not thread-safe, so loader *threads* of one process share a lock; loader *processes* do not.  A worker reads a
-# whole file like SequenceDataset does, with the image block in a shared-memory segment; the parent attaches, copies the
-# block into its (page-locked) staging buffer and removes the segment.
-
-def load_file_in_worker(args):
-    """Runs in a loader process: (image_directory, path) -> picklable description of the file's SequenceDataset."""
-    from multiprocessing import shared_memory
-    image_directory, path = args
-    holder = {}
-
-    def alloc(n, window, features):
-        shm = shared_memory.SharedMemory(create=True, size=max(1, n * window * features))
-        holder["shm"] = shm
-        return np.ndarray((n, window, features), np.int8, buffer=shm.buf)
-    data = SequenceDataset(image_directory, path, None, alloc)
-    shm = holder.get("shm")
-    meta = dict(contigs=data.all_contigs, positions=data.all_positions, depths=data.all_depths,
-                blob=data.candidate_blob, offsets=data.candidate_offsets, freqs=data.all_candidate_frequency,
-                shape=tuple(data.all_images.shape), shm=shm.name if shm is not None else None)
-    if shm is not None:
-        del data
-        # the parent removes the segment; without this the worker's resource tracker reports it as leaked at shutdown
-        from multiprocessing import resource_tracker
-        resource_tracker.unregister(shm._name, "shared_memory")
-        shm.close()                 # the segment stays until the parent unlinks it
-    return meta
-
-
-def dataset_from_worker(meta, image_alloc=None):
-    """Parent side: SequenceDataset equal to the one the worker built; the shared segment is copied out and removed."""
-    from multiprocessing import shared_memory
-    data = SequenceDataset.__new__(SequenceDataset)
-    data._all_candidates = None
-    data.all_contigs, data.all_positions, data.all_depths = meta["contigs"], meta["positions"], meta["depths"]
-    data.candidate_blob, data.candidate_offsets = meta["blob"], meta["offsets"]
-    data.all_candidate_frequency = meta["freqs"]
-    shape = meta["shape"]
-    if meta["shm"] is None:
-        data.all_images = np.zeros(shape, np.int8)
-        return data
-    shm = shared_memory.SharedMemory(name=meta["shm"])
-    try:
-        images = image_alloc(*shape) if image_alloc is not None else np.empty(shape, np.int8)
-        np.copyto(images, np.ndarray(shape, np.int8, buffer=shm.buf))
-        data.all_images = images
-    finally:
-        shm.close()
-        shm.unlink()
-    return data
-
-
-class LoaderPool(object):
-    """`workers` loader processes (spawned: the parent holds a HIP context) reading image files ahead of the consumer,
-    at most workers + 1 files in flight.  Iterating yields the files' SequenceDatasets in the order given."""
-
-    def __init__(self, image_directory, input_files, workers, image_alloc=None):
-        import multiprocessing
-        self._pool = multiprocessing.get_context("spawn").Pool(workers)
-        self._tasks = [(image_directory, f) for f in input_files]
-        self._alloc = image_alloc
-        self._ahead = workers + 1
-        self._pending = []
-        self._next = 0
-
-    def _fill(self):
-        while self._next < len(self._tasks) and len(self._pending) < self._ahead:
-            self._pending.append(self._pool.apply_async(load_file_in_worker, (self._tasks[self._next],)))
-            self._next += 1
-
-    def __iter__(self):
-        try:
-            self._fill()
-            while self._pending:
-                meta = self._pending.pop(0).get()
-                self._fill()
-                yield dataset_from_worker(meta, self._alloc)
-        finally:
-            self.close()
-
-    def close(self):
-        if self._pool is None:
-            return
-        from multiprocessing import shared_memory
-        for res in self._pending:             # consumer stopped early: drop what the workers already produced
-            try:
-                meta = res.get(timeout=60)
-                if meta.get("shm"):
-                    shm = shared_memory.SharedMemory(name=meta["shm"])
-                    shm.close()
-                    shm.unlink()
-            except Exception:
-                pass
-        self._pending = []
-        self._pool.terminate()
-        self._pool.join()
-        self._pool = None
-

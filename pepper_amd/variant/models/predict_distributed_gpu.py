@@ -96,9 +96,7 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
     writer = ThreadPoolExecutor(max_workers=1)
     writes = []
     staging = _StagingBuffers()
-    loaded = None
-    pending = (reader.submit(SequenceDataset, input_filepath, input_files[0], None, staging.alloc)
-               if input_files and loaded is None else None)
+    pending = reader.submit(SequenceDataset, input_filepath, input_files[0], None, staging.alloc) if input_files else None
 
     def write_file(first_batch, input_data, probs):
         # bulk arrays straight into one library call per batch_<n> group (no per-candidate Python objects)
@@ -113,12 +111,9 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
 
     try:
         for file_id, input_file in enumerate(input_files):
-            if loaded is not None:
-                input_data = next(loaded)
-            else:
-                input_data = pending.result()
-                pending = (reader.submit(SequenceDataset, input_filepath, input_files[file_id + 1], None, staging.alloc)
-                           if file_id + 1 < len(input_files) else None)
+            input_data = pending.result()
+            pending = (reader.submit(SequenceDataset, input_filepath, input_files[file_id + 1], None, staging.alloc)
+                       if file_id + 1 < len(input_files) else None)
             n = len(input_data)
             if n:
                 # one packed int8 H2D copy per file, one device pass; float32 probs come back
@@ -133,8 +128,6 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
         for w in writes:
             w.result()
     finally:
-        if loaded is not None:
-            loaded.close()                  # the generator's finally stops the loader processes
         reader.shutdown(wait=True)
         writer.shutdown(wait=True)
         prediction_data_file.close()

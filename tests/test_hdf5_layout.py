@@ -264,27 +264,3 @@ def test_polish_image_chunks_bulk_writer_equals_write_summary(tmp_path):
                 p = "summaries/%s/%s" % (name, ds_name)
                 assert fa.info(p) == fb.info(p), (p, fa.info(p), fb.info(p))
                 assert np.array_equal(fa[p], fb[p]), p
-
-
-def test_loader_processes_return_the_same_datasets(tmp_path):
-    """options.num_workers > 0: image files are read by spawned loader processes (image block through shared memory)."""
-    from pepper_amd import synthetic
-    from pepper_amd.variant.DataStore import DataStore
-    from pepper_amd.variant.models.dataloader_predict import LoaderPool, SequenceDataset
-    files = []
-    for fi, counts in enumerate([(300, 0, 45), (0,), (17,)]):
-        path = str(tmp_path / ("pepper_variants_images_thread_%d.hdf5" % fi))
-        with DataStore(path, "w") as ds:
-            for gi, n in enumerate(counts):
-                x = synthetic.variant_windows(max(n, 1), seed=10 * fi + gi)[:n]
-                cands = np.array([[["1A", "2ACCT", "3AG"][k % 3]] for k in range(n)], dtype=object).reshape(n, 1)
-                ds.write_summary("chr%d_%d_%d" % (fi, gi * 1000, gi * 1000 + 999), ["chr%d" % fi] * n, np.arange(n) + gi * 1000,
-                                 np.full(n, 30), cands, np.full((n, 1), 7), x, [0] * n, [0] * n, False)
-        files.append(path)
-    got = list(LoaderPool(str(tmp_path), files, 2))
-    assert [len(d) for d in got] == [345, 0, 17]
-    for d, path in zip(got, files):
-        want = SequenceDataset(str(tmp_path), path)
-        assert np.array_equal(d.all_images, want.all_images) and np.array_equal(d.all_contigs, want.all_contigs)
-        assert np.array_equal(d.all_positions, want.all_positions) and np.array_equal(d.all_candidates, want.all_candidates)
-        assert np.array_equal(d.candidate_offsets, want.candidate_offsets) and np.array_equal(d.all_candidate_frequency, want.all_candidate_frequency)

