@@ -2,13 +2,15 @@
 //
 // Split of the reference's RegionalSummaryGenerator::generate_summary
 // (/root/reference/pepper_variant/modules/cpp/region_summary.cpp:337-916):
-//   host  : one pass over CIGAR *ops* (not bases) per read -> match / deletion segments for the
-//           GPU, plus everything that needs strings: insert / delete allele keys, their ordered
-//           per-site maps and the sparse matrix updates they imply (:431-555);
-//   GPU   : pileup_count_kernel    per-base walk of the match segments: coverage, strand coverage,
-//                                  base columns, SNP counts and SNP allele tallies (:366-428), and the
-//                                  '*' columns of deleted bases (:541-551)            [atomics, HBM bound]
-//           apply_events_kernel    the host's sparse updates
+//   GPU   : cigar_walk_kernel      the whole per-read walk, one wave per read: coverage, strand coverage, base
+//                                  columns, SNP counts and SNP allele tallies (:366-428), insert quality sums and the
+//                                  sparse indel updates (:431-540), '*' columns of deleted bases (:541-551), one
+//                                  (row, type, strand, length, byte source) record per indel allele vote
+//                                                                                       [atomics, HBM bound]
+//           (PA_ENCODER_HOST_CIGAR=1: round 1's split -- host pass over CIGAR ops -> segment / event lists ->
+//            pileup_count_kernel + apply_events_kernel)
+//   host  : what needs strings: ordered per-site maps of insert / delete allele keys, built only for the sites
+//           that pass the thresholds, from the votes compact_votes_kernel leaves for them;
 //           site_threshold_kernel  per-position fractions vs thresholds in fp64, clamp of columns
 //                                  11..24 (:634-654), compaction of passing sites
 //           gather_windows_kernel  33 x 26 window copy + candidate-specific overwrite (:828-905),
@@ -139,6 +141,142 @@ __global__ __launch_bounds__(256) void pileup_count_kernel(const Seg* __restrict
     }
 }
 
+// The whole per-read walk of populate_summary_matrix (region_summary.cpp:337-566) on the device: one wave per read steps
+// through its CIGAR operations (wave-uniform scalars), the lanes take the bases of a match run / the rows of a deletion
+// 64 at a time with the same per-base arithmetic as pileup_count_kernel, insert quality sums are wave reductions, the
+// sparse indel updates go straight into the matrix, and every indel allele vote is appended as (row, type, strand,
+// length, where the allele's bytes live) for the host, which only ever builds strings for the sites that pass the
+// thresholds.  Replaces the host pass over CIGAR operations + Seg / Event uploads (0.9 of 1.5 ms per 10 kb interval of
+// 60x long reads in round 1).  Integer atomics commute, so the matrix is bit-identical whatever the order.
+struct DVote { int32_t idx, type_rev, len, from_ref; int64_t off; };   // type_rev = type char | strand << 8
+
+struct WalkArgs {
+    const int64_t* read_pos; const uint8_t* read_reverse; const int32_t* read_mapq; const int64_t* seq_offset;
+    const int64_t* cigar_offset; const int32_t* cigar_op; const int32_t* cigar_len;
+    const char* seq; const uint8_t* qual; const char* ref;
+    int64_t ref_len, start, end;
+    int n_reads;
+    int* mat; int* snp_tab; int* counters; int4* ovf; int ovf_cap; DVote* votes; int vote_cap;
+    double min_snp_q, min_indel_q;
+};
+
+__global__ __launch_bounds__(256) void cigar_walk_kernel(WalkArgs a) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= a.n_reads) return;
+    if (a.read_mapq[r] <= 0) return;
+    const bool rev = a.read_reverse[r] != 0;
+    const int64_t s0 = a.seq_offset[r], read_len = a.seq_offset[r + 1] - s0;
+    const int64_t c0 = a.cigar_offset[r], c1 = a.cigar_offset[r + 1];
+    const int64_t start = a.start, end = a.end;
+    int64_t ri = 0, pos = a.read_pos[r];
+    auto refc = [&](int64_t idx) { return idx >= 0 && idx < a.ref_len ? a.ref[idx] : 'N'; };
+    for (int64_t c = c0; c < c1; ++c) {
+        if (pos > end) break;
+        const int op = a.cigar_op[c];
+        const int64_t len = a.cigar_len[c];
+        if (op == OP_M || op == OP_EQ || op == OP_X) {
+            const int64_t lo = pos > start ? pos : start, hi = pos + len - 1 < end ? pos + len - 1 : end;
+            if (lo <= hi) {
+                if (ri + (hi - pos) >= read_len) {          // CIGAR runs past the sequence: reported by the host
+                    if (lane == 0) atomicMax(&a.counters[3], r + 1);
+                    return;
+                }
+                bool anchor = false;
+                if (hi == pos + len - 1 && c != c1 - 1) {
+                    const int nop = a.cigar_op[c + 1];
+                    anchor = (nop == OP_I || nop == OP_D);
+                }
+                for (int64_t q = lo + lane; q <= hi; q += 64) {
+                    const int64_t si = s0 + ri + (q - pos);
+                    if (!((double)a.qual[si] >= a.min_snp_q)) continue;
+                    const int idx = (int)(q - start);
+                    const char rb = refc(idx);
+                    const char base = a.seq[si];
+                    int* row = a.mat + (size_t)idx * ROW;
+                    atomicAdd(&row[C_COV], 1);
+                    if (!(anchor && q == hi)) atomicSub(&row[rev ? 15 : 4], 1);
+                    const int col = symbol_column(rb, base, rev);
+                    if (col >= 0) atomicSub(&row[col], 1);
+                    if (rb != base) {
+                        atomicAdd(&row[C_SNP], 1);
+                        const int k = base == 'A' ? 0 : base == 'C' ? 1 : base == 'G' ? 2 : base == 'T' ? 3 : -1;
+                        if (k >= 0) {
+                            atomicAdd(&a.snp_tab[((size_t)idx * 2 + (rev ? 1 : 0)) * 4 + k], 1);
+                        } else {
+                            const int slot = atomicAdd(&a.counters[0], 1);
+                            if (slot < a.ovf_cap) a.ovf[slot] = make_int4(idx, (int)(unsigned char)base, rev ? 1 : 0, 0);
+                        }
+                    }
+                }
+            }
+            ri += len;
+            pos += len;
+        } else if (op == OP_I) {
+            const int64_t anchor = pos - 1;
+            if (anchor >= start && anchor <= end && ri - 1 >= 0) {
+                const int idx = (int)(anchor - start);
+                const int64_t n = len + 1;
+                const int64_t avail = n < read_len - (ri - 1) ? n : (read_len - (ri - 1) > 0 ? read_len - (ri - 1) : 0);
+                // sum of integer qualities: exact, and equal to the reference's double accumulation
+                long long part = 0;
+                for (int64_t k = ri - 1 + lane; k < ri - 1 + n; k += 64) part += k < read_len ? a.qual[s0 + k] : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                const bool passes = (double)part >= a.min_indel_q * (double)n;
+                if (lane == 0) {
+                    if (passes && (double)a.qual[s0 + ri - 1] < a.min_snp_q) atomicAdd(&a.mat[(size_t)idx * ROW + C_COV], 1);
+                    if (avail + 1 <= 61 && passes) {
+                        const int col = symbol_column(refc(idx), 'I', rev);
+                        if (col >= 0) atomicSub(&a.mat[(size_t)idx * ROW + col], 1);
+                        atomicAdd(&a.mat[(size_t)idx * ROW + C_INS], 1);
+                        const int slot = atomicAdd(&a.counters[2], 1);
+                        if (slot < a.vote_cap) a.votes[slot] = DVote{idx, (int)'2' | (rev ? 256 : 0), (int)avail, 0, s0 + ri - 1};
+                    }
+                }
+            }
+            ri += len;
+        } else if (op == OP_D) {
+            const int64_t anchor = pos - 1;
+            if (anchor >= start && anchor <= end && lane == 0) {
+                const int idx = (int)(anchor - start);
+                const int col = symbol_column(refc(idx), 'D', rev);
+                if (col >= 0) atomicSub(&a.mat[(size_t)idx * ROW + col], 1);
+                int64_t avail = len + 1 < a.ref_len - idx ? len + 1 : a.ref_len - idx;
+                if (avail < 0) avail = 0;
+                if (avail + 1 <= 61) {
+                    atomicAdd(&a.mat[(size_t)idx * ROW + C_DEL], 1);
+                    const int slot = atomicAdd(&a.counters[2], 1);
+                    if (slot < a.vote_cap) a.votes[slot] = DVote{idx, (int)'3' | (rev ? 256 : 0), (int)avail, 1, (int64_t)idx};
+                }
+            }
+            const int64_t lo = pos > start ? pos : start, hi = pos + len - 1 < end ? pos + len - 1 : end;
+            for (int64_t q = lo + lane; q <= hi; q += 64) {
+                const int idx = (int)(q - start);
+                const int col = symbol_column(refc(idx), '*', rev);
+                if (col >= 0) atomicSub(&a.mat[(size_t)idx * ROW + col], 1);
+            }
+            pos += len;
+        } else if (op == OP_N || op == OP_P) {
+            pos += len;
+            ri += len;      // the reference falls through into the soft-clip case (region_summary.cpp:556-561)
+        } else if (op == OP_S) {
+            ri += len;
+        }
+    }
+}
+
+// votes of the sites that passed the thresholds, compacted for the host (a few per cent of all votes)
+// (the number of votes is only known on the device: the grid covers the capacity, counters[2] bounds it)
+__global__ __launch_bounds__(256) void compact_votes_kernel(const DVote* __restrict__ votes, int* __restrict__ counters, int cap,
+                                                            const uint8_t* __restrict__ pass, DVote* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = counters[2] < cap ? counters[2] : cap;
+    if (i >= n) return;
+    const DVote v = votes[i];
+    if (pass[v.idx]) out[atomicAdd(&counters[4], 1)] = v;
+}
+
 __global__ __launch_bounds__(256) void apply_events_kernel(const Event* __restrict__ ev, int n, int* __restrict__ mat) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) atomicAdd(&mat[(size_t)ev[i].row * ROW + ev[i].col], ev[i].delta);
@@ -148,9 +286,11 @@ __global__ __launch_bounds__(256) void site_threshold_kernel(int* __restrict__ m
                                                              int64_t region_start, int64_t cand_start, int64_t cand_end,
                                                              double snp_thr, double ins_thr, double del_thr,
                                                              double min_cov, int* __restrict__ site_count,
-                                                             SiteRec* __restrict__ sites, int site_cap) {
+                                                             SiteRec* __restrict__ sites, int site_cap,
+                                                             uint8_t* __restrict__ pass = nullptr) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= L) return;
+    if (pass) pass[idx] = 0;
     int* row = mat + (size_t)idx * ROW;
     const int cov = row[C_COV];
     const double c = cov > 1 ? (double)cov : 1.0;
@@ -160,6 +300,7 @@ __global__ __launch_bounds__(256) void site_threshold_kernel(int* __restrict__ m
     const int64_t pos = region_start + idx;
     if ((s || n || d) && pos >= cand_start && pos <= cand_end && (double)cov >= min_cov) {
         const int slot = atomicAdd(site_count, 1);
+        if (pass) pass[idx] = 1;
         if (slot < site_cap) {
             SiteRec r;
             r.idx = idx;
@@ -291,6 +432,7 @@ struct pa_encoder {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DBuf d_seq, d_qual, d_ref, d_segs, d_events, d_mat, d_snp, d_ovf, d_counters, d_sites, d_cands, d_img32, d_img8;
+    DBuf d_reads, d_cig, d_votes, d_votes_out, d_pass;     // device CIGAR walk: read tables, operations, allele votes
     DBuf d_pbase, d_pins, d_prow0, d_prows, d_ppix;
     int64_t p_rows = 0;
     std::vector<int64_t> p_positions;
@@ -370,11 +512,15 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
         t_prev = now;
     };
 
+    // PA_ENCODER_HOST_CIGAR=1: round 1's split (host pass over CIGAR operations -> Seg / Event lists -> pileup_count_kernel +
+    // apply_events_kernel); default: the whole walk on the device (cigar_walk_kernel)
+    const char* host_cigar_env = getenv("PA_ENCODER_HOST_CIGAR");       // read per call: the tests run both paths
+    const bool host_cigar = host_cigar_env && host_cigar_env[0] != '0';
+    const int64_t n_ops = p->n_reads > 0 ? p->cigar_offset[p->n_reads] : 0;
     // ---- host pass over CIGAR ops -----------------------------------------------------------
     std::vector<Seg> segs;
     std::vector<Event> events;
-    {
-        const int64_t n_ops = p->n_reads > 0 ? p->cigar_offset[p->n_reads] : 0;
+    if (host_cigar) {
         segs.reserve((size_t)n_ops + 1024);
         events.reserve((size_t)n_ops * 2 + 1024);
     }
@@ -388,7 +534,7 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
         votes.push_back({idx, type, rev, (int32_t)len, src});
     };
     const int64_t total_bases = p->n_reads > 0 ? p->seq_offset[p->n_reads] : 0;
-    for (int32_t r = 0; r < p->n_reads; ++r) {
+    for (int32_t r = 0; host_cigar && r < p->n_reads; ++r) {
         if (p->read_mapq[r] <= 0) continue;
         const bool rev = p->read_reverse[r] != 0;
         const int64_t s0 = p->seq_offset[r], read_len = p->seq_offset[r + 1] - s0;
@@ -498,6 +644,59 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
     int* counters = static_cast<int*>(e->d_counters.p);
     hipLaunchKernelGGL(init_matrix_kernel, dim3((L + 1 + 255) / 256), dim3(256), 0, st, mat,
                        static_cast<const char*>(e->d_ref.p), p->reference_len, L);
+    uint8_t* d_pass = nullptr;
+    if (!host_cigar) {
+        // read tables and operations: [pos i64 n][seq_offset i64 n+1][cigar_offset i64 n+1][mapq i32 n][reverse u8 n]
+        const size_t n = (size_t)p->n_reads;
+        const size_t o_pos = 0, o_soff = o_pos + 8 * n, o_coff = o_soff + 8 * (n + 1), o_mapq = o_coff + 8 * (n + 1),
+                     o_rev = o_mapq + 4 * n, reads_bytes = o_rev + n;
+        ENC_ALLOC(e->d_reads, reads_bytes + 64);
+        ENC_ALLOC(e->d_cig, (size_t)n_ops * 8 + 64);
+        ENC_ALLOC(e->d_votes, (size_t)(n_ops + 1) * sizeof(DVote));
+        ENC_ALLOC(e->d_votes_out, (size_t)(n_ops + 1) * sizeof(DVote));
+        ENC_ALLOC(e->d_pass, (size_t)L + 64);
+        d_pass = static_cast<uint8_t*>(e->d_pass.p);
+        char* dr = static_cast<char*>(e->d_reads.p);
+        if (n > 0) {
+            ENC_HIP(hipMemcpyAsync(dr + o_pos, p->read_pos, 8 * n, hipMemcpyHostToDevice, st));
+            ENC_HIP(hipMemcpyAsync(dr + o_soff, p->seq_offset, 8 * (n + 1), hipMemcpyHostToDevice, st));
+            ENC_HIP(hipMemcpyAsync(dr + o_coff, p->cigar_offset, 8 * (n + 1), hipMemcpyHostToDevice, st));
+            ENC_HIP(hipMemcpyAsync(dr + o_mapq, p->read_mapq, 4 * n, hipMemcpyHostToDevice, st));
+            ENC_HIP(hipMemcpyAsync(dr + o_rev, p->read_reverse, n, hipMemcpyHostToDevice, st));
+        }
+        char* dc = static_cast<char*>(e->d_cig.p);
+        if (n_ops > 0) {
+            ENC_HIP(hipMemcpyAsync(dc, p->cigar_op, (size_t)n_ops * 4, hipMemcpyHostToDevice, st));
+            ENC_HIP(hipMemcpyAsync(dc + (size_t)n_ops * 4, p->cigar_len, (size_t)n_ops * 4, hipMemcpyHostToDevice, st));
+        }
+        if (n > 0) {
+            WalkArgs wa;
+            wa.read_pos = reinterpret_cast<const int64_t*>(dr + o_pos);
+            wa.read_reverse = reinterpret_cast<const uint8_t*>(dr + o_rev);
+            wa.read_mapq = reinterpret_cast<const int32_t*>(dr + o_mapq);
+            wa.seq_offset = reinterpret_cast<const int64_t*>(dr + o_soff);
+            wa.cigar_offset = reinterpret_cast<const int64_t*>(dr + o_coff);
+            wa.cigar_op = reinterpret_cast<const int32_t*>(dc);
+            wa.cigar_len = reinterpret_cast<const int32_t*>(dc + (size_t)n_ops * 4);
+            wa.seq = static_cast<const char*>(e->d_seq.p);
+            wa.qual = static_cast<const uint8_t*>(e->d_qual.p);
+            wa.ref = static_cast<const char*>(e->d_ref.p);
+            wa.ref_len = p->reference_len;
+            wa.start = start;
+            wa.end = end;
+            wa.n_reads = p->n_reads;
+            wa.mat = mat;
+            wa.snp_tab = static_cast<int*>(e->d_snp.p);
+            wa.counters = counters;
+            wa.ovf = static_cast<int4*>(e->d_ovf.p);
+            wa.ovf_cap = ovf_cap;
+            wa.votes = static_cast<DVote*>(e->d_votes.p);
+            wa.vote_cap = (int)n_ops;
+            wa.min_snp_q = q->min_snp_baseq;
+            wa.min_indel_q = q->min_indel_baseq;
+            hipLaunchKernelGGL(cigar_walk_kernel, dim3((p->n_reads + 3) / 4), dim3(256), 0, st, wa);
+        }
+    }
     if (!segs.empty())
         hipLaunchKernelGGL(pileup_count_kernel, dim3(((int)segs.size() + 3) / 4), dim3(256), 0, st,
                            static_cast<const Seg*>(e->d_segs.p), (int)segs.size(), static_cast<const char*>(e->d_seq.p),
@@ -511,13 +710,19 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
                        static_cast<const int*>(e->d_snp.p), L, start, q->candidate_region_start,
                        q->candidate_region_end, q->snp_freq_threshold, q->insert_freq_threshold,
                        q->delete_freq_threshold, q->min_coverage_threshold, counters + 1,
-                       static_cast<SiteRec*>(e->d_sites.p), site_cap);
+                       static_cast<SiteRec*>(e->d_sites.p), site_cap, d_pass);
+    if (!host_cigar && n_ops > 0)      // votes of the passing sites only (vote count read on the device: grid over the capacity)
+        hipLaunchKernelGGL(compact_votes_kernel, dim3(((int)n_ops + 255) / 256), dim3(256), 0, st,
+                           static_cast<const DVote*>(e->d_votes.p), counters, (int)n_ops, d_pass,
+                           static_cast<DVote*>(e->d_votes_out.p));
     ENC_HIP(hipGetLastError());
-    int host_counters[2] = {0, 0};
+    int host_counters[5] = {0, 0, 0, 0, 0};
     lap("uploads + launches");
     ENC_HIP(hipMemcpyAsync(host_counters, counters, sizeof(host_counters), hipMemcpyDeviceToHost, st));
     ENC_HIP(hipStreamSynchronize(st));
     lap("count kernels");
+    if (host_counters[3] > 0)
+        return pa::set_error(PA_ERR_INVALID, "CIGAR of read " + std::to_string(host_counters[3] - 1) + " runs past its sequence");
     const int n_ovf = host_counters[0], n_sites = std::min(host_counters[1], site_cap);
     if (n_ovf > ovf_cap)
         return pa::set_error(PA_ERR_INVALID, "more than 65536 mismatching bases outside ACGT in one region");
@@ -525,7 +730,17 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
     std::vector<int4> ovf((size_t)n_ovf);
     if (n_sites) ENC_HIP(hipMemcpyAsync(sites.data(), e->d_sites.p, sites.size() * sizeof(SiteRec), hipMemcpyDeviceToHost, st));
     if (n_ovf) ENC_HIP(hipMemcpyAsync(ovf.data(), e->d_ovf.p, ovf.size() * sizeof(int4), hipMemcpyDeviceToHost, st));
+    std::vector<DVote> dvotes;
+    if (!host_cigar) {
+        if (host_counters[2] > n_ops) return pa::set_error(PA_ERR_INVALID, "more indel votes than CIGAR operations (corrupt pileup)");
+        dvotes.resize((size_t)host_counters[4]);
+        if (!dvotes.empty())
+            ENC_HIP(hipMemcpyAsync(dvotes.data(), e->d_votes_out.p, dvotes.size() * sizeof(DVote), hipMemcpyDeviceToHost, st));
+    }
     ENC_HIP(hipStreamSynchronize(st));
+    for (const DVote& v : dvotes)
+        votes.push_back({v.idx, (char)(v.type_rev & 0xff), (v.type_rev >> 8) != 0, v.len,
+                         (v.from_ref ? p->reference : p->seq) + v.off});
     std::sort(sites.begin(), sites.end(), [](const SiteRec& a, const SiteRec& b) { return a.idx < b.idx; });
     std::map<int32_t, std::map<char, Tally>> rare;       // SNP alleles outside ACGT
     for (const int4& o : ovf) {

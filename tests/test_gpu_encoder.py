@@ -59,6 +59,37 @@ def test_encoder_matches_oracle_and_reference(name):
         _check(got, pu.run_variant(ref, pile, params, reference_impl=True))
 
 
+@pytest.mark.parametrize("name", ["plain", "ref_skip_pad_fallthrough", "long_indels_61_cap", "low_quality_heavy", "deep_over_125"])
+def test_host_cigar_pass_equals_device_walk(name):
+    """Round 1's split (PA_ENCODER_HOST_CIGAR=1: host pass over CIGAR operations + segment / event kernels) and the
+    device walk (cigar_walk_kernel, the default) are two implementations of the same integer arithmetic: identical
+    candidates, images, depths."""
+    pile, params = _case(**CASES[name])
+    saved = os.environ.get("PA_ENCODER_HOST_CIGAR")
+    try:
+        os.environ.pop("PA_ENCODER_HOST_CIGAR", None)
+        dev = _product(pile, params)
+        os.environ["PA_ENCODER_HOST_CIGAR"] = "1"
+        host = _product(pile, params)
+    finally:
+        if saved is None:
+            os.environ.pop("PA_ENCODER_HOST_CIGAR", None)
+        else:
+            os.environ["PA_ENCODER_HOST_CIGAR"] = saved
+    assert len(dev["candidates"]) > 0
+    _check(dev, dict(host, images=host["images_int32"]))
+
+
+def test_cigar_past_the_sequence_is_an_error():
+    from pepper_amd import _lib
+    pile, params = _case(**CASES["plain"])
+    r = next(k for k in range(pile.n_reads) if pile.read_mapq[k] > 0 and pile.cigar_op[int(pile.cigar_offset[k])] in (0, 7, 8)
+             and pile.read_pos[k] >= pile.region_start)
+    pile.cigar_len[int(pile.cigar_offset[r])] += 100000          # a match run of read r now outruns its bases
+    with pytest.raises(_lib.PepperAmdError, match="runs past its sequence"):
+        _product(pile, params)
+
+
 @pytest.mark.parametrize("preset", sorted(pu.PRESET_PARAMS))
 @pytest.mark.parametrize("name", sorted(PRESET_CASES))
 def test_encoder_under_reference_presets(preset, name):
