@@ -112,6 +112,23 @@ class LaneError(RuntimeError):
     pass
 
 
+def _next_message(result_q, procs):
+    """result_q.get() that notices dead workers: a child that dies before it can report (a crash in native code, or a
+    caller's script without the `if __name__ == "__main__":` guard that spawned children need) must not leave the GPU
+    loop waiting forever."""
+    import queue
+    while True:
+        try:
+            return result_q.get(timeout=2.0)
+        except queue.Empty:
+            dead = [p for p in procs if p.exitcode not in (None, 0)]
+            if dead:
+                raise LaneError("worker process %s exited with code %s before reporting (is the calling script's entry point "
+                                "guarded by `if __name__ == '__main__':`?)" % (dead[0].name, dead[0].exitcode))
+            if procs and all(p.exitcode is not None for p in procs):
+                raise LaneError("all worker processes exited without finishing their lanes")
+
+
 def _close_all(segments):
     for s in segments:
         try:
@@ -232,7 +249,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
             p.start()
         reading, writing = lanes, lanes
         while writing:
-            msg = result_q.get()
+            msg = _next_message(result_q, procs)
             kind, lane = msg[0], msg[1]
             if kind == "error":
                 raise LaneError("lane %d failed:\n%s" % (lane, msg[2]))
@@ -346,7 +363,7 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
         writing = lanes
         files_done = 0
         while writing:
-            msg = result_q.get()
+            msg = _next_message(result_q, procs)
             kind, lane = msg[0], msg[1]
             if kind == "error":
                 raise LaneError("lane %d failed:\n%s" % (lane, msg[2]))
