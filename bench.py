@@ -501,7 +501,7 @@ def main():
     _lib.check(lib.pa_profile_enable(handle, 0))
 
     extras = {}
-    if rank == 0 and not args.no_extras and not args.resident_only:
+    if world == 1 and not args.no_extras and not args.resident_only:
         # (a) the same kernels on inputs already in HBM (round 1's figure): one device pass of `chunk` units, repeated
         xr = pool_dev[:chunk].contiguous()
         outs_d = [torch.empty((chunk,) + sh, dtype=out_dtype, device=dev) for sh in out_shapes]
