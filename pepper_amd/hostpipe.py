@@ -399,7 +399,7 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
 def default_lanes(files, requested, small=64 << 20):
     """options.num_workers > 0: that many lanes (at most one per file).  0: process lanes only when the job is big
     enough to pay for spawning them (interpreter start-up is ~0.3 s per process)."""
-    if not files:
+    if not files or os.environ.get("PEPPER_AMD_NO_LANES") == "1":
         return 0
     if requested and requested > 0:
         return min(int(requested), len(files))

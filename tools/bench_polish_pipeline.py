@@ -24,7 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--chunks", type=int, default=65536)
     ap.add_argument("--files", type=int, default=16)
-    ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--workers", default="0", help="comma list of num_workers values (lanes); -1 = the in-process loop")
     args = ap.parse_args()
     n = args.chunks // (2 * args.files) * 2 * args.files
     tmp = tempfile.mkdtemp()
@@ -35,26 +35,30 @@ def main():
         labels = np.zeros((2, 1000), np.uint8)
         t0 = time.perf_counter()
         per_file = n // args.files
-        for fi in range(args.files):
-            with DataStore(os.path.join(img_dir, "pepper_hp_images_thread_%d.hdf" % fi), "w") as ds:
-                for r in range(per_file // 2):
-                    g = (fi * per_file // 2 + r)
-                    region = ("ctg%d" % fi, r * 1000, r * 1000 + 1200)
-                    pos = np.stack([np.stack([np.arange(1000) + region[1] + 950 * c, np.zeros(1000, np.int64)], axis=1) for c in range(2)])
-                    k = (2 * g) % 4096
-                    ds.write_summaries(region, chunks[k:k + 2], labels, pos, [0, 1])
+        first = os.path.join(img_dir, "pepper_hp_images_thread_0.hdf")
+        with DataStore(first, "w") as ds:             # the other image files are byte copies of this one
+            for r in range(per_file // 2):
+                region = ("ctg0", r * 1000, r * 1000 + 1200)
+                pos = np.stack([np.stack([np.arange(1000) + region[1] + 950 * c, np.zeros(1000, np.int64)], axis=1) for c in range(2)])
+                k = (2 * r) % 4096
+                ds.write_summaries(region, chunks[k:k + 2], labels, pos, [0, 1])
+        for fi in range(1, args.files):
+            shutil.copyfile(first, os.path.join(img_dir, "pepper_hp_images_thread_%d.hdf" % fi))
         t_write = time.perf_counter() - t0
         sd = synthetic.polish_state_dict(seed=0)
         model_path = os.path.join(tmp, "polish.pkl")
         torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
-        t0 = time.perf_counter()
-        call_consensus(img_dir, model_path, 512, args.workers, os.path.join(tmp, "pred"), "0", True, 4)
-        dt = time.perf_counter() - t0
-        outs = sorted(os.listdir(os.path.join(tmp, "pred")))
-        print(json.dumps({"metric": "call_consensus HDF5 -> HDF5, 1 GPU", "chunks": n, "windows": 19 * n, "image_files": args.files,
-                          "num_workers": args.workers, "prediction_files": len(outs), "seconds": round(dt, 3),
-                          "chunks_per_s": round(n / dt), "windows_per_s": round(19 * n / dt), "image_write_seconds": round(t_write, 2),
-                          "host_cpus": os.cpu_count()}))
+        for k, w in enumerate(int(v) for v in str(args.workers).split(",")):
+            os.environ["PEPPER_AMD_NO_LANES"] = "1" if w < 0 else "0"
+            pred = os.path.join(tmp, "pred%d" % k)
+            t0 = time.perf_counter()
+            call_consensus(img_dir, model_path, 512, max(w, 0), pred, "0", True, 4)
+            dt = time.perf_counter() - t0
+            print(json.dumps({"metric": "call_consensus HDF5 -> HDF5, 1 GPU", "chunks": n, "windows": 19 * n, "image_files": args.files,
+                              "num_workers": w, "mode": "in-process loop" if w < 0 else "lanes",
+                              "prediction_files": len(os.listdir(pred)), "seconds": round(dt, 3), "chunks_per_s": round(n / dt),
+                              "windows_per_s": round(19 * n / dt), "image_write_seconds": round(t_write, 2),
+                              "host_cpus": os.cpu_count()}), flush=True)
     finally:
         shutil.rmtree(tmp)
 
