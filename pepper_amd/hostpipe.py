@@ -54,12 +54,18 @@ def _attach(name):
 class Slots(object):
     """`count` shared segments of `nbytes`, created (and page-locked for the GPU) by the process that runs the device."""
 
-    def __init__(self, count, nbytes, register=True):
+    def __init__(self, count, nbytes, register=False):
         self.nbytes = int(nbytes)
         self.segments = [shared_memory.SharedMemory(create=True, size=max(1, self.nbytes)) for _ in range(count)]
         self.names = [s.name for s in self.segments]
         self.registered = []
         if register:
+            self.register()
+
+    def register(self):
+        """Page-lock the segments for the GPU (hipHostRegister).  Called after the worker processes have been started,
+        so that pinning a few GB overlaps their start-up and first reads."""
+        if not self.registered:
             try:
                 import torch
                 rt = torch.cuda.cudart()
@@ -247,6 +253,8 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
                                      daemon=True))
         for p in procs:
             p.start()
+        for sl in slots:
+            sl.register()
         reading, writing = lanes, lanes
         while writing:
             msg = _next_message(result_q, procs)
@@ -360,6 +368,8 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
             procs.append(ctx.Process(target=variant_writer, args=(k, result_q, out, batch_size, write_qs[k]), daemon=True))
         for p in procs:
             p.start()
+        for sl in slots:
+            sl.register()
         writing = lanes
         files_done = 0
         while writing:
