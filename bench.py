@@ -420,7 +420,7 @@ def main():
     else:
         feat = 100 if args.model == "ns-literal" else 10
         chunk = 16384                                   # chunks per device pass (128 rows per workgroup x 2 directions = 256 workgroups)
-        per = args.per_gpu or (chunk if args.resident_only else 32768)
+        per = args.per_gpu or (chunk if (args.resident_only or feat != 10) else 32768)
         pool_n = max(per, args.pool or (per if (args.resident_only or feat != 10) else 65536))
         sd = broadcast_state_dict(lambda: synthetic.polish_state_dict(seed=0, image_features=feat),
                                   synthetic.polish_param_shapes(image_features=feat), world, rank, dev)
