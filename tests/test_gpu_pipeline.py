@@ -88,7 +88,8 @@ def test_run_inference_multi_process_and_loader_workers(tmp_path):
     shards, pepper_prediction_<rank>.hdf) with two callers sharing GPU 0 -- --device_ids "0,0", which the reference's
     list semantics allow (RunInference.py:41-60); the broadcast then runs over gloo because RCCL refuses two ranks on
     one device --
-    and options.num_workers = 2 (spawned loader processes): both must reproduce the single-process files exactly."""
+    and options.num_workers = 2 (two reader / writer process lanes): both must reproduce the single-process records
+    exactly."""
     from pepper_amd.variant.RunInference import run_inference
     img_dir = tmp_path / "images"
     img_dir.mkdir()
@@ -120,9 +121,17 @@ def test_run_inference_multi_process_and_loader_workers(tmp_path):
     assert set(got) == set(want)
     assert all(np.array_equal(got[k], want[k]) for k in want)
 
-    loaders = run("loaders", num_workers=2)
-    got2, batches2 = _read_predictions(str(loaders / "pepper_prediction.hdf"))
-    assert batches2 == want_batches and set(got2) == set(want)
+    # num_workers = 2: two lanes (reader + writer process each, pepper_amd/hostpipe.py), one prediction file per lane with
+    # its own batch numbering; the GPU loop stays in this process
+    lanes = run("lanes", num_workers=2)
+    assert sorted(os.listdir(lanes)) == ["pepper_prediction_0.hdf", "pepper_prediction_1.hdf"]
+    got2 = {}
+    for k in (0, 1):
+        part, batches = _read_predictions(str(lanes / f"pepper_prediction_{k}.hdf"))
+        assert batches == [f"batch_{i}" for i in range(len(batches))] and len(part) > 0
+        assert not (set(part) & set(got2))
+        got2.update(part)
+    assert set(got2) == set(want)
     assert all(np.array_equal(got2[k], want[k]) for k in want)
 
 
@@ -160,6 +169,13 @@ def test_call_consensus_two_callers_share_gpu(tmp_path):
     assert len(one) == 7 and set(one) == set(two)
     for k in one:
         assert np.array_equal(one[k][0], two[k][0]) and np.array_equal(one[k][1], two[k][1])
+    # num_workers = 2: two lanes around one caller's GPU loop
+    call_consensus(str(img_dir), model_path, 128, 2, str(tmp_path / "lanes"), "0", True, 4)
+    assert sorted(os.listdir(tmp_path / "lanes")) == ["pepper_prediction_0_0.hdf", "pepper_prediction_0_1.hdf"]
+    lanes = read(tmp_path / "lanes")
+    assert set(lanes) == set(one)
+    for k in one:
+        assert np.array_equal(one[k][0], lanes[k][0]) and np.array_equal(one[k][1], lanes[k][1])
 
 
 def test_call_consensus_end_to_end(tmp_path):
