@@ -1,0 +1,42 @@
+"""bench.py on a host without a GPU: the file parses its arguments, knows the algorithmic bytes of every kernel label
+it may report as dominant, and reads roofline.traffic from the committed PMC summary."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_help_and_contract_flags():
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--help"], capture_output=True, text=True, check=True).stdout
+    for flag in ("--gpus", "--steps", "--warmup", "--model", "--resident-only"):
+        assert flag in out
+
+
+def test_traffic_comes_from_the_committed_pmc_passes():
+    b = _bench()
+    t = b.measured_traffic("variant", "lstm_dec_h2_fused")
+    assert t is not None and t["source"] == os.path.join("profiles", "r02_variant_pmc.json")
+    table = json.load(open(os.path.join(REPO, t["source"])))["kernels"]["lstm_dec_h2_fused"]
+    assert t["bytes_per_launch"] == table["fetch_bytes_corrected"] + table["write_bytes"]
+    # the decoder reads the encoder's output once and writes its own once: measured traffic within 10 % of that
+    algorithmic = b.ALGORITHMIC_BYTES_PER_UNIT["lstm_dec_h2_fused"] * table["units_per_launch"]
+    assert 0.95 * algorithmic < t["bytes_per_launch"] < 1.10 * algorithmic
+    assert b.measured_traffic("variant", "no_such_kernel") is None
+    for label in ("lstm_rec_h2_fused_in", "lstm_dec_h2_fused", "gemm_h2_linear_1", "gru_dec_h2_fused_dense", "gru_rec_h2_fused_in"):
+        assert label in b.ALGORITHMIC_BYTES_PER_UNIT
+
+
+def test_peaks_are_the_dense_ones():
+    b = _bench()
+    assert b.F16_MFMA_PEAK_TFLOPS == 2500.0 and abs(b.H2_MFMA_PEAK_TFLOPS - 2500.0 / 3) < 1e-9
+    assert b.kernel_peak("lstm_dec_h2_fused") == b.H2_MFMA_PEAK_TFLOPS and b.kernel_peak("lstm_rec") == b.F32_MFMA_PEAK_TFLOPS
