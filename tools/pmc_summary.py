@@ -41,7 +41,8 @@ LABELS = [
     ("gather_windows_kernel", "gather_windows"),
     ("polish_count_kernel", "polish_count"),
     ("polish_pixels_kernel", "polish_pixels"),
-    ("cigar_segments_kernel", "cigar_segments"),
+    ("cigar_walk_kernel", "cigar_walk"),
+    ("compact_votes_kernel", "compact_votes"),
 ]
 
 
