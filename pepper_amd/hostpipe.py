@@ -19,6 +19,7 @@ Worker processes are spawned (the parent holds a HIP context) and import only nu
 """
 import os
 import sys
+import time
 import traceback
 from multiprocessing import get_context, shared_memory
 
@@ -116,6 +117,34 @@ def deal_files(files, lanes):
 
 class LaneError(RuntimeError):
     pass
+
+
+def _trace(t0, what):
+    if os.environ.get("PEPPER_AMD_LANE_TRACE"):
+        sys.stderr.write("[lanes] %-28s %8.3f s\n" % (what, time.perf_counter() - t0))
+
+
+def _start_all(procs):
+    """Start the worker processes WITHOUT letting them re-import the caller's main module.  multiprocessing's spawn makes
+    every child run the parent's __main__ top level (that is how it finds functions defined there); ours live in this
+    module, and a main module that imports torch costs each worker 1.5 s (minutes on a cold page cache) and needs an
+    `if __name__ == "__main__"` guard to be safe.  Hiding __main__'s file / spec while the children are created is what an
+    interactive session looks like to spawn: nothing to re-import."""
+    main = sys.modules.get("__main__")
+    saved_spec, saved_file = getattr(main, "__spec__", None), getattr(main, "__file__", None)
+    had_file = main is not None and hasattr(main, "__file__")
+    try:
+        if main is not None:
+            main.__spec__ = None
+            if had_file:
+                del main.__file__
+        for p in procs:
+            p.start()
+    finally:
+        if main is not None:
+            main.__spec__ = saved_spec
+            if had_file:
+                main.__file__ = saved_file
 
 
 def _next_message(result_q, procs):
@@ -229,6 +258,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
     predict_block(image u8 [n, seq, features], labels u8 [n, seq], phred u8 [n, seq]) runs the device pass on host
     arrays that live in page-locked shared memory and fills labels / phred.  Output files: `<output_stem>.hdf` for one
     lane, `<output_stem>_<lane>.hdf` otherwise.  Returns the number of chunks processed."""
+    t_begin = time.perf_counter()
     groups = deal_files(files, max(1, lanes))
     lanes = len(groups)
     if lanes == 0:
@@ -251,10 +281,11 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
                                      daemon=True))
             procs.append(ctx.Process(target=polish_writer, args=(k, result_q, out, slots[k].names, largs, write_qs[k], free_qs[k]),
                                      daemon=True))
-        for p in procs:
-            p.start()
+        _start_all(procs)
+        _trace(t_begin, "workers started")
         for sl in slots:
             sl.register()
+        _trace(t_begin, "slots page-locked")
         reading, writing = lanes, lanes
         while writing:
             msg = _next_message(result_q, procs)
@@ -264,6 +295,8 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
             if kind == "block":
                 _, _, slot, n, meta = msg
                 image, _, _, labels, phred = layout.views(slots[lane].segments[slot].buf, n)
+                if done == 0:
+                    _trace(t_begin, "first block on the GPU")
                 predict_block(image, labels, phred)
                 del image, labels, phred
                 write_qs[lane].put((slot, n, meta))
@@ -275,8 +308,10 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
                 write_qs[lane].put(None)
             elif kind == "write_done":
                 writing -= 1
+        _trace(t_begin, "all lanes written")
         for p in procs:
             p.join(timeout=60)
+        _trace(t_begin, "workers joined")
     finally:
         for p in procs:
             if p.is_alive():
@@ -346,6 +381,7 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
     host array in page-locked shared memory.  Output: `<output_stem>.hdf` for one lane, `<output_stem>_<lane>.hdf`
     otherwise; batch_<n> numbering runs over the files of a lane, as it runs over the files of a caller in the reference
     (predict_distributed_gpu.py:40-67).  Returns (batches written, windows processed)."""
+    t_begin = time.perf_counter()
     groups = deal_files(files, max(1, lanes))
     lanes = len(groups)
     if lanes == 0:
@@ -366,10 +402,11 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
             procs.append(ctx.Process(target=variant_reader, args=(k, result_q, image_directory, groups[k], slots[k].names,
                                                                    slot_bytes, free_qs[k]), daemon=True))
             procs.append(ctx.Process(target=variant_writer, args=(k, result_q, out, batch_size, write_qs[k]), daemon=True))
-        for p in procs:
-            p.start()
+        _start_all(procs)
+        _trace(t_begin, "workers started")
         for sl in slots:
             sl.register()
+        _trace(t_begin, "slots page-locked")
         writing = lanes
         files_done = 0
         while writing:
@@ -380,6 +417,8 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
             if kind == "block":
                 _, _, slot, meta = msg
                 contigs, positions, depths, blob, offsets, freqs, shape = meta
+                if windows == 0:
+                    _trace(t_begin, "first block on the GPU")
                 if shape[0]:
                     images = slots[lane].view(slot, 0, shape, np.int8)
                     probs = forward_block(images)
@@ -395,8 +434,10 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
             elif kind == "write_done":
                 writing -= 1
                 batches += msg[2]
+        _trace(t_begin, "all lanes written")
         for p in procs:
             p.join(timeout=60)
+        _trace(t_begin, "workers joined")
     finally:
         for p in procs:
             if p.is_alive():

@@ -11,7 +11,6 @@ from os import listdir
 from os.path import isfile, join
 
 import numpy as np
-import torch
 
 from pepper_amd import h5
 
@@ -105,6 +104,7 @@ class SequenceDataset(object):
         depth = [item[2] for item in batch]
         candidate = [item[3] for item in batch]
         candidate_frequency = [item[4] for item in batch]
+        import torch        # only here: the lane pipeline's reader processes import this module and must stay torch-free
         image = torch.FloatTensor(np.array([item[5] for item in batch]))
         return [contig, position, depth, candidate, candidate_frequency, image]
 
