@@ -67,8 +67,10 @@ int pa_variant_forward_device(pa_variant_model* m, const int8_t* images, int64_t
 /* Same with float32 images (the reference feeds FloatTensor; values need not be integral). */
 int pa_variant_forward_device_f32(pa_variant_model* m, const float* images, int64_t n,
                                   float* probs, float* logits);
-/* Same with HOST pointers: H2D copy of the packed int8 windows, forward, D2H copy of the
- * results, synchronous.  replaces predict_distributed_gpu.py:60-67 (.cuda() ... .cpu()). */
+/* Same with HOST pointers, any n: the call is cut into device passes of max_chunk windows and the H2D copy of
+ * pass i+1 / the D2H copy of pass i-1 run on their own streams beside the kernels of pass i (asynchronous only from
+ * page-locked buffers, see pa_host_register); returns when the results are in `probs`.
+ * replaces predict_distributed_gpu.py:60-67 (.cuda() ... .cpu() per batch). */
 int pa_variant_forward_host(pa_variant_model* m, const int8_t* images, int64_t n, float* probs,
                             float* logits);
 
@@ -123,6 +125,13 @@ int pa_profile_get(void* model, int32_t idx, char* label, int32_t label_cap, dou
                    int64_t* launches, double* flops);    /* synchronises the stream            */
 /* Block until everything queued on the handle's stream has finished. */
 int pa_synchronize(void* model);
+
+/* Page-lock / release caller memory (hipHostRegister / hipHostUnregister).  The *_host entry points copy asynchronously --
+ * H2D of the next device pass and D2H of the previous one beside the kernels -- only from page-locked buffers; the
+ * reference gets the same effect from DataLoader(pin_memory=True).  Used for the shared-memory slots of the reader /
+ * writer lanes (pepper_amd/hostpipe.py), which a torch allocation cannot provide. */
+int pa_host_register(void* ptr, int64_t bytes);
+int pa_host_unregister(void* ptr);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,8 @@ SYMBOLS = [
     ("pa_profile_get", ctypes.c_int, [c_void_p, c_int32, c_char_p, c_int32, ctypes.POINTER(c_double),
                                       ctypes.POINTER(c_int64), ctypes.POINTER(c_double)]),
     ("pa_synchronize", ctypes.c_int, [c_void_p]),
+    ("pa_host_register", ctypes.c_int, [c_void_p, c_int64]),
+    ("pa_host_unregister", ctypes.c_int, [c_void_p]),
     # include/pepper_amd_encoder.h (struct pointers passed as void*; typed structs live in
     # pepper_amd/variant/PEPPER_VARIANT.py)
     ("pa_encoder_create", ctypes.c_int, [c_int32, c_void_p, ctypes.POINTER(c_void_p)]),

@@ -1114,6 +1114,18 @@ int pa_profile_get(void* model, int32_t idx, char* label, int32_t label_cap, dou
     return PA_OK;
 }
 
+int pa_host_register(void* ptr, int64_t bytes) {
+    if (!ptr || bytes <= 0) return fail(PA_ERR_INVALID, "bad buffer");
+    HIP_TRY(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    return PA_OK;
+}
+
+int pa_host_unregister(void* ptr) {
+    if (!ptr) return fail(PA_ERR_INVALID, "bad buffer");
+    HIP_TRY(hipHostUnregister(ptr));
+    return PA_OK;
+}
+
 int pa_synchronize(void* model) {
     ModelBase* b = as_base(model);
     if (!b) return fail(PA_ERR_INVALID, "bad model handle");

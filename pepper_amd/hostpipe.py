@@ -53,30 +53,32 @@ def _attach(name):
 
 
 class Slots(object):
-    """`count` shared segments of `nbytes`, created (and page-locked for the GPU) by the process that runs the device."""
+    """`count` shared segments of `nbytes`, created by the process that runs the device.  register_async() page-locks
+    them for the GPU (pa_host_register = hipHostRegister, ~4 GB/s on the MI355X host) on a background thread, in the
+    order given, while the workers start and read; ready(i) waits for segment i."""
 
-    def __init__(self, count, nbytes, register=False):
+    def __init__(self, count, nbytes):
+        import threading
         self.nbytes = int(nbytes)
         self.segments = [shared_memory.SharedMemory(create=True, size=max(1, self.nbytes)) for _ in range(count)]
         self.names = [s.name for s in self.segments]
         self.registered = []
-        if register:
-            self.register()
+        self._ready = [threading.Event() for _ in range(count)]
 
-    def register(self):
-        """Page-lock the segments for the GPU (hipHostRegister).  Called after the worker processes have been started,
-        so that pinning a few GB overlaps their start-up and first reads."""
-        if not self.registered:
-            try:
-                import torch
-                rt = torch.cuda.cudart()
-                for s in self.segments:
-                    ptr = np.frombuffer(s.buf, np.uint8).ctypes.data
-                    rc = rt.cudaHostRegister(ptr, self.nbytes, 0)
-                    if int(rc) == 0:
-                        self.registered.append(ptr)
-            except Exception:
-                pass      # pageable slots still work, the copies just stage through the runtime
+    def _register_one(self, i):
+        try:
+            from pepper_amd import _lib
+            lib = _lib.load()
+            ptr = np.frombuffer(self.segments[i].buf, np.uint8).ctypes.data
+            if lib.pa_host_register(ptr, self.nbytes) == 0:
+                self.registered.append(ptr)
+        except Exception:
+            pass          # pageable slots still work, the copies just stage through the runtime
+        finally:
+            self._ready[i].set()
+
+    def ready(self, i):
+        self._ready[i].wait()
 
     def view(self, i, offset, shape, dtype):
         return np.ndarray(shape, dtype, buffer=self.segments[i].buf, offset=offset)
@@ -84,10 +86,10 @@ class Slots(object):
     def close(self):
         if self.registered:
             try:
-                import torch
-                rt = torch.cuda.cudart()
+                from pepper_amd import _lib
+                lib = _lib.load()
                 for ptr in self.registered:
-                    rt.cudaHostUnregister(ptr)
+                    lib.pa_host_unregister(ptr)
             except Exception:
                 pass
             self.registered = []
@@ -101,6 +103,31 @@ class Slots(object):
             except Exception:
                 pass
         self.segments = []
+
+
+def register_async(slot_sets, use_gpu=True):
+    """Page-lock every segment of every Slots object on one background thread: slot 0 of each lane first, then slot 1 ...
+    (the order the lanes will need them).  Without a GPU (CPU tests) the segments are just marked ready."""
+    import threading
+    order = [(sl, i) for i in range(max(len(sl.segments) for sl in slot_sets)) for sl in slot_sets if i < len(sl.segments)]
+
+    def work():
+        for sl, i in order:
+            if use_gpu:
+                sl._register_one(i)
+            else:
+                sl._ready[i].set()
+    t = threading.Thread(target=work, name="pepper-amd-pagelock", daemon=True)
+    t.start()
+    return t
+
+
+def _have_gpu():
+    try:
+        from pepper_amd import _lib
+        return _lib.load().pa_device_count() > 0
+    except Exception:
+        return False
 
 
 def deal_files(files, lanes):
@@ -272,6 +299,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
     write_qs = [ctx.Queue() for _ in range(lanes)]
     procs = []
     done = 0
+    locker = None
     try:
         for k in range(lanes):
             for s in range(slots_per_lane):
@@ -283,9 +311,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
                                      daemon=True))
         _start_all(procs)
         _trace(t_begin, "workers started")
-        for sl in slots:
-            sl.register()
-        _trace(t_begin, "slots page-locked")
+        locker = register_async(slots, _have_gpu())
         reading, writing = lanes, lanes
         while writing:
             msg = _next_message(result_q, procs)
@@ -295,6 +321,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
             if kind == "block":
                 _, _, slot, n, meta = msg
                 image, _, _, labels, phred = layout.views(slots[lane].segments[slot].buf, n)
+                slots[lane].ready(slot)
                 if done == 0:
                     _trace(t_begin, "first block on the GPU")
                 predict_block(image, labels, phred)
@@ -309,6 +336,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
             elif kind == "write_done":
                 writing -= 1
         _trace(t_begin, "all lanes written")
+        locker.join()
         for p in procs:
             p.join(timeout=60)
         _trace(t_begin, "workers joined")
@@ -316,6 +344,8 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
         for p in procs:
             if p.is_alive():
                 p.terminate()
+        if locker is not None:
+            locker.join()
         for s in slots:
             s.close()
     return done
@@ -374,7 +404,7 @@ def variant_writer(lane, result_q, *args):
     _guarded(_variant_writer, lane, result_q, args)
 
 
-def variant_lanes(image_directory, files, output_stem, forward_block, batch_size, lanes, slots_per_lane=2, log=None):
+def variant_lanes(image_directory, files, output_stem, forward_block, batch_size, lanes, slots_per_lane=0, log=None):
     """Run the variant predict loop over `files` with `lanes` reader/writer process pairs.
 
     forward_block(images int8 [n, window, features]) -> float32 probabilities [n, classes] runs the device pass on a
@@ -387,6 +417,8 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
     if lanes == 0:
         return 0, 0
     slot_bytes = max(os.path.getsize(f) for f in files)       # the image block of a file is smaller than the file
+    if slots_per_lane <= 0:      # with four lanes or more the other lanes keep the GPU busy while one lane's slot is in use
+        slots_per_lane = 1 if lanes >= 4 else 2
     ctx = get_context("spawn")
     slots = [Slots(slots_per_lane, slot_bytes) for _ in range(lanes)]
     result_q = ctx.Queue()
@@ -394,6 +426,7 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
     write_qs = [ctx.Queue() for _ in range(lanes)]
     procs = []
     windows = batches = 0
+    locker = None
     try:
         for k in range(lanes):
             for s in range(slots_per_lane):
@@ -404,9 +437,7 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
             procs.append(ctx.Process(target=variant_writer, args=(k, result_q, out, batch_size, write_qs[k]), daemon=True))
         _start_all(procs)
         _trace(t_begin, "workers started")
-        for sl in slots:
-            sl.register()
-        _trace(t_begin, "slots page-locked")
+        locker = register_async(slots, _have_gpu())
         writing = lanes
         files_done = 0
         while writing:
@@ -417,6 +448,7 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
             if kind == "block":
                 _, _, slot, meta = msg
                 contigs, positions, depths, blob, offsets, freqs, shape = meta
+                slots[lane].ready(slot)
                 if windows == 0:
                     _trace(t_begin, "first block on the GPU")
                 if shape[0]:
@@ -435,6 +467,7 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
                 writing -= 1
                 batches += msg[2]
         _trace(t_begin, "all lanes written")
+        locker.join()
         for p in procs:
             p.join(timeout=60)
         _trace(t_begin, "workers joined")
@@ -442,6 +475,8 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
         for p in procs:
             if p.is_alive():
                 p.terminate()
+        if locker is not None:
+            locker.join()
         for s in slots:
             s.close()
     return batches, windows
