@@ -279,11 +279,13 @@ def polish_writer(lane, result_q, *args):
     _guarded(_polish_writer, lane, result_q, args)
 
 
-def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1000, features=10, slots_per_lane=3, log=None):
+def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1000, features=10, slots_per_lane=3, log=None,
+                 prepare=None):
     """Run the polish predict loop over `files` with `lanes` reader/writer process pairs.
 
     predict_block(image u8 [n, seq, features], labels u8 [n, seq], phred u8 [n, seq]) runs the device pass on host
-    arrays that live in page-locked shared memory and fills labels / phred.  Output files: `<output_stem>.hdf` for one
+    arrays that live in page-locked shared memory and fills labels / phred; prepare() (optional) runs in this process
+    right after the workers have been started.  Output files: `<output_stem>.hdf` for one
     lane, `<output_stem>_<lane>.hdf` otherwise.  Returns the number of chunks processed."""
     t_begin = time.perf_counter()
     groups = deal_files(files, max(1, lanes))
@@ -312,6 +314,9 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
         _start_all(procs)
         _trace(t_begin, "workers started")
         locker = register_async(slots, _have_gpu())
+        if prepare is not None:
+            prepare()              # e.g. load the checkpoint and build the model while the readers start and read
+            _trace(t_begin, "caller prepared")
         reading, writing = lanes, lanes
         while writing:
             msg = _next_message(result_q, procs)
@@ -354,43 +359,118 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
 # ============================================================================================================
 # variant: summaries/<region> image groups -> predictions/batch_<n>
 # ============================================================================================================
-def _variant_reader(lane, result_q, image_directory, files, slot_names, slot_bytes, free_q):
-    from pepper_amd.variant.models.dataloader_predict import SequenceDataset
+VARIANT_BLOCK_WINDOWS = 131072      # a reader hands over this many windows at a time (112 MB of int8 summaries)
+
+
+def _variant_reader(lane, result_q, image_directory, files, slot_names, slot_bytes, free_q, block_windows=VARIANT_BLOCK_WINDOWS):
+    """Files of the lane, in order; each file's summaries groups in name order (as SequenceDataset reads them), handed over
+    in blocks of whole groups of about VARIANT_BLOCK_WINDOWS windows: the GPU starts after the first block, not after the
+    first file, and a slot is a block, not a file."""
+    from pepper_amd import h5
     segs = [_attach(n) for n in slot_names]
+
+    def flush(slot, rows, shape, parts, file_end):
+        contigs, positions, depths, cands, freqs = parts
+        if rows:
+            width = max(c.dtype.itemsize for c in contigs)
+            blob = np.frombuffer(b"".join(cands) + b"\0", np.uint8)
+            ends = np.flatnonzero(blob[:-1] == 0)
+            offsets = np.concatenate(([0], ends[:-1] + 1)).astype(np.int64) if len(ends) else np.zeros(0, np.int64)
+            meta = (np.concatenate([c.astype("S%d" % width) for c in contigs]), np.concatenate(positions), np.concatenate(depths),
+                    blob, offsets, np.concatenate(freqs), (rows,) + tuple(shape))
+        else:
+            meta = None
+        result_q.put(("block", lane, slot, meta, file_end))
+
     try:
         for path in files:
-            slot = free_q.get()
-
-            def alloc(n, window, features, _slot=slot):
-                if n * window * features > slot_bytes:
-                    raise LaneError("%s holds %d windows, more than a staging slot of %d bytes" % (path, n, slot_bytes))
-                return np.ndarray((n, window, features), np.int8, buffer=segs[_slot].buf)
-            data = SequenceDataset(image_directory, path, None, alloc)
-            meta = (data.all_contigs, data.all_positions, data.all_depths, data.candidate_blob, data.candidate_offsets,
-                    data.all_candidate_frequency, tuple(data.all_images.shape))
-            del data
-            result_q.put(("block", lane, slot, meta))
+            slot, rows, shape = None, 0, None
+            parts = ([], [], [], [], [])
+            with h5.File(path, 'r') as f:
+                names = f.keys('summaries') if 'summaries' in f else []
+                for name in names:
+                    base = 'summaries/' + name + '/'
+                    dims = f.info(base + 'images')[0]
+                    n = int(dims[0])
+                    if n == 0:
+                        continue
+                    if shape is None:
+                        shape = tuple(dims[1:])
+                    elif tuple(dims[1:]) != shape:
+                        raise ValueError("image shapes differ between groups: %r vs %r" % (tuple(dims[1:]), shape))
+                    per = int(np.prod(shape))
+                    if n * per > slot_bytes:
+                        raise LaneError("group %s of %s holds %d windows, more than a staging slot of %d bytes" % (name, path, n, slot_bytes))
+                    if slot is not None and ((rows + n) * per > slot_bytes or rows >= block_windows):
+                        flush(slot, rows, shape, parts, False)
+                        slot, rows, parts = None, 0, ([], [], [], [], [])
+                    if slot is None:
+                        slot = free_q.get()
+                    images = np.ndarray((n,) + shape, np.int8, buffer=segs[slot].buf, offset=rows * per)
+                    f.read_into(base + 'images', images)
+                    del images
+                    rows += n
+                    parts[0].append(f[base + 'contigs'])
+                    parts[1].append(f[base + 'positions'])
+                    parts[2].append(f[base + 'depths'])
+                    parts[3].append(f.read_strings_raw(base + 'candidates'))
+                    parts[4].append(f[base + 'candidate_frequency'])
+            if slot is None:
+                slot = free_q.get()
+            flush(slot, rows, shape if shape is not None else (33, 26), parts, True)      # (possibly empty) end-of-file block
         result_q.put(("read_done", lane))
     finally:
         _close_all(segs)
 
 
 def _variant_writer(lane, result_q, output_filename, batch_size, write_q):
+    """predictions/batch_<n> groups of batch_size windows, cut per image file exactly as the in-process loop cuts them (a
+    file's windows in order, the last batch of a file partial, numbering continuing over the lane's files): rows of a
+    block that do not fill a batch wait for the next block of the same file."""
     from pepper_amd.variant.DataStorePredict import DataStore
     store = DataStore(output_filename, mode='w')
     batch_no = 0
+    held = None            # (contigs, positions, depths, candidate strings list, freqs, probs) not yet written
+
+    def rows_of(item):
+        contigs, positions, depths, blob, offsets, freqs, probs = item
+        raw = blob.tobytes().split(b"\0")[:len(offsets)]
+        return [contigs, positions, depths, raw, freqs, probs]
+
+    def write(rows, count):
+        nonlocal batch_no
+        contigs, positions, depths, raw, freqs, probs = rows
+        for s in range(0, count, batch_size):
+            e = min(count, s + batch_size)
+            blob = np.frombuffer(b"\0".join(raw[s:e]) + b"\0\0", np.uint8)
+            lens = np.fromiter((len(r) + 1 for r in raw[s:e]), np.int64, e - s)
+            offsets = np.concatenate(([0], np.cumsum(lens)[:-1])) if e > s else np.zeros(0, np.int64)
+            store.write_prediction_arrays(batch_no, contigs[s:e], positions[s:e], depths[s:e], blob, offsets, freqs[s:e], probs[s:e])
+            batch_no += 1
+
     try:
         while True:
             item = write_q.get()
             if item is None:
                 break
-            contigs, positions, depths, blob, offsets, freqs, probs = item
-            n = len(positions)
-            for s in range(0, n, batch_size):
-                e = min(n, s + batch_size)
-                store.write_prediction_arrays(batch_no, contigs[s:e], positions[s:e], depths[s:e], blob, offsets[s:e],
-                                              freqs[s:e], probs[s:e])
-                batch_no += 1
+            payload, file_end = item
+            rows = rows_of(payload) if payload is not None else None
+            if held is not None and rows is not None:
+                width = max(held[0].dtype.itemsize, rows[0].dtype.itemsize)
+                rows = [np.concatenate([held[0].astype("S%d" % width), rows[0].astype("S%d" % width)]),
+                        np.concatenate([held[1], rows[1]]), np.concatenate([held[2], rows[2]]), held[3] + rows[3],
+                        np.concatenate([held[4], rows[4]]), np.concatenate([held[5], rows[5]])]
+            elif rows is None:
+                rows = held
+            held = None
+            if rows is None:
+                continue
+            n = len(rows[1])
+            full = n if file_end else (n // batch_size) * batch_size
+            if full:
+                write(rows, full)
+            if full < n:
+                held = [rows[0][full:], rows[1][full:], rows[2][full:], rows[3][full:], rows[4][full:], rows[5][full:]]
         result_q.put(("write_done", lane, batch_no))
     finally:
         store.close()
@@ -404,7 +484,8 @@ def variant_writer(lane, result_q, *args):
     _guarded(_variant_writer, lane, result_q, args)
 
 
-def variant_lanes(image_directory, files, output_stem, forward_block, batch_size, lanes, slots_per_lane=0, log=None):
+def variant_lanes(image_directory, files, output_stem, forward_block, batch_size, lanes, slots_per_lane=0, log=None,
+                  block_windows=VARIANT_BLOCK_WINDOWS, prepare=None):
     """Run the variant predict loop over `files` with `lanes` reader/writer process pairs.
 
     forward_block(images int8 [n, window, features]) -> float32 probabilities [n, classes] runs the device pass on a
@@ -416,9 +497,11 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
     lanes = len(groups)
     if lanes == 0:
         return 0, 0
-    slot_bytes = max(os.path.getsize(f) for f in files)       # the image block of a file is smaller than the file
-    if slots_per_lane <= 0:      # with four lanes or more the other lanes keep the GPU busy while one lane's slot is in use
-        slots_per_lane = 1 if lanes >= 4 else 2
+    # a slot holds one block of whole groups: VARIANT_BLOCK_WINDOWS windows plus room for the group that crosses the mark
+    # (a file smaller than that needs only its own size; a single group larger than a slot is an error the caller sees)
+    slot_bytes = min(max(os.path.getsize(f) for f in files), 3 * max(block_windows, VARIANT_BLOCK_WINDOWS) * 33 * 26)
+    if slots_per_lane <= 0:
+        slots_per_lane = 2
     ctx = get_context("spawn")
     slots = [Slots(slots_per_lane, slot_bytes) for _ in range(lanes)]
     result_q = ctx.Queue()
@@ -433,11 +516,14 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
                 free_qs[k].put(s)
             out = output_stem + ".hdf" if lanes == 1 else "%s_%d.hdf" % (output_stem, k)
             procs.append(ctx.Process(target=variant_reader, args=(k, result_q, image_directory, groups[k], slots[k].names,
-                                                                   slot_bytes, free_qs[k]), daemon=True))
+                                                                   slot_bytes, free_qs[k], block_windows), daemon=True))
             procs.append(ctx.Process(target=variant_writer, args=(k, result_q, out, batch_size, write_qs[k]), daemon=True))
         _start_all(procs)
         _trace(t_begin, "workers started")
         locker = register_async(slots, _have_gpu())
+        if prepare is not None:
+            prepare()              # e.g. load the checkpoint and build the model while the readers start and read
+            _trace(t_begin, "caller prepared")
         writing = lanes
         files_done = 0
         while writing:
@@ -446,21 +532,24 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
             if kind == "error":
                 raise LaneError("lane %d failed:\n%s" % (lane, msg[2]))
             if kind == "block":
-                _, _, slot, meta = msg
-                contigs, positions, depths, blob, offsets, freqs, shape = meta
-                slots[lane].ready(slot)
-                if windows == 0:
-                    _trace(t_begin, "first block on the GPU")
-                if shape[0]:
+                _, _, slot, meta, file_end = msg
+                if meta is not None:
+                    contigs, positions, depths, blob, offsets, freqs, shape = meta
+                    slots[lane].ready(slot)
+                    if windows == 0:
+                        _trace(t_begin, "first block on the GPU")
                     images = slots[lane].view(slot, 0, shape, np.int8)
                     probs = forward_block(images)
                     del images
-                    write_qs[lane].put((contigs, positions, depths, blob, offsets, freqs, np.asarray(probs)))
+                    write_qs[lane].put(((contigs, positions, depths, blob, offsets, freqs, np.asarray(probs)), file_end))
                     windows += shape[0]
+                else:
+                    write_qs[lane].put((None, file_end))
                 free_qs[lane].put(slot)               # the forward has consumed the images
-                files_done += 1
-                if log is not None:
-                    log(files_done)
+                if file_end:
+                    files_done += 1
+                    if log is not None:
+                        log(files_done)
             elif kind == "read_done":
                 write_qs[lane].put(None)
             elif kind == "write_done":

@@ -31,13 +31,18 @@ DEVICE_CHUNKS = 8192     # chunks per device pass (19 windows of 100 rows each; 
 def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size, num_workers, rank, device_id,
             model=None):
     torch.cuda.set_device(device_id)
-    if model is None:
-        model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model_for_training(
-            model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS, image_features=ImageSizeOptions.IMAGE_HEIGHT,
-            seq_len=ImageSizeOptions.SEQ_LENGTH, num_classes=ImageSizeOptions.TOTAL_LABELS)
-    model.eval()
+    holder = {"model": model}
+
+    def get_model():
+        if holder["model"] is None:
+            holder["model"] = ModelHandler.load_simple_model_for_training(
+                model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS, image_features=ImageSizeOptions.IMAGE_HEIGHT,
+                seq_len=ImageSizeOptions.SEQ_LENGTH, num_classes=ImageSizeOptions.TOTAL_LABELS)[0]
+            holder["model"].eval()
+        return holder["model"]
     # big jobs (or num_workers > 0, the reference's DataLoader(num_workers=...)): reader and writer processes per lane of
-    # image files around this process's GPU loop; libhdf5's one-lock-per-process is what bounds the loop below
+    # image files around this process's GPU loop; libhdf5's one-lock-per-process is what bounds the loop below.  The
+    # checkpoint is loaded while the workers start and read.
     from pepper_amd import hostpipe
     lanes = hostpipe.default_lanes(file_chunks, num_workers)
     layout = hostpipe.PolishLayout(DEVICE_CHUNKS, ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT)
@@ -45,10 +50,12 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
         def log(done):
             if rank == 0:
                 _log("INFO: CHUNKS PROCESSED " + str(done) + ".")
-        hostpipe.polish_lanes(file_chunks, output_filepath + "pepper_prediction_" + str(rank), model.predict_chunks_into, lanes,
+        hostpipe.polish_lanes(file_chunks, output_filepath + "pepper_prediction_" + str(rank),
+                              lambda image, labels, phred: get_model().predict_chunks_into(image, labels, phred), lanes,
                               block=DEVICE_CHUNKS, seq_len=ImageSizeOptions.SEQ_LENGTH, features=ImageSizeOptions.IMAGE_HEIGHT,
-                              slots_per_lane=2, log=log)
+                              slots_per_lane=2, log=log, prepare=get_model)
         return rank
+    model = get_model()
     output_filename = output_filepath + "pepper_prediction_" + str(rank) + ".hdf"
     prediction_data_file = DataStore(output_filename, mode='w')
     input_data = SequenceDataset(input_filepath, file_chunks)

@@ -65,22 +65,29 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
     if device is None:
         device = torch.cuda.current_device()
     torch.cuda.set_device(device)
-    if model is None:
-        model, hidden_size, gru_layers, prev_ite = ModelHandler.load_simple_model_for_training(
-            options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT,
-            num_classes=ImageSizeOptions.TOTAL_LABELS, num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)
-    model.eval()
+    holder = {"model": model}
+
+    def get_model():
+        if holder["model"] is None:
+            holder["model"] = ModelHandler.load_simple_model_for_training(
+                options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT,
+                num_classes=ImageSizeOptions.TOTAL_LABELS, num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)[0]
+            holder["model"].eval()
+        return holder["model"]
     suffix = "" if rank is None else "_" + str(rank)
     # big jobs (or options.num_workers > 0, the reference's DataLoader(num_workers=...), RunInferenceArguments.py:75-82): reader
-    # and writer processes per lane of image files around this process's GPU loop (libhdf5 has one lock per process)
+    # and writer processes per lane of image files around this process's GPU loop (libhdf5 has one lock per process); the
+    # checkpoint is loaded while they start and read
     from pepper_amd import hostpipe
     lanes = hostpipe.default_lanes(input_files, int(getattr(options, "num_workers", 0) or 0))
-    if lanes > 0 and hostpipe.shm_room(2 * lanes * max(__import__("os").path.getsize(f) for f in input_files)):
+    if lanes > 0 and hostpipe.shm_room(2 * lanes * 3 * hostpipe.VARIANT_BLOCK_WINDOWS * 33 * 26):
+        torch.set_num_threads(max(1, int(threads)))
+
         def log(done):
             _log("INFO: FILES COMPLETED: " + str(done) + "/" + str(len(input_files)) + ".")
         return hostpipe.variant_lanes(input_filepath, input_files, output_filepath + "pepper_prediction" + suffix,
-                                      lambda images: model(torch.from_numpy(images), False).numpy(), options.batch_size, lanes,
-                                      log=log)
+                                      lambda images: get_model()(torch.from_numpy(images), False).numpy(), options.batch_size, lanes,
+                                      log=log, prepare=get_model)
     output_filename = output_filepath + "pepper_prediction" + suffix + ".hdf"
     prediction_data_file = DataStore(output_filename, mode='w')
     torch.set_num_threads(max(1, int(threads)))
@@ -97,6 +104,7 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
     writes = []
     staging = _StagingBuffers()
     pending = reader.submit(SequenceDataset, input_filepath, input_files[0], None, staging.alloc) if input_files else None
+    model = get_model()          # the checkpoint is loaded while the first image file is being read
 
     def write_file(first_batch, input_data, probs):
         # bulk arrays straight into one library call per batch_<n> group (no per-candidate Python objects)

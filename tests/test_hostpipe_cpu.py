@@ -31,7 +31,7 @@ def _fake_forward(images):
     return (e / e.sum(1, keepdims=True)).astype(np.float32)
 
 
-def _read_variant_predictions(path):
+def _read_variant_predictions(path, compositions=None):
     out = {}
     with h5.File(path) as f:
         batches = sorted(f.keys("predictions"), key=lambda s: int(s.split("_")[1]))
@@ -39,6 +39,8 @@ def _read_variant_predictions(path):
             base = "predictions/%s/" % b
             pos, cand, probs, contigs = f[base + "positions"], f[base + "candidates"], f[base + "base_prediction"], f[base + "contigs"]
             assert probs.dtype == np.float64 and f[base + "depths"].dtype == np.uint8
+            if compositions is not None:
+                compositions.append(tuple(int(p) for p in pos))
             for i in range(len(pos)):
                 out[(bytes(contigs[i]), int(pos[i]), str(cand[i, 0]))] = np.array(probs[i])
     return out, batches
@@ -50,14 +52,18 @@ def test_variant_lanes_write_what_the_in_process_loop_writes(tmp_path):
     files = _variant_files(tmp_path, [(300, 0, 45), (0,), (17,), (700,)])
     out = tmp_path / "pred"
     out.mkdir()
-    batches, windows = hostpipe.variant_lanes(str(tmp_path), files, str(out / "pepper_prediction"), _fake_forward, 256, lanes=2)
+    # block_windows = 100: the readers hand a file over in several blocks of whole groups (300 | 45, 700 alone, ...), the
+    # writers must still cut batches of 256 per FILE exactly like the in-process loop (345 -> 256 + 89, 700 -> 256 + 256 + 188)
+    batches, windows = hostpipe.variant_lanes(str(tmp_path), files, str(out / "pepper_prediction"), _fake_forward, 256, lanes=2,
+                                              block_windows=100)
     assert windows == 300 + 45 + 17 + 700
     produced = sorted(os.listdir(out))
     assert produced == ["pepper_prediction_0.hdf", "pepper_prediction_1.hdf"]
     got = {}
     nb = 0
+    got_comp, want_comp = [], []
     for name in produced:
-        part, names = _read_variant_predictions(str(out / name))
+        part, names = _read_variant_predictions(str(out / name), got_comp)
         assert names == ["batch_%d" % i for i in range(len(names))]        # numbering runs over the files of a lane
         assert not set(part) & set(got)
         got.update(part)
@@ -75,7 +81,8 @@ def test_variant_lanes_write_what_the_in_process_loop_writes(tmp_path):
                 ds.write_prediction_arrays(b, d.all_contigs[s:e], d.all_positions[s:e], d.all_depths[s:e], d.candidate_blob,
                                            d.candidate_offsets[s:e], d.all_candidate_frequency[s:e], probs[s:e])
                 b += 1
-    want, _ = _read_variant_predictions(ref_path)
+    want, _ = _read_variant_predictions(ref_path, want_comp)
+    assert sorted(got_comp) == sorted(want_comp) and sorted(len(c) for c in want_comp) == [17, 89, 188, 256, 256, 256]
     assert set(want) == set(got) and len(want) == windows
     assert all(np.array_equal(want[k], got[k]) for k in want)
     assert not [n for n in os.listdir("/dev/shm") if n.startswith("psm_")] or True     # segments are unlinked by Slots.close
