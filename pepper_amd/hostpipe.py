@@ -146,6 +146,10 @@ class LaneError(RuntimeError):
     pass
 
 
+class SlotTooSmall(LaneError):
+    """One summaries group does not fit a staging slot: the caller falls back to its in-process loop."""
+
+
 def _trace(t0, what):
     if os.environ.get("PEPPER_AMD_LANE_TRACE"):
         sys.stderr.write("[lanes] %-28s %8.3f s\n" % (what, time.perf_counter() - t0))
@@ -322,7 +326,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
             msg = _next_message(result_q, procs)
             kind, lane = msg[0], msg[1]
             if kind == "error":
-                raise LaneError("lane %d failed:\n%s" % (lane, msg[2]))
+                raise (SlotTooSmall if "SlotTooSmall" in msg[2] else LaneError)("lane %d failed:\n%s" % (lane, msg[2]))
             if kind == "block":
                 _, _, slot, n, meta = msg
                 image, _, _, labels, phred = layout.views(slots[lane].segments[slot].buf, n)
@@ -359,7 +363,8 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
 # ============================================================================================================
 # variant: summaries/<region> image groups -> predictions/batch_<n>
 # ============================================================================================================
-VARIANT_BLOCK_WINDOWS = 131072      # a reader hands over this many windows at a time (112 MB of int8 summaries)
+VARIANT_BLOCK_WINDOWS = 65536       # a reader hands over about this many windows at a time (56 MB of int8 summaries)
+VARIANT_SLOT_BYTES = 3 * VARIANT_BLOCK_WINDOWS * 33 * 26 // 2      # a block plus the group that crosses the mark: 84 MB
 
 
 def _variant_reader(lane, result_q, image_directory, files, slot_names, slot_bytes, free_q, block_windows=VARIANT_BLOCK_WINDOWS):
@@ -400,7 +405,7 @@ def _variant_reader(lane, result_q, image_directory, files, slot_names, slot_byt
                         raise ValueError("image shapes differ between groups: %r vs %r" % (tuple(dims[1:]), shape))
                     per = int(np.prod(shape))
                     if n * per > slot_bytes:
-                        raise LaneError("group %s of %s holds %d windows, more than a staging slot of %d bytes" % (name, path, n, slot_bytes))
+                        raise SlotTooSmall("group %s of %s holds %d windows, more than a staging slot of %d bytes" % (name, path, n, slot_bytes))
                     if slot is not None and ((rows + n) * per > slot_bytes or rows >= block_windows):
                         flush(slot, rows, shape, parts, False)
                         slot, rows, parts = None, 0, ([], [], [], [], [])
@@ -497,9 +502,10 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
     lanes = len(groups)
     if lanes == 0:
         return 0, 0
-    # a slot holds one block of whole groups: VARIANT_BLOCK_WINDOWS windows plus room for the group that crosses the mark
-    # (a file smaller than that needs only its own size; a single group larger than a slot is an error the caller sees)
-    slot_bytes = min(max(os.path.getsize(f) for f in files), 3 * max(block_windows, VARIANT_BLOCK_WINDOWS) * 33 * 26)
+    # a slot holds one block of whole groups: block_windows windows plus room for the group that crosses the mark (a file
+    # smaller than that needs only its own size; a single group larger than a slot raises SlotTooSmall).  Small slots
+    # matter: page-locking holds the process's mm lock, and 4 GB of it slowed the concurrent checkpoint load by 0.5 s
+    slot_bytes = min(max(os.path.getsize(f) for f in files), max(VARIANT_SLOT_BYTES, 3 * block_windows * 33 * 26 // 2))
     if slots_per_lane <= 0:
         slots_per_lane = 2
     ctx = get_context("spawn")
@@ -530,7 +536,7 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
             msg = _next_message(result_q, procs)
             kind, lane = msg[0], msg[1]
             if kind == "error":
-                raise LaneError("lane %d failed:\n%s" % (lane, msg[2]))
+                raise (SlotTooSmall if "SlotTooSmall" in msg[2] else LaneError)("lane %d failed:\n%s" % (lane, msg[2]))
             if kind == "block":
                 _, _, slot, meta, file_end = msg
                 if meta is not None:
@@ -571,9 +577,11 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
     return batches, windows
 
 
-def default_lanes(files, requested, small=64 << 20):
+def default_lanes(files, requested, small=64 << 20, most=8):
     """options.num_workers > 0: that many lanes (at most one per file).  0: process lanes only when the job is big
-    enough to pay for spawning them (interpreter start-up is ~0.3 s per process)."""
+    enough to pay for them (start-up of the workers + page-locking of the slots is ~0.3 s), and then `most` of them
+    (measured on the MI355X host: 4 readers keep the variant loop at the device rate, 8 the polish loop; more lanes only
+    add page-locking and scheduling)."""
     if not files or os.environ.get("PEPPER_AMD_NO_LANES") == "1":
         return 0
     if requested and requested > 0:
@@ -581,7 +589,7 @@ def default_lanes(files, requested, small=64 << 20):
     total = sum(os.path.getsize(f) for f in files)
     if total < small or len(files) < 2:
         return 0
-    return min(len(files), 8)
+    return min(len(files), most)
 
 
 if __name__ == "__main__":

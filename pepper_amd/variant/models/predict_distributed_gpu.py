@@ -79,15 +79,22 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
     # and writer processes per lane of image files around this process's GPU loop (libhdf5 has one lock per process); the
     # checkpoint is loaded while they start and read
     from pepper_amd import hostpipe
-    lanes = hostpipe.default_lanes(input_files, int(getattr(options, "num_workers", 0) or 0))
-    if lanes > 0 and hostpipe.shm_room(2 * lanes * 3 * hostpipe.VARIANT_BLOCK_WINDOWS * 33 * 26):
+    lanes = hostpipe.default_lanes(input_files, int(getattr(options, "num_workers", 0) or 0), small=512 << 20, most=4)
+    if lanes > 0 and hostpipe.shm_room(2 * lanes * hostpipe.VARIANT_SLOT_BYTES):
         torch.set_num_threads(max(1, int(threads)))
 
         def log(done):
             _log("INFO: FILES COMPLETED: " + str(done) + "/" + str(len(input_files)) + ".")
-        return hostpipe.variant_lanes(input_filepath, input_files, output_filepath + "pepper_prediction" + suffix,
-                                      lambda images: get_model()(torch.from_numpy(images), False).numpy(), options.batch_size, lanes,
-                                      log=log, prepare=get_model)
+        try:
+            return hostpipe.variant_lanes(input_filepath, input_files, output_filepath + "pepper_prediction" + suffix,
+                                          lambda images: get_model()(torch.from_numpy(images), False).numpy(), options.batch_size,
+                                          lanes, log=log, prepare=get_model)
+        except hostpipe.SlotTooSmall as e:
+            # a single summaries group above 84 MB (98 k windows; a 100 kb region has a few hundred): the in-process loop
+            # below takes whole files and has no such limit
+            _log("INFO: " + str(e).strip().splitlines()[-1] + " -- continuing in one process.")
+            from pepper_amd.variant.RunInference import remove_stale_predictions
+            remove_stale_predictions(output_filepath, pattern="pepper_prediction" + suffix)
     output_filename = output_filepath + "pepper_prediction" + suffix + ".hdf"
     prediction_data_file = DataStore(output_filename, mode='w')
     torch.set_num_threads(max(1, int(threads)))

@@ -170,3 +170,18 @@ def test_default_lanes_policy(tmp_path):
     assert hostpipe.default_lanes([], 4) == 0
     groups = hostpipe.deal_files(small, 2)
     assert sorted(sum(groups, [])) == sorted(small) and len(groups) == 2
+
+
+def test_group_larger_than_a_slot_is_reported_as_such(tmp_path):
+    """A single summaries group above the staging slot (84 MB = 98 k windows; a 100 kb region has a few hundred) cannot be
+    handed over in blocks of whole groups: the lanes raise SlotTooSmall and predict() continues in one process."""
+    import pytest
+    from pepper_amd.variant.DataStore import DataStore
+    n = 100_000
+    x = np.resize(synthetic.variant_windows(512, seed=3), (n, 33, 26))
+    path = str(tmp_path / "pepper_variants_images_thread_0.hdf5")
+    with DataStore(path, "w") as ds:
+        ds.write_summary("chr1_0_100000", ["chr1"] * n, np.arange(n), np.full(n, 30), np.array([["1A"]] * n, dtype=object),
+                         np.full((n, 1), 7), x, [0] * n, [0] * n, False)
+    with pytest.raises(hostpipe.SlotTooSmall):
+        hostpipe.variant_lanes(str(tmp_path), [path], str(tmp_path / "pepper_prediction"), _fake_forward, 512, lanes=1)
