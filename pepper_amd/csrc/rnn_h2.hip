@@ -402,7 +402,8 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
                                                             uint32_t* __restrict__ Y, int ldy, int B, int T,
                                                             const uint32_t* __restrict__ Xh = nullptr, int ldxh = 0,
                                                             const uint32_t* __restrict__ Wd = nullptr,
-                                                            float* __restrict__ P = nullptr) {
+                                                            float* __restrict__ P = nullptr,
+                                                            unsigned long long* __restrict__ dbg = nullptr) {
     static_assert(!DENSE || (XG && H == 128), "the fused head belongs to the H = 128 layer fed by an h2 layer output");
     constexpr int DC = 5;                        // classes of the fused head (columns of the 16-wide MFMA tile in use)
     constexpr int KT = H + KX, KS = KT / 16, KSH = H / 16, NT = H / 32, RG = 8 / NT, MTG = MT * RG;
@@ -663,15 +664,27 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
         }
     };
 
+    // PA_DEBUG_TIMING=1 (tools/phase_timing_gru.py): cycles one workgroup's waves spend per phase, summed over the steps
+    const bool stamp = dbg != nullptr && blockIdx.x == 8 && lane == 0;
+    unsigned long long tsum[5] = {0, 0, 0, 0, 0}, tq = 0;
+    auto tick = [&](int k) {
+        if (stamp) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (k >= 0) tsum[k] += now - tq;
+            tq = now;
+        }
+    };
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
         const int tp = step > 0 ? (dir ? t + 1 : t - 1) : t;   // time index of h_{s-1} (step 0: h0, rewritten later)
+        tick(-1);
         // ---------------- MFMA phase ----------------
         {
             if (DENSE) {
                 dense_partials();                       // head partials of h_{s-1} (step 0: of h0, rewritten by step 1)
                 __builtin_amdgcn_sched_barrier(0);
             }
+            tick(0);
             Frag ring[2];
             load_step(0, ring[0]);
             u32x4 ycv = {0, 0, 0, 0};
@@ -734,7 +747,9 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) xn[m][qd] = load_xp4(m, t, 2, qd);
         }
+        tick(1);
         lds_barrier();
+        tick(2);
 
         // ---------------- gate phase ----------------
         const int tn = dir ? t - 1 : t + 1;
@@ -758,7 +773,13 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
                 if (step + 1 < T) seed_chunk(m, qd, tn);
             }
         if (step + 1 < T) x_store();
+        tick(3);
         lds_barrier();
+        tick(4);
+    }
+    if (stamp) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dbg[wave * 8 + k] = tsum[k];
     }
 
     {
@@ -1014,6 +1035,19 @@ namespace pa {
 
 unsigned long long* debug_buffer();   // rnn.hip (PA_DEBUG_TIMING=1)
 
+// PA_DEBUG_TIMING=1: [2 kernels][8 waves][8] u64 phase sums of the GRU step loops (decoder+head first, fused encoder
+// second), read by pa_debug_dump_gru_timing (tools/phase_timing_gru.py); debug aid, not in the ABI headers
+unsigned long long* g_dbg_gru = nullptr;
+unsigned long long* gru_debug_buffer() {
+    static const bool on = [] { const char* e = getenv("PA_DEBUG_TIMING"); return e && e[0] == '1'; }();
+    if (!on) return nullptr;
+    if (!g_dbg_gru) {
+        if (hipMalloc(&g_dbg_gru, 128 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_dbg_gru, 0, 128 * sizeof(unsigned long long));
+    }
+    return g_dbg_gru;
+}
+
 // W [G*H, K] per direction (K = H, or H + KX with [W_hh | W_ih | 0]) -> per-lane h2 fragments
 // [dir][G*H/32][K/16][hi, lo][64 lanes][8 halves]; lane l of tile nt, step s holds
 // W[nt*32 + (l&31)][16 s + 8 (l>>5) + e], e = 0..7.
@@ -1107,7 +1141,8 @@ hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, 
             if (stream_nt())
                 hipLaunchKernelGGL((gru_rec_h2_kernel<128, 16, false, 2>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
                                    F, x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
-                                   static_cast<uint32_t*>(Y), ldy, B, T);
+                                   static_cast<uint32_t*>(Y), ldy, B, T, (const uint32_t*)nullptr, 0, (const uint32_t*)nullptr,
+                                   (float*)nullptr, gru_debug_buffer() ? gru_debug_buffer() + 64 : nullptr);
             else
                 hipLaunchKernelGGL((gru_rec_h2_kernel<128, 16>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
                                    F, x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
@@ -1162,7 +1197,8 @@ hipError_t launch_gru_dec_h2_dense(int H, const void* Xh, int ldxh, const float*
 #define PA_GDD(AUX_)                                                                                                   \
     hipLaunchKernelGGL((gru_rec_h2_kernel<128, 256, true, AUX_, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, \
                        (const uint8_t*)nullptr, 0, (int64_t)0, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn, \
-                       (uint32_t*)nullptr, 8, B, T, static_cast<const uint32_t*>(Xh), ldxh, static_cast<const uint32_t*>(Wd), P)
+                       (uint32_t*)nullptr, 8, B, T, static_cast<const uint32_t*>(Xh), ldxh, static_cast<const uint32_t*>(Wd), P, \
+                       gru_debug_buffer())
     if (stream_nt()) PA_GDD(2); else PA_GDD(0);
 #undef PA_GDD
     return hipGetLastError();
@@ -1198,3 +1234,8 @@ hipError_t launch_gru_dec_h2(int H, const void* Xh, int ldxh, const float* bias,
 }
 
 }  // namespace pa
+
+extern "C" int pa_debug_dump_gru_timing(unsigned long long* host_out) {   // 128 values
+    if (!pa::g_dbg_gru) return 1;
+    return hipMemcpy(host_out, pa::g_dbg_gru, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
