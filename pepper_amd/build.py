@@ -72,7 +72,7 @@ def build(force=False, verbose=False):
     # F16C conversions clang calls a soft-float routine per value (0.4 s per variant model instead of tens of ms)
     tmp = f"{LIB}.{os.getpid()}.tmp"
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Xarch_host", "-mf16c",
-           "-Wno-unused-result", "-o", tmp] + SOURCES
+           "-Wno-unused-result"] + os.environ.get("PEPPER_AMD_EXTRA_HIPCC_FLAGS", "").split() + ["-o", tmp] + SOURCES
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     try:

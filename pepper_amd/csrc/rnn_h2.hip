@@ -665,6 +665,9 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
     };
 
     // PA_DEBUG_TIMING=1 (tools/phase_timing_gru.py): cycles one workgroup's waves spend per phase, summed over the steps
+    // (compiled in only with -DPA_GRU_PHASE_TIMING -- PEPPER_AMD_EXTRA_HIPCC_FLAGS for pepper_amd.build -- because the ten
+    // extra registers push the XG forms over their 256-register budget)
+#ifdef PA_GRU_PHASE_TIMING
     const bool stamp = dbg != nullptr && blockIdx.x == 8 && lane == 0;
     unsigned long long tsum[5] = {0, 0, 0, 0, 0}, tq = 0;
     auto tick = [&](int k) {
@@ -674,6 +677,9 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
             tq = now;
         }
     };
+#else
+    auto tick = [](int) {};
+#endif
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
         const int tp = step > 0 ? (dir ? t + 1 : t - 1) : t;   // time index of h_{s-1} (step 0: h0, rewritten later)
@@ -777,10 +783,12 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
         lds_barrier();
         tick(4);
     }
+#ifdef PA_GRU_PHASE_TIMING
     if (stamp) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) dbg[wave * 8 + k] = tsum[k];
     }
+#endif
 
     {
         const int tl = dir ? 0 : T - 1;

@@ -1,4 +1,5 @@
 """Debug aid (not product): where one workgroup's waves of the polish GRU step loops spend their cycles.
+    PEPPER_AMD_EXTRA_HIPCC_FLAGS=-DPA_GRU_PHASE_TIMING python -m pepper_amd.build   (then rebuild without it)
     PA_DEBUG_TIMING=1 python tools/phase_timing_gru.py
 Per kernel (decoder + fused head, fused encoder) and wave: cycles per step in the head block, the MFMA phase, the wait at
 the barrier behind it, the gate phase, and the wait at the barrier behind that (s_memtime sums over the 100 steps of the
