@@ -372,7 +372,10 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
     }
     if (want_h2 && ((G == 4 && H == 256) || (G == 3 && H == 128))) {
         const int KXh2 = G == 4 ? 32 : std::max(16, pa::gru_fused_input_kx(H, K));
-        auto pack_upload = [&](DevBuf*& dst, const float* const wx[2], int KX) -> int {
+        // bias column of the fused first layer (rnn_h2.hip BC): the (gate-scaled) input-side bias of every row, i.e. what
+        // the step loop would otherwise seed its accumulators with
+        const float* const bias_x[2] = {bs.data(), bs.data() + (size_t)G * H};
+        auto pack_upload = [&](DevBuf*& dst, const float* const wx[2], int KX, bool with_bias = false) -> int {
             for (int d = 0; d < 2; ++d) {
                 for (int64_t i = 0; i < (int64_t)G * H * H; ++i)
                     if (!(std::fabs(whh_x[d][i]) < 65504.0f)) return fail(PA_ERR_INVALID, "recurrent weight not representable in f16 range");
@@ -380,8 +383,11 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
                     for (int64_t i = 0; i < (int64_t)G * H * K; ++i)
                         if (!(std::fabs(wx[d][i]) < 65504.0f)) return fail(PA_ERR_INVALID, "input weight not representable in f16 range");
             }
+            if (with_bias)
+                for (int64_t i = 0; i < (int64_t)2 * G * H; ++i)
+                    if (!(std::fabs(bs[(size_t)i]) < 65504.0f)) return fail(PA_ERR_INVALID, "bias not representable in f16 range");
             std::vector<uint32_t> hp(pa::rec_weights_h2_words(G, H, KX));
-            pa::pack_rec_weights_h2(whh_x, wx, G, H, K, KX, hp.data());
+            pa::pack_rec_weights_h2(whh_x, wx, G, H, K, KX, hp.data(), with_bias ? bias_x : nullptr);
             dst = m->new_buf();
             if (int rc = dst->ensure(hp.size() * sizeof(uint32_t))) return rc;
             HIP_TRY(hipMemcpy(dst->p, hp.data(), hp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -390,7 +396,7 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
         const float* const none[2] = {nullptr, nullptr};
         if (int rc = pack_upload(out.w_hh_h2, none, 0)) return rc;
         if (K <= KXh2)
-            if (int rc = pack_upload(out.w_cat_h2, wih_x, KXh2)) return rc;
+            if (int rc = pack_upload(out.w_cat_h2, wih_x, KXh2, true)) return rc;
         if (K == 2 * H)
             if (int rc = pack_upload(out.w_cat_dec_h2, wih_x, K)) return rc;
     }

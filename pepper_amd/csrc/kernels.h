@@ -54,7 +54,7 @@ hipError_t launch_gru_rec_fused(int H, const uint8_t* X, int F, int64_t x_bstrid
 // selects the fused form (int8 rows [B, T, F], bias [2*4H]); otherwise Xp seeds the accumulators as in
 // launch_lstm_rec.  Y receives the layer output in the h2 split format (ldy in 4-byte elements).
 void pack_rec_weights_h2(const float* const whh[2], const float* const wih[2], int G, int H, int F, int KX,
-                         uint32_t* out);
+                         uint32_t* out, const float* const* bias = nullptr);   // bias: column H + F (fused layers, F < KX)
 size_t rec_weights_h2_words(int G, int H, int KX);
 int gru_fused_input_kx(int H, int F);   // 16 / 128: padded width of the uint8-input step loop; 0: projection as a GEMM
 // prescaled: weights / bias / Xp were multiplied per gate row by the exp2 constants (see rnn_h2.hip).

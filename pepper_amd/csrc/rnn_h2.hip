@@ -59,7 +59,10 @@ PA_DEV unsigned swap_pair(unsigned v) { return (unsigned)__builtin_amdgcn_update
 // SAUX: cache policy of the streams that pass through once -- the x slab loads of the XG form and the y stores (2 = nt:
 // the lines are not kept in the XCD's L2, which has to hold this direction's 3 MB of weight fragments that every
 // workgroup re-reads every step; 0 = default policy).
-template <int H, int KX, bool PRE, bool XG = false, int SAUX = 0>
+// BC (fused int8 first layer with F < KX): the bias lives in column H + F of the packed weights and x carries a constant
+// 1.0 there, so the first MFMA of a step starts every accumulator from the inline constant 0: no bias loads and no 128
+// register moves per step in the gate phase, which is bound by VALU issue (two waves per SIMD, ~1300 instructions each).
+template <int H, int KX, bool PRE, bool XG = false, int SAUX = 0, bool BC = false>
 __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
                                                                      const int8_t* __restrict__ Xi, int F,
                                                                      const float* __restrict__ bias,
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 
     // accumulator seed of (row tile m, register chunk qd) for step t (identical to rnn.hip)
     auto seed_chunk = [&](int m, int qd, int t) {
+        if (BC) return;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (KX) {
@@ -137,8 +141,9 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                 int brow = b0 + row;
                 brow = brow < B ? brow : B - 1;
                 const int8_t* src = Xi + ((size_t)brow * T + t) * F;
-                const _Float16 h0 = f < F ? (_Float16)(float)src[f] : (_Float16)0.0f;
-                const _Float16 h1 = f + 1 < F ? (_Float16)(float)src[f + 1] : (_Float16)0.0f;
+                const _Float16 one = BC ? (_Float16)1.0f : (_Float16)0.0f;     // the bias column's input
+                const _Float16 h0 = f < F ? (_Float16)(float)src[f] : (f == F ? one : (_Float16)0.0f);
+                const _Float16 h1 = f + 1 < F ? (_Float16)(float)src[f + 1] : (f + 1 == F ? one : (_Float16)0.0f);
                 xv[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) |
                         ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
             }
@@ -260,11 +265,13 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                 for (int term = 0; term < 3; ++term) {
                     // int8 summaries are exact in the hi half: their lo half is identically zero, so is lo(a) * hi(w)
                     if (XI8 && s >= KSH && term == 0) continue;
+                    const bool fresh = BC && s == 0 && term == 0;       // accumulators start from the inline constant 0
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
-                            acc[m][g] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0], acc[m][g]);
+                            acc[m][g] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0],
+                                               fresh ? f32x16{} : acc[m][g]);
                 }
                 if (XG && s + 1 < KS && s > YC) {
 #pragma unroll
@@ -391,7 +398,10 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 // MFMAs per step), the four k-quarter partials are summed through an LDS scratch behind a barrier the x ring needs
 // anyway, and 5 x 128 floats per step go to P[dir][batch tile][t][class][128 rows] (2.5 KB instead of the 128 KB of y).
 // polish_combine_kernel (head.hip) adds the two directions and the bias, takes the softmax and overlap-adds it.
-template <int H, int KX, bool XG = false, int SAUX = 0, bool DENSE = false>
+// BC: as in lstm_rec_h2_kernel, for the fused uint8 first layer with F < KX = 16: b_r, b_z and the input half of the n
+// gate's bias come out of the matrix pipe (bias column of the packed weights x constant 1.0 input); b_hn still seeds
+// the hidden half's accumulator.
+template <int H, int KX, bool XG = false, int SAUX = 0, bool DENSE = false, bool BC = false>
 __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
                                                             const uint8_t* __restrict__ Xi, int F, int64_t xi_bstride,
                                                             const float* __restrict__ bias,
@@ -549,7 +559,9 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
     const float b_r = KX ? bias[dir * 3 * H + col] : 0.0f, b_z = KX ? bias[dir * 3 * H + H + col] : 0.0f,
                 b_nx = KX ? bias[dir * 3 * H + 2 * H + col] : 0.0f;
     auto seed_chunk = [&](int m, int qd, int t) {
-        if (KX) {
+        if (KX && BC) {
+            // nothing: r, z and the input half of n start from the inline constant 0 (bias column)
+        } else if (KX) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[m][0][4 * qd + e] = b_r;
@@ -588,8 +600,9 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
                 if (XPT == 4) {
                     xv[k] = f < F ? *reinterpret_cast<const uint32_t*>(src + f) : 0u;
                 } else {
-                    const _Float16 v0 = f < F ? (_Float16)(float)src[f] : (_Float16)0.0f;
-                    const _Float16 v1 = f + 1 < F ? (_Float16)(float)src[f + 1] : (_Float16)0.0f;
+                    const _Float16 one = BC ? (_Float16)1.0f : (_Float16)0.0f;     // the bias column's input
+                    const _Float16 v0 = f < F ? (_Float16)(float)src[f] : (f == F ? one : (_Float16)0.0f);
+                    const _Float16 v1 = f + 1 < F ? (_Float16)(float)src[f + 1] : (f + 1 == F ? one : (_Float16)0.0f);
                     xv[k] = (unsigned)__builtin_bit_cast(unsigned short, v0) | ((unsigned)__builtin_bit_cast(unsigned short, v1) << 16);
                 }
             }
@@ -719,7 +732,11 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
                             const int ai = (g == 2 && s >= KSH) ? NA - 1 : g;
-                            acc[m][ai] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0], acc[m][ai]);
+                            // BC: the first product into r / z (k step 0) and into the input half of n (first x step; its
+                            // lo(a) term is skipped) starts from the inline constant 0
+                            const bool fresh = BC && ((ai < 2 && s == 0 && term == 0) || (ai == NA - 1 && NA == 4 && s == KSH && term == 1));
+                            acc[m][ai] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0],
+                                                fresh ? f32x16{} : acc[m][ai]);
                         }
                 }
                 if (s + 1 < KS) {
@@ -1032,6 +1049,12 @@ inline bool stream_nt() {
     return on;
 }
 
+// PA_BIAS_COLUMN=0: fused first layers seed their accumulators with the bias in the gate phase (round 1's form)
+inline bool bias_column() {
+    static const bool on = [] { const char* e = getenv("PA_BIAS_COLUMN"); return !e || e[0] != '0'; }();
+    return on;
+}
+
 inline int rec_grid(int B) {
     const int nbt = (B + MT - 1) / MT;
     return 2 * ((nbt + 3) / 4) * 4;
@@ -1059,8 +1082,10 @@ unsigned long long* gru_debug_buffer() {
 // W [G*H, K] per direction (K = H, or H + KX with [W_hh | W_ih | 0]) -> per-lane h2 fragments
 // [dir][G*H/32][K/16][hi, lo][64 lanes][8 halves]; lane l of tile nt, step s holds
 // W[nt*32 + (l&31)][16 s + 8 (l>>5) + e], e = 0..7.
+// bias != nullptr (fused first layers with F < KX): column H + F of the packed matrix holds bias[d][n]; the step loop
+// feeds a constant 1.0 in that input column, so the matrix pipe adds the bias and the accumulators start from zero.
 void pack_rec_weights_h2(const float* const whh[2], const float* const wih[2], int G, int H, int F, int KX,
-                         uint32_t* out) {
+                         uint32_t* out, const float* const* bias) {
     const int KT = H + KX, NTt = G * H / 32, KS = KT / 16;
     _Float16* o = reinterpret_cast<_Float16*>(out);
     for (int d = 0; d < 2; ++d)
@@ -1072,6 +1097,7 @@ void pack_rec_weights_h2(const float* const whh[2], const float* const wih[2], i
                         float v = 0.0f;
                         if (k < H) v = whh[d][(size_t)n * H + k];
                         else if (wih[0] != nullptr && k - H < F) v = wih[d][(size_t)n * F + (k - H)];
+                        else if (bias != nullptr && k - H == F && F < KX) v = bias[d][n];
                         const _Float16 hi = (_Float16)v;
                         const size_t base = ((((size_t)d * NTt + nt) * KS + s) * 2) * 512 + (size_t)l * 8 + e;
                         o[base] = hi;
@@ -1113,7 +1139,11 @@ hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, 
     if (X != nullptr) {
         if (F <= 0 || F > 32) return hipErrorInvalidValue;
         const size_t lds = (size_t)MT * ((256 + 32) * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4;
-        if (prescaled && stream_nt())
+        if (prescaled && stream_nt() && F < 32 && bias_column())
+            hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32, true, false, 2, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
+                               F, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y), ldy, B, T,
+                               debug_buffer() ? debug_buffer() + 8 * 80 * 2 : nullptr);
+        else if (prescaled && stream_nt())
             hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32, true, false, 2>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
                                F, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y), ldy, B, T,
                                debug_buffer() ? debug_buffer() + 8 * 80 * 2 : nullptr);
@@ -1146,7 +1176,12 @@ hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, 
         const int KX = gru_fused_input_kx(H, F);
         if (KX == 16) {
             const size_t lds = (size_t)2 * MT * ((128 + 16) * 4 + 16);
-            if (stream_nt())
+            if (stream_nt() && F < 16 && bias_column())
+                hipLaunchKernelGGL((gru_rec_h2_kernel<128, 16, false, 2, false, true>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
+                                   F, x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
+                                   static_cast<uint32_t*>(Y), ldy, B, T, (const uint32_t*)nullptr, 0, (const uint32_t*)nullptr,
+                                   (float*)nullptr, gru_debug_buffer() ? gru_debug_buffer() + 64 : nullptr);
+            else if (stream_nt())
                 hipLaunchKernelGGL((gru_rec_h2_kernel<128, 16, false, 2>), dim3(grid), dim3(512), lds, stream, (const float*)nullptr, 0, X,
                                    F, x_bstride, bias, static_cast<const uint32_t*>(Wp), bhn, h0, ldh0, hn, ldhn,
                                    static_cast<uint32_t*>(Y), ldy, B, T, (const uint32_t*)nullptr, 0, (const uint32_t*)nullptr,
