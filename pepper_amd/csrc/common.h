@@ -51,6 +51,23 @@ PA_DEV float selu_f(float x) {
     return scale * (x > 0.0f ? x : alpha * expm1f(x));
 }
 
+// One element of a recurrent state -> its word of the h2 row image (even lane: [hi(self), hi(odd neighbour)], odd lane:
+// [lo(even neighbour), lo(self)]) in four VALU operations: v_cvt_f16_f32 (hi, round to nearest even), v_fma_mixhi_f16
+// (lo = f16(v - hi), one rounding, into the upper half of the same register), a quad-permute DPP move (the neighbour's
+// pair) and v_perm_b32 with the lane's byte selector (h2_select).  Same values as the separate cvt / sub / cvt / select
+// sequence it replaces, a third of its instructions -- the gate phases are VALU-issue bound.
+PA_DEV unsigned h2_select(bool odd) { return odd ? 0x03020706u : 0x05040100u; }
+PA_DEV unsigned h2_pair(float v) {       // [f16 hi | f16 lo << 16]
+    unsigned p;
+    asm("v_cvt_f16_f32 %0, %1\n\tv_fma_mixhi_f16 %0, %1, 1.0, -%0 op_sel_hi:[0,0,1]" : "=&v"(p) : "v"(v));
+    return p;
+}
+PA_DEV unsigned h2_word_of(float v, unsigned select) {
+    const unsigned p = h2_pair(v);
+    const unsigned q = (unsigned)__builtin_amdgcn_mov_dpp((int)p, 0xB1, 0xF, 0xF, true);
+    return __builtin_amdgcn_perm(q, p, select);
+}
+
 // Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  Unlike
 // __syncthreads() it does not drain vmcnt, so global loads / stores issued before it (next-step
 // accumulator seeds, y stores) stay in flight across the barrier.

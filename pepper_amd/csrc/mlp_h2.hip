@@ -22,7 +22,6 @@ constexpr int MT = 64, D = 512, KS = D / 16, NTILES = D / 32;
 constexpr int ROWB = D * 4 + 16, ROWD = ROWB / 4;      // 2064-byte rows: odd number of 16-byte slots
 
 PA_DEV f32x16 mfma_h(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-PA_DEV unsigned swap_pair(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
 
 template <int NL>
 __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __restrict__ X, int ldx,
@@ -133,11 +132,7 @@ __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __rest
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = selu_f(acc[m][nn][r]);
-                    const _Float16 hi = (_Float16)v;
-                    const _Float16 lo = (_Float16)(v - (float)hi);
-                    const unsigned uhi = __builtin_bit_cast(unsigned short, hi), ulo = __builtin_bit_cast(unsigned short, lo);
-                    const unsigned got = swap_pair(odd ? uhi : ulo);
-                    dst[(32 * m + (r & 3) + 8 * (r >> 2)) * ROWD] = odd ? (got | (ulo << 16)) : (uhi | (got << 16));
+                    dst[(32 * m + (r & 3) + 8 * (r >> 2)) * ROWD] = h2_word_of(v, h2_select(odd));
                 }
         }
         lds_barrier();                      // next layer's input visible

@@ -43,7 +43,7 @@ PA_DEV void decode_block(int bid, int& dir, int& btile) {
 }
 
 // value of lane ^ 1 (quad_perm [1,0,3,2])
-PA_DEV unsigned swap_pair(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
+
 
 // PRE: the packed weights, the bias and Xp arrive pre-multiplied per gate row by -log2(e) (i, f, o) or
 // +2 log2(e) (g), so the accumulators ARE the exp2 arguments of sigmoid / tanh (api.hip build_rec_layer).
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     const int hcol = 32 * u + li;
     uint32_t* hl_dst = lds + 4 * hf * ROWD + (hcol >> 3) * 8 + ((li & 1) ? 4 : 0) + ((hcol & 7) >> 1);
     const bool odd = li & 1;
+    const unsigned h2sel = h2_select(odd);
 
     // The weights do not depend on the step: the B fragments of k step 0 are requested during the last
     // k step of the previous time step and fly under the gate phase (ring[0].b stays live across it).
@@ -362,11 +363,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const float hv = k ? hv2.y : hv2.x;
-                        const _Float16 hi = (_Float16)hv;
-                        const _Float16 lo = (_Float16)(hv - (float)hi);
-                        const unsigned uhi = __builtin_bit_cast(unsigned short, hi), ulo = __builtin_bit_cast(unsigned short, lo);
-                        const unsigned got = swap_pair(odd ? uhi : ulo);   // even lanes send lo, odd lanes send hi
-                        hl_dst[(32 * m + ((r + k) & 3) + 8 * ((r + k) >> 2)) * ROWD] = odd ? (got | (ulo << 16)) : (uhi | (got << 16));
+                        hl_dst[(32 * m + ((r + k) & 3) + 8 * ((r + k) >> 2)) * ROWD] = h2_word_of(hv, h2sel);
                     }
                 }
                 if (step + 1 < T) seed_chunk(m, qd, tn);
@@ -464,10 +461,12 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
         0x00020000);
     auto dense_partials = [&]() {
         typedef float f32x4v __attribute__((ext_vector_type(4)));
-        const int i16 = lane & 15, kg = lane >> 4;
+        int dl = lane;                    // opaque: the addresses below are recomputed per call, not held in registers
+        asm volatile("" : "+v"(dl));
+        const int i16 = dl & 15, kg = dl >> 4;
         const uint32_t* drow = lds + (rg * MT + i16) * ROWD + (u * 4 + kg) * 8;
-        const h8 bd_hi = *reinterpret_cast<const h8*>(dw_lds + (u * 2 + 0) * 256 + lane * 4);
-        const h8 bd_lo = *reinterpret_cast<const h8*>(dw_lds + (u * 2 + 1) * 256 + lane * 4);
+        const h8 bd_hi = *reinterpret_cast<const h8*>(dw_lds + (u * 2 + 0) * 256 + dl * 4);
+        const h8 bd_lo = *reinterpret_cast<const h8*>(dw_lds + (u * 2 + 1) * 256 + dl * 4);
         h8 ah[4], al[4];
         f32x4v dacc[4];
 #pragma unroll
@@ -525,21 +524,17 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
     };
     // packed h2 word of one element (see lstm_rec_h2_kernel)
-    auto h2_word = [&](float hv) {
-        const _Float16 hi = (_Float16)hv;
-        const _Float16 lo = (_Float16)(hv - (float)hi);
-        const unsigned uhi = __builtin_bit_cast(unsigned short, hi), ulo = __builtin_bit_cast(unsigned short, lo);
-        const unsigned got = swap_pair(odd ? uhi : ulo);
-        return odd ? (got | (ulo << 16)) : (uhi | (got << 16));
-    };
+    unsigned h2sel = h2_select(odd);
+    auto h2_word = [&](float hv) { return h2_word_of(hv, h2sel); };
 
     // exact f32 h_{t-1} of this lane's 32 elements (the z * h term and the final state).  The forms that sit at the
     // 256-register limit of two waves per SIMD keep the last HL of them in a per-wave private LDS strip [HL][64 lanes]
     // instead of registers (the gate phase has LDS slots to spare; same trick as the LSTM's cell state): all of row
     // tile 1 in the XG forms, half of it in the wide-input form.
     constexpr int HL = XG ? 16 : (KX >= 64 ? 15 : 0);
-    float* hls = reinterpret_cast<float*>(lds + MTG * ROWD + (XG ? 2 * XSLOT : 0) + (DENSE ? 4 * 2 * 256 + 4 * DC * MTG : 0)) +
-                 wave * (HL * 64) + lane;
+    float* const hls_wave = reinterpret_cast<float*>(lds + MTG * ROWD + (XG ? 2 * XSLOT : 0) + (DENSE ? 4 * 2 * 256 + 4 * DC * MTG : 0)) +
+                            wave * (HL * 64);
+    float* hls = hls_wave + lane;
     f32x16 hreg[2], acc[2][NA];
     auto h_get = [&](int m, int r) { return (m == 1 && r >= 16 - HL) ? hls[(r - (16 - HL)) * 64] : hreg[m][r]; };
     auto h_set = [&](int m, int r, float v) {
@@ -555,31 +550,29 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
             h_set(m, r, hv);
             hl_dst[dr * ROWD] = h2_word(hv);
         }
-    const float bn = bhn[dir * H + col];
-    const float b_r = KX ? bias[dir * 3 * H + col] : 0.0f, b_z = KX ? bias[dir * 3 * H + H + col] : 0.0f,
-                b_nx = KX ? bias[dir * 3 * H + 2 * H + col] : 0.0f;
+    const float bn0 = KX ? 0.0f : bhn[dir * H + col];          // unfused form: seeds the hidden half of n
+    const __amdgpu_buffer_rsrc_t bhrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bhn + dir * H), 0, H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t birs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(bias != nullptr ? bias + dir * 3 * H : bhn), 0, bias != nullptr ? 3 * H * 4 : 0, 0x00020000);
+    // Fused forms (KX > 0): no accumulator is seeded.  The first product into each one starts from the inline constant 0
+    // and the biases enter the gate arithmetic where they cost nothing -- b_r, b_z, b_in as the addend of the multiply that
+    // scales the exponent argument anyway (cr, cz, cn; zero with the bias column, which carries them through the
+    // MFMAs), b_hn as one add.  Unfused form: r, z start from the precomputed input projection, the hidden half of n from b_hn.
+    // (The four per-column constants are re-read every step, just ahead of the gate phase, instead of living in
+    // registers through the MFMA phase: the XG forms sit at the 256-register limit.)
+    constexpr float L2E = 1.4426950408889634f;
     auto seed_chunk = [&](int m, int qd, int t) {
-        if (KX && BC) {
-            // nothing: r, z and the input half of n start from the inline constant 0 (bias column)
-        } else if (KX) {
+        if (KX) return;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[m][0][4 * qd + e] = b_r;
-                acc[m][1][4 * qd + e] = b_z;
-                acc[m][NA - 1][4 * qd + e] = b_nx;
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const f32x4 v = load_xp4(m, t, g, qd);
-                acc[m][g][4 * qd] = v.x;
-                acc[m][g][4 * qd + 1] = v.y;
-                acc[m][g][4 * qd + 2] = v.z;
-                acc[m][g][4 * qd + 3] = v.w;
-            }
+        for (int g = 0; g < 2; ++g) {
+            const f32x4 v = load_xp4(m, t, g, qd);
+            acc[m][g][4 * qd] = v.x;
+            acc[m][g][4 * qd + 1] = v.y;
+            acc[m][g][4 * qd + 2] = v.z;
+            acc[m][g][4 * qd + 3] = v.w;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[m][2][4 * qd + e] = bn;
+        for (int e = 0; e < 4; ++e) acc[m][2][4 * qd + e] = bn0;
     };
     // fused: uint8 x_t (exact in f16) -> hi halves of columns [H, H+KX).  KX = 16: one thread per feature pair,
     // byte loads.  KX >= 64 (wide summaries; the launcher requires F % 4 == 0 and 4-byte aligned rows): one thread
@@ -732,9 +725,9 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
                             const int ai = (g == 2 && s >= KSH) ? NA - 1 : g;
-                            // BC: the first product into r / z (k step 0) and into the input half of n (first x step; its
-                            // lo(a) term is skipped) starts from the inline constant 0
-                            const bool fresh = BC && ((ai < 2 && s == 0 && term == 0) || (ai == NA - 1 && NA == 4 && s == KSH && term == 1));
+                            // fused forms: the first product into r / z / the hidden half of n (k step 0) and into the input
+                            // half of n (first x step; uint8 rows skip its lo(a) term) starts from the inline constant 0
+                            const bool fresh = KX && ((ai < 3 && s == 0 && term == 0) || (ai == 3 && s == KSH && term == (XU8 ? 1 : 0)));
                             acc[m][ai] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0],
                                                 fresh ? f32x16{} : acc[m][ai]);
                         }
@@ -770,11 +763,35 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) xn[m][qd] = load_xp4(m, t, 2, qd);
         }
+        // The per-lane addresses and selectors of the gate phase are recomputed from the lane id every step (made opaque
+        // so the recomputation is not hoisted): loop-invariant otherwise, they would hold registers through the MFMA phase.
+        int gl = lane;
+        asm volatile("" : "+v"(gl));
+        const int gcol = u * 32 + (gl & 31);
+        float bn = 0.0f, cr = 0.0f, cz = 0.0f, cn = 0.0f;
+        if (KX) {
+            const unsigned coff = (unsigned)gcol * 4u;
+            auto ldf = [&](const __amdgpu_buffer_rsrc_t& rs, int g) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, coff, (unsigned)(g * H * 4), 0));
+            };
+            bn = ldf(bhrs, 0);
+            if (!BC) {
+                cr = -L2E * ldf(birs, 0);
+                cz = -L2E * ldf(birs, 1);
+                cn = 2.0f * L2E * ldf(birs, 2);
+            }
+        }
         tick(1);
         lds_barrier();
         tick(2);
 
         // ---------------- gate phase ----------------
+        {
+            const bool godd = gl & 1;
+            hl_dst = lds + (rg * MT + 4 * (gl >> 5)) * ROWD + (gcol >> 3) * 8 + (godd ? 4 : 0) + ((gcol & 7) >> 1);
+            h2sel = h2_select(godd);
+            hls = hls_wave + gl;
+        }
         const int tn = dir ? t - 1 : t + 1;
         if (step + 1 < T) x_load(tn);
 #pragma unroll
@@ -785,10 +802,11 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * qd + e;
                     const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
-                    const float rgate = fast_sigmoid(acc[m][0][r]);
-                    const float zgate = fast_sigmoid(acc[m][1][r]);
+                    const float rgate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc[m][0][r], -L2E, cr)));
+                    const float zgate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc[m][1][r], -L2E, cz)));
                     const float xnv = KX ? acc[m][NA - 1][r] : xn[m][qd][e];
-                    const float ngate = fast_tanh(xnv + rgate * acc[m][2][r]);
+                    const float narg = __builtin_fmaf(rgate, KX ? acc[m][2][r] + bn : acc[m][2][r], xnv);
+                    const float ngate = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(narg, 2.0f * L2E, cn)));
                     const float hv = (1.0f - zgate) * ngate + zgate * h_get(m, r);
                     h_set(m, r, hv);
                     hl_dst[dr * ROWD] = h2_word(hv);
@@ -871,13 +889,8 @@ __global__ __launch_bounds__(256, 1) void gru_dec_h2_kernel(const uint32_t* __re
     for (int idx = tid; idx < MTG * ROWD; idx += NTHR) lds[idx] = 0u;
     __syncthreads();
 
-    auto h2_word = [&](float hv) {
-        const _Float16 hi = (_Float16)hv;
-        const _Float16 lo = (_Float16)(hv - (float)hi);
-        const unsigned uhi = __builtin_bit_cast(unsigned short, hi), ulo = __builtin_bit_cast(unsigned short, lo);
-        const unsigned got = swap_pair(odd ? uhi : ulo);
-        return odd ? (got | (ulo << 16)) : (uhi | (got << 16));
-    };
+    const unsigned h2sel = h2_select(odd);
+    auto h2_word = [&](float hv) { return h2_word_of(hv, h2sel); };
 
     f32x16 hreg[2], acc[2][4];     // r, z, n(hidden half), n(input half)
 #pragma unroll
