@@ -62,6 +62,14 @@ PA_DEV unsigned h2_pair(float v) {       // [f16 hi | f16 lo << 16]
     asm("v_cvt_f16_f32 %0, %1\n\tv_fma_mixhi_f16 %0, %1, 1.0, -%0 op_sel_hi:[0,0,1]" : "=&v"(p) : "v"(v));
     return p;
 }
+// Same image written as two 16-bit LDS stores from the lane's own pair (hi at dst, lo 16 bytes on; dst = the lane's
+// column in the hi half of its k chunk): no cross-lane exchange, two VALU operations per element instead of four -- the
+// LDS port is nearly idle in the gate phases.
+PA_DEV void h2_store16(unsigned short* dst, float v) {
+    const unsigned p = h2_pair(v);
+    dst[0] = (unsigned short)p;
+    dst[8] = (unsigned short)(p >> 16);
+}
 PA_DEV unsigned h2_word_of(float v, unsigned select) {
     const unsigned p = h2_pair(v);
     const unsigned q = (unsigned)__builtin_amdgcn_mov_dpp((int)p, 0xB1, 0xF, 0xF, true);

@@ -106,16 +106,13 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     const unsigned woff = lane * 16u;
 
     // accumulator seed of (row tile m, register chunk qd) for step t (identical to rnn.hip)
+    // Fused forms (KX > 0) seed nothing: the first product into every accumulator starts from the inline constant 0 and the
+    // four biases of the lane's column are added in the gate phase (packed adds; with the bias column they are zero).
     auto seed_chunk = [&](int m, int qd, int t) {
-        if (BC) return;
+        if (KX) return;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (KX) {
-                const float bv = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff, (unsigned)(g * H) * 4u, 0));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[m][g][4 * qd + e] = bv;
-            } else {
+            {
                 const unsigned ct = (unsigned)(dir * (4 * NT) + g * NT + u);
                 const unsigned so = (((unsigned)(m * T + t) * (ldx >> 5) + ct) * 4u + qd) * 1024u;
                 const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
@@ -213,11 +210,10 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     };
 
     // gate-phase h write: element (row, col = 32u + li) -> hi half at row*ROWB + (col/8)*32 + (col%8)*2,
-    // lo half 16 bytes later.  Even lanes write the dword {hi(col), hi(col+1)}, odd lanes {lo(col-1), lo(col)}.
+    // lo half 16 bytes later: two 16-bit stores from the lane's own pair (h2_store16).
     const int hcol = 32 * u + li;
-    uint32_t* hl_dst = lds + 4 * hf * ROWD + (hcol >> 3) * 8 + ((li & 1) ? 4 : 0) + ((hcol & 7) >> 1);
+    unsigned short* hl_dst = reinterpret_cast<unsigned short*>(lds + 4 * hf * ROWD + (hcol >> 3) * 8 + ((hcol & 7) >> 1)) + (hcol & 1);
     const bool odd = li & 1;
-    const unsigned h2sel = h2_select(odd);
 
     // The weights do not depend on the step: the B fragments of k step 0 are requested during the last
     // k step of the previous time step and fly under the gate phase (ring[0].b stays live across it).
@@ -266,7 +262,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                 for (int term = 0; term < 3; ++term) {
                     // int8 summaries are exact in the hi half: their lo half is identically zero, so is lo(a) * hi(w)
                     if (XI8 && s >= KSH && term == 0) continue;
-                    const bool fresh = BC && s == 0 && term == 0;       // accumulators start from the inline constant 0
+                    const bool fresh = KX && s == 0 && term == 0;       // accumulators start from the inline constant 0
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -321,6 +317,13 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // the lane's four biases, re-read every step (in flight across the barrier) rather than held through the MFMA phase
+        float cb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (KX && !BC) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                cb[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff, (unsigned)(g * H) * 4u, 0));
+        }
         if (stamp) dbg[(u * 80 + 2 * step) * 2 + 1] = __builtin_amdgcn_s_memtime();
 
         lds_barrier();                    // every wave has finished reading h_{t-1}
@@ -345,6 +348,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                     const f32x2 one = {1.0f, 1.0f};
                     f32x2 ai = {acc[m][0][r], acc[m][0][r + 1]}, af = {acc[m][1][r], acc[m][1][r + 1]},
                           ag = {acc[m][2][r], acc[m][2][r + 1]}, ao = {acc[m][3][r], acc[m][3][r + 1]};
+                    if (KX && !BC) { ai += cb[0]; af += cb[1]; ag += cb[2]; ao += cb[3]; }
                     if (!PRE) {
                         ai *= -1.4426950408889634f; af *= -1.4426950408889634f;
                         ag *= 2.8853900817779268f;  ao *= -1.4426950408889634f;
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const float hv = k ? hv2.y : hv2.x;
-                        hl_dst[(32 * m + ((r + k) & 3) + 8 * ((r + k) >> 2)) * ROWD] = h2_word_of(hv, h2sel);
+                        h2_store16(hl_dst + (32 * m + ((r + k) & 3) + 8 * ((r + k) >> 2)) * ROWD * 2, hv);
                     }
                 }
                 if (step + 1 < T) seed_chunk(m, qd, tn);
@@ -442,7 +446,8 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
     const unsigned xoff = lane * 16u, woff = lane * 16u;
     const size_t lb = (size_t)(r0 + 4 * hf);
     const bool odd = li & 1;
-    uint32_t* hl_dst = lds + (rg * MT + 4 * hf) * ROWD + (col >> 3) * 8 + (odd ? 4 : 0) + ((col & 7) >> 1);
+    // the lane's column in the hi half of its k chunk, as a 16-bit address (h2_store16)
+    unsigned short* hl_dst = reinterpret_cast<unsigned short*>(lds + (rg * MT + 4 * hf) * ROWD + (col >> 3) * 8 + ((col & 7) >> 1)) + (col & 1);
     const uint32_t* arow = lds + (rg * MT + li) * ROWD + hf * 8;
 
     for (int idx = tid; idx < MTG * ROWD; idx += 512) lds[idx] = 0u;
@@ -524,8 +529,6 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff, so, 0));
     };
     // packed h2 word of one element (see lstm_rec_h2_kernel)
-    unsigned h2sel = h2_select(odd);
-    auto h2_word = [&](float hv) { return h2_word_of(hv, h2sel); };
 
     // exact f32 h_{t-1} of this lane's 32 elements (the z * h term and the final state).  The forms that sit at the
     // 256-register limit of two waves per SIMD keep the last HL of them in a per-wave private LDS strip [HL][64 lanes]
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
             const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
             const float hv = h0 != nullptr ? h0[(lb + dr) * ldh0 + dir * H + col] : 0.0f;
             h_set(m, r, hv);
-            hl_dst[dr * ROWD] = h2_word(hv);
+            h2_store16(hl_dst + dr * ROWD * 2, hv);
         }
     const float bn0 = KX ? 0.0f : bhn[dir * H + col];          // unfused form: seeds the hidden half of n
     const __amdgpu_buffer_rsrc_t bhrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bhn + dir * H), 0, H * 4, 0x00020000);
@@ -787,9 +790,7 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 
         // ---------------- gate phase ----------------
         {
-            const bool godd = gl & 1;
-            hl_dst = lds + (rg * MT + 4 * (gl >> 5)) * ROWD + (gcol >> 3) * 8 + (godd ? 4 : 0) + ((gcol & 7) >> 1);
-            h2sel = h2_select(godd);
+            hl_dst = reinterpret_cast<unsigned short*>(lds + (rg * MT + 4 * (gl >> 5)) * ROWD + (gcol >> 3) * 8 + ((gcol & 7) >> 1)) + (gcol & 1);
             hls = hls_wave + gl;
         }
         const int tn = dir ? t - 1 : t + 1;
@@ -799,17 +800,32 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; e += 2) {
+                    // two elements per pass on 2-vectors, so the plain arithmetic issues as packed f32 instructions (as in
+                    // lstm_rec_h2_kernel); h' = n + z (h - n)
                     const int r = 4 * qd + e;
-                    const int dr = 32 * m + (r & 3) + 8 * (r >> 2);
-                    const float rgate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc[m][0][r], -L2E, cr)));
-                    const float zgate = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc[m][1][r], -L2E, cz)));
-                    const float xnv = KX ? acc[m][NA - 1][r] : xn[m][qd][e];
-                    const float narg = __builtin_fmaf(rgate, KX ? acc[m][2][r] + bn : acc[m][2][r], xnv);
-                    const float ngate = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(narg, 2.0f * L2E, cn)));
-                    const float hv = (1.0f - zgate) * ngate + zgate * h_get(m, r);
-                    h_set(m, r, hv);
-                    hl_dst[dr * ROWD] = h2_word(hv);
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    auto ex2 = [](f32x2 v) { return f32x2{__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; };
+                    auto rcp = [](f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; };
+                    auto fma2 = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
+                    auto dup = [](float v) { return f32x2{v, v}; };
+                    const f32x2 one = {1.0f, 1.0f};
+                    const f32x2 ar = {acc[m][0][r], acc[m][0][r + 1]}, az = {acc[m][1][r], acc[m][1][r + 1]};
+                    f32x2 anh = {acc[m][2][r], acc[m][2][r + 1]};
+                    const f32x2 anx = KX ? f32x2{acc[m][NA - 1][r], acc[m][NA - 1][r + 1]} : f32x2{xn[m][qd][e], xn[m][qd][e + 1]};
+                    const f32x2 rgate = rcp(one + ex2(fma2(ar, dup(-L2E), dup(cr))));
+                    const f32x2 zgate = rcp(one + ex2(fma2(az, dup(-L2E), dup(cz))));
+                    if (KX) anh += dup(bn);
+                    const f32x2 narg = fma2(rgate, anh, anx);
+                    const f32x2 ngate = fma2(dup(-2.0f), rcp(one + ex2(fma2(narg, dup(2.0f * L2E), dup(cn)))), one);
+                    const f32x2 hold = {h_get(m, r), h_get(m, r + 1)};
+                    const f32x2 hv2 = fma2(zgate, hold - ngate, ngate);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float hv = k ? hv2.y : hv2.x;
+                        h_set(m, r + k, hv);
+                        h2_store16(hl_dst + (32 * m + ((r + k) & 3) + 8 * ((r + k) >> 2)) * ROWD * 2, hv);
+                    }
                 }
                 if (step + 1 < T) seed_chunk(m, qd, tn);
             }
