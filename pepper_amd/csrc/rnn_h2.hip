@@ -169,7 +169,11 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 
     struct Frag { h8 b[4][2], a[2][2]; };     // [gate][hi, lo], [row tile][hi, lo]
     const uint32_t* arow = lds + li * ROWD + hf * 8;
+    bool exp_loads = true;       // PA_EXP_NO_BLOAD (energy experiment, wrong results): weight fragments loaded once, not per step
     auto load_b = [&](int s, Frag& fr) {
+#ifdef PA_EXP_NO_BLOAD
+        if (!exp_loads) return;
+#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -228,6 +232,10 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
         x_load(t0);
         x_store();
         load_b(0, ring[0]);
+#ifdef PA_EXP_NO_BLOAD
+        load_b(1, ring[1]);
+        exp_loads = false;
+#endif
     }
     __syncthreads();
 

@@ -10,7 +10,7 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int KIND, int GAP, int INTRA>
+template <int KIND, int GAP, int INTRA, bool BOTH = false>
 __global__ __launch_bounds__(512, 1) void k(int nm, int nv, float* out, unsigned long long* t) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __shared__ float sink[512];
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(512, 1) void k(int nm, int nv, float* out, unsigned
         if (KIND == 1) v[q] = __builtin_amdgcn_exp2f(v[q]) * 0.25f;
         if (KIND == 2) v[q] = __builtin_amdgcn_rcpf(v[q] + 1.5f);
     };
-    if (wave < 4) {
+    if (wave < 4 || BOTH) {
         h8 a, b;
         for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(lane + i); b[i] = (_Float16)(lane - i); }
         f32x16 acc[6] = {};
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(512, 1) void k(int nm, int nv, float* out, unsigned
                 if (GAP % 16 == 12) asm volatile("s_nop 11");
                 if (GAP >= 32) asm volatile("s_nop 15");
 #pragma unroll
-                for (int e = 0; e < INTRA; ++e) valu((q + e) & 7);
+                for (int e = 0; e < INTRA; ++e) valu((q * INTRA + e) & 7);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -60,6 +60,18 @@ __global__ __launch_bounds__(512, 1) void k(int nm, int nv, float* out, unsigned
     __syncthreads();
     out[blockIdx.x * 512 + threadIdx.x] = sink[threadIdx.x ^ 1];
     if (blockIdx.x == 3 && lane == 0) t[wave] = t1 - t0;
+}
+
+template <int KIND, int INTRA>
+void run_both(const char* name, int nm) {
+    float* out; unsigned long long* t;
+    (void)hipMalloc(&out, 256 * 512 * 4); (void)hipMalloc(&t, 64);
+    unsigned long long h[8];
+    for (int r = 0; r < 2; ++r) { hipLaunchKernelGGL((k<KIND, 0, INTRA, true>), dim3(256), dim3(512), 0, 0, nm, 0, out, t); (void)hipDeviceSynchronize(); }
+    (void)hipMemcpy(h, t, 64, hipMemcpyDeviceToHost);
+    printf("%-5s all 8 waves: MFMA + %d VALU behind each   waves 0-3 %8llu  waves 4-7 %8llu  (%.1f cycles per MFMA of the SIMD)\n", name, INTRA, h[0], h[4],
+           (double)(h[4] > h[0] ? h[4] : h[0]) / (12.0 * nm));
+    (void)hipFree(out); (void)hipFree(t);
 }
 
 template <int KIND, int GAP, int INTRA>
@@ -89,5 +101,16 @@ int main() {
     run<0, 0, 8>("fma", 20000, 60000);
     run<1, 24, 0>("exp2", 20000, 15000);
     run<1, 0, 2>("exp2", 20000, 15000);
+    // both waves of every SIMD run the mixed stream: is the VALU work of one hidden under the MFMAs of the pair?
+    run_both<0, 0>("fma", 20000);
+    run_both<0, 2>("fma", 20000);
+    run_both<0, 4>("fma", 20000);
+    run_both<0, 6>("fma", 20000);
+    run_both<0, 8>("fma", 20000);
+    run_both<0, 12>("fma", 20000);
+    run_both<1, 1>("exp2", 20000);
+    run_both<1, 2>("exp2", 20000);
+    run_both<1, 3>("exp2", 20000);
+    run_both<2, 2>("rcp", 20000);
     return 0;
 }
