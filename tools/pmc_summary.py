@@ -27,8 +27,8 @@ LABELS = [
     ("mlp_tail_h2_kernel", "mlp_tail_h2"),
     ("splitk_finish_kernel", "splitk_finish"),
     ("gru_rec_h2_kernel<128, 16", "gru_rec_h2_fused_in"),
-    ("gru_rec_h2_kernel<128, 256, true, 2, true>", "gru_dec_h2_fused_dense"),
-    ("gru_rec_h2_kernel<128, 256, true, 0, true>", "gru_dec_h2_fused_dense"),
+    ("gru_rec_h2_kernel<128, 256, true, 2, true", "gru_dec_h2_fused_dense"),
+    ("gru_rec_h2_kernel<128, 256, true, 0, true", "gru_dec_h2_fused_dense"),
     ("gru_rec_h2_kernel<128, 256", "gru_dec_h2_fused"),
     ("gru_dec_h2_kernel", "gru_dec_h2_fused"),
     ("polish_dense_acc_h2_kernel", "dense_softmax_acc"),
