@@ -40,3 +40,27 @@ def test_peaks_are_the_dense_ones():
     b = _bench()
     assert b.F16_MFMA_PEAK_TFLOPS == 2500.0 and abs(b.H2_MFMA_PEAK_TFLOPS - 2500.0 / 3) < 1e-9
     assert b.kernel_peak("lstm_dec_h2_fused") == b.H2_MFMA_PEAK_TFLOPS and b.kernel_peak("lstm_rec") == b.F32_MFMA_PEAK_TFLOPS
+
+
+def test_profiler_names_map_to_the_labels_the_bench_line_uses():
+    """tools/pmc_summary.py turns rocprofv3's kernel names into the library's profile labels; a template that grows a
+    parameter must not silently send a kernel to another label (the polish bench line lost its traffic that way)."""
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(REPO, "tools", "pmc_summary.py"))
+    pmc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pmc)
+    b = _bench()
+    want = {
+        "void pa::(anonymous namespace)::lstm_rec_h2_kernel<256, 512, true, true, 2, false>(float const*, int)": "lstm_dec_h2_fused",
+        "void pa::(anonymous namespace)::lstm_rec_h2_kernel<256, 32, true, false, 2, true>(float const*)": "lstm_rec_h2_fused_in",
+        "void pa::(anonymous namespace)::gru_rec_h2_kernel<128, 256, true, 2, true, false>(float const*)": "gru_dec_h2_fused_dense",
+        "void pa::(anonymous namespace)::gru_rec_h2_kernel<128, 256, true, 0, true, false>(float const*)": "gru_dec_h2_fused_dense",
+        "void pa::(anonymous namespace)::gru_rec_h2_kernel<128, 256, true, 2, false, false>(float const*)": "gru_dec_h2_fused",
+        "void pa::(anonymous namespace)::gru_rec_h2_kernel<128, 16, false, 2, false, true>(float const*)": "gru_rec_h2_fused_in",
+    }
+    for name, label in want.items():
+        assert pmc.label_of(name) == label, name
+    # every dominant-kernel label of the committed passes is one the bench line knows, and the polish line finds its traffic
+    for model, dominant in (("variant", "lstm_dec_h2_fused"), ("polish", "gru_dec_h2_fused_dense")):
+        table = json.load(open(os.path.join(REPO, "profiles", "r02_%s_pmc.json" % model)))["kernels"]
+        assert dominant in table and dominant in b.ALGORITHMIC_BYTES_PER_UNIT
+        assert b.measured_traffic(model, dominant) is not None
