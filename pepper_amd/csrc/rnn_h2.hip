@@ -105,8 +105,8 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     const unsigned xoff = KX ? li * 4u : lane * 16u;
     const unsigned woff = lane * 16u;
 
-    // accumulator seed of (row tile m, register chunk qd) for step t (identical to rnn.hip)
-    // Fused forms (KX > 0) seed nothing: the first product into every accumulator starts from the inline constant 0 and the
+    // accumulator seed of (row tile m, register chunk qd) for step t: the unfused form starts from the precomputed input
+    // projection (identical to rnn.hip).  Fused forms (KX > 0) seed nothing: the first product into every accumulator starts from the inline constant 0 and the
     // four biases of the lane's column are added in the gate phase (packed adds; with the bias column they are zero).
     auto seed_chunk = [&](int m, int qd, int t) {
         if (KX) return;
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 // anyway, and 5 x 128 floats per step go to P[dir][batch tile][t][class][128 rows] (2.5 KB instead of the 128 KB of y).
 // polish_combine_kernel (head.hip) adds the two directions and the bias, takes the softmax and overlap-adds it.
 // BC: as in lstm_rec_h2_kernel, for the fused uint8 first layer with F < KX = 16: b_r, b_z and the input half of the n
-// gate's bias come out of the matrix pipe (bias column of the packed weights x constant 1.0 input); b_hn still seeds
-// the hidden half's accumulator.
+// gate's bias come out of the matrix pipe (bias column of the packed weights x constant 1.0 input); b_hn is added in the
+// gate phase.  No fused form seeds an accumulator (see seed_chunk below).
 template <int H, int KX, bool XG = false, int SAUX = 0, bool DENSE = false, bool BC = false>
 __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
                                                             const uint8_t* __restrict__ Xi, int F, int64_t xi_bstride,
@@ -1086,7 +1086,7 @@ inline bool stream_nt() {
     return on;
 }
 
-// PA_BIAS_COLUMN=0: fused first layers seed their accumulators with the bias in the gate phase (round 1's form)
+// PA_BIAS_COLUMN=0: the fused first layers take their biases in the gate phase instead of from the bias column
 inline bool bias_column() {
     static const bool on = [] { const char* e = getenv("PA_BIAS_COLUMN"); return !e || e[0] != '0'; }();
     return on;
