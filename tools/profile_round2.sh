@@ -2,7 +2,7 @@
 # statistics + PMC passes of the device-resident pass.  Tight timeouts.
 set -x
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r02f}
+TAG=${TAG:-r02}
 mkdir -p $R/gpurun_out
 cd $R
 timeout 300 python -m pytest tests -q -m gpu > gpurun_out/${TAG}_gpu_tests.log 2>&1; tail -4 gpurun_out/${TAG}_gpu_tests.log
