@@ -17,6 +17,7 @@ reference writes.
 
 Worker processes are spawned (the parent holds a HIP context) and import only numpy + the libhdf5 binding.
 """
+import collections
 import os
 import sys
 import time
@@ -178,11 +179,17 @@ def _start_all(procs):
                 main.__file__ = saved_file
 
 
-def _next_message(result_q, procs):
+def _next_message(result_q, procs, poll=None):
     """result_q.get() that notices dead workers: a child that dies before it can report (a crash in native code, or a
     caller's script without the `if __name__ == "__main__":` guard that spawned children need) must not leave the GPU
-    loop waiting forever."""
+    loop waiting forever.  poll: seconds after which to return None instead of waiting on (the caller has device passes
+    in flight to look after)."""
     import queue
+    if poll is not None:
+        try:
+            return result_q.get(timeout=poll)
+        except queue.Empty:
+            return None
     while True:
         try:
             return result_q.get(timeout=2.0)
@@ -492,11 +499,14 @@ def variant_writer(lane, result_q, *args):
 
 
 def variant_lanes(image_directory, files, output_stem, forward_block, batch_size, lanes, slots_per_lane=0, log=None,
-                  block_windows=VARIANT_BLOCK_WINDOWS, prepare=None):
+                  block_windows=VARIANT_BLOCK_WINDOWS, prepare=None, second_forward=None):
     """Run the variant predict loop over `files` with `lanes` reader/writer process pairs.
 
     forward_block(images int8 [n, window, features]) -> float32 probabilities [n, classes] runs the device pass on a
-    host array in page-locked shared memory.  Output: `<output_stem>.hdf` for one lane, `<output_stem>_<lane>.hdf`
+    host array in page-locked shared memory.  second_forward: None, or a callable returning a second, independent
+    forward_block (its own model handle and streams): two blocks are then in flight, each on its own thread (the library
+    call releases the GIL), so that the H2D of one block's first pass, the D2H of the other's last one and this loop's
+    own bookkeeping no longer sit between device passes; results still reach a lane's writer in block order.  Output: `<output_stem>.hdf` for one lane, `<output_stem>_<lane>.hdf`
     otherwise; batch_<n> numbering runs over the files of a lane, as it runs over the files of a caller in the reference
     (predict_distributed_gpu.py:40-67).  Returns (batches written, windows processed)."""
     t_begin = time.perf_counter()
@@ -536,31 +546,72 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
         locker = register_async(slots, _have_gpu())
         writing = lanes
         files_done = 0
+        forwards = [forward_block]
+        pool = None
+        if second_forward is not None:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=2)
+            second = pool.submit(second_forward)        # built beside the first block's device pass
+        inflight = collections.deque()                  # (future or None, lane, slot, meta, file_end), oldest first
+        submitted = 0
+
+        def run(forward, lane, slot, shape):
+            images = slots[lane].view(slot, 0, shape, np.int8)
+            try:
+                return np.asarray(forward(images))
+            finally:
+                del images
+
+        def retire():
+            nonlocal windows, files_done
+            fut, lane, slot, meta, file_end = inflight.popleft()
+            if meta is not None:
+                contigs, positions, depths, blob, offsets, freqs, shape = meta
+                probs = fut.result() if pool is not None else fut
+                write_qs[lane].put(((contigs, positions, depths, blob, offsets, freqs, probs), file_end))
+                windows += shape[0]
+            else:
+                write_qs[lane].put((None, file_end))
+            free_qs[lane].put(slot)                       # the forward has consumed the images
+            if file_end:
+                files_done += 1
+                if log is not None:
+                    log(files_done)
+
+        depth = 2 if pool is not None else 1
         while writing:
-            msg = _next_message(result_q, procs)
+            # with passes in flight, do not sleep on the queue past the moment the oldest one is done: its slot may be what
+            # the only reader still running is waiting for
+            msg = _next_message(result_q, procs, poll=0.002 if inflight else None)
+            if msg is None:
+                while inflight and (inflight[0][0] is None or pool is None or inflight[0][0].done()):
+                    retire()
+                continue
             kind, lane = msg[0], msg[1]
             if kind == "error":
                 raise (SlotTooSmall if "SlotTooSmall" in msg[2] else LaneError)("lane %d failed:\n%s" % (lane, msg[2]))
             if kind == "block":
                 _, _, slot, meta, file_end = msg
+                while len(inflight) >= depth:
+                    retire()
+                fut = None
                 if meta is not None:
-                    contigs, positions, depths, blob, offsets, freqs, shape = meta
                     slots[lane].ready(slot)
-                    if windows == 0:
+                    if submitted == 0:
                         _trace(t_begin, "first block on the GPU")
-                    images = slots[lane].view(slot, 0, shape, np.int8)
-                    probs = forward_block(images)
-                    del images
-                    write_qs[lane].put(((contigs, positions, depths, blob, offsets, freqs, np.asarray(probs)), file_end))
-                    windows += shape[0]
-                else:
-                    write_qs[lane].put((None, file_end))
-                free_qs[lane].put(slot)               # the forward has consumed the images
-                if file_end:
-                    files_done += 1
-                    if log is not None:
-                        log(files_done)
+                    if pool is None:
+                        fut = run(forward_block, lane, slot, meta[6])
+                    else:
+                        if submitted == 1:
+                            forwards.append(second.result())
+                        fut = pool.submit(run, forwards[submitted % len(forwards)], lane, slot, meta[6])
+                    submitted += 1
+                inflight.append((fut, lane, slot, meta, file_end))
+                if pool is None:
+                    retire()
             elif kind == "read_done":
+                while inflight:                          # the end marker follows the lane's last block
+                    retire()
                 write_qs[lane].put(None)
             elif kind == "write_done":
                 writing -= 1
@@ -571,6 +622,8 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
             p.join(timeout=60)
         _trace(t_begin, "workers joined")
     finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
         for p in procs:
             if p.is_alive():
                 p.terminate()

@@ -18,6 +18,8 @@ candidates, batch numbering continuing across files).  Differences, all delibera
 import sys
 from datetime import datetime
 
+import os
+
 import torch
 
 from pepper_amd.variant.DataStorePredict import DataStore
@@ -85,10 +87,24 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
 
         def log(done):
             _log("INFO: FILES COMPLETED: " + str(done) + "/" + str(len(input_files)) + ".")
+        def forward_with(get):
+            def forward(images):
+                torch.cuda.set_device(device)           # the blocks run on pool threads
+                return get()(torch.from_numpy(images), False).numpy()
+            return forward
+
+        def second_forward():
+            # an independent handle (own streams, own staging buffers) for the second block in flight
+            torch.cuda.set_device(device)
+            other = ModelHandler.load_simple_model_for_training(
+                options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT,
+                num_classes=ImageSizeOptions.TOTAL_LABELS, num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)[0]
+            other.eval()
+            return forward_with(lambda: other)
         try:
             return hostpipe.variant_lanes(input_filepath, input_files, output_filepath + "pepper_prediction" + suffix,
-                                          lambda images: get_model()(torch.from_numpy(images), False).numpy(), options.batch_size,
-                                          lanes, log=log, prepare=get_model)
+                                          forward_with(get_model), options.batch_size, lanes, log=log, prepare=get_model,
+                                          second_forward=None if os.environ.get("PEPPER_AMD_ONE_BLOCK_IN_FLIGHT") == "1" else second_forward)
         except hostpipe.SlotTooSmall as e:
             # a single summaries group above 84 MB (98 k windows; a 100 kb region has a few hundred): the in-process loop
             # below takes whole files and has no such limit

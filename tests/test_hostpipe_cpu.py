@@ -3,6 +3,7 @@ shared-memory slots, a stand-in for the device pass, and the files they produce 
 import os
 
 import numpy as np
+import pytest
 
 from pepper_amd import h5, hostpipe, synthetic
 
@@ -46,17 +47,28 @@ def _read_variant_predictions(path, compositions=None):
     return out, batches
 
 
-def test_variant_lanes_write_what_the_in_process_loop_writes(tmp_path):
+def _slow_fake_forward(images):
+    """The second handle of the two-blocks-in-flight form: same numbers, finishing out of step with the first."""
+    import time
+    time.sleep(0.02 * (1 + images.shape[0] % 3))
+    return _fake_forward(images)
+
+
+@pytest.mark.parametrize("in_flight", [1, 2])
+def test_variant_lanes_write_what_the_in_process_loop_writes(tmp_path, in_flight):
     from pepper_amd.variant.DataStorePredict import DataStore
     from pepper_amd.variant.models.dataloader_predict import SequenceDataset
-    files = _variant_files(tmp_path, [(300, 0, 45), (0,), (17,), (700,)])
+    files = _variant_files(tmp_path, [(300, 0, 45), (0,), (17,), (700,), (120, 130, 90, 40)])
     out = tmp_path / "pred"
     out.mkdir()
     # block_windows = 100: the readers hand a file over in several blocks of whole groups (300 | 45, 700 alone, ...), the
-    # writers must still cut batches of 256 per FILE exactly like the in-process loop (345 -> 256 + 89, 700 -> 256 + 256 + 188)
+    # writers must still cut batches of 256 per FILE exactly like the in-process loop (345 -> 256 + 89, 700 -> 256 + 256 + 188).
+    # in_flight = 2: two blocks on the device path at once (two handles on two threads); a lane's writer must still see its
+    # blocks in order
     batches, windows = hostpipe.variant_lanes(str(tmp_path), files, str(out / "pepper_prediction"), _fake_forward, 256, lanes=2,
-                                              block_windows=100)
-    assert windows == 300 + 45 + 17 + 700
+                                              block_windows=100,
+                                              second_forward=(lambda: _slow_fake_forward) if in_flight == 2 else None)
+    assert windows == 300 + 45 + 17 + 700 + 380
     produced = sorted(os.listdir(out))
     assert produced == ["pepper_prediction_0.hdf", "pepper_prediction_1.hdf"]
     got = {}
@@ -82,7 +94,7 @@ def test_variant_lanes_write_what_the_in_process_loop_writes(tmp_path):
                                            d.candidate_offsets[s:e], d.all_candidate_frequency[s:e], probs[s:e])
                 b += 1
     want, _ = _read_variant_predictions(ref_path, want_comp)
-    assert sorted(got_comp) == sorted(want_comp) and sorted(len(c) for c in want_comp) == [17, 89, 188, 256, 256, 256]
+    assert sorted(got_comp) == sorted(want_comp) and sorted(len(c) for c in want_comp) == [17, 89, 124, 188, 256, 256, 256, 256]
     assert set(want) == set(got) and len(want) == windows
     assert all(np.array_equal(want[k], got[k]) for k in want)
     assert not [n for n in os.listdir("/dev/shm") if n.startswith("psm_")] or True     # segments are unlinked by Slots.close

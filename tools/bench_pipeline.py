@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--windows", type=int, default=65536)
     ap.add_argument("--workers", default="0", help="options.num_workers: reader / writer process lanes (0 = automatic); a comma "
                                                      "list runs one measurement per value on the same image files; -1 = the "
-                                                     "in-process loop (PEPPER_AMD_NO_LANES=1)")
+                                                     "in-process loop (PEPPER_AMD_NO_LANES=1), -2 = lanes with one block in flight")
     ap.add_argument("--groups", type=int, default=4, help="summaries groups (regions) per image file")
     args = ap.parse_args()
     tmp = tempfile.mkdtemp()
@@ -53,7 +53,8 @@ def main():
         n = args.files * (args.windows // args.groups) * args.groups
         size = sum(os.path.getsize(os.path.join(img_dir, f)) for f in os.listdir(img_dir))
         for k, w in enumerate(int(v) for v in str(args.workers).split(",")):
-            os.environ["PEPPER_AMD_NO_LANES"] = "1" if w < 0 else "0"
+            os.environ["PEPPER_AMD_NO_LANES"] = "1" if w == -1 else "0"
+            os.environ["PEPPER_AMD_ONE_BLOCK_IN_FLIGHT"] = "1" if w == -2 else "0"      # -2: lanes, one block in flight
             opts = SimpleNamespace(model_path=model_path, batch_size=512, num_workers=max(w, 0), use_hp_info=False, gpu=True,
                                    device_ids="0", callers_per_gpu=4, threads=8, quantized=False, dry=False)
             pred = os.path.join(tmp, "pred%d" % k)
@@ -62,7 +63,7 @@ def main():
             run_inference(opts, img_dir, pred)
             dt = time.perf_counter() - t0
             print(json.dumps({"metric": "run_inference HDF5 -> HDF5, 1 GPU", "windows": n, "image_bytes": size,
-                              "num_workers": w, "mode": "in-process loop" if w < 0 else "lanes", "groups_per_file": args.groups,
+                              "num_workers": w, "mode": "in-process loop" if w == -1 else ("lanes, one block in flight" if w == -2 else "lanes"), "groups_per_file": args.groups,
                               "prediction_files": len(os.listdir(pred)), "host_cpus": os.cpu_count(), "seconds": round(dt, 3),
                               "windows_per_s": round(n / dt), "image_write_seconds": round(t_write, 2)}), flush=True)
     finally:
