@@ -197,3 +197,24 @@ def test_group_larger_than_a_slot_is_reported_as_such(tmp_path):
                          np.full((n, 1), 7), x, [0] * n, [0] * n, False)
     with pytest.raises(hostpipe.SlotTooSmall):
         hostpipe.variant_lanes(str(tmp_path), [path], str(tmp_path / "pepper_prediction"), _fake_forward, 512, lanes=1)
+
+
+@pytest.mark.parametrize("in_flight", [1, 2])
+def test_a_failing_device_pass_ends_the_lanes_instead_of_hanging(tmp_path, in_flight):
+    """An exception in the forward (on the caller's thread, or on a pool thread with two blocks in flight) must come out of
+    variant_lanes with the workers gone and the shared-memory segments released."""
+    files = _variant_files(tmp_path, [(300, 200), (150, 150, 150)])
+    out = tmp_path / "pred"
+    out.mkdir()
+    calls = []
+
+    def bad_forward(images):
+        calls.append(images.shape[0])
+        if len(calls) >= 2:
+            raise RuntimeError("device pass failed")
+        return _fake_forward(images)
+    before = set(os.listdir("/dev/shm"))
+    with pytest.raises(RuntimeError, match="device pass failed"):
+        hostpipe.variant_lanes(str(tmp_path), files, str(out / "pepper_prediction"), bad_forward, 256, lanes=2, block_windows=100,
+                               second_forward=(lambda: bad_forward) if in_flight == 2 else None)
+    assert not {n for n in set(os.listdir("/dev/shm")) - before if n.startswith("psm_")}
