@@ -1122,7 +1122,8 @@ int pa_profile_get(void* model, int32_t idx, char* label, int32_t label_cap, dou
 
 int pa_host_register(void* ptr, int64_t bytes) {
     if (!ptr || bytes <= 0) return fail(PA_ERR_INVALID, "bad buffer");
-    HIP_TRY(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    // portable: the caller may be a helper thread whose current device is not the model's (HIP's current device is per thread)
+    HIP_TRY(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable));
     return PA_OK;
 }
 

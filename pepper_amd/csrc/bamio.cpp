@@ -238,6 +238,7 @@ int aux_size(uint8_t t) {
         case 'A': case 'c': case 'C': return 1;
         case 's': case 'S': return 2;
         case 'f': case 'i': case 'I': return 4;
+        case 'd': return 8;
         default: return -1;
     }
 }
@@ -295,7 +296,7 @@ const uint8_t* find_cg(const uint8_t* s, const uint8_t* end, uint32_t* count) {
         s += 3;
         switch (type) {
             case 'A': s += 1; break;
-            case 'c': case 'C': case 's': case 'S': case 'i': case 'I': case 'f': {
+            case 'c': case 'C': case 's': case 'S': case 'i': case 'I': case 'f': case 'd': {
                 const int sz = aux_size(type);
                 if (end - s < sz) return nullptr;
                 s += sz;
@@ -312,7 +313,7 @@ const uint8_t* find_cg(const uint8_t* s, const uint8_t* end, uint32_t* count) {
                 if (esz < 0) return nullptr;
                 const uint32_t cnt = le32(s + 1);
                 if ((uint64_t)(end - s - 5) < (uint64_t)cnt * esz) return nullptr;
-                if (is_cg && s[0] == 'I') {
+                if (is_cg && (s[0] == 'I' || s[0] == 'i')) {
                     *count = cnt;
                     return s + 5;
                 }
@@ -453,13 +454,15 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
         // placeholder <l_seq>S<ref_len>N in the core field; htslib (the reference's reader) swaps it in transparently
         const uint8_t* cig = &rec[o_cigar];
         uint32_t n_cig = n_cigar_op;
-        if (n_cigar_op == 2 && (le32(cig) & 15) == 4 && (le32(cig) >> 4) == l_seq && (le32(cig + 4) & 15) == 3) {
+        // same tests as htslib's bam_tag2cigar (sam.c): first operation <l_seq>S; a CG tag of type B,I (or B,i) with at least
+        // as many operations as the core field; anything else keeps the core CIGAR as it is
+        if (n_cigar_op >= 1 && (le32(cig) & 15) == 4 && (le32(cig) >> 4) == l_seq) {
             uint32_t cnt = 0;
             const uint8_t* real = find_cg(&rec[o_aux], rec.data() + block_size, &cnt);
-            if (!real)
-                return bam_fail(-6, "BAM record carries the long-CIGAR placeholder (<l_seq>S<ref_len>N) but no CG:B,I tag");
-            cig = real;
-            n_cig = cnt;
+            if (real && cnt >= n_cigar_op && cnt < (1u << 29)) {
+                cig = real;
+                n_cig = cnt;
+            }
         }
         int64_t ref_len = 0;
         for (uint32_t k = 0; k < n_cig; ++k) {

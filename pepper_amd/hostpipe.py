@@ -42,6 +42,9 @@ def shm_room(nbytes):
         return False
 
 
+_pagelock_warned = False
+
+
 def _attach(name):
     """Attach to a segment the parent owns; the attaching process must not let its resource tracker unlink it."""
     shm = shared_memory.SharedMemory(name=name)
@@ -61,9 +64,20 @@ class Slots(object):
     def __init__(self, count, nbytes):
         import threading
         self.nbytes = int(nbytes)
-        self.segments = [shared_memory.SharedMemory(create=True, size=max(1, self.nbytes)) for _ in range(count)]
-        self.names = [s.name for s in self.segments]
+        self.segments = []
         self.registered = []
+        try:
+            for _ in range(count):
+                seg = shared_memory.SharedMemory(create=True, size=max(1, self.nbytes))
+                self.segments.append(seg)
+                # tmpfs allocates lazily and statvfs is checked by every rank for itself: reserve the pages now, so that N
+                # ranks (or a small --shm-size) overcommitting /dev/shm fail HERE, where the caller can still fall back to
+                # its in-process loop, instead of a reader dying of SIGBUS in the middle of the run
+                os.posix_fallocate(seg._fd, 0, max(1, self.nbytes))
+        except OSError as e:
+            self.close()
+            raise NoSharedMemory("no room for %d shared-memory slots of %d MB in /dev/shm: %s" % (count, self.nbytes >> 20, e))
+        self.names = [s.name for s in self.segments]
         self._ready = [threading.Event() for _ in range(count)]
 
     def _register_one(self, i):
@@ -73,8 +87,15 @@ class Slots(object):
             ptr = np.frombuffer(self.segments[i].buf, np.uint8).ctypes.data
             if lib.pa_host_register(ptr, self.nbytes) == 0:
                 self.registered.append(ptr)
-        except Exception:
-            pass          # pageable slots still work, the copies just stage through the runtime
+            else:
+                raise RuntimeError((lib.pa_last_error() or b"pa_host_register failed").decode())
+        except Exception as e:
+            # pageable slots still work (the copies stage through the runtime, no longer beside the kernels): say so once
+            global _pagelock_warned
+            if not _pagelock_warned:
+                _pagelock_warned = True
+                sys.stderr.write("[pepper_amd] page-locking a %d MB lane slot failed (%s): host<->device copies of the lanes "
+                                 "will be staged, expect a lower rate\n" % (self.nbytes >> 20, e))
         finally:
             self._ready[i].set()
 
@@ -145,6 +166,23 @@ def deal_files(files, lanes):
 
 class LaneError(RuntimeError):
     pass
+
+
+class NoSharedMemory(LaneError):
+    """/dev/shm cannot hold the staging slots: the caller falls back to its in-process loop."""
+
+
+def make_slots(lanes, count, nbytes):
+    """One Slots object per lane; the ones already created are released when a later one finds no room."""
+    made = []
+    try:
+        for _ in range(lanes):
+            made.append(Slots(count, nbytes))
+    except NoSharedMemory:
+        for sl in made:
+            sl.close()
+        raise
+    return made
 
 
 class SlotTooSmall(LaneError):
@@ -306,7 +344,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
     layout = PolishLayout(block, seq_len, features)
     largs = (block, seq_len, features)
     ctx = get_context("spawn")
-    slots = [Slots(slots_per_lane, layout.nbytes) for _ in range(lanes)]
+    slots = make_slots(lanes, slots_per_lane, layout.nbytes)
     result_q = ctx.Queue()
     free_qs = [ctx.Queue() for _ in range(lanes)]
     write_qs = [ctx.Queue() for _ in range(lanes)]
@@ -521,13 +559,14 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
     if slots_per_lane <= 0:
         slots_per_lane = 2
     ctx = get_context("spawn")
-    slots = [Slots(slots_per_lane, slot_bytes) for _ in range(lanes)]
+    slots = make_slots(lanes, slots_per_lane, slot_bytes)
     result_q = ctx.Queue()
     free_qs = [ctx.Queue() for _ in range(lanes)]
     write_qs = [ctx.Queue() for _ in range(lanes)]
     procs = []
     windows = batches = 0
     locker = None
+    pool = second = None          # bound before the try: the finally reads them when prepare() or a worker start raises
     try:
         for k in range(lanes):
             for s in range(slots_per_lane):
@@ -547,7 +586,6 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
         writing = lanes
         files_done = 0
         forwards = [forward_block]
-        pool = None
         if second_forward is not None:
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(max_workers=2)

@@ -50,11 +50,15 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
         def log(done):
             if rank == 0:
                 _log("INFO: CHUNKS PROCESSED " + str(done) + ".")
-        hostpipe.polish_lanes(file_chunks, output_filepath + "pepper_prediction_" + str(rank),
-                              lambda image, labels, phred: get_model().predict_chunks_into(image, labels, phred), lanes,
-                              block=DEVICE_CHUNKS, seq_len=ImageSizeOptions.SEQ_LENGTH, features=ImageSizeOptions.IMAGE_HEIGHT,
-                              slots_per_lane=2, log=log, prepare=get_model)
-        return rank
+        try:
+            hostpipe.polish_lanes(file_chunks, output_filepath + "pepper_prediction_" + str(rank),
+                                  lambda image, labels, phred: get_model().predict_chunks_into(image, labels, phred), lanes,
+                                  block=DEVICE_CHUNKS, seq_len=ImageSizeOptions.SEQ_LENGTH, features=ImageSizeOptions.IMAGE_HEIGHT,
+                                  slots_per_lane=2, log=log, prepare=get_model)
+            return rank
+        except hostpipe.NoSharedMemory as e:
+            # raised before any worker started or any file was written (the ranks of one host share /dev/shm)
+            _log("INFO: " + str(e) + " -- continuing in one process.")
     model = get_model()
     output_filename = output_filepath + "pepper_prediction_" + str(rank) + ".hdf"
     prediction_data_file = DataStore(output_filename, mode='w')

@@ -93,12 +93,18 @@ def dist_backend(device_ids):
     return "nccl" if len(set(device_ids)) == len(device_ids) else "gloo"
 
 
-def remove_stale_predictions(output_dir, pattern="pepper_prediction"):
+def remove_stale_predictions(output_dir, pattern="pepper_prediction", exact=False):
     """The file names depend on the number of callers (pepper_prediction.hdf vs pepper_prediction_<rank>.hdf) and the
     next stage globs every *.hdf of the directory (FindCandidates.py:151-166): leftovers of an earlier run with a
-    different GPU count would be mixed into the VCF."""
+    different GPU count would be mixed into the VCF.  exact=True removes only <pattern>.hdf and <pattern>_<lane>.hdf --
+    what ONE caller wrote -- so that rank 1's clean-up ("pepper_prediction_1") leaves pepper_prediction_10.hdf,
+    pepper_prediction_11_0.hdf ... of the other running ranks alone."""
+    import re
+    own = re.compile(re.escape(pattern) + r"(_\d+)?\.hdf") if exact else None
     for name in listdir(output_dir):
-        if name.startswith(pattern) and name.endswith(".hdf") and isfile(join(output_dir, name)):
+        if not isfile(join(output_dir, name)):
+            continue
+        if (own.fullmatch(name) if exact else (name.startswith(pattern) and name.endswith(".hdf"))):
             os.remove(join(output_dir, name))
 
 

@@ -105,12 +105,12 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
             return hostpipe.variant_lanes(input_filepath, input_files, output_filepath + "pepper_prediction" + suffix,
                                           forward_with(get_model), options.batch_size, lanes, log=log, prepare=get_model,
                                           second_forward=None if os.environ.get("PEPPER_AMD_ONE_BLOCK_IN_FLIGHT") == "1" else second_forward)
-        except hostpipe.SlotTooSmall as e:
+        except (hostpipe.SlotTooSmall, hostpipe.NoSharedMemory) as e:
             # a single summaries group above 84 MB (98 k windows; a 100 kb region has a few hundred): the in-process loop
             # below takes whole files and has no such limit
             _log("INFO: " + str(e).strip().splitlines()[-1] + " -- continuing in one process.")
             from pepper_amd.variant.RunInference import remove_stale_predictions
-            remove_stale_predictions(output_filepath, pattern="pepper_prediction" + suffix)
+            remove_stale_predictions(output_filepath, pattern="pepper_prediction" + suffix, exact=True)
     output_filename = output_filepath + "pepper_prediction" + suffix + ".hdf"
     prediction_data_file = DataStore(output_filename, mode='w')
     torch.set_num_threads(max(1, int(threads)))

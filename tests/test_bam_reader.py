@@ -132,7 +132,8 @@ def test_block_cache_eviction_and_buffer_reuse(tmp_path):
 def test_long_cigar_in_cg_tag(tmp_path):
     """Records whose CIGAR lives in the CG:B,I tag behind the <l_seq>S<ref_len>N placeholder (reads with more than 65535
     operations; htslib swaps the real CIGAR in transparently): same reads as with the CIGAR in the core field; a
-    placeholder without the tag is an error, not a silently dropped read."""
+    placeholder without a usable tag keeps its core CIGAR, as htslib's bam_tag2cigar does (sam.c: no CG tag, a tag that is
+    not B,I / B,i, or one with fewer operations than the core field -> the record is left alone)."""
     rng = np.random.default_rng(31)
     ref = pu.random_reference(rng, 20000)
     reads = pu.simulate_reads(rng, ref, 0, n_reads=120, read_len=(300, 4000), clip_rate=0.3)
@@ -143,6 +144,8 @@ def test_long_cigar_in_cg_tag(tmp_path):
         if i % 4 == 0:
             r["hp"] = 2
             r["aux"] = hp_aux(2) + b"XBBs\x02\0\0\0\x01\0\x02\0"     # tags in front of CG are walked over
+        if i % 8 == 2:
+            r["aux"] = r.get("aux", b"") + b"XDd" + np.float64(1.5).tobytes()   # including an 8-byte 'd' value
     path = str(tmp_path / "cg.bam")
     bu.write_bam(path, [("ctg", 20000)], {0: reads}, flush_every=11)
     bam = BAM_handler(path)
@@ -158,12 +161,14 @@ def test_long_cigar_in_cg_tag(tmp_path):
     bam = BAM_handler(path2)
     compare(bam.get_reads("ctg", 100, 30000, False, 0, 0), bu.restated_get_reads([big], 100, 30000, False, 0))
     bam.close()
+    # the placeholder with no CG tag behind it: the read keeps <l_seq>S<ref_len>N
     bad = dict(reads[0], long_cigar=True, drop_cg=True)
     path3 = str(tmp_path / "nocg.bam")
     bu.write_bam(path3, [("ctg", 20000)], {0: [bad]})
+    ref_len = sum(n for op, n in bad["cigar"] if op in (0, 2, 3, 7, 8))
+    as_stored = dict(bad, cigar=[(4, len(bad["seq"])), (3, ref_len)])
     bam = BAM_handler(path3)
-    with pytest.raises(BamError):
-        bam.get_reads("ctg", 0, 20000, False, 0, 0)
+    compare(bam.get_reads("ctg", 0, 20000, False, 0, 0), bu.restated_get_reads([as_stored], 0, 20000, False, 0))
     bam.close()
 
 

@@ -91,3 +91,18 @@ def test_shard_files_matches_reference_rule():
     assert max(loads) <= 1.08 * (sum(sizes) / 8)
     assert max(sum(sizes[i] for i in range(r, 22, 8)) for r in range(8)) > 1.25 * (sum(sizes) / 8)      # round robin would not be
     assert all(chunk == sorted(chunk, key=names.index) for chunk in got)
+
+
+def test_one_callers_clean_up_leaves_the_other_callers_files(tmp_path):
+    """The SlotTooSmall fall-back of rank 1 removes what rank 1's lanes wrote (pepper_prediction_1.hdf,
+    pepper_prediction_1_<lane>.hdf) and nothing of ranks 10, 11 ... that share the prefix."""
+    from pepper_amd.variant.RunInference import remove_stale_predictions
+    names = ["pepper_prediction_1.hdf", "pepper_prediction_1_0.hdf", "pepper_prediction_1_3.hdf", "pepper_prediction_10.hdf",
+             "pepper_prediction_11_0.hdf", "pepper_prediction_12.hdf", "pepper_prediction.hdf", "other.hdf"]
+    for n in names:
+        (tmp_path / n).write_bytes(b"x")
+    remove_stale_predictions(str(tmp_path), pattern="pepper_prediction_1", exact=True)
+    assert sorted(os.listdir(tmp_path)) == sorted(["pepper_prediction_10.hdf", "pepper_prediction_11_0.hdf",
+                                                   "pepper_prediction_12.hdf", "pepper_prediction.hdf", "other.hdf"])
+    remove_stale_predictions(str(tmp_path))                      # start of a run: every prediction file of the directory
+    assert sorted(os.listdir(tmp_path)) == ["other.hdf"]

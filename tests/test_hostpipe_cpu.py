@@ -218,3 +218,36 @@ def test_a_failing_device_pass_ends_the_lanes_instead_of_hanging(tmp_path, in_fl
         hostpipe.variant_lanes(str(tmp_path), files, str(out / "pepper_prediction"), bad_forward, 256, lanes=2, block_windows=100,
                                second_forward=(lambda: bad_forward) if in_flight == 2 else None)
     assert not {n for n in set(os.listdir("/dev/shm")) - before if n.startswith("psm_")}
+
+
+def test_a_failing_prepare_keeps_its_own_exception_and_leaves_nothing_behind(tmp_path):
+    """prepare() (checkpoint load + model build beside the starting readers) raising -- a bad --model_path -- must come
+    out of variant_lanes as itself, not as an UnboundLocalError from the clean-up, with workers and segments gone."""
+    files = _variant_files(tmp_path, [(300, 200), (150, 150, 150)])
+
+    def prepare():
+        raise FileNotFoundError("no such checkpoint")
+    before = set(os.listdir("/dev/shm"))
+    with pytest.raises(FileNotFoundError, match="no such checkpoint"):
+        hostpipe.variant_lanes(str(tmp_path), files, str(tmp_path / "pepper_prediction"), _fake_forward, 256, lanes=2,
+                               prepare=prepare, second_forward=lambda: _fake_forward)
+    assert not {n for n in set(os.listdir("/dev/shm")) - before if n.startswith("psm_")}
+
+
+def test_slots_reserve_their_pages_or_say_there_is_no_room(tmp_path, monkeypatch):
+    """The segments' pages are reserved at creation (posix_fallocate), so an over-committed /dev/shm is reported as
+    NoSharedMemory -- which the predict loops answer with their in-process loop -- and whatever was created is released."""
+    before = set(os.listdir("/dev/shm"))
+    sl = hostpipe.Slots(2, 1 << 20)
+    assert all(os.stat("/dev/shm/" + n).st_blocks * 512 >= 1 << 20 for n in sl.names)     # allocated, not sparse
+    sl.close()
+    calls = []
+
+    def no_space(fd, off, n):
+        calls.append(n)
+        if len(calls) >= 3:
+            raise OSError(28, "No space left on device")
+    monkeypatch.setattr(os, "posix_fallocate", no_space)
+    with pytest.raises(hostpipe.NoSharedMemory, match="no room"):
+        hostpipe.make_slots(2, 2, 1 << 20)
+    assert not {n for n in set(os.listdir("/dev/shm")) - before if n.startswith("psm_")}
