@@ -9,9 +9,11 @@
  *   implementation region_summary.cpp:69-96 (axes), 174-191 (reference row), 337-566 (per-read
  *   walk), 568-916 (thresholds, candidate windows).
  * Reads arrive as flat arrays (the fields of type_read / CigarOp, read.h:52-64, cigar.h:30-53)
- * instead of per-read Python objects.  The per-base counting, the threshold/clamp pass and the
+ * instead of per-read Python objects.  The whole per-read walk, the threshold/clamp pass and the
  * candidate window gather run as HIP kernels; the allele-string bookkeeping (ordered maps of
  * candidate strings) stays on the host, as in SURVEY.md section 7 step 7.
+ * MANY REGIONS PER CALL (pa_encoder_generate_summary_batch) is the form that fills the chip: one
+ * workgroup owns one 512-position tile of one region, a 100 kb region has ~200 of them.
  */
 #ifndef PEPPER_AMD_ENCODER_H
 #define PEPPER_AMD_ENCODER_H
@@ -59,6 +61,24 @@ void pa_encoder_destroy(pa_encoder* e);
  * would return (train_mode=False); results stay in the handle until the next call. */
 int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* pileup, const pa_summary_params* params,
                                 int64_t* n_candidates);
+
+/* Many regions per launch: pileups[n_regions], params[n_regions] (one window size and one feature size per batch),
+ * n_candidates[n_regions] (may be NULL).  Results are those of region 0, then region 1, ... in pa_encoder_get_results.
+ * The buffers behind `pileups` (reference, seq) must stay valid until the call returns: candidate allele strings are
+ * cut from them on the host. */
+int pa_encoder_generate_summary_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups,
+                                      const pa_summary_params* params, int64_t* n_candidates);
+/* The two halves of the call above, for a caller that keeps a batch resident in HBM: stage = validate + upload,
+ * run = kernels + host candidate enumeration + window gather (may be repeated; the pileup buffers must outlive the
+ * last run).  bench.py times pa_encoder_run_staged. */
+int pa_encoder_stage_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const pa_summary_params* params);
+int pa_encoder_run_staged(pa_encoder* e, int64_t* n_candidates);
+/* Times of the last run in milliseconds, HIP events on the encoder's stream: [0] record kernels (segment_reads x 2 +
+ * tile_offsets), [1] tile_count_kernel, [2] compact_votes_kernel + pack_results_kernel, [3] gather_windows_kernel; host clock:
+ * [4] candidate enumeration, [5] the whole run.  Sizes of the staged batch: [0] read bases, [1] matrix rows,
+ * [2] reads, [3] CIGAR operations, [4] tiles, [5] regions. */
+int pa_encoder_last_timing(pa_encoder* e, double* ms, int32_t n);
+int pa_encoder_batch_stats(pa_encoder* e, int64_t* out, int32_t n);
 
 /* Copy results of the last call (HOST pointers, any may be NULL):
  *   positions int64 [n], depths int32 [n], candidate_frequency int32 [n]  (CandidateImageSummary

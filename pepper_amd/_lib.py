@@ -60,6 +60,11 @@ SYMBOLS = [
     ("pa_encoder_create", ctypes.c_int, [c_int32, c_void_p, ctypes.POINTER(c_void_p)]),
     ("pa_encoder_destroy", None, [c_void_p]),
     ("pa_encoder_generate_summary", ctypes.c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64)]),
+    ("pa_encoder_generate_summary_batch", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    ("pa_encoder_stage_batch", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    ("pa_encoder_run_staged", ctypes.c_int, [c_void_p, c_void_p]),
+    ("pa_encoder_last_timing", ctypes.c_int, [c_void_p, c_void_p, c_int32]),
+    ("pa_encoder_batch_stats", ctypes.c_int, [c_void_p, c_void_p, c_int32]),
     ("pa_encoder_get_results", ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_int64, ctypes.POINTER(c_int64)]),
     ("pa_encoder_device_images", c_void_p, [c_void_p]),

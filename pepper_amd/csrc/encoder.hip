@@ -1,54 +1,81 @@
-// Variant summary encoder (include/pepper_amd_encoder.h): pileup -> candidate images.
+// Variant summary encoder (include/pepper_amd_encoder.h): pileups of many regions -> candidate images, one launch set.
 //
 // Split of the reference's RegionalSummaryGenerator::generate_summary
 // (/root/reference/pepper_variant/modules/cpp/region_summary.cpp:337-916):
-//   GPU   : cigar_walk_kernel      the whole per-read walk, one wave per read: coverage, strand coverage, base
-//                                  columns, SNP counts and SNP allele tallies (:366-428), insert quality sums and the
-//                                  sparse indel updates (:431-540), '*' columns of deleted bases (:541-551), one
-//                                  (row, type, strand, length, byte source) record per indel allele vote
-//                                                                                       [atomics, HBM bound]
-//           (PA_ENCODER_HOST_CIGAR=1: round 1's split -- host pass over CIGAR ops -> segment / event lists ->
-//            pileup_count_kernel + apply_events_kernel)
-//   host  : what needs strings: ordered per-site maps of insert / delete allele keys, built only for the sites
-//           that pass the thresholds, from the votes compact_votes_kernel leaves for them;
-//           site_threshold_kernel  per-position fractions vs thresholds in fp64, clamp of columns
-//                                  11..24 (:634-654), compaction of passing sites
-//           gather_windows_kernel  33 x 26 window copy + candidate-specific overwrite (:828-905),
-//                                  int32 image_matrix and the int8 wrap DataStore.py:68 applies
-//   host  : candidate enumeration in the reference's std::set order with its filters (:669-712).
-// The matrix lives on the device as int32 [L+1][32]: columns 0..25 = the image, 26 coverage,
-// 27 snp_count, 28 insert_count, 29 delete_count (128-byte rows).
-#include "../../include/pepper_amd_encoder.h"
-#include "../../include/pepper_amd.h"
-
+//   GPU   segment_reads_kernel   one wave per read: prefix sums over its CIGAR operations, one 16-byte record per
+//                                (read, 512-row tile) the read touches = where the walk of that tile starts
+//         tile_offsets_kernel    (run twice around an exclusive scan: count per tile, then fill each tile's slice)
+//         tile_count_kernel      ONE WORKGROUP OWNS ONE TILE: 28 int32 counters x 512 rows privatised in LDS (coverage,
+//                                SNP / insert / delete counts, the 16 image columns the walk updates, the 8 SNP allele
+//                                tallies); its waves walk the tile's records (encoder_common.h: one row per lane, LDS
+//                                atomics only, :366-551); then the same workgroup applies the per-position pass of :568-654
+//                                (fractions vs thresholds in fp64, passing-site records, clamp of columns 11..24) and
+//                                stores the finished tile ONCE, coalesced: int32 [row][26], the algorithmic 104 bytes per
+//                                position.  No global atomics on the matrix, no zero-fill pass, no read-modify-write pass
+//                                [HBM bound: 2 B per aligned base in, 104 B per position out]
+//         compact_votes_kernel   indel allele votes of the sites that passed (a few per cent of all votes)
+//   host  what needs strings: ordered per-site maps of allele keys for the passing sites, candidate enumeration in the
+//         reference's std::set order with its filters (:669-712)
+//   GPU   gather_windows_kernel  33 x 26 window copy + candidate-specific overwrite (:828-905), int32 image_matrix and
+//                                the int8 wrap DataStore.py:68 applies
+// Round 2 walked one wave per read with global int32 atomics on a [L+1][32] matrix: 559 MB of atomic write traffic for
+// 22 MB of algorithmic bytes on one 100 kb / 60x region, 759 waves on a 1024-SIMD chip.  Here parallelism = tiles
+// (~200 per 100 kb region, x regions per batch) and every matrix byte is written exactly once.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
-#include "kernels.h"
+#include "encoder_common.h"
+
+using namespace pa_enc;
 
 namespace {
 
-enum { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP_P = 6, OP_EQ = 7, OP_X = 8 };
-constexpr int MAXC = 125, ROW = 32, C_COV = 26, C_SNP = 27, C_INS = 28, C_DEL = 29;
-constexpr uint32_t SEG_REV = 1, SEG_DEL = 2, SEG_ANCHOR = 4;
+constexpr int MAXC = 125;
+constexpr int TP = 512;             // rows per tile = threads of a tile_count_kernel workgroup
+constexpr int MATF = 26;            // int32 per matrix row in HBM (the image columns)
+constexpr int NCNT = 28;            // privatised counters per row
+constexpr int NW = 8, NT = 64 * NW;  // waves / threads of a tile_count_kernel workgroup: NT == TP, a thread owns a row in the per-position pass
+constexpr int UNR = 8;              // rows per lane in flight in the row phase: 64 x UNR = TP
+constexpr int VCAP = 1024;          // indel votes a tile keeps in LDS (nanopore: ~600 per 512 rows x 60 reads; more spill to the global list)
+static_assert(NT == TP && 64 * UNR == TP, "one thread per row, UNR rows per lane");
+// counter slots: 0 coverage, 1 snp_count, 2 insert_count, 3 delete_count, 4 = column 4 (forward strand coverage),
+// 5..11 = columns 8..14 (forward A C G T I D *), 12 = column 15 (reverse strand coverage), 13..19 = columns 19..25,
+// 20..23 / 24..27 = forward / reverse tallies of mismatching A C G T (the SNP allele map of :409-425)
+enum { K_COV = 0, K_SNP = 1, K_INS = 2, K_DEL = 3, K_FWD = 4, K_REV = 12, K_TAB = 20 };
+// counters of a run
+enum { CT_OVF = 0, CT_VOTES = 2, CT_ERR = 3, CT_N = 8 };
+// per region, behind them: [2 r] passing sites, [2 r + 1] votes of passing sites -- both lists are written region by region
+// (sites of region r from row_base, votes from vote_base), so the host never has to sort a batch's records by region
 
-struct Seg {          // a run of consecutive reference positions touched by one CIGAR op
-    int64_t seq0;     // offset of the first base in the concatenated seq / qual arrays
-    int32_t idx0;     // first row (pos - region_start)
-    int32_t n;        // rows
-    uint32_t flags;   // SEG_REV | SEG_DEL | SEG_ANCHOR (last base anchors an indel: no strand coverage)
-    int32_t pad;
+struct RegRec {                      // one region of the batch, as the kernels see it
+    int64_t ref_off;                 // first byte of its reference in d_ref
+    int64_t row_base;                // first row of its matrix (multiple of 16: line-aligned tile stores)
+    int64_t seq_base;                // first base of its reads in d_seq / d_qual
+    int32_t ref_len, L;              // L = region_end - region_start + 1; the matrix has L + 1 rows (row L stays zero)
+    int32_t tile0, n_tiles;
+    int32_t cand_lo, cand_hi;        // candidate_region_start / _end as rows (clamped into int32)
+    int32_t qmin;                    // smallest integer base quality that is >= min_snp_baseq (256: none)
+    int32_t vote_base;               // first slot of the region's slice of the passing-vote list (= its first CIGAR operation)
+    double min_snp_q, min_indel_q, snp_thr, ins_thr, del_thr, min_cov;
 };
-struct Event { int32_t row, col, delta, pad; };
-struct SiteRec { int32_t idx, cov, flags, fwd[4], rev[4]; };
+struct TileRec { int32_t read, op, row, ri; };   // walk of `read` enters the tile at operation `op`, whose first row / read index are given
+struct SiteRec { int32_t region, idx, cov, flags, fwd[4], rev[4]; };
+struct Vote { uint32_t idx, meta; int64_t off; };          // meta = type (1 insert, 2 delete) | reverse << 2 | from_ref << 3 | len << 4 | region << 10
 struct CandDesc {
     int32_t idx, type;        // row of the candidate site; 1 SNP, 2 insert, 3 delete
     int32_t vcol, vval;       // columns 1/2/3 <- alt base code / allele length
@@ -56,7 +83,7 @@ struct CandDesc {
     int32_t neg_f, neg_r;     // columns negated on the centre row (-1: none)
     int32_t last;             // delete: last spill row of the window (else -1)
     int32_t star_f, star_r;   // delete: '*' columns negated on spill rows
-    int32_t pad;
+    int32_t region;
 };
 
 __host__ __device__ inline bool is_acgt(char c) {
@@ -78,6 +105,7 @@ __host__ __device__ inline int symbol_column(char ref_base, char symbol, bool re
         default: return first + 6;
     }
 }
+__device__ __forceinline__ int column_slot(int col) { return col < 15 ? col - 3 : col - 6; }   // columns 8..14 / 19..25
 __host__ __device__ inline int base_code(char c) {
     switch (up(c)) {
         case 'A': return 1;
@@ -88,244 +116,451 @@ __host__ __device__ inline int base_code(char c) {
     }
 }
 
-__global__ __launch_bounds__(256) void init_matrix_kernel(int* __restrict__ mat, const char* __restrict__ ref,
-                                                          int64_t ref_len, int L) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i > L) return;
-    int4* row = reinterpret_cast<int4*>(mat + (size_t)i * ROW);
-#pragma unroll
-    for (int k = 0; k < ROW / 4; ++k) row[k] = make_int4(0, 0, 0, 0);
-    if (i < L) mat[(size_t)i * ROW] = base_code(i < ref_len ? ref[i] : 'N');
-}
-
-// One wave per segment chunk of <= 64 consecutive positions, one lane per base (the host splits
-// longer runs): 64 lanes hit 64 distinct matrix rows, so the int32 atomics of a wave never collide
-// and the per-base work is fully parallel (a thread-per-segment version walked ~25 bases serially
-// and took 1.07 ms for 5.7 M bases).
-__global__ __launch_bounds__(256) void pileup_count_kernel(const Seg* __restrict__ segs, int nseg,
-                                                           const char* __restrict__ seq,
-                                                           const uint8_t* __restrict__ qual,
-                                                           const char* __restrict__ ref, int64_t ref_len,
-                                                           int* __restrict__ mat, int* __restrict__ snp_tab,
-                                                           int* __restrict__ ovf_count, int4* __restrict__ ovf,
-                                                           int ovf_cap, double min_snp_q) {
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int i = threadIdx.x & 63;
-    if (s >= nseg) return;
-    const Seg sg = segs[s];
-    if (i >= sg.n) return;
-    const bool rev = sg.flags & SEG_REV;
-    const int idx = sg.idx0 + i;
-    const char rb = idx < ref_len ? ref[idx] : 'N';
-    if (sg.flags & SEG_DEL) {
-        const int col = symbol_column(rb, '*', rev);
-        if (col >= 0) atomicSub(&mat[(size_t)idx * ROW + col], 1);
-        return;
-    }
-    if (!((double)qual[sg.seq0 + i] >= min_snp_q)) return;
-    const char base = seq[sg.seq0 + i];
-    int* row = mat + (size_t)idx * ROW;
-    atomicAdd(&row[C_COV], 1);
-    if (!((sg.flags & SEG_ANCHOR) && i == sg.n - 1)) atomicSub(&row[rev ? 15 : 4], 1);
-    const int col = symbol_column(rb, base, rev);
-    if (col >= 0) atomicSub(&row[col], 1);
-    if (rb != base) {                       // case-sensitive, as the reference compares
-        atomicAdd(&row[C_SNP], 1);
-        const int k = base == 'A' ? 0 : base == 'C' ? 1 : base == 'G' ? 2 : base == 'T' ? 3 : -1;
-        if (k >= 0) {
-            atomicAdd(&snp_tab[((size_t)idx * 2 + (rev ? 1 : 0)) * 4 + k], 1);
-        } else {                            // rare alphabet (N, IUPAC, lower case): exact key kept on host
-            const int slot = atomicAdd(ovf_count, 1);
-            if (slot < ovf_cap) ovf[slot] = make_int4(idx, (int)(unsigned char)base, rev ? 1 : 0, 0);
-        }
-    }
-}
-
-// The whole per-read walk of populate_summary_matrix (region_summary.cpp:337-566) on the device: one wave per read steps
-// through its CIGAR operations (wave-uniform scalars), the lanes take the bases of a match run / the rows of a deletion
-// 64 at a time with the same per-base arithmetic as pileup_count_kernel, insert quality sums are wave reductions, the
-// sparse indel updates go straight into the matrix, and every indel allele vote is appended as (row, type, strand,
-// length, where the allele's bytes live) for the host, which only ever builds strings for the sites that pass the
-// thresholds.  Replaces the host pass over CIGAR operations + Seg / Event uploads (0.9 of 1.5 ms per 10 kb interval of
-// 60x long reads in round 1).  Integer atomics commute, so the matrix is bit-identical whatever the order.
-struct DVote { int32_t idx, type_rev, len, from_ref; int64_t off; };   // type_rev = type char | strand << 8
-
-struct WalkArgs {
-    const int64_t* read_pos; const uint8_t* read_reverse; const int32_t* read_mapq; const int64_t* seq_offset;
-    const int64_t* cigar_offset; const int32_t* cigar_op; const int32_t* cigar_len;
-    const char* seq; const uint8_t* qual; const char* ref;
-    int64_t ref_len, start, end;
-    int n_reads;
-    int* mat; int* snp_tab; int* counters; int4* ovf; int ovf_cap; DVote* votes; int vote_cap;
-    double min_snp_q, min_indel_q;
-};
-
-__global__ __launch_bounds__(256) void cigar_walk_kernel(WalkArgs a) {
+// ---- records: where the walk of each (read, tile) starts -----------------------------------------------------------
+// Two passes of the same walk: FILL = false counts the records of every tile (atomics spread over the tiles), an exclusive
+// scan turns the counts into offsets, FILL = true writes each record into its tile's slice.  (One pass appending to a
+// global list cost 3 ms for 64 regions: ~300 k returning atomics on ONE counter serialise at ~10 ns each.)
+template <bool FILL>
+__global__ __launch_bounds__(256) void segment_reads_kernel(const ReadRec* __restrict__ reads, int n_reads,
+                                                            const RegRec* __restrict__ regions,
+                                                            const int32_t* __restrict__ cigar_op,
+                                                            const int32_t* __restrict__ cigar_len, int* __restrict__ tile_count,
+                                                            const int* __restrict__ tile_off, int* __restrict__ tile_fill,
+                                                            TileRec* __restrict__ recs, int rec_cap) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (r >= a.n_reads) return;
-    if (a.read_mapq[r] <= 0) return;
-    const bool rev = a.read_reverse[r] != 0;
-    const int64_t s0 = a.seq_offset[r], read_len = a.seq_offset[r + 1] - s0;
-    const int64_t c0 = a.cigar_offset[r], c1 = a.cigar_offset[r + 1];
-    const int64_t start = a.start, end = a.end;
-    int64_t ri = 0, pos = a.read_pos[r];
-    auto refc = [&](int64_t idx) { return idx >= 0 && idx < a.ref_len ? a.ref[idx] : 'N'; };
-    for (int64_t c = c0; c < c1; ++c) {
-        if (pos > end) break;
-        const int op = a.cigar_op[c];
-        const int64_t len = a.cigar_len[c];
-        if (op == OP_M || op == OP_EQ || op == OP_X) {
-            const int64_t lo = pos > start ? pos : start, hi = pos + len - 1 < end ? pos + len - 1 : end;
-            if (lo <= hi) {
-                if (ri + (hi - pos) >= read_len) {          // CIGAR runs past the sequence: reported by the host
-                    if (lane == 0) atomicMax(&a.counters[3], r + 1);
-                    return;
-                }
-                bool anchor = false;
-                if (hi == pos + len - 1 && c != c1 - 1) {
-                    const int nop = a.cigar_op[c + 1];
-                    anchor = (nop == OP_I || nop == OP_D);
-                }
-                for (int64_t q = lo + lane; q <= hi; q += 64) {
-                    const int64_t si = s0 + ri + (q - pos);
-                    if (!((double)a.qual[si] >= a.min_snp_q)) continue;
-                    const int idx = (int)(q - start);
-                    const char rb = refc(idx);
-                    const char base = a.seq[si];
-                    int* row = a.mat + (size_t)idx * ROW;
-                    atomicAdd(&row[C_COV], 1);
-                    if (!(anchor && q == hi)) atomicSub(&row[rev ? 15 : 4], 1);
-                    const int col = symbol_column(rb, base, rev);
-                    if (col >= 0) atomicSub(&row[col], 1);
-                    if (rb != base) {
-                        atomicAdd(&row[C_SNP], 1);
-                        const int k = base == 'A' ? 0 : base == 'C' ? 1 : base == 'G' ? 2 : base == 'T' ? 3 : -1;
-                        if (k >= 0) {
-                            atomicAdd(&a.snp_tab[((size_t)idx * 2 + (rev ? 1 : 0)) * 4 + k], 1);
-                        } else {
-                            const int slot = atomicAdd(&a.counters[0], 1);
-                            if (slot < a.ovf_cap) a.ovf[slot] = make_int4(idx, (int)(unsigned char)base, rev ? 1 : 0, 0);
-                        }
-                    }
-                }
+    if (r >= n_reads) return;
+    const ReadRec rd = reads[r];
+    if (!(rd.flags & READ_MAPQ_OK)) return;
+    const RegRec* reg = regions + rd.region;
+    const int L = reg->L, tile0 = reg->tile0;
+    auto put = [&](int tile, int op, int row, int ri) {
+        if (!FILL) {
+            atomicAdd(&tile_count[tile], 1);
+        } else {
+            const int slot = tile_off[tile] + atomicAdd(&tile_fill[tile], 1);
+            if (slot < rec_cap) recs[slot] = TileRec{r, op, row, ri};     // past the capacity: the host repeats the run with room
+        }
+    };
+    int pos = rd.row0, ri = 0;
+    if (pos > L - 1) return;
+    if (pos >= 0 && lane == 0) put(tile0 + pos / TP, rd.c0, pos, 0);
+    for (int cb = 0; cb < rd.ncig; cb += 64) {
+        const int i = cb + lane;
+        const bool valid = i < rd.ncig;
+        const int op = valid ? cigar_op[rd.c0 + i] : OP_H;
+        const int len = valid ? cigar_len[rd.c0 + i] : 0;
+        const int radv = variant_ref_advance(op, len), qadv = variant_read_advance(op, len);
+        const int rinc = wave_inclusive_sum(radv), qinc = FILL ? wave_inclusive_sum(qadv) : 0;
+        const int first = pos + rinc - radv, after = pos + rinc;
+        // the operation that holds row k * TP (the first row of tile k) opens the read's walk of that tile
+        if (radv > 0 && first <= L - 1) {
+            int lo = first > rd.row0 + 1 ? first : rd.row0 + 1;
+            if (lo < 0) lo = 0;
+            const int last_row = after - 1 < L - 1 ? after - 1 : L - 1;      // (an operation that ends before row 0 opens no tile)
+            for (int k = (lo + TP - 1) / TP; k * TP <= last_row; ++k) put(tile0 + k, rd.c0 + i, first, ri + qinc - qadv);
+        }
+        pos += wave_total(rinc);
+        if (FILL) ri += wave_total(qinc);
+        if (pos > L - 1) break;
+    }
+}
+
+// exclusive scan of the per-tile record counts (one workgroup; tiles per batch: 12.5 k for 64 regions of 100 kb)
+__global__ __launch_bounds__(1024) void tile_offsets_kernel(const int* __restrict__ tile_count, int n_tiles, int* __restrict__ tile_off) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_tiles ? tile_count[i] : 0;
+        const int inc = wave_inclusive_sum(v);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int before = carry;
+        for (int k = 0; k < w; ++k) before += wsum[k];
+        if (i < n_tiles) tile_off[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_off[n_tiles] = carry;
+}
+
+// ---- the tile kernel -----------------------------------------------------------------------------------------------
+struct TileArgs {
+    const ReadRec* reads; const RegRec* regions; const int32_t* tile_region;
+    const int32_t* cigar_op; const int32_t* cigar_len; const char* seq; const uint8_t* qual; const char* ref;
+    const TileRec* recs; const int* tile_off; int rec_cap;
+    int* mat; uint8_t* pass; SiteRec* sites; Vote* votes; Vote* votes_out; int vote_cap; int4* ovf; int ovf_cap; int* counters;
+    int* region_counts;
+};
+
+// Append v to the global list `out` (counter `count`) from the lanes where `has`: one global atomic per wave.
+__device__ __forceinline__ void wave_append_vote(bool has, const Vote& v, Vote* out, int* count, int cap, int lane) {
+    const unsigned long long m = __ballot(has);
+    if (!m) return;
+    int base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(count, __popcll(m));
+    base = __builtin_amdgcn_readlane(base, leader);
+    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (has && slot < cap) out[slot] = v;
+}
+
+#ifndef PA_TILE_MIN_WAVES
+#define PA_TILE_MIN_WAVES 4          // measured equal at 4 / 6 / 8 (2 / 3 / 4 workgroups per CU); 6 and 8 spill 7 / 19 registers to scratch
+#endif
+__global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileArgs a) {
+    __shared__ int cnt[NCNT * TP];                 // [counter][row]; reused as the finished [row][26] tile for the store
+    __shared__ char ref_s[TP];
+    __shared__ uint8_t pass_s[TP];
+    __shared__ int s_first[NW][65], s_ri[NW][64], s_op[NW][64];
+    __shared__ uint2 vbuf[VCAP];                   // indel allele votes of this tile: only those of passing rows leave the CU
+    __shared__ int vcount;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x;
+    const int region = a.tile_region[tile];
+    const RegRec reg = a.regions[region];
+    const int L = reg.L;
+    const int tile_lo = (tile - reg.tile0) * TP, tile_hi = tile_lo + TP - 1;
+    const int live_max = tile_hi + 1 < L - 1 ? tile_hi + 1 : L - 1;   // operations starting past this row are not this tile's (pos > end: not walked at all)
+    for (int i = tid; i < NCNT * TP; i += NT) cnt[i] = 0;
+    if (tid < TP) {
+        const int idx = tile_lo + tid;
+        ref_s[tid] = idx < reg.ref_len ? a.ref[reg.ref_off + idx] : 'N';
+    }
+    if (tid == 0) vcount = 0;
+    __syncthreads();
+
+    const int rec0 = a.tile_off[tile], rec1 = a.tile_off[tile + 1] < a.rec_cap ? a.tile_off[tile + 1] : a.rec_cap;
+    int* first_s = s_first[w];
+    int* ri_s = s_ri[w];
+    int* op_s = s_op[w];
+    TileRec rec{0, 0, 0, 0};
+    if (rec0 + w < rec1) rec = a.recs[rec0 + w];
+    for (int k = rec0 + w; k < rec1; k += NW) {
+        // three independent loads: the read's table entry, the first 64 operations (the arrays are padded: no bound needed
+        // to issue them), and the next record of this wave
+        const ReadRec rd_v = a.reads[rec.read];
+        int op_ld = a.cigar_op[rec.op + lane], len_ld = a.cigar_len[rec.op + lane], next_ld = a.cigar_op[rec.op + lane + 1];
+        TileRec rec_next = rec;
+        if (k + NW < rec1) rec_next = a.recs[k + NW];
+        // the record and the read's entry are the same in every lane: keep them in scalar registers
+        struct { int64_t s0; int32_t c0, ncig, slen, flags; } rd;
+        rd.s0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rd_v.s0 >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)rd_v.s0));
+        rd.c0 = __builtin_amdgcn_readfirstlane(rd_v.c0);
+        rd.ncig = __builtin_amdgcn_readfirstlane(rd_v.ncig);
+        rd.slen = __builtin_amdgcn_readfirstlane(rd_v.slen);
+        rd.flags = __builtin_amdgcn_readfirstlane(rd_v.flags);
+        rec.read = __builtin_amdgcn_readfirstlane(rec.read);
+        rec.op = __builtin_amdgcn_readfirstlane(rec.op);
+        rec.row = __builtin_amdgcn_readfirstlane(rec.row);
+        rec.ri = __builtin_amdgcn_readfirstlane(rec.ri);
+        const uint8_t* qual0 = a.qual + rd.s0;         // scalar base + 32-bit lane offset
+        const char* seq0 = a.seq + rd.s0;
+        const bool rev = rd.flags & READ_REV;
+        const int c_end = rd.c0 + rd.ncig;
+        int pos = rec.row, ri = rec.ri;
+        for (int c = rec.op; c < c_end; c += 64) {
+            const int i = c + lane;
+            if (c != rec.op) {
+                op_ld = a.cigar_op[i];
+                len_ld = a.cigar_len[i];
+                next_ld = a.cigar_op[i + 1];
             }
-            ri += len;
-            pos += len;
-        } else if (op == OP_I) {
-            const int64_t anchor = pos - 1;
-            if (anchor >= start && anchor <= end && ri - 1 >= 0) {
-                const int idx = (int)(anchor - start);
-                const int64_t n = len + 1;
-                const int64_t avail = n < read_len - (ri - 1) ? n : (read_len - (ri - 1) > 0 ? read_len - (ri - 1) : 0);
-                // sum of integer qualities: exact, and equal to the reference's double accumulation
-                long long part = 0;
-                for (int64_t k = ri - 1 + lane; k < ri - 1 + n; k += 64) part += k < read_len ? a.qual[s0 + k] : 0;
+            const bool valid = i < c_end;
+            const int op = valid ? op_ld : OP_H;
+            const int len = valid ? len_ld : 0;
+            const int next_op = i + 1 < c_end ? next_ld : -1;
+            const int radv = variant_ref_advance(op, len), qadv = variant_read_advance(op, len);
+            const int rinc = wave_inclusive_sum(radv), qinc = wave_inclusive_sum(qadv);
+            const int first = pos + rinc - radv, rfirst = ri + qinc - qadv;
+            const int total_r = wave_total(rinc);
+            const bool live = valid && first <= live_max;
+            const int anchor = first - 1;                                   // row an insert / a deletion is credited to
+            const bool mine = live && anchor >= tile_lo && anchor <= tile_hi;   // (anchor <= L - 2 follows from first <= L - 1)
+            const bool is_ins = mine && op == OP_I && rfirst - 1 >= 0;
+            const int n_ins = len + 1;
+            const int span_lo = pos > tile_lo ? pos : tile_lo;
+            int span_hi = pos + total_r - 1;
+            if (span_hi > tile_hi) span_hi = tile_hi;
+            if (span_hi > L - 1) span_hi = L - 1;
+
+            // -- scratch for the row phase
+            first_s[lane] = valid ? first : 0x7fffffff;
+            if (lane == 63) first_s[64] = valid ? pos + total_r : 0x7fffffff;
+            ri_s[lane] = rfirst;
+            // bit 4: an insert or a deletion follows, so the last base of this match run anchors it (:381-391)
+            op_s[lane] = op | ((next_op == OP_I || next_op == OP_D) ? 16 : 0);
+            __builtin_amdgcn_wave_barrier();
+
+            // -- the row phase's loads first: one reference row per lane, UNR rows in flight; owners by binary search over the
+            //    scratch, then every quality / base byte load of the (read, tile) is issued before anything waits on one
+            bool is_m[UNR], is_d[UNR], anchored[UNR];
+            int pl[UNR], qv[UNR];
+            char bv[UNR];
+            bool past = false;
+            {
+                unsigned si[UNR];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-                const bool passes = (double)part >= a.min_indel_q * (double)n;
-                if (lane == 0) {
-                    if (passes && (double)a.qual[s0 + ri - 1] < a.min_snp_q) atomicAdd(&a.mat[(size_t)idx * ROW + C_COV], 1);
-                    if (avail + 1 <= 61 && passes) {
-                        const int col = symbol_column(refc(idx), 'I', rev);
-                        if (col >= 0) atomicSub(&a.mat[(size_t)idx * ROW + col], 1);
-                        atomicAdd(&a.mat[(size_t)idx * ROW + C_INS], 1);
-                        const int slot = atomicAdd(&a.counters[2], 1);
-                        if (slot < a.vote_cap) a.votes[slot] = DVote{idx, (int)'2' | (rev ? 256 : 0), (int)avail, 0, s0 + ri - 1};
-                    }
+                for (int u = 0; u < UNR; ++u) {
+                    const int p = span_lo + lane + 64 * u;
+                    const bool act = p <= span_hi;
+                    const int pc = act ? p : span_lo;
+                    const int j = owner_of_row(first_s, pc);
+                    const int opj = op_s[j], oj = opj & 15;
+                    const int rp = ri_s[j] + (pc - first_s[j]);
+                    const bool m = act && (oj == OP_M || oj == OP_EQ || oj == OP_X);
+                    const bool inb = (unsigned)rp < (unsigned)rd.slen;
+                    past |= m && !inb;
+                    is_m[u] = m && inb;
+                    is_d[u] = act && oj == OP_D;
+                    anchored[u] = (opj & 16) && pc + 1 == first_s[j + 1];
+                    pl[u] = pc - tile_lo;
+                    si[u] = is_m[u] ? (unsigned)rp : 0u;       // (a lane without a base loads the read's first byte: no exec mask)
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    qv[u] = (int)__builtin_nontemporal_load(qual0 + si[u]);
+                    bv[u] = __builtin_nontemporal_load(seq0 + si[u]);
                 }
             }
-            ri += len;
-        } else if (op == OP_D) {
-            const int64_t anchor = pos - 1;
-            if (anchor >= start && anchor <= end && lane == 0) {
-                const int idx = (int)(anchor - start);
-                const int col = symbol_column(refc(idx), 'D', rev);
-                if (col >= 0) atomicSub(&a.mat[(size_t)idx * ROW + col], 1);
-                int64_t avail = len + 1 < a.ref_len - idx ? len + 1 : a.ref_len - idx;
+            if (past) atomicMax(&a.counters[CT_ERR], rec.read + 1);    // CIGAR runs past the sequence: reported by the host
+
+            // -- one operation per lane: inserts (:431-490) and deletion anchors (:491-540)
+            long long qsum = 0;
+            if (is_ins) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)                  // most inserts are a few bases: eight loads at once
+                    qsum += (q < n_ins && rfirst - 1 + q < rd.slen) ? qual0[(unsigned)(rfirst - 1 + q)] : 0;
+                if (n_ins <= 33)
+                    for (int q = 8; q < n_ins; ++q) qsum += rfirst - 1 + q < rd.slen ? qual0[(unsigned)(rfirst - 1 + q)] : 0;
+            }
+            for (unsigned long long big = __ballot(is_ins && n_ins > 33); big; big &= big - 1) {   // long inserts: the wave sums
+                const int src = __ffsll((long long)big) - 1;
+                const int n = __builtin_amdgcn_readlane(n_ins, src), r0 = __builtin_amdgcn_readlane(rfirst, src) - 1;
+                int part = 0;
+                for (int q = lane; q < n; q += 64) part += r0 + q < rd.slen ? qual0[(unsigned)(r0 + q)] : 0;
+                const int total = wave_sum(part);
+                if (lane == src) qsum = total;
+            }
+            bool vote = false;
+            unsigned vmeta = 0, voff = 0;
+            if (is_ins) {
+                const int avail = n_ins < rd.slen - (rfirst - 1) ? n_ins : (rd.slen - (rfirst - 1) > 0 ? rd.slen - (rfirst - 1) : 0);
+                const bool passes = (double)qsum >= reg.min_indel_q * (double)n_ins;
+                const int al = anchor - tile_lo;
+                // (the reference reads the anchor base's quality without a bound; a CIGAR that ends past the sequence is an error here)
+                const int anchor_q = rfirst - 1 < rd.slen ? (int)qual0[(unsigned)(rfirst - 1)] : 0;
+                if (passes && (double)anchor_q < reg.min_snp_q) atomicAdd(&cnt[K_COV * TP + al], 1);
+                if (avail + 1 <= 61 && passes) {
+                    if (is_acgt(ref_s[al])) atomicAdd(&cnt[((rev ? K_REV : K_FWD) + 5) * TP + al], 1);   // column I
+                    atomicAdd(&cnt[K_INS * TP + al], 1);
+                    vote = true;
+                    vmeta = 1u | (rev ? 4u : 0u) | ((unsigned)avail << 4) | ((unsigned)al << 10);
+                    voff = (unsigned)(rd.s0 - reg.seq_base + rfirst - 1);
+                }
+            }
+            if (mine && op == OP_D) {
+                const int al = anchor - tile_lo;
+                if (is_acgt(ref_s[al])) atomicAdd(&cnt[((rev ? K_REV : K_FWD) + 6) * TP + al], 1);       // column D, no quality test
+                int avail = len + 1 < reg.ref_len - anchor ? len + 1 : reg.ref_len - anchor;
                 if (avail < 0) avail = 0;
                 if (avail + 1 <= 61) {
-                    atomicAdd(&a.mat[(size_t)idx * ROW + C_DEL], 1);
-                    const int slot = atomicAdd(&a.counters[2], 1);
-                    if (slot < a.vote_cap) a.votes[slot] = DVote{idx, (int)'3' | (rev ? 256 : 0), (int)avail, 1, (int64_t)idx};
+                    atomicAdd(&cnt[K_DEL * TP + al], 1);
+                    vote = true;
+                    vmeta = 2u | (rev ? 4u : 0u) | 8u | ((unsigned)avail << 4) | ((unsigned)al << 10);
+                    voff = (unsigned)anchor;
                 }
             }
-            const int64_t lo = pos > start ? pos : start, hi = pos + len - 1 < end ? pos + len - 1 : end;
-            for (int64_t q = lo + lane; q <= hi; q += 64) {
-                const int idx = (int)(q - start);
-                const int col = symbol_column(refc(idx), '*', rev);
-                if (col >= 0) atomicSub(&a.mat[(size_t)idx * ROW + col], 1);
+            {   // allele votes wait in LDS for the verdict on their row; a tile with more than VCAP of them spills the rest
+                const unsigned long long m = __ballot(vote);
+                if (m) {
+                    int base = 0;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (lane == leader) base = atomicAdd(&vcount, __popcll(m));
+                    base = __builtin_amdgcn_readlane(base, leader);
+                    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                    const bool spill = vote && slot >= VCAP;
+                    if (vote && !spill) vbuf[slot] = make_uint2(voff, vmeta);
+                    if (__ballot(spill))
+                        wave_append_vote(spill, Vote{(uint32_t)(tile_lo + (int)(vmeta >> 10)), (vmeta & 1023u) | ((uint32_t)region << 10), (int64_t)voff},
+                                         a.votes, &a.counters[CT_VOTES], a.vote_cap, lane);
+                }
             }
-            pos += len;
-        } else if (op == OP_N || op == OP_P) {
-            pos += len;
-            ri += len;      // the reference falls through into the soft-clip case (region_summary.cpp:556-561)
-        } else if (op == OP_S) {
-            ri += len;
+
+            // -- the rows: match runs (:357-430) and the '*' rows of deletions (:541-551).  Branch-free: every lane issues
+            //    the same five LDS atomics with a 0 / 1 addend (the LDS pipe is 7 % busy, the instruction issue is the
+            //    bound: exec-mask bookkeeping around five `if`s cost more than the idle adds); letters -> columns by
+            //    arithmetic: (c >> 1) & 3 sends A C T G to 0 1 2 3, and the byte of "ACTG" at that index says whether c was one
+            const int strand = rev ? K_REV : K_FWD;
+            bool rare = false;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const unsigned rb = (unsigned char)ref_s[pl[u]], b = (unsigned char)bv[u];
+                const unsigned ru = rb & 0xDFu, bu = b & 0xDFu;
+                const unsigned ridx = (ru >> 1) & 3u, bidx = (bu >> 1) & 3u;
+                const bool ref_ok = ((0x47544341u >> (ridx * 8)) & 0xFFu) == ru;        // is_acgt(reference base)
+                const unsigned letter = (0x47544341u >> (bidx * 8)) & 0xFFu;
+                const int acgt = (int)(bidx ^ (bidx >> 1));                              // A C G T -> 0 1 2 3
+                const int sym = letter == bu ? acgt : (bu == 'I' ? 4 : (bu == 'D' ? 5 : 6));   // symbol_column's switch
+                const bool q_ok = is_m[u] && qv[u] >= reg.qmin;
+                const bool mism = q_ok && rb != b;                                       // case-sensitive, as the reference compares
+                const bool plain = letter == b;                                          // an upper-case A C G T: tallied on the device
+                const int o = pl[u];
+                atomicAdd(&cnt[K_COV * TP + o], q_ok ? 1 : 0);
+                atomicAdd(&cnt[strand * TP + o], (q_ok && !anchored[u]) ? 1 : 0);
+                atomicAdd(&cnt[(strand + (is_d[u] ? 7 : 1 + sym)) * TP + o], ((is_d[u] || q_ok) && ref_ok) ? 1 : 0);
+                atomicAdd(&cnt[K_SNP * TP + o], mism ? 1 : 0);
+                atomicAdd(&cnt[(K_TAB + (rev ? 4 : 0) + acgt) * TP + o], (mism && plain) ? 1 : 0);
+                rare |= mism && !plain;
+            }
+            if (rare) {                                      // rare alphabet (N, IUPAC, lower case): exact key kept on host
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const unsigned rb = (unsigned char)ref_s[pl[u]], b = (unsigned char)bv[u];
+                    const bool plain = ((0x47544341u >> ((((b & 0xDFu) >> 1) & 3u) * 8)) & 0xFFu) == b;
+                    if (is_m[u] && qv[u] >= reg.qmin && rb != b && !plain) {
+                        const int slot = atomicAdd(&a.counters[CT_OVF], 1);
+                        if (slot < a.ovf_cap) a.ovf[slot] = make_int4(pl[u] + tile_lo, (int)b, rev ? 1 : 0, region);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            pos += total_r;
+            ri += wave_total(qinc);
+            if (pos > live_max) break;
         }
+        rec = rec_next;
+    }
+    __syncthreads();
+
+    // ---- the tile is complete: per-position pass of generate_summary (:568-654), then one coalesced store --------
+    const int idx = tile_lo + tid;
+    int vals[MATF];
+#pragma unroll
+    for (int f = 0; f < MATF; ++f) vals[f] = 0;
+    int cov = 0, n_snp = 0, n_ins = 0, n_del = 0, tab[8];
+    const bool row = tid < TP && idx < L;
+    if (row) {
+        cov = cnt[K_COV * TP + tid];
+        n_snp = cnt[K_SNP * TP + tid];
+        n_ins = cnt[K_INS * TP + tid];
+        n_del = cnt[K_DEL * TP + tid];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) tab[t] = cnt[(K_TAB + t) * TP + tid];
+        vals[0] = base_code(ref_s[tid]);
+        vals[4] = -cnt[K_FWD * TP + tid];
+        vals[15] = -cnt[K_REV * TP + tid];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            vals[8 + s] = -cnt[(K_FWD + 1 + s) * TP + tid];
+            vals[19 + s] = -cnt[(K_REV + 1 + s) * TP + tid];
+        }
+    }
+    __syncthreads();                               // every counter is in registers: the LDS becomes the output tile
+    if (tid < TP) pass_s[tid] = 0;
+    if (row) {
+        const double c = cov > 1 ? (double)cov : 1.0;
+        const bool s = (double)n_snp / c >= reg.snp_thr;
+        const bool n = (double)n_ins / c >= reg.ins_thr;
+        const bool d = (double)n_del / c >= reg.del_thr;
+        const bool passes = (s || n || d) && idx >= reg.cand_lo && idx <= reg.cand_hi && (double)cov >= reg.min_cov;
+        a.pass[reg.row_base + idx] = passes ? 1 : 0;
+        pass_s[tid] = passes ? 1 : 0;
+        if (passes) {
+            const int slot = atomicAdd(&a.region_counts[2 * region], 1);       // < L: one per row at most
+            {
+                SiteRec r;
+                r.region = region;
+                r.idx = idx;
+                r.cov = cov;
+                r.flags = (s ? 1 : 0) | (n ? 2 : 0) | (d ? 4 : 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    r.fwd[t] = tab[t];
+                    r.rev[t] = tab[4 + t];
+                }
+                a.sites[reg.row_base + slot] = r;
+            }
+        }
+#pragma unroll
+        for (int col = 11; col < 25; ++col) vals[col] = max(-MAXC, min(MAXC, vals[col]));
+    }
+    if (tid < TP) {
+#pragma unroll
+        for (int f = 0; f < MATF; ++f) cnt[tid * MATF + f] = vals[f];
+    }
+    __syncthreads();
+    const int n_rows = L + 1 - tile_lo < TP ? L + 1 - tile_lo : TP;
+    const int n_out = n_rows * MATF;
+    int* dst = a.mat + (reg.row_base + tile_lo) * (int64_t)MATF;          // 128-byte aligned: row_base % 16 == 0, tile_lo % 512 == 0
+    for (int i = tid; i < n_out / 4; i += NT) reinterpret_cast<int4*>(dst)[i] = reinterpret_cast<const int4*>(cnt)[i];
+    for (int i = (n_out & ~3) + tid; i < n_out; i += NT) dst[i] = cnt[i];
+    // the votes of the rows that passed (a few per cent) go to the host's list
+    const int nv = vcount < VCAP ? vcount : VCAP;
+    for (int i0 = 0; i0 < nv; i0 += NT) {
+        const int i = i0 + tid;
+        const uint2 pv = i < nv ? vbuf[i] : make_uint2(0, 0);
+        const bool has = i < nv && pass_s[pv.y >> 10];
+        wave_append_vote(has, Vote{(uint32_t)(tile_lo + (int)(pv.y >> 10)), (pv.y & 1023u) | ((uint32_t)region << 10), (int64_t)pv.x},
+                         a.votes_out + reg.vote_base, &a.region_counts[2 * region + 1], 0x7fffffff, lane);
     }
 }
 
-// votes of the sites that passed the thresholds, compacted for the host (a few per cent of all votes)
-// (the number of votes is only known on the device: the grid covers the capacity, counters[2] bounds it)
-__global__ __launch_bounds__(256) void compact_votes_kernel(const DVote* __restrict__ votes, int* __restrict__ counters, int cap,
-                                                            const uint8_t* __restrict__ pass, DVote* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int n = counters[2] < cap ? counters[2] : cap;
-    if (i >= n) return;
-    const DVote v = votes[i];
-    if (pass[v.idx]) out[atomicAdd(&counters[4], 1)] = v;
-}
-
-__global__ __launch_bounds__(256) void apply_events_kernel(const Event* __restrict__ ev, int n, int* __restrict__ mat) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&mat[(size_t)ev[i].row * ROW + ev[i].col], ev[i].delta);
-}
-
-__global__ __launch_bounds__(256) void site_threshold_kernel(int* __restrict__ mat, const int* __restrict__ snp_tab, int L,
-                                                             int64_t region_start, int64_t cand_start, int64_t cand_end,
-                                                             double snp_thr, double ins_thr, double del_thr,
-                                                             double min_cov, int* __restrict__ site_count,
-                                                             SiteRec* __restrict__ sites, int site_cap,
-                                                             uint8_t* __restrict__ pass = nullptr) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= L) return;
-    if (pass) pass[idx] = 0;
-    int* row = mat + (size_t)idx * ROW;
-    const int cov = row[C_COV];
-    const double c = cov > 1 ? (double)cov : 1.0;
-    const bool s = (double)row[C_SNP] / c >= snp_thr;
-    const bool n = (double)row[C_INS] / c >= ins_thr;
-    const bool d = (double)row[C_DEL] / c >= del_thr;
-    const int64_t pos = region_start + idx;
-    if ((s || n || d) && pos >= cand_start && pos <= cand_end && (double)cov >= min_cov) {
-        const int slot = atomicAdd(site_count, 1);
-        if (pass) pass[idx] = 1;
-        if (slot < site_cap) {
-            SiteRec r;
-            r.idx = idx;
-            r.cov = cov;
-            r.flags = (s ? 1 : 0) | (n ? 2 : 0) | (d ? 4 : 0);
-            for (int k = 0; k < 4; ++k) {
-                r.fwd[k] = snp_tab[((size_t)idx * 2 + 0) * 4 + k];
-                r.rev[k] = snp_tab[((size_t)idx * 2 + 1) * 4 + k];
-            }
-            sites[slot] = r;
-        }
+// votes of the sites that passed the thresholds, compacted for the host
+// (the number of votes is only known on the device: a fixed grid strides over counters[CT_VOTES] of them)
+__global__ __launch_bounds__(256) void compact_votes_kernel(const Vote* __restrict__ votes, const int* __restrict__ counters, int cap,
+                                                            const RegRec* __restrict__ regions, const uint8_t* __restrict__ pass,
+                                                            int* __restrict__ region_counts, Vote* __restrict__ out) {
+    const int n = counters[CT_VOTES] < cap ? counters[CT_VOTES] : cap;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const Vote v = votes[i];
+        const int r = (int)(v.meta >> 10);
+        if (pass[regions[r].row_base + v.idx]) out[regions[r].vote_base + atomicAdd(&region_counts[2 * r + 1], 1)] = v;
     }
-    for (int col = 11; col < 25; ++col) row[col] = max(-MAXC, min(MAXC, row[col]));
+}
+
+// The two region-sliced lists made dense for one copy to the host: region r's sites / votes move to the prefix sums of the
+// counts before it (one workgroup per region; the counts of a batch are a few hundred integers).
+__global__ __launch_bounds__(256) void pack_results_kernel(const RegRec* __restrict__ regions, const int* __restrict__ region_counts,
+                                                           const SiteRec* __restrict__ sites, const Vote* __restrict__ votes,
+                                                           SiteRec* __restrict__ sites_out, Vote* __restrict__ votes_out) {
+    __shared__ int off[2];
+    const int r = blockIdx.x;
+    if (threadIdx.x < 2) off[threadIdx.x] = 0;
+    __syncthreads();
+    int s = 0, v = 0;
+    for (int q = threadIdx.x; q < r; q += 256) {
+        s += region_counts[2 * q];
+        v += region_counts[2 * q + 1];
+    }
+    if (s) atomicAdd(&off[0], s);
+    if (v) atomicAdd(&off[1], v);
+    __syncthreads();
+    const int ns = region_counts[2 * r], nv = region_counts[2 * r + 1];
+    const SiteRec* src_s = sites + regions[r].row_base;
+    const Vote* src_v = votes + regions[r].vote_base;
+    for (int i = threadIdx.x; i < ns; i += 256) sites_out[off[0] + i] = src_s[i];
+    for (int i = threadIdx.x; i < nv; i += 256) votes_out[off[1] + i] = src_v[i];
 }
 
 // one 64-lane workgroup per candidate: 33 x 26 = 858 cells
-__global__ __launch_bounds__(64) void gather_windows_kernel(const int* __restrict__ mat, const CandDesc* __restrict__ cands,
-                                                            int L, int W, int F, int mid, int* __restrict__ out32,
-                                                            int8_t* __restrict__ out8) {
+__global__ __launch_bounds__(64) void gather_windows_kernel(const int* __restrict__ mat, const RegRec* __restrict__ regions,
+                                                            const CandDesc* __restrict__ cands, int W, int F, int mid,
+                                                            int* __restrict__ out32, int8_t* __restrict__ out8) {
     const CandDesc cd = cands[blockIdx.x];
+    const int L = regions[cd.region].L;
+    const int* m = mat + regions[cd.region].row_base * MATF;
     const size_t base = (size_t)blockIdx.x * W * F;
     for (int e = threadIdx.x; e < W * F; e += 64) {
         const int r = e / F, f = e - r * F;
         const int row = cd.idx - mid + r;
-        int v = (row >= 0 && row <= L && f < 26) ? mat[(size_t)row * ROW + f] : 0;
+        int v = (row >= 0 && row <= L && f < MATF) ? m[(size_t)row * MATF + f] : 0;
         if (r == mid) {
             if (f == cd.vcol) v = cd.vval;
             else if (f == cd.type + 4) v = cd.fwd;        // 5 / 6 / 7
@@ -342,445 +577,172 @@ __global__ __launch_bounds__(64) void gather_windows_kernel(const int* __restric
     }
 }
 
-// ---- polish encoder -----------------------------------------------------------------------------
-constexpr uint32_t PSEG_REV = 1, PSEG_GAP = 2, PSEG_INS = 4;
-constexpr int PROW = 16, PC_COV = 10;       // base counts int32 [L][16]: 10 features + coverage
+struct Tally { int total = 0, fwd = 0, rev = 0; };
 
-struct PSeg {
-    int64_t seq0;
-    int32_t idx0, n;      // MATCH/GAP: first position row; INS: first insert-slot row
-    uint32_t flags;
-    int32_t cov_idx;      // GAP: row credited with coverage (deletion start), -1 if outside the region
+struct RegHost {
+    pa_pileup p;
+    pa_summary_params q;
+    int L = 0;
+    int64_t row_base = 0, seq_base = 0, op_base = 0, read_base = 0;
 };
-struct PRow { int32_t idx, slot; };   // output row -> (position row, 0 = base row / k = insert slot k)
 
-__host__ __device__ inline int polish_feature(char b, bool rev) {   // summary_generator.cpp:16-32
-    int k;
-    switch (up(b)) {
-        case 'A': k = 0; break;
-        case 'C': k = 1; break;
-        case 'G': k = 2; break;
-        case 'T': k = 3; break;
-        default: return rev ? 8 : 9;
-    }
-    return rev ? k : k + 4;
-}
+}  // namespace
 
-__global__ __launch_bounds__(256) void polish_count_kernel(const PSeg* __restrict__ segs, int nseg,
-                                                           const char* __restrict__ seq, int* __restrict__ base,
-                                                           int* __restrict__ ins) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= nseg) return;
-    const PSeg sg = segs[s];
-    const bool rev = sg.flags & PSEG_REV;
-    if (sg.flags & PSEG_GAP) {
-        const int col = rev ? 8 : 9;
-        for (int i = 0; i < sg.n; ++i) atomicAdd(&base[(size_t)(sg.idx0 + i) * PROW + col], 1);
-        if (sg.cov_idx >= 0) atomicAdd(&base[(size_t)sg.cov_idx * PROW + PC_COV], sg.n);
-    } else if (sg.flags & PSEG_INS) {
-        for (int i = 0; i < sg.n; ++i)
-            atomicAdd(&ins[(size_t)(sg.idx0 + i) * PROW + polish_feature(seq[sg.seq0 + i], rev)], 1);
-    } else {
-        for (int i = 0; i < sg.n; ++i) {
-            int* row = base + (size_t)(sg.idx0 + i) * PROW;
-            atomicAdd(&row[polish_feature(seq[sg.seq0 + i], rev)], 1);
-            atomicAdd(&row[PC_COV], 1);
-        }
-    }
-}
+namespace {
 
-__global__ __launch_bounds__(256) void polish_pixels_kernel(const PRow* __restrict__ rows, int nrows,
-                                                            const int* __restrict__ base, const int* __restrict__ ins,
-                                                            const int* __restrict__ ins_row0, uint8_t* __restrict__ out) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= nrows) return;
-    const PRow pr = rows[r];
-    const int cov = pr.idx >= 0 ? base[(size_t)pr.idx * PROW + PC_COV] : 0;
-    const double c = cov > 1 ? (double)cov : 1.0;
-    const int* src = pr.idx < 0 ? nullptr
-                                : (pr.slot == 0 ? base + (size_t)pr.idx * PROW
-                                                : ins + (size_t)(ins_row0[pr.idx] + pr.slot - 1) * PROW);
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        const double v = src ? ((double)src[j] / c) * 254.0 : 0.0;
-        out[(size_t)r * 10 + j] = (uint8_t)((long long)v & 0xff);   // double -> uint8 as x86-64 gcc truncates
-    }
-}
-
-struct DBuf {
+// page-locked host buffer that only grows (results of a run: one asynchronous copy each, no page faults per run)
+struct HBuf {
     void* p = nullptr;
     size_t bytes = 0;
     bool ensure(size_t need) {
         if (need <= bytes) return true;
-        if (p) (void)hipFree(p);
+        if (p) (void)hipHostFree(p);
         p = nullptr;
         bytes = 0;
-        const size_t grow = need + need / 4 + 256;
-        if (hipMalloc(&p, grow) != hipSuccess) return false;
+        const size_t grow = need + need / 2 + 4096;
+        if (hipHostMalloc(&p, grow, hipHostMallocDefault) != hipSuccess) return false;
         bytes = grow;
         return true;
     }
-    ~DBuf() { if (p) (void)hipFree(p); }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+    ~HBuf() { if (p) (void)hipHostFree(p); }
 };
 
-struct Tally { int total = 0, fwd = 0, rev = 0; };
+// worker threads that live as long as the encoder: the candidate enumeration of a batch is one short task per region
+// (a few hundred microseconds of ordered maps and strings), and starting 16 threads per run cost more than the tasks
+class RegionPool {
+public:
+    explicit RegionPool(int n) {
+        for (int t = 0; t < n; ++t) threads_.emplace_back([this] { loop(); });
+    }
+    ~RegionPool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread& t : threads_) t.join();
+    }
+    int size() const { return (int)threads_.size(); }
+    // fn(i) for i in [0, n): on the workers and on the caller; returns when all are done
+    void run(int n, const std::function<void(int)>& fn) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0);
+            left_ = n;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void drain() {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= n_) return;
+            (*fn_)(i);
+            std::lock_guard<std::mutex> g(m_);
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return stop_ || epoch_ != seen; });
+                if (stop_) return;
+                seen = epoch_;
+            }
+            drain();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, left_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
 
 }  // namespace
 
-struct pa_encoder {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    DBuf d_seq, d_qual, d_ref, d_segs, d_events, d_mat, d_snp, d_ovf, d_counters, d_sites, d_cands, d_img32, d_img8;
-    DBuf d_reads, d_cig, d_votes, d_votes_out, d_pass;     // device CIGAR walk: read tables, operations, allele votes
-    DBuf d_pbase, d_pins, d_prow0, d_prows, d_ppix;
-    int64_t p_rows = 0;
-    std::vector<int64_t> p_positions;
-    // results of the last call
+struct pa_variant_batch {
+    std::vector<RegHost> regs;
+    int64_t total_bases = 0, total_ops = 0, total_reads = 0, total_rows = 0, total_ref = 0;
+    int n_tiles = 0, W = 33, F = 26, mid = 16;
+    int rec_cap = 0, ovf_cap = 0;
+    bool staged = false;
+    DBuf d_seq, d_qual, d_ref, d_cig_op, d_cig_len, d_reads, d_regions, d_tile_region;
+    DBuf d_zero;                      // counters [CT_N] | per-region counts [2 n_regions] | tile_count [n_tiles] | tile_fill [n_tiles]: cleared per run
+    DBuf d_tile_off, d_sorted, d_mat, d_pass, d_sites, d_votes, d_votes_out, d_sites_dense, d_votes_dense, d_ovf, d_cands, d_img32, d_img8;
+    HBuf h_counts, h_sites, h_votes;
+    std::unique_ptr<RegionPool> pool;
+    // results of the last run
     int64_t n = 0;
-    int W = 33, F = 26;
+    std::vector<int64_t> region_n;
+    std::vector<int64_t> positions;
+    std::vector<int32_t> depths, freqs;
+    std::string names;
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+void pa_variant_batch_free(pa_variant_batch* b) { delete b; }
+
+namespace {
+
+// candidates of one region in the reference's order (std::set<string> per site, region_summary.cpp:667-916)
+struct RegionOut {
+    std::vector<CandDesc> cands;
     std::vector<int64_t> positions;
     std::vector<int32_t> depths, freqs;
     std::string names;
 };
 
-#define ENC_HIP(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess) return pa::set_error(PA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-#define ENC_ALLOC(buf, bytes_)                                                                          \
-    do {                                                                                                \
-        if (!(buf).ensure(bytes_)) return pa::set_error(PA_ERR_HIP, "hipMalloc failed in encoder workspace"); \
-    } while (0)
-
-extern "C" {
-
-int pa_encoder_create(int32_t device, void* hip_stream, pa_encoder** out) {
-    if (!out) return pa::set_error(PA_ERR_INVALID, "null argument");
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
-        return pa::set_error(PA_ERR_NO_DEVICE, "no HIP device visible: the pepper_amd encoder has no CPU fallback");
-    if (device < 0 || device >= count) return pa::set_error(PA_ERR_INVALID, "device ordinal out of range");
-    ENC_HIP(hipSetDevice(device));
-    auto* e = new pa_encoder();
-    e->device = device;
-    if (hip_stream) e->stream = static_cast<hipStream_t>(hip_stream);
-    else {
-        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
-            delete e;
-            return pa::set_error(PA_ERR_HIP, "hipStreamCreate failed");
-        }
-        e->own_stream = true;
-    }
-    *out = e;
-    return PA_OK;
-}
-
-void pa_encoder_destroy(pa_encoder* e) {
-    if (!e) return;
-    (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
-    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
-    delete e;
-}
-
-int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summary_params* q, int64_t* n_candidates) {
-    if (!e || !p || !q || !n_candidates) return pa::set_error(PA_ERR_INVALID, "null argument");
-    if (p->region_end < p->region_start || p->region_end - p->region_start > (int64_t)1 << 28)
-        return pa::set_error(PA_ERR_INVALID, "bad region");
-    if (q->feature_size < 26 || q->candidate_window_size < 2 || q->candidate_window_size > 254)
-        return pa::set_error(PA_ERR_INVALID, "feature_size must be >= 26 and 2 <= candidate_window_size <= 254");
-    ENC_HIP(hipSetDevice(e->device));
-    const int64_t start = p->region_start, end = p->region_end;
-    const int L = (int)(end - start + 1);
-    const int W = q->candidate_window_size + 1, F = q->feature_size, mid = q->candidate_window_size / 2;
-    e->W = W;
-    e->F = F;
-    e->n = 0;
-    e->positions.clear();
-    e->depths.clear();
-    e->freqs.clear();
-    e->names.clear();
-    auto refc = [&](int64_t idx) { return idx >= 0 && idx < p->reference_len ? p->reference[idx] : 'N'; };
-    static const bool trace = getenv("PA_ENCODER_TRACE") != nullptr;      // host phase times on stderr
-    auto t_prev = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-        if (!trace) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[encoder] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
-        t_prev = now;
-    };
-
-    // PA_ENCODER_HOST_CIGAR=1: round 1's split (host pass over CIGAR operations -> Seg / Event lists -> pileup_count_kernel +
-    // apply_events_kernel); default: the whole walk on the device (cigar_walk_kernel)
-    const char* host_cigar_env = getenv("PA_ENCODER_HOST_CIGAR");       // read per call: the tests run both paths
-    const bool host_cigar = host_cigar_env && host_cigar_env[0] != '0';
-    const int64_t n_ops = p->n_reads > 0 ? p->cigar_offset[p->n_reads] : 0;
-    // ---- host pass over CIGAR ops -----------------------------------------------------------
-    std::vector<Seg> segs;
-    std::vector<Event> events;
-    if (host_cigar) {
-        segs.reserve((size_t)n_ops + 1024);
-        events.reserve((size_t)n_ops * 2 + 1024);
-    }
-    // Indel allele votes are only recorded here (site, type, where the allele's bytes live); the ordered
-    // per-site maps of allele strings the reference keeps for EVERY position (region_summary.cpp:431-555)
-    // are built later and only for the few sites that pass the thresholds -- one string allocation and two
-    // map look-ups per indel event were most of the host time of a region.
-    struct IndelVote { int32_t idx; char type; bool rev; int32_t len; const char* src; };
-    std::vector<IndelVote> votes;
-    auto vote = [&](int32_t idx, char type, const char* src, int64_t len, bool rev) {
-        votes.push_back({idx, type, rev, (int32_t)len, src});
-    };
-    const int64_t total_bases = p->n_reads > 0 ? p->seq_offset[p->n_reads] : 0;
-    for (int32_t r = 0; host_cigar && r < p->n_reads; ++r) {
-        if (p->read_mapq[r] <= 0) continue;
-        const bool rev = p->read_reverse[r] != 0;
-        const int64_t s0 = p->seq_offset[r], read_len = p->seq_offset[r + 1] - s0;
-        const char* seq = p->seq + s0;
-        const uint8_t* ql = p->qual + s0;
-        const int64_t c0 = p->cigar_offset[r], c1 = p->cigar_offset[r + 1];
-        int64_t ri = 0, pos = p->read_pos[r];
-        for (int64_t c = c0; c < c1; ++c) {
-            if (pos > end) break;
-            const int op = p->cigar_op[c];
-            const int64_t len = p->cigar_len[c];
-            if (op == OP_M || op == OP_EQ || op == OP_X) {
-                const int64_t lo = std::max(pos, start), hi = std::min(pos + len - 1, end);   // touched positions
-                if (lo <= hi) {
-                    if (ri + (hi - pos) >= read_len)
-                        return pa::set_error(PA_ERR_INVALID, "CIGAR of read " + std::to_string(r) + " runs past its sequence");
-                    bool anchor = false;
-                    if (hi == pos + len - 1 && c != c1 - 1) {
-                        const int nop = p->cigar_op[c + 1];
-                        anchor = (nop == OP_I || nop == OP_D);
-                    }
-                    for (int64_t q0 = lo; q0 <= hi; q0 += 64) {       // one wave per <= 64 positions
-                        const int64_t q1 = std::min(hi, q0 + 63);
-                        Seg sg;
-                        sg.seq0 = s0 + ri + (q0 - pos);
-                        sg.idx0 = (int32_t)(q0 - start);
-                        sg.n = (int32_t)(q1 - q0 + 1);
-                        sg.flags = (rev ? SEG_REV : 0) | ((anchor && q1 == hi) ? SEG_ANCHOR : 0);
-                        sg.pad = 0;
-                        segs.push_back(sg);
-                    }
-                }
-                ri += len;
-                pos += len;
-            } else if (op == OP_I) {
-                const int64_t anchor = pos - 1;
-                if (anchor >= start && anchor <= end && ri - 1 >= 0) {
-                    const int32_t idx = (int32_t)(anchor - start);
-                    const int64_t n = len + 1;
-                    const int64_t avail = std::max<int64_t>(0, std::min<int64_t>(n, read_len - (ri - 1)));
-                    double qsum = 0;
-                    for (int64_t k = ri - 1; k < ri - 1 + n; ++k) qsum += k < read_len ? ql[k] : 0;
-                    const bool passes = qsum >= q->min_indel_baseq * (double)n;
-                    if (passes && (double)ql[ri - 1] < q->min_snp_baseq) events.push_back({idx, C_COV, 1, 0});
-                    if (avail + 1 <= 61 && passes) {
-                        const int col = symbol_column(refc(idx), 'I', rev);
-                        if (col >= 0) events.push_back({idx, col, -1, 0});
-                        events.push_back({idx, C_INS, 1, 0});
-                        vote(idx, '2', seq + (ri - 1), avail, rev);
-                    }
-                }
-                ri += len;
-            } else if (op == OP_D) {
-                const int64_t anchor = pos - 1;
-                if (anchor >= start && anchor <= end) {
-                    const int32_t idx = (int32_t)(anchor - start);
-                    const int col = symbol_column(refc(idx), 'D', rev);
-                    if (col >= 0) events.push_back({idx, col, -1, 0});
-                    const int64_t avail = std::max<int64_t>(0, std::min<int64_t>(len + 1, p->reference_len - idx));
-                    if (avail + 1 <= 61) {
-                        events.push_back({idx, C_DEL, 1, 0});
-                        vote(idx, '3', p->reference + idx, avail, rev);
-                    }
-                }
-                const int64_t lo = std::max(pos, start), hi = std::min(pos + len - 1, end);
-                for (int64_t q0 = lo; q0 <= hi; q0 += 64)
-                    segs.push_back({0, (int32_t)(q0 - start), (int32_t)(std::min(hi, q0 + 63) - q0 + 1),
-                                    (rev ? SEG_REV : 0) | SEG_DEL, 0});
-                pos += len;
-            } else if (op == OP_N || op == OP_P) {
-                pos += len;
-                ri += len;      // the reference falls through into the soft-clip case (region_summary.cpp:556-561)
-            } else if (op == OP_S) {
-                ri += len;
-            }
-        }
-    }
-
-    // ---- device: counts -----------------------------------------------------------------------
-    const int ovf_cap = 1 << 16;
-    const int site_cap = L;
-    ENC_ALLOC(e->d_seq, (size_t)total_bases + 16);
-    ENC_ALLOC(e->d_qual, (size_t)total_bases + 16);
-    ENC_ALLOC(e->d_ref, (size_t)p->reference_len + 16);
-    ENC_ALLOC(e->d_segs, segs.size() * sizeof(Seg) + 16);
-    lap("cigar pass");
-    ENC_ALLOC(e->d_events, events.size() * sizeof(Event) + 16);
-    ENC_ALLOC(e->d_mat, (size_t)(L + 1) * ROW * sizeof(int));
-    ENC_ALLOC(e->d_snp, (size_t)L * 8 * sizeof(int));
-    ENC_ALLOC(e->d_ovf, (size_t)ovf_cap * sizeof(int4));
-    ENC_ALLOC(e->d_counters, 64);
-    ENC_ALLOC(e->d_sites, (size_t)site_cap * sizeof(SiteRec));
-    hipStream_t st = e->stream;
-    if (total_bases > 0) {
-        ENC_HIP(hipMemcpyAsync(e->d_seq.p, p->seq, (size_t)total_bases, hipMemcpyHostToDevice, st));
-        ENC_HIP(hipMemcpyAsync(e->d_qual.p, p->qual, (size_t)total_bases, hipMemcpyHostToDevice, st));
-    }
-    if (p->reference_len > 0)
-        ENC_HIP(hipMemcpyAsync(e->d_ref.p, p->reference, (size_t)p->reference_len, hipMemcpyHostToDevice, st));
-    if (!segs.empty())
-        ENC_HIP(hipMemcpyAsync(e->d_segs.p, segs.data(), segs.size() * sizeof(Seg), hipMemcpyHostToDevice, st));
-    if (!events.empty())
-        ENC_HIP(hipMemcpyAsync(e->d_events.p, events.data(), events.size() * sizeof(Event), hipMemcpyHostToDevice, st));
-    ENC_HIP(hipMemsetAsync(e->d_snp.p, 0, (size_t)L * 8 * sizeof(int), st));
-    ENC_HIP(hipMemsetAsync(e->d_counters.p, 0, 64, st));
-    int* mat = static_cast<int*>(e->d_mat.p);
-    int* counters = static_cast<int*>(e->d_counters.p);
-    hipLaunchKernelGGL(init_matrix_kernel, dim3((L + 1 + 255) / 256), dim3(256), 0, st, mat,
-                       static_cast<const char*>(e->d_ref.p), p->reference_len, L);
-    uint8_t* d_pass = nullptr;
-    if (!host_cigar) {
-        // read tables and operations: [pos i64 n][seq_offset i64 n+1][cigar_offset i64 n+1][mapq i32 n][reverse u8 n]
-        const size_t n = (size_t)p->n_reads;
-        const size_t o_pos = 0, o_soff = o_pos + 8 * n, o_coff = o_soff + 8 * (n + 1), o_mapq = o_coff + 8 * (n + 1),
-                     o_rev = o_mapq + 4 * n, reads_bytes = o_rev + n;
-        ENC_ALLOC(e->d_reads, reads_bytes + 64);
-        ENC_ALLOC(e->d_cig, (size_t)n_ops * 8 + 64);
-        ENC_ALLOC(e->d_votes, (size_t)(n_ops + 1) * sizeof(DVote));
-        ENC_ALLOC(e->d_votes_out, (size_t)(n_ops + 1) * sizeof(DVote));
-        ENC_ALLOC(e->d_pass, (size_t)L + 64);
-        d_pass = static_cast<uint8_t*>(e->d_pass.p);
-        char* dr = static_cast<char*>(e->d_reads.p);
-        if (n > 0) {
-            ENC_HIP(hipMemcpyAsync(dr + o_pos, p->read_pos, 8 * n, hipMemcpyHostToDevice, st));
-            ENC_HIP(hipMemcpyAsync(dr + o_soff, p->seq_offset, 8 * (n + 1), hipMemcpyHostToDevice, st));
-            ENC_HIP(hipMemcpyAsync(dr + o_coff, p->cigar_offset, 8 * (n + 1), hipMemcpyHostToDevice, st));
-            ENC_HIP(hipMemcpyAsync(dr + o_mapq, p->read_mapq, 4 * n, hipMemcpyHostToDevice, st));
-            ENC_HIP(hipMemcpyAsync(dr + o_rev, p->read_reverse, n, hipMemcpyHostToDevice, st));
-        }
-        char* dc = static_cast<char*>(e->d_cig.p);
-        if (n_ops > 0) {
-            ENC_HIP(hipMemcpyAsync(dc, p->cigar_op, (size_t)n_ops * 4, hipMemcpyHostToDevice, st));
-            ENC_HIP(hipMemcpyAsync(dc + (size_t)n_ops * 4, p->cigar_len, (size_t)n_ops * 4, hipMemcpyHostToDevice, st));
-        }
-        if (n > 0) {
-            WalkArgs wa;
-            wa.read_pos = reinterpret_cast<const int64_t*>(dr + o_pos);
-            wa.read_reverse = reinterpret_cast<const uint8_t*>(dr + o_rev);
-            wa.read_mapq = reinterpret_cast<const int32_t*>(dr + o_mapq);
-            wa.seq_offset = reinterpret_cast<const int64_t*>(dr + o_soff);
-            wa.cigar_offset = reinterpret_cast<const int64_t*>(dr + o_coff);
-            wa.cigar_op = reinterpret_cast<const int32_t*>(dc);
-            wa.cigar_len = reinterpret_cast<const int32_t*>(dc + (size_t)n_ops * 4);
-            wa.seq = static_cast<const char*>(e->d_seq.p);
-            wa.qual = static_cast<const uint8_t*>(e->d_qual.p);
-            wa.ref = static_cast<const char*>(e->d_ref.p);
-            wa.ref_len = p->reference_len;
-            wa.start = start;
-            wa.end = end;
-            wa.n_reads = p->n_reads;
-            wa.mat = mat;
-            wa.snp_tab = static_cast<int*>(e->d_snp.p);
-            wa.counters = counters;
-            wa.ovf = static_cast<int4*>(e->d_ovf.p);
-            wa.ovf_cap = ovf_cap;
-            wa.votes = static_cast<DVote*>(e->d_votes.p);
-            wa.vote_cap = (int)n_ops;
-            wa.min_snp_q = q->min_snp_baseq;
-            wa.min_indel_q = q->min_indel_baseq;
-            hipLaunchKernelGGL(cigar_walk_kernel, dim3((p->n_reads + 3) / 4), dim3(256), 0, st, wa);
-        }
-    }
-    if (!segs.empty())
-        hipLaunchKernelGGL(pileup_count_kernel, dim3(((int)segs.size() + 3) / 4), dim3(256), 0, st,
-                           static_cast<const Seg*>(e->d_segs.p), (int)segs.size(), static_cast<const char*>(e->d_seq.p),
-                           static_cast<const uint8_t*>(e->d_qual.p), static_cast<const char*>(e->d_ref.p),
-                           p->reference_len, mat, static_cast<int*>(e->d_snp.p), counters,
-                           static_cast<int4*>(e->d_ovf.p), ovf_cap, q->min_snp_baseq);
-    if (!events.empty())
-        hipLaunchKernelGGL(apply_events_kernel, dim3(((int)events.size() + 255) / 256), dim3(256), 0, st,
-                           static_cast<const Event*>(e->d_events.p), (int)events.size(), mat);
-    hipLaunchKernelGGL(site_threshold_kernel, dim3((L + 255) / 256), dim3(256), 0, st, mat,
-                       static_cast<const int*>(e->d_snp.p), L, start, q->candidate_region_start,
-                       q->candidate_region_end, q->snp_freq_threshold, q->insert_freq_threshold,
-                       q->delete_freq_threshold, q->min_coverage_threshold, counters + 1,
-                       static_cast<SiteRec*>(e->d_sites.p), site_cap, d_pass);
-    if (!host_cigar && n_ops > 0)      // votes of the passing sites only (vote count read on the device: grid over the capacity)
-        hipLaunchKernelGGL(compact_votes_kernel, dim3(((int)n_ops + 255) / 256), dim3(256), 0, st,
-                           static_cast<const DVote*>(e->d_votes.p), counters, (int)n_ops, d_pass,
-                           static_cast<DVote*>(e->d_votes_out.p));
-    ENC_HIP(hipGetLastError());
-    int host_counters[5] = {0, 0, 0, 0, 0};
-    lap("uploads + launches");
-    ENC_HIP(hipMemcpyAsync(host_counters, counters, sizeof(host_counters), hipMemcpyDeviceToHost, st));
-    ENC_HIP(hipStreamSynchronize(st));
-    lap("count kernels");
-    if (host_counters[3] > 0)
-        return pa::set_error(PA_ERR_INVALID, "CIGAR of read " + std::to_string(host_counters[3] - 1) + " runs past its sequence");
-    const int n_ovf = host_counters[0], n_sites = std::min(host_counters[1], site_cap);
-    if (n_ovf > ovf_cap)
-        return pa::set_error(PA_ERR_INVALID, "more than 65536 mismatching bases outside ACGT in one region");
-    std::vector<SiteRec> sites((size_t)n_sites);
-    std::vector<int4> ovf((size_t)n_ovf);
-    if (n_sites) ENC_HIP(hipMemcpyAsync(sites.data(), e->d_sites.p, sites.size() * sizeof(SiteRec), hipMemcpyDeviceToHost, st));
-    if (n_ovf) ENC_HIP(hipMemcpyAsync(ovf.data(), e->d_ovf.p, ovf.size() * sizeof(int4), hipMemcpyDeviceToHost, st));
-    std::vector<DVote> dvotes;
-    if (!host_cigar) {
-        if (host_counters[2] > n_ops) return pa::set_error(PA_ERR_INVALID, "more indel votes than CIGAR operations (corrupt pileup)");
-        dvotes.resize((size_t)host_counters[4]);
-        if (!dvotes.empty())
-            ENC_HIP(hipMemcpyAsync(dvotes.data(), e->d_votes_out.p, dvotes.size() * sizeof(DVote), hipMemcpyDeviceToHost, st));
-    }
-    ENC_HIP(hipStreamSynchronize(st));
-    for (const DVote& v : dvotes)
-        votes.push_back({v.idx, (char)(v.type_rev & 0xff), (v.type_rev >> 8) != 0, v.len,
-                         (v.from_ref ? p->reference : p->seq) + v.off});
-    std::sort(sites.begin(), sites.end(), [](const SiteRec& a, const SiteRec& b) { return a.idx < b.idx; });
+void enumerate_region(const RegHost& rh, int region, int mid, const SiteRec* sites, size_t n_sites, const Vote* votes,
+                      size_t n_votes, const int4* ovf, size_t n_ovf, RegionOut& out) {
+    const pa_pileup& p = rh.p;
+    const pa_summary_params& q = rh.q;
+    auto refc = [&](int64_t idx) { return idx >= 0 && idx < p.reference_len ? p.reference[idx] : 'N'; };
     std::map<int32_t, std::map<char, Tally>> rare;       // SNP alleles outside ACGT
-    for (const int4& o : ovf) {
-        Tally& t = rare[o.x][(char)o.y];
+    for (size_t k = 0; k < n_ovf; ++k) {
+        Tally& t = rare[ovf[k].x][(char)ovf[k].y];
         t.total += 1;
-        (o.z ? t.rev : t.fwd) += 1;
+        (ovf[k].z ? t.rev : t.fwd) += 1;
     }
-
-    // votes bucketed by site (counting sort, stable: order of arrival does not matter for the tallies)
-    std::vector<int32_t> vote_begin((size_t)L + 2, 0);
-    for (const IndelVote& v : votes) vote_begin[(size_t)v.idx + 1] += 1;
-    for (int i = 0; i <= L; ++i) vote_begin[(size_t)i + 1] += vote_begin[i];
-    std::vector<int32_t> vote_order(votes.size());
-    {
-        std::vector<int32_t> cursor(vote_begin.begin(), vote_begin.end() - 1);
-        for (size_t k = 0; k < votes.size(); ++k) vote_order[(size_t)cursor[votes[k].idx]++] = (int32_t)k;
-    }
-
-    // ---- host: candidates in the reference's order (std::set<string> per site) -------------------
-    std::vector<CandDesc> cands;
-    for (const SiteRec& s : sites) {
+    size_t vk = 0;                                        // votes are sorted by site, like the sites
+    struct VoteKey { const char* bytes; uint32_t len; char type; bool rev; };
+    std::vector<VoteKey> keys;
+    for (size_t si = 0; si < n_sites; ++si) {
+        const SiteRec& s = sites[si];
         const int depth = std::min(s.cov, MAXC);
         const char rb = refc(s.idx);
         auto accept = [&](char type, const Tally& t) {
             const double freq = (double)t.total / std::max(1.0, (double)depth);
-            if ((double)t.total < q->candidate_support_threshold) return false;
-            if (type != '1' && freq < q->indel_candidate_freq_threshold) return false;
-            if (type == '1' && freq < q->snp_candidate_freq_threshold) return false;
-            if (type != '1' && q->skip_indels) return false;
+            if ((double)t.total < q.candidate_support_threshold) return false;
+            if (type != '1' && freq < q.indel_candidate_freq_threshold) return false;
+            if (type == '1' && freq < q.snp_candidate_freq_threshold) return false;
+            if (type != '1' && q.skip_indels) return false;
             if ((type == '1' && !(s.flags & 1)) || (type == '2' && !(s.flags & 2)) || (type == '3' && !(s.flags & 4)))
                 return false;
             return true;
         };
-        auto emit = [&](const std::string& key, const Tally& t, const CandDesc& d) {
-            cands.push_back(d);
-            e->positions.push_back(start + s.idx);
-            e->depths.push_back(depth);
-            e->freqs.push_back(std::min(t.total, MAXC));
-            e->names += key;
-            e->names.push_back('\0');
+        auto emit = [&](const std::string& key, const Tally& t, CandDesc d) {
+            d.region = region;
+            out.cands.push_back(d);
+            out.positions.push_back(p.region_start + s.idx);
+            out.depths.push_back(depth);
+            out.freqs.push_back(std::min(t.total, MAXC));
+            out.names += key;
+            out.names.push_back('\0');
         };
         // SNP alleles: "1" + base, ordered by the raw base character
         std::map<char, Tally> snps;
@@ -804,54 +766,414 @@ int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summ
             d.last = -1; d.star_f = d.star_r = -1;
             emit(std::string("1") + kv.first, kv.second, d);
         }
-        if (vote_begin[(size_t)s.idx] == vote_begin[(size_t)s.idx + 1]) continue;
-        std::map<std::string, Tally> site_indels;          // ordered allele keys ("2..." < "3...")
-        for (int32_t k = vote_begin[(size_t)s.idx]; k < vote_begin[(size_t)s.idx + 1]; ++k) {
-            const IndelVote& v = votes[(size_t)vote_order[(size_t)k]];
-            std::string key(1, v.type);
-            key.append(v.src, (size_t)v.len);
-            Tally& t = site_indels[key];
-            t.total += 1;
-            (v.rev ? t.rev : t.fwd) += 1;
+        while (vk < n_votes && (int32_t)votes[vk].idx < s.idx) ++vk;
+        if (vk >= n_votes || (int32_t)votes[vk].idx != s.idx) continue;
+        // allele keys "2" + anchor + inserted bases / "3" + deleted reference bases in std::map<std::string> order, without
+        // building a string per vote (one allocation per vote was most of the host time of a batch): order the site's votes
+        // by (type, bytes) and tally the runs of equal keys
+        keys.clear();
+        for (; vk < n_votes && (int32_t)votes[vk].idx == s.idx; ++vk) {
+            const Vote& v = votes[vk];
+            keys.push_back(VoteKey{((v.meta & 8u) ? p.reference : p.seq) + v.off, (uint32_t)((v.meta >> 4) & 63u),
+                                   (v.meta & 3u) == 1u ? '2' : '3', (v.meta & 4u) != 0});
         }
-        for (const auto& kv : site_indels) {
-            const char type = kv.first[0];
-            if (!accept(type, kv.second)) continue;
-            CandDesc d{};
-            d.idx = s.idx; d.type = type - '0';
-            d.fwd = std::min(kv.second.fwd, MAXC); d.rev = std::min(kv.second.rev, MAXC);
-            const int alen = (int)kv.first.size() - 1;
-            d.vval = std::min(alen, MAXC);
-            d.star_f = d.star_r = -1;
-            if (type == '2') {
-                d.vcol = 2; d.last = -1;
-                d.neg_f = symbol_column(rb, 'I', false); d.neg_r = symbol_column(rb, 'I', true);
-            } else {
-                d.vcol = 3; d.last = std::min(mid + alen - 1, q->candidate_window_size - 1);
-                d.neg_f = symbol_column(rb, 'D', false); d.neg_r = symbol_column(rb, 'D', true);
-                d.star_f = symbol_column(rb, '*', false); d.star_r = symbol_column(rb, '*', true);
+        std::sort(keys.begin(), keys.end(), [](const VoteKey& x, const VoteKey& y) {
+            if (x.type != y.type) return x.type < y.type;
+            const int c = std::memcmp(x.bytes, y.bytes, std::min(x.len, y.len));
+            return c != 0 ? c < 0 : x.len < y.len;
+        });
+        for (size_t k0 = 0; k0 < keys.size();) {
+            size_t k1 = k0;
+            Tally t;
+            while (k1 < keys.size() && keys[k1].type == keys[k0].type && keys[k1].len == keys[k0].len &&
+                   std::memcmp(keys[k1].bytes, keys[k0].bytes, keys[k0].len) == 0) {
+                t.total += 1;
+                (keys[k1].rev ? t.rev : t.fwd) += 1;
+                ++k1;
             }
-            emit(kv.first, kv.second, d);
+            const char type = keys[k0].type;
+            const int alen = (int)keys[k0].len;
+            if (accept(type, t)) {
+                CandDesc d{};
+                d.idx = s.idx; d.type = type - '0';
+                d.fwd = std::min(t.fwd, MAXC); d.rev = std::min(t.rev, MAXC);
+                d.vval = std::min(alen, MAXC);
+                d.star_f = d.star_r = -1;
+                if (type == '2') {
+                    d.vcol = 2; d.last = -1;
+                    d.neg_f = symbol_column(rb, 'I', false); d.neg_r = symbol_column(rb, 'I', true);
+                } else {
+                    d.vcol = 3; d.last = std::min(mid + alen - 1, q.candidate_window_size - 1);
+                    d.neg_f = symbol_column(rb, 'D', false); d.neg_r = symbol_column(rb, 'D', true);
+                    d.star_f = symbol_column(rb, '*', false); d.star_r = symbol_column(rb, '*', true);
+                }
+                std::string key(1, type);
+                key.append(keys[k0].bytes, keys[k0].len);
+                emit(key, t, d);
+            }
+            k0 = k1;
+        }
+    }
+}
+
+int stage_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const pa_summary_params* params) {
+    if (!e || n_regions < 0 || (n_regions > 0 && (!pileups || !params))) return pa::set_error(PA_ERR_INVALID, "null argument");
+    if (n_regions >= (1 << 22)) return pa::set_error(PA_ERR_INVALID, "more than 4194303 regions in one batch");
+    ENC_HIP(hipSetDevice(e->device));
+    if (!e->variant) e->variant = new pa_variant_batch();
+    pa_variant_batch& b = *e->variant;
+    b.staged = false;
+    b.regs.assign((size_t)n_regions, RegHost());
+    b.total_bases = b.total_ops = b.total_reads = b.total_rows = b.total_ref = 0;
+    b.n_tiles = 0;
+    std::vector<RegRec> regrecs((size_t)n_regions);
+    for (int r = 0; r < n_regions; ++r) {
+        const pa_pileup& p = pileups[r];
+        const pa_summary_params& q = params[r];
+        if (p.region_end < p.region_start || p.region_end - p.region_start > (int64_t)1 << 28) return pa::set_error(PA_ERR_INVALID, "bad region");
+        if (q.feature_size < 26 || q.candidate_window_size < 2 || q.candidate_window_size > 254)
+            return pa::set_error(PA_ERR_INVALID, "feature_size must be >= 26 and 2 <= candidate_window_size <= 254");
+        if (r > 0 && (q.feature_size != params[0].feature_size || q.candidate_window_size != params[0].candidate_window_size))
+            return pa::set_error(PA_ERR_INVALID, "one batch has one window size and one feature size");
+        if (p.n_reads < 0 || p.reference_len < 0) return pa::set_error(PA_ERR_INVALID, "negative count");
+        if (p.reference_len > 0x7fffffff || (p.n_reads > 0 && p.seq_offset[p.n_reads] > 0xffffffffll))
+            return pa::set_error(PA_ERR_INVALID, "a region is limited to 2^32 read bases and 2^31 reference bases");
+        RegHost& rh = b.regs[(size_t)r];
+        rh.p = p;
+        rh.q = q;
+        rh.L = (int)(p.region_end - p.region_start + 1);
+        rh.row_base = b.total_rows;
+        rh.seq_base = b.total_bases;
+        rh.op_base = b.total_ops;
+        rh.read_base = b.total_reads;
+        RegRec& g = regrecs[(size_t)r];
+        g.ref_off = b.total_ref;
+        g.row_base = rh.row_base;
+        g.seq_base = rh.seq_base;
+        g.ref_len = (int32_t)std::min<int64_t>(p.reference_len, 0x7fffffff);
+        g.L = rh.L;
+        g.tile0 = b.n_tiles;
+        g.n_tiles = (rh.L + 1 + TP - 1) / TP;
+        auto row_of = [&](int64_t pos) { return (int32_t)std::max<int64_t>(-2, std::min<int64_t>(pos - p.region_start, 0x7ffffff0)); };
+        g.cand_lo = row_of(q.candidate_region_start);
+        g.cand_hi = row_of(q.candidate_region_end);
+        // integer base quality Q passes `(double)Q >= min_snp_baseq` iff Q >= qmin
+        g.qmin = std::isnan(q.min_snp_baseq) ? 256 : (q.min_snp_baseq <= 0 ? 0 : (q.min_snp_baseq > 255 ? 256 : (int)std::ceil(q.min_snp_baseq)));
+        g.vote_base = (int32_t)rh.op_base;
+        g.min_snp_q = q.min_snp_baseq;
+        g.min_indel_q = q.min_indel_baseq;
+        g.snp_thr = q.snp_freq_threshold;
+        g.ins_thr = q.insert_freq_threshold;
+        g.del_thr = q.delete_freq_threshold;
+        g.min_cov = q.min_coverage_threshold;
+        b.total_rows += (rh.L + 1 + 15) & ~(int64_t)15;      // 16 rows x 104 B = 13 x 128 B: every tile store starts on a line
+        b.total_ref += p.reference_len;
+        b.total_reads += p.n_reads;
+        b.total_bases += p.n_reads > 0 ? p.seq_offset[p.n_reads] : 0;
+        b.total_ops += p.n_reads > 0 ? p.cigar_offset[p.n_reads] : 0;
+        b.n_tiles += g.n_tiles;
+        if (b.total_rows > ((int64_t)1 << 30) || b.total_ops > 0x7ffffff0 || b.total_reads > 0x7ffffff0)
+            return pa::set_error(PA_ERR_INVALID, "batch too large: more than 2^30 rows or 2^31 CIGAR operations / reads");
+    }
+    b.W = n_regions ? params[0].candidate_window_size + 1 : 33;
+    b.F = n_regions ? params[0].feature_size : 26;
+    b.mid = n_regions ? params[0].candidate_window_size / 2 : 16;
+
+    // read table
+    std::vector<ReadRec> reads((size_t)b.total_reads);
+    std::vector<int32_t> tile_region((size_t)b.n_tiles);
+    for (int r = 0; r < n_regions; ++r) {
+        const RegHost& rh = b.regs[(size_t)r];
+        const pa_pileup& p = rh.p;
+        for (int t = 0; t < regrecs[(size_t)r].n_tiles; ++t) tile_region[(size_t)(regrecs[(size_t)r].tile0 + t)] = r;
+        for (int32_t k = 0; k < p.n_reads; ++k) {
+            ReadRec& rd = reads[(size_t)(rh.read_base + k)];
+            const int64_t slen = p.seq_offset[k + 1] - p.seq_offset[k], ncig = p.cigar_offset[k + 1] - p.cigar_offset[k];
+            const int64_t row0 = p.read_pos[k] - p.region_start;
+            if (slen < 0 || ncig < 0 || slen > 0x7ffffff0) return pa::set_error(PA_ERR_INVALID, "offsets of read " + std::to_string(k) + " are not ascending");
+            rd.s0 = rh.seq_base + p.seq_offset[k];
+            rd.c0 = (int32_t)(rh.op_base + p.cigar_offset[k]);
+            rd.ncig = (int32_t)ncig;
+            rd.slen = (int32_t)slen;
+            // a read further than 2^30 rows from the region cannot reach it (CIGAR lengths are < 2^28 each, but their sum is
+            // walked in int32): such a read is dropped here exactly as the walk would never touch a row
+            rd.row0 = (int32_t)std::max<int64_t>(-(1 << 30), std::min<int64_t>(row0, 1 << 30));
+            rd.region = r;
+            rd.flags = (p.read_reverse[k] ? READ_REV : 0) | ((p.read_mapq[k] > 0 && row0 > -(1 << 30)) ? READ_MAPQ_OK : 0);
         }
     }
 
-    lap("candidate enumeration");
-    // ---- device: window gather ----------------------------------------------------------------------
-    e->n = (int64_t)cands.size();
-    *n_candidates = e->n;
-    if (e->n > 0) {
-        ENC_ALLOC(e->d_cands, cands.size() * sizeof(CandDesc));
-        ENC_ALLOC(e->d_img32, (size_t)e->n * W * F * sizeof(int));
-        ENC_ALLOC(e->d_img8, (size_t)e->n * W * F);
-        ENC_HIP(hipMemcpyAsync(e->d_cands.p, cands.data(), cands.size() * sizeof(CandDesc), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)e->n), dim3(64), 0, st, mat,
-                           static_cast<const CandDesc*>(e->d_cands.p), L, W, F, mid, static_cast<int*>(e->d_img32.p),
-                           static_cast<int8_t*>(e->d_img8.p));
+    hipStream_t st = e->stream;
+    ENC_ALLOC(b.d_seq, (size_t)b.total_bases + 64);
+    ENC_ALLOC(b.d_qual, (size_t)b.total_bases + 64);
+    ENC_ALLOC(b.d_ref, (size_t)b.total_ref + 64);
+    ENC_ALLOC(b.d_cig_op, (size_t)b.total_ops * 4 + 1024);      // the tile kernel issues 65-operation loads before it knows the read's end
+    ENC_ALLOC(b.d_cig_len, (size_t)b.total_ops * 4 + 1024);
+    ENC_ALLOC(b.d_reads, reads.size() * sizeof(ReadRec) + 64);
+    ENC_ALLOC(b.d_regions, regrecs.size() * sizeof(RegRec) + 64);
+    ENC_ALLOC(b.d_tile_region, tile_region.size() * 4 + 64);
+    for (int r = 0; r < n_regions; ++r) {
+        const RegHost& rh = b.regs[(size_t)r];
+        const pa_pileup& p = rh.p;
+        const int64_t nb = p.n_reads > 0 ? p.seq_offset[p.n_reads] : 0, no = p.n_reads > 0 ? p.cigar_offset[p.n_reads] : 0;
+        if (nb > 0) {
+            ENC_HIP(hipMemcpyAsync(b.d_seq.as<char>() + rh.seq_base, p.seq, (size_t)nb, hipMemcpyHostToDevice, st));
+            ENC_HIP(hipMemcpyAsync(b.d_qual.as<char>() + rh.seq_base, p.qual, (size_t)nb, hipMemcpyHostToDevice, st));
+        }
+        if (no > 0) {
+            ENC_HIP(hipMemcpyAsync(b.d_cig_op.as<int32_t>() + rh.op_base, p.cigar_op, (size_t)no * 4, hipMemcpyHostToDevice, st));
+            ENC_HIP(hipMemcpyAsync(b.d_cig_len.as<int32_t>() + rh.op_base, p.cigar_len, (size_t)no * 4, hipMemcpyHostToDevice, st));
+        }
+        if (p.reference_len > 0)
+            ENC_HIP(hipMemcpyAsync(b.d_ref.as<char>() + regrecs[(size_t)r].ref_off, p.reference, (size_t)p.reference_len, hipMemcpyHostToDevice, st));
+    }
+    if (!reads.empty()) ENC_HIP(hipMemcpyAsync(b.d_reads.p, reads.data(), reads.size() * sizeof(ReadRec), hipMemcpyHostToDevice, st));
+    if (n_regions) {
+        ENC_HIP(hipMemcpyAsync(b.d_regions.p, regrecs.data(), regrecs.size() * sizeof(RegRec), hipMemcpyHostToDevice, st));
+        ENC_HIP(hipMemcpyAsync(b.d_tile_region.p, tile_region.data(), tile_region.size() * 4, hipMemcpyHostToDevice, st));
+    }
+    ENC_HIP(hipStreamSynchronize(st));            // the tables above are locals
+    // records: a read enters a tile once per TP rows it spans, plus its first tile; reads with long deletions / skips span
+    // more rows than they have bases, so the kernels count what they could not store and the run is repeated with room
+    b.rec_cap = (int)std::min<int64_t>(0x7ffffff0, b.total_bases / TP + 2 * b.total_reads + 1024);
+    b.ovf_cap = (int)std::min<int64_t>(0x7ffffff0, std::max<int64_t>(1 << 16, b.total_bases / 64));
+    b.staged = true;
+    return PA_OK;
+}
+
+int run_staged(pa_encoder* e, int64_t* n_candidates) {
+    if (!e || !e->variant || !e->variant->staged) return pa::set_error(PA_ERR_INVALID, "no staged batch");
+    ENC_HIP(hipSetDevice(e->device));
+    pa_variant_batch& b = *e->variant;
+    hipStream_t st = e->stream;
+    const int n_regions = (int)b.regs.size();
+    b.n = 0;
+    b.region_n.assign((size_t)n_regions, 0);
+    b.positions.clear();
+    b.depths.clear();
+    b.freqs.clear();
+    b.names.clear();
+    for (double& m : b.ms) m = 0;
+    if (n_regions == 0) return PA_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const int vote_cap = (int)std::min<int64_t>(b.total_ops + 1, 0x7ffffff0);
+    const size_t n_zero = (size_t)CT_N + 2 * (size_t)n_regions + 2 * (size_t)b.n_tiles;
+    ENC_ALLOC(b.d_zero, n_zero * 4);
+    ENC_ALLOC(b.d_tile_off, ((size_t)b.n_tiles + 1) * 4);
+    ENC_ALLOC(b.d_mat, (size_t)b.total_rows * MATF * 4 + 64);
+    ENC_ALLOC(b.d_pass, (size_t)b.total_rows + 64);
+    ENC_ALLOC(b.d_sites, (size_t)b.total_rows * sizeof(SiteRec));
+    ENC_ALLOC(b.d_votes, (size_t)vote_cap * sizeof(Vote));
+    ENC_ALLOC(b.d_votes_out, (size_t)vote_cap * sizeof(Vote));
+    ENC_ALLOC(b.d_sites_dense, (size_t)b.total_rows * sizeof(SiteRec));
+    ENC_ALLOC(b.d_votes_dense, (size_t)vote_cap * sizeof(Vote));
+    if (!b.h_counts.ensure(((size_t)CT_N + 2 * (size_t)n_regions + 1) * 4)) return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed");
+    int* host_counters = b.h_counts.as<int>();                  // [CT_N] | per-region counts | records
+    const int* host_rc = host_counters + CT_N;
+    for (int attempt = 0;; ++attempt) {
+        ENC_ALLOC(b.d_sorted, (size_t)b.rec_cap * sizeof(TileRec));
+        ENC_ALLOC(b.d_ovf, (size_t)b.ovf_cap * sizeof(int4));
+        int* counters = b.d_zero.as<int>();
+        int* region_counts = counters + CT_N;
+        int* tile_count = region_counts + 2 * n_regions;
+        int* tile_fill = tile_count + b.n_tiles;
+        ENC_HIP(hipMemsetAsync(b.d_zero.p, 0, n_zero * 4, st));
+        ENC_HIP(hipEventRecord(e->ev[0], st));
+        const dim3 seg_grid((unsigned)((b.total_reads + 3) / 4));
+        if (b.total_reads > 0)
+            hipLaunchKernelGGL(segment_reads_kernel<false>, seg_grid, dim3(256), 0, st, b.d_reads.as<ReadRec>(), (int)b.total_reads,
+                               b.d_regions.as<RegRec>(), b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), tile_count,
+                               (const int*)nullptr, (int*)nullptr, (TileRec*)nullptr, 0);
+        hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, st, tile_count, b.n_tiles, b.d_tile_off.as<int>());
+        if (b.total_reads > 0)
+            hipLaunchKernelGGL(segment_reads_kernel<true>, seg_grid, dim3(256), 0, st, b.d_reads.as<ReadRec>(), (int)b.total_reads,
+                               b.d_regions.as<RegRec>(), b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), tile_count,
+                               b.d_tile_off.as<int>(), tile_fill, b.d_sorted.as<TileRec>(), b.rec_cap);
+        ENC_HIP(hipEventRecord(e->ev[1], st));
+        TileArgs ta;
+        ta.reads = b.d_reads.as<ReadRec>();
+        ta.regions = b.d_regions.as<RegRec>();
+        ta.tile_region = b.d_tile_region.as<int32_t>();
+        ta.cigar_op = b.d_cig_op.as<int32_t>();
+        ta.cigar_len = b.d_cig_len.as<int32_t>();
+        ta.seq = b.d_seq.as<char>();
+        ta.qual = b.d_qual.as<uint8_t>();
+        ta.ref = b.d_ref.as<char>();
+        ta.recs = b.d_sorted.as<TileRec>();
+        ta.tile_off = b.d_tile_off.as<int>();
+        ta.rec_cap = b.rec_cap;
+        ta.mat = b.d_mat.as<int>();
+        ta.pass = b.d_pass.as<uint8_t>();
+        ta.sites = b.d_sites.as<SiteRec>();
+        ta.votes = b.d_votes.as<Vote>();
+        ta.votes_out = b.d_votes_out.as<Vote>();
+        ta.vote_cap = vote_cap;
+        ta.ovf = b.d_ovf.as<int4>();
+        ta.ovf_cap = b.ovf_cap;
+        ta.counters = counters;
+        ta.region_counts = region_counts;
+        hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)b.n_tiles), dim3(NT), 0, st, ta);
+        ENC_HIP(hipEventRecord(e->ev[2], st));
+        hipLaunchKernelGGL(compact_votes_kernel, dim3((unsigned)std::min(2048, (vote_cap + 255) / 256)), dim3(256), 0, st, b.d_votes.as<Vote>(), counters,
+                           vote_cap, b.d_regions.as<RegRec>(), b.d_pass.as<uint8_t>(), region_counts, b.d_votes_out.as<Vote>());
+        hipLaunchKernelGGL(pack_results_kernel, dim3((unsigned)n_regions), dim3(256), 0, st, b.d_regions.as<RegRec>(), region_counts,
+                           b.d_sites.as<SiteRec>(), b.d_votes_out.as<Vote>(), b.d_sites_dense.as<SiteRec>(), b.d_votes_dense.as<Vote>());
+        ENC_HIP(hipEventRecord(e->ev[3], st));
+        ENC_HIP(hipGetLastError());
+        ENC_HIP(hipMemcpyAsync(host_counters, counters, ((size_t)CT_N + 2 * (size_t)n_regions) * 4, hipMemcpyDeviceToHost, st));
+        ENC_HIP(hipMemcpyAsync(host_counters + CT_N + 2 * n_regions, b.d_tile_off.as<int>() + b.n_tiles, sizeof(int), hipMemcpyDeviceToHost, st));
+        ENC_HIP(hipStreamSynchronize(st));
+        const int n_recs = host_counters[CT_N + 2 * n_regions];
+        if (n_recs > b.rec_cap || host_counters[CT_OVF] > b.ovf_cap) {
+            if (attempt >= 2) return pa::set_error(PA_ERR_HIP, "encoder record buffers could not be sized");
+            b.rec_cap = std::max(b.rec_cap, n_recs + 1024);
+            b.ovf_cap = std::max(b.ovf_cap, host_counters[CT_OVF] + 1024);
+            continue;
+        }
+        break;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); b.ms[0] = ms;       // records: count pass + offsets + fill pass
+    (void)hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); b.ms[1] = ms;       // tile_count_kernel
+    (void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); b.ms[2] = ms;       // compact_votes_kernel + pack_results_kernel
+    if (host_counters[CT_ERR] > 0) {
+        const int64_t g = host_counters[CT_ERR] - 1;
+        size_t r = 0;
+        while (r + 1 < b.regs.size() && b.regs[r + 1].read_base <= g) ++r;
+        return pa::set_error(PA_ERR_INVALID, "CIGAR of read " + std::to_string(g - b.regs[r].read_base) + (n_regions > 1 ? " of region " + std::to_string(r) : "") +
+                                                 " runs past its sequence");
+    }
+    if (host_counters[CT_VOTES] > vote_cap) return pa::set_error(PA_ERR_INVALID, "more indel votes than CIGAR operations (corrupt pileup)");
+    // region r's sites / votes are [s0[r], s0[r + 1]) / [v0[r], v0[r + 1]) of the dense lists
+    std::vector<size_t> s0((size_t)n_regions + 1, 0), v0((size_t)n_regions + 1, 0), o0((size_t)n_regions + 1, 0);
+    for (int r = 0; r < n_regions; ++r) {
+        s0[(size_t)r + 1] = s0[(size_t)r] + (size_t)host_rc[2 * r];
+        v0[(size_t)r + 1] = v0[(size_t)r] + (size_t)host_rc[2 * r + 1];
+    }
+    const size_t n_sites = s0[(size_t)n_regions], n_votes = v0[(size_t)n_regions];
+    const int n_ovf = host_counters[CT_OVF];
+    if (!b.h_sites.ensure(n_sites * sizeof(SiteRec) + 64) || !b.h_votes.ensure(n_votes * sizeof(Vote) + 64))
+        return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed");
+    SiteRec* sites = b.h_sites.as<SiteRec>();
+    Vote* votes = b.h_votes.as<Vote>();
+    std::vector<int4> ovf((size_t)n_ovf);
+    if (n_sites) ENC_HIP(hipMemcpyAsync(sites, b.d_sites_dense.p, n_sites * sizeof(SiteRec), hipMemcpyDeviceToHost, st));
+    if (n_votes) ENC_HIP(hipMemcpyAsync(votes, b.d_votes_dense.p, n_votes * sizeof(Vote), hipMemcpyDeviceToHost, st));
+    if (n_ovf) ENC_HIP(hipMemcpyAsync(ovf.data(), b.d_ovf.p, ovf.size() * sizeof(int4), hipMemcpyDeviceToHost, st));
+    ENC_HIP(hipStreamSynchronize(st));
+    const auto t_host = std::chrono::steady_clock::now();
+    if (n_ovf) {                                                 // rare alphabet: a handful per batch, grouped here
+        std::sort(ovf.begin(), ovf.end(), [](const int4& x, const int4& y) { return x.w < y.w; });
+        for (const int4& o : ovf) o0[(size_t)o.w + 1] += 1;
+    }
+    for (int r = 0; r < n_regions; ++r) o0[(size_t)r + 1] += o0[(size_t)r];
+    b.ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host).count();
+    std::vector<RegionOut> outs((size_t)n_regions);
+    const std::function<void(int)> work = [&](int r) {
+        std::sort(sites + s0[(size_t)r], sites + s0[(size_t)r + 1], [](const SiteRec& x, const SiteRec& y) { return x.idx < y.idx; });
+        std::sort(votes + v0[(size_t)r], votes + v0[(size_t)r + 1], [](const Vote& x, const Vote& y) { return x.idx < y.idx; });
+        enumerate_region(b.regs[(size_t)r], r, b.mid, sites + s0[(size_t)r], s0[(size_t)r + 1] - s0[(size_t)r], votes + v0[(size_t)r],
+                         v0[(size_t)r + 1] - v0[(size_t)r], ovf.data() + o0[(size_t)r], o0[(size_t)r + 1] - o0[(size_t)r], outs[(size_t)r]);
+    };
+    if (n_regions < 4) {
+        for (int r = 0; r < n_regions; ++r) work(r);
+    } else {
+        if (!b.pool) {
+            const char* env = getenv("PA_ENCODER_HOST_THREADS");
+            const int n = env ? atoi(env) : (int)std::thread::hardware_concurrency() / 4;
+            b.pool.reset(new RegionPool(std::max(1, std::min(n, 32)) - 1));
+        }
+        b.pool->run(n_regions, work);
+    }
+    b.ms[7] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host).count();   // ... + the regions' threads
+    std::vector<CandDesc> cands;
+    for (int r = 0; r < n_regions; ++r) {
+        const RegionOut& o = outs[(size_t)r];
+        b.region_n[(size_t)r] = (int64_t)o.cands.size();
+        cands.insert(cands.end(), o.cands.begin(), o.cands.end());
+        b.positions.insert(b.positions.end(), o.positions.begin(), o.positions.end());
+        b.depths.insert(b.depths.end(), o.depths.begin(), o.depths.end());
+        b.freqs.insert(b.freqs.end(), o.freqs.begin(), o.freqs.end());
+        b.names += o.names;
+    }
+    b.ms[4] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host).count();   // host enumeration
+    b.n = (int64_t)cands.size();
+    if (n_candidates)
+        for (int r = 0; r < n_regions; ++r) n_candidates[r] = b.region_n[(size_t)r];
+    if (b.n > 0) {
+        ENC_ALLOC(b.d_cands, cands.size() * sizeof(CandDesc));
+        ENC_ALLOC(b.d_img32, (size_t)b.n * b.W * b.F * sizeof(int));
+        ENC_ALLOC(b.d_img8, (size_t)b.n * b.W * b.F);
+        ENC_HIP(hipMemcpyAsync(b.d_cands.p, cands.data(), cands.size() * sizeof(CandDesc), hipMemcpyHostToDevice, st));
+        ENC_HIP(hipEventRecord(e->ev[4], st));
+        hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)b.n), dim3(64), 0, st, b.d_mat.as<int>(), b.d_regions.as<RegRec>(),
+                           b.d_cands.as<CandDesc>(), b.W, b.F, b.mid, b.d_img32.as<int>(), b.d_img8.as<int8_t>());
+        ENC_HIP(hipEventRecord(e->ev[5], st));
         ENC_HIP(hipGetLastError());
         ENC_HIP(hipStreamSynchronize(st));
+        (void)hipEventElapsedTime(&ms, e->ev[4], e->ev[5]); b.ms[3] = ms;   // gather_windows_kernel
     }
-    lap("window gather");
+    b.ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();  // whole run, host clock
     return PA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pa_encoder_create(int32_t device, void* hip_stream, pa_encoder** out) {
+    if (!out) return pa::set_error(PA_ERR_INVALID, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return pa::set_error(PA_ERR_NO_DEVICE, "no HIP device visible: the pepper_amd encoder has no CPU fallback");
+    if (device < 0 || device >= count) return pa::set_error(PA_ERR_INVALID, "device ordinal out of range");
+    ENC_HIP(hipSetDevice(device));
+    auto* e = new pa_encoder();
+    e->device = device;
+    if (hip_stream) e->stream = static_cast<hipStream_t>(hip_stream);
+    else {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete e;
+            return pa::set_error(PA_ERR_HIP, "hipStreamCreate failed");
+        }
+        e->own_stream = true;
+    }
+    for (hipEvent_t& ev : e->ev)
+        if (hipEventCreate(&ev) != hipSuccess) {
+            pa_encoder_destroy(e);
+            return pa::set_error(PA_ERR_HIP, "hipEventCreate failed");
+        }
+    *out = e;
+    return PA_OK;
+}
+
+void pa_encoder_destroy(pa_encoder* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (hipEvent_t ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    pa_variant_batch_free(e->variant);
+    pa_polish_batch_free(e->polish);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int pa_encoder_stage_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const pa_summary_params* params) {
+    return stage_batch(e, n_regions, pileups, params);
+}
+
+int pa_encoder_run_staged(pa_encoder* e, int64_t* n_candidates) { return run_staged(e, n_candidates); }
+
+int pa_encoder_generate_summary_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const pa_summary_params* params,
+                                      int64_t* n_candidates) {
+    const int rc = stage_batch(e, n_regions, pileups, params);
+    return rc != PA_OK ? rc : run_staged(e, n_candidates);
+}
+
+int pa_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, const pa_summary_params* q, int64_t* n_candidates) {
+    if (!e || !p || !q || !n_candidates) return pa::set_error(PA_ERR_INVALID, "null argument");
+    return pa_encoder_generate_summary_batch(e, 1, p, q, n_candidates);
 }
 
 int pa_encoder_get_results(pa_encoder* e, int64_t* positions, int32_t* depths, int32_t* candidate_frequency,
@@ -859,137 +1181,42 @@ int pa_encoder_get_results(pa_encoder* e, int64_t* positions, int32_t* depths, i
                            int64_t* candidates_needed) {
     if (!e) return pa::set_error(PA_ERR_INVALID, "null encoder");
     ENC_HIP(hipSetDevice(e->device));
-    const size_t n = (size_t)e->n;
-    if (positions) std::copy(e->positions.begin(), e->positions.end(), positions);
-    if (depths) std::copy(e->depths.begin(), e->depths.end(), depths);
-    if (candidate_frequency) std::copy(e->freqs.begin(), e->freqs.end(), candidate_frequency);
-    if (candidates_needed) *candidates_needed = (int64_t)e->names.size();
-    if (candidates && candidates_cap >= (int64_t)e->names.size()) std::memcpy(candidates, e->names.data(), e->names.size());
+    if (!e->variant) {
+        if (candidates_needed) *candidates_needed = 0;
+        return PA_OK;
+    }
+    const pa_variant_batch& b = *e->variant;
+    const size_t n = (size_t)b.n;
+    if (positions) std::copy(b.positions.begin(), b.positions.end(), positions);
+    if (depths) std::copy(b.depths.begin(), b.depths.end(), depths);
+    if (candidate_frequency) std::copy(b.freqs.begin(), b.freqs.end(), candidate_frequency);
+    if (candidates_needed) *candidates_needed = (int64_t)b.names.size();
+    if (candidates && candidates_cap >= (int64_t)b.names.size()) std::memcpy(candidates, b.names.data(), b.names.size());
     if (n > 0 && images_i32)
-        ENC_HIP(hipMemcpyAsync(images_i32, e->d_img32.p, n * e->W * e->F * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        ENC_HIP(hipMemcpyAsync(images_i32, b.d_img32.p, n * b.W * b.F * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     if (n > 0 && images_i8)
-        ENC_HIP(hipMemcpyAsync(images_i8, e->d_img8.p, n * e->W * e->F, hipMemcpyDeviceToHost, e->stream));
+        ENC_HIP(hipMemcpyAsync(images_i8, b.d_img8.p, n * b.W * b.F, hipMemcpyDeviceToHost, e->stream));
     ENC_HIP(hipStreamSynchronize(e->stream));
     return PA_OK;
 }
 
-int pa_polish_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, int64_t start_pos, int64_t end_pos,
-                                       int64_t* n_rows) {
-    if (!e || !p || !n_rows) return pa::set_error(PA_ERR_INVALID, "null argument");
-    if (p->region_end < p->region_start || p->region_end - p->region_start > (int64_t)1 << 28 || end_pos < start_pos)
-        return pa::set_error(PA_ERR_INVALID, "bad region");
-    ENC_HIP(hipSetDevice(e->device));
-    const int64_t start = p->region_start, end = p->region_end;
-    const int L = (int)(end - start + 1);
-    std::vector<PSeg> segs;
-    std::vector<int32_t> longest((size_t)L, 0);
-    struct InsOp { int32_t idx; int32_t len; int64_t seq0; bool rev; };
-    std::vector<InsOp> ins_ops;
-    const int64_t total_bases = p->n_reads > 0 ? p->seq_offset[p->n_reads] : 0;
-    for (int32_t r = 0; r < p->n_reads; ++r) {
-        if (p->read_mapq[r] <= 0) continue;
-        const bool rev = p->read_reverse[r] != 0;
-        const int64_t s0 = p->seq_offset[r], read_len = p->seq_offset[r + 1] - s0;
-        int64_t ri = 0, pos = p->read_pos[r];
-        for (int64_t c = p->cigar_offset[r]; c < p->cigar_offset[r + 1]; ++c) {
-            if (pos > end_pos) break;
-            const int op = p->cigar_op[c];
-            const int64_t len = p->cigar_len[c];
-            if (op == OP_M || op == OP_EQ || op == OP_X) {
-                const int64_t lo = std::max(pos, start), hi = std::min(pos + len - 1, end);
-                if (lo <= hi) {
-                    if (ri + (hi - pos) >= read_len)
-                        return pa::set_error(PA_ERR_INVALID, "CIGAR of read " + std::to_string(r) + " runs past its sequence");
-                    segs.push_back({s0 + ri + (lo - pos), (int32_t)(lo - start), (int32_t)(hi - lo + 1), rev ? PSEG_REV : 0u, -1});
-                }
-                ri += len;
-                pos += len;
-            } else if (op == OP_I) {
-                const int64_t anchor = pos - 1;
-                if (anchor >= start && anchor <= end) {
-                    if (ri + len > read_len)
-                        return pa::set_error(PA_ERR_INVALID, "insert of read " + std::to_string(r) + " runs past its sequence");
-                    const int32_t idx = (int32_t)(anchor - start);
-                    ins_ops.push_back({idx, (int32_t)len, s0 + ri, rev});
-                    longest[(size_t)idx] = std::max<int32_t>(longest[(size_t)idx], (int32_t)len);
-                }
-                ri += len;
-            } else if (op == OP_D || op == OP_N || op == OP_P) {
-                const int64_t lo = std::max(pos, start), hi = std::min(pos + len - 1, end);
-                if (lo <= hi)
-                    segs.push_back({0, (int32_t)(lo - start), (int32_t)(hi - lo + 1), (rev ? PSEG_REV : 0u) | PSEG_GAP,
-                                    (pos >= start && pos <= end) ? (int32_t)(pos - start) : -1});
-                pos += len;
-            } else if (op == OP_S) {
-                ri += len;
-            }
-        }
-    }
-    // insert-slot rows: prefix sum of the longest insert per anchor
-    std::vector<int32_t> ins_row0((size_t)L + 1, 0);
-    for (int i = 0; i < L; ++i) ins_row0[(size_t)i + 1] = ins_row0[(size_t)i] + longest[(size_t)i];
-    const int total_ins_rows = ins_row0[(size_t)L];
-    for (const InsOp& io : ins_ops)
-        segs.push_back({io.seq0, ins_row0[(size_t)io.idx], io.len, (io.rev ? PSEG_REV : 0u) | PSEG_INS, -1});
-    // output rows in the reference's order: position, then its insert slots
-    std::vector<PRow> rows;
-    e->p_positions.clear();
-    for (int64_t pos = start_pos; pos <= end_pos; ++pos) {
-        const bool in = pos >= start && pos <= end;
-        const int32_t idx = in ? (int32_t)(pos - start) : -1;
-        rows.push_back({idx, 0});
-        e->p_positions.push_back(pos);
-        e->p_positions.push_back(0);
-        const int32_t n_ins = in ? longest[(size_t)idx] : 0;
-        for (int32_t k = 1; k <= n_ins; ++k) {
-            rows.push_back({idx, k});
-            e->p_positions.push_back(pos);
-            e->p_positions.push_back(k);
-        }
-    }
-    e->p_rows = (int64_t)rows.size();
-    *n_rows = e->p_rows;
-
-    hipStream_t st = e->stream;
-    ENC_ALLOC(e->d_seq, (size_t)total_bases + 16);
-    ENC_ALLOC(e->d_segs, segs.size() * sizeof(PSeg) + 16);
-    ENC_ALLOC(e->d_pbase, (size_t)L * PROW * sizeof(int));
-    ENC_ALLOC(e->d_pins, (size_t)(total_ins_rows + 1) * PROW * sizeof(int));
-    ENC_ALLOC(e->d_prow0, (size_t)(L + 1) * sizeof(int));
-    ENC_ALLOC(e->d_prows, rows.size() * sizeof(PRow) + 16);
-    ENC_ALLOC(e->d_ppix, rows.size() * 10 + 16);
-    if (total_bases > 0) ENC_HIP(hipMemcpyAsync(e->d_seq.p, p->seq, (size_t)total_bases, hipMemcpyHostToDevice, st));
-    if (!segs.empty()) ENC_HIP(hipMemcpyAsync(e->d_segs.p, segs.data(), segs.size() * sizeof(PSeg), hipMemcpyHostToDevice, st));
-    ENC_HIP(hipMemcpyAsync(e->d_prow0.p, ins_row0.data(), (size_t)(L + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    ENC_HIP(hipMemcpyAsync(e->d_prows.p, rows.data(), rows.size() * sizeof(PRow), hipMemcpyHostToDevice, st));
-    ENC_HIP(hipMemsetAsync(e->d_pbase.p, 0, (size_t)L * PROW * sizeof(int), st));
-    ENC_HIP(hipMemsetAsync(e->d_pins.p, 0, (size_t)(total_ins_rows + 1) * PROW * sizeof(int), st));
-    if (!segs.empty())
-        hipLaunchKernelGGL(polish_count_kernel, dim3(((int)segs.size() + 255) / 256), dim3(256), 0, st,
-                           static_cast<const PSeg*>(e->d_segs.p), (int)segs.size(), static_cast<const char*>(e->d_seq.p),
-                           static_cast<int*>(e->d_pbase.p), static_cast<int*>(e->d_pins.p));
-    hipLaunchKernelGGL(polish_pixels_kernel, dim3(((int)rows.size() + 255) / 256), dim3(256), 0, st,
-                       static_cast<const PRow*>(e->d_prows.p), (int)rows.size(), static_cast<const int*>(e->d_pbase.p),
-                       static_cast<const int*>(e->d_pins.p), static_cast<const int*>(e->d_prow0.p),
-                       static_cast<uint8_t*>(e->d_ppix.p));
-    ENC_HIP(hipGetLastError());
-    ENC_HIP(hipStreamSynchronize(st));
-    return PA_OK;
-}
-
-int pa_polish_encoder_get_results(pa_encoder* e, uint8_t* image, int64_t* positions) {
-    if (!e) return pa::set_error(PA_ERR_INVALID, "null encoder");
-    ENC_HIP(hipSetDevice(e->device));
-    if (positions) std::copy(e->p_positions.begin(), e->p_positions.end(), positions);
-    if (image && e->p_rows > 0) {
-        ENC_HIP(hipMemcpyAsync(image, e->d_ppix.p, (size_t)e->p_rows * 10, hipMemcpyDeviceToHost, e->stream));
-        ENC_HIP(hipStreamSynchronize(e->stream));
-    }
-    return PA_OK;
-}
-
 const int8_t* pa_encoder_device_images(pa_encoder* e) {
-    return (e && e->n > 0) ? static_cast<const int8_t*>(e->d_img8.p) : nullptr;
+    return (e && e->variant && e->variant->n > 0) ? e->variant->d_img8.as<int8_t>() : nullptr;
+}
+
+int pa_encoder_last_timing(pa_encoder* e, double* ms, int32_t n) {
+    if (!e || !ms || n < 0) return pa::set_error(PA_ERR_INVALID, "null argument");
+    for (int i = 0; i < n; ++i) ms[i] = (e->variant && i < 8) ? e->variant->ms[i] : 0.0;
+    return PA_OK;
+}
+
+int pa_encoder_batch_stats(pa_encoder* e, int64_t* out, int32_t n) {
+    if (!e || !out || n < 0) return pa::set_error(PA_ERR_INVALID, "null argument");
+    const int64_t v[6] = {e->variant ? e->variant->total_bases : 0, e->variant ? e->variant->total_rows : 0,
+                          e->variant ? e->variant->total_reads : 0, e->variant ? e->variant->total_ops : 0,
+                          e->variant ? (int64_t)e->variant->n_tiles : 0, e->variant ? (int64_t)e->variant->regs.size() : 0};
+    for (int i = 0; i < n; ++i) out[i] = i < 6 ? v[i] : 0;
+    return PA_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,133 @@
+// Shared pieces of the two summary encoders (encoder.hip: variant, encoder_polish.hip: polish).
+//
+// Both walk CIGAR strings on the device the same way.  A wave takes 64 operations at a time, one per lane; a wave-wide
+// prefix sum of the reference / read advances gives every operation its first reference row and its first read index
+// (no serial walk); the sparse per-operation work (insert anchors, deletion anchors) is done one operation per lane, the
+// dense per-base work one REFERENCE ROW per lane: lane l takes row span_lo + l + 64 k and finds the operation that owns
+// it by a 6-step binary search over the 64 first-rows the wave has just written to its LDS scratch.  Consecutive lanes
+// therefore touch consecutive rows (conflict-free LDS atomics on a [counter][row] tile) and consecutive read bytes
+// (coalesced loads), whatever the lengths of the match runs -- a lane-per-operation walk idles on the longest run of the 64,
+// a wave-per-operation walk (round 2) used 10-20 lanes of 64 on nanopore CIGARs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pepper_amd.h"
+#include "../../include/pepper_amd_encoder.h"
+#include "kernels.h"
+
+namespace pa_enc {
+
+enum { OP_M = 0, OP_I = 1, OP_D = 2, OP_N = 3, OP_S = 4, OP_H = 5, OP_P = 6, OP_EQ = 7, OP_X = 8 };
+
+// inclusive prefix sum over the 64 lanes of a wave on the DPP network (row_shr 1/2/4/8 inside each row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3); lanes without a source add the `old` operand, 0
+__device__ __forceinline__ int wave_inclusive_sum(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+__device__ __forceinline__ int wave_total(int inclusive) { return __builtin_amdgcn_readlane(inclusive, 63); }
+__device__ __forceinline__ int wave_sum(int x) { return wave_total(wave_inclusive_sum(x)); }
+// minimum / maximum over the wave on the same network (identity in the lanes without a source), the same in every lane
+__device__ __forceinline__ int wave_min(int x) {
+    const int id = 0x7fffffff;
+    x = min(x, __builtin_amdgcn_update_dpp(id, x, 0x111, 0xf, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(id, x, 0x112, 0xf, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(id, x, 0x114, 0xf, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(id, x, 0x118, 0xf, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(id, x, 0x142, 0xa, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(id, x, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ int wave_max(int x) { return -wave_min(-x); }       // (callers keep |x| < 2^31 - 1)
+
+// reference / read advance of one operation as populate_summary_matrix steps (region_summary.cpp:357-563): N and P advance
+// the reference AND, through the missing break, the read (:556-561)
+__device__ __forceinline__ int variant_ref_advance(int op, int len) {
+    return (op == OP_M || op == OP_EQ || op == OP_X || op == OP_D || op == OP_N || op == OP_P) ? len : 0;
+}
+__device__ __forceinline__ int variant_read_advance(int op, int len) {
+    return (op == OP_M || op == OP_EQ || op == OP_X || op == OP_I || op == OP_S || op == OP_N || op == OP_P) ? len : 0;
+}
+// the polish walk (summary_generator.cpp:47-121): D, N and P are gaps that advance only the reference
+__device__ __forceinline__ int polish_ref_advance(int op, int len) {
+    return (op == OP_M || op == OP_EQ || op == OP_X || op == OP_D || op == OP_N || op == OP_P) ? len : 0;
+}
+__device__ __forceinline__ int polish_read_advance(int op, int len) {
+    return (op == OP_M || op == OP_EQ || op == OP_X || op == OP_I || op == OP_S) ? len : 0;
+}
+
+// last j in [0, 64) with first_row[j] <= row; first_row is non-decreasing (INT_MAX past the read's last operation) and
+// first_row[0] <= row
+__device__ __forceinline__ int owner_of_row(const int* first_row, int row) {
+    int j = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1)
+        if (first_row[j + step] <= row) j += step;
+    return j;
+}
+
+struct DBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    bool ensure(size_t need) {
+        if (need <= bytes) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        const size_t grow = need + need / 4 + 256;
+        if (hipMalloc(&p, grow) != hipSuccess) return false;
+        bytes = grow;
+        return true;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+    ~DBuf() { if (p) (void)hipFree(p); }
+};
+
+// one read of a batch: where its bases, qualities and operations start in the concatenated device arrays
+struct ReadRec {
+    int64_t s0;        // first base in seq / qual
+    int32_t c0;        // first operation in cigar_op / cigar_len
+    int32_t ncig;
+    int32_t slen;
+    int32_t row0;      // type_read.pos - region_start
+    int32_t region;
+    int32_t flags;     // 1 reverse strand, 2 mapping quality > 0
+};
+constexpr int READ_REV = 1, READ_MAPQ_OK = 2;
+
+}  // namespace pa_enc
+
+#define ENC_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return pa::set_error(PA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define ENC_ALLOC(buf, bytes_)                                                                          \
+    do {                                                                                                \
+        if (!(buf).ensure(bytes_)) return pa::set_error(PA_ERR_HIP, "hipMalloc failed in encoder workspace"); \
+    } while (0)
+
+struct pa_variant_batch;     // encoder.hip
+struct pa_polish_batch;      // encoder_polish.hip
+
+struct pa_encoder {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[8] = {};
+    pa_variant_batch* variant = nullptr;
+    pa_polish_batch* polish = nullptr;
+};
+
+// the two halves free their own state (defined next to the structs)
+void pa_variant_batch_free(pa_variant_batch*);
+void pa_polish_batch_free(pa_polish_batch*);

@@ -14,6 +14,7 @@ Checkpoint dict keys follow
   ({'model_state_dict', 'hidden_size', 'gru_layers', 'epochs', ...}).
 Synthetic summary distributions follow SURVEY.md section 8(d) (V-syn / P-syn).
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -256,3 +257,156 @@ def simulate_clipped_reads(rng, reference, region_start, n_reads, sub=0.04, ins=
         pos.append(region_start + a)
         seqs.append("".join(out) or "A")
     return pos, seqs
+
+
+# ---- E-syn: pileups for the summary encoder ------------------------------------------------------------------------
+ESYN_SEED = 20260928
+
+
+def encoder_region(seed=ESYN_SEED, region=100_000, flank=100, depth=60, read_len=8000, region_start=10_000,
+                   event_rate=0.02, sub_rate=0.04, snp_every=1000, indel_every=700):
+    """One nanopore-like pileup as the flat arrays of pa_pileup (include/pepper_amd_encoder.h), vectorised.
+
+    A `region` + 2 x `flank` + 1 reference window (AlignmentSummarizer.py:181-182 pads 100 each side) at ~`depth`x:
+    reads of N(read_len, read_len / 4) reference span starting anywhere from half a read before the window to its end
+    (clipped to it, as the BAM reader clips); random inserts / deletions of 1..5 bases at `event_rate` per position and
+    sub_rate substitutions (sequencing noise); qualities uniform 3..39; a heterozygous or homozygous SNP about every
+    `snp_every` positions (two haplotypes) and a systematic indel site about every `indel_every` positions where 35 % of
+    the covering reads carry the same insert or deletion (what homopolymers do to nanopore reads) -- so that SNP, insert
+    and delete candidates all occur.  -> (reference bytes, flat dict, region_start, region_end)."""
+    rng = np.random.default_rng(seed)
+    L = region + 2 * flank + 1
+    hap = rng.integers(0, 4, size=(2, L), dtype=np.uint8)
+    hap[1] = hap[0]
+    sites = np.flatnonzero(rng.random(L) < 1.0 / snp_every)
+    alt = (hap[0, sites] + rng.integers(1, 4, size=len(sites))) % 4
+    hom = rng.random(len(sites)) < 0.4
+    ref = hap[0].copy()
+    hap[0, sites] = np.where(hom, alt, hap[0, sites])          # haplotype 0 carries the homozygous ones,
+    hap[1, sites] = alt                                        # haplotype 1 all of them
+    n_reads = int(depth * L / read_len) + 8
+    start = rng.integers(-read_len // 2, L - 50, size=n_reads)
+    span_end = np.minimum(L, start + rng.normal(read_len, read_len / 4, size=n_reads).astype(np.int64))
+    s = np.maximum(0, start)
+    keep = span_end - s >= 100
+    s, e = s[keep], span_end[keep]
+    n_reads = len(s)
+    span = e - s
+    which = rng.integers(0, 2, size=n_reads)
+    # events as flat (read, reference position, insert?, length) lists: noise + the systematic sites, ordered per read
+    n_noise = rng.poisson(span * event_rate)
+    ev_read = np.repeat(np.arange(n_reads), n_noise)
+    ev_pos = s[ev_read] + 20 + (rng.random(len(ev_read)) * (span[ev_read] - 40)).astype(np.int64)
+    ev_ins = rng.random(len(ev_read)) < 0.5
+    ev_len = rng.integers(1, 6, size=len(ev_read))
+    isites = np.flatnonzero(rng.random(L) < 1.0 / indel_every)
+    site_ins = rng.random(len(isites)) < 0.5
+    site_len = rng.integers(1, 9, size=len(isites))
+    carried = (isites[None, :] >= s[:, None] + 20) & (isites[None, :] < e[:, None] - 40) & (rng.random((n_reads, len(isites))) < 0.35)
+    cr, cs = np.nonzero(carried)
+    ev_read = np.concatenate([ev_read, cr])
+    ev_pos = np.concatenate([ev_pos, isites[cs]])
+    ev_ins = np.concatenate([ev_ins, site_ins[cs]])
+    ev_len = np.concatenate([ev_len, site_len[cs]])
+    order = np.lexsort((ev_pos, ev_read))
+    ev_read, ev_pos, ev_ins, ev_len = ev_read[order], ev_pos[order], ev_ins[order], ev_len[order]
+    # an event needs 8 matched bases after the end of the one before it and 20 before the end of the read: drop the ones
+    # that do not, until the survivors all do (a dropped event can uncover a closer predecessor)
+    while True:
+        prev_end = np.concatenate([[0], ev_pos[:-1] + np.where(ev_ins[:-1], 0, ev_len[:-1])])
+        first = np.concatenate([[True], ev_read[1:] != ev_read[:-1]])
+        prev_end = np.where(first, s[ev_read], prev_end)
+        ok = (ev_pos - prev_end >= 8) & (ev_pos + np.where(ev_ins, 0, ev_len) <= e[ev_read] - 20)
+        if ok.all():
+            break
+        ev_read, ev_pos, ev_ins, ev_len = ev_read[ok], ev_pos[ok], ev_ins[ok], ev_len[ok]
+    gap = ev_pos - prev_end                                     # matched bases before the event
+    n_keep = np.bincount(ev_read, minlength=n_reads)
+    kk = np.arange(len(ev_read)) - np.repeat(np.cumsum(n_keep) - n_keep, n_keep)
+    ev_end = ev_pos + np.where(ev_ins, 0, ev_len)
+    last_end = s.copy()                                         # reads without events: one match run from s
+    np.maximum.at(last_end, ev_read, ev_end)
+    tail = e - last_end
+    # operations per read: (M gap, I/D len) x n_keep, then M tail
+    ops_per = 2 * n_keep + 1
+    coff = np.zeros(n_reads + 1, np.int64)
+    np.cumsum(ops_per, out=coff[1:])
+    total_ops = int(coff[-1])
+    cigar_op = np.zeros(total_ops + 1, np.int32)
+    cigar_len = np.zeros(total_ops + 1, np.int32)
+    at = coff[ev_read] + 2 * kk
+    cigar_len[at] = gap
+    cigar_op[at + 1] = np.where(ev_ins, 1, 2)
+    cigar_len[at + 1] = ev_len
+    cigar_len[coff[1:] - 1] = tail
+    # read segments = operations that consume read bases (M and I); each has a length and, for M, a reference start
+    seg_len = np.where(cigar_op[:total_ops] == 2, 0, cigar_len[:total_ops]).astype(np.int64)
+    seg_ref = np.zeros(total_ops, np.int64)
+    seg_ref[at] = prev_end
+    seg_ref[coff[1:] - 1] = last_end
+    op_read = np.repeat(np.arange(n_reads), ops_per)
+    seg_start = np.cumsum(seg_len) - seg_len
+    total = int(seg_len.sum())
+    is_ins_op = cigar_op[:total_ops] == 1
+    # every read base of a match run = haplotype[which][seg_ref + offset in the run]: one gather through a per-run offset
+    hap_flat = hap.reshape(-1)
+    seg_off = np.where(is_ins_op, 0, seg_ref + which[op_read] * L) - seg_start
+    src = np.repeat(seg_off, seg_len)
+    src += np.arange(total)
+    np.clip(src, 0, 2 * L - 1, out=src)                         # inserted bases: any in-range index, overwritten below
+    seq = hap_flat[src]
+    ins_ops = np.flatnonzero(is_ins_op)
+    ins_at = np.repeat(seg_start[ins_ops], seg_len[ins_ops]) + (np.arange(int(seg_len[ins_ops].sum())) -
+                                                                  np.repeat(np.cumsum(seg_len[ins_ops]) - seg_len[ins_ops], seg_len[ins_ops]))
+    seq[ins_at] = rng.integers(0, 4, size=len(ins_at), dtype=np.uint8)
+    # carriers of one systematic insert site share its bases: seeded by the site position
+    site_of_op = np.full(total_ops, -1, np.int64)
+    sys_ev = np.isin(ev_pos, isites) & ev_ins
+    site_of_op[at[sys_ev] + 1] = ev_pos[sys_ev]
+    sys_ops = np.flatnonzero(site_of_op >= 0)
+    if len(sys_ops):
+        sys_at = np.repeat(seg_start[sys_ops], seg_len[sys_ops]) + (np.arange(int(seg_len[sys_ops].sum())) -
+                                                                      np.repeat(np.cumsum(seg_len[sys_ops]) - seg_len[sys_ops], seg_len[sys_ops]))
+        k_in = np.arange(len(sys_at)) - np.repeat(np.cumsum(seg_len[sys_ops]) - seg_len[sys_ops], seg_len[sys_ops])
+        seq[sys_at] = ((np.repeat(site_of_op[sys_ops], seg_len[sys_ops]) * 7 + k_in * 3) % 4).astype(np.uint8)
+    sub_at = np.cumsum(rng.geometric(sub_rate, size=int(total * sub_rate * 1.2) + 64)) - 1
+    sub_at = sub_at[sub_at < total]
+    seq[sub_at] = (seq[sub_at] + rng.integers(1, 4, size=len(sub_at), dtype=np.uint8)) % 4
+    alphabet = np.frombuffer(b"ACGT", np.uint8)
+    read_bases = np.zeros(n_reads + 1, np.int64)
+    np.cumsum(np.bincount(op_read, weights=seg_len, minlength=n_reads).astype(np.int64), out=read_bases[1:])
+    flat = dict(read_pos=(region_start + s).astype(np.int64), read_reverse=(rng.random(n_reads) < 0.5).astype(np.uint8),
+                read_mapq=np.full(n_reads, 60, np.int32), seq_offset=read_bases,
+                seq=np.concatenate([alphabet[seq], np.zeros(1, np.uint8)]),
+                qual=np.concatenate([rng.integers(3, 40, size=total, dtype=np.uint8), np.zeros(1, np.uint8)]),
+                cigar_offset=coff, cigar_op=cigar_op, cigar_len=cigar_len, n_reads=int(n_reads))
+    return alphabet[ref].tobytes(), flat, region_start, region_start + L - 1
+
+
+def encoder_regions(n, seed=ESYN_SEED, workers=0, **kw):
+    """n regions (seeds seed, seed + 1, ...), generated on `workers` processes (0: one per 4 regions, at most 16)."""
+    if workers <= 0:
+        workers = max(1, min(16, n // 4, os.cpu_count() or 1))
+    if workers == 1 or n == 1:
+        return [encoder_region(seed + k, **kw) for k in range(n)]
+    # spawned workers (numpy only); the parent's __main__ is hidden while they start so that none of them re-imports a
+    # main module that pulls in torch (the trick of pepper_amd.hostpipe._start_all)
+    import sys
+    from multiprocessing import get_context
+    main = sys.modules.get("__main__")
+    saved_spec, saved_file = getattr(main, "__spec__", None), getattr(main, "__file__", None)
+    had_file = main is not None and hasattr(main, "__file__")
+    try:
+        if main is not None:
+            main.__spec__ = None
+            if had_file:
+                del main.__file__
+        pool = get_context("spawn").Pool(workers)
+    finally:
+        if main is not None:
+            main.__spec__ = saved_spec
+            if had_file:
+                main.__file__ = saved_file
+    with pool:
+        futs = [pool.apply_async(encoder_region, (seed + k,), kw) for k in range(n)]
+        return [f.get() for f in futs]

@@ -152,39 +152,12 @@ class RegionalSummaryGenerator(object):
                                 candidate_support_threshold, skip_indels, candidate_region_start,
                                 candidate_region_end, candidate_window_size, feature_size, train_mode=False,
                                 want_int32=False):
-        if train_mode:
-            raise NotImplementedError("train_mode label generation (truth VCF haplotypes) is outside the inference path")
-        flat = reads if isinstance(reads, dict) else flatten_reads(reads)
-        lib, enc = _encoder(self.device)
-        ref = self.reference_sequence.encode("latin-1") if isinstance(self.reference_sequence, str) else bytes(self.reference_sequence)
-        p = _Pileup(self.ref_start, self.ref_end, ref, len(ref), flat["n_reads"],
-                    flat["read_pos"].ctypes.data, flat["read_reverse"].ctypes.data, flat["read_mapq"].ctypes.data,
-                    flat["seq_offset"].ctypes.data, flat["seq"].ctypes.data, flat["qual"].ctypes.data,
-                    flat["cigar_offset"].ctypes.data, flat["cigar_op"].ctypes.data, flat["cigar_len"].ctypes.data)
-        q = _Params(min_snp_baseq, min_indel_baseq, snp_freq_threshold, insert_freq_threshold,
-                    delete_freq_threshold, min_coverage_threshold, snp_candidate_freq_threshold,
-                    indel_candidate_freq_threshold, candidate_support_threshold, 1 if skip_indels else 0,
-                    int(candidate_region_start), int(candidate_region_end), int(candidate_window_size),
-                    int(feature_size))
-        n = ctypes.c_int64()
-        _lib.check(lib.pa_encoder_generate_summary(enc, ctypes.cast(ctypes.pointer(p), ctypes.c_void_p),
-                                                   ctypes.cast(ctypes.pointer(q), ctypes.c_void_p), ctypes.byref(n)))
-        n = n.value
-        W, F = candidate_window_size + 1, feature_size
-        positions = np.zeros(n, np.int64)
-        depths = np.zeros(n, np.int32)
-        freqs = np.zeros(n, np.int32)
-        img8 = np.zeros((n, W, F), np.int8)
-        img32 = np.zeros((n, W, F), np.int32) if want_int32 else None
-        needed = ctypes.c_int64()
-        _lib.check(lib.pa_encoder_get_results(enc, None, None, None, None, None, None, 0, ctypes.byref(needed)))
-        names = ctypes.create_string_buffer(max(1, needed.value))
-        _lib.check(lib.pa_encoder_get_results(enc, positions.ctypes.data, depths.ctypes.data, freqs.ctypes.data,
-                                              img32.ctypes.data if want_int32 else None, img8.ctypes.data,
-                                              ctypes.cast(names, ctypes.c_void_p), needed.value, ctypes.byref(needed)))
-        cands = [s.decode("latin-1") for s in names.raw[:needed.value].split(b"\0")[:n]]
-        return dict(positions=positions, depths=depths, candidate_frequency=freqs, images=img8, images_int32=img32,
-                    candidates=cands)
+        return generate_summary_arrays_batch([self], [reads], min_snp_baseq, min_indel_baseq, snp_freq_threshold,
+                                             insert_freq_threshold, delete_freq_threshold, min_coverage_threshold,
+                                             snp_candidate_freq_threshold, indel_candidate_freq_threshold,
+                                             candidate_support_threshold, skip_indels,
+                                             [(candidate_region_start, candidate_region_end)], candidate_window_size,
+                                             feature_size, train_mode, want_int32)[0]
 
     def generate_summary(self, reads, *args):
         """-> list[CandidateImageSummary], as the pybind method (region_summary.h:191-206)."""
@@ -195,3 +168,97 @@ class RegionalSummaryGenerator(object):
                                              [out["candidates"][i]], [int(out["candidate_frequency"][i])],
                                              out["images_int32"][i].tolist(), 0, 0))
         return res
+
+
+def _pileup_struct(gen, flat, keep):
+    ref = gen.reference_sequence.encode("latin-1") if isinstance(gen.reference_sequence, str) else bytes(gen.reference_sequence)
+    keep.append(ref)
+    return _Pileup(gen.ref_start, gen.ref_end, ref, len(ref), flat["n_reads"],
+                   flat["read_pos"].ctypes.data, flat["read_reverse"].ctypes.data, flat["read_mapq"].ctypes.data,
+                   flat["seq_offset"].ctypes.data, flat["seq"].ctypes.data, flat["qual"].ctypes.data,
+                   flat["cigar_offset"].ctypes.data, flat["cigar_op"].ctypes.data, flat["cigar_len"].ctypes.data)
+
+
+class StagedBatch(object):
+    """A batch of regions uploaded once (pa_encoder_stage_batch) and encoded any number of times
+    (pa_encoder_run_staged): what bench.py times with the inputs resident in HBM."""
+
+    def __init__(self, generators, reads_list, params, candidate_regions, candidate_window_size=32, feature_size=26):
+        device = generators[0].device if generators else 0
+        self.lib, self.enc = _encoder(device)
+        self.n_regions = len(generators)
+        self.window, self.features = candidate_window_size + 1, feature_size
+        self._keep = []
+        self.flats = [r if isinstance(r, dict) else flatten_reads(r) for r in reads_list]
+        self.piles = (_Pileup * max(1, self.n_regions))(*[_pileup_struct(g, f, self._keep) for g, f in zip(generators, self.flats)])
+        (min_snp_baseq, min_indel_baseq, snp_freq_threshold, insert_freq_threshold, delete_freq_threshold,
+         min_coverage_threshold, snp_candidate_freq_threshold, indel_candidate_freq_threshold,
+         candidate_support_threshold, skip_indels) = params
+        self.params = (_Params * max(1, self.n_regions))(*[
+            _Params(min_snp_baseq, min_indel_baseq, snp_freq_threshold, insert_freq_threshold, delete_freq_threshold,
+                    min_coverage_threshold, snp_candidate_freq_threshold, indel_candidate_freq_threshold,
+                    candidate_support_threshold, 1 if skip_indels else 0, int(lo), int(hi), int(candidate_window_size),
+                    int(feature_size)) for lo, hi in candidate_regions])
+        _lib.check(self.lib.pa_encoder_stage_batch(self.enc, self.n_regions, ctypes.cast(self.piles, ctypes.c_void_p),
+                                                   ctypes.cast(self.params, ctypes.c_void_p)))
+        self.counts = np.zeros(max(1, self.n_regions), np.int64)
+
+    def run(self):
+        """-> candidates per region"""
+        _lib.check(self.lib.pa_encoder_run_staged(self.enc, self.counts.ctypes.data))
+        return self.counts[:self.n_regions]
+
+    def timing(self):
+        ms = np.zeros(8, np.float64)
+        _lib.check(self.lib.pa_encoder_last_timing(self.enc, ms.ctypes.data, 8))
+        return dict(records_ms=ms[0], tile_count_ms=ms[1], compact_votes_ms=ms[2], gather_windows_ms=ms[3],
+                    host_enumeration_ms=ms[4], run_ms=ms[5], host_bucket_ms=ms[6], host_bucket_and_threads_ms=ms[7])
+
+    def stats(self):
+        v = np.zeros(6, np.int64)
+        _lib.check(self.lib.pa_encoder_batch_stats(self.enc, v.ctypes.data, 6))
+        return dict(bases=int(v[0]), rows=int(v[1]), reads=int(v[2]), cigar_ops=int(v[3]), tiles=int(v[4]), regions=int(v[5]))
+
+    def results(self, want_int32=False):
+        """-> one dict per region (the arrays of generate_summary_arrays)"""
+        n = int(self.counts[:self.n_regions].sum())
+        W, F = self.window, self.features
+        positions = np.zeros(n, np.int64)
+        depths = np.zeros(n, np.int32)
+        freqs = np.zeros(n, np.int32)
+        img8 = np.zeros((n, W, F), np.int8)
+        img32 = np.zeros((n, W, F), np.int32) if want_int32 else None
+        needed = ctypes.c_int64()
+        lib, enc = self.lib, self.enc
+        _lib.check(lib.pa_encoder_get_results(enc, None, None, None, None, None, None, 0, ctypes.byref(needed)))
+        names = ctypes.create_string_buffer(max(1, needed.value))
+        _lib.check(lib.pa_encoder_get_results(enc, positions.ctypes.data, depths.ctypes.data, freqs.ctypes.data,
+                                              img32.ctypes.data if want_int32 else None, img8.ctypes.data,
+                                              ctypes.cast(names, ctypes.c_void_p), needed.value, ctypes.byref(needed)))
+        cands = [s.decode("latin-1") for s in names.raw[:needed.value].split(b"\0")[:n]]
+        out, at = [], 0
+        for k in self.counts[:self.n_regions]:
+            k = int(k)
+            out.append(dict(positions=positions[at:at + k], depths=depths[at:at + k], candidate_frequency=freqs[at:at + k],
+                            images=img8[at:at + k], images_int32=img32[at:at + k] if want_int32 else None,
+                            candidates=cands[at:at + k]))
+            at += k
+        return out
+
+
+def generate_summary_arrays_batch(generators, reads_list, min_snp_baseq, min_indel_baseq, snp_freq_threshold,
+                                  insert_freq_threshold, delete_freq_threshold, min_coverage_threshold,
+                                  snp_candidate_freq_threshold, indel_candidate_freq_threshold,
+                                  candidate_support_threshold, skip_indels, candidate_regions, candidate_window_size,
+                                  feature_size, train_mode=False, want_int32=False):
+    """Many regions through one set of launches (pa_encoder_generate_summary_batch): generators[i] with reads_list[i]
+    (type_read-like objects or the flat arrays of flatten_reads) and candidate_regions[i] = (start, end); the other
+    arguments are those of RegionalSummaryGenerator.generate_summary.  -> one dict of arrays per region."""
+    if train_mode:
+        raise NotImplementedError("train_mode label generation (truth VCF haplotypes) is outside the inference path")
+    batch = StagedBatch(generators, reads_list,
+                        (min_snp_baseq, min_indel_baseq, snp_freq_threshold, insert_freq_threshold, delete_freq_threshold,
+                         min_coverage_threshold, snp_candidate_freq_threshold, indel_candidate_freq_threshold,
+                         candidate_support_threshold, skip_indels), candidate_regions, candidate_window_size, feature_size)
+    batch.run()
+    return batch.results(want_int32)

@@ -59,25 +59,137 @@ def test_encoder_matches_oracle_and_reference(name):
         _check(got, pu.run_variant(ref, pile, params, reference_impl=True))
 
 
-@pytest.mark.parametrize("name", ["plain", "ref_skip_pad_fallthrough", "long_indels_61_cap", "low_quality_heavy", "deep_over_125"])
-def test_host_cigar_pass_equals_device_walk(name):
-    """Round 1's split (PA_ENCODER_HOST_CIGAR=1: host pass over CIGAR operations + segment / event kernels) and the
-    device walk (cigar_walk_kernel, the default) are two implementations of the same integer arithmetic: identical
-    candidates, images, depths."""
-    pile, params = _case(**CASES[name])
-    saved = os.environ.get("PA_ENCODER_HOST_CIGAR")
-    try:
-        os.environ.pop("PA_ENCODER_HOST_CIGAR", None)
-        dev = _product(pile, params)
-        os.environ["PA_ENCODER_HOST_CIGAR"] = "1"
-        host = _product(pile, params)
-    finally:
-        if saved is None:
-            os.environ.pop("PA_ENCODER_HOST_CIGAR", None)
-        else:
-            os.environ["PA_ENCODER_HOST_CIGAR"] = saved
-    assert len(dev["candidates"]) > 0
-    _check(dev, dict(host, images=host["images_int32"]))
+def _both(pile, params):
+    oracle, ref = pu.load_restatement(), pu.load_reference_encoder()
+    want = pu.run_variant(oracle, pile, params)
+    if ref is not None:
+        other = pu.run_variant(ref, pile, params, reference_impl=True)
+        assert other["candidates"] == want["candidates"] and np.array_equal(other["images"], want["images"])
+    return want
+
+
+def _gen_and_flat(pile):
+    from pepper_amd.variant.PEPPER_VARIANT import RegionalSummaryGenerator
+    gen = RegionalSummaryGenerator("chr20", pile.region_start, pile.region_end, pile.reference.decode())
+    flat = dict(read_pos=pile.read_pos, read_reverse=pile.read_reverse, read_mapq=pile.read_mapq,
+                seq_offset=pile.seq_offset, seq=pile.seq, qual=pile.qual, cigar_offset=pile.cigar_offset,
+                cigar_op=pile.cigar_op, cigar_len=pile.cigar_len, n_reads=pile.n_reads)
+    return gen, flat
+
+
+def _tile_edge_case(seed, rows, **kw):
+    """A region of exactly `rows` positions with SNPs, inserts and deletions planted on the rows either side of every
+    256 rows (the tile is 512 rows: every other one is a tile boundary) (the anchor of an indel belongs to the tile before the operation's first row)."""
+    rng = np.random.default_rng(seed)
+    off = 40_000
+    ref = pu.random_reference(rng, rows)
+    snps, indels = {}, {}
+    for row in range(20, min(rows, 250) - 10, 60):
+        snps[off + row] = (rng.choice([c for c in "ACGT" if c != ref[row]]), 0.7)
+    for b in range(256, rows - 70, 256):
+        for row, what in ((b - 1, "I"), (b, "D"), (b - 2, "D"), (b + 1, "I")):
+            indels[off + row] = ("I", "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 9)))), 0.8) if what == "I" \
+                else ("D", int(rng.integers(1, 30)), 0.8)
+        for row in (b - 3, b + 2):
+            rb = ref[row]
+            snps[off + row] = (rng.choice([c for c in "ACGT" if c != rb]), 0.7)
+    reads = pu.simulate_reads(rng, ref, off, n_reads=int(45 * rows / 900), read_len=(300, 1500), snp_sites=snps,
+                              indel_sites=indels, **kw)
+    return pu.FlatPileup(off, off + rows - 1, ref, reads), pu.make_params(off, off + rows - 1)
+
+
+@pytest.mark.parametrize("rows", [1023, 1024, 1025, 511, 512, 513, 256, 255, 700])
+def test_tile_boundaries(rows):
+    """Region lengths around a multiple of the 512-row tile (at L % 512 == 0 the all-zero row L has a tile of its own)
+    and indels / SNPs on the boundary rows."""
+    pile, params = _tile_edge_case(100 + rows, rows)
+    want = _both(pile, params)
+    assert len(want["candidates"]) > 0
+    _check(_product(pile, params), want)
+
+
+def _inner_region_case(seed, **kw):
+    """Reads simulated over 9 kb, the generator built on an inner 6 kb of it: reads start before the region, end after
+    it, cross it entirely; inserts and deletions up to 600 long (deletions spanning three tiles, inserts summed by the
+    whole wave), reads of several kb (tens of tile records each)."""
+    rng = np.random.default_rng(seed)
+    off, total, lo, hi = 70_000, 9000, 1500, 7500
+    ref = pu.random_reference(rng, total)
+    snps = {}
+    for p in rng.choice(np.arange(off + lo + 30, off + hi - 30), size=25, replace=False):
+        rb = ref[p - off]
+        snps[int(p)] = (rng.choice([c for c in "ACGT" if c != rb]), float(rng.choice([0.2, 0.6, 1.0])))
+    reads = pu.simulate_reads(rng, ref, off, n_reads=140, read_len=(1500, 7000), snp_sites=snps, **kw)
+    pile = pu.FlatPileup(off + lo, off + hi, ref[lo:hi + 1], reads)
+    return pile, pu.make_params(off + lo + 100, off + hi - 100)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(max_indel=600, ins_rate=0.004, del_rate=0.004), dict(skip_rate=0.003, eqx=True),
+                                dict(long_indel_rate=0.3, low_q_rate=0.4)])
+def test_reads_reaching_over_the_region_edges(kw):
+    pile, params = _inner_region_case(7 + len(kw), **kw)
+    assert (pile.read_pos < pile.region_start).any() and (pile.read_pos > pile.region_start + 256).any()
+    want = _both(pile, params)
+    assert len(want["candidates"]) > 0
+    _check(_product(pile, params), want)
+
+
+def test_batch_of_regions_equals_region_by_region():
+    """Many regions per launch (pa_encoder_generate_summary_batch): regions of different lengths, depths and candidate
+    ranges -- an empty pileup and a region shorter than a tile among them -- give, region by region, what the oracle
+    gives for each alone; and a second batch on the same handle does not see the first."""
+    from pepper_amd.variant.PEPPER_VARIANT import generate_summary_arrays_batch
+    cases = [_case(**CASES["plain"]), _tile_edge_case(3, 1024), _case(**CASES["deep_over_125"]), _inner_region_case(5),
+             _case(**CASES["ref_skip_pad_fallthrough"]), _tile_edge_case(4, 90), _case(**CASES["indel_heavy"])]
+    rng = np.random.default_rng(9)
+    ref = pu.random_reference(rng, 801)
+    cases.insert(3, (pu.FlatPileup(5000, 5800, ref, []), pu.make_params(5000, 5800)))
+    p0 = cases[0][1]
+    for order in (list(range(len(cases))), [6, 2, 0]):
+        gens, flats = zip(*[_gen_and_flat(cases[k][0]) for k in order])
+        got = generate_summary_arrays_batch(
+            list(gens), list(flats), p0.min_snp_baseq, p0.min_indel_baseq, p0.snp_freq_threshold, p0.insert_freq_threshold,
+            p0.delete_freq_threshold, p0.min_coverage_threshold, p0.snp_candidate_freq_threshold,
+            p0.indel_candidate_freq_threshold, p0.candidate_support_threshold, bool(p0.skip_indels),
+            [(cases[k][1].candidate_region_start, cases[k][1].candidate_region_end) for k in order], 32, 26, False, want_int32=True)
+        assert len(got) == len(order)
+        for k, g in zip(order, got):
+            want = pu.run_variant(pu.load_restatement(), *cases[k])
+            assert len(want["candidates"]) > 0 or cases[k][0].n_reads < 10
+            _check(g, want)
+
+
+def test_more_tile_records_than_the_first_guess():
+    """Reads of few bases that span many tiles (long deletions): the record buffer is sized from the base count, the
+    kernels count what did not fit and the run is repeated with room -- same result as the oracle."""
+    rng = np.random.default_rng(77)
+    off, rows = 5000, 20000
+    ref = pu.random_reference(rng, rows)
+    reads = []
+    for k in range(60):
+        cigar, seq = [], []
+        pos = int(rng.integers(0, 2000))
+        at = pos
+        while at < rows - 1200:
+            n = int(rng.integers(6, 14))
+            b = list(ref[at:at + n])
+            if rng.random() < 0.5:
+                b[n // 2] = "ACGT"[("ACGT".index(b[n // 2]) + 1) % 4]
+            seq.extend(b)
+            cigar.append((pu.OP_M, n))
+            d = int(rng.integers(500, 1100))
+            cigar.append((pu.OP_D, d))
+            at += n + d
+        seq.extend(ref[at:at + 8])
+        cigar.append((pu.OP_M, 8))
+        reads.append(dict(pos=off + pos, reverse=bool(k % 2), mapq=30, seq="".join(seq),
+                          qual=np.full(len(seq), 20, np.uint8), cigar=cigar))
+    reads.sort(key=lambda r: r["pos"])
+    pile = pu.FlatPileup(off, off + rows - 1, ref, reads)
+    params = pu.make_params(off, off + rows - 1, min_coverage_threshold=1)
+    assert pile.seq_offset[-1] // 256 + 2 * len(reads) + 1024 < sum(len(r["cigar"]) // 2 for r in reads) * 3
+    want = _both(pile, params)
+    _check(_product(pile, params), want)
 
 
 def test_cigar_past_the_sequence_is_an_error():

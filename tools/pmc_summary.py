@@ -42,6 +42,10 @@ LABELS = [
     ("polish_count_kernel", "polish_count"),
     ("polish_pixels_kernel", "polish_pixels"),
     ("cigar_walk_kernel", "cigar_walk"),
+    ("tile_count_kernel", "tile_count"),
+    ("segment_reads_kernel", "segment_reads"),
+    ("tile_offsets_kernel", "tile_offsets"),
+    ("bin_records_kernel", "bin_records"),
     ("compact_votes_kernel", "compact_votes"),
 ]
 
