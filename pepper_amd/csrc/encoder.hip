@@ -75,7 +75,10 @@ struct RegRec {                      // one region of the batch, as the kernels 
 };
 struct TileRec { int32_t read, op, row, ri; };   // walk of `read` enters the tile at operation `op`, whose first row / read index are given
 struct SiteRec { int32_t region, idx, cov, flags, fwd[4], rev[4]; };
-struct Vote { uint32_t idx, meta; int64_t off; };          // meta = type (1 insert, 2 delete) | reverse << 2 | from_ref << 3 | len << 4 | region << 10
+// meta = type (1 insert, 2 delete) | reverse << 2 | from_ref << 3 | len << 4 | region << 10; prefix = the first 8 bytes of the allele,
+// first byte in the top bits (compares like the string), filled for the votes of passing rows: the host orders alleles without touching
+// the reads unless two of them agree on 8 bytes
+struct Vote { uint32_t idx, meta; int64_t off; uint64_t prefix; };
 struct CandDesc {
     int32_t idx, type;        // row of the candidate site; 1 SNP, 2 insert, 3 delete
     int32_t vcol, vval;       // columns 1/2/3 <- alt base code / allele length
@@ -198,6 +201,12 @@ struct TileArgs {
     int* region_counts;
 };
 
+__device__ __forceinline__ uint64_t allele_prefix(const char* bytes, uint32_t off, uint32_t len) {
+    uint64_t p = 0;
+    for (uint32_t k = 0; k < 8; ++k) p = (p << 8) | (k < len ? (uint64_t)(unsigned char)bytes[(size_t)off + k] : 0);
+    return p;
+}
+
 // Append v to the global list `out` (counter `count`) from the lanes where `has`: one global atomic per wave.
 __device__ __forceinline__ void wave_append_vote(bool has, const Vote& v, Vote* out, int* count, int cap, int lane) {
     const unsigned long long m = __ballot(has);
@@ -310,7 +319,8 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
                 for (int u = 0; u < UNR; ++u) {
                     const int p = span_lo + lane + 64 * u;
                     const bool act = p <= span_hi;
-                    const int pc = act ? p : span_lo;
+                    // a lane past the span keeps a row of its own (its five adds are zeros): equal addresses would serialise in the LDS
+                    const int pc = act ? p : tile_lo + ((lane + 64 * u) & (TP - 1));
                     const int j = owner_of_row(first_s, pc);
                     const int opj = op_s[j], oj = opj & 15;
                     const int rp = ri_s[j] + (pc - first_s[j]);
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
                     const bool spill = vote && slot >= VCAP;
                     if (vote && !spill) vbuf[slot] = make_uint2(voff, vmeta);
                     if (__ballot(spill))
-                        wave_append_vote(spill, Vote{(uint32_t)(tile_lo + (int)(vmeta >> 10)), (vmeta & 1023u) | ((uint32_t)region << 10), (int64_t)voff},
+                        wave_append_vote(spill, Vote{(uint32_t)(tile_lo + (int)(vmeta >> 10)), (vmeta & 1023u) | ((uint32_t)region << 10), (int64_t)voff, 0},
                                          a.votes, &a.counters[CT_VOTES], a.vote_cap, lane);
                 }
             }
@@ -501,14 +511,15 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
     int* dst = a.mat + (reg.row_base + tile_lo) * (int64_t)MATF;          // 128-byte aligned: row_base % 16 == 0, tile_lo % 512 == 0
     for (int i = tid; i < n_out / 4; i += NT) reinterpret_cast<int4*>(dst)[i] = reinterpret_cast<const int4*>(cnt)[i];
     for (int i = (n_out & ~3) + tid; i < n_out; i += NT) dst[i] = cnt[i];
-    // the votes of the rows that passed (a few per cent) go to the host's list
+    // the votes of the rows that passed (a few per cent) go to the host's list, each with the first bytes of its allele
     const int nv = vcount < VCAP ? vcount : VCAP;
     for (int i0 = 0; i0 < nv; i0 += NT) {
         const int i = i0 + tid;
         const uint2 pv = i < nv ? vbuf[i] : make_uint2(0, 0);
         const bool has = i < nv && pass_s[pv.y >> 10];
-        wave_append_vote(has, Vote{(uint32_t)(tile_lo + (int)(pv.y >> 10)), (pv.y & 1023u) | ((uint32_t)region << 10), (int64_t)pv.x},
-                         a.votes_out + reg.vote_base, &a.region_counts[2 * region + 1], 0x7fffffff, lane);
+        Vote v{(uint32_t)(tile_lo + (int)(pv.y >> 10)), (pv.y & 1023u) | ((uint32_t)region << 10), (int64_t)pv.x, 0};
+        if (has) v.prefix = allele_prefix((pv.y & 8u) ? a.ref + reg.ref_off : a.seq + reg.seq_base, pv.x, (pv.y >> 4) & 63u);
+        wave_append_vote(has, v, a.votes_out + reg.vote_base, &a.region_counts[2 * region + 1], 0x7fffffff, lane);
     }
 }
 
@@ -516,12 +527,16 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
 // (the number of votes is only known on the device: a fixed grid strides over counters[CT_VOTES] of them)
 __global__ __launch_bounds__(256) void compact_votes_kernel(const Vote* __restrict__ votes, const int* __restrict__ counters, int cap,
                                                             const RegRec* __restrict__ regions, const uint8_t* __restrict__ pass,
+                                                            const char* __restrict__ seq, const char* __restrict__ ref,
                                                             int* __restrict__ region_counts, Vote* __restrict__ out) {
     const int n = counters[CT_VOTES] < cap ? counters[CT_VOTES] : cap;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const Vote v = votes[i];
+        Vote v = votes[i];
         const int r = (int)(v.meta >> 10);
-        if (pass[regions[r].row_base + v.idx]) out[regions[r].vote_base + atomicAdd(&region_counts[2 * r + 1], 1)] = v;
+        if (pass[regions[r].row_base + v.idx]) {
+            v.prefix = allele_prefix((v.meta & 8u) ? ref + regions[r].ref_off : seq + regions[r].seq_base, (uint32_t)v.off, (v.meta >> 4) & 63u);
+            out[regions[r].vote_base + atomicAdd(&region_counts[2 * r + 1], 1)] = v;
+        }
     }
 }
 
@@ -707,6 +722,27 @@ struct RegionOut {
     std::string names;
 };
 
+inline const char* allele_bytes(const Vote& v, const pa_pileup& p) { return ((v.meta & 8u) ? p.reference : p.seq) + v.off; }
+// order of the votes of one region: site, then the allele key as std::map<std::string> orders "2..." / "3..." strings
+// (type character, bytes as unsigned chars, the shorter of two that agree first).  The 8-byte prefix decides nearly always.
+inline bool vote_less(const Vote& x, const Vote& y, const pa_pileup& p) {
+    if (x.idx != y.idx) return x.idx < y.idx;
+    const uint32_t tx = x.meta & 3u, ty = y.meta & 3u;
+    if (tx != ty) return tx < ty;
+    if (x.prefix != y.prefix) return x.prefix < y.prefix;
+    const uint32_t lx = (x.meta >> 4) & 63u, ly = (y.meta >> 4) & 63u;
+    if (lx > 8 && ly > 8) {
+        const int c = std::memcmp(allele_bytes(x, p) + 8, allele_bytes(y, p) + 8, std::min(lx, ly) - 8);
+        if (c != 0) return c < 0;
+    }
+    return lx < ly;
+}
+inline bool same_allele(const Vote& x, const Vote& y, const pa_pileup& p) {
+    if (x.idx != y.idx || ((x.meta ^ y.meta) & 3u) || x.prefix != y.prefix) return false;
+    const uint32_t lx = (x.meta >> 4) & 63u, ly = (y.meta >> 4) & 63u;
+    return lx == ly && (lx <= 8 || std::memcmp(allele_bytes(x, p) + 8, allele_bytes(y, p) + 8, lx - 8) == 0);
+}
+
 void enumerate_region(const RegHost& rh, int region, int mid, const SiteRec* sites, size_t n_sites, const Vote* votes,
                       size_t n_votes, const int4* ovf, size_t n_ovf, RegionOut& out) {
     const pa_pileup& p = rh.p;
@@ -719,8 +755,6 @@ void enumerate_region(const RegHost& rh, int region, int mid, const SiteRec* sit
         (ovf[k].z ? t.rev : t.fwd) += 1;
     }
     size_t vk = 0;                                        // votes are sorted by site, like the sites
-    struct VoteKey { const char* bytes; uint32_t len; char type; bool rev; };
-    std::vector<VoteKey> keys;
     for (size_t si = 0; si < n_sites; ++si) {
         const SiteRec& s = sites[si];
         const int depth = std::min(s.cov, MAXC);
@@ -768,31 +802,19 @@ void enumerate_region(const RegHost& rh, int region, int mid, const SiteRec* sit
         }
         while (vk < n_votes && (int32_t)votes[vk].idx < s.idx) ++vk;
         if (vk >= n_votes || (int32_t)votes[vk].idx != s.idx) continue;
-        // allele keys "2" + anchor + inserted bases / "3" + deleted reference bases in std::map<std::string> order, without
-        // building a string per vote (one allocation per vote was most of the host time of a batch): order the site's votes
-        // by (type, bytes) and tally the runs of equal keys
-        keys.clear();
-        for (; vk < n_votes && (int32_t)votes[vk].idx == s.idx; ++vk) {
-            const Vote& v = votes[vk];
-            keys.push_back(VoteKey{((v.meta & 8u) ? p.reference : p.seq) + v.off, (uint32_t)((v.meta >> 4) & 63u),
-                                   (v.meta & 3u) == 1u ? '2' : '3', (v.meta & 4u) != 0});
-        }
-        std::sort(keys.begin(), keys.end(), [](const VoteKey& x, const VoteKey& y) {
-            if (x.type != y.type) return x.type < y.type;
-            const int c = std::memcmp(x.bytes, y.bytes, std::min(x.len, y.len));
-            return c != 0 ? c < 0 : x.len < y.len;
-        });
-        for (size_t k0 = 0; k0 < keys.size();) {
+        // allele keys "2" + anchor + inserted bases / "3" + deleted reference bases in std::map<std::string> order: the region's
+        // votes arrive ordered by (site, type, allele bytes) -- see vote_less -- so equal keys are runs
+        for (size_t k0 = vk; k0 < n_votes && (int32_t)votes[k0].idx == s.idx;) {
             size_t k1 = k0;
             Tally t;
-            while (k1 < keys.size() && keys[k1].type == keys[k0].type && keys[k1].len == keys[k0].len &&
-                   std::memcmp(keys[k1].bytes, keys[k0].bytes, keys[k0].len) == 0) {
+            while (k1 < n_votes && same_allele(votes[k1], votes[k0], p)) {
                 t.total += 1;
-                (keys[k1].rev ? t.rev : t.fwd) += 1;
+                ((votes[k1].meta & 4u) ? t.rev : t.fwd) += 1;
                 ++k1;
             }
-            const char type = keys[k0].type;
-            const int alen = (int)keys[k0].len;
+            const Vote& v = votes[k0];
+            const char type = (v.meta & 3u) == 1u ? '2' : '3';
+            const int alen = (int)((v.meta >> 4) & 63u);
             if (accept(type, t)) {
                 CandDesc d{};
                 d.idx = s.idx; d.type = type - '0';
@@ -808,11 +830,12 @@ void enumerate_region(const RegHost& rh, int region, int mid, const SiteRec* sit
                     d.star_f = symbol_column(rb, '*', false); d.star_r = symbol_column(rb, '*', true);
                 }
                 std::string key(1, type);
-                key.append(keys[k0].bytes, keys[k0].len);
+                key.append(allele_bytes(v, p), (size_t)alen);
                 emit(key, t, d);
             }
             k0 = k1;
         }
+        while (vk < n_votes && (int32_t)votes[vk].idx == s.idx) ++vk;
     }
 }
 
@@ -1015,7 +1038,8 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
         hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)b.n_tiles), dim3(NT), 0, st, ta);
         ENC_HIP(hipEventRecord(e->ev[2], st));
         hipLaunchKernelGGL(compact_votes_kernel, dim3((unsigned)std::min(2048, (vote_cap + 255) / 256)), dim3(256), 0, st, b.d_votes.as<Vote>(), counters,
-                           vote_cap, b.d_regions.as<RegRec>(), b.d_pass.as<uint8_t>(), region_counts, b.d_votes_out.as<Vote>());
+                           vote_cap, b.d_regions.as<RegRec>(), b.d_pass.as<uint8_t>(), b.d_seq.as<char>(), b.d_ref.as<char>(), region_counts,
+                           b.d_votes_out.as<Vote>());
         hipLaunchKernelGGL(pack_results_kernel, dim3((unsigned)n_regions), dim3(256), 0, st, b.d_regions.as<RegRec>(), region_counts,
                            b.d_sites.as<SiteRec>(), b.d_votes_out.as<Vote>(), b.d_sites_dense.as<SiteRec>(), b.d_votes_dense.as<Vote>());
         ENC_HIP(hipEventRecord(e->ev[3], st));
@@ -1071,7 +1095,8 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
     std::vector<RegionOut> outs((size_t)n_regions);
     const std::function<void(int)> work = [&](int r) {
         std::sort(sites + s0[(size_t)r], sites + s0[(size_t)r + 1], [](const SiteRec& x, const SiteRec& y) { return x.idx < y.idx; });
-        std::sort(votes + v0[(size_t)r], votes + v0[(size_t)r + 1], [](const Vote& x, const Vote& y) { return x.idx < y.idx; });
+        const pa_pileup& pile = b.regs[(size_t)r].p;
+        std::sort(votes + v0[(size_t)r], votes + v0[(size_t)r + 1], [&pile](const Vote& x, const Vote& y) { return vote_less(x, y, pile); });
         enumerate_region(b.regs[(size_t)r], r, b.mid, sites + s0[(size_t)r], s0[(size_t)r + 1] - s0[(size_t)r], votes + v0[(size_t)r],
                          v0[(size_t)r + 1] - v0[(size_t)r], ovf.data() + o0[(size_t)r], o0[(size_t)r + 1] - o0[(size_t)r], outs[(size_t)r]);
     };

@@ -27,8 +27,9 @@ def main():
                                                      "list runs one measurement per value on the same image files; -1 = the "
                                                      "in-process loop (PEPPER_AMD_NO_LANES=1), -2 = lanes with one block in flight")
     ap.add_argument("--groups", type=int, default=4, help="summaries groups (regions) per image file")
+    ap.add_argument("--dir", default=None, help="parent of the scratch directory (default: the system's temporary directory; /dev/shm = tmpfs)")
     args = ap.parse_args()
-    tmp = tempfile.mkdtemp()
+    tmp = tempfile.mkdtemp(dir=args.dir)
     try:
         img_dir = os.path.join(tmp, "images")
         os.makedirs(img_dir)

@@ -25,9 +25,10 @@ def main():
     ap.add_argument("--chunks", type=int, default=65536)
     ap.add_argument("--files", type=int, default=16)
     ap.add_argument("--workers", default="0", help="comma list of num_workers values (lanes); -1 = the in-process loop")
+    ap.add_argument("--dir", default=None, help="parent of the scratch directory (default: the system's temporary directory; /dev/shm = tmpfs)")
     args = ap.parse_args()
     n = args.chunks // (2 * args.files) * 2 * args.files
-    tmp = tempfile.mkdtemp()
+    tmp = tempfile.mkdtemp(dir=args.dir)
     try:
         img_dir = os.path.join(tmp, "images")
         os.makedirs(img_dir)
