@@ -104,8 +104,14 @@ const int8_t* pa_encoder_device_images(pa_encoder* e);
  * ------------------------------------------------------------------------------------------ */
 int pa_polish_encoder_generate_summary(pa_encoder* e, const pa_pileup* pileup, int64_t start_pos,
                                        int64_t end_pos, int64_t* n_rows);
-/* HOST pointers: image uint8 [n_rows, 10], positions int64 [n_rows, 2]; either may be NULL. */
+/* Many regions per launch: pileups[n_regions], start_pos[n_regions], end_pos[n_regions] -> n_rows[n_regions] (may be NULL);
+ * the results are the rows of region 0, then region 1, ...  The whole per-read walk runs on the device. */
+int pa_polish_encoder_generate_summary_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups,
+                                             const int64_t* start_pos, const int64_t* end_pos, int64_t* n_rows);
+/* HOST pointers: image uint8 [n_rows, 10], positions int64 [n_rows, 2] (of all regions of the last call); either may be NULL. */
 int pa_polish_encoder_get_results(pa_encoder* e, uint8_t* image, int64_t* positions);
+/* HIP-event times of the last call in ms: [0] record / scan kernels, [1] polish_tile_kernel, [2] polish_insert_rows_kernel. */
+int pa_polish_encoder_last_timing(pa_encoder* e, double* ms, int32_t n);
 
 #ifdef __cplusplus
 }

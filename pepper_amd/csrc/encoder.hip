@@ -147,7 +147,12 @@ __global__ __launch_bounds__(256) void segment_reads_kernel(const ReadRec* __res
     };
     int pos = rd.row0, ri = 0;
     if (pos > L - 1) return;
-    if (pos >= 0 && lane == 0) put(tile0 + pos / TP, rd.c0, pos, 0);
+    if (pos >= 0 && lane == 0) {
+        put(tile0 + pos / TP, rd.c0, pos, 0);
+        // an insert in front of the read's first aligned base (S I M) is anchored on the row before it: when that row is the
+        // last one of the previous tile, that tile walks the read's leading operations too
+        if (pos > 0 && pos % TP == 0) put(tile0 + pos / TP - 1, rd.c0, pos, 0);
+    }
     for (int cb = 0; cb < rd.ncig; cb += 64) {
         const int i = cb + lane;
         const bool valid = i < rd.ncig;
@@ -1095,8 +1100,20 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
     std::vector<RegionOut> outs((size_t)n_regions);
     const std::function<void(int)> work = [&](int r) {
         std::sort(sites + s0[(size_t)r], sites + s0[(size_t)r + 1], [](const SiteRec& x, const SiteRec& y) { return x.idx < y.idx; });
+        // votes by (site, type, allele): one 64-bit key per vote decides nearly every comparison (28 bits of site, 2 of type, the
+        // first 34 bits of the allele); the rare ties fall back to the full order
         const pa_pileup& pile = b.regs[(size_t)r].p;
-        std::sort(votes + v0[(size_t)r], votes + v0[(size_t)r + 1], [&pile](const Vote& x, const Vote& y) { return vote_less(x, y, pile); });
+        Vote* vb = votes + v0[(size_t)r];
+        const size_t nv = v0[(size_t)r + 1] - v0[(size_t)r];
+        std::vector<std::pair<uint64_t, uint32_t>> order(nv);
+        for (size_t k = 0; k < nv; ++k)
+            order[k] = {((uint64_t)vb[k].idx << 36) | ((uint64_t)(vb[k].meta & 3u) << 34) | (vb[k].prefix >> 30), (uint32_t)k};
+        std::sort(order.begin(), order.end(), [&](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) {
+            return x.first != y.first ? x.first < y.first : vote_less(vb[x.second], vb[y.second], pile);
+        });
+        std::vector<Vote> sorted(nv);
+        for (size_t k = 0; k < nv; ++k) sorted[k] = vb[order[k].second];
+        std::copy(sorted.begin(), sorted.end(), vb);
         enumerate_region(b.regs[(size_t)r], r, b.mid, sites + s0[(size_t)r], s0[(size_t)r + 1] - s0[(size_t)r], votes + v0[(size_t)r],
                          v0[(size_t)r + 1] - v0[(size_t)r], ovf.data() + o0[(size_t)r], o0[(size_t)r + 1] - o0[(size_t)r], outs[(size_t)r]);
     };
@@ -1106,7 +1123,7 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
         if (!b.pool) {
             const char* env = getenv("PA_ENCODER_HOST_THREADS");
             const int n = env ? atoi(env) : (int)std::thread::hardware_concurrency() / 4;
-            b.pool.reset(new RegionPool(std::max(1, std::min(n, 32)) - 1));
+            b.pool.reset(new RegionPool(std::max(1, std::min(n, 64)) - 1));
         }
         b.pool->run(n_regions, work);
     }

@@ -1,6 +1,22 @@
-// Polish summary encoder (include/pepper_amd_encoder.h): pileup -> uint8 summary rows.
+// Polish summary encoder (include/pepper_amd_encoder.h): pileups of many regions -> uint8 summary rows, one launch set.
 // Reference: /root/reference/pepper/modules/src/pileup_summary/summary_generator.cpp:16-32 (feature index), 47-121
 // (per-read walk), 274-306 (pixels), 370-393 (row order).
+//
+// Round 2 walked the CIGAR strings on the host and uploaded segment lists; here the whole walk is on the device, with the
+// machinery of the variant encoder (encoder_common.h):
+//   polish_segment_kernel<false>  one wave per read: prefix sums over its operations; longest insert per anchor (atomicMax),
+//                                 tile record counts
+//   polish_rows_kernel            one workgroup per region: exclusive scan of the longest inserts = where every position's
+//                                 insert rows sit among the region's insert slots and among its output rows; region totals
+//   (host: one small copy of the totals -> output sizes)
+//   polish_segment_kernel<true>   the (read, tile) records into their tiles' slices
+//   polish_tile_kernel            one workgroup owns 512 positions: 10 feature counts + coverage privatised in LDS, the tile's
+//                                 records walked one row per lane; insert bases go to the (sparse) insert-slot counts with global
+//                                 atomics; then the base rows' pixels uint8(count / max(1, coverage) * 254) are stored, once
+//   polish_insert_rows_kernel     the insert rows' pixels (normalised by the anchor's coverage) and every row's (position, index)
+// Reference quirks kept: a deletion credits coverage to its FIRST position once per deleted position inside the region
+// (:105-110); REF_SKIP and PAD count as deletions; the walk of a read stops at the first operation that starts past end_pos,
+// but an operation that started before it is counted to its end; no quality or mapping-quality-beyond->0 filter.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -14,20 +30,25 @@ using namespace pa_enc;
 
 namespace {
 
-__host__ __device__ inline int up(char c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
+constexpr int TP = 512, NW = 8, NT = 64 * NW, UNR = 8;   // rows per tile = threads per workgroup; rows per lane in flight
+constexpr int NF = 10, K_COV = 10, NCNT = 11;            // features, coverage slot, counters per row
+constexpr int PROW = 16;                                 // int32 per insert slot in HBM (10 used)
+static_assert(NT == TP && 64 * UNR == TP, "one thread per row");
+enum { PC_ERR = 0, PC_N = 4 };
 
-// ---- polish encoder -----------------------------------------------------------------------------
-constexpr uint32_t PSEG_REV = 1, PSEG_GAP = 2, PSEG_INS = 4;
-constexpr int PROW = 16, PC_COV = 10;       // base counts int32 [L][16]: 10 features + coverage
-
-struct PSeg {
-    int64_t seq0;
-    int32_t idx0, n;      // MATCH/GAP: first position row; INS: first insert-slot row
-    uint32_t flags;
-    int32_t cov_idx;      // GAP: row credited with coverage (deletion start), -1 if outside the region
+struct PRegRec {
+    int64_t row_base;            // first row of the region in longest / ins_base / coverage
+    int64_t seq_base;
+    int64_t pos0;                // region_start
+    int32_t L;                   // region_end - region_start + 1
+    int32_t tile0, n_tiles;
+    int32_t stop_row;            // end_pos - region_start: operations that start past it are not walked
+    int32_t out_lo, out_hi;      // start_pos / end_pos as rows (may lie outside [0, L))
+    int32_t pad[2];
 };
-struct PRow { int32_t idx, slot; };   // output row -> (position row, 0 = base row / k = insert slot k)
+struct TileRec { int32_t read, op, row, ri; };
 
+__host__ __device__ inline int up(char c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
 __host__ __device__ inline int polish_feature(char b, bool rev) {   // summary_generator.cpp:16-32
     int k;
     switch (up(b)) {
@@ -40,173 +61,555 @@ __host__ __device__ inline int polish_feature(char b, bool rev) {   // summary_g
     return rev ? k : k + 4;
 }
 
-__global__ __launch_bounds__(256) void polish_count_kernel(const PSeg* __restrict__ segs, int nseg,
-                                                           const char* __restrict__ seq, int* __restrict__ base,
-                                                           int* __restrict__ ins) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= nseg) return;
-    const PSeg sg = segs[s];
-    const bool rev = sg.flags & PSEG_REV;
-    if (sg.flags & PSEG_GAP) {
-        const int col = rev ? 8 : 9;
-        for (int i = 0; i < sg.n; ++i) atomicAdd(&base[(size_t)(sg.idx0 + i) * PROW + col], 1);
-        if (sg.cov_idx >= 0) atomicAdd(&base[(size_t)sg.cov_idx * PROW + PC_COV], sg.n);
-    } else if (sg.flags & PSEG_INS) {
-        for (int i = 0; i < sg.n; ++i)
-            atomicAdd(&ins[(size_t)(sg.idx0 + i) * PROW + polish_feature(seq[sg.seq0 + i], rev)], 1);
-    } else {
-        for (int i = 0; i < sg.n; ++i) {
-            int* row = base + (size_t)(sg.idx0 + i) * PROW;
-            atomicAdd(&row[polish_feature(seq[sg.seq0 + i], rev)], 1);
-            atomicAdd(&row[PC_COV], 1);
+// exclusive scan of the per-tile record counts (one workgroup)
+__global__ __launch_bounds__(1024) void polish_tile_offsets_kernel(const int* __restrict__ tile_count, int n_tiles, int* __restrict__ tile_off) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_tiles ? tile_count[i] : 0;
+        const int inc = wave_inclusive_sum(v);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int before = carry;
+        for (int k = 0; k < w; ++k) before += wsum[k];
+        if (i < n_tiles) tile_off[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_off[n_tiles] = carry;
+}
+
+// FILL = false: longest insert per anchor + record counts; FILL = true: the records
+template <bool FILL>
+__global__ __launch_bounds__(256) void polish_segment_kernel(const ReadRec* __restrict__ reads, int n_reads,
+                                                             const PRegRec* __restrict__ regions,
+                                                             const int32_t* __restrict__ cigar_op, const int32_t* __restrict__ cigar_len,
+                                                             int* __restrict__ longest, int* __restrict__ tile_count,
+                                                             const int* __restrict__ tile_off, int* __restrict__ tile_fill,
+                                                             TileRec* __restrict__ recs, int rec_cap, int* __restrict__ counters) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= n_reads) return;
+    const ReadRec rd = reads[r];
+    if (!(rd.flags & READ_MAPQ_OK)) return;
+    const PRegRec* reg = regions + rd.region;
+    const int L = reg->L, tile0 = reg->tile0, stop = reg->stop_row;
+    auto put = [&](int tile, int op, int row, int ri) {
+        if (!FILL) {
+            atomicAdd(&tile_count[tile], 1);
+        } else {
+            const int slot = tile_off[tile] + atomicAdd(&tile_fill[tile], 1);
+            if (slot < rec_cap) recs[slot] = TileRec{r, op, row, ri};
+        }
+    };
+    int pos = rd.row0, ri = 0;
+    if (pos > stop) return;
+    if (pos >= 0 && pos <= L - 1 && lane == 0) put(tile0 + pos / TP, rd.c0, pos, 0);
+    // an insert in front of the read's first aligned base is anchored on the row before it: when that row is the last one of
+    // the previous tile, that tile walks the read's leading operations too
+    if (pos >= 1 && pos <= L && (pos % TP == 0 || pos == L) && lane == 0) put(tile0 + (pos - 1) / TP, rd.c0, pos, 0);
+    for (int cb = 0; cb < rd.ncig; cb += 64) {
+        const int i = cb + lane;
+        const bool valid = i < rd.ncig;
+        const int op = valid ? cigar_op[rd.c0 + i] : OP_H;
+        const int len = valid ? cigar_len[rd.c0 + i] : 0;
+        const int radv = polish_ref_advance(op, len), qadv = polish_read_advance(op, len);
+        const int rinc = wave_inclusive_sum(radv), qinc = wave_inclusive_sum(qadv);
+        const int first = pos + rinc - radv, after = pos + rinc, rfirst = ri + qinc - qadv;
+        const bool walked = valid && first <= stop;
+        if (!FILL && walked && op == OP_I) {
+            const int anchor = first - 1;
+            if (anchor >= 0 && anchor <= L - 1) {
+                if (rfirst + len > rd.slen) atomicMax(&counters[PC_ERR], 2 * (r + 1) + 1);   // insert runs past the sequence
+                else atomicMax(&longest[reg->row_base + anchor], len);
+            }
+        }
+        if (walked && radv > 0 && first <= L - 1) {
+            int lo = first > rd.row0 + 1 ? first : rd.row0 + 1;
+            if (lo < 0) lo = 0;
+            const int last_row = after - 1 < L - 1 ? after - 1 : L - 1;
+            for (int k = (lo + TP - 1) / TP; k * TP <= last_row; ++k) put(tile0 + k, rd.c0 + i, first, rfirst);
+        }
+        pos += wave_total(rinc);
+        ri += wave_total(qinc);
+        if (pos > stop) break;
+    }
+}
+
+// one workgroup per region: ins_base[row] = insert rows of the output positions before `row` (exclusive scan of the longest
+// inserts over the rows that are output positions); totals[r] = the region's insert rows
+__global__ __launch_bounds__(1024) void polish_rows_kernel(const PRegRec* __restrict__ regions, const int* __restrict__ longest,
+                                                           int* __restrict__ ins_base, int* __restrict__ totals) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const PRegRec reg = regions[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lo = reg.out_lo > 0 ? reg.out_lo : 0, hi = reg.out_hi < reg.L - 1 ? reg.out_hi : reg.L - 1;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < reg.L; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i >= lo && i <= hi) ? longest[reg.row_base + i] : 0;
+        const int inc = wave_inclusive_sum(v);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int before = carry;
+        for (int k = 0; k < w; ++k) before += wsum[k];
+        if (i < reg.L) ins_base[reg.row_base + i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+struct PTileArgs {
+    const ReadRec* reads; const PRegRec* regions; const int32_t* tile_region; const int32_t* cigar_op; const int32_t* cigar_len;
+    const char* seq; const TileRec* recs; const int* tile_off; int rec_cap;
+    const int* longest; const int* ins_base; const int64_t* slot_base; const int64_t* out_base;
+    int* ins_counts; int* coverage; uint8_t* pixels; int* counters;
+};
+
+__global__ __launch_bounds__(NT, 4) void polish_tile_kernel(PTileArgs a) {
+    __shared__ int cnt[NCNT * TP];
+    __shared__ int s_first[NW][65], s_ri[NW][64], s_op[NW][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x;
+    const int region = a.tile_region[tile];
+    const PRegRec reg = a.regions[region];
+    const int L = reg.L;
+    const int tile_lo = (tile - reg.tile0) * TP, tile_hi = tile_lo + TP - 1;
+    const int live_max = tile_hi + 1 < reg.stop_row ? tile_hi + 1 : reg.stop_row;
+    const int out_lo = reg.out_lo > 0 ? reg.out_lo : 0, out_hi = reg.out_hi < L - 1 ? reg.out_hi : L - 1;
+    for (int i = tid; i < NCNT * TP; i += NT) cnt[i] = 0;
+    __syncthreads();
+    const int rec0 = a.tile_off[tile], rec1 = a.tile_off[tile + 1] < a.rec_cap ? a.tile_off[tile + 1] : a.rec_cap;
+    int* first_s = s_first[w];
+    int* ri_s = s_ri[w];
+    int* op_s = s_op[w];
+    const int64_t slot0 = a.slot_base[region];
+    TileRec rec{0, 0, 0, 0};
+    if (rec0 + w < rec1) rec = a.recs[rec0 + w];
+    for (int k = rec0 + w; k < rec1; k += NW) {
+        const ReadRec rd_v = a.reads[rec.read];
+        int op_ld = a.cigar_op[rec.op + lane], len_ld = a.cigar_len[rec.op + lane];
+        TileRec rec_next = rec;
+        if (k + NW < rec1) rec_next = a.recs[k + NW];
+        const int64_t s0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rd_v.s0 >> 32)) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)rd_v.s0));
+        const int slen = __builtin_amdgcn_readfirstlane(rd_v.slen);
+        const int c_end = __builtin_amdgcn_readfirstlane(rd_v.c0) + __builtin_amdgcn_readfirstlane(rd_v.ncig);
+        const bool rev = __builtin_amdgcn_readfirstlane(rd_v.flags) & READ_REV;
+        const int rec_read = __builtin_amdgcn_readfirstlane(rec.read), rec_op = __builtin_amdgcn_readfirstlane(rec.op);
+        const char* seq0 = a.seq + s0;
+        int pos = __builtin_amdgcn_readfirstlane(rec.row), ri = __builtin_amdgcn_readfirstlane(rec.ri);
+        for (int c = rec_op; c < c_end; c += 64) {
+            const int i = c + lane;
+            if (c != rec_op) {
+                op_ld = a.cigar_op[i];
+                len_ld = a.cigar_len[i];
+            }
+            const bool valid = i < c_end;
+            const int op = valid ? op_ld : OP_H;
+            const int len = valid ? len_ld : 0;
+            const int radv = polish_ref_advance(op, len), qadv = polish_read_advance(op, len);
+            const int rinc = wave_inclusive_sum(radv), qinc = wave_inclusive_sum(qadv);
+            const int first = pos + rinc - radv, rfirst = ri + qinc - qadv;
+            const int total_r = wave_total(rinc);
+            const bool live = valid && first <= live_max;
+            first_s[lane] = valid ? first : 0x7fffffff;
+            if (lane == 63) first_s[64] = valid ? pos + total_r : 0x7fffffff;
+            ri_s[lane] = rfirst;
+            op_s[lane] = live ? op : OP_H;                 // an operation that starts past end_pos is not walked: its rows count nothing
+            __builtin_amdgcn_wave_barrier();
+            const int span_lo = pos > tile_lo ? pos : tile_lo;
+            int span_hi = pos + total_r - 1;
+            if (span_hi > tile_hi) span_hi = tile_hi;
+            if (span_hi > L - 1) span_hi = L - 1;
+
+            // -- row phase loads first
+            bool is_m[UNR], is_gap[UNR];
+            int pl[UNR];
+            char bv[UNR];
+            bool past = false;
+            {
+                unsigned si[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int p = span_lo + lane + 64 * u;
+                    const bool act = p <= span_hi;
+                    const int pc = act ? p : tile_lo + ((lane + 64 * u) & (TP - 1));
+                    const int j = owner_of_row(first_s, pc);
+                    const int oj = op_s[j];
+                    const int rp = ri_s[j] + (pc - first_s[j]);
+                    const bool m = act && (oj == OP_M || oj == OP_EQ || oj == OP_X);
+                    const bool inb = (unsigned)rp < (unsigned)slen;
+                    past |= m && !inb;
+                    is_m[u] = m && inb;
+                    is_gap[u] = act && (oj == OP_D || oj == OP_N || oj == OP_P);
+                    pl[u] = pc - tile_lo;
+                    si[u] = is_m[u] ? (unsigned)rp : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) bv[u] = __builtin_nontemporal_load(seq0 + si[u]);
+            }
+            if (past) atomicMax(&a.counters[PC_ERR], 2 * (rec_read + 1));   // CIGAR runs past the sequence
+
+            // -- one operation per lane: insert bases into the insert slots (:83-97), the coverage credit of gaps (:105-110)
+            const int anchor = first - 1;
+            if (live && op == OP_I && anchor >= tile_lo && anchor <= tile_hi && anchor >= out_lo && anchor <= out_hi && rfirst + len <= slen) {
+                int* slot = a.ins_counts + (slot0 + a.ins_base[reg.row_base + anchor]) * PROW;
+                for (int q = 0; q < len; ++q) atomicAdd(&slot[(int64_t)q * PROW + polish_feature(seq0[(unsigned)(rfirst + q)], rev)], 1);
+            }
+            if (live && radv > 0 && (op == OP_D || op == OP_N || op == OP_P) && first >= tile_lo && first <= tile_hi && first <= L - 1) {
+                const int lo_r = first, hi_r = first + len - 1 < L - 1 ? first + len - 1 : L - 1;     // (first >= tile_lo >= 0)
+                atomicAdd(&cnt[K_COV * TP + first - tile_lo], hi_r - lo_r + 1);
+            }
+
+            // -- the rows: a matched base counts its feature and coverage, a deleted position the strand's gap feature
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const unsigned bu = (unsigned char)bv[u] & 0xDFu;
+                const unsigned bidx = (bu >> 1) & 3u;
+                const bool letter = ((0x47544341u >> (bidx * 8)) & 0xFFu) == bu;
+                const int acgt = (int)(bidx ^ (bidx >> 1));
+                const int feat = is_gap[u] ? (rev ? 8 : 9) : (letter ? (rev ? acgt : acgt + 4) : (rev ? 8 : 9));
+                atomicAdd(&cnt[feat * TP + pl[u]], (is_m[u] || is_gap[u]) ? 1 : 0);
+                atomicAdd(&cnt[K_COV * TP + pl[u]], is_m[u] ? 1 : 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            pos += total_r;
+            ri += wave_total(qinc);
+            if (pos > live_max) break;
+        }
+        rec = rec_next;
+    }
+    __syncthreads();
+
+    // ---- pixels of the base rows (:274-306), coverage kept for the insert rows
+    const int idx = tile_lo + tid;
+    if (idx < L) {
+        const int cov = cnt[K_COV * TP + tid];
+        a.coverage[reg.row_base + idx] = cov;
+        if (idx >= reg.out_lo && idx <= reg.out_hi) {
+            const double c = cov > 1 ? (double)cov : 1.0;
+            uint8_t* out = a.pixels + (a.out_base[region] + (idx - reg.out_lo) + a.ins_base[reg.row_base + idx]) * NF;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const double v = ((double)cnt[j * TP + tid] / c) * 254.0;
+                out[j] = (uint8_t)((long long)v & 0xff);       // double -> uint8 as x86-64 gcc truncates
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void polish_pixels_kernel(const PRow* __restrict__ rows, int nrows,
-                                                            const int* __restrict__ base, const int* __restrict__ ins,
-                                                            const int* __restrict__ ins_row0, uint8_t* __restrict__ out) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= nrows) return;
-    const PRow pr = rows[r];
-    const int cov = pr.idx >= 0 ? base[(size_t)pr.idx * PROW + PC_COV] : 0;
-    const double c = cov > 1 ? (double)cov : 1.0;
-    const int* src = pr.idx < 0 ? nullptr
-                                : (pr.slot == 0 ? base + (size_t)pr.idx * PROW
-                                                : ins + (size_t)(ins_row0[pr.idx] + pr.slot - 1) * PROW);
+// one thread per output position of every region: its (position, 0) row and its insert rows' positions and pixels
+__global__ __launch_bounds__(256) void polish_insert_rows_kernel(const PRegRec* __restrict__ regions, const int64_t* __restrict__ out_pos_base,
+                                                                 int n_regions, int64_t total_positions, const int* __restrict__ longest,
+                                                                 const int* __restrict__ ins_base, const int64_t* __restrict__ slot_base,
+                                                                 const int64_t* __restrict__ out_base, const int* __restrict__ ins_counts,
+                                                                 const int* __restrict__ coverage, uint8_t* __restrict__ pixels,
+                                                                 int64_t* __restrict__ positions) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total_positions) return;
+    int lo = 0, hi = n_regions - 1;                         // region of output position g: out_pos_base is ascending
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (out_pos_base[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    const PRegRec reg = regions[lo];
+    const int idx = reg.out_lo + (int)(g - out_pos_base[lo]);
+    const bool in = idx >= 0 && idx <= reg.L - 1;
+    const int n_ins = in ? longest[reg.row_base + idx] : 0;
+    // rows before it: one per output position + the insert rows of the in-region positions before it
+    int before_ins = 0;
+    if (in) before_ins = ins_base[reg.row_base + idx];
+    else if (idx > reg.L - 1 && reg.L > 0) {
+        const int last = reg.out_hi < reg.L - 1 ? reg.out_hi : reg.L - 1;
+        before_ins = last >= 0 && last >= reg.out_lo ? ins_base[reg.row_base + last] + longest[reg.row_base + last] : 0;
+    }
+    const int64_t row = out_base[lo] + (idx - reg.out_lo) + before_ins;
+    positions[2 * row] = reg.pos0 + idx;
+    positions[2 * row + 1] = 0;
+    if (n_ins > 0) {
+        const int cov = coverage[reg.row_base + idx];
+        const double c = cov > 1 ? (double)cov : 1.0;
+        for (int k = 0; k < n_ins; ++k) {
+            const int* src = ins_counts + (slot_base[lo] + before_ins + k) * PROW;
+            uint8_t* out = pixels + (row + 1 + k) * NF;
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
-        const double v = src ? ((double)src[j] / c) * 254.0 : 0.0;
-        out[(size_t)r * 10 + j] = (uint8_t)((long long)v & 0xff);   // double -> uint8 as x86-64 gcc truncates
+            for (int j = 0; j < NF; ++j) {
+                const double v = ((double)src[j] / c) * 254.0;
+                out[j] = (uint8_t)((long long)v & 0xff);
+            }
+            positions[2 * (row + 1 + k)] = reg.pos0 + idx;
+            positions[2 * (row + 1 + k) + 1] = k + 1;
+        }
     }
 }
+
+struct PRegHost {
+    pa_pileup p;
+    int64_t start_pos = 0, end_pos = 0, row_base = 0, seq_base = 0, op_base = 0, read_base = 0;
+    int L = 0;
+};
+
 }  // namespace
 
 struct pa_polish_batch {
-    DBuf d_seq, d_segs, d_pbase, d_pins, d_prow0, d_prows, d_ppix;
-    int64_t p_rows = 0;
-    std::vector<int64_t> p_positions;
+    std::vector<PRegHost> regs;
+    std::vector<int64_t> region_rows;        // output rows per region of the last run
+    int64_t total_bases = 0, total_ops = 0, total_reads = 0, total_rows = 0, total_out = 0;
+    int n_tiles = 0, rec_cap = 0;
+    DBuf d_seq, d_cig_op, d_cig_len, d_reads, d_regions, d_tile_region, d_zero, d_tile_off, d_sorted, d_ins_base, d_totals,
+        d_bases, d_ins_counts, d_coverage, d_pixels, d_positions;
+    double ms[4] = {0, 0, 0, 0};
 };
 
 void pa_polish_batch_free(pa_polish_batch* b) { delete b; }
 
-extern "C" {
+namespace {
 
-int pa_polish_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, int64_t start_pos, int64_t end_pos,
-                                       int64_t* n_rows) {
-    if (!e || !p || !n_rows) return pa::set_error(PA_ERR_INVALID, "null argument");
-    if (p->region_end < p->region_start || p->region_end - p->region_start > (int64_t)1 << 28 || end_pos < start_pos)
-        return pa::set_error(PA_ERR_INVALID, "bad region");
+int polish_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const int64_t* start_pos, const int64_t* end_pos,
+                 int64_t* n_rows) {
+    if (!e || n_regions < 0 || (n_regions > 0 && (!pileups || !start_pos || !end_pos))) return pa::set_error(PA_ERR_INVALID, "null argument");
     ENC_HIP(hipSetDevice(e->device));
     if (!e->polish) e->polish = new pa_polish_batch();
     pa_polish_batch& b = *e->polish;
-    const int64_t start = p->region_start, end = p->region_end;
-    const int L = (int)(end - start + 1);
-    std::vector<PSeg> segs;
-    std::vector<int32_t> longest((size_t)L, 0);
-    struct InsOp { int32_t idx; int32_t len; int64_t seq0; bool rev; };
-    std::vector<InsOp> ins_ops;
-    const int64_t total_bases = p->n_reads > 0 ? p->seq_offset[p->n_reads] : 0;
-    for (int32_t r = 0; r < p->n_reads; ++r) {
-        if (p->read_mapq[r] <= 0) continue;
-        const bool rev = p->read_reverse[r] != 0;
-        const int64_t s0 = p->seq_offset[r], read_len = p->seq_offset[r + 1] - s0;
-        int64_t ri = 0, pos = p->read_pos[r];
-        for (int64_t c = p->cigar_offset[r]; c < p->cigar_offset[r + 1]; ++c) {
-            if (pos > end_pos) break;
-            const int op = p->cigar_op[c];
-            const int64_t len = p->cigar_len[c];
-            if (op == OP_M || op == OP_EQ || op == OP_X) {
-                const int64_t lo = std::max(pos, start), hi = std::min(pos + len - 1, end);
-                if (lo <= hi) {
-                    if (ri + (hi - pos) >= read_len)
-                        return pa::set_error(PA_ERR_INVALID, "CIGAR of read " + std::to_string(r) + " runs past its sequence");
-                    segs.push_back({s0 + ri + (lo - pos), (int32_t)(lo - start), (int32_t)(hi - lo + 1), rev ? PSEG_REV : 0u, -1});
-                }
-                ri += len;
-                pos += len;
-            } else if (op == OP_I) {
-                const int64_t anchor = pos - 1;
-                if (anchor >= start && anchor <= end) {
-                    if (ri + len > read_len)
-                        return pa::set_error(PA_ERR_INVALID, "insert of read " + std::to_string(r) + " runs past its sequence");
-                    const int32_t idx = (int32_t)(anchor - start);
-                    ins_ops.push_back({idx, (int32_t)len, s0 + ri, rev});
-                    longest[(size_t)idx] = std::max<int32_t>(longest[(size_t)idx], (int32_t)len);
-                }
-                ri += len;
-            } else if (op == OP_D || op == OP_N || op == OP_P) {
-                const int64_t lo = std::max(pos, start), hi = std::min(pos + len - 1, end);
-                if (lo <= hi)
-                    segs.push_back({0, (int32_t)(lo - start), (int32_t)(hi - lo + 1), (rev ? PSEG_REV : 0u) | PSEG_GAP,
-                                    (pos >= start && pos <= end) ? (int32_t)(pos - start) : -1});
-                pos += len;
-            } else if (op == OP_S) {
-                ri += len;
-            }
-        }
-    }
-    // insert-slot rows: prefix sum of the longest insert per anchor
-    std::vector<int32_t> ins_row0((size_t)L + 1, 0);
-    for (int i = 0; i < L; ++i) ins_row0[(size_t)i + 1] = ins_row0[(size_t)i] + longest[(size_t)i];
-    const int total_ins_rows = ins_row0[(size_t)L];
-    for (const InsOp& io : ins_ops)
-        segs.push_back({io.seq0, ins_row0[(size_t)io.idx], io.len, (io.rev ? PSEG_REV : 0u) | PSEG_INS, -1});
-    // output rows in the reference's order: position, then its insert slots
-    std::vector<PRow> rows;
-    b.p_positions.clear();
-    for (int64_t pos = start_pos; pos <= end_pos; ++pos) {
-        const bool in = pos >= start && pos <= end;
-        const int32_t idx = in ? (int32_t)(pos - start) : -1;
-        rows.push_back({idx, 0});
-        b.p_positions.push_back(pos);
-        b.p_positions.push_back(0);
-        const int32_t n_ins = in ? longest[(size_t)idx] : 0;
-        for (int32_t k = 1; k <= n_ins; ++k) {
-            rows.push_back({idx, k});
-            b.p_positions.push_back(pos);
-            b.p_positions.push_back(k);
-        }
-    }
-    b.p_rows = (int64_t)rows.size();
-    *n_rows = b.p_rows;
-
     hipStream_t st = e->stream;
-    ENC_ALLOC(b.d_seq, (size_t)total_bases + 16);
-    ENC_ALLOC(b.d_segs, segs.size() * sizeof(PSeg) + 16);
-    ENC_ALLOC(b.d_pbase, (size_t)L * PROW * sizeof(int));
-    ENC_ALLOC(b.d_pins, (size_t)(total_ins_rows + 1) * PROW * sizeof(int));
-    ENC_ALLOC(b.d_prow0, (size_t)(L + 1) * sizeof(int));
-    ENC_ALLOC(b.d_prows, rows.size() * sizeof(PRow) + 16);
-    ENC_ALLOC(b.d_ppix, rows.size() * 10 + 16);
-    if (total_bases > 0) ENC_HIP(hipMemcpyAsync(b.d_seq.p, p->seq, (size_t)total_bases, hipMemcpyHostToDevice, st));
-    if (!segs.empty()) ENC_HIP(hipMemcpyAsync(b.d_segs.p, segs.data(), segs.size() * sizeof(PSeg), hipMemcpyHostToDevice, st));
-    ENC_HIP(hipMemcpyAsync(b.d_prow0.p, ins_row0.data(), (size_t)(L + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    ENC_HIP(hipMemcpyAsync(b.d_prows.p, rows.data(), rows.size() * sizeof(PRow), hipMemcpyHostToDevice, st));
-    ENC_HIP(hipMemsetAsync(b.d_pbase.p, 0, (size_t)L * PROW * sizeof(int), st));
-    ENC_HIP(hipMemsetAsync(b.d_pins.p, 0, (size_t)(total_ins_rows + 1) * PROW * sizeof(int), st));
-    if (!segs.empty())
-        hipLaunchKernelGGL(polish_count_kernel, dim3(((int)segs.size() + 255) / 256), dim3(256), 0, st,
-                           static_cast<const PSeg*>(b.d_segs.p), (int)segs.size(), static_cast<const char*>(b.d_seq.p),
-                           static_cast<int*>(b.d_pbase.p), static_cast<int*>(b.d_pins.p));
-    hipLaunchKernelGGL(polish_pixels_kernel, dim3(((int)rows.size() + 255) / 256), dim3(256), 0, st,
-                       static_cast<const PRow*>(b.d_prows.p), (int)rows.size(), static_cast<const int*>(b.d_pbase.p),
-                       static_cast<const int*>(b.d_pins.p), static_cast<const int*>(b.d_prow0.p),
-                       static_cast<uint8_t*>(b.d_ppix.p));
+    b.regs.assign((size_t)n_regions, PRegHost());
+    b.region_rows.assign((size_t)n_regions, 0);
+    b.total_bases = b.total_ops = b.total_reads = b.total_rows = b.total_out = 0;
+    b.n_tiles = 0;
+    if (n_regions == 0) return PA_OK;
+    std::vector<PRegRec> regrecs((size_t)n_regions);
+    std::vector<int64_t> out_pos_base((size_t)n_regions + 1, 0);
+    for (int r = 0; r < n_regions; ++r) {
+        const pa_pileup& p = pileups[r];
+        if (p.region_end < p.region_start || p.region_end - p.region_start > (int64_t)1 << 28 || end_pos[r] < start_pos[r] ||
+            end_pos[r] - start_pos[r] > (int64_t)1 << 28 || start_pos[r] < p.region_start - ((int64_t)1 << 28) ||
+            end_pos[r] > p.region_end + ((int64_t)1 << 28))
+            return pa::set_error(PA_ERR_INVALID, "bad region");
+        if (p.n_reads < 0) return pa::set_error(PA_ERR_INVALID, "negative count");
+        PRegHost& rh = b.regs[(size_t)r];
+        rh.p = p;
+        rh.start_pos = start_pos[r];
+        rh.end_pos = end_pos[r];
+        rh.L = (int)(p.region_end - p.region_start + 1);
+        rh.row_base = b.total_rows;
+        rh.seq_base = b.total_bases;
+        rh.op_base = b.total_ops;
+        rh.read_base = b.total_reads;
+        PRegRec& g = regrecs[(size_t)r];
+        g.row_base = rh.row_base;
+        g.seq_base = rh.seq_base;
+        g.pos0 = p.region_start;
+        g.L = rh.L;
+        g.tile0 = b.n_tiles;
+        g.n_tiles = (rh.L + TP - 1) / TP;
+        g.stop_row = (int32_t)(end_pos[r] - p.region_start);
+        g.out_lo = (int32_t)(start_pos[r] - p.region_start);
+        g.out_hi = (int32_t)(end_pos[r] - p.region_start);
+        g.pad[0] = g.pad[1] = 0;
+        out_pos_base[(size_t)r + 1] = out_pos_base[(size_t)r] + (end_pos[r] - start_pos[r] + 1);
+        b.total_rows += rh.L;
+        b.total_reads += p.n_reads;
+        b.total_bases += p.n_reads > 0 ? p.seq_offset[p.n_reads] : 0;
+        b.total_ops += p.n_reads > 0 ? p.cigar_offset[p.n_reads] : 0;
+        b.n_tiles += g.n_tiles;
+        if (b.total_rows > ((int64_t)1 << 30) || b.total_ops > 0x7ffffff0 || b.total_reads > 0x3ffffff0 || out_pos_base[(size_t)r + 1] > ((int64_t)1 << 31))
+            return pa::set_error(PA_ERR_INVALID, "batch too large");
+    }
+    std::vector<ReadRec> reads((size_t)b.total_reads);
+    std::vector<int32_t> tile_region((size_t)b.n_tiles);
+    for (int r = 0; r < n_regions; ++r) {
+        const PRegHost& rh = b.regs[(size_t)r];
+        const pa_pileup& p = rh.p;
+        for (int t = 0; t < regrecs[(size_t)r].n_tiles; ++t) tile_region[(size_t)(regrecs[(size_t)r].tile0 + t)] = r;
+        for (int32_t k = 0; k < p.n_reads; ++k) {
+            ReadRec& rd = reads[(size_t)(rh.read_base + k)];
+            const int64_t slen = p.seq_offset[k + 1] - p.seq_offset[k], ncig = p.cigar_offset[k + 1] - p.cigar_offset[k];
+            const int64_t row0 = p.read_pos[k] - p.region_start;
+            if (slen < 0 || ncig < 0 || slen > 0x7ffffff0) return pa::set_error(PA_ERR_INVALID, "offsets of read " + std::to_string(k) + " are not ascending");
+            rd.s0 = rh.seq_base + p.seq_offset[k];
+            rd.c0 = (int32_t)(rh.op_base + p.cigar_offset[k]);
+            rd.ncig = (int32_t)ncig;
+            rd.slen = (int32_t)slen;
+            rd.row0 = (int32_t)std::max<int64_t>(-(1 << 30), std::min<int64_t>(row0, 1 << 30));
+            rd.region = r;
+            rd.flags = (p.read_reverse[k] ? READ_REV : 0) | ((p.read_mapq[k] > 0 && row0 > -(1 << 30)) ? READ_MAPQ_OK : 0);
+        }
+    }
+    ENC_ALLOC(b.d_seq, (size_t)b.total_bases + 64);
+    ENC_ALLOC(b.d_cig_op, (size_t)b.total_ops * 4 + 1024);
+    ENC_ALLOC(b.d_cig_len, (size_t)b.total_ops * 4 + 1024);
+    ENC_ALLOC(b.d_reads, reads.size() * sizeof(ReadRec) + 64);
+    ENC_ALLOC(b.d_regions, regrecs.size() * sizeof(PRegRec) + 64);
+    ENC_ALLOC(b.d_tile_region, tile_region.size() * 4 + 64);
+    for (int r = 0; r < n_regions; ++r) {
+        const PRegHost& rh = b.regs[(size_t)r];
+        const pa_pileup& p = rh.p;
+        const int64_t nb = p.n_reads > 0 ? p.seq_offset[p.n_reads] : 0, no = p.n_reads > 0 ? p.cigar_offset[p.n_reads] : 0;
+        if (nb > 0) ENC_HIP(hipMemcpyAsync(b.d_seq.as<char>() + rh.seq_base, p.seq, (size_t)nb, hipMemcpyHostToDevice, st));
+        if (no > 0) {
+            ENC_HIP(hipMemcpyAsync(b.d_cig_op.as<int32_t>() + rh.op_base, p.cigar_op, (size_t)no * 4, hipMemcpyHostToDevice, st));
+            ENC_HIP(hipMemcpyAsync(b.d_cig_len.as<int32_t>() + rh.op_base, p.cigar_len, (size_t)no * 4, hipMemcpyHostToDevice, st));
+        }
+    }
+    if (!reads.empty()) ENC_HIP(hipMemcpyAsync(b.d_reads.p, reads.data(), reads.size() * sizeof(ReadRec), hipMemcpyHostToDevice, st));
+    ENC_HIP(hipMemcpyAsync(b.d_regions.p, regrecs.data(), regrecs.size() * sizeof(PRegRec), hipMemcpyHostToDevice, st));
+    if (!tile_region.empty()) ENC_HIP(hipMemcpyAsync(b.d_tile_region.p, tile_region.data(), tile_region.size() * 4, hipMemcpyHostToDevice, st));
+
+    // zeroed per run: counters | longest [rows] | tile_count | tile_fill
+    const size_t n_zero = (size_t)PC_N + (size_t)b.total_rows + 2 * (size_t)b.n_tiles;
+    ENC_ALLOC(b.d_zero, n_zero * 4);
+    ENC_ALLOC(b.d_tile_off, ((size_t)b.n_tiles + 1) * 4);
+    ENC_ALLOC(b.d_ins_base, (size_t)b.total_rows * 4 + 64);
+    ENC_ALLOC(b.d_totals, (size_t)n_regions * 4);
+    ENC_ALLOC(b.d_coverage, (size_t)b.total_rows * 4 + 64);
+    ENC_ALLOC(b.d_bases, (size_t)(3 * (size_t)n_regions + 1) * 8);
+    if (b.rec_cap == 0) b.rec_cap = 1024;
+    b.rec_cap = std::max<int>(b.rec_cap, (int)std::min<int64_t>(0x7ffffff0, b.total_bases / TP + 2 * b.total_reads + 1024));
+    int* counters = b.d_zero.as<int>();
+    int* longest = counters + PC_N;
+    int* tile_count = longest + b.total_rows;
+    int* tile_fill = tile_count + b.n_tiles;
+    std::vector<int> totals((size_t)n_regions);
+    std::vector<int64_t> bases(3 * (size_t)n_regions + 1);       // slot_base | out_base | out_pos_base
+    int host_counters[PC_N] = {0, 0, 0, 0};
+    for (int attempt = 0;; ++attempt) {
+        ENC_ALLOC(b.d_sorted, (size_t)b.rec_cap * sizeof(TileRec));
+        ENC_HIP(hipMemsetAsync(b.d_zero.p, 0, n_zero * 4, st));
+        ENC_HIP(hipEventRecord(e->ev[0], st));
+        const dim3 seg_grid((unsigned)((b.total_reads + 3) / 4));
+        if (b.total_reads > 0)
+            hipLaunchKernelGGL(polish_segment_kernel<false>, seg_grid, dim3(256), 0, st, b.d_reads.as<ReadRec>(), (int)b.total_reads,
+                               b.d_regions.as<PRegRec>(), b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), longest, tile_count,
+                               (const int*)nullptr, (int*)nullptr, (TileRec*)nullptr, 0, counters);
+        hipLaunchKernelGGL(polish_rows_kernel, dim3((unsigned)n_regions), dim3(1024), 0, st, b.d_regions.as<PRegRec>(), longest,
+                           b.d_ins_base.as<int>(), b.d_totals.as<int>());
+        if (b.n_tiles > 0)
+            hipLaunchKernelGGL(polish_tile_offsets_kernel, dim3(1), dim3(1024), 0, st, tile_count, b.n_tiles, b.d_tile_off.as<int>());
+        if (b.total_reads > 0)
+            hipLaunchKernelGGL(polish_segment_kernel<true>, seg_grid, dim3(256), 0, st, b.d_reads.as<ReadRec>(), (int)b.total_reads,
+                               b.d_regions.as<PRegRec>(), b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), longest, tile_count,
+                               b.d_tile_off.as<int>(), tile_fill, b.d_sorted.as<TileRec>(), b.rec_cap, counters);
+        ENC_HIP(hipGetLastError());
+        int n_recs = 0;
+        ENC_HIP(hipMemcpyAsync(totals.data(), b.d_totals.p, (size_t)n_regions * 4, hipMemcpyDeviceToHost, st));
+        ENC_HIP(hipMemcpyAsync(host_counters, counters, sizeof(host_counters), hipMemcpyDeviceToHost, st));
+        if (b.n_tiles > 0) ENC_HIP(hipMemcpyAsync(&n_recs, b.d_tile_off.as<int>() + b.n_tiles, 4, hipMemcpyDeviceToHost, st));
+        ENC_HIP(hipStreamSynchronize(st));
+        if (n_recs > b.rec_cap) {
+            if (attempt >= 2) return pa::set_error(PA_ERR_HIP, "encoder record buffers could not be sized");
+            b.rec_cap = n_recs + 1024;
+            continue;
+        }
+        break;
+    }
+    auto report = [&](int code) {
+        const int64_t g = code / 2 - 1;
+        size_t r = 0;
+        while (r + 1 < b.regs.size() && b.regs[r + 1].read_base <= g) ++r;
+        return pa::set_error(PA_ERR_INVALID, std::string(code & 1 ? "insert" : "CIGAR") + " of read " + std::to_string(g - b.regs[r].read_base) +
+                                                 (n_regions > 1 ? " of region " + std::to_string(r) : "") + " runs past its sequence");
+    };
+    if (host_counters[PC_ERR] > 0) return report(host_counters[PC_ERR]);
+    int64_t total_ins = 0;
+    b.total_out = 0;
+    for (int r = 0; r < n_regions; ++r) {
+        bases[(size_t)r] = total_ins;                                            // first insert slot of the region
+        bases[(size_t)n_regions + (size_t)r] = b.total_out;                      // first output row of the region
+        bases[2 * (size_t)n_regions + (size_t)r] = out_pos_base[(size_t)r];
+        b.region_rows[(size_t)r] = (b.regs[(size_t)r].end_pos - b.regs[(size_t)r].start_pos + 1) + totals[(size_t)r];
+        total_ins += totals[(size_t)r];
+        b.total_out += b.region_rows[(size_t)r];
+        if (n_rows) n_rows[r] = b.region_rows[(size_t)r];
+    }
+    bases[3 * (size_t)n_regions] = out_pos_base[(size_t)n_regions];
+    ENC_ALLOC(b.d_ins_counts, (size_t)(total_ins + 1) * PROW * 4);
+    ENC_ALLOC(b.d_pixels, (size_t)b.total_out * NF + 64);
+    ENC_ALLOC(b.d_positions, (size_t)b.total_out * 16 + 64);
+    ENC_HIP(hipMemcpyAsync(b.d_bases.p, bases.data(), bases.size() * 8, hipMemcpyHostToDevice, st));
+    ENC_HIP(hipMemsetAsync(b.d_ins_counts.p, 0, (size_t)(total_ins + 1) * PROW * 4, st));
+    ENC_HIP(hipMemsetAsync(b.d_pixels.p, 0, (size_t)b.total_out * NF + 64, st));
+    const int64_t* slot_base = b.d_bases.as<int64_t>();
+    const int64_t* out_base = slot_base + n_regions;
+    const int64_t* d_out_pos_base = out_base + n_regions;
+    ENC_HIP(hipEventRecord(e->ev[1], st));
+    if (b.n_tiles > 0) {
+        PTileArgs ta;
+        ta.reads = b.d_reads.as<ReadRec>();
+        ta.regions = b.d_regions.as<PRegRec>();
+        ta.tile_region = b.d_tile_region.as<int32_t>();
+        ta.cigar_op = b.d_cig_op.as<int32_t>();
+        ta.cigar_len = b.d_cig_len.as<int32_t>();
+        ta.seq = b.d_seq.as<char>();
+        ta.recs = b.d_sorted.as<TileRec>();
+        ta.tile_off = b.d_tile_off.as<int>();
+        ta.rec_cap = b.rec_cap;
+        ta.longest = longest;
+        ta.ins_base = b.d_ins_base.as<int>();
+        ta.slot_base = slot_base;
+        ta.out_base = out_base;
+        ta.ins_counts = b.d_ins_counts.as<int>();
+        ta.coverage = b.d_coverage.as<int>();
+        ta.pixels = b.d_pixels.as<uint8_t>();
+        ta.counters = counters;
+        hipLaunchKernelGGL(polish_tile_kernel, dim3((unsigned)b.n_tiles), dim3(NT), 0, st, ta);
+    }
+    ENC_HIP(hipEventRecord(e->ev[2], st));
+    const int64_t total_positions = out_pos_base[(size_t)n_regions];
+    hipLaunchKernelGGL(polish_insert_rows_kernel, dim3((unsigned)((total_positions + 255) / 256)), dim3(256), 0, st, b.d_regions.as<PRegRec>(),
+                       d_out_pos_base, n_regions, total_positions, longest, b.d_ins_base.as<int>(), slot_base, out_base,
+                       b.d_ins_counts.as<int>(), b.d_coverage.as<int>(), b.d_pixels.as<uint8_t>(), b.d_positions.as<int64_t>());
+    ENC_HIP(hipEventRecord(e->ev[3], st));
     ENC_HIP(hipGetLastError());
+    ENC_HIP(hipMemcpyAsync(host_counters, counters, sizeof(host_counters), hipMemcpyDeviceToHost, st));
     ENC_HIP(hipStreamSynchronize(st));
+    if (host_counters[PC_ERR] > 0) return report(host_counters[PC_ERR]);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); b.ms[0] = ms;     // segment passes + scans (+ the copy of the totals)
+    (void)hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); b.ms[1] = ms;     // polish_tile_kernel
+    (void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); b.ms[2] = ms;     // polish_insert_rows_kernel
     return PA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pa_polish_encoder_generate_summary_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const int64_t* start_pos,
+                                             const int64_t* end_pos, int64_t* n_rows) {
+    return polish_batch(e, n_regions, pileups, start_pos, end_pos, n_rows);
+}
+
+int pa_polish_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, int64_t start_pos, int64_t end_pos, int64_t* n_rows) {
+    if (!e || !p || !n_rows) return pa::set_error(PA_ERR_INVALID, "null argument");
+    return polish_batch(e, 1, p, &start_pos, &end_pos, n_rows);
 }
 
 int pa_polish_encoder_get_results(pa_encoder* e, uint8_t* image, int64_t* positions) {
     if (!e || !e->polish) return pa::set_error(PA_ERR_INVALID, "null encoder or no polish summary");
     ENC_HIP(hipSetDevice(e->device));
     pa_polish_batch& b = *e->polish;
-    if (positions) std::copy(b.p_positions.begin(), b.p_positions.end(), positions);
-    if (image && b.p_rows > 0) {
-        ENC_HIP(hipMemcpyAsync(image, b.d_ppix.p, (size_t)b.p_rows * 10, hipMemcpyDeviceToHost, e->stream));
+    if (b.total_out > 0) {
+        if (image) ENC_HIP(hipMemcpyAsync(image, b.d_pixels.p, (size_t)b.total_out * NF, hipMemcpyDeviceToHost, e->stream));
+        if (positions) ENC_HIP(hipMemcpyAsync(positions, b.d_positions.p, (size_t)b.total_out * 16, hipMemcpyDeviceToHost, e->stream));
         ENC_HIP(hipStreamSynchronize(e->stream));
     }
     return PA_OK;
 }
+
+int pa_polish_encoder_last_timing(pa_encoder* e, double* ms, int32_t n) {
+    if (!e || !ms || n < 0) return pa::set_error(PA_ERR_INVALID, "null argument");
+    for (int i = 0; i < n; ++i) ms[i] = (e->polish && i < 4) ? e->polish->ms[i] : 0.0;
+    return PA_OK;
+}
+
 }  // extern "C"

@@ -60,6 +60,42 @@ class SummaryGenerator(object):
         self._genomic_pos = None
 
 
+def generate_summaries(generators, reads_list, spans):
+    """Many regions through one set of launches (pa_polish_encoder_generate_summary_batch): generators[i] (SummaryGenerator
+    objects) with reads_list[i] (type_read-like objects or flatten_reads arrays) and spans[i] = (start_pos, end_pos).  Fills
+    every generator's .image / .positions_array as generate_summary does."""
+    if not generators:
+        return
+    lib, enc = _encoder(generators[0].device)
+    n = len(generators)
+    flats = [r if isinstance(r, dict) else flatten_reads(r) for r in reads_list]
+    keep = []
+    piles = (_Pileup * n)()
+    for i, (g, flat) in enumerate(zip(generators, flats)):
+        ref = g.reference_sequence.encode("latin-1") if isinstance(g.reference_sequence, str) else bytes(g.reference_sequence)
+        keep.append(ref)
+        piles[i] = _Pileup(g.ref_start, g.ref_end, ref, len(ref), flat["n_reads"], flat["read_pos"].ctypes.data,
+                           flat["read_reverse"].ctypes.data, flat["read_mapq"].ctypes.data, flat["seq_offset"].ctypes.data,
+                           flat["seq"].ctypes.data, flat["qual"].ctypes.data, flat["cigar_offset"].ctypes.data,
+                           flat["cigar_op"].ctypes.data, flat["cigar_len"].ctypes.data)
+    starts = np.array([int(s) for s, _ in spans], np.int64)
+    ends = np.array([int(e) for _, e in spans], np.int64)
+    rows = np.zeros(n, np.int64)
+    _lib.check(lib.pa_polish_encoder_generate_summary_batch(enc, n, ctypes.cast(piles, ctypes.c_void_p), starts.ctypes.data,
+                                                            ends.ctypes.data, rows.ctypes.data))
+    total = int(rows.sum())
+    image = np.zeros((total, 10), np.uint8)
+    pos = np.zeros((total, 2), np.int64)
+    _lib.check(lib.pa_polish_encoder_get_results(enc, image.ctypes.data, pos.ctypes.data))
+    at = 0
+    for g, k in zip(generators, rows):
+        k = int(k)
+        g.image = image[at:at + k]
+        g.positions_array = pos[at:at + k]
+        g._genomic_pos = None
+        at += k
+
+
 _realigners = {}
 
 

@@ -258,6 +258,70 @@ def test_encoder_object_interface_and_edges():
     assert _product(empty, params)["candidates"] == []
 
 
+def test_insert_in_front_of_the_first_aligned_base_on_a_tile_boundary():
+    """S I M reads that start exactly on row 512 / 1024: the insert is anchored on the last row of the previous tile, a tile
+    the read does not otherwise touch."""
+    rng = np.random.default_rng(91)
+    off, rows = 30_000, 1600
+    ref = pu.random_reference(rng, rows)
+    reads = pu.simulate_reads(rng, ref, off, n_reads=70, read_len=(300, 900))
+    for k in range(24):
+        row0 = 512 * (1 + k % 2)
+        n = 200 + 7 * k
+        ins = "ACGTTG"[:1 + k % 4]
+        reads.append(dict(pos=off + row0, reverse=bool(k % 2), mapq=30, seq="TT" + ins + ref[row0:row0 + n],
+                          qual=np.full(2 + len(ins) + n, 25, np.uint8), cigar=[(pu.OP_S, 2), (pu.OP_I, len(ins)), (pu.OP_M, n)]))
+    reads.sort(key=lambda r: r["pos"])
+    pile = pu.FlatPileup(off, off + rows - 1, ref, reads)
+    params = pu.make_params(off, off + rows - 1)
+    want = _both(pile, params)
+    assert any(c[0] == "2" for c, p in zip(want["candidates"], want["positions"]) if p - off in (511, 1023))
+    _check(_product(pile, params), want)
+    # the polish encoder counts the same inserts into the insert slots of rows 511 / 1023
+    from pepper_amd.polish.PEPPER import SummaryGenerator
+    want_img, want_pos = pu.run_polish_oracle(pu.load_restatement(), pile, off, off + rows - 1)
+    gen = SummaryGenerator(ref, "contig_1", off, off + rows - 1)
+    gen.generate_summary([R(d) for d in reads], off, off + rows - 1)
+    assert ((want_pos[:, 0] == off + 511) & (want_pos[:, 1] > 0)).any()
+    assert np.array_equal(gen.positions_array, want_pos) and np.array_equal(gen.image, want_img)
+
+
+def _polish_cases():
+    cases = []
+    for seed, kw in ((21, {}), (22, dict(ins_rate=0.04, del_rate=0.04)), (23, dict(skip_rate=0.01, eqx=True))):
+        rng = np.random.default_rng(seed)
+        ref = pu.random_reference(rng, 1201)
+        indels = {7300: ("I", "ACGTAC", 0.5), 7600: ("D", 9, 0.6), 7900: ("I", "T", 0.9), 7511: ("I", "GG", 0.7), 7512: ("D", 3, 0.7)}
+        reads = pu.simulate_reads(rng, ref, 7000, 90, read_len=(200, 700), indel_sites=indels, **kw)
+        cases.append((pu.FlatPileup(7000, 8200, ref, reads), reads, ref, 7000, 8200, 7000, 8200))
+    # reads simulated over 4 kb, the generator built on an inner 2.5 kb, summarised over a span that is wider on one side and
+    # narrower on the other: reads crossing both edges, deletions of hundreds of bases, rows outside the region (all zero)
+    rng = np.random.default_rng(24)
+    ref = pu.random_reference(rng, 4000)
+    reads = pu.simulate_reads(rng, ref, 50_000, 80, read_len=(800, 3500), max_indel=300, ins_rate=0.004, del_rate=0.004)
+    cases.append((pu.FlatPileup(50_700, 53_199, ref[700:3200], reads), reads, ref[700:3200], 50_700, 53_199, 50_650, 53_100))
+    return cases
+
+
+def test_polish_encoder_device_walk_and_batches():
+    """The polish walk on the device (tile records, insert slots by prefix sums) against the oracle restatement: single regions,
+    a span that differs from the generator's region, and all of them as one batch."""
+    from pepper_amd.polish.PEPPER import SummaryGenerator, generate_summaries
+    oracle = pu.load_restatement()
+    cases = _polish_cases()
+    wants = [pu.run_polish_oracle(oracle, c[0], c[5], c[6]) for c in cases]
+    for c, (want_img, want_pos) in zip(cases, wants):
+        gen = SummaryGenerator(c[2], "contig_1", c[3], c[4])
+        gen.generate_summary([R(d) for d in c[1]], c[5], c[6])
+        assert np.array_equal(gen.positions_array, want_pos)
+        assert np.array_equal(gen.image, want_img)
+    gens = [SummaryGenerator(c[2], "contig_1", c[3], c[4]) for c in cases]
+    generate_summaries(gens, [[R(d) for d in c[1]] for c in cases], [(c[5], c[6]) for c in cases])
+    for g, (want_img, want_pos) in zip(gens, wants):
+        assert np.array_equal(g.positions_array, want_pos) and np.array_equal(g.image, want_img)
+    assert wants[3][0].shape[0] > 53_100 - 50_650 + 1 and (wants[3][1][:50, 0] < 50_700).all()
+
+
 def test_polish_encoder_matches_oracle():
     """Polish summary encoder against the oracle restatement (itself pinned to the reference build by
     tests/test_encoder_oracle.py):
