@@ -57,6 +57,10 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names,
                       void* hip_stream, pa_variant_model** out);
 void pa_variant_destroy(pa_variant_model* m);
 
+/* Rows (windows) since creation whose MLP tile was re-run in plain f32 because an activation did not fit the f16-split
+ * operand format (|x| >= 65504 or NaN; simple_model.py:60-78 is f32 throughout): diagnostics, results are the f32 ones either way. */
+int pa_variant_overflow_rows(pa_variant_model* m, int64_t* rows);
+
 /* forward(x, train_mode=False): images int8 [n, window, image_features] (the dtype the images
  * HDF5 stores: pepper_variant/modules/python/DataStore.py:68) -> probs float32 [n, classes].
  * logits (pre-softmax, = forward(x, train_mode=True)) may be NULL.  All pointers are DEVICE

@@ -480,6 +480,7 @@ struct pa_variant_model : ModelBase {
     std::vector<RecLayer> rec;   // encoder layers then decoder layers
     Linear lin[5], out;
     DevBuf *mlp_w = nullptr, *mlp_b = nullptr;   // linear_2..5 as h2 fragments + their biases (mlp_h2.hip)
+    DevBuf *mlp_w32 = nullptr;   // device array of the four f32 weight pointers + the out-of-range row counter behind them
     DevBuf *xp, *ya, *yb, *l1, *l2, *stage_in[2], *stage_p[2], *stage_l[2];
 };
 
@@ -545,6 +546,13 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
             if (rc == PA_OK && hipMemcpy(m->mlp_w->p, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
                 rc = fail(PA_ERR_HIP, "upload of the packed MLP weights failed");
             if (rc == PA_OK) rc = upload(m->mlp_b, b4);
+            if (rc == PA_OK) {      // the f32 matrices the kernel re-runs a tile on when an activation leaves the f16 range
+                const float* ptrs[5] = {m->lin[1].w->f(), m->lin[2].w->f(), m->lin[3].w->f(), m->lin[4].w->f(), nullptr};
+                m->mlp_w32 = m->new_buf();
+                rc = m->mlp_w32->ensure(sizeof(ptrs));
+                if (rc == PA_OK && hipMemcpy(m->mlp_w32->p, ptrs, sizeof(ptrs), hipMemcpyHostToDevice) != hipSuccess)
+                    rc = fail(PA_ERR_HIP, "upload of the MLP weight table failed");
+            }
         }
     }
     if (rc != PA_OK) {
@@ -669,7 +677,8 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     if (m->mlp_w != nullptr && C <= 8) {
         LAUNCH_TRY(m, "mlp_tail_h2", 2.0 * n * m->L1 * (4.0 * m->L1 + C),
                    pa::launch_mlp_tail_h2(m->l1->f(), m->L1, m->mlp_w->p, m->mlp_b->f(), 4, m->out.w->f(), m->out.b->f(), C,
-                                          probs, logits, (int)n, m->stream));
+                                          probs, logits, (int)n, m->stream, static_cast<const float* const*>(m->mlp_w32->p),
+                                          reinterpret_cast<int*>(static_cast<char*>(m->mlp_w32->p) + 4 * sizeof(float*))));
         return PA_OK;
     }
     float* a = m->l1->f();
@@ -700,6 +709,18 @@ static int variant_forward(pa_variant_model* m, int a_kind, const void* images, 
                                            logits ? logits + off * C : nullptr))
             return rc;
     }
+    return PA_OK;
+}
+
+int pa_variant_overflow_rows(pa_variant_model* m, int64_t* rows) {
+    if (!m || m->magic != 0x50414d44 || !rows) return fail(PA_ERR_INVALID, "bad model handle");
+    HIP_TRY(hipSetDevice(m->device));
+    int v = 0;
+    if (m->mlp_w32 != nullptr) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        HIP_TRY(hipMemcpy(&v, static_cast<char*>(m->mlp_w32->p) + 4 * sizeof(float*), sizeof(int), hipMemcpyDeviceToHost));
+    }
+    *rows = v;
     return PA_OK;
 }
 

@@ -93,8 +93,11 @@ hipError_t launch_polish_combine(const float* P, const float* bias, float* acc, 
 // mlp_h2.hip: linear_2..5 (512 -> 512, SELU) + output layer + softmax fused, 64 rows per workgroup.
 void pack_mlp_weights_h2(const float* const* W, int NL, uint32_t* out);
 size_t mlp_weights_h2_words(int NL);
+// W32: DEVICE array of the NL f32 weight matrices [512][512] (the exact re-run of a 64-row tile in which an activation left the
+// f16 range: >= 65504 or NaN); overflow_rows (device counter, may be null) counts the rows that took it.
 hipError_t launch_mlp_tail_h2(const float* X, int ldx, const void* Wp, const float* bias, int NL, const float* Wout,
-                              const float* bout, int C, float* probs, float* logits, int n, hipStream_t stream);
+                              const float* bout, int C, float* probs, float* logits, int n, hipStream_t stream,
+                              const float* const* W32, int* overflow_rows);
 
 // head.hip
 hipError_t launch_dense_small(int mode, const float* X, int ldx, const float* W, const float* bias,

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __rest
                                                              const float* __restrict__ Wout,       // [C][512]
                                                              const float* __restrict__ bout, int C,
                                                              float* __restrict__ probs, float* __restrict__ logits,
-                                                             int n) {
+                                                             int n, const float* const* __restrict__ W32,  // [NL] f32 [512][512]: exact re-run
+                                                             int* __restrict__ overflow_rows) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];      // [MT][ROWD]
     static_assert((ROWB / 16) % 2 == 1, "row stride must be an odd number of 16-byte slots");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -38,6 +39,10 @@ __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __rest
     const int li = lane & 31, hf = lane >> 5;
     const int b0 = blockIdx.x * MT;
 
+    // An activation of 65504 or more (or a NaN) does not fit the hi half of the h2 format: every conversion below checks its
+    // value, and a workgroup that saw one re-runs its 64 rows with plain f32 arithmetic at the end (simple_model.py:60-78 is
+    // f32 throughout): never a silent inf / NaN.
+    bool bad = false;
     // ---- stage the f32 input rows as h2: thread = (row, eight groups of 8 columns) ----
     {
         const int row = tid >> 3, gsel = tid & 7;              // 64 rows x 8 threads
@@ -53,6 +58,7 @@ __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __rest
             h8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+                bad |= !(fabsf(v[e]) < 65504.0f);
                 hi[e] = (_Float16)v[e];
                 lo[e] = (_Float16)(v[e] - (float)hi[e]);
             }
@@ -132,10 +138,48 @@ __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __rest
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = selu_f(acc[m][nn][r]);
+                    bad |= !(fabsf(v) < 65504.0f);
                     dst[(32 * m + (r & 3) + 8 * (r >> 2)) * ROWD] = h2_word_of(v, h2_select(odd));
                 }
         }
         lds_barrier();                      // next layer's input visible
+    }
+
+    // ---- out-of-range activations somewhere in these 64 rows: the layers again, in f32, from the f32 input ----
+    const bool rerun = __syncthreads_or(bad ? 1 : 0) != 0;
+    float* frow = reinterpret_cast<float*>(lds);       // the same 2064-byte rows, now [64][516] f32
+    if (rerun) {
+        if (tid == 0 && overflow_rows != nullptr) atomicAdd(overflow_rows, n - b0 < MT ? n - b0 : MT);
+        for (int i = tid; i < MT * D; i += 512) {
+            const int row = i / D, col = i - row * D;
+            const int grow = b0 + row < n ? b0 + row : n - 1;
+            frow[row * ROWD + col] = X[(size_t)grow * ldx + col];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int layer = 0; layer < NL; ++layer) {
+            const float* wr = W32[layer] + (size_t)tid * D;      // thread = output unit, all 64 rows
+            float y[MT];
+            const float bv = bias[layer * D + tid];
+#pragma unroll
+            for (int r = 0; r < MT; ++r) y[r] = bv;
+#pragma unroll 1
+            for (int k = 0; k < D; k += 4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+#pragma unroll
+                for (int r = 0; r < MT; ++r) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(frow + r * ROWD + k);     // one address per wave: broadcast
+                    y[r] = fmaf(xv.x, wv.x, y[r]);
+                    y[r] = fmaf(xv.y, wv.y, y[r]);
+                    y[r] = fmaf(xv.z, wv.z, y[r]);
+                    y[r] = fmaf(xv.w, wv.w, y[r]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < MT; ++r) frow[r * ROWD + tid] = selu_f(y[r]);
+            __syncthreads();
+        }
     }
 
     // ---- output layer + softmax: wave w takes rows 8w .. 8w+7, lane = one group of 8 columns ----
@@ -150,7 +194,7 @@ __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __rest
         const h8 lo = *reinterpret_cast<const h8*>(lds + row * ROWD + lane * 8 + 4);
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = (float)hi[e] + (float)lo[e];
+        for (int e = 0; e < 8; ++e) x[e] = rerun ? frow[row * ROWD + lane * 8 + e] : (float)hi[e] + (float)lo[e];
         float logit[8], mx = -INFINITY;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -203,12 +247,13 @@ void pack_mlp_weights_h2(const float* const* W, int NL, uint32_t* out) {
 size_t mlp_weights_h2_words(int NL) { return (size_t)NL * NTILES * KS * 2 * 256; }
 
 hipError_t launch_mlp_tail_h2(const float* X, int ldx, const void* Wp, const float* bias, int NL, const float* Wout,
-                              const float* bout, int C, float* probs, float* logits, int n, hipStream_t stream) {
+                              const float* bout, int C, float* probs, float* logits, int n, hipStream_t stream,
+                              const float* const* W32, int* overflow_rows) {
     if (n <= 0) return hipSuccess;
-    if (NL != 4 || C > 8 || C <= 0 || (ldx & 3)) return hipErrorInvalidValue;
+    if (NL != 4 || C > 8 || C <= 0 || (ldx & 3) || W32 == nullptr) return hipErrorInvalidValue;
     const size_t lds = (size_t)MT * ROWB;
     hipLaunchKernelGGL((mlp_tail_h2_kernel<4>), dim3((n + MT - 1) / MT), dim3(512), lds, stream, X, ldx,
-                       static_cast<const uint32_t*>(Wp), bias, Wout, bout, C, probs, logits, n);
+                       static_cast<const uint32_t*>(Wp), bias, Wout, bout, C, probs, logits, n, W32, overflow_rows);
     return hipGetLastError();
 }
 

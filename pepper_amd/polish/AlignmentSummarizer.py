@@ -153,4 +153,18 @@ class AlignmentSummarizer:
                     done.extend(group)
                 lo = hi
             reads = done
-        return [s.summarise(r) for s, r in zip(summarizers, reads)]
+        # ... and ONE summary-encoder call for the regions that have reads (pa_polish_encoder_generate_summary_batch)
+        gens, flats, spans, live = [], [], [], []
+        for k, (s, r) in enumerate(zip(summarizers, reads)):
+            if len(r) == 0:
+                continue
+            ref_seq = s.fasta_handler.get_reference_sequence(s.chromosome_name, s.region_start_position, s.region_end_position + 1)
+            gens.append(PEPPER.SummaryGenerator(ref_seq, s.chromosome_name, s.region_start_position, s.region_end_position))
+            flats.append(r.as_pileup() if hasattr(r, "as_pileup") else r)
+            spans.append((s.region_start_position, s.region_end_position))
+            live.append(k)
+        PEPPER.generate_summaries(gens, flats, spans)
+        out = [([], [], [], [])] * len(summarizers)
+        for k, g in zip(live, gens):
+            out[k] = summarizers[k].chunk_images(g, chunk_size=ImageSizeOptions.SEQ_LENGTH, chunk_overlap=ImageSizeOptions.SEQ_OVERLAP)
+        return out

@@ -31,7 +31,9 @@ class AlignmentSummarizer:
         self.region_start_position = region_start
         self.region_end_position = region_end
 
-    def create_summary(self, options, bed_list, thread_id, as_arrays=False):
+    def prepare(self, options):
+        """Everything of create_summary up to the encoder call: reads of the padded region (sampled down as the reference
+        does), its reference.  -> (generator, reads, encoder arguments) or None when the region has no reads."""
         if getattr(options, "train_mode", False):
             raise NotImplementedError("train_mode image generation is outside the inference path")
         region_start = max(0, self.region_start_position - ConsensCandidateFinder.REGION_SAFE_BASES)
@@ -63,12 +65,30 @@ class AlignmentSummarizer:
         regional_summary.generate_max_insert_summary(all_reads)
         if flat:
             all_reads = all_reads.as_pileup()
-        args = (all_reads, options.min_snp_baseq, options.min_indel_baseq, options.snp_frequency,
+        args = (options.min_snp_baseq, options.min_indel_baseq, options.snp_frequency,
                 options.insert_frequency, options.delete_frequency, options.min_coverage_threshold,
                 options.snp_candidate_frequency_threshold, options.indel_candidate_frequency_threshold,
                 options.candidate_support_threshold, options.skip_indels, self.region_start_position,
                 self.region_end_position, ImageSizeOptions.CANDIDATE_WINDOW_SIZE, ImageSizeOptions.IMAGE_HEIGHT,
                 False)
+        return regional_summary, all_reads, args
+
+    def create_summary(self, options, bed_list, thread_id, as_arrays=False):
+        prepared = self.prepare(options)
+        if prepared is None:
+            return None
+        regional_summary, all_reads, args = prepared
         if as_arrays:
-            return regional_summary.generate_summary_arrays(*args)
-        return regional_summary.generate_summary(*args)
+            return regional_summary.generate_summary_arrays(all_reads, *args)
+        return regional_summary.generate_summary(all_reads, *args)
+
+
+def create_summaries(prepared):
+    """The encoder call of several regions at once (pa_encoder_generate_summary_batch: one workgroup per 512-position tile, a
+    batch fills the chip where one region does not).  prepared: results of AlignmentSummarizer.prepare (None entries are
+    regions without reads) -> the arrays of generate_summary_arrays per region, None where the region had no reads."""
+    live = [p for p in prepared if p is not None]
+    out = iter(PEPPER_VARIANT.generate_summary_arrays_batch(
+        [p[0] for p in live], [p[1] for p in live], *live[0][2][:10], [(p[2][10], p[2][11]) for p in live],
+        live[0][2][12], live[0][2][13], live[0][2][14])) if live else iter(())
+    return [None if p is None else next(out) for p in prepared]

@@ -52,6 +52,15 @@ class ImageGenerator:
                                          start_position, end_position)
         return summarizer.create_summary(options, bed_list, thread_id, as_arrays=as_arrays)
 
+    def prepare(self, options, start_position, end_position):
+        """The part of generate_summary in front of the encoder call (reads + reference of the interval), for the callers
+        that encode several intervals per call."""
+        if getattr(options, "use_hp_info", False):
+            raise NotImplementedError("--use_hp_info image generation feeds a predictor that is non-functional "
+                                      "in the reference at this commit (SURVEY.md 2.1 V13)")
+        return AlignmentSummarizer(self.bam_handler, self.fasta_handler, self.chromosome_name, start_position,
+                                   end_position).prepare(options)
+
 
 class ImageGenerationUtils:
     @staticmethod
@@ -124,18 +133,24 @@ class ImageGenerationUtils:
         intervals = [r for i, r in enumerate(all_intervals) if i % options.threads == process_id]
         if process_id == 0:
             _log("INFO: STARTING PROCESS: " + str(process_id) + " FOR " + str(len(intervals)) + " INTERVALS")
+        # intervals are encoded ENCODER_BATCH at a time: the reads of a group are fetched (BAM reader, outside the GIL), then one
+        # encoder call covers the group; summaries are written per interval under the reference's group names, in its order
+        batch = max(1, int(getattr(options, "encoder_batch", 0) or os.environ.get("PEPPER_AMD_ENCODER_BATCH", 16)))
+        from pepper_amd.variant.AlignmentSummarizer import create_summaries
         with DataStore(file_name, 'w') as output_hdf_file:
-            for chr_name, _start, _end in intervals:
-                generator = ImageGenerator(chr_name, options.bam, options.fasta, options)
-                out = generator.generate_summary(options, _start, _end, bed_list, process_id, as_arrays=True)
-                if out is None:
-                    continue
-                n = len(out["candidates"])
-                summary_name = chr_name + "_" + str(_start) + "_" + str(_end)
-                output_hdf_file.write_summary(summary_name, [chr_name] * n, out["positions"], out["depths"],
-                                              np.array(out["candidates"], dtype=object).reshape(n, 1),
-                                              out["candidate_frequency"].reshape(n, 1), out["images"],
-                                              [0] * n, [0] * n, False)
+            for g0 in range(0, len(intervals), batch):
+                group = intervals[g0:g0 + batch]
+                prepared = [ImageGenerator(chr_name, options.bam, options.fasta, options).prepare(options, _start, _end)
+                            for chr_name, _start, _end in group]
+                for (chr_name, _start, _end), out in zip(group, create_summaries(prepared)):
+                    if out is None:
+                        continue
+                    n = len(out["candidates"])
+                    summary_name = chr_name + "_" + str(_start) + "_" + str(_end)
+                    output_hdf_file.write_summary(summary_name, [chr_name] * n, out["positions"], out["depths"],
+                                                  np.array(out["candidates"], dtype=object).reshape(n, 1),
+                                                  out["candidate_frequency"].reshape(n, 1), out["images"],
+                                                  [0] * n, [0] * n, False)
         return process_id
 
     @staticmethod

@@ -177,3 +177,44 @@ def test_variant_run_to_run_determinism():
     b.close()
     assert np.array_equal(p0, p1) and np.array_equal(l0, l1)
     assert np.array_equal(p0, p2) and np.array_equal(l0, l2)
+
+
+def _overflow_rows(m):
+    rows = ctypes.c_int64()
+    _lib.check(m.lib.pa_variant_overflow_rows(m.h, ctypes.byref(rows)))
+    return rows.value
+
+
+@pytest.mark.parametrize("case", ["linear_1_bias", "mlp_x38", "mlp_x40"])
+def test_activations_beyond_the_f16_range_get_the_f32_results(case):
+    """The split-f16 operand format holds |x| < 65504.  Checkpoints whose weights are all small (so the split kernels are
+    chosen) but whose dense-layer ACTIVATIONS leave that range -- a huge linear_1 bias; linear_2..4 scaled so that the
+    fourth layer's output passes 65504 in some rows (x38) or most rows (x40) -- must give the f32 reference's probabilities
+    (simple_model.py:60-78 is f32 throughout), never inf / NaN: the MLP kernel re-runs the 64-row tiles concerned in f32 and
+    counts them."""
+    sd = synthetic.variant_state_dict(seed=5, gain=2.0)
+    if case == "linear_1_bias":
+        sd["linear_1.bias"][:32] = 2e5
+    else:
+        for name in ("linear_2", "linear_3", "linear_4"):
+            sd[name + ".weight"] *= float(case[5:])
+        sd["linear_5.weight"] *= 1e-4
+    assert max(np.abs(v).max() for k, v in sd.items() if "weight" in k) < 64          # stays on the split kernels
+    x = synthetic.variant_windows(300, seed=3)
+    with np.errstate(over="ignore"):
+        ref, inter = models_np.variant_forward(sd, x, return_intermediates=True)
+    m = NativeVariant(sd)
+    assert _overflow_rows(m) == 0
+    probs, logits = m.forward(x)
+    rows = _overflow_rows(m)
+    m.close()
+    assert np.isfinite(probs).all() and np.isfinite(logits).all()
+    assert 0 < rows <= 300
+    assert np.abs(probs - ref).max() < TOL
+    assert np.abs(logits - inter["logits"]).max() < TOL * max(1.0, np.abs(inter["logits"]).max())
+    # and a checkpoint inside the range never takes that path
+    sd0 = synthetic.variant_state_dict(seed=5, gain=2.0)
+    m0 = NativeVariant(sd0)
+    m0.forward(x)
+    assert _overflow_rows(m0) == 0
+    m0.close()
