@@ -98,9 +98,44 @@ def _in_repeat(fasta_handler, contig, position):
     return bool(window) and max(window) >= 5
 
 
+def _in_repeat_many(window, contig, positions):
+    """_in_repeat and the upper-cased reference base for many positions of one contig out of the window's text: run lengths
+    of the whole window once, then for each position the longest run among [position-5, position+4) as the 20-base context
+    ref[position-10, position+10) sees it (a run is cut at the context's edges, which are also cut at the contig's)."""
+    positions = np.asarray(positions, dtype=np.int64)
+    text = window.text
+    if text is None or len(text) == 0:
+        bases = [window.get_reference_sequence(contig, int(p), int(p) + 1).upper() for p in positions]
+        return bases, [_in_repeat(window, contig, int(p)) for p in positions]
+    t = np.frombuffer(text.upper().encode("latin-1"), np.uint8)
+    m = len(t)
+    change = np.empty(m, bool)
+    change[0] = True
+    np.not_equal(t[1:], t[:-1], out=change[1:])
+    starts = np.flatnonzero(change)
+    run_id = np.cumsum(change) - 1
+    run_start = starts[run_id]
+    run_end = np.append(starts[1:], m)[run_id]
+    q = positions - window.lo
+    inside = (q >= 0) & (q < m)
+    qc = np.clip(q, 0, m - 1)
+    ctx_lo = np.maximum(np.maximum(positions - 10, 0) - window.lo, 0)
+    ctx_hi = np.minimum(q + 10, m)
+    flag = np.zeros(len(positions), bool)
+    for k in range(-5, 4):
+        idx = q + k
+        ok = (idx >= ctx_lo) & (idx < ctx_hi)
+        ic = np.clip(idx, 0, m - 1)
+        run = np.minimum(run_end[ic], ctx_hi) - np.maximum(run_start[ic], ctx_lo)
+        flag |= ok & (run >= 5)
+    letters = t[qc]
+    bases = [chr(c) if ok else "" for c, ok in zip(letters.tolist(), inside.tolist())]
+    return bases, (flag & inside).tolist()
+
+
 def _select_site(options, contig, position, depth, alleles, supports, prediction, reference_base, in_repeat):
     """One site -> (margin tuple or None, re-genotyping tuple or None)."""
-    predicted_genotype = int(np.argmax(prediction))
+    predicted_genotype = max(range(len(prediction)), key=prediction.__getitem__)      # first maximum, as numpy.argmax
     genotype = ([0, 0], [0, 1], [1, 1])[predicted_genotype]
     prediction_value = prediction[predicted_genotype]
     non_alt_prediction = max(prediction[1], prediction[2])
@@ -168,25 +203,34 @@ def small_chunk_stitch(options, file_chunks):
             candidate_frequencies = hdf5_file[base + "candidate_frequency"]
             base_predictions = np.asarray(hdf5_file[base + "base_prediction"]).astype(np.float32)
 
-        windows = {}
-        for i in range(len(contigs)):
-            contig = contigs[i].decode("UTF-8") if isinstance(contigs[i], bytes) else str(contigs[i])
-            position = int(positions[i])
-            window = windows.get(contig)
-            if window is None:
-                same = [int(positions[k]) for k in range(len(contigs)) if contigs[k] == contigs[i]]
-                window = windows[contig] = _ReferenceWindow(fasta_handler, contig, min(same) - 16, max(same) + 16)
-            depth = int(depths[i])
-            alleles = _parse_list_field(candidates[i])
-            supports = [int(x) for x in _parse_list_field(candidate_frequencies[i])]
-            prediction = [float(v) for v in base_predictions[i]]
-
-            reference_base = window.get_reference_sequence(contig, position, position + 1).upper()
+        n = len(contigs)
+        if n == 0:
+            continue
+        # per batch, with numpy: the contig groups, one reference fetch per group, the reference base and the low-complexity
+        # flag of every position (_in_repeat_many); the per-site rules then run on plain Python scalars
+        names = [c.decode("UTF-8") if isinstance(c, bytes) else str(c) for c in (contigs.tolist() if hasattr(contigs, "tolist") else contigs)]
+        pos = np.asarray(positions, dtype=np.int64).reshape(n)
+        ref_bases = [""] * n
+        in_repeats = [False] * n
+        for contig in dict.fromkeys(names):
+            rows = np.array([k for k in range(n) if names[k] == contig], dtype=np.int64) if len(set(names)) > 1 else np.arange(n)
+            p_rows = pos[rows]
+            window = _ReferenceWindow(fasta_handler, contig, int(p_rows.min()) - 16, int(p_rows.max()) + 16)
+            bases, flags = _in_repeat_many(window, contig, p_rows)
+            for k, base, flag in zip(rows.tolist(), bases, flags):
+                ref_bases[k] = base
+                in_repeats[k] = flag
+        depth_list = np.asarray(depths).reshape(n).tolist()
+        prediction_rows = base_predictions.reshape(n, -1).tolist()           # float32 values as Python floats
+        position_list = pos.tolist()
+        for i in range(n):
+            reference_base = ref_bases[i]
             if reference_base not in _BASES or len(reference_base) != 1:
                 continue
-            in_repeat = _in_repeat(window, contig, position)
-            margin, calling = _select_site(options, contig, position, depth, alleles, supports, prediction,
-                                           reference_base, in_repeat)
+            alleles = _parse_list_field(candidates[i])
+            supports = [int(x) for x in _parse_list_field(candidate_frequencies[i])]
+            margin, calling = _select_site(options, names[i], position_list[i], int(depth_list[i]), alleles, supports,
+                                           prediction_rows[i], reference_base, in_repeats[i])
             if margin is not None:
                 selected_candidate_list_margin.append(margin)
             if calling is not None:

@@ -13,6 +13,7 @@ with six significant digits as htslib's kputd does.  Text rendering is UNPINNED 
 (absent here); the selection logic is covered by hand-derived cases in tests/test_candidate_finder.py.
 """
 import math
+import struct
 
 import numpy as np
 
@@ -20,9 +21,15 @@ from pepper_amd.variant.bgzf import BgzfWriter, TabixBuilder
 from pepper_amd.variant.fasta import FASTA_handler
 
 
+_F32 = struct.Struct("f")
+
+
 def _fmt_float(value):
     """BCF keeps floats as float32; htslib prints them with %g-like 6 significant digits."""
-    v = float(np.float32(value))
+    try:
+        v = _F32.unpack(_F32.pack(value))[0]           # round to float32 (what float(np.float32(value)) gives, 5x cheaper)
+    except OverflowError:
+        v = float(np.float32(value))
     if v != v:
         return "."
     if v == int(v) and abs(v) < 1e6:
@@ -40,7 +47,7 @@ def _picklable_options(options):
 class _VcfFile(object):
     def __init__(self, path, header_text):
         self.path = path
-        self._out = BgzfWriter(path)
+        self._out = BgzfWriter(path, deferred=True)
         self._out.write(header_text)
         self._index = TabixBuilder()
 
@@ -53,9 +60,10 @@ class _VcfFile(object):
 
     def close(self):
         if self._out is not None:
-            self._out.close()
+            out = self._out
+            out.close()
             self._out = None
-            self._index.write(self.path + ".tbi")
+            self._index.write(self.path + ".tbi", resolve=out.resolve)
 
 
 class VCFWriter:
@@ -118,7 +126,7 @@ class VCFWriter:
                 alt_allele = [alt + suffix for alt in alt_allele]
 
             site_in_repeat = in_repeat or site_in_repeat
-            predicted_genotype = int(np.argmax(predictions))
+            predicted_genotype = max(range(len(predictions)), key=predictions.__getitem__)   # first maximum, as numpy.argmax
             if predicted_genotype != 0:
                 gt_qual = predictions[predicted_genotype] if gt_qual < 0 else min(gt_qual, predictions[predicted_genotype])
             elif gt_qual < 0:
@@ -203,7 +211,8 @@ class VCFWriter:
         threads = max(1, int(getattr(options, "threads", 1) or 1))
         block = 4096
         blocks = [sites[i:i + block] for i in range(0, len(sites), block)]
-        if threads > 1 and len(blocks) > 1:
+        # (worker processes pay for pickling the site tuples both ways: below a few hundred thousand sites one process is faster)
+        if threads > 1 and len(sites) >= 400000:
             import concurrent.futures
             plain = _picklable_options(options)
             with concurrent.futures.ProcessPoolExecutor(max_workers=threads) as executor:

@@ -23,16 +23,43 @@ def _block(data, level=6):
     return head + body + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
 
 
-class BgzfWriter(object):
-    """Buffered BGZF writer; `tell()` returns the virtual offset of the next byte written."""
+_pool = None
 
-    def __init__(self, path):
+
+def _compress_pool():
+    """Threads for the deferred writers (zlib releases the GIL while it deflates a block)."""
+    global _pool
+    if _pool is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 2)), thread_name_prefix="bgzf")
+    return _pool
+
+
+class BgzfWriter(object):
+    """Buffered BGZF writer; `tell()` returns the virtual offset of the next byte written.
+
+    deferred=True: blocks are deflated on a thread pool and written, in order, at close(); `tell()` then returns
+    (block number << 16 | offset in the block) and `resolve()` turns such a value into the real virtual offset once the file
+    is closed (the tabix builder keeps the provisional values and resolves them when it writes the index)."""
+
+    def __init__(self, path, deferred=False):
         self._fh = open(path, "wb")
         self._buf = bytearray()
         self._coffset = 0
+        self._deferred = deferred
+        self._pending = []
+        self._block_offsets = [0]
 
     def tell(self):
+        if self._deferred:
+            return (len(self._pending) << 16) | len(self._buf)
         return (self._coffset << 16) | len(self._buf)
+
+    def resolve(self, provisional):
+        if not self._deferred:
+            return provisional
+        return (self._block_offsets[provisional >> 16] << 16) | (provisional & 0xffff)
 
     def write(self, data):
         if isinstance(data, str):
@@ -50,15 +77,24 @@ class BgzfWriter(object):
 
     def _flush_block(self):
         if self._buf:
-            blk = _block(bytes(self._buf))
-            self._fh.write(blk)
-            self._coffset += len(blk)
+            if self._deferred:
+                self._pending.append(_compress_pool().submit(_block, bytes(self._buf)))
+            else:
+                blk = _block(bytes(self._buf))
+                self._fh.write(blk)
+                self._coffset += len(blk)
             self._buf = bytearray()
 
     def close(self):
         if self._fh is None:
             return
         self._flush_block()
+        for fut in self._pending:
+            blk = fut.result()
+            self._fh.write(blk)
+            self._coffset += len(blk)
+            self._block_offsets.append(self._coffset)
+        self._pending = []
         self._fh.write(_EOF)
         self._fh.close()
         self._fh = None
@@ -118,7 +154,10 @@ class TabixBuilder(object):
             if w not in lin:
                 lin[w] = vbeg
 
-    def write(self, path):
+    def write(self, path, resolve=None):
+        """resolve: maps the stored offsets to virtual file offsets (BgzfWriter.resolve of a deferred writer)."""
+        if resolve is None:
+            resolve = int
         names = b"".join(n.encode() + b"\0" for n in self.names)
         out = bytearray(b"TBI\1")
         # n_ref, format (2 = VCF), col_seq, col_beg, col_end, meta char, skip, l_nm
@@ -130,14 +169,14 @@ class TabixBuilder(object):
             for b in sorted(bins):
                 out += struct.pack("<Ii", b, len(bins[b]))
                 for beg, end in bins[b]:
-                    out += struct.pack("<QQ", beg, end)
+                    out += struct.pack("<QQ", resolve(beg), resolve(end))
             lin = self._lin[tid]
             n_intv = (max(lin) + 1) if lin else 0
             out += struct.pack("<i", n_intv)
             last = 0
             for w in range(n_intv):
                 last = lin.get(w, last)        # empty windows inherit the previous offset, as htslib fills them
-                out += struct.pack("<Q", last)
+                out += struct.pack("<Q", resolve(last) if last else 0)
         w = BgzfWriter(path)
         w.write(bytes(out))
         w.close()

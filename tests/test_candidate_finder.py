@@ -300,3 +300,31 @@ def test_vcfs_do_not_depend_on_the_number_of_worker_processes(tmp_path):
         process_candidates(options(fasta=fa, threads=threads), str(tmp_path / "pred"), out)
         digests.append({f: hashlib.md5(open(out + "/" + f, "rb").read()).hexdigest() for f in sorted(os.listdir(out))})
     assert len(digests[0]) == 10 and digests[0] == digests[1]
+
+
+def test_low_complexity_flags_of_a_batch_equal_the_per_site_scan():
+    """_in_repeat_many (run lengths of one fetched window, all positions of a batch at once) against _in_repeat (the
+    reference's per-site scan of the 20-base context, CandidateFinder.py:397-418) -- including positions within ten bases
+    of either end of the contig, where the context is cut."""
+    from pepper_amd.variant import CandidateFinder as cf
+
+    class Fasta(object):
+        def __init__(self, text):
+            self.text = text
+
+        def get_reference_sequence(self, contig, start, stop):
+            return self.text[max(0, start):max(0, stop)]
+    rng = np.random.default_rng(3)
+    pieces = []
+    while sum(len(p) for p in pieces) < 3000:
+        pieces.append("ACGTacgtN"[int(rng.integers(0, 9))] * int(rng.choice([1, 1, 1, 2, 3, 4, 5, 6, 9])))
+    text = "".join(pieces)
+    fasta = Fasta(text)
+    positions = np.unique(np.concatenate([np.arange(0, 25), np.arange(len(text) - 25, len(text) + 3), rng.integers(0, len(text), 400)]))
+    window = cf._ReferenceWindow(fasta, "c", int(positions.min()) - 16, int(positions.max()) + 16)
+    bases, flags = cf._in_repeat_many(window, "c", positions)
+    assert any(flags) and not all(flags)
+    for p, b, f in zip(positions.tolist(), bases, flags):
+        assert b == fasta.get_reference_sequence("c", p, p + 1).upper()
+        if b:
+            assert f == cf._in_repeat(fasta, "c", p), p
