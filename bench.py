@@ -62,6 +62,10 @@ def parse():
                          "regions of 1500 simulated reads, reads/s and DP cell updates/s; encoder = the variant pileup -> "
                          "summary encoder (the other half of north_star's hot path) on a batch of 64 E-syn regions of 100 kb "
                          "at 60x, aligned bases/s, HBM roofline, the reference's own C++ as the CPU baseline")
+    ap.add_argument("--workload", choices=["v-syn", "wg-syn"], default="v-syn",
+                    help="variant model only.  v-syn (default): every rank streams its own pool, weak scaling.  wg-syn: a FIXED job of "
+                         "24 chromosome-sized shards of V-syn windows dealt over the ranks (strong scaling; SURVEY.md 8(d)), once with "
+                         "the reference's round robin and once largest-first onto the least loaded rank; per-rank times in the line")
     ap.add_argument("--per-gpu", type=int, default=0, help="windows (variant) / chunks (polish) per GPU per step")
     ap.add_argument("--pool", type=int, default=0, help="distinct windows / chunks in the page-locked host pool per GPU")
     ap.add_argument("--resident-only", action="store_true",
@@ -582,6 +586,72 @@ def secondary_block(args):
     return out
 
 
+def wg_syn_bench(args, world, rank, device, ranks_seen, lib, handle, pool, unit_bytes, pool_n, host_call, sync):
+    """--workload wg-syn: 24 shards with the chromosomes' proportions, a fixed total, dealt over the ranks by
+    RunInference.shard_files both ways; every rank runs its shards through the host entry point (H2D, forward, D2H) and reports
+    its own time.  value = all windows / the slowest rank's time under the size-ordered deal."""
+    from pepper_amd.variant.RunInference import shard_files
+    total = args.per_gpu or (1 << 22)
+    shards = synthetic.wg_syn_shards(total)
+    names = ["chr%d" % (k + 1) for k in range(22)] + ["chrX", "chrY"]
+    size_of = dict(zip(names, shards))
+    step = 1 << 18                                     # windows per host call (16 device passes)
+    probs = torch.empty((step, 3), dtype=torch.float32, pin_memory=True)
+
+    def run(my):
+        done = 0
+        sync()
+        t0 = time.perf_counter()
+        for name in my:
+            left = size_of[name]
+            while left > 0:
+                c = min(step, left)
+                off = (done % max(1, pool_n - c + 1))
+                host_call(pool.data_ptr() + off * unit_bytes, c, [probs])
+                left -= c
+                done += c
+        sync()
+        return done, time.perf_counter() - t0
+
+    def gather(x):
+        if world == 1:
+            return [x]
+        import torch.distributed as dist
+        out = [None] * world
+        dist.all_gather_object(out, x)
+        return out
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+    results = {}
+    host_call(pool.data_ptr(), min(step, pool_n), [probs])      # warm-up
+    for label, sizes in (("round_robin", None), ("size_ordered", shards)):
+        chunks = shard_files(names, world, sizes)
+        chunks += [[] for _ in range(world - len(chunks))]
+        barrier()
+        n_done, dt = run(chunks[rank])
+        barrier()
+        sys.stderr.write("[bench wg-syn] %s rank %d: %d shards, %d windows, %.3f s\n" % (label, rank, len(chunks[rank]), n_done, dt))
+        per = gather((n_done, dt))
+        results[label] = {"windows_per_rank": [p[0] for p in per], "seconds_per_rank": [round(p[1], 4) for p in per],
+                          "imbalance_max_over_mean_windows": max(p[0] for p in per) / (sum(p[0] for p in per) / world),
+                          "windows_per_s": sum(p[0] for p in per) / max(p[1] for p in per)}
+    if rank == 0:
+        best = results["size_ordered"]
+        print(json.dumps({
+            "metric": "inference windows/sec (whole node)", "value": best["windows_per_s"], "unit": "windows/s", "n_gpus": world,
+            "steps": 1, "warmup": 1, "ms_per_step": max(best["seconds_per_rank"]) * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32 via f16 hi/lo split operands (3 MFMAs per product), f32 accumulate", "data": "synthetic",
+            "config": {"workload": "WG-syn: %d V-syn windows in 24 shards proportional to the GRCh38 chromosome lengths (one image file per "
+                                   "chromosome), a fixed job dealt over the ranks; H2D and D2H included" % sum(shards),
+                       "shard_windows": dict(zip(names, shards)), "parallelism": f"file-shard x{world}, one weight broadcast, no data-path collective",
+                       "ranks_seen": ranks_seen, "deal": "size_ordered (largest shard first onto the least loaded rank; RunInference.shard_files)"},
+            "deals": results,
+            "round_robin_over_size_ordered": results["round_robin"]["windows_per_s"] / best["windows_per_s"]}))
+
+
 def timed_loop(fn, count, sync):
     """count calls of fn between two synchronisations -> seconds."""
     sync()
@@ -704,6 +774,15 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    if variant and args.workload == "wg-syn":
+        if args.resident_only:
+            raise SystemExit("--workload wg-syn times the host entry point: not with --resident-only")
+        wg_syn_bench(args, world, rank, device, ranks_seen, lib, handle, pool, unit_bytes, pool_n, host_call, sync)
+        lib.pa_variant_destroy(handle)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     for k in range(args.warmup):
         step(k)
     sync()
@@ -716,9 +795,14 @@ def main():
     sync()
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_seconds = [dt]
+    sys.stderr.write("[bench] rank %d of %d: %d steps in %.4f s\n" % (rank, world, args.steps, dt))     # every rank, for the SCALE log
     if world > 1:
         import torch.distributed as dist
         on_gpu = dist.get_backend() == "nccl"
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dt)
+        per_rank_seconds = [float(x) for x in gathered]
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if on_gpu else None)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -786,7 +870,7 @@ def main():
                        "reference_hdf5_batch": 512 if variant else 128,
                        "weights": "seeded random init (pepper_amd.synthetic), fp32",
                        "parallelism": f"region-shard x{world}, one weight broadcast, no data-path collective",
-                       "ranks_seen": ranks_seen},
+                       "ranks_seen": ranks_seen, "per_rank_seconds": [round(x, 4) for x in per_rank_seconds]},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": kernel_peak(dom),
                          "unit": "TFLOP/s", "frac": ach / kernel_peak(dom),
                          "traffic": traffic["bytes_per_launch"] if traffic else None,

@@ -43,7 +43,8 @@ typedef struct pa_h5 pa_h5;
 
 const char* pa_h5_last_error(void);
 
-/* mode: 0 = read-only, 1 = create/truncate ('w'), 2 = read-write existing ('r+') */
+/* mode: 0 = read-only, 1 = create/truncate ('w'), 2 = read-write existing ('r+'), 3 = create/truncate with the HDF5 1.10
+ * object formats (written faster when a file is hundreds of thousands of small groups; the prediction stores use it) */
 int pa_h5_open(const char* path, int32_t mode, pa_h5** out);
 int pa_h5_close(pa_h5* f);
 int pa_h5_flush(pa_h5* f);

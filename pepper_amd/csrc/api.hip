@@ -529,7 +529,7 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     if (rc == PA_OK && m->split_gemm && m->L1 == 512) {
         std::string err;
         const float* w4[4];
-        std::vector<float> b4((size_t)4 * m->L1);
+        std::vector<float> b4((size_t)4 * m->L1);                 // raw biases; the kernel's table is built from them below
         bool ok = true;
         for (int i = 0; i < 4 && ok; ++i) {
             w4[i] = sd.get(std::string(lin_names[i + 1]) + ".weight", (int64_t)m->L1 * m->L1, err);
@@ -539,7 +539,17 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
         }
         if (ok) {   // (weights outside the f16 range keep the f32 GEMM chain)
             std::vector<uint32_t> packed(pa::mlp_weights_h2_words(4));
-            pa::pack_mlp_weights_h2(w4, 4, packed.data());
+            float scale[4];
+            pa::pack_mlp_weights_h2(w4, 4, packed.data(), scale);
+            std::vector<float> table((size_t)8 * m->L1 + 4);      // [4][512] bias x scale | [4] 1 / scale | [4][512] bias
+            for (int i = 0; i < 4; ++i) {
+                for (int k = 0; k < m->L1; ++k) {
+                    table[(size_t)i * m->L1 + k] = b4[(size_t)i * m->L1 + k] * scale[i];
+                    table[(size_t)4 * m->L1 + 4 + (size_t)i * m->L1 + k] = b4[(size_t)i * m->L1 + k];
+                }
+                table[(size_t)4 * m->L1 + i] = 1.0f / scale[i];
+            }
+            b4.swap(table);
             m->mlp_w = m->new_buf();
             m->mlp_b = m->new_buf();
             rc = m->mlp_w->ensure(packed.size() * sizeof(uint32_t));

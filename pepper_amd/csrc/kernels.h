@@ -91,7 +91,8 @@ hipError_t launch_polish_combine(const float* P, const float* bias, float* acc, 
                                  hipStream_t stream);
 
 // mlp_h2.hip: linear_2..5 (512 -> 512, SELU) + output layer + softmax fused, 64 rows per workgroup.
-void pack_mlp_weights_h2(const float* const* W, int NL, uint32_t* out);
+// scale[NL] receives each layer's power-of-two packing factor; bias for launch_mlp_tail_h2: [NL][512] x scale | [NL] 1 / scale | [NL][512] raw
+void pack_mlp_weights_h2(const float* const* W, int NL, uint32_t* out, float* scale);
 size_t mlp_weights_h2_words(int NL);
 // W32: DEVICE array of the NL f32 weight matrices [512][512] (the exact re-run of a 64-row tile in which an activation left the
 // f16 range: >= 65504 or NaN); overflow_rows (device counter, may be null) counts the rows that took it.

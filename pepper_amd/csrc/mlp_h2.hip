@@ -26,7 +26,7 @@ PA_DEV f32x16 mfma_h(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32
 template <int NL>
 __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __restrict__ X, int ldx,
                                                              const uint32_t* __restrict__ Wp,      // [NL][16][32][2][64][4] dwords
-                                                             const float* __restrict__ bias,       // [NL][512]
+                                                             const float* __restrict__ bias,       // [NL][512] x scale | [NL] 1 / scale | [NL][512] as given
                                                              const float* __restrict__ Wout,       // [C][512]
                                                              const float* __restrict__ bout, int C,
                                                              float* __restrict__ probs, float* __restrict__ logits,
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __rest
             __builtin_amdgcn_sched_barrier(0);
         }
         lds_barrier();                      // every wave has finished reading this layer's input
+        const float unscale = bias[NL * D + layer];      // the layer's weights and bias were packed times a power of two
 #pragma unroll
         for (int nn = 0; nn < 2; ++nn) {
             const int col = 64 * w + 32 * nn + li;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __rest
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = selu_f(acc[m][nn][r]);
+                    const float v = selu_f(acc[m][nn][r] * unscale);
                     bad |= !(fabsf(v) < 65504.0f);
                     dst[(32 * m + (r & 3) + 8 * (r >> 2)) * ROWD] = h2_word_of(v, h2_select(odd));
                 }
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __rest
         for (int layer = 0; layer < NL; ++layer) {
             const float* wr = W32[layer] + (size_t)tid * D;      // thread = output unit, all 64 rows
             float y[MT];
-            const float bv = bias[layer * D + tid];
+            const float bv = bias[NL * D + NL + layer * D + tid];
 #pragma unroll
             for (int r = 0; r < MT; ++r) y[r] = bv;
 #pragma unroll 1
@@ -228,20 +229,35 @@ __global__ __launch_bounds__(512, 1) void mlp_tail_h2_kernel(const float* __rest
 
 namespace pa {
 
-// NL matrices W [512][512] (row = output unit) -> per-lane h2 fragments [layer][n tile 16][k step 32][hi, lo][64][8 halves]
-void pack_mlp_weights_h2(const float* const* W, int NL, uint32_t* out) {
+// NL matrices W [512][512] (row = output unit) -> per-lane h2 fragments [layer][n tile 16][k step 32][hi, lo][64][8 halves].
+// Every layer is packed times a power of two that puts its largest weight near 2^14: the lo half of an h2 value is an f16 too,
+// so a weight below 6e-5 would otherwise lose its low bits to the f16 sub-normal spacing (6e-8 absolute) -- harmless beside
+// activations of order 1, not beside activations of order 1e4.  scale[l] receives the factor; the kernel multiplies the
+// accumulator (bias packed times the same factor) by its reciprocal, exactly.
+void pack_mlp_weights_h2(const float* const* W, int NL, uint32_t* out, float* scale) {
     _Float16* o = reinterpret_cast<_Float16*>(out);
-    for (int l = 0; l < NL; ++l)
+    for (int l = 0; l < NL; ++l) {
+        float mx = 0.0f;
+        for (size_t i = 0; i < (size_t)D * D; ++i) mx = fmaxf(mx, fabsf(W[l][i]));
+        int e = 0;
+        if (mx > 0.0f) {
+            (void)frexpf(mx, &e);                        // mx = f * 2^e, f in [0.5, 1)
+            e = 14 - e;                                  // largest weight -> [2^13, 2^14)
+            e = e > 60 ? 60 : (e < -60 ? -60 : e);
+        }
+        const float sc = ldexpf(1.0f, e);
+        scale[l] = sc;
         for (int nt = 0; nt < NTILES; ++nt)
             for (int s = 0; s < KS; ++s)
                 for (int ln = 0; ln < 64; ++ln)
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = W[l][(size_t)(nt * 32 + (ln & 31)) * D + 16 * s + 8 * (ln >> 5) + e];
+                    for (int e8 = 0; e8 < 8; ++e8) {
+                        const float v = sc * W[l][(size_t)(nt * 32 + (ln & 31)) * D + 16 * s + 8 * (ln >> 5) + e8];
                         const _Float16 hi = (_Float16)v;
-                        const size_t base = ((((size_t)l * NTILES + nt) * KS + s) * 2) * 512 + (size_t)ln * 8 + e;
+                        const size_t base = ((((size_t)l * NTILES + nt) * KS + s) * 2) * 512 + (size_t)ln * 8 + e8;
                         o[base] = hi;
                         o[base + 512] = (_Float16)(v - (float)hi);
                     }
+    }
 }
 
 size_t mlp_weights_h2_words(int NL) { return (size_t)NL * NTILES * KS * 2 * 256; }

@@ -92,7 +92,7 @@ class File(object):
     def __init__(self, path, mode="r"):
         self._lib = load()
         self._h = c_void_p()
-        code = {"r": 0, "w": 1, "r+": 2, "a": 2 if os.path.exists(path) else 1}[mode]
+        code = {"r": 0, "w": 1, "w-new": 3, "r+": 2, "a": 2 if os.path.exists(path) else 1}[mode]
         _check(self._lib.pa_h5_open(os.fsencode(path), code, ctypes.byref(self._h)))
         self.filename, self.mode = path, mode
 

@@ -61,9 +61,10 @@ class Slots(object):
     them for the GPU (pa_host_register = hipHostRegister, ~4 GB/s on the MI355X host) on a background thread, in the
     order given, while the workers start and read; ready(i) waits for segment i."""
 
-    def __init__(self, count, nbytes):
+    def __init__(self, count, nbytes, pin_bytes=None):
         import threading
         self.nbytes = int(nbytes)
+        self.pin_bytes = self.nbytes if pin_bytes is None else min(int(pin_bytes), self.nbytes)   # leading bytes the GPU touches
         self.segments = []
         self.registered = []
         try:
@@ -85,7 +86,7 @@ class Slots(object):
             from pepper_amd import _lib
             lib = _lib.load()
             ptr = np.frombuffer(self.segments[i].buf, np.uint8).ctypes.data
-            if lib.pa_host_register(ptr, self.nbytes) == 0:
+            if lib.pa_host_register(ptr, self.pin_bytes) == 0:
                 self.registered.append(ptr)
             else:
                 raise RuntimeError((lib.pa_last_error() or b"pa_host_register failed").decode())
@@ -172,12 +173,12 @@ class NoSharedMemory(LaneError):
     """/dev/shm cannot hold the staging slots: the caller falls back to its in-process loop."""
 
 
-def make_slots(lanes, count, nbytes):
+def make_slots(lanes, count, nbytes, pin_bytes=None):
     """One Slots object per lane; the ones already created are released when a later one finds no room."""
     made = []
     try:
         for _ in range(lanes):
-            made.append(Slots(count, nbytes))
+            made.append(Slots(count, nbytes, pin_bytes))
     except NoSharedMemory:
         for sl in made:
             sl.close()
@@ -264,12 +265,15 @@ class PolishLayout(object):
 
     def __init__(self, block, seq_len, features):
         self.block, self.seq_len, self.features = block, seq_len, features
+        # what the GPU reads and writes first, in one range (the only part that is page-locked: 12 KB of a chunk's 28 KB); the
+        # position / index rows only travel from the reader to the writer
         self.o_image = 0
-        self.o_position = _align(block * seq_len * features)
-        self.o_index = self.o_position + _align(block * seq_len * 8)
-        self.o_labels = self.o_index + _align(block * seq_len * 8)
+        self.o_labels = _align(block * seq_len * features)
         self.o_phred = self.o_labels + _align(block * seq_len)
-        self.nbytes = self.o_phred + _align(block * seq_len)
+        self.pin_bytes = self.o_phred + _align(block * seq_len)
+        self.o_position = self.pin_bytes
+        self.o_index = self.o_position + _align(block * seq_len * 8)
+        self.nbytes = self.o_index + _align(block * seq_len * 8)
 
     def views(self, buf, n):
         s, f = self.seq_len, self.features
@@ -344,7 +348,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
     layout = PolishLayout(block, seq_len, features)
     largs = (block, seq_len, features)
     ctx = get_context("spawn")
-    slots = make_slots(lanes, slots_per_lane, layout.nbytes)
+    slots = make_slots(lanes, slots_per_lane, layout.nbytes, layout.pin_bytes)
     result_q = ctx.Queue()
     free_qs = [ctx.Queue() for _ in range(lanes)]
     write_qs = [ctx.Queue() for _ in range(lanes)]
@@ -367,7 +371,8 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
             _trace(t_begin, "caller prepared")
         # page-locking after prepare(): hipHostRegister holds the process's mm lock, and a model creation (hipMalloc,
         # uploads) running beside it took 0.4 s instead of 0.07 s
-        locker = register_async(slots, _have_gpu())
+        # PEPPER_AMD_POLISH_PIN=0: leave the slots pageable (the copies are then staged by the runtime; the path needs ~1 GB/s)
+        locker = register_async(slots, _have_gpu() and os.environ.get("PEPPER_AMD_POLISH_PIN", "1") != "0")
         reading, writing = lanes, lanes
         while writing:
             msg = _next_message(result_q, procs)
@@ -675,8 +680,9 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
 def default_lanes(files, requested, small=64 << 20, most=8):
     """options.num_workers > 0: that many lanes (at most one per file).  0: process lanes only when the job is big
     enough to pay for them (start-up of the workers + page-locking of the slots is ~0.3 s), and then `most` of them
-    (measured on the MI355X host: 4 readers keep the variant loop at the device rate, 8 the polish loop; more lanes only
-    add page-locking and scheduling)."""
+    (measured on the MI355X host: 4 readers keep the variant loop at the device rate; the polish loop, whose files are one
+    HDF5 group per chunk -- ~150 us of libhdf5 per chunk on either side --, takes as many as the host can run: most=None
+    -> a quarter of the CPUs, at most 32)."""
     if not files or os.environ.get("PEPPER_AMD_NO_LANES") == "1":
         return 0
     if requested and requested > 0:
@@ -684,6 +690,8 @@ def default_lanes(files, requested, small=64 << 20, most=8):
     total = sum(os.path.getsize(f) for f in files)
     if total < small or len(files) < 2:
         return 0
+    if most is None:
+        most = max(8, min(32, (os.cpu_count() or 8) // 4))
     return min(len(files), most)
 
 

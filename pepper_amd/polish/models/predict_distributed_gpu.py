@@ -26,6 +26,7 @@ def _log(msg):
 
 
 DEVICE_CHUNKS = 8192     # chunks per device pass (19 windows of 100 rows each; 128 chunks per workgroup and direction)
+LANE_CHUNKS = int(os.environ.get("PEPPER_AMD_POLISH_BLOCK", 4096))   # chunks a reader lane hands over at a time (a slot: 115 MB, 49 MB of it page-locked)
 
 
 def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size, num_workers, rank, device_id,
@@ -44,8 +45,8 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
     # image files around this process's GPU loop; libhdf5's one-lock-per-process is what bounds the loop below.  The
     # checkpoint is loaded while the workers start and read.
     from pepper_amd import hostpipe
-    lanes = hostpipe.default_lanes(file_chunks, num_workers)
-    layout = hostpipe.PolishLayout(DEVICE_CHUNKS, ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT)
+    lanes = hostpipe.default_lanes(file_chunks, num_workers, most=None)
+    layout = hostpipe.PolishLayout(LANE_CHUNKS, ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT)
     if lanes > 0 and hostpipe.shm_room(2 * lanes * layout.nbytes):
         def log(done):
             if rank == 0:
@@ -53,7 +54,7 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
         try:
             hostpipe.polish_lanes(file_chunks, output_filepath + "pepper_prediction_" + str(rank),
                                   lambda image, labels, phred: get_model().predict_chunks_into(image, labels, phred), lanes,
-                                  block=DEVICE_CHUNKS, seq_len=ImageSizeOptions.SEQ_LENGTH, features=ImageSizeOptions.IMAGE_HEIGHT,
+                                  block=LANE_CHUNKS, seq_len=ImageSizeOptions.SEQ_LENGTH, features=ImageSizeOptions.IMAGE_HEIGHT,
                                   slots_per_lane=2, log=log, prepare=get_model)
             return rank
         except hostpipe.NoSharedMemory as e:

@@ -410,3 +410,17 @@ def encoder_regions(n, seed=ESYN_SEED, workers=0, **kw):
     with pool:
         futs = [pool.apply_async(encoder_region, (seed + k,), kw) for k in range(n)]
         return [f.get() for f in futs]
+
+
+# ---- WG-syn: a whole genome's worth of variant windows, shard sizes like the chromosomes ------------------
+# GRCh38 primary assembly lengths in bases, chr1..22, X, Y (one image file per chromosome, as a per-chromosome run writes them)
+GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
+                  133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616,
+                  64444167, 46709983, 50818468, 156040895, 57227415]
+
+
+def wg_syn_shards(total_windows, multiple=512):
+    """Windows per chromosome file, proportional to the chromosome lengths, each a multiple of `multiple` (the reference's
+    HDF5 batch), summing to about total_windows.  -> list of 24 counts, chr1..22, X, Y."""
+    total_len = float(sum(GRCH38_LENGTHS))
+    return [max(multiple, int(round(total_windows * n / total_len / multiple)) * multiple) for n in GRCH38_LENGTHS]

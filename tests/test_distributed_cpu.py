@@ -106,3 +106,24 @@ def test_one_callers_clean_up_leaves_the_other_callers_files(tmp_path):
                                                    "pepper_prediction_12.hdf", "pepper_prediction.hdf", "other.hdf"])
     remove_stale_predictions(str(tmp_path))                      # start of a run: every prediction file of the directory
     assert sorted(os.listdir(tmp_path)) == ["other.hdf"]
+
+
+def test_wg_syn_shards_and_the_two_deals():
+    """WG-syn: 24 shards with the chromosomes' proportions; over 8 callers the reference's round robin leaves
+    one caller well above the mean, the size-ordered deal of RunInference.shard_files within a few per cent."""
+    from pepper_amd.variant.RunInference import shard_files
+    shards = synthetic.wg_syn_shards(1 << 22)
+    assert len(shards) == 24 and all(s % 512 == 0 and s > 0 for s in shards)
+    assert abs(sum(shards) - (1 << 22)) < 24 * 512
+    assert shards[0] == max(shards) and shards[20] == min(shards)            # chr1 the longest, chr21 the shortest
+    names = ["chr%d" % (k + 1) for k in range(22)] + ["chrX", "chrY"]
+    size = dict(zip(names, shards))
+
+    def imbalance(chunks):
+        loads = [sum(size[n] for n in c) for c in chunks]
+        return max(loads) / (sum(loads) / len(loads))
+    rr, so = shard_files(names, 8), shard_files(names, 8, shards)
+    assert sorted(n for c in rr for n in c) == sorted(names) == sorted(n for c in so for n in c)
+    assert imbalance(rr) > 1.15 and imbalance(so) < 1.05
+    for world in (1, 2, 4):
+        assert imbalance(shard_files(names, world, shards)) < 1.02
