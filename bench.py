@@ -175,12 +175,26 @@ def host_cores():
     return physical, logical
 
 
+def worker_count():
+    """Single-thread CPU workers to run at once: one per physical core, but never more than the CPUs this container may
+    use (affinity and cgroup quota -- pepper_amd.hostinfo; the project's GPU boxes show 256 logical CPUs and grant 16)."""
+    from pepper_amd.hostinfo import usable_cpus
+    physical, _ = host_cores()
+    return max(1, min(physical, usable_cpus()))
+
+
+def cpu_note():
+    from pepper_amd.hostinfo import cgroup_cpu_quota, usable_cpus
+    q = cgroup_cpu_quota()
+    return {"usable_cpus": usable_cpus(), "cgroup_cpu_quota": q}
+
+
 def cpu_baseline_workers(model_kind, seconds):
     """Aggregate of single-thread workers running concurrently in fresh interpreters, ONE PER PHYSICAL CORE (the
     reference's distributed_cpu scheme on the whole box; each worker holds torch + 47 MB of weights, about 0.5 GB)."""
     import subprocess
     physical, logical = host_cores()
-    procs = physical
+    procs = worker_count()
     try:
         import psutil
         procs = max(1, min(procs, int(psutil.virtual_memory().available / (0.8 * 2 ** 30))))
@@ -203,11 +217,11 @@ def cpu_baseline_workers(model_kind, seconds):
         return None
     windows = sum(o["windows"] for o in outs)
     span = max(o["seconds"] for o in outs)
-    return {"value": windows / span, "unit": "windows/s", "cores": len(outs), "host_physical_cores": physical,
-            "host_logical_cpus": logical, "kind": "port",
-            "sample": f"{len(outs)} concurrent single-thread workers, one per physical core (the reference's "
-                      f"distributed_cpu scheme), each looping the torch.nn forward for {seconds:.0f} s; aggregate over "
-                      f"{span:.1f} s (wall incl. interpreter start-up {wall:.0f} s)"}
+    return dict({"value": windows / span, "unit": "windows/s", "cores": len(outs), "host_physical_cores": physical,
+                 "host_logical_cpus": logical, "kind": "port",
+                 "sample": f"{len(outs)} concurrent single-thread workers, one per CPU this container may use (the reference's "
+                           f"distributed_cpu scheme), each looping the torch.nn forward for {seconds:.0f} s; aggregate over "
+                           f"{span:.1f} s (wall incl. interpreter start-up {wall:.0f} s)"}, **cpu_note())
 
 
 def cpu_baseline(model_kind, seconds):
@@ -222,7 +236,9 @@ def cpu_baseline(model_kind, seconds):
     deadline = time.perf_counter() + 3.0 * seconds      # hard bound on the whole leg
     best_t, best_rate = None, 0.0
     with torch.no_grad():
-        for nt in sorted({min(physical, c) for c in (8, 16, 32, 64, physical)}):
+        from pepper_amd.hostinfo import usable_cpus
+        cap = max(1, min(physical, usable_cpus()))
+        for nt in sorted({min(cap, c) for c in (8, 16, 32, 64, cap)}):
             if time.perf_counter() > deadline - seconds:
                 break
             torch.set_num_threads(nt)
@@ -392,7 +408,7 @@ def encoder_cpu_all_cores(seconds, region_size):
     (ImageGenerationUI.py:262-274): that many workers of oracle/encoder_cpu.py, concurrently, each on its own region."""
     import subprocess
     physical, logical = host_cores()
-    procs = physical
+    procs = worker_count()
     try:
         import psutil
         procs = max(1, min(procs, int(psutil.virtual_memory().available / (0.4 * 2 ** 30))))
@@ -413,11 +429,11 @@ def encoder_cpu_all_cores(seconds, region_size):
     if not outs:
         return None
     span = max(o["seconds"] for o in outs)
-    return {"value": sum(o["bases"] for o in outs) / span, "unit": "aligned bases/s", "cores": len(outs),
-            "host_physical_cores": physical, "host_logical_cpus": logical, "kind": outs[0]["kind"],
-            "sample": f"{len(outs)} concurrent single-thread workers, one per physical core, each looping the reference's "
-                      f"RegionalSummaryGenerator (oracle/_ref) on its own E-syn region for {seconds:.0f} s; "
-                      f"{sum(o['regions'] for o in outs)} regions in {span:.1f} s (wall incl. start-up {wall:.0f} s)"}
+    return dict({"value": sum(o["bases"] for o in outs) / span, "unit": "aligned bases/s", "cores": len(outs),
+                 "host_physical_cores": physical, "host_logical_cpus": logical, "kind": outs[0]["kind"],
+                 "sample": f"{len(outs)} concurrent single-thread workers, one per CPU this container may use, each looping the reference's "
+                           f"RegionalSummaryGenerator (oracle/_ref) on its own E-syn region for {seconds:.0f} s; "
+                           f"{sum(o['regions'] for o in outs)} regions in {span:.1f} s (wall incl. start-up {wall:.0f} s)"}, **cpu_note())
 
 
 def encoder_bench(args):

@@ -628,6 +628,21 @@ struct HBuf {
     ~HBuf() { if (p) (void)hipHostFree(p); }
 };
 
+// CPUs this process may really use: the hardware's, cut by a cgroup quota (cgroup v2 cpu.max; the project's GPU boxes show 256
+// logical CPUs and grant 16 -- 64 busy threads would each run at a quarter of the speed)
+int usable_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 4;
+    if (FILE* fh = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long long period = 0;
+        if (fscanf(fh, "%31s %lld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+            n = std::min(n, std::max(1, (int)(atoll(quota) / period)));
+        fclose(fh);
+    }
+    return n;
+}
+
 // worker threads that live as long as the encoder: the candidate enumeration of a batch is one short task per region
 // (a few hundred microseconds of ordered maps and strings), and starting 16 threads per run cost more than the tasks
 class RegionPool {
@@ -1122,8 +1137,7 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
     } else {
         if (!b.pool) {
             const char* env = getenv("PA_ENCODER_HOST_THREADS");
-            const int n = env ? atoi(env) : (int)std::thread::hardware_concurrency() / 4;
-            b.pool.reset(new RegionPool(std::max(1, std::min(n, 64)) - 1));
+            b.pool.reset(new RegionPool(std::max(1, std::min(env ? atoi(env) : usable_cpus(), 32)) - 1));
         }
         b.pool->run(n_regions, work);
     }
