@@ -56,7 +56,9 @@ LABELS = [
 # its whole input once -- 16384 chunks x 100 rows x 1 KB = 1.678 GB per launch, its 0.6 MB of weights stay in L2 -- and
 # FETCH_SIZE reports 1.689 GB for it: the nt-policy 16-byte loads of the step loops' x stream are counted in full.  So
 # factor 1 for the kernels whose bulk reads carry nt, the guide's factor 2 for the rest.
-NT_STREAM_KERNELS = {"gru_dec_h2_fused_dense", "gru_dec_h2_fused", "lstm_dec_h2_fused"}
+# r03: tile_count_kernel (byte-per-lane nt loads) reports 874 MB for 860 MB of bytes it must read once: factor 1 as well
+NT_STREAM_KERNELS = {"gru_dec_h2_fused_dense", "gru_dec_h2_fused", "lstm_dec_h2_fused", "tile_count", "segment_reads", "gather_windows",
+                     "pack_results", "tile_offsets", "compact_votes"}
 
 
 def fetch_factor(label):

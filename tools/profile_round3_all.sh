@@ -11,3 +11,8 @@ import json; d=json.load(open('gpurun_out/$TAG/bench_variant.json')); print(d['v
 PEPPER_AMD_BENCH_SHARE_GPU=1 timeout 400 python bench.py --gpus 8 --steps 3 --warmup 1 --per-gpu 32768 --pool 65536 --no-cpu-baseline --no-extras > gpurun_out/$TAG/bench_8rank_shared_gpu_plumbing.json 2> gpurun_out/$TAG/bench_8rank.err; grep "bench\] rank" gpurun_out/$TAG/bench_8rank.err; head -c 600 gpurun_out/$TAG/bench_8rank_shared_gpu_plumbing.json; echo
 PEPPER_AMD_BENCH_SHARE_GPU=1 timeout 400 python bench.py --gpus 8 --workload wg-syn --per-gpu 1048576 --pool 262144 --no-cpu-baseline --no-extras > gpurun_out/$TAG/bench_wgsyn_8rank_shared_gpu_plumbing.json 2> gpurun_out/$TAG/bench_wgsyn_8rank.err; grep "wg-syn" gpurun_out/$TAG/bench_wgsyn_8rank.err | head -20; head -c 400 gpurun_out/$TAG/bench_wgsyn_8rank_shared_gpu_plumbing.json; echo
 timeout 300 python bench.py --workload wg-syn --no-cpu-baseline > gpurun_out/$TAG/bench_wgsyn_1gpu.json 2> gpurun_out/$TAG/bench_wgsyn_1gpu.err; head -c 500 gpurun_out/$TAG/bench_wgsyn_1gpu.json; echo
+timeout 100 python tools/bench_polish_encoder.py > gpurun_out/$TAG/bench_polish_encoder.json 2>/dev/null; cat gpurun_out/$TAG/bench_polish_encoder.json
+timeout 100 python tools/small_batch_profile.py > gpurun_out/$TAG/small_batch_kernels.json 2>/dev/null
+timeout 300 python bench.py --model encoder > gpurun_out/$TAG/bench_encoder_line.json 2> gpurun_out/$TAG/bench_encoder_line.err; head -c 700 gpurun_out/$TAG/bench_encoder_line.json; echo
+timeout 300 python bench.py --model polish --no-secondary > gpurun_out/$TAG/bench_polish.json 2> gpurun_out/$TAG/bench_polish.err; head -c 400 gpurun_out/$TAG/bench_polish.json; echo
+TAG=$TAG bash tools/profile_round3_encoder.sh > gpurun_out/$TAG/profile_encoder.log 2>&1; tail -30 gpurun_out/$TAG/profile_encoder.log | grep -v "^+"
