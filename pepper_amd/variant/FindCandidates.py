@@ -6,6 +6,7 @@ replaces: /root/reference/pepper_variant/modules/python/FindCandidates.py
 live pipeline and are not reproduced.)  Differences: files are listed in sorted order so the
 per-site record order is deterministic (the reference uses listdir order and as_completed).
 """
+import os
 import sys
 import time
 from datetime import datetime
@@ -38,14 +39,24 @@ def candidate_finder(options, input_dir, output_path):
 
     local_start_time = time.time()
     _log("STARTING CANDIDATE FINDING.")
-    contigs, selected_candidates_phasing, selected_candidates_variant_calling = find_candidates(options, input_dir, all_prediction_pair)
-    end_time = time.time()
-
     factory = getattr(options, "fasta_handler_factory", None)
-    vcf_file_full = VCFWriter(contigs, options.fasta, options.sample_name, output_path, "PEPPER_VARIANT_FULL",
-                              "PEPPER_VARIANT_OUTPUT_PEPPER", "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING",
-                              fasta_handler=factory(options.fasta) if factory is not None else None)
-    totals = vcf_file_full.write_vcf_records(selected_candidates_variant_calling, options)
+
+    def writer():
+        return VCFWriter([], options.fasta, options.sample_name, output_path, "PEPPER_VARIANT_FULL",
+                         "PEPPER_VARIANT_OUTPUT_PEPPER", "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING",
+                         fasta_handler=factory(options.fasta) if factory is not None else None)
+    if os.environ.get("PEPPER_AMD_CANDIDATES_TUPLES") == "1":
+        # the reference-shaped path: one tuple per selected allele, dictionaries of sites, one record at a time
+        contigs, selected_candidates_phasing, selected_candidates_variant_calling = find_candidates(options, input_dir, all_prediction_pair)
+        end_time = time.time()
+        vcf_file_full = writer()
+        totals = vcf_file_full.write_vcf_records(selected_candidates_variant_calling, options)
+    else:
+        # the same rules column-wise (FastCandidates.py; held to the tuple path file by file in tests/test_candidate_finder.py)
+        from pepper_amd.variant import FastCandidates
+        vcf_file_full = writer()
+        contigs, totals = FastCandidates.process(options, all_prediction_pair, vcf_file_full)
+        end_time = time.time()
     vcf_file_full.close()
     total_variants, total_pepper, total_variant_calling, total_variant_calling_snp, total_variant_calling_indel = totals
     _log("FINISHED PROCESSING, TOTAL CANDIDATES FOUND: " + str(total_variants))

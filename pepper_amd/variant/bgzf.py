@@ -56,6 +56,13 @@ class BgzfWriter(object):
             return (len(self._pending) << 16) | len(self._buf)
         return (self._coffset << 16) | len(self._buf)
 
+    def position(self):
+        """Uncompressed bytes written so far (deferred writers: every block but the one being filled holds _BLOCK_DATA bytes,
+        so byte u of the stream has the provisional offset (u // _BLOCK_DATA) << 16 | u % _BLOCK_DATA)."""
+        if not self._deferred:
+            raise ValueError("position() needs a deferred writer")
+        return len(self._pending) * _BLOCK_DATA + len(self._buf)
+
     def resolve(self, provisional):
         if not self._deferred:
             return provisional
@@ -136,6 +143,63 @@ class TabixBuilder(object):
         self._bins = {}     # tid -> {bin: [[beg, end], ...]}
         self._lin = {}      # tid -> {window: min voffset}
         self._tid = {}
+
+    def add_many(self, names, contig_code, beg, end, vbeg, vend):
+        """add() for records that follow each other in the file (vend[i] == vbeg[i + 1]), as arrays: names[contig_code[i]] is
+        record i's contig, the rest integer arrays.  Same bins, chunks and linear index as the calls one by one: a chunk of a bin is a maximal run of
+        file-consecutive records in that bin; a 16 kb window points at the first record that overlaps it."""
+        import numpy as np
+        contig_code = np.asarray(contig_code, dtype=np.int64)
+        n = len(contig_code)
+        if n == 0:
+            return
+        beg = np.asarray(beg, dtype=np.int64)
+        end = np.maximum(np.asarray(end, dtype=np.int64), beg + 1)
+        vbeg = np.asarray(vbeg, dtype=np.int64)
+        vend = np.asarray(vend, dtype=np.int64)
+        last = end - 1
+        bins = np.zeros(n, np.int64)
+        done = np.zeros(n, bool)
+        for shift, base in ((14, ((1 << 15) - 1) // 7), (17, ((1 << 12) - 1) // 7), (20, ((1 << 9) - 1) // 7),
+                            (23, ((1 << 6) - 1) // 7), (26, ((1 << 3) - 1) // 7)):
+            hit = ~done & ((beg >> shift) == (last >> shift))
+            bins[hit] = base + (beg[hit] >> shift)
+            done |= hit
+        # runs of one contig, in file order
+        cuts = np.concatenate([[0], np.flatnonzero(contig_code[1:] != contig_code[:-1]) + 1, [n]]).tolist()
+        for start, stop in zip(cuts[:-1], cuts[1:]):
+            name = names[int(contig_code[start])]
+            tid = self._tid.get(name)
+            if tid is None:
+                tid = self._tid[name] = len(self.names)
+                self.names.append(name)
+                self._bins[tid], self._lin[tid] = {}, {}
+            b = bins[start:stop]
+            edge = np.flatnonzero(np.concatenate([[True], b[1:] != b[:-1]])) + start
+            ends = np.concatenate([edge[1:], [stop]]) - 1
+            for s0, s1 in zip(edge.tolist(), ends.tolist()):
+                chunks = self._bins[tid].setdefault(int(bins[s0]), [])
+                if chunks and chunks[-1][1] == int(vbeg[s0]):
+                    chunks[-1][1] = int(vend[s1])
+                else:
+                    chunks.append([int(vbeg[s0]), int(vend[s1])])
+            lin = self._lin[tid]
+            w0 = beg[start:stop] >> 14
+            w1 = last[start:stop] >> 14
+            idx = np.arange(start, stop)
+            wide = np.flatnonzero(w1 > w0)
+            ws, ids = [w0], [idx]
+            for k in wide.tolist():
+                span = np.arange(int(w0[k]) + 1, int(w1[k]) + 1)
+                ws.append(span)
+                ids.append(np.full(len(span), start + k))
+            ws, ids = np.concatenate(ws), np.concatenate(ids)
+            order = np.lexsort((ids, ws))
+            ws, ids = ws[order], ids[order]
+            first = np.concatenate([[True], ws[1:] != ws[:-1]])
+            for w, k in zip(ws[first].tolist(), ids[first].tolist()):
+                if w not in lin:
+                    lin[w] = int(vbeg[k])
 
     def add(self, contig, beg, end, vbeg, vend):
         tid = self._tid.get(contig)

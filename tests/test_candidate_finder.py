@@ -328,3 +328,89 @@ def test_low_complexity_flags_of_a_batch_equal_the_per_site_scan():
         assert b == fasta.get_reference_sequence("c", p, p + 1).upper()
         if b:
             assert f == cf._in_repeat(fasta, "c", p), p
+
+
+def _synthetic_predictions(tmp_path, n, seed, with_multi):
+    """Prediction batches like the pipeline's (one allele per row, sorted positions) on two contigs, with sites that carry
+    two or three allele records, duplicate (REF, ALT) records, low-complexity stretches, N reference bases and alleles
+    outside ACGT."""
+    rng = np.random.default_rng(seed)
+    length = 12 * n + 1000
+    pieces = []
+    while sum(len(p) for p in pieces) < length:
+        pieces.append("ACGTN"[int(rng.choice(5, p=[0.24, 0.24, 0.24, 0.24, 0.04]))] * int(rng.choice([1, 1, 1, 1, 2, 3, 6, 8])))
+    refs = {"chrB": "".join(pieces)[:length], "chrA": "".join(reversed(pieces))[:length]}
+    fa = str(tmp_path / "syn.fa")
+    with open(fa, "w") as fh:
+        for name, seq in refs.items():                     # file order chrB, chrA: the VCF order is by name
+            fh.write(">" + name + "\n" + "\n".join(seq[i:i + 70] for i in range(0, length, 70)) + "\n")
+    pred_dir = tmp_path / "pred"
+    pred_dir.mkdir()
+    for fi, contig in enumerate(("chrB", "chrA")):
+        ref = refs[contig]
+        store = DataStore(str(pred_dir / ("pepper_prediction_%d.hdf" % fi)), "w")
+        positions = np.sort(rng.choice(np.arange(50, length - 50), n // 2, replace=False))
+        if with_multi:
+            extra = rng.choice(positions, n // 10)
+            positions = np.sort(np.concatenate([positions, extra, extra[: n // 40]]))
+        m_all = len(positions)
+        for b, s in enumerate(range(0, m_all, 256)):
+            pos = positions[s:s + 256].astype(np.int32)
+            m = len(pos)
+            cands = []
+            for p in pos:
+                r = ref[int(p)] if ref[int(p)] in "ACGT" else "A"
+                k = int(rng.integers(0, 7))
+                if k <= 2:
+                    cands.append(["1" + "ACGT"[("ACGT".index(r) + 1 + k) % 4]])
+                elif k == 3:
+                    cands.append(["2" + r + "ACGTT"[: int(rng.integers(1, 5))]])
+                elif k == 4:
+                    cands.append(["3" + ref[int(p):int(p) + int(rng.integers(2, 6))].replace("N", "A")])
+                elif k == 5:
+                    cands.append(["1N"])                                   # not an A C G T allele: skipped
+                else:
+                    cands.append(["2" + r + "A"])
+            probs = rng.dirichlet([0.6, 0.6, 0.6], m)
+            probs[rng.random(m) < 0.05] = [0.0, 1.0, 0.0]                  # exact 1: QUAL capped through max(1e-9, .)
+            store.write_prediction(b, [contig] * m, pos, rng.integers(1, 90, m).astype(np.uint8), np.array(cands, dtype=object),
+                                   rng.integers(0, 60, (m, 1)).astype(np.uint8), probs)
+        store.close()
+    return fa, str(pred_dir)
+
+
+@pytest.mark.parametrize("with_multi,freq", [(False, 0), (True, 0), (True, 0.2)])
+def test_column_path_writes_the_files_of_the_tuple_path(tmp_path, monkeypatch, with_multi, freq):
+    """FastCandidates (numpy columns, bulk writes, arithmetic tabix offsets) against the reference-shaped path (one tuple per
+    allele, one record at a time): the five .vcf.gz hold the same text and the five .tbi the same index."""
+    fa, pred_dir = _synthetic_predictions(tmp_path, 6000, 5, with_multi)
+    opts = options(fasta=fa, report_snp_above_freq=freq, report_indel_above_freq=freq, allowed_multiallelics=2)
+    monkeypatch.setenv("PEPPER_AMD_CANDIDATES_TUPLES", "1")
+    want_totals = process_candidates(opts, pred_dir, str(tmp_path / "tuples"))
+    monkeypatch.delenv("PEPPER_AMD_CANDIDATES_TUPLES")
+    got_totals = process_candidates(opts, pred_dir, str(tmp_path / "columns"))
+    assert tuple(got_totals) == tuple(want_totals) and want_totals[0] > 1000
+    assert want_totals[1] > 0 and want_totals[3] > 0 and want_totals[4] > 0
+    for name in sorted(os.listdir(tmp_path / "tuples")):
+        a, b = str(tmp_path / "tuples" / name), str(tmp_path / "columns" / name)
+        if name.endswith(".tbi"):
+            assert bgzf.parse_tbi(a) != {} and _resolved(bgzf.parse_tbi(a), a[:-4]) == _resolved(bgzf.parse_tbi(b), b[:-4]), name
+        else:
+            assert bgzf.read_bgzf(a) == bgzf.read_bgzf(b), name
+
+
+def _resolved(index, vcf_path):
+    """Virtual offsets -> offsets in the decompressed text (the two paths cut BGZF blocks at the same places, but that is not
+    part of the contract)."""
+    raw = open(vcf_path, "rb").read()
+    starts, pos, total = {}, 0, 0
+    while pos < len(raw):
+        bsize = int.from_bytes(raw[pos + 16:pos + 18], "little") + 1
+        starts[pos] = total
+        total += int.from_bytes(raw[pos + bsize - 4:pos + bsize], "little")
+        pos += bsize
+    starts[len(raw)] = total
+    conv = lambda v: starts[v >> 16] + (v & 0xffff)        # noqa: E731
+    refs = [{"bins": {b: [(conv(x), conv(y)) for x, y in chunks] for b, chunks in r["bins"].items()},
+             "ioff": [conv(v) if v else 0 for v in r["ioff"]]} for r in index["refs"]]
+    return dict(index, refs=refs)
