@@ -495,17 +495,17 @@ def encoder_bench(args):
     b2.run()
     t_one = time.perf_counter() - t0
     out = b2.results()
-    # two handles on two host threads, as image generation runs its workers (one encoder per thread): the candidate
-    # enumeration of one batch overlaps the kernels of the other.  Half of the regions each.
-    two = None
-    if n_regions >= 8 and world == 1:
+    # several handles on as many host threads, as image generation runs its workers (one encoder per thread): the candidate
+    # enumeration of one handle's batch overlaps the kernels of the others'.  The batch is dealt over the handles.
+    two = []
+    for n_handles in ((2, 4) if (n_regions >= 16 and world == 1) else ()):
         import threading
-        half = n_regions // 2
-        done_bases = [0, 0]
-        start_gate = threading.Barrier(3)
+        share = n_regions // n_handles
+        done_bases = [0] * n_handles
+        start_gate = threading.Barrier(n_handles + 1)
 
         def worker(k):
-            sl = slice(k * half, (k + 1) * half)
+            sl = slice(k * share, (k + 1) * share)
             mine = StagedBatch(gens[sl], flats[sl], ont, cand[sl])        # its own handle: _encoder is per thread
             mine.run()
             start_gate.wait()
@@ -513,7 +513,7 @@ def encoder_bench(args):
                 mine.run()
             done_bases[k] = 2 * args.steps * mine.stats()["bases"]
             start_gate.wait()
-        threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(n_handles)]
         for th in threads:
             th.start()
         start_gate.wait()
@@ -522,9 +522,7 @@ def encoder_bench(args):
         t_two = time.perf_counter() - t0
         for th in threads:
             th.join()
-        two = {"value": sum(done_bases) / t_two, "unit": "aligned bases/s", "handles": 2, "regions_per_handle": half,
-               "note": "two encoder handles on two host threads (image generation's worker scheme), each running its half of the "
-                       "regions back to back: one handle's host enumeration beside the other's kernels"}
+        two.append({"value": sum(done_bases) / t_two, "unit": "aligned bases/s", "handles": n_handles, "regions_per_handle": share})
     line = {
         "metric": "variant summary encoder, aligned bases/s (pileup -> candidate summary images)",
         "value": value, "unit": "aligned bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -547,7 +545,9 @@ def encoder_bench(args):
                              "SURVEY.md 8(d); launch duration from HIP events on the encoder's stream around the kernel, averaged "
                              "over the timed steps"},
         "kernels_ms": avg,
-        "two_handles": two,
+        "concurrent_handles": two,
+        "concurrent_handles_note": "N encoder handles on N host threads (image generation's worker scheme), each running its share of "
+                                   "the regions back to back: one handle's host enumeration beside the others' kernels",
         "host_buffers_one_call": {"value": stats["bases"] / t_one, "unit": "aligned bases/s", "ms": t_one * 1e3,
                                   "note": "pa_encoder_generate_summary_batch from pageable numpy arrays: validate + H2D of 0.75 GB + the "
                                           "step above (PCIe-inclusive; never `value`)"},
