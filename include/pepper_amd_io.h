@@ -91,6 +91,12 @@ int pa_h5_write_prediction_batch(pa_h5* f, const char* group, int32_t n, const c
 int pa_h5_read_polish_chunks(pa_h5* f, const char* names, int32_t n, int32_t seq_len, int32_t features, uint8_t* images,
                              int64_t* position, int64_t* index, int64_t* region_start, int64_t* region_end,
                              int64_t* chunk_id, char* contigs, int32_t contig_stride);
+/* How the polish chunks of this handle were read so far: `direct_chunks` had their image / position / index bytes copied
+ * straight out of the mapped file (classic-format files of h5py or pa_h5_open mode 1 opened read-only: the locator in
+ * hdf5io.cpp walks object header -> symbol table -> B-tree -> symbol node -> layout itself), `library_chunks` went through
+ * libhdf5 (anything the locator does not recognise; PEPPER_AMD_H5_DIRECT=0 forces it). */
+int pa_h5_read_stats(pa_h5* f, int64_t* direct_chunks, int64_t* library_chunks);
+
 int pa_h5_write_polish_predictions(pa_h5* f, int32_t n, int32_t seq_len, const char* contigs, int32_t contig_stride,
                                    const int64_t* contig_start, const int64_t* contig_end, const int64_t* chunk_id,
                                    const uint8_t* new_region, const uint8_t* skip, const int64_t* position,

@@ -4,6 +4,11 @@
 
 #include <hdf5.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -61,11 +66,240 @@ hid_t make_space(int rank, const int64_t* dims) {
     return H5Screate_simple(rank, d, nullptr);
 }
 
+// ---- direct locator: where the raw bytes of summaries/<chunk>/{image,position,index} lie in a classic-format file.
+// A polish image file is a few hundred thousand tiny objects and libhdf5 spends ~30 us of CPU per dataset it opens, reads and
+// closes (object header -> datatype/dataspace/layout objects, property lists, ids): ~95 us per chunk of three datasets, which on
+// the 16 CPUs a GPU box grants is the wall of the whole call_consensus pipeline.  The file format itself answers
+// "where are the bytes" in a few pointer hops: group object header -> symbol table message -> B-tree node -> symbol node ->
+// dataset object header -> layout message.  This walks exactly that over a read-only mmap, for the subset of the format that
+// h5py (libver earliest) and pa_h5_open mode 1 write: superblock v0/v1 with 8-byte offsets, version-1 object headers, version-1
+// group B-trees, layout message v3 contiguous.  Anything else -- any signature, version, size or bound that is not what is
+// expected -- makes it answer "don't know" and the caller reads that chunk through libhdf5 as before; it never guesses.
+// (HDF5 File Format Specification 2.0, sections III.A.1 B-trees, III.B/C symbol nodes, III.D local heaps, IV.A.1.a version-1
+// object headers, IV.A.2.i layout, IV.A.2.r symbol table message.)
+class Direct {
+public:
+    static Direct* open(const char* path) {
+        int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+        if (fd < 0) return nullptr;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < 96) { ::close(fd); return nullptr; }
+        void* p = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+        if (p == MAP_FAILED) { ::close(fd); return nullptr; }
+        auto* d = new Direct();
+        d->fd_ = fd;
+        d->p_ = (const uint8_t*)p;
+        d->n_ = (uint64_t)st.st_size;
+        if (!d->superblock()) { delete d; return nullptr; }
+        return d;
+    }
+    ~Direct() {
+        if (p_) munmap((void*)p_, (size_t)n_);
+        if (fd_ >= 0) ::close(fd_);
+    }
+
+    // the metadata is walked through the mapping (clustered in the file's metadata blocks: few pages); the raw data is read
+    // with pread into the caller's array -- touching it through the mapping costs a page fault per 4 KB, 25 us per chunk here
+    struct Span { const uint8_t* data = nullptr; uint64_t offset = 0, bytes = 0; };
+    bool copy(const Span& s, void* out) const {
+        if (s.data) { std::memcpy(out, s.data, (size_t)s.bytes); return true; }
+        uint64_t done = 0;
+        while (done < s.bytes) {
+            const ssize_t r = pread(fd_, (char*)out + done, (size_t)(s.bytes - done), (off_t)(s.offset + done));
+            if (r <= 0) return false;
+            done += (uint64_t)r;
+        }
+        return true;
+    }
+
+    // object header address of <group_addr>/<name>; 0 when absent or not understood
+    uint64_t child(uint64_t group_header, const char* name) const {
+        uint64_t bt = 0, heap = 0;
+        if (!symbol_table(group_header, bt, heap)) return 0;
+        return lookup(bt, heap, name);
+    }
+    uint64_t root() const { return root_header_; }
+
+    // raw bytes of a contiguous (or compact) dataset of `count` little-endian integers of `elem` bytes; false = don't know
+    bool dataset(uint64_t header, uint32_t elem, uint64_t count, Span& out) const {
+        Msgs m;
+        if (!messages(header, m) || !m.layout || !m.dtype || !m.dspace) return false;
+        // datatype: class 0 (fixed point) version 1-3, little-endian, no padding games we care about; size == elem
+        if (m.dtype_len < 8) return false;
+        const uint8_t cv = m.dtype[0];
+        if ((cv & 0x0f) != 0 || (cv >> 4) < 1 || (cv >> 4) > 3) return false;
+        if (m.dtype[1] & 0x01) return false;                                  // big-endian
+        if (rd32(m.dtype + 4) != elem) return false;
+        // dataspace: simple, no permutation; product of the dimensions == count
+        if (m.dspace_len < 8) return false;
+        const uint8_t sv = m.dspace[0], rank = m.dspace[1];
+        uint64_t at;
+        if (sv == 1) at = 8;
+        else if (sv == 2) { if (m.dspace[3] != 1 && !(m.dspace[3] == 0 && rank == 0)) return false; at = 4; }
+        else return false;
+        if (rank > 8 || m.dspace_len < at + 8ull * rank) return false;
+        uint64_t npoints = 1;
+        for (uint32_t k = 0; k < rank; ++k) {
+            const uint64_t dim = rd64(m.dspace + at + 8 * k);
+            if (dim != 0 && npoints > (1ull << 40) / dim) return false;
+            npoints *= dim;
+        }
+        if (npoints != count) return false;
+        if (m.filters) return false;
+        // layout v3: class 1 contiguous {address, size}; class 0 compact {size(2), bytes}
+        if (m.layout_len < 2 || m.layout[0] != 3) return false;
+        const uint64_t want = (uint64_t)elem * count;
+        if (m.layout[1] == 1) {
+            if (m.layout_len < 18) return false;
+            const uint64_t addr = rd64(m.layout + 2), size = rd64(m.layout + 10);
+            if (addr == ~0ull || size != want || !in(addr, size)) return false;
+            out.data = nullptr;
+            out.offset = addr;
+            out.bytes = size;
+            return true;
+        }
+        if (m.layout[1] == 0) {
+            if (m.layout_len < 4) return false;
+            const uint64_t size = rd16(m.layout + 2);
+            if (size != want || m.layout_len < 4 + size) return false;
+            out.data = m.layout + 4;
+            out.bytes = size;
+            return true;
+        }
+        return false;
+    }
+
+private:
+    const uint8_t* p_ = nullptr;
+    uint64_t n_ = 0, root_header_ = 0;
+    int fd_ = -1;
+
+    static uint16_t rd16(const uint8_t* q) { uint16_t v; std::memcpy(&v, q, 2); return v; }
+    static uint32_t rd32(const uint8_t* q) { uint32_t v; std::memcpy(&v, q, 4); return v; }
+    static uint64_t rd64(const uint8_t* q) { uint64_t v; std::memcpy(&v, q, 8); return v; }
+    bool in(uint64_t off, uint64_t len) const { return off <= n_ && len <= n_ - off; }
+
+    bool superblock() {
+        static const uint8_t sig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
+        if (std::memcmp(p_, sig, 8) != 0) return false;                       // a user block moves it: not ours
+        const uint8_t ver = p_[8];
+        if (ver > 1 || p_[13] != 8 || p_[14] != 8) return false;            // 8-byte offsets and lengths
+        uint64_t at = 24 + (ver == 1 ? 4 : 0);                               // v1 adds the indexed-storage K + 2 reserved bytes
+        if (!in(at, 32 + 40)) return false;
+        if (rd64(p_ + at) != 0) return false;                                 // base address
+        at += 32;                                                             // base, free-space, end-of-file, driver info
+        root_header_ = rd64(p_ + at + 8);                                     // root symbol table entry: name offset, header
+        return root_header_ != 0 && in(root_header_, 16);
+    }
+
+    struct Msgs {
+        const uint8_t *layout = nullptr, *dtype = nullptr, *dspace = nullptr, *symtab = nullptr;
+        uint64_t layout_len = 0, dtype_len = 0, dspace_len = 0, symtab_len = 0;
+        bool filters = false;
+    };
+
+    // version-1 object header: 16-byte prefix, then messages {type u16, size u16, flags u8, 3 reserved} in the first block
+    // and in every continuation block (message 0x10 = {address, length})
+    bool messages(uint64_t header, Msgs& m) const {
+        if (!in(header, 16) || p_[header] != 1) return false;
+        uint32_t left = rd16(p_ + header + 2);
+        struct Block { uint64_t at, len; } blocks[16];
+        int nb = 1, ib = 0;
+        blocks[0] = {header + 16, rd32(p_ + header + 8)};
+        while (left > 0 && ib < nb) {
+            uint64_t at = blocks[ib].at;
+            const uint64_t end = at + blocks[ib].len;
+            ++ib;
+            if (!in(at, end - at)) return false;
+            while (left > 0 && at + 8 <= end) {
+                const uint16_t type = rd16(p_ + at), size = rd16(p_ + at + 2);
+                const uint8_t flags = p_[at + 4];
+                const uint8_t* body = p_ + at + 8;
+                if (at + 8 + size > end) return false;
+                if (flags & 0x02) { if (type == 0x08 || type == 0x03 || type == 0x01) return false; }   // shared message
+                else if (type == 0x08) { m.layout = body; m.layout_len = size; }
+                else if (type == 0x03) { m.dtype = body; m.dtype_len = size; }
+                else if (type == 0x01) { m.dspace = body; m.dspace_len = size; }
+                else if (type == 0x11) { m.symtab = body; m.symtab_len = size; }
+                else if (type == 0x0b) m.filters = true;
+                else if (type == 0x10) {
+                    if (size < 16 || nb == 16) return false;
+                    blocks[nb++] = {rd64(body), rd64(body + 8)};
+                }
+                at += 8 + size;
+                --left;
+            }
+        }
+        return left == 0;
+    }
+
+    bool symbol_table(uint64_t header, uint64_t& btree, uint64_t& heap) const {
+        Msgs m;
+        if (!messages(header, m) || !m.symtab || m.symtab_len < 16) return false;
+        btree = rd64(m.symtab);
+        heap = rd64(m.symtab + 8);
+        return true;
+    }
+
+    // name at `off` of a local heap's data segment; nullptr when out of bounds or unterminated
+    const char* heap_name(uint64_t data, uint64_t size, uint64_t off) const {
+        if (off >= size) return nullptr;
+        const void* z = std::memchr(p_ + data + off, 0, (size_t)(size - off));
+        return z ? (const char*)(p_ + data + off) : nullptr;
+    }
+
+    uint64_t lookup(uint64_t btree, uint64_t heap, const char* name) const {
+        if (!in(heap, 32) || std::memcmp(p_ + heap, "HEAP", 4) != 0 || p_[heap + 4] != 0) return 0;
+        const uint64_t hsize = rd64(p_ + heap + 8), hdata = rd64(p_ + heap + 24);
+        if (!in(hdata, hsize)) return 0;
+        uint64_t node = btree;
+        for (int depth = 0; depth < 16; ++depth) {
+            if (!in(node, 24) || std::memcmp(p_ + node, "TREE", 4) != 0 || p_[node + 4] != 0) return 0;
+            const uint8_t level = p_[node + 5];
+            const uint32_t used = rd16(p_ + node + 6);
+            if (used == 0 || !in(node + 24, 16ull * used + 8)) return 0;
+            const uint8_t* kc = p_ + node + 24;                               // key0 child0 key1 child1 ... key_used
+            // child i holds the names in (key[i], key[i+1]]: the first i with name <= key[i+1]
+            uint32_t lo = 0, hi = used;                                       // answer in [lo, hi)
+            while (lo + 1 < hi) {
+                const uint32_t mid = (lo + hi) / 2;                           // is name <= key[mid]?  then the answer is < mid
+                const char* k = heap_name(hdata, hsize, rd64(kc + 16ull * mid));
+                if (!k) return 0;
+                if (std::strcmp(name, k) <= 0) hi = mid; else lo = mid;
+            }
+            const uint64_t next = rd64(kc + 16ull * lo + 8);
+            if (level > 0) { node = next; continue; }
+            // symbol node: "SNOD", version 1, count, entries of 40 bytes sorted by name
+            if (!in(next, 8) || std::memcmp(p_ + next, "SNOD", 4) != 0 || p_[next + 4] != 1) return 0;
+            const uint32_t count = rd16(p_ + next + 6);
+            if (!in(next + 8, 40ull * count)) return 0;
+            uint32_t a = 0, b = count;
+            while (a < b) {
+                const uint32_t mid = (a + b) / 2;
+                const uint8_t* e = p_ + next + 8 + 40ull * mid;
+                const char* k = heap_name(hdata, hsize, rd64(e));
+                if (!k) return 0;
+                const int c = std::strcmp(name, k);
+                if (c == 0) { const uint64_t h = rd64(e + 8); return in(h, 16) ? h : 0; }
+                if (c < 0) b = mid; else a = mid + 1;
+            }
+            return 0;
+        }
+        return 0;
+    }
+};
+
 }  // namespace
 
 struct pa_h5 {
     hid_t file = -1;
     hid_t lcpl = -1;  // create intermediate groups, as h5py's file[path] = data does
+    std::string path;
+    int32_t mode = 0;
+    Direct* direct = nullptr;
+    bool direct_tried = false;
+    int64_t direct_chunks = 0, library_chunks = 0;     // polish chunks read either way (pa_h5_read_stats)
+    ~pa_h5() { delete direct; }
 };
 
 extern "C" {
@@ -112,6 +346,8 @@ int pa_h5_open(const char* path, int32_t mode, pa_h5** out) {
     if (f < 0) return fail(std::string("cannot open HDF5 file '") + path + "'");
     auto* h = new pa_h5();
     h->file = f;
+    h->path = path;
+    h->mode = mode;
     h->lcpl = H5Pcreate(H5P_LINK_CREATE);
     H5Pset_create_intermediate_group(h->lcpl, 1);
     *out = h;
@@ -460,20 +696,53 @@ static int read_polish_chunks_impl(pa_h5* f, const char* names, int32_t n, int32
     Quiet q;
     hid_t root = H5Gopen2(f->file, "summaries", H5P_DEFAULT);
     if (root < 0) return fail("no group 'summaries'");
+    // the three large datasets of a chunk straight from the mapped file where the direct locator understands it (a file opened
+    // read-only; PEPPER_AMD_H5_DIRECT=0: always through the library); per chunk, so one odd group costs one library read
+    static const bool no_direct = getenv("PEPPER_AMD_H5_DIRECT") && getenv("PEPPER_AMD_H5_DIRECT")[0] == '0';
+    if (!f->direct_tried) {
+        f->direct_tried = true;
+        if (f->mode == 0 && !no_direct) f->direct = Direct::open(f->path.c_str());
+    }
+    const Direct* dd = no_direct ? nullptr : f->direct;
+    const uint64_t dsum = dd ? dd->child(dd->root(), "summaries") : 0;
     const char* name = names;
     int rc = 0;
     for (int32_t i = 0; i < n && !rc; ++i, name += strlen(name) + 1) {
         const std::string where = std::string("summaries/") + name + "/";
-        hid_t g = H5Gopen2(root, name, H5P_DEFAULT);
-        if (g < 0) { rc = fail("no group '" + where + "'"); break; }
-        rc = read_numeric(g, "image", H5T_NATIVE_UINT8, (int64_t)seq_len * features, images + (size_t)i * seq_len * features, where);
-        if (!rc) rc = read_numeric(g, "position", H5T_NATIVE_INT64, seq_len, position + (size_t)i * seq_len, where);
-        if (!rc) rc = read_numeric(g, "index", H5T_NATIVE_INT64, seq_len, index + (size_t)i * seq_len, where);
-        // the small datasets: read for the first and the last chunk of the call (and checked against the name), taken from
-        // the name for the others -- four of the seven objects of a chunk, at ~40 us of library time each
+        bool have = false;
+        if (dsum) {
+            const uint64_t g = dd->child(dsum, name);
+            Direct::Span a, b, c;
+            if (g && dd->dataset(dd->child(g, "image"), 1, (uint64_t)seq_len * features, a) &&
+                dd->dataset(dd->child(g, "position"), 8, (uint64_t)seq_len, b) &&
+                dd->dataset(dd->child(g, "index"), 8, (uint64_t)seq_len, c) &&
+                dd->copy(a, images + (size_t)i * seq_len * features) && dd->copy(b, position + (size_t)i * seq_len) &&
+                dd->copy(c, index + (size_t)i * seq_len)) {
+                have = true;
+                ++f->direct_chunks;
+            }
+        }
         std::string contig;
         int64_t s0 = 0, e0 = 0, c0 = 0;
         const bool named = from_names && parse_chunk_name(name, contig, s0, e0, c0) && (int)contig.size() < contig_stride;
+        if (have && named && i != 0 && i != n - 1) {            // nothing of this chunk needs the library
+            region_start[i] = s0;
+            region_end[i] = e0;
+            chunk_id[i] = c0;
+            std::memset(contigs + (size_t)i * contig_stride, 0, (size_t)contig_stride);
+            std::memcpy(contigs + (size_t)i * contig_stride, contig.data(), contig.size());
+            continue;
+        }
+        hid_t g = H5Gopen2(root, name, H5P_DEFAULT);
+        if (g < 0) { rc = fail("no group '" + where + "'"); break; }
+        if (!have) {
+            ++f->library_chunks;
+            rc = read_numeric(g, "image", H5T_NATIVE_UINT8, (int64_t)seq_len * features, images + (size_t)i * seq_len * features, where);
+            if (!rc) rc = read_numeric(g, "position", H5T_NATIVE_INT64, seq_len, position + (size_t)i * seq_len, where);
+            if (!rc) rc = read_numeric(g, "index", H5T_NATIVE_INT64, seq_len, index + (size_t)i * seq_len, where);
+        }
+        // the small datasets: read for the first and the last chunk of the call (and checked against the name), taken from
+        // the name for the others -- four of the seven objects of a chunk, at ~40 us of library time each
         if (!rc && (!named || i == 0 || i == n - 1)) {
             rc = read_numeric(g, "region_start", H5T_NATIVE_INT64, 1, region_start + i, where);
             if (!rc) rc = read_numeric(g, "region_end", H5T_NATIVE_INT64, 1, region_end + i, where);
@@ -506,6 +775,13 @@ int pa_h5_read_polish_chunks(pa_h5* f, const char* names, int32_t n, int32_t seq
         rc = read_polish_chunks_impl(f, names, n, seq_len, features, images, position, index, region_start, region_end, chunk_id,
                                      contigs, contig_stride, false);
     return rc;
+}
+
+int pa_h5_read_stats(pa_h5* f, int64_t* direct_chunks, int64_t* library_chunks) {
+    if (!f || !direct_chunks || !library_chunks) return fail("null argument");
+    *direct_chunks = f->direct_chunks;
+    *library_chunks = f->library_chunks;
+    return 0;
 }
 
 int pa_h5_write_polish_predictions(pa_h5* f, int32_t n, int32_t seq_len, const char* contigs, int32_t contig_stride,

@@ -37,6 +37,7 @@ SYMBOLS = [
     ("pa_h5_write_fixed_strings", ctypes.c_int, [c_void_p, c_char_p, c_int32, P64, c_int32, c_void_p]),
     ("pa_h5_write_vlen_strings", ctypes.c_int, [c_void_p, c_char_p, c_int32, P64, ctypes.POINTER(c_char_p)]),
     ("pa_h5_read_polish_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32]),
+    ("pa_h5_read_stats", ctypes.c_int, [c_void_p, P64, P64]),
     ("pa_h5_read_polish_prediction_region", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                                            ctypes.POINTER(c_int32)]),
     ("pa_h5_write_polish_image_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32, c_char_p, c_int64, c_int64] +
@@ -177,6 +178,12 @@ class File(object):
                                                   index.ctypes.data, start.ctypes.data, end.ctypes.data, chunk.ctypes.data,
                                                   contigs.ctypes.data, contig_width))
         return contigs, start, end, chunk, images, position, index
+
+    def read_stats(self):
+        """(polish chunks copied straight from the mapped file, polish chunks read through libhdf5) of this handle"""
+        a, b = c_int64(), c_int64()
+        _check(self._lib.pa_h5_read_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     @_locked
     def read_polish_prediction_region(self, region_path, seq_len, max_chunks=64):

@@ -264,3 +264,90 @@ def test_polish_image_chunks_bulk_writer_equals_write_summary(tmp_path):
                 p = "summaries/%s/%s" % (name, ds_name)
                 assert fa.info(p) == fb.info(p), (p, fa.info(p), fb.info(p))
                 assert np.array_equal(fa[p], fb[p]), p
+
+
+def _chunks_by_dataset(f, names):
+    return (np.stack([f["summaries/%s/image" % n] for n in names]), np.stack([f["summaries/%s/position" % n] for n in names]),
+            np.stack([f["summaries/%s/index" % n] for n in names]))
+
+
+def test_direct_chunk_reads_equal_the_library(tmp_path):
+    """read_polish_chunks copies image / position / index straight out of the mapped file where hdf5io.cpp's locator knows
+    the format (classic files of h5py and of mode "w"); the bytes are those libhdf5 returns dataset by dataset -- over a
+    group tree three B-tree levels deep, and with the library taking over where the
+    locator says it does not know (1.10-format file)."""
+    n, seq, feat = 2600, 16, 10
+    rng = np.random.default_rng(5)
+    images = rng.integers(0, 255, (n, seq, feat), dtype=np.uint8)
+    position = rng.integers(-1, 1 << 40, (n, seq, 2)).astype(np.int64)
+    labels = np.zeros((n, seq), np.uint8)
+    # names that sort differently as strings and as numbers, long and short contigs, several regions
+    names, regions = [], []
+    for i in range(n):
+        contig = ("c%d" % (i % 7)) if i % 3 else "a_rather_long_contig_name_with_underscores_%d" % (i % 5)
+        regions.append((contig, (i // 40) * 1000, (i // 40) * 1000 + 1200, i % 40))
+        names.append("%s_%d_%d_%d" % regions[-1])
+    assert len(set(names)) == n
+    path = str(tmp_path / "tree.hdf")
+    with h5.File(path, "w") as f:
+        for i in range(n):
+            c, s, e, k = regions[i]
+            f.write_polish_image_chunks([names[i]], c, s, e, np.array([k], np.int64), images[i:i + 1], labels[i:i + 1],
+                                        np.ascontiguousarray(position[i:i + 1, :, 0]), np.ascontiguousarray(position[i:i + 1, :, 1]))
+    order = rng.permutation(n).tolist()
+    asked = [names[i] for i in order]
+    with h5.File(path) as f:
+        contigs, start, end, chunk, im, pos, idx = f.read_polish_chunks(asked, seq, feat)
+        assert f.read_stats() == (n, 0)
+        a, b, c = _chunks_by_dataset(f, asked[:200])
+    assert np.array_equal(im, images[order]) and np.array_equal(pos, position[order, :, 0]) and np.array_equal(idx, position[order, :, 1])
+    assert np.array_equal(a, im[:200]) and np.array_equal(b, pos[:200]) and np.array_equal(c, idx[:200])
+    assert [x.decode() for x in contigs] == [regions[i][0] for i in order]
+    assert start.tolist() == [regions[i][1] for i in order] and chunk.tolist() == [regions[i][3] for i in order]
+    with h5.File(path) as f, pytest.raises(h5.H5Error):
+        f.read_polish_chunks(["c1_0_1200_39x"], seq, feat)                   # an absent group is still an error
+    with h5.File(path) as f, pytest.raises(h5.H5Error):
+        f.read_polish_chunks(asked[:2], seq + 1, feat)                       # a wrong shape too
+
+    new = str(tmp_path / "v110.hdf")                                         # links in the object header, no symbol table
+    with h5.File(new, "w-new") as f:
+        f.write_polish_image_chunks(["x_0_1_%d" % k for k in range(5)], "x", 0, 1, np.arange(5, dtype=np.int64), images[:5], labels[:5],
+                                    np.ascontiguousarray(position[:5, :, 0]), np.ascontiguousarray(position[:5, :, 1]))
+    with h5.File(new) as f:
+        got = f.read_polish_chunks(["x_0_1_%d" % k for k in range(5)], seq, feat)
+        assert f.read_stats() == (0, 5)
+        assert np.array_equal(got[4], images[:5]) and np.array_equal(got[5], position[:5, :, 0])
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/conda/bin/python3.9"), reason="needs the image's h5py interpreter")
+def test_direct_chunk_reads_leave_unknown_layouts_to_the_library(tmp_path):
+    """Files the locator must not guess about: compressed (chunked) datasets, big-endian or narrower integers, a user block
+    in front of the superblock, the latest object formats.  Each is read through libhdf5 with the same values."""
+    script = (
+        "import h5py, numpy as np, sys\n"
+        "rng = np.random.default_rng(3)\n"
+        "im = rng.integers(0, 255, (4, 16, 10), dtype=np.uint8); pos = rng.integers(0, 1 << 33, (4, 16)); idx = pos % 5\n"
+        "np.savez(sys.argv[1] + '/want.npz', im=im, pos=pos, idx=idx)\n"
+        "def fill(f, kind):\n"
+        "    for i in range(4):\n"
+        "        g = f.create_group('summaries/c_0_10_%d' % i)\n"
+        "        if kind == 'gzip': g.create_dataset('image', data=im[i], compression='gzip')\n"
+        "        else: g['image'] = im[i]\n"
+        "        g['position'] = pos[i].astype('>i8') if kind == 'be' else pos[i]\n"
+        "        g['index'] = idx[i].astype('i4') if kind == 'narrow' else idx[i]\n"
+        "        g['contig'] = 'c'; g['region_start'] = 0; g['region_end'] = 10; g['chunk_id'] = i\n"
+        "for kind in ('plain', 'gzip', 'be', 'narrow'):\n"
+        "    with h5py.File(sys.argv[1] + '/' + kind + '.hdf', 'w') as f: fill(f, kind)\n"
+        "with h5py.File(sys.argv[1] + '/userblock.hdf', 'w', userblock_size=512) as f: fill(f, 'plain')\n"
+        "with h5py.File(sys.argv[1] + '/latest.hdf', 'w', libver='latest') as f: fill(f, 'plain')\n")
+    r = subprocess.run(["/opt/conda/bin/python3.9", "-c", script, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = np.load(str(tmp_path / "want.npz"))
+    names = ["c_0_10_%d" % i for i in range(4)]
+    for kind, stats in (("plain", (4, 0)), ("gzip", (0, 4)), ("be", (0, 4)), ("narrow", (0, 4)), ("userblock", (0, 4)),
+                        ("latest", (0, 4))):
+        with h5.File(str(tmp_path / (kind + ".hdf"))) as f:
+            got = f.read_polish_chunks(names, 16, 10)
+            assert f.read_stats() == stats, (kind, f.read_stats())
+        assert np.array_equal(got[4], want["im"]) and np.array_equal(got[5], want["pos"]) and np.array_equal(got[6], want["idx"]), kind
+        assert got[3].tolist() == [0, 1, 2, 3]
