@@ -95,7 +95,7 @@ typedef struct {
     int32_t jump;           /* TrainOptions.WINDOW_JUMP = 50                                   */
     int32_t overlap;        /* SEQ_OVERLAP = 50                                                */
     int32_t device;
-    int32_t max_chunk;      /* chunks per device pass (0 = default 8192)                       */
+    int32_t max_chunk;      /* chunks per device pass (0 = default 16384)                       */
 } pa_polish_config;
 
 int pa_polish_create(const pa_polish_config* cfg, const char* const* names,
@@ -118,6 +118,13 @@ int pa_polish_predict_device(pa_polish_model* m, const uint8_t* images, int64_t 
                              uint8_t* phred, float* acc);
 int pa_polish_predict_host(pa_polish_model* m, const uint8_t* images, int64_t n, uint8_t* labels,
                            uint8_t* phred, float* acc);
+/* The same over n_parts HOST blocks taken as one sequence of chunks (images[p] uint8 [counts[p], seq_length, features] ->
+ * labels[p], phred[p] uint8 [counts[p], seq_length]): one series of device passes of up to max_chunk chunks, whatever the
+ * blocks' sizes.  A polish pass costs about the same for 2 048 chunks as for 16 384 (one workgroup walks the time steps of
+ * 128 chunks), so callers that hold chunks in several buffers -- one per reader process of the HDF5 loop standing in for the
+ * reference's DataLoader(num_workers) (predict_distributed_gpu.py:40-47) -- hand them over together. */
+int pa_polish_predict_host_parts(pa_polish_model* m, int32_t n_parts, const uint8_t* const* images, const int64_t* counts,
+                                 uint8_t* const* labels, uint8_t* const* phred);
 
 /* ------------------------------------------------------------------------------------------
  * Per-kernel timing with HIP events recorded on the handle's own stream (what bench.py's

@@ -49,6 +49,7 @@ SYMBOLS = [
                                                 c_void_p, c_void_p]),
     ("pa_polish_predict_device", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     ("pa_polish_predict_host", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    ("pa_polish_predict_host_parts", ctypes.c_int, [c_void_p, ctypes.c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("pa_profile_enable", ctypes.c_int, [c_void_p, c_int32]),
     ("pa_profile_count", ctypes.c_int, [c_void_p]),
     ("pa_profile_get", ctypes.c_int, [c_void_p, c_int32, c_char_p, c_int32, ctypes.POINTER(c_double),

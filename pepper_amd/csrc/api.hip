@@ -926,7 +926,7 @@ int pa_polish_create(const pa_polish_config* cfg, const char* const* names, cons
         return fail(PA_ERR_INVALID, "bad pa_polish_config (hidden_size must be 128 or 256)");
     auto* m = new pa_polish_model();
     m->cfg = *cfg;
-    if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 8192;
+    if (m->cfg.max_chunk <= 0) m->cfg.max_chunk = 16384;   // 128 chunks per workgroup and direction: 256 workgroups
     m->cfg.max_chunk = std::min<int32_t>(m->cfg.max_chunk, (int32_t)((int64_t)0xf0000000 / ((int64_t)cfg->window * 2 * cfg->hidden_size * 4)));
     if (const char* e = getenv("PA_FUSE_INPUT")) m->fuse_input = e[0] != '0';
     if (const char* e = getenv("PA_SPLIT_GEMM")) m->split_gemm = e[0] != '0';
@@ -1063,10 +1063,16 @@ int pa_polish_predict_device(pa_polish_model* m, const uint8_t* images, int64_t 
     return PA_OK;
 }
 
-int pa_polish_predict_host(pa_polish_model* m, const uint8_t* images, int64_t n, uint8_t* labels,
-                           uint8_t* phred, float* acc) {
-    if (!m || m->magic != 0x50414d44) return fail(PA_ERR_INVALID, "bad model handle");
-    if (n < 0 || (n > 0 && (!images || !labels || !phred))) return fail(PA_ERR_INVALID, "null buffer");
+// One or several host blocks as ONE sequence of device passes: the polish kernels give a workgroup 128 chunks of one
+// direction and walk their time steps in sequence, so a pass costs about the same for 2 048 chunks as for 16 384 -- callers
+// that hold their chunks in several buffers (the reader lanes' slots, pepper_amd/hostpipe.py) hand them over together.
+static int polish_predict_host_impl(pa_polish_model* m, int32_t n_parts, const uint8_t* const* images, const int64_t* counts,
+                                    uint8_t* const* labels, uint8_t* const* phred, float* acc) {
+    int64_t n = 0;
+    for (int32_t p = 0; p < n_parts; ++p) {
+        if (counts[p] < 0 || (counts[p] > 0 && (!images[p] || !labels[p] || !phred[p]))) return fail(PA_ERR_INVALID, "null buffer");
+        n += counts[p];
+    }
     if (n == 0) return PA_OK;
     HIP_TRY(hipSetDevice(m->device));
     if (int rc = m->pipe_init()) return rc;
@@ -1074,6 +1080,17 @@ int pa_polish_predict_host(pa_polish_model* m, const uint8_t* images, int64_t n,
     const int64_t chunk = m->cfg.max_chunk;
     const size_t cap = (size_t)std::min<int64_t>(chunk, n);
     auto& pp = m->pipe;
+    // the pieces of the parts that make up units [off, off + c): f(part, first unit within the part, first unit within the pass, units)
+    auto pieces = [&](int64_t off, int64_t c, auto&& f) -> int {
+        int64_t start = 0;
+        for (int32_t p = 0; p < n_parts; ++p) {
+            const int64_t lo = std::max(off, start), hi = std::min(off + c, start + counts[p]);
+            if (lo < hi)
+                if (int rc = f(p, lo - start, lo - off, hi - lo)) return rc;
+            start += counts[p];
+        }
+        return PA_OK;
+    };
     int64_t i = 0;
     for (int64_t off = 0; off < n; off += chunk, ++i) {
         const int64_t c = std::min<int64_t>(chunk, n - off);
@@ -1084,7 +1101,12 @@ int pa_polish_predict_host(pa_polish_model* m, const uint8_t* images, int64_t n,
         if (acc)
             if (int rc = m->stage_acc[k]->ensure(cap * S * C * sizeof(float))) return rc;
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(pp.h2d, pp.in_free[k], 0));
-        HIP_TRY(hipMemcpyAsync(m->stage_in[k]->p, images + (size_t)off * S * F, (size_t)c * S * F, hipMemcpyHostToDevice, pp.h2d));
+        if (int rc = pieces(off, c, [&](int32_t p, int64_t in_part, int64_t in_pass, int64_t units) -> int {
+                HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(m->stage_in[k]->p) + (size_t)in_pass * S * F,
+                                       images[p] + (size_t)in_part * S * F, (size_t)units * S * F, hipMemcpyHostToDevice, pp.h2d));
+                return PA_OK;
+            }))
+            return rc;
         HIP_TRY(hipEventRecord(pp.in_ready[k], pp.h2d));
         HIP_TRY(hipStreamWaitEvent(m->stream, pp.in_ready[k], 0));
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->stream, pp.out_free[k], 0));
@@ -1095,9 +1117,15 @@ int pa_polish_predict_host(pa_polish_model* m, const uint8_t* images, int64_t n,
         HIP_TRY(hipEventRecord(pp.in_free[k], m->stream));
         HIP_TRY(hipEventRecord(pp.out_ready[k], m->stream));
         HIP_TRY(hipStreamWaitEvent(pp.d2h, pp.out_ready[k], 0));
-        HIP_TRY(hipMemcpyAsync(labels + (size_t)off * S, m->stage_lab[k]->p, (size_t)c * S, hipMemcpyDeviceToHost, pp.d2h));
-        HIP_TRY(hipMemcpyAsync(phred + (size_t)off * S, m->stage_ph[k]->p, (size_t)c * S, hipMemcpyDeviceToHost, pp.d2h));
-        if (acc)
+        if (int rc = pieces(off, c, [&](int32_t p, int64_t in_part, int64_t in_pass, int64_t units) -> int {
+                HIP_TRY(hipMemcpyAsync(labels[p] + (size_t)in_part * S, static_cast<uint8_t*>(m->stage_lab[k]->p) + (size_t)in_pass * S,
+                                       (size_t)units * S, hipMemcpyDeviceToHost, pp.d2h));
+                HIP_TRY(hipMemcpyAsync(phred[p] + (size_t)in_part * S, static_cast<uint8_t*>(m->stage_ph[k]->p) + (size_t)in_pass * S,
+                                       (size_t)units * S, hipMemcpyDeviceToHost, pp.d2h));
+                return PA_OK;
+            }))
+            return rc;
+        if (acc)     // single-part callers only (pa_polish_predict_host)
             HIP_TRY(hipMemcpyAsync(acc + (size_t)off * S * C, m->stage_acc[k]->p, (size_t)c * S * C * sizeof(float),
                                    hipMemcpyDeviceToHost, pp.d2h));
         HIP_TRY(hipEventRecord(pp.out_free[k], pp.d2h));
@@ -1105,6 +1133,20 @@ int pa_polish_predict_host(pa_polish_model* m, const uint8_t* images, int64_t n,
     HIP_TRY(hipStreamSynchronize(pp.d2h));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return PA_OK;
+}
+
+int pa_polish_predict_host(pa_polish_model* m, const uint8_t* images, int64_t n, uint8_t* labels,
+                           uint8_t* phred, float* acc) {
+    if (!m || m->magic != 0x50414d44) return fail(PA_ERR_INVALID, "bad model handle");
+    if (n < 0 || (n > 0 && (!images || !labels || !phred))) return fail(PA_ERR_INVALID, "null buffer");
+    return polish_predict_host_impl(m, 1, &images, &n, &labels, &phred, acc);
+}
+
+int pa_polish_predict_host_parts(pa_polish_model* m, int32_t n_parts, const uint8_t* const* images, const int64_t* counts,
+                                 uint8_t* const* labels, uint8_t* const* phred) {
+    if (!m || m->magic != 0x50414d44) return fail(PA_ERR_INVALID, "bad model handle");
+    if (n_parts < 0 || (n_parts > 0 && (!images || !counts || !labels || !phred))) return fail(PA_ERR_INVALID, "bad argument");
+    return polish_predict_host_impl(m, n_parts, images, counts, labels, phred, nullptr);
 }
 
 // ---- profiler / sync -----------------------------------------------------------------------------

@@ -46,14 +46,16 @@ _pagelock_warned = False
 
 
 def _attach(name):
-    """Attach to a segment the parent owns; the attaching process must not let its resource tracker unlink it."""
-    shm = shared_memory.SharedMemory(name=name)
+    """Attach to a segment the parent owns.  Python 3.10 registers every attach with the resource tracker, which would then
+    unlink the parent's segment when this process ends (and, a reader and a writer attaching the same segment, trips over
+    its own bookkeeping: "KeyError" tracebacks from resource_tracker.py): attach without registering."""
+    from multiprocessing import resource_tracker
+    register = resource_tracker.register
+    resource_tracker.register = lambda *a, **k: None
     try:
-        from multiprocessing import resource_tracker
-        resource_tracker.unregister(shm._name, "shared_memory")
-    except Exception:
-        pass
-    return shm
+        return shared_memory.SharedMemory(name=name)
+    finally:
+        resource_tracker.register = register
 
 
 class Slots(object):
@@ -333,13 +335,23 @@ def polish_writer(lane, result_q, *args):
 
 
 def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1000, features=10, slots_per_lane=3, log=None,
-                 prepare=None):
+                 prepare=None, predict_parts=None, more_predict=None, in_flight=1, pass_blocks=1):
     """Run the polish predict loop over `files` with `lanes` reader/writer process pairs.
 
     predict_block(image u8 [n, seq, features], labels u8 [n, seq], phred u8 [n, seq]) runs the device pass on host
     arrays that live in page-locked shared memory and fills labels / phred; prepare() (optional) runs in this process
     right after the workers have been started.  Output files: `<output_stem>.hdf` for one
-    lane, `<output_stem>_<lane>.hdf` otherwise.  Returns the number of chunks processed."""
+    lane, `<output_stem>_<lane>.hdf` otherwise.  Returns the number of chunks processed.
+
+    The polish kernel gives a workgroup 128 chunks of one direction and walks their 1 900 time steps in sequence, so a
+    device pass takes 60-75 ms whether it holds 512 chunks or 16 384: one lane's block of 4 096 chunks alone leaves three
+    quarters of the chip idle (and five such passes side by side on their own streams took 205 ms each).  Hence
+    pass_blocks > 1 with predict_parts([(image, labels, phred), ...]) -- the blocks that arrived while the device was busy,
+    up to pass_blocks of them, go to the device as ONE pass (pa_polish_predict_host_parts) -- and in_flight > 1 with
+    more_predict() (returns one more independent predictor of the same kind: its own model handle, streams and staging
+    buffers) -- that many passes are under way at once, each on its own thread (the library call releases the GIL), so
+    that the copies of one lie beside the kernels of the other.  The first block does not wait for company.  Blocks reach
+    a lane's writer in the order its reader produced them."""
     t_begin = time.perf_counter()
     groups = deal_files(files, max(1, lanes))
     lanes = len(groups)
@@ -354,7 +366,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
     write_qs = [ctx.Queue() for _ in range(lanes)]
     procs = []
     done = 0
-    locker = None
+    locker = pool = None          # bound before the try: the finally reads them when prepare() or a worker start raises
     try:
         for k in range(lanes):
             for s in range(slots_per_lane):
@@ -373,35 +385,106 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
         # uploads) running beside it took 0.4 s instead of 0.07 s
         # PEPPER_AMD_POLISH_PIN=0: leave the slots pageable (the copies are then staged by the runtime; the path needs ~1 GB/s)
         locker = register_async(slots, _have_gpu() and os.environ.get("PEPPER_AMD_POLISH_PIN", "1") != "0")
-        reading, writing = lanes, lanes
+
+        def one_by_one(parts):
+            for part in parts:
+                predict_block(*part)
+        depth = max(1, int(in_flight)) if more_predict is not None else 1
+        per_pass = max(1, int(pass_blocks))
+        predictors = [predict_parts if predict_parts is not None else one_by_one]
+        extra = []
+        if depth > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=depth)
+            extra = [pool.submit(more_predict) for _ in range(depth - 1)]    # built beside the first pass
+        pending = collections.deque()           # (lane, slot, n, meta) received and not yet on the device, oldest first
+        inflight = collections.deque()          # (future or None, [blocks]) passes under way, oldest first
+        read_done = set()                       # lanes whose end marker waits for their last blocks to retire
+        spans = []                              # (start, end, chunks) of every device pass, for the trace
+        launched = 0
+        writing = lanes
+
+        def run(predict, take):
+            views = [layout.views(slots[lane].segments[slot].buf, n) for lane, slot, n, _ in take]
+            t0 = time.perf_counter()
+            try:
+                predict([(v[0], v[3], v[4]) for v in views])
+            finally:
+                del views
+                spans.append((t0, time.perf_counter(), sum(item[2] for item in take)))
+
+        def launch():
+            nonlocal launched
+            take = [pending.popleft() for _ in range(min(per_pass, len(pending)))]
+            for lane, slot, _, _ in take:
+                slots[lane].ready(slot)
+            if launched == 0:
+                _trace(t_begin, "first block on the GPU")
+            if pool is None:
+                run(predictors[0], take)
+                inflight.append((None, take))
+            else:
+                while len(predictors) < min(depth, launched + 1):
+                    more = extra[len(predictors) - 1].result()
+                    predictors.append(more if predict_parts is not None else
+                                      (lambda parts, one=more: [one(*part) for part in parts]))
+                inflight.append((pool.submit(run, predictors[launched % len(predictors)], take), take))
+            launched += 1
+
+        def retire():
+            nonlocal done
+            fut, take = inflight.popleft()
+            if fut is not None:
+                fut.result()
+            for lane, slot, n, meta in take:
+                write_qs[lane].put((slot, n, meta))
+                done += n
+            if log is not None:
+                log(done)
+            for lane in {item[0] for item in take} & read_done:
+                if all(item[0] != lane for item in pending) and all(item[0] != lane for _, blocks in inflight for item in blocks):
+                    read_done.discard(lane)
+                    write_qs[lane].put(None)             # the end marker follows the lane's last block
+
         while writing:
-            msg = _next_message(result_q, procs)
+            while pending and len(inflight) < depth:
+                launch()
+                if pool is None:
+                    retire()
+            # with passes under way, do not sleep on the queue past the moment the oldest one is done: its slots (freed by
+            # the writers) may be what the readers are waiting for
+            msg = _next_message(result_q, procs, poll=0.002 if inflight else None)
+            if msg is None:
+                while inflight and inflight[0][0].done():
+                    retire()
+                continue
             kind, lane = msg[0], msg[1]
             if kind == "error":
                 raise (SlotTooSmall if "SlotTooSmall" in msg[2] else LaneError)("lane %d failed:\n%s" % (lane, msg[2]))
             if kind == "block":
                 _, _, slot, n, meta = msg
-                image, _, _, labels, phred = layout.views(slots[lane].segments[slot].buf, n)
-                slots[lane].ready(slot)
-                if done == 0:
-                    _trace(t_begin, "first block on the GPU")
-                predict_block(image, labels, phred)
-                del image, labels, phred
-                write_qs[lane].put((slot, n, meta))
-                done += n
-                if log is not None:
-                    log(done)
+                pending.append((lane, slot, n, meta))
             elif kind == "read_done":
-                reading -= 1
-                write_qs[lane].put(None)
+                if any(item[0] == lane for item in pending) or any(item[0] == lane for _, blocks in inflight for item in blocks):
+                    read_done.add(lane)
+                else:
+                    write_qs[lane].put(None)
             elif kind == "write_done":
                 writing -= 1
         _trace(t_begin, "all lanes written")
+        if spans and os.environ.get("PEPPER_AMD_LANE_TRACE"):
+            busy = sum(b - a for a, b, _ in spans)
+            sys.stderr.write("[lanes] %d device passes of %.0f chunks and %.1f ms on average, %.2f of them at once over %.2f s\n"
+                             % (len(spans), sum(c for _, _, c in spans) / len(spans), 1e3 * busy / len(spans),
+                                busy / max(1e-9, max(b for _, b, _ in spans) - spans[0][0]),
+                                max(b for _, b, _ in spans) - spans[0][0]))
         locker.join()
         for p in procs:
             p.join(timeout=60)
         _trace(t_begin, "workers joined")
     finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
         for p in procs:
             if p.is_alive():
                 p.terminate()

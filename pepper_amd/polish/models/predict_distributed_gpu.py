@@ -25,9 +25,14 @@ def _log(msg):
     sys.stderr.flush()
 
 
-DEVICE_CHUNKS = 8192     # chunks per device pass (19 windows of 100 rows each; 128 chunks per workgroup and direction)
+DEVICE_CHUNKS = 16384    # chunks per device pass (19 windows of 100 rows each; 128 chunks per workgroup and direction: 256 workgroups)
 LANE_CHUNKS = int(os.environ.get("PEPPER_AMD_POLISH_BLOCK", 4096))   # chunks a reader lane hands over at a time (a slot: 115 MB, 49 MB of it page-locked)
-
+# The device loop of the lanes: a pass walks 1 900 time steps in sequence and takes 60-75 ms whether it holds 512 chunks or
+# 16 384 (one workgroup per 128 chunks and direction), so the blocks that arrive while the device is busy go to it together --
+# up to LANE_PASS_BLOCKS of them as one pass -- and LANE_PASSES_IN_FLIGHT passes are under way at once, each through its own
+# model handle (the copies of one beside the kernels of the other).
+LANE_PASS_BLOCKS = int(os.environ.get("PEPPER_AMD_POLISH_PASS_BLOCKS", max(1, DEVICE_CHUNKS // LANE_CHUNKS)))
+LANE_PASSES_IN_FLIGHT = int(os.environ.get("PEPPER_AMD_POLISH_IN_FLIGHT", 2))
 
 def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size, num_workers, rank, device_id,
             model=None):
@@ -51,11 +56,21 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
         def log(done):
             if rank == 0:
                 _log("INFO: CHUNKS PROCESSED " + str(done) + ".")
+        def predict_with(get):
+            def predict_parts(parts):
+                torch.cuda.set_device(device_id)            # the passes run on pool threads
+                get().predict_chunk_parts_into(parts)
+            return predict_parts
+
+        def more_predict():
+            torch.cuda.set_device(device_id)
+            other = get_model().clone()
+            return predict_with(lambda: other)
         try:
-            hostpipe.polish_lanes(file_chunks, output_filepath + "pepper_prediction_" + str(rank),
-                                  lambda image, labels, phred: get_model().predict_chunks_into(image, labels, phred), lanes,
+            hostpipe.polish_lanes(file_chunks, output_filepath + "pepper_prediction_" + str(rank), None, lanes,
                                   block=LANE_CHUNKS, seq_len=ImageSizeOptions.SEQ_LENGTH, features=ImageSizeOptions.IMAGE_HEIGHT,
-                                  slots_per_lane=2, log=log, prepare=get_model)
+                                  slots_per_lane=2, log=log, prepare=get_model, predict_parts=predict_with(get_model),
+                                  more_predict=more_predict, in_flight=LANE_PASSES_IN_FLIGHT, pass_blocks=LANE_PASS_BLOCKS)
             return rank
         except hostpipe.NoSharedMemory as e:
             # raised before any worker started or any file was written (the ranks of one host share /dev/shm)

@@ -26,6 +26,7 @@ class TransducerGRU(object):
         self.device = torch.cuda.current_device() if device is None and torch.cuda.is_available() else (device or 0)
         self._handle = None
         self._stream = None
+        self._state = None
 
     def load_state_dict(self, state_dict, strict=True):
         lib = _lib.load()
@@ -40,7 +41,15 @@ class TransducerGRU(object):
         _lib.check(lib.pa_polish_create(ctypes.byref(cfg), names, data, numel, n,
                                         ctypes.c_void_p(self._stream.cuda_stream), ctypes.byref(handle)))
         self._handle = handle
+        self._state = state_dict
         return self
+
+    def clone(self):
+        """A second, independent handle on the same weights (own stream, own staging buffers): what runs a second block on
+        the device while this one's pass is under way (pepper_amd/hostpipe.py polish_lanes)."""
+        other = TransducerGRU(1, self.image_features, self.num_layers, self.hidden_size, self.num_classes, device=self.device,
+                              max_chunk=self.max_chunk)
+        return other.load_state_dict(self._state)
 
     def eval(self):
         return self
@@ -116,6 +125,22 @@ class TransducerGRU(object):
             raise ValueError("labels / phred must be [B, seq_length]")
         _lib.check(_lib.load().pa_polish_predict_host(self.handle, images.ctypes.data, n, labels.ctypes.data,
                                                       phred.ctypes.data, None))
+
+    def predict_chunk_parts_into(self, parts):
+        """predict_chunks_into over several host blocks as one sequence of chunks: parts = [(images [n_p,1000,10], labels
+        [n_p,1000], phred [n_p,1000]), ...].  One series of full-sized device passes whatever the blocks' sizes
+        (pa_polish_predict_host_parts)."""
+        import numpy as np
+        k = len(parts)
+        for images, labels, phred in parts:
+            for a in (images, labels, phred):
+                if a.dtype != np.uint8 or not a.flags.c_contiguous:
+                    raise ValueError("predict_chunk_parts_into wants C-contiguous uint8 arrays")
+            if labels.shape != (images.shape[0], images.shape[1]) or phred.shape != labels.shape:
+                raise ValueError("labels / phred must be [B, seq_length]")
+        ptr = lambda col: (ctypes.c_void_p * k)(*[p[col].ctypes.data for p in parts])   # noqa: E731
+        counts = (ctypes.c_int64 * k)(*[p[0].shape[0] for p in parts])
+        _lib.check(_lib.load().pa_polish_predict_host_parts(self.handle, k, ptr(0), counts, ptr(1), ptr(2)))
 
     def predict_chunks(self, images, return_acc=False):
         """images uint8 [B,1000,10] -> (labels uint8 [B,1000], phred uint8 [B,1000][, acc])."""

@@ -149,3 +149,27 @@ def test_fused_head_equals_the_separate_head():
     rl, rp, inter = models_np.polish_predict_chunks(sd, imgs[pick], 128, return_intermediates=True)
     assert np.abs(a0[pick] - inter["acc"]).max() < TOL
     _check_labels(l0.cpu().numpy()[pick], p0.cpu().numpy()[pick], inter["acc"], rl, rp, inter["phred_f32"])
+
+
+def test_host_blocks_taken_together_equal_the_blocks_one_by_one():
+    """pa_polish_predict_host_parts: several host blocks go to the device as one sequence of chunks (what the reader lanes'
+    slots are handed over as); per chunk the results are those of the blocks predicted alone -- with parts smaller and
+    larger than a device pass, an empty part, and a second handle cloned from the first."""
+    sd = synthetic.polish_state_dict(seed=33, gain=2.0)
+    img = synthetic.polish_chunks(300, seed=6)
+    a = _model(sd, max_chunk=128)
+    want_l = np.empty((300, 1000), np.uint8)
+    want_p = np.empty((300, 1000), np.uint8)
+    a.predict_chunks_into(img, want_l, want_p)
+    cuts = [0, 7, 7, 150, 171, 300]                              # parts of 7, 0, 143, 21, 129 chunks
+    for model in (a, a.clone()):
+        parts = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            parts.append((np.ascontiguousarray(img[lo:hi]), np.full((hi - lo, 1000), 255, np.uint8), np.full((hi - lo, 1000), 255, np.uint8)))
+        model.predict_chunk_parts_into(parts)
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), want_l)
+        assert np.array_equal(np.concatenate([p[2] for p in parts]), want_p)
+        model.predict_chunk_parts_into([])
+    with pytest.raises(ValueError):
+        a.predict_chunk_parts_into([(img[:2], want_l[:3], want_p[:2])])
+    a.close()
