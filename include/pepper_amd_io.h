@@ -91,6 +91,25 @@ int pa_h5_write_prediction_batch(pa_h5* f, const char* group, int32_t n, const c
 int pa_h5_read_polish_chunks(pa_h5* f, const char* names, int32_t n, int32_t seq_len, int32_t features, uint8_t* images,
                              int64_t* position, int64_t* index, int64_t* region_start, int64_t* region_end,
                              int64_t* chunk_id, char* contigs, int32_t contig_stride);
+/* Append-only builder of a polish prediction file (pepper_amd/csrc/h5build.cpp; no libhdf5 involved): the same groups and
+ * datasets as pa_h5_write_polish_predictions -- predictions/<contig>/<contig>-<start>-<end>/{contig_start, contig_end int64
+ * scalars} and .../<chunk_id>/{position, index int64 [seq], bases, phred_score uint8 [seq]} (pepper DataStorePredict.py:49-76)
+ * -- in the classic HDF5 format h5py writes by default: raw rows are appended as they arrive, all metadata (object headers,
+ * local heaps, symbol nodes, group B-trees, superblock) is written by pa_h5_builder_close.  ~3 us of CPU per chunk instead of
+ * libhdf5's 70-150 us.  The file is not an HDF5 file until close has returned 0; names, shapes and dtypes are what the
+ * reference's readers expect (tests/test_hdf5_layout.py reads it back with libhdf5 and h5py).  Same arguments, duplicate
+ * handling (new_region / skip flags decided by the caller) and errors as the libhdf5 entry point. */
+typedef struct pa_h5_builder pa_h5_builder;
+int pa_h5_builder_open(const char* path, pa_h5_builder** out);
+int pa_h5_builder_write_polish_predictions(pa_h5_builder* b, int32_t n, int32_t seq_len, const char* contigs, int32_t contig_stride,
+                                           const int64_t* contig_start, const int64_t* contig_end, const int64_t* chunk_id,
+                                           const uint8_t* new_region, const uint8_t* skip, const int64_t* position,
+                                           const int64_t* index, const uint8_t* bases, const uint8_t* phred);
+/* One integer dataset at `path` (intermediate groups are made as needed), as pa_h5_write; data of at most 64 bytes is kept
+ * in the object header (compact layout). */
+int pa_h5_builder_write(pa_h5_builder* b, const char* path, int32_t type_code, int32_t rank, const int64_t* dims, const void* data);
+int pa_h5_builder_close(pa_h5_builder* b);
+
 /* How the polish chunks of this handle were read so far: `direct_chunks` had their image / position / index bytes copied
  * straight out of the mapped file (classic-format files of h5py or pa_h5_open mode 1 opened read-only: the locator in
  * hdf5io.cpp walks object header -> symbol table -> B-tree -> symbol node -> layout itself), `library_chunks` went through

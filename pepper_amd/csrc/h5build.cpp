@@ -1,0 +1,426 @@
+// Append-only builder of classic-format HDF5 files for the polish prediction store (include/pepper_amd_io.h,
+// pa_h5_builder_*).  Host-only C++; no libhdf5 in here.
+//
+// Why: a polish prediction file is one group of four small datasets per 1000-row chunk (pepper DataStorePredict.py:49-76), and
+// libhdf5 spends 70-150 us of CPU on each such group (object headers, B-tree and heap updates through the metadata cache,
+// property lists, ids) -- with the reader side at ~10 us per chunk (hdf5io.cpp's direct locator) and the device at ~5 us per
+// chunk, the writer processes were what bounded call_consensus on the 16 CPUs a GPU box grants.  The file FORMAT, though, is
+// simple when nothing is ever modified: raw data can be appended as it arrives, and every piece of metadata (object headers,
+// local heaps, symbol nodes, group B-trees) written once, bottom-up, when the file is closed -- children before parents, so every
+// address is known when it is needed.  That is what this does: ~3 us per chunk plus the write() of its 18 KB.
+//
+// What is written (HDF5 File Format Specification 2.0): superblock version 0 (8-byte offsets and lengths, group leaf K 4,
+// internal K 16), version-1 object headers, "old style" groups (symbol table message -> version-1 B-tree of symbol nodes +
+// local heap), datasets with dataspace v1 / fixed-point datatype v1 / fill value v2 (no fill value) / layout v3 (contiguous,
+// or compact for scalars) -- the same structures h5py's default (libver earliest) writes, read back by libhdf5, h5py and this
+// repository's own readers (tests/test_hdf5_layout.py).  Until pa_h5_builder_close() has run the file is not an HDF5 file.
+#include "../../include/pepper_amd_io.h"
+
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+extern "C" const char* pa_h5_last_error(void);
+void pa_h5_set_error(const std::string& msg);      // hdf5io.cpp
+
+namespace {
+
+int fail(const std::string& msg) {
+    pa_h5_set_error(msg);
+    return -1;
+}
+
+constexpr uint64_t UNDEF = ~0ull;
+constexpr int LEAF_K = 4, INTERNAL_K = 16;                    // superblock defaults: 8 symbols per node, 32 children per B-tree node
+constexpr uint64_t SNOD_BYTES = 8 + 2 * LEAF_K * 40;
+constexpr uint64_t TREE_BYTES = 24 + (2 * INTERNAL_K + 1) * 8 + 2 * INTERNAL_K * 8;
+
+struct Obj {
+    std::string name;
+    bool group = false;
+    std::vector<uint32_t> kids;                               // group: indices into objs_
+    uint8_t elem = 0, rank = 0;                               // dataset: bytes per integer element, signedness, shape
+    bool is_signed = false;
+    uint64_t dims[4] = {0, 0, 0, 0};
+    uint64_t bytes = 0, addr = 0;                             // raw data: size; file address (contiguous layout)
+    std::string small;                                        // the data itself when it is at most 64 bytes (compact layout)
+};
+
+void put16(std::vector<uint8_t>& b, uint64_t at, uint16_t v) { std::memcpy(&b[at], &v, 2); }
+void put32(std::vector<uint8_t>& b, uint64_t at, uint32_t v) { std::memcpy(&b[at], &v, 4); }
+void put64(std::vector<uint8_t>& b, uint64_t at, uint64_t v) { std::memcpy(&b[at], &v, 8); }
+
+}  // namespace
+
+struct pa_h5_builder {
+    int fd = -1;
+    std::string path;
+    std::vector<uint8_t> out;                                 // bytes not yet handed to write()
+    uint64_t pos = 0;                                         // file offset of the end of `out`
+    std::vector<Obj> objs;                                    // objs[0] = root group
+    std::unordered_map<std::string, uint32_t> by_path;        // groups below the root, "predictions/<contig>[/<region>]"
+    bool failed = false;
+
+    int flush() {
+        size_t done = 0;
+        while (done < out.size()) {
+            const ssize_t w = ::write(fd, out.data() + done, out.size() - done);
+            if (w < 0) {
+                if (errno == EINTR) continue;
+                failed = true;
+                return fail("write to '" + path + "' failed: " + std::strerror(errno));
+            }
+            done += (size_t)w;
+        }
+        out.clear();
+        return 0;
+    }
+
+    // raw data goes out in 8-byte aligned runs; -> its file address
+    uint64_t append(const void* data, uint64_t bytes) {
+        const uint64_t pad = (8 - pos % 8) % 8;
+        out.insert(out.end(), (size_t)pad, 0);
+        pos += pad;
+        const uint64_t at = pos;
+        const auto* p = static_cast<const uint8_t*>(data);
+        out.insert(out.end(), p, p + bytes);
+        pos += bytes;
+        return at;
+    }
+
+    uint32_t add(uint32_t parent, Obj&& o) {
+        objs.push_back(std::move(o));
+        const uint32_t id = (uint32_t)objs.size() - 1;
+        objs[parent].kids.push_back(id);
+        return id;
+    }
+
+    // the group at `path` below the root, made (with its parents) when absent
+    uint32_t group(const std::string& full) {
+        auto it = by_path.find(full);
+        if (it != by_path.end()) return it->second;
+        const size_t cut = full.rfind('/');
+        const uint32_t parent = cut == std::string::npos ? 0 : group(full.substr(0, cut));
+        Obj g;
+        g.name = cut == std::string::npos ? full : full.substr(cut + 1);
+        g.group = true;
+        const uint32_t id = add(parent, std::move(g));
+        by_path.emplace(full, id);
+        return id;
+    }
+
+    bool has_kid(uint32_t g, const std::string& name) const {
+        for (uint32_t k : objs[g].kids)
+            if (objs[k].name == name) return true;
+        return false;
+    }
+
+    void dataset(uint32_t g, const std::string& name, uint8_t elem, bool is_signed, int rank, const uint64_t* dims, const void* data) {
+        Obj d;
+        d.name = name;
+        d.elem = elem;
+        d.is_signed = is_signed;
+        d.rank = (uint8_t)rank;
+        d.bytes = elem;
+        for (int k = 0; k < rank; ++k) {
+            d.dims[k] = dims[k];
+            d.bytes *= dims[k];
+        }
+        if (d.bytes <= 64) d.small.assign(static_cast<const char*>(data), (size_t)d.bytes);
+        else d.addr = append(data, d.bytes);
+        add(g, std::move(d));
+    }
+
+    void row(uint32_t g, const char* name, uint8_t elem, bool is_signed, const void* data, uint64_t count) {
+        dataset(g, name, elem, is_signed, 1, &count, data);
+    }
+
+    void scalar(uint32_t g, const char* name, int64_t value) { dataset(g, name, 8, true, 0, nullptr, &value); }
+
+    // ---- close: the metadata, children before parents, into `meta` (file address = base + offset) ----------------------
+    std::vector<uint8_t> meta;
+    uint64_t base = 0;
+
+    uint64_t reserve(uint64_t bytes) {                        // 8-byte aligned, zero-filled; -> offset into meta
+        const uint64_t at = (meta.size() + 7) / 8 * 8;
+        meta.resize(at + bytes, 0);
+        return at;
+    }
+
+    void message(uint64_t& at, uint16_t type, uint16_t size) {      // message header; the data follows at `at`
+        put16(meta, at, type);
+        put16(meta, at + 2, size);
+        at += 8;
+    }
+
+    uint64_t dataset_header(const Obj& d) {
+        const bool compact = d.addr == 0;
+        const uint16_t space = (uint16_t)(8 + 8 * d.rank), dtype = 16, fill = 8;
+        const uint16_t layout = compact ? (uint16_t)((4 + d.bytes + 7) / 8 * 8) : 24;
+        const uint32_t body = 4 * 8 + space + dtype + fill + layout;
+        const uint64_t h = reserve(16 + body);
+        meta[h] = 1;
+        put16(meta, h + 2, 4);
+        put32(meta, h + 4, 1);
+        put32(meta, h + 8, body);
+        uint64_t at = h + 16;
+        message(at, 0x0001, space);                           // dataspace v1: version, rank, flags, 5 reserved, dimensions
+        meta[at] = 1;
+        meta[at + 1] = d.rank;
+        for (int k = 0; k < d.rank; ++k) put64(meta, at + 8 + 8 * k, d.dims[k]);
+        at += space;
+        message(at, 0x0003, dtype);                           // datatype v1, class 0 (fixed point), little-endian
+        meta[at] = 0x10;
+        meta[at + 1] = d.is_signed ? 0x08 : 0x00;
+        put32(meta, at + 4, d.elem);
+        put16(meta, at + 8, 0);                               // bit offset
+        put16(meta, at + 10, (uint16_t)(8 * d.elem));         // precision
+        at += dtype;
+        message(at, 0x0005, fill);                            // fill value v2: allocation early (compact) / late, written if set,
+        meta[at] = 2;                                         //   defined with size 0 = the library default
+        meta[at + 1] = compact ? 1 : 2;
+        meta[at + 2] = 2;
+        meta[at + 3] = 1;
+        at += fill;
+        message(at, 0x0008, layout);                          // layout v3
+        meta[at] = 3;
+        if (compact) {
+            meta[at + 1] = 0;                                 // compact: size, data
+            put16(meta, at + 2, (uint16_t)d.bytes);
+            if (d.bytes) std::memcpy(&meta[at + 4], d.small.data(), (size_t)d.bytes);
+        } else {
+            meta[at + 1] = 1;                                 // contiguous: address, size
+            put64(meta, at + 2, d.addr);
+            put64(meta, at + 10, d.bytes);
+        }
+        return base + h;
+    }
+
+    // -> address of the group's object header; *tree / *heap receive what the superblock's root entry caches
+    uint64_t group_header(uint32_t id, uint64_t* tree_out = nullptr, uint64_t* heap_out = nullptr) {
+        std::vector<uint32_t> kids = objs[id].kids;
+        std::sort(kids.begin(), kids.end(), [&](uint32_t a, uint32_t b) { return objs[a].name < objs[b].name; });
+        std::vector<uint64_t> header(kids.size());
+        for (size_t k = 0; k < kids.size(); ++k)
+            header[k] = objs[kids[k]].group ? group_header(kids[k]) : dataset_header(objs[kids[k]]);
+        // local heap: "" at offset 0, then the names, each NUL-terminated and padded to 8 bytes; no free block
+        std::vector<uint64_t> name_at(kids.size());
+        uint64_t heap_bytes = 8;
+        for (size_t k = 0; k < kids.size(); ++k) {
+            name_at[k] = heap_bytes;
+            heap_bytes += (objs[kids[k]].name.size() + 1 + 7) / 8 * 8;
+        }
+        const uint64_t heap = reserve(32 + heap_bytes);
+        std::memcpy(&meta[heap], "HEAP", 4);
+        put64(meta, heap + 8, heap_bytes);
+        put64(meta, heap + 16, 1);                            // H5HL_FREE_NULL: the free list is empty
+        put64(meta, heap + 24, base + heap + 32);
+        for (size_t k = 0; k < kids.size(); ++k)
+            std::memcpy(&meta[heap + 32 + name_at[k]], objs[kids[k]].name.data(), objs[kids[k]].name.size());
+        // symbol nodes of up to 2 * LEAF_K entries
+        const size_t per = 2 * LEAF_K;
+        const size_t n_snod = (kids.size() + per - 1) / per;
+        std::vector<uint64_t> child(n_snod), last_name(n_snod);   // one B-tree level at a time: child addresses, their greatest names
+        for (size_t s = 0; s < n_snod; ++s) {
+            const uint64_t at = reserve(SNOD_BYTES);
+            const size_t lo = s * per, hi = std::min(kids.size(), lo + per);
+            std::memcpy(&meta[at], "SNOD", 4);
+            meta[at + 4] = 1;
+            put16(meta, at + 6, (uint16_t)(hi - lo));
+            for (size_t k = lo; k < hi; ++k) {
+                const uint64_t e = at + 8 + 40 * (k - lo);
+                put64(meta, e, name_at[k]);
+                put64(meta, e + 8, header[k]);                // cache type 0: nothing cached in the scratch pad
+            }
+            child[s] = base + at;
+            last_name[s] = name_at[hi - 1];
+        }
+        // B-tree levels until one node is left (an empty group: one node without entries)
+        uint64_t root = 0;
+        for (uint8_t level = 0;; ++level) {
+            const size_t fan = 2 * INTERNAL_K;
+            const size_t n_node = std::max<size_t>(1, (child.size() + fan - 1) / fan);
+            const uint64_t first = reserve(TREE_BYTES * n_node);
+            std::vector<uint64_t> up_child(n_node), up_last(n_node);
+            for (size_t t = 0; t < n_node; ++t) {
+                const uint64_t at = first + TREE_BYTES * t;
+                const size_t lo = t * fan, hi = std::min(child.size(), lo + fan);
+                std::memcpy(&meta[at], "TREE", 4);
+                meta[at + 4] = 0;                             // node type 0: group nodes
+                meta[at + 5] = level;
+                put16(meta, at + 6, (uint16_t)(hi - lo));
+                put64(meta, at + 8, t == 0 ? UNDEF : base + at - TREE_BYTES);
+                put64(meta, at + 16, t + 1 == n_node ? UNDEF : base + at + TREE_BYTES);
+                // key[0] = the greatest name left of this node ("" for the leftmost), key[j + 1] = the greatest name in child j
+                put64(meta, at + 24, lo == 0 ? 0 : last_name[lo - 1]);
+                for (size_t c = lo; c < hi; ++c) {
+                    put64(meta, at + 24 + 16 * (c - lo) + 8, child[c]);
+                    put64(meta, at + 24 + 16 * (c - lo) + 16, last_name[c]);
+                }
+                up_child[t] = base + at;
+                up_last[t] = hi > lo ? last_name[hi - 1] : 0;
+            }
+            if (n_node == 1) {
+                root = base + first;
+                break;
+            }
+            child.swap(up_child);
+            last_name.swap(up_last);
+        }
+        const uint64_t h = reserve(16 + 24);                  // object header: one symbol table message
+        meta[h] = 1;
+        put16(meta, h + 2, 1);
+        put32(meta, h + 4, 1);
+        put32(meta, h + 8, 24);
+        uint64_t at = h + 16;
+        message(at, 0x0011, 16);
+        put64(meta, at, root);
+        put64(meta, at + 8, base + heap);
+        if (tree_out) *tree_out = root;
+        if (heap_out) *heap_out = base + heap;
+        return base + h;
+    }
+
+    int finish() {
+        if (failed) return -1;
+        const uint64_t pad = (8 - pos % 8) % 8;
+        out.insert(out.end(), (size_t)pad, 0);
+        pos += pad;
+        if (int rc = flush()) return rc;
+        base = pos;
+        uint64_t tree = 0, heap = 0;
+        const uint64_t root = group_header(0, &tree, &heap);
+        out.swap(meta);
+        pos += out.size();
+        if (int rc = flush()) return rc;
+        uint8_t sb[96] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
+        sb[13] = 8;                                           // size of offsets, size of lengths
+        sb[14] = 8;
+        const uint16_t lk = LEAF_K, ik = INTERNAL_K;
+        std::memcpy(sb + 16, &lk, 2);
+        std::memcpy(sb + 18, &ik, 2);
+        const uint64_t zero = 0, undef = UNDEF;
+        std::memcpy(sb + 24, &zero, 8);                       // base address
+        std::memcpy(sb + 32, &undef, 8);                      // free-space info
+        std::memcpy(sb + 40, &pos, 8);                        // end of file
+        std::memcpy(sb + 48, &undef, 8);                      // driver info
+        std::memcpy(sb + 56, &zero, 8);                       // root entry: name offset, header, cache type 1, B-tree and heap
+        std::memcpy(sb + 64, &root, 8);
+        const uint32_t one = 1;
+        std::memcpy(sb + 72, &one, 4);
+        std::memcpy(sb + 80, &tree, 8);
+        std::memcpy(sb + 88, &heap, 8);
+        if (pwrite(fd, sb, sizeof sb, 0) != (ssize_t)sizeof sb) return fail("cannot write the superblock of '" + path + "'");
+        return 0;
+    }
+};
+
+extern "C" {
+
+int pa_h5_builder_open(const char* path, pa_h5_builder** out) {
+    if (!path || !out) return fail("null argument");
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    if (fd < 0) return fail(std::string("cannot create '") + path + "': " + std::strerror(errno));
+    auto* b = new pa_h5_builder();
+    b->fd = fd;
+    b->path = path;
+    b->out.reserve(8 << 20);
+    b->out.assign(96, 0);                                     // the superblock's place; written by close
+    b->pos = 96;
+    Obj root;
+    root.group = true;
+    b->objs.push_back(std::move(root));
+    *out = b;
+    return 0;
+}
+
+int pa_h5_builder_write_polish_predictions(pa_h5_builder* b, int32_t n, int32_t seq_len, const char* contigs, int32_t contig_stride,
+                                           const int64_t* contig_start, const int64_t* contig_end, const int64_t* chunk_id,
+                                           const uint8_t* new_region, const uint8_t* skip, const int64_t* position,
+                                           const int64_t* index, const uint8_t* bases, const uint8_t* phred) {
+    if (!b || n < 0 || seq_len <= 0 || contig_stride <= 0 ||
+        (n > 0 && (!contigs || !contig_start || !contig_end || !chunk_id || !new_region || !skip || !position || !index ||
+                   !bases || !phred)))
+        return fail("bad argument");
+    if (b->failed) return fail("the file has a failed write behind it");
+    for (int32_t i = 0; i < n; ++i) {
+        const char* c = contigs + (size_t)i * contig_stride;
+        const std::string contig(c, strnlen(c, (size_t)contig_stride));
+        if (contig.empty() || contig.find('/') != std::string::npos) return fail("bad contig name '" + contig + "'");
+        const std::string region = "predictions/" + contig + "/" + contig + "-" + std::to_string((long long)contig_start[i]) + "-" +
+                                   std::to_string((long long)contig_end[i]);
+        if (new_region[i]) {
+            if (b->by_path.count(region)) return fail("cannot create group '" + region + "' (already exists)");
+            const uint32_t g = b->group(region);
+            b->scalar(g, "contig_start", contig_start[i]);
+            b->scalar(g, "contig_end", contig_end[i]);
+        }
+        if (skip[i]) continue;
+        auto it = b->by_path.find(region);
+        if (it == b->by_path.end()) return fail("no group '" + region + "' (a chunk before its region)");
+        const std::string chunk = std::to_string((long long)chunk_id[i]);
+        if (b->has_kid(it->second, chunk)) return fail("cannot create group '" + region + "/" + chunk + "' (already exists)");
+        Obj g;
+        g.name = chunk;
+        g.group = true;
+        const uint32_t id = b->add(it->second, std::move(g));
+        b->row(id, "position", 8, true, position + (size_t)i * seq_len, (uint64_t)seq_len);
+        b->row(id, "index", 8, true, index + (size_t)i * seq_len, (uint64_t)seq_len);
+        b->row(id, "bases", 1, false, bases + (size_t)i * seq_len, (uint64_t)seq_len);
+        b->row(id, "phred_score", 1, false, phred + (size_t)i * seq_len, (uint64_t)seq_len);
+        if (b->out.size() >= (4u << 20))
+            if (int rc = b->flush()) return rc;
+    }
+    return 0;
+}
+
+int pa_h5_builder_write(pa_h5_builder* b, const char* path, int32_t type_code, int32_t rank, const int64_t* dims, const void* data) {
+    if (!b || !path || rank < 0 || rank > 4 || (rank > 0 && !dims)) return fail("bad argument");
+    if (b->failed) return fail("the file has a failed write behind it");
+    uint8_t elem;
+    bool is_signed;
+    switch (type_code) {
+        case PA_H5_I8: elem = 1; is_signed = true; break;
+        case PA_H5_U8: elem = 1; is_signed = false; break;
+        case PA_H5_I16: elem = 2; is_signed = true; break;
+        case PA_H5_U16: elem = 2; is_signed = false; break;
+        case PA_H5_I32: elem = 4; is_signed = true; break;
+        case PA_H5_U32: elem = 4; is_signed = false; break;
+        case PA_H5_I64: elem = 8; is_signed = true; break;
+        case PA_H5_U64: elem = 8; is_signed = false; break;
+        default: return fail("the builder writes integer datasets only");
+    }
+    std::string full(path);
+    while (!full.empty() && full[0] == '/') full.erase(0, 1);
+    const size_t cut = full.rfind('/');
+    const std::string name = cut == std::string::npos ? full : full.substr(cut + 1);
+    if (name.empty()) return fail(std::string("bad dataset path '") + path + "'");
+    const uint32_t g = cut == std::string::npos ? 0 : b->group(full.substr(0, cut));
+    if (b->has_kid(g, name)) return fail(std::string("cannot create dataset '") + path + "' (already exists)");
+    uint64_t d[4] = {0, 0, 0, 0}, count = 1;
+    for (int k = 0; k < rank; ++k) {
+        if (dims[k] < 0) return fail("negative dimension");
+        d[k] = (uint64_t)dims[k];
+        count *= d[k];
+    }
+    if (count > 0 && !data) return fail("null data");
+    b->dataset(g, name, elem, is_signed, rank, d, data);
+    if (b->out.size() >= (4u << 20)) return b->flush();
+    return 0;
+}
+
+int pa_h5_builder_close(pa_h5_builder* b) {
+    if (!b) return 0;
+    int rc = b->finish();
+    if (b->fd >= 0 && ::close(b->fd) != 0 && !rc) rc = fail("close of '" + b->path + "' failed");
+    delete b;
+    return rc;
+}
+
+}  // extern "C"

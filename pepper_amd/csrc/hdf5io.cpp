@@ -302,6 +302,8 @@ struct pa_h5 {
     ~pa_h5() { delete direct; }
 };
 
+void pa_h5_set_error(const std::string& msg) { g_err = msg; }     // h5build.cpp reports through the same thread-local text
+
 extern "C" {
 
 const char* pa_h5_last_error(void) { return g_err.c_str(); }

@@ -43,6 +43,10 @@ SYMBOLS = [
     ("pa_h5_write_polish_image_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32, c_char_p, c_int64, c_int64] +
                                                        [c_void_p] * 5),
     ("pa_h5_write_polish_predictions", ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 9),
+    ("pa_h5_builder_open", ctypes.c_int, [c_char_p, ctypes.POINTER(c_void_p)]),
+    ("pa_h5_builder_write_polish_predictions", ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 9),
+    ("pa_h5_builder_write", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, P64, c_void_p]),
+    ("pa_h5_builder_close", ctypes.c_int, [c_void_p]),
     ("pa_h5_write_prediction_batch", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
 ]
@@ -84,6 +88,53 @@ def _check(rc):
     if rc < 0:
         raise H5Error(load().pa_h5_last_error().decode())
     return rc
+
+
+class PredictionBuilder(object):
+    """Append-only writer of a polish prediction file (pa_h5_builder_*, pepper_amd/csrc/h5build.cpp): raw rows go to the file as
+    they come, the HDF5 metadata is written by close().  No libhdf5 involved, so no lock either."""
+
+    def __init__(self, path):
+        self._lib = load()
+        self._h = c_void_p()
+        _check(self._lib.pa_h5_builder_open(os.fsencode(path), ctypes.byref(self._h)))
+        self.filename, self.mode = path, "w"
+
+    def write_polish_predictions(self, contigs, start, end, chunk, new_region, skip, position, index, bases, phred):
+        n, seq_len = bases.shape
+        _check(self._lib.pa_h5_builder_write_polish_predictions(
+            self._h, n, seq_len, contigs.ctypes.data, contigs.dtype.itemsize, start.ctypes.data, end.ctypes.data,
+            chunk.ctypes.data, new_region.ctypes.data, skip.ctypes.data, position.ctypes.data, index.ctypes.data,
+            bases.ctypes.data, phred.ctypes.data))
+
+    def __setitem__(self, path, value):
+        """An integer dataset like h5py's file[path] = value (intermediate groups are made as needed)."""
+        arr = np.asarray(value)
+        shape = arr.shape                     # np.ascontiguousarray would promote 0-d to 1-d
+        arr = np.ascontiguousarray(arr).reshape(shape)
+        if arr.dtype == np.bool_:
+            arr = arr.astype(np.uint8).reshape(shape)
+        if arr.dtype not in _CODES or arr.dtype.kind not in "iu":
+            raise H5Error(f"the prediction builder writes integer datasets only, not {arr.dtype} for '{path}'")
+        dims = (c_int64 * max(1, arr.ndim))(*arr.shape)
+        _check(self._lib.pa_h5_builder_write(self._h, path.encode(), _CODES[arr.dtype], arr.ndim, dims, arr.ctypes.data))
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, None
+            _check(self._lib.pa_h5_builder_close(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class File(object):

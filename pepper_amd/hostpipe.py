@@ -284,43 +284,78 @@ class PolishLayout(object):
                 mk(self.o_labels, (n, s), np.uint8), mk(self.o_phred, (n, s), np.uint8))
 
 
+def _worker_trace(what, lane, chunks, busy, waiting, t_start):
+    """PEPPER_AMD_LANE_TRACE=1: what a worker process spent (CPU seconds of the process, seconds inside the HDF5 calls, seconds
+    waiting for a slot / a block)."""
+    if os.environ.get("PEPPER_AMD_LANE_TRACE"):
+        sys.stderr.write("[lanes] %s %2d: %6d chunks, %.2f s in HDF5 calls (%.1f us per chunk), %.2f s waiting, %.2f s of CPU, "
+                         "%.2f s after start\n" % (what, lane, chunks, busy, 1e6 * busy / max(1, chunks), waiting,
+                                                   time.process_time(), time.perf_counter() - t_start))
+
+
 def _polish_reader(lane, result_q, files, slot_names, layout_args, free_q):
+    t_start = time.perf_counter()
     from pepper_amd import h5
     layout = PolishLayout(*layout_args)
     segs = [_attach(n) for n in slot_names]
+    busy = waiting = 0.0
+    chunks = 0
     try:
+        first = True
         for path in files:
             with h5.File(path, 'r') as f:
                 if 'summaries' not in f:
                     continue
                 names = f.keys('summaries')
-                for a in range(0, len(names), layout.block):
-                    part = names[a:a + layout.block]
+                a = 0
+                while a < len(names):
+                    # a lane's first block is a quarter block: the device starts on it while the readers fill whole ones
+                    part = names[a:a + (max(1, layout.block // 4) if first else layout.block)]
+                    a += len(part)
+                    first = False
+                    t0 = time.perf_counter()
                     slot = free_q.get()
+                    t1 = time.perf_counter()
                     image, position, index, _, _ = layout.views(segs[slot].buf, len(part))
                     contigs, start, end, chunk = f.read_polish_chunks(part, layout.seq_len, layout.features,
                                                                       out=(image, position, index))[:4]
                     result_q.put(("block", lane, slot, len(part), (contigs, start, end, chunk)))
+                    waiting += t1 - t0
+                    busy += time.perf_counter() - t1
+                    chunks += len(part)
         result_q.put(("read_done", lane))
+        _worker_trace("reader", lane, chunks, busy, waiting, t_start)
     finally:
         _close_all(segs)
 
 
 def _polish_writer(lane, result_q, output_filename, slot_names, layout_args, write_q, free_q):
+    t_start = time.perf_counter()
     from pepper_amd.polish.DataStorePredict import DataStore
     layout = PolishLayout(*layout_args)
     segs = [_attach(n) for n in slot_names]
     store = DataStore(output_filename, mode='w')
+    busy = waiting = 0.0
+    chunks = 0
     try:
         while True:
+            t0 = time.perf_counter()
             item = write_q.get()
+            t1 = time.perf_counter()
             if item is None:
                 break
             slot, n, (contigs, start, end, chunk) = item
             _, position, index, labels, phred = layout.views(segs[slot].buf, n)
             store.write_predictions_block(contigs, start, end, chunk, position, index, labels, phred)
             free_q.put(slot)
+            waiting += t1 - t0
+            busy += time.perf_counter() - t1
+            chunks += n
+        t0 = time.perf_counter()
+        store.close()
+        busy += time.perf_counter() - t0
         result_q.put(("write_done", lane))
+        _worker_trace("writer", lane, chunks, busy, waiting, t_start)
     finally:
         store.close()
         _close_all(segs)
@@ -376,7 +411,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
                                      daemon=True))
             procs.append(ctx.Process(target=polish_writer, args=(k, result_q, out, slots[k].names, largs, write_qs[k], free_qs[k]),
                                      daemon=True))
-        _start_all(procs)
+        _start_all(procs[0::2] + procs[1::2])    # the readers first: a process takes ~25 ms to start, the writers have time
         _trace(t_begin, "workers started")
         if prepare is not None:
             prepare()              # e.g. load the checkpoint and build the model while the readers start and read

@@ -351,3 +351,99 @@ def test_direct_chunk_reads_leave_unknown_layouts_to_the_library(tmp_path):
             assert f.read_stats() == stats, (kind, f.read_stats())
         assert np.array_equal(got[4], want["im"]) and np.array_equal(got[5], want["pos"]) and np.array_equal(got[6], want["idx"]), kind
         assert got[3].tolist() == [0, 1, 2, 3]
+
+
+def _prediction_file(path, n, rng, builder):
+    """n chunks over three contigs (one with many regions: several B-tree levels), written a block at a time."""
+    from pepper_amd.polish.DataStorePredict import DataStore as PredStore
+    os.environ["PEPPER_AMD_H5_BUILDER"] = "1" if builder else "0"
+    try:
+        store = PredStore(path, "w")
+    finally:
+        del os.environ["PEPPER_AMD_H5_BUILDER"]
+    assert isinstance(store.file_handler, h5.PredictionBuilder) == builder
+    seq = 1000
+    contigs = np.array([b"chr1" if i % 5 else (b"contig_two" if i % 10 else b"z") for i in range(n)], dtype="S256")
+    start = (np.arange(n) // 3) * 1000
+    end = start + 1200
+    chunk = np.arange(n) % 3
+    position = rng.integers(0, 1 << 40, (n, seq)).astype(np.int64)
+    index = rng.integers(0, 4, (n, seq)).astype(np.int64)
+    bases = rng.integers(0, 5, (n, seq)).astype(np.uint8)
+    phred = rng.integers(0, 60, (n, seq)).astype(np.uint8)
+    for a in range(0, n, 700):
+        b = min(n, a + 700)
+        store.write_predictions_block(contigs[a:b], start[a:b], end[a:b], chunk[a:b], position[a:b], index[a:b], bases[a:b], phred[a:b])
+    store.write_predictions_block(contigs[:3], start[:3], end[:3], chunk[:3], position[:3], index[:3], bases[:3], phred[:3])   # duplicates
+    store.close()
+    return contigs, start, end, chunk, position, index, bases, phred
+
+
+def test_prediction_builder_writes_the_file_libhdf5_writes(tmp_path):
+    """pepper_amd/csrc/h5build.cpp lays a prediction file out itself (rows appended, metadata at close).  libhdf5 must find
+    in it exactly what it finds in the file it wrote itself from the same calls: every group, dataset, shape, type and value
+    -- here with 1 100 regions under one contig (three B-tree levels), names that sort differently as text and as numbers,
+    duplicates skipped; h5diff (the HDF5 tools' own comparison) agrees where the tools are installed."""
+    n = 4000
+    new, old = str(tmp_path / "builder.hdf"), str(tmp_path / "library.hdf")
+    want = _prediction_file(new, n, np.random.default_rng(11), True)
+    _prediction_file(old, n, np.random.default_rng(11), False)
+
+    def walk(f, g):
+        out = {}
+        for name in f.keys(g):
+            p = g + "/" + name
+            try:
+                kids = f.keys(p)
+            except h5.H5Error:
+                kids = None
+            if kids:
+                out.update(walk(f, p))
+            else:
+                out[p] = (f.info(p), f[p])
+        return out
+    with h5.File(new) as a, h5.File(old) as b:
+        assert a.keys("/") == ["predictions"] and sorted(a.keys("predictions")) == ["chr1", "contig_two", "z"]
+        wa, wb = walk(a, "predictions"), walk(b, "predictions")
+        assert wa.keys() == wb.keys() and len(wa) == 4 * n + 2 * len(set(zip(want[0].tolist(), want[1].tolist())))
+        for key in wa:
+            assert wa[key][0] == wb[key][0], (key, wa[key][0], wb[key][0])
+            assert np.array_equal(wa[key][1], wb[key][1]), key
+        contigs, start, end, chunk, position, index, bases, phred = want
+        for i in (0, 1, 2, 1234, n - 1):
+            base = "predictions/%s/%s-%d-%d/%d/" % (contigs[i].decode(), contigs[i].decode(), start[i], end[i], chunk[i])
+            assert np.array_equal(a[base + "position"], position[i]) and np.array_equal(a[base + "phred_score"], phred[i])
+        got = a.read_polish_prediction_region("predictions/chr1/chr1-1000-2200", 1000)
+        assert len(got[0]) == 2                                  # chunks 1 and 2 of that region are chr1's (3 is 'contig_two')
+    if os.path.exists("/opt/conda/bin/h5diff"):
+        r = subprocess.run(["/opt/conda/bin/h5diff", old, new], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    with pytest.raises(h5.H5Error):
+        with h5.PredictionBuilder(str(tmp_path / "dup.hdf")) as f:
+            f["a/b"] = np.arange(3)
+            f["a/b"] = np.arange(3)
+    with h5.PredictionBuilder(str(tmp_path / "empty.hdf")):
+        pass
+    with h5.File(str(tmp_path / "empty.hdf")) as f:
+        assert f.keys("/") == []
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/conda/bin/python3.9"), reason="needs the image's h5py interpreter")
+def test_h5py_reads_the_builder_file(tmp_path):
+    path = str(tmp_path / "builder.hdf")
+    want = _prediction_file(path, 300, np.random.default_rng(12), True)
+    np.savez(str(tmp_path / "want.npz"), position=want[4], bases=want[6])
+    script = ("import h5py, numpy as np, sys\n"
+              "w = np.load(sys.argv[2])\n"
+              "f = h5py.File(sys.argv[1], 'r')\n"
+              "seen = []\n"
+              "f.visititems(lambda n, x: seen.append(n) if isinstance(x, h5py.Dataset) else None)\n"
+              "assert len(seen) == 4 * 300 + 2 * 160, len(seen)\n"
+              "g = f['predictions/z/z-0-1200']\n"
+              "assert g['contig_start'][()] == 0 and g['contig_end'][()] == 1200 and g['contig_end'].dtype == np.int64\n"
+              "assert g['contig_end'].shape == () and sorted(g.keys()) == ['0', 'contig_end', 'contig_start']\n"
+              "assert np.array_equal(g['0/position'][()], w['position'][0]) and g['0/bases'].dtype == np.uint8\n"
+              "assert np.array_equal(f['predictions/chr1/chr1-99000-100200/2/bases'][()], w['bases'][299])\n"
+              "print('fine')\n")
+    r = subprocess.run(["/opt/conda/bin/python3.9", "-c", script, path, str(tmp_path / "want.npz")], capture_output=True, text=True)
+    assert r.returncode == 0 and "fine" in r.stdout, r.stderr[-3000:]
