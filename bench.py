@@ -624,12 +624,13 @@ def secondary_block(args):
         "mode": d["mode"], "scratch": scratch or "system temporary directory",
         "note": "pepper_amd.variant.RunInference.run_inference: image HDF5 files -> predictions HDF5 (libhdf5 reads, H2D, forward, D2H, "
                 "per-batch prediction groups), SURVEY.md 8(d) 'a second number including I/O'"}
-    d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_polish_pipeline.py"), "--chunks", "131072", "--files", "32",
-                   "--workers", "8"] + extra, 400)
+    d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_polish_pipeline.py"), "--chunks", "262144", "--files", "32",
+                   "--workers", "0"] + extra, 400)
     out["call_consensus_hdf5"] = d if "error" in d else {
         "value": d["chunks_per_s"], "unit": "chunks/s", "windows_per_s": d["windows_per_s"], "chunks": d["chunks"], "seconds": d["seconds"],
         "mode": d["mode"], "scratch": scratch or "system temporary directory",
-        "note": "pepper_amd.polish.call_consensus.call_consensus: image HDF5 files -> predictions HDF5"}
+        "note": "pepper_amd.polish.call_consensus.call_consensus: image HDF5 files -> predictions HDF5, start-up included (chunk reads "
+                "bypass libhdf5, prediction files laid out by h5build.cpp, blocks of several reader lanes per device pass)"}
     return out
 
 

@@ -211,8 +211,10 @@ def _start_all(procs):
             main.__spec__ = None
             if had_file:
                 del main.__file__
-        for p in procs:
-            p.start()
+        # a spawned interpreter takes ~20 ms of this process's time to start; four threads start them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=4) as starters:
+            list(starters.map(lambda p: p.start(), procs))
     finally:
         if main is not None:
             main.__spec__ = saved_spec
@@ -481,8 +483,11 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
                     read_done.discard(lane)
                     write_qs[lane].put(None)             # the end marker follows the lane's last block
 
+        reading = lanes
         while writing:
-            while pending and len(inflight) < depth:
+            # a pass costs about the same whatever it holds: the first of the passes under way takes what there is (an idle
+            # device is worse than a small pass), a further one starts only full -- or when nothing more is coming
+            while pending and len(inflight) < depth and (not inflight or len(pending) >= per_pass or reading == 0):
                 launch()
                 if pool is None:
                     retire()
@@ -500,6 +505,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
                 _, _, slot, n, meta = msg
                 pending.append((lane, slot, n, meta))
             elif kind == "read_done":
+                reading -= 1
                 if any(item[0] == lane for item in pending) or any(item[0] == lane for _, blocks in inflight for item in blocks):
                     read_done.add(lane)
                 else:
@@ -798,10 +804,11 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
 def default_lanes(files, requested, small=64 << 20, most=8):
     """options.num_workers > 0: that many lanes (at most one per file).  0: process lanes only when the job is big
     enough to pay for them (start-up of the workers + page-locking of the slots is ~0.3 s), and then `most` of them
-    (measured on the MI355X host: 4 readers keep the variant loop at the device rate; the polish loop, whose files are one
-    HDF5 group per chunk -- ~150 us of libhdf5 per chunk on either side --, scales with the CPUs it may use: most=None ->
-    half of hostinfo.usable_cpus() (a lane is two processes), between 4 and 16.  The project's GPU boxes grant 16 CPUs of
-    their 256: 8 lanes = 51 k chunks/s, 16 lanes 42 k, 32 lanes 30 k -- the lanes then only take time from each other)."""
+    (measured on the MI355X host: 4 readers keep the variant loop at the device rate).  most=None, the polish loop: 3/8 of
+    hostinfo.usable_cpus(), between 3 and 12 -- a lane is two processes that are mostly idle since the chunk reads bypass
+    libhdf5 (~15-30 us per chunk) and the prediction files are laid out by h5build.cpp (~3 us per chunk); the device pass
+    (~200 k chunks/s) is what the lanes have to feed.  On the 16 CPUs the project's GPU boxes grant: 4 lanes 116 k chunks/s,
+    6 lanes 120 k, 8 lanes 102 k (262 144 chunks, start-up included)."""
     if not files or os.environ.get("PEPPER_AMD_NO_LANES") == "1":
         return 0
     if requested and requested > 0:
@@ -811,7 +818,7 @@ def default_lanes(files, requested, small=64 << 20, most=8):
         return 0
     if most is None:
         from pepper_amd.hostinfo import usable_cpus
-        most = max(4, min(16, usable_cpus() // 2))
+        most = max(3, min(12, usable_cpus() * 3 // 8))
     return min(len(files), most)
 
 

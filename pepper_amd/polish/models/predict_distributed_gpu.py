@@ -26,7 +26,8 @@ def _log(msg):
 
 
 DEVICE_CHUNKS = 16384    # chunks per device pass (19 windows of 100 rows each; 128 chunks per workgroup and direction: 256 workgroups)
-LANE_CHUNKS = int(os.environ.get("PEPPER_AMD_POLISH_BLOCK", 4096))   # chunks a reader lane hands over at a time (a slot: 115 MB, 49 MB of it page-locked)
+LANE_CHUNKS = int(os.environ.get("PEPPER_AMD_POLISH_BLOCK", 2048))   # chunks a reader lane hands over at a time (a slot: 57 MB, 25 MB of it page-locked)
+LANE_SLOTS = int(os.environ.get("PEPPER_AMD_POLISH_SLOTS", 4))       # slots per lane: being read, waiting / on the device, being written
 # The device loop of the lanes: a pass walks 1 900 time steps in sequence and takes 60-75 ms whether it holds 512 chunks or
 # 16 384 (one workgroup per 128 chunks and direction), so the blocks that arrive while the device is busy go to it together --
 # up to LANE_PASS_BLOCKS of them as one pass -- and LANE_PASSES_IN_FLIGHT passes are under way at once, each through its own
@@ -52,7 +53,7 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
     from pepper_amd import hostpipe
     lanes = hostpipe.default_lanes(file_chunks, num_workers, most=None)
     layout = hostpipe.PolishLayout(LANE_CHUNKS, ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT)
-    if lanes > 0 and hostpipe.shm_room(2 * lanes * layout.nbytes):
+    if lanes > 0 and hostpipe.shm_room(LANE_SLOTS * lanes * layout.nbytes):
         def log(done):
             if rank == 0:
                 _log("INFO: CHUNKS PROCESSED " + str(done) + ".")
@@ -69,7 +70,7 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
         try:
             hostpipe.polish_lanes(file_chunks, output_filepath + "pepper_prediction_" + str(rank), None, lanes,
                                   block=LANE_CHUNKS, seq_len=ImageSizeOptions.SEQ_LENGTH, features=ImageSizeOptions.IMAGE_HEIGHT,
-                                  slots_per_lane=2, log=log, prepare=get_model, predict_parts=predict_with(get_model),
+                                  slots_per_lane=LANE_SLOTS, log=log, prepare=get_model, predict_parts=predict_with(get_model),
                                   more_predict=more_predict, in_flight=LANE_PASSES_IN_FLIGHT, pass_blocks=LANE_PASS_BLOCKS)
             return rank
         except hostpipe.NoSharedMemory as e:
