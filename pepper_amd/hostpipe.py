@@ -222,6 +222,37 @@ def _start_all(procs):
                 main.__file__ = saved_file
 
 
+class _Preparing(object):
+    """The caller's prepare() (checkpoint load, model creation: ~0.2 s for the variant model) on a thread from the first moment
+    of a lanes call, beside the creation of the slots (tmpfs pages are reserved up front: ~0.15 s per GB) and the start of the
+    worker processes; join() before the first device pass re-raises what it raised."""
+
+    def __init__(self, prepare):
+        self.error = None
+        self.thread = None
+        if prepare is not None:
+            import threading
+            self.thread = threading.Thread(target=self._run, args=(prepare,), daemon=True)
+            self.thread.start()
+
+    def _run(self, prepare):
+        try:
+            prepare()
+        except BaseException as e:       # noqa: B036 -- handed to the joining thread
+            self.error = e
+
+    def wait(self):
+        if self.thread is not None:
+            self.thread.join()
+            self.thread = None
+
+    def join(self):
+        self.wait()
+        if self.error is not None:
+            error, self.error = self.error, None
+            raise error
+
+
 def _next_message(result_q, procs, poll=None):
     """result_q.get() that notices dead workers: a child that dies before it can report (a crash in native code, or a
     caller's script without the `if __name__ == "__main__":` guard that spawned children need) must not leave the GPU
@@ -376,8 +407,8 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
     """Run the polish predict loop over `files` with `lanes` reader/writer process pairs.
 
     predict_block(image u8 [n, seq, features], labels u8 [n, seq], phred u8 [n, seq]) runs the device pass on host
-    arrays that live in page-locked shared memory and fills labels / phred; prepare() (optional) runs in this process
-    right after the workers have been started.  Output files: `<output_stem>.hdf` for one
+    arrays that live in page-locked shared memory and fills labels / phred; prepare() (optional) runs in this process, on a
+    thread, while the slots are made and the workers start.  Output files: `<output_stem>.hdf` for one
     lane, `<output_stem>_<lane>.hdf` otherwise.  Returns the number of chunks processed.
 
     The polish kernel gives a workgroup 128 chunks of one direction and walks their 1 900 time steps in sequence, so a
@@ -397,7 +428,12 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
     layout = PolishLayout(block, seq_len, features)
     largs = (block, seq_len, features)
     ctx = get_context("spawn")
-    slots = make_slots(lanes, slots_per_lane, layout.nbytes, layout.pin_bytes)
+    preparing = _Preparing(prepare)
+    try:
+        slots = make_slots(lanes, slots_per_lane, layout.nbytes, layout.pin_bytes)
+    except BaseException:
+        preparing.wait()
+        raise
     result_q = ctx.Queue()
     free_qs = [ctx.Queue() for _ in range(lanes)]
     write_qs = [ctx.Queue() for _ in range(lanes)]
@@ -415,9 +451,8 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
                                      daemon=True))
         _start_all(procs[0::2] + procs[1::2])    # the readers first: a process takes ~25 ms to start, the writers have time
         _trace(t_begin, "workers started")
-        if prepare is not None:
-            prepare()              # e.g. load the checkpoint and build the model while the readers start and read
-            _trace(t_begin, "caller prepared")
+        preparing.join()           # e.g. the checkpoint loaded and the model built while the slots were made and the readers started
+        _trace(t_begin, "caller prepared")
         # page-locking after prepare(): hipHostRegister holds the process's mm lock, and a model creation (hipMalloc,
         # uploads) running beside it took 0.4 s instead of 0.07 s
         # PEPPER_AMD_POLISH_PIN=0: leave the slots pageable (the copies are then staged by the runtime; the path needs ~1 GB/s)
@@ -524,6 +559,7 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
             p.join(timeout=60)
         _trace(t_begin, "workers joined")
     finally:
+        preparing.wait()
         if pool is not None:
             pool.shutdown(wait=True)
         for p in procs:
@@ -688,7 +724,12 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
     if slots_per_lane <= 0:
         slots_per_lane = 2
     ctx = get_context("spawn")
-    slots = make_slots(lanes, slots_per_lane, slot_bytes)
+    preparing = _Preparing(prepare)
+    try:
+        slots = make_slots(lanes, slots_per_lane, slot_bytes)
+    except BaseException:
+        preparing.wait()
+        raise
     result_q = ctx.Queue()
     free_qs = [ctx.Queue() for _ in range(lanes)]
     write_qs = [ctx.Queue() for _ in range(lanes)]
@@ -706,9 +747,8 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
             procs.append(ctx.Process(target=variant_writer, args=(k, result_q, out, batch_size, write_qs[k]), daemon=True))
         _start_all(procs)
         _trace(t_begin, "workers started")
-        if prepare is not None:
-            prepare()              # e.g. load the checkpoint and build the model while the readers start and read
-            _trace(t_begin, "caller prepared")
+        preparing.join()           # e.g. the checkpoint loaded and the model built while the slots were made and the readers started
+        _trace(t_begin, "caller prepared")
         # page-locking after prepare(): hipHostRegister holds the process's mm lock, and a model creation (hipMalloc,
         # uploads) running beside it took 0.4 s instead of 0.07 s
         locker = register_async(slots, _have_gpu())
@@ -789,6 +829,7 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
             p.join(timeout=60)
         _trace(t_begin, "workers joined")
     finally:
+        preparing.wait()
         if pool is not None:
             pool.shutdown(wait=True)
         for p in procs:

@@ -42,6 +42,7 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
 
     def get_model():
         if holder["model"] is None:
+            torch.cuda.set_device(device_id)                # also reached from a lanes call's preparing thread
             holder["model"] = ModelHandler.load_simple_model_for_training(
                 model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS, image_features=ImageSizeOptions.IMAGE_HEIGHT,
                 seq_len=ImageSizeOptions.SEQ_LENGTH, num_classes=ImageSizeOptions.TOTAL_LABELS)[0]

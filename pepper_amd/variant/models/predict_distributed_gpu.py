@@ -71,6 +71,7 @@ def predict(options, input_filepath, input_files, output_filepath, threads, rank
 
     def get_model():
         if holder["model"] is None:
+            torch.cuda.set_device(device)                   # also reached from a lanes call's preparing thread
             holder["model"] = ModelHandler.load_simple_model_for_training(
                 options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT,
                 num_classes=ImageSizeOptions.TOTAL_LABELS, num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)[0]
