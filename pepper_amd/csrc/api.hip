@@ -477,6 +477,7 @@ struct pa_variant_model : ModelBase {
     bool split_gemm = true;      // PA_SPLIT_GEMM=0 keeps the big GEMMs on the f32 matrix instructions
     bool split_rec = true;       // PA_SPLIT_REC=0 keeps the recurrences on the f32 matrix instructions
     bool fuse_dec = true;        // PA_FUSE_DEC=0: decoder projection as a GEMM + Xp instead of inside the step loop
+    int64_t small_batch = 3072;  // calls of at most this many windows take the GEMM + Xp decoder (PA_SMALL_BATCH)
     std::vector<RecLayer> rec;   // encoder layers then decoder layers
     Linear lin[5], out;
     DevBuf *mlp_w = nullptr, *mlp_b = nullptr;   // linear_2..5 as h2 fragments + their biases (mlp_h2.hip)
@@ -512,6 +513,7 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     if (!(state_dict_max_abs_weight(sd) < kSplitMaxWeight)) m->split_gemm = false;   // see kSplitMaxWeight
     m->split_rec = m->split_rec && m->split_gemm;   // the h2 layer output needs the h2 consumers
     if (const char* e = getenv("PA_FUSE_DEC")) m->fuse_dec = e[0] != '0';
+    if (const char* e = getenv("PA_SMALL_BATCH")) m->small_batch = atoll(e);
     int rc = init_base(m, cfg->device, hip_stream);
     const int H = m->H;
     for (int mod = 0; mod < 2 && rc == PA_OK; ++mod)
@@ -592,9 +594,16 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     const int NX = 2 * 4 * H;  // both directions' gate pre-activations
     // Xp (gate pre-activations, 4.4 GB at 16384 windows) is only materialised when some layer's projection is
     // NOT contracted inside its step loop; otherwise the workspace just holds linear_1's split-K partials
+    // Small calls (the reference's DataLoader batch is 512 windows, predict_distributed_gpu.py:58-67): a step of the fused
+    // decoder loop costs 41 us whatever the number of 64-row tiles -- 8 waves on one CU issue the K = 768 contraction of their
+    // tile, 3 MB of weight fragments per step -- so a call of 128 ... 2048 windows took 2.15 ms.  Below `small_batch` windows the
+    // decoder's input projection runs as one GEMM over all T steps on the whole chip instead (0.13 ms at 512 windows) and the
+    // step loop contracts K = 256 only (14.7 us per step): 512 windows 2.16 -> 1.42 ms, 1024: 2.17 -> 1.59, 2048: 2.18 -> 1.83;
+    // at 4096 the fused loop wins again (profiles/r03_small_batch_kernels.json).  PA_SMALL_BATCH=0: always fused.
+    const bool fuse_dec = m->fuse_dec && n > m->small_batch;
     bool need_xp = !(a_kind == pa::A_I8 && m->fuse_input && !m->rec.empty() && m->rec[0].w_cat != nullptr);
     for (size_t li = 1; li < m->rec.size(); ++li)
-        need_xp = need_xp || !(m->split_rec && m->fuse_dec && m->rec[li].w_cat_dec_h2 != nullptr);
+        need_xp = need_xp || !(m->split_rec && fuse_dec && m->rec[li].w_cat_dec_h2 != nullptr);
     const size_t xp_bytes = std::max(need_xp ? (size_t)np * T * NX * sizeof(float) : (size_t)0,
                                      (size_t)8 * n * m->L1 * sizeof(float));
     if (int rc = m->xp->ensure(xp_bytes)) return rc;
@@ -627,7 +636,7 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
                 LAUNCH_TRY(m, "lstm_rec_fused_in", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
                            pa::launch_lstm_rec_fused(H, static_cast<const int8_t*>(cur), r.K, r.b_in->f(),
                                                      r.w_cat->f(), y, 2 * H, (int)n, T, m->stream));
-        } else if (li > 0 && rec_h2 && cur_h2 && r.w_cat_dec_h2 != nullptr && m->fuse_dec) {
+        } else if (li > 0 && rec_h2 && cur_h2 && r.w_cat_dec_h2 != nullptr && fuse_dec) {
             // h2 layer output -> this layer: projection contracted inside the step loop (no GEMM, no Xp)
             LAUNCH_TRY(m, "lstm_dec_h2_fused", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
                        pa::launch_lstm_dec_h2(H, cur, cur_ld, bias_l, r.w_cat_dec_h2->p, y, 2 * H, (int)n, T, m->stream,

@@ -15,6 +15,23 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["fused", "small-batch"])
+def schedule(request):
+    """Every test of this file under both decoder schedules: calls of at most 3072 windows take the GEMM + Xp decoder
+    (api.hip `small_batch`), larger ones the decoder with the projection inside its step loop; PA_SMALL_BATCH=0 (read at
+    model creation) gives the latter to the small calls the parity tests make."""
+    saved = os.environ.get("PA_SMALL_BATCH")
+    if request.param == "fused":
+        os.environ["PA_SMALL_BATCH"] = "0"
+    else:
+        os.environ.pop("PA_SMALL_BATCH", None)
+    yield request.param
+    if saved is None:
+        os.environ.pop("PA_SMALL_BATCH", None)
+    else:
+        os.environ["PA_SMALL_BATCH"] = saved
+
+
 class NativeVariant:
     """Thin test harness over the raw C ABI (host-pointer entry points)."""
 
