@@ -91,6 +91,24 @@ int pa_h5_write_prediction_batch(pa_h5* f, const char* group, int32_t n, const c
 int pa_h5_read_polish_chunks(pa_h5* f, const char* names, int32_t n, int32_t seq_len, int32_t features, uint8_t* images,
                              int64_t* position, int64_t* index, int64_t* region_start, int64_t* region_end,
                              int64_t* chunk_id, char* contigs, int32_t contig_stride);
+/* One piece of a contig's consensus, as pepper Stitch.py:36-94 (small_chunk_stitch) builds it: the chunks of the given region
+ * groups ("predictions/<contig>/<contig>-<start>-<end>", NUL-separated, each in files[file_of_region[r]]; chunk ids in string
+ * order) are merged by (position, insert index) -- rows with a negative position or index are padding; in a region that does
+ * not start at 0 the rows at positions <= region_start + buffer_positions are the overlap with the region before and are
+ * dropped; the last write of a key wins -- and the labels of the keys in order are decoded (0 -> nothing, 1-4 -> ACGT).
+ * -> first / last position of the piece (-1, -1 and length 0 when nothing is left), the length of its sequence, which
+ * pa_h5_stitch_take then copies out (thread-local between the two calls).  A label above 4 is an error (*bad_label holds it:
+ * the reference raises KeyError).  Chunks are read straight from the mapped file where the direct locator knows the format. */
+int pa_h5_stitch_polish_regions(pa_h5* const* files, const int32_t* file_of_region, const char* region_paths,
+                                const int64_t* region_start, int32_t n_regions, int64_t buffer_positions, int64_t* first_pos,
+                                int64_t* last_pos, int64_t* sequence_len, int64_t* bad_label);
+int pa_h5_stitch_take(char* out, int64_t cap);
+/* The region groups of predictions/<contig>, in name order, with their contig_start / contig_end scalars (what
+ * pepper perform_stitch.py:63-74 collects one h5py call at a time).  Call with buf == NULL for *needed (bytes of the
+ * NUL-separated names) and *count, then with buffers of those sizes. */
+int pa_h5_list_polish_regions(pa_h5* f, const char* contig, char* buf, int64_t cap, int64_t* needed, int64_t* count,
+                              int64_t* starts, int64_t* ends, int64_t cap_regions);
+
 /* Append-only builder of a polish prediction file (pepper_amd/csrc/h5build.cpp; no libhdf5 involved): the same groups and
  * datasets as pa_h5_write_polish_predictions -- predictions/<contig>/<contig>-<start>-<end>/{contig_start, contig_end int64
  * scalars} and .../<chunk_id>/{position, index int64 [seq], bases, phred_score uint8 [seq]} (pepper DataStorePredict.py:49-76)

@@ -120,8 +120,36 @@ public:
     }
     uint64_t root() const { return root_header_; }
 
+    // <group>/a/b/c from `group_header`; 0 when absent or not understood
+    uint64_t resolve(uint64_t group_header, const char* path) const {
+        uint64_t at = group_header;
+        std::string part;
+        for (const char* c = path;; ++c) {
+            if (*c == '/' || *c == 0) {
+                if (!part.empty()) {
+                    at = child(at, part.c_str());
+                    if (!at) return 0;
+                    part.clear();
+                }
+                if (*c == 0) return at;
+            } else part.push_back(*c);
+        }
+    }
+
+    // the links of a group in name order (the order of its B-tree); false = don't know
+    bool children(uint64_t group_header, std::vector<std::pair<std::string, uint64_t>>& out) const {
+        uint64_t bt = 0, heap = 0;
+        if (!symbol_table(group_header, bt, heap)) return false;
+        if (!in(heap, 32) || std::memcmp(p_ + heap, "HEAP", 4) != 0 || p_[heap + 4] != 0) return false;
+        const uint64_t hsize = rd64(p_ + heap + 8), hdata = rd64(p_ + heap + 24);
+        if (!in(hdata, hsize)) return false;
+        return walk(bt, hdata, hsize, 0, out);
+    }
+
     // raw bytes of a contiguous (or compact) dataset of `count` little-endian integers of `elem` bytes; false = don't know
-    bool dataset(uint64_t header, uint32_t elem, uint64_t count, Span& out) const {
+    // count == ANY: whatever the dataspace says, reported in *count_out
+    static constexpr uint64_t ANY = ~0ull;
+    bool dataset(uint64_t header, uint32_t elem, uint64_t count, Span& out, uint64_t* count_out = nullptr) const {
         Msgs m;
         if (!messages(header, m) || !m.layout || !m.dtype || !m.dspace) return false;
         // datatype: class 0 (fixed point) version 1-3, little-endian, no padding games we care about; size == elem
@@ -144,7 +172,9 @@ public:
             if (dim != 0 && npoints > (1ull << 40) / dim) return false;
             npoints *= dim;
         }
+        if (count == ANY) count = npoints;
         if (npoints != count) return false;
+        if (count_out) *count_out = npoints;
         if (m.filters) return false;
         // layout v3: class 1 contiguous {address, size}; class 0 compact {size(2), bytes}
         if (m.layout_len < 2 || m.layout[0] != 3) return false;
@@ -246,6 +276,31 @@ private:
         if (off >= size) return nullptr;
         const void* z = std::memchr(p_ + data + off, 0, (size_t)(size - off));
         return z ? (const char*)(p_ + data + off) : nullptr;
+    }
+
+    bool walk(uint64_t node, uint64_t hdata, uint64_t hsize, int depth, std::vector<std::pair<std::string, uint64_t>>& out) const {
+        if (depth > 16 || !in(node, 24) || std::memcmp(p_ + node, "TREE", 4) != 0 || p_[node + 4] != 0) return false;
+        const uint8_t level = p_[node + 5];
+        const uint32_t used = rd16(p_ + node + 6);
+        if (!in(node + 24, 16ull * used + 8)) return false;
+        for (uint32_t c = 0; c < used; ++c) {
+            const uint64_t kid = rd64(p_ + node + 24 + 16ull * c + 8);
+            if (level > 0) {
+                if (!walk(kid, hdata, hsize, depth + 1, out)) return false;
+                continue;
+            }
+            if (!in(kid, 8) || std::memcmp(p_ + kid, "SNOD", 4) != 0 || p_[kid + 4] != 1) return false;
+            const uint32_t count = rd16(p_ + kid + 6);
+            if (!in(kid + 8, 40ull * count)) return false;
+            for (uint32_t e = 0; e < count; ++e) {
+                const uint8_t* entry = p_ + kid + 8 + 40ull * e;
+                const char* name = heap_name(hdata, hsize, rd64(entry));
+                const uint64_t header = rd64(entry + 8);
+                if (!name || !in(header, 16)) return false;
+                out.emplace_back(name, header);
+            }
+        }
+        return true;
     }
 
     uint64_t lookup(uint64_t btree, uint64_t heap, const char* name) const {
@@ -615,6 +670,18 @@ int pa_h5_write_prediction_batch(pa_h5* f, const char* group, int32_t n, const c
     return rc;
 }
 
+// the direct locator of a file opened read-only (made on first use); nullptr = through the library (PEPPER_AMD_H5_DIRECT=0, a
+// file open for writing, or a file the locator could not map)
+static const Direct* direct_of(pa_h5* f) {
+    static const bool no_direct = getenv("PEPPER_AMD_H5_DIRECT") && getenv("PEPPER_AMD_H5_DIRECT")[0] == '0';
+    if (no_direct) return nullptr;
+    if (!f->direct_tried) {
+        f->direct_tried = true;
+        if (f->mode == 0) f->direct = Direct::open(f->path.c_str());
+    }
+    return f->direct;
+}
+
 // ---- polish stores in bulk: the format keeps one group per 1000-row chunk (8 small datasets in the image file, 4 in the
 // prediction file), so a region-sized device pass touches thousands of datasets; these entry points do the whole block
 // inside the library instead of one Python-level call per dataset.
@@ -700,12 +767,7 @@ static int read_polish_chunks_impl(pa_h5* f, const char* names, int32_t n, int32
     if (root < 0) return fail("no group 'summaries'");
     // the three large datasets of a chunk straight from the mapped file where the direct locator understands it (a file opened
     // read-only; PEPPER_AMD_H5_DIRECT=0: always through the library); per chunk, so one odd group costs one library read
-    static const bool no_direct = getenv("PEPPER_AMD_H5_DIRECT") && getenv("PEPPER_AMD_H5_DIRECT")[0] == '0';
-    if (!f->direct_tried) {
-        f->direct_tried = true;
-        if (f->mode == 0 && !no_direct) f->direct = Direct::open(f->path.c_str());
-    }
-    const Direct* dd = no_direct ? nullptr : f->direct;
+    const Direct* dd = direct_of(f);
     const uint64_t dsum = dd ? dd->child(dd->root(), "summaries") : 0;
     const char* name = names;
     int rc = 0;
@@ -912,6 +974,228 @@ int pa_h5_write_polish_image_chunks(pa_h5* f, const char* names, int32_t n, int3
     H5Sclose(sp_row);
     H5Sclose(sp_one);
     return rc;
+}
+
+}  // extern "C"
+
+// ---- stitch (pepper Stitch.py:36-94): the chunks of prediction regions merged by (position, insert index) ----------------
+namespace {
+
+struct StitchRow { int64_t pos; int64_t idx; uint8_t label; };
+
+thread_local std::string g_stitch;       // the last piece's sequence, until pa_h5_stitch_take copies it out
+
+// rows of every chunk of one region group, chunk ids in string order, contig_start / contig_end skipped; chunks may have any
+// length.  Straight from the mapped file where the locator knows the format, through the library otherwise.
+// -> 0, or -1 (error text set)
+int region_rows(pa_h5* f, const char* region_path, std::vector<int64_t>& pos, std::vector<int64_t>& idx, std::vector<uint8_t>& lab) {
+    pos.clear();
+    idx.clear();
+    lab.clear();
+    if (const Direct* dd = direct_of(f)) {
+        const uint64_t g = dd->resolve(dd->root(), region_path);
+        std::vector<std::pair<std::string, uint64_t>> kids;
+        bool ok = g != 0 && dd->children(g, kids);
+        for (size_t k = 0; ok && k < kids.size(); ++k) {
+            if (kids[k].first == "contig_start" || kids[k].first == "contig_end") continue;
+            Direct::Span a, b, c;
+            uint64_t na = 0, nb = 0, nc = 0;
+            ok = dd->dataset(dd->child(kids[k].second, "position"), 8, Direct::ANY, a, &na) &&
+                 dd->dataset(dd->child(kids[k].second, "index"), 8, Direct::ANY, b, &nb) &&
+                 dd->dataset(dd->child(kids[k].second, "bases"), 1, Direct::ANY, c, &nc) && na == nb && na == nc;
+            if (!ok) break;
+            const size_t at = pos.size();
+            pos.resize(at + na);
+            idx.resize(at + na);
+            lab.resize(at + na);
+            ok = dd->copy(a, pos.data() + at) && dd->copy(b, idx.data() + at) && dd->copy(c, lab.data() + at);
+        }
+        if (ok) return 0;
+        pos.clear();
+        idx.clear();
+        lab.clear();
+    }
+    Quiet q;
+    hid_t g = H5Gopen2(f->file, region_path, H5P_DEFAULT);
+    if (g < 0) return fail(std::string("no group '") + region_path + "'");
+    std::vector<std::string> names;
+    H5Literate(g, H5_INDEX_NAME, H5_ITER_NATIVE, nullptr, collect_names, &names);
+    names.erase(std::remove_if(names.begin(), names.end(),
+                               [](const std::string& s) { return s == "contig_start" || s == "contig_end"; }), names.end());
+    std::sort(names.begin(), names.end());            // the order of Python's sorted() on the chunk ids as strings
+    int rc = 0;
+    for (size_t i = 0; i < names.size() && !rc; ++i) {
+        const std::string where = std::string(region_path) + "/" + names[i] + "/";
+        hid_t c = H5Gopen2(g, names[i].c_str(), H5P_DEFAULT);
+        if (c < 0) { rc = fail("no group '" + where + "'"); break; }
+        hid_t d = H5Dopen2(c, "position", H5P_DEFAULT);
+        hssize_t n = -1;
+        if (d >= 0) {
+            hid_t sp = H5Dget_space(d);
+            n = H5Sget_simple_extent_npoints(sp);
+            H5Sclose(sp);
+            H5Dclose(d);
+        }
+        if (n < 0) rc = fail("no dataset '" + where + "position'");
+        else {
+            const size_t at = pos.size();
+            pos.resize(at + (size_t)n);
+            idx.resize(at + (size_t)n);
+            lab.resize(at + (size_t)n);
+            rc = read_numeric(c, "position", H5T_NATIVE_INT64, n, pos.data() + at, where);
+            if (!rc) rc = read_numeric(c, "index", H5T_NATIVE_INT64, n, idx.data() + at, where);
+            if (!rc) rc = read_numeric(c, "bases", H5T_NATIVE_UINT8, n, lab.data() + at, where);
+        }
+        H5Gclose(c);
+    }
+    H5Gclose(g);
+    return rc;
+}
+
+inline bool key_less(const StitchRow& a, const StitchRow& b) { return a.pos < b.pos || (a.pos == b.pos && a.idx < b.idx); }
+
+}  // namespace
+
+extern "C" {
+
+int pa_h5_stitch_polish_regions(pa_h5* const* files, const int32_t* file_of_region, const char* region_paths,
+                                const int64_t* region_start, int32_t n_regions, int64_t buffer_positions, int64_t* first_pos,
+                                int64_t* last_pos, int64_t* sequence_len, int64_t* bad_label) {
+    if (n_regions < 0 || !first_pos || !last_pos || !sequence_len || !bad_label ||
+        (n_regions > 0 && (!files || !file_of_region || !region_paths || !region_start)))
+        return fail("bad argument");
+    *first_pos = *last_pos = -1;
+    *sequence_len = 0;
+    *bad_label = -1;
+    g_stitch.clear();
+    // `merged` holds one row per (position, index) key, in key order, with the label of the LAST write of that key in the
+    // order of the reference's loops (regions as given, chunk ids as strings, rows as stored): Stitch.py:60-80 fills a dict
+    // that way and sorts its keys.  The rows of a chunk come sorted and a chunk mostly continues where the one before ended,
+    // so each chunk is merged into the tail of `merged` (rows of a chunk that are out of order are sorted first, stably).
+    std::vector<StitchRow> merged, rows, tail;
+    std::vector<int64_t> pos, idx;
+    std::vector<uint8_t> lab;
+    const char* path = region_paths;
+    for (int32_t r = 0; r < n_regions; ++r, path += strlen(path) + 1) {
+        if (int rc = region_rows(files[file_of_region[r]], path, pos, idx, lab)) return rc;
+        const int64_t st = region_start[r];
+        rows.clear();
+        bool sorted = true;
+        for (size_t k = 0; k < pos.size(); ++k) {
+            if (idx[k] < 0 || pos[k] < 0) continue;
+            if (st > 0 && !(pos[k] > st + buffer_positions)) continue;      // the overlap with the region before (:62-66)
+            const StitchRow row{pos[k], idx[k], lab[k]};
+            if (!rows.empty() && key_less(row, rows.back())) sorted = false;
+            rows.push_back(row);
+        }
+        if (rows.empty()) continue;
+        if (!sorted) std::stable_sort(rows.begin(), rows.end(), key_less);
+        // equal keys within the rows: the last one stays
+        size_t w = 0;
+        for (size_t k = 0; k < rows.size(); ++k) {
+            if (w > 0 && !key_less(rows[w - 1], rows[k])) rows[w - 1] = rows[k];
+            else rows[w++] = rows[k];
+        }
+        rows.resize(w);
+        // the part of `merged` at or after the first new key
+        const size_t from = std::lower_bound(merged.begin(), merged.end(), rows.front(), key_less) - merged.begin();
+        if (from == merged.size()) {
+            merged.insert(merged.end(), rows.begin(), rows.end());
+            continue;
+        }
+        tail.assign(merged.begin() + from, merged.end());
+        merged.resize(from);
+        size_t a = 0, b = 0;
+        while (a < tail.size() || b < rows.size()) {
+            if (b == rows.size() || (a < tail.size() && key_less(tail[a], rows[b]))) merged.push_back(tail[a++]);
+            else {
+                if (a < tail.size() && !key_less(rows[b], tail[a])) ++a;   // same key: the later write wins
+                merged.push_back(rows[b++]);
+            }
+        }
+    }
+    if (merged.empty()) return 0;
+    static const char letters[5] = {0, 'A', 'C', 'G', 'T'};
+    g_stitch.reserve(merged.size());
+    for (const StitchRow& row : merged) {
+        if (row.label > 4) {
+            *bad_label = row.label;          // label_decoder[...] raises KeyError in the reference
+            g_stitch.clear();
+            return fail("label " + std::to_string((int)row.label) + " is not a base");
+        }
+        if (row.label) g_stitch.push_back(letters[row.label]);
+    }
+    *first_pos = merged.front().pos;
+    *last_pos = merged.back().pos;
+    *sequence_len = (int64_t)g_stitch.size();
+    return 0;
+}
+
+int pa_h5_stitch_take(char* out, int64_t cap) {
+    if ((int64_t)g_stitch.size() > cap || (!out && !g_stitch.empty())) return fail("buffer too small for the stitched sequence");
+    if (!g_stitch.empty()) std::memcpy(out, g_stitch.data(), g_stitch.size());
+    std::string().swap(g_stitch);
+    return 0;
+}
+
+// the region groups of predictions/<contig> in name order with their contig_start / contig_end (perform_stitch.py:63-74 reads
+// them one h5py call at a time).  names: NUL-separated into buf (needed bytes reported); -> 0, -1 error
+int pa_h5_list_polish_regions(pa_h5* f, const char* contig, char* buf, int64_t cap, int64_t* needed, int64_t* count,
+                              int64_t* starts, int64_t* ends, int64_t cap_regions) {
+    if (!f || !contig || !needed || !count) return fail("null argument");
+    std::vector<std::string> names;
+    std::vector<int64_t> st, en;
+    const std::string base = std::string("predictions/") + contig;
+    bool have = false;
+    if (const Direct* dd = direct_of(f)) {
+        const uint64_t g = dd->resolve(dd->root(), base.c_str());
+        std::vector<std::pair<std::string, uint64_t>> kids;
+        have = g != 0 && dd->children(g, kids);
+        for (size_t k = 0; have && k < kids.size(); ++k) {
+            Direct::Span a, b;
+            int64_t s = 0, e = 0;
+            have = dd->dataset(dd->child(kids[k].second, "contig_start"), 8, 1, a) && dd->dataset(dd->child(kids[k].second, "contig_end"), 8, 1, b) &&
+                   dd->copy(a, &s) && dd->copy(b, &e);
+            names.push_back(kids[k].first);
+            st.push_back(s);
+            en.push_back(e);
+        }
+        if (!have) { names.clear(); st.clear(); en.clear(); }
+    }
+    if (!have) {
+        Quiet q;
+        hid_t g = H5Gopen2(f->file, base.c_str(), H5P_DEFAULT);
+        if (g < 0) return fail("no group '" + base + "'");
+        H5Literate(g, H5_INDEX_NAME, H5_ITER_NATIVE, nullptr, collect_names, &names);
+        std::sort(names.begin(), names.end());
+        int rc = 0;
+        for (size_t k = 0; k < names.size() && !rc; ++k) {
+            hid_t c = H5Gopen2(g, names[k].c_str(), H5P_DEFAULT);
+            const std::string where = base + "/" + names[k] + "/";
+            if (c < 0) { rc = fail("no group '" + where + "'"); break; }
+            int64_t s = 0, e = 0;
+            rc = read_numeric(c, "contig_start", H5T_NATIVE_INT64, 1, &s, where);
+            if (!rc) rc = read_numeric(c, "contig_end", H5T_NATIVE_INT64, 1, &e, where);
+            st.push_back(s);
+            en.push_back(e);
+            H5Gclose(c);
+        }
+        H5Gclose(g);
+        if (rc) return rc;
+    }
+    int64_t bytes = 0;
+    for (const auto& n : names) bytes += (int64_t)n.size() + 1;
+    *needed = bytes;
+    *count = (int64_t)names.size();
+    if (!buf || cap < bytes || !starts || !ends || cap_regions < (int64_t)names.size()) return 0;   // sizes only
+    char* w = buf;
+    for (size_t k = 0; k < names.size(); ++k) {
+        std::memcpy(w, names[k].c_str(), names[k].size() + 1);
+        w += names[k].size() + 1;
+        starts[k] = st[k];
+        ends[k] = en[k];
+    }
+    return 0;
 }
 
 }  // extern "C"

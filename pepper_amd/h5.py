@@ -43,6 +43,9 @@ SYMBOLS = [
     ("pa_h5_write_polish_image_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32, c_char_p, c_int64, c_int64] +
                                                        [c_void_p] * 5),
     ("pa_h5_write_polish_predictions", ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 9),
+    ("pa_h5_stitch_polish_regions", ctypes.c_int, [c_void_p, c_void_p, c_char_p, c_void_p, c_int32, c_int64, P64, P64, P64, P64]),
+    ("pa_h5_stitch_take", ctypes.c_int, [c_void_p, c_int64]),
+    ("pa_h5_list_polish_regions", ctypes.c_int, [c_void_p, c_char_p, c_void_p, c_int64, P64, P64, c_void_p, c_void_p, c_int64]),
     ("pa_h5_builder_open", ctypes.c_int, [c_char_p, ctypes.POINTER(c_void_p)]),
     ("pa_h5_builder_write_polish_predictions", ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 9),
     ("pa_h5_builder_write", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, P64, c_void_p]),
@@ -88,6 +91,27 @@ def _check(rc):
     if rc < 0:
         raise H5Error(load().pa_h5_last_error().decode())
     return rc
+
+
+@_locked
+def stitch_polish_regions(files, file_of_region, region_paths, region_starts, buffer_positions):
+    """pa_h5_stitch_polish_regions over open File objects: -> (first position, last position, sequence str); (-1, -1, '')
+    when no row is left.  A label that is not a base raises KeyError(label), as the reference's label_decoder does."""
+    lib = load()
+    n = len(region_paths)
+    handles = (c_void_p * max(1, len(files)))(*[f._h for f in files])
+    which = np.ascontiguousarray(file_of_region, dtype=np.int32)
+    starts = np.ascontiguousarray(region_starts, dtype=np.int64)
+    blob = b"".join(p.encode() + b"\0" for p in region_paths)
+    first, last, length, bad = c_int64(), c_int64(), c_int64(), c_int64()
+    rc = lib.pa_h5_stitch_polish_regions(handles, which.ctypes.data, blob, starts.ctypes.data, n, int(buffer_positions),
+                                         ctypes.byref(first), ctypes.byref(last), ctypes.byref(length), ctypes.byref(bad))
+    if rc < 0 and bad.value >= 0:
+        raise KeyError(int(bad.value))
+    _check(rc)
+    buf = ctypes.create_string_buffer(max(1, length.value))
+    _check(lib.pa_h5_stitch_take(buf, length.value))
+    return first.value, last.value, buf.raw[:length.value].decode()
 
 
 class PredictionBuilder(object):
@@ -235,6 +259,21 @@ class File(object):
         a, b = c_int64(), c_int64()
         _check(self._lib.pa_h5_read_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    @_locked
+    def list_polish_regions(self, contig):
+        """[(region group name, contig_start, contig_end)] of predictions/<contig>, names in sorted order."""
+        needed, count = c_int64(), c_int64()
+        _check(self._lib.pa_h5_list_polish_regions(self._h, contig.encode(), None, 0, ctypes.byref(needed), ctypes.byref(count),
+                                                   None, None, 0))
+        if count.value == 0:
+            return []
+        buf = ctypes.create_string_buffer(max(1, needed.value))
+        starts, ends = np.empty(count.value, np.int64), np.empty(count.value, np.int64)
+        _check(self._lib.pa_h5_list_polish_regions(self._h, contig.encode(), buf, needed.value, ctypes.byref(needed),
+                                                   ctypes.byref(count), starts.ctypes.data, ends.ctypes.data, count.value))
+        names = buf.raw[:needed.value].split(b"\0")[:count.value]
+        return [(n.decode(), int(s), int(e)) for n, s, e in zip(names, starts.tolist(), ends.tolist())]
 
     @_locked
     def read_polish_prediction_region(self, region_path, seq_len, max_chunks=64):

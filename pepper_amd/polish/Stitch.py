@@ -10,6 +10,7 @@ overlap and dropped), then the last write of every key wins and keys come out so
 Pinned: tests/golden/polish_stitch_ref.fa is the reference's own output on the same prediction arrays.
 """
 import concurrent.futures
+import os
 
 import numpy as np
 
@@ -26,6 +27,29 @@ def chunks(file_names, threads):
 
 
 def small_chunk_stitch(contig, small_chunk_keys):
+    """One piece of the consensus.  The merge runs inside the I/O library (pa_h5_stitch_polish_regions: chunk rows straight
+    from the mapped prediction files, each chunk merged into the tail of the piece; 3 k -> see DESIGN.md chunks/s);
+    PEPPER_AMD_STITCH_NUMPY=1 keeps the numpy form below, which tests hold it to."""
+    if os.environ.get("PEPPER_AMD_STITCH_NUMPY") == "1":
+        return small_chunk_stitch_numpy(contig, small_chunk_keys)
+    buffer_positions = ImageSizeOptions.MIN_IMAGE_OVERLAP * 2
+    open_files, order = {}, []
+    try:
+        which, paths, starts = [], [], []
+        for file_name, contig_name, _st, _end in small_chunk_keys:
+            if file_name not in open_files:
+                open_files[file_name] = len(order)
+                order.append(h5.File(file_name, 'r'))
+            which.append(open_files[file_name])
+            paths.append('predictions/' + contig + '/' + contig_name + '-' + str(_st) + '-' + str(_end))
+            starts.append(_st)
+        return h5.stitch_polish_regions(order, which, paths, starts, buffer_positions)
+    finally:
+        for f in order:
+            f.close()
+
+
+def small_chunk_stitch_numpy(contig, small_chunk_keys):
     buffer_positions = ImageSizeOptions.MIN_IMAGE_OVERLAP * 2
     pos_parts, idx_parts, base_parts = [], [], []
     open_files = {}                       # each prediction file is opened once per call, not once per region

@@ -46,10 +46,8 @@ def perform_stitch(hdf_file_path, output_path, threads):
                 with h5.File(prediction_file, 'r') as hdf5_file:
                     if 'predictions' not in hdf5_file.keys() or contig not in hdf5_file.keys('predictions'):
                         continue
-                    for chunk_key in sorted(hdf5_file.keys('predictions/' + contig)):
-                        base = 'predictions/' + contig + '/' + chunk_key + '/'
-                        all_chunk_keys.append((prediction_file, chunk_key, hdf5_file[base + 'contig_start'],
-                                               hdf5_file[base + 'contig_end']))
+                    # every region group with its contig_start / contig_end in one library call (names in sorted order)
+                    all_chunk_keys.extend((prediction_file, name, start, end) for name, start, end in hdf5_file.list_polish_regions(contig))
             consensus_sequence = create_consensus_sequence(contig, all_chunk_keys, threads)
             _log("FINISHED PROCESSING " + contig + ", POLISHED SEQUENCE LENGTH: " + str(len(consensus_sequence)) + ".")
             if consensus_sequence is not None and len(consensus_sequence) > 0:

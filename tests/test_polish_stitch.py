@@ -122,3 +122,58 @@ def test_stitch_matches_reference_golden(golden_dir, tmp_path):
     for threads in (1, 2):
         out = perform_stitch(str(pred), str(tmp_path / ("o%d" % threads) / "asm"), threads)
         assert open(out).read() == want
+
+
+def test_native_merge_on_rows_no_pipeline_would_write(tmp_path, monkeypatch):
+    """pa_h5_stitch_polish_regions merges chunk by chunk into the tail of the piece and relies on nothing: rows out of order
+    inside a chunk, the same key twice in a chunk, in two chunks, in two regions and in two files (the last write in the
+    reference's loop order wins), chunks of other lengths, a region that lands before everything merged so far -- against
+    the dictionary restatement and the numpy form; files written through libhdf5 (1.10 object formats: the locator does not
+    know them) read the same; a label that is not a base raises KeyError as label_decoder does."""
+    import pytest
+    from pepper_amd.polish import Stitch
+    rng = np.random.default_rng(21)
+
+    def write(builder):
+        monkeypatch.setenv("PEPPER_AMD_H5_BUILDER", "1" if builder else "0")
+        tag = "b" if builder else "l"
+        pred = tmp_path / ("pred_" + tag)
+        pred.mkdir()
+        files = [str(pred / "p0.hdf"), str(pred / "p1.hdf")]
+        r = np.random.default_rng(22)
+        with DataStore(files[0], "w") as a, DataStore(files[1], "w") as b:
+            for store, start, end in ((a, 3000, 4000), (b, 0, 2500), (a, 2400, 3300), (b, 3000, 4000)):   # (3000, 4000) in both files
+                for cid in range(3):
+                    n = int(r.integers(5, 400)) if cid == 1 else 1000                                    # an odd-length chunk
+                    pos = r.integers(start, end + 300, n)
+                    pos[r.random(n) < 0.05] = -1
+                    idx = r.integers(-1, 3, n)
+                    if cid != 2:
+                        order = np.lexsort((idx, pos))
+                        pos, idx = pos[order], idx[order]                                               # chunk 2 stays unsorted
+                    store.write_prediction("ctg", start, end, cid, pos, idx, r.integers(0, 5, n), np.zeros(n))
+        return files
+    want = None
+    for builder in (True, False):
+        files = write(builder)
+        pred = os.path.dirname(files[0])
+        for threads in (1, 3):
+            expect = dict_stitch(files, "ctg", threads)
+            monkeypatch.delenv("PEPPER_AMD_STITCH_NUMPY", raising=False)
+            out = perform_stitch(pred, str(tmp_path / ("n%d%d" % (builder, threads))), threads)
+            got = open(out).read().splitlines()[1]
+            monkeypatch.setenv("PEPPER_AMD_STITCH_NUMPY", "1")
+            out = perform_stitch(pred, str(tmp_path / ("p%d%d" % (builder, threads))), threads)
+            assert got == expect and open(out).read().splitlines()[1] == expect and len(got) > 1000
+        with h5.File(files[0]) as f:
+            regions = f.list_polish_regions("ctg")
+            assert [r[0] for r in regions] == sorted(f.keys("predictions/ctg")) and (regions[0][1], regions[0][2]) == (2400, 3300)
+        want = want or expect
+        assert expect == want                              # the builder's file and libhdf5's hold the same predictions
+    monkeypatch.delenv("PEPPER_AMD_STITCH_NUMPY", raising=False)
+    bad = str(tmp_path / "bad.hdf")
+    with DataStore(bad, "w") as s:
+        s.write_prediction("c", 0, 10, 0, np.arange(10), np.zeros(10, np.int64), np.array([1, 2, 3, 4, 0, 7, 1, 1, 1, 1]), np.zeros(10))
+    with pytest.raises(KeyError):
+        Stitch.small_chunk_stitch("c", [(bad, "c", 0, 10)])
+    assert Stitch.small_chunk_stitch("c", []) == (-1, -1, "")
