@@ -91,6 +91,32 @@ int pa_h5_write_prediction_batch(pa_h5* f, const char* group, int32_t n, const c
 int pa_h5_read_polish_chunks(pa_h5* f, const char* names, int32_t n, int32_t seq_len, int32_t features, uint8_t* images,
                              int64_t* position, int64_t* index, int64_t* region_start, int64_t* region_end,
                              int64_t* chunk_id, char* contigs, int32_t contig_stride);
+/* Candidate selection + VCF record text for the rows of one prediction batch whose candidate lists hold ONE allele each
+ * (what pepper_amd's image generation writes): the rules of pepper_variant CandidateFinder.py:356-581 (small_chunk_stitch /
+ * find_candidates) and VcfWriter.py:48-218 for a site with one allele record.  rules: thresholds per allele kind
+ * (0 SNP "1...", 1 insert "2...", 2 delete "3...").  Per row: position, depth, support (candidate_frequency), prediction
+ * float32 [n,3], the upper-cased reference base (0 = outside the contig) and low-complexity flag of the position, the
+ * allele code ("1A", "2ACC", "3ACG") at alleles + allele_offsets[i] .. allele_offsets[i+1] - separator_bytes (1 for the
+ * NUL-separated text pa_h5_read_strings returns).
+ * -> the number m of rows kept, for each: its row (kept_row), len(REF) (ref_len), flags (bit 0 SNP, bit 1 selected for
+ * re-genotyping, bit 2 REF/ALT swapped (a deletion called by probability), bits 4-5 genotype) and its VCF line
+ * lines[line_offsets[k] .. line_offsets[k+1]) ('\n'-terminated).  -1: error; -2: a row only the reference-shaped Python path
+ * reproduces (NaN probabilities, the reference's division by a zero depth): the caller takes that path for the batch. */
+typedef struct {
+    double p_value[3], p_value_in_lc[3], report_above_freq[3];
+    double snp_q_cutoff, snp_q_cutoff_in_lc, indel_q_cutoff, indel_q_cutoff_in_lc;
+} pa_candidate_rules;
+/* The upper-cased reference base (0 outside the window) and the low-complexity flag of the reference's candidate finder
+ * (CandidateFinder.py:397-418: a homopolymer run >= 5 touching [p - 5, p + 4) inside the context ref[p - 10, p + 10)) for n
+ * positions, out of the text of ONE fetch ref[window_lo, window_lo + text_len) that covers them with 16 bases to spare. */
+int pa_candidates_reference_flags(const char* text, int64_t text_len, int64_t window_lo, int64_t n, const int64_t* position,
+                                  uint8_t* letters, uint8_t* in_repeat);
+int64_t pa_candidates_select_format(const pa_candidate_rules* rules, const char* contig, int64_t n, const int64_t* position,
+                                    const int64_t* depth, const int64_t* support, const float* prediction,
+                                    const uint8_t* reference_base, const uint8_t* in_repeat, const char* alleles,
+                                    const int64_t* allele_offsets, int32_t separator_bytes, int32_t* kept_row, int32_t* ref_len,
+                                    uint8_t* flags, char* lines, int64_t lines_cap, int64_t* line_offsets);
+
 /* One piece of a contig's consensus, as pepper Stitch.py:36-94 (small_chunk_stitch) builds it: the chunks of the given region
  * groups ("predictions/<contig>/<contig>-<start>-<end>", NUL-separated, each in files[file_of_region[r]]; chunk ids in string
  * order) are merged by (position, insert index) -- rows with a negative position or index are padding; in a region that does

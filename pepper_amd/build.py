@@ -35,10 +35,11 @@ def build_io(force=False, verbose=False):
     src = os.path.join(CSRC, "hdf5io.cpp")
     bam = os.path.join(CSRC, "bamio.cpp")      # BAM reader (zlib) lives in the same host-side library
     bld = os.path.join(CSRC, "h5build.cpp")    # append-only writer of polish prediction files (no libhdf5)
+    cnd = os.path.join(CSRC, "candidates.cpp") # candidate selection + VCF record text of a prediction batch
     hdr = os.path.join(CSRC, "..", "..", "include", "pepper_amd_io.h")
-    have_src = all(os.path.exists(f) for f in (src, bam, bld, hdr))
+    have_src = all(os.path.exists(f) for f in (src, bam, bld, cnd, hdr))
     if os.path.exists(IO_LIB) and (not have_src or (not force and os.path.getmtime(IO_LIB) >= max(
-            os.path.getmtime(src), os.path.getmtime(bam), os.path.getmtime(bld), os.path.getmtime(hdr)))):
+            os.path.getmtime(src), os.path.getmtime(bam), os.path.getmtime(bld), os.path.getmtime(cnd), os.path.getmtime(hdr)))):
         return IO_LIB
     inc, lib = os.path.join(HDF5_PREFIX, "include"), os.path.join(HDF5_PREFIX, "lib")
     if not os.path.exists(os.path.join(inc, "hdf5.h")):
@@ -46,7 +47,7 @@ def build_io(force=False, verbose=False):
     # per-process temporary name: loader / writer worker processes that start without a built library may all get
     # here at once; each links its own file and the rename is atomic
     tmp = f"{IO_LIB}.{os.getpid()}.tmp"
-    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", tmp, src, bam, bld, f"-I{inc}", f"-L{lib}",
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", tmp, src, bam, bld, cnd, f"-I{inc}", f"-L{lib}",
            "-lhdf5", "-lz", f"-Wl,-rpath,{lib}"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -46,6 +46,9 @@ SYMBOLS = [
     ("pa_h5_stitch_polish_regions", ctypes.c_int, [c_void_p, c_void_p, c_char_p, c_void_p, c_int32, c_int64, P64, P64, P64, P64]),
     ("pa_h5_stitch_take", ctypes.c_int, [c_void_p, c_int64]),
     ("pa_h5_list_polish_regions", ctypes.c_int, [c_void_p, c_char_p, c_void_p, c_int64, P64, P64, c_void_p, c_void_p, c_int64]),
+    ("pa_candidates_reference_flags", ctypes.c_int, [c_char_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    ("pa_candidates_select_format", c_int64, [c_void_p, c_char_p, c_int64] + [c_void_p] * 8 + [c_int32, c_void_p, c_void_p, c_void_p,
+                                                                                            c_void_p, c_int64, c_void_p]),
     ("pa_h5_builder_open", ctypes.c_int, [c_char_p, ctypes.POINTER(c_void_p)]),
     ("pa_h5_builder_write_polish_predictions", ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 9),
     ("pa_h5_builder_write", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, P64, c_void_p]),
@@ -310,6 +313,18 @@ class File(object):
                                                       positions.ctypes.data, depths.ctypes.data, cand_blob.ctypes.data,
                                                       cand_offsets.ctypes.data, freqs.ctypes.data, probs.ctypes.data,
                                                       probs.shape[1]))
+
+    @_locked
+    def read_strings_raw(self, path):
+        """A string dataset as pa_h5_read_strings returns it: (shape, bytes of the elements, each followed by a NUL)."""
+        shape, cls, size, sgn = self.info(path)
+        if cls not in (CLASS_FIXED, CLASS_VLEN):
+            raise H5Error(f"'{path}' is not a string dataset")
+        needed = c_int64()
+        _check(self._lib.pa_h5_read_strings(self._h, path.encode(), None, 0, ctypes.byref(needed)))
+        buf = ctypes.create_string_buffer(max(1, needed.value))
+        _check(self._lib.pa_h5_read_strings(self._h, path.encode(), buf, needed.value, ctypes.byref(needed)))
+        return shape, buf.raw[:needed.value]
 
     @_locked
     def __getitem__(self, path):

@@ -98,15 +98,16 @@ def _in_repeat(fasta_handler, contig, position):
     return bool(window) and max(window) >= 5
 
 
-def _in_repeat_many(window, contig, positions):
-    """_in_repeat and the upper-cased reference base for many positions of one contig out of the window's text: run lengths
-    of the whole window once, then for each position the longest run among [position-5, position+4) as the 20-base context
-    ref[position-10, position+10) sees it (a run is cut at the context's edges, which are also cut at the contig's)."""
+def _in_repeat_arrays(window, contig, positions):
+    """_in_repeat and the upper-cased reference base for many positions of one contig out of the window's text, as arrays:
+    (letters uint8 [n], 0 where the position lies outside the contig; low-complexity flags bool [n]) -- run lengths of the
+    whole window once, then for each position the longest run among [position-5, position+4) as the 20-base context
+    ref[position-10, position+10) sees it (a run is cut at the context's edges, which are also cut at the contig's).
+    None when the window holds no text (a span too wide to fetch at once)."""
     positions = np.asarray(positions, dtype=np.int64)
     text = window.text
     if text is None or len(text) == 0:
-        bases = [window.get_reference_sequence(contig, int(p), int(p) + 1).upper() for p in positions]
-        return bases, [_in_repeat(window, contig, int(p)) for p in positions]
+        return None
     t = np.frombuffer(text.upper().encode("latin-1"), np.uint8)
     m = len(t)
     change = np.empty(m, bool)
@@ -128,9 +129,18 @@ def _in_repeat_many(window, contig, positions):
         ic = np.clip(idx, 0, m - 1)
         run = np.minimum(run_end[ic], ctx_hi) - np.maximum(run_start[ic], ctx_lo)
         flag |= ok & (run >= 5)
-    letters = t[qc]
-    bases = [chr(c) if ok else "" for c, ok in zip(letters.tolist(), inside.tolist())]
-    return bases, (flag & inside).tolist()
+    return np.where(inside, t[qc], 0).astype(np.uint8), flag & inside
+
+
+def _in_repeat_many(window, contig, positions):
+    """_in_repeat_arrays as lists: (upper-cased reference base or "" per position, low-complexity flag per position)."""
+    arrays = _in_repeat_arrays(window, contig, positions)
+    if arrays is None:
+        positions = np.asarray(positions, dtype=np.int64)
+        bases = [window.get_reference_sequence(contig, int(p), int(p) + 1).upper() for p in positions]
+        return bases, [_in_repeat(window, contig, int(p)) for p in positions]
+    letters, flags = arrays
+    return [chr(c) if c else "" for c in letters.tolist()], flags.tolist()
 
 
 def _select_site(options, contig, position, depth, alleles, supports, prediction, reference_base, in_repeat):

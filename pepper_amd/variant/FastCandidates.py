@@ -6,14 +6,19 @@ Python tuple per selected allele, one dict entry per site, and format and write 
 candidate).  Here a prediction batch is handled as numpy columns (genotype, "non alt" probability, reference base and
 low-complexity flag of every row at once), the selected rows of all batches are ordered and grouped by site with one stable
 lexsort, the records of sites that carry ONE allele record -- nearly all of them -- are formatted in a single pass over plain
-Python lists, and each file is written with one join, its virtual offsets and its tabix index computed arithmetically.
+Python lists -- or, for batches of the form this package's image generation writes (one contig, one allele per row), inside
+the I/O library (pa_candidates_select_format, candidates.cpp: selection and record text of a 512-row batch in ~0.1 ms;
+PEPPER_AMD_CANDIDATES_PYTHON=1 keeps the Python loops) --, and each file is written with one join, its virtual offsets and
+its tabix index computed arithmetically.
 Sites with several allele records go through the reference-shaped merge (VCFWriter.candidate_list_to_variant) unchanged.
 The phasing ("margin") list of find_candidates is not built: the writer never reads it (FindCandidates.py:170-176).
 
 tests/test_candidate_finder.py holds this path to the tuple path: same bytes in every .vcf.gz once decompressed, same
 index content.  Text rendering stays UNPINNED against pysam / htslib (absent from this image), as for the tuple path.
 """
+import ctypes
 import math
+import os
 
 import numpy as np
 
@@ -192,21 +197,175 @@ def _plain_options(options):
     return SimpleNamespace(**{n: getattr(options, n) for n in names})
 
 
+class _Rules(ctypes.Structure):      # pa_candidate_rules (include/pepper_amd_io.h)
+    _fields_ = [("p_value", ctypes.c_double * 3), ("p_value_in_lc", ctypes.c_double * 3), ("report_above_freq", ctypes.c_double * 3),
+                ("snp_q_cutoff", ctypes.c_double), ("snp_q_cutoff_in_lc", ctypes.c_double),
+                ("indel_q_cutoff", ctypes.c_double), ("indel_q_cutoff_in_lc", ctypes.c_double)]
+
+
+def _rules(options):
+    try:
+        return _Rules((ctypes.c_double * 3)(options.snp_p_value, options.insert_p_value, options.delete_p_value),
+                      (ctypes.c_double * 3)(options.snp_p_value_in_lc, options.insert_p_value_in_lc, options.delete_p_value_in_lc),
+                      (ctypes.c_double * 3)(options.report_snp_above_freq, options.report_indel_above_freq,
+                                            options.report_indel_above_freq),
+                      options.snp_q_cutoff, options.snp_q_cutoff_in_lc, options.indel_q_cutoff, options.indel_q_cutoff_in_lc)
+    except TypeError:
+        return None                  # thresholds that are not numbers: the Python path has the reference's behaviour for them
+
+
+class _Segment(object):
+    """The records selected from one prediction batch (plain attributes: a worker process returns these).
+    contig: one name for all rows, or a list per row; pos int64 [m]; ref_len int32 [m]; snp / sel bool [m]; lines: list of
+    bytes; pair(k) -> (REF, first ALT) and record(k) -> the calling tuple of CandidateFinder._select_site, for the few sites
+    that carry several allele records."""
+
+    def __init__(self, contig, pos, ref_len, snp, sel, lines, cols=None, raw=None):
+        self.contig, self.pos, self.ref_len, self.snp, self.sel, self.lines = contig, pos, ref_len, snp, sel, lines
+        self.cols, self.raw = cols, raw
+
+    def __len__(self):
+        return len(self.lines)
+
+    def record(self, k):
+        if self.cols is not None:
+            return self.cols.record(k)
+        row, flags, pos, depth, support, pred, letters, rep, blob, starts = self.raw
+        i = int(row[k])
+        allele = blob[starts[i] + 1:starts[i + 1] - 1].decode()
+        base = chr(letters[i])
+        ref, alt = (allele, base) if flags[k] & 4 else (base, allele)
+        p = [float(x) for x in pred[i]]
+        g = int(flags[k]) >> 4
+        return (self.contig, int(pos[i]), int(pos[i]) + len(ref), ref, [alt], ([0, 0], [0, 1], [1, 1])[g], int(depth[i]),
+                [int(support[i])], p[g], p, [max(p[1], p[2])], bool(rep[i]))
+
+    def pair(self, k):
+        if self.cols is not None:
+            return self.cols.ref[k], self.cols.alt[k]
+        record = self.record(k)
+        return record[3], record[4][0]
+
+
+def _native_batch(options, rules, fasta_handler, file_name, batch_key, files=None):
+    """One prediction batch through pa_candidates_select_format (candidates.cpp): -> a _Segment, or None when the batch is not
+    of the form that path takes (several contigs, candidate lists with several alleles, a reference window too wide, NaN
+    probabilities, a zero depth the reference would divide by): _select_batch + _format_single then.  files: the caller's
+    {file name: open h5.File} (one at a time)."""
+    own = files is None
+    if own:
+        files = {}
+    try:
+        return _native_batch_open(options, rules, fasta_handler, file_name, batch_key, files)
+    finally:
+        if own:
+            for f in files.values():
+                f.close()
+
+
+def _native_batch_open(options, rules, fasta_handler, file_name, batch_key, files):
+    f = files.get(file_name)
+    if f is None:
+        for other in files.values():                       # one prediction file open at a time: the batches come file by file
+            other.close()
+        files.clear()
+        f = files[file_name] = h5.File(file_name, "r")
+        f.has_predictions = "predictions" in f.keys()
+    if not f.has_predictions:
+        return _Segment("", np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, bool), np.zeros(0, bool), [])
+    base = "predictions/" + batch_key + "/"
+    contig_shape, contig_blob = f.read_strings_raw(base + "contigs")
+    shape, blob = f.read_strings_raw(base + "candidates")
+    positions = f[base + "positions"]
+    depths = f[base + "depths"]
+    freq = f[base + "candidate_frequency"]
+    pred = f[base + "base_prediction"]
+    n = int(np.prod(contig_shape)) if contig_shape else 1
+    if n == 0:
+        return _Segment("", np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, bool), np.zeros(0, bool), [])
+    first = contig_blob[:contig_blob.index(b"\0")]
+    if contig_blob != (first + b"\0") * n or tuple(shape) != (n, 1) or np.shape(freq) != (n, 1) or np.asarray(freq).dtype.kind not in "iu":
+        return None
+    text = np.frombuffer(blob, np.uint8)
+    ends = np.flatnonzero(text == 0)
+    if len(ends) != n or np.isin(text, _LIST_BYTES).any():
+        return None
+    starts = np.empty(n + 1, np.int64)
+    starts[0] = 0
+    starts[1:] = ends + 1
+    if (np.diff(starts) < 2).any():                       # an empty candidate string
+        return None
+    pred = np.ascontiguousarray(np.asarray(pred).astype(np.float32)).reshape(n, -1)
+    if pred.shape[1] != 3:
+        raise ValueError("base_prediction of %s/%s has %d classes, expected 3" % (file_name, batch_key, pred.shape[1]))
+    contig = first.decode("UTF-8")
+    pos = np.ascontiguousarray(np.asarray(positions, dtype=np.int64).reshape(n))
+    window = _ReferenceWindow(fasta_handler, contig, int(pos.min()) - 16, int(pos.max()) + 16)
+    if not window.text:
+        return None
+    text = window.text.encode("latin-1")
+    letters, rep = np.empty(n, np.uint8), np.empty(n, np.uint8)
+    if h5.load().pa_candidates_reference_flags(text, len(text), window.lo, n, pos.ctypes.data, letters.ctypes.data, rep.ctypes.data) < 0:
+        raise h5.H5Error(h5.load().pa_h5_last_error().decode())
+    depth = np.ascontiguousarray(np.asarray(depths).reshape(n).astype(np.int64))
+    support = np.ascontiguousarray(np.asarray(freq)[:, 0].astype(np.int64))
+    row, ref_len, flags = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.uint8)
+    offsets = np.empty(n + 1, np.int64)
+    cap = len(blob) + n * (len(first) + 200)
+    lines = ctypes.create_string_buffer(cap)
+    m = h5.load().pa_candidates_select_format(
+        ctypes.byref(rules), first, n, pos.ctypes.data, depth.ctypes.data, support.ctypes.data, pred.ctypes.data,
+        letters.ctypes.data, rep.ctypes.data, blob, starts.ctypes.data, 1, row.ctypes.data, ref_len.ctypes.data,
+        flags.ctypes.data, lines, cap, offsets.ctypes.data)
+    if m == -2:
+        return None
+    if m < 0:
+        raise h5.H5Error(h5.load().pa_h5_last_error().decode())
+    raw_lines = lines.raw
+    cut = offsets[:m + 1].tolist()
+    row, flags = row[:m], flags[:m]
+    return _Segment(contig, pos[row], ref_len[:m].copy(), (flags & 1).astype(bool), (flags & 2).astype(bool),
+                    [raw_lines[cut[k]:cut[k + 1]] for k in range(m)],
+                    raw=(row.copy(), flags.copy(), pos, depth, support, pred, letters, rep, blob, starts))
+
+
+_LIST_BYTES = np.frombuffer(b" ,'\"[]\n", np.uint8)
+
+
+def _python_batch(options, fasta_handler, file_name, batch_key, leftovers):
+    cols = _Columns()
+    _select_batch(options, fasta_handler, file_name, batch_key, cols, leftovers)
+    ref_lens, lines, snps, sels = _format_single(options, cols, range(len(cols)))
+    return _Segment(list(cols.contig), np.asarray(cols.pos, dtype=np.int64).reshape(len(cols)), np.asarray(ref_lens, dtype=np.int32),
+                    np.asarray(snps, dtype=bool), np.asarray(sels, dtype=bool), lines, cols=cols)
+
+
 def _part(options, pairs):
     """Selection + single-site formatting of some prediction batches: what a worker process returns."""
     fasta_handler = _fasta(options)
-    cols, leftovers = _Columns(), []
-    for file_name, batch_key in pairs:
-        _select_batch(options, fasta_handler, file_name, batch_key, cols, leftovers)
-    return cols, leftovers, _format_single(options, cols, range(len(cols)))
+    rules = None if os.environ.get("PEPPER_AMD_CANDIDATES_PYTHON") == "1" else _rules(options)
+    segments, leftovers, files = [], [], {}
+    try:
+        for file_name, batch_key in pairs:
+            segment = _native_batch(options, rules, fasta_handler, file_name, batch_key, files) if rules is not None else None
+            if segment is None:
+                segment = _python_batch(options, fasta_handler, file_name, batch_key, leftovers)
+            if len(segment):
+                segments.append(segment)
+    finally:
+        for f in files.values():
+            f.close()
+    return segments, leftovers
 
 
 def _parts(options, all_prediction_pair):
-    """The batches in order, cut into one part per worker process (options.threads; one process below ~100 k rows or when the
-    FASTA reader is injected -- a factory need not survive pickling)."""
+    """The batches in order, cut into one part per worker process (options.threads; one process below ~100 k rows per worker
+    or when the FASTA reader is injected -- a factory need not survive pickling).  With the selection and the record text inside
+    the I/O library a batch of 512 rows takes ~1 ms, so worker processes (0.3 s to start) only pay for very big jobs."""
     threads = max(1, int(getattr(options, "threads", 1) or 1))
     pairs = list(all_prediction_pair)
-    if threads == 1 or len(pairs) < 8 * threads or getattr(options, "fasta_handler_factory", None) is not None:
+    python_form = os.environ.get("PEPPER_AMD_CANDIDATES_PYTHON") == "1"
+    if threads == 1 or len(pairs) < (8 if python_form else 1024) * threads or getattr(options, "fasta_handler_factory", None) is not None:
         return [_part(options, pairs)]
     import sys
     from multiprocessing import get_context
@@ -259,30 +418,27 @@ def process(options, all_prediction_pair, vcf):
     """all_prediction_pair: [(prediction file, batch key)] as FindCandidates.candidate_finder lists them; vcf: an open
     VCFWriter.  -> (contigs, totals) with totals as write_vcf_records returns them."""
     parts = _parts(options, all_prediction_pair)
-    cols, leftovers = _Columns(), []
-    ref_lens, lines, snps, sels = [], [], [], []
-    for part_cols, part_left, (r, ln, sn, se) in parts:
-        for name in _Columns.__slots__:
-            getattr(cols, name).extend(getattr(part_cols, name))
+    segments, leftovers = [], []
+    for part_segments, part_left in parts:
+        segments.extend(part_segments)
         leftovers.extend(part_left)
-        ref_lens.extend(r)
-        lines.extend(ln)
-        snps.extend(sn)
-        sels.extend(se)
-    n = len(cols)
     plain = _plain_options(options)
+    sizes = np.fromiter(map(len, segments), np.int64, len(segments))
+    n = int(sizes.sum())
     if leftovers:
         # files this package did not write (several alleles in a row's candidate list): every record through the tuple path
         from pepper_amd.variant.CandidateFinder import _by_site
-        contigs, sites = _by_site([cols.record(i) for i in range(n)] + leftovers)
+        contigs, sites = _by_site([seg.record(k) for seg in segments for k in range(len(seg))] + leftovers)
         return contigs, vcf.write_vcf_records(sites, plain)
     if n == 0:
         return [], (0, 0, 0, 0, 0)
     # one stable order by (contig name, position), as _by_site / write_vcf_records sort; sites = runs of equal keys
-    contig_names = sorted(set(cols.contig))
+    contig_names = sorted({c for seg in segments for c in ([seg.contig] if isinstance(seg.contig, str) else seg.contig)})
     rank = {c: k for k, c in enumerate(contig_names)}
-    key_c = np.fromiter(map(rank.__getitem__, cols.contig), np.int64, n)
-    key_p = np.asarray(cols.pos, dtype=np.int64).reshape(n)
+    key_c = np.concatenate([np.full(len(seg), rank[seg.contig], np.int64) if isinstance(seg.contig, str) else
+                            np.fromiter(map(rank.__getitem__, seg.contig), np.int64, len(seg)) for seg in segments])
+    key_p = np.concatenate([seg.pos for seg in segments])
+    lines = [line for seg in segments for line in seg.lines]
     order = np.lexsort((key_p, key_c))
     sc, sp = key_c[order], key_p[order]
     first = np.concatenate([[True], (sc[1:] != sc[:-1]) | (sp[1:] != sp[:-1])])
@@ -291,9 +447,10 @@ def process(options, all_prediction_pair, vcf):
     rows = order[site_at]                                  # original row of every site's first record
     row_list = rows.tolist()
     site_lines = [lines[k] for k in row_list]
-    site_ref_len = np.asarray(ref_lens, dtype=np.int64)[rows]
-    site_snp = np.asarray(snps, dtype=bool)[rows]
-    site_sel = np.asarray(sels, dtype=bool)[rows]
+    site_ref_len = np.concatenate([seg.ref_len for seg in segments]).astype(np.int64)[rows]
+    site_snp = np.concatenate([seg.snp for seg in segments])[rows]
+    site_sel = np.concatenate([seg.sel for seg in segments])[rows]
+    seg_first = np.concatenate([[0], np.cumsum(sizes)])    # global row of every segment's first record
     order_list = None
     for s in np.flatnonzero(site_size > 1).tolist():
         # several allele records at one site: keep the first record of each (REF, first ALT) (:552-573), then the reference's merge
@@ -301,10 +458,12 @@ def process(options, all_prediction_pair, vcf):
             order_list = order.tolist()
         group, seen = [], []
         for k in order_list[site_at[s]:site_at[s] + site_size[s]]:
-            pair = (cols.ref[k], cols.alt[k])
+            si = int(np.searchsorted(seg_first, k, side="right")) - 1
+            local = k - int(seg_first[si])
+            pair = segments[si].pair(local)
             if pair not in seen:
                 seen.append(pair)
-                group.append(cols.record(k))
+                group.append(segments[si].record(local))
         record, is_snp, selected = VCFWriter.format_sites([group], plain)[0]
         site_lines[s], site_ref_len[s], site_snp[s], site_sel[s] = record[3], record[2], is_snp, selected
     totals = _write_all(vcf, contig_names, sc[site_at], sp[site_at], site_ref_len, site_lines, site_snp, site_sel)

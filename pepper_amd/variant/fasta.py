@@ -11,6 +11,8 @@ which aborts).
 """
 import os
 
+_SCANS = {}      # (path, mtime, size) -> (names, index) of the last FASTA file scanned for want of a .fai
+
 
 class FASTA_handler(object):
     def __init__(self, path):
@@ -29,7 +31,14 @@ class FASTA_handler(object):
                     self._names.append(f[0])
                     self._index[f[0]] = (int(f[1]), int(f[2]), int(f[3]), int(f[4]))
         else:
-            self._scan()
+            # one scan per file and process: candidate finding opens the reference once for the records and once per worker
+            st = os.stat(path)
+            key = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+            if key not in _SCANS:
+                self._scan()
+                _SCANS.clear()
+                _SCANS[key] = (list(self._names), dict(self._index))
+            self._names, self._index = list(_SCANS[key][0]), dict(_SCANS[key][1])
         self._fh = open(path, "rb")
 
     def _scan(self):

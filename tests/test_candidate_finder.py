@@ -328,6 +328,18 @@ def test_low_complexity_flags_of_a_batch_equal_the_per_site_scan():
         assert b == fasta.get_reference_sequence("c", p, p + 1).upper()
         if b:
             assert f == cf._in_repeat(fasta, "c", p), p
+    # the same out of the I/O library (pa_candidates_reference_flags), for windows that start at 0 and further in
+    from pepper_amd import h5
+    for lo_pos in (0, 37, 1500):
+        some = positions[positions >= lo_pos]
+        window = cf._ReferenceWindow(fasta, "c", int(some.min()) - 16, int(some.max()) + 16)
+        want_letters, want_flags = cf._in_repeat_arrays(window, "c", some)
+        raw = window.text.encode("latin-1")
+        letters, rep = np.empty(len(some), np.uint8), np.empty(len(some), np.uint8)
+        pos64 = np.ascontiguousarray(some, dtype=np.int64)
+        assert h5.load().pa_candidates_reference_flags(raw, len(raw), window.lo, len(some), pos64.ctypes.data, letters.ctypes.data,
+                                                       rep.ctypes.data) == 0
+        assert np.array_equal(letters, want_letters) and np.array_equal(rep.astype(bool), want_flags)
 
 
 def _synthetic_predictions(tmp_path, n, seed, with_multi):
@@ -414,3 +426,60 @@ def _resolved(index, vcf_path):
     refs = [{"bins": {b: [(conv(x), conv(y)) for x, y in chunks] for b, chunks in r["bins"].items()},
              "ioff": [conv(v) if v else 0 for v in r["ioff"]]} for r in index["refs"]]
     return dict(index, refs=refs)
+
+
+def test_library_batches_equal_the_python_loops(tmp_path, monkeypatch):
+    """pa_candidates_select_format (candidates.cpp) against _select_batch + _format_single on the same batch: the same rows
+    kept, the same record text to the byte -- with support / depth ratios that are exact ties in binary (1/16, 3/16, 5/32:
+    round(x, 3) rounds half to even), probabilities that tie, exact zeros and ones, every threshold of every allele kind in
+    play; batches of another form (two contigs, a zero depth the reference would divide by) are left to the Python loops."""
+    from pepper_amd.variant import FastCandidates as fc
+    from pepper_amd.variant.CandidateFinder import _fasta
+    rng = np.random.default_rng(8)
+    ref = "".join("ACGTN"[int(k)] * int(r) for k, r in zip(rng.choice(5, 9000, p=[0.24, 0.24, 0.24, 0.24, 0.04]), rng.choice([1, 1, 2, 6], 9000)))
+    length = len(ref)
+    fa = str(tmp_path / "r.fa")
+    with open(fa, "w") as fh:
+        fh.write(">c1\n" + ref + "\n>c2\n" + ref[::-1] + "\n")
+    n = 4000
+    pos = np.sort(rng.choice(np.arange(20, length - 20), n, replace=False)).astype(np.int32)
+    depth = rng.choice([1, 2, 8, 16, 32, 64, 90], n).astype(np.uint8)
+    support = rng.integers(0, 60, (n, 1)).astype(np.uint8)
+    cands = []
+    for p in pos:
+        r = ref[int(p)] if ref[int(p)] in "ACGT" else "A"
+        cands.append([("1" + "ACGT"[int(rng.integers(4))], "2" + r + "ACG"[: int(rng.integers(1, 4))], "3" + "ACGTA"[: int(rng.integers(2, 6))],
+                       "1n", "4A", "2")[int(rng.choice(6, p=[0.4, 0.25, 0.25, 0.04, 0.03, 0.03]))]])
+    probs = rng.dirichlet([0.5, 0.5, 0.5], n).astype(np.float32)
+    probs[rng.random(n) < 0.1] = [0.25, 0.5, 0.25]
+    probs[rng.random(n) < 0.05] = [0.5, 0.25, 0.25]
+    probs[rng.random(n) < 0.05] = [0.0, 0.0, 1.0]
+    probs[rng.random(n) < 0.05] = [1.0 / 3, 1.0 / 3, 1.0 / 3]
+    pred = str(tmp_path / "p.hdf")
+    with DataStore(pred, "w") as store:
+        store.write_prediction(0, ["c1"] * n, pos, depth, np.array(cands, dtype=object), support, probs)
+        store.write_prediction(1, ["c1"] * 3 + ["c2"], pos[:4], depth[:4], np.array(cands[:4], dtype=object), support[:4], probs[:4])
+        zero = depth[:4].copy()
+        zero[2] = 0
+        low = probs[:4].copy()
+        low[2] = [0.98, 0.01, 0.01]                         # not called by probability: the frequency rule divides by the depth
+        store.write_prediction(2, ["c2"] * 4, pos[:4], zero, np.array([["1A"]] * 4, dtype=object), support[:4], low)
+    for freq in (0, 0.15):
+        opts = options(fasta=fa, report_snp_above_freq=freq, report_indel_above_freq=freq)
+        handler = _fasta(opts)
+        seg = fc._native_batch(opts, fc._rules(opts), handler, pred, "batch_0")
+        left = []
+        want = fc._python_batch(opts, handler, pred, "batch_0", left)
+        assert seg is not None and seg.raw is not None and not left and len(seg) == len(want) > 1500
+        assert seg.lines == want.lines
+        assert np.array_equal(seg.pos, want.pos) and np.array_equal(seg.ref_len, want.ref_len)
+        assert np.array_equal(seg.snp, want.snp) and np.array_equal(seg.sel, want.sel)
+        for k in (0, 1, len(seg) // 2, len(seg) - 1):
+            assert seg.record(k) == want.record(k) and seg.pair(k) == want.pair(k)
+        assert fc._native_batch(opts, fc._rules(opts), handler, pred, "batch_1") is None          # two contigs
+        if freq:
+            assert fc._native_batch(opts, fc._rules(opts), handler, pred, "batch_2") is None      # the reference's ZeroDivisionError
+            with pytest.raises(ZeroDivisionError):
+                fc._python_batch(opts, handler, pred, "batch_2", [])
+        else:
+            assert len(fc._native_batch(opts, fc._rules(opts), handler, pred, "batch_2")) == len(fc._python_batch(opts, handler, pred, "batch_2", []))
