@@ -365,7 +365,7 @@ def _parts(options, all_prediction_pair):
     threads = max(1, int(getattr(options, "threads", 1) or 1))
     pairs = list(all_prediction_pair)
     python_form = os.environ.get("PEPPER_AMD_CANDIDATES_PYTHON") == "1"
-    if threads == 1 or len(pairs) < (8 if python_form else 1024) * threads or getattr(options, "fasta_handler_factory", None) is not None:
+    if threads == 1 or len(pairs) < (8 if python_form else 256) * threads or getattr(options, "fasta_handler_factory", None) is not None:
         return [_part(options, pairs)]
     import sys
     from multiprocessing import get_context

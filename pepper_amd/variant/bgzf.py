@@ -30,9 +30,11 @@ def _compress_pool():
     """Threads for the deferred writers (zlib releases the GIL while it deflates a block)."""
     global _pool
     if _pool is None:
-        import os
         from concurrent.futures import ThreadPoolExecutor
-        _pool = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 2)), thread_name_prefix="bgzf")
+        from pepper_amd.hostinfo import usable_cpus
+        # the deflate of the five files' blocks is what is left when the records are written in bulk: every CPU this
+        # process may use (not the host's count: a container's quota is often a fraction of it)
+        _pool = ThreadPoolExecutor(max_workers=max(2, min(32, usable_cpus())), thread_name_prefix="bgzf")
     return _pool
 
 
