@@ -315,7 +315,7 @@ class File(object):
                                                       probs.shape[1]))
 
     @_locked
-    def read_strings_raw(self, path):
+    def read_strings_shaped(self, path):
         """A string dataset as pa_h5_read_strings returns it: (shape, bytes of the elements, each followed by a NUL)."""
         shape, cls, size, sgn = self.info(path)
         if cls not in (CLASS_FIXED, CLASS_VLEN):

@@ -274,8 +274,8 @@ def _native_batch_open(options, rules, fasta_handler, file_name, batch_key, file
     if not f.has_predictions:
         return _Segment("", np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, bool), np.zeros(0, bool), [])
     base = "predictions/" + batch_key + "/"
-    contig_shape, contig_blob = f.read_strings_raw(base + "contigs")
-    shape, blob = f.read_strings_raw(base + "candidates")
+    contig_shape, contig_blob = f.read_strings_shaped(base + "contigs")
+    shape, blob = f.read_strings_shaped(base + "candidates")
     positions = f[base + "positions"]
     depths = f[base + "depths"]
     freq = f[base + "candidate_frequency"]
