@@ -478,6 +478,7 @@ struct pa_variant_model : ModelBase {
     bool split_rec = true;       // PA_SPLIT_REC=0 keeps the recurrences on the f32 matrix instructions
     bool fuse_dec = true;        // PA_FUSE_DEC=0: decoder projection as a GEMM + Xp instead of inside the step loop
     int64_t small_batch = 3072;  // calls of at most this many windows take the GEMM + Xp decoder (PA_SMALL_BATCH)
+    int64_t small_rows = 3072;   // ... and 32-row workgroups in both step loops (PA_SMALL_ROWS); at 4096 windows both schedules take 2.25 ms
     std::vector<RecLayer> rec;   // encoder layers then decoder layers
     Linear lin[5], out;
     DevBuf *mlp_w = nullptr, *mlp_b = nullptr;   // linear_2..5 as h2 fragments + their biases (mlp_h2.hip)
@@ -514,6 +515,7 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     m->split_rec = m->split_rec && m->split_gemm;   // the h2 layer output needs the h2 consumers
     if (const char* e = getenv("PA_FUSE_DEC")) m->fuse_dec = e[0] != '0';
     if (const char* e = getenv("PA_SMALL_BATCH")) m->small_batch = atoll(e);
+    if (const char* e = getenv("PA_SMALL_ROWS")) m->small_rows = atoll(e);
     int rc = init_base(m, cfg->device, hip_stream);
     const int H = m->H;
     for (int mod = 0; mod < 2 && rc == PA_OK; ++mod)
@@ -601,6 +603,9 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     // step loop contracts K = 256 only (14.7 us per step): 512 windows 2.16 -> 1.42 ms, 1024: 2.17 -> 1.59, 2048: 2.18 -> 1.83;
     // at 4096 the fused loop wins again (profiles/r03_small_batch_kernels.json).  PA_SMALL_BATCH=0: always fused.
     const bool fuse_dec = m->fuse_dec && n > m->small_batch;
+    // ... and, up to `small_rows` windows, both step loops run with 32-row workgroups (rnn_h2.hip MTILES = 1): a step is one
+    // CU's affair, half the rows are half the MFMAs and half the gate phase per step (PA_SMALL_ROWS, 0 = never)
+    const bool small_rows = n <= m->small_rows;
     bool need_xp = !(a_kind == pa::A_I8 && m->fuse_input && !m->rec.empty() && m->rec[0].w_cat != nullptr);
     for (size_t li = 1; li < m->rec.size(); ++li)
         need_xp = need_xp || !(m->split_rec && fuse_dec && m->rec[li].w_cat_dec_h2 != nullptr);
@@ -631,7 +636,7 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
             if (rec_h2 && r.w_cat_h2 != nullptr)
                 LAUNCH_TRY(m, "lstm_rec_h2_fused_in", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
                            pa::launch_lstm_rec_h2(H, nullptr, 0, static_cast<const int8_t*>(cur), r.K, bias_l,
-                                                  r.w_cat_h2->p, y, 2 * H, (int)n, T, m->stream, r.prescaled));
+                                                  r.w_cat_h2->p, y, 2 * H, (int)n, T, m->stream, r.prescaled, small_rows));
             else
                 LAUNCH_TRY(m, "lstm_rec_fused_in", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
                            pa::launch_lstm_rec_fused(H, static_cast<const int8_t*>(cur), r.K, r.b_in->f(),
@@ -661,7 +666,7 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
             if (rec_h2)
                 LAUNCH_TRY(m, "lstm_rec_h2", 2.0 * n * T * (4.0 * H) * H * 2,
                            pa::launch_lstm_rec_h2(H, m->xp->f(), NX, nullptr, 0, nullptr, r.w_hh_h2->p, y, 2 * H, (int)n,
-                                                  T, m->stream, r.prescaled));
+                                                  T, m->stream, r.prescaled, small_rows));
             else
                 LAUNCH_TRY(m, "lstm_rec", 2.0 * n * T * (4.0 * H) * H * 2,
                            pa::launch_lstm_rec(H, m->xp->f(), NX, r.w_hh->f(), y, 2 * H, (int)n, T, m->stream));

@@ -60,7 +60,7 @@ int gru_fused_input_kx(int H, int F);   // 16 / 128: padded width of the uint8-i
 // prescaled: weights / bias / Xp were multiplied per gate row by the exp2 constants (see rnn_h2.hip).
 hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, int F, const float* bias,
                               const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream,
-                              bool prescaled = false);
+                              bool prescaled = false, bool small = false);   // small: 32-row workgroups (small calls)
 
 // LSTM layer fed by an h2 layer output Xh [B*T, 2H]: projection contracted inside the step loop (weights packed
 // with pack_rec_weights_h2(..., F = 2H, KX = 2H); bias = b_ih + b_hh).

@@ -62,7 +62,12 @@ PA_DEV void decode_block(int bid, int& dir, int& btile) {
 // BC (fused int8 first layer with F < KX): the bias lives in column H + F of the packed weights and x carries a constant
 // 1.0 there, so the first MFMA of a step starts every accumulator from the inline constant 0: no bias loads and no 128
 // register moves per step in the gate phase, which is bound by VALU issue (two waves per SIMD, ~1300 instructions each).
-template <int H, int KX, bool PRE, bool XG = false, int SAUX = 0, bool BC = false>
+// MTILES (row tiles of 32 per workgroup; 2 = the 64-row workgroup everything above describes, 1 = the small-call schedule):
+// a step is one CU's affair -- 8 waves x KS k steps x 12 MTILES MFMAs of 32 cycles on 4 SIMDs, then the gate phase of
+// 16 MTILES elements per lane -- whatever the number of workgroups, so a call of a few hundred windows, which fills a small
+// part of the chip either way, takes half the time per step with 32-row workgroups (twice as many of them, each still
+// streaming the direction's weight fragments from L2).  Big calls keep 64 rows: half the weight stream per window.
+template <int H, int KX, bool PRE, bool XG = false, int SAUX = 0, bool BC = false, int MTILES = 2>
 __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float* __restrict__ Xp, int ldx,
                                                                      const int8_t* __restrict__ Xi, int F,
                                                                      const float* __restrict__ bias,
@@ -71,29 +76,31 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                                                                      unsigned long long* __restrict__ dbg,
                                                                      const uint32_t* __restrict__ Xh = nullptr, int ldxh = 0) {
     constexpr int KT = H + KX, KS = KT / 16, KSH = H / 16, NT = H / 32, NW = H / 32;
+    constexpr int MTL = 32 * MTILES;             // rows of this workgroup
+    static_assert(MTILES == 2 || (MTILES == 1 && !XG), "the x ring of the XG form is laid out for 64 rows");
     constexpr int KL = XG ? H : KT;              // columns kept in the LDS rows
     constexpr int ROWB = KL * 4 + 16;            // bytes per LDS row: h2 image of [h | x] + 16 pad (odd 16-B count)
     constexpr int ROWD = ROWB / 4;               // in dwords
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [MT][ROWD] h2 rows, then c (f32)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [MTL][ROWD] h2 rows, then c (f32)
     static_assert(KS % 2 == 0, "the weight prefetch assumes an even number of k steps");
     static_assert((ROWB / 16) % 2 == 1, "row stride must be an odd number of 16-byte slots");
 
     int dir, btile;
     decode_block(blockIdx.x, dir, btile);
-    const int b0 = btile * MT;
+    const int b0 = btile * MTL;
     if (b0 >= B) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hf = lane >> 5;
 
-    float* cs = reinterpret_cast<float*>(lds + MT * ROWD) + u * (2 * 16 * 64) + lane;     // [wave][m][r][lane]
-    for (int idx = tid; idx < MT * ROWD + NW * 2 * 16 * 64; idx += blockDim.x) lds[idx] = 0u;
-    // XG: x ring after the cell state: 2 slots x [MT rows][XRD dwords] (128 B of x + 16 B pad per row)
-    constexpr int XRD = 36, XSLOT = MT * XRD, NXI = XG ? KX / 32 : 0;   // NXI iterations of two k steps
-    uint32_t* xring = lds + MT * ROWD + NW * 2 * 16 * 64;
+    float* cs = reinterpret_cast<float*>(lds + MTL * ROWD) + u * (MTILES * 16 * 64) + lane;     // [wave][m][r][lane]
+    for (int idx = tid; idx < MTL * ROWD + NW * MTILES * 16 * 64; idx += blockDim.x) lds[idx] = 0u;
+    // XG: x ring after the cell state: 2 slots x [MTL rows][XRD dwords] (128 B of x + 16 B pad per row)
+    constexpr int XRD = 36, XSLOT = MTL * XRD, NXI = XG ? KX / 32 : 0;   // NXI iterations of two k steps
+    uint32_t* xring = lds + MTL * ROWD + NW * MTILES * 16 * 64;
 
-    f32x16 acc[2][4];   // [row tile][gate]
+    f32x16 acc[MTILES][4];   // [row tile][gate]
 
     const size_t urow = (size_t)b0 * T;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     // fused only: x_t (int8, exact in f16) -> hi halves of LDS columns [H, H+KX); lo halves stay 0.
     // One thread per pair of features: 64 rows x KX/2 pairs over 512 threads.
     constexpr bool XI8 = KX > 0 && !XG;
-    constexpr int XN = XI8 ? (MT * KX / 2) / (NW * 64) : 1;
+    constexpr int XN = XI8 ? (MTL * KX / 2) / (NW * 64) : 1;
     unsigned xv[XN];
     auto x_load = [&](int t) {
         if (XI8) {
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     };
     auto xg_store = [&](int j) { *reinterpret_cast<u32x4*>(xst_dst + (j & 1) * XSLOT) = xstage[j & 1]; };
 
-    struct Frag { h8 b[4][2], a[2][2]; };     // [gate][hi, lo], [row tile][hi, lo]
+    struct Frag { h8 b[4][2], a[MTILES][2]; };     // [gate][hi, lo], [row tile][hi, lo]
     const uint32_t* arow = lds + li * ROWD + hf * 8;
     bool exp_loads = true;       // PA_EXP_NO_BLOAD (energy experiment, wrong results): weight fragments loaded once, not per step
     auto load_b = [&](int s, Frag& fr) {
@@ -186,14 +193,14 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
             const int xs = s - KSH;
             const uint32_t* src = xring + ((xs >> 1) & 1) * XSLOT + li * XRD + ((xs & 1) * 2 + hf) * 8;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < MTILES; ++m) {
                 fr.a[m][0] = *reinterpret_cast<const h8*>(src + m * 32 * XRD);
                 fr.a[m][1] = *reinterpret_cast<const h8*>(src + m * 32 * XRD + 4);
             }
             return;
         }
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MTILES; ++m) {
             fr.a[m][0] = *reinterpret_cast<const h8*>(arow + m * 32 * ROWD + s * 16);
             fr.a[m][1] = *reinterpret_cast<const h8*>(arow + m * 32 * ROWD + s * 16 + 4);
         }
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     // y copy: the h part of the LDS rows (H * 4 bytes = H/4 16-byte chunks per row) -> Y, as is
     constexpr int CPR = H / 4;                                // 16-byte chunks per row
     constexpr int YROWS = (NW * 64) / CPR;                    // rows per pass (8)
-    constexpr int YC = MT / YROWS;                            // passes (8)
+    constexpr int YC = MTL / YROWS;                            // passes (8)
     const int yc_row = tid / CPR, yc_c = tid % CPR;
     const uint32_t* yc_src = lds + yc_row * ROWD + yc_c * 4;
     const __amdgpu_buffer_rsrc_t ycrs =
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     {
         const int t0 = dir ? T - 1 : 0;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MTILES; ++m)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) seed_chunk(m, qd, t0);
         x_load(t0);
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #pragma unroll
-                        for (int m = 0; m < 2; ++m)
+                        for (int m = 0; m < MTILES; ++m)
                             acc[m][g] = mfma_h(ring[p].a[m][term == 0 ? 1 : 0], ring[p].b[g][term == 1 ? 1 : 0],
                                                fresh ? f32x16{} : acc[m][g]);
                 }
@@ -294,6 +301,26 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // x slab chunk of a later iteration
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                } else if (MTILES == 1 && s + 1 < KS) {
+                    // 12 MFMAs per k step: 8 weight fragments, 2 A fragments, the y copy's read / write in the first steps
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (B fragment)
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (A fragment)
+                    }
+                    if (s <= YC) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // 1 VMEM write (y copy)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (y copy)
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    }
                 } else if (s + 1 < KS) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -314,6 +341,13 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
                     } else {
                         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                     }
+                } else if (MTILES == 1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // next time step's first B fragments
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 } else {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -344,7 +378,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
         const int tn = dir ? t - 1 : t + 1;
         if (step + 1 < T) x_load(tn);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MTILES; ++m)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
 #pragma unroll
@@ -1169,10 +1203,28 @@ hipError_t launch_lstm_dec_h2(int H, const void* Xh, int ldxh, const float* bias
 }
 
 hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, int F, const float* bias,
-                              const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream, bool prescaled) {
+                              const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream, bool prescaled, bool small) {
     if (B <= 0) return hipSuccess;
     if (H != 256 || (ldy & 7)) return hipErrorInvalidValue;
     const int grid = rec_grid(B);
+    if (small && prescaled) {
+        // 32-row workgroups for small calls (see the kernel's MTILES): twice the workgroups, half the time per step
+        const int nbt = (B + 31) / 32, grid1 = 2 * ((nbt + 3) / 4) * 4;
+        if (X != nullptr && F > 0 && F < 32 && stream_nt() && bias_column()) {
+            const size_t lds = (size_t)32 * ((256 + 32) * 4 + 16) + (size_t)8 * 16 * 64 * 4;
+            hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 32, true, false, 2, true, 1>), dim3(grid1), dim3(512), lds, stream,
+                               (const float*)nullptr, 0, X, F, bias, static_cast<const uint32_t*>(Wp), static_cast<uint32_t*>(Y),
+                               ldy, B, T, (unsigned long long*)nullptr);
+            return hipGetLastError();
+        }
+        if (X == nullptr) {
+            const size_t lds = (size_t)32 * (256 * 4 + 16) + (size_t)8 * 16 * 64 * 4;
+            hipLaunchKernelGGL((lstm_rec_h2_kernel<256, 0, true, false, 0, false, 1>), dim3(grid1), dim3(512), lds, stream, Xp, ldx,
+                               (const int8_t*)nullptr, 0, (const float*)nullptr, static_cast<const uint32_t*>(Wp),
+                               static_cast<uint32_t*>(Y), ldy, B, T, (unsigned long long*)nullptr);
+            return hipGetLastError();
+        }
+    }
     if (X != nullptr) {
         if (F <= 0 || F > 32) return hipErrorInvalidValue;
         const size_t lds = (size_t)MT * ((256 + 32) * 4 + 16) + (size_t)8 * 2 * 16 * 64 * 4;

@@ -1,8 +1,8 @@
 """The product path has three arithmetic configurations (chosen at model creation from the
 environment): default = split-f16 GEMMs and recurrences, PA_SPLIT_REC=0 = split GEMMs around the f32
 recurrent kernels (with the in-place f32 -> h2 conversion passes), PA_SPLIT_GEMM=0 = everything on
-v_mfma_f32_32x32x2_f32; PA_SMALL_BATCH=0 = the fused decoder also for small calls (the default takes the GEMM + Xp decoder
-below 3073 windows).  All must meet the same 1e-4 bar against the reference golden vectors
+v_mfma_f32_32x32x2_f32; PA_SMALL_BATCH=0 / PA_SMALL_ROWS=0 = the big-call schedule also for small calls (the default takes the GEMM + Xp
+decoder below 3073 windows and 32-row workgroups below 2049).  All must meet the same 1e-4 bar against the reference golden vectors
 and agree with each other far inside it."""
 import os
 
@@ -15,12 +15,12 @@ from pepper_amd import synthetic
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-MODES = [{}, {"PA_SPLIT_REC": "0"}, {"PA_SPLIT_GEMM": "0"}, {"PA_SMALL_BATCH": "0"}]
+MODES = [{}, {"PA_SPLIT_REC": "0"}, {"PA_SPLIT_GEMM": "0"}, {"PA_SMALL_BATCH": "0", "PA_SMALL_ROWS": "0"}, {"PA_SMALL_ROWS": "0"}]
 
 
 @pytest.fixture()
 def env_guard():
-    saved = {k: os.environ.get(k) for k in ("PA_SPLIT_REC", "PA_SPLIT_GEMM", "PA_SMALL_BATCH")}
+    saved = {k: os.environ.get(k) for k in ("PA_SPLIT_REC", "PA_SPLIT_GEMM", "PA_SMALL_BATCH", "PA_SMALL_ROWS")}
     yield
     for k, v in saved.items():
         if v is None:
@@ -30,7 +30,7 @@ def env_guard():
 
 
 def _set(mode):
-    for k in ("PA_SPLIT_REC", "PA_SPLIT_GEMM", "PA_SMALL_BATCH"):
+    for k in ("PA_SPLIT_REC", "PA_SPLIT_GEMM", "PA_SMALL_BATCH", "PA_SMALL_ROWS"):
         os.environ.pop(k, None)
     os.environ.update(mode)
 
@@ -53,7 +53,7 @@ def test_variant_modes(golden_dir, env_guard):
         assert np.abs(big - ref).max() < TOL, mode
         outs.append(big)
     assert np.abs(outs[0] - outs[2]).max() < 2e-5 and np.abs(outs[1] - outs[2]).max() < 2e-5
-    assert np.abs(outs[3] - outs[2]).max() < 2e-5
+    assert np.abs(outs[3] - outs[2]).max() < 2e-5 and np.abs(outs[4] - outs[2]).max() < 2e-5
 
 
 def test_polish_modes(golden_dir, env_guard):

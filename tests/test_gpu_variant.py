@@ -15,21 +15,24 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(autouse=True, params=["fused", "small-batch"])
+@pytest.fixture(autouse=True, params=["big-call", "small-call"])
 def schedule(request):
-    """Every test of this file under both decoder schedules: calls of at most 3072 windows take the GEMM + Xp decoder
-    (api.hip `small_batch`), larger ones the decoder with the projection inside its step loop; PA_SMALL_BATCH=0 (read at
-    model creation) gives the latter to the small calls the parity tests make."""
-    saved = os.environ.get("PA_SMALL_BATCH")
-    if request.param == "fused":
-        os.environ["PA_SMALL_BATCH"] = "0"
-    else:
-        os.environ.pop("PA_SMALL_BATCH", None)
+    """Every test of this file under both schedules: calls of at most 3072 windows take the GEMM + Xp decoder and, up to
+    2048 windows, 32-row workgroups in both step loops (api.hip `small_batch`, `small_rows`); larger ones the decoder with
+    the projection inside its step loop and 64-row workgroups.  PA_SMALL_BATCH=0 PA_SMALL_ROWS=0 (read at model creation)
+    give the latter to the small calls the parity tests make."""
+    saved = {k: os.environ.get(k) for k in ("PA_SMALL_BATCH", "PA_SMALL_ROWS")}
+    for k in saved:
+        if request.param == "big-call":
+            os.environ[k] = "0"
+        else:
+            os.environ.pop(k, None)
     yield request.param
-    if saved is None:
-        os.environ.pop("PA_SMALL_BATCH", None)
-    else:
-        os.environ["PA_SMALL_BATCH"] = saved
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 class NativeVariant:

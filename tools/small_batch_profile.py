@@ -1,5 +1,5 @@
 """Per-kernel times of the variant forward at the reference's DataLoader batch (512 windows) and around it, device-resident.
-python tools/small_batch_profile.py"""
+python tools/small_batch_profile.py [sizes, comma-separated]"""
 import ctypes
 import json
 import os
@@ -22,9 +22,10 @@ def main():
     names, data, numel, n, keep = _lib.marshal_state_dict(sd)
     h = ctypes.c_void_p()
     _lib.check(lib.pa_variant_create(ctypes.byref(cfg), names, data, numel, n, None, ctypes.byref(h)))
-    pool = synthetic.variant_windows_device(4096, device=dev)
+    sizes = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [128, 512, 1024, 2048, 4096]
+    pool = synthetic.variant_windows_device(max(sizes), device=dev)
     out = {}
-    for b in (128, 512, 1024, 2048, 4096):
+    for b in sizes:
         probs = torch.empty((b, 3), dtype=torch.float32, device=dev)
         for _ in range(5):
             _lib.check(lib.pa_variant_forward_device(h, pool.data_ptr(), b, probs.data_ptr(), None))
