@@ -276,11 +276,13 @@ ALGORITHMIC_BYTES_PER_UNIT = {
 
 
 def measured_traffic(model_kind, label):
-    """HBM bytes per launch of `label` from the committed PMC passes (profiles/r02_<model>_pmc.json, written by
+    """HBM bytes per launch of `label` from the committed PMC passes (profiles/r03_<model>_pmc.json, else r02_...; written by
     tools/pmc_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this file with --resident-only):
     FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16-byte-per-lane streaming reads, WRITE_SIZE as
     reported.  None where no pass is on file."""
-    path = os.path.join(REPO, "profiles", f"r02_{model_kind}_pmc.json")
+    path = os.path.join(REPO, "profiles", f"r03_{model_kind}_pmc.json")
+    if not os.path.exists(path):
+        path = os.path.join(REPO, "profiles", f"r02_{model_kind}_pmc.json")
     try:
         with open(path) as fh:
             table = json.load(fh)

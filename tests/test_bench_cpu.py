@@ -25,13 +25,15 @@ def test_help_and_contract_flags():
 def test_traffic_comes_from_the_committed_pmc_passes():
     b = _bench()
     t = b.measured_traffic("variant", "lstm_dec_h2_fused")
-    assert t is not None and t["source"] == os.path.join("profiles", "r02_variant_pmc.json")
+    assert t is not None and t["source"] == os.path.join("profiles", "r03_variant_pmc.json")      # this round's passes
     table = json.load(open(os.path.join(REPO, t["source"])))["kernels"]["lstm_dec_h2_fused"]
     assert t["bytes_per_launch"] == table["fetch_bytes_corrected"] + table["write_bytes"]
     # the decoder reads the encoder's output once and writes its own once: measured traffic within 10 % of that
     algorithmic = b.ALGORITHMIC_BYTES_PER_UNIT["lstm_dec_h2_fused"] * table["units_per_launch"]
     assert 0.95 * algorithmic < t["bytes_per_launch"] < 1.10 * algorithmic
     assert b.measured_traffic("variant", "no_such_kernel") is None
+    e = b.encoder_traffic()                                  # the encoder line's traffic: this round's tile_count_kernel passes
+    assert e is not None and e["source"] == os.path.join("profiles", "r03_encoder_variant_pmc.json") and e["bytes_per_launch"] > 1e9
     for label in ("lstm_rec_h2_fused_in", "lstm_dec_h2_fused", "gemm_h2_linear_1", "gru_dec_h2_fused_dense", "gru_rec_h2_fused_in"):
         assert label in b.ALGORITHMIC_BYTES_PER_UNIT
 
