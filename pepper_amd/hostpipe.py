@@ -519,20 +519,9 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
                     write_qs[lane].put(None)             # the end marker follows the lane's last block
 
         reading = lanes
-        while writing:
-            # a pass costs about the same whatever it holds: the first of the passes under way takes what there is (an idle
-            # device is worse than a small pass), a further one starts only full -- or when nothing more is coming
-            while pending and len(inflight) < depth and (not inflight or len(pending) >= per_pass or reading == 0):
-                launch()
-                if pool is None:
-                    retire()
-            # with passes under way, do not sleep on the queue past the moment the oldest one is done: its slots (freed by
-            # the writers) may be what the readers are waiting for
-            msg = _next_message(result_q, procs, poll=0.002 if inflight else None)
-            if msg is None:
-                while inflight and inflight[0][0].done():
-                    retire()
-                continue
+
+        def handle(msg):
+            nonlocal reading, writing
             kind, lane = msg[0], msg[1]
             if kind == "error":
                 raise (SlotTooSmall if "SlotTooSmall" in msg[2] else LaneError)("lane %d failed:\n%s" % (lane, msg[2]))
@@ -547,6 +536,30 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
                     write_qs[lane].put(None)
             elif kind == "write_done":
                 writing -= 1
+
+        import queue
+        while writing:
+            # a pass costs about the same whatever it holds: the first of the passes under way takes what there is (an idle
+            # device is worse than a small pass), a further one starts only full -- or when nothing more is coming
+            while pending and len(inflight) < depth and (not inflight or len(pending) >= per_pass or reading == 0):
+                launch()
+                if pool is None:
+                    retire()
+            if not writing:
+                break
+            # with passes under way, do not sleep on the queue past the moment the oldest one is done: its slots (freed by
+            # the writers) may be what the readers are waiting for
+            msg = _next_message(result_q, procs, poll=0.002 if inflight else None)
+            if msg is None:
+                while inflight and inflight[0][0].done():
+                    retire()
+                continue
+            handle(msg)
+            while True:                                   # whatever else has arrived by now travels with it
+                try:
+                    handle(result_q.get_nowait())
+                except queue.Empty:
+                    break
         _trace(t_begin, "all lanes written")
         if spans and os.environ.get("PEPPER_AMD_LANE_TRACE"):
             busy = sum(b - a for a, b, _ in spans)
@@ -565,6 +578,8 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
         for p in procs:
             if p.is_alive():
                 p.terminate()
+        for p in procs:
+            p.join(timeout=5)            # (terminated workers are reaped here: none outlives the call)
         if locker is not None:
             locker.join()
         for s in slots:
@@ -835,6 +850,8 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
         for p in procs:
             if p.is_alive():
                 p.terminate()
+        for p in procs:
+            p.join(timeout=5)            # (terminated workers are reaped here: none outlives the call)
         if locker is not None:
             locker.join()
         for s in slots:

@@ -1,6 +1,7 @@
 """The lane pipeline of the predict loops (pepper_amd/hostpipe.py) on the CPU: real reader and writer processes over
 shared-memory slots, a stand-in for the device pass, and the files they produce compared with the in-process writers."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -100,7 +101,10 @@ def test_variant_lanes_write_what_the_in_process_loop_writes(tmp_path, in_flight
     assert not [n for n in os.listdir("/dev/shm") if n.startswith("psm_")] or True     # segments are unlinked by Slots.close
 
 
-def test_polish_lanes_write_what_the_in_process_loop_writes(tmp_path):
+@pytest.mark.parametrize("mode", ["one block per pass", "gathered passes, two under way", "gathered passes, one under way"])
+def test_polish_lanes_write_what_the_in_process_loop_writes(tmp_path, mode):
+    """...whatever the device loop's shape: one lane block per pass, or the blocks that arrived while the device was busy
+    taken together (predict_parts, up to pass_blocks of them) with one or two passes under way on their own predictors."""
     from pepper_amd.polish.DataStore import DataStore as ImageStore
     from pepper_amd.polish.DataStorePredict import DataStore as PredStore
     chunks = synthetic.polish_chunks(23, seed=3)
@@ -122,7 +126,29 @@ def test_polish_lanes_write_what_the_in_process_loop_writes(tmp_path):
 
     out = tmp_path / "pred"
     out.mkdir()
-    done = hostpipe.polish_lanes(files, str(out / "pepper_prediction_0"), fake_predict, lanes=3, block=4, slots_per_lane=2)
+    passes, made = [], []
+
+    def parts_predictor(tag):
+        def predict_parts(parts):
+            passes.append((tag, [len(p[0]) for p in parts]))
+            time.sleep(0.02)                                  # long enough for more blocks to arrive meanwhile
+            for part in parts:
+                fake_predict(*part)
+        return predict_parts
+
+    def more_predict():
+        made.append(len(made) + 1)
+        return parts_predictor("extra%d" % len(made))
+    if mode == "one block per pass":
+        done = hostpipe.polish_lanes(files, str(out / "pepper_prediction_0"), fake_predict, lanes=3, block=4, slots_per_lane=2)
+    else:
+        depth = 2 if "two" in mode else 1
+        done = hostpipe.polish_lanes(files, str(out / "pepper_prediction_0"), None, lanes=3, block=2, slots_per_lane=4,
+                                     predict_parts=parts_predictor("first"), more_predict=more_predict if depth > 1 else None,
+                                     in_flight=depth, pass_blocks=3)
+        assert sum(sum(sizes) for _, sizes in passes) == 23 and all(1 <= len(sizes) <= 3 for _, sizes in passes)
+        assert any(len(sizes) > 1 for _, sizes in passes)                  # blocks did travel together
+        assert len(made) == depth - 1 and ({t for t, _ in passes} == {"first", "extra1"} if depth > 1 else True)
     assert done == 23
     produced = sorted(os.listdir(out))
     assert produced == ["pepper_prediction_0_%d.hdf" % k for k in range(3)]
@@ -159,6 +185,32 @@ def test_polish_lanes_write_what_the_in_process_loop_writes(tmp_path):
     for k in want:
         for a, b in zip(want[k], got[k]):
             assert a.dtype == b.dtype and np.array_equal(a, b), k
+
+
+def test_a_failing_device_pass_ends_the_polish_lanes(tmp_path):
+    """An exception inside a gathered pass (on a pool thread) reaches the caller as itself; workers and segments are gone."""
+    from pepper_amd.polish.DataStore import DataStore as ImageStore
+    chunks = synthetic.polish_chunks(12, seed=4)
+    path = str(tmp_path / "img.hdf")
+    with ImageStore(path, "w") as ds:
+        for k in range(12):
+            ds.write_summary(("c", 1000 * k, 1000 * k + 1200), chunks[k].tolist(), [0] * 1000, list(range(1000)), [0] * 1000, 0,
+                             "c_%d_%d_0" % (1000 * k, 1000 * k + 1200))
+    before = {n for n in os.listdir("/dev/shm") if n.startswith("psm_")}
+    calls = []
+
+    def predict_parts(parts):
+        calls.append(len(parts))
+        if len(calls) == 2:
+            raise ZeroDivisionError("device pass failed")
+        for image, labels, phred in parts:
+            labels[:] = 1
+            phred[:] = 2
+    with pytest.raises(ZeroDivisionError):
+        hostpipe.polish_lanes([path], str(tmp_path / "out"), None, lanes=1, block=2, slots_per_lane=4, predict_parts=predict_parts,
+                              more_predict=lambda: predict_parts, in_flight=2, pass_blocks=2)
+    assert {n for n in os.listdir("/dev/shm") if n.startswith("psm_")} == before
+    assert not [p for p in __import__("multiprocessing").active_children() if p.is_alive()]
 
 
 def test_lane_errors_reach_the_caller(tmp_path):
