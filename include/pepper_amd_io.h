@@ -152,6 +152,15 @@ int pa_h5_builder_write_polish_predictions(pa_h5_builder* b, int32_t n, int32_t 
 /* One integer dataset at `path` (intermediate groups are made as needed), as pa_h5_write; data of at most 64 bytes is kept
  * in the object header (compact layout). */
 int pa_h5_builder_write(pa_h5_builder* b, const char* path, int32_t type_code, int32_t rank, const int64_t* dims, const void* data);
+/* A variable-length UTF-8 string scalar, as h5py writes a Python str (global heap object; equal strings share one). */
+int pa_h5_builder_write_string(pa_h5_builder* b, const char* path, const char* text);
+/* The polish image chunks of one region, as pa_h5_write_polish_image_chunks (pepper DataStore.py:53-67): summaries/<name>/
+ * {image u8 [seq, features], label u8 [seq], position, index int64 [seq], contig (string), region_start, region_end,
+ * chunk_id int64 scalars}.  No libhdf5 and so no process-wide lock: the image-generation threads each write their own file. */
+int pa_h5_builder_write_polish_image_chunks(pa_h5_builder* b, const char* names, int32_t n, int32_t seq_len, int32_t features,
+                                            const char* contig, int64_t region_start, int64_t region_end, const int64_t* chunk_id,
+                                            const uint8_t* images, const uint8_t* labels, const int64_t* position,
+                                            const int64_t* index);
 int pa_h5_builder_close(pa_h5_builder* b);
 
 /* How the polish chunks of this handle were read so far: `direct_chunks` had their image / position / index bytes copied

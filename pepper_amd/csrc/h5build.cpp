@@ -24,6 +24,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 extern "C" const char* pa_h5_last_error(void);
@@ -50,6 +51,14 @@ struct Obj {
     uint64_t dims[4] = {0, 0, 0, 0};
     uint64_t bytes = 0, addr = 0;                             // raw data: size; file address (contiguous layout)
     std::string small;                                        // the data itself when it is at most 64 bytes (compact layout)
+    bool vlen = false;                                        // a variable-length UTF-8 string scalar: (collection, object) below
+    uint32_t heap_collection = 0, heap_object = 0, heap_length = 0;
+};
+
+struct HeapCollection {                                       // a global heap collection being filled (GCOL, spec III.E)
+    std::vector<std::string> objects;                         // object k + 1 of the collection
+    uint64_t used = 16;                                       // header + objects (16-byte object headers, data padded to 8)
+    uint64_t addr = 0;                                        // assigned at close
 };
 
 void put16(std::vector<uint8_t>& b, uint64_t at, uint16_t v) { std::memcpy(&b[at], &v, 2); }
@@ -66,6 +75,36 @@ struct pa_h5_builder {
     std::vector<Obj> objs;                                    // objs[0] = root group
     std::unordered_map<std::string, uint32_t> by_path;        // groups below the root, "predictions/<contig>[/<region>]"
     bool failed = false;
+    std::vector<HeapCollection> heaps;                        // variable-length strings: one object per distinct string
+    std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> heap_of;
+
+    // (collection, object index) of a string in the global heap; equal strings share one object (h5py writes one object per
+    // dataset with reference count 0; readers only ever dereference)
+    std::pair<uint32_t, uint32_t> heap_object(const std::string& text) {
+        auto it = heap_of.find(text);
+        if (it != heap_of.end()) return it->second;
+        const uint64_t need = 16 + (text.size() + 7) / 8 * 8;
+        if (heaps.empty() || heaps.back().used + need + 16 > 4096 || heaps.back().objects.size() >= 65000) heaps.emplace_back();
+        HeapCollection& h = heaps.back();
+        h.objects.push_back(text);
+        h.used += need;
+        const std::pair<uint32_t, uint32_t> at((uint32_t)heaps.size() - 1, (uint32_t)h.objects.size());
+        heap_of.emplace(text, at);
+        return at;
+    }
+
+    void vlen_string(uint32_t g, const std::string& name, const std::string& text) {
+        Obj d;
+        d.name = name;
+        d.vlen = true;
+        d.elem = 16;
+        d.bytes = 16;
+        const auto at = heap_object(text);
+        d.heap_collection = at.first;
+        d.heap_object = at.second;
+        d.heap_length = (uint32_t)text.size();
+        add(g, std::move(d));
+    }
 
     int flush() {
         size_t done = 0;
@@ -115,6 +154,9 @@ struct pa_h5_builder {
         return id;
     }
 
+    std::unordered_set<std::string> kid_names;                // names under "summaries" (a group of very many: no linear search)
+    bool has_kid_indexed(uint32_t, const std::string& name) const { return kid_names.count(name) != 0; }
+
     bool has_kid(uint32_t g, const std::string& name) const {
         for (uint32_t k : objs[g].kids)
             if (objs[k].name == name) return true;
@@ -161,7 +203,7 @@ struct pa_h5_builder {
 
     uint64_t dataset_header(const Obj& d) {
         const bool compact = d.addr == 0;
-        const uint16_t space = (uint16_t)(8 + 8 * d.rank), dtype = 16, fill = 8;
+        const uint16_t space = (uint16_t)(8 + 8 * d.rank), dtype = d.vlen ? 24 : 16, fill = 8;
         const uint16_t layout = compact ? (uint16_t)((4 + d.bytes + 7) / 8 * 8) : 24;
         const uint32_t body = 4 * 8 + space + dtype + fill + layout;
         const uint64_t h = reserve(16 + body);
@@ -175,12 +217,19 @@ struct pa_h5_builder {
         meta[at + 1] = d.rank;
         for (int k = 0; k < d.rank; ++k) put64(meta, at + 8 + 8 * k, d.dims[k]);
         at += space;
-        message(at, 0x0003, dtype);                           // datatype v1, class 0 (fixed point), little-endian
-        meta[at] = 0x10;
-        meta[at + 1] = d.is_signed ? 0x08 : 0x00;
-        put32(meta, at + 4, d.elem);
-        put16(meta, at + 8, 0);                               // bit offset
-        put16(meta, at + 10, (uint16_t)(8 * d.elem));         // precision
+        message(at, 0x0003, dtype);
+        if (d.vlen) {
+            // class 9 (variable length) v1: a string, NUL-terminated, UTF-8; 16 bytes in the file (length, collection address,
+            // object index); base type = one-byte integer -- the bytes h5py writes for a Python str
+            static const uint8_t vl[20] = {0x19, 0x01, 0x01, 0x00, 16, 0, 0, 0, 0x10, 0, 0, 0, 1, 0, 0, 0, 0, 0, 8, 0};
+            std::memcpy(&meta[at], vl, sizeof vl);
+        } else {
+            meta[at] = 0x10;                                  // datatype v1, class 0 (fixed point), little-endian
+            meta[at + 1] = d.is_signed ? 0x08 : 0x00;
+            put32(meta, at + 4, d.elem);
+            put16(meta, at + 8, 0);                           // bit offset
+            put16(meta, at + 10, (uint16_t)(8 * d.elem));     // precision
+        }
         at += dtype;
         message(at, 0x0005, fill);                            // fill value v2: allocation early (compact) / late, written if set,
         meta[at] = 2;                                         //   defined with size 0 = the library default
@@ -190,7 +239,13 @@ struct pa_h5_builder {
         at += fill;
         message(at, 0x0008, layout);                          // layout v3
         meta[at] = 3;
-        if (compact) {
+        if (d.vlen) {
+            meta[at + 1] = 0;                                 // compact: the 16-byte reference into the global heap
+            put16(meta, at + 2, 16);
+            put32(meta, at + 4, d.heap_length);
+            put64(meta, at + 8, heaps[d.heap_collection].addr);
+            put32(meta, at + 16, d.heap_object);
+        } else if (compact) {
             meta[at + 1] = 0;                                 // compact: size, data
             put16(meta, at + 2, (uint16_t)d.bytes);
             if (d.bytes) std::memcpy(&meta[at + 4], d.small.data(), (size_t)d.bytes);
@@ -200,6 +255,27 @@ struct pa_h5_builder {
             put64(meta, at + 10, d.bytes);
         }
         return base + h;
+    }
+
+    // the global heap collections: "GCOL", version 1, size; objects {index u16, references u16, 4 reserved, size u64, data
+    // padded to 8}; what is left belongs to object 0, whose size counts its own header (at least 4096 bytes per collection)
+    void heap_collections() {
+        for (HeapCollection& hc : heaps) {
+            const uint64_t size = hc.used + 16 > 4096 ? hc.used + 16 : 4096;
+            const uint64_t g = reserve(size);
+            hc.addr = base + g;
+            std::memcpy(&meta[g], "GCOL", 4);
+            meta[g + 4] = 1;
+            put64(meta, g + 8, size);
+            uint64_t at = g + 16;
+            for (size_t k = 0; k < hc.objects.size(); ++k) {
+                put16(meta, at, (uint16_t)(k + 1));
+                put64(meta, at + 8, hc.objects[k].size());
+                std::memcpy(&meta[at + 16], hc.objects[k].data(), hc.objects[k].size());
+                at += 16 + (hc.objects[k].size() + 7) / 8 * 8;
+            }
+            put64(meta, at + 8, g + size - at);               // object 0: the free space
+        }
     }
 
     // -> address of the group's object header; *tree / *heap receive what the superblock's root entry caches
@@ -294,6 +370,7 @@ struct pa_h5_builder {
         pos += pad;
         if (int rc = flush()) return rc;
         base = pos;
+        heap_collections();
         uint64_t tree = 0, heap = 0;
         const uint64_t root = group_header(0, &tree, &heap);
         out.swap(meta);
@@ -412,6 +489,52 @@ int pa_h5_builder_write(pa_h5_builder* b, const char* path, int32_t type_code, i
     if (count > 0 && !data) return fail("null data");
     b->dataset(g, name, elem, is_signed, rank, d, data);
     if (b->out.size() >= (4u << 20)) return b->flush();
+    return 0;
+}
+
+int pa_h5_builder_write_string(pa_h5_builder* b, const char* path, const char* text) {
+    if (!b || !path || !text) return fail("bad argument");
+    std::string full(path);
+    while (!full.empty() && full[0] == '/') full.erase(0, 1);
+    const size_t cut = full.rfind('/');
+    const std::string name = cut == std::string::npos ? full : full.substr(cut + 1);
+    if (name.empty()) return fail(std::string("bad dataset path '") + path + "'");
+    const uint32_t g = cut == std::string::npos ? 0 : b->group(full.substr(0, cut));
+    if (b->has_kid(g, name)) return fail(std::string("cannot create dataset '") + path + "' (already exists)");
+    b->vlen_string(g, name, text);
+    return 0;
+}
+
+int pa_h5_builder_write_polish_image_chunks(pa_h5_builder* b, const char* names, int32_t n, int32_t seq_len, int32_t features,
+                                            const char* contig, int64_t region_start, int64_t region_end, const int64_t* chunk_id,
+                                            const uint8_t* images, const uint8_t* labels, const int64_t* position,
+                                            const int64_t* index) {
+    if (!b || n < 0 || seq_len <= 0 || features <= 0 || !contig ||
+        (n > 0 && (!names || !chunk_id || !images || !labels || !position || !index)))
+        return fail("bad argument");
+    if (b->failed) return fail("the file has a failed write behind it");
+    const uint32_t summaries = b->group("summaries");
+    const uint64_t d2[2] = {(uint64_t)seq_len, (uint64_t)features}, d1[1] = {(uint64_t)seq_len};
+    const char* name = names;
+    for (int32_t i = 0; i < n; ++i, name += strlen(name) + 1) {
+        if (!*name || std::strchr(name, '/')) return fail(std::string("bad chunk name '") + name + "'");
+        if (b->has_kid_indexed(summaries, name)) return fail(std::string("cannot create group 'summaries/") + name + "' (already exists?)");
+        Obj g;
+        g.name = name;
+        g.group = true;
+        const uint32_t id = b->add(summaries, std::move(g));
+        b->kid_names.emplace(std::string(name));
+        b->dataset(id, "image", 1, false, 2, d2, images + (size_t)i * seq_len * features);
+        b->dataset(id, "label", 1, false, 1, d1, labels + (size_t)i * seq_len);
+        b->dataset(id, "position", 8, true, 1, d1, position + (size_t)i * seq_len);
+        b->dataset(id, "index", 8, true, 1, d1, index + (size_t)i * seq_len);
+        b->vlen_string(id, "contig", contig);
+        b->scalar(id, "region_start", region_start);
+        b->scalar(id, "region_end", region_end);
+        b->scalar(id, "chunk_id", chunk_id[i]);
+        if (b->out.size() >= (4u << 20))
+            if (int rc = b->flush()) return rc;
+    }
     return 0;
 }
 

@@ -52,6 +52,9 @@ SYMBOLS = [
     ("pa_h5_builder_open", ctypes.c_int, [c_char_p, ctypes.POINTER(c_void_p)]),
     ("pa_h5_builder_write_polish_predictions", ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 9),
     ("pa_h5_builder_write", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, P64, c_void_p]),
+    ("pa_h5_builder_write_string", ctypes.c_int, [c_void_p, c_char_p, c_char_p]),
+    ("pa_h5_builder_write_polish_image_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32, c_char_p, c_int64, c_int64] +
+                                                               [c_void_p] * 5),
     ("pa_h5_builder_close", ctypes.c_int, [c_void_p]),
     ("pa_h5_write_prediction_batch", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
@@ -118,8 +121,9 @@ def stitch_polish_regions(files, file_of_region, region_paths, region_starts, bu
 
 
 class PredictionBuilder(object):
-    """Append-only writer of a polish prediction file (pa_h5_builder_*, pepper_amd/csrc/h5build.cpp): raw rows go to the file as
-    they come, the HDF5 metadata is written by close().  No libhdf5 involved, so no lock either."""
+    """Append-only writer of the polish stores -- prediction files and image files -- (pa_h5_builder_*,
+    pepper_amd/csrc/h5build.cpp): raw rows go to the file as they come, the HDF5 metadata is written by close().  No libhdf5
+    involved, so no lock either."""
 
     def __init__(self, path):
         self._lib = load()
@@ -134,8 +138,19 @@ class PredictionBuilder(object):
             chunk.ctypes.data, new_region.ctypes.data, skip.ctypes.data, position.ctypes.data, index.ctypes.data,
             bases.ctypes.data, phred.ctypes.data))
 
+    def write_polish_image_chunks(self, names, contig, region_start, region_end, chunk_id, images, labels, position, index):
+        n, seq_len, features = images.shape
+        blob = b"".join(s.encode() + b"\0" for s in names)
+        _check(self._lib.pa_h5_builder_write_polish_image_chunks(
+            self._h, blob, n, seq_len, features, contig.encode(), int(region_start), int(region_end), chunk_id.ctypes.data,
+            images.ctypes.data, labels.ctypes.data, position.ctypes.data, index.ctypes.data))
+
     def __setitem__(self, path, value):
-        """An integer dataset like h5py's file[path] = value (intermediate groups are made as needed)."""
+        """An integer dataset, or a str as a variable-length string scalar, like h5py's file[path] = value (intermediate
+        groups are made as needed)."""
+        if isinstance(value, str):
+            _check(self._lib.pa_h5_builder_write_string(self._h, path.encode(), value.encode("utf-8")))
+            return
         arr = np.asarray(value)
         shape = arr.shape                     # np.ascontiguousarray would promote 0-d to 1-d
         arr = np.ascontiguousarray(arr).reshape(shape)

@@ -1,6 +1,8 @@
 """Polish images HDF5 store.  Mirrors /root/reference/pepper/modules/python/DataStore.py:6-67:
 summaries/<name>/{image u8 [1000,10], label u8 [1000], position, index, contig, region_start,
 region_end, chunk_id} (position = list of (pos, idx) pairs -> int64 [1000,2] through h5py)."""
+import os
+
 import numpy as np
 
 from pepper_amd import h5
@@ -16,7 +18,12 @@ class DataStore(object):
         self._written = set()
 
     def __enter__(self):
-        self.file_handler = h5.File(self.filename, self.mode)
+        # 'w' -> the append-only builder (h5.PredictionBuilder, csrc/h5build.cpp): no libhdf5 and so no process-wide lock under
+        # the image-generation threads, each of which writes its own file; PEPPER_AMD_H5_BUILDER=0: through libhdf5
+        if self.mode == "w" and os.environ.get("PEPPER_AMD_H5_BUILDER", "1") != "0":
+            self.file_handler = h5.PredictionBuilder(self.filename)
+        else:
+            self.file_handler = h5.File(self.filename, self.mode)
         return self
 
     def __exit__(self, *args):

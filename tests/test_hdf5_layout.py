@@ -447,3 +447,48 @@ def test_h5py_reads_the_builder_file(tmp_path):
               "print('fine')\n")
     r = subprocess.run(["/opt/conda/bin/python3.9", "-c", script, path, str(tmp_path / "want.npz")], capture_output=True, text=True)
     assert r.returncode == 0 and "fine" in r.stdout, r.stderr[-3000:]
+
+
+def test_builder_image_files_equal_the_library_files(tmp_path, monkeypatch):
+    """Polish image files laid out by h5build.cpp (variable-length contig strings in a global heap collection, three scalars
+    and four arrays per chunk) against the files libhdf5 writes from the same calls: the same tree for libhdf5, no difference
+    for h5diff, the same blocks for the chunk reader (which takes the large datasets straight from the mapped file and the
+    first and last chunk's small ones -- the strings included -- through libhdf5), the same str for h5py."""
+    from pepper_amd import synthetic
+    from pepper_amd.polish.DataStore import DataStore
+    from pepper_amd.polish.models.dataloader_predict import SequenceDataset
+    n = 700                                                   # > 126 distinct contig strings: several heap collections
+    chunks = synthetic.polish_chunks(8, seed=2)
+    paths = {}
+    for builder in (True, False):
+        monkeypatch.setenv("PEPPER_AMD_H5_BUILDER", "1" if builder else "0")
+        path = paths[builder] = str(tmp_path / ("img_%d.hdf" % builder))
+        with DataStore(path, "w") as ds:
+            assert isinstance(ds.file_handler, h5.PredictionBuilder) == builder
+            for r in range(n // 2):
+                contig = "contig_%d_with_a_longer_name" % (r % 300)
+                region = (contig, r * 1000, r * 1000 + 1200)
+                pos = np.stack([np.stack([np.arange(1000) + region[1] + 950 * c, np.arange(1000) % 3], axis=1) for c in range(2)])
+                ds.write_summaries(region, chunks[(2 * r) % 8:(2 * r) % 8 + 2], np.zeros((2, 1000), np.uint8), pos, [0, 1])
+            ds.write_summary(("häßlich", 5, 6), chunks[0].tolist(), [0] * 1000, [(i, 0) for i in range(1000)], list(range(1000)), 7, "x_5_6_7")
+    assert_same_tree(dump(paths[True]), dump(paths[False]))
+    if os.path.exists("/opt/conda/bin/h5diff"):
+        r = subprocess.run(["/opt/conda/bin/h5diff", paths[False], paths[True]], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    blocks = {}
+    for builder, path in paths.items():
+        with h5.File(path) as f:
+            names = [k for k in f.keys("summaries") if k != "x_5_6_7"]
+            blocks[builder] = f.read_polish_chunks(names, 1000, 10)
+            assert f.read_stats() == (len(names), 0)
+    for a, b in zip(blocks[True], blocks[False]):
+        assert np.array_equal(a, b)
+    assert blocks[True][0][0].decode().startswith("contig_") and len(blocks[True][0]) == n
+    if os.path.exists("/opt/conda/bin/python3.9"):
+        script = ("import h5py, sys\nf = h5py.File(sys.argv[1], 'r')\ng = f['summaries/x_5_6_7']\n"
+                  "c = g['contig'][()]\nc = c.decode('utf-8') if isinstance(c, bytes) else c\n"
+                  "assert c == 'h\\u00e4\\u00dflich', repr(c)\nassert g['position'].shape == (1000, 2) and g['chunk_id'][()] == 7\n"
+                  "assert h5py.check_string_dtype(g['contig'].dtype).encoding == 'utf-8'\n"
+                  "k = sorted(f['summaries'])[3]\nassert f['summaries'][k]['image'].shape == (1000, 10)\nprint('fine')\n")
+        r = subprocess.run(["/opt/conda/bin/python3.9", "-c", script, paths[True]], capture_output=True, text=True)
+        assert r.returncode == 0 and "fine" in r.stdout, r.stderr[-3000:]
