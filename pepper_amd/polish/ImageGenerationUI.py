@@ -51,7 +51,8 @@ class UserInterfaceView:
 
 
 class UserInterfaceSupport:
-    REGIONS_PER_CALL = 8          # intervals whose reads share one re-alignment call on the GPU
+    # intervals whose reads share one re-alignment call on the GPU (PEPPER_AMD_POLISH_REGIONS_PER_CALL)
+    REGIONS_PER_CALL = int(os.environ.get("PEPPER_AMD_POLISH_REGIONS_PER_CALL", 32))
 
     @staticmethod
     def handle_output_directory(output_directory):
