@@ -5,6 +5,8 @@ Mirrors /root/reference/pepper/modules/python/AlignmentSummarizer.py:18-56 (chun
 chunking) and :159-177 (reads_to_reference_realignment: every read re-aligned to the draft before it is
 summarised, on by default; the alignments run on the GPU, include/pepper_amd_realign.h).
 """
+import os
+
 import numpy as np
 
 from pepper_amd.polish import PEPPER
@@ -14,7 +16,8 @@ from pepper_amd.polish.Options import ImageSizeOptions
 class AlingerOptions(object):
     ALIGNMENT_SAFE_BASES = 20      # pepper Options.py:23-29
     MAX_READS_IN_REGION = 1500
-    MAX_READS_PER_CALL = 3000      # reads of consecutive regions handed to the GPU re-aligner together
+    # reads of consecutive regions handed to the GPU re-aligner together (PEPPER_AMD_POLISH_READS_PER_CALL)
+    MAX_READS_PER_CALL = int(os.environ.get("PEPPER_AMD_POLISH_READS_PER_CALL", 3000))
     RANDOM_SEED = 2719747673
 
 
