@@ -6,8 +6,10 @@
 // property lists, ids) -- with the reader side at ~10 us per chunk (hdf5io.cpp's direct locator) and the device at ~5 us per
 // chunk, the writer processes were what bounded call_consensus on the 16 CPUs a GPU box grants.  The file FORMAT, though, is
 // simple when nothing is ever modified: raw data can be appended as it arrives, and every piece of metadata (object headers,
-// local heaps, symbol nodes, group B-trees) written once, bottom-up, when the file is closed -- children before parents, so every
-// address is known when it is needed.  That is what this does: ~3 us per chunk plus the write() of its 18 KB.
+// local heaps, symbol nodes, group B-trees) written once, bottom-up -- children before parents, so every address is known when
+// it is needed.  A chunk group is complete the moment it is written, so its metadata follows its rows at once (`seal`) and
+// only its name and header address (~50-100 bytes) wait in memory for the B-tree of its parent, which close() lays out
+// together with everything still open.  ~3 us per chunk plus the write() of its 18 KB.
 //
 // What is written (HDF5 File Format Specification 2.0): superblock version 0 (8-byte offsets and lengths, group leaf K 4,
 // internal K 16), version-1 object headers, "old style" groups (symbol table message -> version-1 B-tree of symbol nodes +
@@ -24,7 +26,6 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
-#include <unordered_set>
 #include <vector>
 
 extern "C" const char* pa_h5_last_error(void);
@@ -42,10 +43,19 @@ constexpr int LEAF_K = 4, INTERNAL_K = 16;                    // superblock defa
 constexpr uint64_t SNOD_BYTES = 8 + 2 * LEAF_K * 40;
 constexpr uint64_t TREE_BYTES = 24 + (2 * INTERNAL_K + 1) * 8 + 2 * INTERNAL_K * 8;
 
+// A child whose metadata is already in the file (a chunk group is complete the moment it is written: its object headers,
+// heap, symbol node and B-tree node follow its rows at once): only its name and header address wait for the parent's B-tree.
+struct Link {
+    uint64_t header;
+    uint64_t name_at;                                         // into pa_h5_builder::names
+    uint32_t name_len;
+};
+
 struct Obj {
     std::string name;
     bool group = false;
     std::vector<uint32_t> kids;                               // group: indices into objs_
+    std::vector<Link> sealed;                                 // group: children already written out
     uint8_t elem = 0, rank = 0;                               // dataset: bytes per integer element, signedness, shape
     bool is_signed = false;
     uint64_t dims[4] = {0, 0, 0, 0};
@@ -58,8 +68,9 @@ struct Obj {
 struct HeapCollection {                                       // a global heap collection being filled (GCOL, spec III.E)
     std::vector<std::string> objects;                         // object k + 1 of the collection
     uint64_t used = 16;                                       // header + objects (16-byte object headers, data padded to 8)
-    uint64_t addr = 0;                                        // assigned at close
+    uint64_t addr = 0, size = 4096;                           // its place in the file, reserved when it is opened; written at close
 };
+
 
 void put16(std::vector<uint8_t>& b, uint64_t at, uint16_t v) { std::memcpy(&b[at], &v, 2); }
 void put32(std::vector<uint8_t>& b, uint64_t at, uint32_t v) { std::memcpy(&b[at], &v, 4); }
@@ -75,6 +86,7 @@ struct pa_h5_builder {
     std::vector<Obj> objs;                                    // objs[0] = root group
     std::unordered_map<std::string, uint32_t> by_path;        // groups below the root, "predictions/<contig>[/<region>]"
     bool failed = false;
+    std::vector<char> names;                                  // names of the sealed children, back to back
     std::vector<HeapCollection> heaps;                        // variable-length strings: one object per distinct string
     std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> heap_of;
 
@@ -84,7 +96,15 @@ struct pa_h5_builder {
         auto it = heap_of.find(text);
         if (it != heap_of.end()) return it->second;
         const uint64_t need = 16 + (text.size() + 7) / 8 * 8;
-        if (heaps.empty() || heaps.back().used + need + 16 > 4096 || heaps.back().objects.size() >= 65000) heaps.emplace_back();
+        if (heaps.empty() || heaps.back().used + need + 16 > heaps.back().size || heaps.back().objects.size() >= 65000) {
+            heaps.emplace_back();
+            HeapCollection& fresh = heaps.back();
+            if (16 + need + 16 > fresh.size) fresh.size = 16 + need + 16;
+            const uint64_t pad = (8 - pos % 8) % 8;           // its bytes are written by close(); sealed datasets refer to its
+            out.insert(out.end(), (size_t)(pad + fresh.size), 0);   // address from now on
+            fresh.addr = pos + pad;
+            pos += pad + fresh.size;
+        }
         HeapCollection& h = heaps.back();
         h.objects.push_back(text);
         h.used += need;
@@ -154,12 +174,13 @@ struct pa_h5_builder {
         return id;
     }
 
-    std::unordered_set<std::string> kid_names;                // names under "summaries" (a group of very many: no linear search)
-    bool has_kid_indexed(uint32_t, const std::string& name) const { return kid_names.count(name) != 0; }
-
+    // (linear: for the small groups only; a group of very many sealed children is checked when its B-tree is laid out)
     bool has_kid(uint32_t g, const std::string& name) const {
         for (uint32_t k : objs[g].kids)
             if (objs[k].name == name) return true;
+        if (objs[g].sealed.size() <= 64)
+            for (const Link& l : objs[g].sealed)
+                if (l.name_len == name.size() && std::memcmp(names.data() + l.name_at, name.data(), name.size()) == 0) return true;
         return false;
     }
 
@@ -188,6 +209,7 @@ struct pa_h5_builder {
     // ---- close: the metadata, children before parents, into `meta` (file address = base + offset) ----------------------
     std::vector<uint8_t> meta;
     uint64_t base = 0;
+    std::string duplicate;                                    // a name met twice in one group (seen when its B-tree is laid out)
 
     uint64_t reserve(uint64_t bytes) {                        // 8-byte aligned, zero-filled; -> offset into meta
         const uint64_t at = (meta.size() + 7) / 8 * 8;
@@ -259,46 +281,81 @@ struct pa_h5_builder {
 
     // the global heap collections: "GCOL", version 1, size; objects {index u16, references u16, 4 reserved, size u64, data
     // padded to 8}; what is left belongs to object 0, whose size counts its own header (at least 4096 bytes per collection)
-    void heap_collections() {
+    int heap_collections() {
+        std::vector<uint8_t> block;
         for (HeapCollection& hc : heaps) {
-            const uint64_t size = hc.used + 16 > 4096 ? hc.used + 16 : 4096;
-            const uint64_t g = reserve(size);
-            hc.addr = base + g;
-            std::memcpy(&meta[g], "GCOL", 4);
-            meta[g + 4] = 1;
-            put64(meta, g + 8, size);
-            uint64_t at = g + 16;
+            block.assign((size_t)hc.size, 0);
+            std::memcpy(&block[0], "GCOL", 4);
+            block[4] = 1;
+            put64(block, 8, hc.size);
+            uint64_t at = 16;
             for (size_t k = 0; k < hc.objects.size(); ++k) {
-                put16(meta, at, (uint16_t)(k + 1));
-                put64(meta, at + 8, hc.objects[k].size());
-                std::memcpy(&meta[at + 16], hc.objects[k].data(), hc.objects[k].size());
+                put16(block, at, (uint16_t)(k + 1));
+                put64(block, at + 8, hc.objects[k].size());
+                std::memcpy(&block[at + 16], hc.objects[k].data(), hc.objects[k].size());
                 at += 16 + (hc.objects[k].size() + 7) / 8 * 8;
             }
-            put64(meta, at + 8, g + size - at);               // object 0: the free space
+            put64(block, at + 8, hc.size - at);               // object 0: the free space
+            if (pwrite(fd, block.data(), block.size(), (off_t)hc.addr) != (ssize_t)block.size())
+                return fail("cannot write a string collection of '" + path + "'");
         }
+        return 0;
+    }
+
+    // The metadata of a group that is complete -- its datasets' headers, its heap, symbol node, B-tree node and header -- goes
+    // into the file now, behind its rows, and the group shrinks to a Link in its parent: a file of a million chunk groups keeps
+    // ~50 bytes per chunk in memory until close() instead of every header's fields.  The group and its children are the
+    // last objects of `objs`.
+    int seal(uint32_t parent, uint32_t id) {
+        const uint64_t pad = (8 - pos % 8) % 8;
+        out.insert(out.end(), (size_t)pad, 0);
+        pos += pad;
+        meta.clear();
+        base = pos;
+        const uint64_t header = group_header(id);
+        out.insert(out.end(), meta.begin(), meta.end());
+        pos += meta.size();
+        meta.clear();
+        const std::string& name = objs[id].name;
+        objs[parent].sealed.push_back(Link{header, (uint64_t)names.size(), (uint32_t)name.size()});
+        names.insert(names.end(), name.begin(), name.end());
+        objs[parent].kids.pop_back();                         // (the group was the parent's newest child)
+        objs.resize(id);
+        return 0;
     }
 
     // -> address of the group's object header; *tree / *heap receive what the superblock's root entry caches
     uint64_t group_header(uint32_t id, uint64_t* tree_out = nullptr, uint64_t* heap_out = nullptr) {
-        std::vector<uint32_t> kids = objs[id].kids;
-        std::sort(kids.begin(), kids.end(), [&](uint32_t a, uint32_t b) { return objs[a].name < objs[b].name; });
+        // the children in name order: open ones (their metadata is written here, children before parents) and sealed ones
+        struct Kid { const char* name; size_t len; uint64_t header; uint32_t open; };
+        std::vector<Kid> kids;
+        kids.reserve(objs[id].kids.size() + objs[id].sealed.size());
+        for (uint32_t k : objs[id].kids) kids.push_back(Kid{objs[k].name.data(), objs[k].name.size(), 0, k});
+        for (const Link& l : objs[id].sealed) kids.push_back(Kid{names.data() + l.name_at, l.name_len, l.header, 0});
+        auto less = [](const Kid& a, const Kid& b) {
+            const int c = std::memcmp(a.name, b.name, std::min(a.len, b.len));
+            return c < 0 || (c == 0 && a.len < b.len);
+        };
+        std::sort(kids.begin(), kids.end(), less);
+        for (size_t k = 1; k < kids.size(); ++k)
+            if (!less(kids[k - 1], kids[k])) duplicate = std::string(kids[k].name, kids[k].len);
         std::vector<uint64_t> header(kids.size());
         for (size_t k = 0; k < kids.size(); ++k)
-            header[k] = objs[kids[k]].group ? group_header(kids[k]) : dataset_header(objs[kids[k]]);
+            header[k] = kids[k].open == 0 ? kids[k].header
+                                          : (objs[kids[k].open].group ? group_header(kids[k].open) : dataset_header(objs[kids[k].open]));
         // local heap: "" at offset 0, then the names, each NUL-terminated and padded to 8 bytes; no free block
         std::vector<uint64_t> name_at(kids.size());
         uint64_t heap_bytes = 8;
         for (size_t k = 0; k < kids.size(); ++k) {
             name_at[k] = heap_bytes;
-            heap_bytes += (objs[kids[k]].name.size() + 1 + 7) / 8 * 8;
+            heap_bytes += (kids[k].len + 1 + 7) / 8 * 8;
         }
         const uint64_t heap = reserve(32 + heap_bytes);
         std::memcpy(&meta[heap], "HEAP", 4);
         put64(meta, heap + 8, heap_bytes);
         put64(meta, heap + 16, 1);                            // H5HL_FREE_NULL: the free list is empty
         put64(meta, heap + 24, base + heap + 32);
-        for (size_t k = 0; k < kids.size(); ++k)
-            std::memcpy(&meta[heap + 32 + name_at[k]], objs[kids[k]].name.data(), objs[kids[k]].name.size());
+        for (size_t k = 0; k < kids.size(); ++k) std::memcpy(&meta[heap + 32 + name_at[k]], kids[k].name, kids[k].len);
         // symbol nodes of up to 2 * LEAF_K entries
         const size_t per = 2 * LEAF_K;
         const size_t n_snod = (kids.size() + per - 1) / per;
@@ -369,10 +426,12 @@ struct pa_h5_builder {
         out.insert(out.end(), (size_t)pad, 0);
         pos += pad;
         if (int rc = flush()) return rc;
+        if (int rc = heap_collections()) return rc;
+        meta.clear();
         base = pos;
-        heap_collections();
         uint64_t tree = 0, heap = 0;
         const uint64_t root = group_header(0, &tree, &heap);
+        if (!duplicate.empty()) return fail("two objects named '" + duplicate + "' in one group of '" + path + "'");
         out.swap(meta);
         pos += out.size();
         if (int rc = flush()) return rc;
@@ -451,6 +510,7 @@ int pa_h5_builder_write_polish_predictions(pa_h5_builder* b, int32_t n, int32_t 
         b->row(id, "index", 8, true, index + (size_t)i * seq_len, (uint64_t)seq_len);
         b->row(id, "bases", 1, false, bases + (size_t)i * seq_len, (uint64_t)seq_len);
         b->row(id, "phred_score", 1, false, phred + (size_t)i * seq_len, (uint64_t)seq_len);
+        if (int rc = b->seal(it->second, id)) return rc;
         if (b->out.size() >= (4u << 20))
             if (int rc = b->flush()) return rc;
     }
@@ -518,12 +578,11 @@ int pa_h5_builder_write_polish_image_chunks(pa_h5_builder* b, const char* names,
     const char* name = names;
     for (int32_t i = 0; i < n; ++i, name += strlen(name) + 1) {
         if (!*name || std::strchr(name, '/')) return fail(std::string("bad chunk name '") + name + "'");
-        if (b->has_kid_indexed(summaries, name)) return fail(std::string("cannot create group 'summaries/") + name + "' (already exists?)");
+        if (b->has_kid(summaries, name)) return fail(std::string("cannot create group 'summaries/") + name + "' (already exists?)");
         Obj g;
         g.name = name;
         g.group = true;
         const uint32_t id = b->add(summaries, std::move(g));
-        b->kid_names.emplace(std::string(name));
         b->dataset(id, "image", 1, false, 2, d2, images + (size_t)i * seq_len * features);
         b->dataset(id, "label", 1, false, 1, d1, labels + (size_t)i * seq_len);
         b->dataset(id, "position", 8, true, 1, d1, position + (size_t)i * seq_len);
@@ -532,6 +591,7 @@ int pa_h5_builder_write_polish_image_chunks(pa_h5_builder* b, const char* names,
         b->scalar(id, "region_start", region_start);
         b->scalar(id, "region_end", region_end);
         b->scalar(id, "chunk_id", chunk_id[i]);
+        if (int rc = b->seal(summaries, id)) return rc;
         if (b->out.size() >= (4u << 20))
             if (int rc = b->flush()) return rc;
     }

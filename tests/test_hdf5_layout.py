@@ -484,6 +484,13 @@ def test_builder_image_files_equal_the_library_files(tmp_path, monkeypatch):
     for a, b in zip(blocks[True], blocks[False]):
         assert np.array_equal(a, b)
     assert blocks[True][0][0].decode().startswith("contig_") and len(blocks[True][0]) == n
+    # a name used twice in a group of very many chunks is found when the group's B-tree is laid out: close() fails
+    img, lab, pos = np.zeros((1, 4, 10), np.uint8), np.zeros((1, 4), np.uint8), np.zeros((1, 4), np.int64)
+    dup = h5.PredictionBuilder(str(tmp_path / "dup.hdf"))
+    for k in list(range(100)) + [7]:
+        dup.write_polish_image_chunks(["c_%d" % k], "c", 0, 1, np.array([0], np.int64), img, lab, pos, pos)
+    with pytest.raises(h5.H5Error):
+        dup.close()
     if os.path.exists("/opt/conda/bin/python3.9"):
         script = ("import h5py, sys\nf = h5py.File(sys.argv[1], 'r')\ng = f['summaries/x_5_6_7']\n"
                   "c = g['contig'][()]\nc = c.decode('utf-8') if isinstance(c, bytes) else c\n"
