@@ -130,18 +130,27 @@ class ImageGenerationUtils:
     def generate_image_and_save_to_file(options, all_intervals, bed_list, process_id):
         timestr = time.strftime("%m%d%Y_%H%M%S")
         file_name = options.image_output_directory + "pepper_variants_images_thread_" + str(process_id) + "_" + str(timestr) + ".hdf5"
-        intervals = [r for i, r in enumerate(all_intervals) if i % options.threads == process_id]
+        # intervals are encoded ENCODER_BATCH at a time: the reads of a group are fetched (BAM reader, outside the GIL), then one
+        # encoder call covers the group; summaries are written per interval under the reference's group names.  A worker takes
+        # whole groups of CONSECUTIVE intervals (the reference deals single intervals round robin, ImageGenerationUI.py:262-274;
+        # which worker's file an interval lands in is not read by anything downstream): the reads of an interval start up to
+        # a read length + 16 kb (the BAM index's window) in front of it, so consecutive fetches through one handle find most of
+        # their BGZF blocks already inflated in the handle's cache -- the BAM reader is 93 % of this loop's time.
+        batch = max(1, int(getattr(options, "encoder_batch", 0) or os.environ.get("PEPPER_AMD_ENCODER_BATCH", 16)))
+        intervals = [r for i, r in enumerate(all_intervals) if (i // batch) % options.threads == process_id]
         if process_id == 0:
             _log("INFO: STARTING PROCESS: " + str(process_id) + " FOR " + str(len(intervals)) + " INTERVALS")
-        # intervals are encoded ENCODER_BATCH at a time: the reads of a group are fetched (BAM reader, outside the GIL), then one
-        # encoder call covers the group; summaries are written per interval under the reference's group names, in its order
-        batch = max(1, int(getattr(options, "encoder_batch", 0) or os.environ.get("PEPPER_AMD_ENCODER_BATCH", 16)))
         from pepper_amd.variant.AlignmentSummarizer import create_summaries
+        generators = {}
         with DataStore(file_name, 'w') as output_hdf_file:
             for g0 in range(0, len(intervals), batch):
                 group = intervals[g0:g0 + batch]
-                prepared = [ImageGenerator(chr_name, options.bam, options.fasta, options).prepare(options, _start, _end)
-                            for chr_name, _start, _end in group]
+                prepared = []
+                for chr_name, _start, _end in group:
+                    if chr_name not in generators:
+                        generators.clear()               # one contig's handles at a time per worker
+                        generators[chr_name] = ImageGenerator(chr_name, options.bam, options.fasta, options)
+                    prepared.append(generators[chr_name].prepare(options, _start, _end))
                 for (chr_name, _start, _end), out in zip(group, create_summaries(prepared)):
                     if out is None:
                         continue
