@@ -137,7 +137,8 @@ class ImageGenerationUtils:
         # a read length + 16 kb (the BAM index's window) in front of it, so consecutive fetches through one handle find most of
         # their BGZF blocks already inflated in the handle's cache -- the BAM reader is 93 % of this loop's time.
         batch = max(1, int(getattr(options, "encoder_batch", 0) or os.environ.get("PEPPER_AMD_ENCODER_BATCH", 16)))
-        intervals = [r for i, r in enumerate(all_intervals) if (i // batch) % options.threads == process_id]
+        run = max(1, min(batch, -(-len(all_intervals) // max(1, options.threads))))      # (small jobs: every worker gets some)
+        intervals = [r for i, r in enumerate(all_intervals) if (i // run) % options.threads == process_id]
         if process_id == 0:
             _log("INFO: STARTING PROCESS: " + str(process_id) + " FOR " + str(len(intervals)) + " INTERVALS")
         from pepper_amd.variant.AlignmentSummarizer import create_summaries
