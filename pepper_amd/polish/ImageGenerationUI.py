@@ -130,7 +130,12 @@ class UserInterfaceSupport:
         output_path, bam_file, draft_file, truth_bam, train_mode, downsample_rate = args
         timestr = time.strftime("%m%d%Y_%H%M%S")
         file_name = output_path + "pepper_hp_images_thread_" + str(thread_id) + "_" + str(timestr) + ".hdf"
-        intervals = [r for i, r in enumerate(all_intervals) if i % total_threads == thread_id]
+        # a worker takes runs of CONSECUTIVE intervals (the reference deals single intervals round robin,
+        # ImageGenerationUI.py:262-274; which worker's file an interval lands in is not read by anything downstream): the reads
+        # of an interval start up to a read length + 16 kb in front of it, and consecutive fetches through one BAM handle find
+        # those BGZF blocks already inflated in the handle's cache
+        run = max(1, min(UserInterfaceSupport.REGIONS_PER_CALL, -(-len(all_intervals) // max(1, total_threads))))
+        intervals = [r for i, r in enumerate(all_intervals) if (i // run) % total_threads == thread_id]
         if thread_id == 0:
             _log("INFO: STARTING THREAD: " + str(thread_id) + " FOR " + str(len(intervals)) + " INTERVALS")
         start_time = time.time()
