@@ -149,11 +149,18 @@ struct Bgzf {
                 if (cur->empty()) continue;           // empty block (e.g. the EOF marker)
             }
             const size_t take = std::min(n - done, cur->size() - upos);
-            std::memcpy(out + done, cur->data() + upos, take);
+            if (out) std::memcpy(out + done, cur->data() + upos, take);      // (dst == nullptr: skip n bytes)
             upos += take;
             done += take;
         }
         return done;
+    }
+    // n bytes in place when they all lie in the current block (the cursor moves past them); nullptr otherwise
+    const uint8_t* peek(size_t n) {
+        if (upos + n > cur->size()) return nullptr;
+        const uint8_t* p = cur->data() + upos;
+        upos += n;
+        return p;
     }
     uint64_t tell() const { return ((uint64_t)block_coffset << 16) | (uint64_t)upos; }
 };
@@ -185,6 +192,8 @@ struct pa_bam {
     std::vector<std::vector<uint64_t>> ioff;                   // linear index per reference
     std::vector<uint64_t> ref_min;                             // smallest chunk begin per reference (0 = none)
     ReadSet reads;
+    std::vector<char> scratch_seq;                             // one read's decoded bases / qualities while it is clipped
+    std::vector<uint8_t> scratch_qual;
 };
 
 namespace {
@@ -432,16 +441,22 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
         }
         const uint32_t block_size = le32(w4);
         if (block_size < 32) return bam_fail(-6, "corrupt BAM record");
-        rec.resize(block_size);
-        if (b->bg.read(rec.data(), block_size) != block_size)
-            return bam_fail(b->bg.failed ? -5 : -6, b->bg.failed ? "corrupt or truncated BGZF block" : "truncated BAM record");
-        const int32_t ref_id = (int32_t)le32(&rec[0]);
-        const int32_t pos = (int32_t)le32(&rec[4]);
-        const uint32_t l_read_name = rec[8];
-        const int32_t mapq = rec[9];
-        const uint32_t n_cigar_op = rec[12] | (rec[13] << 8);
-        const uint32_t flag = rec[14] | (rec[15] << 8);
-        const uint32_t l_seq = le32(&rec[16]);
+        // A record that lies inside the current (inflated, cached) block is parsed where it is -- nine in ten with 64 KiB
+        // blocks and reads of a few kb; one that crosses a block boundary is copied out first.
+        const uint8_t* R = b->bg.peek(block_size);
+        if (!R) {
+            rec.resize(block_size);
+            if (b->bg.read(rec.data(), block_size) != block_size)
+                return bam_fail(b->bg.failed ? -5 : -6, b->bg.failed ? "corrupt or truncated BGZF block" : "truncated BAM record");
+            R = rec.data();
+        }
+        const int32_t ref_id = (int32_t)le32(R);
+        const int32_t pos = (int32_t)le32(R + 4);
+        const uint32_t l_read_name = R[8];
+        const int32_t mapq = R[9];
+        const uint32_t n_cigar_op = R[12] | (R[13] << 8);
+        const uint32_t flag = R[14] | (R[15] << 8);
+        const uint32_t l_seq = le32(R + 16);
         if (ref_id != tid) {
             if (ref_id > tid || ref_id < 0) break;      // sorted file: past the contig (unmapped reads come last)
             continue;
@@ -452,26 +467,42 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
         if (o_aux > block_size) return bam_fail(-6, "corrupt BAM record");
         // reads with more than 65535 CIGAR operations (ultra-long nanopore reads) keep their CIGAR in the CG:B,I tag and a
         // placeholder <l_seq>S<ref_len>N in the core field; htslib (the reference's reader) swaps it in transparently
-        const uint8_t* cig = &rec[o_cigar];
+        const uint8_t* cig = R + o_cigar;
         uint32_t n_cig = n_cigar_op;
         // same tests as htslib's bam_tag2cigar (sam.c): first operation <l_seq>S; a CG tag of type B,I (or B,i) with at least
         // as many operations as the core field; anything else keeps the core CIGAR as it is
         if (n_cigar_op >= 1 && (le32(cig) & 15) == 4 && (le32(cig) >> 4) == l_seq) {
             uint32_t cnt = 0;
-            const uint8_t* real = find_cg(&rec[o_aux], rec.data() + block_size, &cnt);
+            const uint8_t* real = find_cg(R + o_aux, R + block_size, &cnt);
             if (real && cnt >= n_cigar_op && cnt < (1u << 29)) {
                 cig = real;
                 n_cig = cnt;
             }
         }
-        int64_t ref_len = 0;
-        for (uint32_t k = 0; k < n_cig; ++k) {
-            const uint32_t c = le32(cig + 4 * k);
+        // The operations in front of the region only move the two cursors (a read of several kb that reaches a 1 kb region
+        // has hundreds of them: this loop was a third of a query's time when it ran through the clipping switch below):
+        // match runs that end at or before `start`, inserts / soft clips and deletions / skips that begin before it -- exactly
+        // what the clipping loop does with them (:176-303: nothing is kept before the first base inside the region).  A read
+        // whose operations run out here ends in front of the region.
+        uint32_t k0 = 0;
+        int64_t rpos = pos, ridx = 0;
+        for (; k0 < n_cig; ++k0) {
+            const uint32_t c = le32(cig + 4 * k0);
             const int op = c & 15;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
+            const int64_t len = c >> 4;
+            if (op == 0 || op == 7 || op == 8) {
+                if (rpos + len > start) break;
+                rpos += len;
+                ridx += len;
+            } else if (op == 1 || op == 4) {
+                if (rpos >= start) break;
+                ridx += len;
+            } else if (op == 2 || op == 3) {
+                if (rpos >= start) break;
+                rpos += len;
+            }
         }
-        const int64_t end = pos + std::max<int64_t>(ref_len, 1);
-        if (end <= start) continue;
+        if (k0 == n_cig) continue;
 
         // ---- filters of get_reads (:138-151) ----
         if (flag & (0x200 | 0x400 | 0x100 | 0x4)) continue;        // qc-fail, duplicate, secondary, unmapped
@@ -479,17 +510,19 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
         if (mapq < min_mapq) continue;
 
         // ---- clip to [start, stop] (:176-303) ----
-        const uint8_t* seqi = &rec[o_seq];
-        const uint8_t* qual = &rec[o_qual];
-        const size_t seq0 = rs.seq.size(), cig0 = rs.cigar_op.size();
-        int64_t pos_start = -1, pos_end = -1, rpos = pos;
-        int64_t ridx = 0;
-        // room for the whole read once (trimmed below); runs of consecutive read bases are decoded in place:
-        // 4-bit codes -> upper-case letters two at a time, qualities copied
-        rs.seq.resize(seq0 + l_seq);
-        rs.qual.resize(seq0 + l_seq);
-        char* seq_out = &rs.seq[seq0];
-        uint8_t* qual_out = rs.qual.data() + seq0;
+        const uint8_t* seqi = R + o_seq;
+        const uint8_t* qual = R + o_qual;
+        const size_t cig0 = rs.cigar_op.size();
+        int64_t pos_start = -1, pos_end = -1;
+        // the kept runs are decoded into a scratch row of the handle (4-bit codes -> upper-case letters two at a time,
+        // qualities copied) and appended to the set when the read is done: what is kept is a region's worth of a read that
+        // may be many kb long
+        if (b->scratch_seq.size() < l_seq) {
+            b->scratch_seq.resize(l_seq);
+            b->scratch_qual.resize(l_seq);
+        }
+        char* seq_out = b->scratch_seq.data();
+        uint8_t* qual_out = b->scratch_qual.data();
         size_t written = 0;
         auto push_run = [&](int64_t idx, int64_t count) {
             char* out = seq_out + written;
@@ -504,7 +537,7 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
             std::memcpy(qual_out + written, qual + idx, (size_t)count);
             written += (size_t)count;
         };
-        for (uint32_t k = 0; k < n_cig; ++k) {
+        for (uint32_t k = k0; k < n_cig; ++k) {
             const uint32_t c = le32(cig + 4 * k);
             const int op = c & 15;
             const int64_t len = c >> 4;
@@ -557,22 +590,22 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
                 rs.cigar_len.push_back((int32_t)kept);
             }
         }
-        rs.seq.resize(seq0 + written);
-        rs.qual.resize(seq0 + written);
         if (written == 0) {                                   // no base inside the region: read dropped (:432)
             rs.cigar_op.resize(cig0);
             rs.cigar_len.resize(cig0);
             continue;
         }
+        rs.seq.insert(rs.seq.end(), seq_out, seq_out + written);
+        rs.qual.insert(rs.qual.end(), qual_out, qual_out + written);
         rs.pos.push_back(pos_start);
         rs.pos_end.push_back(pos_end);
         rs.reverse.push_back((flag & 0x10) ? 1 : 0);
         rs.mapq.push_back(mapq);
         rs.flags.push_back((int32_t)flag);
-        rs.hp.push_back(parse_hp(&rec[o_aux], rec.data() + block_size));
+        rs.hp.push_back(parse_hp(R + o_aux, R + block_size));
         rs.seq_offset.push_back((int64_t)rs.seq.size());
         rs.cigar_offset.push_back((int64_t)rs.cigar_op.size());
-        rs.names.append(reinterpret_cast<const char*>(&rec[o_name]), l_read_name ? l_read_name - 1 : 0);
+        rs.names.append(reinterpret_cast<const char*>(R + o_name), l_read_name ? l_read_name - 1 : 0);
         rs.names.push_back('\0');
         rs.name_offset.push_back((int64_t)rs.names.size());
     }

@@ -60,6 +60,11 @@ def test_random_pileup_regions(tmp_path, with_index):
         for include_supp, min_mapq in ((False, 1), (True, 0), (False, 30)):
             got = bam.get_reads("chrB", start, stop, include_supp, min_mapq, 1)
             compare(got, bu.restated_get_reads(reads, start, stop, include_supp, min_mapq))
+    # many short regions: the cursor fast-forward over the operations in front of a region ends at every kind of operation
+    # (a match run cut by `start`, an insert or a soft clip sitting at it, a deletion spanning it)
+    for start in rng.integers(0, 59990, size=70).tolist():
+        stop = start + int(rng.integers(1, 300))
+        compare(bam.get_reads("chrB", start, stop, True, 0, 1), bu.restated_get_reads(reads, start, stop, True, 0))
     compare(bam.get_reads("chrA", 100, 5000, True, 0, 0), bu.restated_get_reads(other, 100, 5000, True, 0))
     assert len(bam.get_reads("chrC", 0, 100, True, 0, 0)) == 0
     with pytest.raises(BamError):
