@@ -777,12 +777,16 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
         inflight = collections.deque()                  # (future or None, lane, slot, meta, file_end), oldest first
         submitted = 0
 
+        spans = []                                       # (start, end, windows) of every device pass, for the trace
+
         def run(forward, lane, slot, shape):
             images = slots[lane].view(slot, 0, shape, np.int8)
+            t0 = time.perf_counter()
             try:
                 return np.asarray(forward(images))
             finally:
                 del images
+                spans.append((t0, time.perf_counter(), shape[0]))
 
         def retire():
             nonlocal windows, files_done
@@ -839,6 +843,12 @@ def variant_lanes(image_directory, files, output_stem, forward_block, batch_size
                 writing -= 1
                 batches += msg[2]
         _trace(t_begin, "all lanes written")
+        if spans and os.environ.get("PEPPER_AMD_LANE_TRACE"):
+            busy = sum(b - a for a, b, _ in spans)
+            window = max(b for _, b, _ in spans) - spans[0][0]
+            sys.stderr.write("[lanes] %d device passes of %.0f windows and %.1f ms on average, %.2f of them at once over %.2f s "
+                             "(%.2f M windows/s inside)\n" % (len(spans), sum(c for _, _, c in spans) / len(spans), 1e3 * busy / len(spans),
+                                                              busy / max(1e-9, window), window, 1e-6 * sum(c for _, _, c in spans) / max(1e-9, window)))
         locker.join()
         for p in procs:
             p.join(timeout=60)
