@@ -227,6 +227,14 @@ __device__ __forceinline__ void wave_append_vote(bool has, const Vote& v, Vote* 
 #ifndef PA_TILE_MIN_WAVES
 #define PA_TILE_MIN_WAVES 4          // measured equal at 4 / 6 / 8 (2 / 3 / 4 workgroups per CU); 6 and 8 spill 7 / 19 registers to scratch
 #endif
+// -DPA_ENC_STAMP (debug build, tools/enc_phase_cycles.py): shader-clock cycles per phase of the record loop, summed over the
+// waves.  The stamped kernel is several times slower (s_memtime serialises); the SHARES are what it is for.
+#ifdef PA_ENC_STAMP
+__device__ unsigned long long g_enc_cycles[8];
+#define ENC_LAP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); lap_acc[k] += t_ - lap_t; lap_t = t_; } while (0)
+#else
+#define ENC_LAP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileArgs a) {
     __shared__ int cnt[NCNT * TP];                 // [counter][row]; reused as the finished [row][26] tile for the store
     __shared__ char ref_s[TP];
@@ -255,6 +263,9 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
     int* first_s = s_first[w];
     int* ri_s = s_ri[w];
     int* op_s = s_op[w];
+#ifdef PA_ENC_STAMP
+    unsigned long long lap_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lap_t = __builtin_amdgcn_s_memtime();
+#endif
     TileRec rec{0, 0, 0, 0};
     if (rec0 + w < rec1) rec = a.recs[rec0 + w];
     for (int k = rec0 + w; k < rec1; k += NW) {
@@ -281,6 +292,7 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
         const bool rev = rd.flags & READ_REV;
         const int c_end = rd.c0 + rd.ncig;
         int pos = rec.row, ri = rec.ri;
+        ENC_LAP(0);                                   // record set-up: the read's entry, its first 64 operations
         for (int c = rec.op; c < c_end; c += 64) {
             const int i = c + lane;
             if (c != rec.op) {
@@ -347,6 +359,7 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
                 }
             }
             if (past) atomicMax(&a.counters[CT_ERR], rec.read + 1);    // CIGAR runs past the sequence: reported by the host
+            ENC_LAP(1);                               // scans, scratch, owner search, byte loads issued
 
             // -- one operation per lane: inserts (:431-490) and deletion anchors (:491-540)
             long long qsum = 0;
@@ -410,6 +423,7 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
                 }
             }
 
+            ENC_LAP(2);                               // per-operation section (its loads are the first to be waited for)
             // -- the rows: match runs (:357-430) and the '*' rows of deletions (:541-551).  Branch-free: every lane issues
             //    the same five LDS atomics with a 0 / 1 addend (the LDS pipe is 7 % busy, the instruction issue is the
             //    bound: exec-mask bookkeeping around five `if`s cost more than the idle adds); letters -> columns by
@@ -449,13 +463,16 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            ENC_LAP(3);                               // row phase
             pos += total_r;
             ri += wave_total(qinc);
             if (pos > live_max) break;
         }
         rec = rec_next;
     }
+    ENC_LAP(4);
     __syncthreads();
+    ENC_LAP(5);                                       // waiting for the slowest wave of the tile
 
     // ---- the tile is complete: per-position pass of generate_summary (:568-654), then one coalesced store --------
     const int idx = tile_lo + tid;
@@ -529,6 +546,11 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
         if (has) v.prefix = allele_prefix((pv.y & 8u) ? a.ref + reg.ref_off : a.seq + reg.seq_base, pv.x, (pv.y >> 4) & 63u);
         wave_append_vote(has, v, a.votes_out + reg.vote_base, &a.region_counts[2 * region + 1], 0x7fffffff, lane);
     }
+#ifdef PA_ENC_STAMP
+    ENC_LAP(6);                                       // per-position pass, store, votes
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_enc_cycles[k], lap_acc[k]);
+#endif
 }
 
 // votes of the sites that passed the thresholds, compacted for the host
@@ -1198,6 +1220,17 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
 }
 
 }  // namespace
+
+#ifdef PA_ENC_STAMP
+extern "C" int pa_encoder_debug_cycles(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_enc_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_enc_cycles), zero, sizeof zero) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" {
 
