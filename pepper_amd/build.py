@@ -60,14 +60,29 @@ def build_io(force=False, verbose=False):
     return IO_LIB
 
 
+OBJ_DIR = os.path.join(CSRC, "_obj")
+
+
+def _flags():
+    # -mf16c on the host side: weight packing converts ~24 M values to f16 hi/lo halves at model creation; without the
+    # F16C conversions clang calls a soft-float routine per value (0.4 s per variant model instead of tens of ms)
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Xarch_host", "-mf16c", "-Wno-unused-result"] + \
+        os.environ.get("PEPPER_AMD_EXTRA_HIPCC_FLAGS", "").split()
+
+
+def _same_flags():
+    """Were the objects behind the library compiled with the flags of this call?  (A debug build -- e.g. -DPA_ENC_STAMP --
+    must not survive the next ordinary build() just because no source changed.)  A library that arrived without its
+    objects' stamp (a snapshot on a GPU box) is taken as it is."""
+    stamp = os.path.join(OBJ_DIR, "flags.txt")
+    return not os.path.exists(stamp) or open(stamp).read() == " ".join(_flags())
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
-
-
-OBJ_DIR = os.path.join(CSRC, "_obj")
+    return not _same_flags() or any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
 def build(force=False, verbose=False):
@@ -75,10 +90,7 @@ def build(force=False, verbose=False):
     link: an edit of one kernel file costs its own 5-25 s instead of the 45 s of the whole library."""
     if not force and not needs_build():
         return LIB
-    # -mf16c on the host side: weight packing converts ~24 M values to f16 hi/lo halves at model creation; without the
-    # F16C conversions clang calls a soft-float routine per value (0.4 s per variant model instead of tens of ms)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Xarch_host", "-mf16c", "-Wno-unused-result"] + \
-        os.environ.get("PEPPER_AMD_EXTRA_HIPCC_FLAGS", "").split()
+    flags = _flags()
     os.makedirs(OBJ_DIR, exist_ok=True)
     stamp = os.path.join(OBJ_DIR, "flags.txt")
     same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
