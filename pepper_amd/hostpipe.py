@@ -887,7 +887,24 @@ def default_lanes(files, requested, small=64 << 20, most=8):
     if most is None:
         from pepper_amd.hostinfo import usable_cpus
         most = max(3, min(12, usable_cpus() * 3 // 8))
+    # callers of one host share its CPUs: with R ranks of a torch.distributed job here (one per GPU), each takes its R-th
+    most = max(2, most // _ranks_on_this_host())
     return min(len(files), most)
+
+
+def _ranks_on_this_host():
+    """Ranks of the running torch.distributed job on this host (the launchers of this package are single-node: the world
+    size), 1 outside a job.  LOCAL_WORLD_SIZE (torchrun) wins when set."""
+    try:
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", "0"))
+        if local > 0:
+            return local
+        torch_dist = sys.modules.get("torch.distributed")
+        if torch_dist is not None and torch_dist.is_available() and torch_dist.is_initialized():
+            return max(1, int(torch_dist.get_world_size()))
+    except Exception:
+        pass
+    return 1
 
 
 if __name__ == "__main__":

@@ -221,7 +221,8 @@ def test_lane_errors_reach_the_caller(tmp_path):
         hostpipe.polish_lanes([str(bad)], str(tmp_path / "out"), lambda *a: None, lanes=1, block=4)
 
 
-def test_default_lanes_policy(tmp_path):
+def test_default_lanes_policy(tmp_path, monkeypatch):
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     small = []
     for i in range(3):
         p = tmp_path / ("f%d.hdf" % i)
@@ -234,6 +235,16 @@ def test_default_lanes_policy(tmp_path):
     assert hostpipe.default_lanes([], 4) == 0
     groups = hostpipe.deal_files(small, 2)
     assert sorted(sum(groups, [])) == sorted(small) and len(groups) == 2
+    # the ranks of one host share its CPUs: eight callers take an eighth each (never fewer than two lanes)
+    many = []
+    for i in range(16):
+        p = tmp_path / ("g%d.hdf" % i)
+        p.write_bytes(b"x" * 1000)
+        many.append(str(p))
+    alone = hostpipe.default_lanes(many, 0, small=100, most=8)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert alone == 8 and hostpipe.default_lanes(many, 0, small=100, most=8) == 2
+    assert hostpipe.default_lanes(many, 5, small=100, most=8) == 5          # an explicit num_workers is taken as given
 
 
 def test_group_larger_than_a_slot_is_reported_as_such(tmp_path):
