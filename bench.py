@@ -582,7 +582,6 @@ def secondary_block(args):
     measurement (same command, same box, one after the other on the one GPU): polish (BASELINE configs[4]) windows/s with its
     dominant kernel's roofline, the summary encoder's aligned bases/s, and the two HDF5 -> HDF5 rates through the reference's
     entry points (run_inference on >= 4 M windows, call_consensus on >= 128 k chunks) with the files in tmpfs."""
-    import shutil
     import subprocess
     me = os.path.abspath(__file__)
     out = {}
