@@ -51,7 +51,8 @@ constexpr int MATF = 26;            // int32 per matrix row in HBM (the image co
 constexpr int NCNT = 28;            // privatised counters per row
 constexpr int NW = 8, NT = 64 * NW;  // waves / threads of a tile_count_kernel workgroup: NT == TP, a thread owns a row in the per-position pass
 constexpr int UNR = 8;              // rows per lane in flight in the row phase: 64 x UNR = TP
-constexpr int VCAP = 1024;          // indel votes a tile keeps in LDS (nanopore: ~600 per 512 rows x 60 reads; more spill to the global list)
+constexpr int VCAP = 512;           // indel votes a tile keeps in LDS (nanopore: ~600 per 512 rows x 60 reads; more spill to the global list)
+constexpr int XQ = 128;             // per-wave queue of the bases that are not clean matches (processed 64 at a time)
 static_assert(NT == TP && 64 * UNR == TP, "one thread per row, UNR rows per lane");
 // counter slots: 0 coverage, 1 snp_count, 2 insert_count, 3 delete_count, 4 = column 4 (forward strand coverage),
 // 5..11 = columns 8..14 (forward A C G T I D *), 12 = column 15 (reverse strand coverage), 13..19 = columns 19..25,
@@ -227,10 +228,8 @@ __device__ __forceinline__ void wave_append_vote(bool has, const Vote& v, Vote* 
 #ifndef PA_TILE_MIN_WAVES
 #define PA_TILE_MIN_WAVES 4          // measured equal at 4 / 6 / 8 (2 / 3 / 4 workgroups per CU); 6 and 8 spill 7 / 19 registers to scratch
 #endif
-// -DPA_ENC_STAMP (debug build, tools/enc_phase_cycles.py): shader-clock cycles per phase of the record loop, summed over the
-// waves.  The stamped kernel is several times slower (s_memtime serialises); the SHARES are what it is for.
 #ifdef PA_ENC_STAMP
-__device__ unsigned long long g_enc_cycles[8];
+__device__ unsigned long long g_enc_cycles[8];     // debug: shader-clock cycles per phase, summed over the waves
 #define ENC_LAP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); lap_acc[k] += t_ - lap_t; lap_t = t_; } while (0)
 #else
 #define ENC_LAP(k) do { } while (0)
@@ -239,10 +238,22 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
     __shared__ int cnt[NCNT * TP];                 // [counter][row]; reused as the finished [row][26] tile for the store
     __shared__ char ref_s[TP];
     __shared__ uint8_t refok_s[TP];               // is_acgt(reference base) per row
-    __shared__ uint8_t pass_s[TP];
-    __shared__ int s_first[NW][65], s_ri[NW][64], s_op[NW][64];
+    __shared__ int4 s_ent[NW][64];                 // per wave: the reference-consuming operations of the batch that touch the span, in order
+    __shared__ unsigned s_mask[NW][16];            // per wave: bit k = an operation's share of the span starts at row span_lo + k
     __shared__ uint2 vbuf[VCAP];                   // indel allele votes of this tile: only those of passing rows leave the CU
     __shared__ int vcount;
+    // A base of a match run that equals an A/C/G/T reference base and passes the quality test -- 95 % of all bases -- adds one
+    // to the coverage, to its strand's coverage (unless it anchors an insert / a deletion) and to its strand's column of that
+    // letter.  Those three go in per RUN, as +1 / -1 at the run's ends in a difference array (two LDS atomics per operation
+    // instead of three per base; the prefix sums are taken once, when the tile is complete); the row phase only looks at each
+    // base (quality, letter, reference letter) and queues the ones that are NOT of that kind, which are then processed 64 at
+    // a time with the full rules plus the undoing of what the run assumed for them.
+    __shared__ int mcov[2][TP + 8];                // [strand][row]: match runs starting minus match runs ended before this row
+    __shared__ int anch[TP];                       // runs whose last base sits here and anchors an insert / a deletion: forward | reverse << 16
+    __shared__ unsigned xq[NW][XQ];                // queued bases: row | letter << 9 | quality ok << 17 | anchoring << 18 | reverse << 19
+    __shared__ int wtot[2][NW];
+    uint8_t* pass_s = reinterpret_cast<uint8_t*>(&xq[0][0]);   // verdicts of the per-position pass: the queues are empty by then (two
+                                                               // workgroups per CU need the tile's LDS below 80 KB)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
     const int region = a.tile_region[tile];
@@ -251,6 +262,8 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
     const int tile_lo = (tile - reg.tile0) * TP, tile_hi = tile_lo + TP - 1;
     const int live_max = tile_hi + 1 < L - 1 ? tile_hi + 1 : L - 1;   // operations starting past this row are not this tile's (pos > end: not walked at all)
     for (int i = tid; i < NCNT * TP; i += NT) cnt[i] = 0;
+    for (int i = tid; i < 2 * (TP + 8); i += NT) (&mcov[0][0])[i] = 0;
+    if (tid < TP) anch[tid] = 0;
     if (tid < TP) {
         const int idx = tile_lo + tid;
         ref_s[tid] = idx < reg.ref_len ? a.ref[reg.ref_off + idx] : 'N';
@@ -260,12 +273,41 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
     __syncthreads();
 
     const int rec0 = a.tile_off[tile], rec1 = a.tile_off[tile + 1] < a.rec_cap ? a.tile_off[tile + 1] : a.rec_cap;
-    int* first_s = s_first[w];
-    int* ri_s = s_ri[w];
-    int* op_s = s_op[w];
-#ifdef PA_ENC_STAMP
-    unsigned long long lap_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lap_t = __builtin_amdgcn_s_memtime();
-#endif
+    int4* ent_s = s_ent[w];
+    unsigned* mask_s = s_mask[w];
+    // the wave's queue of bases that need the full rules: `qn` entries (wave-uniform), drained 64 at a time
+    unsigned* xq_w = xq[w];
+    int qn = 0;
+    auto drain = [&](int count) {                  // entries [0, count) of the queue, one per lane
+        const bool on = lane < count;
+        const unsigned e = on ? xq_w[lane] : 0u;
+        const int o = (int)(e & 511u);
+        const unsigned b = (e >> 9) & 255u;
+        const bool q_ok = on && ((e >> 17) & 1u), anchoring = (e >> 18) & 1u, erev = (e >> 19) & 1u;
+        const unsigned rb = (unsigned char)ref_s[o];
+        const unsigned ru = rb & 0xDFu, bu = b & 0xDFu;
+        const unsigned ridx = (ru >> 1) & 3u, bidx = (bu >> 1) & 3u;
+        const bool ref_ok = ((0x47544341u >> (ridx * 8)) & 0xFFu) == ru;            // is_acgt(reference base)
+        const unsigned letter = (0x47544341u >> (bidx * 8)) & 0xFFu;
+        const int acgt = (int)(bidx ^ (bidx >> 1));                                  // A C G T -> 0 1 2 3
+        const int racgt = (int)(ridx ^ (ridx >> 1));
+        const int sym = letter == bu ? acgt : (bu == 'I' ? 4 : (bu == 'D' ? 5 : 6));   // symbol_column's switch
+        const bool mism = q_ok && rb != b;                                           // case-sensitive, as the reference compares
+        const bool plain = letter == b;                                              // an upper-case A C G T: tallied on the device
+        const int strand = erev ? K_REV : K_FWD;
+        // what the rules give this base (:357-430) minus what its run assumed for it (coverage, strand coverage unless
+        // anchoring, the reference letter's column where the reference base is a letter)
+        atomicAdd(&cnt[K_COV * TP + o], on ? (q_ok ? 0 : -1) : 0);
+        atomicAdd(&cnt[strand * TP + o], (on && !anchoring && !q_ok) ? -1 : 0);
+        atomicAdd(&cnt[(strand + 1 + racgt) * TP + o], (on && ref_ok) ? -1 : 0);
+        atomicAdd(&cnt[(strand + 1 + sym) * TP + o], (q_ok && ref_ok) ? 1 : 0);
+        atomicAdd(&cnt[K_SNP * TP + o], mism ? 1 : 0);
+        atomicAdd(&cnt[(K_TAB + (erev ? 4 : 0) + acgt) * TP + o], (mism && plain) ? 1 : 0);
+        if (mism && !plain) {                        // rare alphabet (N, IUPAC, lower case): exact key kept on host
+            const int slot = atomicAdd(&a.counters[CT_OVF], 1);
+            if (slot < a.ovf_cap) a.ovf[slot] = make_int4(o + tile_lo, (int)b, erev ? 1 : 0, region);
+        }
+    };
     TileRec rec{0, 0, 0, 0};
     if (rec0 + w < rec1) rec = a.recs[rec0 + w];
     for (int k = rec0 + w; k < rec1; k += NW) {
@@ -292,7 +334,7 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
         const bool rev = rd.flags & READ_REV;
         const int c_end = rd.c0 + rd.ncig;
         int pos = rec.row, ri = rec.ri;
-        ENC_LAP(0);                                   // record set-up: the read's entry, its first 64 operations
+        ENC_LAP(0);                                   // record set-up (waits for the prefetched loads)
         for (int c = rec.op; c < c_end; c += 64) {
             const int i = c + lane;
             if (c != rec.op) {
@@ -318,13 +360,37 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
             if (span_hi > tile_hi) span_hi = tile_hi;
             if (span_hi > L - 1) span_hi = L - 1;
 
-            // -- scratch for the row phase
-            first_s[lane] = valid ? first : 0x7fffffff;
-            if (lane == 63) first_s[64] = valid ? pos + total_r : 0x7fffffff;
-            ri_s[lane] = rfirst;
-            // bit 4: an insert or a deletion follows, so the last base of this match run anchors it (:381-391)
-            op_s[lane] = op | ((next_op == OP_I || next_op == OP_D) ? 16 : 0);
+            // -- scratch for the row phase.  Every row of the span belongs to the reference-consuming operation that covers it:
+            //    those operations are compacted, in order, into {first row, read index there, last row, code | anchoring bit}
+            //    entries, and each marks the row where its share of the span starts in a 512-bit mask.  A row's owner is then
+            //    the number of marks at or before it (one broadcast read of the mask + mbcnt) instead of a six-step binary
+            //    search over the first rows -- the kernel is bound by what it asks of the LDS (16 wave-instructions per 64 rows
+            //    before this, SQ_LDS_IDX_ACTIVE at three quarters of the launch).
+            const int last = first + radv - 1;
+            const bool cons = valid && radv > 0 && last >= span_lo && first <= span_hi;
+            const unsigned long long cm = __ballot(cons);
+            if (lane < 16) mask_s[lane] = 0u;
             __builtin_amdgcn_wave_barrier();
+            if (cons) {
+                const int cidx = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+                // bit 4: an insert or a deletion follows, so the last base of this match run anchors it (:381-391)
+                ent_s[cidx] = make_int4(first, rfirst, last, op | ((next_op == OP_I || next_op == OP_D) ? 16 : 0));
+                const int kk = (first > span_lo ? first : span_lo) - span_lo;
+                atomicOr(&mask_s[kk >> 5], 1u << (kk & 31));
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // -- one match run per lane: its clipped ends into the difference array of its strand, its anchoring last base
+            {
+                const bool match_op = valid && (op == OP_M || op == OP_EQ || op == OP_X) && len > 0;
+                const int lo = first > span_lo ? first : span_lo;
+                const int hi = last < span_hi ? last : span_hi;
+                if (match_op && lo <= hi) {
+                    atomicAdd(&mcov[rev ? 1 : 0][lo - tile_lo], 1);
+                    atomicAdd(&mcov[rev ? 1 : 0][hi + 1 - tile_lo], -1);
+                    if ((next_op == OP_I || next_op == OP_D) && hi == last) atomicAdd(&anch[hi - tile_lo], rev ? 0x10000 : 1);
+                }
+            }
 
             // -- the row phase's loads first: one reference row per lane, UNR rows in flight; owners by binary search over the
             //    scratch, then every quality / base byte load of the (read, tile) is issued before anything waits on one
@@ -334,21 +400,27 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
             bool past = false;
             {
                 unsigned si[UNR];
+                int before = 0;                           // marks in the blocks in front of this one (wave-uniform)
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int p = span_lo + lane + 64 * u;
                     const bool act = p <= span_hi;
-                    // a lane past the span keeps a row of its own (its five adds are zeros): equal addresses would serialise in the LDS
+                    // a lane past the span keeps a row of its own (its add is a zero): equal addresses would serialise in the LDS
                     const int pc = act ? p : tile_lo + ((lane + 64 * u) & (TP - 1));
-                    const int j = owner_of_row(first_s, pc);
-                    const int opj = op_s[j], oj = opj & 15;
-                    const int rp = ri_s[j] + (pc - first_s[j]);
+                    const unsigned m_lo = __builtin_amdgcn_readfirstlane(mask_s[2 * u]), m_hi = __builtin_amdgcn_readfirstlane(mask_s[2 * u + 1]);
+                    const unsigned own = ((lane < 32 ? m_lo >> lane : m_hi >> (lane - 32)) & 1u);
+                    int j = before + (int)__builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u)) + (int)own - 1;
+                    before += __popc(m_lo) + __popc(m_hi);
+                    j = (act && j > 0) ? j : 0;
+                    const int4 e = ent_s[j];
+                    const int oj = e.w & 15;
+                    const int rp = e.y + (pc - e.x);
                     const bool m = act && (oj == OP_M || oj == OP_EQ || oj == OP_X);
                     const bool inb = (unsigned)rp < (unsigned)rd.slen;
                     past |= m && !inb;
                     is_m[u] = m && inb;
                     is_d[u] = act && oj == OP_D;
-                    anchored[u] = (opj & 16) && pc + 1 == first_s[j + 1];
+                    anchored[u] = (e.w & 16) && pc == e.z;
                     pl[u] = pc - tile_lo;
                     si[u] = is_m[u] ? (unsigned)rp : 0u;       // (a lane without a base loads the read's first byte: no exec mask)
                 }
@@ -423,56 +495,76 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
                 }
             }
 
-            ENC_LAP(2);                               // per-operation section (its loads are the first to be waited for)
-            // -- the rows: match runs (:357-430) and the '*' rows of deletions (:541-551).  Branch-free: every lane issues
-            //    the same five LDS atomics with a 0 / 1 addend (the LDS pipe is 7 % busy, the instruction issue is the
-            //    bound: exec-mask bookkeeping around five `if`s cost more than the idle adds); letters -> columns by
-            //    arithmetic: (c >> 1) & 3 sends A C T G to 0 1 2 3, and the byte of "ACTG" at that index says whether c was one
+            ENC_LAP(2);                               // per-operation section (inserts, deletions, votes)
+            // -- the rows: a base that is a clean match (quality passes, equal to an A/C/G/T reference base) is already counted
+            //    by its run; the '*' column of a deletion's rows (:541-551) is one unconditional add; everything else is queued
             const int strand = rev ? K_REV : K_FWD;
-            bool rare = false;
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const unsigned rb = (unsigned char)ref_s[pl[u]], b = (unsigned char)bv[u];
-                const unsigned ru = rb & 0xDFu, bu = b & 0xDFu;
-                const unsigned ridx = (ru >> 1) & 3u, bidx = (bu >> 1) & 3u;
-                const bool ref_ok = ((0x47544341u >> (ridx * 8)) & 0xFFu) == ru;        // is_acgt(reference base); (a 256-byte LDS table for
-                                                                                         // these ~15 operations measured the same: 2.056 vs 2.046 ms)
-                const unsigned letter = (0x47544341u >> (bidx * 8)) & 0xFFu;
-                const int acgt = (int)(bidx ^ (bidx >> 1));                              // A C G T -> 0 1 2 3
-                const int sym = letter == bu ? acgt : (bu == 'I' ? 4 : (bu == 'D' ? 5 : 6));   // symbol_column's switch
-                const bool q_ok = is_m[u] && qv[u] >= reg.qmin;
-                const bool mism = q_ok && rb != b;                                       // case-sensitive, as the reference compares
-                const bool plain = letter == b;                                          // an upper-case A C G T: tallied on the device
                 const int o = pl[u];
-                atomicAdd(&cnt[K_COV * TP + o], q_ok ? 1 : 0);
-                atomicAdd(&cnt[strand * TP + o], (q_ok && !anchored[u]) ? 1 : 0);
-                atomicAdd(&cnt[(strand + (is_d[u] ? 7 : 1 + sym)) * TP + o], ((is_d[u] || q_ok) && ref_ok) ? 1 : 0);
-                atomicAdd(&cnt[K_SNP * TP + o], mism ? 1 : 0);
-                atomicAdd(&cnt[(K_TAB + (rev ? 4 : 0) + acgt) * TP + o], (mism && plain) ? 1 : 0);
-                rare |= mism && !plain;
-            }
-            if (rare) {                                      // rare alphabet (N, IUPAC, lower case): exact key kept on host
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const unsigned rb = (unsigned char)ref_s[pl[u]], b = (unsigned char)bv[u];
-                    const bool plain = ((0x47544341u >> ((((b & 0xDFu) >> 1) & 3u) * 8)) & 0xFFu) == b;
-                    if (is_m[u] && qv[u] >= reg.qmin && rb != b && !plain) {
-                        const int slot = atomicAdd(&a.counters[CT_OVF], 1);
-                        if (slot < a.ovf_cap) a.ovf[slot] = make_int4(pl[u] + tile_lo, (int)b, rev ? 1 : 0, region);
+                const unsigned rb = (unsigned char)ref_s[o], b = (unsigned char)bv[u];
+                const bool ref_ok = refok_s[o] != 0;
+                const bool q_ok = qv[u] >= reg.qmin;
+                atomicAdd(&cnt[(strand + 7) * TP + o], (is_d[u] && ref_ok) ? 1 : 0);
+                const bool other = is_m[u] && !(q_ok && ref_ok && rb == b);
+                const unsigned long long m = __ballot(other);
+                if (m) {                                  // (wave-uniform)
+                    const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (other)
+                        xq_w[slot] = (unsigned)o | (b << 9) | (q_ok ? 1u << 17 : 0u) | (anchored[u] ? 1u << 18 : 0u) | (rev ? 1u << 19 : 0u);
+                    qn += __popcll(m);
+                    __builtin_amdgcn_wave_barrier();
+                    if (qn >= 64) {
+                        drain(64);
+                        const unsigned moved = lane < qn - 64 ? xq_w[64 + lane] : 0u;
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < qn - 64) xq_w[lane] = moved;
+                        qn -= 64;
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            ENC_LAP(3);                               // row phase
+            ENC_LAP(3);                               // row phase (first use of the loaded bytes: their latency lands here)
             pos += total_r;
             ri += wave_total(qinc);
             if (pos > live_max) break;
         }
         rec = rec_next;
     }
+    if (qn > 0) drain(qn);
     ENC_LAP(4);
     __syncthreads();
     ENC_LAP(5);                                       // waiting for the slowest wave of the tile
+
+    // ---- the runs' share: prefix sums of the difference arrays = match-run coverage per strand and row, minus the anchoring
+    //      last bases for the strand columns; the reference letter's column where the reference base is a letter
+    {
+        const int dF = tid < TP ? mcov[0][tid] : 0, dR = tid < TP ? mcov[1][tid] : 0;
+        int sF = wave_inclusive_sum(dF), sR = wave_inclusive_sum(dR);
+        if (lane == 63) {
+            wtot[0][w] = sF;
+            wtot[1][w] = sR;
+        }
+        __syncthreads();
+        for (int k = 0; k < w; ++k) {
+            sF += wtot[0][k];
+            sR += wtot[1][k];
+        }
+        if (tid < TP) {
+            const int an = anch[tid];
+            cnt[K_COV * TP + tid] += sF + sR;
+            cnt[K_FWD * TP + tid] += sF - (an & 0xffff);
+            cnt[K_REV * TP + tid] += sR - (an >> 16);
+            if (refok_s[tid]) {
+                const unsigned ru = (unsigned char)ref_s[tid] & 0xDFu, ridx = (ru >> 1) & 3u;
+                const int racgt = (int)(ridx ^ (ridx >> 1));
+                cnt[(K_FWD + 1 + racgt) * TP + tid] += sF;
+                cnt[(K_REV + 1 + racgt) * TP + tid] += sR;
+            }
+        }
+    }
+    __syncthreads();
 
     // ---- the tile is complete: per-position pass of generate_summary (:568-654), then one coalesced store --------
     const int idx = tile_lo + tid;
@@ -547,7 +639,7 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
         wave_append_vote(has, v, a.votes_out + reg.vote_base, &a.region_counts[2 * region + 1], 0x7fffffff, lane);
     }
 #ifdef PA_ENC_STAMP
-    ENC_LAP(6);                                       // per-position pass, store, votes
+    ENC_LAP(6);                                       // flush: prefix sums, per-position pass, store, votes
     if (lane == 0)
         for (int k = 0; k < 8; ++k) atomicAdd(&g_enc_cycles[k], lap_acc[k]);
 #endif
