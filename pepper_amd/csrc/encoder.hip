@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
             //    entries, and each marks the row where its share of the span starts in a 512-bit mask.  A row's owner is then
             //    the number of marks at or before it (one broadcast read of the mask + mbcnt) instead of a six-step binary
             //    search over the first rows -- the kernel is bound by what it asks of the LDS (16 wave-instructions per 64 rows
-            //    before this, SQ_LDS_IDX_ACTIVE at three quarters of the launch).
+            //    before this, each a round trip that four waves per SIMD have little to cover with).
             const int last = first + radv - 1;
             const bool cons = valid && radv > 0 && last >= span_lo && first <= span_hi;
             const unsigned long long cm = __ballot(cons);
