@@ -49,6 +49,8 @@ def build_io(force=False, verbose=False):
     tmp = f"{IO_LIB}.{os.getpid()}.tmp"
     cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", tmp, src, bam, bld, cnd, f"-I{inc}", f"-L{lib}",
            "-lhdf5", "-lz", f"-Wl,-rpath,{lib}"]
+    if os.path.exists(os.path.join(inc, "libdeflate.h")) and os.path.exists(os.path.join(lib, "libdeflate.so")):
+        cmd.append("-ldeflate")       # bamio.cpp inflates BGZF blocks with it when the header is there (as htslib does)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     try:
