@@ -259,6 +259,17 @@ bool load_bai(pa_bam* b, const std::string& path) {
 }
 
 const char kSeqNt16[] = "=ACMGRSVTWYHKDBN";
+struct SeqPairs {                         // byte of two 4-bit codes -> its two letters (first base in the high nibble)
+    uint16_t t[256];
+    SeqPairs() {
+        for (int b = 0; b < 256; ++b) {
+            const char two[2] = {kSeqNt16[b >> 4], kSeqNt16[b & 15]};
+            std::memcpy(&t[b], two, 2);
+        }
+    }
+    const uint16_t& operator[](uint8_t b) const { return t[b]; }
+};
+const SeqPairs kSeqPairs;
 
 int aux_size(uint8_t t) {
     switch (t) {
@@ -531,6 +542,10 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
         const uint8_t* seqi = R + o_seq;
         const uint8_t* qual = R + o_qual;
         const size_t cig0 = rs.cigar_op.size();
+        if (rs.cigar_op.capacity() < cig0 + (n_cig - k0)) {
+            rs.cigar_op.reserve(2 * (cig0 + (n_cig - k0)));
+            rs.cigar_len.reserve(2 * (cig0 + (n_cig - k0)));
+        }
         int64_t pos_start = -1, pos_end = -1;
         // the kept runs are decoded into a scratch row of the handle (4-bit codes -> upper-case letters two at a time,
         // qualities copied) and appended to the set when the read is done: what is kept is a region's worth of a read that
@@ -542,17 +557,12 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
         char* seq_out = b->scratch_seq.data();
         uint8_t* qual_out = b->scratch_qual.data();
         size_t written = 0;
+        // What is kept of a read is ONE stretch of its bases: from the first base inside the region on, match runs and the
+        // inserts / soft clips behind them follow each other in the read until the region ends (deletions and skips hold no
+        // bases).  The runs are therefore only counted here and the stretch is decoded in one go below.
+        int64_t first_idx = -1;
         auto push_run = [&](int64_t idx, int64_t count) {
-            char* out = seq_out + written;
-            int64_t i = 0;
-            if ((idx & 1) && count > 0) { out[0] = kSeqNt16[seqi[idx >> 1] & 15]; i = 1; }
-            for (; i + 1 < count; i += 2) {
-                const uint8_t byte = seqi[(idx + i) >> 1];
-                out[i] = kSeqNt16[byte >> 4];
-                out[i + 1] = kSeqNt16[byte & 15];
-            }
-            if (i < count) out[i] = kSeqNt16[seqi[(idx + i) >> 1] >> 4];
-            std::memcpy(qual_out + written, qual + idx, (size_t)count);
+            if (first_idx < 0) first_idx = idx;
             written += (size_t)count;
         };
         for (uint32_t k = k0; k < n_cig; ++k) {
@@ -612,6 +622,15 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
             rs.cigar_op.resize(cig0);
             rs.cigar_len.resize(cig0);
             continue;
+        }
+        {   // 4-bit codes -> upper-case letters, two per byte through a pair table; qualities as they are
+            int64_t i = 0, idx = first_idx;
+            const int64_t count = (int64_t)written;
+            if ((idx & 1) && count > 0) { seq_out[0] = kSeqNt16[seqi[idx >> 1] & 15]; i = 1; }
+            const uint8_t* src = seqi + ((idx + i) >> 1);
+            for (; i + 1 < count; i += 2, ++src) std::memcpy(seq_out + i, &kSeqPairs[*src], 2);
+            if (i < count) seq_out[i] = kSeqNt16[*src >> 4];
+            std::memcpy(qual_out, qual + first_idx, written);
         }
         rs.seq.insert(rs.seq.end(), seq_out, seq_out + written);
         rs.qual.insert(rs.qual.end(), qual_out, qual_out + written);
