@@ -243,10 +243,15 @@ __device__ __noinline__ PassOut score_pass_reg(const int8_t* __restrict__ ref, i
 
 constexpr int REG_ROWS = 64 * 24;          // longest padded read the register-resident pass takes
 
+// MAXN: the longest strip (rows per lane) this instantiation carries in registers.  The strip's arrays set the kernel's
+// register count -- 280 with all twelve sizes in one kernel, i.e. ONE wavefront per SIMD for every read, although the reads of
+// a polish region (clipped to a ~1.2 kb window: 20 rows per lane) need 2/3 of that; the host picks the instantiation from the
+// longest read of the call, so ordinary calls run with two wavefronts per SIMD.
+template <int MAXN>
 __device__ PassOut score_pass_any(uint32_t* he, const int8_t* __restrict__ ref, int first, int step, int count,
                                   const int8_t* __restrict__ read, int rfirst, int rstep, int m, int lanes, int terminate) {
     const int rows = ((m + lanes - 1) / lanes) * lanes, R = (rows + 63) >> 6;
-#define PA_PASS(N) return score_pass_reg<N>(ref, first, step, count, read, rfirst, rstep, m, lanes, terminate)
+#define PA_PASS(N) if constexpr (MAXN >= N) return score_pass_reg<N>(ref, first, step, count, read, rfirst, rstep, m, lanes, terminate); else break
     switch ((R + 1) >> 1) {
         case 0: case 1: PA_PASS(2);
         case 2: PA_PASS(4);
@@ -266,7 +271,8 @@ __device__ PassOut score_pass_any(uint32_t* he, const int8_t* __restrict__ ref, 
     return score_pass(he, ref, first, step, count, read, rfirst, rstep, m, lanes, terminate);
 }
 
-__global__ __launch_bounds__(64) void sw_ends_kernel(Job* __restrict__ jobs, const int8_t* __restrict__ ref,
+template <int MAXN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MAXN <= 20 ? 2 : 1, MAXN <= 20 ? 2 : 1))) void sw_ends_kernel(Job* __restrict__ jobs, const int8_t* __restrict__ ref,
                                                      const int8_t* __restrict__ seq) {
     extern __shared__ uint32_t he[];
     Job& J = jobs[blockIdx.x];
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(64) void sw_ends_kernel(Job* __restrict__ jobs, con
         if (pass == 1 && !f.overflow) continue;
         if (pass == 2 && !(f.score > 0 && f.ref >= 0)) continue;
         const bool rev = pass == 2;
-        const PassOut o = score_pass_any(he, rf, rev ? f.ref : 0, rev ? -1 : 1, rev ? f.ref + 1 : n, rd, rev ? f.read : 0,
+        const PassOut o = score_pass_any<MAXN>(he, rf, rev ? f.ref : 0, rev ? -1 : 1, rev ? f.ref + 1 : n, rd, rev ? f.read : 0,
                                          rev ? -1 : 1, rev ? f.read + 1 : m, (pass == 1 || (rev && wide)) ? 8 : 16,
                                          rev ? f.score : -1);
         if (rev) {
@@ -750,7 +756,12 @@ int pa_realigner_align_windows(pa_realigner* r, int32_t n_windows, const char* r
         const int rows = ((max_m + 15) / 16) * 16, R = (rows + 63) / 64;
         const size_t lds = rows > REG_ROWS ? (size_t)64 * R * 4 : 0;
         RA_HIP(hipEventRecord(r->ev[0], r->stream));
-        hipLaunchKernelGGL(sw_ends_kernel, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq);
+        // the instantiation whose register strip just covers the longest read of the call (fewer registers: more wavefronts
+        // per SIMD); a read beyond 24 rows per lane takes the LDS form inside the widest one
+        if (R <= 12) hipLaunchKernelGGL(sw_ends_kernel<12>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq);
+        else if (R <= 16) hipLaunchKernelGGL(sw_ends_kernel<16>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq);
+        else if (R <= 20) hipLaunchKernelGGL(sw_ends_kernel<20>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq);
+        else hipLaunchKernelGGL(sw_ends_kernel<24>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq);
         RA_HIP(hipGetLastError());
         RA_HIP(hipEventRecord(r->ev[1], r->stream));
     }
