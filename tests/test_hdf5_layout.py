@@ -4,6 +4,7 @@ by tests/golden/make_golden_hdf5.py), and the reader must read the reference's f
 import os
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -499,3 +500,42 @@ def test_builder_image_files_equal_the_library_files(tmp_path, monkeypatch):
                   "k = sorted(f['summaries'])[3]\nassert f['summaries'][k]['image'].shape == (1000, 10)\nprint('fine')\n")
         r = subprocess.run(["/opt/conda/bin/python3.9", "-c", script, paths[True]], capture_output=True, text=True)
         assert r.returncode == 0 and "fine" in r.stdout, r.stderr[-3000:]
+
+
+def test_direct_chunk_reads_survive_damaged_metadata(tmp_path):
+    """The locator walks file offsets it read from the file: on a damaged file it must answer "don't know" (and leave the
+    chunk to libhdf5, which then reports the damage) or read what is there -- never run outside the mapping.  Random 8-byte
+    overwrites all over a small image file, in a child process so that a crash would be seen as one."""
+    n, seq, feat = 300, 64, 10
+    rng = np.random.default_rng(0)
+    im = rng.integers(0, 255, (n, seq, feat), dtype=np.uint8)
+    pos = np.tile(np.arange(seq, dtype=np.int64), (n, 1))
+    src = str(tmp_path / "src.hdf")
+    with h5.File(src, "w") as f:
+        for b in range(0, n, 50):
+            f.write_polish_image_chunks(["ctg_%d_%d_%d" % (b, b + 1, k) for k in range(50)], "ctg", b, b + 1, np.arange(50, dtype=np.int64),
+                                        im[b:b + 50], np.zeros((50, seq), np.uint8), pos[b:b + 50], pos[b:b + 50] % 3)
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from pepper_amd import h5\n"
+        "raw = open(sys.argv[1], 'rb').read()\n"
+        "with h5.File(sys.argv[1]) as f: names = f.keys('summaries')\n"
+        "outcomes = []\n"
+        "for seed in range(12):\n"
+        "    rng = np.random.default_rng(seed)\n"
+        "    bad = bytearray(raw)\n"
+        "    for _ in range(400):\n"
+        "        at = int(rng.integers(96, len(bad) - 8))\n"
+        "        bad[at:at + 8] = rng.integers(0, 256, 8, dtype=np.uint8).tobytes()\n"
+        "    path = sys.argv[1] + '.bad'\n"
+        "    open(path, 'wb').write(bad)\n"
+        "    try:\n"
+        "        with h5.File(path) as f:\n"
+        "            f.read_polish_chunks(names, %d, %d)\n"
+        "        outcomes.append('read')\n"
+        "    except h5.H5Error:\n"
+        "        outcomes.append('error')\n"
+        "print('survived', outcomes.count('read'), outcomes.count('error'))\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), seq, feat))
+    r = subprocess.run([sys.executable, "-c", script, src], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "survived" in r.stdout, (r.returncode, r.stderr[-2000:])
