@@ -141,6 +141,18 @@ struct pa_h5_builder {
         return 0;
     }
 
+    // bytes at a place reserved earlier (string collections, the superblock); short writes and EINTR carried on from
+    bool write_at(const void* data, size_t bytes, uint64_t at) {
+        size_t done = 0;
+        while (done < bytes) {
+            const ssize_t w = ::pwrite(fd, static_cast<const char*>(data) + done, bytes - done, (off_t)(at + done));
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) return false;
+            done += (size_t)w;
+        }
+        return true;
+    }
+
     // raw data goes out in 8-byte aligned runs; -> its file address
     uint64_t append(const void* data, uint64_t bytes) {
         const uint64_t pad = (8 - pos % 8) % 8;
@@ -296,8 +308,7 @@ struct pa_h5_builder {
                 at += 16 + (hc.objects[k].size() + 7) / 8 * 8;
             }
             put64(block, at + 8, hc.size - at);               // object 0: the free space
-            if (pwrite(fd, block.data(), block.size(), (off_t)hc.addr) != (ssize_t)block.size())
-                return fail("cannot write a string collection of '" + path + "'");
+            if (!write_at(block.data(), block.size(), hc.addr)) return fail("cannot write a string collection of '" + path + "'");
         }
         return 0;
     }
@@ -452,7 +463,7 @@ struct pa_h5_builder {
         std::memcpy(sb + 72, &one, 4);
         std::memcpy(sb + 80, &tree, 8);
         std::memcpy(sb + 88, &heap, 8);
-        if (pwrite(fd, sb, sizeof sb, 0) != (ssize_t)sizeof sb) return fail("cannot write the superblock of '" + path + "'");
+        if (!write_at(sb, sizeof sb, 0)) return fail("cannot write the superblock of '" + path + "'");
         return 0;
     }
 };
@@ -537,7 +548,7 @@ int pa_h5_builder_write(pa_h5_builder* b, const char* path, int32_t type_code, i
     while (!full.empty() && full[0] == '/') full.erase(0, 1);
     const size_t cut = full.rfind('/');
     const std::string name = cut == std::string::npos ? full : full.substr(cut + 1);
-    if (name.empty()) return fail(std::string("bad dataset path '") + path + "'");
+    if (name.empty() || full.find("//") != std::string::npos) return fail(std::string("bad dataset path '") + path + "'");
     const uint32_t g = cut == std::string::npos ? 0 : b->group(full.substr(0, cut));
     if (b->has_kid(g, name)) return fail(std::string("cannot create dataset '") + path + "' (already exists)");
     uint64_t d[4] = {0, 0, 0, 0}, count = 1;
@@ -554,11 +565,12 @@ int pa_h5_builder_write(pa_h5_builder* b, const char* path, int32_t type_code, i
 
 int pa_h5_builder_write_string(pa_h5_builder* b, const char* path, const char* text) {
     if (!b || !path || !text) return fail("bad argument");
+    if (b->failed) return fail("the file has a failed write behind it");
     std::string full(path);
     while (!full.empty() && full[0] == '/') full.erase(0, 1);
     const size_t cut = full.rfind('/');
     const std::string name = cut == std::string::npos ? full : full.substr(cut + 1);
-    if (name.empty()) return fail(std::string("bad dataset path '") + path + "'");
+    if (name.empty() || full.find("//") != std::string::npos) return fail(std::string("bad dataset path '") + path + "'");
     const uint32_t g = cut == std::string::npos ? 0 : b->group(full.substr(0, cut));
     if (b->has_kid(g, name)) return fail(std::string("cannot create dataset '") + path + "' (already exists)");
     b->vlen_string(g, name, text);

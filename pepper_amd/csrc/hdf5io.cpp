@@ -158,6 +158,7 @@ public:
         if ((cv & 0x0f) != 0 || (cv >> 4) < 1 || (cv >> 4) > 3) return false;
         if (m.dtype[1] & 0x01) return false;                                  // big-endian
         if (rd32(m.dtype + 4) != elem) return false;
+        if (m.dtype_len >= 12 && (rd16(m.dtype + 8) != 0 || rd16(m.dtype + 10) != 8 * elem)) return false;   // bit offset, precision
         // dataspace: simple, no permutation; product of the dimensions == count
         if (m.dspace_len < 8) return false;
         const uint8_t sv = m.dspace[0], rank = m.dspace[1];
@@ -296,7 +297,7 @@ private:
                 const uint8_t* entry = p_ + kid + 8 + 40ull * e;
                 const char* name = heap_name(hdata, hsize, rd64(entry));
                 const uint64_t header = rd64(entry + 8);
-                if (!name || !in(header, 16)) return false;
+                if (!name || !in(header, 16) || out.size() >= (1u << 26)) return false;     // (a tree that loops: don't know)
                 out.emplace_back(name, header);
             }
         }

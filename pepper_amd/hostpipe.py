@@ -550,16 +550,16 @@ def polish_lanes(files, output_stem, predict_block, lanes, block=8192, seq_len=1
             # with passes under way, do not sleep on the queue past the moment the oldest one is done: its slots (freed by
             # the writers) may be what the readers are waiting for
             msg = _next_message(result_q, procs, poll=0.002 if inflight else None)
-            if msg is None:
-                while inflight and inflight[0][0].done():
-                    retire()
-                continue
-            handle(msg)
-            while True:                                   # whatever else has arrived by now travels with it
-                try:
-                    handle(result_q.get_nowait())
-                except queue.Empty:
-                    break
+            if msg is not None:
+                handle(msg)
+                while True:                               # whatever else has arrived by now travels with it
+                    try:
+                        handle(result_q.get_nowait())
+                    except queue.Empty:
+                        break
+            # (after a message as well as after a quiet poll: a steady trickle of blocks must not keep a finished pass waiting)
+            while inflight and inflight[0][0].done():
+                retire()
         _trace(t_begin, "all lanes written")
         if spans and os.environ.get("PEPPER_AMD_LANE_TRACE"):
             busy = sum(b - a for a, b, _ in spans)

@@ -423,6 +423,16 @@ def test_prediction_builder_writes_the_file_libhdf5_writes(tmp_path):
         with h5.PredictionBuilder(str(tmp_path / "dup.hdf")) as f:
             f["a/b"] = np.arange(3)
             f["a/b"] = np.arange(3)
+    # a path with an empty component is an error (libhdf5 would collapse it; a group without a name must not get into a file)
+    with h5.PredictionBuilder(str(tmp_path / "paths.hdf")) as b:
+        for bad in ("a//b", "a/b/", "/"):
+            with pytest.raises(h5.H5Error, match="bad dataset path"):
+                b[bad] = np.arange(3)
+            with pytest.raises(h5.H5Error, match="bad dataset path"):
+                b[bad] = "text"
+        b["/a/b"] = np.arange(3)
+    with h5.File(str(tmp_path / "paths.hdf")) as f:
+        assert f.keys("/") == ["a"] and f.keys("a") == ["b"] and f["a/b"].tolist() == [0, 1, 2]
     with h5.PredictionBuilder(str(tmp_path / "empty.hdf")):
         pass
     with h5.File(str(tmp_path / "empty.hdf")) as f:
