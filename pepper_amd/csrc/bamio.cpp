@@ -623,6 +623,14 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
             rs.cigar_len.resize(cig0);
             continue;
         }
+        if (first_idx < 0 || (uint64_t)first_idx + written > l_seq) {
+            // the CIGAR walks over more bases than the record holds: a record without its bases (SEQ '*', l_seq 0 -- legal,
+            // and nothing to pile up) is left out; anything else is a corrupt record, not something to read past
+            rs.cigar_op.resize(cig0);
+            rs.cigar_len.resize(cig0);
+            if (l_seq == 0) continue;
+            return bam_fail(-6, "corrupt BAM record (CIGAR longer than the read)");
+        }
         {   // 4-bit codes -> upper-case letters, two per byte through a pair table; qualities as they are
             int64_t i = 0, idx = first_idx;
             const int64_t count = (int64_t)written;

@@ -199,3 +199,26 @@ def test_corrupt_block_is_an_error_not_end_of_file(tmp_path):
     with pytest.raises(BamError):
         bam.get_reads("ctg", 0, 30000, False, 0, 0)
     bam.close()
+
+
+def test_records_without_their_bases(tmp_path):
+    """SEQ '*' (l_seq 0 beside a CIGAR: legal, samtools writes it for some supplementary / secondary records) holds nothing to
+    pile up: the record is left out.  A CIGAR that walks over more bases than the record holds is a corrupt record and fails the
+    query -- neither may read past the record."""
+    ok = dict(name="ok", pos=100, cigar=[(0, 50)], seq="ACGTA" * 10, qual=[30] * 50)
+    bare = dict(name="bare", pos=120, cigar=[(0, 80)], seq="", qual=[])
+    path = str(tmp_path / "bare.bam")
+    bu.write_bam(path, [("ctg", 1000)], {0: [ok, bare, dict(ok, name="ok2", pos=130)]})
+    bam = BAM_handler(path)
+    got = bam.get_reads("ctg", 0, 1000, False, 0, 0)
+    assert [r.query_name for r in got] == ["ok", "ok2"]
+    compare(got, bu.restated_get_reads([ok, dict(ok, name="ok2", pos=130)], 0, 1000, False, 0))
+    bam.close()
+    short = dict(name="short", pos=120, cigar=[(0, 80)], seq="ACGT" * 5, qual=[30] * 20)
+    path = str(tmp_path / "short.bam")
+    bu.write_bam(path, [("ctg", 1000)], {0: [ok, short]})
+    bam = BAM_handler(path)
+    with pytest.raises(BamError, match="CIGAR longer than the read"):
+        bam.get_reads("ctg", 0, 1000, False, 0, 0)
+    compare(bam.get_reads("ctg", 0, 115, False, 0, 0), bu.restated_get_reads([ok], 0, 115, False, 0))   # the handle is still usable
+    bam.close()
