@@ -625,11 +625,13 @@ def secondary_block(args):
         "mode": d["mode"], "scratch": scratch or "system temporary directory",
         "note": "pepper_amd.variant.RunInference.run_inference: image HDF5 files -> predictions HDF5 (libhdf5 reads, H2D, forward, D2H, "
                 "per-batch prediction groups), SURVEY.md 8(d) 'a second number including I/O'"}
+    # three runs over the same files, the median reported: the job is 2-3 s of sixteen host CPUs' work beside the device passes and
+    # its time varies by +-15 % from run to run on one box (profiles/r03_polish_pipeline_runs_ab.json)
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_polish_pipeline.py"), "--chunks", "262144", "--files", "32",
-                   "--workers", "0"] + extra, 400)
+                   "--workers", "0,0,0", "--median"] + extra, 400)
     out["call_consensus_hdf5"] = d if "error" in d else {
         "value": d["chunks_per_s"], "unit": "chunks/s", "windows_per_s": d["windows_per_s"], "chunks": d["chunks"], "seconds": d["seconds"],
-        "mode": d["mode"], "scratch": scratch or "system temporary directory",
+        "runs_chunks_per_s": d.get("runs_chunks_per_s"), "mode": d["mode"], "scratch": scratch or "system temporary directory",
         "note": "pepper_amd.polish.call_consensus.call_consensus: image HDF5 files -> predictions HDF5, start-up included (chunk reads "
                 "bypass libhdf5, prediction files laid out by h5build.cpp, blocks of several reader lanes per device pass)"}
     return out

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--files", type=int, default=16)
     ap.add_argument("--workers", default="0", help="comma list of num_workers values (lanes); -1 = the in-process loop")
     ap.add_argument("--dir", default=None, help="parent of the scratch directory (default: the system's temporary directory; /dev/shm = tmpfs)")
+    ap.add_argument("--median", action="store_true", help="after the per-run lines, one more line: the median run, with runs_chunks_per_s")
     args = ap.parse_args()
     n = args.chunks // (2 * args.files) * 2 * args.files
     tmp = tempfile.mkdtemp(dir=args.dir)
@@ -49,17 +50,23 @@ def main():
         sd = synthetic.polish_state_dict(seed=0)
         model_path = os.path.join(tmp, "polish.pkl")
         torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
+        records = []
         for k, w in enumerate(int(v) for v in str(args.workers).split(",")):
             os.environ["PEPPER_AMD_NO_LANES"] = "1" if w < 0 else "0"
             pred = os.path.join(tmp, "pred%d" % k)
             t0 = time.perf_counter()
             call_consensus(img_dir, model_path, 512, max(w, 0), pred, "0", True, 4)
             dt = time.perf_counter() - t0
-            print(json.dumps({"metric": "call_consensus HDF5 -> HDF5, 1 GPU", "chunks": n, "windows": 19 * n, "image_files": args.files,
-                              "num_workers": w, "mode": "in-process loop" if w < 0 else "lanes",
-                              "prediction_files": len(os.listdir(pred)), "seconds": round(dt, 3), "chunks_per_s": round(n / dt),
-                              "windows_per_s": round(19 * n / dt), "image_write_seconds": round(t_write, 2),
-                              "host_cpus": os.cpu_count()}), flush=True)
+            records.append({"metric": "call_consensus HDF5 -> HDF5, 1 GPU", "chunks": n, "windows": 19 * n, "image_files": args.files,
+                            "num_workers": w, "mode": "in-process loop" if w < 0 else "lanes",
+                            "prediction_files": len(os.listdir(pred)), "seconds": round(dt, 3), "chunks_per_s": round(n / dt),
+                            "windows_per_s": round(19 * n / dt), "image_write_seconds": round(t_write, 2),
+                            "host_cpus": os.cpu_count()})
+            print(json.dumps(records[-1]), flush=True)
+            shutil.rmtree(pred, ignore_errors=True)          # (the next run's files take its place in the scratch directory)
+        if args.median and records:
+            middle = sorted(records, key=lambda r: r["seconds"])[len(records) // 2]
+            print(json.dumps(dict(middle, runs_chunks_per_s=[r["chunks_per_s"] for r in records])), flush=True)
     finally:
         shutil.rmtree(tmp)
 
