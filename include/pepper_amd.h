@@ -73,7 +73,9 @@ int pa_variant_forward_device_f32(pa_variant_model* m, const float* images, int6
                                   float* probs, float* logits);
 /* Same with HOST pointers, any n: the call is cut into device passes of max_chunk windows and the H2D copy of
  * pass i+1 / the D2H copy of pass i-1 run on their own streams beside the kernels of pass i (asynchronous only from
- * page-locked buffers, see pa_host_register); returns when the results are in `probs`.
+ * page-locked buffers, see pa_host_register); returns when the results are in `probs`.  A call that fails half way
+ * returns only after what it had queued has drained: nothing reads or writes the caller's buffers after the return
+ * (the same holds for pa_polish_predict_host / _parts).
  * replaces predict_distributed_gpu.py:60-67 (.cuda() ... .cpu() per batch). */
 int pa_variant_forward_host(pa_variant_model* m, const int8_t* images, int64_t n, float* probs,
                             float* logits);

@@ -145,6 +145,13 @@ struct ModelBase {
         pipe.ready = true;
         return PA_OK;
     }
+    // after a host-buffer call has failed half way: what it queued must not still be reading or writing the caller's buffers once
+    // the call has returned (the error text of the failure is kept: nothing here reports)
+    void quiesce() {
+        if (pipe.h2d) (void)hipStreamSynchronize(pipe.h2d);
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (pipe.d2h) (void)hipStreamSynchronize(pipe.d2h);
+    }
     void pipe_destroy() {
         if (!pipe.ready) return;
         for (int k = 0; k < 2; ++k) {
@@ -761,11 +768,7 @@ int pa_variant_forward_device_f32(pa_variant_model* m, const float* images, int6
     return variant_forward(m, pa::A_F32_SCALAR, images, 4, n, probs, logits);
 }
 
-int pa_variant_forward_host(pa_variant_model* m, const int8_t* images, int64_t n, float* probs,
-                            float* logits) {
-    if (!m || m->magic != 0x50414d44) return fail(PA_ERR_INVALID, "bad model handle");
-    if (n < 0 || (n > 0 && (!images || !probs))) return fail(PA_ERR_INVALID, "null buffer");
-    if (n == 0) return PA_OK;
+static int variant_forward_host_run(pa_variant_model* m, const int8_t* images, int64_t n, float* probs, float* logits) {
     HIP_TRY(hipSetDevice(m->device));
     if (int rc = m->pipe_init()) return rc;
     const size_t per = (size_t)m->cfg.window * m->cfg.image_features;
@@ -799,6 +802,16 @@ int pa_variant_forward_host(pa_variant_model* m, const int8_t* images, int64_t n
     HIP_TRY(hipStreamSynchronize(pp.d2h));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return PA_OK;
+}
+
+int pa_variant_forward_host(pa_variant_model* m, const int8_t* images, int64_t n, float* probs,
+                            float* logits) {
+    if (!m || m->magic != 0x50414d44) return fail(PA_ERR_INVALID, "bad model handle");
+    if (n < 0 || (n > 0 && (!images || !probs))) return fail(PA_ERR_INVALID, "null buffer");
+    if (n == 0) return PA_OK;
+    const int rc = variant_forward_host_run(m, images, n, probs, logits);
+    if (rc != PA_OK) m->quiesce();
+    return rc;
 }
 
 }  // extern "C"
@@ -1083,8 +1096,8 @@ int pa_polish_predict_device(pa_polish_model* m, const uint8_t* images, int64_t 
 // One or several host blocks as ONE sequence of device passes: the polish kernels give a workgroup 128 chunks of one
 // direction and walk their time steps in sequence, so a pass costs about the same for 2 048 chunks as for 16 384 -- callers
 // that hold their chunks in several buffers (the reader lanes' slots, pepper_amd/hostpipe.py) hand them over together.
-static int polish_predict_host_impl(pa_polish_model* m, int32_t n_parts, const uint8_t* const* images, const int64_t* counts,
-                                    uint8_t* const* labels, uint8_t* const* phred, float* acc) {
+static int polish_predict_host_run(pa_polish_model* m, int32_t n_parts, const uint8_t* const* images, const int64_t* counts,
+                                   uint8_t* const* labels, uint8_t* const* phred, float* acc) {
     int64_t n = 0;
     for (int32_t p = 0; p < n_parts; ++p) {
         if (counts[p] < 0 || (counts[p] > 0 && (!images[p] || !labels[p] || !phred[p]))) return fail(PA_ERR_INVALID, "null buffer");
@@ -1150,6 +1163,13 @@ static int polish_predict_host_impl(pa_polish_model* m, int32_t n_parts, const u
     HIP_TRY(hipStreamSynchronize(pp.d2h));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return PA_OK;
+}
+
+static int polish_predict_host_impl(pa_polish_model* m, int32_t n_parts, const uint8_t* const* images, const int64_t* counts,
+                                    uint8_t* const* labels, uint8_t* const* phred, float* acc) {
+    const int rc = polish_predict_host_run(m, n_parts, images, counts, labels, phred, acc);
+    if (rc != PA_OK) m->quiesce();
+    return rc;
 }
 
 int pa_polish_predict_host(pa_polish_model* m, const uint8_t* images, int64_t n, uint8_t* labels,
