@@ -38,6 +38,7 @@ SYMBOLS = [
                                          c_void_p, ctypes.POINTER(c_void_p)]),
     ("pa_variant_destroy", None, [c_void_p]),
     ("pa_variant_overflow_rows", ctypes.c_int, [c_void_p, ctypes.POINTER(c_int64)]),
+    ("pa_variant_split_fallbacks", ctypes.c_int, [c_void_p, ctypes.POINTER(c_int64)]),
     ("pa_variant_forward_device", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     ("pa_variant_forward_device_f32", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     ("pa_variant_forward_host", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

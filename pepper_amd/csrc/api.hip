@@ -491,6 +491,21 @@ struct pa_variant_model : ModelBase {
     DevBuf *mlp_w = nullptr, *mlp_b = nullptr;   // linear_2..5 as h2 fragments + their biases (mlp_h2.hip)
     DevBuf *mlp_w32 = nullptr;   // device array of the four f32 weight pointers + the out-of-range row counter behind them
     DevBuf *xp, *ya, *yb, *l1, *l2, *stage_in[2], *stage_p[2], *stage_l[2];
+    // Calls of at most 512 windows (the reference's DataLoader batch) run their step loops with the hidden units of a 32-row
+    // tile split over eight workgroups that exchange h_t through memory every step (rnn_h2.hip lstm_rec_h2_split_kernel;
+    // DESIGN.md 6).  The eight must be resident together, which nothing guarantees when other kernels hold the CUs (other
+    // handles, other processes): a group that does not meet within ~25 ms gives up, the call is then run again with the
+    // ordinary small-call schedule (same results, the caller sees nothing but the time) and the handle leaves the split
+    // alone for its next `US_HOLDOFF` small calls.  PA_UNIT_SPLIT=0: never.
+    bool unit_split = true;
+    int split_holdoff = 0;            // small calls still to run without the split after a group did not meet
+    int64_t split_fallbacks = 0;      // calls that were run again (pa_variant_split_fallbacks)
+    int split_sabotage = 0;           // PA_UNIT_SPLIT_SABOTAGE=n (tests): in the next n split launches one member never arrives
+    DevBuf *us_exch = nullptr, *us_cnt = nullptr, *us_failed = nullptr;
+    int* us_host = nullptr;           // page-locked: [0] the kernel's failure flag, [1] the out-of-range row counter before the call
+    ~pa_variant_model() override {
+        if (us_host) (void)hipHostFree(us_host);
+    }
 };
 
 extern "C" {
@@ -523,6 +538,8 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     if (const char* e = getenv("PA_FUSE_DEC")) m->fuse_dec = e[0] != '0';
     if (const char* e = getenv("PA_SMALL_BATCH")) m->small_batch = atoll(e);
     if (const char* e = getenv("PA_SMALL_ROWS")) m->small_rows = atoll(e);
+    if (const char* e = getenv("PA_UNIT_SPLIT")) m->unit_split = e[0] != '0';
+    if (const char* e = getenv("PA_UNIT_SPLIT_SABOTAGE")) m->split_sabotage = atoi(e);
     int rc = init_base(m, cfg->device, hip_stream);
     const int H = m->H;
     for (int mod = 0; mod < 2 && rc == PA_OK; ++mod)
@@ -582,6 +599,7 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     }
     m->xp = m->new_buf(); m->ya = m->new_buf(); m->yb = m->new_buf();
     m->l1 = m->new_buf(); m->l2 = m->new_buf();
+    m->us_exch = m->new_buf(); m->us_cnt = m->new_buf(); m->us_failed = m->new_buf();
     for (int k = 0; k < 2; ++k) {
         m->stage_in[k] = m->new_buf(); m->stage_p[k] = m->new_buf(); m->stage_l[k] = m->new_buf();
     }
@@ -596,8 +614,10 @@ void pa_variant_destroy(pa_variant_model* m) {
     delete m;
 }
 
+constexpr int US_HOLDOFF = 256;
+
 static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* images, int64_t n,
-                                 float* probs, float* logits) {
+                                 float* probs, float* logits, bool allow_split = true) {
     const int T = m->cfg.window, F = m->cfg.image_features, H = m->H, C = m->cfg.num_classes_type;
     const int64_t np = round_up(n, MT);
     const int NX = 2 * 4 * H;  // both directions' gate pre-activations
@@ -613,7 +633,26 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     // ... and, up to `small_rows` windows, both step loops run with 32-row workgroups (rnn_h2.hip MTILES = 1): a step is one
     // CU's affair, half the rows are half the MFMAs and half the gate phase per step (PA_SMALL_ROWS, 0 = never)
     const bool small_rows = n <= m->small_rows;
-    bool need_xp = !(a_kind == pa::A_I8 && m->fuse_input && !m->rec.empty() && m->rec[0].w_cat != nullptr);
+    // up to 512 windows: every layer as projection GEMM + the unit-split step loop (see pa_variant_model::unit_split)
+    bool unit_split = allow_split && m->unit_split && n <= 512 && H == 256 && m->split_rec && !fuse_dec && m->mlp_w32 != nullptr &&
+                      m->mlp_w != nullptr && C <= 8;
+    for (const RecLayer& r : m->rec) unit_split = unit_split && r.w_hh_h2 != nullptr && r.prescaled;
+    if (unit_split && m->split_holdoff > 0) {
+        --m->split_holdoff;
+        unit_split = false;
+    }
+    int* const ovf_counter = m->mlp_w32 ? reinterpret_cast<int*>(static_cast<char*>(m->mlp_w32->p) + 4 * sizeof(float*)) : nullptr;
+    if (unit_split) {
+        if (int rc = m->us_exch->ensure(pa::lstm_split_exchange_bytes(512))) return rc;
+        if (int rc = m->us_cnt->ensure(pa::lstm_split_counter_bytes(512))) return rc;
+        if (int rc = m->us_failed->ensure(sizeof(int))) return rc;
+        if (!m->us_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->us_host), 2 * sizeof(int), hipHostMallocDefault));
+        HIP_TRY(hipMemsetAsync(m->us_failed->p, 0, sizeof(int), m->stream));
+        // (the out-of-range counter as it is before this call: a pass that gave up feeds garbage to the MLP kernel)
+        HIP_TRY(hipMemcpyAsync(&m->us_host[1], ovf_counter, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    }
+    const bool fuse_in = m->fuse_input && !unit_split;
+    bool need_xp = !(a_kind == pa::A_I8 && fuse_in && !m->rec.empty() && m->rec[0].w_cat != nullptr);
     for (size_t li = 1; li < m->rec.size(); ++li)
         need_xp = need_xp || !(m->split_rec && fuse_dec && m->rec[li].w_cat_dec_h2 != nullptr);
     const size_t xp_bytes = std::max(need_xp ? (size_t)np * T * NX * sizeof(float) : (size_t)0,
@@ -638,7 +677,7 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
         // bias / f32 projection weights matching what the recurrent kernel of this layer expects
         const float* bias_l = (rec_h2 && r.prescaled) ? r.b_in_s->f() : r.b_in->f();
         const float* wih_l = (rec_h2 && r.prescaled) ? r.w_ih_s->f() : r.w_ih->f();
-        if (li == 0 && cur_kind == pa::A_I8 && r.w_cat != nullptr && m->fuse_input) {
+        if (li == 0 && cur_kind == pa::A_I8 && r.w_cat != nullptr && fuse_in) {
             // int8 summaries straight into the recurrent kernel: no Xp round trip
             if (rec_h2 && r.w_cat_h2 != nullptr)
                 LAUNCH_TRY(m, "lstm_rec_h2_fused_in", 2.0 * n * T * (4.0 * H) * (H + r.K) * 2,
@@ -670,7 +709,13 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
                            pa::launch_gemm_nt(cur_kind, cur, cur_ld, wih_l, r.Kp, bias_l, m->xp->f(),
                                               NX, (int)(np * T), NX, r.K, 0, 0, 0, T, (int)n, m->stream));
             }
-            if (rec_h2)
+            if (rec_h2 && unit_split) {
+                const int sabotage = m->split_sabotage > 0 ? 1 : 0;
+                m->split_sabotage -= sabotage;
+                LAUNCH_TRY(m, "lstm_rec_h2_split", 2.0 * n * T * (4.0 * H) * H * 2,
+                           pa::launch_lstm_rec_h2_split(H, m->xp->f(), NX, r.w_hh_h2->p, y, 2 * H, (int)n, T, m->us_exch->p,
+                                                        m->us_cnt->p, static_cast<int*>(m->us_failed->p), m->stream, sabotage));
+            } else if (rec_h2)
                 LAUNCH_TRY(m, "lstm_rec_h2", 2.0 * n * T * (4.0 * H) * H * 2,
                            pa::launch_lstm_rec_h2(H, m->xp->f(), NX, nullptr, 0, nullptr, r.w_hh_h2->p, y, 2 * H, (int)n,
                                                   T, m->stream, r.prescaled, small_rows));
@@ -713,6 +758,17 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
                    pa::launch_mlp_tail_h2(m->l1->f(), m->L1, m->mlp_w->p, m->mlp_b->f(), 4, m->out.w->f(), m->out.b->f(), C,
                                           probs, logits, (int)n, m->stream, static_cast<const float* const*>(m->mlp_w32->p),
                                           reinterpret_cast<int*>(static_cast<char*>(m->mlp_w32->p) + 4 * sizeof(float*))));
+        if (unit_split) {
+            // did every group of the split step loops meet?  (one synchronise per small call: 10-20 us beside its 0.65 ms)
+            HIP_TRY(hipMemcpyAsync(&m->us_host[0], m->us_failed->p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            if (m->us_host[0] != 0) {
+                ++m->split_fallbacks;
+                m->split_holdoff = US_HOLDOFF;
+                HIP_TRY(hipMemcpyAsync(ovf_counter, &m->us_host[1], sizeof(int), hipMemcpyHostToDevice, m->stream));
+                return variant_forward_chunk(m, a_kind, images, n, probs, logits, false);
+            }
+        }
         return PA_OK;
     }
     float* a = m->l1->f();
@@ -743,6 +799,12 @@ static int variant_forward(pa_variant_model* m, int a_kind, const void* images, 
                                            logits ? logits + off * C : nullptr))
             return rc;
     }
+    return PA_OK;
+}
+
+int pa_variant_split_fallbacks(pa_variant_model* m, int64_t* calls) {
+    if (!m || m->magic != 0x50414d44 || !calls) return fail(PA_ERR_INVALID, "bad argument");
+    *calls = m->split_fallbacks;
     return PA_OK;
 }
 

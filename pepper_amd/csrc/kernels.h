@@ -62,6 +62,14 @@ hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, 
                               const void* Wp, void* Y, int ldy, int B, int T, hipStream_t stream,
                               bool prescaled = false, bool small = false);   // small: 32-row workgroups (small calls)
 
+// The step loop of a call of at most 512 windows with a tile's hidden units split over eight workgroups that exchange h_t
+// through `exch` every step (rnn_h2.hip lstm_rec_h2_split_kernel); prescaled weights only.  *failed is set when a group
+// of workgroups did not meet (not resident together): the caller runs the layer again another way.  sabotage: tests only.
+size_t lstm_split_exchange_bytes(int B);
+size_t lstm_split_counter_bytes(int B);
+hipError_t launch_lstm_rec_h2_split(int H, const float* Xp, int ldx, const void* Wp, void* Y, int ldy, int B, int T, void* exch,
+                                    void* counters, int* failed, hipStream_t stream, int sabotage = 0);
+
 // LSTM layer fed by an h2 layer output Xh [B*T, 2H]: projection contracted inside the step loop (weights packed
 // with pack_rec_weights_h2(..., F = 2H, KX = 2H); bias = b_ih + b_hh).
 hipError_t launch_lstm_dec_h2(int H, const void* Xh, int ldxh, const float* bias, const void* Wp, void* Y, int ldy, int B,

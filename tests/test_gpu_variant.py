@@ -15,15 +15,18 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(autouse=True, params=["big-call", "small-call"])
+@pytest.fixture(autouse=True, params=["big-call", "small-call", "no-unit-split"])
 def schedule(request):
-    """Every test of this file under both schedules: calls of at most 3072 windows take the GEMM + Xp decoder and, up to
-    2048 windows, 32-row workgroups in both step loops (api.hip `small_batch`, `small_rows`); larger ones the decoder with
-    the projection inside its step loop and 64-row workgroups.  PA_SMALL_BATCH=0 PA_SMALL_ROWS=0 (read at model creation)
-    give the latter to the small calls the parity tests make."""
-    saved = {k: os.environ.get(k) for k in ("PA_SMALL_BATCH", "PA_SMALL_ROWS")}
+    """Every test of this file under every schedule.  "small-call", the defaults: calls of at most 512 windows run their
+    step loops with a tile's hidden units split over eight workgroups that exchange h_t through memory every step (api.hip
+    `unit_split`), calls of at most 3072 windows take the GEMM + Xp decoder and 32-row workgroups in both step loops
+    (`small_batch`, `small_rows`).  "no-unit-split" (PA_UNIT_SPLIT=0): the latter for the calls of at most 512 windows too.
+    "big-call" (PA_SMALL_BATCH=0 PA_SMALL_ROWS=0 PA_UNIT_SPLIT=0): the schedule of large calls -- the decoder with the
+    projection inside its step loop, 64-row workgroups -- for the small calls the parity tests make.  (All read at model
+    creation.)"""
+    saved = {k: os.environ.get(k) for k in ("PA_SMALL_BATCH", "PA_SMALL_ROWS", "PA_UNIT_SPLIT")}
     for k in saved:
-        if request.param == "big-call":
+        if request.param == "big-call" or (request.param == "no-unit-split" and k == "PA_UNIT_SPLIT"):
             os.environ[k] = "0"
         else:
             os.environ.pop(k, None)
@@ -238,3 +241,36 @@ def test_activations_beyond_the_f16_range_get_the_f32_results(case):
     m0.forward(x)
     assert _overflow_rows(m0) == 0
     m0.close()
+
+
+def test_a_call_whose_workgroups_do_not_meet_is_run_again(monkeypatch, schedule):
+    """The unit-split step loop needs the eight workgroups of a tile resident together; a group that does not meet (here:
+    one member is told never to arrive, PA_UNIT_SPLIT_SABOTAGE) gives up after ~25 ms and the call is run again with the
+    ordinary schedule -- same results, counted in pa_variant_split_fallbacks, and the out-of-range row counter does not see
+    the garbage of the abandoned pass.  The handle then leaves the split alone for 256 small calls and comes back to it."""
+    if schedule != "small-call":
+        pytest.skip("the split is off in this schedule")
+    sd = synthetic.variant_state_dict(seed=5)
+    x = synthetic.variant_windows(700, seed=77)
+    monkeypatch.setenv("PA_UNIT_SPLIT", "0")
+    plain = NativeVariant(sd)                              # never splits
+    monkeypatch.delenv("PA_UNIT_SPLIT")
+    clean = NativeVariant(sd)                              # splits, undisturbed
+    monkeypatch.setenv("PA_UNIT_SPLIT_SABOTAGE", "1")
+    m = NativeVariant(sd)                                  # its first split launch has a member that never arrives
+    monkeypatch.delenv("PA_UNIT_SPLIT_SABOTAGE")
+    n, rows = ctypes.c_int64(-1), ctypes.c_int64(-1)
+    got = m.forward(x[:300])[0]
+    _lib.check(m.lib.pa_variant_split_fallbacks(m.h, ctypes.byref(n)))
+    _lib.check(m.lib.pa_variant_overflow_rows(m.h, ctypes.byref(rows)))
+    assert n.value == 1 and rows.value == 0
+    assert np.array_equal(got, plain.forward(x[:300])[0])            # the second run IS the ordinary schedule
+    assert np.abs(got - clean.forward(x[:300])[0]).max() <= 1e-4
+    for k in range(260):                                   # through the hold-off
+        m.forward(x[k:k + 16])
+    assert np.array_equal(m.forward(x[300:650])[0], clean.forward(x[300:650])[0])    # ... and back on the split path
+    _lib.check(m.lib.pa_variant_split_fallbacks(m.h, ctypes.byref(n)))
+    _lib.check(clean.lib.pa_variant_split_fallbacks(clean.h, ctypes.byref(rows)))
+    assert n.value == 1 and rows.value == 0
+    for h in (plain, clean, m):
+        h.close()

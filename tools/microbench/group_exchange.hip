@@ -16,8 +16,12 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
+// MODE 1, the same exchange WITHOUT the two agent-scope fences: every exchanged word is written and read with a relaxed
+// agent-scope atomic access (global_store / global_load with sc1: coherent per access, no L2 write-back / invalidate of
+// everything else the workgroup has touched), ordered by "stores acknowledged (s_waitcnt vmcnt(0)) -> barrier -> arrive" on
+// the writing side and "counter seen -> barrier -> loads issued" on the reading side.
 // one step: write own slice, fence, arrive, wait, fence, read the other slices (summed into `sink` so nothing is optimised away)
-template <int K>
+template <int K, int MODE>
 __global__ __launch_bounds__(128) void exchange_kernel(uint4* __restrict__ h, unsigned* __restrict__ counters, int steps, int spread,
                                                        int n_groups, unsigned long long* __restrict__ cycles, int* __restrict__ gave_up,
                                                        float* __restrict__ sink) {
@@ -41,8 +45,25 @@ __global__ __launch_bounds__(128) void exchange_kernel(uint4* __restrict__ h, un
     bool ok = true;
     for (int s = 0; s < steps && ok; ++s) {
         uint4* dst = mine + (s & 1) * SLICE16;
-        for (int i = tid; i < SLICE16; i += 128) dst[i] = make_uint4(s, member, i, acc);
-        __threadfence();                                                    // release (agent scope)
+        if (MODE == 0) {
+            for (int i = tid; i < SLICE16; i += 128) dst[i] = make_uint4(s, member, i, acc);
+            __threadfence();                                                // release (agent scope)
+        } else if (MODE == 2) {
+            // as MODE 1 with 16-byte buffer accesses carrying the sc1 bit (what lstm_rec_h2_split_kernel issues)
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0x7fffffff, 0x00020000);
+            for (int i = tid; i < SLICE16; i += 128) {
+                const u4 v = {(unsigned)s, (unsigned)member, (unsigned)i, acc};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, i * 16u, 0, 16);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+        } else {
+            unsigned long long* d64 = reinterpret_cast<unsigned long long*>(dst);
+            for (int i = tid; i < 2 * SLICE16; i += 128)
+                __hip_atomic_store(d64 + i, (unsigned long long)(unsigned)s | ((unsigned long long)(unsigned)(i + acc) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);                                  // every store acknowledged
+        }
         __syncthreads();
         if (tid == 0) {
             atomicAdd(cnt, 1u);
@@ -55,15 +76,48 @@ __global__ __launch_bounds__(128) void exchange_kernel(uint4* __restrict__ h, un
             if (!ok) atomicAdd(gave_up, 1);
         }
         ok = __syncthreads_and(ok);
-        __threadfence();                                                    // acquire
+        if (MODE == 0) __threadfence();                                     // acquire
         for (int m = 0; m < K; ++m) {
             if (m == member) continue;
             const uint4* src = h + ((size_t)group * K + m) * SLICE16 * 2 + (s & 1) * SLICE16;
-            for (int i = tid; i < SLICE16; i += 128) {
-                const uint4 v = src[i];
-                acc += v.x + v.z;
-                if (v.x != (unsigned)s) atomicAdd(gave_up, 1 << 16);        // a stale slice: the exchange is broken
+            // (all loads of a slice in flight together, checked afterwards: a check per load would put a full memory round
+            // trip between one load and the next)
+            bool stale = false;
+            if (MODE == 0) {
+                constexpr int PER = SLICE16 / 128;
+                uint4 v[PER];
+#pragma unroll
+                for (int j = 0; j < PER; ++j) v[j] = src[tid + 128 * j];
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    acc += v[j].x + v[j].z;
+                    stale |= v[j].x != (unsigned)s;
+                }
+            } else if (MODE == 2) {
+                constexpr int PER = SLICE16 / 128;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(src), 0, 0x7fffffff, 0x00020000);
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                u4 v[PER];
+#pragma unroll
+                for (int j = 0; j < PER; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 128 * j) * 16u, 0, 16);
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    acc += v[j].x + v[j].z;
+                    stale |= v[j].x != (unsigned)s;
+                }
+            } else {
+                constexpr int PER = 2 * SLICE16 / 128;
+                const unsigned long long* s64 = reinterpret_cast<const unsigned long long*>(src);
+                unsigned long long v[PER];
+#pragma unroll
+                for (int j = 0; j < PER; ++j) v[j] = __hip_atomic_load(s64 + tid + 128 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    acc += (unsigned)(v[j] >> 32);
+                    stale |= (unsigned)v[j] != (unsigned)s;
+                }
             }
+            if (stale) atomicAdd(gave_up, 1 << 16);                         // a stale slice: the exchange is broken
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -71,7 +125,7 @@ __global__ __launch_bounds__(128) void exchange_kernel(uint4* __restrict__ h, un
     if (acc == 0xdeadbeef) sink[0] = 1.0f;
 }
 
-template <int K>
+template <int K, int MODE>
 int run(int groups, int steps) {
     uint4* h = nullptr;
     unsigned* counters = nullptr;
@@ -92,14 +146,15 @@ int run(int groups, int steps) {
         CHECK(hipEventCreate(&a));
         CHECK(hipEventCreate(&b));
         CHECK(hipEventRecord(a, 0));
-        hipLaunchKernelGGL((exchange_kernel<K>), dim3(blocks), dim3(128), 0, 0, h, counters, steps, spread, groups, cycles, gave_up, sink);
+        hipLaunchKernelGGL((exchange_kernel<K, MODE>), dim3(blocks), dim3(128), 0, 0, h, counters, steps, spread, groups, cycles, gave_up, sink);
         CHECK(hipEventRecord(b, 0));
         CHECK(hipEventSynchronize(b));
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, a, b));
         int bad = 0;
         CHECK(hipMemcpy(&bad, gave_up, 4, hipMemcpyDeviceToHost));
-        printf("K=%d groups=%d (%d workgroups) members %s: %.2f us per step%s\n", K, groups, groups * K,
+        printf("%s K=%d groups=%d (%d workgroups) members %s: %.2f us per step%s\n",
+               MODE == 2 ? "sc1 16-byte buffer ops: " : (MODE ? "sc1 accesses, no fences:" : "agent-scope fences:     "), K, groups, groups * K,
                spread ? "spread over the XCDs" : "on one XCD       ", 1e3 * ms / steps,
                bad ? (bad >> 16 ? "  ** STALE DATA SEEN **" : "  ** a group gave up **") : "");
     }
@@ -111,9 +166,15 @@ int main(int argc, char** argv) {
     const int steps = argc > 1 ? atoi(argv[1]) : 2000;
     // 512 windows = 16 tiles x 2 directions = 32 groups; 1024 windows = 64 groups
     for (int groups : {32, 64}) {
-        if (run<2>(groups, steps)) return 1;
-        if (run<4>(groups, steps)) return 1;
-        if (groups * 8 <= 256 && run<8>(groups, steps)) return 1;
+        if (run<2, 0>(groups, steps)) return 1;
+        if (run<4, 0>(groups, steps)) return 1;
+        if (groups * 8 <= 256 && run<8, 0>(groups, steps)) return 1;
+        if (run<2, 1>(groups, steps)) return 1;
+        if (run<4, 1>(groups, steps)) return 1;
+        if (groups * 8 <= 256 && run<8, 1>(groups, steps)) return 1;
+        if (run<2, 2>(groups, steps)) return 1;
+        if (run<4, 2>(groups, steps)) return 1;
+        if (groups * 8 <= 256 && run<8, 2>(groups, steps)) return 1;
     }
     return 0;
 }
