@@ -498,6 +498,7 @@ struct pa_variant_model : ModelBase {
     // ordinary small-call schedule (same results, the caller sees nothing but the time) and the handle leaves the split
     // alone for its next `US_HOLDOFF` small calls.  PA_UNIT_SPLIT=0: never.
     bool unit_split = true;
+    int64_t unit_split_max = 1024;    // PA_UNIT_SPLIT_MAX: 512 = only the eight-member form (513-1024 windows: four members of 64 units)
     int split_holdoff = 0;            // small calls still to run without the split after a group did not meet
     int64_t split_fallbacks = 0;      // calls that were run again (pa_variant_split_fallbacks)
     int split_sabotage = 0;           // PA_UNIT_SPLIT_SABOTAGE=n (tests): in the next n split launches one member never arrives
@@ -540,6 +541,7 @@ int pa_variant_create(const pa_variant_config* cfg, const char* const* names, co
     if (const char* e = getenv("PA_SMALL_ROWS")) m->small_rows = atoll(e);
     if (const char* e = getenv("PA_UNIT_SPLIT")) m->unit_split = e[0] != '0';
     if (const char* e = getenv("PA_UNIT_SPLIT_SABOTAGE")) m->split_sabotage = atoi(e);
+    if (const char* e = getenv("PA_UNIT_SPLIT_MAX")) m->unit_split_max = std::min<int64_t>(1024, atoll(e));
     int rc = init_base(m, cfg->device, hip_stream);
     const int H = m->H;
     for (int mod = 0; mod < 2 && rc == PA_OK; ++mod)
@@ -634,7 +636,7 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     // CU's affair, half the rows are half the MFMAs and half the gate phase per step (PA_SMALL_ROWS, 0 = never)
     const bool small_rows = n <= m->small_rows;
     // up to 512 windows: every layer as projection GEMM + the unit-split step loop (see pa_variant_model::unit_split)
-    bool unit_split = allow_split && m->unit_split && n <= 512 && H == 256 && m->split_rec && !fuse_dec && m->mlp_w32 != nullptr &&
+    bool unit_split = allow_split && m->unit_split && n <= m->unit_split_max && H == 256 && m->split_rec && !fuse_dec && m->mlp_w32 != nullptr &&
                       m->mlp_w != nullptr && C <= 8;
     for (const RecLayer& r : m->rec) unit_split = unit_split && r.w_hh_h2 != nullptr && r.prescaled;
     if (unit_split && m->split_holdoff > 0) {
@@ -643,8 +645,8 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     }
     int* const ovf_counter = m->mlp_w32 ? reinterpret_cast<int*>(static_cast<char*>(m->mlp_w32->p) + 4 * sizeof(float*)) : nullptr;
     if (unit_split) {
-        if (int rc = m->us_exch->ensure(pa::lstm_split_exchange_bytes(512))) return rc;
-        if (int rc = m->us_cnt->ensure(pa::lstm_split_counter_bytes(512))) return rc;
+        if (int rc = m->us_exch->ensure(pa::lstm_split_exchange_bytes(1024))) return rc;
+        if (int rc = m->us_cnt->ensure(pa::lstm_split_counter_bytes(1024))) return rc;
         if (int rc = m->us_failed->ensure(sizeof(int))) return rc;
         if (!m->us_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->us_host), 2 * sizeof(int), hipHostMallocDefault));
         HIP_TRY(hipMemsetAsync(m->us_failed->p, 0, sizeof(int), m->stream));

@@ -441,25 +441,26 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 // (two fit a CU), the spin is bounded (~25 ms), and a group that does not meet sets *failed and returns instead of hanging:
 // the host then runs the call again with the ordinary small-call schedule (api.hip variant_forward_chunk).
 // PRE form only (weights, Xp and bias pre-multiplied by the exp2 factors; Xp = x W_ih^T + b from the projection GEMM).
-constexpr int US_K = 8;                       // members per group
 constexpr int US_AUX_SC1 = 16;                // cache policy bit sc1 of the gfx940+ buffer instructions
 
-template <int H>
+// NTW: unit tiles of 32 per member.  1: eight members (calls of at most 512 windows: 256 workgroups); 2: four members of 64
+// units (513-1024 windows), each wave with two accumulators and 256 VGPRs of weights.
+template <int H, int NTW>
 __global__ __launch_bounds__(256, 1) void lstm_rec_h2_split_kernel(const float* __restrict__ Xp, int ldx,
                                                                    const uint32_t* __restrict__ Wp, uint32_t* __restrict__ Y,
                                                                    int ldy, int B, int T, uint32_t* __restrict__ exch,
                                                                    unsigned* __restrict__ counters, int* __restrict__ failed,
                                                                    int tiles4, int sabotage) {
-    static_assert(H == 256, "eight members of 32 units");
-    constexpr int KS = H / 16, NT = H / 32;
+    static_assert(H == 256 && (NTW == 1 || NTW == 2), "eight members of 32 units or four of 64");
+    constexpr int KS = H / 16, NT = H / 32, K = NT / NTW;
     constexpr int ROWB = H * 4 + 16, ROWD = ROWB / 4;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];      // [32][ROWD] h2 rows | gate buffer [4][16][64] f32 | flag
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];      // [32][ROWD] h2 rows | gate buffer [4][NTW][16][64] f32 | flag
     float* gbuf = reinterpret_cast<float*>(lds + 32 * ROWD);
-    uint32_t* flag = lds + 32 * ROWD + 4 * 16 * 64;
+    uint32_t* flag = lds + 32 * ROWD + 4 * NTW * 16 * 64;
 
     // members of a group share an XCD (blockIdx % 8) and follow each other there; XCDs 0-3 forward, 4-7 reverse (rnn.hip)
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int dir = xcd >> 2, member = q % US_K, btile = (q / US_K) * 4 + (xcd & 3);
+    const int dir = xcd >> 2, member = q % K, btile = (q / K) * 4 + (xcd & 3);
     const int b0 = btile * 32;
     if (b0 >= B) return;                                                  // (the whole group returns)
     const int group = dir * tiles4 + btile;
@@ -470,50 +471,57 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_h2_split_kernel(const float* 
     for (int idx = tid; idx < 32 * ROWD; idx += 256) lds[idx] = 0u;
     if (tid == 0) *flag = 0u;
 
-    // this wave's recurrent weights: fragment (gate w, unit tile `member`, k step s, hi / lo) at byte
-    // (((w * NT + member) * KS + s) * 2 + hl) * 1024 + lane * 16 of the direction's block (pack_rec_weights_h2)
-    h8 bw[KS][2];
+    // this wave's recurrent weights: fragment (gate w, unit tile u, k step s, hi / lo) at byte
+    // (((w * NT + u) * KS + s) * 2 + hl) * 1024 + lane * 16 of the direction's block (pack_rec_weights_h2)
+    h8 bw[NTW][KS][2];
     {
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint32_t*>(Wp + (size_t)dir * (4 * NT) * KS * 512), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
-            for (int hl = 0; hl < 2; ++hl)
-                bw[s][hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(
-                                                       wrs, lane * 16u, (unsigned)(((w * NT + member) * KS + s) * 2 + hl) * 1024u, 0));
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl)
+                    bw[j][s][hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                              wrs, lane * 16u,
+                                                              (unsigned)(((w * NT + member * NTW + j) * KS + s) * 2 + hl) * 1024u, 0));
     }
     // accumulator seeds: the projection's tile (row tile, t, column tile ct, register chunk qd), as lstm_rec_h2_kernel reads it
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(Xp + (size_t)btile * T * (ldx >> 5) * 1024), 0, 0x7fffffff, 0x00020000);
-    const unsigned ct = (unsigned)(dir * (4 * NT) + w * NT + member);
-    f32x16 acc;
+    const unsigned ct0 = (unsigned)(dir * (4 * NT) + w * NT + member * NTW);
+    f32x16 acc[NTW];
     auto seed = [&](int t) {
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const unsigned so = (((unsigned)t * (ldx >> 5) + ct) * 4u + qd) * 1024u;
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, lane * 16u, so, 0));
-            acc[4 * qd] = v.x;
-            acc[4 * qd + 1] = v.y;
-            acc[4 * qd + 2] = v.z;
-            acc[4 * qd + 3] = v.w;
-        }
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const unsigned so = (((unsigned)t * (ldx >> 5) + ct0 + j) * 4u + qd) * 1024u;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, lane * 16u, so, 0));
+                acc[j][4 * qd] = v.x;
+                acc[j][4 * qd + 1] = v.y;
+                acc[j][4 * qd + 2] = v.z;
+                acc[j][4 * qd + 3] = v.w;
+            }
     };
 
     const uint32_t* arow = lds + li * ROWD + hf * 8;
-    const int hcol = 32 * member + li;
+    const int hcol = 32 * member * NTW + li;                              // (+ 32 j: 64 halves further on in the row)
     unsigned short* hl_dst = reinterpret_cast<unsigned short*>(lds + 4 * hf * ROWD + (hcol >> 3) * 8 + ((hcol & 7) >> 1)) + (hcol & 1);
-    // exchange geometry: thread = (row, 16-byte chunk xc of a member's 128 bytes of that row)
+    // exchange geometry: thread = (row, 16-byte chunk xc of every 128 bytes of that row); a member's slice is NTW x 128 bytes
     const int xrow = tid >> 3, xc = tid & 7;
-    uint32_t* my_chunk = lds + xrow * ROWD + (member * 8 + xc) * 4;
     const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(
         exch + (size_t)group * 2 * 32 * H, 0, 0x7fffffff, 0x00020000);   // [parity][32 rows][H dwords]
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         Y + (size_t)b0 * T * ldy + dir * H, 0, 0x7fffffff, 0x00020000);
-    const unsigned yoff = ((unsigned)(xrow * T) * ldy + (member * 8 + xc) * 4) * 4u;
     unsigned* cnt = counters + group * 32;                                // own 128-byte line
 
-    float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float c[NTW][4];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[j][e] = 0.0f;
     seed(dir ? T - 1 : 0);
     __syncthreads();
 
@@ -529,46 +537,58 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_h2_split_kernel(const float* 
                     n0 = *reinterpret_cast<const h8*>(arow + (s + 1) * 16);
                     n1 = *reinterpret_cast<const h8*>(arow + (s + 1) * 16 + 4);
                 }
-                acc = mfma_h(a1, bw[s][0], acc);
-                acc = mfma_h(a0, bw[s][1], acc);
-                acc = mfma_h(a0, bw[s][0], acc);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[j] = mfma_h(a1, bw[j][s][0], acc[j]);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[j] = mfma_h(a0, bw[j][s][1], acc[j]);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[j] = mfma_h(a0, bw[j][s][0], acc[j]);
                 a0 = n0;
                 a1 = n1;
             }
         }
         // ---- this wave's activation (the accumulators are exp2 arguments): sigmoid for i, f, o; tanh for g ----
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r]));
-            gbuf[(w * 16 + r) * 64 + lane] = w == 2 ? 1.0f - 2.0f * sg : sg;
-        }
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[j][r]));
+                gbuf[((w * NTW + j) * 16 + r) * 64 + lane] = w == 2 ? 1.0f - 2.0f * sg : sg;
+            }
         if (step + 1 < T) seed(dir ? t - 1 : t + 1);      // the next step's seeds fly under the rest of this one
         lds_barrier();                                    // gates visible; every wave has finished reading h_{t-1}
         // ---- element-wise update, a quarter of the tile per wave: registers 4w .. 4w+3 = rows 8w + e + 4 hf ----
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = 4 * w + e;
-            const float ig = gbuf[(0 * 16 + r) * 64 + lane], fg = gbuf[(1 * 16 + r) * 64 + lane];
-            const float gg = gbuf[(2 * 16 + r) * 64 + lane], og = gbuf[(3 * 16 + r) * 64 + lane];
-            const float cn = fg * c[e] + ig * gg;
-            c[e] = cn;
-            const float hv = og * (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cn * 2.8853900817779268f)));
-            h2_store16(hl_dst + (e + 8 * w) * ROWD * 2, hv);
-        }
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * w + e;
+                const float ig = gbuf[((0 * NTW + j) * 16 + r) * 64 + lane], fg = gbuf[((1 * NTW + j) * 16 + r) * 64 + lane];
+                const float gg = gbuf[((2 * NTW + j) * 16 + r) * 64 + lane], og = gbuf[((3 * NTW + j) * 16 + r) * 64 + lane];
+                const float cn = fg * c[j][e] + ig * gg;
+                c[j][e] = cn;
+                const float hv = og * (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(cn * 2.8853900817779268f)));
+                h2_store16(hl_dst + j * 64 + (e + 8 * w) * ROWD * 2, hv);
+            }
         lds_barrier();                                    // this member's slice of h_t is complete in LDS
         // ---- publish: y_t and (not after the last step) the exchange buffer of this step's parity ----
-        const u32x4 mine = *reinterpret_cast<const u32x4*>(my_chunk);
-        __builtin_amdgcn_raw_buffer_store_b128(mine, yrs, yoff, ((unsigned)t * ldy) * 4u, 0);
-        if (step + 1 == T) break;
         const unsigned pbase = (unsigned)(step & 1) * (32u * H * 4u);
-        __builtin_amdgcn_raw_buffer_store_b128(mine, ers, (unsigned)(xrow * H + (member * 8 + xc) * 4) * 4u, pbase, US_AUX_SC1);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int chunk = (member * NTW + j) * 8 + xc;
+            const u32x4 mine = *reinterpret_cast<const u32x4*>(lds + xrow * ROWD + chunk * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(mine, yrs, ((unsigned)(xrow * T) * ldy + chunk * 4) * 4u, ((unsigned)t * ldy) * 4u, 0);
+            if (step + 1 < T)
+                __builtin_amdgcn_raw_buffer_store_b128(mine, ers, (unsigned)(xrow * H + chunk * 4) * 4u, pbase, US_AUX_SC1);
+        }
+        if (step + 1 == T) break;
         __builtin_amdgcn_s_waitcnt(0);                    // every store of this thread acknowledged ...
         __builtin_amdgcn_s_barrier();                     // ... and of this member
         if (tid == 0) {
             // (sabotage: the tests' way to a group that does not meet -- its last member never arrives)
-            if (!(sabotage && group == 0 && member == US_K - 1))
+            if (!(sabotage && group == 0 && member == K - 1))
                 __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned want = (unsigned)US_K * (unsigned)(step + 1);
+            const unsigned want = (unsigned)K * (unsigned)(step + 1);
             int spins = 0;
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                 if (++spins > (1 << 14)) {                // ~25 ms: the group is not resident together; the host runs the call again
@@ -580,15 +600,15 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_h2_split_kernel(const float* 
             }
         }
         lds_barrier();
-        if (*flag) return;                                // (uniform: the whole member gives up; the host reports it)
+        if (*flag) return;                                // (uniform: the whole member gives up; the host runs the call again)
         // ---- every member's slice of h_t (the own one included: same bytes) -> the LDS rows ----
         {
-            u32x4 v[US_K];
+            u32x4 v[NT];
 #pragma unroll
-            for (int m2 = 0; m2 < US_K; ++m2)
+            for (int m2 = 0; m2 < NT; ++m2)
                 v[m2] = __builtin_amdgcn_raw_buffer_load_b128(ers, (unsigned)(xrow * H + (m2 * 8 + xc) * 4) * 4u, pbase, US_AUX_SC1);
 #pragma unroll
-            for (int m2 = 0; m2 < US_K; ++m2) *reinterpret_cast<u32x4*>(lds + xrow * ROWD + (m2 * 8 + xc) * 4) = v[m2];
+            for (int m2 = 0; m2 < NT; ++m2) *reinterpret_cast<u32x4*>(lds + xrow * ROWD + (m2 * 8 + xc) * 4) = v[m2];
         }
         lds_barrier();                                    // h_t visible
     }
@@ -1371,9 +1391,10 @@ hipError_t launch_lstm_dec_h2(int H, const void* Xh, int ldxh, const float* bias
     return hipGetLastError();
 }
 
-// Unit-split step loop (lstm_rec_h2_split_kernel): B <= 512, prescaled weights, Xp from the projection GEMM.
+// Unit-split step loop (lstm_rec_h2_split_kernel): B <= 1024, prescaled weights, Xp from the projection GEMM.
 // exch: 2 * tiles4 groups x 64 KB; counters: 2 * tiles4 x 128 B (zeroed here); failed: one int the kernel sets when a group
-// did not meet.  tiles4 = row tiles of 32 rounded up to a multiple of four.
+// did not meet.  tiles4 = row tiles of 32 rounded up to a multiple of four.  Eight members of 32 units up to 512 windows,
+// four of 64 units above: at most 256 workgroups either way.
 size_t lstm_split_exchange_bytes(int B) { return (size_t)2 * (((B + 31) / 32 + 3) / 4 * 4) * 2 * 32 * 256 * 4; }
 size_t lstm_split_counter_bytes(int B) { return (size_t)2 * (((B + 31) / 32 + 3) / 4 * 4) * 128; }
 
@@ -1381,14 +1402,20 @@ hipError_t launch_lstm_rec_h2_split(int H, const float* Xp, int ldx, const void*
                                     void* counters, int* failed, hipStream_t stream, int sabotage) {
     if (B <= 0) return hipSuccess;
     const int tiles4 = ((B + 31) / 32 + 3) / 4 * 4;
-    const int grid = 8 * US_K * (tiles4 / 4);
+    const int ntw = B <= 512 ? 1 : 2;
+    const int grid = 8 * (8 / ntw) * (tiles4 / 4);
     if (H != 256 || (ldy & 7) || grid > 256 || !exch || !counters || !failed) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(counters, 0, lstm_split_counter_bytes(B), stream);
     if (e != hipSuccess) return e;
-    const size_t lds = (size_t)32 * (256 * 4 + 16) + (size_t)4 * 16 * 64 * 4 + 16;
-    hipLaunchKernelGGL((lstm_rec_h2_split_kernel<256>), dim3(grid), dim3(256), lds, stream, Xp, ldx, static_cast<const uint32_t*>(Wp),
-                       static_cast<uint32_t*>(Y), ldy, B, T, static_cast<uint32_t*>(exch), static_cast<unsigned*>(counters), failed,
-                       tiles4, sabotage);
+    const size_t lds = (size_t)32 * (256 * 4 + 16) + (size_t)4 * ntw * 16 * 64 * 4 + 16;
+    if (ntw == 1)
+        hipLaunchKernelGGL((lstm_rec_h2_split_kernel<256, 1>), dim3(grid), dim3(256), lds, stream, Xp, ldx, static_cast<const uint32_t*>(Wp),
+                           static_cast<uint32_t*>(Y), ldy, B, T, static_cast<uint32_t*>(exch), static_cast<unsigned*>(counters), failed,
+                           tiles4, sabotage);
+    else
+        hipLaunchKernelGGL((lstm_rec_h2_split_kernel<256, 2>), dim3(grid), dim3(256), lds, stream, Xp, ldx, static_cast<const uint32_t*>(Wp),
+                           static_cast<uint32_t*>(Y), ldy, B, T, static_cast<uint32_t*>(exch), static_cast<unsigned*>(counters), failed,
+                           tiles4, sabotage);
     return hipGetLastError();
 }
 

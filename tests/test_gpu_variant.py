@@ -19,7 +19,7 @@ TOL = 1e-4
 def schedule(request):
     """Every test of this file under every schedule.  "small-call", the defaults: calls of at most 512 windows run their
     step loops with a tile's hidden units split over eight workgroups that exchange h_t through memory every step (api.hip
-    `unit_split`), calls of at most 3072 windows take the GEMM + Xp decoder and 32-row workgroups in both step loops
+    `unit_split`; four workgroups of 64 units for 513-1024 windows), calls of at most 3072 windows take the GEMM + Xp decoder and 32-row workgroups in both step loops
     (`small_batch`, `small_rows`).  "no-unit-split" (PA_UNIT_SPLIT=0): the latter for the calls of at most 512 windows too.
     "big-call" (PA_SMALL_BATCH=0 PA_SMALL_ROWS=0 PA_UNIT_SPLIT=0): the schedule of large calls -- the decoder with the
     projection inside its step loop, 64-row workgroups -- for the small calls the parity tests make.  (All read at model
@@ -87,7 +87,7 @@ def test_variant_two_layer_golden(golden_dir):
     assert np.abs(probs - g["probs"]).max() < TOL
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 130, 515])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 130, 512, 515, 1024])
 def test_variant_ragged_batches_vs_oracle(n):
     sd = synthetic.variant_state_dict(seed=5, gain=2.0)
     x = synthetic.variant_windows(n, seed=77 + n)
@@ -272,5 +272,12 @@ def test_a_call_whose_workgroups_do_not_meet_is_run_again(monkeypatch, schedule)
     _lib.check(m.lib.pa_variant_split_fallbacks(m.h, ctypes.byref(n)))
     _lib.check(clean.lib.pa_variant_split_fallbacks(clean.h, ctypes.byref(rows)))
     assert n.value == 1 and rows.value == 0
-    for h in (plain, clean, m):
+    # the four-member form of calls of 513-1024 windows
+    monkeypatch.setenv("PA_UNIT_SPLIT_SABOTAGE", "1")
+    m4 = NativeVariant(sd)
+    monkeypatch.delenv("PA_UNIT_SPLIT_SABOTAGE")
+    got = m4.forward(x)[0]
+    _lib.check(m4.lib.pa_variant_split_fallbacks(m4.h, ctypes.byref(n)))
+    assert n.value == 1 and np.array_equal(got, plain.forward(x)[0]) and np.abs(got - clean.forward(x)[0]).max() <= 1e-4
+    for h in (plain, clean, m, m4):
         h.close()
