@@ -60,8 +60,8 @@ void pa_variant_destroy(pa_variant_model* m);
 /* Rows (windows) since creation whose MLP tile was re-run in plain f32 because an activation did not fit the f16-split
  * operand format (|x| >= 65504 or NaN; simple_model.py:60-78 is f32 throughout): diagnostics, results are the f32 ones either way. */
 int pa_variant_overflow_rows(pa_variant_model* m, int64_t* rows);
-/* Calls of at most 512 windows run their recurrent layers with a tile's hidden units split over eight workgroups that meet
- * every step; they must be resident on the GPU together, which other work on the device can prevent.  A call whose
+/* Calls of at most 1024 windows run their recurrent layers with a tile's hidden units split over eight (above 512 windows:
+ * four) workgroups that meet every step; they must be resident on the GPU together, which other work on the device can prevent.  A call whose
  * workgroups did not meet is run again with the ordinary schedule (same results): this counts those calls since creation
  * (diagnostics; PA_UNIT_SPLIT=0 in the environment at creation switches the split off).  Such calls are synchronous: they
  * return when their results are in the output buffers. */
@@ -70,7 +70,7 @@ int pa_variant_split_fallbacks(pa_variant_model* m, int64_t* calls);
 /* forward(x, train_mode=False): images int8 [n, window, image_features] (the dtype the images
  * HDF5 stores: pepper_variant/modules/python/DataStore.py:68) -> probs float32 [n, classes].
  * logits (pre-softmax, = forward(x, train_mode=True)) may be NULL.  All pointers are DEVICE
- * pointers; the call is asynchronous on the handle's stream (calls of at most 512 windows: see
+ * pointers; the call is asynchronous on the handle's stream (calls of at most 1024 windows: see
  * pa_variant_split_fallbacks).
  * replaces: simple_model.py:48-82 as called by predict_distributed_gpu.py:58-65. */
 int pa_variant_forward_device(pa_variant_model* m, const int8_t* images, int64_t n, float* probs,

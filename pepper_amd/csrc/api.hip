@@ -491,8 +491,8 @@ struct pa_variant_model : ModelBase {
     DevBuf *mlp_w = nullptr, *mlp_b = nullptr;   // linear_2..5 as h2 fragments + their biases (mlp_h2.hip)
     DevBuf *mlp_w32 = nullptr;   // device array of the four f32 weight pointers + the out-of-range row counter behind them
     DevBuf *xp, *ya, *yb, *l1, *l2, *stage_in[2], *stage_p[2], *stage_l[2];
-    // Calls of at most 512 windows (the reference's DataLoader batch) run their step loops with the hidden units of a 32-row
-    // tile split over eight workgroups that exchange h_t through memory every step (rnn_h2.hip lstm_rec_h2_split_kernel;
+    // Calls of at most 1024 windows (the reference's DataLoader batch is 512) run their step loops with the hidden units of a
+    // 32-row tile split over eight (above 512 windows: four) workgroups that exchange h_t through memory every step (rnn_h2.hip lstm_rec_h2_split_kernel;
     // DESIGN.md 6).  The eight must be resident together, which nothing guarantees when other kernels hold the CUs (other
     // handles, other processes): a group that does not meet within ~25 ms gives up, the call is then run again with the
     // ordinary small-call schedule (same results, the caller sees nothing but the time) and the handle leaves the split
@@ -635,7 +635,7 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     // ... and, up to `small_rows` windows, both step loops run with 32-row workgroups (rnn_h2.hip MTILES = 1): a step is one
     // CU's affair, half the rows are half the MFMAs and half the gate phase per step (PA_SMALL_ROWS, 0 = never)
     const bool small_rows = n <= m->small_rows;
-    // up to 512 windows: every layer as projection GEMM + the unit-split step loop (see pa_variant_model::unit_split)
+    // up to 1024 windows: every layer as projection GEMM + the unit-split step loop (see pa_variant_model::unit_split)
     bool unit_split = allow_split && m->unit_split && n <= m->unit_split_max && H == 256 && m->split_rec && !fuse_dec && m->mlp_w32 != nullptr &&
                       m->mlp_w != nullptr && C <= 8;
     for (const RecLayer& r : m->rec) unit_split = unit_split && r.w_hh_h2 != nullptr && r.prescaled;

@@ -426,8 +426,8 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 }
 
 // ------------------------------------------------------------------------------------------------
-// The step loop of a call of at most 512 windows (PA_UNIT_SPLIT=0: off) with the hidden units of a 32-row tile
-// split over EIGHT workgroups that exchange their slices of h_t through memory every step.
+// The step loop of a call of at most 1024 windows (PA_UNIT_SPLIT=0: off) with the hidden units of a 32-row tile
+// split over EIGHT workgroups (four above 512 windows, NTW = 2) that exchange their slices of h_t through memory every step.
 // A step of the 32-row workgroup above is one CU's affair (~10 us: 384 MFMAs on four SIMDs, a 1 MB weight stream, the
 // gate phase of 8 waves); with the units split, member j of a (direction, tile) group keeps the recurrent weights of units
 // [32j, 32j + 32) in REGISTERS (wave w = gate w: 16 k steps x (hi, lo) fragments = 128 VGPRs, loaded once), issues 48 MFMAs
