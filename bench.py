@@ -18,6 +18,7 @@ synchronize; the device-resident rate (inputs already in HBM, what round 1 repor
 line.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -886,6 +887,12 @@ def main():
                              "note": "one synchronous call per batch: H2D, forward, D2H, as predict_distributed_gpu.py:58-67 loops"},
             "device_resident": {"value": nb * b * windows_per_unit / td, "unit": "windows/s", "ms_per_call": td / nb * 1e3,
                                 "note": "calls queued back to back on one stream, inputs in HBM"}}
+        if variant and hasattr(lib, "pa_variant_split_fallbacks"):
+            # calls of this size run their step loops with a tile's hidden units split over eight workgroups; a
+            # call whose workgroups did not meet on the GPU is run again the ordinary way -- how many of the 400 above were
+            again = ctypes.c_int64(-1)
+            _lib.check(lib.pa_variant_split_fallbacks(handle, ctypes.byref(again)))
+            extras["batch512"]["schedule"] = {"unit_split": os.environ.get("PA_UNIT_SPLIT", "1") != "0", "calls_run_again": again.value}
 
     if rank == 0:
         windows = world * args.steps * per * windows_per_unit
