@@ -86,3 +86,29 @@ def test_two_tile_workgroups_fit_a_cu(tmp_path):
         assert lds <= 160 * 1024 // 2, lds
         assert vgprs <= 128, vgprs
     assert found
+
+
+def test_unit_split_step_loops_keep_their_weights_in_registers(tmp_path):
+    """lstm_rec_h2_split_kernel (calls of at most 1024 windows) holds a wave's recurrent weights in registers for the whole step
+    loop -- 128 VGPRs with eight members of 32 units, 256 with four of 64 -- and nothing may go to scratch.  The eight-member
+    form has to stay at or below 256 registers: two of its workgroups (one wave per SIMD each) then share a CU, which is what
+    lets two calls of 512 windows be on the GPU together (residency)."""
+    asm = _asm(tmp_path, "rnn_h2.hip")
+    kernels = _kernels(asm)
+    eight = [v for k, v in kernels.items() if "lstm_rec_h2_split_kernelILi256ELi1E" in k]
+    four = [v for k, v in kernels.items() if "lstm_rec_h2_split_kernelILi256ELi2E" in k]
+    assert len(eight) == 1 and len(four) == 1
+    assert eight[0][1] == 0 and four[0][1] == 0
+    assert 128 < eight[0][0] <= 256, eight
+    assert 256 < four[0][0] <= 512, four
+    for needle in ("lstm_rec_h2_split_kernelILi256ELi1E", "lstm_rec_h2_split_kernelILi256ELi2E"):
+        name = next(k for k in kernels if needle in k)
+        lines = asm.split("\n")
+        start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
+        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+        body = lines[start:end]
+        assert not any("scratch_" in l for l in body), needle
+        # the exchange: sc1 on the 16-byte stores / loads, and no agent-scope fence (buffer_wbl2 / buffer_inv) anywhere
+        assert sum("buffer_load_dwordx4" in l and "sc1" in l for l in body) == 8, needle
+        assert any("buffer_store_dwordx4" in l and "sc1" in l for l in body), needle
+        assert not any("buffer_wbl2" in l or "buffer_inv" in l for l in body), needle
