@@ -73,6 +73,16 @@ def test_no_gpu_means_loud_failure(lib):
         ReadAligner(0, 8, "ACGTACGT").align_arrays([0], [0, 4], [65, 67, 71, 84])
 
 
+def test_diagnostic_accessors_refuse_a_null_handle(lib):
+    """pa_variant_overflow_rows / pa_variant_split_fallbacks are plain reads of a handle's counters: a NULL handle or a NULL
+    destination is PA_ERR_INVALID with a message, on any machine."""
+    import ctypes
+    n = ctypes.c_int64(7)
+    for fn in (lib.pa_variant_overflow_rows, lib.pa_variant_split_fallbacks):
+        assert fn(None, ctypes.byref(n)) != 0 and n.value == 7
+        assert lib.pa_last_error()
+
+
 def test_product_never_imports_oracle():
     bad = []
     for root, _, files in os.walk(os.path.join(REPO, "pepper_amd")):
