@@ -2,7 +2,8 @@
 with its own handle, make `calls` calls of `b` windows at the same time; every process reports its time per call, how many
 calls were run again because a tile's workgroups did not meet (pa_variant_split_fallbacks) and the largest difference from
 the results of an undisturbed first call.
-    python tools/split_contention.py [processes=4] [b=512] [calls=300]"""
+    python tools/split_contention.py [processes=4] [b=512] [calls=300] [threads]
+"threads": the N callers are threads of ONE process (each with its own handle and streams), as the lanes' two blocks in flight are."""
 import ctypes
 import json
 import multiprocessing as mp
@@ -43,6 +44,18 @@ def main():
     procs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     b = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     calls = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+    if len(sys.argv) > 4 and sys.argv[4] == "threads":
+        import queue
+        import threading
+        start, out = threading.Barrier(procs), queue.Queue()
+        ts = [threading.Thread(target=worker, args=(r, b, calls, start, out)) for r in range(procs)]
+        for t in ts:
+            t.start()
+        rows = [out.get(timeout=120) for _ in ts]
+        for t in ts:
+            t.join(timeout=30)
+        print(json.dumps({"threads_of_one_process": procs, "windows_per_call": b, "calls": calls, "ranks": sorted(rows, key=lambda r: r["rank"])}))
+        return
     ctx = mp.get_context("spawn")
     start, out = ctx.Barrier(procs), ctx.Queue()
     ps = [ctx.Process(target=worker, args=(r, b, calls, start, out)) for r in range(procs)]
