@@ -27,6 +27,13 @@ IO_LIB = os.path.join(CSRC, "libpepper_amd_io.so")
 HDF5_PREFIX = os.environ.get("PEPPER_AMD_HDF5_PREFIX", "/opt/conda")
 
 
+def _have_libdeflate(inc, lib):
+    """Header and a linkable shared library, both under the HDF5 prefix (PEPPER_AMD_LIBDEFLATE=0 turns it off)."""
+    if os.environ.get("PEPPER_AMD_LIBDEFLATE", "1") == "0":
+        return False
+    return os.path.exists(os.path.join(inc, "libdeflate.h")) and os.path.exists(os.path.join(lib, "libdeflate.so"))
+
+
 def build_io(force=False, verbose=False):
     """g++ build of the HDF5 I/O helper (include/pepper_amd_io.h) against libhdf5 1.10.
 
@@ -47,10 +54,15 @@ def build_io(force=False, verbose=False):
     # per-process temporary name: loader / writer worker processes that start without a built library may all get
     # here at once; each links its own file and the rename is atomic
     tmp = f"{IO_LIB}.{os.getpid()}.tmp"
-    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", tmp, src, bam, bld, cnd, f"-I{inc}", f"-L{lib}",
-           "-lhdf5", "-lz", f"-Wl,-rpath,{lib}"]
-    if os.path.exists(os.path.join(inc, "libdeflate.h")) and os.path.exists(os.path.join(lib, "libdeflate.so")):
-        cmd.append("-ldeflate")       # bamio.cpp inflates BGZF blocks with it when the header is there (as htslib does)
+    # libraries of the prefix by their full paths (not -L: the prefix also holds an older libstdc++ that must not be the one
+    # the link resolves against)
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", tmp, src, bam, bld, cnd, f"-I{inc}",
+           os.path.join(lib, "libhdf5.so"), "-lz", "-lpthread", f"-Wl,-rpath,{lib}", "-Wl,--no-undefined"]
+    # libdeflate (htslib's own choice for BGZF blocks) is decided HERE, once: the macro and the library go together, and
+    # bamio.cpp tests only the macro -- a header found by the compiler without a linkable library (or the other way round)
+    # can no longer produce a library that fails at dlopen; --no-undefined makes any such mismatch a build error
+    if _have_libdeflate(inc, lib):
+        cmd += ["-DPA_HAVE_LIBDEFLATE=1", os.path.join(lib, "libdeflate.so")]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     try:

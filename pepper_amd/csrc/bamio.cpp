@@ -17,9 +17,8 @@
 // order.  With a .bai the scan starts at the linear-index offset of start's 16 kb window; without one
 // the contig is scanned from its first record (correct, slower).
 #include <zlib.h>
-#if __has_include(<libdeflate.h>)
+#ifdef PA_HAVE_LIBDEFLATE      // set by pepper_amd/build.py together with -ldeflate (one decision: header AND library)
 #include <libdeflate.h>        // htslib's own choice for BGZF blocks where it is installed: 2-3x zlib's inflate
-#define PA_HAVE_LIBDEFLATE 1
 #endif
 
 #include <algorithm>
