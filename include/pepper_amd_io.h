@@ -223,6 +223,28 @@ int pa_bam_copy_reads(pa_bam* b, int64_t* pos, int64_t* pos_end, uint8_t* revers
                       int32_t* hp, int64_t* seq_offset, char* seq, uint8_t* qual, int64_t* cigar_offset,
                       int32_t* cigar_op, int32_t* cigar_len, char* names);
 
+/* The reads of a run of regions of ONE contig in the packed form the GPU encoder clips and decodes itself
+ * (pa_encoder_stage_packed, include/pepper_amd_encoder.h): what get_reads(contig, start[r], stop[r], ...) would return for
+ * every region r, without the per-read walk on the host.  start / stop ascend.  Per kept record (filters and region test of
+ * bam_handler.cpp:115-151: pos < stop, end > start, not qc-fail / duplicate / secondary / unmapped, supplementary only on
+ * request, mapq >= min_mapq) one table entry and ONE copy of `CIGAR words | 4-bit bases | qualities` as the record holds them
+ * (4-byte aligned at data_off) in `arena`, shared by all the regions the read reaches; pair_read[region_pairs[r] ..
+ * region_pairs[r + 1]) are the reads of region r in file order.  The reads the reference's clipping would drop (no base inside
+ * the region) are still listed: the device drops them.  When the arena or a table fills up the call stops at a region
+ * boundary: *n_done regions (>= 1, else the call fails) are complete and described by counts = {reads, pairs, arena bytes};
+ * the caller continues with region n_done. */
+typedef struct {
+    int64_t data_off;      /* in the arena: n_cigar uint32 (len << 4 | op), (l_seq + 1) / 2 bytes of 4-bit bases, l_seq qualities */
+    int32_t pos;           /* 0-based leftmost position of the record */
+    int32_t n_cigar;
+    int32_t l_seq;
+    int32_t flags;         /* BAM flag | mapping quality << 16 */
+} pa_packed_read;
+int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const int64_t* start, const int64_t* stop,
+                        int32_t include_supplementary, int32_t min_mapq, uint8_t* arena, int64_t arena_cap,
+                        pa_packed_read* reads, int32_t reads_cap, int32_t* pair_read, int32_t pairs_cap,
+                        int32_t* region_pairs, int32_t* n_done, int64_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

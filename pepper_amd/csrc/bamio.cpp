@@ -211,6 +211,8 @@ struct pa_bam {
     ReadSet reads;
     std::vector<char> scratch_seq;                             // one read's decoded bases / qualities while it is clipped
     std::vector<uint8_t> scratch_qual;
+    std::vector<std::pair<int32_t, int32_t>> pack_pairs;       // pa_bam_pack_regions: (region, read) as the walk finds them
+    std::vector<int64_t> pack_closed;
 };
 
 namespace {
@@ -657,6 +659,187 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
     if (seq_bytes) *seq_bytes = (int64_t)rs.seq.size();
     if (n_cigar) *n_cigar = (int64_t)rs.cigar_op.size();
     if (name_bytes) *name_bytes = (int64_t)rs.names.size();
+    return 0;
+}
+
+// ---- packed form for the GPU encoder: no clipping, no decoding on the host --------------------------------------------
+// What get_reads does per (read, region) on the host -- the walk that clips the read to the region, 4-bit codes -> letters --
+// is left to the device (pepper_amd/csrc/encoder.hip, unpack_clip_kernel); the host inflates the BGZF blocks, walks the record
+// headers, applies get_reads' filters (:138-151) and its region test, and copies each kept record's
+//     CIGAR words | 4-bit bases | qualities
+// -- one contiguous slice of the record as BAM stores it -- ONCE into the caller's arena (a page-locked buffer of the
+// encoder), however many of the batch's regions the read reaches.  1.5 bytes per base + 4 per operation cross PCIe instead of
+// 2 + 8, and the host's per-base work is one memcpy.
+int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const int64_t* start, const int64_t* stop,
+                        int32_t include_supplementary, int32_t min_mapq, uint8_t* arena, int64_t arena_cap,
+                        pa_packed_read* reads, int32_t reads_cap, int32_t* pair_read, int32_t pairs_cap,
+                        int32_t* region_pairs, int32_t* n_done, int64_t* counts) {
+    if (!b || !contig || n_regions < 0 || (n_regions > 0 && (!start || !stop)) || !arena || !reads || !pair_read || !region_pairs || !n_done)
+        return bam_fail(-1, "null argument");
+    *n_done = 0;
+    for (int r = 0; r <= n_regions; ++r) region_pairs[r] = 0;
+    if (counts) counts[0] = counts[1] = counts[2] = 0;
+    if (n_regions == 0) return 0;
+    for (int r = 0; r < n_regions; ++r)
+        if (stop[r] < start[r] || (r > 0 && (start[r] < start[r - 1] || stop[r] < stop[r - 1])))
+            return bam_fail(-1, "pack_regions: regions must be ascending in start and stop");
+    int tid = -1;
+    for (size_t i = 0; i < b->names.size(); ++i)
+        if (b->names[i] == contig) tid = (int)i;
+    if (tid < 0) return bam_fail(-4, std::string("contig not in the BAM header: ") + contig);
+
+    uint64_t from = b->first_record;
+    bool nothing = false;
+    if (b->has_index && tid < (int)b->ioff.size()) {
+        const auto& lin = b->ioff[tid];
+        int64_t w = std::max<int64_t>(0, start[0]) >> 14;
+        uint64_t off = 0;
+        if (!lin.empty()) {
+            if (w >= (int64_t)lin.size()) w = (int64_t)lin.size() - 1;
+            for (int64_t k = w; k >= 0 && off == 0; --k) off = lin[k];
+        }
+        if (off == 0) off = b->ref_min[tid];
+        if (off == 0) nothing = true;
+        from = off;
+    }
+    b->bg.failed = false;
+    if (!nothing && !b->bg.seek(from)) return bam_fail(-5, "BGZF seek failed (corrupt file or index)");
+
+    // pairs arrive read by read; they leave grouped by region
+    std::vector<std::pair<int32_t, int32_t>>& pairs = b->pack_pairs;     // (region, read)
+    pairs.clear();
+    int64_t used = 0;
+    int32_t n_reads = 0;
+    int r_lo = 0;                       // regions in front of r_lo end at or before the current record's position
+    bool full = false;
+    const int64_t last_stop = stop[n_regions - 1];
+    std::vector<uint8_t> rec;
+    // what was complete when region k closed (every record with pos < stop[k] seen): reads, pairs, arena bytes
+    std::vector<int64_t>& closed = b->pack_closed;
+    closed.assign((size_t)n_regions * 3, 0);
+    int n_closed = 0;
+    auto close_up_to = [&](int64_t pos) {            // regions whose stop <= pos can get no further read
+        while (n_closed < n_regions && stop[n_closed] <= pos) {
+            closed[(size_t)n_closed * 3] = n_reads;
+            closed[(size_t)n_closed * 3 + 1] = (int64_t)pairs.size();
+            closed[(size_t)n_closed * 3 + 2] = used;
+            ++n_closed;
+        }
+    };
+    while (!nothing) {
+        uint8_t w4[4];
+        const size_t got4 = b->bg.read(w4, 4);
+        if (b->bg.failed) return bam_fail(-5, "corrupt or truncated BGZF block");
+        if (got4 != 4) {
+            if (got4 != 0) return bam_fail(-6, "truncated BAM record");
+            break;
+        }
+        const uint32_t block_size = le32(w4);
+        if (block_size < 32) return bam_fail(-6, "corrupt BAM record");
+        const uint8_t* R = b->bg.peek(block_size);
+        if (!R) {
+            rec.resize(block_size);
+            if (b->bg.read(rec.data(), block_size) != block_size)
+                return bam_fail(b->bg.failed ? -5 : -6, b->bg.failed ? "corrupt or truncated BGZF block" : "truncated BAM record");
+            R = rec.data();
+        }
+        const int32_t ref_id = (int32_t)le32(R);
+        const int32_t pos = (int32_t)le32(R + 4);
+        const uint32_t l_read_name = R[8];
+        const int32_t mapq = R[9];
+        const uint32_t n_cigar_op = R[12] | (R[13] << 8);
+        const uint32_t flag = R[14] | (R[15] << 8);
+        const uint32_t l_seq = le32(R + 16);
+        if (ref_id != tid) {
+            if (ref_id > tid || ref_id < 0) break;
+            continue;
+        }
+        if (pos >= last_stop) break;
+        const size_t o_cigar = 32 + (size_t)l_read_name, o_seq = o_cigar + 4ull * n_cigar_op, o_qual = o_seq + (l_seq + 1) / 2,
+                     o_aux = o_qual + l_seq;
+        if (o_aux > block_size) return bam_fail(-6, "corrupt BAM record");
+        close_up_to(pos);
+        while (r_lo < n_regions && stop[r_lo] <= pos) ++r_lo;
+        // ---- filters of get_reads (:138-151); a record without bases has nothing to pile up ----
+        if (flag & (0x200 | 0x400 | 0x100 | 0x4)) continue;
+        if (!include_supplementary && (flag & 0x800)) continue;
+        if (mapq < min_mapq) continue;
+        if (l_seq == 0) continue;
+        const uint8_t* cig = R + o_cigar;
+        uint32_t n_cig = n_cigar_op;
+        if (n_cigar_op >= 1 && (le32(cig) & 15) == 4 && (le32(cig) >> 4) == l_seq) {      // long CIGAR in the CG tag (as above)
+            uint32_t cnt = 0;
+            const uint8_t* real = find_cg(R + o_aux, R + block_size, &cnt);
+            if (real && cnt >= n_cigar_op && cnt < (1u << 29)) {
+                cig = real;
+                n_cig = cnt;
+            }
+        }
+        if (n_cig == 0) continue;                            // no alignment to walk: get_reads keeps nothing of it
+        // the region test of the iterator: pos < stop and end > start, end = pos + reference length (at least pos + 1); only a
+        // read that starts in front of a region needs its end
+        int64_t end = -1;
+        int first_pair = -1;
+        for (int r = r_lo; r < n_regions && start[r] < (end < 0 ? (int64_t)0x7fffffffffffll : end); ++r) {
+            if (pos >= stop[r]) continue;
+            if (pos < start[r]) {
+                if (end < 0) {
+                    int64_t ref_len = 0;
+                    for (uint32_t k = 0; k < n_cig; ++k) {
+                        const uint32_t c = le32(cig + 4 * k);
+                        const int op = c & 15;
+                        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
+                    }
+                    end = pos + std::max<int64_t>(1, ref_len);
+                }
+                if (end <= start[r]) break;                  // (starts ascend: no later region either)
+            }
+            if ((int64_t)pairs.size() >= pairs_cap) { full = true; break; }
+            if (first_pair < 0) first_pair = (int)pairs.size();
+            pairs.emplace_back(r, n_reads);
+        }
+        if (full) break;
+        if (first_pair < 0) continue;
+        const int64_t bytes = 4ll * n_cig + (l_seq + 1) / 2 + l_seq;
+        const int64_t at = (used + 3) & ~(int64_t)3;
+        if (n_reads >= reads_cap || at + bytes + 64 > arena_cap) {
+            pairs.resize((size_t)first_pair);
+            full = true;
+            break;
+        }
+        if (cig == R + o_cigar) {
+            std::memcpy(arena + at, cig, (size_t)bytes);      // the three fields follow each other in the record
+        } else {
+            std::memcpy(arena + at, cig, 4ull * n_cig);
+            std::memcpy(arena + at + 4ll * n_cig, R + o_seq, (size_t)((l_seq + 1) / 2 + l_seq));
+        }
+        pa_packed_read& pr = reads[n_reads++];
+        pr.data_off = at;
+        pr.pos = pos;
+        pr.n_cigar = (int32_t)n_cig;
+        pr.l_seq = (int32_t)l_seq;
+        pr.flags = (int32_t)(flag | ((uint32_t)mapq << 16));
+        used = at + bytes;
+    }
+    if (!full) close_up_to(0x7fffffffffffffffll);        // the walk ended: every region is complete
+    if (n_closed == 0)
+        return bam_fail(-7, "pack_regions: the reads of one region do not fit the arena / tables (grow them or take get_reads)");
+    const int64_t reads_kept = closed[(size_t)(n_closed - 1) * 3], pairs_kept = closed[(size_t)(n_closed - 1) * 3 + 1];
+    // pairs of the closed regions, grouped by region (a stable counting sort: the reads of a region stay in file order)
+    for (int64_t k = 0; k < pairs_kept; ++k)
+        if (pairs[(size_t)k].first < n_closed) region_pairs[pairs[(size_t)k].first + 1] += 1;
+    for (int r = 0; r < n_regions; ++r) region_pairs[r + 1] += region_pairs[r];
+    {
+        std::vector<int32_t> fill(region_pairs, region_pairs + n_regions);
+        for (int64_t k = 0; k < pairs_kept; ++k)
+            if (pairs[(size_t)k].first < n_closed) pair_read[fill[(size_t)pairs[(size_t)k].first]++] = pairs[(size_t)k].second;
+    }
+    *n_done = n_closed;
+    if (counts) {
+        counts[0] = reads_kept;
+        counts[1] = region_pairs[n_closed];
+        counts[2] = closed[(size_t)(n_closed - 1) * 3 + 2];
+    }
     return 0;
 }
 

@@ -29,6 +29,8 @@ SYMBOLS = [
     ("pa_bam_header_text", ctypes.c_int, [c_void_p, c_void_p, c_int64, P64]),
     ("pa_bam_get_reads", ctypes.c_int, [c_void_p, c_char_p, c_int64, c_int64, c_int32, c_int32, c_int32, P64, P64, P64, P64]),
     ("pa_bam_copy_reads", ctypes.c_int, [c_void_p] + [c_void_p] * 13),
+    ("pa_bam_pack_regions", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64,
+                                           c_void_p, c_int32, c_void_p, c_int32, c_void_p, ctypes.POINTER(c_int32), c_void_p]),
 ]
 _bound = False
 
@@ -120,6 +122,10 @@ class ReadSet(object):
             yield self[i]
 
 
+PACKED_READ = np.dtype([("data_off", np.int64), ("pos", np.int32), ("n_cigar", np.int32), ("l_seq", np.int32),
+                        ("flags", np.int32)])          # pa_packed_read (include/pepper_amd_io.h)
+
+
 class BAM_handler(object):
     def __init__(self, path):
         self._h = c_void_p()
@@ -178,6 +184,23 @@ class BAM_handler(object):
                     if parts[0] == "SM" and len(parts) > 1:
                         samples.add(parts[1])
         return samples
+
+    def pack_regions(self, chromosome, starts, stops, include_supplementary, min_mapq, arena, reads, pair_read):
+        """pa_bam_pack_regions: the reads of the regions [starts[r], stops[r]] (ascending, one contig) in the packed form of the
+        GPU encoder, written into the caller's buffers -- arena: uint8 array (the encoder's page-locked arena), reads: array
+        of PACKED_READ, pair_read: int32 array.  -> (n_done, region_pairs int32 [n + 1], (n_reads, n_pairs, arena_bytes)):
+        the first n_done regions are complete; the caller goes on with the rest when n_done < len(starts)."""
+        starts = np.ascontiguousarray(starts, np.int64)
+        stops = np.ascontiguousarray(stops, np.int64)
+        n = len(starts)
+        region_pairs = np.zeros(n + 1, np.int32)
+        counts = np.zeros(3, np.int64)
+        n_done = c_int32()
+        _check(_lib().pa_bam_pack_regions(self._h, str(chromosome).encode(), n, starts.ctypes.data, stops.ctypes.data,
+                                          int(bool(include_supplementary)), int(min_mapq), arena.ctypes.data, arena.nbytes,
+                                          reads.ctypes.data, len(reads), pair_read.ctypes.data, len(pair_read),
+                                          region_pairs.ctypes.data, ctypes.byref(n_done), counts.ctypes.data))
+        return n_done.value, region_pairs, (int(counts[0]), int(counts[1]), int(counts[2]))
 
     def get_reads(self, chromosome, start, stop, include_supplementary, min_mapq=0, min_baseq=0):
         lib = _lib()

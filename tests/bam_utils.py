@@ -152,3 +152,68 @@ def restated_get_reads(records, start, stop, include_supplementary, min_mapq):
                             cigar=out_cigar, mapq=rec.get("mapq", 60), reverse=bool(flag & 0x10), flag=flag,
                             hp=rec.get("hp", 0)))
     return out
+
+
+# ---- the packed form (pa_bam_pack_regions) and the closed form of the clipping walk the device runs on it -------------
+
+def unpack_packed_read(arena, rd):
+    """One pa_packed_read entry -> dict(pos, cigar, seq, qual, flag, mapq) (arena: uint8 array)."""
+    off, n_cig, l_seq = int(rd["data_off"]), int(rd["n_cigar"]), int(rd["l_seq"])
+    words = np.frombuffer(arena[off:off + 4 * n_cig].tobytes(), "<u4")
+    cigar = [(int(w) & 15, int(w) >> 4) for w in words]
+    packed = arena[off + 4 * n_cig:off + 4 * n_cig + (l_seq + 1) // 2]
+    codes = np.empty(2 * len(packed), np.uint8)
+    codes[0::2] = packed >> 4
+    codes[1::2] = packed & 15
+    seq = "".join("=ACMGRSVTWYHKDBN"[c] for c in codes[:l_seq])
+    q0 = off + 4 * n_cig + (l_seq + 1) // 2
+    flags = int(rd["flags"])
+    return dict(pos=int(rd["pos"]), cigar=cigar, seq=seq, qual=arena[q0:q0 + l_seq].tolist(), flag=flags & 0xffff,
+                mapq=(flags >> 16) & 0xff)
+
+
+def closed_form_clip(rec, start, stop, chunk=64):
+    """The clipping of bam_handler.cpp:176-303 WITHOUT its running state, as unpack_clip_kernel (pepper_amd/csrc/encoder.hip)
+    computes it: every operation's reference / read position from prefix sums over `chunk` operations at a time, what is kept
+    of it from those alone plus one bit -- has an earlier operation kept an aligned base ("anchored").
+    -> None when no base of the read lies inside [start, stop], else dict(pos, cigar, first_idx, written)."""
+    rpos, ridx = rec["pos"], 0
+    anchored = False
+    out, written, pos_start, first_idx = [], 0, -1, -1
+    cigar = rec["cigar"]
+    for cb in range(0, len(cigar), chunk):
+        ops = cigar[cb:cb + chunk]
+        rb, qb = [], []
+        r, q = rpos, ridx
+        for op, n in ops:
+            rb.append(r)
+            qb.append(q)
+            if op in (0, 7, 8, 2, 3):
+                r += n
+            if op in (0, 7, 8, 1, 4):
+                q += n
+        kept_m = [max(0, min(b + n - 1, stop) - max(b, start) + 1) if op in (0, 7, 8) else 0 for (op, n), b in zip(ops, rb)]
+        first = next((i for i, k in enumerate(kept_m) if k > 0), None)
+        for i, ((op, n), b, qq) in enumerate(zip(ops, rb, qb)):
+            anch = anchored or (first is not None and i > first)
+            kept = 0
+            if op in (0, 7, 8):
+                kept = kept_m[i]
+            elif op in (1, 4):
+                kept = n if (start <= b <= stop and anch) else 0
+            elif op in (2, 3):
+                kept = min(n, stop - b + 1) if (start <= b <= stop and anch) else 0
+            if kept > 0:
+                out.append((op, kept))
+                if op in (0, 7, 8, 1, 4):
+                    written += kept
+        if not anchored and first is not None:
+            anchored = True
+            pos_start = max(rb[first], start)
+            first_idx = qb[first] + max(0, start - rb[first])
+        rpos, ridx = r, q
+        if rpos > stop:
+            break
+    if written == 0:
+        return None
+    return dict(pos=pos_start, cigar=out, first_idx=first_idx, written=written)

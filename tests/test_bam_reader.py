@@ -222,3 +222,96 @@ def test_records_without_their_bases(tmp_path):
         bam.get_reads("ctg", 0, 1000, False, 0, 0)
     compare(bam.get_reads("ctg", 0, 115, False, 0, 0), bu.restated_get_reads([ok], 0, 115, False, 0))   # the handle is still usable
     bam.close()
+
+
+def _mixed_reads(rng, ref_len, n_reads, read_len):
+    ref = pu.random_reference(rng, ref_len)
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=n_reads, read_len=read_len, clip_rate=0.4, mapq_zero_rate=0.1)
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    for i, r in enumerate(reads):
+        r["name"] = "read%d" % i
+        r["flag"] = (16 if r["reverse"] else 0) | int(rng.choice([0, 0x800, 0x100, 0x400, 0x200, 0x4], p=[.86, .04, .04, .02, .02, .02]))
+    return reads
+
+
+def test_closed_form_of_the_clipping_walk():
+    """What the device computes per (read, region) from prefix sums (bam_utils.closed_form_clip) equals the reference's
+    sequential walk (bam_utils.restated_get_reads) -- on random reads with every operation kind, regions of a few bases to a few
+    kb, and chunk sizes that put the first kept base on a chunk edge."""
+    rng = np.random.default_rng(41)
+    reads = _mixed_reads(rng, 30000, 500, (100, 5000))
+    extra = [dict(pos=95, cigar=[(4, 3), (1, 2), (0, 5), (2, 4), (1, 3), (0, 6), (3, 9), (0, 2), (4, 2)], seq="A" * 23, qual=[9] * 23),
+             dict(pos=100, cigar=[(5, 4), (2, 3), (0, 4)], seq="ACGT", qual=[9] * 4),
+             dict(pos=90, cigar=[(0, 10), (2, 30)], seq="A" * 10, qual=[9] * 10),        # only a deletion reaches the region
+             dict(pos=80, cigar=[(0, 20), (1, 4), (0, 3)], seq="A" * 27, qual=[9] * 27)]   # insert sitting right at start
+    cases = 0
+    for rec in reads + extra:
+        end = rec["pos"] + max(1, bu.ref_length(rec["cigar"]))
+        spots = [rec["pos"] - 5, rec["pos"], rec["pos"] + 7, (rec["pos"] + end) // 2, end - 2, end]
+        for start in spots + (list(range(88, 125)) if rec in extra else []):
+            for width in (0, 1, 13, 700):
+                start, stop = max(0, int(start)), max(0, int(start)) + width
+                want = bu.restated_get_reads([dict(rec, flag=0, mapq=60)], start, stop, True, 0)
+                for chunk in (64, 3):
+                    got = bu.closed_form_clip(rec, start, stop, chunk)
+                    if not want:
+                        # (the iterator's own test may have dropped the read before the walk: the closed form then keeps nothing
+                        # or is never asked)
+                        assert got is None or not (rec["pos"] < stop and end > start)
+                        continue
+                    w = want[0]
+                    assert got is not None and (got["pos"], got["cigar"]) == (w["pos"], w["cigar"])
+                    assert rec["seq"][got["first_idx"]:got["first_idx"] + got["written"]].upper() == w["seq"]
+                    cases += 1
+    assert cases > 5000
+
+
+def test_pack_regions_lists_what_get_reads_returns(tmp_path):
+    """pa_bam_pack_regions + the closed-form clip == get_reads for every region of a batch: filters, the iterator's region test,
+    reads shared by neighbouring regions stored once, regions cut off when the arena is small (n_done < n)."""
+    from pepper_amd.variant.bam import PACKED_READ
+    rng = np.random.default_rng(43)
+    reads = _mixed_reads(rng, 60000, 900, (300, 6000))
+    other = _mixed_reads(rng, 9000, 40, (200, 900))
+    path = str(tmp_path / "p.bam")
+    bu.write_bam(path, [("chrA", 9000), ("chrB", 60000)], {0: other, 1: reads}, flush_every=37)
+    bam = BAM_handler(path)
+    edges = list(range(0, 60000, 7000)) + [60000]
+    starts = np.array([max(0, a - 100) for a in edges[:-1]], np.int64)
+    stops = np.array([b + 100 for b in edges[1:]], np.int64)
+
+    def check(arena_bytes, include_supp, min_mapq):
+        arena = np.zeros(arena_bytes, np.uint8)
+        table = np.zeros(4000, PACKED_READ)
+        pair_read = np.zeros(8000, np.int32)
+        r0, calls = 0, 0
+        while r0 < len(starts):
+            n_done, region_pairs, (n_reads, n_pairs, used) = bam.pack_regions("chrB", starts[r0:], stops[r0:], include_supp, min_mapq,
+                                                                               arena, table, pair_read)
+            calls += 1
+            assert 1 <= n_done <= len(starts) - r0 and used <= arena_bytes and region_pairs[n_done] == n_pairs
+            assert len(set(int(table["data_off"][k]) for k in range(n_reads))) == n_reads
+            for r in range(n_done):
+                got = []
+                for k in pair_read[region_pairs[r]:region_pairs[r + 1]].tolist():
+                    rec = bu.unpack_packed_read(arena, table[k])
+                    c = bu.closed_form_clip(rec, int(starts[r0 + r]), int(stops[r0 + r]))
+                    if c is not None:
+                        got.append((c["pos"], c["cigar"], rec["seq"][c["first_idx"]:c["first_idx"] + c["written"]],
+                                    rec["qual"][c["first_idx"]:c["first_idx"] + c["written"]], bool(rec["flag"] & 16), rec["mapq"]))
+                want = bam.get_reads("chrB", int(starts[r0 + r]), int(stops[r0 + r]), include_supp, min_mapq, 0)
+                assert got == [(w.pos, [(c.cigar_op, c.cigar_len) for c in w.cigar_tuples], w.sequence, w.base_qualities,
+                                w.flags.is_reverse, w.mapping_quality) for w in want]
+            r0 += n_done
+        return calls
+    assert check(1 << 24, False, 1) == 1
+    assert check(1 << 24, True, 0) == 1
+    total = sum(4 * len(r["cigar"]) + 3 * len(r["seq"]) // 2 for r in reads)
+    assert check(total // 3, False, 0) > 2           # a third of the contig's read data: the batch is cut into several calls
+    with pytest.raises(BamError, match="do not fit"):
+        bam.pack_regions("chrB", starts, stops, False, 0, np.zeros(total // 40, np.uint8), np.zeros(4000, PACKED_READ),
+                         np.zeros(8000, np.int32))
+    with pytest.raises(BamError):
+        bam.pack_regions("chrB", starts[::-1], stops[::-1], False, 0, np.zeros(1 << 20, np.uint8), np.zeros(4000, PACKED_READ),
+                         np.zeros(8000, np.int32))
+    bam.close()
