@@ -21,6 +21,7 @@ extern "C" {
 #define PA_ERR_INVALID 1   /* bad argument / missing or mis-shaped tensor */
 #define PA_ERR_HIP 2       /* HIP runtime error (message in pa_last_error) */
 #define PA_ERR_NO_DEVICE 3 /* no gfx950 device visible */
+#define PA_ERR_UNSUPPORTED 4 /* well-formed input this entry point does not take (the message names the one that does) */
 
 /* Thread-local message describing the last non-zero return on this thread. */
 const char* pa_last_error(void);

@@ -73,9 +73,47 @@ int pa_encoder_generate_summary_batch(pa_encoder* e, int32_t n_regions, const pa
  * last run).  bench.py times pa_encoder_run_staged. */
 int pa_encoder_stage_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const pa_summary_params* params);
 int pa_encoder_run_staged(pa_encoder* e, int64_t* n_candidates);
+/* ------------------------------------------------------------------------------------------
+ * The packed form: reads as BAM stores them, clipped and decoded ON THE DEVICE.
+ * replaces, for the image generator: BAM_handler.get_reads per region (bam_handler.cpp:176-303, the walk that clips a
+ * read to the region and decodes its bases) + the hand-over of the clipped reads above.  pa_bam_pack_regions
+ * (include/pepper_amd_io.h) fills the arena and the tables for a run of regions; here they are uploaded with one copy each and
+ * unpack_clip_kernel (one wave per (read, region)) produces what pa_encoder_stage_batch would have been given.  Results are
+ * those of the host-clipped form bit for bit.  Nothing in the call waits for the device; pa_encoder_run_staged follows.
+ *   arena        what pa_bam_pack_regions wrote (pa_encoder_host_arena returns a page-locked block of the handle for it:
+ *                the upload is then asynchronous; any host memory works)
+ *   reads        n_reads table entries; pair_read[region_pairs[r] .. region_pairs[r + 1]) = the reads of region r
+ *   regions      per region the generator's ref_start / ref_end (= the fetch range given to the packer) and its reference
+ * The `reference` buffers must stay valid until the run returns (deleted bases of candidate alleles are cut from them).
+ * An operation of 2^24 bases or more fails the run with PA_ERR_UNSUPPORTED: take the host-clipped form for that batch.
+ * ------------------------------------------------------------------------------------------ */
+#ifndef PA_PACKED_READ_DEFINED
+#define PA_PACKED_READ_DEFINED
+typedef struct {
+    int64_t data_off;      /* in the arena: n_cigar uint32 (len << 4 | op), (l_seq + 1) / 2 bytes of 4-bit bases, l_seq qualities */
+    int32_t pos;           /* 0-based leftmost position of the record */
+    int32_t n_cigar;
+    int32_t l_seq;
+    int32_t flags;         /* BAM flag | mapping quality << 16 */
+} pa_packed_read;
+#endif
+typedef struct {
+    int64_t region_start, region_end;
+    const char* reference;
+    int64_t reference_len;
+} pa_packed_region;
+void* pa_encoder_host_arena(pa_encoder* e, int64_t bytes);      /* page-locked, grows, valid until the next call with more bytes */
+int pa_encoder_stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_region* regions, const pa_summary_params* params,
+                            const uint8_t* arena, int64_t arena_bytes, const pa_packed_read* reads, int32_t n_reads,
+                            const int32_t* pair_read, const int32_t* region_pairs);
+/* Reads with at least one base inside each region of the last run -- the reference's len(all_reads) after get_reads (an
+ * interval without any writes no summary group, AlignmentSummarizer.py:200-204); host-clipped form: the pileup's n_reads. */
+int pa_encoder_region_reads(pa_encoder* e, int32_t* n_reads, int32_t n);
+
 /* Times of the last run in milliseconds, HIP events on the encoder's stream: [0] record kernels (segment_reads x 2 +
  * tile_offsets), [1] tile_count_kernel, [2] compact_votes_kernel + pack_results_kernel, [3] gather_windows_kernel; host clock:
- * [4] candidate enumeration, [5] the whole run.  Sizes of the staged batch: [0] read bases, [1] matrix rows,
+ * [4] candidate enumeration, [5] the whole run, [6], [7] parts of [4]; packed form: [8] upload of arena + tables,
+ * [9] unpack_clip_kernel.  Sizes of the staged batch: [0] read bases, [1] matrix rows,
  * [2] reads, [3] CIGAR operations, [4] tiles, [5] regions. */
 int pa_encoder_last_timing(pa_encoder* e, double* ms, int32_t n);
 int pa_encoder_batch_stats(pa_encoder* e, int64_t* out, int32_t n);

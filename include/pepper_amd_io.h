@@ -233,6 +233,8 @@ int pa_bam_copy_reads(pa_bam* b, int64_t* pos, int64_t* pos_end, uint8_t* revers
  * the region) are still listed: the device drops them.  When the arena or a table fills up the call stops at a region
  * boundary: *n_done regions (>= 1, else the call fails) are complete and described by counts = {reads, pairs, arena bytes};
  * the caller continues with region n_done. */
+#ifndef PA_PACKED_READ_DEFINED
+#define PA_PACKED_READ_DEFINED
 typedef struct {
     int64_t data_off;      /* in the arena: n_cigar uint32 (len << 4 | op), (l_seq + 1) / 2 bytes of 4-bit bases, l_seq qualities */
     int32_t pos;           /* 0-based leftmost position of the record */
@@ -240,6 +242,7 @@ typedef struct {
     int32_t l_seq;
     int32_t flags;         /* BAM flag | mapping quality << 16 */
 } pa_packed_read;
+#endif
 int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const int64_t* start, const int64_t* stop,
                         int32_t include_supplementary, int32_t min_mapq, uint8_t* arena, int64_t arena_cap,
                         pa_packed_read* reads, int32_t reads_cap, int32_t* pair_read, int32_t pairs_cap,

@@ -66,6 +66,10 @@ SYMBOLS = [
     ("pa_encoder_generate_summary_batch", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     ("pa_encoder_stage_batch", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     ("pa_encoder_run_staged", ctypes.c_int, [c_void_p, c_void_p]),
+    ("pa_encoder_host_arena", c_void_p, [c_void_p, c_int64]),
+    ("pa_encoder_stage_packed", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
+                                               c_void_p, c_void_p]),
+    ("pa_encoder_region_reads", ctypes.c_int, [c_void_p, c_void_p, c_int32]),
     ("pa_encoder_last_timing", ctypes.c_int, [c_void_p, c_void_p, c_int32]),
     ("pa_encoder_batch_stats", ctypes.c_int, [c_void_p, c_void_p, c_int32]),
     ("pa_encoder_get_results", ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -119,10 +123,15 @@ def load():
     return lib
 
 
+PA_ERR_UNSUPPORTED = 4
+
+
 def check(rc):
     if rc != PA_OK:
         msg = load().pa_last_error()
-        raise PepperAmdError(f"pepper_amd error {rc}: {msg.decode() if msg else '?'}")
+        err = PepperAmdError(f"pepper_amd error {rc}: {msg.decode() if msg else '?'}")
+        err.code = rc
+        raise err
 
 
 def _as_numpy_f32(v):

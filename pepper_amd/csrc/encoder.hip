@@ -59,7 +59,8 @@ static_assert(NT == TP && 64 * UNR == TP, "one thread per row, UNR rows per lane
 // 20..23 / 24..27 = forward / reverse tallies of mismatching A C G T (the SNP allele map of :409-425)
 enum { K_COV = 0, K_SNP = 1, K_INS = 2, K_DEL = 3, K_FWD = 4, K_REV = 12, K_TAB = 20 };
 // counters of a run
-enum { CT_OVF = 0, CT_VOTES = 2, CT_ERR = 3, CT_N = 8 };
+enum { CT_OVF = 0, CT_VOTES = 2, CT_ERR = 3, CT_POOL = 4, CT_N = 8 };
+constexpr int POOL_SLOT = 64;       // bytes per pooled allele (an allele is at most 61 bytes, region_summary.cpp:455)
 // per region, behind them: [2 r] passing sites, [2 r + 1] votes of passing sites -- both lists are written region by region
 // (sites of region r from row_base, votes from vote_base), so the host never has to sort a batch's records by region
 
@@ -172,6 +173,121 @@ __global__ __launch_bounds__(256) void segment_reads_kernel(const ReadRec* __res
         pos += wave_total(rinc);
         if (FILL) ri += wave_total(qinc);
         if (pos > L - 1) break;
+    }
+}
+
+
+// ---- packed form: clip + decode on the device -----------------------------------------------------------------------
+// pa_bam_pack_regions (pepper_amd/csrc/bamio.cpp) ships every record as BAM stores it -- uint32 CIGAR words, 4-bit bases, one
+// byte per quality -- once per batch; what the reference's get_reads does per (read, region) on the host (bam_handler.cpp:
+// 176-303: walk the CIGAR, keep what lies inside [start, stop], decode the kept stretch of bases) is this kernel: one wave per
+// (read, region) pair.  The walk has no running state here: 64 operations at a time, wave prefix sums give every operation its
+// reference / read position, and what is kept of it follows from those plus one bit -- has an earlier operation kept an aligned
+// base ("anchored": inserts, soft clips, deletions and skips are kept only behind one) [tests/bam_utils.py closed_form_clip is
+// the same arithmetic in Python, checked against the sequential walk].  The kept bases are ONE stretch of the read
+// (bamio.cpp, pa_bam_get_reads); it is decoded four bases per lane into the byte-per-base arrays tile_count_kernel reads.
+struct PackedRead { int64_t data_off; int32_t pos, n_cigar, l_seq, flags; };     // = pa_packed_read
+struct PairRec { int64_t s0; int32_t read, region, c0, pad; };                   // where the pair's clipped bases / operations go
+static_assert(sizeof(PackedRead) == sizeof(pa_packed_read) && sizeof(PackedRead) == 24 && sizeof(PairRec) == 24, "packed tables");
+
+struct UnpackArgs {
+    const PairRec* pairs; int n_pairs;
+    const PackedRead* preads; const RegRec* regions; const int64_t* region_start; const uint8_t* arena;
+    ReadRec* reads; int32_t* cigar_op; int32_t* cigar_len; char* seq; uint8_t* qual;
+    int* live;        // [n_regions] reads with a base inside | [n_regions] first inconsistent read + 1 | [n_regions + 1] first unsupported + 1
+    int n_regions;
+};
+
+__global__ __launch_bounds__(256) void unpack_clip_kernel(UnpackArgs a) {
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pi >= a.n_pairs) return;
+    const PairRec pr = a.pairs[pi];
+    const PackedRead rd = a.preads[pr.read];
+    const int64_t start = a.region_start[pr.region], stop = start + a.regions[pr.region].L - 1;
+    const uint32_t* cig = reinterpret_cast<const uint32_t*>(a.arena + rd.data_off);
+    // positions relative to the region's start, clamped far outside it: a read that begins 2^30 bases in front of the region
+    // would need operations the check below refuses anyway
+    int64_t rel64 = (int64_t)rd.pos - start;
+    int rpos = (int)(rel64 < -(1 << 30) ? -(1 << 30) : rel64);      // (rd.pos < stop: the packer's region test)
+    const int last = (int)(stop - start);                            // rows 0 .. last are inside
+    int ridx = 0, n_out = 0, written = 0, pos_start = 0, first_idx = 0;
+    bool anchored = false, unsupported = false;
+    for (int cb = 0; cb < rd.n_cigar; cb += 64) {
+        const int i = cb + lane;
+        const uint32_t c = i < rd.n_cigar ? cig[i] : 5u;             // (H: nothing)
+        const int op = (int)(c & 15u), len = (int)(c >> 4);
+        const bool isM = op == OP_M || op == OP_EQ || op == OP_X, isIS = op == OP_I || op == OP_S, isDN = op == OP_D || op == OP_N;
+        if (__ballot(len >= (1 << 24))) { unsupported = true; break; }          // (prefix sums are 32-bit: 64 x 2^24 fits)
+        const int radv = (isM || isDN) ? len : 0, qadv = (isM || isIS) ? len : 0;
+        const int rinc = wave_inclusive_sum(radv), qinc = wave_inclusive_sum(qadv);
+        const int rb = rpos + rinc - radv, qb = ridx + qinc - qadv;
+        const int lo = rb > 0 ? rb : 0, hi = rb + len - 1 < last ? rb + len - 1 : last;
+        const int kept_m = (isM && hi >= lo) ? hi - lo + 1 : 0;
+        const unsigned long long mm = __ballot(kept_m > 0);
+        const int first = mm ? __ffsll((long long)mm) - 1 : 64;
+        const bool anch = anchored || lane > first;
+        const bool inside = rb >= 0 && rb <= last;
+        int kept = kept_m;
+        if (isIS) kept = (inside && anch) ? len : 0;
+        if (isDN) kept = (inside && anch) ? (len < last - rb + 1 ? len : last - rb + 1) : 0;
+        if (!anchored && mm) {
+            pos_start = __builtin_amdgcn_readlane(lo, first);
+            first_idx = __builtin_amdgcn_readlane(qb + (rb < 0 ? -rb : 0), first);
+            anchored = true;
+        }
+        const unsigned long long km = __ballot(kept > 0);
+        if (kept > 0) {
+            const int slot = pr.c0 + n_out + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+            a.cigar_op[slot] = op;
+            a.cigar_len[slot] = kept;
+        }
+        n_out += __popcll(km);
+        written += wave_sum((isM || isIS) ? kept : 0);
+        rpos += wave_total(rinc);
+        ridx += wave_total(qinc);
+        if (rpos > last) break;
+    }
+    const bool bad = !unsupported && written > 0 && ((unsigned)first_idx + (unsigned)written > (unsigned)rd.l_seq);
+    if (lane == 0) {
+        if (unsupported) atomicMax(&a.live[a.n_regions + 1], pr.read + 1);
+        if (bad) atomicMax(&a.live[a.n_regions], pr.read + 1);
+    }
+    if (unsupported || bad) written = 0;
+    if (lane == 0) {
+        ReadRec out;
+        out.s0 = pr.s0;
+        out.c0 = pr.c0;
+        out.ncig = written > 0 ? n_out : 0;
+        out.slen = written;
+        out.row0 = pos_start;
+        out.region = pr.region;
+        out.flags = ((rd.flags & 0x10) ? READ_REV : 0) | ((written > 0 && ((rd.flags >> 16) & 0xff) > 0) ? READ_MAPQ_OK : 0);
+        a.reads[pi] = out;
+        if (written > 0) atomicAdd(&a.live[pr.region], 1);
+    }
+    if (written <= 0) return;
+    // the kept stretch: bases first_idx .. first_idx + written - 1 of the record, four per lane and step
+    const uint8_t* packed = a.arena + rd.data_off + 4ll * rd.n_cigar;
+    const uint8_t* quals = packed + (rd.l_seq + 1) / 2;
+    const unsigned long long lut_lo = 0x565352474d43413dull;                // "=ACMGRSV", first letter in the low byte
+    const unsigned long long lut_hi = 0x4e42444b48595754ull;                // "TWYHKDBN"
+    uint32_t* seq_out = reinterpret_cast<uint32_t*>(a.seq + pr.s0);         // (s0 is a multiple of 4)
+    uint32_t* qual_out = reinterpret_cast<uint32_t*>(a.qual + pr.s0);
+    auto letter = [&](unsigned code) -> unsigned {
+        const unsigned long long t = (code & 8u) ? lut_hi : lut_lo;
+        return (unsigned)(t >> ((code & 7u) * 8u)) & 0xffu;
+    };
+    for (int j = lane; 4 * j < written; j += 64) {
+        const int bidx = first_idx + 4 * j;
+        const uint8_t* src = packed + (bidx >> 1);
+        const unsigned p0 = src[0], p1 = src[1], p2 = src[2];               // (past the record's bases: its qualities / the arena's padding)
+        unsigned c0, c1, c2, c3;
+        if (bidx & 1) { c0 = p0 & 15u; c1 = p1 >> 4; c2 = p1 & 15u; c3 = p2 >> 4; }
+        else { c0 = p0 >> 4; c1 = p0 & 15u; c2 = p1 >> 4; c3 = p1 & 15u; }
+        seq_out[j] = letter(c0) | (letter(c1) << 8) | (letter(c2) << 16) | (letter(c3) << 24);
+        const uint8_t* q = quals + bidx;
+        qual_out[j] = (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24);
     }
 }
 
@@ -664,9 +780,14 @@ __global__ __launch_bounds__(256) void compact_votes_kernel(const Vote* __restri
 
 // The two region-sliced lists made dense for one copy to the host: region r's sites / votes move to the prefix sums of the
 // counts before it (one workgroup per region; the counts of a batch are a few hundred integers).
+// An insert allele of more than 8 bytes (its first 8 travel in the vote's prefix) is copied into a pool slot here and the vote's
+// `off` becomes the slot: the host orders and names alleles without the reads, which in the packed form (pa_encoder_stage_packed)
+// it never holds decoded.
 __global__ __launch_bounds__(256) void pack_results_kernel(const RegRec* __restrict__ regions, const int* __restrict__ region_counts,
                                                            const SiteRec* __restrict__ sites, const Vote* __restrict__ votes,
-                                                           SiteRec* __restrict__ sites_out, Vote* __restrict__ votes_out) {
+                                                           SiteRec* __restrict__ sites_out, Vote* __restrict__ votes_out,
+                                                           const char* __restrict__ seq, char* __restrict__ pool, int pool_cap,
+                                                           int* __restrict__ counters) {
     __shared__ int off[2];
     const int r = blockIdx.x;
     if (threadIdx.x < 2) off[threadIdx.x] = 0;
@@ -683,7 +804,18 @@ __global__ __launch_bounds__(256) void pack_results_kernel(const RegRec* __restr
     const SiteRec* src_s = sites + regions[r].row_base;
     const Vote* src_v = votes + regions[r].vote_base;
     for (int i = threadIdx.x; i < ns; i += 256) sites_out[off[0] + i] = src_s[i];
-    for (int i = threadIdx.x; i < nv; i += 256) votes_out[off[1] + i] = src_v[i];
+    const char* rseq = seq + regions[r].seq_base;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        Vote v = src_v[i];
+        const uint32_t len = (v.meta >> 4) & 63u;
+        if (!(v.meta & 8u) && len > 8) {
+            const int slot = atomicAdd(&counters[CT_POOL], 1);
+            if (slot < pool_cap)
+                for (uint32_t k = 0; k < len; ++k) pool[(size_t)slot * POOL_SLOT + k] = rseq[(size_t)v.off + k];
+            v.off = slot;
+        }
+        votes_out[off[1] + i] = v;
+    }
 }
 
 // one 64-lane workgroup per candidate: 33 x 26 = 858 cells
@@ -831,9 +963,18 @@ struct pa_variant_batch {
     std::vector<RegHost> regs;
     int64_t total_bases = 0, total_ops = 0, total_reads = 0, total_rows = 0, total_ref = 0;
     int n_tiles = 0, W = 33, F = 26, mid = 16;
-    int rec_cap = 0, ovf_cap = 0;
-    bool staged = false;
+    int rec_cap = 0, ovf_cap = 0, pool_cap = 0;
+    bool staged = false, packed = false;
     DBuf d_seq, d_qual, d_ref, d_cig_op, d_cig_len, d_reads, d_regions, d_tile_region;
+    // the tables of the staged batch as the kernels get them: the buffers above (pa_encoder_stage_batch) or slices of d_meta
+    // (pa_encoder_stage_packed, one upload for all of them)
+    const RegRec* p_regions = nullptr;
+    const int32_t* p_tile_region = nullptr;
+    const char* p_ref = nullptr;
+    // packed form: the caller's arena as uploaded, the tables, what unpack_clip_kernel reports per region
+    DBuf d_arena, d_meta, d_live, d_pool;
+    HBuf h_arena, h_meta, h_live, h_pool;
+    std::vector<int32_t> live;        // reads with a base inside each region (the reference's len(all_reads)) of the last run
     DBuf d_zero;                      // counters [CT_N] | per-region counts [2 n_regions] | tile_count [n_tiles] | tile_fill [n_tiles]: cleared per run
     DBuf d_tile_off, d_sorted, d_mat, d_pass, d_sites, d_votes, d_votes_out, d_sites_dense, d_votes_dense, d_ovf, d_cands, d_img32, d_img8;
     HBuf h_counts, h_sites, h_votes;
@@ -844,7 +985,7 @@ struct pa_variant_batch {
     std::vector<int64_t> positions;
     std::vector<int32_t> depths, freqs;
     std::string names;
-    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double ms[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 void pa_variant_batch_free(pa_variant_batch* b) { delete b; }
@@ -859,30 +1000,41 @@ struct RegionOut {
     std::string names;
 };
 
-inline const char* allele_bytes(const Vote& v, const pa_pileup& p) { return ((v.meta & 8u) ? p.reference : p.seq) + v.off; }
+// where the bytes of a vote's allele past the first eight live: deleted bases in the region's reference, inserted ones in the
+// pool slot pack_results_kernel filled (the first eight are the vote's prefix)
+struct AlleleSrc { const char* reference; const char* pool; };
+inline const char* allele_tail(const Vote& v, const AlleleSrc& p) {
+    return ((v.meta & 8u) ? p.reference + v.off : p.pool + (size_t)v.off * POOL_SLOT) + 8;
+}
+inline void append_allele(std::string& key, const Vote& v, const AlleleSrc& p) {
+    const uint32_t len = (v.meta >> 4) & 63u;
+    for (uint32_t k = 0; k < std::min(len, 8u); ++k) key.push_back((char)(v.prefix >> (56 - 8 * k)));
+    if (len > 8) key.append(allele_tail(v, p), (size_t)len - 8);
+}
 // order of the votes of one region: site, then the allele key as std::map<std::string> orders "2..." / "3..." strings
 // (type character, bytes as unsigned chars, the shorter of two that agree first).  The 8-byte prefix decides nearly always.
-inline bool vote_less(const Vote& x, const Vote& y, const pa_pileup& p) {
+inline bool vote_less(const Vote& x, const Vote& y, const AlleleSrc& p) {
     if (x.idx != y.idx) return x.idx < y.idx;
     const uint32_t tx = x.meta & 3u, ty = y.meta & 3u;
     if (tx != ty) return tx < ty;
     if (x.prefix != y.prefix) return x.prefix < y.prefix;
     const uint32_t lx = (x.meta >> 4) & 63u, ly = (y.meta >> 4) & 63u;
     if (lx > 8 && ly > 8) {
-        const int c = std::memcmp(allele_bytes(x, p) + 8, allele_bytes(y, p) + 8, std::min(lx, ly) - 8);
+        const int c = std::memcmp(allele_tail(x, p), allele_tail(y, p), std::min(lx, ly) - 8);
         if (c != 0) return c < 0;
     }
     return lx < ly;
 }
-inline bool same_allele(const Vote& x, const Vote& y, const pa_pileup& p) {
+inline bool same_allele(const Vote& x, const Vote& y, const AlleleSrc& p) {
     if (x.idx != y.idx || ((x.meta ^ y.meta) & 3u) || x.prefix != y.prefix) return false;
     const uint32_t lx = (x.meta >> 4) & 63u, ly = (y.meta >> 4) & 63u;
-    return lx == ly && (lx <= 8 || std::memcmp(allele_bytes(x, p) + 8, allele_bytes(y, p) + 8, lx - 8) == 0);
+    return lx == ly && (lx <= 8 || std::memcmp(allele_tail(x, p), allele_tail(y, p), lx - 8) == 0);
 }
 
 void enumerate_region(const RegHost& rh, int region, int mid, const SiteRec* sites, size_t n_sites, const Vote* votes,
-                      size_t n_votes, const int4* ovf, size_t n_ovf, RegionOut& out) {
+                      size_t n_votes, const int4* ovf, size_t n_ovf, const char* pool, RegionOut& out) {
     const pa_pileup& p = rh.p;
+    const AlleleSrc src{p.reference, pool};
     const pa_summary_params& q = rh.q;
     auto refc = [&](int64_t idx) { return idx >= 0 && idx < p.reference_len ? p.reference[idx] : 'N'; };
     std::map<int32_t, std::map<char, Tally>> rare;       // SNP alleles outside ACGT
@@ -961,7 +1113,7 @@ void enumerate_region(const RegHost& rh, int region, int mid, const SiteRec* sit
         for (size_t k0 = vk; k0 < n_votes && (int32_t)votes[k0].idx == s.idx;) {
             size_t k1 = k0;
             Tally t;
-            while (k1 < n_votes && same_allele(votes[k1], votes[k0], p)) {
+            while (k1 < n_votes && same_allele(votes[k1], votes[k0], src)) {
                 t.total += 1;
                 ((votes[k1].meta & 4u) ? t.rev : t.fwd) += 1;
                 ++k1;
@@ -984,7 +1136,7 @@ void enumerate_region(const RegHost& rh, int region, int mid, const SiteRec* sit
                     d.star_f = symbol_column(rb, '*', false); d.star_r = symbol_column(rb, '*', true);
                 }
                 std::string key(1, type);
-                key.append(allele_bytes(v, p), (size_t)alen);
+                append_allele(key, v, src);
                 emit(key, t, d);
             }
             k0 = k1;
@@ -1000,6 +1152,7 @@ int stage_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, cons
     if (!e->variant) e->variant = new pa_variant_batch();
     pa_variant_batch& b = *e->variant;
     b.staged = false;
+    b.ms[8] = b.ms[9] = 0;
     b.regs.assign((size_t)n_regions, RegHost());
     b.total_bases = b.total_ops = b.total_reads = b.total_rows = b.total_ref = 0;
     b.n_tiles = 0;
@@ -1114,6 +1267,171 @@ int stage_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, cons
     // more rows than they have bases, so the kernels count what they could not store and the run is repeated with room
     b.rec_cap = (int)std::min<int64_t>(0x7ffffff0, b.total_bases / TP + 2 * b.total_reads + 1024);
     b.ovf_cap = (int)std::min<int64_t>(0x7ffffff0, std::max<int64_t>(1 << 16, b.total_bases / 64));
+    b.pool_cap = (int)std::min<int64_t>(0x7ffffff0, std::max<int64_t>(4096, b.total_ops / 64));
+    b.p_regions = b.d_regions.as<RegRec>();
+    b.p_tile_region = b.d_tile_region.as<int32_t>();
+    b.p_ref = b.d_ref.as<char>();
+    b.packed = false;
+    b.live.assign((size_t)n_regions, 0);
+    for (int r = 0; r < n_regions; ++r) b.live[(size_t)r] = pileups[r].n_reads;
+    b.staged = true;
+    return PA_OK;
+}
+
+
+// The packed form of a batch (include/pepper_amd_encoder.h): tables built in ONE page-locked block and uploaded with one copy,
+// the arena with another, then unpack_clip_kernel -- nothing here waits for the device.
+int stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_region* regions, const pa_summary_params* params,
+                 const uint8_t* arena, int64_t arena_bytes, const pa_packed_read* reads, int32_t n_reads, const int32_t* pair_read,
+                 const int32_t* region_pairs) {
+    if (!e || n_regions < 0 || (n_regions > 0 && (!regions || !params || !region_pairs)) || arena_bytes < 0 || n_reads < 0 ||
+        (n_reads > 0 && (!arena || !reads || !pair_read)))
+        return pa::set_error(PA_ERR_INVALID, "null argument");
+    if (n_regions >= (1 << 22)) return pa::set_error(PA_ERR_INVALID, "more than 4194303 regions in one batch");
+    ENC_HIP(hipSetDevice(e->device));
+    if (!e->variant) e->variant = new pa_variant_batch();
+    pa_variant_batch& b = *e->variant;
+    b.staged = false;
+    b.ms[8] = b.ms[9] = 0;
+    b.regs.assign((size_t)n_regions, RegHost());
+    b.total_bases = b.total_ops = b.total_reads = b.total_rows = b.total_ref = 0;
+    b.n_tiles = 0;
+    const int64_t n_pairs = n_regions ? region_pairs[n_regions] : 0;
+    if (n_pairs < 0 || (n_regions && region_pairs[0] != 0)) return pa::set_error(PA_ERR_INVALID, "region_pairs must start at 0 and ascend");
+    for (int r = 0; r < n_regions; ++r) {
+        const pa_packed_region& p = regions[r];
+        const pa_summary_params& q = params[r];
+        if (p.region_end < p.region_start || p.region_end - p.region_start > (int64_t)1 << 28) return pa::set_error(PA_ERR_INVALID, "bad region");
+        if (q.feature_size < 26 || q.candidate_window_size < 2 || q.candidate_window_size > 254)
+            return pa::set_error(PA_ERR_INVALID, "feature_size must be >= 26 and 2 <= candidate_window_size <= 254");
+        if (r > 0 && (q.feature_size != params[0].feature_size || q.candidate_window_size != params[0].candidate_window_size))
+            return pa::set_error(PA_ERR_INVALID, "one batch has one window size and one feature size");
+        if (p.reference_len < 0 || p.reference_len > 0x7fffffff || region_pairs[r + 1] < region_pairs[r])
+            return pa::set_error(PA_ERR_INVALID, "negative count");
+        b.total_ref += p.reference_len;
+        b.total_rows += ((p.region_end - p.region_start + 1) + 1 + 15) & ~(int64_t)15;
+        b.n_tiles += (int)((p.region_end - p.region_start + 1 + 1 + TP - 1) / TP);
+        if (b.total_rows > ((int64_t)1 << 30)) return pa::set_error(PA_ERR_INVALID, "batch too large: more than 2^30 rows");
+    }
+    // one block: [RegRec x R][region_start x R][tile_region x tiles][PackedRead x reads][PairRec x pairs][reference bytes]
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_reg = 0, o_start = up16(o_reg + (size_t)n_regions * sizeof(RegRec)), o_tile = up16(o_start + (size_t)n_regions * 8),
+                 o_reads = up16(o_tile + (size_t)b.n_tiles * 4), o_pairs = up16(o_reads + (size_t)n_reads * sizeof(PackedRead)),
+                 o_ref = up16(o_pairs + (size_t)n_pairs * sizeof(PairRec)), meta_bytes = up16(o_ref + (size_t)b.total_ref + 64);
+    if (!b.h_meta.ensure(meta_bytes) || !b.h_live.ensure(((size_t)n_regions + 2) * 4)) return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed");
+    char* hm = b.h_meta.as<char>();
+    RegRec* regrecs = reinterpret_cast<RegRec*>(hm + o_reg);
+    int64_t* rstart = reinterpret_cast<int64_t*>(hm + o_start);
+    int32_t* tile_region = reinterpret_cast<int32_t*>(hm + o_tile);
+    PairRec* pairs = reinterpret_cast<PairRec*>(hm + o_pairs);
+    if (n_reads) std::memcpy(hm + o_reads, reads, (size_t)n_reads * sizeof(PackedRead));
+    b.total_rows = 0;
+    b.total_ref = 0;
+    b.n_tiles = 0;
+    for (int r = 0; r < n_regions; ++r) {
+        const pa_packed_region& p = regions[r];
+        const pa_summary_params& q = params[r];
+        RegHost& rh = b.regs[(size_t)r];
+        rh.p = pa_pileup{};
+        rh.p.region_start = p.region_start;
+        rh.p.region_end = p.region_end;
+        rh.p.reference = p.reference;
+        rh.p.reference_len = p.reference_len;
+        rh.p.n_reads = region_pairs[r + 1] - region_pairs[r];
+        rh.q = q;
+        rh.L = (int)(p.region_end - p.region_start + 1);
+        rh.row_base = b.total_rows;
+        rh.seq_base = b.total_bases;
+        rh.op_base = b.total_ops;
+        rh.read_base = region_pairs[r];
+        RegRec& g = regrecs[r];
+        g.ref_off = b.total_ref;
+        g.row_base = rh.row_base;
+        g.seq_base = rh.seq_base;
+        g.ref_len = (int32_t)p.reference_len;
+        g.L = rh.L;
+        g.tile0 = b.n_tiles;
+        g.n_tiles = (rh.L + 1 + TP - 1) / TP;
+        auto row_of = [&](int64_t pos) { return (int32_t)std::max<int64_t>(-2, std::min<int64_t>(pos - p.region_start, 0x7ffffff0)); };
+        g.cand_lo = row_of(q.candidate_region_start);
+        g.cand_hi = row_of(q.candidate_region_end);
+        g.qmin = std::isnan(q.min_snp_baseq) ? 256 : (q.min_snp_baseq <= 0 ? 0 : (q.min_snp_baseq > 255 ? 256 : (int)std::ceil(q.min_snp_baseq)));
+        g.vote_base = (int32_t)rh.op_base;
+        g.min_snp_q = q.min_snp_baseq;
+        g.min_indel_q = q.min_indel_baseq;
+        g.snp_thr = q.snp_freq_threshold;
+        g.ins_thr = q.insert_freq_threshold;
+        g.del_thr = q.delete_freq_threshold;
+        g.min_cov = q.min_coverage_threshold;
+        rstart[r] = p.region_start;
+        for (int t = 0; t < g.n_tiles; ++t) tile_region[g.tile0 + t] = r;
+        if (p.reference_len > 0) std::memcpy(hm + o_ref + b.total_ref, p.reference, (size_t)p.reference_len);
+        // where each pair's clipped bases and operations go: room for the whole read (what is kept is known on the device only)
+        for (int32_t k = region_pairs[r]; k < region_pairs[r + 1]; ++k) {
+            const int32_t ri = pair_read[k];
+            if (ri < 0 || ri >= n_reads) return pa::set_error(PA_ERR_INVALID, "pair_read out of range");
+            const pa_packed_read& rd = reads[ri];
+            if (rd.n_cigar < 0 || rd.l_seq < 0 || rd.data_off < 0 || (rd.data_off & 3) ||
+                rd.data_off + 4ll * rd.n_cigar + (rd.l_seq + 1) / 2 + rd.l_seq > arena_bytes)
+                return pa::set_error(PA_ERR_INVALID, "packed read " + std::to_string(ri) + " lies outside the arena");
+            pairs[k] = PairRec{b.total_bases, ri, r, (int32_t)b.total_ops, 0};
+            b.total_bases += ((int64_t)rd.l_seq + 3 & ~(int64_t)3) + 4;
+            b.total_ops += rd.n_cigar;
+            if (b.total_ops > 0x7ffffff0) return pa::set_error(PA_ERR_INVALID, "batch too large: more than 2^31 CIGAR operations");
+        }
+        if (b.total_bases - rh.seq_base > 0xffffff00ll) return pa::set_error(PA_ERR_INVALID, "a region is limited to 2^32 read bases");
+        b.total_rows += (rh.L + 1 + 15) & ~(int64_t)15;
+        b.total_ref += p.reference_len;
+        b.n_tiles += g.n_tiles;
+    }
+    b.total_reads = n_pairs;
+    b.W = n_regions ? params[0].candidate_window_size + 1 : 33;
+    b.F = n_regions ? params[0].feature_size : 26;
+    b.mid = n_regions ? params[0].candidate_window_size / 2 : 16;
+
+    hipStream_t st = e->stream;
+    ENC_ALLOC(b.d_arena, (size_t)arena_bytes + 256);
+    ENC_ALLOC(b.d_meta, meta_bytes);
+    ENC_ALLOC(b.d_live, ((size_t)n_regions + 2) * 4);
+    ENC_ALLOC(b.d_seq, (size_t)b.total_bases + 64);
+    ENC_ALLOC(b.d_qual, (size_t)b.total_bases + 64);
+    ENC_ALLOC(b.d_cig_op, (size_t)b.total_ops * 4 + 1024);
+    ENC_ALLOC(b.d_cig_len, (size_t)b.total_ops * 4 + 1024);
+    ENC_ALLOC(b.d_reads, (size_t)n_pairs * sizeof(ReadRec) + 64);
+    ENC_HIP(hipEventRecord(e->ev[6], st));
+    if (arena_bytes > 0) ENC_HIP(hipMemcpyAsync(b.d_arena.p, arena, (size_t)arena_bytes, hipMemcpyHostToDevice, st));
+    ENC_HIP(hipMemcpyAsync(b.d_meta.p, hm, meta_bytes, hipMemcpyHostToDevice, st));
+    ENC_HIP(hipMemsetAsync(b.d_live.p, 0, ((size_t)n_regions + 2) * 4, st));
+    ENC_HIP(hipEventRecord(e->ev[7], st));
+    const char* dm = b.d_meta.as<char>();
+    b.p_regions = reinterpret_cast<const RegRec*>(dm + o_reg);
+    b.p_tile_region = reinterpret_cast<const int32_t*>(dm + o_tile);
+    b.p_ref = dm + o_ref;
+    if (n_pairs > 0) {
+        UnpackArgs ua;
+        ua.pairs = reinterpret_cast<const PairRec*>(dm + o_pairs);
+        ua.n_pairs = (int)n_pairs;
+        ua.preads = reinterpret_cast<const PackedRead*>(dm + o_reads);
+        ua.regions = b.p_regions;
+        ua.region_start = reinterpret_cast<const int64_t*>(dm + o_start);
+        ua.arena = b.d_arena.as<uint8_t>();
+        ua.reads = b.d_reads.as<ReadRec>();
+        ua.cigar_op = b.d_cig_op.as<int32_t>();
+        ua.cigar_len = b.d_cig_len.as<int32_t>();
+        ua.seq = b.d_seq.as<char>();
+        ua.qual = b.d_qual.as<uint8_t>();
+        ua.live = b.d_live.as<int>();
+        ua.n_regions = n_regions;
+        hipLaunchKernelGGL(unpack_clip_kernel, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, st, ua);
+        ENC_HIP(hipGetLastError());
+    }
+    ENC_HIP(hipEventRecord(e->ev[8], st));
+    ENC_HIP(hipMemcpyAsync(b.h_live.p, b.d_live.p, ((size_t)n_regions + 2) * 4, hipMemcpyDeviceToHost, st));
+    b.rec_cap = (int)std::min<int64_t>(0x7ffffff0, b.total_bases / TP + 2 * b.total_reads + 1024);
+    b.ovf_cap = (int)std::min<int64_t>(0x7ffffff0, std::max<int64_t>(1 << 16, b.total_bases / 64));
+    b.pool_cap = (int)std::min<int64_t>(0x7ffffff0, std::max<int64_t>(4096, b.total_ops / 64));
+    b.live.assign((size_t)n_regions, 0);
+    b.packed = true;
     b.staged = true;
     return PA_OK;
 }
@@ -1130,7 +1448,7 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
     b.depths.clear();
     b.freqs.clear();
     b.names.clear();
-    for (double& m : b.ms) m = 0;
+    for (int k = 0; k < 8; ++k) b.ms[k] = 0;          // ([8], [9] belong to the staging of this batch)
     if (n_regions == 0) return PA_OK;
     const auto t_begin = std::chrono::steady_clock::now();
     const int vote_cap = (int)std::min<int64_t>(b.total_ops + 1, 0x7ffffff0);
@@ -1150,6 +1468,7 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
     for (int attempt = 0;; ++attempt) {
         ENC_ALLOC(b.d_sorted, (size_t)b.rec_cap * sizeof(TileRec));
         ENC_ALLOC(b.d_ovf, (size_t)b.ovf_cap * sizeof(int4));
+        ENC_ALLOC(b.d_pool, (size_t)b.pool_cap * POOL_SLOT);
         int* counters = b.d_zero.as<int>();
         int* region_counts = counters + CT_N;
         int* tile_count = region_counts + 2 * n_regions;
@@ -1159,23 +1478,23 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
         const dim3 seg_grid((unsigned)((b.total_reads + 3) / 4));
         if (b.total_reads > 0)
             hipLaunchKernelGGL(segment_reads_kernel<false>, seg_grid, dim3(256), 0, st, b.d_reads.as<ReadRec>(), (int)b.total_reads,
-                               b.d_regions.as<RegRec>(), b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), tile_count,
+                               b.p_regions, b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), tile_count,
                                (const int*)nullptr, (int*)nullptr, (TileRec*)nullptr, 0);
         hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, st, tile_count, b.n_tiles, b.d_tile_off.as<int>());
         if (b.total_reads > 0)
             hipLaunchKernelGGL(segment_reads_kernel<true>, seg_grid, dim3(256), 0, st, b.d_reads.as<ReadRec>(), (int)b.total_reads,
-                               b.d_regions.as<RegRec>(), b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), tile_count,
+                               b.p_regions, b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), tile_count,
                                b.d_tile_off.as<int>(), tile_fill, b.d_sorted.as<TileRec>(), b.rec_cap);
         ENC_HIP(hipEventRecord(e->ev[1], st));
         TileArgs ta;
         ta.reads = b.d_reads.as<ReadRec>();
-        ta.regions = b.d_regions.as<RegRec>();
-        ta.tile_region = b.d_tile_region.as<int32_t>();
+        ta.regions = b.p_regions;
+        ta.tile_region = b.p_tile_region;
         ta.cigar_op = b.d_cig_op.as<int32_t>();
         ta.cigar_len = b.d_cig_len.as<int32_t>();
         ta.seq = b.d_seq.as<char>();
         ta.qual = b.d_qual.as<uint8_t>();
-        ta.ref = b.d_ref.as<char>();
+        ta.ref = b.p_ref;
         ta.recs = b.d_sorted.as<TileRec>();
         ta.tile_off = b.d_tile_off.as<int>();
         ta.rec_cap = b.rec_cap;
@@ -1192,20 +1511,22 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
         hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)b.n_tiles), dim3(NT), 0, st, ta);
         ENC_HIP(hipEventRecord(e->ev[2], st));
         hipLaunchKernelGGL(compact_votes_kernel, dim3((unsigned)std::min(2048, (vote_cap + 255) / 256)), dim3(256), 0, st, b.d_votes.as<Vote>(), counters,
-                           vote_cap, b.d_regions.as<RegRec>(), b.d_pass.as<uint8_t>(), b.d_seq.as<char>(), b.d_ref.as<char>(), region_counts,
+                           vote_cap, b.p_regions, b.d_pass.as<uint8_t>(), b.d_seq.as<char>(), b.p_ref, region_counts,
                            b.d_votes_out.as<Vote>());
-        hipLaunchKernelGGL(pack_results_kernel, dim3((unsigned)n_regions), dim3(256), 0, st, b.d_regions.as<RegRec>(), region_counts,
-                           b.d_sites.as<SiteRec>(), b.d_votes_out.as<Vote>(), b.d_sites_dense.as<SiteRec>(), b.d_votes_dense.as<Vote>());
+        hipLaunchKernelGGL(pack_results_kernel, dim3((unsigned)n_regions), dim3(256), 0, st, b.p_regions, region_counts,
+                           b.d_sites.as<SiteRec>(), b.d_votes_out.as<Vote>(), b.d_sites_dense.as<SiteRec>(), b.d_votes_dense.as<Vote>(),
+                           b.d_seq.as<char>(), b.d_pool.as<char>(), b.pool_cap, counters);
         ENC_HIP(hipEventRecord(e->ev[3], st));
         ENC_HIP(hipGetLastError());
         ENC_HIP(hipMemcpyAsync(host_counters, counters, ((size_t)CT_N + 2 * (size_t)n_regions) * 4, hipMemcpyDeviceToHost, st));
         ENC_HIP(hipMemcpyAsync(host_counters + CT_N + 2 * n_regions, b.d_tile_off.as<int>() + b.n_tiles, sizeof(int), hipMemcpyDeviceToHost, st));
         ENC_HIP(hipStreamSynchronize(st));
         const int n_recs = host_counters[CT_N + 2 * n_regions];
-        if (n_recs > b.rec_cap || host_counters[CT_OVF] > b.ovf_cap) {
+        if (n_recs > b.rec_cap || host_counters[CT_OVF] > b.ovf_cap || host_counters[CT_POOL] > b.pool_cap) {
             if (attempt >= 2) return pa::set_error(PA_ERR_HIP, "encoder record buffers could not be sized");
             b.rec_cap = std::max(b.rec_cap, n_recs + 1024);
             b.ovf_cap = std::max(b.ovf_cap, host_counters[CT_OVF] + 1024);
+            b.pool_cap = std::max(b.pool_cap, host_counters[CT_POOL] + 1024);
             continue;
         }
         break;
@@ -1214,6 +1535,19 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
     (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); b.ms[0] = ms;       // records: count pass + offsets + fill pass
     (void)hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); b.ms[1] = ms;       // tile_count_kernel
     (void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); b.ms[2] = ms;       // compact_votes_kernel + pack_results_kernel
+    if (b.packed && b.ms[8] == 0 && b.ms[9] == 0) {
+        (void)hipEventElapsedTime(&ms, e->ev[6], e->ev[7]); b.ms[8] = ms;   // upload of the arena and the tables
+        (void)hipEventElapsedTime(&ms, e->ev[7], e->ev[8]); b.ms[9] = ms;   // unpack_clip_kernel
+    }
+    if (b.packed) {               // what unpack_clip_kernel reported while the batch was staged (the copy is long done)
+        const int* hl = b.h_live.as<int>();
+        if (hl[n_regions] > 0)
+            return pa::set_error(PA_ERR_INVALID, "packed read " + std::to_string(hl[n_regions] - 1) + ": its CIGAR walks over more bases than the record holds");
+        if (hl[n_regions + 1] > 0)
+            return pa::set_error(PA_ERR_UNSUPPORTED, "packed read " + std::to_string(hl[n_regions + 1] - 1) +
+                                                         ": a CIGAR operation of 2^24 bases or more (take the host-clipped form for this batch)");
+        for (int r = 0; r < n_regions; ++r) b.live[(size_t)r] = hl[r];
+    }
     if (host_counters[CT_ERR] > 0) {
         const int64_t g = host_counters[CT_ERR] - 1;
         size_t r = 0;
@@ -1229,15 +1563,18 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
         v0[(size_t)r + 1] = v0[(size_t)r] + (size_t)host_rc[2 * r + 1];
     }
     const size_t n_sites = s0[(size_t)n_regions], n_votes = v0[(size_t)n_regions];
-    const int n_ovf = host_counters[CT_OVF];
-    if (!b.h_sites.ensure(n_sites * sizeof(SiteRec) + 64) || !b.h_votes.ensure(n_votes * sizeof(Vote) + 64))
+    const int n_ovf = host_counters[CT_OVF], n_pool = host_counters[CT_POOL];
+    if (!b.h_sites.ensure(n_sites * sizeof(SiteRec) + 64) || !b.h_votes.ensure(n_votes * sizeof(Vote) + 64) ||
+        !b.h_pool.ensure((size_t)n_pool * POOL_SLOT + 64))
         return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed");
+    const char* pool = b.h_pool.as<char>();
     SiteRec* sites = b.h_sites.as<SiteRec>();
     Vote* votes = b.h_votes.as<Vote>();
     std::vector<int4> ovf((size_t)n_ovf);
     if (n_sites) ENC_HIP(hipMemcpyAsync(sites, b.d_sites_dense.p, n_sites * sizeof(SiteRec), hipMemcpyDeviceToHost, st));
     if (n_votes) ENC_HIP(hipMemcpyAsync(votes, b.d_votes_dense.p, n_votes * sizeof(Vote), hipMemcpyDeviceToHost, st));
     if (n_ovf) ENC_HIP(hipMemcpyAsync(ovf.data(), b.d_ovf.p, ovf.size() * sizeof(int4), hipMemcpyDeviceToHost, st));
+    if (n_pool) ENC_HIP(hipMemcpyAsync(b.h_pool.p, b.d_pool.p, (size_t)n_pool * POOL_SLOT, hipMemcpyDeviceToHost, st));
     ENC_HIP(hipStreamSynchronize(st));
     const auto t_host = std::chrono::steady_clock::now();
     if (n_ovf) {                                                 // rare alphabet: a handful per batch, grouped here
@@ -1251,7 +1588,7 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
         std::sort(sites + s0[(size_t)r], sites + s0[(size_t)r + 1], [](const SiteRec& x, const SiteRec& y) { return x.idx < y.idx; });
         // votes by (site, type, allele): one 64-bit key per vote decides nearly every comparison (28 bits of site, 2 of type, the
         // first 34 bits of the allele); the rare ties fall back to the full order
-        const pa_pileup& pile = b.regs[(size_t)r].p;
+        const AlleleSrc pile{b.regs[(size_t)r].p.reference, pool};
         Vote* vb = votes + v0[(size_t)r];
         const size_t nv = v0[(size_t)r + 1] - v0[(size_t)r];
         std::vector<std::pair<uint64_t, uint32_t>> order(nv);
@@ -1264,7 +1601,7 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
         for (size_t k = 0; k < nv; ++k) sorted[k] = vb[order[k].second];
         std::copy(sorted.begin(), sorted.end(), vb);
         enumerate_region(b.regs[(size_t)r], r, b.mid, sites + s0[(size_t)r], s0[(size_t)r + 1] - s0[(size_t)r], votes + v0[(size_t)r],
-                         v0[(size_t)r + 1] - v0[(size_t)r], ovf.data() + o0[(size_t)r], o0[(size_t)r + 1] - o0[(size_t)r], outs[(size_t)r]);
+                         v0[(size_t)r + 1] - v0[(size_t)r], ovf.data() + o0[(size_t)r], o0[(size_t)r + 1] - o0[(size_t)r], pool, outs[(size_t)r]);
     };
     if (n_regions < 4) {
         for (int r = 0; r < n_regions; ++r) work(r);
@@ -1300,7 +1637,7 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
         ENC_ALLOC(b.d_img8, (size_t)b.n * b.W * b.F);
         ENC_HIP(hipMemcpyAsync(b.d_cands.p, cands.data(), cands.size() * sizeof(CandDesc), hipMemcpyHostToDevice, st));
         ENC_HIP(hipEventRecord(e->ev[4], st));
-        hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)b.n), dim3(64), 0, st, b.d_mat.as<int>(), b.d_regions.as<RegRec>(),
+        hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)b.n), dim3(64), 0, st, b.d_mat.as<int>(), b.p_regions,
                            b.d_cands.as<CandDesc>(), b.W, b.F, b.mid, b.d_img32.as<int>(), b.d_img8.as<int8_t>());
         ENC_HIP(hipEventRecord(e->ev[5], st));
         ENC_HIP(hipGetLastError());
@@ -1370,6 +1707,25 @@ int pa_encoder_stage_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pi
 
 int pa_encoder_run_staged(pa_encoder* e, int64_t* n_candidates) { return run_staged(e, n_candidates); }
 
+void* pa_encoder_host_arena(pa_encoder* e, int64_t bytes) {
+    if (!e || bytes < 0 || hipSetDevice(e->device) != hipSuccess) return nullptr;
+    if (!e->variant) e->variant = new pa_variant_batch();
+    if (e->stream) (void)hipStreamSynchronize(e->stream);        // (an upload out of the old block may still be running)
+    return e->variant->h_arena.ensure((size_t)bytes) ? e->variant->h_arena.p : nullptr;
+}
+
+int pa_encoder_stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_region* regions, const pa_summary_params* params,
+                            const uint8_t* arena, int64_t arena_bytes, const pa_packed_read* reads, int32_t n_reads,
+                            const int32_t* pair_read, const int32_t* region_pairs) {
+    return stage_packed(e, n_regions, regions, params, arena, arena_bytes, reads, n_reads, pair_read, region_pairs);
+}
+
+int pa_encoder_region_reads(pa_encoder* e, int32_t* n_reads, int32_t n) {
+    if (!e || !n_reads || n < 0) return pa::set_error(PA_ERR_INVALID, "null argument");
+    for (int i = 0; i < n; ++i) n_reads[i] = (e->variant && i < (int)e->variant->live.size()) ? e->variant->live[(size_t)i] : 0;
+    return PA_OK;
+}
+
 int pa_encoder_generate_summary_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const pa_summary_params* params,
                                       int64_t* n_candidates) {
     const int rc = stage_batch(e, n_regions, pileups, params);
@@ -1411,7 +1767,7 @@ const int8_t* pa_encoder_device_images(pa_encoder* e) {
 
 int pa_encoder_last_timing(pa_encoder* e, double* ms, int32_t n) {
     if (!e || !ms || n < 0) return pa::set_error(PA_ERR_INVALID, "null argument");
-    for (int i = 0; i < n; ++i) ms[i] = (e->variant && i < 8) ? e->variant->ms[i] : 0.0;
+    for (int i = 0; i < n; ++i) ms[i] = (e->variant && i < 12) ? e->variant->ms[i] : 0.0;
     return PA_OK;
 }
 

@@ -123,7 +123,7 @@ struct pa_encoder {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[12] = {};
     pa_variant_batch* variant = nullptr;
     pa_polish_batch* polish = nullptr;
 };

@@ -137,30 +137,113 @@ class ImageGenerationUtils:
         # a read length + 16 kb (the BAM index's window) in front of it, so consecutive fetches through one handle find most of
         # their BGZF blocks already inflated in the handle's cache -- the BAM reader is 93 % of this loop's time.
         batch = max(1, int(getattr(options, "encoder_batch", 0) or os.environ.get("PEPPER_AMD_ENCODER_BATCH", 16)))
-        run = max(1, min(batch, -(-len(all_intervals) // max(1, options.threads))))      # (small jobs: every worker gets some)
+        # a worker takes whole runs of consecutive intervals; large jobs are cut so that every worker gets several runs
+        run = max(1, min(batch, -(-len(all_intervals) // max(1, options.threads * 4))))
         intervals = [r for i, r in enumerate(all_intervals) if (i // run) % options.threads == process_id]
         if process_id == 0:
             _log("INFO: STARTING PROCESS: " + str(process_id) + " FOR " + str(len(intervals)) + " INTERVALS")
         from pepper_amd.variant.AlignmentSummarizer import create_summaries
         generators = {}
+        stats = getattr(options, "stage_seconds", None)      # a dict the caller wants the stage times of this worker added to
+
+        def lap(key, t0):
+            if stats is not None:
+                stats[key] = stats.get(key, 0.0) + time.perf_counter() - t0
+            return time.perf_counter()
+
+        def write(output_hdf_file, chr_name, _start, _end, out):
+            n = len(out["candidates"])
+            summary_name = chr_name + "_" + str(_start) + "_" + str(_end)
+            output_hdf_file.write_summary(summary_name, [chr_name] * n, out["positions"], out["depths"],
+                                          np.array(out["candidates"], dtype=object).reshape(n, 1),
+                                          out["candidate_frequency"].reshape(n, 1), out["images"],
+                                          [0] * n, [0] * n, False)
+
+        def host_clipped(output_hdf_file, group):
+            """The form in which the host clips every read to its interval (BAM_handler.get_reads): injected handlers,
+            intervals whose reads are sampled down, operations the device-side clip refuses."""
+            prepared = []
+            for chr_name, _start, _end in group:
+                if chr_name not in generators:
+                    generators.clear()               # one contig's handles at a time per worker
+                    generators[chr_name] = ImageGenerator(chr_name, options.bam, options.fasta, options)
+                prepared.append(generators[chr_name].prepare(options, _start, _end))
+            for (chr_name, _start, _end), out in zip(group, create_summaries(prepared)):
+                if out is not None:
+                    write(output_hdf_file, chr_name, _start, _end, out)
+
+        packed = (getattr(options, "bam_handler_factory", None) is None and getattr(options, "fasta_handler_factory", None) is None
+                  and os.environ.get("PEPPER_AMD_PACKED_READS", "1") != "0" and not getattr(options, "train_mode", False))
+        if getattr(options, "use_hp_info", False):
+            packed = False                           # (host_clipped raises the reference's message for it)
         with DataStore(file_name, 'w') as output_hdf_file:
-            for g0 in range(0, len(intervals), batch):
-                group = intervals[g0:g0 + batch]
-                prepared = []
-                for chr_name, _start, _end in group:
-                    if chr_name not in generators:
-                        generators.clear()               # one contig's handles at a time per worker
-                        generators[chr_name] = ImageGenerator(chr_name, options.bam, options.fasta, options)
-                    prepared.append(generators[chr_name].prepare(options, _start, _end))
-                for (chr_name, _start, _end), out in zip(group, create_summaries(prepared)):
-                    if out is None:
-                        continue
-                    n = len(out["candidates"])
-                    summary_name = chr_name + "_" + str(_start) + "_" + str(_end)
-                    output_hdf_file.write_summary(summary_name, [chr_name] * n, out["positions"], out["depths"],
-                                                  np.array(out["candidates"], dtype=object).reshape(n, 1),
-                                                  out["candidate_frequency"].reshape(n, 1), out["images"],
-                                                  [0] * n, [0] * n, False)
+            if not packed:
+                for g0 in range(0, len(intervals), batch):
+                    host_clipped(output_hdf_file, intervals[g0:g0 + batch])
+                return process_id
+            # The packed form: per group of consecutive intervals ONE call of the BAM reader (inflate, header walk, filters; no
+            # clipping, no decoding: the reads cross PCIe as BAM stores them, once per group) and ONE of the encoder (clip +
+            # decode + summary + windows on the device); both run outside the GIL, each worker on its own handles.
+            from pepper_amd import _lib
+            from pepper_amd.variant.AlignmentSummarizer import AlingerOptions, ConsensCandidateFinder
+            from pepper_amd.variant.Options import ImageSizeOptions
+            from pepper_amd.variant.PEPPER_VARIANT import PackedEncoder
+            enc = PackedEncoder(getattr(options, "device", 0),
+                                arena_bytes=int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20)
+            bam_handler, fasta_handler = _handlers(options, options.bam, options.fasta)
+            safe = ConsensCandidateFinder.REGION_SAFE_BASES
+            params = (options.min_snp_baseq, options.min_indel_baseq, options.snp_frequency, options.insert_frequency,
+                      options.delete_frequency, options.min_coverage_threshold, options.snp_candidate_frequency_threshold,
+                      options.indel_candidate_frequency_threshold, options.candidate_support_threshold, options.skip_indels)
+            g0 = 0
+            while g0 < len(intervals):
+                # consecutive intervals of one contig, ascending
+                g1 = g0 + 1
+                while (g1 < len(intervals) and g1 - g0 < batch and intervals[g1][0] == intervals[g0][0]
+                       and intervals[g1][1] >= intervals[g1 - 1][1] and intervals[g1][2] >= intervals[g1 - 1][2]):
+                    g1 += 1
+                group = intervals[g0:g1]
+                chr_name = group[0][0]
+                regions = [(max(0, s - safe), e + safe) for _, s, e in group]
+                t0 = time.perf_counter()
+                try:
+                    n_done, region_pairs, counts = enc.pack(bam_handler, chr_name, [r[0] for r in regions], [r[1] for r in regions],
+                                                            options.include_supplementary, options.min_mapq)
+                except Exception as err:
+                    if "do not fit" not in str(err):
+                        raise
+                    n_done = 0                       # one interval's reads outgrow the arena
+                t0 = lap("bam_pack", t0)
+                if n_done == 0:
+                    host_clipped(output_hdf_file, group[:1])
+                    g0 += 1
+                    continue
+                group, regions = group[:n_done], regions[:n_done]
+                per_region = np.diff(region_pairs[:n_done + 1])
+                # the reference samples an interval's reads down to min(MAX_READS_IN_REGION, downsample_rate * n)
+                # (AlignmentSummarizer.py:192-199) in read order: such intervals take the host-clipped form
+                if options.downsample_rate < 1.0 or int(per_region.max(initial=0)) > AlingerOptions.MAX_READS_IN_REGION:
+                    host_clipped(output_hdf_file, group)
+                    g0 += n_done
+                    continue
+                references = [fasta_handler.get_reference_sequence(chr_name, a, b + 1) for a, b in regions]
+                t0 = lap("fasta", t0)
+                try:
+                    outs, live = enc.encode(regions, references, region_pairs, counts, params, [(s, e) for _, s, e in group],
+                                            ImageSizeOptions.CANDIDATE_WINDOW_SIZE, ImageSizeOptions.IMAGE_HEIGHT)
+                except _lib.PepperAmdError as err:
+                    if getattr(err, "code", 0) != _lib.PA_ERR_UNSUPPORTED:
+                        raise
+                    host_clipped(output_hdf_file, group)
+                    g0 += n_done
+                    continue
+                t0 = lap("encode", t0)
+                for (chr_name, _start, _end), out, n_reads in zip(group, outs, live):
+                    if n_reads > 0:                  # (no read with a base inside: create_summary returns None, nothing is written)
+                        write(output_hdf_file, chr_name, _start, _end, out)
+                lap("hdf5", t0)
+                g0 += n_done
+            enc.close()
         return process_id
 
     @staticmethod

@@ -209,10 +209,11 @@ class StagedBatch(object):
         return self.counts[:self.n_regions]
 
     def timing(self):
-        ms = np.zeros(8, np.float64)
-        _lib.check(self.lib.pa_encoder_last_timing(self.enc, ms.ctypes.data, 8))
+        ms = np.zeros(12, np.float64)
+        _lib.check(self.lib.pa_encoder_last_timing(self.enc, ms.ctypes.data, 12))
         return dict(records_ms=ms[0], tile_count_ms=ms[1], compact_votes_ms=ms[2], gather_windows_ms=ms[3],
-                    host_enumeration_ms=ms[4], run_ms=ms[5], host_bucket_ms=ms[6], host_bucket_and_threads_ms=ms[7])
+                    host_enumeration_ms=ms[4], run_ms=ms[5], host_bucket_ms=ms[6], host_bucket_and_threads_ms=ms[7],
+                    upload_ms=ms[8], unpack_clip_ms=ms[9])
 
     def stats(self):
         v = np.zeros(6, np.int64)
@@ -244,6 +245,77 @@ class StagedBatch(object):
                             candidates=cands[at:at + k]))
             at += k
         return out
+
+
+class _PackedRegion(ctypes.Structure):
+    _fields_ = [("region_start", ctypes.c_int64), ("region_end", ctypes.c_int64), ("reference", ctypes.c_char_p),
+                ("reference_len", ctypes.c_int64)]
+
+
+class PackedEncoder(object):
+    """The packed form of a batch (pa_encoder_stage_packed): the reads of a run of regions as pa_bam_pack_regions leaves them
+    in this object's page-locked arena -- CIGAR words, 4-bit bases, qualities, once per read -- clipped to each region and
+    decoded by the device.  One object per worker thread: it owns its encoder handle (stream, workspace, arena)."""
+
+    def __init__(self, device=0, arena_bytes=192 << 20, max_reads=1 << 18, max_pairs=1 << 19):
+        from pepper_amd.variant.bam import PACKED_READ
+        self.lib = _lib.load()
+        self.enc = ctypes.c_void_p()
+        _lib.check(self.lib.pa_encoder_create(device, None, ctypes.byref(self.enc)))
+        ptr = self.lib.pa_encoder_host_arena(self.enc, arena_bytes)
+        if not ptr:
+            raise _lib.PepperAmdError("page-locked arena of %d bytes could not be allocated" % arena_bytes)
+        self.arena = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(arena_bytes,))
+        self.reads = np.zeros(max_reads, PACKED_READ)
+        self.pair_read = np.zeros(max_pairs, np.int32)
+
+    def close(self):
+        if self.enc:
+            self.arena = None
+            self.lib.pa_encoder_destroy(self.enc)
+            self.enc = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def pack(self, bam_handler, contig, starts, stops, include_supplementary, min_mapq):
+        """-> (n_done, region_pairs, (n_reads, n_pairs, arena_bytes)): BAM_handler.pack_regions into this object's buffers."""
+        return bam_handler.pack_regions(contig, starts, stops, include_supplementary, min_mapq, self.arena, self.reads, self.pair_read)
+
+    def encode(self, regions, references, region_pairs, counts, params, candidate_regions, candidate_window_size=32, feature_size=26,
+               want_int32=False):
+        """regions: [(ref_start, ref_end)] of the packed run (the fetch ranges), references: their sequences (bytes / str),
+        region_pairs / counts: what pack() returned, params: the ten thresholds of generate_summary in order,
+        candidate_regions: [(start, end)].  -> (one dict of arrays per region as generate_summary_arrays, reads per region)."""
+        n = len(regions)
+        refs = [r.encode("latin-1") if isinstance(r, str) else bytes(r) for r in references]
+        regs = (_PackedRegion * max(1, n))(*[_PackedRegion(int(a), int(b), ref, len(ref)) for (a, b), ref in zip(regions, refs)])
+        (min_snp_baseq, min_indel_baseq, snp_freq_threshold, insert_freq_threshold, delete_freq_threshold,
+         min_coverage_threshold, snp_candidate_freq_threshold, indel_candidate_freq_threshold,
+         candidate_support_threshold, skip_indels) = params
+        pars = (_Params * max(1, n))(*[
+            _Params(min_snp_baseq, min_indel_baseq, snp_freq_threshold, insert_freq_threshold, delete_freq_threshold,
+                    min_coverage_threshold, snp_candidate_freq_threshold, indel_candidate_freq_threshold,
+                    candidate_support_threshold, 1 if skip_indels else 0, int(lo), int(hi), int(candidate_window_size),
+                    int(feature_size)) for lo, hi in candidate_regions])
+        region_pairs = np.ascontiguousarray(region_pairs[:n + 1], np.int32)
+        n_reads, _n_pairs, arena_bytes = counts
+        _lib.check(self.lib.pa_encoder_stage_packed(self.enc, n, ctypes.cast(regs, ctypes.c_void_p), ctypes.cast(pars, ctypes.c_void_p),
+                                                    self.arena.ctypes.data, int(arena_bytes), self.reads.ctypes.data, int(n_reads),
+                                                    self.pair_read.ctypes.data, region_pairs.ctypes.data))
+        batch = StagedBatch.__new__(StagedBatch)
+        batch.lib, batch.enc, batch.n_regions = self.lib, self.enc, n
+        batch.window, batch.features = candidate_window_size + 1, feature_size
+        batch.counts = np.zeros(max(1, n), np.int64)
+        batch._keep = (regs, pars, refs)
+        batch.run()
+        live = np.zeros(max(1, n), np.int32)
+        _lib.check(self.lib.pa_encoder_region_reads(self.enc, live.ctypes.data, n))
+        self.last = batch
+        return batch.results(want_int32), live[:n]
 
 
 def generate_summary_arrays_batch(generators, reads_list, min_snp_baseq, min_indel_baseq, snp_freq_threshold,
