@@ -106,6 +106,10 @@ void* pa_encoder_host_arena(pa_encoder* e, int64_t bytes);      /* page-locked, 
 int pa_encoder_stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_region* regions, const pa_summary_params* params,
                             const uint8_t* arena, int64_t arena_bytes, const pa_packed_read* reads, int32_t n_reads,
                             const int32_t* pair_read, const int32_t* region_pairs);
+/* Host threads of a run's candidate enumeration (one short task per region): 0 = the default (the CPUs the process may use),
+ * 1 = the calling thread alone -- what image generation sets, whose workers each drive their own encoder while the other
+ * CPUs inflate BGZF blocks. */
+int pa_encoder_set_host_threads(pa_encoder* e, int32_t n);
 /* Reads with at least one base inside each region of the last run -- the reference's len(all_reads) after get_reads (an
  * interval without any writes no summary group, AlignmentSummarizer.py:200-204); host-clipped form: the pileup's n_reads. */
 int pa_encoder_region_reads(pa_encoder* e, int32_t* n_reads, int32_t n);

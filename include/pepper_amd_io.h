@@ -161,6 +161,13 @@ int pa_h5_builder_write_polish_image_chunks(pa_h5_builder* b, const char* names,
                                             const char* contig, int64_t region_start, int64_t region_end, const int64_t* chunk_id,
                                             const uint8_t* images, const uint8_t* labels, const int64_t* position,
                                             const int64_t* index);
+/* One summaries/<name> group of a variant image file, as pepper_variant DataStore.py:54-71 (write_summary, inference mode):
+ * contigs 'S<len>' [n] (the one contig name n times), positions int32 [n], depths uint8 [n], candidates variable-length utf-8
+ * [n,1] (NUL-terminated at cand_blob + cand_offsets[i]), candidate_frequency uint8 [n,1], images int8 [n, window, features].
+ * The image-generation workers each write their own file without libhdf5's process-wide lock. */
+int pa_h5_builder_write_variant_summary(pa_h5_builder* b, const char* name, int32_t n, const char* contig, const int32_t* positions,
+                                        const uint8_t* depths, const char* cand_blob, const int64_t* cand_offsets, const uint8_t* freqs,
+                                        const int8_t* images, int32_t window, int32_t features);
 int pa_h5_builder_close(pa_h5_builder* b);
 
 /* How the polish chunks of this handle were read so far: `direct_chunks` had their image / position / index bytes copied

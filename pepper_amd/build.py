@@ -74,6 +74,32 @@ def build_io(force=False, verbose=False):
     return IO_LIB
 
 
+TOOLS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+SYNTH_BAM = os.path.join(TOOLS, "synth_bam")
+
+
+def build_tools(force=False):
+    """tools/synth_bam: the generator of the synthetic BAM + FASTA that bench.py's image-generation leg reads (bench data, not
+    product code).  Returns its path, or None where the tools directory did not travel."""
+    src = os.path.join(TOOLS, "synth_bam.cpp")
+    if not os.path.exists(src):
+        return SYNTH_BAM if os.path.exists(SYNTH_BAM) else None
+    if not force and os.path.exists(SYNTH_BAM) and os.path.getmtime(SYNTH_BAM) >= os.path.getmtime(src):
+        return SYNTH_BAM
+    inc, lib = os.path.join(HDF5_PREFIX, "include"), os.path.join(HDF5_PREFIX, "lib")
+    tmp = f"{SYNTH_BAM}.{os.getpid()}.tmp"
+    cmd = ["g++", "-O2", "-std=c++17", "-o", tmp, src, "-lz", "-lpthread"]
+    if _have_libdeflate(inc, lib):
+        cmd += [f"-I{inc}", "-DPA_HAVE_LIBDEFLATE=1", os.path.join(lib, "libdeflate.so"), f"-Wl,-rpath,{lib}"]
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, SYNTH_BAM)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    return SYNTH_BAM
+
+
 OBJ_DIR = os.path.join(CSRC, "_obj")
 
 
@@ -145,3 +171,4 @@ def build(force=False, verbose=False):
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
     print(build_io(force=True, verbose=True))
+    print(build_tools(force=True))

@@ -979,6 +979,7 @@ struct pa_variant_batch {
     DBuf d_tile_off, d_sorted, d_mat, d_pass, d_sites, d_votes, d_votes_out, d_sites_dense, d_votes_dense, d_ovf, d_cands, d_img32, d_img8;
     HBuf h_counts, h_sites, h_votes;
     std::unique_ptr<RegionPool> pool;
+    int host_threads = 0;             // threads of the candidate enumeration: 0 = the default below, 1 = the calling thread alone
     // results of the last run
     int64_t n = 0;
     std::vector<int64_t> region_n;
@@ -1603,7 +1604,7 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
         enumerate_region(b.regs[(size_t)r], r, b.mid, sites + s0[(size_t)r], s0[(size_t)r + 1] - s0[(size_t)r], votes + v0[(size_t)r],
                          v0[(size_t)r + 1] - v0[(size_t)r], ovf.data() + o0[(size_t)r], o0[(size_t)r + 1] - o0[(size_t)r], pool, outs[(size_t)r]);
     };
-    if (n_regions < 4) {
+    if (n_regions < 4 || b.host_threads == 1) {
         for (int r = 0; r < n_regions; ++r) work(r);
     } else {
         if (!b.pool) {
@@ -1611,7 +1612,7 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
             // a burst of ~0.3 ms tasks, one per region: a quarter of the hardware threads even where a cgroup quota grants fewer
             // CPUs on average (the quota is per 100 ms period; measured on the 16-of-256 box: 16 threads 1.45 ms per 64 regions,
             // 32 threads 0.94 ms)
-            const int dflt = std::max(usable_cpus(), (int)std::thread::hardware_concurrency() / 4);
+            const int dflt = b.host_threads > 0 ? b.host_threads : std::max(usable_cpus(), (int)std::thread::hardware_concurrency() / 4);
             b.pool.reset(new RegionPool(std::max(1, std::min(env ? atoi(env) : dflt, 64)) - 1));
         }
         b.pool->run(n_regions, work);
@@ -1718,6 +1719,14 @@ int pa_encoder_stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_re
                             const uint8_t* arena, int64_t arena_bytes, const pa_packed_read* reads, int32_t n_reads,
                             const int32_t* pair_read, const int32_t* region_pairs) {
     return stage_packed(e, n_regions, regions, params, arena, arena_bytes, reads, n_reads, pair_read, region_pairs);
+}
+
+int pa_encoder_set_host_threads(pa_encoder* e, int32_t n) {
+    if (!e || n < 0) return pa::set_error(PA_ERR_INVALID, "null encoder or negative thread count");
+    if (!e->variant) e->variant = new pa_variant_batch();
+    e->variant->host_threads = n;
+    e->variant->pool.reset();
+    return PA_OK;
 }
 
 int pa_encoder_region_reads(pa_encoder* e, int32_t* n_reads, int32_t n) {

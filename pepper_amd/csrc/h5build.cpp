@@ -61,8 +61,9 @@ struct Obj {
     uint64_t dims[4] = {0, 0, 0, 0};
     uint64_t bytes = 0, addr = 0;                             // raw data: size; file address (contiguous layout)
     std::string small;                                        // the data itself when it is at most 64 bytes (compact layout)
-    bool vlen = false;                                        // a variable-length UTF-8 string scalar: (collection, object) below
-    uint32_t heap_collection = 0, heap_object = 0, heap_length = 0;
+    bool vlen = false;                                        // variable-length UTF-8 strings: a scalar ((collection, object) below,
+    uint32_t heap_collection = 0, heap_object = 0, heap_length = 0;   // compact layout) or an array of references at `addr`
+    bool fixed_string = false;                                // numpy 'S<elem>' fields: null-padded ASCII, `elem` bytes each
 };
 
 struct HeapCollection {                                       // a global heap collection being filled (GCOL, spec III.E)
@@ -123,6 +124,43 @@ struct pa_h5_builder {
         d.heap_collection = at.first;
         d.heap_object = at.second;
         d.heap_length = (uint32_t)text.size();
+        add(g, std::move(d));
+    }
+
+    // n strings as an array dataset of shape dims: the references {length u32, collection address u64, object u32} are raw
+    // data like any other (the collections' places are reserved when they are opened)
+    void vlen_string_array(uint32_t g, const std::string& name, int rank, const uint64_t* dims, const char* blob, const int64_t* offsets,
+                           uint64_t n) {
+        std::vector<uint8_t> refs((size_t)n * 16, 0);
+        for (uint64_t i = 0; i < n; ++i) {
+            const std::string text(blob + offsets[i]);
+            const auto at = heap_object(text);
+            const uint32_t len = (uint32_t)text.size(), obj = at.second;
+            std::memcpy(&refs[(size_t)i * 16], &len, 4);
+            std::memcpy(&refs[(size_t)i * 16 + 4], &heaps[at.first].addr, 8);
+            std::memcpy(&refs[(size_t)i * 16 + 12], &obj, 4);
+        }
+        Obj d;
+        d.name = name;
+        d.vlen = true;
+        d.elem = 16;
+        d.rank = (uint8_t)rank;
+        d.bytes = 16 * n;
+        for (int k = 0; k < rank; ++k) d.dims[k] = dims[k];
+        // (an empty array keeps the contiguous form with an undefined address, as the library writes it)
+        d.addr = n ? append(refs.data(), d.bytes) : UNDEF;
+        add(g, std::move(d));
+    }
+
+    void fixed_strings(uint32_t g, const std::string& name, uint64_t n, uint32_t width, const char* data) {
+        Obj d;
+        d.name = name;
+        d.fixed_string = true;
+        d.elem = (uint8_t)width;
+        d.rank = 1;
+        d.dims[0] = n;
+        d.bytes = n * width;
+        d.addr = n ? append(data, d.bytes) : UNDEF;
         add(g, std::move(d));
     }
 
@@ -212,6 +250,22 @@ struct pa_h5_builder {
         add(g, std::move(d));
     }
 
+    // an array dataset in the contiguous layout whatever its size (what `file[path] = ndarray` gives; empty: no storage yet)
+    void big_dataset(uint32_t g, const std::string& name, uint8_t elem, bool is_signed, int rank, const uint64_t* dims, const void* data) {
+        Obj d;
+        d.name = name;
+        d.elem = elem;
+        d.is_signed = is_signed;
+        d.rank = (uint8_t)rank;
+        d.bytes = elem;
+        for (int k = 0; k < rank; ++k) {
+            d.dims[k] = dims[k];
+            d.bytes *= dims[k];
+        }
+        d.addr = d.bytes ? append(data, d.bytes) : UNDEF;
+        add(g, std::move(d));
+    }
+
     void row(uint32_t g, const char* name, uint8_t elem, bool is_signed, const void* data, uint64_t count) {
         dataset(g, name, elem, is_signed, 1, &count, data);
     }
@@ -237,7 +291,7 @@ struct pa_h5_builder {
 
     uint64_t dataset_header(const Obj& d) {
         const bool compact = d.addr == 0;
-        const uint16_t space = (uint16_t)(8 + 8 * d.rank), dtype = d.vlen ? 24 : 16, fill = 8;
+        const uint16_t space = (uint16_t)(8 + 8 * d.rank), dtype = d.vlen ? 24 : (d.fixed_string ? 8 : 16), fill = 8;
         const uint16_t layout = compact ? (uint16_t)((4 + d.bytes + 7) / 8 * 8) : 24;
         const uint32_t body = 4 * 8 + space + dtype + fill + layout;
         const uint64_t h = reserve(16 + body);
@@ -257,6 +311,10 @@ struct pa_h5_builder {
             // object index); base type = one-byte integer -- the bytes h5py writes for a Python str
             static const uint8_t vl[20] = {0x19, 0x01, 0x01, 0x00, 16, 0, 0, 0, 0x10, 0, 0, 0, 1, 0, 0, 0, 0, 0, 8, 0};
             std::memcpy(&meta[at], vl, sizeof vl);
+        } else if (d.fixed_string) {
+            meta[at] = 0x13;                                  // datatype v1, class 3 (string): null-padded, ASCII -- what h5py
+            meta[at + 1] = 0x01;                              // writes for a numpy 'S' array
+            put32(meta, at + 4, d.elem);
         } else {
             meta[at] = 0x10;                                  // datatype v1, class 0 (fixed point), little-endian
             meta[at + 1] = d.is_signed ? 0x08 : 0x00;
@@ -273,7 +331,11 @@ struct pa_h5_builder {
         at += fill;
         message(at, 0x0008, layout);                          // layout v3
         meta[at] = 3;
-        if (d.vlen) {
+        if (d.vlen && !compact) {
+            meta[at + 1] = 1;                                 // contiguous: the array of 16-byte references
+            put64(meta, at + 2, d.addr);
+            put64(meta, at + 10, d.bytes);
+        } else if (d.vlen) {
             meta[at + 1] = 0;                                 // compact: the 16-byte reference into the global heap
             put16(meta, at + 2, 16);
             put32(meta, at + 4, d.heap_length);
@@ -607,6 +669,36 @@ int pa_h5_builder_write_polish_image_chunks(pa_h5_builder* b, const char* names,
         if (b->out.size() >= (4u << 20))
             if (int rc = b->flush()) return rc;
     }
+    return 0;
+}
+
+int pa_h5_builder_write_variant_summary(pa_h5_builder* b, const char* name, int32_t n, const char* contig, const int32_t* positions,
+                                        const uint8_t* depths, const char* cand_blob, const int64_t* cand_offsets, const uint8_t* freqs,
+                                        const int8_t* images, int32_t window, int32_t features) {
+    if (!b || !name || n < 0 || !contig || window <= 0 || features <= 0 ||
+        (n > 0 && (!positions || !depths || !cand_blob || !cand_offsets || !freqs || !images)))
+        return fail("bad argument");
+    if (b->failed) return fail("the file has a failed write behind it");
+    if (!*name || std::strchr(name, '/')) return fail(std::string("bad summary name '") + name + "'");
+    const size_t width = n > 0 ? std::max<size_t>(1, strlen(contig)) : 1;      // (numpy: np.array([], dtype='S') is 'S1')
+    if (width > 255) return fail("contig name longer than 255 bytes");
+    const uint32_t summaries = b->group("summaries");
+    if (b->has_kid(summaries, name)) return fail(std::string("cannot create group 'summaries/") + name + "' (already exists)");
+    Obj g;
+    g.name = name;
+    g.group = true;
+    const uint32_t id = b->add(summaries, std::move(g));
+    std::string names((size_t)n * width, '\0');
+    for (int32_t i = 0; i < n; ++i) std::memcpy(&names[(size_t)i * width], contig, strlen(contig));
+    const uint64_t d1[1] = {(uint64_t)n}, d2[2] = {(uint64_t)n, 1}, d3[3] = {(uint64_t)n, (uint64_t)window, (uint64_t)features};
+    b->fixed_strings(id, "contigs", (uint64_t)n, (uint32_t)width, names.data());
+    b->big_dataset(id, "positions", 4, true, 1, d1, positions);
+    b->big_dataset(id, "depths", 1, false, 1, d1, depths);
+    b->vlen_string_array(id, "candidates", 2, d2, cand_blob, cand_offsets, (uint64_t)n);
+    b->big_dataset(id, "candidate_frequency", 1, false, 2, d2, freqs);
+    b->big_dataset(id, "images", 1, true, 3, d3, images);
+    if (int rc = b->seal(summaries, id)) return rc;
+    if (b->out.size() >= (4u << 20)) return b->flush();
     return 0;
 }
 

@@ -55,6 +55,7 @@ SYMBOLS = [
     ("pa_h5_builder_write_string", ctypes.c_int, [c_void_p, c_char_p, c_char_p]),
     ("pa_h5_builder_write_polish_image_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32, c_char_p, c_int64, c_int64] +
                                                                [c_void_p] * 5),
+    ("pa_h5_builder_write_variant_summary", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_char_p] + [c_void_p] * 6 + [c_int32, c_int32]),
     ("pa_h5_builder_close", ctypes.c_int, [c_void_p]),
     ("pa_h5_write_prediction_batch", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
@@ -144,6 +145,18 @@ class PredictionBuilder(object):
         _check(self._lib.pa_h5_builder_write_polish_image_chunks(
             self._h, blob, n, seq_len, features, contig.encode(), int(region_start), int(region_end), chunk_id.ctypes.data,
             images.ctypes.data, labels.ctypes.data, position.ctypes.data, index.ctypes.data))
+
+    def write_variant_summary(self, name, contig, positions, depths, candidates, freqs, images):
+        """One summaries/<name> group of a variant image file (pa_h5_builder_write_variant_summary): positions int32 [n], depths
+        uint8 [n], candidates: n strings, freqs uint8 [n], images int8 [n, window, features]."""
+        n = len(positions)
+        blob = b"".join(c.encode("utf-8") + b"\0" for c in candidates)
+        offsets = np.zeros(n + 1, np.int64)
+        if n:
+            np.cumsum([len(c.encode("utf-8")) + 1 for c in candidates], out=offsets[1:])
+        _check(self._lib.pa_h5_builder_write_variant_summary(
+            self._h, name.encode(), n, contig.encode(), positions.ctypes.data, depths.ctypes.data, blob, offsets.ctypes.data,
+            freqs.ctypes.data, images.ctypes.data, images.shape[1], images.shape[2]))
 
     def __setitem__(self, path, value):
         """An integer dataset, or a str as a variable-length string scalar, like h5py's file[path] = value (intermediate

@@ -5,6 +5,8 @@ write_summary): summaries/<chr_start_end>/{contigs 'S', positions i32, depths u8
 vlen-str, candidate_frequency u8, images int8 [N,33,26]} (+ base_labels / type_label u8 in train
 mode).  Written through pepper_amd.h5 (libhdf5) instead of h5py.
 """
+import os
+
 import numpy as np
 
 from pepper_amd import h5
@@ -31,7 +33,12 @@ class DataStore(object):
         self._written = set()
 
     def __enter__(self):
-        self.file_handler = h5.File(self.filename, self.mode)
+        # 'w' -> the append-only builder (h5.PredictionBuilder, csrc/h5build.cpp): no libhdf5 and so no process-wide lock under
+        # the image-generation workers, each of which writes its own file; PEPPER_AMD_H5_BUILDER=0: through libhdf5
+        if self.mode == "w" and os.environ.get("PEPPER_AMD_H5_BUILDER", "1") != "0":
+            self.file_handler = h5.PredictionBuilder(self.filename)
+        else:
+            self.file_handler = h5.File(self.filename, self.mode)
         return self
 
     def __exit__(self, *args):
@@ -44,6 +51,23 @@ class DataStore(object):
         self._written.add(summary_name)
         base = '{}/{}/'.format(self._summary_path_, summary_name)
         fh = self.file_handler
+        if isinstance(fh, h5.PredictionBuilder):
+            # one library call per group (pa_h5_builder_write_variant_summary): what image generation writes -- inference
+            # mode, one contig per group, one candidate allele per row
+            n = len(positions)
+            rows = np.asarray(all_candidates, dtype=object).reshape(n, -1) if n else np.zeros((0, 1), object)
+            if train_mode or (n and rows.shape[1] != 1) or len(set(contigs)) > 1:
+                raise h5.H5Error("the append-only writer takes inference-mode summaries of one contig with one candidate allele "
+                                 "per row; set PEPPER_AMD_H5_BUILDER=0 for anything else")
+            img = np.asarray(all_images)
+            img = np.ascontiguousarray(img if img.dtype == np.int8 else wrap_int8(all_images))
+            if n == 0:
+                img = np.zeros((0, 33, 26), np.int8)
+            fh.write_variant_summary(summary_name, str(contigs[0]) if n else "",
+                                     np.ascontiguousarray(np.asarray(positions, dtype=np.int64).astype(np.int32)),
+                                     np.ascontiguousarray(wrap_uint8(depths)), [str(c) for c in rows[:, 0]] if n else [],
+                                     np.ascontiguousarray(wrap_uint8(all_candidate_frequency)).reshape(n), img)
+            return
         fh[base + "contigs"] = np.array(contigs, dtype='S')
         fh[base + "positions"] = np.asarray(positions, dtype=np.int64).astype(np.int32)
         fh[base + "depths"] = wrap_uint8(depths)

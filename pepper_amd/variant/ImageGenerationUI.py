@@ -22,6 +22,9 @@ from pepper_amd.variant.AlignmentSummarizer import AlignmentSummarizer
 from pepper_amd.variant.DataStore import DataStore
 
 
+_STATS_LOCK = __import__("threading").Lock()
+
+
 def _log(msg):
     sys.stderr.write("[" + datetime.now().strftime('%m-%d-%Y %H:%M:%S') + "] " + msg + "\n")
     sys.stderr.flush()
@@ -145,11 +148,18 @@ class ImageGenerationUtils:
         from pepper_amd.variant.AlignmentSummarizer import create_summaries
         generators = {}
         stats = getattr(options, "stage_seconds", None)      # a dict the caller wants the stage times of this worker added to
+        mine = {}
 
         def lap(key, t0):
+            now = time.perf_counter()
+            mine[key] = mine.get(key, 0.0) + now - t0
+            return now
+
+        def report():
             if stats is not None:
-                stats[key] = stats.get(key, 0.0) + time.perf_counter() - t0
-            return time.perf_counter()
+                with _STATS_LOCK:
+                    for key, v in mine.items():
+                        stats[key] = stats.get(key, 0.0) + v
 
         def write(output_hdf_file, chr_name, _start, _end, out):
             n = len(out["candidates"])
@@ -180,6 +190,7 @@ class ImageGenerationUtils:
             if not packed:
                 for g0 in range(0, len(intervals), batch):
                     host_clipped(output_hdf_file, intervals[g0:g0 + batch])
+                report()
                 return process_id
             # The packed form: per group of consecutive intervals ONE call of the BAM reader (inflate, header walk, filters; no
             # clipping, no decoding: the reads cross PCIe as BAM stores them, once per group) and ONE of the encoder (clip +
@@ -188,19 +199,24 @@ class ImageGenerationUtils:
             from pepper_amd.variant.AlignmentSummarizer import AlingerOptions, ConsensCandidateFinder
             from pepper_amd.variant.Options import ImageSizeOptions
             from pepper_amd.variant.PEPPER_VARIANT import PackedEncoder
-            enc = PackedEncoder(getattr(options, "device", 0),
-                                arena_bytes=int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20)
+            t_setup = time.perf_counter()
+            # (every CPU the process has is inflating BGZF blocks in some worker: the encoder's host part runs on this thread)
+            enc = PackedEncoder.acquire(getattr(options, "device", 0), int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20,
+                                        host_threads=1)
             bam_handler, fasta_handler = _handlers(options, options.bam, options.fasta)
+            lap("setup", t_setup)
             safe = ConsensCandidateFinder.REGION_SAFE_BASES
             params = (options.min_snp_baseq, options.min_indel_baseq, options.snp_frequency, options.insert_frequency,
                       options.delete_frequency, options.min_coverage_threshold, options.snp_candidate_frequency_threshold,
                       options.indel_candidate_frequency_threshold, options.candidate_support_threshold, options.skip_indels)
             g0 = 0
             while g0 < len(intervals):
-                # consecutive intervals of one contig, ascending
+                # ADJACENT intervals of one contig, ascending (the packer walks every record between the first and the last
+                # region of a call: a group must not bridge the gap to this worker's next run of intervals)
                 g1 = g0 + 1
                 while (g1 < len(intervals) and g1 - g0 < batch and intervals[g1][0] == intervals[g0][0]
-                       and intervals[g1][1] >= intervals[g1 - 1][1] and intervals[g1][2] >= intervals[g1 - 1][2]):
+                       and intervals[g1 - 1][1] <= intervals[g1][1] <= intervals[g1 - 1][2] + 2 * safe
+                       and intervals[g1][2] >= intervals[g1 - 1][2]):
                     g1 += 1
                 group = intervals[g0:g1]
                 chr_name = group[0][0]
@@ -243,7 +259,10 @@ class ImageGenerationUtils:
                         write(output_hdf_file, chr_name, _start, _end, out)
                 lap("hdf5", t0)
                 g0 += n_done
-            enc.close()
+            enc.release()
+            t_close = time.perf_counter()
+        lap("close", t_close)
+        report()
         return process_id
 
     @staticmethod

@@ -257,11 +257,30 @@ class PackedEncoder(object):
     in this object's page-locked arena -- CIGAR words, 4-bit bases, qualities, once per read -- clipped to each region and
     decoded by the device.  One object per worker thread: it owns its encoder handle (stream, workspace, arena)."""
 
-    def __init__(self, device=0, arena_bytes=192 << 20, max_reads=1 << 18, max_pairs=1 << 19):
+    _idle = []                      # encoders returned by release(): a later job's workers take them instead of pinning new arenas
+    _idle_lock = __import__("threading").Lock()
+
+    @classmethod
+    def acquire(cls, device=0, arena_bytes=192 << 20, host_threads=1):
+        """An encoder from the process-wide pool (or a new one): pinning a 256 MB arena and the first device allocations cost
+        ~0.15 s per worker, which a long-running process pays once."""
+        with cls._idle_lock:
+            for k, enc in enumerate(cls._idle):
+                if enc.device == device and enc.arena is not None and enc.arena.nbytes == arena_bytes:
+                    return cls._idle.pop(k)
+        return cls(device, arena_bytes, host_threads=host_threads)
+
+    def release(self):
+        with self._idle_lock:
+            self._idle.append(self)
+
+    def __init__(self, device=0, arena_bytes=192 << 20, max_reads=1 << 18, max_pairs=1 << 19, host_threads=0):
         from pepper_amd.variant.bam import PACKED_READ
         self.lib = _lib.load()
+        self.device = device
         self.enc = ctypes.c_void_p()
         _lib.check(self.lib.pa_encoder_create(device, None, ctypes.byref(self.enc)))
+        _lib.check(self.lib.pa_encoder_set_host_threads(self.enc, host_threads))
         ptr = self.lib.pa_encoder_host_arena(self.enc, arena_bytes)
         if not ptr:
             raise _lib.PepperAmdError("page-locked arena of %d bytes could not be allocated" % arena_bytes)

@@ -30,7 +30,7 @@ def _groups(directory):
     out = {}
     for fn in sorted(os.listdir(directory)):
         with h5.File(os.path.join(directory, fn)) as f:
-            for name in (f.keys("summaries") if f.exists("summaries") else []):
+            for name in (f.keys("summaries") if "summaries" in f else []):
                 assert name not in out
                 g = "summaries/" + name + "/"
                 out[name] = dict(images=f[g + "images"], positions=f[g + "positions"], depths=f[g + "depths"],

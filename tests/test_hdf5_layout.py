@@ -38,20 +38,56 @@ def assert_same_tree(a, b):
         assert np.array_equal(np.asarray(va), np.asarray(vb)), k
 
 
-def test_variant_images_reader_and_writer(golden_dir, tmp_path):
+@pytest.mark.parametrize("builder", [True, False])
+def test_variant_images_reader_and_writer(golden_dir, tmp_path, monkeypatch, builder):
+    """Both writers of the image store -- the append-only one image generation uses (h5build.cpp: fixed-width contig strings,
+    the candidate strings as references into global heap collections) and the libhdf5 one -- against the file the reference's
+    own DataStore wrote under h5py: same tree for libhdf5, no difference for h5diff, same arrays and str for h5py."""
     from pepper_amd.variant.DataStore import DataStore
     from pepper_amd.variant.models.dataloader_predict import SequenceDataset
+    monkeypatch.setenv("PEPPER_AMD_H5_BUILDER", "1" if builder else "0")
     ref = os.path.join(golden_dir, "variant_images_ref.hdf5")
     inp = np.load(os.path.join(golden_dir, "variant_images_inputs.npz"), allow_pickle=True)
     names = sorted({k.split("__")[0] for k in inp.files})
     mine = str(tmp_path / "mine.hdf5")
     with DataStore(mine, "w") as ds:
+        assert isinstance(ds.file_handler, h5.PredictionBuilder) == builder
         for n in names:
             g = {k.split("__")[1]: inp[k] for k in inp.files if k.startswith(n + "__")}
             ds.write_summary(n, g["contigs"].tolist(), g["positions"].tolist(), g["depths"].tolist(),
                              g["candidates"].tolist(), g["candidate_frequency"].tolist(), g["images"].tolist(),
                              [0] * len(g["contigs"]), [0] * len(g["contigs"]), False)
     assert_same_tree(dump(ref), dump(mine))
+    if os.path.exists("/opt/conda/bin/h5diff"):
+        r = subprocess.run(["/opt/conda/bin/h5diff", ref, mine], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # many groups (several heap collections, a B-tree of more than one level), one without candidates, long alleles
+    big = str(tmp_path / "big.hdf5")
+    rng = np.random.default_rng(5)
+    want = {}
+    with DataStore(big, "w") as ds:
+        for k in range(300):
+            n = 0 if k == 17 else int(rng.integers(1, 40))
+            cands = [["%d%s" % (rng.integers(1, 4), "".join(rng.choice(list("ACGT"), int(rng.integers(1, 60)))))] for _ in range(n)]
+            img = rng.integers(-128, 128, (n, 33, 26)).astype(np.int8)
+            pos = rng.integers(0, 1 << 30, n)
+            want["ctg%d_%d_%d" % (k % 3, k, k + 1)] = (pos, cands, img)
+            ds.write_summary("ctg%d_%d_%d" % (k % 3, k, k + 1), ["ctg%d" % (k % 3)] * n, pos, rng.integers(0, 126, n),
+                             np.array(cands, dtype=object).reshape(n, 1), rng.integers(0, 126, (n, 1)), img, [0] * n, [0] * n, False)
+    with h5.File(big) as f:
+        assert sorted(f.keys("summaries")) == sorted(want)
+        for name, (pos, cands, img) in want.items():
+            assert np.array_equal(f["summaries/%s/positions" % name], pos.astype(np.int32))
+            assert f["summaries/%s/candidates" % name].tolist() == cands and np.array_equal(f["summaries/%s/images" % name].reshape(img.shape), img)
+            assert f.info("summaries/%s/contigs" % name)[0] == (len(pos),)
+    if os.path.exists("/opt/conda/bin/python3.9"):
+        script = ("import h5py, sys, numpy as np\nf = h5py.File(sys.argv[1], 'r')\ng = f['summaries/ctg2_17_18']\n"
+                  "assert g['images'].shape == (0, 33, 26) and g['candidates'].shape == (0, 1) and g['contigs'].shape == (0,)\n"
+                  "g = f['summaries/ctg0_3_4']\nassert g['contigs'].dtype == np.dtype('S4') and g['contigs'][0] == b'ctg0'\n"
+                  "c = g['candidates'][0, 0]\nc = c.decode() if isinstance(c, bytes) else c\nassert c[0] in '123' and g['images'].dtype == np.int8\n"
+                  "assert h5py.check_string_dtype(g['candidates'].dtype).length is None and len(f['summaries']) == 300\nprint('fine')\n")
+        r = subprocess.run(["/opt/conda/bin/python3.9", "-c", script, big], capture_output=True, text=True)
+        assert r.returncode == 0 and "fine" in r.stdout, r.stderr[-3000:]
     # int8 wrap of unclamped columns, as numpy 1.22 did it
     d = dump(ref)
     img = d["summaries/chr20_1000_2000/images"][4]
