@@ -98,6 +98,9 @@ def self_spawn(args):
     sys.exit(subprocess.call(cmd))
 
 
+COLLECTIVE_NOTE = "none (one rank)"
+
+
 def dist_setup(args):
     """-> (world, rank, device ordinal, ranks_seen).  ranks_seen comes out of a real all-reduce."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,14 +117,34 @@ def dist_setup(args):
     share = os.environ.get("PEPPER_AMD_BENCH_SHARE_GPU") == "1" and ndev < world
     device = local % ndev if share else local
     torch.cuda.set_device(device)
+    global COLLECTIVE_NOTE
     if share:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         one = torch.ones(1)
-    else:
+        dist.all_reduce(one)
+        COLLECTIVE_NOTE = "gloo (ranks share devices: plumbing check)"
+        return world, rank, device, int(one.item())
+    # RCCL first; if its initialisation or its first collective fails on this box every rank falls back to gloo for the one
+    # weight broadcast and the timing barriers (the data path has no collective), and the line says so
+    try:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
         one = torch.ones(1, device=torch.device("cuda", device))
-    dist.all_reduce(one)
-    return world, rank, device, int(one.item())
+        dist.all_reduce(one)
+        torch.cuda.synchronize(device)
+        COLLECTIVE_NOTE = "nccl (RCCL)"
+        return world, rank, device, int(one.item())
+    except Exception as err:        # noqa: BLE001 -- whatever RCCL raises, the bench goes on
+        sys.stderr.write("[bench] rank %d: RCCL unusable (%s); falling back to gloo\n" % (rank, repr(err)[:200]))
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)      # the store of the failed group may linger
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        one = torch.ones(1)
+        dist.all_reduce(one)
+        COLLECTIVE_NOTE = "gloo (RCCL initialisation failed: %s)" % repr(err)[:160]
+        return world, rank, device, int(one.item())
 
 
 def broadcast_state_dict(make_sd, shapes, world, rank, dev):
@@ -281,15 +304,22 @@ def measured_traffic(model_kind, label):
     tools/pmc_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this file with --resident-only):
     FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16-byte-per-lane streaming reads, WRITE_SIZE as
     reported.  None where no pass is on file."""
-    path = os.path.join(REPO, "profiles", f"r03_{model_kind}_pmc.json")
-    if not os.path.exists(path):
-        path = os.path.join(REPO, "profiles", f"r02_{model_kind}_pmc.json")
+    for tag in ("r04", "r03", "r02"):
+        path = os.path.join(REPO, "profiles", f"{tag}_{model_kind}_pmc.json")
+        if os.path.exists(path):
+            break
     try:
         with open(path) as fh:
             table = json.load(fh)
         k = table["kernels"][label]
-        return {"bytes_per_launch": k["fetch_bytes_corrected"] + k["write_bytes"], "fetch_bytes_corrected": k["fetch_bytes_corrected"],
+        total = k["fetch_bytes_corrected"] + k["write_bytes"]
+        return {"bytes_per_launch": total, "fetch_bytes_corrected": k["fetch_bytes_corrected"],
                 "write_bytes": k["write_bytes"], "units_per_launch": k.get("units_per_launch"),
+                # the counters north_star names, of the same profiled launches: MFMA-busy cycles / (GRBM_GUI_ACTIVE x 1024 SIMDs),
+                # and the HBM bytes above over the launch's profiled duration
+                "mfma_busy_frac": k.get("mfma_busy_frac"),
+                "hbm_GBps_profiled": (total / (k["avg_us"] * 1e-6) / 1e9) if k.get("avg_us") else None,
+                "avg_us_profiled": k.get("avg_us"),
                 "source": os.path.relpath(path, REPO)}
     except Exception:
         return None
@@ -578,6 +608,49 @@ def encoder_bench(args):
         dist.destroy_process_group()
 
 
+def make_images_leg(scratch):
+    """generate_images (pepper_variant make_images / call_variant's first step) on a synthetic 64 Mb BAM at 60x written by
+    tools/synth_bam: BAM + FASTA -> candidate image HDF5 files, Mb of reference per second with the stage times of the workers
+    (tools/bench_variant_images.py).  Three runs over the same files, the median reported."""
+    import shutil
+    import subprocess
+    import tempfile
+    base = scratch or tempfile.gettempdir()
+    try:
+        st = os.statvfs(base)
+        bases = 64_000_000 if st.f_bavail * st.f_frsize > (12 << 30) else 16_000_000
+    except OSError:
+        bases = 16_000_000
+    work = tempfile.mkdtemp(prefix="pepper_amd_images_", dir=base)
+    tool = os.path.join(REPO, "tools", "bench_variant_images.py")
+    try:
+        from pepper_amd.hostinfo import usable_cpus
+        threads = max(1, usable_cpus())
+        p = subprocess.run([sys.executable, tool, "make_fast", work, str(bases)], capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            return {"error": (p.stderr or "synth_bam failed").strip().splitlines()[-1][:300]}
+        made = json.loads(p.stdout.strip().splitlines()[-1])
+        p = subprocess.run([sys.executable, tool, "run", work, ",".join([str(threads)] * 3)], capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if not lines:
+            return {"error": (p.stderr or "no output").strip().splitlines()[-1][:300]}
+        d = json.loads(lines[-1])
+        runs = sorted(d["runs"], key=lambda r: r["mb_reference_per_s"])
+        mid = runs[len(runs) // 2]
+        return {"value": mid["mb_reference_per_s"], "unit": "Mb of reference/s", "aligned_gbases_per_s": mid["aligned_gbases_per_s"],
+                "seconds": mid["seconds"], "threads": mid["threads"], "runs_mb_per_s": [r["mb_reference_per_s"] for r in runs],
+                "stage_seconds_summed_over_workers": mid["stage_seconds_summed_over_workers"], "data": d["data"],
+                "synth_seconds": made["seconds"], "image_file_mb": mid["image_file_mb"],
+                "note": "pepper_amd.variant.ImageGenerationUI.generate_images, intervals of 100 kb, one worker thread per usable CPU, each "
+                        "with its own BAM handle, page-locked arena and encoder: bam_pack = BGZF inflate (libdeflate) + record-header walk + "
+                        "one slice copy per read (no clipping, no decoding on the host), encode = upload + unpack_clip_kernel + the summary "
+                        "kernels + candidate enumeration + result copy, hdf5 = the append-only writer; the CPUs' inflate rate bounds it"}
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def secondary_block(args):
     """The other workloads of the hot path, each as its own short run of this file / the pipeline tools after the headline
     measurement (same command, same box, one after the other on the one GPU): polish (BASELINE configs[4]) windows/s with its
@@ -599,18 +672,32 @@ def secondary_block(args):
             return d
         except Exception as e:          # a failing secondary leg must not take the headline line with it
             return {"error": repr(e)[:300]}
-    d = last_json([sys.executable, me, "--model", "polish", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extras"], 300)
+    def median_of(cmd, timeout, runs=3, key="value"):
+        """The run with the median `key` of `runs` fresh processes (each a few seconds: start-up and box noise decide the second
+        digit of any single one), with every run's figure beside it."""
+        got = [last_json(cmd, timeout) for _ in range(runs)]
+        good = sorted((g for g in got if "error" not in g), key=lambda g: g[key])
+        if not good:
+            return got[0]
+        mid = good[len(good) // 2]
+        mid["_runs"] = [round(g[key], 1) for g in good]
+        return mid
+    d = median_of([sys.executable, me, "--model", "polish", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"], 300)
     out["polish"] = d if "error" in d else {
         "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"],
         "h2d_d2h": d["config"]["h2d_d2h"], "roofline": {k: d["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
-                                                                                      "frac_algorithmic_of_dtype_peak") if k in d["roofline"]},
-        "seconds": d["_seconds"]}
-    d = last_json([sys.executable, me, "--model", "encoder", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"], 300)
+                                                                                      "frac_algorithmic_of_dtype_peak", "mfma_busy_frac",
+                                                                                      "hbm_GBps") if k in d["roofline"]},
+        "batch128": d.get("batch128"), "device_resident": (d.get("device_resident") or {}).get("value"),
+        "runs": d["_runs"], "seconds": d["_seconds"]}
+    d = median_of([sys.executable, me, "--model", "encoder", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"], 300)
     out["encoder"] = d if "error" in d else {
         "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "regions_per_step": d["config"]["regions_per_gpu_per_step"],
         "aligned_bases_per_step": d["config"]["aligned_bases_per_step"], "candidates_per_step": d["config"]["candidates_per_step"],
-        "roofline": {k: d["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch")},
-        "host_buffers_one_call": d["host_buffers_one_call"]["value"], "seconds": d["_seconds"]}
+        "roofline": {k: d["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                                   "issue") if k in d["roofline"]},
+        "host_buffers_one_call": d["host_buffers_one_call"]["value"], "packed_host_fed": d.get("packed_host_fed"),
+        "runs": d["_runs"], "seconds": d["_seconds"]}
     scratch = None
     try:
         st = os.statvfs("/dev/shm")
@@ -619,8 +706,9 @@ def secondary_block(args):
     except OSError:
         pass
     extra = ["--dir", scratch] if scratch else []
-    d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_pipeline.py"), "--files", "8", "--windows", "524288", "--groups", "512",
-                   "--workers", "0"] + extra, 400)
+    out["make_images"] = make_images_leg(scratch)
+    d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_pipeline.py"), "--files", "16", "--windows", "524288", "--groups", "512",
+                   "--workers", "0"] + extra, 600)
     out["run_inference_hdf5"] = d if "error" in d else {
         "value": d["windows_per_s"], "unit": "windows/s", "windows": d["windows"], "image_bytes": d["image_bytes"], "seconds": d["seconds"],
         "mode": d["mode"], "scratch": scratch or "system temporary directory",
@@ -628,8 +716,8 @@ def secondary_block(args):
                 "per-batch prediction groups), SURVEY.md 8(d) 'a second number including I/O'"}
     # three runs over the same files, the median reported: the job is 2-3 s of sixteen host CPUs' work beside the device passes and
     # its time varies by +-15 % from run to run on one box (profiles/r03_polish_pipeline_runs_ab.json)
-    d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_polish_pipeline.py"), "--chunks", "262144", "--files", "32",
-                   "--workers", "0,0,0", "--median"] + extra, 400)
+    d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_polish_pipeline.py"), "--chunks", "524288", "--files", "64",
+                   "--workers", "0,0,0", "--median"] + extra, 900)
     out["call_consensus_hdf5"] = d if "error" in d else {
         "value": d["chunks_per_s"], "unit": "chunks/s", "windows_per_s": d["windows_per_s"], "chunks": d["chunks"], "seconds": d["seconds"],
         "runs_chunks_per_s": d.get("runs_chunks_per_s"), "mode": d["mode"], "scratch": scratch or "system temporary directory",
@@ -928,11 +1016,18 @@ def main():
                        "reference_hdf5_batch": 512 if variant else 128,
                        "weights": "seeded random init (pepper_amd.synthetic), fp32",
                        "parallelism": f"region-shard x{world}, one weight broadcast, no data-path collective",
-                       "ranks_seen": ranks_seen, "per_rank_seconds": [round(x, 4) for x in per_rank_seconds]},
+                       "ranks_seen": ranks_seen, "per_rank_seconds": [round(x, 4) for x in per_rank_seconds],
+                       "collective_backend": COLLECTIVE_NOTE},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": kernel_peak(dom),
                          "unit": "TFLOP/s", "frac": ach / kernel_peak(dom),
                          "traffic": traffic["bytes_per_launch"] if traffic else None,
                          "traffic_detail": traffic,
+                         "mfma_busy_frac": traffic.get("mfma_busy_frac") if traffic else None,
+                         "hbm_GBps": traffic.get("hbm_GBps_profiled") if traffic else None,
+                         "hbm_frac_of_peak": (traffic["hbm_GBps_profiled"] / HBM_PEAK_GBPS) if traffic and traffic.get("hbm_GBps_profiled") else None,
+                         "counters_note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), hbm_GBps = (FETCH_SIZE + "
+                                          "WRITE_SIZE bytes) / profiled launch duration: rocprofv3 --pmc passes of this command with "
+                                          "--resident-only, committed under profiles/ (traffic_detail.source)",
                          "algorithmic_bytes_per_launch": (ALGORITHMIC_BYTES_PER_UNIT[dom] * min(per, chunk)
                                                           if dom in ALGORITHMIC_BYTES_PER_UNIT else None),
                          "frac_algorithmic_of_dtype_peak": ach / (F16_MFMA_PEAK_TFLOPS if h2 else F32_MFMA_PEAK_TFLOPS),

@@ -302,6 +302,7 @@ struct RecLayer {
     DevBuf *w_hh_h2 = nullptr;  // LSTM H=256: W_hh as h2 fragments (rnn_h2.hip)
     DevBuf *w_cat_h2 = nullptr; // LSTM first layer: [W_hh | W_ih] as h2 fragments
     DevBuf *w_cat_dec_h2 = nullptr; // layer fed by an h2 layer output (K = 2H): [W_hh | W_ih] fragments
+    DevBuf *w_hh_small_h2 = nullptr; // GRU H=128: W_hh as 16x16x32 fragments for the small-call step loop (gru_small_h2_kernel)
     DevBuf *b_in = nullptr;    // [2*G*H]       LSTM: b_ih + b_hh; GRU: b_ih + (b_hr, b_hz, 0)
     DevBuf *w_hh = nullptr;    // packed
     DevBuf *b_hn = nullptr;    // GRU only: [2*H]
@@ -406,6 +407,13 @@ int build_rec_layer(ModelBase* m, const StateDict& sd, const std::string& prefix
             if (int rc = pack_upload(out.w_cat_h2, wih_x, KXh2, true)) return rc;
         if (K == 2 * H)
             if (int rc = pack_upload(out.w_cat_dec_h2, wih_x, K)) return rc;
+        if (G == 3 && H == 128) {
+            std::vector<uint32_t> hp(pa::gru_small_weights_h2_words(H));
+            pa::pack_gru_small_weights_h2(whh_x, H, hp.data());
+            out.w_hh_small_h2 = m->new_buf();
+            if (int rc = out.w_hh_small_h2->ensure(hp.size() * sizeof(uint32_t))) return rc;
+            HIP_TRY(hipMemcpy(out.w_hh_small_h2->p, hp.data(), hp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
     }
     if ((G == 4 && H == 256 && K <= 32) || (G == 3 && H == 128 && K <= 16)) {
         std::vector<float> cat;
@@ -891,6 +899,7 @@ struct pa_polish_model : ModelBase {
     bool fuse_dec = true;        // PA_FUSE_DEC=0: decoder projection as a GEMM + Xp instead of inside the step loop
     bool y_h2 = false;           // format of the last polish_window output
     bool fuse_head = true;       // PA_FUSE_HEAD=0: last decoder layer writes y, dense1 + softmax + overlap-add as their own kernel
+    int small_max = 1024;        // calls of at most this many chunks take the small-call schedule (PA_POLISH_SMALL_MAX; 0: never)
     std::vector<RecLayer> enc, dec;
     Linear dense;
     DevBuf *dense_h2 = nullptr;  // dense1 as h2 fragments of the 16x16x32 tile (rnn_h2.hip pack_dense_head_h2)
@@ -931,7 +940,25 @@ static int polish_window(pa_polish_model* m, int x_kind, const void* x, int x_ld
             // wide uint8 inputs (16 < F <= 128) are read as dwords by the step loop: rows must be 4-byte aligned
             const bool fused_h2_ok = rec_h2 && r.w_cat_h2 != nullptr &&
                                      (r.K <= 16 || ((xbs & 3) == 0 && (reinterpret_cast<uintptr_t>(cur) & 3) == 0));
-            if (stage == 0 && l == 0 && cur_kind == pa::A_U8 && (r.w_cat != nullptr || fused_h2_ok) && m->fuse_input) {
+            // Small calls: a step's latency is what counts (19 windows x 200 dependent steps whatever n is), so the projections
+            // run as GEMMs over all T steps and the step loops as 16-row workgroups with their weights in registers
+            const bool small = m->small_max > 0 && n <= m->small_max && rec_h2 && r.w_hh_small_h2 != nullptr && H == 128 &&
+                               (cur_h2 ? (r.w_ih_h2 != nullptr && m->split_gemm) : (stage == 0 && l == 0));
+            if (small) {
+                if (cur_h2)
+                    LAUNCH_TRY(m, "gemm_h2_inproj_small", 2.0 * M * NX * r.K,
+                               pa::launch_gemm_h2(cur, cur_ld, (size_t)M * cur_ld * 4, r.w_ih_h2->p, r.K,
+                                                  (size_t)NX * r.K * 4, r.b_in->f(), m->xp->f(), NX,
+                                                  (int)(round_up(n, MTP) * T), NX, r.K, 0, 0, 0, T, (int)n, m->stream));
+                else
+                    LAUNCH_TRY(m, "gemm_inproj_in_small", 2.0 * M * NX * r.K,
+                               pa::launch_gemm_nt(cur_kind, cur, cur_ld, r.w_ih->f(), r.Kp, r.b_in->f(), m->xp->f(), NX,
+                                                  (int)(round_up(n, MTP) * T), NX, r.K, 0, 0, cur_bs, T, (int)n, m->stream));
+                LAUNCH_TRY(m, "gru_small_h2", 2.0 * n * T * (3.0 * H) * H * 2,
+                           pa::launch_gru_small_h2(H, m->xp->f(), NX, r.w_hh_small_h2->p, r.b_hn->f(), h0l, ldh, hnl, ldh, y, 2 * H,
+                                                   (int)n, T, m->stream));
+                cur_h2 = true;
+            } else if (stage == 0 && l == 0 && cur_kind == pa::A_U8 && (r.w_cat != nullptr || fused_h2_ok) && m->fuse_input) {
                 if (fused_h2_ok)
                     LAUNCH_TRY(m, "gru_rec_h2_fused_in", 2.0 * n * T * (3.0 * H) * (H + r.K) * 2,
                                pa::launch_gru_rec_h2(H, nullptr, 0, static_cast<const uint8_t*>(cur), r.K, xbs, r.b_in->f(),
@@ -1041,6 +1068,7 @@ int pa_polish_create(const pa_polish_config* cfg, const char* const* names, cons
         }
     if (rc == PA_OK) rc = build_linear(m, sd, "dense1", 2 * H, cfg->num_classes, m->dense);
     if (const char* e = getenv("PA_FUSE_HEAD")) m->fuse_head = e[0] != '0';
+    if (const char* e = getenv("PA_POLISH_SMALL_MAX")) m->small_max = std::max(0, atoi(e));
     if (rc == PA_OK && m->split_rec && H == 128 && cfg->num_classes <= 5) {
         std::string err;
         const float* w = sd.get("dense1.weight", (int64_t)cfg->num_classes * 2 * H, err);

@@ -81,6 +81,12 @@ hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, 
 
 // GRU layer whose input is an h2 layer output [B*T, 2H]: projection fused into the step loop (weights packed
 // with pack_rec_weights_h2(..., F = 2H, KX = 2H); bias = b_ih + (b_hr, b_hz, 0)).
+// Small calls (H = 128): 16-row workgroups with the recurrent weights in registers (rnn_h2.hip gru_small_h2_kernel); Xp from
+// the projection GEMM (bias folded), Wp from pack_gru_small_weights_h2, Y in h2 format.
+void pack_gru_small_weights_h2(const float* const whh[2], int H, uint32_t* out);
+size_t gru_small_weights_h2_words(int H);
+hipError_t launch_gru_small_h2(int H, const float* Xp, int ldx, const void* Wp, const float* bhn, const float* h0, int ldh0,
+                               float* hn, int ldhn, void* Y, int ldy, int B, int T, hipStream_t stream);
 hipError_t launch_gru_dec_h2(int H, const void* Xh, int ldxh, const float* bias, const void* Wp, const float* bhn,
                              const float* h0, int ldh0, float* hn, int ldhn, void* Y, int ldy, int B, int T,
                              hipStream_t stream);

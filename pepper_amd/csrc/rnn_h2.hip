@@ -1092,6 +1092,179 @@ __global__ __launch_bounds__(512, 1) void gru_rec_h2_kernel(const float* __restr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// GRU step loop for SMALL calls (polish model, H = 128; the reference's default batch is 128 chunks,
+// pepper/modules/python/models/predict_distributed_gpu.py:40-47).  A call of n chunks runs 19 windows x
+// (100 + 100) DEPENDENT steps whatever n is, so a small call is bound by the latency of one step, not by
+// throughput: gru_rec_h2_kernel's 128-row workgroup takes ~14 us per step (8 waves x 36-72 MFMAs of 32
+// cycles, a 200-600 KB weight stream from L2 and a gate phase of 32 elements per lane) with two of 256 CUs
+// busy.  Here ONE workgroup of four waves owns 16 batch rows of one direction:
+//   * wave u owns hidden units [32u, 32u + 32) of all three gates, so r, z and n of an element meet in one lane and
+//     nothing but h_t itself crosses waves;
+//   * the wave's recurrent weights -- 3 gates x 32 units x K = 128, (hi, lo) halves -- stay in REGISTERS for the
+//     whole loop (192 VGPRs as B fragments of v_mfma_f32_16x16x32_f16): no weight stream at all;
+//   * h lives in LDS in h2 form in TWO row images (step parity): the gate phase writes h_t into one while slower
+//     waves may still read h_{t-1} from the other, so a step has ONE workgroup barrier;
+//   * the input projections (+ b_ih, + b_hr / b_hz) come precomputed in Xp (one GEMM over all T steps on the whole
+//     chip in front of the loop), fetched one step ahead; the layer output is the LDS image copied out 16 bytes
+//     per lane while the next step contracts.
+// Per step and wave: 72 MFMAs of 16 cycles + a gate phase of 8 elements per lane.  n chunks = 2 * ceil(n / 16)
+// workgroups: the reference's 128-chunk batch spreads over 16 CUs instead of 2, 2048 chunks fill the chip.
+//   /root/reference/pepper/modules/python/models/simple_model.py:30,32
+template <int H>
+__global__ __launch_bounds__(256, 1) void gru_small_h2_kernel(const float* __restrict__ Xp, int ldx,
+                                                              const uint32_t* __restrict__ Wp,
+                                                              const float* __restrict__ bhn,
+                                                              const float* __restrict__ h0, int ldh0,
+                                                              float* __restrict__ hn, int ldhn,
+                                                              uint32_t* __restrict__ Y, int ldy, int B, int T) {
+    static_assert(H == 128, "four waves x 32 units");
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    constexpr int RT = 16, NT = H / 32, KS = H / 32;            // rows per workgroup, unit tiles = waves, k steps of 32
+    constexpr int ROWB = H * 4 + 16, ROWD = ROWB / 4;
+    constexpr float L2E = 1.4426950408889634f;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * RT * ROWD];      // two h2 row images (step parity)
+    const int dir = blockIdx.x & 1, btile = blockIdx.x >> 1;
+    const int b0 = btile * RT;
+    if (b0 >= B) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, q4 = lane >> 4;
+
+    // ---- the wave's weights: [dir][u][gate 3][sub 2][k step KS][hi, lo][64 lanes][16 B] ----
+    h8 w[3][2][KS][2];
+    {
+        const uint32_t* wsrc = Wp + ((size_t)(dir * NT + u) * (3 * 2 * KS * 2)) * 256 + lane * 4;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int hl = 0; hl < 2; ++hl)
+                        w[g][sb][s][hl] = *reinterpret_cast<const h8*>(wsrc + (size_t)(((g * 2 + sb) * KS + s) * 2 + hl) * 256);
+    }
+    // ---- h0 -> registers (exact f32, for the z * h term and the final state) and the first LDS image ----
+    float hreg[2][4];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 4 * q4 + e, col = u * 32 + sb * 16 + c16;
+            const float hv = h0 != nullptr ? h0[(size_t)(b0 + row) * ldh0 + dir * H + col] : 0.0f;
+            hreg[sb][e] = hv;
+            h2_store16(reinterpret_cast<unsigned short*>(lds + row * ROWD + (col >> 3) * 8 + ((col & 7) >> 1)) + (col & 1), hv);
+        }
+    float bn[2];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) bn[sb] = bhn[dir * H + u * 32 + sb * 16 + c16];
+
+    // Xp: C fragments of the projection GEMM's 32 x 32 tiles, [32-row batch tile][t][column tile][qd 4][lane 64][4 floats]
+    // (lane l of such a tile: column l & 31, rows 8 qd + 4 (l >> 5) + e); this workgroup is half hh of its batch tile, and
+    // a 16 x 16 accumulator lane (column c16, rows 4 q4 + e) finds its four values in ONE 16-byte slot
+    const int hh = (b0 >> 4) & 1;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Xp + (size_t)(b0 >> 5) * T * (ldx >> 5) * 1024), 0, 0x7fffffff, 0x00020000);
+    const unsigned xlane = (unsigned)(((2 * hh + (q4 >> 1)) * 64 + (q4 & 1) * 32 + c16) * 16);
+    auto load_xp = [&](int t, f32x4v (&dst)[3][2]) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const unsigned tile = ((unsigned)t * (unsigned)(ldx >> 5) + (unsigned)(dir * 3 * NT + g * NT + u)) * 4096u;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+                dst[g][sb] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, xlane + sb * 256u, tile, 0));
+        }
+    };
+    // y copy: 16 rows x 32 chunks of 16 bytes, two per thread
+    const int yrow = tid >> 5, ychunk = tid & 31;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)b0 * T * ldy + dir * H, 0, 0x7fffffff, 0x00020000);
+    auto y_copy = [&](const uint32_t* img, int t) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = yrow + 8 * k;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(img + row * ROWD + ychunk * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(v, yrs, (unsigned)((row * T) * ldy + ychunk * 4) * 4u, (unsigned)t * (unsigned)ldy * 4u, 0);
+        }
+    };
+
+    // Xp two steps ahead in two register sets (steps of even / odd parity): the loads a step issues are consumed two steps on,
+    // so no wait in a step refers to what that step itself asked for
+    f32x4v xa[3][2], xb[3][2];
+    load_xp(dir ? T - 1 : 0, xa);
+    if (T > 1) load_xp(dir ? T - 2 : 1, xb);
+    __syncthreads();
+    auto do_step = [&](int step, f32x4v (&mine)[3][2]) {
+        const int t = dir ? T - 1 - step : step;
+        const uint32_t* cur = lds + (step & 1) * (RT * ROWD);
+        uint32_t* nxt = lds + ((step & 1) ^ 1) * (RT * ROWD);
+        // the layer output of the step before: its LDS image is `cur` (published by the barrier that ended that step)
+        if (step > 0) y_copy(cur, dir ? t + 1 : t - 1);
+        f32x4v ar[2], az[2], anh[2], anx[2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            ar[sb] = mine[0][sb];
+            az[sb] = mine[1][sb];
+            anx[sb] = mine[2][sb];
+            anh[sb] = f32x4v{bn[sb], bn[sb], bn[sb], bn[sb]};
+        }
+        if (step + 2 < T) load_xp(dir ? t - 2 : t + 2, mine);
+        // ---------------- MFMA phase: [r z nh] += h_{t-1} W_hh^T, three-term split product ----------------
+        const uint32_t* arow = cur + c16 * ROWD + q4 * 8;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const h8 a_hi = *reinterpret_cast<const h8*>(arow + s * 32);
+            const h8 a_lo = *reinterpret_cast<const h8*>(arow + s * 32 + 4);
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                ar[sb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, w[0][sb][s][0], ar[sb], 0, 0, 0);
+                az[sb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, w[1][sb][s][0], az[sb], 0, 0, 0);
+                anh[sb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, w[2][sb][s][0], anh[sb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                ar[sb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, w[0][sb][s][1], ar[sb], 0, 0, 0);
+                az[sb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, w[1][sb][s][1], az[sb], 0, 0, 0);
+                anh[sb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, w[2][sb][s][1], anh[sb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                ar[sb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, w[0][sb][s][0], ar[sb], 0, 0, 0);
+                az[sb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, w[1][sb][s][0], az[sb], 0, 0, 0);
+                anh[sb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, w[2][sb][s][0], anh[sb], 0, 0, 0);
+            }
+        }
+        // ---------------- gate phase: the lane's eight elements; h' = n + z (h - n) ----------------
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-L2E * ar[sb][e]));
+                const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-L2E * az[sb][e]));
+                const float narg = __builtin_fmaf(rg, anh[sb][e], anx[sb][e]);
+                const float ng = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.0f * L2E * narg)), 1.0f);
+                const float hv = __builtin_fmaf(zg, hreg[sb][e] - ng, ng);
+                hreg[sb][e] = hv;
+                const int row = 4 * q4 + e, col = u * 32 + sb * 16 + c16;
+                h2_store16(reinterpret_cast<unsigned short*>(nxt + row * ROWD + (col >> 3) * 8 + ((col & 7) >> 1)) + (col & 1), hv);
+            }
+        lds_barrier();                                      // h_t complete in `nxt`; every wave is past its reads of `cur`
+    };
+    for (int step = 0; step < T; step += 2) {
+        do_step(step, xa);
+        if (step + 1 < T) do_step(step + 1, xb);
+    }
+    y_copy(lds + (T & 1) * (RT * ROWD), dir ? 0 : T - 1);
+    if (hn != nullptr) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                hn[(size_t)(b0 + 4 * q4 + e) * ldhn + dir * H + u * 32 + sb * 16 + c16] = hreg[sb][e];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // GRU decoder layer with its input projection fused (polish model): the layer input x_t is the previous
 // layer's output, already an h2 tensor [B*T, KX] with KX = 2H, so the step contracts [h_{t-1} | x_t]
@@ -1511,6 +1684,42 @@ hipError_t launch_gru_rec_h2(int H, const float* Xp, int ldx, const uint8_t* X, 
                            (const uint8_t*)nullptr, 0, (int64_t)0, (const float*)nullptr, static_cast<const uint32_t*>(Wp),
                            bhn, h0, ldh0, hn, ldhn, static_cast<uint32_t*>(Y), ldy, B, T);
     }
+    return hipGetLastError();
+}
+
+
+// W_hh [3H, H] per direction -> B fragments of v_mfma_f32_16x16x32_f16 in h2 form for gru_small_h2_kernel:
+// [dir][unit tile u H/32][gate 3][sub 2][k step H/32][hi, lo][64 lanes][8 halves]; lane l holds
+// W[g H + 32 u + 16 sub + (l & 15)][32 s + 8 (l >> 4) + e].
+void pack_gru_small_weights_h2(const float* const whh[2], int H, uint32_t* out) {
+    const int NTt = H / 32, KS = H / 32;
+    _Float16* o = reinterpret_cast<_Float16*>(out);
+    for (int d = 0; d < 2; ++d)
+        for (int u = 0; u < NTt; ++u)
+            for (int g = 0; g < 3; ++g)
+                for (int sb = 0; sb < 2; ++sb)
+                    for (int s = 0; s < KS; ++s)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                const int n = g * H + 32 * u + 16 * sb + (l & 15), k = 32 * s + 8 * (l >> 4) + e;
+                                const float v = whh[d][(size_t)n * H + k];
+                                const _Float16 hi = (_Float16)v;
+                                const size_t base = ((((((size_t)d * NTt + u) * 3 + g) * 2 + sb) * KS + s) * 2) * 512 + (size_t)l * 8 + e;
+                                o[base] = hi;
+                                o[base + 512] = (_Float16)(v - (float)hi);
+                            }
+}
+
+size_t gru_small_weights_h2_words(int H) { return (size_t)2 * (H / 32) * 3 * 2 * (H / 32) * 2 * 256; }
+
+// Rows of the workspace a call of B chunks must have behind Xp / Y / h0 / hn (whole 32-row projection tiles)
+hipError_t launch_gru_small_h2(int H, const float* Xp, int ldx, const void* Wp, const float* bhn, const float* h0, int ldh0,
+                               float* hn, int ldhn, void* Y, int ldy, int B, int T, hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    if (H != 128 || (ldy & 7) || (ldx & 31) || !Xp || !Wp || !Y) return hipErrorInvalidValue;
+    const int grid = 2 * ((B + 15) / 16);
+    hipLaunchKernelGGL((gru_small_h2_kernel<128>), dim3(grid), dim3(256), 0, stream, Xp, ldx, static_cast<const uint32_t*>(Wp), bhn, h0,
+                       ldh0, hn, ldhn, static_cast<uint32_t*>(Y), ldy, B, T);
     return hipGetLastError();
 }
 

@@ -12,6 +12,25 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["small-call", "big-call"])
+def schedule(request):
+    """Every test of this file under both schedules (read at model creation).  "small-call", the default: calls of at most
+    1024 chunks run their projections as GEMMs over all steps and their step loops as 16-row workgroups with the recurrent
+    weights in registers (gru_small_h2_kernel; api.hip `small_max`).  "big-call" (PA_POLISH_SMALL_MAX=0): the 128-row step
+    loops with the projections and dense1 fused, which calls of more than 1024 chunks take, for the small calls these tests
+    make."""
+    saved = os.environ.get("PA_POLISH_SMALL_MAX")
+    if request.param == "big-call":
+        os.environ["PA_POLISH_SMALL_MAX"] = "0"
+    else:
+        os.environ.pop("PA_POLISH_SMALL_MAX", None)
+    yield request.param
+    if saved is None:
+        os.environ.pop("PA_POLISH_SMALL_MAX", None)
+    else:
+        os.environ["PA_POLISH_SMALL_MAX"] = saved
+
+
 def _model(sd, **kw):
     from pepper_amd.polish.models.simple_model import TransducerGRU
     m = TransducerGRU(1, 10, kw.pop("gru_layers", 1), 128, 5, bidirectional=True, **kw)
@@ -113,12 +132,14 @@ def test_polish_many_chunks_properties():
     assert np.abs(a0[pick] - inter["acc"]).max() < TOL
 
 
-def test_fused_head_equals_the_separate_head():
-    """The default predict path contracts dense1 inside the last decoder layer's step loop (gru_rec_h2_kernel<.., DENSE>
+def test_fused_head_equals_the_separate_head(schedule):
+    """(Big-call schedule: the small-call one has no fused head.)  The default predict path contracts dense1 inside the last decoder layer's step loop (gru_rec_h2_kernel<.., DENSE>
     + polish_combine_kernel; no layer output in HBM); PA_FUSE_HEAD=0 keeps that layer's output and runs dense1 +
     softmax + overlap-add as their own kernel.  Same three-term split products in a different summation order: the
     accumulators agree far inside the bar, ragged tails and more than one 128-row batch tile included."""
     from pepper_amd import _lib
+    if schedule != "big-call":
+        pytest.skip("the fused head belongs to the big-call schedule")
     sd = synthetic.polish_state_dict(seed=33, gain=2.0)
     imgs = synthetic.polish_chunks(261, seed=77)
     imgs[5, 300:] = 0
@@ -173,3 +194,30 @@ def test_host_blocks_taken_together_equal_the_blocks_one_by_one():
     with pytest.raises(ValueError):
         a.predict_chunk_parts_into([(img[:2], want_l[:3], want_p[:2])])
     a.close()
+
+
+@pytest.mark.parametrize("n", [16, 17, 1000, 1024, 1025])
+def test_small_call_schedule_equals_the_big_call_schedule(n, schedule):
+    """The two schedules on the same chunks: 16-row tiles that end on / behind / before a tile edge, the largest small call and
+    the first big one.  Same arithmetic in a different order (projection GEMM + K = 128 loop vs the fused K = 384 loop): the
+    accumulated softmax agrees far inside the 1e-4 bar, labels agree except at ties."""
+    if schedule != "small-call":
+        pytest.skip("one comparison, made under the default environment")
+    sd = synthetic.polish_state_dict(seed=36, gain=2.0)
+    img = torch.from_numpy(synthetic.polish_chunks(n, seed=300 + n)).cuda()
+    a = _model(sd)
+    la, pa_, acc_a = a.predict_chunks(img, return_acc=True)
+    a.close()
+    os.environ["PA_POLISH_SMALL_MAX"] = "0"
+    try:
+        b = _model(sd)
+    finally:
+        os.environ.pop("PA_POLISH_SMALL_MAX", None)
+    lb, pb, acc_b = b.predict_chunks(img, return_acc=True)
+    b.close()
+    acc_a, acc_b = acc_a.cpu().numpy(), acc_b.cpu().numpy()
+    assert np.abs(acc_a - acc_b).max() < 2e-5
+    top2 = np.sort(acc_b, axis=2)[:, :, -2:]
+    tie = (top2[:, :, 1] - top2[:, :, 0]) < 1e-4
+    assert ((la.cpu().numpy() == lb.cpu().numpy()) | tie).all()
+    assert (pa_.cpu().numpy() == pb.cpu().numpy()).mean() > 0.999
