@@ -56,13 +56,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", choices=["variant", "polish", "ns-literal", "realign", "encoder"], default="variant",
+    ap.add_argument("--model", choices=["variant", "polish", "ns-literal", "realign", "encoder", "polish-encoder"], default="variant",
                     help="variant = BASELINE configs[1] shapes (the headline); polish = configs[4]; ns-literal = the polish "
                          "stack at the north_star's literal synthetic shape (100-step windows x 100 features; not a "
                          "reference shape, reported separately); realign = the polish read re-aligner (SSW) on "
                          "regions of 1500 simulated reads, reads/s and DP cell updates/s; encoder = the variant pileup -> "
                          "summary encoder (the other half of north_star's hot path) on a batch of 64 E-syn regions of 100 kb "
-                         "at 60x, aligned bases/s, HBM roofline, the reference's own C++ as the CPU baseline")
+                         "at 60x, aligned bases/s, HBM roofline, the reference's own C++ as the CPU baseline; polish-encoder = the "
+                         "polish SummaryGenerator on 256 regions of 1000 + 2 x 100 positions at 60x, likewise")
     ap.add_argument("--workload", choices=["v-syn", "wg-syn"], default="v-syn",
                     help="variant model only.  v-syn (default): every rank streams its own pool, weak scaling.  wg-syn: a FIXED job of "
                          "24 chromosome-sized shards of V-syn windows dealt over the ranks (strong scaling; SURVEY.md 8(d)), once with "
@@ -608,6 +609,118 @@ def encoder_bench(args):
         dist.destroy_process_group()
 
 
+def polish_encoder_cpu_all_cores(seconds):
+    """One single-thread worker per usable CPU, each looping the reference's SummaryGenerator on its own region (the reference's
+    image generation is one such worker per core: pepper/modules/python/ImageGenerationUI.py)."""
+    import subprocess
+    physical, logical = host_cores()
+    procs = worker_count()
+    cmd = [sys.executable, os.path.join(REPO, "oracle", "encoder_cpu.py"), "--polish", "--seconds", str(seconds), "--region-size", "1000"]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS="1")
+    ps = [subprocess.Popen(cmd + ["--seed", str(k)], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(procs)]
+    outs = []
+    for p in ps:
+        try:
+            out, _ = p.communicate(timeout=6 * seconds + 120)
+            outs.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:
+            p.kill()
+    if not outs:
+        return None
+    span = max(o["seconds"] for o in outs)
+    return dict({"value": sum(o["bases"] for o in outs) / span, "unit": "aligned bases/s", "cores": len(outs),
+                 "host_physical_cores": physical, "host_logical_cpus": logical, "kind": outs[0]["kind"],
+                 "sample": f"{len(outs)} concurrent single-thread workers, one per CPU this container may use, each looping the reference's "
+                           f"polish SummaryGenerator (oracle/_ref) on its own region for {seconds:.0f} s; "
+                           f"{sum(o['regions'] for o in outs)} regions in {span:.1f} s"}, **cpu_note())
+
+
+POLISH_ENCODER_BYTES_PER_BASE = 1     # the polish walk reads the bases only (no quality test: summary_generator.cpp:47-121)
+POLISH_ENCODER_BYTES_PER_ROW = 26     # 10 pixel bytes + the (position, insert index) pair of int64 per output row
+
+
+def polish_encoder_bench(args):
+    """`--model polish-encoder`: one step = pa_polish_encoder_run_staged over a batch of regions resident in HBM (record kernels,
+    longest-insert scan, polish_tile_kernel, insert rows); the host-buffer form (stage + run + result copy) beside it."""
+    from pepper_amd.polish.PEPPER import StagedSummaries, SummaryGenerator
+    n_regions = args.per_gpu or 256
+    # (read_len / depth chosen so that the reads, clipped to the 1.2 kb window, cover it ~60x)
+    regions = synthetic.encoder_regions(n_regions, seed=synthetic.ESYN_SEED + 5000, region=1000, read_len=2000, depth=140)
+    gens = [SummaryGenerator(ref, "contig_1", rs, re_) for ref, _, rs, re_ in regions]
+    flats = [flat for _, flat, _, _ in regions]
+    spans = [(rs, re_) for _, _, rs, re_ in regions]
+    batch = StagedSummaries(gens, flats, spans)
+    for _ in range(max(1, args.warmup)):
+        rows = batch.run()
+    stats = batch.stats()
+    torch.cuda.synchronize(0)
+    times = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run()
+        times.append(batch.timing())
+    torch.cuda.synchronize(0)
+    dt = time.perf_counter() - t0
+    avg = {k: float(np.mean([t[k] for t in times])) for k in times[0]}
+    value = args.steps * stats["bases"] / dt
+    alg_bytes = POLISH_ENCODER_BYTES_PER_BASE * stats["bases"] + POLISH_ENCODER_BYTES_PER_ROW * stats["rows"]
+    achieved = alg_bytes / (avg["tile_ms"] * 1e-3) / 1e9
+    # host buffers in, host arrays out, one call (what AlignmentSummarizer.create_summaries makes per batch of regions)
+    reps = max(3, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        b2 = StagedSummaries(gens, flats, spans)
+        b2.run()
+        image, pos = b2.results()
+    t_one = (time.perf_counter() - t0) / reps
+    line = {
+        "metric": "polish summary encoder, aligned bases/s (pileup -> summary rows)",
+        "value": value, "unit": "aligned bases/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32 counts (uint8 bases in, uint8 pixels + int64 (position, index) rows out)", "data": "synthetic",
+        "config": {"workload": f"P-enc-syn: {n_regions} regions of 1000 + 2 x 100 positions at ~60x (reads clipped to the region as the BAM "
+                               "reader clips them), an insert or a deletion every ~50 bases, 4 % substitutions "
+                               "(pepper_amd.synthetic.encoder_region(region=1000)); one step = pa_polish_encoder_run_staged, pileups "
+                               "resident in HBM, rows left on the device",
+                   "regions_per_step": n_regions, "aligned_bases_per_step": stats["bases"], "rows_per_step": stats["rows"],
+                   "reads": stats["reads"], "cigar_operations": stats["cigar_ops"], "tiles": stats["tiles"],
+                   "regions_per_s": args.steps * n_regions / dt, "timed_seconds": dt},
+        "roofline": {"bound": "hbm", "kernel": "polish_tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                     "avg_launch_ms": avg["tile_ms"],
+                     "note": "algorithmic bytes = 1 B per aligned base (the polish walk tests no quality) + 26 B per output row (10 "
+                             "pixels + the (position, index) int64 pair); 512-position tiles of 1.2 kb regions: 768 workgroups for 256 "
+                             "regions, the launch is latency- not bandwidth-bound at this size"},
+        "kernels_ms": avg,
+        "host_buffers_one_call": {"value": stats["bases"] / t_one, "unit": "aligned bases/s", "ms": t_one * 1e3,
+                                  "regions_per_s": n_regions / t_one,
+                                  "note": "pa_polish_encoder_stage_batch + run + result copy per batch: gather into page-locked blocks, one "
+                                          "H2D per array, kernels, one wait, D2H of the rows"},
+    }
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(REPO, "oracle"))
+        from oracle import encoder_cpu
+        one = encoder_cpu.time_polish_regions(regions[:16], args.cpu_seconds)
+        single = {"value": one["bases"] / one["seconds"], "unit": "aligned bases/s", "cores": 1, "kind": one["kind"],
+                  "sample": f"{one['regions']} of the same regions through the reference's SummaryGenerator "
+                            f"({'oracle/_ref build of summary_generator.cpp' if one['kind'] == 'reference' else 'oracle restatement'}), "
+                            f"one thread, {one['seconds']:.1f} s"}
+        multi = polish_encoder_cpu_all_cores(args.cpu_seconds)
+        line["cpu_baseline"] = multi or single
+        line["cpu_baseline_one_core"] = single
+        line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        line["vs_baseline"] = line["speedup_vs_cpu_baseline"]
+        # parity spot check of the timed configuration: region 0's rows against the CPU encoder
+        kind, run = encoder_cpu.load_polish()
+        p0 = encoder_cpu.region_structs(regions[0])[0]
+        img = np.zeros((int(rows[0]) + 16, 10), np.uint8)
+        posn = np.zeros((int(rows[0]) + 16, 2), np.int64)
+        n0 = run(p0, regions[0][2], regions[0][3], img.ctypes.data, posn.ctypes.data, len(img))
+        line["rows_region0"] = {"device": int(rows[0]), "cpu": n0,
+                                "identical": bool(n0 == int(rows[0]) and np.array_equal(img[:n0], image[:n0]) and np.array_equal(posn[:n0], pos[:n0]))}
+    print(json.dumps(line))
+
+
 def make_images_leg(scratch):
     """generate_images (pepper_variant make_images / call_variant's first step) on a synthetic 64 Mb BAM at 60x written by
     tools/synth_bam: BAM + FASTA -> candidate image HDF5 files, Mb of reference per second with the stage times of the workers
@@ -698,6 +811,12 @@ def secondary_block(args):
                                                    "issue") if k in d["roofline"]},
         "host_buffers_one_call": d["host_buffers_one_call"]["value"], "packed_host_fed": d.get("packed_host_fed"),
         "runs": d["_runs"], "seconds": d["_seconds"]}
+    d = median_of([sys.executable, me, "--model", "polish-encoder", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"], 300)
+    out["polish_encoder"] = d if "error" in d else {
+        "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "regions_per_step": d["config"]["regions_per_step"],
+        "aligned_bases_per_step": d["config"]["aligned_bases_per_step"], "rows_per_step": d["config"]["rows_per_step"],
+        "roofline": {k: d["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")},
+        "host_buffers_one_call": d["host_buffers_one_call"]["value"], "runs": d["_runs"], "seconds": d["_seconds"]}
     scratch = None
     try:
         st = os.statvfs("/dev/shm")
@@ -813,6 +932,10 @@ def main():
         return
     if args.model == "encoder":
         encoder_bench(args)
+        return
+    if args.model == "polish-encoder":
+        torch.cuda.set_device(0)
+        polish_encoder_bench(args)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)

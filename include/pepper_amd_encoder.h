@@ -150,6 +150,13 @@ int pa_polish_encoder_generate_summary(pa_encoder* e, const pa_pileup* pileup, i
  * the results are the rows of region 0, then region 1, ...  The whole per-read walk runs on the device. */
 int pa_polish_encoder_generate_summary_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups,
                                              const int64_t* start_pos, const int64_t* end_pos, int64_t* n_rows);
+/* The two halves of the call above (stage = validate + upload, run = the kernels; may be repeated: what bench.py times with the
+ * pileups resident in HBM), and the sizes of the staged batch / last run: [0] read bases, [1] output rows, [2] reads, [3] CIGAR
+ * operations, [4] tiles, [5] regions. */
+int pa_polish_encoder_stage_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const int64_t* start_pos,
+                                  const int64_t* end_pos);
+int pa_polish_encoder_run_staged(pa_encoder* e, int64_t* n_rows);
+int pa_polish_encoder_batch_stats(pa_encoder* e, int64_t* out, int32_t n);
 /* HOST pointers: image uint8 [n_rows, 10], positions int64 [n_rows, 2] (of all regions of the last call); either may be NULL. */
 int pa_polish_encoder_get_results(pa_encoder* e, uint8_t* image, int64_t* positions);
 /* HIP-event times of the last call in ms: [0] record / scan kernels, [1] polish_tile_kernel, [2] polish_insert_rows_kernel. */

@@ -101,15 +101,51 @@ def time_regions(regions, seconds):
     return {"bases": bases, "regions": done, "seconds": time.perf_counter() - t0, "kind": kind}
 
 
+def load_polish():
+    """-> (kind, run(pileup, start_pos, end_pos) -> rows): the reference's own SummaryGenerator (oracle/_ref/
+    libref_polish_encoder.so, built from pepper/modules/src/pileup_summary/summary_generator.cpp as it lies) or, where that
+    build did not travel, the restatement."""
+    ref = os.path.join(HERE, "_ref", "libref_polish_encoder.so")
+    if os.path.exists(ref):
+        fn, kind = ctypes.CDLL(ref).ref_polish_generate_summary, "reference"
+    else:
+        fn, kind = ctypes.CDLL(os.path.join(HERE, "libpileup_oracle.so")).oracle_polish_generate_summary, "port"
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.POINTER(Pileup), ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+
+    def run(p, start_pos, end_pos, image=None, positions=None, cap=0):
+        return int(fn(ctypes.byref(p), start_pos, end_pos, image, positions, cap))
+    return kind, run
+
+
+def time_polish_regions(regions, seconds):
+    """Loop the CPU polish encoder over `regions` ((reference, flat, start, end) of pepper_amd.synthetic.encoder_region) until
+    `seconds` have passed: one call per region with room for its rows, as AlignmentSummarizer.py:340-347 makes it."""
+    kind, run = load_polish()
+    structs = [region_structs(r)[0] for r in regions]
+    img = np.zeros((1 << 20, 10), np.uint8)
+    pos = np.zeros((1 << 20, 2), np.int64)
+    bases = done = rows = 0
+    t0 = time.perf_counter()
+    while done < 1 or time.perf_counter() - t0 < seconds:
+        k = done % len(structs)
+        rows = run(structs[k], regions[k][2], regions[k][3], img.ctypes.data, pos.ctypes.data, len(img))
+        bases += int(regions[k][1]["seq_offset"][-1])
+        done += 1
+    return {"bases": bases, "regions": done, "seconds": time.perf_counter() - t0, "kind": kind, "rows_last": rows}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--polish", action="store_true", help="the polish SummaryGenerator on --region-size + 2 x 100 positions")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--region-size", type=int, default=100_000)
     args = ap.parse_args()
     from pepper_amd import synthetic
-    region = synthetic.encoder_region(synthetic.ESYN_SEED + args.seed, region=args.region_size)
-    print(json.dumps(time_regions([region], args.seconds)))
+    kw = dict(read_len=2000, depth=140) if args.polish else {}      # (bench.py polish_encoder_bench: ~60x over the 1.2 kb window)
+    region = synthetic.encoder_region(synthetic.ESYN_SEED + args.seed, region=args.region_size, **kw)
+    print(json.dumps((time_polish_regions if args.polish else time_regions)([region], args.seconds)))
 
 
 if __name__ == "__main__":

@@ -79,6 +79,9 @@ SYMBOLS = [
     ("pa_polish_encoder_generate_summary", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int64,
                                                           ctypes.POINTER(c_int64)]),
     ("pa_polish_encoder_generate_summary_batch", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("pa_polish_encoder_stage_batch", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    ("pa_polish_encoder_run_staged", ctypes.c_int, [c_void_p, c_void_p]),
+    ("pa_polish_encoder_batch_stats", ctypes.c_int, [c_void_p, c_void_p, c_int32]),
     ("pa_polish_encoder_get_results", ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     ("pa_polish_encoder_last_timing", ctypes.c_int, [c_void_p, c_void_p, c_int32]),
     # include/pepper_amd_realign.h

@@ -899,7 +899,7 @@ struct pa_polish_model : ModelBase {
     bool fuse_dec = true;        // PA_FUSE_DEC=0: decoder projection as a GEMM + Xp instead of inside the step loop
     bool y_h2 = false;           // format of the last polish_window output
     bool fuse_head = true;       // PA_FUSE_HEAD=0: last decoder layer writes y, dense1 + softmax + overlap-add as their own kernel
-    int small_max = 1024;        // calls of at most this many chunks take the small-call schedule (PA_POLISH_SMALL_MAX; 0: never)
+    int small_max = 4096;        // calls of at most this many chunks take the small-call schedule (PA_POLISH_SMALL_MAX; 0: never)
     std::vector<RecLayer> enc, dec;
     Linear dense;
     DevBuf *dense_h2 = nullptr;  // dense1 as h2 fragments of the 16x16x32 tile (rnn_h2.hip pack_dense_head_h2)

@@ -859,24 +859,6 @@ struct RegHost {
 
 namespace {
 
-// page-locked host buffer that only grows (results of a run: one asynchronous copy each, no page faults per run)
-struct HBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    bool ensure(size_t need) {
-        if (need <= bytes) return true;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        bytes = 0;
-        const size_t grow = need + need / 2 + 4096;
-        if (hipHostMalloc(&p, grow, hipHostMallocDefault) != hipSuccess) return false;
-        bytes = grow;
-        return true;
-    }
-    template <typename T> T* as() const { return static_cast<T*>(p); }
-    ~HBuf() { if (p) (void)hipHostFree(p); }
-};
-
 // CPUs this process may really use: the hardware's, cut by a cgroup quota (cgroup v2 cpu.max; the project's GPU boxes show 256
 // logical CPUs and grant 16 -- 64 busy threads would each run at a quarter of the speed)
 int usable_cpus() {

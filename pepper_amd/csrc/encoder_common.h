@@ -92,6 +92,25 @@ struct DBuf {
     ~DBuf() { if (p) (void)hipFree(p); }
 };
 
+// page-locked host buffer that only grows (results of a run: one asynchronous copy each, no page faults per run)
+struct HBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    bool ensure(size_t need) {
+        if (need <= bytes) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        const size_t grow = need + need / 2 + 4096;
+        if (hipHostMalloc(&p, grow, hipHostMallocDefault) != hipSuccess) return false;
+        bytes = grow;
+        return true;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+    ~HBuf() { if (p) (void)hipHostFree(p); }
+};
+
+
 // one read of a batch: where its bases, qualities and operations start in the concatenated device arrays
 struct ReadRec {
     int64_t s0;        // first base in seq / qual

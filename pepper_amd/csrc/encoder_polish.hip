@@ -8,7 +8,9 @@
 //                                 tile record counts
 //   polish_rows_kernel            one workgroup per region: exclusive scan of the longest inserts = where every position's
 //                                 insert rows sit among the region's insert slots and among its output rows; region totals
-//   (host: one small copy of the totals -> output sizes)
+//   polish_bases_kernel           prefix sums of the totals over the regions: every region's first insert slot / output row --
+//                                 the totals never visit the host in the middle of a call; outputs are sized by a bound that
+//                                 grows with what a handle has seen, and a run that outgrows it is repeated with room
 //   polish_segment_kernel<true>   the (read, tile) records into their tiles' slices
 //   polish_tile_kernel            one workgroup owns 512 positions: 10 feature counts + coverage privatised in LDS, the tile's
 //                                 records walked one row per lane; insert bases go to the (sparse) insert-slot counts with global
@@ -34,7 +36,7 @@ constexpr int TP = 512, NW = 8, NT = 64 * NW, UNR = 8;   // rows per tile = thre
 constexpr int NF = 10, K_COV = 10, NCNT = 11;            // features, coverage slot, counters per row
 constexpr int PROW = 16;                                 // int32 per insert slot in HBM (10 used)
 static_assert(NT == TP && 64 * UNR == TP, "one thread per row");
-enum { PC_ERR = 0, PC_N = 4 };
+enum { PC_ERR = 0, PC_INS = 1, PC_OUT = 2, PC_BUG = 3, PC_N = 4 };   // PC_BUG: an index left its buffer (never, unless a kernel is wrong)     // error code | insert rows of the batch | output rows of the batch
 
 struct PRegRec {
     int64_t row_base;            // first row of the region in longest / ins_base / coverage
@@ -168,11 +170,44 @@ __global__ __launch_bounds__(1024) void polish_rows_kernel(const PRegRec* __rest
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// one workgroup: slot_base[r] = insert rows of the regions before r, out_base[r] = out_pos_base[r] + slot_base[r]; the batch's
+// totals for the host
+__global__ __launch_bounds__(1024) void polish_bases_kernel(const int* __restrict__ totals, const int64_t* __restrict__ out_pos_base,
+                                                            int n_regions, int64_t* __restrict__ slot_base, int64_t* __restrict__ out_base,
+                                                            int* __restrict__ counters) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_regions; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_regions ? totals[i] : 0;
+        const int inc = wave_inclusive_sum(v);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int before = carry;
+        for (int k = 0; k < w; ++k) before += wsum[k];
+        if (i < n_regions) {
+            slot_base[i] = before + inc - v;
+            out_base[i] = out_pos_base[i] + before + inc - v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counters[PC_INS] = carry;
+        counters[PC_OUT] = (int)(out_pos_base[n_regions] + carry);
+    }
+}
+
 struct PTileArgs {
     const ReadRec* reads; const PRegRec* regions; const int32_t* tile_region; const int32_t* cigar_op; const int32_t* cigar_len;
     const char* seq; const TileRec* recs; const int* tile_off; int rec_cap;
     const int* longest; const int* ins_base; const int64_t* slot_base; const int64_t* out_base;
     int* ins_counts; int* coverage; uint8_t* pixels; int* counters;
+    int64_t ins_cap, out_cap;        // insert slots / output rows the buffers hold: a batch that needs more is run again with room
 };
 
 __global__ __launch_bounds__(NT, 4) void polish_tile_kernel(PTileArgs a) {
@@ -263,8 +298,10 @@ __global__ __launch_bounds__(NT, 4) void polish_tile_kernel(PTileArgs a) {
             // -- one operation per lane: insert bases into the insert slots (:83-97), the coverage credit of gaps (:105-110)
             const int anchor = first - 1;
             if (live && op == OP_I && anchor >= tile_lo && anchor <= tile_hi && anchor >= out_lo && anchor <= out_hi && rfirst + len <= slen) {
-                int* slot = a.ins_counts + (slot0 + a.ins_base[reg.row_base + anchor]) * PROW;
-                for (int q = 0; q < len; ++q) atomicAdd(&slot[(int64_t)q * PROW + polish_feature(seq0[(unsigned)(rfirst + q)], rev)], 1);
+                const int64_t s_at = slot0 + a.ins_base[reg.row_base + anchor];
+                int* slot = a.ins_counts + s_at * PROW;
+                if (s_at + len <= a.ins_cap)
+                    for (int q = 0; q < len; ++q) atomicAdd(&slot[(int64_t)q * PROW + polish_feature(seq0[(unsigned)(rfirst + q)], rev)], 1);
             }
             if (live && radv > 0 && (op == OP_D || op == OP_N || op == OP_P) && first >= tile_lo && first <= tile_hi && first <= L - 1) {
                 const int lo_r = first, hi_r = first + len - 1 < L - 1 ? first + len - 1 : L - 1;     // (first >= tile_lo >= 0)
@@ -296,9 +333,10 @@ __global__ __launch_bounds__(NT, 4) void polish_tile_kernel(PTileArgs a) {
     if (idx < L) {
         const int cov = cnt[K_COV * TP + tid];
         a.coverage[reg.row_base + idx] = cov;
-        if (idx >= reg.out_lo && idx <= reg.out_hi) {
+        const int64_t o_at = a.out_base[region] + (idx - reg.out_lo) + a.ins_base[reg.row_base + idx];
+        if (idx >= reg.out_lo && idx <= reg.out_hi && o_at < a.out_cap) {
             const double c = cov > 1 ? (double)cov : 1.0;
-            uint8_t* out = a.pixels + (a.out_base[region] + (idx - reg.out_lo) + a.ins_base[reg.row_base + idx]) * NF;
+            uint8_t* out = a.pixels + o_at * NF;
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 const double v = ((double)cnt[j * TP + tid] / c) * 254.0;
@@ -314,7 +352,8 @@ __global__ __launch_bounds__(256) void polish_insert_rows_kernel(const PRegRec* 
                                                                  const int* __restrict__ ins_base, const int64_t* __restrict__ slot_base,
                                                                  const int64_t* __restrict__ out_base, const int* __restrict__ ins_counts,
                                                                  const int* __restrict__ coverage, uint8_t* __restrict__ pixels,
-                                                                 int64_t* __restrict__ positions) {
+                                                                 int64_t* __restrict__ positions, int64_t out_cap, int64_t ins_cap,
+                                                                 int64_t total_rows, int* __restrict__ counters) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= total_positions) return;
     int lo = 0, hi = n_regions - 1;                         // region of output position g: out_pos_base is ascending
@@ -334,6 +373,11 @@ __global__ __launch_bounds__(256) void polish_insert_rows_kernel(const PRegRec* 
         before_ins = last >= 0 && last >= reg.out_lo ? ins_base[reg.row_base + last] + longest[reg.row_base + last] : 0;
     }
     const int64_t row = out_base[lo] + (idx - reg.out_lo) + before_ins;
+    if (row < 0 || n_ins < 0 || before_ins < 0 || (in && reg.row_base + idx >= total_rows)) {
+        atomicMax(&counters[PC_BUG], 1 + (row < 0 ? 1 : 0) + (n_ins < 0 ? 2 : 0) + (before_ins < 0 ? 4 : 0));
+        return;
+    }
+    if (row + n_ins >= out_cap || slot_base[lo] + before_ins + n_ins > ins_cap) return;      // (the run is repeated with room)
     positions[2 * row] = reg.pos0 + idx;
     positions[2 * row + 1] = 0;
     if (n_ins > 0) {
@@ -364,10 +408,14 @@ struct PRegHost {
 struct pa_polish_batch {
     std::vector<PRegHost> regs;
     std::vector<int64_t> region_rows;        // output rows per region of the last run
-    int64_t total_bases = 0, total_ops = 0, total_reads = 0, total_rows = 0, total_out = 0;
+    int64_t total_bases = 0, total_ops = 0, total_reads = 0, total_rows = 0, total_out = 0, total_positions = 0;
     int n_tiles = 0, rec_cap = 0;
-    DBuf d_seq, d_cig_op, d_cig_len, d_reads, d_regions, d_tile_region, d_zero, d_tile_off, d_sorted, d_ins_base, d_totals,
+    int64_t ins_cap = 0;                     // insert slots the output buffers hold (grows with what the handle has seen)
+    bool staged = false;
+    DBuf d_seq, d_cig_op, d_cig_len, d_meta, d_zero, d_tile_off, d_sorted, d_ins_base, d_totals,
         d_bases, d_ins_counts, d_coverage, d_pixels, d_positions;
+    HBuf h_seq, h_cig_op, h_cig_len, h_meta, h_back;
+    size_t o_reads = 0, o_regions = 0, o_tile = 0, o_pos = 0;     // the tables inside d_meta
     double ms[4] = {0, 0, 0, 0};
 };
 
@@ -375,20 +423,23 @@ void pa_polish_batch_free(pa_polish_batch* b) { delete b; }
 
 namespace {
 
-int polish_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const int64_t* start_pos, const int64_t* end_pos,
-                 int64_t* n_rows) {
+// validate + upload: the reads of all regions gathered into page-locked blocks (one copy to the device per array instead of
+// three pageable ones per region), the tables in one block; nothing here waits for the device
+int polish_stage(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const int64_t* start_pos, const int64_t* end_pos) {
     if (!e || n_regions < 0 || (n_regions > 0 && (!pileups || !start_pos || !end_pos))) return pa::set_error(PA_ERR_INVALID, "null argument");
     ENC_HIP(hipSetDevice(e->device));
     if (!e->polish) e->polish = new pa_polish_batch();
     pa_polish_batch& b = *e->polish;
     hipStream_t st = e->stream;
+    b.staged = false;
     b.regs.assign((size_t)n_regions, PRegHost());
     b.region_rows.assign((size_t)n_regions, 0);
-    b.total_bases = b.total_ops = b.total_reads = b.total_rows = b.total_out = 0;
+    b.total_bases = b.total_ops = b.total_reads = b.total_rows = b.total_out = b.total_positions = 0;
     b.n_tiles = 0;
-    if (n_regions == 0) return PA_OK;
-    std::vector<PRegRec> regrecs((size_t)n_regions);
-    std::vector<int64_t> out_pos_base((size_t)n_regions + 1, 0);
+    if (n_regions == 0) {
+        b.staged = true;
+        return PA_OK;
+    }
     for (int r = 0; r < n_regions; ++r) {
         const pa_pileup& p = pileups[r];
         if (p.region_end < p.region_start || p.region_end - p.region_start > (int64_t)1 << 28 || end_pos[r] < start_pos[r] ||
@@ -405,32 +456,49 @@ int polish_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, con
         rh.seq_base = b.total_bases;
         rh.op_base = b.total_ops;
         rh.read_base = b.total_reads;
-        PRegRec& g = regrecs[(size_t)r];
-        g.row_base = rh.row_base;
-        g.seq_base = rh.seq_base;
-        g.pos0 = p.region_start;
-        g.L = rh.L;
-        g.tile0 = b.n_tiles;
-        g.n_tiles = (rh.L + TP - 1) / TP;
-        g.stop_row = (int32_t)(end_pos[r] - p.region_start);
-        g.out_lo = (int32_t)(start_pos[r] - p.region_start);
-        g.out_hi = (int32_t)(end_pos[r] - p.region_start);
-        g.pad[0] = g.pad[1] = 0;
-        out_pos_base[(size_t)r + 1] = out_pos_base[(size_t)r] + (end_pos[r] - start_pos[r] + 1);
         b.total_rows += rh.L;
         b.total_reads += p.n_reads;
         b.total_bases += p.n_reads > 0 ? p.seq_offset[p.n_reads] : 0;
         b.total_ops += p.n_reads > 0 ? p.cigar_offset[p.n_reads] : 0;
-        b.n_tiles += g.n_tiles;
-        if (b.total_rows > ((int64_t)1 << 30) || b.total_ops > 0x7ffffff0 || b.total_reads > 0x3ffffff0 || out_pos_base[(size_t)r + 1] > ((int64_t)1 << 31))
+        b.n_tiles += (rh.L + TP - 1) / TP;
+        b.total_positions += end_pos[r] - start_pos[r] + 1;
+        if (b.total_rows > ((int64_t)1 << 30) || b.total_ops > 0x7ffffff0 || b.total_reads > 0x3ffffff0 || b.total_positions > ((int64_t)1 << 30))
             return pa::set_error(PA_ERR_INVALID, "batch too large");
     }
-    std::vector<ReadRec> reads((size_t)b.total_reads);
-    std::vector<int32_t> tile_region((size_t)b.n_tiles);
+    // one block: [ReadRec x reads][PRegRec x regions][tile_region x tiles][out_pos_base x (regions + 1)]
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    b.o_reads = 0;
+    b.o_regions = up16((size_t)b.total_reads * sizeof(ReadRec));
+    b.o_tile = up16(b.o_regions + (size_t)n_regions * sizeof(PRegRec));
+    b.o_pos = up16(b.o_tile + (size_t)b.n_tiles * 4);
+    const size_t meta_bytes = up16(b.o_pos + ((size_t)n_regions + 1) * 8);
+    if (!b.h_meta.ensure(meta_bytes) || !b.h_seq.ensure((size_t)b.total_bases + 64) || !b.h_cig_op.ensure((size_t)b.total_ops * 4 + 64) ||
+        !b.h_cig_len.ensure((size_t)b.total_ops * 4 + 64))
+        return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed");
+    char* hm = b.h_meta.as<char>();
+    ReadRec* reads = reinterpret_cast<ReadRec*>(hm + b.o_reads);
+    PRegRec* regrecs = reinterpret_cast<PRegRec*>(hm + b.o_regions);
+    int32_t* tile_region = reinterpret_cast<int32_t*>(hm + b.o_tile);
+    int64_t* out_pos_base = reinterpret_cast<int64_t*>(hm + b.o_pos);
+    int tile0 = 0;
+    out_pos_base[0] = 0;
     for (int r = 0; r < n_regions; ++r) {
         const PRegHost& rh = b.regs[(size_t)r];
         const pa_pileup& p = rh.p;
-        for (int t = 0; t < regrecs[(size_t)r].n_tiles; ++t) tile_region[(size_t)(regrecs[(size_t)r].tile0 + t)] = r;
+        PRegRec& g = regrecs[r];
+        g.row_base = rh.row_base;
+        g.seq_base = rh.seq_base;
+        g.pos0 = p.region_start;
+        g.L = rh.L;
+        g.tile0 = tile0;
+        g.n_tiles = (rh.L + TP - 1) / TP;
+        g.stop_row = (int32_t)(rh.end_pos - p.region_start);
+        g.out_lo = (int32_t)(rh.start_pos - p.region_start);
+        g.out_hi = (int32_t)(rh.end_pos - p.region_start);
+        g.pad[0] = g.pad[1] = 0;
+        out_pos_base[r + 1] = out_pos_base[r] + (rh.end_pos - rh.start_pos + 1);
+        for (int t = 0; t < g.n_tiles; ++t) tile_region[tile0 + t] = r;
+        tile0 += g.n_tiles;
         for (int32_t k = 0; k < p.n_reads; ++k) {
             ReadRec& rd = reads[(size_t)(rh.read_base + k)];
             const int64_t slen = p.seq_offset[k + 1] - p.seq_offset[k], ncig = p.cigar_offset[k + 1] - p.cigar_offset[k];
@@ -444,27 +512,41 @@ int polish_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, con
             rd.region = r;
             rd.flags = (p.read_reverse[k] ? READ_REV : 0) | ((p.read_mapq[k] > 0 && row0 > -(1 << 30)) ? READ_MAPQ_OK : 0);
         }
+        const int64_t nb = p.n_reads > 0 ? p.seq_offset[p.n_reads] : 0, no = p.n_reads > 0 ? p.cigar_offset[p.n_reads] : 0;
+        if (nb > 0) std::memcpy(b.h_seq.as<char>() + rh.seq_base, p.seq, (size_t)nb);
+        if (no > 0) {
+            std::memcpy(b.h_cig_op.as<int32_t>() + rh.op_base, p.cigar_op, (size_t)no * 4);
+            std::memcpy(b.h_cig_len.as<int32_t>() + rh.op_base, p.cigar_len, (size_t)no * 4);
+        }
     }
     ENC_ALLOC(b.d_seq, (size_t)b.total_bases + 64);
     ENC_ALLOC(b.d_cig_op, (size_t)b.total_ops * 4 + 1024);
     ENC_ALLOC(b.d_cig_len, (size_t)b.total_ops * 4 + 1024);
-    ENC_ALLOC(b.d_reads, reads.size() * sizeof(ReadRec) + 64);
-    ENC_ALLOC(b.d_regions, regrecs.size() * sizeof(PRegRec) + 64);
-    ENC_ALLOC(b.d_tile_region, tile_region.size() * 4 + 64);
-    for (int r = 0; r < n_regions; ++r) {
-        const PRegHost& rh = b.regs[(size_t)r];
-        const pa_pileup& p = rh.p;
-        const int64_t nb = p.n_reads > 0 ? p.seq_offset[p.n_reads] : 0, no = p.n_reads > 0 ? p.cigar_offset[p.n_reads] : 0;
-        if (nb > 0) ENC_HIP(hipMemcpyAsync(b.d_seq.as<char>() + rh.seq_base, p.seq, (size_t)nb, hipMemcpyHostToDevice, st));
-        if (no > 0) {
-            ENC_HIP(hipMemcpyAsync(b.d_cig_op.as<int32_t>() + rh.op_base, p.cigar_op, (size_t)no * 4, hipMemcpyHostToDevice, st));
-            ENC_HIP(hipMemcpyAsync(b.d_cig_len.as<int32_t>() + rh.op_base, p.cigar_len, (size_t)no * 4, hipMemcpyHostToDevice, st));
-        }
+    ENC_ALLOC(b.d_meta, meta_bytes);
+    if (b.total_bases > 0) ENC_HIP(hipMemcpyAsync(b.d_seq.p, b.h_seq.p, (size_t)b.total_bases, hipMemcpyHostToDevice, st));
+    if (b.total_ops > 0) {
+        ENC_HIP(hipMemcpyAsync(b.d_cig_op.p, b.h_cig_op.p, (size_t)b.total_ops * 4, hipMemcpyHostToDevice, st));
+        ENC_HIP(hipMemcpyAsync(b.d_cig_len.p, b.h_cig_len.p, (size_t)b.total_ops * 4, hipMemcpyHostToDevice, st));
     }
-    if (!reads.empty()) ENC_HIP(hipMemcpyAsync(b.d_reads.p, reads.data(), reads.size() * sizeof(ReadRec), hipMemcpyHostToDevice, st));
-    ENC_HIP(hipMemcpyAsync(b.d_regions.p, regrecs.data(), regrecs.size() * sizeof(PRegRec), hipMemcpyHostToDevice, st));
-    if (!tile_region.empty()) ENC_HIP(hipMemcpyAsync(b.d_tile_region.p, tile_region.data(), tile_region.size() * 4, hipMemcpyHostToDevice, st));
+    ENC_HIP(hipMemcpyAsync(b.d_meta.p, hm, meta_bytes, hipMemcpyHostToDevice, st));
+    b.staged = true;
+    return PA_OK;
+}
 
+// the kernels of the staged batch; one wait, at the end (sizes, errors, rows per region)
+int polish_run(pa_encoder* e, int64_t* n_rows) {
+    if (!e || !e->polish || !e->polish->staged) return pa::set_error(PA_ERR_INVALID, "no staged batch");
+    ENC_HIP(hipSetDevice(e->device));
+    pa_polish_batch& b = *e->polish;
+    hipStream_t st = e->stream;
+    const int n_regions = (int)b.regs.size();
+    b.total_out = 0;
+    if (n_regions == 0) return PA_OK;
+    const char* dm = b.d_meta.as<char>();
+    const ReadRec* d_reads = reinterpret_cast<const ReadRec*>(dm + b.o_reads);
+    const PRegRec* d_regions = reinterpret_cast<const PRegRec*>(dm + b.o_regions);
+    const int32_t* d_tile_region = reinterpret_cast<const int32_t*>(dm + b.o_tile);
+    const int64_t* d_out_pos_base = reinterpret_cast<const int64_t*>(dm + b.o_pos);
     // zeroed per run: counters | longest [rows] | tile_count | tile_fill
     const size_t n_zero = (size_t)PC_N + (size_t)b.total_rows + 2 * (size_t)b.n_tiles;
     ENC_ALLOC(b.d_zero, n_zero * 4);
@@ -472,109 +554,105 @@ int polish_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, con
     ENC_ALLOC(b.d_ins_base, (size_t)b.total_rows * 4 + 64);
     ENC_ALLOC(b.d_totals, (size_t)n_regions * 4);
     ENC_ALLOC(b.d_coverage, (size_t)b.total_rows * 4 + 64);
-    ENC_ALLOC(b.d_bases, (size_t)(3 * (size_t)n_regions + 1) * 8);
-    if (b.rec_cap == 0) b.rec_cap = 1024;
-    b.rec_cap = std::max<int>(b.rec_cap, (int)std::min<int64_t>(0x7ffffff0, b.total_bases / TP + 2 * b.total_reads + 1024));
+    ENC_ALLOC(b.d_bases, (size_t)(2 * (size_t)n_regions + 1) * 8);
+    if (!b.h_back.ensure(((size_t)PC_N + 1 + (size_t)n_regions) * 4)) return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed");
+    b.rec_cap = std::max<int>(std::max(b.rec_cap, 1024), (int)std::min<int64_t>(0x7ffffff0, b.total_bases / TP + 2 * b.total_reads + 1024));
+    // insert rows: one per position and base of the longest insert anchored there -- known on the device only.  Room for two
+    // per position to begin with (nanopore pileups at 60x: ~1.3), and for what the handle has needed before
+    b.ins_cap = std::max<int64_t>(b.ins_cap, 2 * b.total_rows + 4096);
     int* counters = b.d_zero.as<int>();
     int* longest = counters + PC_N;
     int* tile_count = longest + b.total_rows;
     int* tile_fill = tile_count + b.n_tiles;
-    std::vector<int> totals((size_t)n_regions);
-    std::vector<int64_t> bases(3 * (size_t)n_regions + 1);       // slot_base | out_base | out_pos_base
-    int host_counters[PC_N] = {0, 0, 0, 0};
+    int* back = b.h_back.as<int>();            // [PC_N] counters | records | totals per region
     for (int attempt = 0;; ++attempt) {
+        const int64_t out_cap = b.total_positions + b.ins_cap;
         ENC_ALLOC(b.d_sorted, (size_t)b.rec_cap * sizeof(TileRec));
+        ENC_ALLOC(b.d_ins_counts, (size_t)(b.ins_cap + 1) * PROW * 4);
+        ENC_ALLOC(b.d_pixels, (size_t)out_cap * NF + 64);
+        ENC_ALLOC(b.d_positions, (size_t)out_cap * 16 + 64);
         ENC_HIP(hipMemsetAsync(b.d_zero.p, 0, n_zero * 4, st));
+        ENC_HIP(hipMemsetAsync(b.d_ins_counts.p, 0, (size_t)(b.ins_cap + 1) * PROW * 4, st));
+        ENC_HIP(hipMemsetAsync(b.d_pixels.p, 0, (size_t)out_cap * NF + 64, st));     // (rows of positions outside the region stay zero)
         ENC_HIP(hipEventRecord(e->ev[0], st));
         const dim3 seg_grid((unsigned)((b.total_reads + 3) / 4));
         if (b.total_reads > 0)
-            hipLaunchKernelGGL(polish_segment_kernel<false>, seg_grid, dim3(256), 0, st, b.d_reads.as<ReadRec>(), (int)b.total_reads,
-                               b.d_regions.as<PRegRec>(), b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), longest, tile_count,
-                               (const int*)nullptr, (int*)nullptr, (TileRec*)nullptr, 0, counters);
-        hipLaunchKernelGGL(polish_rows_kernel, dim3((unsigned)n_regions), dim3(1024), 0, st, b.d_regions.as<PRegRec>(), longest,
-                           b.d_ins_base.as<int>(), b.d_totals.as<int>());
+            hipLaunchKernelGGL(polish_segment_kernel<false>, seg_grid, dim3(256), 0, st, d_reads, (int)b.total_reads, d_regions,
+                               b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), longest, tile_count, (const int*)nullptr, (int*)nullptr,
+                               (TileRec*)nullptr, 0, counters);
+        hipLaunchKernelGGL(polish_rows_kernel, dim3((unsigned)n_regions), dim3(1024), 0, st, d_regions, longest, b.d_ins_base.as<int>(),
+                           b.d_totals.as<int>());
+        int64_t* slot_base = b.d_bases.as<int64_t>();
+        int64_t* out_base = slot_base + n_regions;
+        hipLaunchKernelGGL(polish_bases_kernel, dim3(1), dim3(1024), 0, st, b.d_totals.as<int>(), d_out_pos_base, n_regions, slot_base, out_base,
+                           counters);
         if (b.n_tiles > 0)
             hipLaunchKernelGGL(polish_tile_offsets_kernel, dim3(1), dim3(1024), 0, st, tile_count, b.n_tiles, b.d_tile_off.as<int>());
         if (b.total_reads > 0)
-            hipLaunchKernelGGL(polish_segment_kernel<true>, seg_grid, dim3(256), 0, st, b.d_reads.as<ReadRec>(), (int)b.total_reads,
-                               b.d_regions.as<PRegRec>(), b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), longest, tile_count,
-                               b.d_tile_off.as<int>(), tile_fill, b.d_sorted.as<TileRec>(), b.rec_cap, counters);
+            hipLaunchKernelGGL(polish_segment_kernel<true>, seg_grid, dim3(256), 0, st, d_reads, (int)b.total_reads, d_regions,
+                               b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), longest, tile_count, b.d_tile_off.as<int>(), tile_fill,
+                               b.d_sorted.as<TileRec>(), b.rec_cap, counters);
+        ENC_HIP(hipEventRecord(e->ev[1], st));
+        if (b.n_tiles > 0) {
+            PTileArgs ta;
+            ta.reads = d_reads;
+            ta.regions = d_regions;
+            ta.tile_region = d_tile_region;
+            ta.cigar_op = b.d_cig_op.as<int32_t>();
+            ta.cigar_len = b.d_cig_len.as<int32_t>();
+            ta.seq = b.d_seq.as<char>();
+            ta.recs = b.d_sorted.as<TileRec>();
+            ta.tile_off = b.d_tile_off.as<int>();
+            ta.rec_cap = b.rec_cap;
+            ta.longest = longest;
+            ta.ins_base = b.d_ins_base.as<int>();
+            ta.slot_base = slot_base;
+            ta.out_base = out_base;
+            ta.ins_counts = b.d_ins_counts.as<int>();
+            ta.coverage = b.d_coverage.as<int>();
+            ta.pixels = b.d_pixels.as<uint8_t>();
+            ta.counters = counters;
+            ta.ins_cap = b.ins_cap;
+            ta.out_cap = out_cap;
+            hipLaunchKernelGGL(polish_tile_kernel, dim3((unsigned)b.n_tiles), dim3(NT), 0, st, ta);
+        }
+        ENC_HIP(hipEventRecord(e->ev[2], st));
+        hipLaunchKernelGGL(polish_insert_rows_kernel, dim3((unsigned)((b.total_positions + 255) / 256)), dim3(256), 0, st, d_regions,
+                           d_out_pos_base, n_regions, b.total_positions, longest, b.d_ins_base.as<int>(), slot_base, out_base,
+                           b.d_ins_counts.as<int>(), b.d_coverage.as<int>(), b.d_pixels.as<uint8_t>(), b.d_positions.as<int64_t>(), out_cap,
+                           b.ins_cap, b.total_rows, counters);
+        ENC_HIP(hipEventRecord(e->ev[3], st));
         ENC_HIP(hipGetLastError());
-        int n_recs = 0;
-        ENC_HIP(hipMemcpyAsync(totals.data(), b.d_totals.p, (size_t)n_regions * 4, hipMemcpyDeviceToHost, st));
-        ENC_HIP(hipMemcpyAsync(host_counters, counters, sizeof(host_counters), hipMemcpyDeviceToHost, st));
-        if (b.n_tiles > 0) ENC_HIP(hipMemcpyAsync(&n_recs, b.d_tile_off.as<int>() + b.n_tiles, 4, hipMemcpyDeviceToHost, st));
+        ENC_HIP(hipMemcpyAsync(back, counters, PC_N * 4, hipMemcpyDeviceToHost, st));
+        back[PC_N] = 0;
+        if (b.n_tiles > 0) ENC_HIP(hipMemcpyAsync(back + PC_N, b.d_tile_off.as<int>() + b.n_tiles, 4, hipMemcpyDeviceToHost, st));
+        ENC_HIP(hipMemcpyAsync(back + PC_N + 1, b.d_totals.p, (size_t)n_regions * 4, hipMemcpyDeviceToHost, st));
         ENC_HIP(hipStreamSynchronize(st));
-        if (n_recs > b.rec_cap) {
-            if (attempt >= 2) return pa::set_error(PA_ERR_HIP, "encoder record buffers could not be sized");
-            b.rec_cap = n_recs + 1024;
+        const int n_recs = back[PC_N];
+        if (n_recs > b.rec_cap || back[PC_INS] > b.ins_cap) {
+            if (attempt >= 2) return pa::set_error(PA_ERR_HIP, "encoder buffers could not be sized");
+            b.rec_cap = std::max(b.rec_cap, n_recs + 1024);
+            b.ins_cap = std::max<int64_t>(b.ins_cap, (int64_t)back[PC_INS] + back[PC_INS] / 4 + 1024);
             continue;
         }
         break;
     }
-    auto report = [&](int code) {
+    if (back[PC_BUG] != 0) return pa::set_error(PA_ERR_HIP, "polish encoder: an index left its buffer (code " + std::to_string(back[PC_BUG]) + ")");
+    if (back[PC_ERR] > 0) {
+        const int code = back[PC_ERR];
         const int64_t g = code / 2 - 1;
         size_t r = 0;
         while (r + 1 < b.regs.size() && b.regs[r + 1].read_base <= g) ++r;
         return pa::set_error(PA_ERR_INVALID, std::string(code & 1 ? "insert" : "CIGAR") + " of read " + std::to_string(g - b.regs[r].read_base) +
                                                  (n_regions > 1 ? " of region " + std::to_string(r) : "") + " runs past its sequence");
-    };
-    if (host_counters[PC_ERR] > 0) return report(host_counters[PC_ERR]);
-    int64_t total_ins = 0;
-    b.total_out = 0;
+    }
     for (int r = 0; r < n_regions; ++r) {
-        bases[(size_t)r] = total_ins;                                            // first insert slot of the region
-        bases[(size_t)n_regions + (size_t)r] = b.total_out;                      // first output row of the region
-        bases[2 * (size_t)n_regions + (size_t)r] = out_pos_base[(size_t)r];
-        b.region_rows[(size_t)r] = (b.regs[(size_t)r].end_pos - b.regs[(size_t)r].start_pos + 1) + totals[(size_t)r];
-        total_ins += totals[(size_t)r];
+        b.region_rows[(size_t)r] = (b.regs[(size_t)r].end_pos - b.regs[(size_t)r].start_pos + 1) + back[PC_N + 1 + r];
         b.total_out += b.region_rows[(size_t)r];
         if (n_rows) n_rows[r] = b.region_rows[(size_t)r];
     }
-    bases[3 * (size_t)n_regions] = out_pos_base[(size_t)n_regions];
-    ENC_ALLOC(b.d_ins_counts, (size_t)(total_ins + 1) * PROW * 4);
-    ENC_ALLOC(b.d_pixels, (size_t)b.total_out * NF + 64);
-    ENC_ALLOC(b.d_positions, (size_t)b.total_out * 16 + 64);
-    ENC_HIP(hipMemcpyAsync(b.d_bases.p, bases.data(), bases.size() * 8, hipMemcpyHostToDevice, st));
-    ENC_HIP(hipMemsetAsync(b.d_ins_counts.p, 0, (size_t)(total_ins + 1) * PROW * 4, st));
-    ENC_HIP(hipMemsetAsync(b.d_pixels.p, 0, (size_t)b.total_out * NF + 64, st));
-    const int64_t* slot_base = b.d_bases.as<int64_t>();
-    const int64_t* out_base = slot_base + n_regions;
-    const int64_t* d_out_pos_base = out_base + n_regions;
-    ENC_HIP(hipEventRecord(e->ev[1], st));
-    if (b.n_tiles > 0) {
-        PTileArgs ta;
-        ta.reads = b.d_reads.as<ReadRec>();
-        ta.regions = b.d_regions.as<PRegRec>();
-        ta.tile_region = b.d_tile_region.as<int32_t>();
-        ta.cigar_op = b.d_cig_op.as<int32_t>();
-        ta.cigar_len = b.d_cig_len.as<int32_t>();
-        ta.seq = b.d_seq.as<char>();
-        ta.recs = b.d_sorted.as<TileRec>();
-        ta.tile_off = b.d_tile_off.as<int>();
-        ta.rec_cap = b.rec_cap;
-        ta.longest = longest;
-        ta.ins_base = b.d_ins_base.as<int>();
-        ta.slot_base = slot_base;
-        ta.out_base = out_base;
-        ta.ins_counts = b.d_ins_counts.as<int>();
-        ta.coverage = b.d_coverage.as<int>();
-        ta.pixels = b.d_pixels.as<uint8_t>();
-        ta.counters = counters;
-        hipLaunchKernelGGL(polish_tile_kernel, dim3((unsigned)b.n_tiles), dim3(NT), 0, st, ta);
-    }
-    ENC_HIP(hipEventRecord(e->ev[2], st));
-    const int64_t total_positions = out_pos_base[(size_t)n_regions];
-    hipLaunchKernelGGL(polish_insert_rows_kernel, dim3((unsigned)((total_positions + 255) / 256)), dim3(256), 0, st, b.d_regions.as<PRegRec>(),
-                       d_out_pos_base, n_regions, total_positions, longest, b.d_ins_base.as<int>(), slot_base, out_base,
-                       b.d_ins_counts.as<int>(), b.d_coverage.as<int>(), b.d_pixels.as<uint8_t>(), b.d_positions.as<int64_t>());
-    ENC_HIP(hipEventRecord(e->ev[3], st));
-    ENC_HIP(hipGetLastError());
-    ENC_HIP(hipMemcpyAsync(host_counters, counters, sizeof(host_counters), hipMemcpyDeviceToHost, st));
-    ENC_HIP(hipStreamSynchronize(st));
-    if (host_counters[PC_ERR] > 0) return report(host_counters[PC_ERR]);
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); b.ms[0] = ms;     // segment passes + scans (+ the copy of the totals)
+    (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); b.ms[0] = ms;     // segment passes + scans
     (void)hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); b.ms[1] = ms;     // polish_tile_kernel
     (void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); b.ms[2] = ms;     // polish_insert_rows_kernel
     return PA_OK;
@@ -586,12 +664,30 @@ extern "C" {
 
 int pa_polish_encoder_generate_summary_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const int64_t* start_pos,
                                              const int64_t* end_pos, int64_t* n_rows) {
-    return polish_batch(e, n_regions, pileups, start_pos, end_pos, n_rows);
+    const int rc = polish_stage(e, n_regions, pileups, start_pos, end_pos);
+    return rc != PA_OK ? rc : polish_run(e, n_rows);
+}
+
+int pa_polish_encoder_stage_batch(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, const int64_t* start_pos,
+                                  const int64_t* end_pos) {
+    return polish_stage(e, n_regions, pileups, start_pos, end_pos);
+}
+
+int pa_polish_encoder_run_staged(pa_encoder* e, int64_t* n_rows) { return polish_run(e, n_rows); }
+
+int pa_polish_encoder_batch_stats(pa_encoder* e, int64_t* out, int32_t n) {
+    if (!e || !out || n < 0) return pa::set_error(PA_ERR_INVALID, "null argument");
+    const pa_polish_batch* b = e->polish;
+    const int64_t v[6] = {b ? b->total_bases : 0, b ? b->total_out : 0, b ? b->total_reads : 0, b ? b->total_ops : 0,
+                          b ? (int64_t)b->n_tiles : 0, b ? (int64_t)b->regs.size() : 0};
+    for (int i = 0; i < n; ++i) out[i] = i < 6 ? v[i] : 0;
+    return PA_OK;
 }
 
 int pa_polish_encoder_generate_summary(pa_encoder* e, const pa_pileup* p, int64_t start_pos, int64_t end_pos, int64_t* n_rows) {
     if (!e || !p || !n_rows) return pa::set_error(PA_ERR_INVALID, "null argument");
-    return polish_batch(e, 1, p, &start_pos, &end_pos, n_rows);
+    const int rc = polish_stage(e, 1, p, &start_pos, &end_pos);
+    return rc != PA_OK ? rc : polish_run(e, n_rows);
 }
 
 int pa_polish_encoder_get_results(pa_encoder* e, uint8_t* image, int64_t* positions) {

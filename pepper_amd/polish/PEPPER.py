@@ -96,6 +96,50 @@ def generate_summaries(generators, reads_list, spans):
         at += k
 
 
+class StagedSummaries(object):
+    """A batch of polish regions uploaded once (pa_polish_encoder_stage_batch) and encoded any number of times
+    (pa_polish_encoder_run_staged): what bench.py --model polish-encoder times with the pileups resident in HBM."""
+
+    def __init__(self, generators, flats, spans):
+        self.lib, self.enc = _encoder(generators[0].device if generators else 0)
+        self.n = len(generators)
+        self._keep = [g.reference_sequence.encode("latin-1") if isinstance(g.reference_sequence, str) else bytes(g.reference_sequence)
+                      for g in generators]
+        self.flats = flats
+        self.piles = (_Pileup * max(1, self.n))(*[
+            _Pileup(g.ref_start, g.ref_end, ref, len(ref), flat["n_reads"], flat["read_pos"].ctypes.data,
+                    flat["read_reverse"].ctypes.data, flat["read_mapq"].ctypes.data, flat["seq_offset"].ctypes.data,
+                    flat["seq"].ctypes.data, flat["qual"].ctypes.data, flat["cigar_offset"].ctypes.data,
+                    flat["cigar_op"].ctypes.data, flat["cigar_len"].ctypes.data)
+            for g, ref, flat in zip(generators, self._keep, flats)])
+        self.starts = np.array([int(s) for s, _ in spans], np.int64)
+        self.ends = np.array([int(e) for _, e in spans], np.int64)
+        self.rows = np.zeros(max(1, self.n), np.int64)
+        _lib.check(self.lib.pa_polish_encoder_stage_batch(self.enc, self.n, ctypes.cast(self.piles, ctypes.c_void_p),
+                                                          self.starts.ctypes.data, self.ends.ctypes.data))
+
+    def run(self):
+        _lib.check(self.lib.pa_polish_encoder_run_staged(self.enc, self.rows.ctypes.data))
+        return self.rows[:self.n]
+
+    def timing(self):
+        ms = np.zeros(4, np.float64)
+        _lib.check(self.lib.pa_polish_encoder_last_timing(self.enc, ms.ctypes.data, 4))
+        return dict(records_ms=ms[0], tile_ms=ms[1], insert_rows_ms=ms[2])
+
+    def stats(self):
+        v = np.zeros(6, np.int64)
+        _lib.check(self.lib.pa_polish_encoder_batch_stats(self.enc, v.ctypes.data, 6))
+        return dict(bases=int(v[0]), rows=int(v[1]), reads=int(v[2]), cigar_ops=int(v[3]), tiles=int(v[4]), regions=int(v[5]))
+
+    def results(self):
+        total = int(self.rows[:self.n].sum())
+        image = np.zeros((total, 10), np.uint8)
+        pos = np.zeros((total, 2), np.int64)
+        _lib.check(self.lib.pa_polish_encoder_get_results(self.enc, image.ctypes.data, pos.ctypes.data))
+        return image, pos
+
+
 _realigners = {}
 
 

@@ -360,3 +360,42 @@ def test_polish_chunker():
     s.image, s.genomic_pos = s.image[:1000], s.genomic_pos[:1000]
     images, _, _, ids = AlignmentSummarizer.chunk_images(s, 1000, 50)
     assert ids == [0]
+
+
+def test_polish_encoder_against_the_reference_build_and_the_goldens(golden_dir):
+    """The HIP polish encoder compared DIRECTLY with the reference's own SummaryGenerator (oracle/_ref/libref_polish_encoder.so,
+    built from summary_generator.cpp as it lies; it travels with the snapshot) on the six pileup families of
+    tests/test_encoder_oracle.py, and with the committed golden vectors written by that build (tests/golden/
+    encoder_polish_*.npz) -- one hop, not two; single calls and all six as one batch (the device-side sizing of the outputs:
+    the "deep" and "long_inserts" families need several times the rows of the others)."""
+    from test_encoder_oracle import POLISH_CASES, _polish_case
+    from pepper_amd.polish.PEPPER import SummaryGenerator, generate_summaries
+    ref_lib = pu.load_reference_polish_encoder()
+
+    def flat_of(pile):
+        return dict(read_pos=pile.read_pos, read_reverse=pile.read_reverse, read_mapq=pile.read_mapq, seq_offset=pile.seq_offset,
+                    seq=pile.seq, qual=pile.qual, cigar_offset=pile.cigar_offset, cigar_op=pile.cigar_op, cigar_len=pile.cigar_len,
+                    n_reads=pile.n_reads)
+    gens, reads_list, spans, wants = [], [], [], []
+    for name in sorted(POLISH_CASES):
+        pile, start, end = _polish_case(**POLISH_CASES[name])
+        want = pu.run_polish_reference(ref_lib, pile, start, end) if ref_lib is not None else None
+        golden = os.path.join(golden_dir, f"encoder_polish_{name}.npz")
+        if os.path.exists(golden):
+            g = np.load(golden, allow_pickle=False)
+            if want is not None:
+                assert np.array_equal(want[0], g["image"]) and np.array_equal(want[1], g["positions"])
+            want = (g["image"], g["positions"])
+        if want is None:
+            continue
+        gen = SummaryGenerator(pile.reference, "contig_1", start, end)
+        gen.generate_summary(flat_of(pile), start, end)
+        assert np.array_equal(gen.positions_array, want[1]) and np.array_equal(gen.image, want[0]), name
+        gens.append(SummaryGenerator(pile.reference, "contig_1", start, end))
+        reads_list.append(flat_of(pile))
+        spans.append((start, end))
+        wants.append(want)
+    assert len(wants) >= 3                         # the goldens at least; all six where oracle/_ref travelled
+    generate_summaries(gens, reads_list, spans)
+    for g, (img, pos) in zip(gens, wants):
+        assert np.array_equal(g.positions_array, pos) and np.array_equal(g.image, img)

@@ -15,9 +15,9 @@ TOL = 1e-4
 @pytest.fixture(autouse=True, params=["small-call", "big-call"])
 def schedule(request):
     """Every test of this file under both schedules (read at model creation).  "small-call", the default: calls of at most
-    1024 chunks run their projections as GEMMs over all steps and their step loops as 16-row workgroups with the recurrent
+    4096 chunks run their projections as GEMMs over all steps and their step loops as 16-row workgroups with the recurrent
     weights in registers (gru_small_h2_kernel; api.hip `small_max`).  "big-call" (PA_POLISH_SMALL_MAX=0): the 128-row step
-    loops with the projections and dense1 fused, which calls of more than 1024 chunks take, for the small calls these tests
+    loops with the projections and dense1 fused, which calls of more than 4096 chunks take, for the small calls these tests
     make."""
     saved = os.environ.get("PA_POLISH_SMALL_MAX")
     if request.param == "big-call":
@@ -196,7 +196,7 @@ def test_host_blocks_taken_together_equal_the_blocks_one_by_one():
     a.close()
 
 
-@pytest.mark.parametrize("n", [16, 17, 1000, 1024, 1025])
+@pytest.mark.parametrize("n", [16, 17, 1000, 4096, 4097])
 def test_small_call_schedule_equals_the_big_call_schedule(n, schedule):
     """The two schedules on the same chunks: 16-row tiles that end on / behind / before a tile edge, the largest small call and
     the first big one.  Same arithmetic in a different order (projection GEMM + K = 128 loop vs the fused K = 384 loop): the
