@@ -647,6 +647,9 @@ static int variant_forward_chunk(pa_variant_model* m, int a_kind, const void* im
     bool unit_split = allow_split && m->unit_split && n <= m->unit_split_max && H == 256 && m->split_rec && !fuse_dec && m->mlp_w32 != nullptr &&
                       m->mlp_w != nullptr && C <= 8;
     for (const RecLayer& r : m->rec) unit_split = unit_split && r.w_hh_h2 != nullptr && r.prescaled;
+    // the members of a group wait for each other: every workgroup of the launch must be on the device at once (a CPX
+    // partition of 32 CUs, or a device that reports fewer CUs, never holds 256 of them -- no split there, no spin, no re-run)
+    if (unit_split && pa::lstm_split_grid((int)n) > pa::lstm_split_resident_workgroups(n <= 512 ? 1 : 2)) unit_split = false;
     if (unit_split && m->split_holdoff > 0) {
         --m->split_holdoff;
         unit_split = false;

@@ -67,6 +67,9 @@ hipError_t launch_lstm_rec_h2(int H, const float* Xp, int ldx, const int8_t* X, 
 // of workgroups did not meet (not resident together): the caller runs the layer again another way.  sabotage: tests only.
 size_t lstm_split_exchange_bytes(int B);
 size_t lstm_split_counter_bytes(int B);
+// workgroups of a split launch for B windows, and how many of them the current device holds at once (the launch needs all)
+int lstm_split_grid(int B);
+int lstm_split_resident_workgroups(int ntw);
 hipError_t launch_lstm_rec_h2_split(int H, const float* Xp, int ldx, const void* Wp, void* Y, int ldy, int B, int T, void* exch,
                                     void* counters, int* failed, hipStream_t stream, int sabotage = 0);
 

@@ -106,9 +106,13 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(KX ? bias + dir * 4 * H + 32 * u : Xp + (size_t)(b0 >> 5) * T * (ldx >> 5) * 1024), 0,
         0x7fffffff, 0x00020000);
-    // fragment (g, s, hi/lo) of this wave lives at byte (((g*NT + u) * KS + s) * 2 + hl) * 1024 + lane * 16
+    // fragment (g, s, hi/lo) of this wave lives at byte (((g*NT + u) * KS + s) * 2 + hl) * 1024 + lane * 16 of the direction's
+    // block.  The wave's own term (u) is part of the descriptor's base, so that every fragment's scalar offset is a
+    // compile-time constant the compiler re-materialises with one s_mov where it needs it: with `u` inside the offset the
+    // 8 KS sums were loop-invariant VALUES, kept live across the time loop and spilled -- 315 scalar registers parked in vector
+    // lanes and 314 v_readlane_b32 per time step in the K = 768 form.
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(Wp + (size_t)dir * (4 * NT) * KS * 512), 0, 0x7fffffff, 0x00020000);
+        const_cast<uint32_t*>(Wp + ((size_t)dir * (4 * NT) + u) * KS * 512), 0, 0x7fffffff, 0x00020000);
     const unsigned xoff = KX ? li * 4u : lane * 16u;
     const unsigned woff = lane * 16u;
 
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(H / 32 * 64, 1) void lstm_rec_h2_kernel(const float
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl)
                 fr.b[g][hl] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(
-                                                         wrs, woff, (unsigned)(((g * NT + u) * KS + s) * 2 + hl) * 1024u, 0));
+                                                         wrs, woff, (unsigned)((g * NT * KS + s) * 2 + hl) * 1024u, 0));
     };
     auto load_a = [&](int s, Frag& fr, int) {
         if (XG && s >= KSH) {
@@ -589,9 +593,13 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_h2_split_kernel(const float* 
             if (!(sabotage && group == 0 && member == K - 1))
                 __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned want = (unsigned)K * (unsigned)(step + 1);
+            // The first meeting waits for members that may not have been dispatched yet (other queues hold the CUs): ~12 ms.
+            // Members that have met once are all resident and stay so (a queue is preempted as a whole, and then nobody's
+            // count advances), so a later meeting that takes more than ~3 ms -- a thousand exchanges' worth -- is a lost group.
+            const int bound = step == 0 ? (1 << 13) : (1 << 11);
             int spins = 0;
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                if (++spins > (1 << 14)) {                // ~25 ms: the group is not resident together; the host runs the call again
+                if (++spins > bound) {                    // the group is not resident together; the host runs the call again
                     *flag = 1u;
                     __hip_atomic_store(failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
@@ -1570,6 +1578,30 @@ hipError_t launch_lstm_dec_h2(int H, const void* Xh, int ldxh, const float* bias
 // four of 64 units above: at most 256 workgroups either way.
 size_t lstm_split_exchange_bytes(int B) { return (size_t)2 * (((B + 31) / 32 + 3) / 4 * 4) * 2 * 32 * 256 * 4; }
 size_t lstm_split_counter_bytes(int B) { return (size_t)2 * (((B + 31) / 32 + 3) / 4 * 4) * 128; }
+
+// Workgroups of the split step loop the current device holds at once: the members of a group spin on each other, so a launch
+// must fit the chip as a whole (what one CU takes of the kernel x the CUs the device reports -- 256 on a whole MI355X, 32 on
+// one of its CPX partitions).  ntw as in the kernel (1: eight members, 2: four).
+int lstm_split_resident_workgroups(int ntw) {
+    static int cached[2] = {-1, -1};
+    int& c = cached[ntw == 2 ? 1 : 0];
+    if (c >= 0) return c;
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    const size_t lds = (size_t)32 * (256 * 4 + 16) + (size_t)4 * ntw * 16 * 64 * 4 + 16;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e == hipSuccess)
+        e = ntw == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_rec_h2_split_kernel<256, 2>, 256, lds)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_rec_h2_split_kernel<256, 1>, 256, lds);
+    c = e == hipSuccess ? per_cu * prop.multiProcessorCount : 0;
+    return c;
+}
+
+int lstm_split_grid(int B) {
+    const int tiles4 = ((B + 31) / 32 + 3) / 4 * 4;
+    return 8 * (8 / (B <= 512 ? 1 : 2)) * (tiles4 / 4);
+}
 
 hipError_t launch_lstm_rec_h2_split(int H, const float* Xp, int ldx, const void* Wp, void* Y, int ldy, int B, int T, void* exch,
                                     void* counters, int* failed, hipStream_t stream, int sabotage) {
