@@ -54,6 +54,7 @@ constexpr int UNR = 8;              // rows per lane in flight in the row phase:
 constexpr int VCAP = 512;           // indel votes a tile keeps in LDS (nanopore: ~600 per 512 rows x 60 reads; more spill to the global list)
 constexpr int XQ = 128;             // per-wave queue of the bases that are not clean matches (processed 64 at a time)
 static_assert(NT == TP && 64 * UNR == TP, "one thread per row, UNR rows per lane");
+static_assert(VCAP == NT, "the flush takes one buffered vote per thread");
 // counter slots: 0 coverage, 1 snp_count, 2 insert_count, 3 delete_count, 4 = column 4 (forward strand coverage),
 // 5..11 = columns 8..14 (forward A C G T I D *), 12 = column 15 (reverse strand coverage), 13..19 = columns 19..25,
 // 20..23 / 24..27 = forward / reverse tallies of mismatching A C G T (the SNP allele map of :409-425)
@@ -321,6 +322,7 @@ struct TileArgs {
     const TileRec* recs; const int* tile_off; int rec_cap;
     int* mat; uint8_t* pass; SiteRec* sites; Vote* votes; Vote* votes_out; int vote_cap; int4* ovf; int ovf_cap; int* counters;
     int* region_counts;
+    int debug;        // PA_TILE_DEBUG (profiling only, tools/tile_ablation.sh): parts of the kernel switched off
 };
 
 __device__ __forceinline__ uint64_t allele_prefix(const char* bytes, uint32_t off, uint32_t len) {
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
     __shared__ int anch[TP];                       // runs whose last base sits here and anchors an insert / a deletion: forward | reverse << 16
     __shared__ unsigned xq[NW][XQ];                // queued bases: row | letter << 9 | quality ok << 17 | anchoring << 18 | reverse << 19
     __shared__ int wtot[2][NW];
+    __shared__ int s_out[4];                       // passing sites / votes of the tile; their first slots in the region's lists
     uint8_t* pass_s = reinterpret_cast<uint8_t*>(&xq[0][0]);   // verdicts of the per-position pass: the queues are empty by then (two
                                                                // workgroups per CU need the tile's LDS below 80 KB)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -386,9 +389,10 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
         refok_s[tid] = is_acgt(ref_s[tid]) ? 1 : 0;
     }
     if (tid == 0) vcount = 0;
+    if (tid < 4) s_out[tid] = 0;
     __syncthreads();
 
-    const int rec0 = a.tile_off[tile], rec1 = a.tile_off[tile + 1] < a.rec_cap ? a.tile_off[tile + 1] : a.rec_cap;
+    const int rec0 = a.tile_off[tile], rec1 = (a.debug & 1) ? rec0 : (a.tile_off[tile + 1] < a.rec_cap ? a.tile_off[tile + 1] : a.rec_cap);
     int4* ent_s = s_ent[w];
     unsigned* mask_s = s_mask[w];
     // the wave's queue of bases that need the full rules: `qn` entries (wave-uniform), drained 64 at a time
@@ -469,13 +473,19 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
             const bool live = valid && first <= live_max;
             const int anchor = first - 1;                                   // row an insert / a deletion is credited to
             const bool mine = live && anchor >= tile_lo && anchor <= tile_hi;   // (anchor <= L - 2 follows from first <= L - 1)
-            const bool is_ins = mine && op == OP_I && rfirst - 1 >= 0;
+            const bool is_ins = mine && op == OP_I && rfirst - 1 >= 0 && !(a.debug & 8);
             const int n_ins = len + 1;
             const int span_lo = pos > tile_lo ? pos : tile_lo;
             int span_hi = pos + total_r - 1;
             if (span_hi > tile_hi) span_hi = tile_hi;
             if (span_hi > L - 1) span_hi = L - 1;
 
+            // -- an insert's qualities (its anchor base and its first seven bases: nearly every insert is that short) as two
+            //    unaligned dwords, asked for FIRST: they are back before the row phase's sixteen byte loads, which are asked for
+            //    next and which the per-operation section would otherwise wait behind (loads return in order)
+            typedef unsigned __attribute__((aligned(1))) u32u;
+            const unsigned q_at = is_ins ? (unsigned)(rfirst - 1) : 0u;
+            const unsigned qw0 = *reinterpret_cast<const u32u*>(qual0 + q_at), qw1 = *reinterpret_cast<const u32u*>(qual0 + q_at + 4);
             // -- scratch for the row phase.  Every row of the span belongs to the reference-consuming operation that covers it:
             //    those operations are compacted, in order, into {first row, read index there, last row, code | anchoring bit}
             //    entries, and each marks the row where its share of the span starts in a 512-bit mask.  A row's owner is then
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
                 const bool match_op = valid && (op == OP_M || op == OP_EQ || op == OP_X) && len > 0;
                 const int lo = first > span_lo ? first : span_lo;
                 const int hi = last < span_hi ? last : span_hi;
-                if (match_op && lo <= hi) {
+                if (match_op && lo <= hi && !(a.debug & 64)) {
                     atomicAdd(&mcov[rev ? 1 : 0][lo - tile_lo], 1);
                     atomicAdd(&mcov[rev ? 1 : 0][hi + 1 - tile_lo], -1);
                     if ((next_op == OP_I || next_op == OP_D) && hi == last) atomicAdd(&anch[hi - tile_lo], rev ? 0x10000 : 1);
@@ -552,9 +562,12 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
             // -- one operation per lane: inserts (:431-490) and deletion anchors (:491-540)
             long long qsum = 0;
             if (is_ins) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)                  // most inserts are a few bases: eight loads at once
-                    qsum += (q < n_ins && rfirst - 1 + q < rd.slen) ? qual0[(unsigned)(rfirst - 1 + q)] : 0;
+                // bytes 0 .. min(n_ins, bases left in the read, 8) - 1 of the two dwords
+                int take = n_ins < rd.slen - (rfirst - 1) ? n_ins : rd.slen - (rfirst - 1);
+                take = take < 8 ? (take > 0 ? take : 0) : 8;
+                const unsigned m0 = take >= 4 ? 0xffffffffu : ((1u << (8 * take)) - 1u);
+                const unsigned m1 = take >= 8 ? 0xffffffffu : (take > 4 ? ((1u << (8 * (take - 4))) - 1u) : 0u);
+                qsum = (long long)__builtin_amdgcn_sad_u8(qw0 & m0, 0u, __builtin_amdgcn_sad_u8(qw1 & m1, 0u, 0u));
                 if (n_ins <= 33)
                     for (int q = 8; q < n_ins; ++q) qsum += rfirst - 1 + q < rd.slen ? qual0[(unsigned)(rfirst - 1 + q)] : 0;
             }
@@ -573,7 +586,7 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
                 const bool passes = (double)qsum >= reg.min_indel_q * (double)n_ins;
                 const int al = anchor - tile_lo;
                 // (the reference reads the anchor base's quality without a bound; a CIGAR that ends past the sequence is an error here)
-                const int anchor_q = rfirst - 1 < rd.slen ? (int)qual0[(unsigned)(rfirst - 1)] : 0;
+                const int anchor_q = rfirst - 1 < rd.slen ? (int)(qw0 & 255u) : 0;
                 if (passes && (double)anchor_q < reg.min_snp_q) atomicAdd(&cnt[K_COV * TP + al], 1);
                 if (avail + 1 <= 61 && passes) {
                     if (refok_s[al]) atomicAdd(&cnt[((rev ? K_REV : K_FWD) + 5) * TP + al], 1);   // column I
@@ -583,7 +596,7 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
                     voff = (unsigned)(rd.s0 - reg.seq_base + rfirst - 1);
                 }
             }
-            if (mine && op == OP_D) {
+            if (mine && op == OP_D && !(a.debug & 8)) {
                 const int al = anchor - tile_lo;
                 if (refok_s[al]) atomicAdd(&cnt[((rev ? K_REV : K_FWD) + 6) * TP + al], 1);       // column D, no quality test
                 int avail = len + 1 < reg.ref_len - anchor ? len + 1 : reg.ref_len - anchor;
@@ -615,6 +628,10 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
             // -- the rows: a base that is a clean match (quality passes, equal to an A/C/G/T reference base) is already counted
             //    by its run; the '*' column of a deletion's rows (:541-551) is one unconditional add; everything else is queued
             const int strand = rev ? K_REV : K_FWD;
+            // Which of the lane's rows need the full rules, as a bit per row; the wave's exceptions of the whole pass then enter
+            // the queue with ONE prefix sum (round 3 pushed per row slot: eight ballots, rank computations, queue-length updates
+            // and drain tests per pass, nearly all of them taken -- 5 % of the bases are exceptions, three per 64 rows)
+            unsigned om = 0, okm = 0;
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int o = pl[u];
@@ -622,21 +639,55 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
                 const bool ref_ok = refok_s[o] != 0;
                 const bool q_ok = qv[u] >= reg.qmin;
                 atomicAdd(&cnt[(strand + 7) * TP + o], (is_d[u] && ref_ok) ? 1 : 0);
-                const bool other = is_m[u] && !(q_ok && ref_ok && rb == b);
-                const unsigned long long m = __ballot(other);
-                if (m) {                                  // (wave-uniform)
-                    const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (other)
-                        xq_w[slot] = (unsigned)o | (b << 9) | (q_ok ? 1u << 17 : 0u) | (anchored[u] ? 1u << 18 : 0u) | (rev ? 1u << 19 : 0u);
-                    qn += __popcll(m);
+                const bool other = is_m[u] && !(q_ok && ref_ok && rb == b) && !(a.debug & 32);
+                om |= other ? 1u << u : 0u;
+                okm |= q_ok ? 1u << u : 0u;
+            }
+            if (__ballot(om != 0u)) {                     // (wave-uniform)
+                const int mine_n = __popc(om);
+                const int inc = wave_inclusive_sum(mine_n);
+                const int total = wave_total(inc);
+                if (qn + total <= XQ) {
+                    int slot = qn + inc - mine_n;
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+                        if ((om >> u) & 1u) {
+                            xq_w[slot++] = (unsigned)pl[u] | ((unsigned)(unsigned char)bv[u] << 9) | (((okm >> u) & 1u) << 17) |
+                                           (anchored[u] ? 1u << 18 : 0u) | (rev ? 1u << 19 : 0u);
+                        }
+                    qn += total;
                     __builtin_amdgcn_wave_barrier();
-                    if (qn >= 64) {
+                    while (qn >= 64) {
                         drain(64);
                         const unsigned moved = lane < qn - 64 ? xq_w[64 + lane] : 0u;
                         __builtin_amdgcn_wave_barrier();
                         if (lane < qn - 64) xq_w[lane] = moved;
                         qn -= 64;
                         __builtin_amdgcn_wave_barrier();
+                    }
+                } else {
+                    // more exceptions in one pass than the queue holds (a read that disagrees with the reference nearly
+                    // everywhere): row slot by row slot, draining as it fills
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const bool other = (om >> u) & 1u;
+                        const unsigned long long m = __ballot(other);
+                        if (m) {
+                            const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                            if (other)
+                                xq_w[slot] = (unsigned)pl[u] | ((unsigned)(unsigned char)bv[u] << 9) | (((okm >> u) & 1u) << 17) |
+                                             (anchored[u] ? 1u << 18 : 0u) | (rev ? 1u << 19 : 0u);
+                            qn += __popcll(m);
+                            __builtin_amdgcn_wave_barrier();
+                            if (qn >= 64) {
+                                drain(64);
+                                const unsigned moved = lane < qn - 64 ? xq_w[64 + lane] : 0u;
+                                __builtin_amdgcn_wave_barrier();
+                                if (lane < qn - 64) xq_w[lane] = moved;
+                                qn -= 64;
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        }
                     }
                 }
             }
@@ -707,28 +758,25 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
     }
     __syncthreads();                               // every counter is in registers: the LDS becomes the output tile
     if (tid < TP) pass_s[tid] = 0;
-    if (row) {
+    bool passes = false;
+    SiteRec site{};
+    if (row && !(a.debug & 4)) {
         const double c = cov > 1 ? (double)cov : 1.0;
         const bool s = (double)n_snp / c >= reg.snp_thr;
         const bool n = (double)n_ins / c >= reg.ins_thr;
         const bool d = (double)n_del / c >= reg.del_thr;
-        const bool passes = (s || n || d) && idx >= reg.cand_lo && idx <= reg.cand_hi && (double)cov >= reg.min_cov;
+        passes = (s || n || d) && idx >= reg.cand_lo && idx <= reg.cand_hi && (double)cov >= reg.min_cov;
         a.pass[reg.row_base + idx] = passes ? 1 : 0;
         pass_s[tid] = passes ? 1 : 0;
         if (passes) {
-            const int slot = atomicAdd(&a.region_counts[2 * region], 1);       // < L: one per row at most
-            {
-                SiteRec r;
-                r.region = region;
-                r.idx = idx;
-                r.cov = cov;
-                r.flags = (s ? 1 : 0) | (n ? 2 : 0) | (d ? 4 : 0);
+            site.region = region;
+            site.idx = idx;
+            site.cov = cov;
+            site.flags = (s ? 1 : 0) | (n ? 2 : 0) | (d ? 4 : 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    r.fwd[t] = tab[t];
-                    r.rev[t] = tab[4 + t];
-                }
-                a.sites[reg.row_base + slot] = r;
+            for (int t = 0; t < 4; ++t) {
+                site.fwd[t] = tab[t];
+                site.rev[t] = tab[4 + t];
             }
         }
 #pragma unroll
@@ -742,18 +790,36 @@ __global__ __launch_bounds__(NT, PA_TILE_MIN_WAVES) void tile_count_kernel(TileA
     const int n_rows = L + 1 - tile_lo < TP ? L + 1 - tile_lo : TP;
     const int n_out = n_rows * MATF;
     int* dst = a.mat + (reg.row_base + tile_lo) * (int64_t)MATF;          // 128-byte aligned: row_base % 16 == 0, tile_lo % 512 == 0
-    for (int i = tid; i < n_out / 4; i += NT) reinterpret_cast<int4*>(dst)[i] = reinterpret_cast<const int4*>(cnt)[i];
-    for (int i = (n_out & ~3) + tid; i < n_out; i += NT) dst[i] = cnt[i];
-    // the votes of the rows that passed (a few per cent) go to the host's list, each with the first bytes of its allele
-    const int nv = vcount < VCAP ? vcount : VCAP;
-    for (int i0 = 0; i0 < nv; i0 += NT) {
-        const int i = i0 + tid;
-        const uint2 pv = i < nv ? vbuf[i] : make_uint2(0, 0);
-        const bool has = i < nv && pass_s[pv.y >> 10];
-        Vote v{(uint32_t)(tile_lo + (int)(pv.y >> 10)), (pv.y & 1023u) | ((uint32_t)region << 10), (int64_t)pv.x, 0};
-        if (has) v.prefix = allele_prefix((pv.y & 8u) ? a.ref + reg.ref_off : a.seq + reg.seq_base, pv.x, (pv.y >> 4) & 63u);
-        wave_append_vote(has, v, a.votes_out + reg.vote_base, &a.region_counts[2 * region + 1], 0x7fffffff, lane);
+    if (!(a.debug & 2)) {
+        for (int i = tid; i < n_out / 4; i += NT) reinterpret_cast<int4*>(dst)[i] = reinterpret_cast<const int4*>(cnt)[i];
+        for (int i = (n_out & ~3) + tid; i < n_out; i += NT) dst[i] = cnt[i];
     }
+    // The sites that passed and the votes of their rows (a few per cent of each) go to the region's lists, each vote with the
+    // first bytes of its allele.  ONE update of the region's two counters per TILE: round 3 updated the site counter once per
+    // passing row and the vote counter once per wave, and with ~200 tiles of a region at work on the same two words those
+    // returning atomics, served one after the other by the L2, were a sixth of the kernel (tools/tile_ablation.sh).
+    const int nv = (a.debug & 128) ? 0 : (vcount < VCAP ? vcount : VCAP);       // (VCAP == NT: one vote per thread)
+    const uint2 pv = tid < nv ? vbuf[tid] : make_uint2(0, 0);
+    const bool has = tid < nv && pass_s[pv.y >> 10];
+    Vote v{(uint32_t)(tile_lo + (int)(pv.y >> 10)), (pv.y & 1023u) | ((uint32_t)region << 10), (int64_t)pv.x, 0};
+    if (has) v.prefix = allele_prefix((pv.y & 8u) ? a.ref + reg.ref_off : a.seq + reg.seq_base, pv.x, (pv.y >> 4) & 63u);
+    const unsigned long long sm = __ballot(passes), vm = __ballot(has);
+    int s_at = 0, v_at = 0;
+    if (lane == 0) {
+        if (sm) s_at = atomicAdd(&s_out[0], __popcll(sm));
+        if (vm) v_at = atomicAdd(&s_out[1], __popcll(vm));
+    }
+    s_at = __builtin_amdgcn_readfirstlane(s_at);      // (with every lane active: lane 0's value)
+    v_at = __builtin_amdgcn_readfirstlane(v_at);
+    __syncthreads();
+    if (tid == 0) {
+        if (s_out[0]) s_out[2] = atomicAdd(&a.region_counts[2 * region], s_out[0]);       // < L: one per row at most
+        if (s_out[1]) s_out[3] = atomicAdd(&a.region_counts[2 * region + 1], s_out[1]);
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (passes) a.sites[reg.row_base + s_out[2] + s_at + __popcll(sm & below)] = site;
+    if (has) a.votes_out[reg.vote_base + s_out[3] + v_at + __popcll(vm & below)] = v;
 #ifdef PA_ENC_STAMP
     ENC_LAP(6);                                       // flush: prefix sums, per-position pass, store, votes
     if (lane == 0)
@@ -1491,6 +1557,8 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
         ta.ovf_cap = b.ovf_cap;
         ta.counters = counters;
         ta.region_counts = region_counts;
+        static const int tile_debug = [] { const char* e = getenv("PA_TILE_DEBUG"); return e ? atoi(e) : 0; }();
+        ta.debug = tile_debug;
         hipLaunchKernelGGL(tile_count_kernel, dim3((unsigned)b.n_tiles), dim3(NT), 0, st, ta);
         ENC_HIP(hipEventRecord(e->ev[2], st));
         hipLaunchKernelGGL(compact_votes_kernel, dim3((unsigned)std::min(2048, (vote_cap + 255) / 256)), dim3(256), 0, st, b.d_votes.as<Vote>(), counters,
