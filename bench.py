@@ -423,16 +423,40 @@ HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md
 
 
 def encoder_traffic():
-    """HBM bytes per launch of tile_count_kernel from the committed PMC passes (profiles/r03_encoder_variant_pmc.json)."""
-    path = os.path.join(REPO, "profiles", "r03_encoder_variant_pmc.json")
+    """HBM bytes and instruction counts per launch of tile_count_kernel from the committed PMC passes (profiles/
+    r04_encoder_variant_pmc.json, else r03)."""
+    path = os.path.join(REPO, "profiles", "r04_encoder_variant_pmc.json")
+    if not os.path.exists(path):
+        path = os.path.join(REPO, "profiles", "r03_encoder_variant_pmc.json")
     try:
         with open(path) as fh:
             k = json.load(fh)["kernels"]["tile_count"]
         return {"bytes_per_launch": k["fetch_bytes_reported"] + k["write_bytes"], "fetch_bytes_reported": k["fetch_bytes_reported"],
                 "write_bytes": k["write_bytes"], "source": os.path.relpath(path, REPO),
+                "insts": {c: k.get(c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAIT_ANY",
+                                                "SQ_WAVE_CYCLES") if k.get(c) is not None},
+                "avg_us_profiled": k.get("avg_us"),
                 "note": "FETCH_SIZE as reported (byte-per-lane nt loads: on the same batch it reports 0.99 GB against 0.74 GB of "
                         "read bytes + 0.10 GB of CIGAR operations + 0.04 GB of records and tables, so no doubling applies to "
                         "this access pattern), WRITE_SIZE as reported"}
+    except Exception:
+        return None
+
+
+def encoder_issue_roof(traffic, launch_ms):
+    """The roof that binds tile_count_kernel is instruction issue, not HBM (the launch moves 1.1x its algorithmic bytes at a tenth
+    of the HBM rate): vector wave-instructions of one launch (rocprofv3 SQ_INSTS_VALU, committed PMC pass) x 4 cycles each over
+    the SIMD-cycles the launch had (1024 SIMDs x launch duration x 2.4 GHz); the scalar and LDS instructions of the same launch
+    are listed beside it (they issue on their own ports)."""
+    try:
+        ins = traffic["insts"]
+        valu = float(ins["SQ_INSTS_VALU"])
+        simd_cycles = 1024 * launch_ms * 1e-3 * 2.4e9
+        return {"bound": "valu issue", "valu_wave_instructions": valu, "salu_wave_instructions": ins.get("SQ_INSTS_SALU"),
+                "lds_wave_instructions": ins.get("SQ_INSTS_LDS"), "cycles_per_valu_instruction": 4, "simd_cycles_available": simd_cycles,
+                "frac": 4.0 * valu / simd_cycles,
+                "wait_share_of_wave_cycles": (ins["SQ_WAIT_ANY"] / ins["SQ_WAVE_CYCLES"]) if ins.get("SQ_WAVE_CYCLES") else None,
+                "source": traffic["source"]}
     except Exception:
         return None
 
@@ -575,6 +599,7 @@ def encoder_bench(args):
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic["bytes_per_launch"] if traffic else None,
                      "traffic_detail": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_ms": avg["tile_count_ms"],
+                     "issue": encoder_issue_roof(traffic, avg["tile_count_ms"]),
                      "note": "algorithmic bytes = 2 B per aligned base (base + quality) + 104 B per region position (26 int32), "
                              "SURVEY.md 8(d); launch duration from HIP events on the encoder's stream around the kernel, averaged "
                              "over the timed steps"},
@@ -817,6 +842,12 @@ def secondary_block(args):
         "aligned_bases_per_step": d["config"]["aligned_bases_per_step"], "rows_per_step": d["config"]["rows_per_step"],
         "roofline": {k: d["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")},
         "host_buffers_one_call": d["host_buffers_one_call"]["value"], "runs": d["_runs"], "seconds": d["_seconds"]}
+    d = median_of([sys.executable, me, "--model", "realign", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"], 300)
+    out["realign"] = d if "error" in d else {
+        "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"],
+        "reads_per_s_4_worker_threads": d.get("reads_per_s_4_worker_threads"), "ms_per_60_read_region": d.get("ms_per_60_read_region"),
+        "roofline": {k: d["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac")},
+        "kernels": d.get("kernels"), "cpu_baseline": d.get("cpu_baseline"), "runs": d["_runs"], "seconds": d["_seconds"]}
     scratch = None
     try:
         st = os.statvfs("/dev/shm")

@@ -127,9 +127,13 @@ class PredictionBuilder(object):
     involved, so no lock either."""
 
     def __init__(self, path):
+        # The bytes on disk are not an HDF5 file until close() has written the metadata: they are laid out under
+        # `<path>.tmp` and take the final name only when close() has succeeded, so that a worker that is killed or raises mid-run
+        # leaves no `*.hdf` behind for the next step's directory listing (perform_stitch, run_inference) to choke on.
         self._lib = load()
         self._h = c_void_p()
-        _check(self._lib.pa_h5_builder_open(os.fsencode(path), ctypes.byref(self._h)))
+        self._tmp = str(path) + ".tmp"
+        _check(self._lib.pa_h5_builder_open(os.fsencode(self._tmp), ctypes.byref(self._h)))
         self.filename, self.mode = path, "w"
 
     def write_polish_predictions(self, contigs, start, end, chunk, new_region, skip, position, index, bases, phred):
@@ -177,17 +181,35 @@ class PredictionBuilder(object):
     def close(self):
         if self._h:
             h, self._h = self._h, None
-            _check(self._lib.pa_h5_builder_close(h))
+            try:
+                _check(self._lib.pa_h5_builder_close(h))
+            except Exception:
+                if os.path.exists(self._tmp):
+                    os.remove(self._tmp)
+                raise
+            os.replace(self._tmp, self.filename)
 
     def __enter__(self):
         return self
 
-    def __exit__(self, *a):
+    def __exit__(self, exc_type, *a):
+        if exc_type is not None:
+            # the block raised: whatever was written is not a complete store -- finish the native object, keep nothing
+            h, self._h = self._h, None
+            if h:
+                self._lib.pa_h5_builder_close(h)
+                if os.path.exists(self._tmp):
+                    os.remove(self._tmp)
+            return
         self.close()
 
     def __del__(self):
+        # (a writer that was never closed: the metadata is still written so that the handle is released, and the file keeps
+        # its temporary name -- an explicit close() is what publishes a store)
         try:
-            self.close()
+            h, self._h = self._h, None
+            if h:
+                self._lib.pa_h5_builder_close(h)
         except Exception:
             pass
 

@@ -27,7 +27,7 @@ class DataStore(object):
         return self
 
     def __exit__(self, *args):
-        self.file_handler.close()
+        self.file_handler.__exit__(*args)      # (the append-only writer publishes the file only when the block did not raise)
 
     def write_summary(self, region, image, label, position, index, chunk_id, summary_name):
         contig_name, region_start, region_end = region

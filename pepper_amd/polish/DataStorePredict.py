@@ -35,7 +35,7 @@ class DataStore(object):
         return self
 
     def __exit__(self, *args):
-        self.close()
+        self.file_handler.__exit__(*args)      # (the append-only writer publishes the file only when the block did not raise)
 
     def write_prediction(self, contig, contig_start, contig_end, chunk_id, position, index, predicted_bases,
                          phred_score):

@@ -42,7 +42,7 @@ class DataStore(object):
         return self
 
     def __exit__(self, *args):
-        self.file_handler.close()
+        self.file_handler.__exit__(*args)      # (the append-only writer publishes the file only when the block did not raise)
 
     def write_summary(self, summary_name, contigs, positions, depths, all_candidates, all_candidate_frequency,
                       all_images, all_base_labels, all_type_label, train_mode):
