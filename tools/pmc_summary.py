@@ -47,6 +47,12 @@ LABELS = [
     ("tile_offsets_kernel", "tile_offsets"),
     ("bin_records_kernel", "bin_records"),
     ("compact_votes_kernel", "compact_votes"),
+    ("gru_small_h2_kernel", "gru_small_h2"),
+    ("unpack_clip_kernel", "unpack_clip"),
+    ("pack_results_kernel", "pack_results"),
+    ("polish_tile_kernel", "polish_tile"),
+    ("polish_segment_kernel", "polish_segment"),
+    ("polish_insert_rows_kernel", "polish_insert_rows"),
 ]
 
 
