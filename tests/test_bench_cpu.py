@@ -25,7 +25,8 @@ def test_help_and_contract_flags():
 def test_traffic_comes_from_the_committed_pmc_passes():
     b = _bench()
     t = b.measured_traffic("variant", "lstm_dec_h2_fused")
-    assert t is not None and t["source"] == os.path.join("profiles", "r03_variant_pmc.json")      # this round's passes
+    assert t is not None and t["source"] == os.path.join("profiles", "r04_variant_pmc.json")      # this round's passes
+    assert 0.5 < t["mfma_busy_frac"] < 1.0 and 100 < t["hbm_GBps_profiled"] < 8000               # the counters north_star names
     table = json.load(open(os.path.join(REPO, t["source"])))["kernels"]["lstm_dec_h2_fused"]
     assert t["bytes_per_launch"] == table["fetch_bytes_corrected"] + table["write_bytes"]
     # the decoder reads the encoder's output once and writes its own once: measured traffic within 10 % of that
@@ -33,7 +34,9 @@ def test_traffic_comes_from_the_committed_pmc_passes():
     assert 0.95 * algorithmic < t["bytes_per_launch"] < 1.10 * algorithmic
     assert b.measured_traffic("variant", "no_such_kernel") is None
     e = b.encoder_traffic()                                  # the encoder line's traffic: this round's tile_count_kernel passes
-    assert e is not None and e["source"] == os.path.join("profiles", "r03_encoder_variant_pmc.json") and e["bytes_per_launch"] > 1e9
+    assert e is not None and e["source"] == os.path.join("profiles", "r04_encoder_variant_pmc.json") and e["bytes_per_launch"] > 1e9
+    issue = b.encoder_issue_roof(e, e["avg_us_profiled"] * 1e-3)      # the roof that binds the encoder's kernel: instruction issue
+    assert issue is not None and 0.3 < issue["frac"] < 1.0 and issue["valu_wave_instructions"] > 1e8
     for label in ("lstm_rec_h2_fused_in", "lstm_dec_h2_fused", "gemm_h2_linear_1", "gru_dec_h2_fused_dense", "gru_rec_h2_fused_in"):
         assert label in b.ALGORITHMIC_BYTES_PER_UNIT
 
