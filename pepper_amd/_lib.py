@@ -94,6 +94,12 @@ SYMBOLS = [
                                                   [ctypes.POINTER(c_int64)]),
     ("pa_realigner_copy_cigars", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     ("pa_realigner_stage_ticks", ctypes.c_int, [c_void_p, c_void_p]),
+    # include/pepper_amd_io_device.h
+    ("pa_inflater_create", ctypes.c_int, [c_int32, ctypes.POINTER(c_void_p)]),
+    ("pa_inflater_destroy", None, [c_void_p]),
+    ("pa_inflater_inflate", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int64, c_int32]),
+    ("pa_inflater_last_kernel_ms", ctypes.c_int, [c_void_p, ctypes.POINTER(c_double)]),
     ("pa_realigner_last_timing", ctypes.c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double),
                                                 ctypes.POINTER(c_int64)]),
 ]

@@ -10,7 +10,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpepper_amd.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_h2.hip", "rnn.hip", "rnn_h2.hip", "mlp_h2.hip", "head.hip", "encoder.hip", "encoder_polish.hip", "realign.hip"]
+SOURCES = ["api.hip", "inflate.hip", "gemm.hip", "gemm_h2.hip", "rnn.hip", "rnn_h2.hip", "mlp_h2.hip", "head.hip", "encoder.hip", "encoder_polish.hip", "realign.hip"]
 HEADERS = ["common.h", "kernels.h", "encoder_common.h", os.path.join("..", "..", "include", "pepper_amd.h"),
            os.path.join("..", "..", "include", "pepper_amd_encoder.h"),
            os.path.join("..", "..", "include", "pepper_amd_realign.h")]

@@ -24,6 +24,9 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -213,6 +216,9 @@ struct pa_bam {
     std::vector<uint8_t> scratch_qual;
     std::vector<std::pair<int32_t, int32_t>> pack_pairs;       // pa_bam_pack_regions: (region, read) as the walk finds them
     std::vector<int64_t> pack_closed;
+    std::string path;
+    int span_fd = -1;                                          // pa_bam_read_span: its own descriptor (pread, no shared position)
+    int64_t file_bytes = -1;
 };
 
 namespace {
@@ -398,6 +404,7 @@ int pa_bam_open(const char* path, pa_bam** out) {
     if (!ok) { fclose(b->bg.fp); delete b; return bam_fail(-3, std::string("HEADER ERROR: truncated BAM header: ") + path); }
     while (!b->text.empty() && b->text.back() == '\0') b->text.pop_back();
     b->first_record = b->bg.tell();
+    b->path = path;
     const std::string p(path);
     b->has_index = load_bai(b, p + ".bai");
     if (!b->has_index && p.size() > 4 && p.substr(p.size() - 4) == ".bam") b->has_index = load_bai(b, p.substr(0, p.size() - 4) + ".bai");
@@ -408,6 +415,7 @@ int pa_bam_open(const char* path, pa_bam** out) {
 void pa_bam_close(pa_bam* b) {
     if (!b) return;
     if (b->bg.fp) fclose(b->bg.fp);
+    if (b->span_fd >= 0) close(b->span_fd);
     delete b;
 }
 
@@ -670,48 +678,21 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
 // -- one contiguous slice of the record as BAM stores it -- ONCE into the caller's arena (a page-locked buffer of the
 // encoder), however many of the batch's regions the read reaches.  1.5 bytes per base + 4 per operation cross PCIe instead of
 // 2 + 8, and the host's per-base work is one memcpy.
-int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const int64_t* start, const int64_t* stop,
-                        int32_t include_supplementary, int32_t min_mapq, uint8_t* arena, int64_t arena_cap,
-                        pa_packed_read* reads, int32_t reads_cap, int32_t* pair_read, int32_t pairs_cap,
-                        int32_t* region_pairs, int32_t* n_done, int64_t* counts) {
-    if (!b || !contig || n_regions < 0 || (n_regions > 0 && (!start || !stop)) || !arena || !reads || !pair_read || !region_pairs || !n_done)
-        return bam_fail(-1, "null argument");
-    *n_done = 0;
-    for (int r = 0; r <= n_regions; ++r) region_pairs[r] = 0;
-    if (counts) counts[0] = counts[1] = counts[2] = 0;
-    if (n_regions == 0) return 0;
-    for (int r = 0; r < n_regions; ++r)
-        if (stop[r] < start[r] || (r > 0 && (start[r] < start[r - 1] || stop[r] < stop[r - 1])))
-            return bam_fail(-1, "pack_regions: regions must be ascending in start and stop");
-    int tid = -1;
-    for (size_t i = 0; i < b->names.size(); ++i)
-        if (b->names[i] == contig) tid = (int)i;
-    if (tid < 0) return bam_fail(-4, std::string("contig not in the BAM header: ") + contig);
-
-    uint64_t from = b->first_record;
-    bool nothing = false;
-    if (b->has_index && tid < (int)b->ioff.size()) {
-        const auto& lin = b->ioff[tid];
-        int64_t w = std::max<int64_t>(0, start[0]) >> 14;
-        uint64_t off = 0;
-        if (!lin.empty()) {
-            if (w >= (int64_t)lin.size()) w = (int64_t)lin.size() - 1;
-            for (int64_t k = w; k >= 0 && off == 0; --k) off = lin[k];
-        }
-        if (off == 0) off = b->ref_min[tid];
-        if (off == 0) nothing = true;
-        from = off;
-    }
-    b->bg.failed = false;
-    if (!nothing && !b->bg.seek(from)) return bam_fail(-5, "BGZF seek failed (corrupt file or index)");
-
+namespace {
+// The walk shared by pa_bam_pack_regions (records from the BGZF reader, slices copied into the arena) and
+// pa_bam_pack_inflated (mem != NULL: records in place in an inflated span, data_off = the slice's offset in the span).
+int pack_walk(pa_bam* b, int tid, bool nothing, const uint8_t* mem, int64_t mem_bytes, int64_t mem_first, bool mem_final,
+              int32_t n_regions, const int64_t* start, const int64_t* stop, int32_t include_supplementary, int32_t min_mapq,
+              uint8_t* arena, int64_t arena_cap, pa_packed_read* reads, int32_t reads_cap, int32_t* pair_read, int32_t pairs_cap,
+              int32_t* region_pairs, int32_t* n_done, int64_t* counts) {
     // pairs arrive read by read; they leave grouped by region
     std::vector<std::pair<int32_t, int32_t>>& pairs = b->pack_pairs;     // (region, read)
     pairs.clear();
     int64_t used = 0;
     int32_t n_reads = 0;
     int r_lo = 0;                       // regions in front of r_lo end at or before the current record's position
-    bool full = false;
+    bool full = false, cut = false;
+    int64_t mem_at = mem_first;
     const int64_t last_stop = stop[n_regions - 1];
     std::vector<uint8_t> rec;
     // what was complete when region k closed (every record with pos < stop[k] seen): reads, pairs, arena bytes
@@ -727,21 +708,33 @@ int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const 
         }
     };
     while (!nothing) {
-        uint8_t w4[4];
-        const size_t got4 = b->bg.read(w4, 4);
-        if (b->bg.failed) return bam_fail(-5, "corrupt or truncated BGZF block");
-        if (got4 != 4) {
-            if (got4 != 0) return bam_fail(-6, "truncated BAM record");
-            break;
-        }
-        const uint32_t block_size = le32(w4);
-        if (block_size < 32) return bam_fail(-6, "corrupt BAM record");
-        const uint8_t* R = b->bg.peek(block_size);
-        if (!R) {
-            rec.resize(block_size);
-            if (b->bg.read(rec.data(), block_size) != block_size)
-                return bam_fail(b->bg.failed ? -5 : -6, b->bg.failed ? "corrupt or truncated BGZF block" : "truncated BAM record");
-            R = rec.data();
+        uint32_t block_size = 0;
+        const uint8_t* R = nullptr;
+        if (mem) {
+            // records in place in an inflated span: one that the span cuts off ends the walk like a full table does
+            if (mem_at + 4 > mem_bytes) { cut = mem_at < mem_bytes || !mem_final; break; }
+            block_size = le32(mem + mem_at);
+            if (block_size < 32) return bam_fail(-6, "corrupt BAM record");
+            if (mem_at + 4 + (int64_t)block_size > mem_bytes) { cut = true; break; }
+            R = mem + mem_at + 4;
+            mem_at += 4 + (int64_t)block_size;
+        } else {
+            uint8_t w4[4];
+            const size_t got4 = b->bg.read(w4, 4);
+            if (b->bg.failed) return bam_fail(-5, "corrupt or truncated BGZF block");
+            if (got4 != 4) {
+                if (got4 != 0) return bam_fail(-6, "truncated BAM record");
+                break;
+            }
+            block_size = le32(w4);
+            if (block_size < 32) return bam_fail(-6, "corrupt BAM record");
+            R = b->bg.peek(block_size);
+            if (!R) {
+                rec.resize(block_size);
+                if (b->bg.read(rec.data(), block_size) != block_size)
+                    return bam_fail(b->bg.failed ? -5 : -6, b->bg.failed ? "corrupt or truncated BGZF block" : "truncated BAM record");
+                R = rec.data();
+            }
         }
         const int32_t ref_id = (int32_t)le32(R);
         const int32_t pos = (int32_t)le32(R + 4);
@@ -801,17 +794,29 @@ int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const 
         if (full) break;
         if (first_pair < 0) continue;
         const int64_t bytes = 4ll * n_cig + (l_seq + 1) / 2 + l_seq;
-        const int64_t at = (used + 3) & ~(int64_t)3;
-        if (n_reads >= reads_cap || at + bytes + 64 > arena_cap) {
-            pairs.resize((size_t)first_pair);
-            full = true;
-            break;
-        }
-        if (cig == R + o_cigar) {
-            std::memcpy(arena + at, cig, (size_t)bytes);      // the three fields follow each other in the record
+        int64_t at;
+        if (mem) {
+            // in place: the slice is the record's own bytes (any alignment); a CIGAR kept in the CG tag is not one slice
+            if (cig != R + o_cigar) return bam_fail(-8, "pack_inflated: a record keeps its CIGAR in the CG tag (take pack_regions)");
+            if (n_reads >= reads_cap) {
+                pairs.resize((size_t)first_pair);
+                full = true;
+                break;
+            }
+            at = (int64_t)(cig - mem);
         } else {
-            std::memcpy(arena + at, cig, 4ull * n_cig);
-            std::memcpy(arena + at + 4ll * n_cig, R + o_seq, (size_t)((l_seq + 1) / 2 + l_seq));
+            at = (used + 3) & ~(int64_t)3;
+            if (n_reads >= reads_cap || at + bytes + 64 > arena_cap) {
+                pairs.resize((size_t)first_pair);
+                full = true;
+                break;
+            }
+            if (cig == R + o_cigar) {
+                std::memcpy(arena + at, cig, (size_t)bytes);      // the three fields follow each other in the record
+            } else {
+                std::memcpy(arena + at, cig, 4ull * n_cig);
+                std::memcpy(arena + at + 4ll * n_cig, R + o_seq, (size_t)((l_seq + 1) / 2 + l_seq));
+            }
         }
         pa_packed_read& pr = reads[n_reads++];
         pr.data_off = at;
@@ -819,11 +824,13 @@ int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const 
         pr.n_cigar = (int32_t)n_cig;
         pr.l_seq = (int32_t)l_seq;
         pr.flags = (int32_t)(flag | ((uint32_t)mapq << 16));
-        used = at + bytes;
+        used = mem ? used + bytes : at + bytes;
     }
-    if (!full) close_up_to(0x7fffffffffffffffll);        // the walk ended: every region is complete
-    if (n_closed == 0)
+    if (!full && !cut) close_up_to(0x7fffffffffffffffll);        // the walk ended: every region is complete
+    if (n_closed == 0) {
+        if (cut) return bam_fail(-9, "pack_inflated: the span ends before the first region's last read (take a longer span)");
         return bam_fail(-7, "pack_regions: the reads of one region do not fit the arena / tables (grow them or take get_reads)");
+    }
     const int64_t reads_kept = closed[(size_t)(n_closed - 1) * 3], pairs_kept = closed[(size_t)(n_closed - 1) * 3 + 1];
     // pairs of the closed regions, grouped by region (a stable counting sort: the reads of a region stay in file order)
     for (int64_t k = 0; k < pairs_kept; ++k)
@@ -841,6 +848,188 @@ int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const 
         counts[2] = closed[(size_t)(n_closed - 1) * 3 + 2];
     }
     return 0;
+}
+}  // namespace
+
+int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const int64_t* start, const int64_t* stop,
+                        int32_t include_supplementary, int32_t min_mapq, uint8_t* arena, int64_t arena_cap,
+                        pa_packed_read* reads, int32_t reads_cap, int32_t* pair_read, int32_t pairs_cap,
+                        int32_t* region_pairs, int32_t* n_done, int64_t* counts) {
+    if (!b || !contig || n_regions < 0 || (n_regions > 0 && (!start || !stop)) || !arena || !reads || !pair_read || !region_pairs || !n_done)
+        return bam_fail(-1, "null argument");
+    *n_done = 0;
+    for (int r = 0; r <= n_regions; ++r) region_pairs[r] = 0;
+    if (counts) counts[0] = counts[1] = counts[2] = 0;
+    if (n_regions == 0) return 0;
+    for (int r = 0; r < n_regions; ++r)
+        if (stop[r] < start[r] || (r > 0 && (start[r] < start[r - 1] || stop[r] < stop[r - 1])))
+            return bam_fail(-1, "pack_regions: regions must be ascending in start and stop");
+    int tid = -1;
+    for (size_t i = 0; i < b->names.size(); ++i)
+        if (b->names[i] == contig) tid = (int)i;
+    if (tid < 0) return bam_fail(-4, std::string("contig not in the BAM header: ") + contig);
+
+    uint64_t from = b->first_record;
+    bool nothing = false;
+    if (b->has_index && tid < (int)b->ioff.size()) {
+        const auto& lin = b->ioff[tid];
+        int64_t w = std::max<int64_t>(0, start[0]) >> 14;
+        uint64_t off = 0;
+        if (!lin.empty()) {
+            if (w >= (int64_t)lin.size()) w = (int64_t)lin.size() - 1;
+            for (int64_t k = w; k >= 0 && off == 0; --k) off = lin[k];
+        }
+        if (off == 0) off = b->ref_min[tid];
+        if (off == 0) nothing = true;
+        from = off;
+    }
+    b->bg.failed = false;
+    if (!nothing && !b->bg.seek(from)) return bam_fail(-5, "BGZF seek failed (corrupt file or index)");
+
+    return pack_walk(b, tid, nothing, nullptr, 0, 0, false, n_regions, start, stop, include_supplementary, min_mapq, arena, arena_cap,
+                     reads, reads_cap, pair_read, pairs_cap, region_pairs, n_done, counts);
+}
+
+namespace {
+int find_tid(pa_bam* b, const char* contig) {
+    for (size_t i = 0; i < b->names.size(); ++i)
+        if (b->names[i] == contig) return (int)i;
+    return -1;
+}
+bool open_span_fd(pa_bam* b) {
+    if (b->span_fd >= 0) return true;
+    b->span_fd = open(b->path.c_str(), O_RDONLY);
+    if (b->span_fd < 0) return false;
+    struct stat st;
+    if (fstat(b->span_fd, &st) != 0) return false;
+    b->file_bytes = (int64_t)st.st_size;
+    return true;
+}
+}  // namespace
+
+int pa_bam_region_span(pa_bam* b, const char* contig, int64_t start, int64_t stop, int32_t lookahead_windows,
+                       int64_t* begin_coffset, int32_t* begin_uoffset, int64_t* end_coffset, int32_t* to_contig_end) {
+    if (!b || !contig || !begin_coffset || !begin_uoffset || !end_coffset || !to_contig_end || stop < start || lookahead_windows < 0)
+        return bam_fail(-1, "null or invalid argument");
+    const int tid = find_tid(b, contig);
+    if (tid < 0) return bam_fail(-4, std::string("contig not in the BAM header: ") + contig);
+    if (!b->has_index || tid >= (int)b->ioff.size()) return bam_fail(-10, "region_span needs the .bai index");
+    if (!open_span_fd(b)) return bam_fail(-2, "cannot open the BAM file for span reads");
+    const auto& lin = b->ioff[tid];
+    uint64_t off = 0;
+    if (!lin.empty()) {
+        int64_t w = std::max<int64_t>(0, start) >> 14;
+        if (w >= (int64_t)lin.size()) w = (int64_t)lin.size() - 1;
+        for (int64_t k = w; k >= 0 && off == 0; --k) off = lin[k];
+    }
+    if (off == 0) off = b->ref_min[tid];
+    if (off == 0) {                                   // no record of the contig at all
+        *begin_coffset = *end_coffset = 0;
+        *begin_uoffset = 0;
+        *to_contig_end = 1;
+        return 0;
+    }
+    *begin_coffset = (int64_t)(off >> 16);
+    *begin_uoffset = (int32_t)(off & 0xffff);
+    // the end: the first indexed record of a window `lookahead_windows` beyond the one after stop -- a record there starts at
+    // or after stop unless a read longer than the lookahead reaches it (the walk notices: it must SEE a record at or beyond
+    // the last stop); past the contig's windows: where the next contig's records begin, or the end of the file
+    uint64_t end = 0;
+    const int64_t w2 = ((std::max<int64_t>(stop, 1) - 1) >> 14) + 1 + lookahead_windows;
+    for (int64_t k = w2; k < (int64_t)lin.size() && end == 0; ++k)
+        if (lin[k] > off) end = lin[k];
+    *to_contig_end = 0;
+    if (end == 0) {
+        *to_contig_end = 1;
+        for (size_t t = (size_t)tid + 1; t < b->ref_min.size() && end == 0; ++t) end = b->ref_min[t];
+        *end_coffset = end ? (int64_t)(end >> 16) + 1 : b->file_bytes;     // (+1: the member that holds the next contig's first record)
+        return 0;
+    }
+    *end_coffset = (int64_t)(end >> 16) + 1;
+    return 0;
+}
+
+int pa_bam_read_span(pa_bam* b, int64_t begin, int64_t end_min, int32_t extra_members, uint8_t* buf, int64_t buf_cap,
+                     int64_t* comp_off, int32_t* comp_len, int64_t* out_off, int32_t* out_len, int32_t blocks_cap,
+                     int32_t* n_blocks, int64_t* comp_bytes, int64_t* out_bytes, int32_t* complete) {
+    if (!b || !buf || !comp_off || !comp_len || !out_off || !out_len || !n_blocks || !comp_bytes || !out_bytes || !complete ||
+        begin < 0 || buf_cap < 0 || blocks_cap < 0 || extra_members < 0)
+        return bam_fail(-1, "null or invalid argument");
+    if (!open_span_fd(b)) return bam_fail(-2, "cannot open the BAM file for span reads");
+    *n_blocks = 0;
+    *comp_bytes = *out_bytes = 0;
+    *complete = 0;
+    end_min = std::min(end_min, b->file_bytes);
+    const int64_t want = std::min<int64_t>(b->file_bytes - begin, (end_min - begin) + ((int64_t)extra_members + 1) * 65536);
+    if (want <= 0) { *complete = 1; return 0; }
+    const int64_t take = std::min(want, buf_cap);
+    int64_t got = 0;
+    while (got < take) {
+        const ssize_t r = pread(b->span_fd, buf + got, (size_t)(take - got), (off_t)(begin + got));
+        if (r < 0) return bam_fail(-5, "read error in the BAM file");
+        if (r == 0) break;
+        got += r;
+    }
+    int64_t p = 0, at = 0;
+    int32_t n = 0, extra = 0;
+    bool covered = false;
+    while (true) {
+        if (begin + p >= end_min) {
+            if (extra >= extra_members) { covered = true; break; }
+            ++extra;
+        }
+        if (begin + p >= b->file_bytes) { covered = true; break; }
+        if (p + 18 > got) break;
+        const uint8_t* h = buf + p;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return bam_fail(-5, "no BGZF member where the index points");
+        const int xlen = h[10] | (h[11] << 8);
+        if (p + 12 + xlen > got) break;
+        int bsize = -1;
+        for (int q = 0; q + 4 <= xlen;) {
+            const int slen = h[12 + q + 2] | (h[12 + q + 3] << 8);
+            if (h[12 + q] == 'B' && h[12 + q + 1] == 'C' && slen == 2 && q + 6 <= xlen) bsize = (h[12 + q + 4] | (h[12 + q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        const int clen = bsize - 12 - xlen - 8;
+        if (bsize < 0 || clen < 0) return bam_fail(-5, "malformed BGZF member");
+        if (p + bsize > got) break;
+        if (n >= blocks_cap) break;
+        const uint32_t isize = le32(h + bsize - 4);
+        if (isize > 65536) return bam_fail(-5, "BGZF member larger than 64 KiB");
+        comp_off[n] = p + 12 + xlen;
+        comp_len[n] = clen;
+        out_off[n] = at;
+        out_len[n] = (int32_t)isize;
+        at += isize;
+        p += bsize;
+        ++n;
+    }
+    *n_blocks = n;
+    *comp_bytes = p;
+    *out_bytes = at;
+    *complete = covered ? 1 : 0;
+    return 0;
+}
+
+int pa_bam_pack_inflated(pa_bam* b, const uint8_t* data, int64_t data_bytes, int64_t first_record, int32_t data_is_final,
+                         const char* contig, int32_t n_regions, const int64_t* start, const int64_t* stop,
+                         int32_t include_supplementary, int32_t min_mapq, pa_packed_read* reads, int32_t reads_cap,
+                         int32_t* pair_read, int32_t pairs_cap, int32_t* region_pairs, int32_t* n_done, int64_t* counts) {
+    if (!b || !contig || n_regions < 0 || (n_regions > 0 && (!start || !stop)) || (data_bytes > 0 && !data) || data_bytes < 0 ||
+        first_record < 0 || !reads || !pair_read || !region_pairs || !n_done)
+        return bam_fail(-1, "null argument");
+    *n_done = 0;
+    for (int r = 0; r <= n_regions; ++r) region_pairs[r] = 0;
+    if (counts) counts[0] = counts[1] = counts[2] = 0;
+    if (n_regions == 0) return 0;
+    for (int r = 0; r < n_regions; ++r)
+        if (stop[r] < start[r] || (r > 0 && (start[r] < start[r - 1] || stop[r] < stop[r - 1])))
+            return bam_fail(-1, "pack_inflated: regions must be ascending in start and stop");
+    const int tid = find_tid(b, contig);
+    if (tid < 0) return bam_fail(-4, std::string("contig not in the BAM header: ") + contig);
+    static const uint8_t none = 0;
+    return pack_walk(b, tid, false, data ? data : &none, data_bytes, first_record, data_is_final != 0, n_regions, start, stop,
+                     include_supplementary, min_mapq, nullptr, 0, reads, reads_cap, pair_read, pairs_cap, region_pairs, n_done, counts);
 }
 
 int pa_bam_copy_reads(pa_bam* b, int64_t* pos, int64_t* pos_end, uint8_t* reverse, int32_t* mapq, int32_t* flags,

@@ -25,7 +25,7 @@ def _declared(*headers):
 
 
 def test_header_symbols_are_exported(lib):
-    declared = _declared("pepper_amd.h", "pepper_amd_encoder.h", "pepper_amd_realign.h")
+    declared = _declared("pepper_amd.h", "pepper_amd_encoder.h", "pepper_amd_realign.h", "pepper_amd_io_device.h")
     assert len(declared) >= 22
     from pepper_amd import _lib
     bound = {name for name, _, _ in _lib.SYMBOLS}

@@ -1,0 +1,159 @@
+"""BGZF members inflated on the device (include/pepper_amd_io_device.h, csrc/inflate.hip) against zlib on the same bytes.
+
+The checker here is zlib itself (the library htslib inflates with): every member is built with zlib's raw DEFLATE at a given
+level / strategy, so the three block types of RFC 1951, several blocks per member, empty stored blocks (sync flushes),
+overlapping matches, incompressible data, the 28-byte end-of-file member and members of the maximum size are all in the
+inputs.  Bit-exact or an error: there is no tolerance.
+"""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from pepper_amd import _lib
+from pepper_amd.bgzf import BgzfError, DeviceInflater, block_table
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EOF_MEMBER = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def member(payload, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_at=(), extra_subfield=False):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    body, last = b"", 0
+    for cut in flush_at:
+        body += c.compress(payload[last:cut]) + c.flush(zlib.Z_SYNC_FLUSH)
+        last = cut
+    body += c.compress(payload[last:]) + c.flush()
+    extra = b"BC\x02\x00\x00\x00"
+    if extra_subfield:                       # another subfield in front of BC: the table must scan for it
+        extra = b"XY\x03\x00abc" + extra
+    bsize = 12 + len(extra) + len(body) + 8
+    assert bsize <= 65536
+    extra = extra[:-2] + struct.pack("<H", bsize - 1)
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", len(extra)) + extra + body +
+            struct.pack("<II", zlib.crc32(payload), len(payload)))
+
+
+def payloads(rng):
+    text = (b"@read/%d\tchr20\t" * 50) + bytes(rng.integers(33, 74, 3000, dtype=np.uint8))
+    quals = bytes(np.clip(rng.normal(20, 6, 60000), 1, 50).astype(np.uint8))
+    nibbles = bytes(rng.choice(np.array([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88],
+                                        np.uint8), 30000))
+    yield "one byte", b"A"
+    yield "zeros", bytes(65280)
+    yield "period 3", b"abc" * 20000
+    yield "period 300", bytes(rng.integers(0, 256, 300, dtype=np.uint8)) * 200
+    yield "random", bytes(rng.integers(0, 256, 65280, dtype=np.uint8))
+    yield "text", text
+    yield "qualities", quals
+    yield "4-bit bases", nibbles
+    yield "record-like", (struct.pack("<iiIIiiii", 5000, 0, 0x12483c0a, 40 << 16 | 700, 6000, -1, -1, 0) + b"read_000123\0" +
+                          bytes(rng.integers(0, 2 ** 31, 700, dtype=np.uint32).view(np.uint8)) + nibbles[:3000] + quals[:6000]) * 4
+
+
+def inflate_and_compare(members, expect):
+    buf = b"".join(members)
+    table = block_table(buf)
+    assert len(table[0]) == len(members)
+    with DeviceInflater() as inf:
+        got = inf.inflate(buf, table)
+    want = b"".join(expect)
+    assert got.size == len(want)
+    assert got.tobytes() == want
+
+
+@pytest.mark.gpu
+def test_every_block_type_and_data_kind():
+    rng = np.random.default_rng(7)
+    members, expect = [], []
+    for name, data in payloads(rng):
+        data = data[:65280]
+        for level, strategy in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
+                                (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)):
+            if level == 0 and len(data) > 65000:
+                data_l = data[:65000]                     # (a stored member carries 5 bytes per block on top of the data)
+            else:
+                data_l = data
+            if strategy == zlib.Z_FIXED and name == "random":
+                data_l = data[:50000]                     # (fixed codes expand random bytes beyond a member)
+            members.append(member(data_l, level, strategy))
+            expect.append(data_l)
+    assert zlib.decompress(members[3][18:-8], -15) == expect[3]          # the builder itself
+    inflate_and_compare(members, expect)
+
+
+@pytest.mark.gpu
+def test_several_blocks_per_member_and_empty_stored_blocks():
+    rng = np.random.default_rng(8)
+    data = bytes(np.clip(rng.normal(30, 8, 60000), 0, 93).astype(np.uint8))
+    members = [member(data, 6, flush_at=(1, 2, 1000, 1000, 33333)), member(data, 1, flush_at=(59999,)),
+               member(data[:40000], 0, flush_at=(7, 8, 9)), member(data, 6, zlib.Z_FIXED, flush_at=(30000,), extra_subfield=True),
+               EOF_MEMBER, member(b"", 6), member(b"", 0), member(b"x" * 258 + b"y", 9)]
+    expect = [data, data, data[:40000], data, b"", b"", b"", b"x" * 258 + b"y"]
+    inflate_and_compare(members, expect)
+
+
+@pytest.mark.gpu
+def test_many_members_of_a_bam_file(tmp_path):
+    """A whole synthetic BAM (tools/synth_bam: libdeflate's encoder, not zlib's) member by member."""
+    tool = os.path.join(ROOT, "tools", "synth_bam")
+    if not os.path.exists(tool):
+        pytest.skip("tools/synth_bam is not built")
+    subprocess.run([tool, str(tmp_path), "300000", "30", "3", "2"], check=True, capture_output=True)
+    bam = str(tmp_path / "reads.bam")
+    raw = open(bam, "rb").read()
+    table = block_table(raw)
+    assert len(table[0]) > 50
+    want = b"".join(zlib.decompress(raw[o:o + n], -15) for o, n in zip(table[0].tolist(), table[1].tolist()))
+    with DeviceInflater() as inf:
+        got = inf.inflate(raw, table, repeats=3)
+        assert inf.last_kernel_ms > 0
+    assert got.tobytes() == want
+    assert got[:4].tobytes() == b"BAM\1"
+
+
+@pytest.mark.gpu
+def test_malformed_members_fail_the_call():
+    rng = np.random.default_rng(9)
+    data = bytes(np.clip(rng.normal(30, 8, 20000), 0, 93).astype(np.uint8))
+    good = member(data, 6)
+    table = block_table(good)
+    with DeviceInflater() as inf:
+        assert inf.inflate(good, table).tobytes() == data
+        short = [a.copy() for a in table]
+        short[1][0] //= 2                                   # the stream stops half way
+        with pytest.raises(_lib.PepperAmdError, match="BGZF block 0"):
+            inf.inflate(good, short)
+        wrong = [a.copy() for a in table]
+        wrong[3][0] -= 1                                    # ISIZE one short of what the stream holds
+        with pytest.raises(_lib.PepperAmdError, match="ISIZE"):
+            inf.inflate(good, wrong)
+        bad = bytearray(good)
+        bad[18] = (bad[18] & 0xf9) | 0x06                   # block type 3
+        with pytest.raises(_lib.PepperAmdError, match="reserved"):
+            inf.inflate(bytes(bad), table)
+        stored = member(data[:100], 0)
+        bad = bytearray(stored)
+        bad[21] ^= 0xff                                     # NLEN no longer the complement of LEN
+        with pytest.raises(_lib.PepperAmdError, match="LEN"):
+            inf.inflate(bytes(bad), block_table(stored))
+        far = [a.copy() for a in table]
+        far[0][0] = len(good)                               # outside the buffer: refused before anything is launched
+        with pytest.raises(_lib.PepperAmdError, match="outside"):
+            inf.inflate(good, far)
+        assert inf.inflate(good, table).tobytes() == data   # the handle is fine afterwards
+
+
+def test_block_table_reads_the_member_headers():
+    a, b = member(b"hello" * 100, 6), member(b"", 6, extra_subfield=True)
+    comp_off, comp_len, out_off, out_len = block_table(a + b + EOF_MEMBER, base=10)
+    assert comp_off.tolist() == [18, len(a) + 18 + 7, len(a) + len(b) + 18]
+    assert out_off.tolist() == [10, 510, 510] and out_len.tolist() == [500, 0, 0]
+    assert zlib.decompress((a + b)[comp_off[0]:comp_off[0] + comp_len[0]], -15) == b"hello" * 100
+    with pytest.raises(BgzfError):
+        block_table(a[:-1])
+    with pytest.raises(BgzfError):
+        block_table(b"\0" * 40)
