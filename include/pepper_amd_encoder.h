@@ -81,7 +81,8 @@ int pa_encoder_run_staged(pa_encoder* e, int64_t* n_candidates);
  * unpack_clip_kernel (one wave per (read, region)) produces what pa_encoder_stage_batch would have been given.  Results are
  * those of the host-clipped form bit for bit.  Nothing in the call waits for the device; pa_encoder_run_staged follows.
  *   arena        what pa_bam_pack_regions wrote (pa_encoder_host_arena returns a page-locked block of the handle for it:
- *                the upload is then asynchronous; any host memory works)
+ *                the upload is then asynchronous; any host memory works); NULL: the span pa_encoder_inflate_bgzf left on
+ *                the device (data_off then need not be aligned)
  *   reads        n_reads table entries; pair_read[region_pairs[r] .. region_pairs[r + 1]) = the reads of region r
  *   regions      per region the generator's ref_start / ref_end (= the fetch range given to the packer) and its reference
  * The `reference` buffers must stay valid until the run returns (deleted bases of candidate alleles are cut from them).
@@ -106,6 +107,18 @@ void* pa_encoder_host_arena(pa_encoder* e, int64_t bytes);      /* page-locked, 
 int pa_encoder_stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_region* regions, const pa_summary_params* params,
                             const uint8_t* arena, int64_t arena_bytes, const pa_packed_read* reads, int32_t n_reads,
                             const int32_t* pair_read, const int32_t* region_pairs);
+/* The arena filled ON THE DEVICE from the file's own bytes: the BGZF members of a span (pa_bam_read_span, include/
+ * pepper_amd_io.h, fills `comp` -- pa_encoder_host_span returns a second page-locked block for it -- and the four tables) are
+ * inflated into the encoder's device arena, one wavefront per member (csrc/inflate.hip; what htslib's bgzf_read_block does
+ * beneath sam_itr_next, bam_handler.cpp:341-372), and copied to host_out (NULL: not) for the host's record walk
+ * (pa_bam_pack_inflated, whose data_off are offsets into exactly these bytes).  pa_encoder_stage_packed with arena = NULL then
+ * takes the bytes where they are.  A malformed member fails the call (PA_ERR_INVALID, the member and the reason in
+ * pa_last_error); the members' CRC32 is not verified, as in the host reader.  Timings: [10] the inflate kernel (HIP events),
+ * [11] the whole call on the host clock (upload, kernel, download). */
+void* pa_encoder_host_span(pa_encoder* e, int64_t bytes);
+int pa_encoder_inflate_bgzf(pa_encoder* e, const uint8_t* comp, int64_t comp_bytes, int32_t n_blocks, const int64_t* comp_off,
+                            const int32_t* comp_len, const int64_t* out_off, const int32_t* out_len, int64_t out_bytes,
+                            uint8_t* host_out);
 /* Host threads of a run's candidate enumeration (one short task per region): 0 = the default (the CPUs the process may use),
  * 1 = the calling thread alone -- what image generation sets, whose workers each drive their own encoder while the other
  * CPUs inflate BGZF blocks. */

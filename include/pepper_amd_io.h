@@ -255,6 +255,34 @@ int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const 
                         pa_packed_read* reads, int32_t reads_cap, int32_t* pair_read, int32_t pairs_cap,
                         int32_t* region_pairs, int32_t* n_done, int64_t* counts);
 
+/* ---- the same packed form over a span inflated elsewhere (on the device: pa_encoder_inflate_bgzf, include/
+ * pepper_amd_encoder.h; or any inflate) ------------------------------------------------------------------------------------
+ * pa_bam_region_span  where the records that can reach [start, stop) of `contig` lie in the file (needs the .bai): from the
+ *                     BGZF member of the linear index's offset for start's 16 kb window (begin_coffset; the first record
+ *                     begins begin_uoffset bytes into that member's data) to end_coffset, the end of the member holding the
+ *                     first indexed record of the window `lookahead_windows` beyond stop's -- or (to_contig_end = 1) where the
+ *                     next contig's records begin / the end of the file.  Nothing of the contig: begin = end = 0.
+ * pa_bam_read_span    the members of [begin, ...) up to the first one starting at or after end_min plus `extra_members` more,
+ *                     read with one pread into buf, and their tables for the inflate (comp_off/comp_len: the raw DEFLATE bytes
+ *                     inside buf; out_off/out_len: the ISIZE bytes laid back to back).  *complete = 0 when buf or the tables
+ *                     were too small for that (the members listed are whole ones either way).
+ * pa_bam_pack_inflated  pa_bam_pack_regions' walk over the inflated bytes, records left in place: data_off = the offset of
+ *                     the record's `CIGAR words | 4-bit bases | qualities` in `data` (not aligned; the device form reads
+ *                     unaligned words), counts[2] = the bytes of the kept slices.  The walk must see a record at or beyond
+ *                     the last stop (or the end of a span that data_is_final says holds the contig's last record); when the
+ *                     span ends earlier the regions closed by then are done (*n_done) and the caller takes a later span for the
+ *                     rest -- none closed: -9.  A record whose CIGAR lives in the CG tag is no single slice: -8, take
+ *                     pa_bam_pack_regions for that batch. */
+int pa_bam_region_span(pa_bam* b, const char* contig, int64_t start, int64_t stop, int32_t lookahead_windows,
+                       int64_t* begin_coffset, int32_t* begin_uoffset, int64_t* end_coffset, int32_t* to_contig_end);
+int pa_bam_read_span(pa_bam* b, int64_t begin, int64_t end_min, int32_t extra_members, uint8_t* buf, int64_t buf_cap,
+                     int64_t* comp_off, int32_t* comp_len, int64_t* out_off, int32_t* out_len, int32_t blocks_cap,
+                     int32_t* n_blocks, int64_t* comp_bytes, int64_t* out_bytes, int32_t* complete);
+int pa_bam_pack_inflated(pa_bam* b, const uint8_t* data, int64_t data_bytes, int64_t first_record, int32_t data_is_final,
+                         const char* contig, int32_t n_regions, const int64_t* start, const int64_t* stop,
+                         int32_t include_supplementary, int32_t min_mapq, pa_packed_read* reads, int32_t reads_cap,
+                         int32_t* pair_read, int32_t pairs_cap, int32_t* region_pairs, int32_t* n_done, int64_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

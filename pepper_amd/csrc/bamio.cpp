@@ -712,10 +712,11 @@ int pack_walk(pa_bam* b, int tid, bool nothing, const uint8_t* mem, int64_t mem_
         const uint8_t* R = nullptr;
         if (mem) {
             // records in place in an inflated span: one that the span cuts off ends the walk like a full table does
-            if (mem_at + 4 > mem_bytes) { cut = mem_at < mem_bytes || !mem_final; break; }
+            // (a final span runs into the next contig's records or to the end of the file: what it cuts off is not this contig's)
+            if (mem_at + 4 > mem_bytes) { cut = !mem_final; break; }
             block_size = le32(mem + mem_at);
             if (block_size < 32) return bam_fail(-6, "corrupt BAM record");
-            if (mem_at + 4 + (int64_t)block_size > mem_bytes) { cut = true; break; }
+            if (mem_at + 4 + (int64_t)block_size > mem_bytes) { cut = !mem_final; break; }
             R = mem + mem_at + 4;
             mem_at += 4 + (int64_t)block_size;
         } else {

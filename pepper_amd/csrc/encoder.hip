@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void unpack_clip_kernel(UnpackArgs a) {
     const PairRec pr = a.pairs[pi];
     const PackedRead rd = a.preads[pr.read];
     const int64_t start = a.region_start[pr.region], stop = start + a.regions[pr.region].L - 1;
-    const uint32_t* cig = reinterpret_cast<const uint32_t*>(a.arena + rd.data_off);
+    typedef uint32_t __attribute__((aligned(1))) word_any;        // (a slice left in place in an inflated span sits at any byte)
+    const word_any* cig = reinterpret_cast<const word_any*>(a.arena + rd.data_off);
     // positions relative to the region's start, clamped far outside it: a read that begins 2^30 bases in front of the region
     // would need operations the check below refuses anyway
     int64_t rel64 = (int64_t)rd.pos - start;
@@ -1020,8 +1021,9 @@ struct pa_variant_batch {
     const int32_t* p_tile_region = nullptr;
     const char* p_ref = nullptr;
     // packed form: the caller's arena as uploaded, the tables, what unpack_clip_kernel reports per region
-    DBuf d_arena, d_meta, d_live, d_pool;
-    HBuf h_arena, h_meta, h_live, h_pool;
+    DBuf d_arena, d_meta, d_live, d_pool, d_comp, d_inf;
+    HBuf h_arena, h_meta, h_live, h_pool, h_comp, h_inf;
+    int64_t resident_bytes = 0;      // inflated bytes pa_encoder_inflate_bgzf left in d_arena (0: none)
     std::vector<int32_t> live;        // reads with a base inside each region (the reference's len(all_reads)) of the last run
     DBuf d_zero;                      // counters [CT_N] | per-region counts [2 n_regions] | tile_count [n_tiles] | tile_fill [n_tiles]: cleared per run
     DBuf d_tile_off, d_sorted, d_mat, d_pass, d_sites, d_votes, d_votes_out, d_sites_dense, d_votes_dense, d_ovf, d_cands, d_img32, d_img8;
@@ -1334,12 +1336,16 @@ int stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_region* regio
                  const uint8_t* arena, int64_t arena_bytes, const pa_packed_read* reads, int32_t n_reads, const int32_t* pair_read,
                  const int32_t* region_pairs) {
     if (!e || n_regions < 0 || (n_regions > 0 && (!regions || !params || !region_pairs)) || arena_bytes < 0 || n_reads < 0 ||
-        (n_reads > 0 && (!arena || !reads || !pair_read)))
+        (n_reads > 0 && (!reads || !pair_read)))
         return pa::set_error(PA_ERR_INVALID, "null argument");
     if (n_regions >= (1 << 22)) return pa::set_error(PA_ERR_INVALID, "more than 4194303 regions in one batch");
     ENC_HIP(hipSetDevice(e->device));
     if (!e->variant) e->variant = new pa_variant_batch();
     pa_variant_batch& b = *e->variant;
+    // arena == NULL: the bytes pa_encoder_inflate_bgzf left on the device
+    const bool resident = arena == nullptr && n_reads > 0;
+    if (resident && (b.resident_bytes <= 0 || arena_bytes > b.resident_bytes))
+        return pa::set_error(PA_ERR_INVALID, "no arena given and no inflated span of that size resident on the device");
     b.staged = false;
     b.ms[8] = b.ms[9] = 0;
     b.regs.assign((size_t)n_regions, RegHost());
@@ -1420,7 +1426,7 @@ int stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_region* regio
             const int32_t ri = pair_read[k];
             if (ri < 0 || ri >= n_reads) return pa::set_error(PA_ERR_INVALID, "pair_read out of range");
             const pa_packed_read& rd = reads[ri];
-            if (rd.n_cigar < 0 || rd.l_seq < 0 || rd.data_off < 0 || (rd.data_off & 3) ||
+            if (rd.n_cigar < 0 || rd.l_seq < 0 || rd.data_off < 0 ||
                 rd.data_off + 4ll * rd.n_cigar + (rd.l_seq + 1) / 2 + rd.l_seq > arena_bytes)
                 return pa::set_error(PA_ERR_INVALID, "packed read " + std::to_string(ri) + " lies outside the arena");
             pairs[k] = PairRec{b.total_bases, ri, r, (int32_t)b.total_ops, 0};
@@ -1439,7 +1445,10 @@ int stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_region* regio
     b.mid = n_regions ? params[0].candidate_window_size / 2 : 16;
 
     hipStream_t st = e->stream;
-    ENC_ALLOC(b.d_arena, (size_t)arena_bytes + 256);
+    if (!resident) {
+        ENC_ALLOC(b.d_arena, (size_t)arena_bytes + 256);
+        b.resident_bytes = 0;
+    }
     ENC_ALLOC(b.d_meta, meta_bytes);
     ENC_ALLOC(b.d_live, ((size_t)n_regions + 2) * 4);
     ENC_ALLOC(b.d_seq, (size_t)b.total_bases + 64);
@@ -1448,7 +1457,7 @@ int stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_region* regio
     ENC_ALLOC(b.d_cig_len, (size_t)b.total_ops * 4 + 1024);
     ENC_ALLOC(b.d_reads, (size_t)n_pairs * sizeof(ReadRec) + 64);
     ENC_HIP(hipEventRecord(e->ev[6], st));
-    if (arena_bytes > 0) ENC_HIP(hipMemcpyAsync(b.d_arena.p, arena, (size_t)arena_bytes, hipMemcpyHostToDevice, st));
+    if (arena_bytes > 0 && !resident) ENC_HIP(hipMemcpyAsync(b.d_arena.p, arena, (size_t)arena_bytes, hipMemcpyHostToDevice, st));
     ENC_HIP(hipMemcpyAsync(b.d_meta.p, hm, meta_bytes, hipMemcpyHostToDevice, st));
     ENC_HIP(hipMemsetAsync(b.d_live.p, 0, ((size_t)n_regions + 2) * 4, st));
     ENC_HIP(hipEventRecord(e->ev[7], st));
@@ -1763,6 +1772,65 @@ void* pa_encoder_host_arena(pa_encoder* e, int64_t bytes) {
     if (!e->variant) e->variant = new pa_variant_batch();
     if (e->stream) (void)hipStreamSynchronize(e->stream);        // (an upload out of the old block may still be running)
     return e->variant->h_arena.ensure((size_t)bytes) ? e->variant->h_arena.p : nullptr;
+}
+
+void* pa_encoder_host_span(pa_encoder* e, int64_t bytes) {
+    if (!e || bytes < 0 || hipSetDevice(e->device) != hipSuccess) return nullptr;
+    if (!e->variant) e->variant = new pa_variant_batch();
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    return e->variant->h_comp.ensure((size_t)bytes) ? e->variant->h_comp.p : nullptr;
+}
+
+// BGZF members -> the encoder's device arena (inflate.hip: one wavefront per member), and a copy for the host's record walk
+int pa_encoder_inflate_bgzf(pa_encoder* e, const uint8_t* comp, int64_t comp_bytes, int32_t n_blocks, const int64_t* comp_off,
+                            const int32_t* comp_len, const int64_t* out_off, const int32_t* out_len, int64_t out_bytes,
+                            uint8_t* host_out) {
+    if (!e || n_blocks < 0 || comp_bytes < 0 || out_bytes < 0 ||
+        (n_blocks > 0 && (!comp || !comp_off || !comp_len || !out_off || !out_len)))
+        return pa::set_error(PA_ERR_INVALID, "null or negative argument");
+    for (int32_t k = 0; k < n_blocks; ++k)
+        if (comp_off[k] < 0 || comp_len[k] < 0 || comp_off[k] + comp_len[k] > comp_bytes || out_off[k] < 0 || out_len[k] < 0 ||
+            out_off[k] + out_len[k] > out_bytes)
+            return pa::set_error(PA_ERR_INVALID, "BGZF block " + std::to_string(k) + " lies outside the buffers");
+    ENC_HIP(hipSetDevice(e->device));
+    if (!e->variant) e->variant = new pa_variant_batch();
+    pa_variant_batch& b = *e->variant;
+    b.resident_bytes = 0;
+    b.ms[10] = b.ms[11] = 0;
+    if (n_blocks == 0) return PA_OK;
+    hipStream_t st = e->stream;
+    const size_t nb = (size_t)n_blocks, table_bytes = nb * 28;
+    ENC_ALLOC(b.d_arena, (size_t)out_bytes + 256);
+    ENC_ALLOC(b.d_comp, (size_t)comp_bytes + 64);
+    ENC_ALLOC(b.d_inf, table_bytes);
+    if (!b.h_inf.ensure(table_bytes)) return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed in the inflate tables");
+    char* hm = b.h_inf.as<char>();
+    std::memcpy(hm, comp_off, nb * 8);
+    std::memcpy(hm + nb * 8, out_off, nb * 8);
+    std::memcpy(hm + nb * 16, comp_len, nb * 4);
+    std::memcpy(hm + nb * 20, out_len, nb * 4);
+    char* dm = b.d_inf.as<char>();
+    const auto t0 = std::chrono::steady_clock::now();
+    ENC_HIP(hipMemcpyAsync(b.d_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
+    ENC_HIP(hipMemcpyAsync(dm, hm, nb * 24, hipMemcpyHostToDevice, st));
+    ENC_HIP(hipEventRecord(e->ev[10], st));
+    pa::launch_bgzf_inflate(st, b.d_comp.as<uint8_t>(), reinterpret_cast<const int64_t*>(dm), reinterpret_cast<const int32_t*>(dm + nb * 16),
+                            reinterpret_cast<const int64_t*>(dm + nb * 8), reinterpret_cast<const int32_t*>(dm + nb * 20),
+                            b.d_arena.as<uint8_t>(), reinterpret_cast<int32_t*>(dm + nb * 24), n_blocks);
+    ENC_HIP(hipGetLastError());
+    ENC_HIP(hipEventRecord(e->ev[11], st));
+    ENC_HIP(hipMemcpyAsync(hm + nb * 24, dm + nb * 24, nb * 4, hipMemcpyDeviceToHost, st));
+    if (host_out && out_bytes > 0) ENC_HIP(hipMemcpyAsync(host_out, b.d_arena.p, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
+    ENC_HIP(hipStreamSynchronize(st));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, e->ev[10], e->ev[11]) == hipSuccess) b.ms[10] = ms;
+    b.ms[11] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const int32_t* status = reinterpret_cast<const int32_t*>(hm + nb * 24);
+    for (int32_t k = 0; k < n_blocks; ++k)
+        if (status[k] != 0)
+            return pa::set_error(PA_ERR_INVALID, "BGZF block " + std::to_string(k) + ": " + pa::inflate_status_text(status[k]));
+    b.resident_bytes = out_bytes;
+    return PA_OK;
 }
 
 int pa_encoder_stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_region* regions, const pa_summary_params* params,

@@ -209,6 +209,7 @@ class ImageGenerationUtils:
             params = (options.min_snp_baseq, options.min_indel_baseq, options.snp_frequency, options.insert_frequency,
                       options.delete_frequency, options.min_coverage_threshold, options.snp_candidate_frequency_threshold,
                       options.indel_candidate_frequency_threshold, options.candidate_support_threshold, options.skip_indels)
+            device_inflate = os.environ.get("PEPPER_AMD_DEVICE_INFLATE", "1") != "0"
             g0 = 0
             while g0 < len(intervals):
                 # ADJACENT intervals of one contig, ascending (the packer walks every record between the first and the last
@@ -222,14 +223,23 @@ class ImageGenerationUtils:
                 chr_name = group[0][0]
                 regions = [(max(0, s - safe), e + safe) for _, s, e in group]
                 t0 = time.perf_counter()
-                try:
-                    n_done, region_pairs, counts = enc.pack(bam_handler, chr_name, [r[0] for r in regions], [r[1] for r in regions],
-                                                            options.include_supplementary, options.min_mapq)
-                except Exception as err:
-                    if "do not fit" not in str(err):
-                        raise
-                    n_done = 0                       # one interval's reads outgrow the arena
-                t0 = lap("bam_pack", t0)
+                # the BGZF members inflated on the device where the BAM has an index (PEPPER_AMD_DEVICE_INFLATE=0: on the host);
+                # a batch the device form cannot take (pack_device's docstring) goes through the host packer
+                on_device = enc.pack_device(bam_handler, chr_name, [r[0] for r in regions], [r[1] for r in regions],
+                                            options.include_supplementary, options.min_mapq, laps=mine) if device_inflate else None
+                resident = on_device is not None
+                if resident:
+                    n_done, region_pairs, counts = on_device
+                    t0 = time.perf_counter()
+                else:
+                    try:
+                        n_done, region_pairs, counts = enc.pack(bam_handler, chr_name, [r[0] for r in regions], [r[1] for r in regions],
+                                                                options.include_supplementary, options.min_mapq)
+                    except Exception as err:
+                        if "do not fit" not in str(err):
+                            raise
+                        n_done = 0                       # one interval's reads outgrow the arena
+                    t0 = lap("bam_pack", t0)
                 if n_done == 0:
                     host_clipped(output_hdf_file, group[:1])
                     g0 += 1
@@ -246,7 +256,7 @@ class ImageGenerationUtils:
                 t0 = lap("fasta", t0)
                 try:
                     outs, live = enc.encode(regions, references, region_pairs, counts, params, [(s, e) for _, s, e in group],
-                                            ImageSizeOptions.CANDIDATE_WINDOW_SIZE, ImageSizeOptions.IMAGE_HEIGHT)
+                                            ImageSizeOptions.CANDIDATE_WINDOW_SIZE, ImageSizeOptions.IMAGE_HEIGHT, resident=resident)
                 except _lib.PepperAmdError as err:
                     if getattr(err, "code", 0) != _lib.PA_ERR_UNSUPPORTED:
                         raise
@@ -259,6 +269,10 @@ class ImageGenerationUtils:
                         write(output_hdf_file, chr_name, _start, _end, out)
                 lap("hdf5", t0)
                 g0 += n_done
+            if stats is not None and enc.inflated_bytes:
+                mine["inflate_kernel"] = mine.get("inflate_kernel", 0.0) + enc.inflate_ms / 1e3
+                mine["inflated_bytes"] = mine.get("inflated_bytes", 0.0) + enc.inflated_bytes
+                enc.inflate_ms, enc.inflated_bytes = 0.0, 0
             enc.release()
             t_close = time.perf_counter()
         lap("close", t_close)

@@ -287,6 +287,10 @@ class PackedEncoder(object):
         self.arena = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(arena_bytes,))
         self.reads = np.zeros(max_reads, PACKED_READ)
         self.pair_read = np.zeros(max_pairs, np.int32)
+        self.span = None                # page-locked block for a file span's BGZF members (pack_device), allocated on first use
+        self.tables = None
+        self.inflate_ms = 0.0           # device time of the inflate kernels of this object's pack_device calls
+        self.inflated_bytes = 0
 
     def close(self):
         if self.enc:
@@ -304,8 +308,65 @@ class PackedEncoder(object):
         """-> (n_done, region_pairs, (n_reads, n_pairs, arena_bytes)): BAM_handler.pack_regions into this object's buffers."""
         return bam_handler.pack_regions(contig, starts, stops, include_supplementary, min_mapq, self.arena, self.reads, self.pair_read)
 
+    def pack_device(self, bam_handler, contig, starts, stops, include_supplementary, min_mapq, lookahead_windows=4, laps=None):
+        """The same tables with the BGZF members inflated ON THE DEVICE (pa_encoder_inflate_bgzf) into the encoder's arena and
+        the records left in place there: the file span of the regions' reads (BAM index) is read as it is, uploaded, inflated
+        one wavefront per member, and walked on the host in a downloaded copy (headers, filters, region test -- no inflate, no
+        copy).  -> (n_done, region_pairs, counts) for encode(..., resident=True), or None when the batch has to take pack():
+        no index, a span larger than the arena even for one region, a record with its CIGAR in the CG tag, reads longer than
+        the span's lookahead."""
+        import time
+        from pepper_amd.variant.bam import BamError
+        if not bam_handler.has_index():
+            return None
+        if self.span is None:
+            cap = self.arena.nbytes + (1 << 20)
+            ptr = self.lib.pa_encoder_host_span(self.enc, cap)
+            if not ptr:
+                raise _lib.PepperAmdError("page-locked span block of %d bytes could not be allocated" % cap)
+            self.span = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(cap,))
+            nb = max(4096, self.arena.nbytes // 4096)
+            self.tables = (np.zeros(nb, np.int64), np.zeros(nb, np.int32), np.zeros(nb, np.int64), np.zeros(nb, np.int32))
+        t0 = time.perf_counter()
+        n = len(starts)
+        while n >= 1:
+            begin, first, end, final = bam_handler.region_span(contig, int(starts[0]), int(stops[n - 1]), lookahead_windows)
+            if end <= begin:                         # no record of the contig: every region is done, with nothing in it
+                return n, np.zeros(n + 1, np.int32), (0, 0, 0)
+            n_blocks, comp_bytes, out_bytes, complete = bam_handler.read_span(begin, end, self.span, self.tables, 1)
+            if complete and out_bytes + 256 <= self.arena.nbytes:
+                break
+            n //= 2
+        else:
+            return None
+        if laps is not None:
+            laps["bam_span_read"] = laps.get("bam_span_read", 0.0) + time.perf_counter() - t0
+            t0 = time.perf_counter()
+        comp_off, comp_len, out_off, out_len = self.tables
+        _lib.check(self.lib.pa_encoder_inflate_bgzf(self.enc, self.span.ctypes.data, comp_bytes, n_blocks, comp_off.ctypes.data,
+                                                    comp_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data, out_bytes,
+                                                    self.arena.ctypes.data))
+        ms = np.zeros(12, np.float64)
+        _lib.check(self.lib.pa_encoder_last_timing(self.enc, ms.ctypes.data, 12))
+        self.inflate_ms += float(ms[10])
+        self.inflated_bytes += int(out_bytes)
+        if laps is not None:
+            laps["bam_inflate_device"] = laps.get("bam_inflate_device", 0.0) + time.perf_counter() - t0
+            t0 = time.perf_counter()
+        try:
+            n_done, region_pairs, counts = bam_handler.pack_inflated(self.arena, out_bytes, first, final, contig, starts[:n], stops[:n],
+                                                                     include_supplementary, min_mapq, self.reads, self.pair_read)
+        except BamError as err:
+            if getattr(err, "code", 0) in (-7, -8, -9):
+                return None
+            raise
+        finally:
+            if laps is not None:
+                laps["bam_walk"] = laps.get("bam_walk", 0.0) + time.perf_counter() - t0
+        return n_done, region_pairs, (counts[0], counts[1], int(out_bytes))
+
     def encode(self, regions, references, region_pairs, counts, params, candidate_regions, candidate_window_size=32, feature_size=26,
-               want_int32=False):
+               want_int32=False, resident=False):
         """regions: [(ref_start, ref_end)] of the packed run (the fetch ranges), references: their sequences (bytes / str),
         region_pairs / counts: what pack() returned, params: the ten thresholds of generate_summary in order,
         candidate_regions: [(start, end)].  -> (one dict of arrays per region as generate_summary_arrays, reads per region)."""
@@ -322,8 +383,10 @@ class PackedEncoder(object):
                     int(feature_size)) for lo, hi in candidate_regions])
         region_pairs = np.ascontiguousarray(region_pairs[:n + 1], np.int32)
         n_reads, _n_pairs, arena_bytes = counts
+        # resident: the arena is the inflated span pack_device left on the device
         _lib.check(self.lib.pa_encoder_stage_packed(self.enc, n, ctypes.cast(regs, ctypes.c_void_p), ctypes.cast(pars, ctypes.c_void_p),
-                                                    self.arena.ctypes.data, int(arena_bytes), self.reads.ctypes.data, int(n_reads),
+                                                    None if (resident and n_reads > 0) else self.arena.ctypes.data,
+                                                    int(arena_bytes), self.reads.ctypes.data, int(n_reads),
                                                     self.pair_read.ctypes.data, region_pairs.ctypes.data))
         batch = StagedBatch.__new__(StagedBatch)
         batch.lib, batch.enc, batch.n_regions = self.lib, self.enc, n

@@ -31,6 +31,13 @@ SYMBOLS = [
     ("pa_bam_copy_reads", ctypes.c_int, [c_void_p] + [c_void_p] * 13),
     ("pa_bam_pack_regions", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64,
                                            c_void_p, c_int32, c_void_p, c_int32, c_void_p, ctypes.POINTER(c_int32), c_void_p]),
+    ("pa_bam_region_span", ctypes.c_int, [c_void_p, c_char_p, c_int64, c_int64, c_int32, P64, ctypes.POINTER(c_int32), P64,
+                                          ctypes.POINTER(c_int32)]),
+    ("pa_bam_read_span", ctypes.c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int32, ctypes.POINTER(c_int32), P64, P64, ctypes.POINTER(c_int32)]),
+    ("pa_bam_pack_inflated", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_char_p, c_int32, c_void_p, c_void_p,
+                                            c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
+                                            ctypes.POINTER(c_int32), c_void_p]),
 ]
 _bound = False
 
@@ -52,7 +59,9 @@ def _lib():
 
 def _check(rc):
     if rc < 0:
-        raise BamError(_lib().pa_bam_last_error().decode())
+        err = BamError(_lib().pa_bam_last_error().decode())
+        err.code = rc
+        raise err
     return rc
 
 
@@ -200,6 +209,41 @@ class BAM_handler(object):
                                           int(bool(include_supplementary)), int(min_mapq), arena.ctypes.data, arena.nbytes,
                                           reads.ctypes.data, len(reads), pair_read.ctypes.data, len(pair_read),
                                           region_pairs.ctypes.data, ctypes.byref(n_done), counts.ctypes.data))
+        return n_done.value, region_pairs, (int(counts[0]), int(counts[1]), int(counts[2]))
+
+    # ---- the packed form over spans inflated on the device (include/pepper_amd_io.h) ----
+    def region_span(self, chromosome, start, stop, lookahead_windows=4):
+        """-> (begin_coffset, begin_uoffset, end_coffset, to_contig_end): the file span of the records reaching [start, stop)."""
+        b, u, e, f = c_int64(), c_int32(), c_int64(), c_int32()
+        _check(_lib().pa_bam_region_span(self._h, str(chromosome).encode(), int(start), int(stop), int(lookahead_windows),
+                                         ctypes.byref(b), ctypes.byref(u), ctypes.byref(e), ctypes.byref(f)))
+        return b.value, u.value, e.value, bool(f.value)
+
+    def read_span(self, begin, end_min, buf, tables, extra_members=1):
+        """Members of the file span into `buf` (uint8 array) and their inflate tables into `tables` = (comp_off int64, comp_len
+        int32, out_off int64, out_len int32) -> (n_blocks, comp_bytes, out_bytes, complete)."""
+        comp_off, comp_len, out_off, out_len = tables
+        n, cb, ob, done = c_int32(), c_int64(), c_int64(), c_int32()
+        _check(_lib().pa_bam_read_span(self._h, int(begin), int(end_min), int(extra_members), buf.ctypes.data, buf.nbytes,
+                                       comp_off.ctypes.data, comp_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
+                                       min(len(comp_off), len(comp_len), len(out_off), len(out_len)), ctypes.byref(n),
+                                       ctypes.byref(cb), ctypes.byref(ob), ctypes.byref(done)))
+        return n.value, cb.value, ob.value, bool(done.value)
+
+    def pack_inflated(self, data, data_bytes, first_record, data_is_final, chromosome, starts, stops, include_supplementary,
+                      min_mapq, reads, pair_read):
+        """pa_bam_pack_inflated: pack_regions' tables over an inflated span (`data`: uint8 array), records left in place."""
+        starts = np.ascontiguousarray(starts, np.int64)
+        stops = np.ascontiguousarray(stops, np.int64)
+        n = len(starts)
+        region_pairs = np.zeros(n + 1, np.int32)
+        counts = np.zeros(3, np.int64)
+        n_done = c_int32()
+        _check(_lib().pa_bam_pack_inflated(self._h, data.ctypes.data, int(data_bytes), int(first_record), int(bool(data_is_final)),
+                                           str(chromosome).encode(), n, starts.ctypes.data, stops.ctypes.data,
+                                           int(bool(include_supplementary)), int(min_mapq), reads.ctypes.data, len(reads),
+                                           pair_read.ctypes.data, len(pair_read), region_pairs.ctypes.data, ctypes.byref(n_done),
+                                           counts.ctypes.data))
         return n_done.value, region_pairs, (int(counts[0]), int(counts[1]), int(counts[2]))
 
     def get_reads(self, chromosome, start, stop, include_supplementary, min_mapq=0, min_baseq=0):

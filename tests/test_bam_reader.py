@@ -315,3 +315,109 @@ def test_pack_regions_lists_what_get_reads_returns(tmp_path):
         bam.pack_regions("chrB", starts[::-1], stops[::-1], False, 0, np.zeros(1 << 20, np.uint8), np.zeros(4000, PACKED_READ),
                          np.zeros(8000, np.int32))
     bam.close()
+
+
+def _inflate_span(bam, chromosome, start, stop, lookahead, buf_bytes=1 << 26, blocks=4096, extra=1):
+    """region_span + read_span + zlib on every member (the host stand-in of the device inflate) -> (data, first, final, complete)."""
+    import zlib
+    begin, first, end, final = bam.region_span(chromosome, start, stop, lookahead)
+    buf = np.zeros(buf_bytes, np.uint8)
+    tables = (np.zeros(blocks, np.int64), np.zeros(blocks, np.int32), np.zeros(blocks, np.int64), np.zeros(blocks, np.int32))
+    n, comp_bytes, out_bytes, complete = bam.read_span(begin, end, buf, tables, extra)
+    data = np.zeros(max(out_bytes, 1), np.uint8)
+    for k in range(n):
+        o, l, at, m = int(tables[0][k]), int(tables[1][k]), int(tables[2][k]), int(tables[3][k])
+        got = zlib.decompress(buf[o:o + l].tobytes(), -15)
+        assert len(got) == m
+        data[at:at + m] = np.frombuffer(got, np.uint8)
+    return data, out_bytes, first, final, complete, n
+
+
+def test_pack_inflated_equals_pack_regions(tmp_path):
+    """The span form (pa_bam_region_span / read_span / pack_inflated: records left in place in an inflated stretch of the file)
+    lists exactly pack_regions' reads and pairs; a span that stops short closes fewer regions; a contig's tail runs to the
+    next contig's first member; unaligned slices."""
+    from pepper_amd.variant.bam import PACKED_READ
+    rng = np.random.default_rng(47)
+    reads = _mixed_reads(rng, 200000, 1500, (300, 9000))
+    other = _mixed_reads(rng, 9000, 40, (200, 900))
+    last = _mixed_reads(rng, 30000, 100, (200, 3000))
+    path = str(tmp_path / "s.bam")
+    bu.write_bam(path, [("chrA", 9000), ("chrB", 200000), ("chrC", 30000), ("chrD", 1000)], {0: other, 1: reads, 2: last}, flush_every=23)
+    bam = BAM_handler(path)
+
+    def tables():
+        return np.zeros(8000, PACKED_READ), np.zeros(16000, np.int32)
+
+    def compare(chromosome, starts, stops, lookahead, include_supp=False, min_mapq=0):
+        starts, stops = np.asarray(starts, np.int64), np.asarray(stops, np.int64)
+        data, data_bytes, first, final, complete, _ = _inflate_span(bam, chromosome, int(starts[0]), int(stops[-1]), lookahead)
+        assert complete
+        t1, p1 = tables()
+        n1, rp1, (nr1, np1, used1) = bam.pack_inflated(data, data_bytes, first, final, chromosome, starts, stops, include_supp, min_mapq,
+                                                        t1, p1)
+        arena = np.zeros(1 << 25, np.uint8)
+        t2, p2 = tables()
+        n2, rp2, (nr2, np2, used2) = bam.pack_regions(chromosome, starts[:n1], stops[:n1], include_supp, min_mapq, arena, t2, p2)
+        assert n2 == n1 and nr1 == nr2 and np1 == np2
+        assert rp1[:n1 + 1].tolist() == rp2[:n1 + 1].tolist() and p1[:np1].tolist() == p2[:np2].tolist()
+        odd = 0
+        for k in range(nr1):
+            a, b = bu.unpack_packed_read(data, t1[k]), bu.unpack_packed_read(arena, t2[k])
+            assert a == b
+            odd += int(t1[k]["data_off"]) & 3 != 0
+        return n1, nr1, odd
+
+    edges = list(range(20000, 90000, 5000))
+    n, n_reads, odd = compare("chrB", [a - 50 for a in edges[:-1]], [b + 50 for b in edges[1:]], 4)
+    assert n == len(edges) - 1 and n_reads > 50 and odd > 10            # (records do not sit on word boundaries)
+    assert compare("chrB", [100000], [101000], 4, True, 5)[0] == 1
+    assert compare("chrB", [190000, 195000], [195000, 200000], 4)[0] == 2  # the contig's tail: the span runs to chrC's first record
+    assert compare("chrC", [0, 10000, 20000], [10000, 20000, 30000], 4)[0] == 3   # the last contig with records: to the end of the file
+    assert compare("chrA", [0], [9000], 0)[0] == 1
+    # a contig without records: an empty span, every region done with nothing in it
+    begin, first, end, final = bam.region_span("chrD", 0, 1000)
+    assert (begin, end, final) == (0, 0, True)
+    t, p = tables()
+    n_done, rp, counts = bam.pack_inflated(np.zeros(1, np.uint8), 0, 0, True, "chrD", [0], [1000], False, 0, t, p)
+    assert n_done == 1 and counts == (0, 0, 0)
+    # a span that stops short of the last region's reads: the regions closed by then are done, the rest is the caller's
+    starts, stops = np.arange(20000, 120000, 10000), np.arange(30000, 130000, 10000)
+    data, data_bytes, first, final, complete, n_members = _inflate_span(bam, "chrB", 20000, 60000, 0)
+    assert not final
+    t, p = tables()
+    n_done, rp, (nr, npairs, _) = bam.pack_inflated(data, data_bytes, first, False, "chrB", starts, stops, False, 0, t, p)
+    assert 4 <= n_done < len(starts)
+    arena = np.zeros(1 << 25, np.uint8)
+    t2, p2 = tables()
+    n2, rp2, (nr2, np2, _) = bam.pack_regions("chrB", starts[:n_done], stops[:n_done], False, 0, arena, t2, p2)
+    assert (n2, nr2, np2) == (n_done, nr, npairs) and p[:npairs].tolist() == p2[:np2].tolist()
+    # ... and one that ends before the first region closes is refused
+    with pytest.raises(BamError, match="longer span") as e:
+        bam.pack_inflated(data, 70000, first, False, "chrB", [20000], [150000], False, 0, t, p)
+    assert e.value.code == -9
+    # buffers too small for the span: whole members only, complete = False
+    assert not _inflate_span(bam, "chrB", 20000, 90000, 4, buf_bytes=200000)[4]
+    assert not _inflate_span(bam, "chrB", 20000, 90000, 4, blocks=3)[4]
+    # the full tables: stops at a region boundary like pack_regions
+    data, data_bytes, first, final, complete, _ = _inflate_span(bam, "chrB", 20000, 90000, 4)
+    small = np.zeros(60, PACKED_READ)
+    n_done, rp, (nr, npairs, _) = bam.pack_inflated(data, data_bytes, first, final, "chrB", [a - 50 for a in edges[:-1]],
+                                                    [b + 50 for b in edges[1:]], False, 0, small, np.zeros(16000, np.int32))
+    assert 1 <= n_done < len(edges) - 1 and nr <= 60
+    bam.close()
+
+
+def test_pack_inflated_refuses_a_cigar_in_the_cg_tag(tmp_path):
+    rng = np.random.default_rng(48)
+    seq = "".join("ACGT"[k] for k in rng.integers(0, 4, 2000))
+    rec = dict(name="long", flag=0, pos=10, mapq=60, cigar=[(0, 500), (2, 3), (0, 1500)], seq=seq, qual=[30] * len(seq), long_cigar=True)
+    path = str(tmp_path / "cg.bam")
+    bu.write_bam(path, [("chrA", 400000)], {0: [rec]})
+    bam = BAM_handler(path)
+    from pepper_amd.variant.bam import PACKED_READ
+    data, data_bytes, first, final, complete, _ = _inflate_span(bam, "chrA", 0, 1000, 1)
+    with pytest.raises(BamError) as e:
+        bam.pack_inflated(data, data_bytes, first, final, "chrA", [0], [1000], False, 0, np.zeros(10, PACKED_READ), np.zeros(10, np.int32))
+    assert e.value.code == -8
+    bam.close()

@@ -50,16 +50,26 @@ def _same(a, b):
 
 
 def _both(monkeypatch, tmp_path, tag, make_options, **env):
+    """The packed form twice -- BGZF members inflated on the device (the default with an index) and on the host -- and the
+    host-clipped form: the first two must agree with each other here, the caller compares with the third."""
     from pepper_amd.variant.ImageGenerationUI import ImageGenerationUtils
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     monkeypatch.setenv("PEPPER_AMD_PACKED_READS", "1")
+    monkeypatch.setenv("PEPPER_AMD_DEVICE_INFLATE", "1")
     stats = {}
     ImageGenerationUtils.generate_images(make_options(str(tmp_path / (tag + "_packed")), stage_seconds=stats))
+    monkeypatch.setenv("PEPPER_AMD_DEVICE_INFLATE", "0")
+    stats_host = {}
+    ImageGenerationUtils.generate_images(make_options(str(tmp_path / (tag + "_packed_host")), stage_seconds=stats_host))
     monkeypatch.setenv("PEPPER_AMD_PACKED_READS", "0")
     ImageGenerationUtils.generate_images(make_options(str(tmp_path / (tag + "_host"))))
-    assert "encode" in stats                       # the packed path really ran
-    return _groups(str(tmp_path / (tag + "_packed"))), _groups(str(tmp_path / (tag + "_host")))
+    assert "encode" in stats and "encode" in stats_host                       # the packed path really ran
+    assert "bam_inflate_device" in stats and stats.get("inflated_bytes", 0) > 0 and "bam_inflate_device" not in stats_host
+    assert "bam_pack" in stats_host
+    packed = _groups(str(tmp_path / (tag + "_packed")))
+    _same(packed, _groups(str(tmp_path / (tag + "_packed_host"))))
+    return packed, _groups(str(tmp_path / (tag + "_host")))
 
 
 def _write(tmp_path, refs, reads_by_tid, **kw):
@@ -157,4 +167,66 @@ def test_packed_form_refuses_what_it_cannot_walk(tmp_path):
         with pytest.raises(_lib.PepperAmdError) as err:
             enc.encode([(0, 1000)], ["A" * 1001], region_pairs, counts, params, [(100, 900)])
         assert err.value.code == code
+        # the same records left in place in the span inflated on the device
+        n_done, region_pairs, counts = enc.pack_device(BAM_handler(path), "ctg", [0], [1000], False, 0)
+        assert n_done == 1 and counts[0] == 2
+        with pytest.raises(_lib.PepperAmdError) as err:
+            enc.encode([(0, 1000)], ["A" * 1001], region_pairs, counts, params, [(100, 900)], resident=True)
+        assert err.value.code == code
         enc.close()
+
+
+def test_device_inflated_span_gives_the_host_packers_summaries(tmp_path):
+    """PackedEncoder.pack_device (span read, inflate on the device, records walked in place) against PackedEncoder.pack for the
+    same run of regions: the same tables (slices at any byte offset instead of copied to word boundaries) and the same encoder
+    output; a BAM without an index and a record with its CIGAR in the CG tag send the batch to the host packer (None)."""
+    from pepper_amd.variant.bam import BAM_handler
+    from pepper_amd.variant.PEPPER_VARIANT import PackedEncoder
+    rng = np.random.default_rng(913)
+    ref = pu.random_reference(rng, 60000)
+    sites = {int(p): ("ACGT"[("ACGT".index(ref[p]) + 1) % 4], 0.5) for p in rng.choice(np.arange(300, 59000), 150, replace=False)}
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=2500, read_len=(500, 6000), snp_sites=sites,
+                              indel_sites={20000: ("I", "ACGTACGTTTGACA", 0.5), 30000: ("D", 12, 0.5)}, clip_rate=0.3)
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    for i, r in enumerate(reads):
+        r["name"] = "read_%05d" % i
+    bam, _ = _write(tmp_path, [("ctg", ref)], {0: reads}, flush_every=19)
+    params = (1, 1, 0.1, 0.15, 0.15, 3, 0.1, 0.12, 2, False)
+    edges = list(range(5000, 56000, 5000))
+    starts, stops = [a - 100 for a in edges[:-1]], [b + 100 for b in edges[1:]]
+    regions = list(zip(starts, stops))
+    refs = [ref[a:b + 1] for a, b in regions]
+    cands = list(zip(edges[:-1], edges[1:]))
+    enc = PackedEncoder(0, arena_bytes=64 << 20)
+    handler = BAM_handler(bam)
+    n_done, rp_h, counts_h = enc.pack(handler, "ctg", starts, stops, False, 1)
+    assert n_done == len(starts)
+    want, live_h = enc.encode(regions, refs, rp_h, counts_h, params, cands)
+    laps = {}
+    n_done, rp_d, counts_d = enc.pack_device(handler, "ctg", starts, stops, False, 1, laps=laps)
+    assert n_done == len(starts) and counts_d[:2] == counts_h[:2] and rp_d.tolist() == rp_h.tolist()
+    assert {"bam_span_read", "bam_inflate_device", "bam_walk"} <= set(laps) and enc.inflated_bytes == counts_d[2] > 0
+    got, live_d = enc.encode(regions, refs, rp_d, counts_d, params, cands, resident=True)
+    assert live_d.tolist() == live_h.tolist() and sum(len(g["candidates"]) for g in got) > 100
+    for g, w in zip(got, want):
+        assert sorted(g) == sorted(w)
+        for key in g:
+            assert (g[key] == w[key]) if isinstance(g[key], list) else np.array_equal(g[key], w[key]), key
+    # a resident span is used once: the next staging without one must bring its arena
+    from pepper_amd import _lib
+    n_done, rp_h, counts_h = enc.pack(handler, "ctg", starts[:2], stops[:2], False, 1)
+    again, _ = enc.encode(regions[:2], refs[:2], rp_h, counts_h, params, cands[:2])
+    with pytest.raises(_lib.PepperAmdError, match="resident"):
+        enc.encode(regions[:2], refs[:2], rp_h, counts_h, params, cands[:2], resident=True)
+    for key in again[0]:
+        assert (again[0][key] == want[0][key]) if isinstance(want[0][key], list) else np.array_equal(again[0][key], want[0][key])
+    # no index: the host packer's batch
+    os.remove(bam + ".bai")
+    assert enc.pack_device(BAM_handler(bam), "ctg", starts, stops, False, 1) is None
+    enc.close()
+    cg = [dict(reads[k], long_cigar=True) if k == 40 else reads[k] for k in range(len(reads))]
+    bam2 = str(tmp_path / "cg.bam")
+    bu.write_bam(bam2, [("ctg", len(ref))], {0: cg})
+    enc = PackedEncoder(0, arena_bytes=64 << 20)
+    assert enc.pack_device(BAM_handler(bam2), "ctg", starts, stops, False, 1) is None
+    enc.close()
