@@ -265,7 +265,8 @@ int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const 
  * pa_bam_read_span    the members of [begin, ...) up to the first one starting at or after end_min plus `extra_members` more,
  *                     read with one pread into buf, and their tables for the inflate (comp_off/comp_len: the raw DEFLATE bytes
  *                     inside buf; out_off/out_len: the ISIZE bytes laid back to back).  *complete = 0 when buf or the tables
- *                     were too small for that (the members listed are whole ones either way).
+ *                     were too small for that (the members listed are whole ones either way), 1 when covered, 3 when
+ *                     the span also ran to the end of the file (the inflated data is then final for pack_inflated).
  * pa_bam_pack_inflated  pa_bam_pack_regions' walk over the inflated bytes, records left in place: data_off = the offset of
  *                     the record's `CIGAR words | 4-bit bases | qualities` in `data` (not aligned; the device form reads
  *                     unaligned words), counts[2] = the bytes of the kept slices.  The walk must see a record at or beyond

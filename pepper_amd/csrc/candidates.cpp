@@ -106,12 +106,15 @@ int64_t pa_candidates_select_format(const pa_candidate_rules* rules, const char*
         const int64_t code_len = allele_offsets[i + 1] - allele_offsets[i] - separator_bytes;
         if (code_len < 1) continue;
         const int kind = code[0] - '1';                                // '1' SNP, '2' insert, '3' delete
-        if (kind < 0 || kind > 2) continue;
         const char* allele = code + 1;
         const int64_t allele_len = code_len - 1;
         bool plain = true;
         for (int64_t k = 0; k < allele_len; ++k) plain = plain && is_base((unsigned char)allele[k]);
         if (!plain) continue;
+        // the reference divides support by depth for every valid allele, whatever its type (CandidateFinder.py:478): float
+        // division by zero there, so the batch goes to the caller's Python path, which raises it
+        if (depth[i] == 0) return -2;
+        if (kind < 0 || kind > 2) continue;
         const float p0 = prediction[3 * i], p1 = prediction[3 * i + 1], p2 = prediction[3 * i + 2];
         if (std::isnan(p0) || std::isnan(p1) || std::isnan(p2)) return -2;     // numpy's argmax / maximum rules for NaN: the caller's Python path
         const int g = (p1 > p0) ? ((p2 > p1) ? 2 : 1) : ((p2 > p0) ? 2 : 0);   // first maximum
@@ -122,7 +125,6 @@ int64_t pa_candidates_select_format(const pa_candidate_rules* rules, const char*
         if (!by_probability) {
             const double above = rules->report_above_freq[kind];
             if (!(0 < above)) continue;
-            if (depth[i] == 0) return -2;                              // float division by zero in the reference: the caller's Python path raises it
             if (!(above <= (double)support[i] / (double)depth[i])) continue;
         }
         // a deletion swaps roles: the deleted stretch is REF, the anchor base ALT (CandidateFinder.py:490-501)

@@ -132,17 +132,18 @@ def _select_batch(options, fasta_handler, file_name, batch_key, cols, leftovers)
         if rb not in bases:                       # (one upper-cased character or "")
             continue
         code = alleles[i]
-        entry = thresholds.get(code[0:1])
-        if entry is None:
-            continue
         allele = code[1:]
         if not set(allele) <= bases:
+            continue
+        vaf = float(supports[i]) / float(depth[i])    # for every valid allele, whatever its type: CandidateFinder.py:478 (depth 0 raises)
+        entry = thresholds.get(code[0:1])
+        if entry is None:
             continue
         rep = in_repeats[i]
         na = non_alt[i]
         by_probability = na >= (entry[1] if rep else entry[0])
         if not by_probability:
-            if not 0 < entry[2] <= float(supports[i]) / float(depth[i]):
+            if not 0 < entry[2] <= vaf:
                 continue
         if code[0] == "3" and by_probability:
             c_ref.append(allele)                  # a deletion swaps roles: the deleted stretch is REF, the anchor base ALT (:490-501)
@@ -426,9 +427,10 @@ def process(options, all_prediction_pair, vcf):
     sizes = np.fromiter(map(len, segments), np.int64, len(segments))
     n = int(sizes.sum())
     if leftovers:
-        # files this package did not write (several alleles in a row's candidate list): every record through the tuple path
-        from pepper_amd.variant.CandidateFinder import _by_site
-        contigs, sites = _by_site([seg.record(k) for seg in segments for k in range(len(seg))] + leftovers)
+        # files this package did not write (several alleles in a row's candidate list): the whole job through the tuple path,
+        # whose record order (batch by batch) decides which duplicate of a site survives
+        from pepper_amd.variant.CandidateFinder import find_candidates
+        contigs, _, sites = find_candidates(options, None, all_prediction_pair)
         return contigs, vcf.write_vcf_records(sites, plain)
     if n == 0:
         return [], (0, 0, 0, 0, 0)

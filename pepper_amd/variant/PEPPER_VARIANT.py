@@ -333,7 +333,8 @@ class PackedEncoder(object):
             begin, first, end, final = bam_handler.region_span(contig, int(starts[0]), int(stops[n - 1]), lookahead_windows)
             if end <= begin:                         # no record of the contig: every region is done, with nothing in it
                 return n, np.zeros(n + 1, np.int32), (0, 0, 0)
-            n_blocks, comp_bytes, out_bytes, complete = bam_handler.read_span(begin, end, self.span, self.tables, 1)
+            n_blocks, comp_bytes, out_bytes, complete, at_eof = bam_handler.read_span(begin, end, self.span, self.tables, 1)
+            final = final or at_eof
             if complete and out_bytes + 256 <= self.arena.nbytes:
                 break
             n //= 2

@@ -221,14 +221,14 @@ class BAM_handler(object):
 
     def read_span(self, begin, end_min, buf, tables, extra_members=1):
         """Members of the file span into `buf` (uint8 array) and their inflate tables into `tables` = (comp_off int64, comp_len
-        int32, out_off int64, out_len int32) -> (n_blocks, comp_bytes, out_bytes, complete)."""
+        int32, out_off int64, out_len int32) -> (n_blocks, comp_bytes, out_bytes, complete, at_eof)."""
         comp_off, comp_len, out_off, out_len = tables
         n, cb, ob, done = c_int32(), c_int64(), c_int64(), c_int32()
         _check(_lib().pa_bam_read_span(self._h, int(begin), int(end_min), int(extra_members), buf.ctypes.data, buf.nbytes,
                                        comp_off.ctypes.data, comp_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
                                        min(len(comp_off), len(comp_len), len(out_off), len(out_len)), ctypes.byref(n),
                                        ctypes.byref(cb), ctypes.byref(ob), ctypes.byref(done)))
-        return n.value, cb.value, ob.value, bool(done.value)
+        return n.value, cb.value, ob.value, bool(done.value & 1), bool(done.value & 2)
 
     def pack_inflated(self, data, data_bytes, first_record, data_is_final, chromosome, starts, stops, include_supplementary,
                       min_mapq, reads, pair_read):

@@ -323,7 +323,8 @@ def _inflate_span(bam, chromosome, start, stop, lookahead, buf_bytes=1 << 26, bl
     begin, first, end, final = bam.region_span(chromosome, start, stop, lookahead)
     buf = np.zeros(buf_bytes, np.uint8)
     tables = (np.zeros(blocks, np.int64), np.zeros(blocks, np.int32), np.zeros(blocks, np.int64), np.zeros(blocks, np.int32))
-    n, comp_bytes, out_bytes, complete = bam.read_span(begin, end, buf, tables, extra)
+    n, comp_bytes, out_bytes, complete, at_eof = bam.read_span(begin, end, buf, tables, extra)
+    final = final or at_eof
     data = np.zeros(max(out_bytes, 1), np.uint8)
     for k in range(n):
         o, l, at, m = int(tables[0][k]), int(tables[1][k]), int(tables[2][k]), int(tables[3][k])
