@@ -975,11 +975,11 @@ int pa_bam_read_span(pa_bam* b, int64_t begin, int64_t end_min, int32_t extra_me
     int32_t n = 0, extra = 0;
     bool covered = false, at_eof = false;
     while (true) {
+        if (begin + p >= b->file_bytes) { covered = at_eof = true; break; }
         if (begin + p >= end_min) {
             if (extra >= extra_members) { covered = true; break; }
             ++extra;
         }
-        if (begin + p >= b->file_bytes) { covered = at_eof = true; break; }
         if (p + 18 > got) break;
         const uint8_t* h = buf + p;
         if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return bam_fail(-5, "no BGZF member where the index points");

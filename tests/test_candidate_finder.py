@@ -477,9 +477,7 @@ def test_library_batches_equal_the_python_loops(tmp_path, monkeypatch):
         for k in (0, 1, len(seg) // 2, len(seg) - 1):
             assert seg.record(k) == want.record(k) and seg.pair(k) == want.pair(k)
         assert fc._native_batch(opts, fc._rules(opts), handler, pred, "batch_1") is None          # two contigs
-        if freq:
-            assert fc._native_batch(opts, fc._rules(opts), handler, pred, "batch_2") is None      # the reference's ZeroDivisionError
-            with pytest.raises(ZeroDivisionError):
-                fc._python_batch(opts, handler, pred, "batch_2", [])
-        else:
-            assert len(fc._native_batch(opts, fc._rules(opts), handler, pred, "batch_2")) == len(fc._python_batch(opts, handler, pred, "batch_2", []))
+        # a row of depth 0 with a valid allele: the reference divides by it whatever the rules (CandidateFinder.py:478)
+        assert fc._native_batch(opts, fc._rules(opts), handler, pred, "batch_2") is None
+        with pytest.raises(ZeroDivisionError):
+            fc._python_batch(opts, handler, pred, "batch_2", [])
