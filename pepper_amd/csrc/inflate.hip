@@ -32,6 +32,8 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,6 +47,7 @@ namespace {
 
 constexpr int LIT_BITS = 10, DIST_BITS = 8, CL_BITS = 7;
 constexpr int MAX_LIT = 288, MAX_DIST = 32;
+constexpr int RING_WORDS = 128;                  // two chunks of 64 words of the compressed stream
 
 enum InflateStatus : int32_t {
     INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_STORED_LEN = 2, INF_OVERSUBSCRIBED = 3, INF_NO_END_CODE = 4, INF_BAD_CODE = 5,
@@ -61,58 +64,85 @@ struct Tables {
     int lit_count[16], dist_count[16], cl_count[16];
     uint8_t lens[MAX_LIT + MAX_DIST + 16];        // literal/length lengths, then the distance lengths
     uint8_t cl_lens[20];
+    uint32_t ring[RING_WORDS];
+    uint8_t scratch[64];                          // per output byte of a step: the lane of the symbol that starts there
 };
 
 PA_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// the compressed bytes of one block as a stream of bits
-struct Bits {
-    const uint32_t* words;      // the word holding the block's first byte
-    int n_words;                // words that hold bytes of the block
-    int chunk;                  // `cur` holds words [64 chunk, 64 chunk + 64)
-    int widx;                   // the next word to take
-    uint32_t cur, nxt;          // per lane
-    uint64_t bb;                // bits not yet consumed, the next one lowest
-    int bc;
+// inclusive prefix sum across the wavefront (DPP row shifts, then the row broadcasts)
+PA_DEV int wave_scan_add(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// inclusive prefix maximum across the wavefront of values >= -1
+PA_DEV int wave_scan_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+// The compressed bytes of one member as a stream of bits, a window of it in LDS: chunk c (64 words) lives in
+// ring[(c & 1) * 64 ..], chunks `loaded - 2` and `loaded - 1` are there, chunk `loaded` is in flight in `pre`.
+struct Stream {
+    const uint32_t* words;      // the word holding the member's first byte
+    int n_words;                // words that hold bytes of the member
+    uint32_t* ring;
+    int loaded;
+    uint32_t pre;               // per lane
+    int p;                      // bit position of the next symbol, from `words`
 
     PA_DEV uint32_t fetch(int c) const {
         const int i = c * 64 + (int)threadIdx.x;
         return i < n_words ? words[i] : 0u;
     }
-    PA_DEV void seek(int byte_off) {            // position at a byte of the block (relative to `words`)
-        widx = byte_off >> 2;
-        chunk = widx >> 6;
-        cur = fetch(chunk);
-        nxt = fetch(chunk + 1);
-        bb = 0;
-        bc = 0;
-        refill();
-        const int skip = (byte_off & 3) * 8;
-        bb >>= skip;
-        bc -= skip;
-        refill();
+    PA_DEV void seek(int bit) {
+        p = bit;
+        const int c = bit >> 11;
+        __syncthreads();
+        ring[(c & 1) * 64 + threadIdx.x] = fetch(c);
+        ring[((c + 1) & 1) * 64 + threadIdx.x] = fetch(c + 1);
+        loaded = c + 2;
+        pre = fetch(loaded);
+        __syncthreads();
     }
-    PA_DEV void refill() {                      // at least 33 bits afterwards (zeros beyond the end of the block)
-        while (bc <= 32) {
-            if ((widx >> 6) != chunk) {
-                cur = nxt;
-                ++chunk;
-                nxt = fetch(chunk + 1);
-            }
-            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, widx & 63);
-            bb |= (uint64_t)w << bc;
-            bc += 32;
-            ++widx;
+    // every read at or after p reaches at most 160 bits further (lane 63's three words)
+    PA_DEV void ensure() {
+        while (((p + 160) >> 11) >= loaded) {
+            __syncthreads();
+            ring[(loaded & 1) * 64 + threadIdx.x] = pre;
+            ++loaded;
+            pre = fetch(loaded);
+            __syncthreads();
         }
     }
-    PA_DEV uint32_t peek() const { return (uint32_t)bb; }
-    PA_DEV void drop(int n) { bb >>= n; bc -= n; }
-    PA_DEV uint32_t take(int n) {               // n <= 16
-        const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
-        drop(n);
-        return v;
+    // 64 bits from bit position q (the lane's own, or a uniform one)
+    PA_DEV uint64_t bits_at(int q) const {
+        const int d = q >> 5, sh = q & 31;
+        const uint32_t w0 = ring[d & (RING_WORDS - 1)], w1 = ring[(d + 1) & (RING_WORDS - 1)], w2 = ring[(d + 2) & (RING_WORDS - 1)];
+        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+        return ((uint64_t)hi << 32) | lo;
     }
-    PA_DEV long long consumed_bits() const { return (long long)widx * 32 - bc; }
+    PA_DEV uint64_t peek() {                    // uniform
+        ensure();
+        const uint64_t v = bits_at(p);
+        return ((uint64_t)(uint32_t)uni((int)(v >> 32)) << 32) | (uint32_t)uni((int)v);
+    }
+    PA_DEV uint32_t take(int n) {               // n <= 32
+        const uint64_t v = peek();
+        p += n;
+        return (uint32_t)(v & ((1ull << n) - 1ull));
+    }
 };
 
 // Canonical code of `n` symbols from their lengths (RFC 1951 3.2.2): count[], the symbols in (length, symbol) order and
@@ -152,6 +182,7 @@ PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, 
     for (int t = lane; t < (1 << tbits); t += 64) {
         int code = 0, first = 0, index = 0;
         uint16_t e = 0;
+#pragma unroll 1
         for (int len = 1; len <= tbits; ++len) {
             code |= (t >> (len - 1)) & 1;
             const int c = count[len];
@@ -169,126 +200,158 @@ PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, 
     return true;
 }
 
-// One symbol: the primary table, or bit by bit for a longer code.  -1: the bits are no code of the set.
-PA_DEV int decode(Bits& in, const uint16_t* table, int tbits, const int* count, const uint16_t* syms) {
-    const uint32_t bits = in.peek();
+// One symbol from uniform bits: the primary table, or bit by bit for a longer code.  -1: the bits are no code of the set.
+// *used: the code's length.
+PA_DEV int decode(uint32_t bits, const uint16_t* table, int tbits, const int* count, const uint16_t* syms, int* used) {
     const int e = uni(table[bits & ((1u << tbits) - 1u)]);
     if (e) {
-        in.drop(e & 15);
+        *used = e & 15;
         return e >> 4;
     }
     int code = 0, first = 0, index = 0;
+#pragma unroll 1
     for (int len = 1; len < 16; ++len) {
         code |= (bits >> (len - 1)) & 1;
         const int c = uni(count[len]);
         if (code - c < first) {
-            in.drop(len);
+            *used = len;
             return uni(syms[index + (code - first)]);
         }
         index += c;
         first = (first + c) << 1;
         code <<= 1;
     }
+    *used = 0;
     return -1;
 }
 
-__global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
+// what a lane found at its bit offset: the symbol's total bits (code, extra bits, for a match also the distance's) | flags
+constexpr int F_MATCH = 64, F_END = 128, F_INVALID = 256;
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
                                                          const int32_t* __restrict__ comp_len, const int64_t* __restrict__ out_off,
                                                          const int32_t* __restrict__ out_len, uint8_t* out_base,
-                                                         int32_t* __restrict__ status) {
+                                                         int32_t* __restrict__ status, unsigned long long* dbg) {
     __shared__ Tables T;
+    int n_steps = 0, n_match = 0, n_fallback = 0, n_blocks_in = 0, n_far = 0;
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
     const int64_t coff = comp_off[blk];
     const int clen = comp_len[blk], olen = out_len[blk];
     uint8_t* out = out_base + out_off[blk];
     const int mis = (int)(coff & 3);
-    Bits in;
+    Stream in;
     in.words = reinterpret_cast<const uint32_t*>(comp + (coff - mis));
     in.n_words = (mis + clen + 3) >> 2;
-    in.seek(mis);
+    in.ring = T.ring;
+    in.seek(mis * 8);
     const uint8_t* in_bytes = comp + (coff - mis);
+    const unsigned long long below = (1ull << lane) - 1ull;
 
-    int pos = 0;                 // bytes written or staged
-    int staged = 0;              // literals in `stage` (lane k: the byte for out[pos - staged + k])
-    int stage = 0;
+    int pos = 0;                 // bytes written
     int err = INF_OK;
-    auto flush = [&]() {
-        if (staged) {
-            if (lane < staged) out[pos - staged + lane] = (uint8_t)stage;
-            staged = 0;
+    // A load does not wait for this wavefront's own earlier stores to the same bytes (the read path overtakes the write
+    // path): bytes are read back only below `safe`, the position up to which the stores are known complete -- advanced by a
+    // full s_waitcnt vmcnt(0), which a step pays only when one of its sources lies above it.
+    int safe = 0;
+    auto stores_done = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    auto copy_match = [&](int dst, int len, int dist) {
+        stores_done();
+        const uint8_t* src = out + dst - dist;
+        if (dist >= len) {
+            for (int k = lane; k < len; k += 64) out[dst + k] = src[k];
+        } else {
+            for (int k = lane; k < len; k += 64) out[dst + k] = src[k % dist];
         }
     };
 
-    bool last = olen == 0 && clen == 0;        // nothing at all: an empty block without a stream
+    // The bytes of a step whose matches read memory are completed one step later: their loads are in flight while the next
+    // window is decoded.  pend_n bytes at pend_pos: lane j's byte is the value of lane pend_root[j] -- a literal (pend_val
+    // >= 0) or what that lane loaded (pend_byte).
+    int pend_n = 0, pend_pos = 0;
+    int pend_val = 0, pend_root = 0;
+    uint8_t pend_byte = 0;
+    auto complete = [&]() {
+        if (pend_n) {
+            const int own = pend_val >= 0 ? pend_val : (int)pend_byte;
+            const int v = __builtin_amdgcn_ds_bpermute(pend_root << 2, own);
+            if (lane < pend_n) out[pend_pos + lane] = (uint8_t)v;
+            pend_n = 0;
+        }
+    };
+
+    bool last = olen == 0 && clen == 0;        // nothing at all: an empty member without a stream
     while (!last && !err) {
-        in.refill();
         last = in.take(1) != 0;
         const int type = (int)in.take(2);
         if (type == 0) {
             // stored: to the next byte, LEN, ~LEN, the bytes
-            in.drop(in.bc & 7);
-            in.refill();
+            complete();
+            in.p = (in.p + 7) & ~7;
             const uint32_t len = in.take(16), nlen = in.take(16);
             if ((len ^ nlen) != 0xffffu) { err = INF_STORED_LEN; break; }
-            flush();
-            const int from = (int)(in.consumed_bits() >> 3);
+            const int from = in.p >> 3;
             if (from + (int)len > mis + clen) { err = INF_INPUT; break; }
             if (pos + (int)len > olen) { err = INF_OUTPUT; break; }
             for (int k = lane; k < (int)len; k += 64) out[pos + k] = in_bytes[from + k];
             pos += (int)len;
-            in.seek(from + (int)len);
+            in.seek(in.p + 8 * (int)len);
             continue;
         }
         if (type == 3) { err = INF_BAD_BLOCK_TYPE; break; }
-        int hlit = 288, hdist = 32;
         if (type == 1) {
             for (int s = lane; s < 288; s += 64) T.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
             if (lane < 32) T.lens[288 + lane] = 5;
         } else {
-            in.refill();
-            hlit = (int)in.take(5) + 257;
-            hdist = (int)in.take(5) + 1;
-            const int hclen = (int)in.take(4) + 4;
+            const int hlit = (int)in.take(5) + 257, hdist = (int)in.take(5) + 1, hclen = (int)in.take(4) + 4;
             if (hlit > 286 || hdist > 30) { err = INF_BAD_COUNTS; break; }
             if (lane < 19) T.cl_lens[lane] = 0;
             __syncthreads();
-            for (int k = 0; k < hclen; ++k) {
-                in.refill();
-                const int v = (int)in.take(3);
-                // the order of the code length code lengths (RFC 1951 3.2.7), 5 bits each
-                const unsigned long long lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 |
-                                              6ull << 35 | 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
-                const unsigned long long hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
-                const int idx = k < 12 ? (int)((lo >> (5 * k)) & 31) : (int)((hi >> (5 * (k - 12))) & 31);
-                if (lane == 0) T.cl_lens[idx] = (uint8_t)v;
+            // the order of the code length code lengths (RFC 1951 3.2.7), 5 bits each
+            const unsigned long long lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 |
+                                          6ull << 35 | 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+            const unsigned long long hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+            {
+                // 19 x 3 bits = 57 bits: one peek, every lane its own code length
+                const uint64_t v = in.peek();
+                if (lane < hclen) {
+                    const int idx = lane < 12 ? (int)((lo >> (5 * lane)) & 31) : (int)((hi >> (5 * (lane - 12))) & 31);
+                    T.cl_lens[idx] = (uint8_t)((v >> (3 * lane)) & 7);
+                }
+                in.p += 3 * hclen;
             }
             __syncthreads();
             if (!build_table(T.cl_lens, 19, T.cl_count, T.cl_sym, T.cl_table, CL_BITS)) { err = INF_OVERSUBSCRIBED; break; }
             const int total = hlit + hdist;
             int i = 0, prev = 0;
             while (i < total) {
-                in.refill();
-                const int sym = decode(in, T.cl_table, CL_BITS, T.cl_count, T.cl_sym);
+                const uint32_t v = (uint32_t)in.peek();
+                int used;
+                const int sym = decode(v, T.cl_table, CL_BITS, T.cl_count, T.cl_sym, &used);
                 if (sym < 0) { err = INF_BAD_CODE; break; }
                 if (sym < 16) {
                     if (lane == 0) T.lens[i] = (uint8_t)sym;
                     prev = sym;
                     ++i;
+                    in.p += used;
                     continue;
                 }
                 int rep, val = 0;
                 if (sym == 16) {
                     if (i == 0) { err = INF_BAD_REPEAT; break; }
                     val = prev;
-                    rep = 3 + (int)in.take(2);
+                    rep = 3 + (int)((v >> used) & 3);
+                    used += 2;
                 } else if (sym == 17) {
-                    rep = 3 + (int)in.take(3);
+                    rep = 3 + (int)((v >> used) & 7);
+                    used += 3;
                     prev = 0;
                 } else {
-                    rep = 11 + (int)in.take(7);
+                    rep = 11 + (int)((v >> used) & 127);
+                    used += 7;
                     prev = 0;
                 }
+                in.p += used;
                 if (i + rep > total) { err = INF_BAD_REPEAT; break; }
                 for (int k = lane; k < rep; k += 64) T.lens[i + k] = (uint8_t)val;
                 i += rep;
@@ -309,67 +372,204 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
             err = INF_OVERSUBSCRIBED;
             break;
         }
-        (void)hlit;
-        // the symbols of the block
-        for (;;) {
-            in.refill();
-            int sym = decode(in, T.lit_table, LIT_BITS, T.lit_count, T.lit_sym);
-            if (sym < 256) {
-                if (sym < 0) { err = INF_BAD_CODE; break; }
-                if (pos >= olen) { err = INF_OUTPUT; break; }
-                asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stage) : "s"(sym), "s"(staged) : "m0");
-                ++staged;
-                ++pos;
-                if (staged == 64) {
-                    out[pos - 64 + lane] = (uint8_t)stage;
-                    staged = 0;
+        // ---- the symbols of the block: 64 bit offsets at a time ----
+        // Lane k decodes whatever starts at bit p + k (most offsets are inside a symbol: their result is never looked at);
+        // the symbols that do start in the window are found by following the lengths from offset 0.
+        ++n_blocks_in;
+        for (bool more = true; more && !err;) {
+            ++n_steps;
+            in.ensure();
+            const uint64_t bits = in.bits_at(in.p + lane);
+            const uint32_t e = T.lit_table[(uint32_t)bits & ((1u << LIT_BITS) - 1u)];
+            const int len = (int)(e & 15u), sym = (int)(e >> 4);
+            int info = len, val = sym, dist = 0;
+            if (e == 0u || sym > 285) info = F_INVALID;
+            else if (sym == 256) info = len | F_END;
+            {
+                // a length symbol: its extra bits, the distance code behind them, the distance's extra bits
+                const int s = sym - 257;
+                const bool longer = s >= 8 && s != 28;
+                const int eb = longer ? (s - 4) >> 2 : 0;
+                const int base = longer ? ((4 + (s & 3)) << eb) + 3 : (s == 28 ? 258 : s + 3);
+                uint64_t after = bits >> len;
+                const int mlen = base + (int)((uint32_t)after & ((1u << eb) - 1u));
+                after >>= eb;
+                const uint32_t de = T.dist_table[(uint32_t)after & ((1u << DIST_BITS) - 1u)];
+                const int dlen = (int)(de & 15u), dsym = (int)(de >> 4);
+                const int deb = dsym < 4 ? 0 : (dsym >> 1) - 1;
+                const int dbase = dsym < 4 ? dsym + 1 : ((2 + (dsym & 1)) << deb) + 1;
+                const int d = dbase + (int)((uint32_t)(after >> dlen) & ((1u << deb) - 1u));
+                if (e != 0u && sym > 256 && sym <= 285) {
+                    if (de == 0u || dsym > 29) info = F_INVALID;
+                    else { info = (len + eb + dlen + deb) | F_MATCH; val = mlen; dist = d; }
                 }
-                continue;
             }
-            if (sym == 256) break;
-            if (sym > 285) { err = INF_LENGTH; break; }
-            sym -= 257;
-            int len;
-            if (sym < 8) len = sym + 3;
-            else if (sym == 28) len = 258;
-            else {
-                const int eb = (sym - 4) >> 2;
-                len = ((4 + (sym & 3)) << eb) + 3 + (int)in.take(eb);
+            // follow the symbols from offset 0
+            unsigned long long chain = 0;
+            int k = 0, stop = 0;
+            int f = __builtin_amdgcn_readlane(info, 0);
+            while (f < F_END) {
+                chain |= 1ull << k;
+                k += f & 63;
+                if (k >= 64) break;
+                f = __builtin_amdgcn_readlane(info, k);
             }
-            in.refill();
-            const int dsym = decode(in, T.dist_table, DIST_BITS, T.dist_count, T.dist_sym);
-            if (dsym < 0 || dsym > 29) { err = INF_BAD_CODE; break; }
-            int dist;
-            if (dsym < 4) dist = dsym + 1;
-            else {
-                const int eb = (dsym >> 1) - 1;
-                dist = ((2 + (dsym & 1)) << eb) + 1 + (int)in.take(eb);
+            if (k < 64) {                                   // the end-of-block code, or something the lanes could not decode
+                if (f & F_END) { chain |= 1ull << k; k += f & 63; stop = 1; }
+                else stop = 2;
             }
-            if (dist > pos) { err = INF_DISTANCE; break; }
-            if (pos + len > olen) { err = INF_OUTPUT; break; }
-            flush();
-            const uint8_t* src = out + pos - dist;
-            if (dist >= len) {
-                for (int k = lane; k < len; k += 64) out[pos + k] = src[k];
+            const bool on = (chain >> lane) & 1ull;
+            const bool is_match = on && (info & F_MATCH), is_lit = on && !(info & (F_MATCH | F_END));
+            unsigned long long matches = __ballot(is_match);
+            const unsigned long long lits = __ballot(is_lit);
+            int off, produced;
+            if (matches == 0) {
+                off = __popcll(lits & below);
+                produced = __popcll(lits);
             } else {
-                for (int k = lane; k < len; k += 64) out[pos + k] = src[k % dist];
+                const int mine = is_lit ? 1 : (is_match ? val : 0);
+                const int incl = wave_scan_add(mine);
+                off = incl - mine;
+                produced = __builtin_amdgcn_readlane(incl, 63);
             }
-            pos += len;
+            if (pos + produced > olen) { err = INF_OUTPUT; break; }
+            if (matches == 0) {
+                if (is_lit) out[pos + off] = (uint8_t)val;            // (no read of memory: whatever is pending stays pending)
+            } else if (produced <= 64) {
+                // Every output byte of the step on its own lane: which symbol it belongs to (the symbols mark their first
+                // byte; a prefix maximum spreads the mark), then a literal's value or a match byte's source -- memory in front
+                // of the step, or an earlier byte of this same step, followed back to a literal or a memory byte.
+                T.scratch[lane] = 0xff;
+                __syncthreads();
+                if (is_lit || is_match) T.scratch[off] = (uint8_t)lane;
+                __syncthreads();
+                const int mark = T.scratch[lane];
+                const int packed = wave_scan_max(mark != 0xff ? (lane << 8 | mark) : -1);
+                const int start = packed >> 8;
+                const int word = __builtin_amdgcn_ds_bpermute((packed & 255) << 2, is_match ? (val | dist << 9 | 1 << 25) : val);
+                const bool active = lane < produced;
+                const bool m = active && ((word >> 25) & 1);
+                const int sval = word & 511, d = (word >> 9) & 0xffff;
+                if (__ballot(m && d > pos + start)) { err = INF_DISTANCE; break; }
+                int rel = lane - start;
+                if (__ballot(m && d < sval)) {
+                    if (m && d < sval) rel %= d;                       // distance < length: the source repeats
+                }
+                const int src = pos + start - d + rel;
+                const bool in_step = m && src >= pos, from_mem = m && !in_step;
+                int root = in_step ? src - pos : lane;
+                if (__ballot(in_step)) {
+                    for (;;) {
+                        const int next = __builtin_amdgcn_ds_bpermute(root << 2, root);
+                        if (!__ballot(next != root)) break;
+                        root = next;
+                    }
+                }
+                n_match += __popcll(matches);
+                if (pend_n && __ballot(from_mem && src >= pend_pos)) complete();
+                if (__ballot(from_mem && src >= safe)) {
+                    stores_done();
+                    safe = pend_n ? pend_pos : pos;
+                }
+                uint8_t b = 0;
+                if (from_mem) b = out[src];
+                complete();                                            // the step before: its loads were issued a step ago
+                pend_byte = b;
+                pend_val = (active && !m) ? sval : -1;
+                pend_root = root;
+                pend_n = produced;
+                pend_pos = pos;
+                matches = 0;
+            } else {
+                // a step of more than 64 bytes (long matches): the literals, then match by match in order
+                complete();
+                if (is_lit) out[pos + off] = (uint8_t)val;
+                while (matches) {
+                    const int m = __builtin_ctzll(matches);
+                    matches &= matches - 1;
+                    const int mlen = __builtin_amdgcn_readlane(val, m), md = __builtin_amdgcn_readlane(dist, m);
+                    const int dst = pos + __builtin_amdgcn_readlane(off, m);
+                    if (md > dst) { err = INF_DISTANCE; break; }
+                    ++n_match;
+                    copy_match(dst, mlen, md);
+                }
+            }
+            if (err) break;
+            pos += produced;
+            in.p += k;
+            if (stop == 1) more = false;
+            else if (stop == 2) {
+                complete();
+                // a code longer than the primary table (or no code at all) at p: this one symbol from uniform bits
+                ++n_fallback;
+                const uint64_t v = in.peek();
+                int used;
+                int s = decode((uint32_t)v, T.lit_table, LIT_BITS, T.lit_count, T.lit_sym, &used);
+                if (s < 0) { err = INF_BAD_CODE; break; }
+                if (s < 256) {
+                    if (pos >= olen) { err = INF_OUTPUT; break; }
+                    if (lane == 0) out[pos] = (uint8_t)s;
+                    ++pos;
+                    in.p += used;
+                } else if (s == 256) {
+                    in.p += used;
+                    more = false;
+                } else {
+                    if (s > 285) { err = INF_LENGTH; break; }
+                    s -= 257;
+                    uint64_t after = v >> used;
+                    int mlen;
+                    if (s < 8) mlen = s + 3;
+                    else if (s == 28) mlen = 258;
+                    else {
+                        const int eb = (s - 4) >> 2;
+                        mlen = ((4 + (s & 3)) << eb) + 3 + (int)((uint32_t)after & ((1u << eb) - 1u));
+                        after >>= eb;
+                        used += eb;
+                    }
+                    int dused;
+                    const int dsym = decode((uint32_t)after, T.dist_table, DIST_BITS, T.dist_count, T.dist_sym, &dused);
+                    if (dsym < 0 || dsym > 29) { err = INF_BAD_CODE; break; }
+                    after >>= dused;
+                    used += dused;
+                    int md;
+                    if (dsym < 4) md = dsym + 1;
+                    else {
+                        const int deb = (dsym >> 1) - 1;
+                        md = ((2 + (dsym & 1)) << deb) + 1 + (int)((uint32_t)after & ((1u << deb) - 1u));
+                        used += deb;
+                    }
+                    if (md > pos) { err = INF_DISTANCE; break; }
+                    if (pos + mlen > olen) { err = INF_OUTPUT; break; }
+                    copy_match(pos, mlen, md);
+                    pos += mlen;
+                    in.p += used;
+                }
+            }
         }
     }
-    flush();
+    complete();
     if (!err && pos != olen) err = INF_OUTPUT;
-    if (!err && in.consumed_bits() > (long long)(mis + clen) * 8) err = INF_INPUT;
+    if (!err && in.p > (mis + clen) * 8) err = INF_INPUT;
     if (lane == 0) status[blk] = err;
+    if (dbg && lane == 0) {
+        atomicAdd(&dbg[0], (unsigned long long)n_steps);
+        atomicAdd(&dbg[1], (unsigned long long)n_match);
+        atomicAdd(&dbg[2], (unsigned long long)n_fallback);
+        atomicAdd(&dbg[3], (unsigned long long)n_blocks_in);
+        atomicAdd(&dbg[4], (unsigned long long)n_far);
+        atomicAdd(&dbg[5], (unsigned long long)pos);
+    }
 }
 
 }  // namespace
 
 void launch_bgzf_inflate(hipStream_t stream, const uint8_t* comp, const int64_t* comp_off, const int32_t* comp_len,
-                         const int64_t* out_off, const int32_t* out_len, uint8_t* out, int32_t* status, int n_blocks) {
+                         const int64_t* out_off, const int32_t* out_len, uint8_t* out, int32_t* status, int n_blocks,
+                         unsigned long long* debug_counts) {
     if (n_blocks <= 0) return;
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
-                       status);
+                       status, debug_counts);
 }
 
 const char* inflate_status_text(int32_t s) {
@@ -488,16 +688,30 @@ int pa_inflater_inflate(pa_inflater* h, const uint8_t* comp, int64_t comp_bytes,
     INF_HIP(hipMemcpyAsync(d_clen, comp_len, nb * 4, hipMemcpyHostToDevice, h->stream));
     INF_HIP(hipMemcpyAsync(d_olen, out_len, nb * 4, hipMemcpyHostToDevice, h->stream));
     const int reps = std::max(1, (int)repeats);
+    // (a byte the kernel fails to write must not be one a previous call left there: this handle serves the tests)
+    if (out_bytes) INF_HIP(hipMemsetAsync(h->d_out, 0xA5, (size_t)out_bytes, h->stream));
+    unsigned long long* d_dbg = nullptr;
+    if (getenv("PA_INFLATE_DEBUG")) {             // symbol statistics of the call on stderr (a diagnostic, not part of the ABI)
+        INF_HIP(hipMalloc(reinterpret_cast<void**>(&d_dbg), 64));
+        INF_HIP(hipMemsetAsync(d_dbg, 0, 64, h->stream));
+    }
     INF_HIP(hipEventRecord(h->ev[0], h->stream));
     for (int r = 0; r < reps; ++r)
         pa::launch_bgzf_inflate(h->stream, static_cast<const uint8_t*>(h->d_comp), d_coff, d_clen, d_ooff, d_olen,
-                                static_cast<uint8_t*>(h->d_out), d_status, n_blocks);
+                                static_cast<uint8_t*>(h->d_out), d_status, n_blocks, r == 0 ? d_dbg : nullptr);
     INF_HIP(hipGetLastError());
     INF_HIP(hipEventRecord(h->ev[1], h->stream));
     std::vector<int32_t> status(nb);
     INF_HIP(hipMemcpyAsync(status.data(), d_status, nb * 4, hipMemcpyDeviceToHost, h->stream));
     if (out_bytes) INF_HIP(hipMemcpyAsync(out, h->d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, h->stream));
     INF_HIP(hipStreamSynchronize(h->stream));
+    if (d_dbg) {
+        unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
+        (void)hipMemcpy(c, d_dbg, sizeof c, hipMemcpyDeviceToHost);
+        (void)hipFree(d_dbg);
+        fprintf(stderr, "inflate: %d members, %llu bytes, %llu DEFLATE blocks, %llu window steps, %llu matches (%llu beyond 4 KiB), "
+                        "%llu long-code symbols\n", n_blocks, c[5], c[3], c[0], c[1], c[4], c[2]);
+    }
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->kernel_ms = (double)ms / reps;
     for (int32_t b = 0; b < n_blocks; ++b)

@@ -131,6 +131,7 @@ hipError_t launch_polish_finalize(const float* acc, uint8_t* labels, uint8_t* ph
 // inflate.hip: one wavefront per BGZF block (tables of block b: comp_off/comp_len = its raw DEFLATE bytes in `comp`,
 // out_off/out_len = where its ISIZE bytes go in `out`); status[b] != 0 names the block's error (inflate_status_text)
 void launch_bgzf_inflate(hipStream_t stream, const uint8_t* comp, const int64_t* comp_off, const int32_t* comp_len,
-                         const int64_t* out_off, const int32_t* out_len, uint8_t* out, int32_t* status, int n_blocks);
+                         const int64_t* out_off, const int32_t* out_len, uint8_t* out, int32_t* status, int n_blocks,
+                         unsigned long long* debug_counts = nullptr);
 const char* inflate_status_text(int32_t s);
 }  // namespace pa
