@@ -250,13 +250,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
     int pos = 0;                 // bytes written
     int err = INF_OK;
-    // A load does not wait for this wavefront's own earlier stores to the same bytes (the read path overtakes the write
-    // path): bytes are read back only below `safe`, the position up to which the stores are known complete -- advanced by a
-    // full s_waitcnt vmcnt(0), which a step pays only when one of its sources lies above it.
-    int safe = 0;
-    auto stores_done = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // (A wavefront's vector memory operations reach its L1 in program order: a load issued after a store of the same
+    // wavefront to the same bytes returns them -- the ordinary single-thread guarantee every in-place loop relies on; the
+    // tests run every RLE-like pattern, where a match reads what the instruction before it wrote.)
     auto copy_match = [&](int dst, int len, int dist) {
-        stores_done();
         const uint8_t* src = out + dst - dist;
         if (dist >= len) {
             for (int k = lane; k < len; k += 64) out[dst + k] = src[k];
@@ -467,10 +464,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 }
                 n_match += __popcll(matches);
                 if (pend_n && __ballot(from_mem && src >= pend_pos)) complete();
-                if (__ballot(from_mem && src >= safe)) {
-                    stores_done();
-                    safe = pend_n ? pend_pos : pos;
-                }
                 uint8_t b = 0;
                 if (from_mem) b = out[src];
                 complete();                                            // the step before: its loads were issued a step ago

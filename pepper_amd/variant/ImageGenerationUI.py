@@ -269,10 +269,10 @@ class ImageGenerationUtils:
                         write(output_hdf_file, chr_name, _start, _end, out)
                 lap("hdf5", t0)
                 g0 += n_done
-            if stats is not None and enc.inflated_bytes:
+            if enc.inflated_bytes:
                 mine["inflate_kernel"] = mine.get("inflate_kernel", 0.0) + enc.inflate_ms / 1e3
                 mine["inflated_bytes"] = mine.get("inflated_bytes", 0.0) + enc.inflated_bytes
-                enc.inflate_ms, enc.inflated_bytes = 0.0, 0
+            enc.inflate_ms, enc.inflated_bytes = 0.0, 0
             enc.release()
             t_close = time.perf_counter()
         lap("close", t_close)

@@ -97,6 +97,31 @@ def test_several_blocks_per_member_and_empty_stored_blocks():
 
 
 @pytest.mark.gpu
+def test_matches_that_read_what_was_just_written_under_load():
+    """2 400 members in one launch (every wavefront slot of the chip busy), each a short-period pattern: every match reads
+    bytes the same wavefront stored an instruction or a step earlier -- inside a step (resolved between lanes), across steps
+    (through memory, the store still in flight) and through the byte-by-byte path of long matches."""
+    rng = np.random.default_rng(10)
+    members, expect = [], []
+    for k in range(2400):
+        period = int(rng.integers(1, 70))
+        unit = bytes(rng.integers(0, 256, period, dtype=np.uint8))
+        n = int(rng.integers(200, 20000))
+        data = bytearray((unit * (n // period + 1))[:n])
+        for at in rng.integers(0, n, int(rng.integers(0, 6))):          # a few literals that break the period
+            data[int(at)] ^= 0x5a
+        data = bytes(data)
+        members.append(member(data, (1, 6, 9)[k % 3], (zlib.Z_DEFAULT_STRATEGY, zlib.Z_RLE, zlib.Z_FIXED)[(k // 3) % 3]))
+        expect.append(data)
+    buf = b"".join(members)
+    table = block_table(buf)
+    want = b"".join(expect)
+    with DeviceInflater() as inf:
+        for _ in range(3):
+            assert inf.inflate(buf, table).tobytes() == want
+
+
+@pytest.mark.gpu
 def test_many_members_of_a_bam_file(tmp_path):
     """A whole synthetic BAM (tools/synth_bam: libdeflate's encoder, not zlib's) member by member."""
     tool = os.path.join(ROOT, "tools", "synth_bam")
