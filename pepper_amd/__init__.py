@@ -1,0 +1,11 @@
+"""pepper_amd: the MI355X-native hot path of PEPPER.
+
+One process-wide setting is made here, before anything can have started the HIP runtime: the runtime multiplexes a process's
+streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and kernels of different streams that share a queue run one
+after the other.  Image generation drives one stream per worker thread (sixteen on a box): with four queues an encoder
+launch of one worker waits behind another worker's 10 ms inflate launch -- 105 Mb of reference/s; with a queue per stream
+150.  An explicit GPU_MAX_HW_QUEUES in the environment wins.
+"""
+import os as _os
+
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")

@@ -1730,6 +1730,10 @@ int pa_encoder_create(int32_t device, void* hip_stream, pa_encoder** out) {
         return pa::set_error(PA_ERR_NO_DEVICE, "no HIP device visible: the pepper_amd encoder has no CPU fallback");
     if (device < 0 || device >= count) return pa::set_error(PA_ERR_INVALID, "device ordinal out of range");
     ENC_HIP(hipSetDevice(device));
+    // PEPPER_AMD_BLOCKING_SYNC=1: waits on the device sleep instead of spinning (sixteen image-generation workers spinning in
+    // hipStreamSynchronize use up the CPUs the other workers' host stages need); refused once the device is in use: ignored
+    if (const char* v = getenv("PEPPER_AMD_BLOCKING_SYNC"))
+        if (v[0] == '1') (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
     auto* e = new pa_encoder();
     e->device = device;
     if (hip_stream) e->stream = static_cast<hipStream_t>(hip_stream);
