@@ -70,6 +70,11 @@ struct Tables {
 
 PA_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// A workgroup here is ONE wavefront, and a wavefront's LDS instructions execute in issue order: hand-offs between lanes
+// through LDS need the compiler to keep the program order, nothing else.  (__syncthreads() would also drain vmcnt -- the
+// gather of the step before and its store, which are meant to stay in flight.)
+PA_DEV void wave_order() { asm volatile("" ::: "memory"); }
+
 // inclusive prefix sum across the wavefront (DPP row shifts, then the row broadcasts)
 PA_DEV int wave_scan_add(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
@@ -109,21 +114,21 @@ struct Stream {
     PA_DEV void seek(int bit) {
         p = bit;
         const int c = bit >> 11;
-        __syncthreads();
+        wave_order();
         ring[(c & 1) * 64 + threadIdx.x] = fetch(c);
         ring[((c + 1) & 1) * 64 + threadIdx.x] = fetch(c + 1);
         loaded = c + 2;
         pre = fetch(loaded);
-        __syncthreads();
+        wave_order();
     }
     // every read at or after p reaches at most 160 bits further (lane 63's three words)
     PA_DEV void ensure() {
         while (((p + 160) >> 11) >= loaded) {
-            __syncthreads();
+            wave_order();
             ring[(loaded & 1) * 64 + threadIdx.x] = pre;
             ++loaded;
             pre = fetch(loaded);
-            __syncthreads();
+            wave_order();
         }
     }
     // 64 bits from bit position q (the lane's own, or a uniform one)
@@ -150,9 +155,9 @@ struct Stream {
 PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, uint16_t* table, int tbits) {
     const int lane = threadIdx.x;
     if (lane < 16) count[lane] = 0;
-    __syncthreads();
+    wave_order();
     for (int s = lane; s < n; s += 64) atomicAdd(&count[lens[s]], 1);
-    __syncthreads();
+    wave_order();
     int offs[16];
     int left = 1, total = 0;
     bool ok = true;
@@ -165,7 +170,7 @@ PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, 
         left = (left << 1) - c;
         if (left < 0) ok = false;
     }
-    __syncthreads();
+    wave_order();
     if (lane == 0) count[0] = 0;
     if (!ok) return false;
     for (int base = 0; base < n; base += 64) {
@@ -178,7 +183,7 @@ PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, 
             offs[len] += __popcll(mask);
         }
     }
-    __syncthreads();
+    wave_order();
     for (int t = lane; t < (1 << tbits); t += 64) {
         int code = 0, first = 0, index = 0;
         uint16_t e = 0;
@@ -196,7 +201,7 @@ PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, 
         }
         table[t] = e;
     }
-    __syncthreads();
+    wave_order();
     return true;
 }
 
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const int hlit = (int)in.take(5) + 257, hdist = (int)in.take(5) + 1, hclen = (int)in.take(4) + 4;
             if (hlit > 286 || hdist > 30) { err = INF_BAD_COUNTS; break; }
             if (lane < 19) T.cl_lens[lane] = 0;
-            __syncthreads();
+            wave_order();
             // the order of the code length code lengths (RFC 1951 3.2.7), 5 bits each
             const unsigned long long lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 |
                                           6ull << 35 | 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 }
                 in.p += 3 * hclen;
             }
-            __syncthreads();
+            wave_order();
             if (!build_table(T.cl_lens, 19, T.cl_count, T.cl_sym, T.cl_table, CL_BITS)) { err = INF_OVERSUBSCRIBED; break; }
             const int total = hlit + hdist;
             int i = 0, prev = 0;
@@ -354,16 +359,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 i += rep;
             }
             if (err) break;
-            __syncthreads();
+            wave_order();
             if (uni(T.lens[256]) == 0) { err = INF_NO_END_CODE; break; }
             // the distance lengths follow the literal/length ones directly: move them to their own place
             uint8_t dl = 0;
             if (lane < hdist) dl = T.lens[hlit + lane];
-            __syncthreads();
+            wave_order();
             if (lane < 32) T.lens[288 + lane] = lane < hdist ? dl : 0;
             for (int s = hlit + lane; s < 288; s += 64) T.lens[s] = 0;
         }
-        __syncthreads();
+        wave_order();
         if (!build_table(T.lens, 288, T.lit_count, T.lit_sym, T.lit_table, LIT_BITS) ||
             !build_table(T.lens + 288, 32, T.dist_count, T.dist_sym, T.dist_table, DIST_BITS)) {
             err = INF_OVERSUBSCRIBED;
@@ -437,9 +442,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 // byte; a prefix maximum spreads the mark), then a literal's value or a match byte's source -- memory in front
                 // of the step, or an earlier byte of this same step, followed back to a literal or a memory byte.
                 T.scratch[lane] = 0xff;
-                __syncthreads();
+                wave_order();
                 if (is_lit || is_match) T.scratch[off] = (uint8_t)lane;
-                __syncthreads();
+                wave_order();
                 const int mark = T.scratch[lane];
                 const int packed = wave_scan_max(mark != 0xff ? (lane << 8 | mark) : -1);
                 const int start = packed >> 8;
@@ -702,8 +707,8 @@ int pa_inflater_inflate(pa_inflater* h, const uint8_t* comp, int64_t comp_bytes,
         unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
         (void)hipMemcpy(c, d_dbg, sizeof c, hipMemcpyDeviceToHost);
         (void)hipFree(d_dbg);
-        fprintf(stderr, "inflate: %d members, %llu bytes, %llu DEFLATE blocks, %llu window steps, %llu matches (%llu beyond 4 KiB), "
-                        "%llu long-code symbols\n", n_blocks, c[5], c[3], c[0], c[1], c[4], c[2]);
+        fprintf(stderr, "inflate: %d members, %llu bytes, %llu DEFLATE blocks, %llu window steps, %llu matches, %llu long-code symbols\n",
+                n_blocks, c[5], c[3], c[0], c[1], c[2]);
     }
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->kernel_ms = (double)ms / reps;
