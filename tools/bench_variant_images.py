@@ -48,9 +48,8 @@ def run(data, thread_counts=(16,), region_size=100000, warm=True):
     from pepper_amd.variant.ImageGenerationUI import ImageGenerationUtils
     info = json.load(open(os.path.join(data, "synth.json")))
     mb = info["genome_bases"] / 1e6
-    if warm:      # library load, first allocations, and the file into the page cache -- not part of the rate
-        ImageGenerationUtils.generate_images(options(data, os.path.join(data, "vimages_warm"), max(thread_counts), region_size,
-                                                     region="ctg1:0-%d" % min(info["genome_bases"] - 1, 3200000)))
+    if warm:      # library load, the workers' buffers grown to the size of the job's groups, the file in the page cache -- not part of the rate
+        ImageGenerationUtils.generate_images(options(data, os.path.join(data, "vimages_warm"), thread_counts[0], region_size))
         shutil.rmtree(os.path.join(data, "vimages_warm"), ignore_errors=True)
     runs = []
     for threads in thread_counts:
