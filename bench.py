@@ -930,7 +930,35 @@ def secondary_block(args):
     extra = ["--dir", scratch] if scratch else []
     out["make_images"] = make_images_leg(scratch)
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "8000000"], 300)
+
+    def inflate_roofline(d):
+        """Two roofs of bgzf_inflate_kernel for the launch just timed: HBM (algorithmic bytes = compressed in + inflated out) and
+        vector instruction issue (SQ_INSTS_VALU of the committed PMC pass of the same workload x 4 cycles over the SIMD-cycles the
+        launch had).  The second one binds."""
+        roof = {"bound": "hbm", "kernel": "bgzf_inflate_kernel", "algorithmic_bytes_per_launch": d["compressed_bytes"] + d["inflated_bytes"],
+                "achieved": (d["compressed_bytes"] + d["inflated_bytes"]) / d["kernel_ms"] / 1e6, "peak": 8000.0, "unit": "GB/s", "traffic": None}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        try:
+            ins = {}
+            path = os.path.join(REPO, "profiles", "r04_inflate_kernel_stats.txt")
+            for line in open(path):
+                parts = line.split()
+                if len(parts) >= 2 and parts[0].startswith("SQ_"):
+                    ins[parts[0]] = float(parts[1])
+            members = next(int(line.split()[1]) for line in open(path) if line.startswith("inflate:"))
+            scale = d["members"] / members                      # (the committed pass had this many members per launch)
+            simd_cycles = 1024 * d["kernel_ms"] * 1e-3 * 2.4e9
+            roof["issue"] = {"bound": "valu issue", "valu_wave_instructions": ins["SQ_INSTS_VALU"] * scale,
+                             "salu_wave_instructions": ins["SQ_INSTS_SALU"] * scale, "lds_wave_instructions": ins["SQ_INSTS_LDS"] * scale,
+                             "cycles_per_valu_instruction": 4, "simd_cycles_available": simd_cycles,
+                             "frac": 4.0 * ins["SQ_INSTS_VALU"] * scale / simd_cycles,
+                             "wait_share_of_wave_cycles": ins["SQ_WAIT_ANY"] / ins["SQ_WAVE_CYCLES"] if ins.get("SQ_WAVE_CYCLES") else None,
+                             "source": "profiles/r04_inflate_kernel_stats.txt"}
+        except Exception:       # noqa: BLE001
+            roof["issue"] = None
+        return roof
     out["bgzf_inflate"] = d if "error" in d else {
+        "roofline": inflate_roofline(d),
         "value": d["device_GBps_inflated"], "unit": "GB/s of inflated bytes", "kernel": "bgzf_inflate_kernel", "kernel_ms": d["kernel_ms"],
         "members": d["members"], "compressed_bytes": d["compressed_bytes"], "inflated_bytes": d["inflated_bytes"],
         "cpu_zlib_one_core_GBps": d["zlib_one_core_GBps"], "identical_to_zlib": d["sample_identical"],

@@ -7,20 +7,27 @@
 // <= 64 KiB DEFLATE streams -- the unit the chip parallelises over.
 //
 // DEFLATE is RFC 1951 (stored, fixed and dynamic blocks; the length / distance base-and-extra-bit tables below are the
-// RFC's, written as their closed forms).  A symbol is a chain of dependent steps (peek bits -> table -> consume), so a
-// wavefront decodes its block as UNIFORM code: bit buffer, table index, positions all live in scalar registers, the
-// 64 lanes serve as
-//   - the input window: lane l of `cur` holds compressed word 64 c + l, consumed with v_readlane (one global load per
-//     256 bytes of input, the next window already in flight),
-//   - the literal staging register: v_writelane puts literal k into lane k, one 64-byte store per 64 literals,
-//   - the match copier: a match of up to 258 bytes is one or a few byte-per-lane load/store pairs (overlapping matches,
-//     distance < length, read source byte (i mod distance): every source byte exists before the match starts),
-//   - the table builders (counting, the stable order of symbols by code length through ballots, the primary table filled
-//     one entry per lane).
+// RFC's, written as their closed forms).  A symbol is a chain of dependent steps (peek bits -> table -> consume); decoded
+// as uniform scalar code a member costs ~40 scalar instructions per symbol and the chip runs at the scalar units' issue
+// rate (14 GB/s, the first version of this file).  What is here instead, per step of one wavefront:
+//   1. 64 bit offsets at once: lane k looks up whatever would start at bit p + k of the stream -- literal/length code from
+//      the primary table, for a length symbol also its extra bits, the distance code behind them and that code's extra
+//      bits, all from the lane's own 64 bits (three words of a 512-byte window of the stream kept in LDS).  Most lanes
+//      sit inside a symbol: their result is never looked at.
+//   2. the symbols that do start in the window: follow the lengths from offset 0 (v_readlane per symbol, 6-7 per step).
+//   3. the step's OUTPUT, one lane per byte: the symbols mark their first byte in a 64-byte LDS scratch, a prefix maximum
+//      spreads the mark, ds_bpermute fetches the symbol's (value, distance); a match byte's source is memory in front of
+//      the step or an earlier byte of the same step, followed back between lanes to a literal or a memory byte.  One
+//      gather load and one store of up to 64 bytes per step.
+//   4. the step is completed one step later: its loads are in flight while the next window is decoded (a step whose
+//      sources reach into the pending bytes completes them first).
+// Steps of more than 64 output bytes (long matches) and codes longer than the primary tables take a per-symbol path.
 // Huffman tables in LDS: a primary table of 2^10 (literal/length) and 2^8 (distance) 16-bit entries (symbol << 4 | length),
 // longer codes through the canonical count/symbol arrays bit by bit (RFC 1951 3.2.2's numbering; rare by construction:
-// a code longer than 10 bits has probability < 2^-10).  3.9 KB of LDS per wavefront, so the 32 wavefront slots of a CU
-// all hold a block.
+// a code longer than 10 bits has probability < 2^-10).  Tables are built by all lanes: counts by LDS atomics, the stable
+// order of symbols by code length through ballots, the primary table one entry per lane.  4.6 KB of LDS and 64 VGPRs per
+// wavefront, so the 32 wavefront slots of a CU all hold a member.  A workgroup is one wavefront: hand-offs through LDS
+// need program order only (wave_order), no barrier.
 //
 // Checks: over-subscribed code sets, codes without a symbol, distances beyond the produced output, output beyond the
 // block's ISIZE, a stored block's LEN/NLEN complement, input consumed beyond the block -> a non-zero status word per
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                          const int32_t* __restrict__ out_len, uint8_t* out_base,
                                                          int32_t* __restrict__ status, unsigned long long* dbg) {
     __shared__ Tables T;
-    int n_steps = 0, n_match = 0, n_fallback = 0, n_blocks_in = 0, n_far = 0;
+    int n_steps = 0, n_match = 0, n_fallback = 0, n_blocks_in = 0;      // statistics for PA_INFLATE_DEBUG
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
     const int64_t coff = comp_off[blk];
@@ -555,7 +562,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         atomicAdd(&dbg[1], (unsigned long long)n_match);
         atomicAdd(&dbg[2], (unsigned long long)n_fallback);
         atomicAdd(&dbg[3], (unsigned long long)n_blocks_in);
-        atomicAdd(&dbg[4], (unsigned long long)n_far);
         atomicAdd(&dbg[5], (unsigned long long)pos);
     }
 }
