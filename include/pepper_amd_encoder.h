@@ -119,6 +119,16 @@ void* pa_encoder_host_span(pa_encoder* e, int64_t bytes);
 int pa_encoder_inflate_bgzf(pa_encoder* e, const uint8_t* comp, int64_t comp_bytes, int32_t n_blocks, const int64_t* comp_off,
                             const int32_t* comp_len, const int64_t* out_off, const int32_t* out_len, int64_t out_bytes,
                             uint8_t* host_out);
+/* The BAM records of the span pa_encoder_inflate_bgzf left on the device, read out THERE: 40 bytes per record
+ * (pa_record_header, include/pepper_amd_io.h: where its CIGAR / bases / qualities lie, position, counts, flags, the reference
+ * bases its operations cover) instead of the span itself back over PCIe -- pa_encoder_inflate_bgzf with host_out = NULL, then
+ * this, then pa_bam_pack_headers.  entries: record starts inside the span, ascending (pa_bam_span_entries: the first record and
+ * the linear index's entry of every later 16 kb window); one lane follows the records from each entry up to the next, at
+ * most cap_per_entry of them.  flags[0] != 0: nothing was copied -- 1 a lane ran out of slots, 2 a record shorter than its
+ * core fields, 4 more records than headers_cap; flags[1] = 1: the span ends inside a record (what the walk of
+ * pa_bam_pack_inflated treats as a cut).  The caller then takes the span to the host after all. */
+int pa_encoder_walk_records(pa_encoder* e, int64_t data_bytes, const int64_t* entries, int32_t n_entries, int32_t cap_per_entry,
+                            void* headers, int64_t headers_cap, int64_t* n_headers, int32_t* flags);
 /* Host threads of a run's candidate enumeration (one short task per region): 0 = the default (the CPUs the process may use),
  * 1 = the calling thread alone -- what image generation sets, whose workers each drive their own encoder while the other
  * CPUs inflate BGZF blocks. */

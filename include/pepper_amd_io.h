@@ -274,6 +274,28 @@ int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const 
  *                     span ends earlier the regions closed by then are done (*n_done) and the caller takes a later span for the
  *                     rest -- none closed: -9.  A record whose CIGAR lives in the CG tag is no single slice: -8, take
  *                     pa_bam_pack_regions for that batch. */
+/* One record of an inflated span as the device's walk reads it out (pa_encoder_walk_records, include/pepper_amd_encoder.h):
+ * data_off = where the record's `CIGAR words | bases | qualities` start in the span, ref_len = the reference bases its
+ * operations cover, state = 0, 1 (the placeholder of a CIGAR kept in the CG tag) or 2 (fields that overrun the record). */
+#ifndef PA_RECORD_HEADER_DEFINED
+#define PA_RECORD_HEADER_DEFINED
+typedef struct {
+    int64_t data_off;
+    int32_t ref_id, pos, l_seq, n_cigar;
+    int32_t flags;         /* BAM flag | mapping quality << 16 */
+    int32_t ref_len, state, block_size;
+} pa_record_header;
+#endif
+/* pa_bam_span_entries  record starts inside the span of the handle's last pa_bam_read_span, as offsets into the inflated bytes:
+ *                     first_record, then the linear index's entry of every later 16 kb window whose record lies in the span
+ *                     (ascending, distinct) -- where the device's walk starts its lanes.
+ * pa_bam_pack_headers  pa_bam_pack_inflated's walk over the headers the device read out instead of over the bytes. */
+int pa_bam_span_entries(pa_bam* b, const char* contig, int64_t first_record, const int64_t* out_off, int32_t n_blocks,
+                        int64_t* entries, int32_t entries_cap, int32_t* n_entries);
+int pa_bam_pack_headers(pa_bam* b, const pa_record_header* headers, int64_t n_headers, int32_t data_is_final, const char* contig,
+                        int32_t n_regions, const int64_t* start, const int64_t* stop, int32_t include_supplementary, int32_t min_mapq,
+                        pa_packed_read* reads, int32_t reads_cap, int32_t* pair_read, int32_t pairs_cap, int32_t* region_pairs,
+                        int32_t* n_done, int64_t* counts);
 int pa_bam_region_span(pa_bam* b, const char* contig, int64_t start, int64_t stop, int32_t lookahead_windows,
                        int64_t* begin_coffset, int32_t* begin_uoffset, int64_t* end_coffset, int32_t* to_contig_end);
 int pa_bam_read_span(pa_bam* b, int64_t begin, int64_t end_min, int32_t extra_members, uint8_t* buf, int64_t buf_cap,

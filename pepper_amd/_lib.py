@@ -72,6 +72,8 @@ SYMBOLS = [
     ("pa_encoder_host_span", c_void_p, [c_void_p, c_int64]),
     ("pa_encoder_inflate_bgzf", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                                c_void_p]),
+    ("pa_encoder_walk_records", ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_int64,
+                                               ctypes.POINTER(c_int64), c_void_p]),
     ("pa_encoder_region_reads", ctypes.c_int, [c_void_p, c_void_p, c_int32]),
     ("pa_encoder_set_host_threads", ctypes.c_int, [c_void_p, c_int32]),
     ("pa_encoder_last_timing", ctypes.c_int, [c_void_p, c_void_p, c_int32]),

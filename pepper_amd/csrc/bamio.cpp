@@ -218,6 +218,7 @@ struct pa_bam {
     std::vector<int64_t> pack_closed;
     std::string path;
     int span_fd = -1;                                          // pa_bam_read_span: its own descriptor (pread, no shared position)
+    std::vector<int64_t> span_members;                         // file offsets of the members of the last pa_bam_read_span
     int64_t file_bytes = -1;
 };
 
@@ -679,10 +680,11 @@ int pa_bam_get_reads(pa_bam* b, const char* contig, int64_t start, int64_t stop,
 // encoder), however many of the batch's regions the read reaches.  1.5 bytes per base + 4 per operation cross PCIe instead of
 // 2 + 8, and the host's per-base work is one memcpy.
 namespace {
-// The walk shared by pa_bam_pack_regions (records from the BGZF reader, slices copied into the arena) and
-// pa_bam_pack_inflated (mem != NULL: records in place in an inflated span, data_off = the slice's offset in the span).
+// The walk shared by pa_bam_pack_regions (records from the BGZF reader, slices copied into the arena),
+// pa_bam_pack_inflated (mem != NULL: records in place in an inflated span, data_off = the slice's offset in the span) and
+// pa_bam_pack_headers (hdrs != NULL: the same span, its record headers already read out by the device's walk).
 int pack_walk(pa_bam* b, int tid, bool nothing, const uint8_t* mem, int64_t mem_bytes, int64_t mem_first, bool mem_final,
-              int32_t n_regions, const int64_t* start, const int64_t* stop, int32_t include_supplementary, int32_t min_mapq,
+              const pa_record_header* hdrs, int64_t n_hdrs, int32_t n_regions, const int64_t* start, const int64_t* stop, int32_t include_supplementary, int32_t min_mapq,
               uint8_t* arena, int64_t arena_cap, pa_packed_read* reads, int32_t reads_cap, int32_t* pair_read, int32_t pairs_cap,
               int32_t* region_pairs, int32_t* n_done, int64_t* counts) {
     // pairs arrive read by read; they leave grouped by region
@@ -707,9 +709,22 @@ int pack_walk(pa_bam* b, int tid, bool nothing, const uint8_t* mem, int64_t mem_
             ++n_closed;
         }
     };
+    int64_t hk = 0;
     while (!nothing) {
         uint32_t block_size = 0;
         const uint8_t* R = nullptr;
+        int32_t ref_id, pos, mapq;
+        uint32_t n_cigar_op, flag, l_seq;
+        size_t o_cigar = 0, o_seq = 0, o_aux = 0;
+        const pa_record_header* H = nullptr;
+        if (hdrs) {
+            // the device's walk has read the headers: one entry per record of the span, in file order
+            if (hk >= n_hdrs) { cut = !mem_final; break; }
+            H = &hdrs[hk++];
+            if (H->state == 2) return bam_fail(-6, "corrupt BAM record");
+            ref_id = H->ref_id; pos = H->pos; mapq = (H->flags >> 16) & 0xff;
+            n_cigar_op = (uint32_t)H->n_cigar; flag = (uint32_t)H->flags & 0xffffu; l_seq = (uint32_t)H->l_seq;
+        } else {
         if (mem) {
             // records in place in an inflated span: one that the span cuts off ends the walk like a full table does
             // (a final span runs into the next contig's records or to the end of the file: what it cuts off is not this contig's)
@@ -737,21 +752,24 @@ int pack_walk(pa_bam* b, int tid, bool nothing, const uint8_t* mem, int64_t mem_
                 R = rec.data();
             }
         }
-        const int32_t ref_id = (int32_t)le32(R);
-        const int32_t pos = (int32_t)le32(R + 4);
-        const uint32_t l_read_name = R[8];
-        const int32_t mapq = R[9];
-        const uint32_t n_cigar_op = R[12] | (R[13] << 8);
-        const uint32_t flag = R[14] | (R[15] << 8);
-        const uint32_t l_seq = le32(R + 16);
+        ref_id = (int32_t)le32(R);
+        pos = (int32_t)le32(R + 4);
+        mapq = R[9];
+        n_cigar_op = R[12] | (R[13] << 8);
+        flag = R[14] | (R[15] << 8);
+        l_seq = le32(R + 16);
+        }
         if (ref_id != tid) {
             if (ref_id > tid || ref_id < 0) break;
             continue;
         }
         if (pos >= last_stop) break;
-        const size_t o_cigar = 32 + (size_t)l_read_name, o_seq = o_cigar + 4ull * n_cigar_op, o_qual = o_seq + (l_seq + 1) / 2,
-                     o_aux = o_qual + l_seq;
-        if (o_aux > block_size) return bam_fail(-6, "corrupt BAM record");
+        if (!H) {
+            o_cigar = 32 + (size_t)R[8];
+            o_seq = o_cigar + 4ull * n_cigar_op;
+            o_aux = o_seq + (l_seq + 1) / 2 + l_seq;
+            if (o_aux > block_size) return bam_fail(-6, "corrupt BAM record");
+        }
         close_up_to(pos);
         while (r_lo < n_regions && stop[r_lo] <= pos) ++r_lo;
         // ---- filters of get_reads (:138-151); a record without bases has nothing to pile up ----
@@ -759,9 +777,9 @@ int pack_walk(pa_bam* b, int tid, bool nothing, const uint8_t* mem, int64_t mem_
         if (!include_supplementary && (flag & 0x800)) continue;
         if (mapq < min_mapq) continue;
         if (l_seq == 0) continue;
-        const uint8_t* cig = R + o_cigar;
+        const uint8_t* cig = H ? nullptr : R + o_cigar;
         uint32_t n_cig = n_cigar_op;
-        if (n_cigar_op >= 1 && (le32(cig) & 15) == 4 && (le32(cig) >> 4) == l_seq) {      // long CIGAR in the CG tag (as above)
+        if (!H && n_cigar_op >= 1 && (le32(cig) & 15) == 4 && (le32(cig) >> 4) == l_seq) {      // long CIGAR in the CG tag (as above)
             uint32_t cnt = 0;
             const uint8_t* real = find_cg(R + o_aux, R + block_size, &cnt);
             if (real && cnt >= n_cigar_op && cnt < (1u << 29)) {
@@ -772,7 +790,7 @@ int pack_walk(pa_bam* b, int tid, bool nothing, const uint8_t* mem, int64_t mem_
         if (n_cig == 0) continue;                            // no alignment to walk: get_reads keeps nothing of it
         // the region test of the iterator: pos < stop and end > start, end = pos + reference length (at least pos + 1); only a
         // read that starts in front of a region needs its end
-        int64_t end = -1;
+        int64_t end = H ? (int64_t)pos + std::max<int64_t>(1, H->ref_len) : -1;     // (the device's walk summed the operations)
         int first_pair = -1;
         for (int r = r_lo; r < n_regions && start[r] < (end < 0 ? (int64_t)0x7fffffffffffll : end); ++r) {
             if (pos >= stop[r]) continue;
@@ -796,7 +814,15 @@ int pack_walk(pa_bam* b, int tid, bool nothing, const uint8_t* mem, int64_t mem_
         if (first_pair < 0) continue;
         const int64_t bytes = 4ll * n_cig + (l_seq + 1) / 2 + l_seq;
         int64_t at;
-        if (mem) {
+        if (H) {
+            if (H->state == 1) return bam_fail(-8, "pack_headers: a record keeps its CIGAR in the CG tag (take pack_regions)");
+            if (n_reads >= reads_cap) {
+                pairs.resize((size_t)first_pair);
+                full = true;
+                break;
+            }
+            at = H->data_off;
+        } else if (mem) {
             // in place: the slice is the record's own bytes (any alignment); a CIGAR kept in the CG tag is not one slice
             if (cig != R + o_cigar) return bam_fail(-8, "pack_inflated: a record keeps its CIGAR in the CG tag (take pack_regions)");
             if (n_reads >= reads_cap) {
@@ -825,7 +851,7 @@ int pack_walk(pa_bam* b, int tid, bool nothing, const uint8_t* mem, int64_t mem_
         pr.n_cigar = (int32_t)n_cig;
         pr.l_seq = (int32_t)l_seq;
         pr.flags = (int32_t)(flag | ((uint32_t)mapq << 16));
-        used = mem ? used + bytes : at + bytes;
+        used = (mem || H) ? used + bytes : at + bytes;
     }
     if (!full && !cut) close_up_to(0x7fffffffffffffffll);        // the walk ended: every region is complete
     if (n_closed == 0) {
@@ -887,7 +913,7 @@ int pa_bam_pack_regions(pa_bam* b, const char* contig, int32_t n_regions, const 
     b->bg.failed = false;
     if (!nothing && !b->bg.seek(from)) return bam_fail(-5, "BGZF seek failed (corrupt file or index)");
 
-    return pack_walk(b, tid, nothing, nullptr, 0, 0, false, n_regions, start, stop, include_supplementary, min_mapq, arena, arena_cap,
+    return pack_walk(b, tid, nothing, nullptr, 0, 0, false, nullptr, 0, n_regions, start, stop, include_supplementary, min_mapq, arena, arena_cap,
                      reads, reads_cap, pair_read, pairs_cap, region_pairs, n_done, counts);
 }
 
@@ -960,6 +986,7 @@ int pa_bam_read_span(pa_bam* b, int64_t begin, int64_t end_min, int32_t extra_me
     *n_blocks = 0;
     *comp_bytes = *out_bytes = 0;
     *complete = 0;
+    b->span_members.clear();
     end_min = std::min(end_min, b->file_bytes);
     const int64_t want = std::min<int64_t>(b->file_bytes - begin, (end_min - begin) + ((int64_t)extra_members + 1) * 65536);
     if (want <= 0) { *complete = 1; return 0; }
@@ -997,6 +1024,7 @@ int pa_bam_read_span(pa_bam* b, int64_t begin, int64_t end_min, int32_t extra_me
         if (n >= blocks_cap) break;
         const uint32_t isize = le32(h + bsize - 4);
         if (isize > 65536) return bam_fail(-5, "BGZF member larger than 64 KiB");
+        b->span_members.push_back(begin + p);
         comp_off[n] = p + 12 + xlen;
         comp_len[n] = clen;
         out_off[n] = at;
@@ -1010,6 +1038,54 @@ int pa_bam_read_span(pa_bam* b, int64_t begin, int64_t end_min, int32_t extra_me
     *out_bytes = at;
     *complete = covered ? (at_eof ? 3 : 1) : 0;
     return 0;
+}
+
+int pa_bam_span_entries(pa_bam* b, const char* contig, int64_t first_record, const int64_t* out_off, int32_t n_blocks,
+                        int64_t* entries, int32_t entries_cap, int32_t* n_entries) {
+    if (!b || !contig || !out_off || !entries || !n_entries || entries_cap < 1 || first_record < 0 || n_blocks < 0)
+        return bam_fail(-1, "null or invalid argument");
+    if ((size_t)n_blocks != b->span_members.size()) return bam_fail(-1, "span_entries: not the tables of the handle's last read_span");
+    const int tid = find_tid(b, contig);
+    if (tid < 0) return bam_fail(-4, std::string("contig not in the BAM header: ") + contig);
+    int32_t n = 0;
+    entries[n++] = first_record;
+    if (b->has_index && tid < (int)b->ioff.size() && n_blocks > 0) {
+        const auto& members = b->span_members;
+        for (const uint64_t v : b->ioff[tid]) {
+            if (v == 0) continue;
+            const int64_t c = (int64_t)(v >> 16);
+            if (c < members.front() || c > members.back()) continue;
+            const auto it = std::lower_bound(members.begin(), members.end(), c);
+            if (it == members.end() || *it != c) continue;                   // (not a member start: a foreign index)
+            const int64_t at = out_off[it - members.begin()] + (int64_t)(v & 0xffff);
+            if (at <= entries[n - 1]) continue;
+            if (n >= entries_cap) break;
+            entries[n++] = at;
+        }
+    }
+    *n_entries = n;
+    return 0;
+}
+
+int pa_bam_pack_headers(pa_bam* b, const pa_record_header* headers, int64_t n_headers, int32_t data_is_final, const char* contig,
+                        int32_t n_regions, const int64_t* start, const int64_t* stop, int32_t include_supplementary, int32_t min_mapq,
+                        pa_packed_read* reads, int32_t reads_cap, int32_t* pair_read, int32_t pairs_cap, int32_t* region_pairs,
+                        int32_t* n_done, int64_t* counts) {
+    if (!b || !contig || n_regions < 0 || (n_regions > 0 && (!start || !stop)) || (n_headers > 0 && !headers) || n_headers < 0 ||
+        !reads || !pair_read || !region_pairs || !n_done)
+        return bam_fail(-1, "null argument");
+    *n_done = 0;
+    for (int r = 0; r <= n_regions; ++r) region_pairs[r] = 0;
+    if (counts) counts[0] = counts[1] = counts[2] = 0;
+    if (n_regions == 0) return 0;
+    for (int r = 0; r < n_regions; ++r)
+        if (stop[r] < start[r] || (r > 0 && (start[r] < start[r - 1] || stop[r] < stop[r - 1])))
+            return bam_fail(-1, "pack_headers: regions must be ascending in start and stop");
+    const int tid = find_tid(b, contig);
+    if (tid < 0) return bam_fail(-4, std::string("contig not in the BAM header: ") + contig);
+    static const pa_record_header none{};
+    return pack_walk(b, tid, false, nullptr, 0, 0, data_is_final != 0, headers ? headers : &none, n_headers, n_regions, start, stop,
+                     include_supplementary, min_mapq, nullptr, 0, reads, reads_cap, pair_read, pairs_cap, region_pairs, n_done, counts);
 }
 
 int pa_bam_pack_inflated(pa_bam* b, const uint8_t* data, int64_t data_bytes, int64_t first_record, int32_t data_is_final,
@@ -1029,7 +1105,7 @@ int pa_bam_pack_inflated(pa_bam* b, const uint8_t* data, int64_t data_bytes, int
     const int tid = find_tid(b, contig);
     if (tid < 0) return bam_fail(-4, std::string("contig not in the BAM header: ") + contig);
     static const uint8_t none = 0;
-    return pack_walk(b, tid, false, data ? data : &none, data_bytes, first_record, data_is_final != 0, n_regions, start, stop,
+    return pack_walk(b, tid, false, data ? data : &none, data_bytes, first_record, data_is_final != 0, nullptr, 0, n_regions, start, stop,
                      include_supplementary, min_mapq, nullptr, 0, reads, reads_cap, pair_read, pairs_cap, region_pairs, n_done, counts);
 }
 

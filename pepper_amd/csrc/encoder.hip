@@ -1021,8 +1021,8 @@ struct pa_variant_batch {
     const int32_t* p_tile_region = nullptr;
     const char* p_ref = nullptr;
     // packed form: the caller's arena as uploaded, the tables, what unpack_clip_kernel reports per region
-    DBuf d_arena, d_meta, d_live, d_pool, d_comp, d_inf;
-    HBuf h_arena, h_meta, h_live, h_pool, h_comp, h_inf;
+    DBuf d_arena, d_meta, d_live, d_pool, d_comp, d_inf, d_walk;
+    HBuf h_arena, h_meta, h_live, h_pool, h_comp, h_inf, h_walk;
     int64_t resident_bytes = 0;      // inflated bytes pa_encoder_inflate_bgzf left in d_arena (0: none)
     std::vector<int32_t> live;        // reads with a base inside each region (the reference's len(all_reads)) of the last run
     DBuf d_zero;                      // counters [CT_N] | per-region counts [2 n_regions] | tile_count [n_tiles] | tile_fill [n_tiles]: cleared per run
@@ -1834,6 +1834,53 @@ int pa_encoder_inflate_bgzf(pa_encoder* e, const uint8_t* comp, int64_t comp_byt
         if (status[k] != 0)
             return pa::set_error(PA_ERR_INVALID, "BGZF block " + std::to_string(k) + ": " + pa::inflate_status_text(status[k]));
     b.resident_bytes = out_bytes;
+    return PA_OK;
+}
+
+// The record headers of the span pa_encoder_inflate_bgzf left on the device (inflate.hip: record_chase_kernel and friends)
+int pa_encoder_walk_records(pa_encoder* e, int64_t data_bytes, const int64_t* entries, int32_t n_entries, int32_t cap_per_entry,
+                            void* headers, int64_t headers_cap, int64_t* n_headers, int32_t* flags) {
+    if (!e || !entries || n_entries < 1 || cap_per_entry < 1 || !headers || headers_cap < 0 || !n_headers || !flags || data_bytes < 0)
+        return pa::set_error(PA_ERR_INVALID, "null or invalid argument");
+    *n_headers = 0;
+    flags[0] = flags[1] = 0;
+    if (!e->variant || e->variant->resident_bytes <= 0 || data_bytes > e->variant->resident_bytes)
+        return pa::set_error(PA_ERR_INVALID, "no inflated span of that size resident on the device");
+    for (int32_t k = 0; k < n_entries; ++k)
+        if (entries[k] < 0 || entries[k] > data_bytes || (k > 0 && entries[k] <= entries[k - 1]))
+            return pa::set_error(PA_ERR_INVALID, "record entries must ascend inside the span");
+    ENC_HIP(hipSetDevice(e->device));
+    pa_variant_batch& b = *e->variant;
+    hipStream_t st = e->stream;
+    const size_t n = (size_t)n_entries, slots = n * (size_t)cap_per_entry;
+    const size_t o_counts = n * 8, o_base = o_counts + n * 4, o_flags = o_base + (n + 1) * 4, o_slots = (o_flags + 8 + 63) & ~(size_t)63,
+                 o_out = o_slots + slots * 40, total = o_out + slots * 40;
+    ENC_ALLOC(b.d_walk, total);
+    if (!b.h_walk.ensure(n * 8 + 64)) return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed in the record walk");
+    char* dw = b.d_walk.as<char>();
+    char* hw = b.h_walk.as<char>();
+    std::memcpy(hw, entries, n * 8);
+    const auto t0 = std::chrono::steady_clock::now();
+    ENC_HIP(hipMemcpyAsync(dw, hw, n * 8, hipMemcpyHostToDevice, st));
+    ENC_HIP(hipMemsetAsync(dw + o_flags, 0, 8, st));
+    pa::launch_record_walk(st, b.d_arena.as<uint8_t>(), data_bytes, reinterpret_cast<const int64_t*>(dw), n_entries, cap_per_entry,
+                           dw + o_slots, reinterpret_cast<int32_t*>(dw + o_counts), reinterpret_cast<int32_t*>(dw + o_base),
+                           reinterpret_cast<int32_t*>(dw + o_flags), dw + o_out);
+    ENC_HIP(hipGetLastError());
+    int32_t* tail = reinterpret_cast<int32_t*>(hw + n * 8);            // [0] the number of records, [1..2] the flags
+    ENC_HIP(hipMemcpyAsync(tail, dw + o_base + n * 4, 4, hipMemcpyDeviceToHost, st));
+    ENC_HIP(hipMemcpyAsync(tail + 1, dw + o_flags, 8, hipMemcpyDeviceToHost, st));
+    ENC_HIP(hipStreamSynchronize(st));
+    flags[0] = tail[1];
+    flags[1] = tail[2];
+    const int64_t found = tail[0];
+    if (flags[0] == 0 && found > headers_cap) flags[0] |= 4;            // the caller's table is too small
+    if (flags[0] == 0 && found > 0) {
+        ENC_HIP(hipMemcpyAsync(headers, dw + o_out, (size_t)found * 40, hipMemcpyDeviceToHost, st));
+        ENC_HIP(hipStreamSynchronize(st));
+    }
+    *n_headers = flags[0] == 0 ? found : 0;
+    b.ms[11] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PA_OK;
 }
 

@@ -566,7 +566,109 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
 }
 
+// ---- the BAM records of an inflated span ---------------------------------------------------------------------------
+// A BAM record says how long it is and nothing else: finding the records is a pointer chase.  The linear index gives a
+// record start per 16 kb window; one lane per such entry follows the block sizes up to the next entry (one dependent
+// 4-byte load per record, the 32-byte core read beside it), then one wavefront per record sums the reference bases of its
+// operations.  What leaves the device is 40 bytes per record instead of the span.
+struct RecHdr { int64_t data_off; int32_t ref_id, pos, l_seq, n_cigar, flags, ref_len, state, block_size; };   // = pa_record_header
+
+PA_DEV uint32_t load32(const uint8_t* p) {
+    typedef uint32_t __attribute__((aligned(1))) word_any;
+    return *reinterpret_cast<const word_any*>(p);
+}
+
+// flags[0]: 1 a lane ran out of slots, 2 a record shorter than its core;  flags[1]: 1 the span ends inside a record
+__global__ __launch_bounds__(64) void record_chase_kernel(const uint8_t* __restrict__ data, int64_t data_bytes,
+                                                         const int64_t* __restrict__ entries, int n_entries, int cap,
+                                                         RecHdr* __restrict__ slots, int32_t* __restrict__ counts, int32_t* flags) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_entries) return;
+    int64_t at = entries[i];
+    const int64_t stop = i + 1 < n_entries ? entries[i + 1] : data_bytes;
+    RecHdr* mine = slots + (size_t)i * cap;
+    int j = 0;
+    while (at < stop) {
+        if (at + 4 > data_bytes) { atomicOr(&flags[1], 1); break; }
+        const uint32_t bs = load32(data + at);
+        if (bs < 32) { atomicOr(&flags[0], 2); break; }
+        if (at + 4 + (int64_t)bs > data_bytes) { atomicOr(&flags[1], 1); break; }
+        if (j >= cap) { atomicOr(&flags[0], 1); break; }
+        const uint8_t* R = data + at + 4;
+        const uint32_t w2 = load32(R + 8), w3 = load32(R + 12);
+        RecHdr h;
+        h.ref_id = (int32_t)load32(R);
+        h.pos = (int32_t)load32(R + 4);
+        h.l_seq = (int32_t)load32(R + 16);
+        h.n_cigar = (int32_t)(w3 & 0xffffu);
+        h.flags = (int32_t)((w3 >> 16) | (((w2 >> 8) & 0xffu) << 16));
+        const int64_t o_cigar = 32 + (int64_t)(w2 & 0xffu);
+        h.data_off = at + 4 + o_cigar;
+        h.ref_len = 0;
+        h.block_size = (int32_t)bs;
+        const int64_t o_aux = o_cigar + 4ll * h.n_cigar + ((int64_t)(uint32_t)h.l_seq + 1) / 2 + (int64_t)(uint32_t)h.l_seq;
+        h.state = (h.l_seq < 0 || o_aux > (int64_t)bs) ? 2 : 0;
+        mine[j++] = h;
+        at += 4 + (int64_t)bs;
+    }
+    counts[i] = j;
+}
+
+// exclusive prefix of the lanes' record counts (n_entries is a few hundred at most: one wavefront, 64 at a time)
+__global__ __launch_bounds__(64) void record_base_kernel(const int32_t* __restrict__ counts, int n_entries, int32_t* __restrict__ base) {
+    int carry = 0;
+    for (int i0 = 0; i0 < n_entries; i0 += 64) {
+        const int i = i0 + (int)threadIdx.x;
+        const int c = i < n_entries ? counts[i] : 0;
+        const int incl = wave_scan_add(c);
+        if (i < n_entries) base[i] = carry + incl - c;
+        carry += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (threadIdx.x == 0) base[n_entries] = carry;
+}
+
+// one wavefront per slot: the reference bases of the record's operations; the placeholder of a CIGAR kept in the CG tag
+// (kSmN, SAM specification 4.2.2: first operation S over all bases) marks the record for the host path
+__global__ __launch_bounds__(256) void record_finish_kernel(const uint8_t* __restrict__ data, const RecHdr* __restrict__ slots,
+                                                           const int32_t* __restrict__ counts, const int32_t* __restrict__ base,
+                                                           int cap, int n_entries, RecHdr* __restrict__ out) {
+    const int slot = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = slot / cap, j = slot - i * cap;
+    if (i >= n_entries || j >= counts[i]) return;
+    RecHdr h = slots[(size_t)i * cap + j];
+    int ref = 0;
+    if (h.state == 0) {
+        const uint8_t* cig = data + h.data_off;
+        for (int k0 = 0; k0 < h.n_cigar; k0 += 64) {
+            const int k = k0 + lane;
+            const uint32_t c = k < h.n_cigar ? load32(cig + 4ll * k) : 5u;
+            const int op = (int)(c & 15u);
+            ref += (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ? (int)(c >> 4) : 0;
+        }
+        for (int o = 32; o > 0; o >>= 1) ref += __shfl_xor(ref, o, 64);
+        if (h.n_cigar >= 1) {
+            const uint32_t c0 = load32(cig);
+            if ((c0 & 15u) == 4u && (int)(c0 >> 4) == h.l_seq) h.state = 1;
+        }
+    }
+    if (lane == 0) {
+        h.ref_len = ref;
+        out[base[i] + j] = h;
+    }
+}
+
 }  // namespace
+
+void launch_record_walk(hipStream_t stream, const uint8_t* data, int64_t data_bytes, const int64_t* entries, int n_entries, int cap,
+                        void* slots, int32_t* counts, int32_t* base, int32_t* flags, void* out) {
+    if (n_entries <= 0) return;
+    hipLaunchKernelGGL(record_chase_kernel, dim3((unsigned)((n_entries + 63) / 64)), dim3(64), 0, stream, data, data_bytes, entries,
+                       n_entries, cap, static_cast<RecHdr*>(slots), counts, flags);
+    hipLaunchKernelGGL(record_base_kernel, dim3(1), dim3(64), 0, stream, counts, n_entries, base);
+    const long long n_slots = (long long)n_entries * cap;
+    hipLaunchKernelGGL(record_finish_kernel, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, stream, data,
+                       static_cast<const RecHdr*>(slots), counts, base, cap, n_entries, static_cast<RecHdr*>(out));
+}
 
 void launch_bgzf_inflate(hipStream_t stream, const uint8_t* comp, const int64_t* comp_off, const int32_t* comp_len,
                          const int64_t* out_off, const int32_t* out_len, uint8_t* out, int32_t* status, int n_blocks,

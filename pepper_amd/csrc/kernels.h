@@ -134,4 +134,9 @@ void launch_bgzf_inflate(hipStream_t stream, const uint8_t* comp, const int64_t*
                          const int64_t* out_off, const int32_t* out_len, uint8_t* out, int32_t* status, int n_blocks,
                          unsigned long long* debug_counts = nullptr);
 const char* inflate_status_text(int32_t s);
+// the BAM records of an inflated span (inflate.hip): entries = record starts (ascending; a lane follows the records from each
+// up to the next), slots [n_entries][cap] and out [<= n_entries * cap] of 40-byte pa_record_header, counts [n_entries],
+// base [n_entries + 1] (base[n_entries] = the number of records), flags [2] (zeroed by the caller)
+void launch_record_walk(hipStream_t stream, const uint8_t* data, int64_t data_bytes, const int64_t* entries, int n_entries, int cap,
+                        void* slots, int32_t* counts, int32_t* base, int32_t* flags, void* out);
 }  // namespace pa

@@ -11,6 +11,7 @@ struct-of-arrays form (images already int8-packed on the device) for callers tha
 per-candidate Python objects.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -289,6 +290,8 @@ class PackedEncoder(object):
         self.pair_read = np.zeros(max_pairs, np.int32)
         self.span = None                # page-locked block for a file span's BGZF members (pack_device), allocated on first use
         self.tables = None
+        self.headers = None             # record headers of a span as the device's walk returns them
+        self.entries = None
         self.inflate_ms = 0.0           # device time of the inflate kernels of this object's pack_device calls
         self.inflated_bytes = 0
 
@@ -344,19 +347,46 @@ class PackedEncoder(object):
             laps["bam_span_read"] = laps.get("bam_span_read", 0.0) + time.perf_counter() - t0
             t0 = time.perf_counter()
         comp_off, comp_len, out_off, out_len = self.tables
-        _lib.check(self.lib.pa_encoder_inflate_bgzf(self.enc, self.span.ctypes.data, comp_bytes, n_blocks, comp_off.ctypes.data,
-                                                    comp_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data, out_bytes,
-                                                    self.arena.ctypes.data))
-        ms = np.zeros(12, np.float64)
-        _lib.check(self.lib.pa_encoder_last_timing(self.enc, ms.ctypes.data, 12))
-        self.inflate_ms += float(ms[10])
-        self.inflated_bytes += int(out_bytes)
+        device_walk = os.environ.get("PEPPER_AMD_DEVICE_WALK", "1") != "0"
+
+        def inflate(host_copy):
+            _lib.check(self.lib.pa_encoder_inflate_bgzf(self.enc, self.span.ctypes.data, comp_bytes, n_blocks, comp_off.ctypes.data,
+                                                        comp_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data, out_bytes,
+                                                        self.arena.ctypes.data if host_copy else None))
+            ms = np.zeros(12, np.float64)
+            _lib.check(self.lib.pa_encoder_last_timing(self.enc, ms.ctypes.data, 12))
+            self.inflate_ms += float(ms[10])
+            self.inflated_bytes += int(out_bytes)
+        inflate(not device_walk)
         if laps is not None:
             laps["bam_inflate_device"] = laps.get("bam_inflate_device", 0.0) + time.perf_counter() - t0
             t0 = time.perf_counter()
+        headers = None
+        if device_walk:
+            # the record headers read out on the device (40 bytes per record come back instead of the span)
+            if self.headers is None:
+                from pepper_amd.variant.bam import RECORD_HEADER
+                self.headers = np.zeros(max(1 << 16, self.arena.nbytes // 512), RECORD_HEADER)
+                self.entries = np.zeros(8192, np.int64)
+            n_entries = bam_handler.span_entries(contig, first, out_off, n_blocks, self.entries)
+            n_headers, flags = ctypes.c_int64(), np.zeros(2, np.int32)
+            _lib.check(self.lib.pa_encoder_walk_records(self.enc, out_bytes, self.entries.ctypes.data, n_entries, 2048,
+                                                        self.headers.ctypes.data, len(self.headers), ctypes.byref(n_headers),
+                                                        flags.ctypes.data))
+            if flags[0] == 0:
+                headers = n_headers.value
+            else:
+                inflate(True)                        # (a window with more records than a lane's slots, ...: the span to the host after all)
+            if laps is not None:
+                laps["bam_walk_device"] = laps.get("bam_walk_device", 0.0) + time.perf_counter() - t0
+                t0 = time.perf_counter()
         try:
-            n_done, region_pairs, counts = bam_handler.pack_inflated(self.arena, out_bytes, first, final, contig, starts[:n], stops[:n],
-                                                                     include_supplementary, min_mapq, self.reads, self.pair_read)
+            if headers is not None:
+                n_done, region_pairs, counts = bam_handler.pack_headers(self.headers, headers, final, contig, starts[:n], stops[:n],
+                                                                        include_supplementary, min_mapq, self.reads, self.pair_read)
+            else:
+                n_done, region_pairs, counts = bam_handler.pack_inflated(self.arena, out_bytes, first, final, contig, starts[:n], stops[:n],
+                                                                         include_supplementary, min_mapq, self.reads, self.pair_read)
         except BamError as err:
             if getattr(err, "code", 0) in (-7, -8, -9):
                 return None

@@ -35,6 +35,9 @@ SYMBOLS = [
                                           ctypes.POINTER(c_int32)]),
     ("pa_bam_read_span", ctypes.c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int32, ctypes.POINTER(c_int32), P64, P64, ctypes.POINTER(c_int32)]),
+    ("pa_bam_span_entries", ctypes.c_int, [c_void_p, c_char_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, ctypes.POINTER(c_int32)]),
+    ("pa_bam_pack_headers", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_char_p, c_int32, c_void_p, c_void_p, c_int32, c_int32,
+                                           c_void_p, c_int32, c_void_p, c_int32, c_void_p, ctypes.POINTER(c_int32), c_void_p]),
     ("pa_bam_pack_inflated", ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_char_p, c_int32, c_void_p, c_void_p,
                                             c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                                             ctypes.POINTER(c_int32), c_void_p]),
@@ -133,6 +136,8 @@ class ReadSet(object):
 
 PACKED_READ = np.dtype([("data_off", np.int64), ("pos", np.int32), ("n_cigar", np.int32), ("l_seq", np.int32),
                         ("flags", np.int32)])          # pa_packed_read (include/pepper_amd_io.h)
+RECORD_HEADER = np.dtype([("data_off", np.int64), ("ref_id", np.int32), ("pos", np.int32), ("l_seq", np.int32), ("n_cigar", np.int32),
+                          ("flags", np.int32), ("ref_len", np.int32), ("state", np.int32), ("block_size", np.int32)])      # pa_record_header
 
 
 class BAM_handler(object):
@@ -229,6 +234,29 @@ class BAM_handler(object):
                                        min(len(comp_off), len(comp_len), len(out_off), len(out_len)), ctypes.byref(n),
                                        ctypes.byref(cb), ctypes.byref(ob), ctypes.byref(done)))
         return n.value, cb.value, ob.value, bool(done.value & 1), bool(done.value & 2)
+
+    def span_entries(self, chromosome, first_record, out_off, n_blocks, entries):
+        """Record starts inside the last read_span's inflated bytes (first_record, then the linear index's entries) into the
+        int64 array `entries` -> their number."""
+        n = c_int32()
+        _check(_lib().pa_bam_span_entries(self._h, str(chromosome).encode(), int(first_record), out_off.ctypes.data, int(n_blocks),
+                                          entries.ctypes.data, len(entries), ctypes.byref(n)))
+        return n.value
+
+    def pack_headers(self, headers, n_headers, data_is_final, chromosome, starts, stops, include_supplementary, min_mapq, reads,
+                     pair_read):
+        """pa_bam_pack_headers: pack_inflated's tables from the record headers the device read out (array of RECORD_HEADER)."""
+        starts = np.ascontiguousarray(starts, np.int64)
+        stops = np.ascontiguousarray(stops, np.int64)
+        n = len(starts)
+        region_pairs = np.zeros(n + 1, np.int32)
+        counts = np.zeros(3, np.int64)
+        n_done = c_int32()
+        _check(_lib().pa_bam_pack_headers(self._h, headers.ctypes.data, int(n_headers), int(bool(data_is_final)), str(chromosome).encode(),
+                                          n, starts.ctypes.data, stops.ctypes.data, int(bool(include_supplementary)), int(min_mapq),
+                                          reads.ctypes.data, len(reads), pair_read.ctypes.data, len(pair_read),
+                                          region_pairs.ctypes.data, ctypes.byref(n_done), counts.ctypes.data))
+        return n_done.value, region_pairs, (int(counts[0]), int(counts[1]), int(counts[2]))
 
     def pack_inflated(self, data, data_bytes, first_record, data_is_final, chromosome, starts, stops, include_supplementary,
                       min_mapq, reads, pair_read):

@@ -422,3 +422,82 @@ def test_pack_inflated_refuses_a_cigar_in_the_cg_tag(tmp_path):
         bam.pack_inflated(data, data_bytes, first, final, "chrA", [0], [1000], False, 0, np.zeros(10, PACKED_READ), np.zeros(10, np.int32))
     assert e.value.code == -8
     bam.close()
+
+
+def _host_headers(data, data_bytes, first):
+    """What the device's record walk returns (pa_record_header per record of the span), derived here record by record."""
+    from pepper_amd.variant.bam import RECORD_HEADER
+    out, at = [], int(first)
+    while at + 4 <= data_bytes:
+        bs = int.from_bytes(data[at:at + 4].tobytes(), "little")
+        if at + 4 + bs > data_bytes:
+            break
+        R = data[at + 4:at + 4 + bs].tobytes()
+        ref_id, pos = int.from_bytes(R[0:4], "little", signed=True), int.from_bytes(R[4:8], "little", signed=True)
+        l_name, mapq = R[8], R[9]
+        n_cig, flag, l_seq = int.from_bytes(R[12:14], "little"), int.from_bytes(R[14:16], "little"), int.from_bytes(R[16:20], "little")
+        words = np.frombuffer(R[32 + l_name:32 + l_name + 4 * n_cig], "<u4")
+        ref_len = int(sum(int(w) >> 4 for w in words if (int(w) & 15) in (0, 2, 3, 7, 8)))
+        state = 1 if n_cig >= 1 and (int(words[0]) & 15) == 4 and (int(words[0]) >> 4) == l_seq else 0
+        out.append((at + 4 + 32 + l_name, ref_id, pos, l_seq, n_cig, flag | mapq << 16, ref_len, state, bs))
+        at += 4 + bs
+    return np.array(out, RECORD_HEADER), at
+
+
+def test_pack_headers_equals_pack_inflated_and_entries_are_record_starts(tmp_path):
+    """pa_bam_pack_headers over the headers of a span's records (what the device's walk reads out) == pa_bam_pack_inflated over
+    the span's bytes; pa_bam_span_entries lists record starts (the first record, then the linear index's windows)."""
+    from pepper_amd.variant.bam import PACKED_READ
+    rng = np.random.default_rng(49)
+    reads = _mixed_reads(rng, 150000, 1400, (300, 9000))
+    tail = _mixed_reads(rng, 20000, 60, (200, 2000))
+    path = str(tmp_path / "h.bam")
+    bu.write_bam(path, [("chrA", 150000), ("chrB", 20000)], {0: reads, 1: tail}, flush_every=31)
+    bam = BAM_handler(path)
+    for starts, stops, lookahead in (([20000, 30000, 40000], [30100, 40100, 50100], 4), ([100000, 120000], [120000, 150000], 2),
+                                     ([20000, 60000, 100000], [60000, 100000, 140000], 0)):
+        import zlib
+        begin, first, end, final = bam.region_span("chrA", starts[0], stops[-1], lookahead)
+        buf = np.zeros(1 << 26, np.uint8)
+        tables = (np.zeros(4096, np.int64), np.zeros(4096, np.int32), np.zeros(4096, np.int64), np.zeros(4096, np.int32))
+        n, comp_bytes, out_bytes, complete, at_eof = bam.read_span(begin, end, buf, tables, 1)
+        assert complete
+        final = final or at_eof
+        data = np.zeros(out_bytes + 8, np.uint8)
+        for k in range(n):
+            o, l, at, m = int(tables[0][k]), int(tables[1][k]), int(tables[2][k]), int(tables[3][k])
+            data[at:at + m] = np.frombuffer(zlib.decompress(buf[o:o + l].tobytes(), -15), np.uint8)
+        headers, walked_to = _host_headers(data, out_bytes, first)
+        assert len(headers) > 100
+        entries = np.zeros(1024, np.int64)
+        n_entries = bam.span_entries("chrA", first, tables[2], n, entries)
+        starts_of_records = set()
+        at = int(first)
+        for h in headers:
+            starts_of_records.add(at)
+            at += 4 + int(h["block_size"])
+        assert n_entries >= 2 and int(entries[0]) == first and all(int(e) in starts_of_records for e in entries[:n_entries])
+        assert np.all(np.diff(entries[:n_entries]) > 0)
+        t1, p1 = np.zeros(8000, PACKED_READ), np.zeros(16000, np.int32)
+        t2, p2 = np.zeros(8000, PACKED_READ), np.zeros(16000, np.int32)
+        try:
+            a = bam.pack_inflated(data, out_bytes, first, final, "chrA", starts, stops, False, 1, t1, p1)
+        except BamError as err:
+            with pytest.raises(BamError) as again:
+                bam.pack_headers(headers, len(headers), final, "chrA", starts, stops, False, 1, t2, p2)
+            assert again.value.code == err.code
+            continue
+        b = bam.pack_headers(headers, len(headers), final, "chrA", starts, stops, False, 1, t2, p2)
+        assert a[0] == b[0] and a[1].tolist() == b[1].tolist() and a[2] == b[2]
+        assert t1[:a[2][0]].tobytes() == t2[:b[2][0]].tobytes() and p1[:a[2][1]].tolist() == p2[:b[2][1]].tolist()
+    # a record marked as keeping its CIGAR in the CG tag sends the batch to the host packer; a corrupt one fails
+    bad = headers.copy()
+    kept = int(np.flatnonzero((bad["pos"] < 140000) & (bad["pos"] > 100000) & ((bad["flags"] & 0xf04) == 0) & ((bad["flags"] >> 16) > 0))[0])
+    bad["state"][kept] = 1
+    with pytest.raises(BamError) as e:
+        bam.pack_headers(bad, len(bad), final, "chrA", starts, stops, False, 1, t2, p2)
+    assert e.value.code == -8
+    bad["state"][kept] = 2
+    with pytest.raises(BamError, match="corrupt"):
+        bam.pack_headers(bad, len(bad), final, "chrA", starts, stops, False, 1, t2, p2)
+    bam.close()

@@ -230,3 +230,34 @@ def test_device_inflated_span_gives_the_host_packers_summaries(tmp_path):
     enc = PackedEncoder(0, arena_bytes=64 << 20)
     assert enc.pack_device(BAM_handler(bam2), "ctg", starts, stops, False, 1) is None
     enc.close()
+
+
+
+def test_device_record_walk_equals_the_host_walk(tmp_path, monkeypatch):
+    """pack_device with the records read out on the device (pa_encoder_walk_records + pa_bam_pack_headers, the default) and with
+    the span walked on the host (PEPPER_AMD_DEVICE_WALK=0): the same tables; a window with more records than a lane has
+    slots (3 000 short reads inside 16 kb) takes the host walk by itself."""
+    from pepper_amd.variant.bam import BAM_handler
+    from pepper_amd.variant.PEPPER_VARIANT import PackedEncoder
+    rng = np.random.default_rng(914)
+    ref = pu.random_reference(rng, 80000)
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=2500, read_len=(500, 7000), clip_rate=0.3, mapq_zero_rate=0.05)
+    short = pu.simulate_reads(rng, ref[40000:52000], 40000, n_reads=3000, read_len=(80, 200))
+    for tag, recs in (("long", reads), ("short", sorted(reads + short, key=lambda r: r["pos"]))):
+        recs = [r for r in recs if not any(op in (3, 6) for op, _ in r["cigar"])]
+        for i, r in enumerate(recs):
+            r["name"] = "q%d" % i
+        bam = str(tmp_path / (tag + ".bam"))
+        bu.write_bam(bam, [("ctg", len(ref))], {0: recs}, flush_every=53)
+        edges = list(range(5000, 76000, 7000))
+        starts, stops = [a - 100 for a in edges[:-1]], [b + 100 for b in edges[1:]]
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("PEPPER_AMD_DEVICE_WALK", mode)
+            enc = PackedEncoder(0, arena_bytes=64 << 20)
+            laps = {}
+            n_done, rp, counts = enc.pack_device(BAM_handler(bam), "ctg", starts, stops, False, 1, laps=laps)
+            assert ("bam_walk_device" in laps) == (mode == "1")
+            got[mode] = (n_done, rp.tolist(), counts, enc.reads[:counts[0]].tobytes(), enc.pair_read[:counts[1]].tolist())
+            enc.close()
+        assert got["1"] == got["0"] and got["1"][0] == len(starts) and got["1"][2][0] > 500
