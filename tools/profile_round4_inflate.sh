@@ -7,7 +7,7 @@ python tools/bench_inflate.py --genome 8000000 > gpurun_out/r04_inflate_bench.js
 python tools/bench_variant_images.py make_fast /tmp/vb 64000000 60 > gpurun_out/r04_mk.log 2>&1
 timeout 300 python tools/bench_variant_images.py run /tmp/vb 16,16,16,16 2> /dev/null | grep "^{" > gpurun_out/r04_make_images_64mb.json
 PEPPER_AMD_DEVICE_INFLATE=0 timeout 300 python tools/bench_variant_images.py run /tmp/vb 16,16,16 2> /dev/null | grep "^{" > gpurun_out/r04_make_images_64mb_host_inflate.json
-timeout 300 python tools/bench_variant_images.py run /tmp/vb 24,24,32,32 2> /dev/null | grep "^{" > gpurun_out/r04_make_images_64mb_more_threads.json
+PEPPER_AMD_DEVICE_WALK=0 timeout 300 python tools/bench_variant_images.py run /tmp/vb 16,16,16 2> /dev/null | grep "^{" > gpurun_out/r04_make_images_64mb_host_walk.json
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r04_images_stats -o img -- python $R/tools/bench_variant_images.py run /tmp/vb 16 > $R/gpurun_out/r04_images_stats.log 2>&1
 cd $R
