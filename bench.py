@@ -851,10 +851,11 @@ def make_images_leg(scratch):
                 "synth_seconds": made["seconds"], "image_file_mb": mid["image_file_mb"],
                 "note": "pepper_amd.variant.ImageGenerationUI.generate_images, intervals of 100 kb, one worker thread per usable CPU, each "
                         "with its own BAM handle, page-locked arena and encoder: bam_span_read = the file span of a group of intervals "
-                        "(pread), bam_inflate_device = upload + bgzf_inflate_kernel (one wavefront per BGZF member) + download of the "
-                        "inflated span, bam_walk = record headers, filters, region test on the host (records stay in place on the "
-                        "device), encode = unpack_clip_kernel + the summary kernels + candidate enumeration + result copy, hdf5 = the "
-                        "append-only writer; inflate_kernel = the kernel's event time summed over the workers' streams"}
+                        "(pread), bam_inflate_device = upload + bgzf_inflate_kernel (one wavefront per BGZF member), bam_walk_device = the "
+                        "record headers read out on the device (40 bytes per record come back; the records stay in place there), "
+                        "bam_walk = filters, region test and pair lists on the host over those headers, encode = unpack_clip_kernel + "
+                        "the summary kernels + candidate enumeration + result copy, hdf5 = the append-only writer; inflate_kernel = "
+                        "the kernel's event time summed over the workers' streams"}
     except Exception as e:      # noqa: BLE001
         return {"error": repr(e)[:300]}
     finally:
