@@ -1813,17 +1813,23 @@ int pa_encoder_inflate_bgzf(pa_encoder* e, const uint8_t* comp, int64_t comp_byt
     std::memcpy(hm + nb * 8, out_off, nb * 8);
     std::memcpy(hm + nb * 16, comp_len, nb * 4);
     std::memcpy(hm + nb * 20, out_len, nb * 4);
-    char* dm = b.d_inf.as<char>();
+    // The tables are read, and the status words written, in the page-locked block itself (it is mapped into the device's
+    // address space): each of a job's small copies otherwise waits for CUs behind other workers' long-lived inflate
+    // wavefronts (the runtime's copy kernels: ~1.5 ms apiece in the trace of DESIGN.md 4.4).
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, hm, 0) != hipSuccess || !mapped) mapped = nullptr;
+    std::memset(hm + nb * 24, 0xff, nb * 4);                  // (a member the kernel never reaches reads as an error)
+    char* dm = mapped ? static_cast<char*>(mapped) : b.d_inf.as<char>();
     const auto t0 = std::chrono::steady_clock::now();
     ENC_HIP(hipMemcpyAsync(b.d_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
-    ENC_HIP(hipMemcpyAsync(dm, hm, nb * 24, hipMemcpyHostToDevice, st));
+    if (!mapped) ENC_HIP(hipMemcpyAsync(dm, hm, nb * 24, hipMemcpyHostToDevice, st));
     ENC_HIP(hipEventRecord(e->ev[10], st));
     pa::launch_bgzf_inflate(st, b.d_comp.as<uint8_t>(), reinterpret_cast<const int64_t*>(dm), reinterpret_cast<const int32_t*>(dm + nb * 16),
                             reinterpret_cast<const int64_t*>(dm + nb * 8), reinterpret_cast<const int32_t*>(dm + nb * 20),
                             b.d_arena.as<uint8_t>(), reinterpret_cast<int32_t*>(dm + nb * 24), n_blocks);
     ENC_HIP(hipGetLastError());
     ENC_HIP(hipEventRecord(e->ev[11], st));
-    ENC_HIP(hipMemcpyAsync(hm + nb * 24, dm + nb * 24, nb * 4, hipMemcpyDeviceToHost, st));
+    if (!mapped) ENC_HIP(hipMemcpyAsync(hm + nb * 24, dm + nb * 24, nb * 4, hipMemcpyDeviceToHost, st));
     if (host_out && out_bytes > 0) ENC_HIP(hipMemcpyAsync(host_out, b.d_arena.p, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
     ENC_HIP(hipStreamSynchronize(st));
     float ms = 0.0f;
@@ -1856,28 +1862,37 @@ int pa_encoder_walk_records(pa_encoder* e, int64_t data_bytes, const int64_t* en
     const size_t o_counts = n * 8, o_base = o_counts + n * 4, o_flags = o_base + (n + 1) * 4, o_slots = (o_flags + 8 + 63) & ~(size_t)63,
                  o_out = o_slots + slots * 40, total = o_out + slots * 40;
     ENC_ALLOC(b.d_walk, total);
-    if (!b.h_walk.ensure(n * 8 + 64)) return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed in the record walk");
+    const size_t h_tail = (n * 8 + 63) & ~(size_t)63;
+    if (!b.h_walk.ensure(h_tail + 64)) return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed in the record walk");
     char* dw = b.d_walk.as<char>();
     char* hw = b.h_walk.as<char>();
     std::memcpy(hw, entries, n * 8);
+    int32_t* tail = reinterpret_cast<int32_t*>(hw + h_tail);           // [0] the number of records, [1..2] the flags
+    tail[0] = tail[1] = tail[2] = 0;
+    // entries in and totals out through the page-locked block itself where it is mapped (see pa_encoder_inflate_bgzf)
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, hw, 0) != hipSuccess || !mapped) mapped = nullptr;
+    char* mw = static_cast<char*>(mapped);
     const auto t0 = std::chrono::steady_clock::now();
-    ENC_HIP(hipMemcpyAsync(dw, hw, n * 8, hipMemcpyHostToDevice, st));
+    if (!mapped) ENC_HIP(hipMemcpyAsync(dw, hw, n * 8, hipMemcpyHostToDevice, st));
     ENC_HIP(hipMemsetAsync(dw + o_flags, 0, 8, st));
-    pa::launch_record_walk(st, b.d_arena.as<uint8_t>(), data_bytes, reinterpret_cast<const int64_t*>(dw), n_entries, cap_per_entry,
-                           dw + o_slots, reinterpret_cast<int32_t*>(dw + o_counts), reinterpret_cast<int32_t*>(dw + o_base),
-                           reinterpret_cast<int32_t*>(dw + o_flags), dw + o_out);
+    pa::launch_record_walk(st, b.d_arena.as<uint8_t>(), data_bytes, reinterpret_cast<const int64_t*>(mapped ? mw : dw), n_entries,
+                           cap_per_entry, dw + o_slots, reinterpret_cast<int32_t*>(dw + o_counts), reinterpret_cast<int32_t*>(dw + o_base),
+                           reinterpret_cast<int32_t*>(dw + o_flags), dw + o_out, (int64_t)slots,
+                           mapped ? reinterpret_cast<int32_t*>(mw + h_tail) : nullptr);
     ENC_HIP(hipGetLastError());
-    int32_t* tail = reinterpret_cast<int32_t*>(hw + n * 8);            // [0] the number of records, [1..2] the flags
-    ENC_HIP(hipMemcpyAsync(tail, dw + o_base + n * 4, 4, hipMemcpyDeviceToHost, st));
-    ENC_HIP(hipMemcpyAsync(tail + 1, dw + o_flags, 8, hipMemcpyDeviceToHost, st));
+    if (!mapped) {
+        ENC_HIP(hipMemcpyAsync(tail, dw + o_base + n * 4, 4, hipMemcpyDeviceToHost, st));
+        ENC_HIP(hipMemcpyAsync(tail + 1, dw + o_flags, 8, hipMemcpyDeviceToHost, st));
+    }
     ENC_HIP(hipStreamSynchronize(st));
     flags[0] = tail[1];
     flags[1] = tail[2];
     const int64_t found = tail[0];
     if (flags[0] == 0 && found > headers_cap) flags[0] |= 4;            // the caller's table is too small
-    if (flags[0] == 0 && found > 0) {
-        ENC_HIP(hipMemcpyAsync(headers, dw + o_out, (size_t)found * 40, hipMemcpyDeviceToHost, st));
-        ENC_HIP(hipStreamSynchronize(st));
+    if (flags[0] == 0 && found > 0) {                                   // (the headers themselves: one copy out of device memory --
+        ENC_HIP(hipMemcpyAsync(headers, dw + o_out, (size_t)found * 40, hipMemcpyDeviceToHost, st));      // 40-byte stores of single
+        ENC_HIP(hipStreamSynchronize(st));                                                              // lanes across PCIe are slower)
     }
     *n_headers = flags[0] == 0 ? found : 0;
     b.ms[11] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -615,7 +615,8 @@ __global__ __launch_bounds__(64) void record_chase_kernel(const uint8_t* __restr
 }
 
 // exclusive prefix of the lanes' record counts (n_entries is a few hundred at most: one wavefront, 64 at a time)
-__global__ __launch_bounds__(64) void record_base_kernel(const int32_t* __restrict__ counts, int n_entries, int32_t* __restrict__ base) {
+__global__ __launch_bounds__(64) void record_base_kernel(const int32_t* __restrict__ counts, int n_entries, int32_t* __restrict__ base,
+                                                        const int32_t* flags, int32_t* tail) {
     int carry = 0;
     for (int i0 = 0; i0 < n_entries; i0 += 64) {
         const int i = i0 + (int)threadIdx.x;
@@ -624,17 +625,26 @@ __global__ __launch_bounds__(64) void record_base_kernel(const int32_t* __restri
         if (i < n_entries) base[i] = carry + incl - c;
         carry += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (threadIdx.x == 0) base[n_entries] = carry;
+    if (threadIdx.x == 0) {
+        base[n_entries] = carry;
+        if (tail) {                              // (page-locked host memory: what the caller reads after the stream's last kernel)
+            tail[0] = carry;
+            tail[1] = flags[0];
+            tail[2] = flags[1];
+        }
+    }
 }
 
 // one wavefront per slot: the reference bases of the record's operations; the placeholder of a CIGAR kept in the CG tag
 // (kSmN, SAM specification 4.2.2: first operation S over all bases) marks the record for the host path
 __global__ __launch_bounds__(256) void record_finish_kernel(const uint8_t* __restrict__ data, const RecHdr* __restrict__ slots,
                                                            const int32_t* __restrict__ counts, const int32_t* __restrict__ base,
-                                                           int cap, int n_entries, RecHdr* __restrict__ out) {
-    const int slot = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int i = slot / cap, j = slot - i * cap;
-    if (i >= n_entries || j >= counts[i]) return;
+                                                           int cap, int n_entries, RecHdr* __restrict__ out, long long out_cap) {
+    // sixteen workgroups = 64 wavefronts per entry, striding over its records (a wavefront per SLOT would be mostly empty ones)
+    const int i = blockIdx.x >> 4, lane = threadIdx.x & 63;
+    if (i >= n_entries) return;
+    const int n = counts[i];
+    for (int j = (blockIdx.x & 15) * 4 + ((int)threadIdx.x >> 6); j < n; j += 64) {
     RecHdr h = slots[(size_t)i * cap + j];
     int ref = 0;
     if (h.state == 0) {
@@ -651,23 +661,23 @@ __global__ __launch_bounds__(256) void record_finish_kernel(const uint8_t* __res
             if ((c0 & 15u) == 4u && (int)(c0 >> 4) == h.l_seq) h.state = 1;
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && (long long)base[i] + j < out_cap) {
         h.ref_len = ref;
         out[base[i] + j] = h;
+    }
     }
 }
 
 }  // namespace
 
 void launch_record_walk(hipStream_t stream, const uint8_t* data, int64_t data_bytes, const int64_t* entries, int n_entries, int cap,
-                        void* slots, int32_t* counts, int32_t* base, int32_t* flags, void* out) {
+                        void* slots, int32_t* counts, int32_t* base, int32_t* flags, void* out, int64_t out_cap, int32_t* tail) {
     if (n_entries <= 0) return;
     hipLaunchKernelGGL(record_chase_kernel, dim3((unsigned)((n_entries + 63) / 64)), dim3(64), 0, stream, data, data_bytes, entries,
                        n_entries, cap, static_cast<RecHdr*>(slots), counts, flags);
-    hipLaunchKernelGGL(record_base_kernel, dim3(1), dim3(64), 0, stream, counts, n_entries, base);
-    const long long n_slots = (long long)n_entries * cap;
-    hipLaunchKernelGGL(record_finish_kernel, dim3((unsigned)((n_slots + 3) / 4)), dim3(256), 0, stream, data,
-                       static_cast<const RecHdr*>(slots), counts, base, cap, n_entries, static_cast<RecHdr*>(out));
+    hipLaunchKernelGGL(record_base_kernel, dim3(1), dim3(64), 0, stream, counts, n_entries, base, flags, tail);
+    hipLaunchKernelGGL(record_finish_kernel, dim3((unsigned)n_entries * 16u), dim3(256), 0, stream, data,
+                       static_cast<const RecHdr*>(slots), counts, base, cap, n_entries, static_cast<RecHdr*>(out), (long long)out_cap);
 }
 
 void launch_bgzf_inflate(hipStream_t stream, const uint8_t* comp, const int64_t* comp_off, const int32_t* comp_len,

@@ -138,5 +138,6 @@ const char* inflate_status_text(int32_t s);
 // up to the next), slots [n_entries][cap] and out [<= n_entries * cap] of 40-byte pa_record_header, counts [n_entries],
 // base [n_entries + 1] (base[n_entries] = the number of records), flags [2] (zeroed by the caller)
 void launch_record_walk(hipStream_t stream, const uint8_t* data, int64_t data_bytes, const int64_t* entries, int n_entries, int cap,
-                        void* slots, int32_t* counts, int32_t* base, int32_t* flags, void* out);
+                        void* slots, int32_t* counts, int32_t* base, int32_t* flags, void* out, int64_t out_cap, int32_t* tail);
+// (out: room for out_cap headers, device or mapped page-locked memory; tail, if not NULL: [0] the number of records, [1..2] the flags)
 }  // namespace pa
