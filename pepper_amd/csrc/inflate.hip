@@ -63,7 +63,7 @@ enum InflateStatus : int32_t {
 
 struct Tables {
     uint16_t lit_table[1 << LIT_BITS];
-    uint16_t dist_table[1 << DIST_BITS];
+    uint32_t dist_table[1 << DIST_BITS];
     uint16_t cl_table[1 << CL_BITS];
     uint16_t lit_sym[MAX_LIT];
     uint16_t dist_sym[MAX_DIST];
@@ -159,7 +159,34 @@ struct Stream {
 
 // Canonical code of `n` symbols from their lengths (RFC 1951 3.2.2): count[], the symbols in (length, symbol) order and
 // the primary table of 2^tbits entries.  Returns false for an over-subscribed set.  All lanes call it.
-PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, uint16_t* table, int tbits) {
+// What a primary-table entry holds (0 = no code of at most `tbits` bits starts like this index):
+//   PLAIN   uint16  length | symbol << 4                                              (the code length code)
+//   LITLEN  uint16  length | extra bits << 4 | is-length << 7 | value << 8            value = the literal, or a length
+//                   symbol's base - 3; the end-of-block code is "a length with 7 extra bits"; symbols 286 / 287: 0
+//   DIST    uint32  length | extra bits << 4 | base << 8                              distance symbols 30 / 31: 0
+// so that a lane of the window decode needs no arithmetic on symbol numbers (RFC 1951 3.2.5's tables in closed form here).
+enum TableFormat { PLAIN, LITLEN, DIST };
+
+PA_DEV uint32_t table_entry(TableFormat format, int sym, int len) {
+    if (format == PLAIN) return (uint32_t)((sym << 4) | len);
+    if (format == LITLEN) {
+        if (sym < 256) return (uint32_t)(len | sym << 8);
+        if (sym == 256) return (uint32_t)(len | 7 << 4 | 1 << 7);
+        if (sym > 285) return 0u;
+        const int s = sym - 257;
+        const bool longer = s >= 8 && s != 28;
+        const int eb = longer ? (s - 4) >> 2 : 0;
+        const int base = longer ? ((4 + (s & 3)) << eb) + 3 : (s == 28 ? 258 : s + 3);
+        return (uint32_t)(len | eb << 4 | 1 << 7 | (base - 3) << 8);
+    }
+    if (sym > 29) return 0u;
+    const int eb = sym < 4 ? 0 : (sym >> 1) - 1;
+    const int base = sym < 4 ? sym + 1 : ((2 + (sym & 1)) << eb) + 1;
+    return (uint32_t)(len | eb << 4 | base << 8);
+}
+
+template <TableFormat FORMAT, typename Entry>
+PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, Entry* table, int tbits) {
     const int lane = threadIdx.x;
     if (lane < 16) count[lane] = 0;
     wave_order();
@@ -193,13 +220,13 @@ PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, 
     wave_order();
     for (int t = lane; t < (1 << tbits); t += 64) {
         int code = 0, first = 0, index = 0;
-        uint16_t e = 0;
+        Entry e = 0;
 #pragma unroll 1
         for (int len = 1; len <= tbits; ++len) {
             code |= (t >> (len - 1)) & 1;
             const int c = count[len];
             if (code - c < first) {
-                e = (uint16_t)((syms[index + (code - first)] << 4) | len);
+                e = (Entry)table_entry(FORMAT, syms[index + (code - first)], len);
                 break;
             }
             index += c;
@@ -237,10 +264,29 @@ PA_DEV int decode(uint32_t bits, const uint16_t* table, int tbits, const int* co
     return -1;
 }
 
+// One symbol bit by bit from the canonical arrays alone (RFC 1951 3.2.2) -- the per-symbol path behind the window decode.
+PA_DEV int decode_canonical(uint32_t bits, const int* count, const uint16_t* syms, int* used) {
+    int code = 0, first = 0, index = 0;
+#pragma unroll 1
+    for (int len = 1; len < 16; ++len) {
+        code |= (bits >> (len - 1)) & 1;
+        const int c = uni(count[len]);
+        if (code - c < first) {
+            *used = len;
+            return uni(syms[index + (code - first)]);
+        }
+        index += c;
+        first = (first + c) << 1;
+        code <<= 1;
+    }
+    *used = 0;
+    return -1;
+}
+
 // what a lane found at its bit offset: the symbol's total bits (code, extra bits, for a match also the distance's) | flags
 constexpr int F_MATCH = 64, F_END = 128, F_INVALID = 256;
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
                                                          const int32_t* __restrict__ comp_len, const int64_t* __restrict__ out_off,
                                                          const int32_t* __restrict__ out_len, uint8_t* out_base,
                                                          int32_t* __restrict__ status, unsigned long long* dbg) {
@@ -330,7 +376,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 in.p += 3 * hclen;
             }
             wave_order();
-            if (!build_table(T.cl_lens, 19, T.cl_count, T.cl_sym, T.cl_table, CL_BITS)) { err = INF_OVERSUBSCRIBED; break; }
+            if (!build_table<PLAIN>(T.cl_lens, 19, T.cl_count, T.cl_sym, T.cl_table, CL_BITS)) { err = INF_OVERSUBSCRIBED; break; }
             const int total = hlit + hdist;
             int i = 0, prev = 0;
             while (i < total) {
@@ -376,8 +422,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             for (int s = hlit + lane; s < 288; s += 64) T.lens[s] = 0;
         }
         wave_order();
-        if (!build_table(T.lens, 288, T.lit_count, T.lit_sym, T.lit_table, LIT_BITS) ||
-            !build_table(T.lens + 288, 32, T.dist_count, T.dist_sym, T.dist_table, DIST_BITS)) {
+        if (!build_table<LITLEN>(T.lens, 288, T.lit_count, T.lit_sym, T.lit_table, LIT_BITS) ||
+            !build_table<DIST>(T.lens + 288, 32, T.dist_count, T.dist_sym, T.dist_table, DIST_BITS)) {
             err = INF_OVERSUBSCRIBED;
             break;
         }
@@ -389,46 +435,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             ++n_steps;
             in.ensure();
             const uint64_t bits = in.bits_at(in.p + lane);
-            const uint32_t e = T.lit_table[(uint32_t)bits & ((1u << LIT_BITS) - 1u)];
-            const int len = (int)(e & 15u), sym = (int)(e >> 4);
-            int info = len, val = sym, dist = 0;
-            if (e == 0u || sym > 285) info = F_INVALID;
-            else if (sym == 256) info = len | F_END;
-            {
-                // a length symbol: its extra bits, the distance code behind them, the distance's extra bits
-                const int s = sym - 257;
-                const bool longer = s >= 8 && s != 28;
-                const int eb = longer ? (s - 4) >> 2 : 0;
-                const int base = longer ? ((4 + (s & 3)) << eb) + 3 : (s == 28 ? 258 : s + 3);
-                uint64_t after = bits >> len;
-                const int mlen = base + (int)((uint32_t)after & ((1u << eb) - 1u));
-                after >>= eb;
-                const uint32_t de = T.dist_table[(uint32_t)after & ((1u << DIST_BITS) - 1u)];
-                const int dlen = (int)(de & 15u), dsym = (int)(de >> 4);
-                const int deb = dsym < 4 ? 0 : (dsym >> 1) - 1;
-                const int dbase = dsym < 4 ? dsym + 1 : ((2 + (dsym & 1)) << deb) + 1;
-                const int d = dbase + (int)((uint32_t)(after >> dlen) & ((1u << deb) - 1u));
-                if (e != 0u && sym > 256 && sym <= 285) {
-                    if (de == 0u || dsym > 29) info = F_INVALID;
-                    else { info = (len + eb + dlen + deb) | F_MATCH; val = mlen; dist = d; }
-                }
-            }
-            // follow the symbols from offset 0
-            unsigned long long chain = 0;
-            int k = 0, stop = 0;
-            int f = __builtin_amdgcn_readlane(info, 0);
-            while (f < F_END) {
-                chain |= 1ull << k;
-                k += f & 63;
-                if (k >= 64) break;
-                f = __builtin_amdgcn_readlane(info, k);
-            }
+            const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+            const uint32_t e = T.lit_table[lo & ((1u << LIT_BITS) - 1u)];
+            const int len = (int)(e & 15u), eb = (int)((e >> 4) & 7u);
+            // as if it were a length symbol: its extra bits, the distance code behind them, that code's extra bits
+            const uint32_t behind = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(len + eb));     // (at most 15 + 7 bits in)
+            const uint32_t de = T.dist_table[behind & ((1u << DIST_BITS) - 1u)];
+            const int dlen = (int)(de & 15u), deb = (int)((de >> 4) & 15u);
+            // Selects, not branches, and every select on ONE comparison: a lane mask is a scalar register pair, and combining
+            // two of them is work for the scalar unit -- the unit this kernel is bound by.
+            const int total_m = (len + eb + dlen + deb) | F_MATCH;
+            const int info_m = de == 0u ? F_INVALID : total_m;
+            const int info_l = eb == 7 ? (len | F_END) : info_m;
+            const int info_e = (e & 128u) ? info_l : len;
+            const int info = e == 0u ? F_INVALID : info_e;
+            const int xlen = (int)__builtin_amdgcn_ubfe(lo, (uint32_t)len, (uint32_t)eb);
+            const int val = (e & 128u) ? (int)(e >> 8) + 3 + xlen : (int)(e >> 8);
+            const int dist = (int)(de >> 8) + (int)__builtin_amdgcn_ubfe(behind, (uint32_t)dlen, (uint32_t)deb);
+            // (eight scalar instructions per symbol, written out: the scalar unit is shared by the CU's four SIMDs and is the
+            // unit this kernel keeps busiest -- the compiler's version of the loop took fourteen)
+            unsigned long long chain;
+            int k, f, stop = 0;
+            asm volatile("s_mov_b64 %[chain], 0\n\t"
+                         "s_mov_b32 %[k], 0\n"
+                         "1:\n\t"
+                         "v_readlane_b32 %[f], %[info], %[k]\n\t"
+                         "s_cmpk_gt_i32 %[f], 0x7f\n\t"
+                         "s_cbranch_scc1 2f\n\t"
+                         "s_bitset1_b64 %[chain], %[k]\n\t"
+                         "s_and_b32 %[f], %[f], 63\n\t"
+                         "s_add_i32 %[k], %[k], %[f]\n\t"
+                         "s_cmpk_lt_i32 %[k], 64\n\t"
+                         "s_cbranch_scc1 1b\n\t"
+                         "s_mov_b32 %[f], 0\n"
+                         "2:\n\t"
+                         : [chain] "=&s"(chain), [k] "=&s"(k), [f] "=&s"(f)
+                         : [info] "v"(info)
+                         : "scc");
             if (k < 64) {                                   // the end-of-block code, or something the lanes could not decode
                 if (f & F_END) { chain |= 1ull << k; k += f & 63; stop = 1; }
                 else stop = 2;
             }
-            const bool on = (chain >> lane) & 1ull;
-            const bool is_match = on && (info & F_MATCH), is_lit = on && !(info & (F_MATCH | F_END));
+            // what this lane is as a symbol of the step: 0 nothing (or the end code: it writes nothing), 1 a literal, 2 a match
+            const int on = (int)((chain >> lane) & 1ull);
+            const int kind = on ? (int)((0x021u >> (__builtin_amdgcn_ubfe((uint32_t)info, 6u, 2u) << 2)) & 3u) : 0;
+            const bool is_lit = kind == 1, is_match = kind == 2;
             unsigned long long matches = __ballot(is_match);
             const unsigned long long lits = __ballot(is_lit);
             int off, produced;
@@ -450,22 +501,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 // of the step, or an earlier byte of this same step, followed back to a literal or a memory byte.
                 T.scratch[lane] = 0xff;
                 wave_order();
-                if (is_lit || is_match) T.scratch[off] = (uint8_t)lane;
+                if (kind != 0) T.scratch[off] = (uint8_t)lane;
                 wave_order();
                 const int mark = T.scratch[lane];
                 const int packed = wave_scan_max(mark != 0xff ? (lane << 8 | mark) : -1);
                 const int start = packed >> 8;
                 const int word = __builtin_amdgcn_ds_bpermute((packed & 255) << 2, is_match ? (val | dist << 9 | 1 << 25) : val);
-                const bool active = lane < produced;
-                const bool m = active && ((word >> 25) & 1);
+                const int mi = lane < produced ? (word >> 25) & 1 : 0;            // this byte comes from a match
+                const bool m = mi != 0;
                 const int sval = word & 511, d = (word >> 9) & 0xffff;
-                if (__ballot(m && d > pos + start)) { err = INF_DISTANCE; break; }
+                if (__ballot((m ? d : 0) > pos + start)) { err = INF_DISTANCE; break; }
                 int rel = lane - start;
-                if (__ballot(m && d < sval)) {
-                    if (m && d < sval) rel %= d;                       // distance < length: the source repeats
+                const bool wraps = (m ? d : 0x7fffffff) < sval;                  // distance < length: the source repeats
+                if (__ballot(wraps)) {
+                    if (wraps) rel %= d;
                 }
                 const int src = pos + start - d + rel;
-                const bool in_step = m && src >= pos, from_mem = m && !in_step;
+                const bool in_step = (m ? src : -1) >= pos, from_mem = (m ? src : 0x7fffffff) < pos;
                 int root = in_step ? src - pos : lane;
                 if (__ballot(in_step)) {
                     for (;;) {
@@ -475,12 +527,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     }
                 }
                 n_match += __popcll(matches);
-                if (pend_n && __ballot(from_mem && src >= pend_pos)) complete();
+                if (pend_n && __ballot((from_mem ? src : -1) >= pend_pos)) complete();
                 uint8_t b = 0;
                 if (from_mem) b = out[src];
                 complete();                                            // the step before: its loads were issued a step ago
                 pend_byte = b;
-                pend_val = (active && !m) ? sval : -1;
+                pend_val = lane < produced ? (m ? -1 : sval) : -1;
                 pend_root = root;
                 pend_n = produced;
                 pend_pos = pos;
@@ -509,7 +561,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 ++n_fallback;
                 const uint64_t v = in.peek();
                 int used;
-                int s = decode((uint32_t)v, T.lit_table, LIT_BITS, T.lit_count, T.lit_sym, &used);
+                int s = decode_canonical((uint32_t)v, T.lit_count, T.lit_sym, &used);
                 if (s < 0) { err = INF_BAD_CODE; break; }
                 if (s < 256) {
                     if (pos >= olen) { err = INF_OUTPUT; break; }
@@ -533,7 +585,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                         used += eb;
                     }
                     int dused;
-                    const int dsym = decode((uint32_t)after, T.dist_table, DIST_BITS, T.dist_count, T.dist_sym, &dused);
+                    const int dsym = decode_canonical((uint32_t)after, T.dist_count, T.dist_sym, &dused);
                     if (dsym < 0 || dsym > 29) { err = INF_BAD_CODE; break; }
                     after >>= dused;
                     used += dused;
