@@ -22,12 +22,18 @@
 //   4. the step is completed one step later: its loads are in flight while the next window is decoded (a step whose
 //      sources reach into the pending bytes completes them first).
 // Steps of more than 64 output bytes (long matches) and codes longer than the primary tables take a per-symbol path.
-// Huffman tables in LDS: a primary table of 2^10 (literal/length) and 2^8 (distance) 16-bit entries (symbol << 4 | length),
-// longer codes through the canonical count/symbol arrays bit by bit (RFC 1951 3.2.2's numbering; rare by construction:
-// a code longer than 10 bits has probability < 2^-10).  Tables are built by all lanes: counts by LDS atomics, the stable
-// order of symbols by code length through ballots, the primary table one entry per lane.  4.6 KB of LDS and 64 VGPRs per
-// wavefront, so the 32 wavefront slots of a CU all hold a member.  A workgroup is one wavefront: hand-offs through LDS
-// need program order only (wave_order), no barrier.
+// Huffman tables in LDS: a primary table of 2^10 literal/length entries (16 bits: code length, extra-bit count, the
+// literal or the length's base) and 2^8 distance entries (32 bits: code length, extra-bit count, base) -- no lane does
+// arithmetic on symbol numbers; longer codes through the canonical count/symbol arrays bit by bit (RFC 1951 3.2.2's
+// numbering; rare by construction: a code longer than 10 bits has probability < 2^-10).  Tables are built by all lanes:
+// counts by LDS atomics, the stable order of symbols by code length through ballots, the primary table one entry per
+// lane.  5.1 KB of LDS per wavefront.  A workgroup is one wavefront: hand-offs through LDS need program order only
+// (wave_order), no barrier.
+// What binds the kernel is the CU's ONE scalar unit, shared by its four SIMDs (measured before the diet: 185 scalar
+// against 169 vector instructions per step -- the scalar unit needs 4 x 185 = 740 cycles for the four SIMDs' steps, a
+// SIMD's vector unit 4 x 169 = 676 for its own): the symbol chain is written out in eight scalar instructions per symbol, every lane select hangs on ONE comparison (combining two lane
+// masks is scalar work), and the register budget is six wavefronts per SIMD (79 VGPRs; at eight, spills cost more than
+// the two wavefronts bring).
 //
 // Checks: over-subscribed code sets, codes without a symbol, distances beyond the produced output, output beyond the
 // block's ISIZE, a stored block's LEN/NLEN complement, input consumed beyond the block -> a non-zero status word per
