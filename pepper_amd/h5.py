@@ -162,6 +162,14 @@ class PredictionBuilder(object):
             self._h, name.encode(), n, contig.encode(), positions.ctypes.data, depths.ctypes.data, blob, offsets.ctypes.data,
             freqs.ctypes.data, images.ctypes.data, images.shape[1], images.shape[2]))
 
+    def write_variant_summary_packed(self, name, contig, positions, depths, blob, offsets, freqs, images):
+        """write_variant_summary with the candidate strings as the encoder returns them: `blob` = n NUL-terminated strings back
+        to back, `offsets` int64 [n + 1]."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        _check(self._lib.pa_h5_builder_write_variant_summary(
+            self._h, name.encode(), len(positions), contig.encode(), positions.ctypes.data, depths.ctypes.data, blob, offsets.ctypes.data,
+            freqs.ctypes.data, images.ctypes.data, images.shape[1], images.shape[2]))
+
     def __setitem__(self, path, value):
         """An integer dataset, or a str as a variable-length string scalar, like h5py's file[path] = value (intermediate
         groups are made as needed)."""

@@ -44,6 +44,26 @@ class DataStore(object):
     def __exit__(self, *args):
         self.file_handler.__exit__(*args)      # (the append-only writer publishes the file only when the block did not raise)
 
+    def write_summary_packed(self, summary_name, contig, out):
+        """One interval's summary straight from the encoder's result dict (PEPPER_VARIANT.StagedBatch.results): the datasets
+        of write_summary in inference mode, the candidate strings as the library returned them -- no per-candidate Python
+        object on the way (the append-only writer only; returns False when the file is written through libhdf5)."""
+        fh = self.file_handler
+        if not isinstance(fh, h5.PredictionBuilder) or "candidates_blob" not in out:
+            return False
+        if summary_name in self._written:
+            return True
+        self._written.add(summary_name)
+        n = len(out["positions"])
+        img = out["images"] if n else np.zeros((0, 33, 26), np.int8)
+        fh.write_variant_summary_packed(summary_name, contig if n else "",
+                                        np.ascontiguousarray(out["positions"].astype(np.int32)),
+                                        np.ascontiguousarray(out["depths"].astype(np.uint8)),
+                                        out["candidates_blob"], out["candidates_offsets"],
+                                        np.ascontiguousarray(out["candidate_frequency"].astype(np.uint8)),
+                                        np.ascontiguousarray(img))
+        return True
+
     def write_summary(self, summary_name, contigs, positions, depths, all_candidates, all_candidate_frequency,
                       all_images, all_base_labels, all_type_label, train_mode):
         if summary_name in self._written:

@@ -164,6 +164,8 @@ class ImageGenerationUtils:
         def write(output_hdf_file, chr_name, _start, _end, out):
             n = len(out["candidates"])
             summary_name = chr_name + "_" + str(_start) + "_" + str(_end)
+            if output_hdf_file.write_summary_packed(summary_name, chr_name, out):
+                return
             output_hdf_file.write_summary(summary_name, [chr_name] * n, out["positions"], out["depths"],
                                           np.array(out["candidates"], dtype=object).reshape(n, 1),
                                           out["candidate_frequency"].reshape(n, 1), out["images"],

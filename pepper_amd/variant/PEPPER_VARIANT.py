@@ -237,13 +237,19 @@ class StagedBatch(object):
         _lib.check(lib.pa_encoder_get_results(enc, positions.ctypes.data, depths.ctypes.data, freqs.ctypes.data,
                                               img32.ctypes.data if want_int32 else None, img8.ctypes.data,
                                               ctypes.cast(names, ctypes.c_void_p), needed.value, ctypes.byref(needed)))
-        cands = [s.decode("latin-1") for s in names.raw[:needed.value].split(b"\0")[:n]]
+        raw = names.raw[:needed.value]
+        cands = [s.decode("latin-1") for s in raw.split(b"\0")[:n]]
+        # the same strings as the library left them (NUL-terminated, back to back) with their offsets: what the image writer
+        # takes without going through n Python strings again (DataStore.write_summary_packed)
+        ends = np.flatnonzero(np.frombuffer(raw, np.uint8) == 0)[:n].astype(np.int64) + 1
+        starts = np.concatenate([[0], ends]) if n else np.zeros(1, np.int64)
         out, at = [], 0
         for k in self.counts[:self.n_regions]:
             k = int(k)
+            lo, hi = int(starts[at]), int(starts[at + k])
             out.append(dict(positions=positions[at:at + k], depths=depths[at:at + k], candidate_frequency=freqs[at:at + k],
                             images=img8[at:at + k], images_int32=img32[at:at + k] if want_int32 else None,
-                            candidates=cands[at:at + k]))
+                            candidates=cands[at:at + k], candidates_blob=raw[lo:hi], candidates_offsets=starts[at:at + k + 1] - lo))
             at += k
         return out
 

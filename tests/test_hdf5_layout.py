@@ -585,3 +585,31 @@ def test_direct_chunk_reads_survive_damaged_metadata(tmp_path):
         "print('survived', outcomes.count('read'), outcomes.count('error'))\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), seq, feat))
     r = subprocess.run([sys.executable, "-c", script, src], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "survived" in r.stdout, (r.returncode, r.stderr[-2000:])
+
+
+def test_packed_summary_write_equals_the_per_candidate_path(tmp_path):
+    """DataStore.write_summary_packed (the encoder's candidate strings handed to the writer as one block) writes the file
+    write_summary writes from the same interval's lists, byte for byte -- wrapped depths and frequencies included."""
+    import filecmp
+    from pepper_amd.variant.DataStore import DataStore
+    rng = np.random.default_rng(5)
+    outs = []
+    for n in (0, 1, 257):
+        cands = ["1A" if k % 3 else "2ACGTT"[:2 + k % 5] for k in range(n)]
+        raw = ("\0".join(cands) + "\0").encode() if n else b""
+        ends = np.flatnonzero(np.frombuffer(raw, np.uint8) == 0).astype(np.int64) + 1
+        outs.append(dict(positions=np.arange(n, dtype=np.int64) + 7, depths=rng.integers(0, 400, n).astype(np.int32),
+                         candidate_frequency=rng.integers(0, 400, n).astype(np.int32),
+                         images=rng.integers(-128, 128, (n, 33, 26)).astype(np.int8), candidates=cands, candidates_blob=raw,
+                         candidates_offsets=np.concatenate([[0], ends]).astype(np.int64)))
+    a, b = str(tmp_path / "a.hdf5"), str(tmp_path / "b.hdf5")
+    with DataStore(a, "w") as f:
+        for i, out in enumerate(outs):
+            assert f.write_summary_packed("chr_%d_%d" % (i, i + 1), "chr", out)
+    with DataStore(b, "w") as f:
+        for i, out in enumerate(outs):
+            n = len(out["positions"])
+            f.write_summary("chr_%d_%d" % (i, i + 1), ["chr"] * n, out["positions"], out["depths"],
+                            np.array(out["candidates"], dtype=object).reshape(n, 1), out["candidate_frequency"].reshape(n, 1),
+                            out["images"], [0] * n, [0] * n, False)
+    assert filecmp.cmp(a, b, shallow=False)
