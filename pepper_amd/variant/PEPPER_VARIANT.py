@@ -376,7 +376,10 @@ class PackedEncoder(object):
                 self.entries = np.zeros(8192, np.int64)
             n_entries = bam_handler.span_entries(contig, first, out_off, n_blocks, self.entries)
             n_headers, flags = ctypes.c_int64(), np.zeros(2, np.int32)
-            _lib.check(self.lib.pa_encoder_walk_records(self.enc, out_bytes, self.entries.ctypes.data, n_entries, 2048,
+            # slots per entry: 2 048 records of one 16 kb window, fewer when a span has very many windows (low coverage): the
+            # device keeps two 40-byte tables of entries x slots; a window that overflows its slots takes the host walk
+            slots = max(64, min(2048, (32 << 20) // (40 * max(1, n_entries))))
+            _lib.check(self.lib.pa_encoder_walk_records(self.enc, out_bytes, self.entries.ctypes.data, n_entries, slots,
                                                         self.headers.ctypes.data, len(self.headers), ctypes.byref(n_headers),
                                                         flags.ctypes.data))
             if flags[0] == 0:
