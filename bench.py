@@ -963,6 +963,9 @@ def secondary_block(args):
         "value": d["device_GBps_inflated"], "unit": "GB/s of inflated bytes", "kernel": "bgzf_inflate_kernel", "kernel_ms": d["kernel_ms"],
         "members": d["members"], "compressed_bytes": d["compressed_bytes"], "inflated_bytes": d["inflated_bytes"],
         "cpu_zlib_one_core_GBps": d["zlib_one_core_GBps"], "identical_to_zlib": d["sample_identical"],
+        "cpu_baseline": {"value": d.get("host_library_all_cores_GBps"), "unit": "GB/s of inflated bytes", "cores": d.get("host_cores"),
+                         "kind": "port", "one_core": d.get("host_library_one_core_GBps"), "identical": d.get("identical_to_host_library"),
+                         "sample": "all the members through pa_bgzf_inflate_host (libdeflate, htslib's inflate), one thread per usable CPU"},
         "note": "csrc/inflate.hip on the BGZF members of a synthetic 8 Mb / 60x BAM (tools/synth_bam, libdeflate level 1), inputs "
                 "resident, HIP events: one wavefront per member, 64 bit offsets decoded speculatively per step; bound by instruction "
                 "issue and the symbol-to-symbol dependency of DEFLATE, not by HBM (the bytes moved are compressed in + inflated out)"}

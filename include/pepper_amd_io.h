@@ -296,6 +296,10 @@ int pa_bam_pack_headers(pa_bam* b, const pa_record_header* headers, int64_t n_he
                         int32_t n_regions, const int64_t* start, const int64_t* stop, int32_t include_supplementary, int32_t min_mapq,
                         pa_packed_read* reads, int32_t reads_cap, int32_t* pair_read, int32_t pairs_cap, int32_t* region_pairs,
                         int32_t* n_done, int64_t* counts);
+/* The host's counterpart of the device inflate (include/pepper_amd_io_device.h) over the same member tables: libdeflate where
+ * it is installed (htslib's choice), zlib otherwise, on n_threads threads -- the CPU baseline of the inflate bench. */
+int pa_bgzf_inflate_host(const uint8_t* comp, int64_t comp_bytes, int32_t n_blocks, const int64_t* comp_off, const int32_t* comp_len,
+                         const int64_t* out_off, const int32_t* out_len, uint8_t* out, int64_t out_bytes, int32_t n_threads);
 int pa_bam_region_span(pa_bam* b, const char* contig, int64_t start, int64_t stop, int32_t lookahead_windows,
                        int64_t* begin_coffset, int32_t* begin_uoffset, int64_t* end_coffset, int32_t* to_contig_end);
 int pa_bam_read_span(pa_bam* b, int64_t begin, int64_t end_min, int32_t extra_members, uint8_t* buf, int64_t buf_cap,

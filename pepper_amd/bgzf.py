@@ -88,3 +88,20 @@ class DeviceInflater(object):
         ms = ctypes.c_double()
         _lib.check(self._lib.pa_inflater_last_kernel_ms(self._h, ctypes.byref(ms)))
         return ms.value
+
+
+def inflate_host(comp, table, threads=1):
+    """The same members through the I/O library on the host (pa_bgzf_inflate_host: libdeflate / zlib on `threads` threads) --
+    the CPU baseline beside DeviceInflater.  -> uint8 array."""
+    from pepper_amd.variant import bam
+    fn = bam._lib().pa_bgzf_inflate_host
+    comp = np.frombuffer(comp, np.uint8) if not isinstance(comp, np.ndarray) else np.ascontiguousarray(comp, np.uint8)
+    comp_off, comp_len, out_off, out_len = [np.ascontiguousarray(a, t) for a, t in zip(table, (np.int64, np.int32, np.int64, np.int32))]
+    n = len(comp_off)
+    out_bytes = int((out_off + out_len).max()) if n else 0
+    out = np.empty(max(out_bytes, 1), np.uint8)
+    rc = fn(comp.ctypes.data, comp.size, n, comp_off.ctypes.data, comp_len.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
+            out.ctypes.data, out_bytes, int(threads))
+    if rc != 0:
+        raise BgzfError("host inflate failed (%d)" % rc)
+    return out[:out_bytes]

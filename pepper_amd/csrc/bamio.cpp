@@ -31,6 +31,7 @@
 #include <deque>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -933,6 +934,56 @@ bool open_span_fd(pa_bam* b) {
     return true;
 }
 }  // namespace
+
+// The host's counterpart of the device inflate, for baselines and cross-checks: the same member tables, libdeflate (zlib
+// where it is not installed) on n_threads threads, members dealt round robin.
+int pa_bgzf_inflate_host(const uint8_t* comp, int64_t comp_bytes, int32_t n_blocks, const int64_t* comp_off, const int32_t* comp_len,
+                         const int64_t* out_off, const int32_t* out_len, uint8_t* out, int64_t out_bytes, int32_t n_threads) {
+    if (n_blocks < 0 || comp_bytes < 0 || out_bytes < 0 || (n_blocks > 0 && (!comp || !comp_off || !comp_len || !out_off || !out_len)) ||
+        (out_bytes > 0 && !out))
+        return bam_fail(-1, "null or negative argument");
+    for (int32_t k = 0; k < n_blocks; ++k)
+        if (comp_off[k] < 0 || comp_len[k] < 0 || comp_off[k] + comp_len[k] > comp_bytes || out_off[k] < 0 || out_len[k] < 0 ||
+            out_off[k] + out_len[k] > out_bytes)
+            return bam_fail(-1, "block " + std::to_string(k) + " lies outside the buffers");
+    const int nt = std::max(1, std::min<int>(n_threads, std::max(1, n_blocks)));
+    std::vector<int> bad((size_t)nt, -1);
+    auto work = [&](int t) {
+#ifdef PA_HAVE_LIBDEFLATE
+        libdeflate_decompressor* ld = libdeflate_alloc_decompressor();
+#endif
+        for (int32_t k = t; k < n_blocks; k += nt) {
+            if (out_len[k] == 0) continue;
+            bool ok;
+#ifdef PA_HAVE_LIBDEFLATE
+            ok = ld && libdeflate_deflate_decompress(ld, comp + comp_off[k], (size_t)comp_len[k], out + out_off[k], (size_t)out_len[k],
+                                                     nullptr) == LIBDEFLATE_SUCCESS;
+#else
+            z_stream zs{};
+            ok = inflateInit2(&zs, -15) == Z_OK;
+            if (ok) {
+                zs.next_in = const_cast<uint8_t*>(comp + comp_off[k]);
+                zs.avail_in = (uInt)comp_len[k];
+                zs.next_out = out + out_off[k];
+                zs.avail_out = (uInt)out_len[k];
+                ok = inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.avail_out == 0;
+                inflateEnd(&zs);
+            }
+#endif
+            if (!ok && bad[(size_t)t] < 0) bad[(size_t)t] = k;
+        }
+#ifdef PA_HAVE_LIBDEFLATE
+        if (ld) libdeflate_free_decompressor(ld);
+#endif
+    };
+    std::vector<std::thread> threads;
+    for (int t = 1; t < nt; ++t) threads.emplace_back(work, t);
+    work(0);
+    for (auto& th : threads) th.join();
+    for (int t = 0; t < nt; ++t)
+        if (bad[(size_t)t] >= 0) return bam_fail(-5, "BGZF block " + std::to_string(bad[(size_t)t]) + " does not inflate to its ISIZE");
+    return 0;
+}
 
 int pa_bam_region_span(pa_bam* b, const char* contig, int64_t start, int64_t stop, int32_t lookahead_windows,
                        int64_t* begin_coffset, int32_t* begin_uoffset, int64_t* end_coffset, int32_t* to_contig_end) {

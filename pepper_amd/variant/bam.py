@@ -31,6 +31,7 @@ SYMBOLS = [
     ("pa_bam_copy_reads", ctypes.c_int, [c_void_p] + [c_void_p] * 13),
     ("pa_bam_pack_regions", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64,
                                            c_void_p, c_int32, c_void_p, c_int32, c_void_p, ctypes.POINTER(c_int32), c_void_p]),
+    ("pa_bgzf_inflate_host", ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32]),
     ("pa_bam_region_span", ctypes.c_int, [c_void_p, c_char_p, c_int64, c_int64, c_int32, P64, ctypes.POINTER(c_int32), P64,
                                           ctypes.POINTER(c_int32)]),
     ("pa_bam_read_span", ctypes.c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,

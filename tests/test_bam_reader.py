@@ -501,3 +501,28 @@ def test_pack_headers_equals_pack_inflated_and_entries_are_record_starts(tmp_pat
     with pytest.raises(BamError, match="corrupt"):
         bam.pack_headers(bad, len(bad), final, "chrA", starts, stops, False, 1, t2, p2)
     bam.close()
+
+
+def test_host_inflate_of_member_tables():
+    """pa_bgzf_inflate_host (the CPU baseline of the inflate bench): the members of a table through libdeflate / zlib on several
+    threads equal zlib's output; a member that does not inflate to its ISIZE fails the call."""
+    import struct
+    import zlib
+    from pepper_amd.bgzf import BgzfError, block_table, inflate_host
+    rng = np.random.default_rng(50)
+
+    def member(data, level):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(data) + c.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(body) + 25) + body +
+                struct.pack("<II", zlib.crc32(data), len(data)))
+    datas = [bytes(rng.integers(33, 74, int(rng.integers(1, 60000)), dtype=np.uint8)) for _ in range(40)] + [b"", b"abc" * 5000]
+    buf = b"".join(member(d, k % 10) for k, d in enumerate(datas))
+    table = block_table(buf)
+    for threads in (1, 3, 64):
+        assert inflate_host(buf, table, threads).tobytes() == b"".join(datas)
+    wrong = [a.copy() for a in table]
+    wrong[3][5] += 1
+    wrong[2][6:] += 1
+    with pytest.raises(BgzfError):
+        inflate_host(buf, wrong, 2)

@@ -18,7 +18,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from pepper_amd.bgzf import DeviceInflater, block_table      # noqa: E402
+from pepper_amd.bgzf import DeviceInflater, block_table, inflate_host      # noqa: E402
+from pepper_amd.hostinfo import usable_cpus      # noqa: E402
 
 
 def main():
@@ -56,12 +57,25 @@ def main():
         ok = ok and got[oo:oo + len(want)].tobytes() == want
     t_cpu = time.perf_counter() - t0
     sample_bytes = int(table[3][:sample].sum())
+    # the host's own inflate of ALL the members on every CPU the process may use (libdeflate where installed, as htslib):
+    # the baseline the device form replaced in image generation, and a comparison of every byte
+    cores = max(1, usable_cpus())
+    inflate_host(raw, table, cores)
+    t0 = time.perf_counter()
+    host = inflate_host(raw, table, cores)
+    t_host = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    inflate_host(raw, [a[:sample] for a in table], 1)
+    t_host1 = time.perf_counter() - t0
+    all_identical = bool(host.size == got.size and np.array_equal(host, got))
     print(json.dumps({"members": n, "compressed_bytes": int(raw.size), "inflated_bytes": out_bytes,
                       "kernel_ms": round(ms, 3), "device_GBps_inflated": round(out_bytes / ms / 1e6, 2),
                       "device_GBps_compressed": round(raw.size / ms / 1e6, 2),
                       "host_call_s_with_transfers": round(t_call, 3), "repeats": args.repeats,
                       "zlib_one_core_GBps": round(sample_bytes / t_cpu / 1e9, 3), "zlib_sample_members": sample,
-                      "sample_identical": bool(ok), "python_table_s": round(t_table, 3)}))
+                      "sample_identical": bool(ok), "host_library_all_cores_GBps": round(out_bytes / t_host / 1e9, 2), "host_cores": cores,
+                      "host_library_one_core_GBps": round(sample_bytes / t_host1 / 1e9, 3), "identical_to_host_library": all_identical,
+                      "python_table_s": round(t_table, 3)}))
 
 
 if __name__ == "__main__":
