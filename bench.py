@@ -944,10 +944,15 @@ def secondary_block(args):
             path = os.path.join(REPO, "profiles", "r04_inflate_kernel_stats.txt")
             for line in open(path):
                 parts = line.split()
-                if len(parts) >= 2 and parts[0].startswith("SQ_"):
+                if len(parts) >= 2 and (parts[0].startswith("SQ_") or parts[0] in ("FETCH_SIZE", "WRITE_SIZE")):
                     ins[parts[0]] = float(parts[1])
             members = next(int(line.split()[1]) for line in open(path) if line.startswith("inflate:"))
             scale = d["members"] / members                      # (the committed pass had this many members per launch)
+            if "FETCH_SIZE" in ins and "WRITE_SIZE" in ins:      # KB per launch, each counter in its own pass (MI355X_MICROARCH.md)
+                roof["traffic"] = (ins["FETCH_SIZE"] + ins["WRITE_SIZE"]) * 1024.0 * scale
+                roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of profiles/r04_inflate_kernel_stats.txt: the writes are the inflated "
+                                        "bytes once; the fetches are 7x the compressed input -- every match byte is a byte-wide gather that "
+                                        "pulls a whole line, mostly of output this wavefront wrote moments ago")
             simd_cycles = 1024 * d["kernel_ms"] * 1e-3 * 2.4e9
             roof["issue"] = {"bound": "valu issue", "valu_wave_instructions": ins["SQ_INSTS_VALU"] * scale,
                              "salu_wave_instructions": ins["SQ_INSTS_SALU"] * scale, "lds_wave_instructions": ins["SQ_INSTS_LDS"] * scale,

@@ -18,8 +18,10 @@ cd /tmp
 timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r04_inflate_stats -o inf -- $B > $R/gpurun_out/r04_inflate_stats.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $R/gpurun_out/r04_inflate_pmc1 -o inf -- $B > $R/gpurun_out/r04_inflate_pmc1.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES -d $R/gpurun_out/r04_inflate_pmc2 -o inf -- $B > $R/gpurun_out/r04_inflate_pmc2.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/r04_inflate_fetch -o inf -- $B > $R/gpurun_out/r04_inflate_fetch.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/r04_inflate_write -o inf -- $B > $R/gpurun_out/r04_inflate_write.log 2>&1
 cd $R
 python tools/rocprof_db_summary.py gpurun_out/r04_images_stats > gpurun_out/r04_make_images_kernel_stats.txt
-python tools/rocprof_db_summary.py gpurun_out/r04_inflate_stats gpurun_out/r04_inflate_pmc1 gpurun_out/r04_inflate_pmc2 --only bgzf > gpurun_out/r04_inflate_kernel_stats.txt
+python tools/rocprof_db_summary.py gpurun_out/r04_inflate_stats gpurun_out/r04_inflate_pmc1 gpurun_out/r04_inflate_pmc2 gpurun_out/r04_inflate_fetch gpurun_out/r04_inflate_write --only bgzf > gpurun_out/r04_inflate_kernel_stats.txt
 PA_INFLATE_DEBUG=1 $B 2>&1 > /dev/null | tail -1 >> gpurun_out/r04_inflate_kernel_stats.txt
 find gpurun_out -name "*.db" -delete
