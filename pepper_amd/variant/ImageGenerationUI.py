@@ -254,7 +254,10 @@ class ImageGenerationUtils:
                     host_clipped(output_hdf_file, group)
                     g0 += n_done
                     continue
-                references = [fasta_handler.get_reference_sequence(chr_name, a, b + 1) for a, b in regions]
+                # one fetch for the group's whole stretch of the contig (adjacent intervals), sliced per interval
+                lo, hi = regions[0][0], max(b for _, b in regions) + 1
+                whole = fasta_handler.get_reference_bytes(chr_name, lo, hi)
+                references = [whole[a - lo:b + 1 - lo] for a, b in regions]
                 t0 = lap("fasta", t0)
                 try:
                     outs, live = enc.encode(regions, references, region_pairs, counts, params, [(s, e) for _, s, e in group],

@@ -14,6 +14,9 @@ import os
 _SCANS = {}      # (path, mtime, size) -> (names, index) of the last FASTA file scanned for want of a .fai
 
 
+_UPPER = bytes(range(256)).upper()
+
+
 class FASTA_handler(object):
     def __init__(self, path):
         if not os.path.isfile(path):
@@ -81,16 +84,21 @@ class FASTA_handler(object):
             return -1
         return self._index[chromosome_name][0]
 
-    def get_reference_sequence(self, region, start, stop):
+    def get_reference_bytes(self, region, start, stop):
+        """get_reference_sequence as upper-case bytes (what the encoders take; image generation fetches a whole group of
+        intervals with one call and slices it)."""
         if region not in self._index:
             raise KeyError("CHROMOSOME NAME NOT PRESENT IN REFERENCE FASTA FILE: %s %d %d" % (region, start, stop))
         length, offset, line_bases, line_width = self._index[region]
         start = max(0, int(start))
         stop = min(length, int(stop))
         if stop <= start or line_bases <= 0:
-            return ""
+            return b""
         first = offset + (start // line_bases) * line_width + start % line_bases
         last = offset + ((stop - 1) // line_bases) * line_width + (stop - 1) % line_bases
         self._fh.seek(first)
         raw = self._fh.read(last - first + 1)
-        return raw.replace(b"\n", b"").replace(b"\r", b"").decode().upper()
+        return raw.translate(_UPPER, b"\n\r")               # line ends out and upper case in one pass
+
+    def get_reference_sequence(self, region, start, stop):
+        return self.get_reference_bytes(region, start, stop).decode()
