@@ -185,6 +185,40 @@ int pa_polish_encoder_get_results(pa_encoder* e, uint8_t* image, int64_t* positi
 /* HIP-event times of the last call in ms: [0] record / scan kernels, [1] polish_tile_kernel, [2] polish_insert_rows_kernel. */
 int pa_polish_encoder_last_timing(pa_encoder* e, double* ms, int32_t n);
 
+/* ------------------------------------------------------------------------------------------
+ * The polish image chain: BAM records -> image chunks of N regions without a host hop in between.
+ * replaces, per region: AlignmentSummarizer.create_summary's inference branch --
+ *   bam_handler.get_reads(chr, start, end, False, 0, 0)            pepper/modules/python/AlignmentSummarizer.py:296-303
+ *   reads_to_reference_realignment (ReadAligner over every read)   :159-177, 328-332; simple_aligner.cpp:66-106
+ *   SummaryGenerator(...).generate_summary(reads, start, end)      :334-347; summary_generator.cpp:47-121, 274-306, 370-393
+ *   chunk_images(summary, 1000, 50)                                :18-56
+ * The reads arrive in the packed form of pa_encoder_stage_packed (or are the span pa_encoder_inflate_bgzf left on the device:
+ * arena = NULL); unpack_clip_kernel clips and decodes them per (read, region), the re-aligner (include/pepper_amd_realign.h)
+ * takes them from there and leaves positions and CIGARs on the device, the summary encoder reads those, and the rows are cut
+ * into chunks of chunk_size rows (the next one starting chunk_overlap rows before the end of the previous one, the last one
+ * padded with zero rows and (-1, -1) positions) by a kernel.  One download: the chunks.
+ *   regions[r]   region_start / region_end = the region (reads fetched from it, summary over it); reference / reference_len =
+ *                the draft from region_start to region_end + ALIGNMENT_SAFE_BASES (20), shorter at the contig's end: the
+ *                re-aligner's window (ignored when realign == 0)
+ *   realign      realignment_flag of create_summary
+ * Outputs (any may be NULL): n_rows[r] summary rows, region_reads[r] = the reference's len(all_reads), n_chunks[r] (0 for a
+ * region without reads: it writes nothing), *total_chunks.  The reservoir sample of a region with more than
+ * MAX_READS_IN_REGION reads is the caller's business (such a region goes through the per-region entry points).
+ * PA_ERR_UNSUPPORTED: a batch this form does not take (an operation of 2^24 bases, a read that keeps more than 2 L + 64 bases
+ * of a region of L positions): nothing was produced, take the host-clipped form.
+ * ------------------------------------------------------------------------------------------ */
+int pa_polish_chain_run(pa_encoder* e, int32_t n_regions, const pa_packed_region* regions, const uint8_t* arena, int64_t arena_bytes,
+                        const pa_packed_read* reads, int32_t n_reads, const int32_t* pair_read, const int32_t* region_pairs,
+                        int32_t realign, int32_t chunk_size, int32_t chunk_overlap, int64_t* n_rows, int32_t* region_reads,
+                        int32_t* n_chunks, int64_t* total_chunks);
+/* The chunks of the last run, region after region, in page-locked memory of the handle (valid until its next run):
+ * images uint8 [total_chunks, chunk_size, 10], position / index int64 [total_chunks, chunk_size]. */
+int pa_polish_chain_chunks(pa_encoder* e, const uint8_t** images, const int64_t** position, const int64_t** index);
+/* Host-clock times of the last run in ms: [0] tables + upload + unpack launch, [1] re-aligner (its waits included) + apply,
+ * [2] summary encoder (its wait included), [3] chunk kernel + download; HIP events: [5] score kernels, [6] band launches.
+ * counts: [0] (read, region) pairs, [1] reads re-aligned, [2] CIGAR operations written, [3] summary rows. */
+int pa_polish_chain_last_timing(pa_encoder* e, double* ms, int32_t n_ms, int64_t* counts, int32_t n_counts);
+
 #ifdef __cplusplus
 }
 #endif

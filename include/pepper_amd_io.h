@@ -161,6 +161,13 @@ int pa_h5_builder_write_polish_image_chunks(pa_h5_builder* b, const char* names,
                                             const char* contig, int64_t region_start, int64_t region_end, const int64_t* chunk_id,
                                             const uint8_t* images, const uint8_t* labels, const int64_t* position,
                                             const int64_t* index);
+/* The chunks of MANY regions of one contig in one call (the polish image chain, include/pepper_amd_encoder.h): region r has
+ * n_chunks[r] consecutive chunks in images / position / index (chunk ids 0 .. n_chunks[r] - 1, groups
+ * summaries/<contig>_<start>_<end>_<chunk id> as pepper ImageGenerationUI.py:203-211 names them); labels NULL: zeros (inference
+ * mode).  A group that exists already is skipped, as DataStore.write_summary does (DataStore.py:53-56). */
+int pa_h5_builder_write_polish_image_regions(pa_h5_builder* b, int32_t n_regions, const char* contig, const int64_t* region_start,
+                                             const int64_t* region_end, const int32_t* n_chunks, int32_t seq_len, int32_t features,
+                                             const uint8_t* images, const uint8_t* labels, const int64_t* position, const int64_t* index);
 /* One summaries/<name> group of a variant image file, as pepper_variant DataStore.py:54-71 (write_summary, inference mode):
  * contigs 'S<len>' [n] (the one contig name n times), positions int32 [n], depths uint8 [n], candidates variable-length utf-8
  * [n,1] (NUL-terminated at cand_blob + cand_offsets[i]), candidate_frequency uint8 [n,1], images int8 [n, window, features].

@@ -89,6 +89,10 @@ SYMBOLS = [
     ("pa_polish_encoder_batch_stats", ctypes.c_int, [c_void_p, c_void_p, c_int32]),
     ("pa_polish_encoder_get_results", ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     ("pa_polish_encoder_last_timing", ctypes.c_int, [c_void_p, c_void_p, c_int32]),
+    ("pa_polish_chain_run", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p,
+                                           c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("pa_polish_chain_chunks", ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("pa_polish_chain_last_timing", ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32]),
     # include/pepper_amd_realign.h
     ("pa_realigner_create", ctypes.c_int, [c_int32, c_void_p, ctypes.POINTER(c_void_p)]),
     ("pa_realigner_destroy", None, [c_void_p]),

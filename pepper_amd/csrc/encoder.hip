@@ -39,6 +39,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/pepper_amd_realign.h"
 #include "encoder_common.h"
 
 using namespace pa_enc;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void segment_reads_kernel(const ReadRec* __res
 // the same arithmetic in Python, checked against the sequential walk].  The kept bases are ONE stretch of the read
 // (bamio.cpp, pa_bam_get_reads); it is decoded four bases per lane into the byte-per-base arrays tile_count_kernel reads.
 struct PackedRead { int64_t data_off; int32_t pos, n_cigar, l_seq, flags; };     // = pa_packed_read
-struct PairRec { int64_t s0; int32_t read, region, c0, pad; };                   // where the pair's clipped bases / operations go
+struct PairRec { int64_t s0; int32_t read, region, c0, cap; };                   // where the pair's clipped bases / operations go; cap > 0: room for that many bases only
 static_assert(sizeof(PackedRead) == sizeof(pa_packed_read) && sizeof(PackedRead) == 24 && sizeof(PairRec) == 24, "packed tables");
 
 struct UnpackArgs {
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void unpack_clip_kernel(UnpackArgs a) {
         ridx += wave_total(qinc);
         if (rpos > last) break;
     }
+    if (pr.cap > 0 && written > pr.cap) unsupported = true;      // (the polish chain gives a pair the room a region can fill)
     const bool bad = !unsupported && written > 0 && ((unsigned)first_idx + (unsigned)written > (unsigned)rd.l_seq);
     if (lane == 0) {
         if (unsupported) atomicMax(&a.live[a.n_regions + 1], pr.read + 1);
@@ -1710,6 +1712,107 @@ int run_staged(pa_encoder* e, int64_t* n_candidates) {
 
 }  // namespace
 
+// The packed reads of a batch of regions clipped and decoded on the device WITHOUT the variant encoder's tables: what the polish
+// image chain (encoder_polish.hip) starts from.  Same arena / read / pair tables as stage_packed, same kernel; the regions are
+// given by their bounds alone.  Nothing here waits for the device.
+int pa_enc::unpack_packed_regions(pa_encoder* e, int32_t n_regions, const int64_t* region_start, const int64_t* region_end,
+                                  const uint8_t* arena, int64_t arena_bytes, const pa_packed_read* reads, int32_t n_reads,
+                                  const int32_t* pair_read, const int32_t* region_pairs, int32_t extra_ops_per_pair, UnpackedReads* out) {
+    if (!e || !out || n_regions < 0 || (n_regions > 0 && (!region_start || !region_end || !region_pairs)) || arena_bytes < 0 || n_reads < 0 ||
+        (n_reads > 0 && (!reads || !pair_read)))
+        return pa::set_error(PA_ERR_INVALID, "null argument");
+    ENC_HIP(hipSetDevice(e->device));
+    if (!e->variant) e->variant = new pa_variant_batch();
+    pa_variant_batch& b = *e->variant;
+    const bool resident = arena == nullptr && n_reads > 0;
+    if (resident && (b.resident_bytes <= 0 || arena_bytes > b.resident_bytes))
+        return pa::set_error(PA_ERR_INVALID, "no arena given and no inflated span of that size resident on the device");
+    b.staged = false;               // (the variant encoder's staged batch, if any, shares these buffers)
+    const int64_t n_pairs = n_regions ? region_pairs[n_regions] : 0;
+    if (n_pairs < 0 || (n_regions && region_pairs[0] != 0)) return pa::set_error(PA_ERR_INVALID, "region_pairs must start at 0 and ascend");
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_reg = 0, o_start = up16(o_reg + (size_t)n_regions * sizeof(RegRec)), o_reads = up16(o_start + (size_t)n_regions * 8),
+                 o_pairs = up16(o_reads + (size_t)n_reads * sizeof(PackedRead)), meta_bytes = up16(o_pairs + (size_t)n_pairs * sizeof(PairRec)) + 64;
+    if (!b.h_meta.ensure(meta_bytes) || !b.h_live.ensure(((size_t)n_regions + 2) * 4)) return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed");
+    char* hm = b.h_meta.as<char>();
+    RegRec* regrecs = reinterpret_cast<RegRec*>(hm + o_reg);
+    int64_t* rstart = reinterpret_cast<int64_t*>(hm + o_start);
+    PairRec* pairs = reinterpret_cast<PairRec*>(hm + o_pairs);
+    if (n_reads) std::memcpy(hm + o_reads, reads, (size_t)n_reads * sizeof(PackedRead));
+    int64_t total_bases = 0, total_ops = 0;
+    for (int r = 0; r < n_regions; ++r) {
+        if (region_end[r] < region_start[r] || region_end[r] - region_start[r] > (int64_t)1 << 28) return pa::set_error(PA_ERR_INVALID, "bad region");
+        if (region_pairs[r + 1] < region_pairs[r]) return pa::set_error(PA_ERR_INVALID, "region_pairs must ascend");
+        RegRec& g = regrecs[r];
+        std::memset(&g, 0, sizeof(g));
+        g.L = (int32_t)(region_end[r] - region_start[r] + 1);
+        rstart[r] = region_start[r];
+        for (int32_t k = region_pairs[r]; k < region_pairs[r + 1]; ++k) {
+            const int32_t ri = pair_read[k];
+            if (ri < 0 || ri >= n_reads) return pa::set_error(PA_ERR_INVALID, "pair_read out of range");
+            const pa_packed_read& rd = reads[ri];
+            if (rd.n_cigar < 0 || rd.l_seq < 0 || rd.data_off < 0 ||
+                rd.data_off + 4ll * rd.n_cigar + (rd.l_seq + 1) / 2 + rd.l_seq > arena_bytes)
+                return pa::set_error(PA_ERR_INVALID, "packed read " + std::to_string(ri) + " lies outside the arena");
+            // the clipped stretch of a read holds its aligned bases inside the region and the inserts between them: room for the
+            // whole read would be 10-50 kb per pair of a 1 kb region, so a pair gets min(l_seq, 2 L + 64) bases; a pair that
+            // keeps more is reported as unsupported (h_live[n_regions + 1]) and the caller takes the host-clipped form
+            const int64_t cap = std::min<int64_t>(rd.l_seq, 2ll * g.L + 64);
+            pairs[k] = PairRec{total_bases, ri, r, (int32_t)total_ops, (int32_t)cap};
+            total_bases += ((cap + 3) & ~(int64_t)3) + 4;
+            // (kept M / D / N operations each cover a row of the region, kept I / S ones a kept base)
+            total_ops += std::min<int64_t>(rd.n_cigar, (int64_t)g.L + cap + 2);
+        }
+    }
+    const int64_t extra_ops = extra_ops_per_pair < 0 ? 0 : total_bases + n_pairs * (int64_t)extra_ops_per_pair;
+    if (total_ops + extra_ops > 0x7ffffff0) return pa::set_error(PA_ERR_INVALID, "batch too large: more than 2^31 CIGAR operations");
+    hipStream_t st = e->stream;
+    if (!resident) {
+        ENC_ALLOC(b.d_arena, (size_t)arena_bytes + 256);
+        b.resident_bytes = 0;
+    }
+    ENC_ALLOC(b.d_meta, meta_bytes);
+    ENC_ALLOC(b.d_live, ((size_t)n_regions + 2) * 4);
+    ENC_ALLOC(b.d_seq, (size_t)total_bases + 64);
+    ENC_ALLOC(b.d_qual, (size_t)total_bases + 64);
+    ENC_ALLOC(b.d_cig_op, (size_t)(total_ops + extra_ops) * 4 + 1024);
+    ENC_ALLOC(b.d_cig_len, (size_t)(total_ops + extra_ops) * 4 + 1024);
+    ENC_ALLOC(b.d_reads, (size_t)n_pairs * sizeof(ReadRec) + 64);
+    if (arena_bytes > 0 && !resident) ENC_HIP(hipMemcpyAsync(b.d_arena.p, arena, (size_t)arena_bytes, hipMemcpyHostToDevice, st));
+    ENC_HIP(hipMemcpyAsync(b.d_meta.p, hm, meta_bytes, hipMemcpyHostToDevice, st));
+    ENC_HIP(hipMemsetAsync(b.d_live.p, 0, ((size_t)n_regions + 2) * 4, st));
+    const char* dm = b.d_meta.as<char>();
+    if (n_pairs > 0) {
+        UnpackArgs ua;
+        ua.pairs = reinterpret_cast<const PairRec*>(dm + o_pairs);
+        ua.n_pairs = (int)n_pairs;
+        ua.preads = reinterpret_cast<const PackedRead*>(dm + o_reads);
+        ua.regions = reinterpret_cast<const RegRec*>(dm + o_reg);
+        ua.region_start = reinterpret_cast<const int64_t*>(dm + o_start);
+        ua.arena = b.d_arena.as<uint8_t>();
+        ua.reads = b.d_reads.as<ReadRec>();
+        ua.cigar_op = b.d_cig_op.as<int32_t>();
+        ua.cigar_len = b.d_cig_len.as<int32_t>();
+        ua.seq = b.d_seq.as<char>();
+        ua.qual = b.d_qual.as<uint8_t>();
+        ua.live = b.d_live.as<int>();
+        ua.n_regions = n_regions;
+        hipLaunchKernelGGL(unpack_clip_kernel, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, st, ua);
+        ENC_HIP(hipGetLastError());
+    }
+    ENC_HIP(hipMemcpyAsync(b.h_live.p, b.d_live.p, ((size_t)n_regions + 2) * 4, hipMemcpyDeviceToHost, st));
+    out->reads = b.d_reads.as<ReadRec>();
+    out->cigar_op = b.d_cig_op.as<int32_t>();
+    out->cigar_len = b.d_cig_len.as<int32_t>();
+    out->seq = b.d_seq.as<char>();
+    out->n_pairs = n_pairs;
+    out->total_bases = total_bases;
+    out->total_ops = total_ops;
+    out->extra_ops = extra_ops;
+    out->h_live = b.h_live.as<int>();
+    return PA_OK;
+}
+
 #ifdef PA_ENC_STAMP
 extern "C" int pa_encoder_debug_cycles(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_enc_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
@@ -1761,6 +1864,7 @@ void pa_encoder_destroy(pa_encoder* e) {
         if (ev) (void)hipEventDestroy(ev);
     pa_variant_batch_free(e->variant);
     pa_polish_batch_free(e->polish);
+    if (e->realigner) pa_realigner_destroy(e->realigner);      // (the image chain's, on this encoder's stream)
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

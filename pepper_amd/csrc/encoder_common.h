@@ -145,7 +145,49 @@ struct pa_encoder {
     hipEvent_t ev[12] = {};
     pa_variant_batch* variant = nullptr;
     pa_polish_batch* polish = nullptr;
+    struct pa_realigner* realigner = nullptr;      // the polish image chain's re-aligner on this encoder's stream (made on first use)
 };
+
+// ---- the polish image chain (encoder_polish.hip: pa_polish_chain_*) crosses the three files; the pieces it calls --------------
+namespace pa_enc {
+// what unpack_clip_kernel (encoder.hip) left ON THE DEVICE for the (read, region) pairs of a packed batch: every pair's clipped
+// read as the host-clipped form would have uploaded it (ReadRec, CIGAR arrays, bases as text).  The CIGAR arrays have room
+// for extra_ops more operations behind the total_ops the pairs may use (the re-aligned CIGARs go there): total_bases +
+// n_pairs x extra_ops_per_pair of them (extra_ops_per_pair < 0: none).
+struct UnpackedReads {
+    ReadRec* reads = nullptr;
+    int32_t* cigar_op = nullptr;
+    int32_t* cigar_len = nullptr;
+    const char* seq = nullptr;
+    int64_t n_pairs = 0, total_bases = 0, total_ops = 0, extra_ops = 0;      // slots the pairs were given (bounds of what they use)
+    const int* h_live = nullptr;     // page-locked [n_regions + 2], valid once the stream has been waited for: reads with a base
+                                     // inside each region | first inconsistent read + 1 | first unsupported read + 1
+};
+int unpack_packed_regions(pa_encoder* e, int32_t n_regions, const int64_t* region_start, const int64_t* region_end,
+                          const uint8_t* arena, int64_t arena_bytes, const pa_packed_read* reads, int32_t n_reads,
+                          const int32_t* pair_read, const int32_t* region_pairs, int32_t extra_ops_per_pair, UnpackedReads* out);
+}  // namespace pa_enc
+
+namespace pa_ra {
+// The re-aligner over reads that are already on the device (realign.hip).  reads[k] (ReadRec of pair k: s0, slen, row0 = read
+// position - region start, region, flags) against window `region`: codes [window_off[region], + window_len[region]) of the
+// window text uploaded by this call.  Reads without READ_MAPQ_OK are not aligned (the summary skips them).  On return the
+// re-aligner's stream (the one it was created on) has been waited for once or more; the results are on the device: jobs (the kernels' table: state, ref_begin, ops_off,
+// n_ops per read) and the compacted operations (len << 4 | op).
+struct DeviceResult {
+    const void* jobs = nullptr;          // Job [n_reads] (realign.hip)
+    const uint32_t* ops = nullptr;
+    int64_t ops_written = 0;
+    int32_t n_aligned = 0;
+};
+int align_device(pa_realigner* r, const char* window_text, int64_t window_bytes, const int64_t* window_off,
+                 const int32_t* window_len, int32_t n_windows, const pa_enc::ReadRec* d_reads, int32_t n_reads, const char* d_seq,
+                 int64_t seq_bytes, int32_t max_region_len, DeviceResult* out);
+// per read k with a new alignment: reads[k].row0 += ref_begin, its CIGAR = the operations decoded into cigar_op / cigar_len at
+// ops_base + ops_off ('=' and 'X' as MATCH when collapse_eqx), c0 / ncig pointing there
+int apply_device(pa_realigner* r, pa_enc::ReadRec* d_reads, int32_t n_reads, int32_t* cigar_op,
+                 int32_t* cigar_len, int64_t ops_base, int32_t collapse_eqx);
+}  // namespace pa_ra
 
 // the two halves free their own state (defined next to the structs)
 void pa_variant_batch_free(pa_variant_batch*);

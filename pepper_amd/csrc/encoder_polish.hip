@@ -22,10 +22,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
 
+#include "../../include/pepper_amd_realign.h"
 #include "encoder_common.h"
 
 using namespace pa_enc;
@@ -417,6 +419,19 @@ struct pa_polish_batch {
     HBuf h_seq, h_cig_op, h_cig_len, h_meta, h_back;
     size_t o_reads = 0, o_regions = 0, o_tile = 0, o_pos = 0;     // the tables inside d_meta
     double ms[4] = {0, 0, 0, 0};
+    // device-fed form (the image chain): the reads are where unpack_clip_kernel / the re-aligner left them
+    const ReadRec* x_reads = nullptr;
+    const char* x_seq = nullptr;
+    const int32_t* x_cig_op = nullptr;
+    const int32_t* x_cig_len = nullptr;
+    // the image chain's chunked output (pa_polish_chain_run): [n_chunks, chunk_size, 10] pixels, [n_chunks, chunk_size] position / index
+    DBuf d_chunk_tab, d_chunk_img, d_chunk_pos, d_chunk_idx;
+    HBuf h_chunk_tab, h_chunk_img, h_chunk_pos, h_chunk_idx, h_windows;
+    std::vector<int32_t> chunk_count;        // per region
+    int64_t n_chunks = 0;
+    int32_t chunk_size = 0;
+    double chain_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t chain_counts[4] = {0, 0, 0, 0};   // pairs, reads re-aligned, operations written, rows
 };
 
 void pa_polish_batch_free(pa_polish_batch* b) { delete b; }
@@ -432,6 +447,9 @@ int polish_stage(pa_encoder* e, int32_t n_regions, const pa_pileup* pileups, con
     pa_polish_batch& b = *e->polish;
     hipStream_t st = e->stream;
     b.staged = false;
+    b.x_reads = nullptr;
+    b.x_seq = nullptr;
+    b.x_cig_op = b.x_cig_len = nullptr;
     b.regs.assign((size_t)n_regions, PRegHost());
     b.region_rows.assign((size_t)n_regions, 0);
     b.total_bases = b.total_ops = b.total_reads = b.total_rows = b.total_out = b.total_positions = 0;
@@ -543,7 +561,10 @@ int polish_run(pa_encoder* e, int64_t* n_rows) {
     b.total_out = 0;
     if (n_regions == 0) return PA_OK;
     const char* dm = b.d_meta.as<char>();
-    const ReadRec* d_reads = reinterpret_cast<const ReadRec*>(dm + b.o_reads);
+    const ReadRec* d_reads = b.x_reads ? b.x_reads : reinterpret_cast<const ReadRec*>(dm + b.o_reads);
+    const int32_t* d_cig_op = b.x_reads ? b.x_cig_op : b.d_cig_op.as<int32_t>();
+    const int32_t* d_cig_len = b.x_reads ? b.x_cig_len : b.d_cig_len.as<int32_t>();
+    const char* d_seq = b.x_reads ? b.x_seq : b.d_seq.as<char>();
     const PRegRec* d_regions = reinterpret_cast<const PRegRec*>(dm + b.o_regions);
     const int32_t* d_tile_region = reinterpret_cast<const int32_t*>(dm + b.o_tile);
     const int64_t* d_out_pos_base = reinterpret_cast<const int64_t*>(dm + b.o_pos);
@@ -578,7 +599,7 @@ int polish_run(pa_encoder* e, int64_t* n_rows) {
         const dim3 seg_grid((unsigned)((b.total_reads + 3) / 4));
         if (b.total_reads > 0)
             hipLaunchKernelGGL(polish_segment_kernel<false>, seg_grid, dim3(256), 0, st, d_reads, (int)b.total_reads, d_regions,
-                               b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), longest, tile_count, (const int*)nullptr, (int*)nullptr,
+                               d_cig_op, d_cig_len, longest, tile_count, (const int*)nullptr, (int*)nullptr,
                                (TileRec*)nullptr, 0, counters);
         hipLaunchKernelGGL(polish_rows_kernel, dim3((unsigned)n_regions), dim3(1024), 0, st, d_regions, longest, b.d_ins_base.as<int>(),
                            b.d_totals.as<int>());
@@ -590,7 +611,7 @@ int polish_run(pa_encoder* e, int64_t* n_rows) {
             hipLaunchKernelGGL(polish_tile_offsets_kernel, dim3(1), dim3(1024), 0, st, tile_count, b.n_tiles, b.d_tile_off.as<int>());
         if (b.total_reads > 0)
             hipLaunchKernelGGL(polish_segment_kernel<true>, seg_grid, dim3(256), 0, st, d_reads, (int)b.total_reads, d_regions,
-                               b.d_cig_op.as<int32_t>(), b.d_cig_len.as<int32_t>(), longest, tile_count, b.d_tile_off.as<int>(), tile_fill,
+                               d_cig_op, d_cig_len, longest, tile_count, b.d_tile_off.as<int>(), tile_fill,
                                b.d_sorted.as<TileRec>(), b.rec_cap, counters);
         ENC_HIP(hipEventRecord(e->ev[1], st));
         if (b.n_tiles > 0) {
@@ -598,9 +619,9 @@ int polish_run(pa_encoder* e, int64_t* n_rows) {
             ta.reads = d_reads;
             ta.regions = d_regions;
             ta.tile_region = d_tile_region;
-            ta.cigar_op = b.d_cig_op.as<int32_t>();
-            ta.cigar_len = b.d_cig_len.as<int32_t>();
-            ta.seq = b.d_seq.as<char>();
+            ta.cigar_op = d_cig_op;
+            ta.cigar_len = d_cig_len;
+            ta.seq = d_seq;
             ta.recs = b.d_sorted.as<TileRec>();
             ta.tile_off = b.d_tile_off.as<int>();
             ta.rec_cap = b.rec_cap;
@@ -658,6 +679,109 @@ int polish_run(pa_encoder* e, int64_t* n_rows) {
     return PA_OK;
 }
 
+// The tables of a batch whose reads are already on the device (the image chain): regions from their bounds, the ReadRec table,
+// bases and CIGAR arrays where unpack_clip_kernel and the re-aligner left them.  Nothing here waits for the device.
+int polish_stage_device(pa_encoder* e, int32_t n_regions, const int64_t* region_start, const int64_t* region_end,
+                        const int32_t* region_pairs, const UnpackedReads& u) {
+    ENC_HIP(hipSetDevice(e->device));
+    if (!e->polish) e->polish = new pa_polish_batch();
+    pa_polish_batch& b = *e->polish;
+    hipStream_t st = e->stream;
+    b.staged = false;
+    b.regs.assign((size_t)n_regions, PRegHost());
+    b.region_rows.assign((size_t)n_regions, 0);
+    b.total_bases = u.total_bases;
+    b.total_ops = u.total_ops + u.extra_ops;
+    b.total_reads = u.n_pairs;
+    b.total_rows = b.total_out = b.total_positions = 0;
+    b.n_tiles = 0;
+    b.x_reads = u.reads;
+    b.x_seq = u.seq;
+    b.x_cig_op = u.cigar_op;
+    b.x_cig_len = u.cigar_len;
+    if (n_regions == 0) {
+        b.staged = true;
+        return PA_OK;
+    }
+    for (int r = 0; r < n_regions; ++r) {
+        if (region_end[r] < region_start[r] || region_end[r] - region_start[r] > (int64_t)1 << 28) return pa::set_error(PA_ERR_INVALID, "bad region");
+        PRegHost& rh = b.regs[(size_t)r];
+        rh.p = pa_pileup{};
+        rh.p.region_start = region_start[r];
+        rh.p.region_end = region_end[r];
+        rh.p.n_reads = region_pairs[r + 1] - region_pairs[r];
+        rh.start_pos = region_start[r];
+        rh.end_pos = region_end[r];
+        rh.L = (int)(region_end[r] - region_start[r] + 1);
+        rh.row_base = b.total_rows;
+        rh.read_base = region_pairs[r];
+        b.total_rows += rh.L;
+        b.n_tiles += (rh.L + TP - 1) / TP;
+        b.total_positions += rh.L;
+        if (b.total_rows > ((int64_t)1 << 30)) return pa::set_error(PA_ERR_INVALID, "batch too large");
+    }
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    b.o_reads = 0;
+    b.o_regions = 0;
+    b.o_tile = up16(b.o_regions + (size_t)n_regions * sizeof(PRegRec));
+    b.o_pos = up16(b.o_tile + (size_t)b.n_tiles * 4);
+    const size_t meta_bytes = up16(b.o_pos + ((size_t)n_regions + 1) * 8);
+    if (!b.h_meta.ensure(meta_bytes)) return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed");
+    char* hm = b.h_meta.as<char>();
+    PRegRec* regrecs = reinterpret_cast<PRegRec*>(hm + b.o_regions);
+    int32_t* tile_region = reinterpret_cast<int32_t*>(hm + b.o_tile);
+    int64_t* out_pos_base = reinterpret_cast<int64_t*>(hm + b.o_pos);
+    int tile0 = 0;
+    out_pos_base[0] = 0;
+    for (int r = 0; r < n_regions; ++r) {
+        const PRegHost& rh = b.regs[(size_t)r];
+        PRegRec& g = regrecs[r];
+        g.row_base = rh.row_base;
+        g.seq_base = 0;
+        g.pos0 = rh.p.region_start;
+        g.L = rh.L;
+        g.tile0 = tile0;
+        g.n_tiles = (rh.L + TP - 1) / TP;
+        g.stop_row = rh.L - 1;
+        g.out_lo = 0;
+        g.out_hi = rh.L - 1;
+        g.pad[0] = g.pad[1] = 0;
+        out_pos_base[r + 1] = out_pos_base[r] + rh.L;
+        for (int t = 0; t < g.n_tiles; ++t) tile_region[tile0 + t] = r;
+        tile0 += g.n_tiles;
+    }
+    ENC_ALLOC(b.d_meta, meta_bytes);
+    ENC_HIP(hipMemcpyAsync(b.d_meta.p, hm, meta_bytes, hipMemcpyHostToDevice, st));
+    b.staged = true;
+    return PA_OK;
+}
+
+// chunk_images (pepper AlignmentSummarizer.py:18-56) for every region of the batch: one thread per row of a chunk.  tab[c] =
+// {first source row (among all output rows of the batch), rows taken from there}; the rows behind them are zero pixels with
+// position / index -1.
+struct ChunkRec { int64_t src; int32_t n, pad; };
+__global__ __launch_bounds__(256) void polish_chunk_rows_kernel(const ChunkRec* __restrict__ tab, int chunk_size, const uint8_t* __restrict__ pixels,
+                                                                const int64_t* __restrict__ positions, uint8_t* __restrict__ img,
+                                                                int64_t* __restrict__ pos, int64_t* __restrict__ idx) {
+    const int c = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= chunk_size) return;
+    const ChunkRec t = tab[c];
+    const int64_t o = (int64_t)c * chunk_size + i;
+    uint8_t* dst = img + o * NF;
+    if (i < t.n) {
+        const uint8_t* src = pixels + (t.src + i) * NF;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) dst[j] = src[j];
+        pos[o] = positions[2 * (t.src + i)];
+        idx[o] = positions[2 * (t.src + i) + 1];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) dst[j] = 0;
+        pos[o] = -1;
+        idx[o] = -1;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -705,6 +829,161 @@ int pa_polish_encoder_get_results(pa_encoder* e, uint8_t* image, int64_t* positi
 int pa_polish_encoder_last_timing(pa_encoder* e, double* ms, int32_t n) {
     if (!e || !ms || n < 0) return pa::set_error(PA_ERR_INVALID, "null argument");
     for (int i = 0; i < n; ++i) ms[i] = (e->polish && i < 4) ? e->polish->ms[i] : 0.0;
+    return PA_OK;
+}
+
+// ---- the polish image chain ------------------------------------------------------------------------------------------------
+int pa_polish_chain_run(pa_encoder* e, int32_t n_regions, const pa_packed_region* regions, const uint8_t* arena, int64_t arena_bytes,
+                        const pa_packed_read* reads, int32_t n_reads, const int32_t* pair_read, const int32_t* region_pairs,
+                        int32_t realign, int32_t chunk_size, int32_t chunk_overlap, int64_t* n_rows, int32_t* region_reads,
+                        int32_t* n_chunks, int64_t* total_chunks) {
+    if (!e || n_regions < 0 || (n_regions > 0 && (!regions || !region_pairs)) || chunk_size <= 0 || chunk_overlap < 0 || chunk_overlap >= chunk_size)
+        return pa::set_error(PA_ERR_INVALID, "null argument");
+    ENC_HIP(hipSetDevice(e->device));
+    if (!e->polish) e->polish = new pa_polish_batch();
+    pa_polish_batch& b = *e->polish;
+    hipStream_t st = e->stream;
+    b.n_chunks = 0;
+    b.chunk_size = chunk_size;
+    b.chunk_count.assign((size_t)n_regions, 0);
+    for (double& v : b.chain_ms) v = 0;
+    for (int64_t& v : b.chain_counts) v = 0;
+    if (total_chunks) *total_chunks = 0;
+    if (n_regions == 0) return PA_OK;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    auto t0 = now();
+    std::vector<int64_t> rs((size_t)n_regions), re((size_t)n_regions);
+    int max_L = 1, max_wl = 0;
+    int64_t window_bytes = 0;
+    for (int r = 0; r < n_regions; ++r) {
+        rs[(size_t)r] = regions[r].region_start;
+        re[(size_t)r] = regions[r].region_end;
+        if (re[(size_t)r] < rs[(size_t)r] || re[(size_t)r] - rs[(size_t)r] > (int64_t)1 << 24) return pa::set_error(PA_ERR_INVALID, "bad region");
+        max_L = std::max(max_L, (int)(re[(size_t)r] - rs[(size_t)r] + 1));
+        if (realign) {
+            if (regions[r].reference_len < 0 || regions[r].reference_len > (int64_t)1 << 26 || (regions[r].reference_len > 0 && !regions[r].reference))
+                return pa::set_error(PA_ERR_INVALID, "bad reference window");
+            max_wl = std::max(max_wl, (int)regions[r].reference_len);
+            window_bytes += regions[r].reference_len;
+        }
+    }
+    // 1. clip + decode the pairs on the device
+    UnpackedReads u;
+    int rc = unpack_packed_regions(e, n_regions, rs.data(), re.data(), arena, arena_bytes, reads, n_reads, pair_read, region_pairs,
+                                   realign ? max_wl + 4 : -1, &u);
+    if (rc != PA_OK) return rc;
+    b.chain_counts[0] = u.n_pairs;
+    b.chain_ms[0] = since(t0);
+    t0 = now();
+    // 2. every read re-aligned to its region's window of the draft (simple_aligner.cpp:66-106); the new CIGARs behind the old ones
+    if (realign && u.n_pairs > 0) {
+        if (!e->realigner) {
+            rc = pa_realigner_create(e->device, st, &e->realigner);
+            if (rc != PA_OK) return rc;
+        }
+        if (!b.h_windows.ensure((size_t)window_bytes + (size_t)n_regions * 12 + 64)) return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed");
+        char* text = b.h_windows.as<char>();
+        std::vector<int64_t> woff((size_t)n_regions);
+        std::vector<int32_t> wlen((size_t)n_regions);
+        int64_t at = 0;
+        for (int r = 0; r < n_regions; ++r) {
+            woff[(size_t)r] = at;
+            wlen[(size_t)r] = (int32_t)regions[r].reference_len;
+            if (regions[r].reference_len > 0) std::memcpy(text + at, regions[r].reference, (size_t)regions[r].reference_len);
+            at += regions[r].reference_len;
+        }
+        pa_ra::DeviceResult res;
+        rc = pa_ra::align_device(e->realigner, text, window_bytes, woff.data(), wlen.data(), n_regions, u.reads, (int32_t)u.n_pairs, u.seq,
+                                 u.total_bases, max_L, &res);
+        if (rc != PA_OK) return rc;
+        b.chain_counts[1] = res.n_aligned;
+        b.chain_counts[2] = res.ops_written;
+        if (res.ops_written > u.extra_ops) return pa::set_error(PA_ERR_HIP, "polish chain: more re-aligned operations than the CIGAR arrays hold");
+        (void)pa_realigner_last_timing(e->realigner, &b.chain_ms[5], &b.chain_ms[6], nullptr);
+        rc = pa_ra::apply_device(e->realigner, u.reads, (int32_t)u.n_pairs, u.cigar_op, u.cigar_len, u.total_ops, 1);
+        if (rc != PA_OK) return rc;
+    }
+    b.chain_ms[1] = since(t0);
+    t0 = now();
+    // 3. the summary of every region from those reads
+    rc = polish_stage_device(e, n_regions, rs.data(), re.data(), region_pairs, u);
+    if (rc != PA_OK) return rc;
+    std::vector<int64_t> rows((size_t)n_regions, 0);
+    rc = polish_run(e, rows.data());
+    if (rc != PA_OK) return rc;
+    // (the stream has been waited for: what unpack_clip_kernel reported is here)
+    if (u.h_live[n_regions] > 0)
+        return pa::set_error(PA_ERR_INVALID, "packed read " + std::to_string(u.h_live[n_regions] - 1) + ": its CIGAR walks over more bases than the record holds");
+    if (u.h_live[n_regions + 1] > 0)
+        return pa::set_error(PA_ERR_UNSUPPORTED, "packed read " + std::to_string(u.h_live[n_regions + 1] - 1) +
+                                                     ": an operation of 2^24 bases or more, or more kept bases than a region's pair holds (take the host-clipped form)");
+    b.chain_ms[2] = since(t0);
+    t0 = now();
+    // 4. chunks: a region without reads has none (AlignmentSummarizer.py:311-312)
+    int64_t total = 0, first_row = 0;
+    for (int r = 0; r < n_regions; ++r) {
+        const int64_t nr = rows[(size_t)r];
+        int32_t c = 0;
+        if (u.h_live[r] > 0 && nr > 0) c = nr <= chunk_size ? 1 : 1 + (int32_t)((nr - chunk_size + (chunk_size - chunk_overlap) - 1) / (chunk_size - chunk_overlap));
+        b.chunk_count[(size_t)r] = c;
+        total += c;
+        if (n_rows) n_rows[r] = nr;
+        if (region_reads) region_reads[r] = u.h_live[r];
+        if (n_chunks) n_chunks[r] = c;
+        b.chain_counts[3] += nr;
+    }
+    b.n_chunks = total;
+    if (total_chunks) *total_chunks = total;
+    if (total > 0) {
+        if (!b.h_chunk_tab.ensure((size_t)total * sizeof(ChunkRec)) || !b.h_chunk_img.ensure((size_t)total * chunk_size * NF) ||
+            !b.h_chunk_pos.ensure((size_t)total * chunk_size * 8) || !b.h_chunk_idx.ensure((size_t)total * chunk_size * 8))
+            return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed");
+        ChunkRec* tab = b.h_chunk_tab.as<ChunkRec>();
+        int64_t k = 0;
+        for (int r = 0; r < n_regions; ++r) {
+            const int64_t nr = rows[(size_t)r];
+            int64_t start = 0, end = std::min<int64_t>(nr, chunk_size);
+            for (int32_t c = 0; c < b.chunk_count[(size_t)r]; ++c) {
+                tab[k++] = ChunkRec{first_row + start, (int32_t)(end - start), 0};
+                start = end - chunk_overlap;
+                end = std::min<int64_t>(nr, start + chunk_size);
+            }
+            first_row += nr;
+        }
+        ENC_ALLOC(b.d_chunk_tab, (size_t)total * sizeof(ChunkRec));
+        ENC_ALLOC(b.d_chunk_img, (size_t)total * chunk_size * NF);
+        ENC_ALLOC(b.d_chunk_pos, (size_t)total * chunk_size * 8);
+        ENC_ALLOC(b.d_chunk_idx, (size_t)total * chunk_size * 8);
+        ENC_HIP(hipMemcpyAsync(b.d_chunk_tab.p, tab, (size_t)total * sizeof(ChunkRec), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(polish_chunk_rows_kernel, dim3((unsigned)((chunk_size + 255) / 256), (unsigned)total), dim3(256), 0, st,
+                           b.d_chunk_tab.as<ChunkRec>(), chunk_size, b.d_pixels.as<uint8_t>(), b.d_positions.as<int64_t>(),
+                           b.d_chunk_img.as<uint8_t>(), b.d_chunk_pos.as<int64_t>(), b.d_chunk_idx.as<int64_t>());
+        ENC_HIP(hipGetLastError());
+        ENC_HIP(hipMemcpyAsync(b.h_chunk_img.p, b.d_chunk_img.p, (size_t)total * chunk_size * NF, hipMemcpyDeviceToHost, st));
+        ENC_HIP(hipMemcpyAsync(b.h_chunk_pos.p, b.d_chunk_pos.p, (size_t)total * chunk_size * 8, hipMemcpyDeviceToHost, st));
+        ENC_HIP(hipMemcpyAsync(b.h_chunk_idx.p, b.d_chunk_idx.p, (size_t)total * chunk_size * 8, hipMemcpyDeviceToHost, st));
+        ENC_HIP(hipStreamSynchronize(st));
+    } else {
+        for (int r = 0; r < n_regions; ++r) first_row += rows[(size_t)r];
+    }
+    b.chain_ms[3] = since(t0);
+    return PA_OK;
+}
+
+int pa_polish_chain_chunks(pa_encoder* e, const uint8_t** images, const int64_t** position, const int64_t** index) {
+    if (!e || !e->polish) return pa::set_error(PA_ERR_INVALID, "no chain run");
+    const pa_polish_batch& b = *e->polish;
+    if (images) *images = b.n_chunks > 0 ? b.h_chunk_img.as<uint8_t>() : nullptr;
+    if (position) *position = b.n_chunks > 0 ? b.h_chunk_pos.as<int64_t>() : nullptr;
+    if (index) *index = b.n_chunks > 0 ? b.h_chunk_idx.as<int64_t>() : nullptr;
+    return PA_OK;
+}
+
+int pa_polish_chain_last_timing(pa_encoder* e, double* ms, int32_t n_ms, int64_t* counts, int32_t n_counts) {
+    if (!e || n_ms < 0 || n_counts < 0) return pa::set_error(PA_ERR_INVALID, "null argument");
+    for (int i = 0; ms && i < n_ms; ++i) ms[i] = (e->polish && i < 8) ? e->polish->chain_ms[i] : 0.0;
+    for (int i = 0; counts && i < n_counts; ++i) counts[i] = (e->polish && i < 4) ? e->polish->chain_counts[i] : 0;
     return PA_OK;
 }
 

@@ -672,6 +672,44 @@ int pa_h5_builder_write_polish_image_chunks(pa_h5_builder* b, const char* names,
     return 0;
 }
 
+int pa_h5_builder_write_polish_image_regions(pa_h5_builder* b, int32_t n_regions, const char* contig, const int64_t* region_start,
+                                             const int64_t* region_end, const int32_t* n_chunks, int32_t seq_len, int32_t features,
+                                             const uint8_t* images, const uint8_t* labels, const int64_t* position, const int64_t* index) {
+    if (!b || n_regions < 0 || seq_len <= 0 || features <= 0 || !contig || (n_regions > 0 && (!region_start || !region_end || !n_chunks)))
+        return fail("bad argument");
+    if (b->failed) return fail("the file has a failed write behind it");
+    if (!*contig || std::strchr(contig, '/')) return fail(std::string("bad contig name '") + contig + "'");
+    const uint32_t summaries = b->group("summaries");
+    const uint64_t d2[2] = {(uint64_t)seq_len, (uint64_t)features}, d1[1] = {(uint64_t)seq_len};
+    const std::vector<uint8_t> zeros((size_t)seq_len, 0);
+    size_t k = 0;
+    for (int32_t r = 0; r < n_regions; ++r) {
+        if (n_chunks[r] < 0) return fail("negative chunk count");
+        if (n_chunks[r] > 0 && (!images || !position || !index)) return fail("bad argument");
+        const std::string stem = std::string(contig) + "_" + std::to_string(region_start[r]) + "_" + std::to_string(region_end[r]) + "_";
+        for (int32_t c = 0; c < n_chunks[r]; ++c, ++k) {
+            const std::string name = stem + std::to_string(c);
+            if (b->has_kid(summaries, name.c_str())) continue;          // (DataStore.write_summary: a group written before is skipped)
+            Obj g;
+            g.name = name;
+            g.group = true;
+            const uint32_t id = b->add(summaries, std::move(g));
+            b->dataset(id, "image", 1, false, 2, d2, images + k * seq_len * features);
+            b->dataset(id, "label", 1, false, 1, d1, labels ? labels + k * seq_len : zeros.data());
+            b->dataset(id, "position", 8, true, 1, d1, position + k * seq_len);
+            b->dataset(id, "index", 8, true, 1, d1, index + k * seq_len);
+            b->vlen_string(id, "contig", contig);
+            b->scalar(id, "region_start", region_start[r]);
+            b->scalar(id, "region_end", region_end[r]);
+            b->scalar(id, "chunk_id", (int64_t)c);
+            if (int rc = b->seal(summaries, id)) return rc;
+            if (b->out.size() >= (4u << 20))
+                if (int rc = b->flush()) return rc;
+        }
+    }
+    return 0;
+}
+
 int pa_h5_builder_write_variant_summary(pa_h5_builder* b, const char* name, int32_t n, const char* contig, const int32_t* positions,
                                         const uint8_t* depths, const char* cand_blob, const int64_t* cand_offsets, const uint8_t* freqs,
                                         const int8_t* images, int32_t window, int32_t features) {

@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "common.h"
+#include "encoder_common.h"
 #include "kernels.h"
 
 namespace {
@@ -273,10 +274,15 @@ __device__ PassOut score_pass_any(uint32_t* he, const int8_t* __restrict__ ref, 
 
 template <int MAXN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MAXN <= 20 ? 2 : 1, MAXN <= 20 ? 2 : 1))) void sw_ends_kernel(Job* __restrict__ jobs, const int8_t* __restrict__ ref,
-                                                     const int8_t* __restrict__ seq) {
+                                                     const int8_t* __restrict__ seq, int r_lo, int r_hi) {
     extern __shared__ uint32_t he[];
     Job& J = jobs[blockIdx.x];
     if (J.state != ST_NEW) return;
+    {   // a launch takes the reads whose strip (rows per lane of the 8-bit segmentation, the longer one) lies in (r_lo, r_hi]:
+        // the device-fed form launches every instantiation over the whole table, each read runs in the narrowest that holds it
+        const int R = ((((J.m + 15) / 16) * 16) + 63) >> 6;
+        if (R <= r_lo || R > r_hi) return;
+    }
     const int8_t* rf = ref + J.ref_off;
     const int8_t* rd = seq + J.seq_off;
     const int n = J.n, m = J.m;
@@ -601,6 +607,7 @@ struct pa_realigner {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DBuf d_ref, d_seq, d_jobs, d_dir, d_ops, d_counter;
+    pa_enc::HBuf h_meta, h_back;                                 // device-fed form: window text + tables up, counters back
     std::vector<Job> jobs;
     std::vector<uint32_t> ops;
     int64_t total_ops = 0;
@@ -758,10 +765,10 @@ int pa_realigner_align_windows(pa_realigner* r, int32_t n_windows, const char* r
         RA_HIP(hipEventRecord(r->ev[0], r->stream));
         // the instantiation whose register strip just covers the longest read of the call (fewer registers: more wavefronts
         // per SIMD); a read beyond 24 rows per lane takes the LDS form inside the widest one
-        if (R <= 12) hipLaunchKernelGGL(sw_ends_kernel<12>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq);
-        else if (R <= 16) hipLaunchKernelGGL(sw_ends_kernel<16>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq);
-        else if (R <= 20) hipLaunchKernelGGL(sw_ends_kernel<20>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq);
-        else hipLaunchKernelGGL(sw_ends_kernel<24>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq);
+        if (R <= 12) hipLaunchKernelGGL(sw_ends_kernel<12>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
+        else if (R <= 16) hipLaunchKernelGGL(sw_ends_kernel<16>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
+        else if (R <= 20) hipLaunchKernelGGL(sw_ends_kernel<20>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
+        else hipLaunchKernelGGL(sw_ends_kernel<24>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
         RA_HIP(hipGetLastError());
         RA_HIP(hipEventRecord(r->ev[1], r->stream));
     }
@@ -886,3 +893,324 @@ int pa_realigner_copy_cigars(pa_realigner* r, int32_t collapse_eqx, int64_t* cig
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The device-fed form (encoder_common.h, pa_ra::align_device / apply_device): the reads are where unpack_clip_kernel left
+// them (ReadRec table, bases as text), the job table is built and the band stage laid out by kernels, and the results --
+// job table and compacted operations -- stay on the device for the summary encoder.  One wait for the common case (counters
+// after the first band launch); reads whose band outgrows the first rows (half width > 64) go through the host-laid-out
+// rounds of pa_realigner_align_windows afterwards.
+namespace {
+
+enum { DC_TOO_LONG = 0, DC_BAD = 1, DC_UNFINISHED = 2, DC_ERR = 3, DC_ALIGNED = 4, DC_N = 8 };     // int32 counters; [6..7] = dir bytes (u64)
+
+// one wave per read: its kept bases (text) -> codes at the same offsets
+__global__ __launch_bounds__(256) void codes_of_reads_kernel(const pa_enc::ReadRec* __restrict__ reads, int n_reads,
+                                                             const char* __restrict__ text, int8_t* __restrict__ codes) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= n_reads) return;
+    const pa_enc::ReadRec rd = reads[k];
+    if (!(rd.flags & pa_enc::READ_MAPQ_OK)) return;
+    for (int i = lane; i < rd.slen; i += 64) {
+        const int c = text[rd.s0 + i] & 0xdf;
+        codes[rd.s0 + i] = (int8_t)(c == 'A' || c == 'U' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4);
+    }
+}
+
+__global__ __launch_bounds__(256) void jobs_of_reads_kernel(const pa_enc::ReadRec* __restrict__ reads, int n_reads,
+                                                            const int64_t* __restrict__ window_off, const int32_t* __restrict__ window_len,
+                                                            Job* __restrict__ jobs, int* __restrict__ counters, int max_m) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_reads) return;
+    const pa_enc::ReadRec rd = reads[k];
+    Job J;
+    J.ref_off = 0; J.n = 0; J.m = rd.slen; J.state = ST_KEPT; J.seq_off = rd.s0;
+    J.score = 0; J.wide = 0; J.ref_begin = -1; J.ref_end = 0; J.read_begin = -1; J.read_end = 0;
+    J.bw = 0; J.dir_width = 0; J.dir_off = 0; J.ops_off = 0; J.ops_cap = 0; J.n_ops = 0;
+    J.t_ends = J.t_dp = J.t_trace = J.t_emit = 0;
+    if ((rd.flags & pa_enc::READ_MAPQ_OK) && rd.slen > 0) {      // (a read the summary skips is not aligned: nothing reads its CIGAR)
+        const int wl = window_len[rd.region], off = rd.row0;
+        if (off < 0) J.state = ST_DROPPED;                          // simple_aligner.cpp:72-76 (a clipped read never starts there)
+        else if (off > wl) atomicMax(&counters[DC_BAD], k + 1);
+        else if (rd.slen > max_m) atomicMax(&counters[DC_TOO_LONG], k + 1);
+        else {
+            J.ref_off = (int32_t)(window_off[rd.region] + off);
+            J.n = wl - off;
+            if (J.n > 0) J.state = ST_NEW;
+        }
+    }
+    jobs[k] = J;
+}
+
+// what the host does between the two stages (pa_realigner_align_windows): which reads go on, their first band, their slice of
+// the direction workspace (rows of at most 129 slots: half width <= 64)
+__global__ __launch_bounds__(256) void band_layout_kernel(Job* __restrict__ jobs, int n_reads, int* __restrict__ counters,
+                                                          unsigned long long dir_capacity) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_reads) return;
+    Job& J = jobs[k];
+    if (J.state != ST_NEW) return;
+    if (J.score <= 1 || J.ref_begin < 0) { J.state = ST_KEPT; return; }      // simple_aligner.cpp:85
+    const int n2 = J.ref_end - J.ref_begin + 1, m2 = J.read_end - J.read_begin + 1;
+    J.bw = abs(n2 - m2) + 1;
+    J.ops_cap = n2 + m2 + 4;
+    J.dir_width = min(n2, 129);
+    bool wider = min(2 * J.bw + 1, n2) > J.dir_width;                         // the first band is wider already
+    if (!wider) {
+        const unsigned long long need = (unsigned long long)m2 * J.dir_width * BAND_WAVES;
+        const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(counters + 6), need);
+        if (at + need > dir_capacity) wider = true;
+        else J.dir_off = (int64_t)at;
+    }
+    J.state = wider ? ST_WIDER : ST_BAND;
+}
+
+// after the band launch: reads still to be done (their band outgrew the first rows), failed, aligned
+__global__ __launch_bounds__(256) void count_states_kernel(const Job* __restrict__ jobs, int n_reads, int* __restrict__ counters) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int state = k < n_reads ? jobs[k].state : ST_KEPT;
+    const unsigned long long more = __ballot(state == ST_WIDER || state == ST_BAND), err = __ballot(state == ST_ERR),
+                             done = __ballot(state == ST_DONE);
+    if ((threadIdx.x & 63) == 0) {
+        if (more) atomicAdd(&counters[DC_UNFINISHED], __popcll(more));
+        if (err) atomicAdd(&counters[DC_ERR], __popcll(err));
+        if (done) atomicAdd(&counters[DC_ALIGNED], __popcll(done));
+    }
+}
+
+// one wave per newly aligned read: its operations decoded behind the batch's CIGAR arrays, the ReadRec pointed there
+__global__ __launch_bounds__(256) void apply_alignment_kernel(const Job* __restrict__ jobs, const uint32_t* __restrict__ ops,
+                                                              pa_enc::ReadRec* __restrict__ reads, int n_reads,
+                                                              int32_t* __restrict__ cigar_op, int32_t* __restrict__ cigar_len,
+                                                              long long ops_base, int collapse_eqx) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= n_reads) return;
+    const Job& J = jobs[k];
+    if (J.state != ST_DONE || J.n_ops <= 0) return;                           // (an empty CIGAR leaves the read as it was: simple_aligner.cpp:96)
+    const long long at = ops_base + J.ops_off;
+    for (int i = lane; i < J.n_ops; i += 64) {
+        const uint32_t w = ops[J.ops_off + i];
+        int op = (int)(w & 15u);
+        if (collapse_eqx && (op == OP_EQ || op == OP_X)) op = 0;
+        cigar_op[at + i] = op;
+        cigar_len[at + i] = (int32_t)(w >> 4);
+    }
+    if (lane == 0) {
+        pa_enc::ReadRec& rd = reads[k];
+        rd.row0 += J.ref_begin;
+        rd.c0 = (int32_t)at;
+        rd.ncig = J.n_ops;
+    }
+}
+
+// the band rounds laid out by the host over r->jobs (states ST_BAND / ST_WIDER pending): round 0 with rows of at most 129 slots,
+// later rounds with full rows; dj holds the table on the device before and after
+int band_rounds_host(pa_realigner* r, Job* dj, const int8_t* dref, const int8_t* dseq, int32_t n_reads, int first_round, int aux) {
+    for (int round = first_round; round < 3; ++round) {
+        int64_t dir_total = 0;
+        int cap = 0, pending = 0;
+        for (Job& J : r->jobs) {
+            if (J.state == ST_WIDER) J.state = ST_BAND;
+            if (J.state != ST_BAND) continue;
+            const int n2 = J.ref_end - J.ref_begin + 1, m2 = J.read_end - J.read_begin + 1;
+            J.dir_width = round == 0 ? std::min(n2, 129) : n2;
+            if (round == 0 && std::min(2 * J.bw + 1, n2) > J.dir_width) J.dir_width = n2;   // first band already wider
+            J.dir_off = dir_total;
+            dir_total += (int64_t)m2 * J.dir_width * BAND_WAVES;
+            const int bw_cap = J.dir_width >= n2 ? INT32_MAX / 4 : (J.dir_width - 1) / 2;
+            cap = std::max(cap, (int)std::min<int64_t>(2 * (int64_t)bw_cap + 3, n2 + 2) + 2);
+            ++pending;
+        }
+        if (!pending) break;
+        const size_t lds = (size_t)cap * 12 * BAND_WAVES + (size_t)aux + 64;
+        if (lds > 150 * 1024) return pa::set_error(PA_ERR_INVALID, "alignment too long for the band stage");
+        RA_ALLOC(r->d_dir, (size_t)std::max<int64_t>(dir_total, 1));
+        RA_HIP(hipMemcpyAsync(dj, r->jobs.data(), sizeof(Job) * (size_t)n_reads, hipMemcpyHostToDevice, r->stream));
+        if (lds > 64 * 1024)
+            RA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+        RA_HIP(hipEventRecord(r->ev[2], r->stream));
+        hipLaunchKernelGGL(band_kernel, dim3(n_reads), dim3(64 * BAND_WAVES), lds, r->stream, dj, dref, dseq,
+                           static_cast<uint8_t*>(r->d_dir.p), static_cast<uint32_t*>(r->d_ops.p),
+                           static_cast<unsigned long long*>(r->d_counter.p), cap);
+        RA_HIP(hipGetLastError());
+        RA_HIP(hipEventRecord(r->ev[3], r->stream));
+        RA_HIP(hipMemcpyAsync(r->jobs.data(), dj, sizeof(Job) * (size_t)n_reads, hipMemcpyDeviceToHost, r->stream));
+        RA_HIP(hipStreamSynchronize(r->stream));
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r->ev[2], r->ev[3]) == hipSuccess) r->band_ms += ms;
+    }
+    return PA_OK;
+}
+
+}  // namespace
+
+int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window_bytes, const int64_t* window_off,
+                        const int32_t* window_len, int32_t n_windows, const pa_enc::ReadRec* d_reads, int32_t n_reads, const char* d_seq,
+                        int64_t seq_bytes, int32_t max_region_len, DeviceResult* out) {
+    if (!r || !out || n_reads < 0 || n_windows < 0 || window_bytes < 0 || seq_bytes < 0 ||
+        (n_reads > 0 && (!window_text || !window_off || !window_len || !d_reads || !d_seq || n_windows <= 0)))
+        return pa::set_error(PA_ERR_INVALID, "null argument");
+    if (window_bytes > (int64_t)1 << 30) return pa::set_error(PA_ERR_INVALID, "reference windows too long");
+    RA_HIP(hipSetDevice(r->device));
+    *out = DeviceResult();
+    r->jobs.clear();
+    r->ops.clear();
+    r->total_ops = 0;
+    r->ends_ms = r->band_ms = 0.0;
+    r->cells = 0;
+    if (n_reads == 0) return PA_OK;
+    hipStream_t st = r->stream;
+    int max_wl = 0;
+    for (int32_t w = 0; w < n_windows; ++w) {
+        if (window_len[w] < 0 || window_off[w] < 0 || window_off[w] + window_len[w] > window_bytes)
+            return pa::set_error(PA_ERR_INVALID, "window " + std::to_string(w) + " lies outside the window text");
+        max_wl = std::max(max_wl, window_len[w]);
+    }
+    // a clipped read holds the aligned bases of its region and the inserts between them; beyond 2 L + 64 bases (and beyond the
+    // kernels' 14-bit cell fields) the call is refused and the caller takes the host-fed form
+    const int max_m = std::min(MAX_READ, 2 * std::max(max_region_len, 1) + 64);
+    // [window text -> codes][window_off][window_len] in one page-locked block, one upload
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_off = up16((size_t)window_bytes + 64), o_len = up16(o_off + (size_t)n_windows * 8), meta = up16(o_len + (size_t)n_windows * 4);
+    if (!r->h_meta.ensure(meta) || !r->h_back.ensure(256)) return pa::set_error(PA_ERR_HIP, "hipHostMalloc failed");
+    char* hm = static_cast<char*>(r->h_meta.p);
+    std::memcpy(hm, window_text, (size_t)window_bytes);
+    std::memcpy(hm + o_off, window_off, (size_t)n_windows * 8);
+    std::memcpy(hm + o_len, window_len, (size_t)n_windows * 4);
+    RA_ALLOC(r->d_ref, meta);
+    RA_ALLOC(r->d_seq, (size_t)seq_bytes + 64);
+    RA_ALLOC(r->d_jobs, sizeof(Job) * (size_t)n_reads);
+    RA_ALLOC(r->d_counter, 8 + DC_N * 4);
+    // operations: a read's worst case is n2 + m2 + 4 <= its window + its bases + 4
+    const int64_t ops_cap_total = seq_bytes + (int64_t)n_reads * (max_wl + 4);
+    RA_ALLOC(r->d_ops, sizeof(uint32_t) * (size_t)std::max<int64_t>(ops_cap_total, 1));
+    // direction bytes of the first rows (<= 129 slots): what the reads of a region at ordinary length need; what does not fit
+    // there is laid out by the host afterwards
+    const unsigned long long dir_capacity = std::min<unsigned long long>((unsigned long long)n_reads * (unsigned long long)(max_region_len + 64) *
+                                                                             129ull * BAND_WAVES, 24ull << 30);
+    RA_ALLOC(r->d_dir, (size_t)std::max<unsigned long long>(dir_capacity, 1));
+    RA_HIP(hipMemcpyAsync(r->d_ref.p, hm, meta, hipMemcpyHostToDevice, st));
+    RA_HIP(hipMemsetAsync(r->d_counter.p, 0, 8 + DC_N * 4, st));
+    int8_t* dref = static_cast<int8_t*>(r->d_ref.p);
+    const int64_t* d_woff = reinterpret_cast<const int64_t*>(dref + o_off);
+    const int32_t* d_wlen = reinterpret_cast<const int32_t*>(dref + o_len);
+    int8_t* dseq = static_cast<int8_t*>(r->d_seq.p);
+    Job* dj = static_cast<Job*>(r->d_jobs.p);
+    unsigned long long* d_opsctr = static_cast<unsigned long long*>(r->d_counter.p);
+    int* d_ctr = reinterpret_cast<int*>(d_opsctr + 1);
+    if (window_bytes > 0)
+        hipLaunchKernelGGL(to_codes_kernel, dim3((unsigned)((window_bytes + 255) / 256)), dim3(256), 0, st, dref, window_bytes);
+    hipLaunchKernelGGL(codes_of_reads_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, d_reads, n_reads, d_seq, dseq);
+    hipLaunchKernelGGL(jobs_of_reads_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, d_reads, n_reads, d_woff, d_wlen, dj,
+                       d_ctr, max_m);
+    RA_HIP(hipEventRecord(r->ev[0], st));
+    {
+        // every instantiation over the whole table: a read runs in the narrowest register strip that holds it (two wavefronts per
+        // SIMD up to 20 rows per lane); LDS for the rows beyond the widest strip
+        const int rows = ((max_m + 15) / 16) * 16, R = (rows + 63) / 64;
+        const size_t lds = rows > REG_ROWS ? (size_t)64 * R * 4 : 0;
+        hipLaunchKernelGGL(sw_ends_kernel<12>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 0, 12);
+        hipLaunchKernelGGL(sw_ends_kernel<16>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 12, 16);
+        hipLaunchKernelGGL(sw_ends_kernel<20>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 16, 20);
+        hipLaunchKernelGGL(sw_ends_kernel<24>, dim3(n_reads), dim3(64), lds, st, dj, dref, dseq, 20, 1 << 30);
+        RA_HIP(hipGetLastError());
+    }
+    RA_HIP(hipEventRecord(r->ev[1], st));
+    hipLaunchKernelGGL(band_layout_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, dj, n_reads, d_ctr, dir_capacity);
+    const int aux = 3 * (max_wl + max_m) + 4;
+    {
+        const int cap = std::min(2 * 64 + 3, max_wl + 2) + 2;
+        const size_t lds = (size_t)cap * 12 * BAND_WAVES + (size_t)aux + 64;
+        if (lds > 150 * 1024) return pa::set_error(PA_ERR_INVALID, "alignment too long for the band stage");
+        if (lds > 64 * 1024)
+            RA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RA_HIP(hipEventRecord(r->ev[2], st));
+        hipLaunchKernelGGL(band_kernel, dim3(n_reads), dim3(64 * BAND_WAVES), lds, st, dj, dref, dseq, static_cast<uint8_t*>(r->d_dir.p),
+                           static_cast<uint32_t*>(r->d_ops.p), d_opsctr, cap);
+        RA_HIP(hipGetLastError());
+        RA_HIP(hipEventRecord(r->ev[3], st));
+    }
+    hipLaunchKernelGGL(count_states_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, dj, n_reads, d_ctr);
+    int* back = static_cast<int*>(r->h_back.p);
+    RA_HIP(hipMemcpyAsync(back, r->d_counter.p, 8 + DC_N * 4, hipMemcpyDeviceToHost, st));
+    RA_HIP(hipStreamSynchronize(st));
+    {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r->ev[0], r->ev[1]) == hipSuccess) r->ends_ms = ms;
+        if (hipEventElapsedTime(&ms, r->ev[2], r->ev[3]) == hipSuccess) r->band_ms = ms;
+    }
+    const int* ctr = back + 2;
+    if (ctr[DC_BAD] > 0) return pa::set_error(PA_ERR_INVALID, "read " + std::to_string(ctr[DC_BAD] - 1) + " starts beyond the reference window");
+    if (ctr[DC_TOO_LONG] > 0)
+        return pa::set_error(PA_ERR_UNSUPPORTED, "read " + std::to_string(ctr[DC_TOO_LONG] - 1) + " keeps more than " + std::to_string(max_m) +
+                                                     " bases of its region (take the host-fed form for this batch)");
+    out->n_aligned = ctr[DC_ALIGNED];
+    // reads whose band left the first rows (ST_WIDER: from the layout or from the band kernel's doubling), and -- never, unless a
+    // kernel is wrong -- a band that found nothing (ST_ERR): the table comes to the host and the remaining rounds run as in
+    // pa_realigner_align_windows, with full rows
+    if (ctr[DC_UNFINISHED] > 0 || ctr[DC_ERR] > 0) {
+        const bool more = ctr[DC_UNFINISHED] > 0;
+        r->jobs.resize((size_t)n_reads);
+        RA_HIP(hipMemcpyAsync(r->jobs.data(), dj, sizeof(Job) * (size_t)n_reads, hipMemcpyDeviceToHost, st));
+        RA_HIP(hipStreamSynchronize(st));
+        if (more) {
+            const int rc = band_rounds_host(r, dj, dref, dseq, n_reads, 1, aux);
+            if (rc != PA_OK) return rc;
+        }
+        int aligned = 0;
+        for (int32_t k = 0; k < n_reads; ++k) {
+            const Job& J = r->jobs[(size_t)k];
+            if (J.state == ST_ERR || J.state == ST_BAND || J.state == ST_WIDER)
+                return pa::set_error(PA_ERR_INVALID, "read " + std::to_string(k) + ": the band stage did not reach the alignment score "
+                                     "(the reference library aborts on such an alignment)");
+            aligned += J.state == ST_DONE;
+        }
+        out->n_aligned = aligned;
+        r->jobs.clear();
+        RA_HIP(hipMemcpyAsync(back, r->d_counter.p, 8, hipMemcpyDeviceToHost, st));
+        RA_HIP(hipStreamSynchronize(st));
+    }
+    static const bool trace = getenv("PA_REALIGN_TRACE") != nullptr;      // what the band stage needed, on stderr
+    if (trace) {
+        std::vector<Job> jj((size_t)n_reads);
+        RA_HIP(hipMemcpyAsync(jj.data(), dj, sizeof(Job) * (size_t)n_reads, hipMemcpyDeviceToHost, st));
+        RA_HIP(hipStreamSynchronize(st));
+        long hist_bw[12] = {0}, hist_att[12] = {0}, n_done = 0, n_kept = 0;
+        double t_ends = 0, t_dp = 0, t_trace = 0, t_emit = 0;
+        for (const Job& J : jj) {
+            if (J.state != ST_DONE) { n_kept += 1; continue; }
+            ++n_done;
+            const int n2 = J.ref_end - J.ref_begin + 1, m2 = J.read_end - J.read_begin + 1, base = std::abs(n2 - m2) + 1;
+            int a = 0, b = 0;
+            while ((base << a) < J.bw && a < 11) ++a;
+            while ((1 << b) < J.bw && b < 11) ++b;
+            hist_att[a]++; hist_bw[b]++;
+            t_ends += J.t_ends; t_dp += J.t_dp; t_trace += J.t_trace; t_emit += J.t_emit;
+        }
+        fprintf(stderr, "[realign-device] reads %d aligned %ld other %ld | score %.3f ms band %.3f ms | winning attempt:", n_reads, n_done, n_kept,
+                r->ends_ms, r->band_ms);
+        for (int k = 0; k < 12; ++k) fprintf(stderr, " %ld", hist_att[k]);
+        fprintf(stderr, " | log2(bw):");
+        for (int k = 0; k < 12; ++k) fprintf(stderr, " %ld", hist_bw[k]);
+        if (n_done) fprintf(stderr, " | per read us: ends %.1f dp %.1f trace %.1f emit %.1f", t_ends / n_done / 100, t_dp / n_done / 100, t_trace / n_done / 100, t_emit / n_done / 100);
+        fprintf(stderr, "\n");
+    }
+    out->jobs = dj;
+    out->ops = static_cast<const uint32_t*>(r->d_ops.p);
+    out->ops_written = (int64_t)*reinterpret_cast<unsigned long long*>(back);
+    if (out->ops_written > ops_cap_total) return pa::set_error(PA_ERR_HIP, "re-aligner: more operations than the output holds");
+    return PA_OK;
+}
+
+int pa_ra::apply_device(pa_realigner* r, pa_enc::ReadRec* d_reads, int32_t n_reads, int32_t* cigar_op, int32_t* cigar_len,
+                        int64_t ops_base, int32_t collapse_eqx) {
+    if (!r || n_reads < 0 || (n_reads > 0 && (!d_reads || !cigar_op || !cigar_len || !r->d_jobs.p || !r->d_ops.p)))
+        return pa::set_error(PA_ERR_INVALID, "null argument");
+    if (n_reads == 0) return PA_OK;
+    RA_HIP(hipSetDevice(r->device));
+    hipLaunchKernelGGL(apply_alignment_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, r->stream, static_cast<const Job*>(r->d_jobs.p),
+                       static_cast<const uint32_t*>(r->d_ops.p), d_reads, n_reads, cigar_op, cigar_len, (long long)ops_base, (int)collapse_eqx);
+    RA_HIP(hipGetLastError());
+    return PA_OK;
+}

@@ -55,6 +55,8 @@ SYMBOLS = [
     ("pa_h5_builder_write_string", ctypes.c_int, [c_void_p, c_char_p, c_char_p]),
     ("pa_h5_builder_write_polish_image_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32, c_char_p, c_int64, c_int64] +
                                                                [c_void_p] * 5),
+    ("pa_h5_builder_write_polish_image_regions", ctypes.c_int, [c_void_p, c_int32, c_char_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32] +
+                                                                [c_void_p] * 4),
     ("pa_h5_builder_write_variant_summary", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_char_p] + [c_void_p] * 6 + [c_int32, c_int32]),
     ("pa_h5_builder_close", ctypes.c_int, [c_void_p]),
     ("pa_h5_write_prediction_batch", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
@@ -149,6 +151,17 @@ class PredictionBuilder(object):
         _check(self._lib.pa_h5_builder_write_polish_image_chunks(
             self._h, blob, n, seq_len, features, contig.encode(), int(region_start), int(region_end), chunk_id.ctypes.data,
             images.ctypes.data, labels.ctypes.data, position.ctypes.data, index.ctypes.data))
+
+    def write_polish_image_regions(self, contig, region_start, region_end, n_chunks, seq_len, features, images, position, index):
+        """The chunks of many regions of one contig in one call (pa_h5_builder_write_polish_image_regions): region r has
+        n_chunks[r] consecutive chunks in images (address of uint8 [*, seq_len, features]) / position / index (addresses of
+        int64 [*, seq_len]); labels are zeros.  The three are raw addresses: the image chain's page-locked blocks."""
+        region_start = np.ascontiguousarray(region_start, np.int64)
+        region_end = np.ascontiguousarray(region_end, np.int64)
+        n_chunks = np.ascontiguousarray(n_chunks, np.int32)
+        _check(self._lib.pa_h5_builder_write_polish_image_regions(
+            self._h, len(n_chunks), contig.encode(), region_start.ctypes.data, region_end.ctypes.data, n_chunks.ctypes.data,
+            int(seq_len), int(features), images, None, position, index))
 
     def write_variant_summary(self, name, contig, positions, depths, candidates, freqs, images):
         """One summaries/<name> group of a variant image file (pa_h5_builder_write_variant_summary): positions int32 [n], depths

@@ -68,3 +68,25 @@ class DataStore(object):
             images, labels, np.ascontiguousarray(positions[:, :, 0], dtype=np.int64),
             np.ascontiguousarray(positions[:, :, 1], dtype=np.int64))
 
+    def write_regions(self, contig_name, region_starts, region_ends, n_chunks, seq_len, features, images, position, index):
+        """The chunks of many regions of one contig as the image chain leaves them (pa_polish_chain_chunks: raw addresses of
+        uint8 [*, seq_len, features] and int64 [*, seq_len] blocks, region after region, chunk ids 0 .. n_chunks[r] - 1):
+        the groups write_summary would make for each of them, in one library call."""
+        if hasattr(self.file_handler, "write_polish_image_regions"):
+            self.file_handler.write_polish_image_regions(str(contig_name), region_starts, region_ends, n_chunks, seq_len, features,
+                                                         images, position, index)
+            return
+        import ctypes
+        total = int(np.sum(n_chunks))
+        if total == 0:
+            return
+        img = np.ctypeslib.as_array(ctypes.cast(images, ctypes.POINTER(ctypes.c_uint8)), shape=(total, seq_len, features))
+        pos = np.ctypeslib.as_array(ctypes.cast(position, ctypes.POINTER(ctypes.c_int64)), shape=(total, seq_len))
+        idx = np.ctypeslib.as_array(ctypes.cast(index, ctypes.POINTER(ctypes.c_int64)), shape=(total, seq_len))
+        at = 0
+        for a, b, k in zip(region_starts, region_ends, n_chunks):
+            k = int(k)
+            if k:
+                self.write_summaries((contig_name, int(a), int(b)), img[at:at + k], np.zeros((k, seq_len), np.uint8),
+                                     np.stack([pos[at:at + k], idx[at:at + k]], axis=2), list(range(k)))
+            at += k

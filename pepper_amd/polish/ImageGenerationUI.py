@@ -11,6 +11,7 @@ import os
 import re
 import sys
 import time
+import threading
 from concurrent.futures import ThreadPoolExecutor
 from datetime import datetime
 
@@ -19,6 +20,9 @@ from pepper_amd.polish.DataStore import DataStore
 from pepper_amd.polish.Options import ImageSizeOptions
 from pepper_amd.variant.bam import BAM_handler
 from pepper_amd.variant.fasta import FASTA_handler
+
+
+_STATS_LOCK = threading.Lock()
 
 
 def _log(message):
@@ -50,9 +54,23 @@ class UserInterfaceView:
         return AlignmentSummarizer.create_summaries(summarizers)
 
 
+def parse_device_ids(device_ids):
+    """`device_ids` as the reference's callers give it ("0,1,2", call_consensus.py:60-66), a list, or None -> [0]."""
+    if device_ids is None or device_ids == "":
+        return [0]
+    if isinstance(device_ids, str):
+        return [int(d) for d in device_ids.split(",") if d.strip() != ""] or [0]
+    if isinstance(device_ids, int):
+        return [device_ids]
+    return [int(d) for d in device_ids] or [0]
+
+
 class UserInterfaceSupport:
     # intervals whose reads share one re-alignment call on the GPU (PEPPER_AMD_POLISH_REGIONS_PER_CALL)
     REGIONS_PER_CALL = int(os.environ.get("PEPPER_AMD_POLISH_REGIONS_PER_CALL", 32))
+    # intervals per call of the device-resident chain (PEPPER_AMD_POLISH_CHAIN_REGIONS): ~64 reads each at 60x, so 128 of them
+    # are ~8 000 re-alignments per launch -- several wavefronts per SIMD
+    CHAIN_REGIONS = int(os.environ.get("PEPPER_AMD_POLISH_CHAIN_REGIONS", 128))
 
     @staticmethod
     def handle_output_directory(output_directory):
@@ -126,6 +144,147 @@ class UserInterfaceSupport:
         return images, labels, positions, image_chunk_ids, (chr_name, _start, _end)
 
     @staticmethod
+    def chain_generator(args, all_intervals, total_threads, thread_id, device, stats=None):
+        """image_generator through the device-resident chain (PEPPER.PolishChain): per run of consecutive intervals ONE call of
+        the BAM reader's packed form (the file's BGZF members inflated and walked on the device) and ONE of the chain (clip,
+        re-align, summarise, cut into chunks on the device), then one call of the image writer.  Intervals the chain does not
+        take -- more than MAX_READS_IN_REGION reads (the reservoir sample is drawn in read order on the host), a record with
+        its CIGAR in the CG tag, a read that keeps more bases than a pair's slot -- go through parse_regions as before."""
+        import numpy as np
+        from pepper_amd import _lib
+        from pepper_amd.polish import PEPPER
+        from pepper_amd.polish.AlignmentSummarizer import AlingerOptions
+        from pepper_amd.variant.PEPPER_VARIANT import PackedEncoder
+        output_path, bam_file, draft_file, truth_bam, train_mode, downsample_rate = args
+        timestr = time.strftime("%m%d%Y_%H%M%S")
+        file_name = output_path + "pepper_hp_images_thread_" + str(thread_id) + "_" + str(timestr) + ".hdf"
+        batch = max(1, UserInterfaceSupport.CHAIN_REGIONS)
+        run = max(1, min(batch, -(-len(all_intervals) // max(1, total_threads * 2))))
+        intervals = [r for i, r in enumerate(all_intervals) if (i // run) % total_threads == thread_id]
+        if thread_id == 0:
+            _log("INFO: STARTING THREAD: " + str(thread_id) + " FOR " + str(len(intervals)) + " INTERVALS")
+        start_time = time.time()
+        mine = {}
+
+        def lap(key, t0):
+            now = time.perf_counter()
+            mine[key] = mine.get(key, 0.0) + now - t0
+            return now
+
+        enc = PackedEncoder.acquire(device, int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20, host_threads=1)
+        chain = PEPPER.PolishChain(enc)
+        device_inflate = os.environ.get("PEPPER_AMD_DEVICE_INFLATE", "1") != "0"
+        safe = AlingerOptions.ALIGNMENT_SAFE_BASES
+        seq_len, features = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+        views = {}
+        handles = {}
+        try:
+            with DataStore(file_name, 'w') as output_hdf_file:
+                def host_form(chr_name, block):
+                    """parse_regions (host-clipped reads, host arrays between the stages) for the intervals of `block`."""
+                    key = (chr_name, bam_file, draft_file)
+                    if key not in views:
+                        views.clear()
+                        views[key] = UserInterfaceView(chr_name, bam_file, draft_file, truth_bam, train_mode)
+                    for g0 in range(0, len(block), UserInterfaceSupport.REGIONS_PER_CALL):
+                        part = block[g0:g0 + UserInterfaceSupport.REGIONS_PER_CALL]
+                        results = views[key].parse_regions([(a, b) for _, a, b in part], downsample_rate)
+                        for region, (images, labels, positions, chunk_ids) in zip(part, results):
+                            if len(images):
+                                output_hdf_file.write_summaries(region, images, labels, positions, chunk_ids)
+
+                counter = 0
+                while counter < len(intervals):
+                    chr_name = intervals[counter][0]
+                    g1 = counter + 1
+                    # ADJACENT intervals of one contig, ascending (the packer walks every record between the first and the last one)
+                    while (g1 < len(intervals) and g1 - counter < batch and intervals[g1][0] == chr_name
+                           and intervals[g1 - 1][1] <= intervals[g1][1] <= intervals[g1 - 1][2] + 1
+                           and intervals[g1][2] >= intervals[g1 - 1][2]):
+                        g1 += 1
+                    block = intervals[counter:g1]
+                    if chr_name not in handles:
+                        handles.clear()
+                        handles[chr_name] = (BAM_handler(bam_file), FASTA_handler(draft_file))
+                    bam_handler, fasta_handler = handles[chr_name]
+                    starts, stops = [a for _, a, _ in block], [b for _, _, b in block]
+                    t0 = time.perf_counter()
+                    on_device = enc.pack_device(bam_handler, chr_name, starts, stops, False, 0, laps=mine) if device_inflate else None
+                    resident = on_device is not None
+                    n_done = 0
+                    if resident:
+                        n_done, region_pairs, counts = on_device
+                    else:
+                        try:
+                            n_done, region_pairs, counts = enc.pack(bam_handler, chr_name, starts, stops, False, 0)
+                        except Exception as err:
+                            if getattr(err, "code", 0) != -7:      # (-7: one interval's reads outgrow the arena)
+                                raise
+                    t0 = lap("bam_pack", t0)
+                    if n_done == 0:
+                        host_form(chr_name, block[:1])
+                        counter += 1
+                        continue
+                    block, starts, stops = block[:n_done], starts[:n_done], stops[:n_done]
+                    region_pairs = np.asarray(region_pairs[:n_done + 1], np.int32)
+                    per_region = np.diff(region_pairs)
+                    deep = np.flatnonzero(per_region > AlingerOptions.MAX_READS_IN_REGION)
+                    if len(deep):
+                        # a pile beyond the reference's cap is sampled down in read order (AlignmentSummarizer.py:314-326): on the
+                        # host; the chain sees those intervals without reads and their chunks come from host_form below
+                        keep = np.ones(int(region_pairs[-1]), bool)
+                        for r in deep:
+                            keep[region_pairs[r]:region_pairs[r + 1]] = False
+                        kept = enc.pair_read[:int(region_pairs[-1])][keep]
+                        enc.pair_read[:len(kept)] = kept
+                        per_region = per_region.copy()
+                        per_region[deep] = 0
+                        region_pairs = np.concatenate([[0], np.cumsum(per_region)]).astype(np.int32)
+                        counts = (counts[0], int(region_pairs[-1]), counts[2])
+                    lo = starts[0]
+                    whole = fasta_handler.get_reference_bytes(chr_name, lo, max(stops) + safe + 1)
+                    windows = [whole[a - lo:b + safe + 1 - lo] for a, b in zip(starts, stops)]
+                    t0 = lap("fasta", t0)
+                    try:
+                        _rows, _live, chunks = chain.run(list(zip(starts, stops)), windows, region_pairs, counts, realign=True,
+                                                         resident=resident, chunk_size=seq_len, chunk_overlap=ImageSizeOptions.SEQ_OVERLAP)
+                    except _lib.PepperAmdError as err:
+                        if getattr(err, "code", 0) != _lib.PA_ERR_UNSUPPORTED:
+                            raise
+                        host_form(chr_name, block)
+                        counter += n_done
+                        continue
+                    t0 = lap("chain", t0)
+                    for key, v in chain.timing().items():
+                        if key.endswith("_ms"):
+                            mine["chain_" + key[:-3]] = mine.get("chain_" + key[:-3], 0.0) + v / 1e3
+                        else:
+                            mine[key] = mine.get(key, 0) + v
+                    img, pos, idx = chain.chunk_pointers()
+                    output_hdf_file.write_regions(chr_name, starts, stops, chunks, seq_len, features, img, pos, idx)
+                    t0 = lap("hdf5", t0)
+                    if len(deep):
+                        host_form(chr_name, [block[r] for r in deep])
+                        lap("deep_host_form", t0)
+                    before = counter
+                    counter += n_done
+                    if thread_id == 0 and counter // 1000 > before // 1000:
+                        elapsed = int(time.time() - start_time)
+                        _log("INFO: [THREAD " + "{:02d}".format(thread_id) + "] " + str(counter) + "/" + str(len(intervals))
+                             + " COMPLETE (" + str(int(100 * counter / len(intervals))) + "%) [ELAPSED TIME: "
+                             + str(elapsed // 60) + " Min " + str(elapsed % 60) + " Sec]")
+                t_close = time.perf_counter()
+            lap("close", t_close)
+        finally:
+            enc.inflate_ms, enc.inflated_bytes = 0.0, 0
+            enc.release()
+        if stats is not None:
+            with _STATS_LOCK:
+                for key, v in mine.items():
+                    stats[key] = stats.get(key, 0.0) + v
+        return thread_id
+
+    @staticmethod
     def image_generator(args, all_intervals, total_threads, thread_id):
         output_path, bam_file, draft_file, truth_bam, train_mode, downsample_rate = args
         timestr = time.strftime("%m%d%Y_%H%M%S")
@@ -187,18 +346,33 @@ class UserInterfaceSupport:
         return contigs, all_intervals
 
     @staticmethod
+    def worker_device(device_ids, thread_id):
+        """Worker t works on device_ids[t % n] (the reference's callers give device_ids to call_consensus only,
+        call_consensus.py:60-66; its image generation is CPU work)."""
+        ids = parse_device_ids(device_ids)
+        return ids[thread_id % len(ids)]
+
+    @staticmethod
     def chromosome_level_parallelization(chr_list, bam_file, draft_file, truth_bam, output_path, total_threads, train_mode,
-                                         downsample_rate=1.0):
+                                         downsample_rate=1.0, device_ids=None, stats=None):
         if train_mode:
             raise NotImplementedError("train_mode image generation is outside the inference path")
         contigs, all_intervals = UserInterfaceSupport.make_intervals(chr_list, draft_file)
         _log("INFO: TOTAL CONTIGS: " + str(len(contigs)) + " TOTAL INTERVALS: " + str(len(all_intervals)))
         args = (output_path, bam_file, draft_file, truth_bam, train_mode, downsample_rate)
+        # the device-resident chain is the default; PEPPER_AMD_POLISH_CHAIN=0: host arrays between the stages (round 4's form,
+        # device 0 only)
+        chain = os.environ.get("PEPPER_AMD_POLISH_CHAIN", "1") != "0" and downsample_rate >= 1.0
+
+        def work(thread_id, n):
+            if chain:
+                return UserInterfaceSupport.chain_generator(args, all_intervals, n, thread_id,
+                                                            UserInterfaceSupport.worker_device(device_ids, thread_id), stats)
+            return UserInterfaceSupport.image_generator(args, all_intervals, n, thread_id)
         if total_threads <= 1:
-            UserInterfaceSupport.image_generator(args, all_intervals, 1, 0)
+            work(0, 1)
             return
         with ThreadPoolExecutor(max_workers=total_threads) as executor:
-            futures = [executor.submit(UserInterfaceSupport.image_generator, args, all_intervals, total_threads, thread_id)
-                       for thread_id in range(total_threads)]
+            futures = [executor.submit(work, thread_id, total_threads) for thread_id in range(total_threads)]
             for fut in futures:
                 fut.result()            # a worker's exception stops the run (the reference logs it and carries on)

@@ -140,6 +140,64 @@ class StagedSummaries(object):
         return image, pos
 
 
+class PolishChain(object):
+    """BAM records -> image chunks of a run of regions on the device (include/pepper_amd_encoder.h, pa_polish_chain_run): what
+    AlignmentSummarizer.create_summary does per region -- get_reads, ReadAligner, SummaryGenerator, chunk_images
+    (/root/reference/pepper/modules/python/AlignmentSummarizer.py:296-358) -- for N regions per call, with the reads clipped,
+    re-aligned, summarised and cut into chunks without leaving the GPU.  `packed` is a pepper_amd.variant.PEPPER_VARIANT.
+    PackedEncoder: its pack_device() / pack() fill the tables this object hands on (one object per worker thread)."""
+
+    def __init__(self, packed):
+        self.packed = packed
+        self.lib = packed.lib
+        self.n_chunks = 0
+        self.chunk_size = 0
+
+    def run(self, regions, windows, region_pairs, counts, realign=True, resident=False, chunk_size=1000, chunk_overlap=50):
+        """regions: [(start, end)] of the packed run; windows[r]: the draft from start to end + 20 (bytes; shorter at the
+        contig's end); region_pairs / counts: what pack_device() / pack() returned.
+        -> (rows per region, reads per region, chunks per region)."""
+        from pepper_amd.variant.PEPPER_VARIANT import _PackedRegion
+        pe = self.packed
+        n = len(regions)
+        refs = [w if isinstance(w, bytes) else bytes(w) for w in windows]
+        regs = (_PackedRegion * max(1, n))(*[_PackedRegion(int(a), int(b), ref, len(ref)) for (a, b), ref in zip(regions, refs)])
+        region_pairs = np.ascontiguousarray(region_pairs[:n + 1], np.int32)
+        n_reads, _n_pairs, arena_bytes = counts
+        rows, live, chunks = np.zeros(max(1, n), np.int64), np.zeros(max(1, n), np.int32), np.zeros(max(1, n), np.int32)
+        total = ctypes.c_int64()
+        _lib.check(self.lib.pa_polish_chain_run(
+            pe.enc, n, ctypes.cast(regs, ctypes.c_void_p), None if (resident and n_reads > 0) else pe.arena.ctypes.data,
+            int(arena_bytes), pe.reads.ctypes.data, int(n_reads), pe.pair_read.ctypes.data, region_pairs.ctypes.data,
+            1 if realign else 0, int(chunk_size), int(chunk_overlap), rows.ctypes.data, live.ctypes.data, chunks.ctypes.data,
+            ctypes.byref(total)))
+        self.n_chunks, self.chunk_size = total.value, int(chunk_size)
+        return rows[:n], live[:n], chunks[:n]
+
+    def chunk_pointers(self):
+        """Addresses of the last run's chunks in the handle's page-locked memory: images uint8 [n_chunks, chunk_size, 10],
+        position / index int64 [n_chunks, chunk_size]; valid until the next run."""
+        img, pos, idx = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(self.lib.pa_polish_chain_chunks(self.packed.enc, ctypes.byref(img), ctypes.byref(pos), ctypes.byref(idx)))
+        return img.value, pos.value, idx.value
+
+    def chunk_arrays(self):
+        """The same as numpy views (copy them to keep them past the next run)."""
+        img, pos, idx = self.chunk_pointers()
+        n, c = self.n_chunks, self.chunk_size
+        if n == 0:
+            return np.zeros((0, c, 10), np.uint8), np.zeros((0, c), np.int64), np.zeros((0, c), np.int64)
+        return (np.ctypeslib.as_array(ctypes.cast(img, ctypes.POINTER(ctypes.c_uint8)), shape=(n, c, 10)),
+                np.ctypeslib.as_array(ctypes.cast(pos, ctypes.POINTER(ctypes.c_int64)), shape=(n, c)),
+                np.ctypeslib.as_array(ctypes.cast(idx, ctypes.POINTER(ctypes.c_int64)), shape=(n, c)))
+
+    def timing(self):
+        ms, counts = np.zeros(8, np.float64), np.zeros(4, np.int64)
+        _lib.check(self.lib.pa_polish_chain_last_timing(self.packed.enc, ms.ctypes.data, 8, counts.ctypes.data, 4))
+        return dict(unpack_ms=ms[0], realign_ms=ms[1], encode_ms=ms[2], chunk_ms=ms[3], score_kernel_ms=ms[5], band_kernel_ms=ms[6],
+                    pairs=int(counts[0]), realigned=int(counts[1]), cigar_ops=int(counts[2]), rows=int(counts[3]))
+
+
 _realigners = {}
 
 

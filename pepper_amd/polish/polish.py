@@ -36,7 +36,7 @@ def polish(bam_filepath, fasta_filepath, output_path, threads, region, model_pat
     prediction_output_directory = output_dir + "predictions_" + str(timestr) + "/"
     _log("INFO: RUN-ID: " + str(timestr))
     _log("STEP 1: GENERATING IMAGES -> " + image_output_directory)
-    make_images(bam_filepath, fasta_filepath, region, image_output_directory, threads)
+    make_images(bam_filepath, fasta_filepath, region, image_output_directory, threads, device_ids=device_ids)
     _log("STEP 2: RUNNING INFERENCE -> " + prediction_output_directory)
     call_consensus(image_output_directory, model_path, batch_size, num_workers, prediction_output_directory, device_ids,
                    gpu_mode, threads)

@@ -1,0 +1,186 @@
+"""The polish image chain (pa_polish_chain_run: BAM records -> clipped reads -> re-aligned reads -> summary rows -> chunks, all on
+the device) against (a) the reference's own builds -- oracle/_ref/libref_ssw.so for every re-alignment and oracle/_ref/
+libref_polish_encoder.so for every summary, fed by the tests' restatement of get_reads' clipping -- and (b) the host form of the
+same pipeline (PEPPER_AMD_POLISH_CHAIN=0: host arrays between the stages), whose image files must be identical dataset by dataset.
+Reference: pepper/modules/python/AlignmentSummarizer.py:18-56, 296-358; simple_aligner.cpp:66-106; summary_generator.cpp."""
+import glob
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import bam_utils as bu
+import pileup_utils as pu
+from oracle import ssw
+from pepper_amd import h5
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(tmp_path, seed, length, n_reads, read_len, deep_at=None, extra=()):
+    rng = np.random.default_rng(seed)
+    draft = pu.random_reference(rng, length)
+    reads = pu.simulate_reads(rng, draft, 0, n_reads=n_reads, read_len=read_len, ins_rate=0.03, del_rate=0.03)
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    if deep_at is not None:          # a pile beyond MAX_READS_IN_REGION: short reads stacked on one stretch
+        a, b, n = deep_at
+        more = pu.simulate_reads(rng, draft[a:b], a, n_reads=n, read_len=(120, 260), ins_rate=0.02, del_rate=0.02)
+        reads += [r for r in more if not any(op in (3, 6) for op, _ in r["cigar"])]
+    reads += list(extra)
+    reads.sort(key=lambda r: r["pos"])
+    for i, r in enumerate(reads):
+        r["name"] = "q%d" % i
+    bam_path, fa_path = str(tmp_path / "reads.bam"), str(tmp_path / "draft.fa")
+    bu.write_bam(bam_path, [("ctg1", len(draft))], {0: reads})
+    with open(fa_path, "w") as fh:
+        fh.write(">ctg1\n" + draft + "\n")
+    return draft, reads, bam_path, fa_path
+
+
+def _groups(path):
+    out = {}
+    with h5.File(path) as f:
+        for name in f.keys("summaries"):
+            base = "summaries/" + name + "/"
+            out[name] = {k: np.asarray(f[base + k]) for k in ("image", "label", "position", "index", "region_start", "region_end", "chunk_id")}
+            out[name]["contig"] = f[base + "contig"]
+    return out
+
+
+def _make(bam_path, fa_path, out_dir, threads, chain, monkeypatch, regions=None, device_ids=None):
+    from pepper_amd.polish import ImageGenerationUI as ui
+    from pepper_amd.polish.make_images import make_images
+    monkeypatch.setenv("PEPPER_AMD_POLISH_CHAIN", "1" if chain else "0")
+    if regions is not None:
+        monkeypatch.setattr(ui.UserInterfaceSupport, "CHAIN_REGIONS", regions)
+    make_images(bam_path, fa_path, None, out_dir, threads, device_ids=device_ids)
+    merged = {}
+    for path in glob.glob(os.path.join(out_dir, "*.hdf")):
+        merged.update(_groups(path))
+    return merged
+
+
+def _assert_same(got, want):
+    assert sorted(got) == sorted(want)
+    for name in want:
+        for key, w in want[name].items():
+            g = got[name][key]
+            assert (g == w) if isinstance(w, (str, bytes)) else np.array_equal(g, w), (name, key)
+
+
+def test_chain_images_equal_the_reference_builds(tmp_path, monkeypatch):
+    """Every interval of a 6.3 kb draft through the chain (one call: 7 intervals), compared with the reference's own SSW and
+    SummaryGenerator builds fed by the restated clipping: one hop to the reference."""
+    from pepper_amd.polish.AlignmentSummarizer import AlignmentSummarizer
+    from pepper_amd.polish.ImageGenerationUI import UserInterfaceSupport
+    ref_enc = pu.load_reference_polish_encoder()
+    if ref_enc is None or not ssw.have_reference():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    low = dict(pos=2950, reverse=False, mapq=0, seq="ACGT" * 60, qual=np.full(240, 20, np.uint8), cigar=[(0, 240)])
+    draft, reads, bam_path, fa_path = _dataset(tmp_path, 311, 6300, 330, (500, 3000), extra=[low])
+    got = _make(bam_path, fa_path, str(tmp_path / "chain"), 1, True, monkeypatch)
+    _, intervals = UserInterfaceSupport.make_intervals([("ctg1", None)], fa_path)
+    assert len(intervals) == 7
+    checked = 0
+    for (_, start, end) in intervals:
+        clipped = bu.restated_get_reads(reads, start, end, False, 0)
+        res = ssw.realign_reads(draft[start:end + 20], start, [r["pos"] for r in clipped], [r["seq"] for r in clipped],
+                                aligner=ssw.align_reference)
+        realigned = [dict(r, pos=p, cigar=[(0 if o in (7, 8) else o, n) for o, n in ops]) if st == 1 else r
+                     for r, (st, score, p, pe, ops) in zip(clipped, res)]
+        img, pos = pu.run_polish_reference(ref_enc, pu.FlatPileup(start, end, draft[start:end + 1], realigned), start, end)
+        want = AlignmentSummarizer.chunk_images(SimpleNamespace(image=img, genomic_pos=[tuple(x) for x in pos.tolist()]), 1000, 50)
+        for cid, (wi, wp) in enumerate(zip(want[0], want[2])):
+            g = got["ctg1_%d_%d_%d" % (start, end, cid)]
+            assert np.array_equal(g["image"], wi), (start, cid)
+            assert np.array_equal(g["position"], wp[:, 0]) and np.array_equal(g["index"], wp[:, 1])
+            assert int(g["region_start"]) == start and int(g["region_end"]) == end and int(g["chunk_id"]) == cid
+            assert not g["label"].any() and g["contig"] == "ctg1"
+            checked += 1
+        assert "ctg1_%d_%d_%d" % (start, end, len(want[0])) not in got
+    assert checked == len(got) and checked >= 10
+
+
+@pytest.mark.parametrize("threads,regions", [(1, 128), (3, 2), (2, 5)])
+def test_chain_files_equal_the_host_form(tmp_path, monkeypatch, threads, regions):
+    """Image files of the chain and of the host form, dataset by dataset: a stretch without reads (no groups), a pile of more
+    than 1 500 reads (reservoir sample on the host, the chain's other intervals unaffected), several calls per worker."""
+    draft, reads, bam_path, fa_path = _dataset(tmp_path, 97 + threads, 9400, 260, (400, 2600), deep_at=(5100, 5500, 1900))
+    # nothing reaches 6 850 .. 8 150: the interval 6 900 - 8 100 has no reads
+    reads2 = [r for r in reads if r["pos"] + bu.ref_length(r["cigar"]) < 6850 or r["pos"] > 8150]
+    bu.write_bam(bam_path, [("ctg1", len(draft))], {0: reads2})
+    want = _make(bam_path, fa_path, str(tmp_path / "host"), 1, False, monkeypatch)
+    got = _make(bam_path, fa_path, str(tmp_path / "chain"), threads, True, monkeypatch, regions=regions)
+    assert not any(name.startswith("ctg1_6900_") for name in want) and any(name.startswith("ctg1_7900_") for name in want)
+    assert any(name.startswith("ctg1_4900_") for name in want)
+    _assert_same(got, want)
+
+
+def test_chain_host_packed_form_and_no_realignment(tmp_path, monkeypatch):
+    """PEPPER_AMD_DEVICE_INFLATE=0: the arena filled by the host packer and uploaded (the form a BAM without an index takes);
+    and PolishChain.run(realign=False) against create_summary(realignment_flag=False)."""
+    from pepper_amd.polish import PEPPER
+    from pepper_amd.polish.AlignmentSummarizer import AlignmentSummarizer
+    from pepper_amd.variant.PEPPER_VARIANT import PackedEncoder
+    from pepper_amd.variant.bam import BAM_handler
+    from pepper_amd.variant.fasta import FASTA_handler
+    draft, reads, bam_path, fa_path = _dataset(tmp_path, 5, 3300, 150, (300, 1500))
+    want = _make(bam_path, fa_path, str(tmp_path / "host"), 1, False, monkeypatch)
+    monkeypatch.setenv("PEPPER_AMD_DEVICE_INFLATE", "0")
+    got = _make(bam_path, fa_path, str(tmp_path / "chain"), 1, True, monkeypatch)
+    _assert_same(got, want)
+
+    bam, fasta = BAM_handler(bam_path), FASTA_handler(fa_path)
+    enc = PackedEncoder(0, 64 << 20, host_threads=1)
+    chain = PEPPER.PolishChain(enc)
+    bounds = [(0, 1100), (900, 2100), (1900, 3100)]
+    starts, stops = [a for a, _ in bounds], [b for _, b in bounds]
+    n_done, region_pairs, counts = enc.pack(bam, "ctg1", starts, stops, False, 0)
+    assert n_done == 3
+    rows, live, chunks = chain.run(bounds, [b"" for _ in bounds], region_pairs, counts, realign=False)
+    img, pos, idx = [a.copy() for a in chain.chunk_arrays()]
+    at = 0
+    for (a, b), k, n_live in zip(bounds, chunks, live):
+        s = AlignmentSummarizer(bam, fasta, "ctg1", a, b)
+        wi, _, wp, ids = s.create_summary(realignment_flag=False)
+        assert len(wi) == k and n_live == len(bam.get_reads("ctg1", a, b, False, 0, 0))
+        for c in range(k):
+            assert np.array_equal(img[at + c], wi[c]) and np.array_equal(pos[at + c], wp[c][:, 0]) and np.array_equal(idx[at + c], wp[c][:, 1])
+        at += k
+    assert at == len(img)
+    enc.close()
+
+
+def test_chain_refuses_what_it_cannot_hold(tmp_path):
+    """A read that keeps more bases of a region than a pair's slot (2 L + 64): PA_ERR_UNSUPPORTED, and image generation takes the
+    host form for that run of intervals."""
+    from pepper_amd import _lib
+    from pepper_amd.polish import PEPPER
+    from pepper_amd.variant.PEPPER_VARIANT import PackedEncoder
+    from pepper_amd.variant.bam import BAM_handler
+    rng = np.random.default_rng(8)
+    draft = pu.random_reference(rng, 900)
+    ins = "".join(rng.choice(list("ACGT"), 700))
+    fat = dict(pos=100, reverse=False, mapq=60, seq=draft[100:200] + ins + draft[200:300], qual=np.full(900, 20, np.uint8),
+               cigar=[(0, 100), (1, 700), (0, 100)], name="fat")
+    bam_path = str(tmp_path / "fat.bam")
+    bu.write_bam(bam_path, [("ctg1", len(draft))], {0: [fat]})
+    enc = PackedEncoder(0, 16 << 20, host_threads=1)
+    chain = PEPPER.PolishChain(enc)
+    n_done, region_pairs, counts = enc.pack(BAM_handler(bam_path), "ctg1", [90], [310], False, 0)
+    with pytest.raises(_lib.PepperAmdError) as err:
+        chain.run([(90, 310)], [draft[90:331].encode()], region_pairs, counts)
+    assert err.value.code == _lib.PA_ERR_UNSUPPORTED
+    enc.close()
+
+
+def test_worker_device_map_and_device_ids(tmp_path, monkeypatch):
+    """device_ids "0,0": two workers, each on `its` device -- the files are those of the single-device run."""
+    from pepper_amd.polish.ImageGenerationUI import UserInterfaceSupport, parse_device_ids
+    assert parse_device_ids("0,2,5") == [0, 2, 5] and parse_device_ids(None) == [0] and parse_device_ids([1]) == [1]
+    assert [UserInterfaceSupport.worker_device("0,1,2", t) for t in range(5)] == [0, 1, 2, 0, 1]
+    draft, reads, bam_path, fa_path = _dataset(tmp_path, 77, 4200, 160, (400, 2000))
+    want = _make(bam_path, fa_path, str(tmp_path / "one"), 1, True, monkeypatch)
+    got = _make(bam_path, fa_path, str(tmp_path / "two"), 2, True, monkeypatch, regions=2, device_ids="0,0")
+    _assert_same(got, want)
