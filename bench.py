@@ -862,6 +862,59 @@ def make_images_leg(scratch):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def polish_make_images_leg(scratch):
+    """make_images of pepper polish (BAM + draft -> image HDF5 files) on a synthetic 16 Mb draft at 60x written by tools/synth_bam,
+    through the device-resident chain (tools/bench_polish_chain.py): Mb of draft per second with the workers' stage times and the
+    roofline of the stage that bounds it -- the re-aligner's vector instruction issue.  Three runs over the same files, the median."""
+    import shutil
+    import subprocess
+    import tempfile
+    base = scratch or tempfile.gettempdir()
+    work = tempfile.mkdtemp(prefix="pepper_amd_pimages_", dir=base)
+    tool = os.path.join(REPO, "tools", "bench_polish_chain.py")
+    try:
+        from pepper_amd.hostinfo import usable_cpus
+        threads = max(1, min(8, usable_cpus()))
+        p = subprocess.run([sys.executable, tool, "make_fast", work, "16000000"], capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            return {"error": (p.stderr or "synth_bam failed").strip().splitlines()[-1][:300]}
+        made = json.loads(p.stdout.strip().splitlines()[-1])
+        p = subprocess.run([sys.executable, tool, "run", work, ",".join([str(threads)] * 3)], capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if not lines:
+            return {"error": (p.stderr or "no output").strip().splitlines()[-1][:300]}
+        d = json.loads(lines[-1])
+        runs = sorted(d["runs"], key=lambda r: r["mb_draft_per_s"])
+        mid = runs[len(runs) // 2]
+        stages = mid["stage_seconds_summed_over_workers"]
+        out = {"value": mid["mb_draft_per_s"], "unit": "Mb of draft/s", "intervals_per_s": mid["intervals_per_s"],
+               "reads_realigned_per_s": mid["reads_realigned_per_s"], "seconds": mid["seconds"], "threads": mid["threads"],
+               "regions_per_call": d["regions_per_call"], "runs_mb_per_s": [r["mb_draft_per_s"] for r in runs], "counts": mid["counts"],
+               "stage_seconds_summed_over_workers": stages, "data": d["data"], "synth_seconds": made["seconds"],
+               "image_file_mb": mid["image_file_mb"]}
+        # the bound: the two re-aligner kernels' vector instructions (profiles/r05_polish_chain_pmc.txt: wave instructions per read)
+        # x 4 cycles against the SIMD-cycles of the wall time
+        try:
+            ins = {}
+            for line in open(os.path.join(REPO, "profiles", "r05_polish_chain_pmc.txt")):
+                parts = line.split()
+                if len(parts) >= 2 and parts[0] in ("valu_wave_instructions_per_read_score", "valu_wave_instructions_per_read_band"):
+                    ins[parts[0]] = float(parts[1])
+            per_read = ins["valu_wave_instructions_per_read_score"] + ins["valu_wave_instructions_per_read_band"]
+            simd_cycles = 1024 * mid["seconds"] * 2.4e9
+            out["roofline"] = {"bound": "valu issue", "kernel": "sw_ends_kernel + band_kernel", "unit": "G wave-instructions/s",
+                               "achieved": per_read * mid["counts"]["realigned"] / mid["seconds"] / 1e9, "peak": 1024 * 2.4 / 4,
+                               "frac": 4.0 * per_read * mid["counts"]["realigned"] / simd_cycles,
+                               "valu_wave_instructions_per_read": per_read, "source": "profiles/r05_polish_chain_pmc.txt"}
+        except (OSError, KeyError, ValueError):
+            pass
+        return out
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def secondary_block(args):
     """The other workloads of the hot path, each as its own short run of this file / the pipeline tools after the headline
     measurement (same command, same box, one after the other on the one GPU): polish (BASELINE configs[4]) windows/s with its
@@ -930,6 +983,7 @@ def secondary_block(args):
         pass
     extra = ["--dir", scratch] if scratch else []
     out["make_images"] = make_images_leg(scratch)
+    out["polish_make_images"] = polish_make_images_leg(scratch)
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "8000000"], 300)
 
     def inflate_roofline(d):

@@ -1,7 +1,7 @@
 /* pepper_amd -- BGZF blocks inflated on the device (C ABI of libpepper_amd.so).
  *
  * What it replaces: the block inflate under every BAM read of image generation -- htslib's bgzf_read_block beneath
- * sam_itr_next in /root/reference/pepper_variant/modules/src/dataio/bam_handler.cpp:341-372 (get_reads) and
+ * sam_itr_next in /root/reference/pepper_variant/modules/cpp/bam_handler.cpp:341-372 (get_reads) and
  * /root/reference/pepper_hp/modules/src/dataio/bam_handler.cpp (the polisher's copy).  A BGZF file (SAM/BAM specification,
  * section 4.1) is a sequence of independent gzip members of at most 64 KiB of data each; one wavefront inflates one member
  * (RFC 1951: stored, fixed and dynamic blocks).  Like the host reader, the members' CRC32 is not verified; every structural

@@ -1,7 +1,7 @@
 // BGZF blocks inflated on the device: one wavefront per block.
 //
 // What it stands in for: the block-by-block inflate under every BAM read of image generation (the reference reaches it
-// through htslib's bgzf_read_block under sam_itr_next, /root/reference/pepper_variant/modules/src/dataio/bam_handler.cpp:
+// through htslib's bgzf_read_block under sam_itr_next, /root/reference/pepper_variant/modules/cpp/bam_handler.cpp:
 // 341-372; this repository's host form is Bgzf::read_block in bamio.cpp).  After the packed read form of round 4 that host
 // inflate is 89 % of an image-generation worker's time, and a BGZF file is thousands of independent
 // <= 64 KiB DEFLATE streams -- the unit the chip parallelises over.
@@ -636,7 +636,8 @@ PA_DEV uint32_t load32(const uint8_t* p) {
     return *reinterpret_cast<const word_any*>(p);
 }
 
-// flags[0]: 1 a lane ran out of slots, 2 a record shorter than its core;  flags[1]: 1 the span ends inside a record
+// flags[0]: 1 a lane ran out of slots, 2 a record shorter than its core, 8 a lane's walk overshot the next entry (the entries
+// are not record starts);  flags[1]: 1 the span ends inside a record
 __global__ __launch_bounds__(64) void record_chase_kernel(const uint8_t* __restrict__ data, int64_t data_bytes,
                                                          const int64_t* __restrict__ entries, int n_entries, int cap,
                                                          RecHdr* __restrict__ slots, int32_t* __restrict__ counts, int32_t* flags) {
@@ -669,6 +670,9 @@ __global__ __launch_bounds__(64) void record_chase_kernel(const uint8_t* __restr
         mine[j++] = h;
         at += 4 + (int64_t)bs;
     }
+    // the walk from an entry must land exactly on the next one: an entry that is not a record start (a stale or foreign index)
+    // leaves this lane past it and the next lane parsing garbage as headers -- flag it (8) and the caller takes the host walk
+    if (i + 1 < n_entries && at != stop && !(at < stop)) atomicOr(&flags[0], 8);
     counts[i] = j;
 }
 

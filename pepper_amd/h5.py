@@ -224,13 +224,26 @@ class PredictionBuilder(object):
             return
         self.close()
 
+    def abort(self):
+        """Give the store up: the native object is finished and the temporary file removed -- what the predict loops call
+        when a batch raised (a `finally: close()` would publish a partial store under the final name)."""
+        h, self._h = self._h, None
+        if h:
+            self._lib.pa_h5_builder_close(h)
+            if os.path.exists(self._tmp):
+                os.remove(self._tmp)
+
     def __del__(self):
         # (a writer that was never closed: the metadata is still written so that the handle is released, and the file keeps
-        # its temporary name -- an explicit close() is what publishes a store)
+        # its temporary name -- an explicit close() is what publishes a store; say so, a caller that relied on garbage
+        # collection would otherwise lose its output silently)
         try:
             h, self._h = self._h, None
             if h:
                 self._lib.pa_h5_builder_close(h)
+                import warnings
+                warnings.warn("PredictionBuilder for %s was never closed: the store stays under %s" % (self.filename, self._tmp),
+                              ResourceWarning)
         except Exception:
             pass
 

@@ -389,8 +389,10 @@ def _polish_writer(lane, result_q, output_filename, slot_names, layout_args, wri
         busy += time.perf_counter() - t0
         result_q.put(("write_done", lane))
         _worker_trace("writer", lane, chunks, busy, waiting, t_start)
+    except BaseException:
+        store.abort()               # (a lane that raised publishes no partial store under the final name)
+        raise
     finally:
-        store.close()
         _close_all(segs)
 
 

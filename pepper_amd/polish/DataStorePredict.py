@@ -31,6 +31,13 @@ class DataStore(object):
     def close(self):
         self.file_handler.close()
 
+    def abort(self):
+        """The run raised: publish nothing (the append-only writer removes its temporary file; a libhdf5 file is closed)."""
+        if hasattr(self.file_handler, "abort"):
+            self.file_handler.abort()
+        else:
+            self.file_handler.close()
+
     def __enter__(self):
         return self
 

@@ -171,7 +171,11 @@ class UserInterfaceSupport:
             mine[key] = mine.get(key, 0.0) + now - t0
             return now
 
-        enc = PackedEncoder.acquire(device, int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20, host_threads=1)
+        try:
+            enc = PackedEncoder.acquire(device, int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20, host_threads=1)
+        except _lib.PepperAmdError:
+            # no page-locked arena to be had (memlock / cgroup limit): the host form needs none
+            return UserInterfaceSupport.image_generator(args, all_intervals, total_threads, thread_id)
         chain = PEPPER.PolishChain(enc)
         device_inflate = os.environ.get("PEPPER_AMD_DEVICE_INFLATE", "1") != "0"
         safe = AlingerOptions.ALIGNMENT_SAFE_BASES

@@ -109,11 +109,17 @@ def predict(input_filepath, file_chunks, output_filepath, model_path, batch_size
                 _log("INFO: BATCHES PROCESSED " + str(done) + ".")
         for w in writes:
             w.result()
-    finally:
+    except BaseException:
+        # a partial store must not appear under the final name (perform_stitch reads whatever *.hdf the directory holds)
         reader.shutdown(wait=True)
         writer.shutdown(wait=True)
         input_data.close()
-        prediction_data_file.close()
+        prediction_data_file.abort()
+        raise
+    reader.shutdown(wait=True)
+    writer.shutdown(wait=True)
+    input_data.close()
+    prediction_data_file.close()
     return rank
 
 

@@ -2,10 +2,10 @@
 
 replaces: /root/reference/pepper_variant/modules/python/CallVariant.py:12-109 (`call_variant`).
 Same option names and the same three output locations (images_<run>/, predictions_<run>/, VCFs in
-output_dir).  Input checks raise instead of calling exit(); the BAM/FASTA handlers come from
-`options.bam_handler_factory` / `options.fasta_handler_factory` when given (htslib ingestion is not
-part of this package), otherwise the FASTA is read by
-pepper_amd.variant.fasta and a BAM handler must be supplied.
+output_dir).  Input checks raise instead of calling exit().  `options.bam` / `options.fasta` are read by the package's
+own readers (pepper_amd.variant.bam: BGZF members inflated on the device, records walked there;
+pepper_amd.variant.fasta); `options.bam_handler_factory` / `options.fasta_handler_factory`, when given,
+replace them (objects with the reference handlers' methods: tests inject synthetic read sets that way).
 """
 import os
 import sys

@@ -203,8 +203,15 @@ class ImageGenerationUtils:
             from pepper_amd.variant.PEPPER_VARIANT import PackedEncoder
             t_setup = time.perf_counter()
             # (every CPU the process has is inflating BGZF blocks in some worker: the encoder's host part runs on this thread)
-            enc = PackedEncoder.acquire(getattr(options, "device", 0), int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20,
-                                        host_threads=1)
+            try:
+                enc = PackedEncoder.acquire(getattr(options, "device", 0), int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20,
+                                            host_threads=1)
+            except _lib.PepperAmdError:
+                # no page-locked arena to be had (memlock / cgroup limit): the host-clipped form needs none
+                for g0 in range(0, len(intervals), batch):
+                    host_clipped(output_hdf_file, intervals[g0:g0 + batch])
+                report()
+                return process_id
             bam_handler, fasta_handler = _handlers(options, options.bam, options.fasta)
             lap("setup", t_setup)
             safe = ConsensCandidateFinder.REGION_SAFE_BASES
@@ -238,9 +245,9 @@ class ImageGenerationUtils:
                         n_done, region_pairs, counts = enc.pack(bam_handler, chr_name, [r[0] for r in regions], [r[1] for r in regions],
                                                                 options.include_supplementary, options.min_mapq)
                     except Exception as err:
-                        if "do not fit" not in str(err):
+                        if getattr(err, "code", 0) != -7:
                             raise
-                        n_done = 0                       # one interval's reads outgrow the arena
+                        n_done = 0                       # (-7: one interval's reads outgrow the arena)
                     t0 = lap("bam_pack", t0)
                 if n_done == 0:
                     host_clipped(output_hdf_file, group[:1])

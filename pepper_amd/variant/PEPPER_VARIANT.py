@@ -270,12 +270,21 @@ class PackedEncoder(object):
     @classmethod
     def acquire(cls, device=0, arena_bytes=192 << 20, host_threads=1):
         """An encoder from the process-wide pool (or a new one): pinning a 256 MB arena and the first device allocations cost
-        ~0.15 s per worker, which a long-running process pays once."""
+        ~0.15 s per worker, which a long-running process pays once.  Under a memlock / cgroup limit the page-locked arena may
+        not be had at that size: the request is halved down to 16 MB before the error is passed on (a smaller arena means
+        fewer intervals per call, nothing else); the callers fall back to the host-clipped form when even that fails."""
         with cls._idle_lock:
             for k, enc in enumerate(cls._idle):
-                if enc.device == device and enc.arena is not None and enc.arena.nbytes == arena_bytes:
+                if enc.device == device and enc.arena is not None and enc.arena.nbytes <= arena_bytes and enc.arena.nbytes >= min(arena_bytes, 16 << 20):
                     return cls._idle.pop(k)
-        return cls(device, arena_bytes, host_threads=host_threads)
+        size = arena_bytes
+        while True:
+            try:
+                return cls(device, size, host_threads=host_threads)
+            except _lib.PepperAmdError:
+                if size <= 16 << 20:
+                    raise
+                size >>= 1
 
     def release(self):
         with self._idle_lock:
@@ -332,7 +341,7 @@ class PackedEncoder(object):
             cap = self.arena.nbytes + (1 << 20)
             ptr = self.lib.pa_encoder_host_span(self.enc, cap)
             if not ptr:
-                raise _lib.PepperAmdError("page-locked span block of %d bytes could not be allocated" % cap)
+                return None                              # (no second page-locked block under this memlock limit: the host packer's form)
             self.span = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(cap,))
             nb = max(4096, self.arena.nbytes // 4096)
             self.tables = (np.zeros(nb, np.int64), np.zeros(nb, np.int32), np.zeros(nb, np.int64), np.zeros(nb, np.int32))
@@ -379,9 +388,14 @@ class PackedEncoder(object):
             # slots per entry: 2 048 records of one 16 kb window, fewer when a span has very many windows (low coverage): the
             # device keeps two 40-byte tables of entries x slots; a window that overflows its slots takes the host walk
             slots = max(64, min(2048, (32 << 20) // (40 * max(1, n_entries))))
-            _lib.check(self.lib.pa_encoder_walk_records(self.enc, out_bytes, self.entries.ctypes.data, n_entries, slots,
-                                                        self.headers.ctypes.data, len(self.headers), ctypes.byref(n_headers),
-                                                        flags.ctypes.data))
+            try:
+                _lib.check(self.lib.pa_encoder_walk_records(self.enc, out_bytes, self.entries.ctypes.data, n_entries, slots,
+                                                            self.headers.ctypes.data, len(self.headers), ctypes.byref(n_headers),
+                                                            flags.ctypes.data))
+            except _lib.PepperAmdError as err:
+                if getattr(err, "code", 0) != _lib.PA_ERR_INVALID:
+                    raise
+                return None                              # (entries outside the span: a stale index -- the host packer reads the file itself)
             if flags[0] == 0:
                 headers = n_headers.value
             else:

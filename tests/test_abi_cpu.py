@@ -34,6 +34,18 @@ def test_header_symbols_are_exported(lib):
         assert hasattr(lib, name), name
 
 
+def test_no_undeclared_exports(lib):
+    """Every pa_* symbol the product library exports is declared in a header under include/ (the diagnostic hooks in
+    pepper_amd_debug.h, everything else in the drop-in headers)."""
+    import subprocess
+    from pepper_amd import _lib
+    text = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in text.splitlines() if " T " in line and line.split()[-1].startswith("pa_")}
+    declared = _declared("pepper_amd.h", "pepper_amd_encoder.h", "pepper_amd_realign.h", "pepper_amd_io_device.h", "pepper_amd_debug.h")
+    assert exported <= declared, exported - declared
+    assert {"pa_debug_dump_timing", "pa_debug_dump_gru_timing", "pa_debug_gemm_h2_experiment", "pa_debug_gemm_h2"} <= exported
+
+
 def test_io_header_symbols_are_exported():
     from pepper_amd import h5
     io = h5.load()
