@@ -915,6 +915,33 @@ def polish_make_images_leg(scratch):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def e2e_leg(kind, scratch, bases, coverage, runs, need_gb):
+    """tools/bench_e2e.py: the whole job through the reference's top entry point (call_variant / polish) on synthetic inputs, the
+    median of `runs` with the three steps' walls."""
+    import shutil
+    import subprocess
+    import tempfile
+    base = scratch or tempfile.gettempdir()
+    try:
+        st = os.statvfs(base)
+        if st.f_bavail * st.f_frsize < (need_gb << 30):          # a quarter of the job where the scratch space is short
+            bases //= 4
+    except OSError:
+        bases //= 4
+    work = tempfile.mkdtemp(prefix="pepper_amd_e2e_", dir=base)
+    try:
+        p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "bench_e2e.py"), kind, work, str(bases), str(coverage), str(runs)],
+                           capture_output=True, text=True, timeout=1200)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if not lines:
+            return {"error": (p.stderr or "no output").strip().splitlines()[-1][:300]}
+        return json.loads(lines[-1])
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def secondary_block(args):
     """The other workloads of the hot path, each as its own short run of this file / the pipeline tools after the headline
     measurement (same command, same box, one after the other on the one GPU): polish (BASELINE configs[4]) windows/s with its
@@ -984,6 +1011,9 @@ def secondary_block(args):
     extra = ["--dir", scratch] if scratch else []
     out["make_images"] = make_images_leg(scratch)
     out["polish_make_images"] = polish_make_images_leg(scratch)
+    # the two top entry points as one job each (stage walls inside): 256 Mb at 30x for call_variant, 64 Mb at 60x for polish
+    out["call_variant"] = e2e_leg("call_variant", scratch, 256_000_000, 30, 3, 24)
+    out["polish_e2e"] = e2e_leg("polish", scratch, 64_000_000, 60, 2, 16)
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "8000000"], 300)
 
     def inflate_roofline(d):

@@ -18,7 +18,8 @@ def _log(message):
 
 
 def polish(bam_filepath, fasta_filepath, output_path, threads, region, model_path, batch_size, gpu_mode, device_ids,
-           num_workers):
+           num_workers, stage_walls=None):
+    """The reference's ten arguments; stage_walls: a dict that receives the three steps' wall times."""
     for path, what in ((bam_filepath, "BAM"), (fasta_filepath, "FASTA"), (model_path, "MODEL")):
         if not os.path.isfile(path):
             raise FileNotFoundError("CAN NOT LOCATE " + what + " FILE: " + str(path))
@@ -36,9 +37,14 @@ def polish(bam_filepath, fasta_filepath, output_path, threads, region, model_pat
     prediction_output_directory = output_dir + "predictions_" + str(timestr) + "/"
     _log("INFO: RUN-ID: " + str(timestr))
     _log("STEP 1: GENERATING IMAGES -> " + image_output_directory)
+    t0 = time.perf_counter()
     make_images(bam_filepath, fasta_filepath, region, image_output_directory, threads, device_ids=device_ids)
+    t1 = time.perf_counter()
     _log("STEP 2: RUNNING INFERENCE -> " + prediction_output_directory)
     call_consensus(image_output_directory, model_path, batch_size, num_workers, prediction_output_directory, device_ids,
                    gpu_mode, threads)
+    t2 = time.perf_counter()
     _log("STEP 3: RUNNING STITCH -> " + output_dir)
     perform_stitch(prediction_output_directory, output_dir, threads)
+    if stage_walls is not None:
+        stage_walls.update(make_images=t1 - t0, call_consensus=t2 - t1, perform_stitch=time.perf_counter() - t2)

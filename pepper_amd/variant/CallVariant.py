@@ -46,15 +46,21 @@ def call_variant(options):
     _log("IMAGE OUTPUT: " + str(image_output_directory))
     _log("STEP 1/3 GENERATING IMAGES:")
     options.image_output_directory = image_output_directory
+    walls = getattr(options, "stage_walls", None)           # a dict the caller wants the three steps' wall times in
+    t0 = time.perf_counter()
     ImageGenerationUtils.generate_images(options)
+    t1 = time.perf_counter()
 
     _log("STEP 2/3 RUNNING INFERENCE")
     _log("OUTPUT: " + str(prediction_output_directory))
     run_inference(options, image_output_directory, prediction_output_directory)
+    t2 = time.perf_counter()
 
     _log("STEP 3/3 FINDING CANDIDATES")
     _log("OUTPUT: " + str(candidate_output_directory))
     totals = process_candidates(options, prediction_output_directory, candidate_output_directory)
+    if walls is not None:
+        walls.update(make_images=t1 - t0, run_inference=t2 - t1, find_candidates=time.perf_counter() - t2)
 
     elapsed = time.time() - start_time
     _log("TOTAL ELAPSED TIME FOR FINDING CANDIDATES: " + str(int(elapsed / 60)) + " Min " + str(int(elapsed) % 60) + " Sec")
