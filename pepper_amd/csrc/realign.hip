@@ -312,6 +312,269 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MAXN <= 20 ?
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two reads per wavefront (round 5).  The cell values of a polish region's reads stay below 2^15 (4 x 4000), so a 32-bit lane
+// register holds the same cell of TWO reads -- read A in the low halves, read B in the high halves -- and the packed 16-bit
+// instructions (v_pk_add_u16 / v_pk_max_i16 / v_pk_max_u16 / v_pk_sub_u16 clamp) update both with one issue: 15 vector
+// instructions per PAIR of cells where score_pass_reg needs 12.5 + 2 per cell.  What changes against score_pass_reg:
+//   * substitution score by v_perm_b32: the strip keeps G = H - 6; a column's table word holds 10 in byte `code` of its half
+//     (0 elsewhere), a row's selector byte picks byte `base` of its half's table or the constant 0x00 (N, rows past the read):
+//     diag = G + {10, 0} = H + {4, -6}.  The library's padding rows of the last segment (score 0 against everything) are
+//     treated as never-matching rows too: a padding row can only repeat, never exceed, a value an earlier column held in the
+//     read's last row, and every quantity the pass returns changes on a STRICT increase of the running maximum only;
+//   * the gap terms are non-negative, so `max(x - GE, hs - GO, 0)` is two saturating unsigned subtractions and one maximum;
+//   * the row of the end cell is not carried per cell: every lane keeps the maximum it has seen in its strip over all columns,
+//     and when a column's strip maximum exceeds both that and the maximum of the lanes above in this column, it copies its
+//     strip to LDS and notes the column -- the lane that does so in the first column reaching the final maximum is the one
+//     that holds the end cell (nothing it sees later is larger), and the smallest row is found in its copy after the pass;
+//   * the two reads run in lock step over max(columns) steps: the shorter one sees never-matching columns past its end,
+//     which lane 63 does not count.  The callers pair reads of like size (sorted by window length).
+typedef short pk_s16 __attribute__((ext_vector_type(2)));
+typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max_i(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(pk_s16, a), __builtin_bit_cast(pk_s16, b)));
+}
+__device__ __forceinline__ unsigned pk_max_u(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(pk_u16, a), __builtin_bit_cast(pk_u16, b)));
+}
+__device__ __forceinline__ unsigned pk_subs_u(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(pk_u16, a), __builtin_bit_cast(pk_u16, b)));
+}
+__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(pk_u16, a) + __builtin_bit_cast(pk_u16, b));
+}
+__device__ __forceinline__ unsigned dpp_up1_u(unsigned v, unsigned lane0) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138, 0xf, 0xf, false);
+}
+
+struct HalfIn {                      // one read's side of a pass
+    const int8_t* ref; int first, count;         // reference columns first, first + step, ... (count of them)
+    const int8_t* read; int rfirst, m;           // read rows read[rfirst + r * rstep], r < m
+    int lanes, terminate;                        // 16 / 8 segments; stop when a column's maximum equals this (-1: never)
+};
+
+constexpr unsigned G_ZERO = 0xFFFAFFFAu;         // H = 0 in both halves of a G register
+
+template <int R>
+__device__ __forceinline__ void score_pass_pk(uint32_t* snap, const HalfIn a, const HalfIn b, int step, int rstep, PassOut& oa, PassOut& ob) {
+    static_assert(R % 2 == 0, "the strip is copied to LDS four (and at the end two) rows at a time");
+    constexpr int RP = (R + 3) & ~3;              // a lane's copy starts on a 16-byte boundary
+    const int lane = threadIdx.x;
+    const int La = a.m > 0 ? (a.m + a.lanes - 1) / a.lanes : 1, Lb = b.m > 0 ? (b.m + b.lanes - 1) / b.lanes : 1;
+    const int rows_a = a.m > 0 ? La * a.lanes : 0, rows_b = b.m > 0 ? Lb * b.lanes : 0;
+    unsigned G[R], E[R], SEL[R], SEG[R];
+    // the strips' base codes: all the loads first (clamped rows: no branch between them), one wait
+    int qa[R], qb[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int r = lane * R + k;
+        qa[k] = a.read[a.rfirst + (r < a.m ? r : 0) * rstep];       // (m == 0: rfirst == 0, a readable byte of the read text)
+        qb[k] = b.read[b.rfirst + (r < b.m ? r : 0) * rstep];
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int r = lane * R + k;
+        const unsigned sa = (r < a.m && (unsigned)qa[k] < 4u) ? (unsigned)qa[k] : 0x0Cu;
+        const unsigned sb = (r < b.m && (unsigned)qb[k] < 4u) ? 4u + (unsigned)qb[k] : 0x0Cu;
+        SEL[k] = sa | (0x0Cu << 8) | (sb << 16) | (0x0Cu << 24);
+        SEG[k] = ((r >= rows_a || r % La == 0) ? 0u : 0xFFFFu) | ((r >= rows_b || r % Lb == 0) ? 0u : 0xFFFF0000u);
+        G[k] = G_ZERO;
+        E[k] = 0;
+    }
+    uint32_t* my_a = snap + (size_t)lane * RP;
+    uint32_t* my_b = snap + (size_t)64 * RP + (size_t)lane * RP;
+    auto keep = [&](uint32_t* dst, const unsigned (&g)[R]) {
+#pragma unroll
+        for (int k = 0; k + 4 <= R; k += 4) *reinterpret_cast<uint4*>(dst + k) = make_uint4(g[k], g[k + 1], g[k + 2], g[k + 3]);
+        if constexpr (R % 4 == 2) *reinterpret_cast<uint2*>(dst + R - 2) = make_uint2(g[R - 2], g[R - 1]);
+    };
+    // lane 63's view of the two reads
+    int run_a = 0, run_b = 0, endc_a = -1, endc_b = -1, ovf_a = 0, ovf_b = 0;
+    int stop_a = a.count <= 0 || a.m <= 0, stop_b = b.count <= 0 || b.m <= 0;
+    unsigned diag_in = G_ZERO, p0 = G_ZERO, p1 = 0, p2 = 0, p3 = 0, best = 0;
+    int col_a = -1, col_b = -1;
+    const int cmax = a.count > b.count ? a.count : b.count;
+    // Every step updates the strip unconditionally: a lane that has not reached its first column yet (c < 0), or has passed the
+    // last one, sees a never-matching column -- before the first column that leaves H = E = F = 0 as they are, after the last
+    // one nothing reads the strip any more -- so the loop body has no divergent region around the 15 R instructions (the
+    // conditional form kept two copies of the strip alive across the branch: 283 registers at 20 rows per lane).
+    // the column's base code is fetched one step ahead (clamped index: no branch) and turned into the table word when it is used
+    auto code_at = [](const HalfIn& h, int c, int step_) -> int {
+        const int cc = c < 0 ? 0 : (c < h.count ? c : (h.count > 0 ? h.count - 1 : 0));
+        return h.ref[h.first + cc * step_];                     // (count == 0: first == 0, a readable byte of the window text)
+    };
+    auto table_of = [](const HalfIn& h, int c, int code) {
+        return (c >= 0 && c < h.count && (unsigned)code < 4u) ? 10u << (8 * code) : 0u;
+    };
+    int rawa_next = code_at(a, -lane, step), rawb_next = code_at(b, -lane, step);
+    const int steps = cmax + 63;
+    for (int t = 0; t < steps; ++t) {
+        const unsigned i0 = dpp_up1_u(p0, G_ZERO), i1 = dpp_up1_u(p1, 0), i2 = dpp_up1_u(p2, 0), i3 = dpp_up1_u(p3, 0);
+        const int c = t - lane;
+        const unsigned tab_a = table_of(a, c, rawa_next), tab_b = table_of(b, c, rawb_next);
+        rawa_next = code_at(a, c + 1, step);
+        rawb_next = code_at(b, c + 1, step);
+        unsigned dsrc = diag_in, fs = i1, ff = i2, lm = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const unsigned diag = pk_add(dsrc, __builtin_amdgcn_perm(tab_b, tab_a, SEL[k]));
+            dsrc = G[k];
+            fs &= SEG[k];
+            const unsigned hs = pk_max_i(pk_max_i(diag, E[k]), fs), h = pk_max_i(hs, ff), hsgo = pk_subs_u(hs, 0x00080008u);
+            E[k] = pk_max_u(pk_subs_u(E[k], 0x00020002u), hsgo);
+            fs = pk_max_u(pk_subs_u(fs, 0x00020002u), hsgo);
+            ff = pk_max_u(pk_subs_u(ff, 0x00020002u), hsgo);
+            G[k] = pk_add(h, G_ZERO);
+            lm = pk_max_u(lm, h);
+        }
+        diag_in = i0;
+        p0 = G[R - 1];
+        p1 = fs;
+        p2 = ff;
+        p3 = pk_max_u(i3, lm);
+        // the first lane of this column to exceed everything above it, with a value its own strip never held: keep the strip
+        const unsigned cand = pk_subs_u(lm, pk_max_u(i3, best));
+        best = pk_max_u(best, lm);
+        if (cand & 0xFFFFu) { col_a = c; keep(my_a, G); }
+        if (cand >> 16) { col_b = c; keep(my_b, G); }
+        if (lane == 63) {
+            const int cm_a = (int)(p3 & 0xFFFFu), cm_b = (int)(p3 >> 16);
+            if (!stop_a && c >= 0 && c < a.count) {
+                if (cm_a > run_a) {
+                    run_a = cm_a;
+                    if (a.lanes == 16 && run_a + BIAS >= 255) { ovf_a = 1; stop_a = 1; }
+                    else endc_a = c;
+                }
+                if (!stop_a && (cm_a == a.terminate || c == a.count - 1)) stop_a = 1;
+            }
+            if (!stop_b && c >= 0 && c < b.count) {
+                if (cm_b > run_b) {
+                    run_b = cm_b;
+                    if (b.lanes == 16 && run_b + BIAS >= 255) { ovf_b = 1; stop_b = 1; }
+                    else endc_b = c;
+                }
+                if (!stop_b && (cm_b == b.terminate || c == b.count - 1)) stop_b = 1;
+            }
+        }
+        if (bcast63(stop_a & stop_b)) break;
+    }
+    // the end cells' rows out of the holders' copies
+    auto finish = [&](const HalfIn& h, int run, int endc, int ovf, int col, unsigned best_half, const uint32_t* mine, int shift, PassOut& o) {
+        const int rm = bcast63(run), ec = bcast63(endc);
+        o.overflow = bcast63(ovf);
+        o.score = o.overflow ? 255 : rm;
+        o.ref = ec >= 0 ? h.first + ec * step : (h.lanes == 16 ? -1 : 0);
+        int er = -1;
+        if (rm > 0 && ec >= 0 && !o.overflow) {
+            const unsigned long long holders = __ballot((int)best_half == rm && col == ec);
+            if (!holders) o.overflow = 2;          // (never, unless the bookkeeping above is wrong: the read is failed, not mis-aligned)
+            if (holders) {
+                const int l = __ffsll((long long)holders) - 1;
+                int kk = R;
+                const unsigned want = (unsigned)(rm - 6) & 0xFFFFu;
+#pragma unroll
+                for (int k = R - 1; k >= 0; --k)
+                    if (((mine[k] >> shift) & 0xFFFFu) == want) kk = k;
+                er = l * R + __builtin_amdgcn_readlane(kk, l);
+            }
+        }
+        o.read = h.m - 1;
+        if (rm == 0) { if (h.m - 1 > 0) o.read = 0; }
+        else if (er >= 0 && er < h.m - 1) o.read = er;
+    };
+    asm volatile("" ::: "memory");                 // (the copies above are read back through another pointer)
+    finish(a, run_a, endc_a, ovf_a, col_a, best & 0xFFFFu, my_a, 0, oa);
+    finish(b, run_b, endc_b, ovf_b, col_b, best >> 16, my_b, 16, ob);
+}
+
+struct JobPair { int32_t a, b; };            // indices into the job table; b < 0: read a alone
+
+// rows per lane of a read's longer segmentation (the 8-bit one), rounded up to the strips the packed pass exists in
+__device__ __host__ inline int strip_of(int m) { return (((((m + 15) / 16) * 16) + 63) >> 6); }
+
+// One wavefront per pair of reads (JobPair): both through the 8-bit segmentation, those that overflow through the 16-bit one,
+// those with a score through the reversed pass.  One kernel per strip size R (rows per lane): a launch takes the pairs whose
+// longer read needs more than r_lo and at most r_hi = R rows per lane (one size per kernel keeps the register count at
+// 4 R + ~110: two wavefronts per SIMD at every size, three up to 16 rows per lane -- measured no faster than two; all sizes in
+// one kernel cost 342 registers).  LDS: two copies of a strip.
+constexpr int pk_lds_bytes(int R) { return 2 * 64 * ((R + 3) & ~3) * 4; }
+template <int R, int W>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void sw_ends_pair_kernel(Job* __restrict__ jobs, const JobPair* __restrict__ pairs, const int* __restrict__ n_pairs,
+                                                          const int8_t* __restrict__ ref, const int8_t* __restrict__ seq, int r_lo, int r_hi) {
+    extern __shared__ uint32_t snap[];
+    if ((int)blockIdx.x >= *n_pairs) return;
+    const JobPair pr = pairs[blockIdx.x];
+    Job& JA = jobs[pr.a];
+    Job& JB = jobs[pr.b >= 0 ? pr.b : pr.a];
+    const bool two = pr.b >= 0;
+    {
+        const int ra = strip_of(JA.m), rb = two ? strip_of(JB.m) : 0, need = ra > rb ? ra : rb;
+        if (need <= r_lo || need > r_hi) return;
+    }
+    const long long t_start = wall_clock64();
+    // (the job fields are the same in every lane: kept in scalar registers, so that the passes' bounds tests are scalar too)
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni64 = [&](int64_t v) { return (int64_t)(((uint64_t)(uint32_t)uni((int)(v >> 32)) << 32) | (uint32_t)uni((int)v)); };
+    const int na = uni(JA.n), ma = uni(JA.m), nb = uni(JB.n), mb = uni(JB.m);
+    const int8_t* rfa = ref + uni(JA.ref_off);
+    const int8_t* rda = seq + uni64(JA.seq_off);
+    const int8_t* rfb = ref + uni(JB.ref_off);
+    const int8_t* rdb = seq + uni64(JB.seq_off);
+    // pass 0: the 8-bit segmentation; pass 1: the 16-bit one for the reads that left the 8-bit range; pass 2: the begin cells,
+    // from the end cells backwards (one call site: the passes of every strip size are inlined into this loop once)
+    PassOut fa = {0, 0, 0, 0}, fb = {0, 0, 0, 0}, o1 = {0, 0, 0, 0}, o2 = {0, 0, 0, 0};
+    int wide_a = 0, wide_b = 0, bad = 0;
+    int rbeg_a = -1, qbeg_a = -1, rbeg_b = -1, qbeg_b = -1;
+    for (int pass = 0; pass < 3; ++pass) {
+        bool on_a, on_b;
+        if (pass == 0) { on_a = true; on_b = two; }
+        else if (pass == 1) { on_a = fa.overflow == 1; on_b = two && fb.overflow == 1; }
+        else { on_a = fa.score > 0 && fa.ref >= 0; on_b = two && fb.score > 0 && fb.ref >= 0; }
+        if (!on_a && !on_b) continue;
+        const bool rev = pass == 2;
+        const HalfIn ha = {rfa, (rev && on_a) ? fa.ref : 0, !on_a ? 0 : (rev ? fa.ref + 1 : na), rda, (rev && on_a) ? fa.read : 0,
+                           !on_a ? 0 : (rev ? fa.read + 1 : ma), (pass == 1 || (rev && wide_a)) ? 8 : 16, (rev && on_a) ? fa.score : -1};
+        const HalfIn hb = {rfb, (rev && on_b) ? fb.ref : 0, !on_b ? 0 : (rev ? fb.ref + 1 : nb), rdb, (rev && on_b) ? fb.read : 0,
+                           !on_b ? 0 : (rev ? fb.read + 1 : mb), (pass == 1 || (rev && wide_b)) ? 8 : 16, (rev && on_b) ? fb.score : -1};
+        score_pass_pk<R>(snap, ha, hb, rev ? -1 : 1, rev ? -1 : 1, o1, o2);
+        bad |= (on_a && o1.overflow == 2) | ((on_b && o2.overflow == 2) << 1);
+        if (pass == 0) { fa = o1; fb = o2; }
+        else if (pass == 1) {
+            if (on_a) { fa = o1; wide_a = 1; }
+            if (on_b) { fb = o2; wide_b = 1; }
+        } else {
+            if (on_a) { rbeg_a = o1.ref; qbeg_a = fa.read - o1.read; }
+            if (on_b) { rbeg_b = o2.ref; qbeg_b = fb.read - o2.read; }
+        }
+    }
+    if (threadIdx.x == 0) {
+        const int32_t ticks = (int32_t)(wall_clock64() - t_start);
+        if (bad & 1) JA.state = ST_ERR;
+        if (two && (bad & 2)) JB.state = ST_ERR;
+        JA.score = fa.score; JA.wide = wide_a; JA.ref_end = fa.ref; JA.read_end = fa.read; JA.ref_begin = rbeg_a; JA.read_begin = qbeg_a;
+        JA.t_ends = ticks;
+        if (two) {
+            JB.score = fb.score; JB.wide = wide_b; JB.ref_end = fb.ref; JB.read_end = fb.read; JB.ref_begin = rbeg_b; JB.read_begin = qbeg_b;
+            JB.t_ends = ticks;
+        }
+    }
+}
+
+// One launch per call (and a catch-all): the kernel of the strip size that holds the call's longest ordinary read takes every
+// pair up to that size -- shorter reads leave lanes idle, which costs less than the tail of a launch of their own (measured:
+// eight size-sorted launches 11.6 ms, one 7.7 ms for 8 000 reads) -- and the widest kernel takes what is longer.
+inline void launch_pair_kernels(hipStream_t st, int np, Job* dj, const JobPair* dp, const int* dn, const int8_t* dref, const int8_t* dseq, int need) {
+    int size = 24;
+#define PA_PAIR_SIZE(N)                                                                                                                          \
+    if (need <= N && size == 24 && N < 24) {                                                                                                     \
+        size = N;                                                                                                                                \
+        hipLaunchKernelGGL((sw_ends_pair_kernel<N, (N <= 16 ? 3 : 2)>), dim3((unsigned)np), dim3(64), pk_lds_bytes(N), st, dj, dp, dn, dref, dseq, 0, N); \
+    }
+    PA_PAIR_SIZE(8) PA_PAIR_SIZE(12) PA_PAIR_SIZE(16) PA_PAIR_SIZE(18) PA_PAIR_SIZE(20) PA_PAIR_SIZE(22)
+#undef PA_PAIR_SIZE
+    hipLaunchKernelGGL((sw_ends_pair_kernel<24, 2>), dim3((unsigned)np), dim3(64), pk_lds_bytes(24), st, dj, dp, dn, dref, dseq, size == 24 ? 0 : size, 24);
+}
+
 // inclusive prefix sum across the wavefront (same DPP pattern as wave_prefix_max)
 __device__ __forceinline__ int wave_prefix_add(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
@@ -606,7 +869,8 @@ struct pa_realigner {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DBuf d_ref, d_seq, d_jobs, d_dir, d_ops, d_counter;
+    DBuf d_ref, d_seq, d_jobs, d_dir, d_ops, d_counter, d_pairs, d_order;
+    std::vector<JobPair> pairs;                                  // host-fed form: the reads two by two, like sizes together
     pa_enc::HBuf h_meta, h_back;                                 // device-fed form: window text + tables up, counters back
     std::vector<Job> jobs;
     std::vector<uint32_t> ops;
@@ -763,12 +1027,39 @@ int pa_realigner_align_windows(pa_realigner* r, int32_t n_windows, const char* r
         const int rows = ((max_m + 15) / 16) * 16, R = (rows + 63) / 64;
         const size_t lds = rows > REG_ROWS ? (size_t)64 * R * 4 : 0;
         RA_HIP(hipEventRecord(r->ev[0], r->stream));
-        // the instantiation whose register strip just covers the longest read of the call (fewer registers: more wavefronts
-        // per SIMD); a read beyond 24 rows per lane takes the LDS form inside the widest one
-        if (R <= 12) hipLaunchKernelGGL(sw_ends_kernel<12>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
-        else if (R <= 16) hipLaunchKernelGGL(sw_ends_kernel<16>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
-        else if (R <= 20) hipLaunchKernelGGL(sw_ends_kernel<20>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
-        else hipLaunchKernelGGL(sw_ends_kernel<24>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
+        static const bool single = getenv("PA_REALIGN_SINGLE") != nullptr;      // round 4's one-read-per-wavefront kernels (A/B runs)
+        if (single) {
+            // the instantiation whose register strip just covers the longest read of the call (fewer registers: more wavefronts
+            // per SIMD); a read beyond 24 rows per lane takes the LDS form inside the widest one
+            if (R <= 12) hipLaunchKernelGGL(sw_ends_kernel<12>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
+            else if (R <= 16) hipLaunchKernelGGL(sw_ends_kernel<16>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
+            else if (R <= 20) hipLaunchKernelGGL(sw_ends_kernel<20>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
+            else hipLaunchKernelGGL(sw_ends_kernel<24>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 0, 1 << 30);
+        } else {
+            // two reads per wavefront (score_pass_pk), like sizes together; reads beyond 24 rows per lane one by one in the LDS form
+            std::vector<int32_t> order;
+            for (int32_t k = 0; k < n_reads; ++k)
+                if (r->jobs[(size_t)k].state == ST_NEW && strip_of(r->jobs[(size_t)k].m) <= 24) order.push_back(k);
+            std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+                const Job &a = r->jobs[(size_t)x], &b = r->jobs[(size_t)y];
+                return a.n != b.n ? a.n < b.n : (a.m != b.m ? a.m < b.m : x < y);
+            });
+            r->pairs.assign(1 + (order.size() + 1) / 2, JobPair{0, 0});
+            const int32_t np = (int32_t)((order.size() + 1) / 2);
+            r->pairs[0] = JobPair{np, 0};                                        // [0].a = the number of pairs (read by the kernels)
+            for (int32_t i = 0; i < np; ++i)
+                r->pairs[(size_t)i + 1] = JobPair{order[(size_t)2 * i], (size_t)2 * i + 1 < order.size() ? order[(size_t)2 * i + 1] : -1};
+            RA_ALLOC(r->d_pairs, sizeof(JobPair) * r->pairs.size());
+            RA_HIP(hipMemcpyAsync(r->d_pairs.p, r->pairs.data(), sizeof(JobPair) * r->pairs.size(), hipMemcpyHostToDevice, r->stream));
+            const JobPair* dp = static_cast<const JobPair*>(r->d_pairs.p);
+            const int* dn = reinterpret_cast<const int*>(dp);
+            if (np > 0) {
+                int hi = 0;
+                for (int32_t k : order) hi = std::max(hi, strip_of(r->jobs[(size_t)k].m));
+                launch_pair_kernels(r->stream, np, dj, dp + 1, dn, dref, dseq, hi);
+            }
+            if (R > 24) hipLaunchKernelGGL(sw_ends_kernel<24>, dim3(n_reads), dim3(64), lds, r->stream, dj, dref, dseq, 24, 1 << 30);
+        }
         RA_HIP(hipGetLastError());
         RA_HIP(hipEventRecord(r->ev[1], r->stream));
     }
@@ -942,6 +1233,33 @@ __global__ __launch_bounds__(256) void jobs_of_reads_kernel(const pa_enc::ReadRe
     jobs[k] = J;
 }
 
+// The reads two by two for sw_ends_pair_kernel, like window lengths together (a counting sort over n >> shift, one workgroup:
+// a call has a few thousand reads): pairs[0].a = the number of pairs, pairs[1 ..] the pairs.  Reads beyond 24 rows per lane
+// stay out (the one-read kernel's LDS form takes them).
+__global__ __launch_bounds__(1024) void pair_jobs_kernel(const Job* __restrict__ jobs, int n_reads, int shift, int32_t* __restrict__ order,
+                                                         JobPair* __restrict__ pairs) {
+    __shared__ int hist[2048];
+    __shared__ int total;
+    for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0;
+    __syncthreads();
+    auto key_of = [&](const Job& J) { const int k = J.n >> shift; return k < 2047 ? k : 2047; };
+    for (int k = threadIdx.x; k < n_reads; k += 1024)
+        if (jobs[k].state == ST_NEW && strip_of(jobs[k].m) <= 24) atomicAdd(&hist[key_of(jobs[k])], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {                       // exclusive scan of 2048 counters: a few microseconds
+        int run = 0;
+        for (int i = 0; i < 2048; ++i) { const int c = hist[i]; hist[i] = run; run += c; }
+        total = run;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_reads; k += 1024)
+        if (jobs[k].state == ST_NEW && strip_of(jobs[k].m) <= 24) order[atomicAdd(&hist[key_of(jobs[k])], 1)] = k;
+    __syncthreads();
+    const int np = (total + 1) / 2;
+    if (threadIdx.x == 0) pairs[0] = JobPair{np, 0};
+    for (int i = threadIdx.x; i < np; i += 1024) pairs[i + 1] = JobPair{order[2 * i], 2 * i + 1 < total ? order[2 * i + 1] : -1};
+}
+
 // what the host does between the two stages (pa_realigner_align_windows): which reads go on, their first band, their slice of
 // the direction workspace (rows of at most 129 slots: half width <= 64)
 __global__ __launch_bounds__(256) void band_layout_kernel(Job* __restrict__ jobs, int n_reads, int* __restrict__ counters,
@@ -1110,10 +1428,27 @@ int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window
         // SIMD up to 20 rows per lane); LDS for the rows beyond the widest strip
         const int rows = ((max_m + 15) / 16) * 16, R = (rows + 63) / 64;
         const size_t lds = rows > REG_ROWS ? (size_t)64 * R * 4 : 0;
-        hipLaunchKernelGGL(sw_ends_kernel<12>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 0, 12);
-        hipLaunchKernelGGL(sw_ends_kernel<16>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 12, 16);
-        hipLaunchKernelGGL(sw_ends_kernel<20>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 16, 20);
-        hipLaunchKernelGGL(sw_ends_kernel<24>, dim3(n_reads), dim3(64), lds, st, dj, dref, dseq, 20, 1 << 30);
+        static const bool single = getenv("PA_REALIGN_SINGLE") != nullptr;      // round 4's one-read-per-wavefront kernels (A/B runs)
+        if (single) {
+            hipLaunchKernelGGL(sw_ends_kernel<12>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 0, 12);
+            hipLaunchKernelGGL(sw_ends_kernel<16>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 12, 16);
+            hipLaunchKernelGGL(sw_ends_kernel<20>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 16, 20);
+            hipLaunchKernelGGL(sw_ends_kernel<24>, dim3(n_reads), dim3(64), lds, st, dj, dref, dseq, 20, 1 << 30);
+        } else {
+            // two reads per wavefront, like window lengths together (pair_jobs_kernel); every instantiation over the pair table
+            RA_ALLOC(r->d_pairs, sizeof(JobPair) * ((size_t)n_reads / 2 + 2));
+            RA_ALLOC(r->d_order, sizeof(int32_t) * (size_t)n_reads);
+            int shift = 0;
+            while ((max_wl >> shift) >= 2047) ++shift;
+            JobPair* dp = static_cast<JobPair*>(r->d_pairs.p);
+            hipLaunchKernelGGL(pair_jobs_kernel, dim3(1), dim3(1024), 0, st, dj, n_reads, shift, static_cast<int32_t*>(r->d_order.p), dp);
+            const int* dn = reinterpret_cast<const int*>(dp);
+            const unsigned np = (unsigned)(n_reads + 1) / 2;
+            // (the reads' lengths are known on the device only: a region's ordinary read keeps its L aligned bases and some
+            // inserts; what is longer than L + L / 10 + 16 goes to the catch-all launch)
+            launch_pair_kernels(st, (int)np, dj, dp + 1, dn, dref, dseq, strip_of(std::min(max_m, max_region_len + max_region_len / 10 + 16)));
+            if (rows > REG_ROWS) hipLaunchKernelGGL(sw_ends_kernel<24>, dim3(n_reads), dim3(64), lds, st, dj, dref, dseq, 24, 1 << 30);
+        }
         RA_HIP(hipGetLastError());
     }
     RA_HIP(hipEventRecord(r->ev[1], st));
