@@ -599,8 +599,11 @@ __device__ __forceinline__ int wave_max(int v) {
 // the operations.  cap: ints per band array (hb, eb, hc; one set per wavefront); the bytes behind them hold the
 // trace-back steps, the base codes of the aligned windows and the per-step operation classes (3 (m + n) + 4 bytes).
 // ops_counter: running number of operations written to opsws.
-constexpr int BAND_WAVES = 3;
-
+// BAND_WAVES = 3 races three widths (the lowest latency per read: what a call of a few hundred reads wants); = 1 tries the
+// widths one after the other in one wavefront (a third of the wavefronts, LDS and direction bytes, and no work on widths the
+// narrower one made unnecessary: what a call that fills the chip anyway wants).  Either way an attempt stops as soon as it
+// cannot reach the score any more: a later row gains at most one match over the best cell so far.
+template <int BAND_WAVES>
 __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__ jobs, const int8_t* __restrict__ ref,
                                                                const int8_t* __restrict__ seq, uint8_t* __restrict__ dirws,
                                                                uint32_t* __restrict__ opsws,
@@ -650,10 +653,15 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
             for (int k = lane; k < slots; k += 64) { hb[k] = 0; eb[k] = 0; hc[k] = 0; }
             int best = 0;
             bool overtaken = false;                     // a narrower width of this round has reached the score already
+            bool hopeless = false;
             for (int i = 0; i < m; ++i) {
                 if (wave > 0 && (i & 7) == 0) {
                     for (int w = 0; w < wave; ++w) overtaken = overtaken || vbest[w] >= score;
                     if (overtaken) break;
+                }
+                if ((i & 15) == 0 && i > 0) {
+                    // rows i .. m - 1 are still to come: each adds at most a match to the best cell of the rows before
+                    if (wave_max(best) + S_MATCH * (m - i) < score) { hopeless = true; break; }
                 }
                 const int x = max(i - bw, 0), xp = max(i - 1 - bw, 0), sh = x - xp;
                 const int end = min(n - 1, i + bw), U = end - x + 1, edge = min(end + 1, width - 1);
@@ -704,7 +712,7 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
                 if (U > 64)
                     for (int u = 1 + lane; u <= U; u += 64) hb[u] = hc[u];
             }
-            result = overtaken ? -3 : wave_max(best);
+            result = overtaken ? -3 : (hopeless ? 0 : wave_max(best));
         }
         if (lane == 0) vbest[wave] = result;
         __syncthreads();
@@ -847,6 +855,25 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
     }
 }
 
+// wavefronts per read of the band stage: three widths at once for a call that does not fill the chip on its own, one after the
+// other beyond that (PA_BAND_WAVES overrides)
+inline int band_waves_for(int n_reads) {
+    static const int forced = getenv("PA_BAND_WAVES") ? atoi(getenv("PA_BAND_WAVES")) : 0;
+    if (forced == 1 || forced == 3) return forced;
+    return n_reads >= 3072 ? 1 : 3;
+}
+inline hipError_t launch_band(hipStream_t st, int nw, int n_reads, size_t lds, Job* dj, const int8_t* dref, const int8_t* dseq, uint8_t* dir,
+                              uint32_t* ops, unsigned long long* counter, int cap) {
+    if (lds > 64 * 1024) {
+        const hipError_t e = nw == 1 ? hipFuncSetAttribute(reinterpret_cast<const void*>(band_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                     : hipFuncSetAttribute(reinterpret_cast<const void*>(band_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (nw == 1) hipLaunchKernelGGL(band_kernel<1>, dim3(n_reads), dim3(64), lds, st, dj, dref, dseq, dir, ops, counter, cap);
+    else hipLaunchKernelGGL(band_kernel<3>, dim3(n_reads), dim3(192), lds, st, dj, dref, dseq, dir, ops, counter, cap);
+    return hipGetLastError();
+}
+
 struct DBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -889,6 +916,10 @@ struct pa_realigner {
     do {                                                                                                \
         if (!(buf).ensure(bytes_)) return pa::set_error(PA_ERR_HIP, "hipMalloc failed in re-aligner workspace"); \
     } while (0)
+
+namespace {
+int band_rounds_host(pa_realigner* r, Job* dj, const int8_t* dref, const int8_t* dseq, int32_t n_reads, int first_round, int aux, int nw);
+}
 
 extern "C" {
 
@@ -1084,41 +1115,10 @@ int pa_realigner_align_windows(pa_realigner* r, int32_t n_windows, const char* r
     RA_ALLOC(r->d_ops, sizeof(uint32_t) * (size_t)std::max<int64_t>(ops_total, 1));
     RA_ALLOC(r->d_counter, 8);
     RA_HIP(hipMemsetAsync(r->d_counter.p, 0, 8, r->stream));
-    for (int round = 0; round < 3; ++round) {
-        int64_t dir_total = 0;
-        int cap = 0, pending = 0;
-        for (Job& J : r->jobs) {
-            if (J.state == ST_WIDER) J.state = ST_BAND;
-            if (J.state != ST_BAND) continue;
-            const int n2 = J.ref_end - J.ref_begin + 1, m2 = J.read_end - J.read_begin + 1;
-            J.dir_width = round == 0 ? std::min(n2, 129) : n2;
-            if (round == 0 && std::min(2 * J.bw + 1, n2) > J.dir_width) J.dir_width = n2;   // first band already wider
-            J.dir_off = dir_total;
-            dir_total += (int64_t)m2 * J.dir_width * BAND_WAVES;
-            const int bw_cap = J.dir_width >= n2 ? INT32_MAX / 4 : (J.dir_width - 1) / 2;
-            cap = std::max(cap, (int)std::min<int64_t>(2 * (int64_t)bw_cap + 3, n2 + 2) + 2);
-            ++pending;
-        }
-        if (!pending) break;
-        const size_t lds = (size_t)cap * 12 * BAND_WAVES + (size_t)aux + 64;
-        if (lds > 150 * 1024) return pa::set_error(PA_ERR_INVALID, "alignment too long for the band stage");
-        RA_ALLOC(r->d_dir, (size_t)std::max<int64_t>(dir_total, 1));
-        RA_HIP(hipMemcpyAsync(dj, r->jobs.data(), sizeof(Job) * (size_t)n_reads, hipMemcpyHostToDevice, r->stream));
-        if (lds > 64 * 1024)
-            RA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
-        RA_HIP(hipEventRecord(r->ev[2], r->stream));
-        hipLaunchKernelGGL(band_kernel, dim3(n_reads), dim3(64 * BAND_WAVES), lds, r->stream, dj, dref, dseq,
-                           static_cast<uint8_t*>(r->d_dir.p), static_cast<uint32_t*>(r->d_ops.p),
-                           static_cast<unsigned long long*>(r->d_counter.p), cap);
-        RA_HIP(hipGetLastError());
-        RA_HIP(hipEventRecord(r->ev[3], r->stream));
-        lap("band setup");
-        RA_HIP(hipMemcpyAsync(r->jobs.data(), dj, sizeof(Job) * (size_t)n_reads, hipMemcpyDeviceToHost, r->stream));
-        RA_HIP(hipStreamSynchronize(r->stream));
-        lap("band kernel");
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, r->ev[2], r->ev[3]) == hipSuccess) r->band_ms += ms;
+    {
+        const int rc = band_rounds_host(r, dj, dref, dseq, n_reads, 0, aux, band_waves_for(n_reads));
+        if (rc != PA_OK) return rc;
+        lap("band stage");
     }
     {
         float ms = 0.0f;
@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(1024) void pair_jobs_kernel(const Job* __restrict__
 // what the host does between the two stages (pa_realigner_align_windows): which reads go on, their first band, their slice of
 // the direction workspace (rows of at most 129 slots: half width <= 64)
 __global__ __launch_bounds__(256) void band_layout_kernel(Job* __restrict__ jobs, int n_reads, int* __restrict__ counters,
-                                                          unsigned long long dir_capacity) {
+                                                          unsigned long long dir_capacity, int band_waves) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n_reads) return;
     Job& J = jobs[k];
@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(256) void band_layout_kernel(Job* __restrict__ jobs
     J.dir_width = min(n2, 129);
     bool wider = min(2 * J.bw + 1, n2) > J.dir_width;                         // the first band is wider already
     if (!wider) {
-        const unsigned long long need = (unsigned long long)m2 * J.dir_width * BAND_WAVES;
+        const unsigned long long need = (unsigned long long)m2 * J.dir_width * band_waves;
         const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(counters + 6), need);
         if (at + need > dir_capacity) wider = true;
         else J.dir_off = (int64_t)at;
@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(256) void apply_alignment_kernel(const Job* __restr
 
 // the band rounds laid out by the host over r->jobs (states ST_BAND / ST_WIDER pending): round 0 with rows of at most 129 slots,
 // later rounds with full rows; dj holds the table on the device before and after
-int band_rounds_host(pa_realigner* r, Job* dj, const int8_t* dref, const int8_t* dseq, int32_t n_reads, int first_round, int aux) {
+int band_rounds_host(pa_realigner* r, Job* dj, const int8_t* dref, const int8_t* dseq, int32_t n_reads, int first_round, int aux, int nw) {
     for (int round = first_round; round < 3; ++round) {
         int64_t dir_total = 0;
         int cap = 0, pending = 0;
@@ -1334,24 +1334,19 @@ int band_rounds_host(pa_realigner* r, Job* dj, const int8_t* dref, const int8_t*
             J.dir_width = round == 0 ? std::min(n2, 129) : n2;
             if (round == 0 && std::min(2 * J.bw + 1, n2) > J.dir_width) J.dir_width = n2;   // first band already wider
             J.dir_off = dir_total;
-            dir_total += (int64_t)m2 * J.dir_width * BAND_WAVES;
+            dir_total += (int64_t)m2 * J.dir_width * nw;
             const int bw_cap = J.dir_width >= n2 ? INT32_MAX / 4 : (J.dir_width - 1) / 2;
             cap = std::max(cap, (int)std::min<int64_t>(2 * (int64_t)bw_cap + 3, n2 + 2) + 2);
             ++pending;
         }
         if (!pending) break;
-        const size_t lds = (size_t)cap * 12 * BAND_WAVES + (size_t)aux + 64;
+        const size_t lds = (size_t)cap * 12 * nw + (size_t)aux + 64;
         if (lds > 150 * 1024) return pa::set_error(PA_ERR_INVALID, "alignment too long for the band stage");
         RA_ALLOC(r->d_dir, (size_t)std::max<int64_t>(dir_total, 1));
         RA_HIP(hipMemcpyAsync(dj, r->jobs.data(), sizeof(Job) * (size_t)n_reads, hipMemcpyHostToDevice, r->stream));
-        if (lds > 64 * 1024)
-            RA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
         RA_HIP(hipEventRecord(r->ev[2], r->stream));
-        hipLaunchKernelGGL(band_kernel, dim3(n_reads), dim3(64 * BAND_WAVES), lds, r->stream, dj, dref, dseq,
-                           static_cast<uint8_t*>(r->d_dir.p), static_cast<uint32_t*>(r->d_ops.p),
-                           static_cast<unsigned long long*>(r->d_counter.p), cap);
-        RA_HIP(hipGetLastError());
+        RA_HIP(launch_band(r->stream, nw, n_reads, lds, dj, dref, dseq, static_cast<uint8_t*>(r->d_dir.p), static_cast<uint32_t*>(r->d_ops.p),
+                           static_cast<unsigned long long*>(r->d_counter.p), cap));
         RA_HIP(hipEventRecord(r->ev[3], r->stream));
         RA_HIP(hipMemcpyAsync(r->jobs.data(), dj, sizeof(Job) * (size_t)n_reads, hipMemcpyDeviceToHost, r->stream));
         RA_HIP(hipStreamSynchronize(r->stream));
@@ -1403,10 +1398,11 @@ int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window
     // operations: a read's worst case is n2 + m2 + 4 <= its window + its bases + 4
     const int64_t ops_cap_total = seq_bytes + (int64_t)n_reads * (max_wl + 4);
     RA_ALLOC(r->d_ops, sizeof(uint32_t) * (size_t)std::max<int64_t>(ops_cap_total, 1));
+    const int nw = band_waves_for(n_reads);
     // direction bytes of the first rows (<= 129 slots): what the reads of a region at ordinary length need; what does not fit
     // there is laid out by the host afterwards
     const unsigned long long dir_capacity = std::min<unsigned long long>((unsigned long long)n_reads * (unsigned long long)(max_region_len + 64) *
-                                                                             129ull * BAND_WAVES, 24ull << 30);
+                                                                             129ull * nw, 24ull << 30);
     RA_ALLOC(r->d_dir, (size_t)std::max<unsigned long long>(dir_capacity, 1));
     RA_HIP(hipMemcpyAsync(r->d_ref.p, hm, meta, hipMemcpyHostToDevice, st));
     RA_HIP(hipMemsetAsync(r->d_counter.p, 0, 8 + DC_N * 4, st));
@@ -1452,18 +1448,14 @@ int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window
         RA_HIP(hipGetLastError());
     }
     RA_HIP(hipEventRecord(r->ev[1], st));
-    hipLaunchKernelGGL(band_layout_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, dj, n_reads, d_ctr, dir_capacity);
+    hipLaunchKernelGGL(band_layout_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, dj, n_reads, d_ctr, dir_capacity, nw);
     const int aux = 3 * (max_wl + max_m) + 4;
     {
         const int cap = std::min(2 * 64 + 3, max_wl + 2) + 2;
-        const size_t lds = (size_t)cap * 12 * BAND_WAVES + (size_t)aux + 64;
+        const size_t lds = (size_t)cap * 12 * nw + (size_t)aux + 64;
         if (lds > 150 * 1024) return pa::set_error(PA_ERR_INVALID, "alignment too long for the band stage");
-        if (lds > 64 * 1024)
-            RA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         RA_HIP(hipEventRecord(r->ev[2], st));
-        hipLaunchKernelGGL(band_kernel, dim3(n_reads), dim3(64 * BAND_WAVES), lds, st, dj, dref, dseq, static_cast<uint8_t*>(r->d_dir.p),
-                           static_cast<uint32_t*>(r->d_ops.p), d_opsctr, cap);
-        RA_HIP(hipGetLastError());
+        RA_HIP(launch_band(st, nw, n_reads, lds, dj, dref, dseq, static_cast<uint8_t*>(r->d_dir.p), static_cast<uint32_t*>(r->d_ops.p), d_opsctr, cap));
         RA_HIP(hipEventRecord(r->ev[3], st));
     }
     hipLaunchKernelGGL(count_states_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, dj, n_reads, d_ctr);
@@ -1490,7 +1482,7 @@ int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window
         RA_HIP(hipMemcpyAsync(r->jobs.data(), dj, sizeof(Job) * (size_t)n_reads, hipMemcpyDeviceToHost, st));
         RA_HIP(hipStreamSynchronize(st));
         if (more) {
-            const int rc = band_rounds_host(r, dj, dref, dseq, n_reads, 1, aux);
+            const int rc = band_rounds_host(r, dj, dref, dseq, n_reads, 1, aux, nw);
             if (rc != PA_OK) return rc;
         }
         int aligned = 0;
