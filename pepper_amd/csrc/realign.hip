@@ -618,10 +618,12 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
     int* hc = hb + 2 * cap;
     int* sh_best = sm + BAND_WAVES * 3 * cap;                 // [BAND_WAVES] result of each wavefront's attempt
     const int step_cap = m + n + 2;
-    uint8_t* steps = reinterpret_cast<uint8_t*>(sh_best + 4);
-    int8_t* lrf = reinterpret_cast<int8_t*>(steps + step_cap);
+    int8_t* lrf = reinterpret_cast<int8_t*>(sh_best + 4);
     int8_t* lrd = lrf + n;
-    uint8_t* cls = reinterpret_cast<uint8_t*>(lrd + m);
+    // the walk back's steps and the operation classes: written and read once per read, by the winning wavefront alone -- in
+    // the workspace behind the read's direction bytes, not in LDS (LDS per read is what bounds the wavefronts per SIMD here)
+    uint8_t* steps = dirws + J.dir_off + (size_t)BAND_WAVES * m * J.dir_width;
+    uint8_t* cls = steps + step_cap;
     {
         const int8_t* rf = ref + J.ref_off + J.ref_begin;
         const int8_t* rd = seq + J.seq_off + J.read_begin;
@@ -790,6 +792,7 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
         if (lane == 0) J.state = ST_ERR;
         return;
     }
+    __threadfence();                                  // (steps: written by some lanes, read by others below)
     const long long t_trace = wall_clock64();
 
     // Operations in alignment order: soft clip, the first cell, the steps backwards, soft clip; aligned pairs are
@@ -811,6 +814,7 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
         carry_q += bcast63(pq);
     }
     wave_lds_order();
+    __threadfence();                                  // (cls likewise)
     int nruns = 0;
     for (int t0 = 0; t0 < total; t0 += 64) {
         const int t = t0 + lane;
@@ -857,6 +861,10 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
 
 // wavefronts per read of the band stage: three widths at once for a call that does not fill the chip on its own, one after the
 // other beyond that (PA_BAND_WAVES overrides)
+// slots per row of the direction bytes a read gets first: half width <= 64 for three wavefronts per read; <= 128 for one (its one
+// copy of the rows costs less than the three narrow ones, and the reads that outgrow it -- 1.5 % outgrew 64 on nanopore-like
+// data -- each cost a launch that waits for a few 1 200-slot wavefronts)
+inline int first_band_width(int nw) { return nw == 1 ? 257 : 129; }
 inline int band_waves_for(int n_reads) {
     static const int forced = getenv("PA_BAND_WAVES") ? atoi(getenv("PA_BAND_WAVES")) : 0;
     if (forced == 1 || forced == 3) return forced;
@@ -1058,7 +1066,10 @@ int pa_realigner_align_windows(pa_realigner* r, int32_t n_windows, const char* r
         const int rows = ((max_m + 15) / 16) * 16, R = (rows + 63) / 64;
         const size_t lds = rows > REG_ROWS ? (size_t)64 * R * 4 : 0;
         RA_HIP(hipEventRecord(r->ev[0], r->stream));
-        static const bool single = getenv("PA_REALIGN_SINGLE") != nullptr;      // round 4's one-read-per-wavefront kernels (A/B runs)
+        // two reads per wavefront halve the instructions per cell but leave half the wavefronts: a call that cannot fill the 1 024
+        // SIMDs even one read per wavefront (a region on its own) keeps the one-read kernels, whose wavefronts finish sooner
+        static const char* mode = getenv("PA_REALIGN_SINGLE");                   // "1": always one read per wavefront, "0": never (A/B runs)
+        const bool single = mode ? mode[0] == '1' : n_reads <= 2048;
         if (single) {
             // the instantiation whose register strip just covers the longest read of the call (fewer registers: more wavefronts
             // per SIMD); a read beyond 24 rows per lane takes the LDS form inside the widest one
@@ -1110,7 +1121,7 @@ int pa_realigner_align_windows(pa_realigner* r, int32_t n_windows, const char* r
         J.bw = std::abs(n2 - m2) + 1;
         J.ops_cap = n2 + m2 + 4;
         ops_total += J.ops_cap;
-        aux = std::max(aux, 3 * (n2 + m2) + 4);
+        aux = std::max(aux, n2 + m2 + 16);                 // (the two base-code windows; steps and classes live in the workspace)
     }
     RA_ALLOC(r->d_ops, sizeof(uint32_t) * (size_t)std::max<int64_t>(ops_total, 1));
     RA_ALLOC(r->d_counter, 8);
@@ -1263,7 +1274,7 @@ __global__ __launch_bounds__(1024) void pair_jobs_kernel(const Job* __restrict__
 // what the host does between the two stages (pa_realigner_align_windows): which reads go on, their first band, their slice of
 // the direction workspace (rows of at most 129 slots: half width <= 64)
 __global__ __launch_bounds__(256) void band_layout_kernel(Job* __restrict__ jobs, int n_reads, int* __restrict__ counters,
-                                                          unsigned long long dir_capacity, int band_waves) {
+                                                          unsigned long long dir_capacity, int band_waves, int first_width) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n_reads) return;
     Job& J = jobs[k];
@@ -1272,10 +1283,10 @@ __global__ __launch_bounds__(256) void band_layout_kernel(Job* __restrict__ jobs
     const int n2 = J.ref_end - J.ref_begin + 1, m2 = J.read_end - J.read_begin + 1;
     J.bw = abs(n2 - m2) + 1;
     J.ops_cap = n2 + m2 + 4;
-    J.dir_width = min(n2, 129);
+    J.dir_width = min(n2, first_width);
     bool wider = min(2 * J.bw + 1, n2) > J.dir_width;                         // the first band is wider already
     if (!wider) {
-        const unsigned long long need = (unsigned long long)m2 * J.dir_width * band_waves;
+        const unsigned long long need = (unsigned long long)m2 * J.dir_width * band_waves + 2ull * (n2 + m2 + 2);   // + steps, classes
         const unsigned long long at = atomicAdd(reinterpret_cast<unsigned long long*>(counters + 6), need);
         if (at + need > dir_capacity) wider = true;
         else J.dir_off = (int64_t)at;
@@ -1331,10 +1342,10 @@ int band_rounds_host(pa_realigner* r, Job* dj, const int8_t* dref, const int8_t*
             if (J.state == ST_WIDER) J.state = ST_BAND;
             if (J.state != ST_BAND) continue;
             const int n2 = J.ref_end - J.ref_begin + 1, m2 = J.read_end - J.read_begin + 1;
-            J.dir_width = round == 0 ? std::min(n2, 129) : n2;
+            J.dir_width = round == 0 ? std::min(n2, first_band_width(nw)) : n2;
             if (round == 0 && std::min(2 * J.bw + 1, n2) > J.dir_width) J.dir_width = n2;   // first band already wider
             J.dir_off = dir_total;
-            dir_total += (int64_t)m2 * J.dir_width * nw;
+            dir_total += (int64_t)m2 * J.dir_width * nw + 2ll * (n2 + m2 + 2);
             const int bw_cap = J.dir_width >= n2 ? INT32_MAX / 4 : (J.dir_width - 1) / 2;
             cap = std::max(cap, (int)std::min<int64_t>(2 * (int64_t)bw_cap + 3, n2 + 2) + 2);
             ++pending;
@@ -1401,8 +1412,9 @@ int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window
     const int nw = band_waves_for(n_reads);
     // direction bytes of the first rows (<= 129 slots): what the reads of a region at ordinary length need; what does not fit
     // there is laid out by the host afterwards
-    const unsigned long long dir_capacity = std::min<unsigned long long>((unsigned long long)n_reads * (unsigned long long)(max_region_len + 64) *
-                                                                             129ull * nw, 24ull << 30);
+    const int first_width = first_band_width(nw);
+    const unsigned long long dir_capacity = std::min<unsigned long long>((unsigned long long)n_reads * ((unsigned long long)(max_region_len + 64) *
+                                                                             (unsigned long long)first_width * nw + 2ull * (max_wl + max_m + 2)), 24ull << 30);
     RA_ALLOC(r->d_dir, (size_t)std::max<unsigned long long>(dir_capacity, 1));
     RA_HIP(hipMemcpyAsync(r->d_ref.p, hm, meta, hipMemcpyHostToDevice, st));
     RA_HIP(hipMemsetAsync(r->d_counter.p, 0, 8 + DC_N * 4, st));
@@ -1424,7 +1436,8 @@ int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window
         // SIMD up to 20 rows per lane); LDS for the rows beyond the widest strip
         const int rows = ((max_m + 15) / 16) * 16, R = (rows + 63) / 64;
         const size_t lds = rows > REG_ROWS ? (size_t)64 * R * 4 : 0;
-        static const bool single = getenv("PA_REALIGN_SINGLE") != nullptr;      // round 4's one-read-per-wavefront kernels (A/B runs)
+        static const char* mode = getenv("PA_REALIGN_SINGLE");                   // (as in pa_realigner_align_windows)
+        const bool single = mode ? mode[0] == '1' : n_reads <= 2048;
         if (single) {
             hipLaunchKernelGGL(sw_ends_kernel<12>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 0, 12);
             hipLaunchKernelGGL(sw_ends_kernel<16>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 12, 16);
@@ -1448,10 +1461,10 @@ int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window
         RA_HIP(hipGetLastError());
     }
     RA_HIP(hipEventRecord(r->ev[1], st));
-    hipLaunchKernelGGL(band_layout_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, dj, n_reads, d_ctr, dir_capacity, nw);
-    const int aux = 3 * (max_wl + max_m) + 4;
+    hipLaunchKernelGGL(band_layout_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, dj, n_reads, d_ctr, dir_capacity, nw, first_width);
+    const int aux = max_wl + max_m + 16;
     {
-        const int cap = std::min(2 * 64 + 3, max_wl + 2) + 2;
+        const int cap = std::min(2 * ((first_width - 1) / 2) + 3, max_wl + 2) + 2;
         const size_t lds = (size_t)cap * 12 * nw + (size_t)aux + 64;
         if (lds > 150 * 1024) return pa::set_error(PA_ERR_INVALID, "alignment too long for the band stage");
         RA_HIP(hipEventRecord(r->ev[2], st));
