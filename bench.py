@@ -851,7 +851,7 @@ def polish_encoder_bench(args):
     print(json.dumps(line))
 
 
-def make_images_leg(scratch):
+def make_images_leg(scratch, level=1, tags=0, bases_default=64_000_000):
     """generate_images (pepper_variant make_images / call_variant's first step) on a synthetic 64 Mb BAM at 60x written by
     tools/synth_bam: BAM + FASTA -> candidate image HDF5 files, Mb of reference per second with the stage times of the workers
     (tools/bench_variant_images.py).  Three runs over the same files, the median reported."""
@@ -861,15 +861,16 @@ def make_images_leg(scratch):
     base = scratch or tempfile.gettempdir()
     try:
         st = os.statvfs(base)
-        bases = 64_000_000 if st.f_bavail * st.f_frsize > (12 << 30) else 16_000_000
+        bases = bases_default if st.f_bavail * st.f_frsize > (12 << 30) else min(bases_default, 16_000_000)
     except OSError:
-        bases = 16_000_000
+        bases = min(bases_default, 16_000_000)
     work = tempfile.mkdtemp(prefix="pepper_amd_images_", dir=base)
     tool = os.path.join(REPO, "tools", "bench_variant_images.py")
     try:
         from pepper_amd.hostinfo import usable_cpus
         threads = max(1, usable_cpus())
-        p = subprocess.run([sys.executable, tool, "make_fast", work, str(bases)], capture_output=True, text=True, timeout=600)
+        p = subprocess.run([sys.executable, tool, "make_fast", work, str(bases), "60", "2027", str(level), str(tags)], capture_output=True,
+                           text=True, timeout=600)
         if p.returncode != 0:
             return {"error": (p.stderr or "synth_bam failed").strip().splitlines()[-1][:300]}
         made = json.loads(p.stdout.strip().splitlines()[-1])
@@ -1046,6 +1047,11 @@ def secondary_block(args):
         pass
     extra = ["--dir", scratch] if scratch else []
     out["make_images"] = make_images_leg(scratch)
+    # the same job on a BAM as samtools writes it: zlib level 6 members, NM / MD / RG aux data in every record (8 Mb: zlib level 6
+    # writes the synthetic file at a tenth of libdeflate level 1's rate)
+    lv6 = make_images_leg(scratch, level=6, tags=1, bases_default=8_000_000)
+    out["make_images_level6"] = lv6 if "error" in lv6 else {k: lv6[k] for k in ("value", "unit", "seconds", "threads", "runs_mb_per_s", "data",
+                                                                                  "stage_seconds_summed_over_workers", "synth_seconds")}
     out["polish_make_images"] = polish_make_images_leg(scratch)
     # the two top entry points as one job each (stage walls inside): 256 Mb at 30x for call_variant, 64 Mb at 60x for polish
     out["call_variant"] = e2e_leg("call_variant", scratch, 256_000_000, 30, 3, 24)
@@ -1092,8 +1098,17 @@ def secondary_block(args):
                          "kind": "port", "one_core": d.get("host_library_one_core_GBps"), "identical": d.get("identical_to_host_library"),
                          "sample": "all the members through pa_bgzf_inflate_host (libdeflate, htslib's inflate), one thread per usable CPU"},
         "note": "csrc/inflate.hip on the BGZF members of a synthetic 8 Mb / 60x BAM (tools/synth_bam, libdeflate level 1), inputs "
-                "resident, HIP events: one wavefront per member, 64 bit offsets decoded speculatively per step; bound by instruction "
+                "resident, HIP events: one wavefront per member, 64 bit offsets decoded speculatively per step, then every member's "
+                "CRC-32 against its trailer (bgzf_crc_kernel, inside the timed region); bound by instruction "
                 "issue and the symbol-to-symbol dependency of DEFLATE, not by HBM (the bytes moved are compressed in + inflated out)"}
+    # the members as samtools writes them: zlib level 6, NM / MD / RG aux data (longer matches, longer codes)
+    d6 = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "4000000", "--level", "6", "--tags", "1"], 300)
+    out["bgzf_inflate_level6"] = d6 if "error" in d6 else {
+        "value": d6["device_GBps_inflated"], "unit": "GB/s of inflated bytes", "kernel_ms": d6["kernel_ms"], "members": d6["members"],
+        "compressed_bytes": d6["compressed_bytes"], "inflated_bytes": d6["inflated_bytes"], "identical_to_zlib": d6["sample_identical"],
+        "identical_to_host_library": d6.get("identical_to_host_library"),
+        "cpu_baseline": {"value": d6.get("host_library_all_cores_GBps"), "unit": "GB/s of inflated bytes", "cores": d6.get("host_cores"), "kind": "port"},
+        "note": "the same kernels on a synthetic 4 Mb / 60x BAM written with zlib level 6 and NM / MD / RG aux data in every record"}
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_pipeline.py"), "--files", "16", "--windows", "524288", "--groups", "512",
                    "--workers", "0"] + extra, 600)
     out["run_inference_hdf5"] = d if "error" in d else {

@@ -39,6 +39,15 @@
 
 namespace {
 
+// CRC-32 of an inflated member (libdeflate's where it is linked, else zlib's)
+inline uint32_t member_crc32(const uint8_t* data, size_t n) {
+#ifdef PA_HAVE_LIBDEFLATE
+    return libdeflate_crc32(0, data, n);
+#else
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n);
+#endif
+}
+
 thread_local std::string g_bam_err;
 int bam_fail(int code, const std::string& msg) {
     g_bam_err = msg;
@@ -142,6 +151,10 @@ struct Bgzf {
             zs.avail_out = isize;
             if (inflate(&zs, Z_FINISH) != Z_STREAM_END) return false;
 #endif
+        }
+        {   // the member's CRC-32 (htslib's inflate_block fails the read on a mismatch; so does this reader)
+            const uint32_t want = comp[clen] | (comp[clen + 1] << 8) | (comp[clen + 2] << 16) | ((uint32_t)comp[clen + 3] << 24);
+            if (member_crc32(fresh->data(), isize) != want) return false;
         }
         cur = fresh;
         block_coffset = coffset;
@@ -947,7 +960,7 @@ int pa_bgzf_inflate_host(const uint8_t* comp, int64_t comp_bytes, int32_t n_bloc
             out_off[k] + out_len[k] > out_bytes)
             return bam_fail(-1, "block " + std::to_string(k) + " lies outside the buffers");
     const int nt = std::max(1, std::min<int>(n_threads, std::max(1, n_blocks)));
-    std::vector<int> bad((size_t)nt, -1);
+    std::vector<int> bad((size_t)nt, -1), crc_bad((size_t)nt, 0);
     auto work = [&](int t) {
 #ifdef PA_HAVE_LIBDEFLATE
         libdeflate_decompressor* ld = libdeflate_alloc_decompressor();
@@ -970,6 +983,12 @@ int pa_bgzf_inflate_host(const uint8_t* comp, int64_t comp_bytes, int32_t n_bloc
                 inflateEnd(&zs);
             }
 #endif
+            // (`comp` holds whole members: the CRC-32 is the 4 bytes behind the DEFLATE bytes)
+            if (ok && comp_off[k] + comp_len[k] + 4 <= comp_bytes) {
+                const uint8_t* t4 = comp + comp_off[k] + comp_len[k];
+                const uint32_t want = t4[0] | (t4[1] << 8) | (t4[2] << 16) | ((uint32_t)t4[3] << 24);
+                if (member_crc32(out + out_off[k], (size_t)out_len[k]) != want) { ok = false; crc_bad[(size_t)t] = 1; }
+            }
             if (!ok && bad[(size_t)t] < 0) bad[(size_t)t] = k;
         }
 #ifdef PA_HAVE_LIBDEFLATE
@@ -981,7 +1000,9 @@ int pa_bgzf_inflate_host(const uint8_t* comp, int64_t comp_bytes, int32_t n_bloc
     work(0);
     for (auto& th : threads) th.join();
     for (int t = 0; t < nt; ++t)
-        if (bad[(size_t)t] >= 0) return bam_fail(-5, "BGZF block " + std::to_string(bad[(size_t)t]) + " does not inflate to its ISIZE");
+        if (bad[(size_t)t] >= 0)
+            return bam_fail(-5, "BGZF block " + std::to_string(bad[(size_t)t]) +
+                                    (crc_bad[(size_t)t] ? ": CRC32 of the inflated bytes differs from the member's trailer" : " does not inflate to its ISIZE"));
     return 0;
 }
 

@@ -37,7 +37,7 @@
 //
 // Checks: over-subscribed code sets, codes without a symbol, distances beyond the produced output, output beyond the
 // block's ISIZE, a stored block's LEN/NLEN complement, input consumed beyond the block -> a non-zero status word per
-// block (the host call fails with the first one).  Like the host reader the block CRC32 is not verified.
+// block (the host call fails with the first one).  The member's CRC-32 is verified by bgzf_crc_kernel below (round 5).
 #include "../../include/pepper_amd.h"
 #include "../../include/pepper_amd_io_device.h"
 
@@ -64,7 +64,7 @@ constexpr int RING_WORDS = 128;                  // two chunks of 64 words of th
 
 enum InflateStatus : int32_t {
     INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_STORED_LEN = 2, INF_OVERSUBSCRIBED = 3, INF_NO_END_CODE = 4, INF_BAD_CODE = 5,
-    INF_BAD_REPEAT = 6, INF_DISTANCE = 7, INF_OUTPUT = 8, INF_LENGTH = 9, INF_INPUT = 10, INF_BAD_COUNTS = 11
+    INF_BAD_REPEAT = 6, INF_DISTANCE = 7, INF_OUTPUT = 8, INF_LENGTH = 9, INF_INPUT = 10, INF_BAD_COUNTS = 11, INF_CRC = 12
 };
 
 struct Tables {
@@ -742,12 +742,117 @@ void launch_record_walk(hipStream_t stream, const uint8_t* data, int64_t data_by
                        static_cast<const RecHdr*>(slots), counts, base, cap, n_entries, static_cast<RecHdr*>(out), (long long)out_cap);
 }
 
+// ---- CRC-32 of every inflated member against its trailer --------------------------------------------------------------
+// htslib's inflate_block compares crc32() of the inflated block with the member's trailer and fails the read on a mismatch
+// (bgzf.c, under sam_itr_next: bam_handler.cpp:341-372); without it a flipped literal in the file is a silently different
+// base.  One wavefront per member, after the inflate kernel: lane l takes the 1 KiB slice that ENDS 1 024 l bytes before
+// the member's end (slices aligned to the end: only the left-most one is short) through a slice-by-4 table built in LDS
+// (the IEEE 802.3 polynomial, reflected: 0xEDB88320), then the 64 slice CRCs are folded pairwise,
+//   crc(A || B) = crc(A) * x^(8 |B|) mod P  xor  crc(B)        (zlib's crc32_combine: multmodp / x2nmodp of crc32.c, restated)
+// where |B| is a whole number of slices at every level, so the six factors x^(8 * 1024 * 2^j) mod P are compile-time
+// constants.  ~4 k vector instructions per member beside the inflate kernel's ~700 k.
+namespace {
+
+constexpr uint32_t CRC_POLY = 0xEDB88320u;
+constexpr uint32_t crc_multmodp(uint32_t a, uint32_t b) {       // a * b mod P, bit 31 = x^0
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ CRC_POLY : b >> 1;
+    }
+    return p;
+}
+constexpr uint32_t crc_x2nmodp(uint64_t n, unsigned k) {          // x^(n * 2^k) mod P
+    uint32_t table = 1u << 30;                                    // x^1
+    for (unsigned i = 0; i < k; ++i) table = crc_multmodp(table, table);
+    uint32_t p = 1u << 31;                                        // x^0
+    while (n) {
+        if (n & 1) p = crc_multmodp(table, p);
+        n >>= 1;
+        table = crc_multmodp(table, table);
+    }
+    return p;
+}
+constexpr int CRC_SLICE = 1024;
+struct CrcShift { uint32_t k[6]; };
+constexpr CrcShift crc_shifts() {
+    CrcShift s{};
+    for (int j = 0; j < 6; ++j) s.k[j] = crc_x2nmodp((uint64_t)CRC_SLICE << j, 3);      // x^(8 * 1024 * 2^j)
+    return s;
+}
+static_assert(crc_x2nmodp(0, 3) == 0x80000000u && crc_multmodp(0x80000000u, 0x12345678u) == 0x12345678u, "x^0 is the identity");
+
+__device__ __forceinline__ uint32_t crc_multmodp_dev(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+        p ^= (a & (0x80000000u >> i)) ? b : 0u;
+        b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(64) void bgzf_crc_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
+                                                      const int32_t* __restrict__ comp_len, const int64_t* __restrict__ out_off,
+                                                      const int32_t* __restrict__ out_len, const uint8_t* __restrict__ out,
+                                                      int32_t* __restrict__ status, CrcShift shifts) {
+    __shared__ uint32_t T[4][256];
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    if (status[blk] != 0) return;                         // (the inflate kernel refused the member already)
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = (uint32_t)i;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+        T[0][i] = c;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the wavefront's LDS writes are in order; this is for the compiler
+    asm volatile("" ::: "memory");
+    for (int t = 1; t < 4; ++t) {
+        for (int i = lane; i < 256; i += 64) { const uint32_t c = T[t - 1][i]; T[t][i] = (c >> 8) ^ T[0][c & 0xffu]; }
+        asm volatile("" ::: "memory");
+    }
+    const int len = out_len[blk];
+    const uint8_t* data = out + out_off[blk];
+    const int hi = len - CRC_SLICE * lane, lo = hi - CRC_SLICE > 0 ? hi - CRC_SLICE : 0;
+    uint32_t crc = 0;                                     // (the CRC-32 of no bytes)
+    if (hi > 0) {
+        uint32_t c = 0xFFFFFFFFu;
+        int i = lo;
+        for (; i < hi && ((size_t)(data + i) & 3u); ++i) c = T[0][(c ^ data[i]) & 0xffu] ^ (c >> 8);
+        for (; i + 4 <= hi; i += 4) {
+            c ^= *reinterpret_cast<const uint32_t*>(data + i);
+            c = T[3][c & 0xffu] ^ T[2][(c >> 8) & 0xffu] ^ T[1][(c >> 16) & 0xffu] ^ T[0][c >> 24];
+        }
+        for (; i < hi; ++i) c = T[0][(c ^ data[i]) & 0xffu] ^ (c >> 8);
+        crc = c ^ 0xFFFFFFFFu;
+    }
+    // lane l + 2^j holds the bytes in front of lane l's: fold towards lane 0
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const uint32_t left = (uint32_t)__shfl_down((int)crc, 1 << j, 64);
+        if ((lane & ((2 << j) - 1)) == 0) crc = crc_multmodp_dev(shifts.k[j], left) ^ crc;
+    }
+    if (lane == 0) {
+        const uint8_t* t = comp + comp_off[blk] + comp_len[blk];
+        const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (crc != want) status[blk] = INF_CRC;
+    }
+}
+
+}  // namespace
+
 void launch_bgzf_inflate(hipStream_t stream, const uint8_t* comp, const int64_t* comp_off, const int32_t* comp_len,
                          const int64_t* out_off, const int32_t* out_len, uint8_t* out, int32_t* status, int n_blocks,
                          unsigned long long* debug_counts) {
     if (n_blocks <= 0) return;
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
                        status, debug_counts);
+    // every member's CRC-32 against its trailer (the 4 bytes behind its DEFLATE bytes: `comp` holds whole members)
+    constexpr CrcShift shifts = crc_shifts();
+    hipLaunchKernelGGL(bgzf_crc_kernel, dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out, status, shifts);
 }
 
 const char* inflate_status_text(int32_t s) {
@@ -764,6 +869,7 @@ const char* inflate_status_text(int32_t s) {
         case INF_LENGTH: return "invalid length symbol";
         case INF_INPUT: return "stream runs beyond the block's compressed bytes";
         case INF_BAD_COUNTS: return "HLIT or HDIST out of range";
+        case INF_CRC: return "CRC32 of the inflated bytes differs from the member's trailer";
     }
     return "?";
 }

@@ -201,6 +201,66 @@ def test_corrupt_block_is_an_error_not_end_of_file(tmp_path):
     bam.close()
 
 
+def test_flipped_payload_bit_fails_the_crc_on_the_host_paths(tmp_path):
+    """The host reader (Bgzf::read_block) and pa_bgzf_inflate_host check a member's CRC-32 as htslib's inflate_block does: a
+    BAM whose blocks are stored (level 0) with one payload bit flipped inflates structurally and must fail the query."""
+    import struct
+    import zlib
+    from pepper_amd.bgzf import BgzfError, block_table, inflate_host
+    rng = np.random.default_rng(38)
+    data = bytes(rng.integers(0, 256, 5000, dtype=np.uint8))
+
+    def member(payload, level):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(payload) + c.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(body) + 25) + body +
+                struct.pack("<II", zlib.crc32(payload), len(payload)))
+    good = member(data, 0) + member(data[:777], 6)
+    assert inflate_host(good, block_table(good), 2).tobytes() == data + data[:777]
+    bad = bytearray(good)
+    bad[18 + 5 + 2000] ^= 0x04
+    with pytest.raises(BgzfError):
+        inflate_host(bytes(bad), block_table(bytes(bad)), 2)
+    # the BAM reader: flip a base inside a record's block; the query fails instead of returning a different base
+    ref = pu.random_reference(rng, 20000)
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=200, read_len=(300, 1500))
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    path = str(tmp_path / "crc.bam")
+    bu.write_bam(path, [("ctg", 20000)], {0: reads}, flush_every=7)
+    bam = BAM_handler(path)
+    n = len(bam.get_reads("ctg", 0, 20000, False, 0, 0))
+    bam.close()
+    assert n > 100
+    raw = bytearray(open(path, "rb").read())
+    offs, p = [], 0
+    while p < len(raw):
+        offs.append(p)
+        p += (raw[p + 16] | (raw[p + 17] << 8)) + 1
+    victim = offs[len(offs) // 2]
+    size = (raw[victim + 16] | (raw[victim + 17] << 8)) + 1
+    # try bytes of the member's DEFLATE stream until one inflates structurally: only the CRC can tell then
+    caught = False
+    for at in range(victim + 30, victim + size - 9):
+        trial = bytearray(raw)
+        trial[at] ^= 0x01
+        body = bytes(trial[victim + 18:victim + size - 8])
+        try:
+            out = zlib.decompress(body, -15)
+        except zlib.error:
+            continue
+        isize = struct.unpack_from("<I", trial, victim + size - 4)[0]
+        if len(out) != isize:
+            continue
+        open(path, "wb").write(bytes(trial))
+        bam = BAM_handler(path)
+        with pytest.raises(BamError):
+            bam.get_reads("ctg", 0, 20000, False, 0, 0)
+        bam.close()
+        caught = True
+        break
+    assert caught
+
+
 def test_records_without_their_bases(tmp_path):
     """SEQ '*' (l_seq 0 beside a CIGAR: legal, samtools writes it for some supplementary / secondary records) holds nothing to
     pile up: the record is left out.  A CIGAR that walks over more bases than the record holds is a corrupt record and fails the

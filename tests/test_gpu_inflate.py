@@ -172,6 +172,51 @@ def test_malformed_members_fail_the_call():
         assert inf.inflate(good, table).tobytes() == data   # the handle is fine afterwards
 
 
+@pytest.mark.gpu
+def test_a_flipped_payload_bit_fails_the_members_crc():
+    """htslib's inflate_block compares crc32() of the inflated block with the member's trailer; so does the device (bgzf_crc_kernel):
+    a literal flipped inside a stored block, a flipped literal of a fixed-Huffman stream that still decodes, and a wrong
+    trailer all inflate structurally and must fail the call -- in members of 1 byte, of 1 024 k +- 1 bytes (the slice edges of
+    the fold) and of the maximum size; the untouched members pass."""
+    rng = np.random.default_rng(12)
+    sizes = [1, 3, 1023, 1024, 1025, 4097, 33000, 65279, 65280]
+    datas = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in sizes]
+    with DeviceInflater() as inf:
+        for level in (0, 1, 6):
+            members = [member(d, level) for d in datas]
+            buf = b"".join(members)
+            assert inf.inflate(buf, block_table(buf)).tobytes() == b"".join(datas)
+        # stored blocks: every payload byte is a literal of the stream; flip one bit in each member in turn
+        members = [member(d, 0) for d in datas]
+        for k, (m, d) in enumerate(zip(members, datas)):
+            bad = bytearray(m)
+            at = 18 + 5 + (len(d) * 2) // 3                  # header 18 bytes, stored-block header 5: inside the payload
+            bad[at] ^= 0x10
+            buf = b"".join(members[:k] + [bytes(bad)] + members[k + 1:])
+            with pytest.raises(_lib.PepperAmdError, match="BGZF block %d: CRC32" % k):
+                inf.inflate(buf, block_table(buf))
+        # a wrong trailer on an otherwise sound member
+        m = bytearray(member(datas[4], 6))
+        m[-8] ^= 1
+        with pytest.raises(_lib.PepperAmdError, match="CRC32"):
+            inf.inflate(bytes(m), block_table(bytes(m)))
+        # fixed-Huffman literals (text of 8-bit codes 0x30 + c for c < 144): flipping the lowest bit of a code gives another literal
+        text = bytes(rng.integers(65, 91, 3000, dtype=np.uint8))
+        fixed = bytearray(member(text, 6, zlib.Z_FIXED))
+        hit = 0
+        for at in range(40, 400):
+            trial = bytearray(fixed)
+            trial[at] ^= 0x80
+            try:
+                inf.inflate(bytes(trial), block_table(bytes(trial)))
+            except _lib.PepperAmdError as err:
+                hit += "CRC32" in str(err)
+                continue
+            raise AssertionError("a flipped stream bit went unnoticed at byte %d" % at)
+        assert hit > 50                                       # (the others break the code structure and fail earlier)
+        assert inf.inflate(bytes(fixed), block_table(bytes(fixed))).tobytes() == text
+
+
 def test_block_table_reads_the_member_headers():
     a, b = member(b"hello" * 100, 6), member(b"", 6, extra_subfield=True)
     comp_off, comp_len, out_off, out_len = block_table(a + b + EOF_MEMBER, base=10)

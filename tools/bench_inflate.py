@@ -2,7 +2,9 @@
 """Device inflate of a synthetic BAM's BGZF members (csrc/inflate.hip): inflated GB/s of the kernel alone (HIP events, inputs
 resident), beside zlib on one host core over a sample of the same members.
 
-    python tools/bench_inflate.py [--genome 2000000] [--coverage 60] [--repeats 5]
+    python tools/bench_inflate.py [--genome 2000000] [--coverage 60] [--repeats 5] [--level 1] [--tags 0]
+
+--level 6 --tags 1: the members as samtools / htslib write them (zlib level 6, NM / MD / RG aux data in every record).
 """
 import argparse
 import json
@@ -28,11 +30,13 @@ def main():
     ap.add_argument("--coverage", type=int, default=60)
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--bam", default=None)
+    ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--tags", type=int, default=0)
     args = ap.parse_args()
     with tempfile.TemporaryDirectory() as tmp:
         bam = args.bam
         if bam is None:
-            subprocess.run([os.path.join(ROOT, "tools", "synth_bam"), tmp, str(args.genome), str(args.coverage), "11", "0"],
+            subprocess.run([os.path.join(ROOT, "tools", "synth_bam"), tmp, str(args.genome), str(args.coverage), "11", "0", "1", str(args.level), str(args.tags)],
                            check=True, capture_output=True)
             bam = os.path.join(tmp, "reads.bam")
         raw = np.fromfile(bam, np.uint8)
@@ -68,7 +72,7 @@ def main():
     inflate_host(raw, [a[:sample] for a in table], 1)
     t_host1 = time.perf_counter() - t0
     all_identical = bool(host.size == got.size and np.array_equal(host, got))
-    print(json.dumps({"members": n, "compressed_bytes": int(raw.size), "inflated_bytes": out_bytes,
+    print(json.dumps({"deflate_level": args.level, "aux_tags": bool(args.tags), "members": n, "compressed_bytes": int(raw.size), "inflated_bytes": out_bytes,
                       "kernel_ms": round(ms, 3), "device_GBps_inflated": round(out_bytes / ms / 1e6, 2),
                       "device_GBps_compressed": round(raw.size / ms / 1e6, 2),
                       "host_call_s_with_transfers": round(t_call, 3), "repeats": args.repeats,

@@ -2,7 +2,12 @@
 // bench / profiling data for image generation (bench.py secondary.make_images, tools/bench_variant_images.py).
 // Not product code and not an oracle: the package's own BAM reader and the tests' Python writer define the format checks.
 //
-//   synth_bam <out_dir> <genome_bases> [coverage=60] [seed=2027] [threads=0 (all)] [contigs=1]
+//   synth_bam <out_dir> <genome_bases> [coverage=60] [seed=2027] [threads=0 (all)] [contigs=1] [level=1] [tags=0]
+//
+// level: 1 = libdeflate level 1 (the fast default: what the data of rounds 3-4 was written with); 2..9 = zlib's deflate at that
+// level -- 6 is what samtools / htslib write (longer matches, longer codes: the blocks a real BAM holds).  tags = 1: every record
+// carries NM:i, an MD:Z string spelling out its mismatches and deletions, and RG:Z, as aligners write them (the aux data is a
+// fifth of a real record's bytes and compresses unlike the bases).
 //
 // Reads as pepper_amd.synthetic.encoder_region models them (E-syn): 4-12 kb, an insert or a deletion of 1-5 bases every ~50
 // positions, 4 % substitutions, a heterozygous SNP site per ~1 kb and a systematic indel site per ~700 b carried by one of
@@ -67,6 +72,8 @@ struct Piece {
     int64_t n_bases = 0;
 };
 
+int g_level = 1, g_tags = 0;
+
 struct Deflater {
 #ifdef PA_HAVE_LIBDEFLATE
     libdeflate_compressor* c = libdeflate_alloc_compressor(1);
@@ -79,20 +86,25 @@ struct Deflater {
         uint8_t* p = out.comp.data() + at;
         static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
         std::memcpy(p, head, 16);
-        size_t clen;
+        size_t clen = 0;
+        bool done = false;
 #ifdef PA_HAVE_LIBDEFLATE
-        clen = libdeflate_deflate_compress(c, data, n, p + 18, 0x10400);
-#else
-        z_stream zs{};
-        deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
-        zs.next_in = const_cast<uint8_t*>(data);
-        zs.avail_in = (uInt)n;
-        zs.next_out = p + 18;
-        zs.avail_out = 0x10400;
-        deflate(&zs, Z_FINISH);
-        clen = zs.total_out;
-        deflateEnd(&zs);
+        if (g_level == 1) {
+            clen = libdeflate_deflate_compress(c, data, n, p + 18, 0x10400);
+            done = true;
+        }
 #endif
+        if (!done) {                                  // zlib's own deflate at the level asked for (6: what htslib writes)
+            z_stream zs{};
+            deflateInit2(&zs, g_level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+            zs.next_in = const_cast<uint8_t*>(data);
+            zs.avail_in = (uInt)n;
+            zs.next_out = p + 18;
+            zs.avail_out = 0x10400;
+            deflate(&zs, Z_FINISH);
+            clen = zs.total_out;
+            deflateEnd(&zs);
+        }
         const uint32_t bsize = (uint32_t)(clen + 18 + 8 - 1);
         p[16] = bsize & 0xff;
         p[17] = bsize >> 8;
@@ -126,7 +138,7 @@ void make_piece(const Genome& g, int tid, int64_t lo, int64_t hi, double coverag
     raw.reserve(0x20000);
     uint32_t n_blocks = 0;
     std::vector<uint32_t> cigar;
-    std::vector<uint8_t> bases, quals, rec;
+    std::vector<uint8_t> bases, quals, rec, md;
     auto flush = [&](bool all) {
         size_t at = 0;
         while (raw.size() - at >= 0xff00 || (all && at < raw.size())) {
@@ -153,12 +165,24 @@ void make_piece(const Genome& g, int tid, int64_t lo, int64_t hi, double coverag
         };
         int64_t rp = pos;
         const int64_t stop = pos + want;
+        md.clear();
+        uint32_t md_run = 0, nm = 0;
+        auto md_flush = [&]() {
+            char num[16];
+            const int len = snprintf(num, sizeof num, "%u", md_run);
+            md.insert(md.end(), num, num + len);
+            md_run = 0;
+        };
         while (rp < stop) {
             uint8_t b = ref[(size_t)rp];
             const uint64_t h = site_hash((uint64_t)tid, (uint64_t)rp, seed);
             const bool snp_site = (h % 1000) == 0, indel_site = ((h >> 20) % 700) == 0;
             if (snp_site && hap == 1) b = (uint8_t)((b + 1 + ((h >> 40) % 3)) & 3);
             else if (rng.below(100) < 4) b = (uint8_t)((b + 1 + rng.below(3)) & 3);
+            if (g_tags) {
+                if (b == ref[(size_t)rp]) ++md_run;
+                else { md_flush(); md.push_back((uint8_t)kLetters[ref[(size_t)rp]]); ++nm; }
+            }
             bases.push_back(b);
             push(0, 1);
             ++rp;
@@ -175,11 +199,19 @@ void make_piece(const Genome& g, int tid, int64_t lo, int64_t hi, double coverag
             if (ins) {
                 for (uint32_t i = 0; i < n; ++i) bases.push_back((uint8_t)(indel_site && hap == 1 ? ((h >> (2 * i)) & 3) : rng.below(4)));
                 push(1, n);
+                nm += n;
             } else if (del && rp + n < stop - 2) {
                 push(2, n);
+                if (g_tags) {
+                    md_flush();
+                    md.push_back('^');
+                    for (uint32_t i = 0; i < n; ++i) md.push_back((uint8_t)kLetters[ref[(size_t)(rp + i)]]);
+                    nm += n;
+                }
                 rp += n;
             }
         }
+        if (g_tags) md_flush();
         const uint32_t l_seq = (uint32_t)bases.size();
         quals.resize(l_seq);
         for (uint32_t i = 0; i < l_seq; i += 8) {
@@ -198,7 +230,9 @@ void make_piece(const Genome& g, int tid, int64_t lo, int64_t hi, double coverag
         const uint32_t mapq = rng.below(100) < 2 ? 0 : 60;
         const int l_name = snprintf(name, sizeof name, "r%d_%lld_%lld", tid, (long long)lo, (long long)k) + 1;
         const uint32_t n_cig = (uint32_t)cigar.size();
-        const uint32_t body = 32 + (uint32_t)l_name + 4 * std::min<uint32_t>(n_cig, 65535u) + (l_seq + 1) / 2 + l_seq;
+        // aux data as aligners write it: NM:i (uint16), MD:Z, RG:Z
+        const uint32_t aux_bytes = g_tags ? (3 + 2) + (3 + (uint32_t)md.size() + 1) + (3 + 4) : 0;
+        const uint32_t body = 32 + (uint32_t)l_name + 4 * std::min<uint32_t>(n_cig, 65535u) + (l_seq + 1) / 2 + l_seq + aux_bytes;
         if (n_cig > 65535) continue;                 // (never with these lengths)
         rec.resize(4 + body);
         uint8_t* p = rec.data();
@@ -219,6 +253,17 @@ void make_piece(const Genome& g, int tid, int64_t lo, int64_t hi, double coverag
         for (uint32_t i = 0; i + 1 < l_seq; i += 2) *p++ = (uint8_t)((kCode[bases[i]] << 4) | kCode[bases[i + 1]]);
         if (l_seq & 1) *p++ = (uint8_t)(kCode[bases[l_seq - 1]] << 4);
         std::memcpy(p, quals.data(), l_seq);
+        p += l_seq;
+        if (g_tags) {
+            const uint16_t nm16 = (uint16_t)std::min<uint32_t>(nm, 65535u);
+            std::memcpy(p, "NMS", 3); p += 3;
+            std::memcpy(p, &nm16, 2); p += 2;
+            std::memcpy(p, "MDZ", 3); p += 3;
+            std::memcpy(p, md.data(), md.size()); p += md.size();
+            *p++ = 0;
+            std::memcpy(p, "RGZ", 3); p += 3;
+            std::memcpy(p, "rg1", 4); p += 4;
+        }
         // the record starts in block n_blocks + (bytes waiting) / 0xff00 of this piece
         const uint64_t waiting = raw.size();
         out.recs.push_back(RecIndex{(int32_t)pos, (int32_t)end, n_blocks + (uint32_t)(waiting / 0xff00), (uint32_t)(waiting % 0xff00), 4 + body});
@@ -242,6 +287,8 @@ int main(int argc, char** argv) {
     const uint64_t seed = argc > 4 ? (uint64_t)atoll(argv[4]) : 2027;
     int threads = argc > 5 ? atoi(argv[5]) : 0;
     const int n_contigs = std::max(1, argc > 6 ? atoi(argv[6]) : 1);
+    g_level = argc > 7 ? std::max(1, std::min(9, atoi(argv[7]))) : 1;
+    g_tags = argc > 8 ? atoi(argv[8]) != 0 : 0;
     if (threads <= 0) threads = std::max(1u, std::thread::hardware_concurrency());
     if (FILE* fh = fopen("/sys/fs/cgroup/cpu.max", "r")) {       // a cgroup quota below the hardware's thread count
         char quota[32] = {0};
@@ -397,7 +444,10 @@ int main(int argc, char** argv) {
         for (uint64_t v : lin[(size_t)c]) o64(v);
     }
     fclose(bai);
-    printf("{\"records\": %lld, \"read_bases\": %lld, \"genome_bases\": %lld, \"coverage\": %.1f, \"bam_bytes\": %lld, \"threads\": %d}\n",
-           (long long)n_records, (long long)n_bases, (long long)total, (double)n_bases / (double)total, (long long)coff + 28, threads);
+    printf("{\"records\": %lld, \"read_bases\": %lld, \"genome_bases\": %lld, \"coverage\": %.1f, \"bam_bytes\": %lld, \"threads\": %d, "
+           "\"deflate\": \"%s\", \"aux_tags\": %s}\n",
+           (long long)n_records, (long long)n_bases, (long long)total, (double)n_bases / (double)total, (long long)coff + 28, threads,
+           g_level == 1 ? "libdeflate level 1 (zlib level 1 where libdeflate is absent)" : (std::string("zlib level ") + std::to_string(g_level)).c_str(),
+           g_tags ? "true" : "false");
     return 0;
 }
