@@ -102,6 +102,7 @@ def self_spawn(args):
 
 
 COLLECTIVE_NOTE = "none (one rank)"
+BENCH_GROUP = None            # the RCCL process group when every rank could initialise it (dist_setup); None: the gloo default group
 
 
 def dist_setup(args):
@@ -127,27 +128,32 @@ def dist_setup(args):
         dist.all_reduce(one)
         COLLECTIVE_NOTE = "gloo (ranks share devices: plumbing check)"
         return world, rank, device, int(one.item())
-    # RCCL first; if its initialisation or its first collective fails on this box every rank falls back to gloo for the one
-    # weight broadcast and the timing barriers (the data path has no collective), and the line says so
-    try:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
-        one = torch.ones(1, device=torch.device("cuda", device))
-        dist.all_reduce(one)
+    # The ranks AGREE on the backend before anyone commits to it: a gloo group comes up first (it works wherever the
+    # rendezvous does), RCCL is tried as a second group on top of it, and the ranks' verdicts are summed over gloo -- RCCL is
+    # used only if every rank's initialisation and first collective succeeded.  (The earlier form let each rank fall back on its
+    # own: had RCCL failed on some ranks only, those would have re-initialised with gloo while the others sat in an RCCL
+    # collective -- a hang instead of a soft failure.)  The data path has no collective; this carries one weight broadcast
+    # and the timing barriers.
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pepper_amd.parallel import agree_on_rccl
+
+    def try_rccl():
+        group = dist.new_group(backend="nccl", device_id=torch.device("cuda", device))
+        probe = torch.ones(1, device=torch.device("cuda", device))
+        dist.all_reduce(probe, group=group)
         torch.cuda.synchronize(device)
-        COLLECTIVE_NOTE = "nccl (RCCL)"
-        return world, rank, device, int(one.item())
-    except Exception as err:        # noqa: BLE001 -- whatever RCCL raises, the bench goes on
-        sys.stderr.write("[bench] rank %d: RCCL unusable (%s); falling back to gloo\n" % (rank, repr(err)[:200]))
-        try:
-            dist.destroy_process_group()
-        except Exception:
-            pass
-        os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)      # the store of the failed group may linger
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        one = torch.ones(1)
-        dist.all_reduce(one)
-        COLLECTIVE_NOTE = "gloo (RCCL initialisation failed: %s)" % repr(err)[:160]
-        return world, rank, device, int(one.item())
+        if int(probe.item()) != world:
+            raise RuntimeError("RCCL all-reduce over %d ranks returned %d" % (world, int(probe.item())))
+        return group
+    global BENCH_GROUP
+    BENCH_GROUP, failed, why = agree_on_rccl(world, try_rccl)
+    if why:
+        sys.stderr.write("[bench] rank %d: RCCL unusable (%s)\n" % (rank, why))
+    one = torch.ones(1)
+    dist.all_reduce(one)
+    COLLECTIVE_NOTE = ("nccl (RCCL), agreed over a gloo group" if BENCH_GROUP is not None else
+                       "gloo (RCCL unusable on %d of %d ranks%s)" % (failed, world, (": " + why) if why else ""))
+    return world, rank, device, int(one.item())
 
 
 def broadcast_state_dict(make_sd, shapes, world, rank, dev):
@@ -157,8 +163,9 @@ def broadcast_state_dict(make_sd, shapes, world, rank, dev):
         return make_sd()
     import torch.distributed as dist
     from pepper_amd.parallel import broadcast_numpy_state_dict
-    on_gpu = dist.get_backend() == "nccl"
-    return broadcast_numpy_state_dict(make_sd if rank == 0 else None, shapes, device=dev if on_gpu else None)
+    # over the RCCL group when every rank has it (dist_setup), over the gloo group otherwise
+    return broadcast_numpy_state_dict(make_sd if rank == 0 else None, shapes, device=dev if BENCH_GROUP is not None else None,
+                                      group=BENCH_GROUP)
 
 
 def _cpu_runner(model_kind):

@@ -74,3 +74,19 @@ def broadcast_numpy_state_dict(make_state_dict, shapes, src=0, device=None, grou
         out[s[0]] = host[off:off + n].reshape(s[1]).copy()
         off += n
     return out
+
+
+def agree_on_rccl(world, try_rccl):
+    """All ranks decide TOGETHER whether the RCCL group is used: the default group is gloo (up wherever the rendezvous is),
+    `try_rccl()` -- this rank's attempt to create the RCCL group and run a first collective on it, returning the group or raising
+    -- runs on every rank, and the verdicts are summed over gloo.  -> (group or None, ranks that failed, this rank's reason).
+    A rank-local fallback (RCCL failed here, so re-initialise with gloo here) deadlocks the ranks where it did not fail."""
+    ok, why, group = 1.0, "", None
+    try:
+        group = try_rccl()
+    except Exception as err:        # noqa: BLE001 -- whatever the backend raises
+        ok, why = 0.0, repr(err)[:160]
+    verdict = torch.tensor([ok])
+    dist.all_reduce(verdict)
+    failed = world - int(verdict.item())
+    return (group if failed == 0 else None), failed, why

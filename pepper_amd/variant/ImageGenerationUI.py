@@ -30,6 +30,34 @@ def _log(msg):
     sys.stderr.flush()
 
 
+def _on_device(options, device):
+    """`options` as the host-clipped form reads them, with .device = this worker's device."""
+    if int(getattr(options, "device", 0) or 0) == device:
+        return options
+    import copy
+    clone = copy.copy(options)
+    clone.device = device
+    return clone
+
+
+def worker_device(options, process_id):
+    """The device of image-generation worker `process_id`: options.image_device_ids ("0,1,...", a list) or -- what call_variant's
+    callers already give for the inference step -- options.device_ids, dealt round robin; options.device (default 0) without them.
+    The reference's image generation is CPU work (ImageGenerationUI.py:326-339 starts one process per thread); its run_inference
+    deals callers over device_ids the same way (RunInference.py:101-116)."""
+    ids = getattr(options, "image_device_ids", None)
+    if ids in (None, ""):
+        ids = getattr(options, "device_ids", None)
+    if ids in (None, ""):
+        return int(getattr(options, "device", 0) or 0)
+    if isinstance(ids, str):
+        ids = [int(d) for d in ids.split(",") if d.strip() != ""]
+    elif isinstance(ids, int):
+        ids = [ids]
+    ids = [int(d) for d in ids]
+    return ids[process_id % len(ids)] if ids else 0
+
+
 def _handlers(options, bam_path, fasta_path):
     """Injected factories win (tests, other readers); otherwise the package's own BAM (zlib, bamio.cpp) and
     indexed-FASTA readers -- htslib is not needed."""
@@ -139,6 +167,8 @@ class ImageGenerationUtils:
         # which worker's file an interval lands in is not read by anything downstream): the reads of an interval start up to
         # a read length + 16 kb (the BAM index's window) in front of it, so consecutive fetches through one handle find most of
         # their BGZF blocks already inflated in the handle's cache -- the BAM reader is 93 % of this loop's time.
+        device = worker_device(options, process_id)
+        wopts = _on_device(options, device)          # (what the host-clipped form reads .device from)
         batch = max(1, int(getattr(options, "encoder_batch", 0) or os.environ.get("PEPPER_AMD_ENCODER_BATCH", 16)))
         # a worker takes whole runs of consecutive intervals; large jobs are cut so that every worker gets several runs
         run = max(1, min(batch, -(-len(all_intervals) // max(1, options.threads * 4))))
@@ -178,8 +208,8 @@ class ImageGenerationUtils:
             for chr_name, _start, _end in group:
                 if chr_name not in generators:
                     generators.clear()               # one contig's handles at a time per worker
-                    generators[chr_name] = ImageGenerator(chr_name, options.bam, options.fasta, options)
-                prepared.append(generators[chr_name].prepare(options, _start, _end))
+                    generators[chr_name] = ImageGenerator(chr_name, options.bam, options.fasta, wopts)
+                prepared.append(generators[chr_name].prepare(wopts, _start, _end))
             for (chr_name, _start, _end), out in zip(group, create_summaries(prepared)):
                 if out is not None:
                     write(output_hdf_file, chr_name, _start, _end, out)
@@ -204,8 +234,7 @@ class ImageGenerationUtils:
             t_setup = time.perf_counter()
             # (every CPU the process has is inflating BGZF blocks in some worker: the encoder's host part runs on this thread)
             try:
-                enc = PackedEncoder.acquire(getattr(options, "device", 0), int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20,
-                                            host_threads=1)
+                enc = PackedEncoder.acquire(device, int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20, host_threads=1)
             except _lib.PepperAmdError:
                 # no page-locked arena to be had (memlock / cgroup limit): the host-clipped form needs none
                 for g0 in range(0, len(intervals), batch):

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -127,3 +128,32 @@ def test_wg_syn_shards_and_the_two_deals():
     assert imbalance(rr) > 1.15 and imbalance(so) < 1.05
     for world in (1, 2, 4):
         assert imbalance(shard_files(names, world, shards)) < 1.02
+
+
+def _agree_worker(rank, world, port, fail_on, out_dir):
+    import os
+    import torch.distributed as dist
+    from pepper_amd.parallel import agree_on_rccl
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def attempt():
+        if rank in fail_on:
+            raise RuntimeError("no RCCL on rank %d" % rank)
+        return "the-group"
+    group, failed, why = agree_on_rccl(world, attempt)
+    dist.barrier()
+    with open(os.path.join(out_dir, "r%d" % rank), "w") as fh:
+        fh.write("%s %d %s" % (group, failed, "why" if why else "-"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_on", [(), (1,), (0, 1)])
+def test_ranks_agree_on_the_collective_backend(tmp_path, fail_on):
+    """bench.py's N>1 set-up: RCCL failing on SOME ranks must leave every rank on the gloo group (a rank-local fallback hangs the
+    others in an RCCL collective); with it everywhere, every rank gets the group."""
+    port = _free_port()
+    mp.spawn(_agree_worker, args=(2, port, fail_on, str(tmp_path)), nprocs=2, join=True)
+    got = [open(str(tmp_path / ("r%d" % r))).read().split() for r in range(2)]
+    assert got[0][:2] == got[1][:2] == (["the-group", "0"] if not fail_on else ["None", str(len(fail_on))])
+    assert [g[2] for g in got] == ["why" if r in fail_on else "-" for r in range(2)]

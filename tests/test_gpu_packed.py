@@ -261,3 +261,20 @@ def test_device_record_walk_equals_the_host_walk(tmp_path, monkeypatch):
             got[mode] = (n_done, rp.tolist(), counts, enc.reads[:counts[0]].tobytes(), enc.pair_read[:counts[1]].tolist())
             enc.close()
         assert got["1"] == got["0"] and got["1"][0] == len(starts) and got["1"][2][0] > 500
+
+
+def test_workers_over_device_ids_write_the_same_files(tmp_path, monkeypatch):
+    """device_ids "0,0": two workers, each on the device the map gives it (worker t -> device_ids[t % n]) -- the files are those
+    of the run without device_ids."""
+    from pepper_amd.variant.ImageGenerationUI import ImageGenerationUtils
+    rng = np.random.default_rng(913)
+    ref = pu.random_reference(rng, 16000)
+    sites = {int(p): ("ACGT"[("ACGT".index(ref[p]) + 1) % 4], 0.5) for p in rng.choice(np.arange(300, 15000), 40, replace=False)}
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=500, read_len=(400, 2500), snp_sites=sites)
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    for i, r in enumerate(reads):
+        r["name"] = "r%d" % i
+    bam, fa = _write(tmp_path, [("ctg", ref)], {0: reads}, flush_every=31)
+    ImageGenerationUtils.generate_images(_options(bam, fa, str(tmp_path / "one"), None, 2000, 1))
+    ImageGenerationUtils.generate_images(_options(bam, fa, str(tmp_path / "two"), None, 2000, 2, device_ids="0,0"))
+    assert _same(_groups(str(tmp_path / "two")), _groups(str(tmp_path / "one"))) > 20
