@@ -917,7 +917,7 @@ def polish_make_images_leg(scratch):
     tool = os.path.join(REPO, "tools", "bench_polish_chain.py")
     try:
         from pepper_amd.hostinfo import usable_cpus
-        threads = max(1, min(8, usable_cpus()))
+        threads = max(1, usable_cpus())
         p = subprocess.run([sys.executable, tool, "make_fast", work, "16000000"], capture_output=True, text=True, timeout=600)
         if p.returncode != 0:
             return {"error": (p.stderr or "synth_bam failed").strip().splitlines()[-1][:300]}
@@ -1054,9 +1054,9 @@ def secondary_block(args):
         pass
     extra = ["--dir", scratch] if scratch else []
     out["make_images"] = make_images_leg(scratch)
-    # the same job on a BAM as samtools writes it: zlib level 6 members, NM / MD / RG aux data in every record (8 Mb: zlib level 6
+    # the same job on a BAM as samtools writes it: zlib level 6 members, NM / MD / RG aux data in every record (32 Mb: zlib level 6
     # writes the synthetic file at a tenth of libdeflate level 1's rate)
-    lv6 = make_images_leg(scratch, level=6, tags=1, bases_default=8_000_000)
+    lv6 = make_images_leg(scratch, level=6, tags=1, bases_default=32_000_000)
     out["make_images_level6"] = lv6 if "error" in lv6 else {k: lv6[k] for k in ("value", "unit", "seconds", "threads", "runs_mb_per_s", "data",
                                                                                   "stage_seconds_summed_over_workers", "synth_seconds")}
     out["polish_make_images"] = polish_make_images_leg(scratch)

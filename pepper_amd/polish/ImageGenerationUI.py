@@ -71,6 +71,11 @@ class UserInterfaceSupport:
     # intervals per call of the device-resident chain (PEPPER_AMD_POLISH_CHAIN_REGIONS): ~64 reads each at 60x, so 128 of them
     # are ~8 000 re-alignments per launch -- several wavefronts per SIMD
     CHAIN_REGIONS = int(os.environ.get("PEPPER_AMD_POLISH_CHAIN_REGIONS", 128))
+    # intervals per call of the BAM reader's packed form (PEPPER_AMD_POLISH_PACK_REGIONS): the file span of that many intervals is
+    # inflated by ONE launch (a member takes a wavefront ~6 ms whatever the launch holds: 128 intervals are ~220 members, a
+    # launch that leaves most of the chip idle) and stays on the device for the chain calls over its stretches (one worker
+    # thread on a 16 Mb draft at 60x: 4.7 Mb/s with 128 intervals per span, 5.7 with 512, 6.1 with 1 024 -- ~110 MB of arena)
+    PACK_REGIONS = int(os.environ.get("PEPPER_AMD_POLISH_PACK_REGIONS", 1024))
 
     @staticmethod
     def handle_output_directory(output_directory):
@@ -158,7 +163,8 @@ class UserInterfaceSupport:
         output_path, bam_file, draft_file, truth_bam, train_mode, downsample_rate = args
         timestr = time.strftime("%m%d%Y_%H%M%S")
         file_name = output_path + "pepper_hp_images_thread_" + str(thread_id) + "_" + str(timestr) + ".hdf"
-        batch = max(1, UserInterfaceSupport.CHAIN_REGIONS)
+        per_call = max(1, UserInterfaceSupport.CHAIN_REGIONS)
+        batch = max(per_call, UserInterfaceSupport.PACK_REGIONS)
         run = max(1, min(batch, -(-len(all_intervals) // max(1, total_threads * 2))))
         intervals = [r for i, r in enumerate(all_intervals) if (i // run) % total_threads == thread_id]
         if thread_id == 0:
@@ -249,24 +255,30 @@ class UserInterfaceSupport:
                     whole = fasta_handler.get_reference_bytes(chr_name, lo, max(stops) + safe + 1)
                     windows = [whole[a - lo:b + safe + 1 - lo] for a, b in zip(starts, stops)]
                     t0 = lap("fasta", t0)
-                    try:
-                        _rows, _live, chunks = chain.run(list(zip(starts, stops)), windows, region_pairs, counts, realign=True,
-                                                         resident=resident, chunk_size=seq_len, chunk_overlap=ImageSizeOptions.SEQ_OVERLAP)
-                    except _lib.PepperAmdError as err:
-                        if getattr(err, "code", 0) != _lib.PA_ERR_UNSUPPORTED:
-                            raise
-                        host_form(chr_name, block)
-                        counter += n_done
-                        continue
-                    t0 = lap("chain", t0)
-                    for key, v in chain.timing().items():
-                        if key.endswith("_ms"):
-                            mine["chain_" + key[:-3]] = mine.get("chain_" + key[:-3], 0.0) + v / 1e3
-                        else:
-                            mine[key] = mine.get(key, 0) + v
-                    img, pos, idx = chain.chunk_pointers()
-                    output_hdf_file.write_regions(chr_name, starts, stops, chunks, seq_len, features, img, pos, idx)
-                    t0 = lap("hdf5", t0)
+                    refused_at = None
+                    for r0 in range(0, n_done, per_call):           # the chain over stretches of the resident span
+                        r1 = min(n_done, r0 + per_call)
+                        try:
+                            _rows, _live, chunks = chain.run(list(zip(starts[r0:r1], stops[r0:r1])), windows[r0:r1], region_pairs[r0:r1 + 1],
+                                                             counts, realign=True, resident=resident, chunk_size=seq_len,
+                                                             chunk_overlap=ImageSizeOptions.SEQ_OVERLAP)
+                        except _lib.PepperAmdError as err:
+                            if getattr(err, "code", 0) != _lib.PA_ERR_UNSUPPORTED:
+                                raise
+                            host_form(chr_name, block[r0:])          # (this stretch and what follows it in the span)
+                            refused_at = r0
+                            break
+                        t0 = lap("chain", t0)
+                        for key, v in chain.timing().items():
+                            if key.endswith("_ms"):
+                                mine["chain_" + key[:-3]] = mine.get("chain_" + key[:-3], 0.0) + v / 1e3
+                            else:
+                                mine[key] = mine.get(key, 0) + v
+                        img, pos, idx = chain.chunk_pointers()
+                        output_hdf_file.write_regions(chr_name, starts[r0:r1], stops[r0:r1], chunks, seq_len, features, img, pos, idx)
+                        t0 = lap("hdf5", t0)
+                    if refused_at is not None:
+                        deep = [r for r in deep if r < refused_at]
                     if len(deep):
                         host_form(chr_name, [block[r] for r in deep])
                         lap("deep_host_form", t0)

@@ -154,21 +154,23 @@ class PolishChain(object):
         self.chunk_size = 0
 
     def run(self, regions, windows, region_pairs, counts, realign=True, resident=False, chunk_size=1000, chunk_overlap=50):
-        """regions: [(start, end)] of the packed run; windows[r]: the draft from start to end + 20 (bytes; shorter at the
-        contig's end); region_pairs / counts: what pack_device() / pack() returned.
-        -> (rows per region, reads per region, chunks per region)."""
+        """regions: [(start, end)] of the packed run -- or of a stretch of it: region_pairs[0] may be > 0, the pairs of the
+        regions given are then pair_read[region_pairs[0] .. region_pairs[n]) (one pack_device() span serves several chain calls);
+        windows[r]: the draft from start to end + 20 (bytes; shorter at the contig's end); region_pairs / counts: what
+        pack_device() / pack() returned.  -> (rows per region, reads per region, chunks per region)."""
         from pepper_amd.variant.PEPPER_VARIANT import _PackedRegion
         pe = self.packed
         n = len(regions)
         refs = [w if isinstance(w, bytes) else bytes(w) for w in windows]
         regs = (_PackedRegion * max(1, n))(*[_PackedRegion(int(a), int(b), ref, len(ref)) for (a, b), ref in zip(regions, refs)])
-        region_pairs = np.ascontiguousarray(region_pairs[:n + 1], np.int32)
+        first_pair = int(region_pairs[0])
+        region_pairs = np.ascontiguousarray(np.asarray(region_pairs[:n + 1], np.int64) - first_pair, np.int32)
         n_reads, _n_pairs, arena_bytes = counts
         rows, live, chunks = np.zeros(max(1, n), np.int64), np.zeros(max(1, n), np.int32), np.zeros(max(1, n), np.int32)
         total = ctypes.c_int64()
         _lib.check(self.lib.pa_polish_chain_run(
             pe.enc, n, ctypes.cast(regs, ctypes.c_void_p), None if (resident and n_reads > 0) else pe.arena.ctypes.data,
-            int(arena_bytes), pe.reads.ctypes.data, int(n_reads), pe.pair_read.ctypes.data, region_pairs.ctypes.data,
+            int(arena_bytes), pe.reads.ctypes.data, int(n_reads), pe.pair_read.ctypes.data + 4 * first_pair, region_pairs.ctypes.data,
             1 if realign else 0, int(chunk_size), int(chunk_overlap), rows.ctypes.data, live.ctypes.data, chunks.ctypes.data,
             ctypes.byref(total)))
         self.n_chunks, self.chunk_size = total.value, int(chunk_size)

@@ -96,7 +96,7 @@ def polish_job(work, bases, coverage, n_runs):
     info = synth(work, bases, coverage)
     model = os.path.join(work, "polish.pkl")
     checkpoint(model, "polish")
-    threads = max(1, min(8, usable_cpus()))
+    threads = max(1, usable_cpus())
     runs = []
     for k in range(n_runs + 1):
         out = os.path.join(work, "polish_out_%d" % k) + "/"
