@@ -1062,6 +1062,9 @@ def secondary_block(args):
     out["polish_make_images"] = polish_make_images_leg(scratch)
     # the two top entry points as one job each (stage walls inside): 256 Mb at 30x for call_variant, 64 Mb at 60x for polish
     out["call_variant"] = e2e_leg("call_variant", scratch, 256_000_000, 30, 3, 24)
+    # ... and with image generation and inference fused (options.fused_inference: the encoder's windows go to the model on the
+    # device, candidate selection runs while the predictions are written; both HDF5 stores are still written)
+    out["call_variant_fused"] = e2e_leg("call_variant_fused", scratch, 256_000_000, 30, 3, 24)
     out["polish_e2e"] = e2e_leg("polish", scratch, 64_000_000, 60, 2, 16)
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "8000000"], 300)
 

@@ -47,18 +47,40 @@ def call_variant(options):
     _log("STEP 1/3 GENERATING IMAGES:")
     options.image_output_directory = image_output_directory
     walls = getattr(options, "stage_walls", None)           # a dict the caller wants the three steps' wall times in
+    precomputed = None
     t0 = time.perf_counter()
-    ImageGenerationUtils.generate_images(options)
-    t1 = time.perf_counter()
+    fused = bool(getattr(options, "fused_inference", False)) or os.environ.get("PEPPER_AMD_FUSED_CALL_VARIANT") == "1"
+    if fused:
+        # opt-in: the encoder's windows go to the model where they lie on the device; both HDF5 files are still written
+        # (pepper_amd/variant/fused.py).  Steps 1 and 2 are then one step.
+        from pepper_amd.variant.fused import FusedPredictor
+        os.makedirs(prediction_output_directory, exist_ok=True)
+        _log("STEP 1+2/3 GENERATING IMAGES AND RUNNING INFERENCE (FUSED)")
+        _log("OUTPUT: " + str(prediction_output_directory))
+        options.fused_sink = FusedPredictor(options, prediction_output_directory)
+        precomputed = None
+        try:
+            ImageGenerationUtils.generate_images(options)
+        finally:
+            sink, options.fused_sink = options.fused_sink, None
+            sink.close()
+            precomputed = sink.segments or None
+            if walls is not None:
+                walls["fused_writer_drain"] = getattr(sink, "drain_seconds", 0.0)
+        t1 = t2 = time.perf_counter()
+    else:
+        ImageGenerationUtils.generate_images(options)
+        t1 = time.perf_counter()
 
-    _log("STEP 2/3 RUNNING INFERENCE")
-    _log("OUTPUT: " + str(prediction_output_directory))
-    run_inference(options, image_output_directory, prediction_output_directory)
-    t2 = time.perf_counter()
+        _log("STEP 2/3 RUNNING INFERENCE")
+        _log("OUTPUT: " + str(prediction_output_directory))
+        run_inference(options, image_output_directory, prediction_output_directory)
+        t2 = time.perf_counter()
 
     _log("STEP 3/3 FINDING CANDIDATES")
     _log("OUTPUT: " + str(candidate_output_directory))
-    totals = process_candidates(options, prediction_output_directory, candidate_output_directory)
+    totals = process_candidates(options, prediction_output_directory, candidate_output_directory,
+                                precomputed=precomputed if fused else None)
     if walls is not None:
         walls.update(make_images=t1 - t0, run_inference=t2 - t1, find_candidates=time.perf_counter() - t2)
 

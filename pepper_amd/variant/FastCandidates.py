@@ -287,6 +287,14 @@ def _native_batch_open(options, rules, fasta_handler, file_name, batch_key, file
     first = contig_blob[:contig_blob.index(b"\0")]
     if contig_blob != (first + b"\0") * n or tuple(shape) != (n, 1) or np.shape(freq) != (n, 1) or np.asarray(freq).dtype.kind not in "iu":
         return None
+    return native_batch_arrays(options, rules, fasta_handler, first, n, positions, depths, freq, pred, blob, file_name + "/" + batch_key)
+
+
+def native_batch_arrays(options, rules, fasta_handler, first, n, positions, depths, freq, pred, blob, where="(memory)"):
+    """Selection + record text of ONE prediction batch from its arrays (what _native_batch_open reads from a file; the fused
+    call_variant hands over a batch as it writes it): first = the batch's one contig name (bytes), blob = its n candidate strings,
+    each followed by a NUL.  -> _Segment, or None when the batch needs the per-row Python path."""
+    file_name, batch_key = where, ""
     text = np.frombuffer(blob, np.uint8)
     ends = np.flatnonzero(text == 0)
     if len(ends) != n or np.isin(text, _LIST_BYTES).any():
@@ -415,14 +423,35 @@ def _write_all(vcf, names, contig_code, starts, ref_lens, lines, is_snp, selecte
     return tuple(totals)
 
 
-def process(options, all_prediction_pair, vcf):
+def process(options, all_prediction_pair, vcf, precomputed=None):
     """all_prediction_pair: [(prediction file, batch key)] as FindCandidates.candidate_finder lists them; vcf: an open
     VCFWriter.  -> (contigs, totals) with totals as write_vcf_records returns them."""
-    parts = _parts(options, all_prediction_pair)
     segments, leftovers = [], []
-    for part_segments, part_left in parts:
-        segments.extend(part_segments)
-        leftovers.extend(part_left)
+    if precomputed is None:
+        for part_segments, part_left in _parts(options, all_prediction_pair):
+            segments.extend(part_segments)
+            leftovers.extend(part_left)
+    else:
+        # the fused call_variant computed most batches' segments while it wrote them (fused.py); the batches keep the order of the
+        # listing (which record of a duplicated site survives depends on it), the missing ones are done here from the file
+        todo = []
+
+        def flush():
+            part_segments, part_left = _part(options, todo)
+            segments.extend(part_segments)
+            leftovers.extend(part_left)
+            del todo[:]
+        for pair in all_prediction_pair:
+            seg = precomputed.get(pair)
+            if seg is None:
+                todo.append(pair)
+                continue
+            if todo:
+                flush()
+            if len(seg):
+                segments.append(seg)
+        if todo:
+            flush()
     plain = _plain_options(options)
     sizes = np.fromiter(map(len, segments), np.int64, len(segments))
     n = int(sizes.sum())

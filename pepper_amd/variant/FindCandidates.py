@@ -29,7 +29,9 @@ def _log(message):
     sys.stderr.write("[" + str(datetime.now().strftime('%m-%d-%Y %H:%M:%S')) + "] INFO: " + message + "\n")
 
 
-def candidate_finder(options, input_dir, output_path):
+def candidate_finder(options, input_dir, output_path, precomputed=None):
+    """precomputed: {(prediction file, batch key): FastCandidates segment} of batches whose selection was done while they were
+    written (the fused call_variant); the others are read from the files as always."""
     all_prediction_pair = []
     for prediction_file in get_file_paths_from_directory(input_dir):
         with h5.File(prediction_file, 'r') as hdf5_file:
@@ -55,7 +57,7 @@ def candidate_finder(options, input_dir, output_path):
         # the same rules column-wise (FastCandidates.py; held to the tuple path file by file in tests/test_candidate_finder.py)
         from pepper_amd.variant import FastCandidates
         vcf_file_full = writer()
-        contigs, totals = FastCandidates.process(options, all_prediction_pair, vcf_file_full)
+        contigs, totals = FastCandidates.process(options, all_prediction_pair, vcf_file_full, precomputed=precomputed)
         end_time = time.time()
     vcf_file_full.close()
     total_variants, total_pepper, total_variant_calling, total_variant_calling_snp, total_variant_calling_indel = totals
@@ -69,6 +71,6 @@ def candidate_finder(options, input_dir, output_path):
     return totals
 
 
-def process_candidates(options, input_dir, output_dir):
+def process_candidates(options, input_dir, output_dir, precomputed=None):
     output_dir = ImageGenerationUtils.handle_output_directory(output_dir)
-    return candidate_finder(options, input_dir, output_dir)
+    return candidate_finder(options, input_dir, output_dir, precomputed=precomputed)

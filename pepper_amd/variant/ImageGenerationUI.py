@@ -191,8 +191,12 @@ class ImageGenerationUtils:
                     for key, v in mine.items():
                         stats[key] = stats.get(key, 0.0) + v
 
-        def write(output_hdf_file, chr_name, _start, _end, out):
+        sink = getattr(options, "fused_sink", None)         # call_variant's fused form: predictions straight from the encoder's windows
+
+        def write(output_hdf_file, chr_name, _start, _end, out, probs=None):
             n = len(out["candidates"])
+            if sink is not None:
+                sink.submit(chr_name, out, probs if probs is not None else sink.forward_host(device, out["images"]))
             summary_name = chr_name + "_" + str(_start) + "_" + str(_end)
             if output_hdf_file.write_summary_packed(summary_name, chr_name, out):
                 return
@@ -305,9 +309,17 @@ class ImageGenerationUtils:
                     g0 += n_done
                     continue
                 t0 = lap("encode", t0)
+                probs, at = None, 0
+                if sink is not None:
+                    # the group's windows are still where the encoder left them on the device: the model reads them there
+                    total = sum(len(o["positions"]) for o in outs)
+                    probs = sink.forward_device(device, enc.lib.pa_encoder_device_images(enc.enc), total)
+                    t0 = lap("fused_forward", t0)
                 for (chr_name, _start, _end), out, n_reads in zip(group, outs, live):
+                    k = len(out["positions"])
                     if n_reads > 0:                  # (no read with a base inside: create_summary returns None, nothing is written)
-                        write(output_hdf_file, chr_name, _start, _end, out)
+                        write(output_hdf_file, chr_name, _start, _end, out, None if probs is None else probs[at:at + k])
+                    at += k
                 lap("hdf5", t0)
                 g0 += n_done
             if enc.inflated_bytes:

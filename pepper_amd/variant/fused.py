@@ -1,0 +1,189 @@
+"""call_variant with image generation and inference fused (opt-in: options.fused_inference / PEPPER_AMD_FUSED_CALL_VARIANT=1).
+
+The reference's three steps talk through files (/root/reference/pepper_variant/modules/python/CallVariant.py:74-104: make_images
+writes the image HDF5 files, run_inference reads them back).  Here an image-generation worker hands a group's candidate windows
+to the model WHERE THE ENCODER LEFT THEM on the device (pa_encoder_device_images -> pa_variant_forward_device: no D2H -> HDF5 ->
+H2D round trip for the model's input) and queues the predictions for one writer thread; both HDF5 files are still written, with
+the reference's layouts -- the image files by the workers as before, `pepper_prediction.hdf` (predictions/batch_<n> groups of
+options.batch_size candidates) by the writer in arrival order.  Which batch a candidate lands in differs from the unfused run (the
+candidate finder sorts sites itself, CandidateFinder.py:356-581); every candidate's record is the same.
+"""
+import ctypes
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from pepper_amd import _lib
+from pepper_amd.variant.DataStorePredict import DataStore
+from pepper_amd.variant.Options import ImageSizeOptions
+from pepper_amd.variant.models.ModelHander import ModelHandler
+
+
+class FusedPredictor(object):
+    """One per call_variant run: a model handle per device (made on first use, a lock each: the device runs one forward at a
+    time anyway) and one writer thread over a queue of (contig, arrays, probabilities)."""
+
+    def __init__(self, options, output_filepath):
+        self.options = options
+        self.batch_size = int(options.batch_size)
+        self.models = {}
+        self.models_lock = threading.Lock()
+        self.store = DataStore(output_filepath + "pepper_prediction.hdf", mode='w')
+        self.queue = queue.Queue(maxsize=64)
+        self.error = None
+        self.batch_no = 0
+        self.windows = 0
+        self.pending = []            # arrays of the candidates that have not filled a batch yet
+        self.filename = output_filepath + "pepper_prediction.hdf"
+        # the candidate finder's selection + record text of a batch (FastCandidates.native_batch_arrays, inside the I/O library)
+        # runs on a third thread as soon as the batch exists, so that step 3 starts with most of its per-batch work done
+        self.segments = {}
+        self.select_queue = queue.Queue()
+        self.selector = None
+        if not getattr(options, "fused_candidates_off", False):
+            self.selector = threading.Thread(target=self._select_loop, name="fused-candidate-selection", daemon=True)
+            self.selector.start()
+        self.writer = threading.Thread(target=self._write_loop, name="fused-prediction-writer", daemon=True)
+        self.writer.start()
+
+    # ---- model ----
+    def _model(self, device):
+        with self.models_lock:
+            entry = self.models.get(device)
+            if entry is None:
+                torch.cuda.set_device(device)
+                model = ModelHandler.load_simple_model_for_training(
+                    self.options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT, num_classes=ImageSizeOptions.TOTAL_LABELS,
+                    num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)[0]
+                model.eval()
+                entry = self.models[device] = (model, threading.Lock())
+            return entry
+
+    def forward_device(self, device, images_ptr, n):
+        """n int8 windows [n, 33, 26] at device address images_ptr (the encoder's results of its last run: complete, and valid
+        until that encoder's next call) -> float32 probabilities [n, 3] on the host."""
+        if n == 0:
+            return np.zeros((0, ImageSizeOptions.TOTAL_TYPE_LABELS), np.float32)
+        model, lock = self._model(device)
+        lib = _lib.load()
+        with lock:
+            torch.cuda.set_device(device)
+            probs = torch.empty((n, model.num_classes_type), dtype=torch.float32, device=torch.device("cuda", device))
+            _lib.check(lib.pa_variant_forward_device(model.handle, ctypes.c_void_p(images_ptr), n, probs.data_ptr(), None))
+            model._stream.synchronize()
+            return probs.cpu().numpy()
+
+    def forward_host(self, device, images):
+        """int8 windows on the host (the host-clipped form of image generation) -> probabilities."""
+        if len(images) == 0:
+            return np.zeros((0, ImageSizeOptions.TOTAL_TYPE_LABELS), np.float32)
+        model, lock = self._model(device)
+        with lock:
+            torch.cuda.set_device(device)
+            return model(torch.from_numpy(np.ascontiguousarray(images)), False).numpy()
+
+    # ---- predictions ----
+    def submit(self, contig, out, probs):
+        """out: one interval's arrays as the encoder returns them (positions, depths, candidates_blob / offsets or candidates,
+        candidate_frequency); probs float32 [n, 3]."""
+        if self.error is not None:
+            raise self.error
+        if len(out["positions"]):
+            self.queue.put((contig, out, probs))
+
+    def _flush(self, final):
+        """batch_size candidates per predictions/batch_<n> group, as the reference's DataLoader batches them; the groups are
+        written from bulk arrays (one library call each), the candidate strings as the encoder left them (NUL-terminated, back to
+        back)."""
+        while self.pending and (final or sum(len(p[1]) for p in self.pending) >= self.batch_size):
+            take, have = [], 0
+            while self.pending and have < self.batch_size:
+                piece = self.pending[0]
+                room = self.batch_size - have
+                if len(piece[1]) <= room:
+                    take.append(self.pending.pop(0))
+                    have += len(piece[1])
+                else:
+                    contigs, pos, dep, blob, off, freq, probs = piece
+                    cut = int(off[room])                     # first byte of the first candidate that does not fit
+                    take.append((contigs[:room], pos[:room], dep[:room], blob[:cut], off[:room], freq[:room], probs[:room]))
+                    self.pending[0] = (contigs[room:], pos[room:], dep[room:], blob[cut:], off[room:] - cut, freq[room:], probs[room:])
+                    have += room
+            blob = b"".join(t[3] for t in take)
+            bases = np.cumsum([0] + [len(t[3]) for t in take[:-1]])
+            contigs = np.concatenate([t[0] for t in take])
+            positions, depths = np.concatenate([t[1] for t in take]), np.concatenate([t[2] for t in take])
+            freqs, probs = np.concatenate([t[5] for t in take]).reshape(-1, 1), np.concatenate([t[6] for t in take])
+            self.store.write_prediction_arrays(self.batch_no, contigs, positions, depths, np.frombuffer(blob + b"\0", np.uint8),
+                                               np.concatenate([t[4] + base for t, base in zip(take, bases)]), freqs, probs)
+            if self.selector is not None:
+                self.select_queue.put(("batch_" + str(self.batch_no), contigs, positions, depths, freqs, probs, blob))
+            self.batch_no += 1
+            self.windows += have
+
+    def _select_loop(self):
+        """Per batch what FastCandidates._part does from the file: None results (a batch of several contigs, a candidate list the
+        library does not take) are left for step 3 to do from the file."""
+        from pepper_amd.variant import FastCandidates
+        options = self.options
+        try:
+            fasta_handler = FastCandidates._fasta(options)
+            rules = FastCandidates._rules(options)
+            while True:
+                item = self.select_queue.get()
+                if item is None:
+                    break
+                if rules is None:             # (thresholds the library does not take: step 3 does the job the Python way)
+                    continue
+                key, contigs, positions, depths, freqs, probs, blob = item
+                first = bytes(contigs[0])
+                if len(contigs) == 0 or (contigs != contigs[0]).any():
+                    continue
+                seg = FastCandidates.native_batch_arrays(options, rules, fasta_handler, first, len(positions), positions, depths, freqs,
+                                                         probs, blob, self.filename + "/" + key)
+                if seg is not None:
+                    self.segments[(self.filename, key)] = seg
+        except BaseException:             # noqa: BLE001 -- whatever was not selected here is selected in step 3 from the file
+            while self.select_queue.get() is not None:
+                pass
+
+    def _write_loop(self):
+        try:
+            while True:
+                item = self.queue.get()
+                if item is None:
+                    break
+                contig, out, probs = item
+                n = len(out["positions"])
+                # (contigs 'S', positions, depths, the interval's candidate strings, each candidate's offset in them, support, p)
+                offs = np.asarray(out["candidates_offsets"], np.int64)
+                blob = bytes(out["candidates_blob"])[int(offs[0]):int(offs[n]) if len(offs) > n else None]
+                self.pending.append((np.array([contig] * n, dtype='S'), np.asarray(out["positions"], np.int32),
+                                     np.asarray(out["depths"]).astype(np.uint8), blob, offs[:n] - offs[0],
+                                     np.asarray(out["candidate_frequency"]).astype(np.uint8), np.asarray(probs, np.float32)))
+                self._flush(False)
+            self._flush(True)
+        except BaseException as err:      # noqa: BLE001 -- surfaces in submit() / close()
+            self.error = err
+            while True:                   # keep draining so that no producer blocks on a full queue
+                if self.queue.get() is None:
+                    break
+
+    def close(self):
+        import time
+        t0 = time.perf_counter()
+        self.queue.put(None)
+        self.writer.join()
+        if self.selector is not None:
+            self.select_queue.put(None)
+            self.selector.join()
+        self.drain_seconds = time.perf_counter() - t0      # what the two threads still had to do when image generation was over
+        self.store.close()
+        for model, _ in self.models.values():
+            model.close()
+        self.models.clear()
+        if self.error is not None:
+            raise self.error
+        return self.batch_no, self.windows

@@ -370,6 +370,82 @@ def test_call_variant_vcf_identity(tmp_path):
     _assert_same_vcfs(options.output_dir, str(tmp_path / "ovcf"))
 
 
+def test_fused_call_variant_equals_the_three_step_run(tmp_path):
+    """options.fused_inference: the encoder's windows go to the model on the device, both HDF5 stores are still written -- the
+    image files are those of the unfused run, every candidate has the same prediction (batch membership differs: arrival order),
+    and the five VCFs are byte-identical."""
+    import bam_utils as bu
+    import pileup_utils as pu
+    from pepper_amd.variant.CallVariant import call_variant
+    rng = np.random.default_rng(404)
+    ref = pu.random_reference(rng, 9000)
+    sites = {int(p): ("ACGT"[(("ACGT".index(ref[p]) + 1) % 4)], 0.5) for p in rng.choice(np.arange(200, 8800), 50, replace=False)}
+    indels = {900: ("I", "CA", 0.6), 2500: ("D", 2, 0.7), 6100: ("D", 9, 0.5), 7000: ("I", "ACGTACGTTTGACA", 0.4)}
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=700, read_len=(400, 1800), snp_sites=sites, indel_sites=indels)
+    reads = [r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])]
+    # a pile beyond MAX_READS_IN_REGION on one interval: that interval takes the host-clipped form (forward from host buffers)
+    deep = pu.simulate_reads(rng, ref[3000:3900], 3000, n_reads=5300, read_len=(150, 300), snp_sites=sites)
+    reads = sorted(reads + [r for r in deep if not any(op in (3, 6) for op, _ in r["cigar"])], key=lambda r: r["pos"])
+    for i, r in enumerate(reads):
+        r["name"] = "q%d" % i
+    bam_path, fa_path = str(tmp_path / "in.bam"), str(tmp_path / "ref.fa")
+    bu.write_bam(bam_path, [("chr20", len(ref))], {0: reads}, flush_every=50)
+    with open(fa_path, "w") as fh:
+        fh.write(">chr20\n" + "\n".join(ref[i:i + 60] for i in range(0, len(ref), 60)) + "\n")
+    sd = synthetic.variant_state_dict(seed=93, gain=2.5)
+    model_path = str(tmp_path / "model.pkl")
+    torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
+
+    def options(out, **over):
+        o = SimpleNamespace(
+            bam=bam_path, fasta=fa_path, region=None, region_size=1500, threads=3, train_mode=False,
+            use_hp_info=False, include_supplementary=False, output_dir=out,
+            min_mapq=1, min_snp_baseq=1, min_indel_baseq=1, snp_frequency=0.10, insert_frequency=0.15,
+            delete_frequency=0.15, min_coverage_threshold=3, snp_candidate_frequency_threshold=0.10,
+            indel_candidate_frequency_threshold=0.12, candidate_support_threshold=2, skip_indels=False,
+            downsample_rate=1.0,
+            model_path=model_path, batch_size=128, num_workers=0, gpu=True, device_ids="0", callers_per_gpu=1,
+            quantized=False, dry=False, sample_name="SYN", allowed_multiallelics=4,
+            snp_p_value=0.1, insert_p_value=0.25, delete_p_value=0.25, snp_p_value_in_lc=0.1,
+            insert_p_value_in_lc=0.3, delete_p_value_in_lc=0.3, snp_q_cutoff=20, indel_q_cutoff=15,
+            snp_q_cutoff_in_lc=20, indel_q_cutoff_in_lc=10, report_snp_above_freq=0, report_indel_above_freq=0)
+        for k, v in over.items():
+            setattr(o, k, v)
+        return o
+    img_a, pred_a, totals_a = call_variant(options(str(tmp_path / "plain")))
+    img_b, pred_b, totals_b = call_variant(options(str(tmp_path / "fused"), fused_inference=True))
+    assert totals_a == totals_b and totals_a[0] > 30
+
+    def predictions(directory):
+        out = {}
+        for fn in sorted(os.listdir(directory)):
+            with h5.File(os.path.join(directory, fn)) as f:
+                for batch in f.keys("predictions"):
+                    base = "predictions/" + batch + "/"
+                    contigs, pos = f[base + "contigs"].tolist(), f[base + "positions"].tolist()
+                    cand, probs = f[base + "candidates"].tolist(), f[base + "base_prediction"]
+                    depth, freq = f[base + "depths"].tolist(), f[base + "candidate_frequency"].tolist()
+                    assert probs.dtype == np.float64 and len(pos) <= 128
+                    for k in range(len(pos)):
+                        key = (contigs[k], pos[k], cand[k][0])
+                        assert key not in out
+                        out[key] = (depth[k], freq[k][0], tuple(probs[k].tolist()))
+        return out
+    a, b = predictions(pred_a), predictions(pred_b)
+    assert len(a) > 60 and a == b                              # bit-identical probabilities, whatever batch a window rode in
+
+    def images(directory):
+        out = {}
+        for fn in sorted(os.listdir(directory)):
+            with h5.File(os.path.join(directory, fn)) as f:
+                for name in (f.keys("summaries") if "summaries" in f else []):
+                    out[name] = (f["summaries/" + name + "/images"], f["summaries/" + name + "/positions"])
+        return out
+    ia, ib = images(img_a), images(img_b)
+    assert sorted(ia) == sorted(ib) and all(np.array_equal(ia[k][0], ib[k][0]) and np.array_equal(ia[k][1], ib[k][1]) for k in ia)
+    _assert_same_vcfs(str(tmp_path / "fused"), str(tmp_path / "plain"))
+
+
 def _assert_same_vcfs(got_dir, want_dir):
     from pepper_amd.variant import bgzf
     for name in ("PEPPER_VARIANT_FULL", "PEPPER_VARIANT_OUTPUT_PEPPER", "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING",

@@ -3,6 +3,7 @@
   python tools/bench_e2e.py call_variant <dir> [genome_bases=256000000] [coverage=30] [runs=3]
       pepper_amd.variant.CallVariant.call_variant (pepper_variant call_variant, CallVariant.py:74-104):
       BAM + FASTA + checkpoint -> image HDF5 -> predictions HDF5 -> five VCFs
+  python tools/bench_e2e.py call_variant_fused <dir> ...     the same with options.fused_inference (pepper_amd/variant/fused.py)
   python tools/bench_e2e.py polish <dir> [draft_bases=64000000] [coverage=60] [runs=3]
       pepper_amd.polish.polish.polish (pepper polish, polish.py:94-117): BAM + draft + checkpoint -> images -> predictions -> FASTA
 
@@ -32,11 +33,39 @@ def synth(work, bases, coverage, seed=2027):
     return info
 
 
-def checkpoint(path, kind):
+def checkpoint(path, kind, reference_bias=0.0):
+    """Seeded random-init weights; reference_bias leans the variant model's output layer towards the reference class (a random-init
+    head calls every window a variant -- 2.3 M VCF records per 128 Mb --, a trained model a few per hundred: calibrate_bias)."""
     import torch
     from pepper_amd import synthetic
-    sd = synthetic.variant_state_dict(seed=0) if kind == "variant" else synthetic.polish_state_dict(seed=0)
+    sd = synthetic.variant_state_dict(seed=0, gain=2.0) if kind == "variant" else synthetic.polish_state_dict(seed=0)
+    if kind == "variant":
+        sd["output_layer_type.bias"] = sd["output_layer_type.bias"] + __import__("numpy").array([reference_bias, 0.0, 0.0], "float32")
     torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), path)
+
+
+REFERENCE_BIAS = 6.1      # calibrate_bias() on a 128 Mb / 30x job with the seed-0, gain-2 weights: ~2 % of the windows are called
+
+
+def calibrate_bias(pred_dir, fraction=0.02, threshold=0.1):
+    """The reference-class bias at which `fraction` of the warm-up run's windows keep a non-reference probability above the
+    candidate finder's p-value threshold: softmax(z0 + b, z1, z2) for every window from the probabilities written with b = 0."""
+    import numpy as np
+    from pepper_amd import h5
+    rows = []
+    for path in sorted(glob.glob(os.path.join(pred_dir, "*.hdf"))):
+        with h5.File(path) as f:
+            for g in f.keys("predictions")[:400]:
+                rows.append(np.asarray(f["predictions/" + g + "/base_prediction"], np.float64))
+    p = np.clip(np.concatenate(rows), 1e-300, 1.0)
+    r1, r2 = p[:, 1] / p[:, 0], p[:, 2] / p[:, 0]
+    lo, hi = -10.0, 40.0
+    for _ in range(60):
+        b = 0.5 * (lo + hi)
+        a1, a2 = r1 * np.exp(-b), r2 * np.exp(-b)
+        called = (np.maximum(a1, a2) / (1.0 + a1 + a2) > threshold).mean()
+        lo, hi = (b, hi) if called > fraction else (lo, b)
+    return 0.5 * (lo + hi)
 
 
 def median_run(runs, key="seconds"):
@@ -44,12 +73,13 @@ def median_run(runs, key="seconds"):
     return order[len(order) // 2]
 
 
-def call_variant_job(work, bases, coverage, n_runs):
+def call_variant_job(work, bases, coverage, n_runs, fused=False):
     from pepper_amd.hostinfo import usable_cpus
     from pepper_amd.variant.CallVariant import call_variant
     info = synth(work, bases, coverage)
     model = os.path.join(work, "variant.pkl")
-    checkpoint(model, "variant")
+    bias = REFERENCE_BIAS
+    checkpoint(model, "variant", reference_bias=bias)
     threads = max(1, usable_cpus())
     runs = []
     for k in range(n_runs + 1):
@@ -64,10 +94,14 @@ def call_variant_job(work, bases, coverage, n_runs):
             model_path=model, batch_size=512, num_workers=0, gpu=True, device_ids="0", callers_per_gpu=1, quantized=False, dry=False,
             sample_name="SYN", allowed_multiallelics=4, snp_p_value=0.1, insert_p_value=0.25, delete_p_value=0.25, snp_p_value_in_lc=0.1,
             insert_p_value_in_lc=0.3, delete_p_value_in_lc=0.3, snp_q_cutoff=20, indel_q_cutoff=15, snp_q_cutoff_in_lc=20,
-            indel_q_cutoff_in_lc=10, report_snp_above_freq=0, report_indel_above_freq=0, stage_walls=walls, stage_seconds=stages)
+            indel_q_cutoff_in_lc=10, report_snp_above_freq=0, report_indel_above_freq=0, stage_walls=walls, stage_seconds=stages,
+            fused_inference=fused)
         t0 = time.perf_counter()
         image_dir, pred_dir, totals = call_variant(options)
         dt = time.perf_counter() - t0
+        if k == 0 and os.environ.get("PEPPER_AMD_E2E_CALIBRATE") == "1":
+            # what REFERENCE_BIAS was found with: the bias at which ~2 % of the warm-up run's windows are called
+            print(json.dumps({"calibrated_reference_bias": calibrate_bias(pred_dir)}), file=sys.stderr)
         windows = 0
         from pepper_amd import h5
         for path in glob.glob(os.path.join(pred_dir, "*.hdf")):
@@ -76,16 +110,19 @@ def call_variant_job(work, bases, coverage, n_runs):
                     windows += f.info("predictions/" + g + "/positions")[0][0]
         if k > 0:
             runs.append({"seconds": round(dt, 3), "stage_walls": {n: round(v, 3) for n, v in walls.items()}, "windows": windows,
+                         "image_stage_seconds_summed_over_workers": {n: round(v, 2) for n, v in sorted(stages.items()) if n != "inflated_bytes"},
                          "candidates_written": [int(t) for t in totals] if hasattr(totals, "__iter__") else int(totals)})
         shutil.rmtree(out, ignore_errors=True)
     mid = median_run(runs)
     longest = max(mid["stage_walls"].values())
-    return {"metric": "call_variant end to end (BAM + FASTA + checkpoint -> 5 VCFs)", "value": round(info["genome_bases"] / 1e6 / mid["seconds"], 2),
+    return {"metric": "call_variant end to end (BAM + FASTA + checkpoint -> 5 VCFs)" + (", images and inference fused" if fused else ""), "value": round(info["genome_bases"] / 1e6 / mid["seconds"], 2),
             "unit": "Mb of reference/s", "seconds": mid["seconds"], "runs_seconds": [r["seconds"] for r in runs], "stage_walls": mid["stage_walls"],
             "wall_over_longest_stage": round(mid["seconds"] / longest, 3), "windows": mid["windows"],
+            "image_stage_seconds_summed_over_workers": mid["image_stage_seconds_summed_over_workers"],
             "windows_per_s": round(mid["windows"] / mid["seconds"], 1),
             "candidates_per_s_in_find_candidates": round(mid["windows"] / max(1e-9, mid["stage_walls"]["find_candidates"]), 1),
             "candidates_written": mid["candidates_written"], "threads": threads,
+            "model": "seeded random init (gain 2), output layer leaned towards the reference class by %.2f so that ~2 %% of the windows are called" % bias,
             "data": "synthetic BAM %.0f Mb at %.0fx, %d records, %.2f GB (tools/synth_bam), seeded random-init checkpoint" % (
                 info["genome_bases"] / 1e6, info["coverage"], info["records"], info["bam_bytes"] / 1e9), "synth_seconds": info["seconds"]}
 
@@ -124,7 +161,10 @@ def polish_job(work, bases, coverage, n_runs):
 
 if __name__ == "__main__":
     kind, work = sys.argv[1], sys.argv[2]
-    bases = float(sys.argv[3]) if len(sys.argv) > 3 else (256e6 if kind == "call_variant" else 64e6)
-    coverage = float(sys.argv[4]) if len(sys.argv) > 4 else (30 if kind == "call_variant" else 60)
+    bases = float(sys.argv[3]) if len(sys.argv) > 3 else (256e6 if kind.startswith("call_variant") else 64e6)
+    coverage = float(sys.argv[4]) if len(sys.argv) > 4 else (30 if kind.startswith("call_variant") else 60)
     n_runs = int(sys.argv[5]) if len(sys.argv) > 5 else 3
-    print(json.dumps((call_variant_job if kind == "call_variant" else polish_job)(work, bases, coverage, n_runs)))
+    if kind == "call_variant_fused":
+        print(json.dumps(call_variant_job(work, bases, coverage, n_runs, fused=True)))
+    else:
+        print(json.dumps((call_variant_job if kind == "call_variant" else polish_job)(work, bases, coverage, n_runs)))
