@@ -90,7 +90,7 @@ def self_spawn(args):
     import socket
     import subprocess
     ndev = torch.cuda.device_count()
-    if ndev < args.gpus and os.environ.get("PEPPER_AMD_BENCH_SHARE_GPU") != "1":
+    if ndev < args.gpus and os.environ.get("PEPPER_AMD_BENCH_SHARE_GPU") not in ("1", "2"):
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {ndev} HIP device(s) visible\n")
         sys.exit(2)
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
@@ -118,8 +118,11 @@ def dist_setup(args):
     ndev = torch.cuda.device_count()
     # PEPPER_AMD_BENCH_SHARE_GPU=1: a plumbing check of the N-rank code path on a box with fewer GPUs (ranks share
     # devices, gloo instead of RCCL, the line says so); never a scaling number
-    share = os.environ.get("PEPPER_AMD_BENCH_SHARE_GPU") == "1" and ndev < world
-    device = local % ndev if share else local
+    # (=2: the ranks share devices AND go through the backend agreement below -- RCCL refuses two ranks per device, so this
+    # exercises the all-ranks fallback on a 1-GPU box)
+    share_mode = os.environ.get("PEPPER_AMD_BENCH_SHARE_GPU")
+    share = share_mode == "1" and ndev < world
+    device = local % ndev if (share or (share_mode == "2" and ndev < world)) else local
     torch.cuda.set_device(device)
     global COLLECTIVE_NOTE
     if share:
