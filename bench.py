@@ -1069,6 +1069,7 @@ def secondary_block(args):
     # device, candidate selection runs while the predictions are written; both HDF5 stores are still written)
     out["call_variant_fused"] = e2e_leg("call_variant_fused", scratch, 256_000_000, 30, 3, 24)
     out["polish_e2e"] = e2e_leg("polish", scratch, 64_000_000, 60, 2, 16)
+    out["polish_e2e_fused"] = e2e_leg("polish_fused", scratch, 64_000_000, 60, 2, 16)
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "8000000"], 300)
 
     def inflate_roofline(d):

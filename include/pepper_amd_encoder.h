@@ -214,6 +214,10 @@ int pa_polish_chain_run(pa_encoder* e, int32_t n_regions, const pa_packed_region
 /* The chunks of the last run, region after region, in page-locked memory of the handle (valid until its next run):
  * images uint8 [total_chunks, chunk_size, 10], position / index int64 [total_chunks, chunk_size]. */
 int pa_polish_chain_chunks(pa_encoder* e, const uint8_t** images, const int64_t** position, const int64_t** index);
+/* The same images where the chunk kernel left them ON THE DEVICE ([total_chunks, chunk_size, 10] uint8, complete when
+ * pa_polish_chain_run has returned, valid until the handle's next run): what the polish model reads without the HDF5 round trip
+ * (pa_polish_predict_device; pepper_amd/polish/fused.py). */
+int pa_polish_chain_device_chunks(pa_encoder* e, const uint8_t** images);
 /* Host-clock times of the last run in ms: [0] tables + upload + unpack launch, [1] re-aligner (its waits included) + apply,
  * [2] summary encoder (its wait included), [3] chunk kernel + download; HIP events: [5] score kernels, [6] band launches.
  * counts: [0] (read, region) pairs, [1] reads re-aligned, [2] CIGAR operations written, [3] summary rows. */

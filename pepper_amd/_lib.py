@@ -92,6 +92,7 @@ SYMBOLS = [
     ("pa_polish_chain_run", ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p,
                                            c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("pa_polish_chain_chunks", ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("pa_polish_chain_device_chunks", ctypes.c_int, [c_void_p, c_void_p]),
     ("pa_polish_chain_last_timing", ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32]),
     # include/pepper_amd_realign.h
     ("pa_realigner_create", ctypes.c_int, [c_int32, c_void_p, ctypes.POINTER(c_void_p)]),

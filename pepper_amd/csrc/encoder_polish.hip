@@ -980,6 +980,12 @@ int pa_polish_chain_chunks(pa_encoder* e, const uint8_t** images, const int64_t*
     return PA_OK;
 }
 
+int pa_polish_chain_device_chunks(pa_encoder* e, const uint8_t** images) {
+    if (!e || !e->polish || !images) return pa::set_error(PA_ERR_INVALID, "no chain run");
+    *images = e->polish->n_chunks > 0 ? e->polish->d_chunk_img.as<uint8_t>() : nullptr;
+    return PA_OK;
+}
+
 int pa_polish_chain_last_timing(pa_encoder* e, double* ms, int32_t n_ms, int64_t* counts, int32_t n_counts) {
     if (!e || n_ms < 0 || n_counts < 0) return pa::set_error(PA_ERR_INVALID, "null argument");
     for (int i = 0; ms && i < n_ms; ++i) ms[i] = (e->polish && i < 8) ? e->polish->chain_ms[i] : 0.0;

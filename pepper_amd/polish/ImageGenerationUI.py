@@ -149,7 +149,7 @@ class UserInterfaceSupport:
         return images, labels, positions, image_chunk_ids, (chr_name, _start, _end)
 
     @staticmethod
-    def chain_generator(args, all_intervals, total_threads, thread_id, device, stats=None):
+    def chain_generator(args, all_intervals, total_threads, thread_id, device, stats=None, fused=None):
         """image_generator through the device-resident chain (PEPPER.PolishChain): per run of consecutive intervals ONE call of
         the BAM reader's packed form (the file's BGZF members inflated and walked on the device) and ONE of the chain (clip,
         re-align, summarise, cut into chunks on the device), then one call of the image writer.  Intervals the chain does not
@@ -183,6 +183,7 @@ class UserInterfaceSupport:
             # no page-locked arena to be had (memlock / cgroup limit): the host form needs none
             return UserInterfaceSupport.image_generator(args, all_intervals, total_threads, thread_id)
         chain = PEPPER.PolishChain(enc)
+        consensus = fused.worker(thread_id, device) if fused is not None else None      # polish(fused_inference=True): fused.py
         device_inflate = os.environ.get("PEPPER_AMD_DEVICE_INFLATE", "1") != "0"
         safe = AlingerOptions.ALIGNMENT_SAFE_BASES
         seq_len, features = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
@@ -202,6 +203,8 @@ class UserInterfaceSupport:
                         for region, (images, labels, positions, chunk_ids) in zip(part, results):
                             if len(images):
                                 output_hdf_file.write_summaries(region, images, labels, positions, chunk_ids)
+                                if consensus is not None:
+                                    consensus.add_host(region, images, positions, chunk_ids)
 
                 counter = 0
                 while counter < len(intervals):
@@ -277,6 +280,10 @@ class UserInterfaceSupport:
                         img, pos, idx = chain.chunk_pointers()
                         output_hdf_file.write_regions(chr_name, starts[r0:r1], stops[r0:r1], chunks, seq_len, features, img, pos, idx)
                         t0 = lap("hdf5", t0)
+                        if consensus is not None and chain.n_chunks:
+                            _img, pos_v, idx_v = chain.chunk_arrays()
+                            consensus.add(chr_name, starts[r0:r1], stops[r0:r1], chunks, chain.device_chunks(), pos_v, idx_v)
+                            t0 = lap("fused_consensus", t0)
                     if refused_at is not None:
                         deep = [r for r in deep if r < refused_at]
                     if len(deep):
@@ -291,6 +298,14 @@ class UserInterfaceSupport:
                              + str(elapsed // 60) + " Min " + str(elapsed % 60) + " Sec]")
                 t_close = time.perf_counter()
             lap("close", t_close)
+            if consensus is not None:
+                t0 = time.perf_counter()
+                consensus.close()
+                lap("fused_consensus", t0)
+        except BaseException:
+            if consensus is not None:
+                consensus.close(failed=True)
+            raise
         finally:
             enc.inflate_ms, enc.inflated_bytes = 0.0, 0
             enc.release()
@@ -370,7 +385,7 @@ class UserInterfaceSupport:
 
     @staticmethod
     def chromosome_level_parallelization(chr_list, bam_file, draft_file, truth_bam, output_path, total_threads, train_mode,
-                                         downsample_rate=1.0, device_ids=None, stats=None):
+                                         downsample_rate=1.0, device_ids=None, stats=None, fused=None):
         if train_mode:
             raise NotImplementedError("train_mode image generation is outside the inference path")
         contigs, all_intervals = UserInterfaceSupport.make_intervals(chr_list, draft_file)
@@ -383,7 +398,9 @@ class UserInterfaceSupport:
         def work(thread_id, n):
             if chain:
                 return UserInterfaceSupport.chain_generator(args, all_intervals, n, thread_id,
-                                                            UserInterfaceSupport.worker_device(device_ids, thread_id), stats)
+                                                            UserInterfaceSupport.worker_device(device_ids, thread_id), stats, fused)
+            if fused is not None:
+                raise RuntimeError("the fused polish() needs the device-resident chain (PEPPER_AMD_POLISH_CHAIN=0 or a downsample rate switch it off)")
             return UserInterfaceSupport.image_generator(args, all_intervals, n, thread_id)
         if total_threads <= 1:
             work(0, 1)

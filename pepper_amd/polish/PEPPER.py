@@ -183,6 +183,12 @@ class PolishChain(object):
         _lib.check(self.lib.pa_polish_chain_chunks(self.packed.enc, ctypes.byref(img), ctypes.byref(pos), ctypes.byref(idx)))
         return img.value, pos.value, idx.value
 
+    def device_chunks(self):
+        """Device address of the last run's images ([n_chunks, chunk_size, 10] uint8), valid until the next run."""
+        img = ctypes.c_void_p()
+        _lib.check(self.lib.pa_polish_chain_device_chunks(self.packed.enc, ctypes.byref(img)))
+        return img.value
+
     def chunk_arrays(self):
         """The same as numpy views (copy them to keep them past the next run)."""
         img, pos, idx = self.chunk_pointers()

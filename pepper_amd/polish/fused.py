@@ -1,0 +1,129 @@
+"""polish() with image generation and consensus inference fused (opt-in: polish(..., fused_inference=True) /
+PEPPER_AMD_FUSED_POLISH=1).
+
+The reference's steps talk through files (/root/reference/pepper/modules/python/polish.py:94-117: make_images writes the image HDF5
+files, call_consensus reads them back).  Here an image-generation worker keeps the chunks the chain left on the device
+(pa_polish_chain_device_chunks), gathers a few thousand of them, and hands them to the polish model there
+(pa_polish_predict_device: the 19-window loop with hidden carry, labels and phred per position); both HDF5 stores are still
+written -- the image files by the workers as before, one prediction file per worker with the reference's layout
+(predictions/<contig>/<contig>-<start>-<end>/<chunk id>/...), which perform_stitch globs as it does the callers' files.
+"""
+import threading
+
+import numpy as np
+import torch
+
+from pepper_amd.polish.DataStorePredict import DataStore
+from pepper_amd.polish.Options import ImageSizeOptions
+from pepper_amd.polish.models.ModelHander import ModelHandler
+
+
+class _DeviceChunks(object):
+    """A device address as torch sees it (no copy): uint8 [n, seq, features]."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+
+
+class FusedConsensus(object):
+    """One per polish() run: a model per device (a lock each) and, per worker, a device buffer the chain's chunks are gathered
+    in until a full-sized pass is worth launching (PASS_CHUNKS; the small-call schedule of the step loops is several times slower
+    per chunk)."""
+    PASS_CHUNKS = 4096
+
+    def __init__(self, model_path, output_directory):
+        self.model_path = model_path
+        self.output_directory = output_directory
+        self.models, self.models_lock = {}, threading.Lock()
+        self.chunks = 0
+
+    def _model(self, device):
+        with self.models_lock:
+            entry = self.models.get(device)
+            if entry is None:
+                torch.cuda.set_device(device)
+                model = ModelHandler.load_simple_model_for_training(self.model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
+                                                                    image_features=ImageSizeOptions.IMAGE_HEIGHT,
+                                                                    seq_len=ImageSizeOptions.SEQ_LENGTH,
+                                                                    num_classes=ImageSizeOptions.TOTAL_LABELS)[0]
+                entry = self.models[device] = (model, threading.Lock())
+            return entry
+
+    def worker(self, thread_id, device):
+        return _Worker(self, thread_id, device)
+
+    def close(self):
+        for model, _ in self.models.values():
+            model.close()
+        self.models.clear()
+
+
+class _Worker(object):
+    def __init__(self, owner, thread_id, device):
+        self.owner, self.device = owner, device
+        self.seq, self.features = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+        torch.cuda.set_device(device)
+        self.buffer = torch.empty((owner.PASS_CHUNKS, self.seq, self.features), dtype=torch.uint8, device=torch.device("cuda", device))
+        self.position = np.empty((owner.PASS_CHUNKS, self.seq), np.int64)
+        self.index = np.empty((owner.PASS_CHUNKS, self.seq), np.int64)
+        self.meta = []                      # (contig, start, end, chunk id) per gathered chunk
+        self.n = 0
+        self.store = DataStore(owner.output_directory + "pepper_prediction_fused_" + str(thread_id) + ".hdf", mode='w')
+        self.failed = False
+
+    def add(self, contig, starts, stops, chunk_counts, device_images, position, index):
+        """The chunks of one chain call: device_images = their address on the device, position / index = numpy views of the
+        chain's page-locked copies ([total, seq] int64: copied here, the chain overwrites them in its next run)."""
+        meta = [(contig, int(a), int(b), cid) for a, b, c in zip(starts, stops, chunk_counts) for cid in range(int(c))]
+        total, at = len(meta), 0
+        torch.cuda.set_device(self.device)
+        while at < total:
+            take = min(total - at, self.owner.PASS_CHUNKS - self.n)
+            src = torch.as_tensor(_DeviceChunks(device_images + at * self.seq * self.features, (take, self.seq, self.features)),
+                                  device=torch.device("cuda", self.device))
+            self.buffer[self.n:self.n + take].copy_(src)
+            self.position[self.n:self.n + take] = position[at:at + take]
+            self.index[self.n:self.n + take] = index[at:at + take]
+            self.meta.extend(meta[at:at + take])
+            self.n += take
+            at += take
+            if self.n == self.owner.PASS_CHUNKS:
+                self.flush()
+        torch.cuda.current_stream().synchronize()              # (the chain overwrites its chunks in its next run)
+
+    def add_host(self, region, images, positions, chunk_ids):
+        """An interval that went through the host form (a pile beyond the reservoir cap, a span the packed reader refused): its
+        chunks as lists of [seq, features] uint8 arrays and [seq, 2] (position, index) arrays."""
+        contig, start, end = region
+        for image, pos, cid in zip(images, positions, chunk_ids):
+            torch.cuda.set_device(self.device)
+            self.buffer[self.n].copy_(torch.from_numpy(np.ascontiguousarray(image, np.uint8)))
+            pos = np.asarray(pos, np.int64).reshape(self.seq, 2)
+            self.position[self.n], self.index[self.n] = pos[:, 0], pos[:, 1]
+            self.meta.append((str(contig), int(start), int(end), int(cid)))
+            self.n += 1
+            if self.n == self.owner.PASS_CHUNKS:
+                self.flush()
+
+    def flush(self):
+        if self.n == 0:
+            return
+        model, lock = self.owner._model(self.device)
+        with lock:
+            torch.cuda.set_device(self.device)
+            labels, phred = model.predict_chunks(self.buffer[:self.n])
+            labels, phred = labels.cpu().numpy(), phred.cpu().numpy()
+        meta = self.meta[:self.n]
+        contigs = np.array([m[0] for m in meta], dtype='S')
+        self.store.write_predictions_block(contigs, np.array([m[1] for m in meta], np.int64), np.array([m[2] for m in meta], np.int64),
+                                           np.array([m[3] for m in meta], np.int64), self.position[:self.n], self.index[:self.n], labels, phred)
+        self.owner.chunks += self.n
+        del self.meta[:self.n]
+        self.n = 0
+
+    def close(self, failed=False):
+        if failed:
+            self.store.abort()
+            return
+        self.flush()
+        self.store.close()

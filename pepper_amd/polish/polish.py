@@ -18,8 +18,10 @@ def _log(message):
 
 
 def polish(bam_filepath, fasta_filepath, output_path, threads, region, model_path, batch_size, gpu_mode, device_ids,
-           num_workers, stage_walls=None):
-    """The reference's ten arguments; stage_walls: a dict that receives the three steps' wall times."""
+           num_workers, stage_walls=None, fused_inference=None):
+    """The reference's ten arguments; stage_walls: a dict that receives the three steps' wall times; fused_inference (default:
+    PEPPER_AMD_FUSED_POLISH=1): the image workers hand their chunks to the model on the device instead of call_consensus reading
+    the image files back (pepper_amd/polish/fused.py); both stores are still written."""
     for path, what in ((bam_filepath, "BAM"), (fasta_filepath, "FASTA"), (model_path, "MODEL")):
         if not os.path.isfile(path):
             raise FileNotFoundError("CAN NOT LOCATE " + what + " FILE: " + str(path))
@@ -38,12 +40,25 @@ def polish(bam_filepath, fasta_filepath, output_path, threads, region, model_pat
     _log("INFO: RUN-ID: " + str(timestr))
     _log("STEP 1: GENERATING IMAGES -> " + image_output_directory)
     t0 = time.perf_counter()
-    make_images(bam_filepath, fasta_filepath, region, image_output_directory, threads, device_ids=device_ids)
-    t1 = time.perf_counter()
-    _log("STEP 2: RUNNING INFERENCE -> " + prediction_output_directory)
-    call_consensus(image_output_directory, model_path, batch_size, num_workers, prediction_output_directory, device_ids,
-                   gpu_mode, threads)
-    t2 = time.perf_counter()
+    if fused_inference is None:
+        fused_inference = os.environ.get("PEPPER_AMD_FUSED_POLISH") == "1"
+    if fused_inference:
+        from pepper_amd.polish.fused import FusedConsensus
+        UserInterfaceSupport.handle_output_directory(prediction_output_directory)
+        _log("STEP 1+2: GENERATING IMAGES AND RUNNING INFERENCE (FUSED) -> " + prediction_output_directory)
+        sink = FusedConsensus(model_path, prediction_output_directory)
+        try:
+            make_images(bam_filepath, fasta_filepath, region, image_output_directory, threads, device_ids=device_ids, fused=sink)
+        finally:
+            sink.close()
+        t1 = t2 = time.perf_counter()
+    else:
+        make_images(bam_filepath, fasta_filepath, region, image_output_directory, threads, device_ids=device_ids)
+        t1 = time.perf_counter()
+        _log("STEP 2: RUNNING INFERENCE -> " + prediction_output_directory)
+        call_consensus(image_output_directory, model_path, batch_size, num_workers, prediction_output_directory, device_ids,
+                       gpu_mode, threads)
+        t2 = time.perf_counter()
     _log("STEP 3: RUNNING STITCH -> " + output_dir)
     perform_stitch(prediction_output_directory, output_dir, threads)
     if stage_walls is not None:

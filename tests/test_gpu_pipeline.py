@@ -370,6 +370,62 @@ def test_call_variant_vcf_identity(tmp_path):
     _assert_same_vcfs(options.output_dir, str(tmp_path / "ovcf"))
 
 
+def test_fused_polish_equals_the_three_step_run(tmp_path):
+    """polish(..., fused_inference=True): the image workers hand the chain's chunks to the model on the device; the image files are
+    those of the three-step run, every chunk has the same prediction (bases; phred up to one unit where two classes tie), and the
+    polished FASTA is identical -- with a pile beyond the reservoir cap in one interval (host form) and several workers."""
+    import glob
+    import bam_utils as bu
+    import pileup_utils as pu
+    from pepper_amd.polish.polish import polish
+    rng = np.random.default_rng(92)
+    draft = pu.random_reference(rng, 6300)
+    reads = pu.simulate_reads(rng, draft, 0, n_reads=300, read_len=(600, 2500), ins_rate=0.02, del_rate=0.02)
+    deep = pu.simulate_reads(rng, draft[2100:2900], 2100, n_reads=1700, read_len=(150, 300), ins_rate=0.02, del_rate=0.02)
+    reads = sorted([r for r in reads + deep if not any(op in (3, 6) for op, _ in r["cigar"])], key=lambda r: r["pos"])
+    for i, r in enumerate(reads):
+        r["name"] = "q%d" % i
+    bam_path, fa_path = str(tmp_path / "reads.bam"), str(tmp_path / "draft.fa")
+    bu.write_bam(bam_path, [("ctg1", len(draft))], {0: reads})
+    with open(fa_path, "w") as fh:
+        fh.write(">ctg1\n" + draft + "\n")
+    sd = synthetic.polish_state_dict(seed=18, gain=2.0)
+    model_path = str(tmp_path / "polish.pkl")
+    torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
+    outs = {}
+    for name, threads, fused in (("plain", 1, False), ("fused", 2, True)):
+        out_dir = str(tmp_path / name) + "/"
+        walls = {}
+        polish(bam_path, fa_path, out_dir, threads, None, model_path, 64, True, "0", 0, stage_walls=walls, fused_inference=fused)
+        assert (walls["call_consensus"] == 0) == fused
+        fasta = glob.glob(out_dir + "*.fa")
+        assert len(fasta) == 1
+        preds = {}
+        for path in glob.glob(out_dir + "predictions_*/*.hdf"):
+            with h5.File(path) as f:
+                for region, a, b in f.list_polish_regions("ctg1"):
+                    base = "predictions/ctg1/" + region + "/"
+                    assert int(f[base + "contig_start"]) == a and int(f[base + "contig_end"]) == b
+                    for chunk in f.keys(base.rstrip("/")):
+                        if chunk in ("contig_start", "contig_end"):
+                            continue
+                        preds[(region, chunk)] = tuple(np.asarray(f[base + chunk + "/" + k]) for k in ("position", "index", "bases", "phred_score"))
+        images = {}
+        for path in glob.glob(out_dir + "images_*/*.hdf"):
+            with h5.File(path) as f:
+                for g in f.keys("summaries"):
+                    images[g] = np.asarray(f["summaries/" + g + "/image"])
+        outs[name] = (open(fasta[0]).read(), preds, images)
+    (fa_a, pa, ia), (fa_b, pb, ib) = outs["plain"], outs["fused"]
+    assert sorted(ia) == sorted(ib) and all(np.array_equal(ia[k], ib[k]) for k in ia)
+    assert sorted(pa) == sorted(pb) and len(pa) >= 10
+    for key in pa:
+        assert np.array_equal(pa[key][0], pb[key][0]) and np.array_equal(pa[key][1], pb[key][1])
+        assert np.array_equal(pa[key][2], pb[key][2]), key
+        assert np.abs(pa[key][3].astype(int) - pb[key][3].astype(int)).max() <= 1
+    assert fa_a == fa_b
+
+
 def test_fused_call_variant_equals_the_three_step_run(tmp_path):
     """options.fused_inference: the encoder's windows go to the model on the device, both HDF5 stores are still written -- the
     image files are those of the unfused run, every candidate has the same prediction (batch membership differs: arrival order),

@@ -5,6 +5,7 @@
       BAM + FASTA + checkpoint -> image HDF5 -> predictions HDF5 -> five VCFs
   python tools/bench_e2e.py call_variant_fused <dir> ...     the same with options.fused_inference (pepper_amd/variant/fused.py)
   python tools/bench_e2e.py polish <dir> [draft_bases=64000000] [coverage=60] [runs=3]
+  python tools/bench_e2e.py polish_fused <dir> ...           the same with fused_inference=True (pepper_amd/polish/fused.py)
       pepper_amd.polish.polish.polish (pepper polish, polish.py:94-117): BAM + draft + checkpoint -> images -> predictions -> FASTA
 
 Each prints one JSON line: the run with the median wall of `runs` (after one untimed run that loads the libraries, grows the
@@ -127,7 +128,7 @@ def call_variant_job(work, bases, coverage, n_runs, fused=False):
                 info["genome_bases"] / 1e6, info["coverage"], info["records"], info["bam_bytes"] / 1e9), "synth_seconds": info["seconds"]}
 
 
-def polish_job(work, bases, coverage, n_runs):
+def polish_job(work, bases, coverage, n_runs, fused=False):
     from pepper_amd.hostinfo import usable_cpus
     from pepper_amd.polish.polish import polish
     info = synth(work, bases, coverage)
@@ -140,7 +141,8 @@ def polish_job(work, bases, coverage, n_runs):
         shutil.rmtree(out, ignore_errors=True)
         walls = {}
         t0 = time.perf_counter()
-        polish(os.path.join(work, "reads.bam"), os.path.join(work, "draft.fa"), out, threads, None, model, 512, True, "0", 0, stage_walls=walls)
+        polish(os.path.join(work, "reads.bam"), os.path.join(work, "draft.fa"), out, threads, None, model, 512, True, "0", 0, stage_walls=walls,
+               fused_inference=fused)
         dt = time.perf_counter() - t0
         fasta = glob.glob(out + "*.fa")
         size = os.path.getsize(fasta[0]) if fasta else 0
@@ -151,7 +153,7 @@ def polish_job(work, bases, coverage, n_runs):
         shutil.rmtree(out, ignore_errors=True)
     mid = median_run(runs)
     longest = max(mid["stage_walls"].values())
-    return {"metric": "polish end to end (BAM + draft + checkpoint -> polished FASTA)", "value": round(info["genome_bases"] / 1e6 / mid["seconds"], 2),
+    return {"metric": "polish end to end (BAM + draft + checkpoint -> polished FASTA)" + (", images and inference fused" if fused else ""), "value": round(info["genome_bases"] / 1e6 / mid["seconds"], 2),
             "unit": "Mb of draft/s", "seconds": mid["seconds"], "runs_seconds": [r["seconds"] for r in runs], "stage_walls": mid["stage_walls"],
             "wall_over_longest_stage": round(mid["seconds"] / longest, 3), "polished_fasta_bytes": mid["polished_fasta_bytes"],
             "image_file_mb": mid["image_file_mb"], "threads": threads,
@@ -166,5 +168,7 @@ if __name__ == "__main__":
     n_runs = int(sys.argv[5]) if len(sys.argv) > 5 else 3
     if kind == "call_variant_fused":
         print(json.dumps(call_variant_job(work, bases, coverage, n_runs, fused=True)))
+    elif kind == "polish_fused":
+        print(json.dumps(polish_job(work, bases, coverage, n_runs, fused=True)))
     else:
         print(json.dumps((call_variant_job if kind == "call_variant" else polish_job)(work, bases, coverage, n_runs)))
