@@ -24,7 +24,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")     # before the HIP runtime starts (pepper_amd/__init__.py says why)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # before the HIP runtime starts (pepper_amd/__init__.py says why)
 
 import numpy as np
 import torch

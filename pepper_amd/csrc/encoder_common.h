@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -80,6 +82,8 @@ struct DBuf {
     size_t bytes = 0;
     bool ensure(size_t need) {
         if (need <= bytes) return true;
+        static const bool trace = getenv("PA_TRACE_ALLOC") != nullptr;      // every (re)allocation on stderr: a hipFree waits for the device
+        if (trace) fprintf(stderr, "[alloc] device buffer %zu -> %zu bytes\n", bytes, need + need / 4 + 256);
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;

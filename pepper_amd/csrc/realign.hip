@@ -887,6 +887,8 @@ struct DBuf {
     size_t bytes = 0;
     bool ensure(size_t need) {
         if (need <= bytes) return true;
+        static const bool trace = getenv("PA_TRACE_ALLOC") != nullptr;
+        if (trace) fprintf(stderr, "[alloc] re-aligner buffer %zu -> %zu bytes\n", bytes, need + need / 4 + 256);
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;

@@ -39,6 +39,7 @@ def polish(bam_filepath, fasta_filepath, output_path, threads, region, model_pat
     prediction_output_directory = output_dir + "predictions_" + str(timestr) + "/"
     _log("INFO: RUN-ID: " + str(timestr))
     _log("STEP 1: GENERATING IMAGES -> " + image_output_directory)
+    image_stats = {} if stage_walls is not None else None       # the image workers' stage times, summed over the workers
     t0 = time.perf_counter()
     if fused_inference is None:
         fused_inference = os.environ.get("PEPPER_AMD_FUSED_POLISH") == "1"
@@ -48,12 +49,13 @@ def polish(bam_filepath, fasta_filepath, output_path, threads, region, model_pat
         _log("STEP 1+2: GENERATING IMAGES AND RUNNING INFERENCE (FUSED) -> " + prediction_output_directory)
         sink = FusedConsensus(model_path, prediction_output_directory)
         try:
-            make_images(bam_filepath, fasta_filepath, region, image_output_directory, threads, device_ids=device_ids, fused=sink)
+            make_images(bam_filepath, fasta_filepath, region, image_output_directory, threads, device_ids=device_ids, fused=sink,
+                        stats=image_stats)
         finally:
             sink.close()
         t1 = t2 = time.perf_counter()
     else:
-        make_images(bam_filepath, fasta_filepath, region, image_output_directory, threads, device_ids=device_ids)
+        make_images(bam_filepath, fasta_filepath, region, image_output_directory, threads, device_ids=device_ids, stats=image_stats)
         t1 = time.perf_counter()
         _log("STEP 2: RUNNING INFERENCE -> " + prediction_output_directory)
         call_consensus(image_output_directory, model_path, batch_size, num_workers, prediction_output_directory, device_ids,
@@ -63,3 +65,4 @@ def polish(bam_filepath, fasta_filepath, output_path, threads, region, model_pat
     perform_stitch(prediction_output_directory, output_dir, threads)
     if stage_walls is not None:
         stage_walls.update(make_images=t1 - t0, call_consensus=t2 - t1, perform_stitch=time.perf_counter() - t2)
+        stage_walls["image_stage_seconds_summed_over_workers"] = image_stats

@@ -67,6 +67,11 @@ def call_variant(options):
             precomputed = sink.segments or None
             if walls is not None:
                 walls["fused_writer_drain"] = getattr(sink, "drain_seconds", 0.0)
+                walls["fused_forward_summed_over_handles"] = sink.forward_seconds
+                walls["fused_writer_busy_summed"], walls["fused_selection_busy_summed"] = sink.write_seconds, sink.select_seconds
+            if sink.select_error is not None:
+                _log("INFO: THE FUSED RUN'S CANDIDATE SELECTION STOPPED (" + repr(sink.select_error) + "): STEP 3 DOES THE REST FROM THE FILE")
+            _log("INFO: FUSED: " + str(len(sink.segments)) + " OF " + str(sink.batch_no) + " BATCHES SELECTED AHEAD OF STEP 3")
         t1 = t2 = time.perf_counter()
     else:
         ImageGenerationUtils.generate_images(options)

@@ -9,8 +9,10 @@ options.batch_size candidates) by the writer in arrival order.  Which batch a ca
 candidate finder sorts sites itself, CandidateFinder.py:356-581); every candidate's record is the same.
 """
 import ctypes
+import os
 import queue
 import threading
+import time
 
 import numpy as np
 import torch
@@ -22,8 +24,8 @@ from pepper_amd.variant.models.ModelHander import ModelHandler
 
 
 class FusedPredictor(object):
-    """One per call_variant run: a model handle per device (made on first use, a lock each: the device runs one forward at a
-    time anyway) and one writer thread over a queue of (contig, arrays, probabilities)."""
+    """One per call_variant run: up to HANDLES model handles per device (made on first use; a worker takes a free one for its
+    forward) and one writer thread over a queue of (contig, arrays, probabilities)."""
 
     def __init__(self, options, output_filepath):
         self.options = options
@@ -35,7 +37,10 @@ class FusedPredictor(object):
         self.error = None
         self.batch_no = 0
         self.windows = 0
-        self.pending = []            # arrays of the candidates that have not filled a batch yet
+        self.forward_seconds = 0.0
+        self.write_seconds = self.select_seconds = 0.0       # what the two threads spent working (not waiting)
+        self.select_error = None
+        self.pending = {}            # per image worker: arrays of its candidates that have not filled a batch yet
         self.filename = output_filepath + "pepper_prediction.hdf"
         # the candidate finder's selection + record text of a batch (FastCandidates.native_batch_arrays, inside the I/O library)
         # runs on a third thread as soon as the batch exists, so that step 3 starts with most of its per-batch work done
@@ -49,40 +54,56 @@ class FusedPredictor(object):
         self.writer.start()
 
     # ---- model ----
+    HANDLES = 2          # forwards in flight per device: while one handle's results come back, the other's kernels run
+
     def _model(self, device):
+        """A free model handle of the device (made on first use, at most HANDLES of them: own stream and workspace each)."""
         with self.models_lock:
             entry = self.models.get(device)
             if entry is None:
-                torch.cuda.set_device(device)
-                model = ModelHandler.load_simple_model_for_training(
-                    self.options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT, num_classes=ImageSizeOptions.TOTAL_LABELS,
-                    num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)[0]
-                model.eval()
-                entry = self.models[device] = (model, threading.Lock())
-            return entry
+                entry = self.models[device] = {"free": queue.Queue(), "made": 0, "all": []}
+            make = entry["free"].empty() and entry["made"] < max(1, int(os.environ.get("PEPPER_AMD_FUSED_HANDLES", self.HANDLES)))
+            if make:
+                entry["made"] += 1
+        if make:
+            torch.cuda.set_device(device)
+            model = ModelHandler.load_simple_model_for_training(
+                self.options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT, num_classes=ImageSizeOptions.TOTAL_LABELS,
+                num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)[0]
+            model.eval()
+            with self.models_lock:
+                entry["all"].append(model)
+            return entry, model
+        return entry, entry["free"].get()
 
     def forward_device(self, device, images_ptr, n):
         """n int8 windows [n, 33, 26] at device address images_ptr (the encoder's results of its last run: complete, and valid
         until that encoder's next call) -> float32 probabilities [n, 3] on the host."""
         if n == 0:
             return np.zeros((0, ImageSizeOptions.TOTAL_TYPE_LABELS), np.float32)
-        model, lock = self._model(device)
+        entry, model = self._model(device)
         lib = _lib.load()
-        with lock:
+        t0 = time.perf_counter()
+        try:
             torch.cuda.set_device(device)
             probs = torch.empty((n, model.num_classes_type), dtype=torch.float32, device=torch.device("cuda", device))
             _lib.check(lib.pa_variant_forward_device(model.handle, ctypes.c_void_p(images_ptr), n, probs.data_ptr(), None))
             model._stream.synchronize()
             return probs.cpu().numpy()
+        finally:
+            self.forward_seconds += time.perf_counter() - t0        # (summed over the handles: not a wall time)
+            entry["free"].put(model)
 
     def forward_host(self, device, images):
         """int8 windows on the host (the host-clipped form of image generation) -> probabilities."""
         if len(images) == 0:
             return np.zeros((0, ImageSizeOptions.TOTAL_TYPE_LABELS), np.float32)
-        model, lock = self._model(device)
-        with lock:
+        entry, model = self._model(device)
+        try:
             torch.cuda.set_device(device)
             return model(torch.from_numpy(np.ascontiguousarray(images)), False).numpy()
+        finally:
+            entry["free"].put(model)
 
     # ---- predictions ----
     def submit(self, contig, out, probs):
@@ -91,25 +112,27 @@ class FusedPredictor(object):
         if self.error is not None:
             raise self.error
         if len(out["positions"]):
-            self.queue.put((contig, out, probs))
+            self.queue.put((threading.get_ident(), contig, out, probs))
 
-    def _flush(self, final):
-        """batch_size candidates per predictions/batch_<n> group, as the reference's DataLoader batches them; the groups are
-        written from bulk arrays (one library call each), the candidate strings as the encoder left them (NUL-terminated, back to
-        back)."""
-        while self.pending and (final or sum(len(p[1]) for p in self.pending) >= self.batch_size):
+    NEAR = 1 << 20       # a batch holds candidates of ONE worker's consecutive intervals: the next one starts within this many bases
+
+    def _flush(self, pending, final):
+        """batch_size candidates per predictions/batch_<n> group, as the reference's DataLoader batches them, out of ONE worker's
+        stream of intervals (`pending`: its pieces that have not filled a batch yet); the groups are written from bulk arrays (one
+        library call each), the candidate strings as the encoder left them (NUL-terminated, back to back)."""
+        while pending and (final or sum(len(p[1]) for p in pending) >= self.batch_size):
             take, have = [], 0
-            while self.pending and have < self.batch_size:
-                piece = self.pending[0]
+            while pending and have < self.batch_size:
+                piece = pending[0]
                 room = self.batch_size - have
                 if len(piece[1]) <= room:
-                    take.append(self.pending.pop(0))
+                    take.append(pending.pop(0))
                     have += len(piece[1])
                 else:
                     contigs, pos, dep, blob, off, freq, probs = piece
                     cut = int(off[room])                     # first byte of the first candidate that does not fit
                     take.append((contigs[:room], pos[:room], dep[:room], blob[:cut], off[:room], freq[:room], probs[:room]))
-                    self.pending[0] = (contigs[room:], pos[room:], dep[room:], blob[cut:], off[room:] - cut, freq[room:], probs[room:])
+                    pending[0] = (contigs[room:], pos[room:], dep[room:], blob[cut:], off[room:] - cut, freq[room:], probs[room:])
                     have += room
             blob = b"".join(t[3] for t in take)
             bases = np.cumsum([0] + [len(t[3]) for t in take[:-1]])
@@ -138,6 +161,7 @@ class FusedPredictor(object):
                 if rules is None:             # (thresholds the library does not take: step 3 does the job the Python way)
                     continue
                 key, contigs, positions, depths, freqs, probs, blob = item
+                t0 = time.perf_counter()
                 first = bytes(contigs[0])
                 if len(contigs) == 0 or (contigs != contigs[0]).any():
                     continue
@@ -145,7 +169,9 @@ class FusedPredictor(object):
                                                          probs, blob, self.filename + "/" + key)
                 if seg is not None:
                     self.segments[(self.filename, key)] = seg
-        except BaseException:             # noqa: BLE001 -- whatever was not selected here is selected in step 3 from the file
+                self.select_seconds += time.perf_counter() - t0
+        except BaseException as err:      # noqa: BLE001 -- whatever was not selected here is selected in step 3 from the file
+            self.select_error = err
             while self.select_queue.get() is not None:
                 pass
 
@@ -155,16 +181,29 @@ class FusedPredictor(object):
                 item = self.queue.get()
                 if item is None:
                     break
-                contig, out, probs = item
+                source, contig, out, probs = item
+                t0 = time.perf_counter()
                 n = len(out["positions"])
                 # (contigs 'S', positions, depths, the interval's candidate strings, each candidate's offset in them, support, p)
                 offs = np.asarray(out["candidates_offsets"], np.int64)
                 blob = bytes(out["candidates_blob"])[int(offs[0]):int(offs[n]) if len(offs) > n else None]
-                self.pending.append((np.array([contig] * n, dtype='S'), np.asarray(out["positions"], np.int32),
-                                     np.asarray(out["depths"]).astype(np.uint8), blob, offs[:n] - offs[0],
-                                     np.asarray(out["candidate_frequency"]).astype(np.uint8), np.asarray(probs, np.float32)))
-                self._flush(False)
-            self._flush(True)
+                piece = (np.array([contig] * n, dtype='S'), np.asarray(out["positions"], np.int32),
+                         np.asarray(out["depths"]).astype(np.uint8), blob, offs[:n] - offs[0],
+                         np.asarray(out["candidate_frequency"]).astype(np.uint8), np.asarray(probs, np.float32))
+                # the workers' intervals arrive interleaved: a batch is cut from one worker's stream, and closed short where that
+                # stream jumps (its next run of intervals, another contig) -- the candidate finder fetches the reference once per
+                # batch for the span the batch covers (FastCandidates.native_batch_arrays)
+                pending = self.pending.setdefault(source, [])
+                if pending:
+                    last = pending[-1]
+                    gap = int(piece[1][0]) - int(last[1][-1])
+                    if last[0][0] != piece[0][0] or gap < -self.NEAR or gap > self.NEAR:
+                        self._flush(pending, True)
+                pending.append(piece)
+                self._flush(pending, False)
+                self.write_seconds += time.perf_counter() - t0
+            for pending in self.pending.values():
+                self._flush(pending, True)
         except BaseException as err:      # noqa: BLE001 -- surfaces in submit() / close()
             self.error = err
             while True:                   # keep draining so that no producer blocks on a full queue
@@ -172,7 +211,6 @@ class FusedPredictor(object):
                     break
 
     def close(self):
-        import time
         t0 = time.perf_counter()
         self.queue.put(None)
         self.writer.join()
@@ -181,8 +219,9 @@ class FusedPredictor(object):
             self.selector.join()
         self.drain_seconds = time.perf_counter() - t0      # what the two threads still had to do when image generation was over
         self.store.close()
-        for model, _ in self.models.values():
-            model.close()
+        for entry in self.models.values():
+            for model in entry["all"]:
+                model.close()
         self.models.clear()
         if self.error is not None:
             raise self.error

@@ -115,10 +115,11 @@ def call_variant_job(work, bases, coverage, n_runs, fused=False):
                          "candidates_written": [int(t) for t in totals] if hasattr(totals, "__iter__") else int(totals)})
         shutil.rmtree(out, ignore_errors=True)
     mid = median_run(runs)
-    longest = max(mid["stage_walls"].values())
+    longest = max(mid["stage_walls"].get(n, 0.0) for n in ("make_images", "run_inference", "find_candidates"))
     return {"metric": "call_variant end to end (BAM + FASTA + checkpoint -> 5 VCFs)" + (", images and inference fused" if fused else ""), "value": round(info["genome_bases"] / 1e6 / mid["seconds"], 2),
             "unit": "Mb of reference/s", "seconds": mid["seconds"], "runs_seconds": [r["seconds"] for r in runs], "stage_walls": mid["stage_walls"],
             "wall_over_longest_stage": round(mid["seconds"] / longest, 3), "windows": mid["windows"],
+            "runs_stage_walls": [r["stage_walls"] for r in runs],
             "image_stage_seconds_summed_over_workers": mid["image_stage_seconds_summed_over_workers"],
             "windows_per_s": round(mid["windows"] / mid["seconds"], 1),
             "candidates_per_s_in_find_candidates": round(mid["windows"] / max(1e-9, mid["stage_walls"]["find_candidates"]), 1),
@@ -148,7 +149,9 @@ def polish_job(work, bases, coverage, n_runs, fused=False):
         size = os.path.getsize(fasta[0]) if fasta else 0
         images = sum(os.path.getsize(p) for p in glob.glob(out + "images_*/*.hdf"))
         if k > 0:
+            stages = walls.pop("image_stage_seconds_summed_over_workers", None) or {}
             runs.append({"seconds": round(dt, 3), "stage_walls": {n: round(v, 3) for n, v in walls.items()}, "polished_fasta_bytes": size,
+                         "image_stage_seconds_summed_over_workers": {n: round(v, 2) for n, v in sorted(stages.items()) if isinstance(v, float)},
                          "image_file_mb": round(images / 1e6, 1)})
         shutil.rmtree(out, ignore_errors=True)
     mid = median_run(runs)
@@ -156,6 +159,8 @@ def polish_job(work, bases, coverage, n_runs, fused=False):
     return {"metric": "polish end to end (BAM + draft + checkpoint -> polished FASTA)" + (", images and inference fused" if fused else ""), "value": round(info["genome_bases"] / 1e6 / mid["seconds"], 2),
             "unit": "Mb of draft/s", "seconds": mid["seconds"], "runs_seconds": [r["seconds"] for r in runs], "stage_walls": mid["stage_walls"],
             "wall_over_longest_stage": round(mid["seconds"] / longest, 3), "polished_fasta_bytes": mid["polished_fasta_bytes"],
+            "image_stage_seconds_summed_over_workers": mid["image_stage_seconds_summed_over_workers"],
+            "runs_stage_walls": [r["stage_walls"] for r in runs],
             "image_file_mb": mid["image_file_mb"], "threads": threads,
             "data": "synthetic BAM %.0f Mb at %.0fx, %d records, %.2f GB (tools/synth_bam), seeded random-init checkpoint" % (
                 info["genome_bases"] / 1e6, info["coverage"], info["records"], info["bam_bytes"] / 1e9), "synth_seconds": info["seconds"]}
