@@ -8,6 +8,8 @@ files, call_consensus reads them back).  Here an image-generation worker keeps t
 written -- the image files by the workers as before, one prediction file per worker with the reference's layout
 (predictions/<contig>/<contig>-<start>-<end>/<chunk id>/...), which perform_stitch globs as it does the callers' files.
 """
+import os
+import queue
 import threading
 
 import numpy as np
@@ -26,35 +28,50 @@ class _DeviceChunks(object):
 
 
 class FusedConsensus(object):
-    """One per polish() run: a model per device (a lock each) and, per worker, a device buffer the chain's chunks are gathered
-    in until a full-sized pass is worth launching (PASS_CHUNKS; the small-call schedule of the step loops is several times slower
-    per chunk)."""
+    """One per polish() run: up to HANDLES model handles per device (a worker takes a free one for its pass) and, per worker, a
+    device buffer the chain's chunks are gathered in until a full-sized pass is worth launching (PASS_CHUNKS; the small-call
+    schedule of the step loops is several times slower per chunk)."""
     PASS_CHUNKS = 4096
+    HANDLES = 2          # passes in flight per device (own stream and workspace each)
 
     def __init__(self, model_path, output_directory):
         self.model_path = model_path
         self.output_directory = output_directory
         self.models, self.models_lock = {}, threading.Lock()
         self.chunks = 0
+        self.handles = max(1, int(os.environ.get("PEPPER_AMD_FUSED_HANDLES", self.HANDLES)))
 
     def _model(self, device):
+        """(the device's entry, a free model handle of it): made on first use, at most `handles` of them."""
         with self.models_lock:
             entry = self.models.get(device)
             if entry is None:
-                torch.cuda.set_device(device)
-                model = ModelHandler.load_simple_model_for_training(self.model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
-                                                                    image_features=ImageSizeOptions.IMAGE_HEIGHT,
-                                                                    seq_len=ImageSizeOptions.SEQ_LENGTH,
-                                                                    num_classes=ImageSizeOptions.TOTAL_LABELS)[0]
-                entry = self.models[device] = (model, threading.Lock())
-            return entry
+                entry = self.models[device] = {"free": queue.Queue(), "made": 0, "all": []}
+            make = entry["free"].empty() and entry["made"] < self.handles
+            if make:
+                entry["made"] += 1
+                first = entry["all"][0] if entry["all"] else None
+        if not make:
+            return entry, entry["free"].get()
+        torch.cuda.set_device(device)
+        if first is not None:
+            model = first.clone()
+        else:
+            model = ModelHandler.load_simple_model_for_training(self.model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
+                                                                image_features=ImageSizeOptions.IMAGE_HEIGHT,
+                                                                seq_len=ImageSizeOptions.SEQ_LENGTH,
+                                                                num_classes=ImageSizeOptions.TOTAL_LABELS)[0]
+        with self.models_lock:
+            entry["all"].append(model)
+        return entry, model
 
     def worker(self, thread_id, device):
         return _Worker(self, thread_id, device)
 
     def close(self):
-        for model, _ in self.models.values():
-            model.close()
+        for entry in self.models.values():
+            for model in entry["all"]:
+                model.close()
         self.models.clear()
 
 
@@ -108,11 +125,13 @@ class _Worker(object):
     def flush(self):
         if self.n == 0:
             return
-        model, lock = self.owner._model(self.device)
-        with lock:
+        entry, model = self.owner._model(self.device)
+        try:
             torch.cuda.set_device(self.device)
             labels, phred = model.predict_chunks(self.buffer[:self.n])
             labels, phred = labels.cpu().numpy(), phred.cpu().numpy()
+        finally:
+            entry["free"].put(model)
         meta = self.meta[:self.n]
         contigs = np.array([m[0] for m in meta], dtype='S')
         self.store.write_predictions_block(contigs, np.array([m[1] for m in meta], np.int64), np.array([m[2] for m in meta], np.int64),

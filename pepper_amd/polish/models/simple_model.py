@@ -6,6 +6,7 @@ hidden hand-off, plus ``predict_chunks`` = the whole sliding-window loop of
 /root/reference/pepper/modules/python/models/predict_distributed_cpu.py:43-90 on the device.
 """
 import ctypes
+import os
 
 import torch
 
