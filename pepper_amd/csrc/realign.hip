@@ -347,6 +347,10 @@ __device__ __forceinline__ unsigned dpp_up1_u(unsigned v, unsigned lane0) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)lane0, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+__device__ __forceinline__ unsigned dpp_up1_z(unsigned v) {          // lane 0 gets 0 (bound_ctrl: no register to preset)
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+}
+
 struct HalfIn {                      // one read's side of a pass
     const int8_t* ref; int first, count;         // reference columns first, first + step, ... (count of them)
     const int8_t* read; int rfirst, m;           // read rows read[rfirst + r * rstep], r < m
@@ -398,29 +402,33 @@ __device__ __forceinline__ void score_pass_pk(uint32_t* snap, const HalfIn a, co
     // last one, sees a never-matching column -- before the first column that leaves H = E = F = 0 as they are, after the last
     // one nothing reads the strip any more -- so the loop body has no divergent region around the 15 R instructions (the
     // conditional form kept two copies of the strip alive across the branch: 283 registers at 20 rows per lane).
-    // the column's base code is fetched one step ahead (clamped index: no branch) and turned into the table word when it is used
-    auto code_at = [](const HalfIn& h, int c, int step_) -> int {
-        const int cc = c < 0 ? 0 : (c < h.count ? c : (h.count > 0 ? h.count - 1 : 0));
-        return h.ref[h.first + cc * step_];                     // (count == 0: first == 0, a readable byte of the window text)
+    // the column's base code is fetched one step ahead and turned into the table word when it is used.  The offset of a lane's
+    // column moves by `step` while the column index moves inside [0, count - 1] and stays put outside (a clamped index: no branch,
+    // every load inside the window text; count == 0: first == 0, a readable byte) -- no multiply, no 64-bit sum per step
+    auto table_of = [](const HalfIn& h, bool started, int c, int code) {
+        return (started && c < h.count && (unsigned)code < 4u) ? 10u << (8 * code) : 0u;
     };
-    auto table_of = [](const HalfIn& h, int c, int code) {
-        return (c >= 0 && c < h.count && (unsigned)code < 4u) ? 10u << (8 * code) : 0u;
-    };
-    int rawa_next = code_at(a, -lane, step), rawb_next = code_at(b, -lane, step);
+    unsigned off_a = (unsigned)a.first, off_b = (unsigned)b.first;
+    int rawa_next = a.ref[off_a], rawb_next = b.ref[off_b];
     const int steps = cmax + 63;
     for (int t = 0; t < steps; ++t) {
-        const unsigned i0 = dpp_up1_u(p0, G_ZERO), i1 = dpp_up1_u(p1, 0), i2 = dpp_up1_u(p2, 0), i3 = dpp_up1_u(p3, 0);
+        const unsigned i0 = dpp_up1_u(p0, G_ZERO), i1 = dpp_up1_z(p1), i2 = dpp_up1_z(p2), i3 = dpp_up1_z(p3);
         const int c = t - lane;
-        const unsigned tab_a = table_of(a, c, rawa_next), tab_b = table_of(b, c, rawb_next);
-        rawa_next = code_at(a, c + 1, step);
-        rawb_next = code_at(b, c + 1, step);
-        unsigned dsrc = diag_in, fs = i1, ff = i2, lm = 0;
+        const bool started = c >= 0;
+        const unsigned tab_a = table_of(a, started, c, rawa_next), tab_b = table_of(b, started, c, rawb_next);
+        off_a += (started && c + 1 < a.count) ? (unsigned)step : 0u;
+        off_b += (started && c + 1 < b.count) ? (unsigned)step : 0u;
+        rawa_next = a.ref[off_a];
+        rawb_next = b.ref[off_b];
+        // (row k + 1's diagonal term is formed from G[k] BEFORE row k writes it: the old value dies there and the new one takes its
+        // register -- read after the write it cost a register move per row and step)
+        unsigned diag = pk_add(diag_in, __builtin_amdgcn_perm(tab_b, tab_a, SEL[0])), fs = i1, ff = i2, lm = 0;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const unsigned diag = pk_add(dsrc, __builtin_amdgcn_perm(tab_b, tab_a, SEL[k]));
-            dsrc = G[k];
+            const unsigned diag_k = diag;
+            if (k + 1 < R) diag = pk_add(G[k], __builtin_amdgcn_perm(tab_b, tab_a, SEL[k + 1]));
             fs &= SEG[k];
-            const unsigned hs = pk_max_i(pk_max_i(diag, E[k]), fs), h = pk_max_i(hs, ff), hsgo = pk_subs_u(hs, 0x00080008u);
+            const unsigned hs = pk_max_i(pk_max_i(diag_k, E[k]), fs), h = pk_max_i(hs, ff), hsgo = pk_subs_u(hs, 0x00080008u);
             E[k] = pk_max_u(pk_subs_u(E[k], 0x00020002u), hsgo);
             fs = pk_max_u(pk_subs_u(fs, 0x00020002u), hsgo);
             ff = pk_max_u(pk_subs_u(ff, 0x00020002u), hsgo);
@@ -437,31 +445,34 @@ __device__ __forceinline__ void score_pass_pk(uint32_t* snap, const HalfIn a, co
         best = pk_max_u(best, lm);
         if (cand & 0xFFFFu) { col_a = c; keep(my_a, G); }
         if (cand >> 16) { col_b = c; keep(my_b, G); }
-        if (lane == 63) {
-            const int cm_a = (int)(p3 & 0xFFFFu), cm_b = (int)(p3 >> 16);
-            if (!stop_a && c >= 0 && c < a.count) {
+        // lane 63's column is complete: its maxima as wavefront-uniform values -- the running maxima, the end columns and the stop
+        // rules below are scalar-unit work (one v_readlane instead of a block of vector instructions with one lane switched on)
+        {
+            const unsigned cm = (unsigned)__builtin_amdgcn_readlane((int)p3, 63);
+            const int c63 = t - 63, cm_a = (int)(cm & 0xFFFFu), cm_b = (int)(cm >> 16);
+            if (!stop_a && c63 >= 0 && c63 < a.count) {
                 if (cm_a > run_a) {
                     run_a = cm_a;
                     if (a.lanes == 16 && run_a + BIAS >= 255) { ovf_a = 1; stop_a = 1; }
-                    else endc_a = c;
+                    else endc_a = c63;
                 }
-                if (!stop_a && (cm_a == a.terminate || c == a.count - 1)) stop_a = 1;
+                if (!stop_a && (cm_a == a.terminate || c63 == a.count - 1)) stop_a = 1;
             }
-            if (!stop_b && c >= 0 && c < b.count) {
+            if (!stop_b && c63 >= 0 && c63 < b.count) {
                 if (cm_b > run_b) {
                     run_b = cm_b;
                     if (b.lanes == 16 && run_b + BIAS >= 255) { ovf_b = 1; stop_b = 1; }
-                    else endc_b = c;
+                    else endc_b = c63;
                 }
-                if (!stop_b && (cm_b == b.terminate || c == b.count - 1)) stop_b = 1;
+                if (!stop_b && (cm_b == b.terminate || c63 == b.count - 1)) stop_b = 1;
             }
         }
-        if (bcast63(stop_a & stop_b)) break;
+        if (stop_a & stop_b) break;
     }
     // the end cells' rows out of the holders' copies
     auto finish = [&](const HalfIn& h, int run, int endc, int ovf, int col, unsigned best_half, const uint32_t* mine, int shift, PassOut& o) {
-        const int rm = bcast63(run), ec = bcast63(endc);
-        o.overflow = bcast63(ovf);
+        const int rm = run, ec = endc;                  // (wavefront-uniform: lane 63's view, read with v_readlane every step)
+        o.overflow = ovf;
         o.score = o.overflow ? 255 : rm;
         o.ref = ec >= 0 ? h.first + ec * step : (h.lanes == 16 ? -1 : 0);
         int er = -1;
