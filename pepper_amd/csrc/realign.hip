@@ -72,6 +72,7 @@ __global__ void to_codes_kernel(int8_t* __restrict__ buf, int64_t n) {
 }
 
 __device__ __forceinline__ int bcast63(int v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ int uni_value(int v) { return __builtin_amdgcn_readfirstlane(v); }      // the same in every lane: say so
 
 struct PassOut { int score, ref, read, overflow; };
 
@@ -156,6 +157,18 @@ __device__ __forceinline__ int wave_prefix_max(int v, int identity) {
     v = max(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xf, 0xf, false));   // row_shr:8
     v = max(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
     v = max(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// The same with the signed maximum's own identity in the lanes a shift leaves empty: `max(v, shifted-or-INT_MIN)` is then one
+// v_max_i32 with the DPP modifier (a lane without a source keeps v) instead of constant + move + maximum.  For values > INT_MIN.
+__device__ __forceinline__ int wave_prefix_max_min(int v) {
+    constexpr int ID = (int)0x80000000u;
+    v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(ID, v, 0x143, 0xc, 0xf, false));
     return v;
 }
 
@@ -622,8 +635,9 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
     extern __shared__ int sm[];
     Job& J = jobs[blockIdx.x];
     if (J.state != ST_BAND) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = J.ref_end - J.ref_begin + 1, m = J.read_end - J.read_begin + 1, score = J.score;
+    const int lane = threadIdx.x & 63, wave = uni_value((int)(threadIdx.x >> 6));
+    // (the read's fields as wavefront-uniform values: the row and chunk loops below branch on the scalar unit)
+    const int n = uni_value(J.ref_end - J.ref_begin + 1), m = uni_value(J.read_end - J.read_begin + 1), score = uni_value(J.score);
     int* hb = sm + wave * 3 * cap;
     int* eb = hb + cap;
     int* hc = hb + 2 * cap;
@@ -645,7 +659,7 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
     volatile int* vbest = sh_best;
     if (threadIdx.x < BAND_WAVES) sh_best[threadIdx.x] = PENDING;
     __syncthreads();
-    const int base_bw = J.bw, dir_width = J.dir_width;
+    const int base_bw = uni_value(J.bw), dir_width = uni_value(J.dir_width);
     uint8_t* dir = dirws + J.dir_off + (size_t)wave * m * dir_width;
     int bw = 0, stride = 0;
     const long long t_start = wall_clock64();
@@ -687,26 +701,25 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
                 for (int base = 0; base < U; base += 64) {
                     const int u = 1 + base + lane;
                     const bool valid = u <= U;
-                    int hbe = 0, ebe = 0, hbd = 0, rj = 4;
-                    if (valid) {
-                        hbe = hb[u + sh];
-                        ebe = eb[u + sh];
-                        hbd = hb[u + sh - 1];
-                        rj = lrf[x + u - 1];
-                    }
+                    // (lanes past the row's last slot read its last slot: no branch around the loads; what they compute goes
+                    // nowhere -- their term of the chain below is the identity, they store nothing, and the carries are read
+                    // from lane 63 only when the next chunk exists, i.e. when lane 63 is a slot of the row)
+                    const int uc = min(u, U);
+                    const int hbe = hb[uc + sh], ebe = eb[uc + sh], hbd = hb[uc + sh - 1], rj = lrf[x + uc - 1];
                     const int t1 = i == 0 ? -GO : hbe - GO, t2 = i == 0 ? -GE : ebe - GE;
                     const int ecur = max(t1, t2), de = t1 > t2;
                     const int diag = hbd + ((rj == qi && qi < 4) ? S_MATCH : -S_MIS);
                     const int e1 = max(ecur, 0), g = max(e1, diag);
                     // vertical-gap chain of the row: f(u) = max(-GE u, max_{v<u} (g(v) + GE v) - GO - GE (u - 1))
-                    const int pm = wave_prefix_max(valid ? g + u * GE : NEG, NEG);
-                    const int ex = max(dpp_up1_or(pm, NEG), carry_a);
+                    const int pm = wave_prefix_max_min(valid ? g + u * GE : NEG);
+                    const int ex = max(dpp_up1_or(pm, (int)0x80000000u), carry_a);       // (lane 0: carry_a, which is >= NEG)
                     const int f = max(-GE * u, ex - GO - (u - 1) * GE);
                     const int f1 = max(f, 0), hcur = max(g, f1);
                     const int hl = dpp_up1_or(hcur, carry_h), fl = dpp_up1_or(f, carry_f);
                     const int df = (hl - GO) > (fl - GE);
                     const int gap = max(e1, f1);
-                    const int dh = gap <= diag ? 1 : (e1 > f1 ? (de ? 3 : 2) : (df ? 5 : 4));
+                    const bool from_e = e1 > f1;                   // (selects, not branches: the code of the cell's source)
+                    const int dh = gap <= diag ? 1 : (from_e ? 2 : 4) + ((from_e ? de : df) ? 1 : 0);
                     wave_lds_order();                 // every lane has read the previous row's slots of this chunk
                     if (valid) {
                         eb[u] = ecur;
