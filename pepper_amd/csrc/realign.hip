@@ -692,8 +692,12 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
                 }
                 const int x = max(i - bw, 0), xp = max(i - 1 - bw, 0), sh = x - xp;
                 const int end = min(n - 1, i + bw), U = end - x + 1, edge = min(end + 1, width - 1);
+                // the H row is kept twice: row i reads `hp` (row i - 1) and writes `hw`, and the two swap -- a chunk may not
+                // overwrite slots the next chunk still reads, and copying the row back cost a pass over it per row
+                int* const hp = (i & 1) ? hc : hb;
+                int* const hw = (i & 1) ? hb : hc;
                 wave_lds_order();
-                if (lane == 0) { hb[0] = 0; eb[0] = 0; hb[edge] = 0; eb[edge] = 0; hc[0] = 0; }
+                if (lane == 0) { hp[0] = 0; eb[0] = 0; hp[edge] = 0; eb[edge] = 0; }
                 wave_lds_order();
                 const int qi = lrd[i];
                 int carry_a = NEG, carry_h = 0, carry_f = 0;
@@ -705,8 +709,8 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
                     // nowhere -- their term of the chain below is the identity, they store nothing, and the carries are read
                     // from lane 63 only when the next chunk exists, i.e. when lane 63 is a slot of the row)
                     const int uc = min(u, U);
-                    const int hbe = hb[uc + sh], ebe = eb[uc + sh], hbd = hb[uc + sh - 1], rj = lrf[x + uc - 1];
-                    const int t1 = i == 0 ? -GO : hbe - GO, t2 = i == 0 ? -GE : ebe - GE;
+                    const int hbe = hp[uc + sh], ebe = eb[uc + sh], hbd = hp[uc + sh - 1], rj = lrf[x + uc - 1];
+                    const int t1 = hbe - GO, t2 = ebe - GE;        // (row 0 reads the zeros both rows start from: -GO, -GE)
                     const int ecur = max(t1, t2), de = t1 > t2;
                     const int diag = hbd + ((rj == qi && qi < 4) ? S_MATCH : -S_MIS);
                     const int e1 = max(ecur, 0), g = max(e1, diag);
@@ -723,8 +727,7 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
                     wave_lds_order();                 // every lane has read the previous row's slots of this chunk
                     if (valid) {
                         eb[u] = ecur;
-                        if (U <= 64) hb[u] = hcur;      // single chunk: no other chunk still needs the previous row
-                        else hc[u] = hcur;
+                        hw[u] = hcur;
                         drow[u - 1] = (uint8_t)(de | (df << 1) | (dh << 2));
                         best = max(best, hcur);
                     }
@@ -734,9 +737,6 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(Job* __restrict__
                         carry_f = bcast63(f);
                     }
                 }
-                wave_lds_order();
-                if (U > 64)
-                    for (int u = 1 + lane; u <= U; u += 64) hb[u] = hc[u];
             }
             result = overtaken ? -3 : (hopeless ? 0 : wave_max(best));
         }
