@@ -313,11 +313,11 @@ ALGORITHMIC_BYTES_PER_UNIT = {
 
 
 def measured_traffic(model_kind, label):
-    """HBM bytes per launch of `label` from the committed PMC passes (profiles/r03_<model>_pmc.json, else r02_...; written by
+    """HBM bytes per launch of `label` from the committed PMC passes (profiles/r05_<model>_pmc.json, else the latest earlier round's; written by
     tools/pmc_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this file with --resident-only):
     FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16-byte-per-lane streaming reads, WRITE_SIZE as
     reported.  None where no pass is on file."""
-    for tag in ("r04", "r03", "r02"):
+    for tag in ("r05", "r04", "r03", "r02"):
         path = os.path.join(REPO, "profiles", f"{tag}_{model_kind}_pmc.json")
         if os.path.exists(path):
             break
