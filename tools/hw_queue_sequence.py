@@ -1,4 +1,7 @@
-"""Scratch: which step of polish() makes the next make_images slower?  usage: r05_seq.py <work> <sequence e.g. MMMCMMSMMCMM>"""
+"""Which step of polish() makes the NEXT image generation of the same process slower?  make_images / call_consensus / stitch in any
+order inside one process, each step's wall time on stdout.  With GPU_MAX_HW_QUEUES=32 every M after the second C is 1.5x slower
+(profiles/r05_hw_queues_sequence_*.txt, docs/LEDGER_r05.md "Late finding"); 16, the package's setting, shows no step.
+usage: GPU_MAX_HW_QUEUES=<n> python tools/hw_queue_sequence.py <work dir> <sequence of M C S Z, e.g. MMMCMMSMMCMM> [draft bases]"""
 import os, shutil, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
