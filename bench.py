@@ -948,7 +948,7 @@ def polish_make_images_leg(scratch):
                     ins[parts[0]] = float(parts[1])
             per_read = ins["valu_wave_instructions_per_read_score"] + ins["valu_wave_instructions_per_read_band"]
             simd_cycles = 1024 * mid["seconds"] * 2.4e9
-            out["roofline"] = {"bound": "valu issue", "kernel": "sw_ends_kernel + band_kernel", "unit": "G wave-instructions/s",
+            out["roofline"] = {"bound": "valu issue", "kernel": "sw_ends_pair_kernel + band_kernel", "unit": "G wave-instructions/s",
                                "achieved": per_read * mid["counts"]["realigned"] / mid["seconds"] / 1e9, "peak": 1024 * 2.4 / 4,
                                "frac": 4.0 * per_read * mid["counts"]["realigned"] / simd_cycles,
                                "valu_wave_instructions_per_read": per_read, "source": "profiles/r05_polish_chain_pmc.txt"}
