@@ -184,3 +184,18 @@ def test_worker_device_map_and_device_ids(tmp_path, monkeypatch):
     want = _make(bam_path, fa_path, str(tmp_path / "one"), 1, True, monkeypatch)
     got = _make(bam_path, fa_path, str(tmp_path / "two"), 2, True, monkeypatch, regions=2, device_ids="0,0")
     _assert_same(got, want)
+
+
+def test_chain_in_the_packed_kernel_forms():
+    """The chain's re-aligner takes the two-reads-per-wavefront score pass and the one-wavefront band stage by itself only for
+    calls of thousands of reads (what a 128-interval call at 60x is); PA_REALIGN_SINGLE=0 / PA_BAND_WAVES=1 pin those forms for a
+    process: the comparisons with the reference builds and with the host form again, in a child process."""
+    import subprocess
+    import sys
+    if os.environ.get("PEPPER_AMD_REALIGN_FORMS_CHILD") == "1":
+        pytest.skip("the child run itself")
+    env = dict(os.environ, PA_REALIGN_SINGLE="0", PA_BAND_WAVES="1", PEPPER_AMD_REALIGN_FORMS_CHILD="1")
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                          "-k", "reference_builds or host_form"],
+                         env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-2000:]

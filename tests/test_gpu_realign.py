@@ -223,3 +223,63 @@ def test_low_complexity_sequences():
         seqs += [lowc(150, kind), reference[10:400], reference[20:30] * 6]
         out = _gpu_align(reference, 300, pos, seqs)
         _assert_same(out, ssw.realign_reads(reference, 300, pos, seqs))
+
+
+def test_a_call_that_fills_the_chip_takes_the_packed_kernels():
+    """>= 3 072 reads in one call: the score pass with two reads per wavefront (sw_ends_pair_kernel: reads paired by window
+    length, several strip sizes in one call, the 24-row catch-all, a read beyond 24 rows per lane in the LDS form) and the band
+    stage with one wavefront per read (band_kernel<1>: widths tried in turn, first rows of 257 slots, the wider relaunch for long
+    gaps) -- the forms no smaller call reaches by itself.  Every field and operation against the SSW restatement."""
+    from pepper_amd.polish.PEPPER import align_windows
+    rng = np.random.default_rng(19)
+    windows, pos, seqs, which = [], [], [], []
+    plans = [(1000, 1220, 520, {}), (50000, 1220, 520, dict(sub=0.08, ins=0.06, dele=0.08)), (90000, 700, 500, {}),
+             (200000, 1220, 520, {}), (300000, 400, 480, dict(min_len=20)), (400000, 1530, 300, dict(min_len=900)),
+             (500000, 1220, 300, {})]
+    for w, (start, width, n_reads, kw) in enumerate(plans):
+        text = _rand_seq(rng, width)
+        p, s = ssw.simulate_reads(rng, text, start, n_reads, **kw)
+        if w == 6:
+            # long insertions and deletions: bands beyond the first rows' 257 slots
+            for k in range(0, 60):
+                a = int(rng.integers(0, 200))
+                seg = text[a:a + int(rng.integers(500, 900))]
+                cut = int(rng.integers(20, len(seg) - 20))
+                gap = int(rng.integers(150, 400))
+                s[k] = seg[:cut] + _rand_seq(rng, gap) + seg[cut:] if k % 2 else seg[:cut] + seg[min(len(seg) - 10, cut + gap):]
+                p[k] = start + a
+        windows.append((start, text))
+        pos += p
+        seqs += s
+        which += [w] * len(p)
+    # one read beyond the register strips (1 600 bases against its own long window), N runs, a one-base read
+    long_text = _rand_seq(rng, 2000)
+    windows.append((700000, long_text))
+    pos += [700000, 700010, 700020, 700030]
+    seqs += [long_text[:1600], "N" * 50 + long_text[60:300], "A", long_text[30:1300]]
+    which += [7] * 4
+    assert len(seqs) >= 3072
+    expect = []
+    for w, (start, text) in enumerate(windows):
+        idx = [k for k in range(len(seqs)) if which[k] == w]
+        expect += ssw.realign_reads(text, start, [pos[k] for k in idx], [seqs[k] for k in idx])
+    blob = [s.encode() for s in seqs]
+    off = np.zeros(len(seqs) + 1, np.int64)
+    np.cumsum([len(b) for b in blob], out=off[1:])
+    out = align_windows(windows, which, pos, off, np.frombuffer(b"".join(blob), np.uint8), collapse_eqx=False)
+    _assert_same(out, expect)
+    assert (out["status"] == 1).sum() > 3000
+
+
+@pytest.mark.parametrize("single,band_waves", [("0", "1"), ("0", "3"), ("1", "1")])
+def test_every_case_in_the_forced_kernel_forms(single, band_waves):
+    """PA_REALIGN_SINGLE / PA_BAND_WAVES pin the kernel forms for a whole process (they are read once): the cases above, small
+    calls included, through the two-reads-per-wavefront score pass and the one-wavefront band stage (and the other mixes)."""
+    import subprocess
+    import sys
+    if os.environ.get("PEPPER_AMD_REALIGN_FORMS_CHILD") == "1":
+        pytest.skip("the child run itself")
+    env = dict(os.environ, PA_REALIGN_SINGLE=single, PA_BAND_WAVES=band_waves, PEPPER_AMD_REALIGN_FORMS_CHILD="1")
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-2000:]
