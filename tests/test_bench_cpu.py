@@ -25,7 +25,7 @@ def test_help_and_contract_flags():
 def test_traffic_comes_from_the_committed_pmc_passes():
     b = _bench()
     t = b.measured_traffic("variant", "lstm_dec_h2_fused")
-    assert t is not None and t["source"] == os.path.join("profiles", "r04_variant_pmc.json")      # this round's passes
+    assert t is not None and t["source"] == os.path.join("profiles", "r05_variant_pmc.json")      # this round's passes
     assert 0.5 < t["mfma_busy_frac"] < 1.0 and 100 < t["hbm_GBps_profiled"] < 8000               # the counters north_star names
     table = json.load(open(os.path.join(REPO, t["source"])))["kernels"]["lstm_dec_h2_fused"]
     assert t["bytes_per_launch"] == table["fetch_bytes_corrected"] + table["write_bytes"]
