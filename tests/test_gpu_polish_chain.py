@@ -84,22 +84,68 @@ def test_chain_images_equal_the_reference_builds(tmp_path, monkeypatch):
     assert len(intervals) == 7
     checked = 0
     for (_, start, end) in intervals:
-        clipped = bu.restated_get_reads(reads, start, end, False, 0)
-        res = ssw.realign_reads(draft[start:end + 20], start, [r["pos"] for r in clipped], [r["seq"] for r in clipped],
-                                aligner=ssw.align_reference)
-        realigned = [dict(r, pos=p, cigar=[(0 if o in (7, 8) else o, n) for o, n in ops]) if st == 1 else r
-                     for r, (st, score, p, pe, ops) in zip(clipped, res)]
-        img, pos = pu.run_polish_reference(ref_enc, pu.FlatPileup(start, end, draft[start:end + 1], realigned), start, end)
-        want = AlignmentSummarizer.chunk_images(SimpleNamespace(image=img, genomic_pos=[tuple(x) for x in pos.tolist()]), 1000, 50)
-        for cid, (wi, wp) in enumerate(zip(want[0], want[2])):
-            g = got["ctg1_%d_%d_%d" % (start, end, cid)]
-            assert np.array_equal(g["image"], wi), (start, cid)
-            assert np.array_equal(g["position"], wp[:, 0]) and np.array_equal(g["index"], wp[:, 1])
-            assert int(g["region_start"]) == start and int(g["region_end"]) == end and int(g["chunk_id"]) == cid
-            assert not g["label"].any() and g["contig"] == "ctg1"
-            checked += 1
-        assert "ctg1_%d_%d_%d" % (start, end, len(want[0])) not in got
+        checked += _check_interval(got, ref_enc, "ctg1", draft, start, end, bu.restated_get_reads(reads, start, end, False, 0))
     assert checked == len(got) and checked >= 10
+
+
+def _check_interval(got, ref_enc, contig, draft, start, end, clipped):
+    """One interval's chunks in `got` against the reference's SSW build (every clipped read re-aligned to draft[start, end + 20))
+    and its SummaryGenerator build on the re-aligned reads; -> chunks compared."""
+    from pepper_amd.polish.AlignmentSummarizer import AlignmentSummarizer
+    res = ssw.realign_reads(draft[start:end + 20], start, [r["pos"] for r in clipped], [r["seq"] for r in clipped],
+                            aligner=ssw.align_reference)
+    realigned = [dict(r, pos=p, cigar=[(0 if o in (7, 8) else o, n) for o, n in ops]) if st == 1 else r
+                 for r, (st, score, p, pe, ops) in zip(clipped, res)]
+    img, pos = pu.run_polish_reference(ref_enc, pu.FlatPileup(start, end, draft[start:end + 1], realigned), start, end)
+    want = AlignmentSummarizer.chunk_images(SimpleNamespace(image=img, genomic_pos=[tuple(x) for x in pos.tolist()]), 1000, 50)
+    for cid, (wi, wp) in enumerate(zip(want[0], want[2])):
+        g = got["%s_%d_%d_%d" % (contig, start, end, cid)]
+        assert np.array_equal(g["image"], wi), (start, cid)
+        assert np.array_equal(g["position"], wp[:, 0]) and np.array_equal(g["index"], wp[:, 1])
+        assert int(g["region_start"]) == start and int(g["region_end"]) == end and int(g["chunk_id"]) == cid
+        assert not g["label"].any() and g["contig"] == contig
+    assert "%s_%d_%d_%d" % (contig, start, end, len(want[0])) not in got
+    return len(want[0])
+
+
+def test_sampled_intervals_of_a_bench_shaped_job_equal_the_reference_builds(tmp_path, monkeypatch):
+    """tools/synth_bam's data (the shape bench.py's polish_make_images leg runs on: 60x of 4-12 kb reads with mapq-0 / duplicate /
+    secondary / supplementary records among them), 2 Mb here: every interval through default make_images with 8 workers -- calls
+    of 128 intervals, ~8 500 reads each, i.e. the packed kernel forms the product picks by itself -- and 12 of them (the first,
+    the last, 10 drawn at random) against the reference's SSW and SummaryGenerator builds, the reads parsed from the BAM by the
+    tests' own BGZF / BAM reader."""
+    import json
+    import subprocess
+    import test_gpu_images_vs_ref as vr
+    from pepper_amd import build
+    from pepper_amd.polish.ImageGenerationUI import UserInterfaceSupport
+    from pepper_amd.variant.fasta import FASTA_handler
+    ref_enc = pu.load_reference_polish_encoder()
+    tool = build.build_tools()
+    if ref_enc is None or not ssw.have_reference() or tool is None:
+        pytest.skip("oracle/_ref or tools/synth_bam not available")
+    work = str(tmp_path)
+    info = json.loads(subprocess.run([tool, work, "2000000", "60", "78"], check=True, capture_output=True, text=True).stdout)
+    bam, fa = os.path.join(work, "reads.bam"), os.path.join(work, "draft.fa")
+    got = _make(bam, fa, os.path.join(work, "chain"), 8, True, monkeypatch)
+    fasta = FASTA_handler(fa)
+    contig = fasta.get_chromosome_names()[0]
+    length = fasta.get_chromosome_sequence_length(contig)
+    assert length == info["genome_bases"]
+    draft = fasta.get_reference_sequence(contig, 0, length)
+    _, intervals = UserInterfaceSupport.make_intervals([(contig, None)], fa)
+    assert len(intervals) > 1500
+    linear = vr._bai_linear(bam + ".bai", 0)
+    rng = np.random.default_rng(6)
+    picks = sorted({0, len(intervals) - 1} | {int(k) for k in rng.choice(np.arange(1, len(intervals) - 1), 10, replace=False)})
+    checked = 0
+    for k in picks:
+        _, start, end = intervals[k]
+        records = vr._records_reaching(bam, linear, start, end + 1)
+        clipped = vr._clip(records, start, end, False, 0)
+        assert 0 < len(clipped) < 1500             # (below the reservoir cap: the interval goes through the chain)
+        checked += _check_interval(got, ref_enc, contig, draft, start, end, clipped)
+    assert checked >= 12
 
 
 @pytest.mark.parametrize("threads,regions", [(1, 128), (3, 2), (2, 5)])
