@@ -620,8 +620,8 @@ __device__ __forceinline__ int wave_max(int v) {
 
 // Three wavefronts per read try three consecutive band widths of the doubling sequence at once (the attempts are
 // independent; the narrowest one that reaches the score is the library's); that wavefront alone walks back and writes
-// the operations.  cap: ints per band array (hb, eb, hc; one set per wavefront); the bytes behind them hold the
-// trace-back steps, the base codes of the aligned windows and the per-step operation classes (3 (m + n) + 4 bytes).
+// the operations.  cap: ints per band array (the H row twice -- hb and hc, read and written in turn -- and eb; one set per
+// wavefront); the bytes behind them hold the trace-back steps, the base codes of the aligned windows and the per-step operation classes (3 (m + n) + 4 bytes).
 // ops_counter: running number of operations written to opsws.
 // BAND_WAVES = 3 races three widths (the lowest latency per read: what a call of a few hundred reads wants); = 1 tries the
 // widths one after the other in one wavefront (a third of the wavefronts, LDS and direction bytes, and no work on widths the
