@@ -175,6 +175,14 @@ int pa_h5_builder_write_polish_image_regions(pa_h5_builder* b, int32_t n_regions
 int pa_h5_builder_write_variant_summary(pa_h5_builder* b, const char* name, int32_t n, const char* contig, const int32_t* positions,
                                         const uint8_t* depths, const char* cand_blob, const int64_t* cand_offsets, const uint8_t* freqs,
                                         const int8_t* images, int32_t window, int32_t features);
+/* One predictions/<name> group of a variant prediction file, as pepper_variant DataStorePredict.py:26-67 (write_prediction) --
+ * the datasets of pa_h5_write_prediction_batch above without libhdf5: contigs 'S<longest>' [n], positions int32 [n], depths uint8
+ * [n], candidates variable-length utf-8 [n,1], candidate_frequency uint8 [n,1], base_prediction float64 [n, n_classes] (probs
+ * are float32 here; `np.float` in the reference is float64).  The fused call_variant's writer thread lays out ~9 000 such
+ * groups per 256 Mb: 0.3 ms each through libhdf5, a few microseconds here. */
+int pa_h5_builder_write_prediction_batch(pa_h5_builder* b, const char* name, int32_t n, const char* contigs, int32_t contig_stride,
+                                         const int32_t* positions, const uint8_t* depths, const char* cand_blob,
+                                         const int64_t* cand_offsets, const uint8_t* freqs, const float* probs, int32_t n_classes);
 int pa_h5_builder_close(pa_h5_builder* b);
 
 /* How the polish chunks of this handle were read so far: `direct_chunks` had their image / position / index bytes copied

@@ -47,33 +47,32 @@ int pa_candidates_reference_flags(const char* text, int64_t text_len, int64_t wi
         pa_h5_set_error("bad argument");
         return -1;
     }
-    // homopolymer runs of the upper-cased window: run_lo[i] / run_hi[i] = first index / one past the last of i's run
-    std::string up((size_t)text_len, 0);
-    for (int64_t i = 0; i < text_len; ++i) {
+    // Per position, the 20-base context ref[p - 10, p + 10) cut at the contig's start and at the window's end, upper-cased: a
+    // homopolymer run of >= 5 INSIDE it that touches [p - 5, p + 4) (CandidateFinder.py:397-418).  The context is scanned where
+    // it lies (20 characters per position; run tables over the whole window -- tens of kilobases for 512 positions -- were most
+    // of a batch's selection time).
+    auto up = [&](int64_t i) -> unsigned char {
         const unsigned char c = (unsigned char)text[i];
-        up[(size_t)i] = (char)((c >= 'a' && c <= 'z') ? c - 32 : c);
-    }
-    std::vector<int32_t> run_lo((size_t)text_len), run_hi((size_t)text_len);
-    for (int64_t i = 0; i < text_len; ++i) run_lo[(size_t)i] = (i > 0 && up[(size_t)i] == up[(size_t)i - 1]) ? run_lo[(size_t)i - 1] : (int32_t)i;
-    for (int64_t i = text_len - 1; i >= 0; --i)
-        run_hi[(size_t)i] = (i + 1 < text_len && up[(size_t)i] == up[(size_t)i + 1]) ? run_hi[(size_t)i + 1] : (int32_t)(i + 1);
+        return (unsigned char)((c >= 'a' && c <= 'z') ? c - 32 : c);
+    };
     for (int64_t r = 0; r < n; ++r) {
         const int64_t p = position[r], q = p - window_lo;
         const bool inside = q >= 0 && q < text_len;
-        letters[r] = inside ? (uint8_t)up[(size_t)q] : 0;
+        letters[r] = inside ? (uint8_t)up(q) : 0;
         bool flag = false;
         if (inside) {
-            // the 20-base context ref[p - 10, p + 10) cut at the contig's start and at the window's end; a run >= 5 inside it
-            // touching [p - 5, p + 4) (CandidateFinder.py:397-418)
             int64_t ctx_lo = (p - 10 > 0 ? p - 10 : 0) - window_lo;
             if (ctx_lo < 0) ctx_lo = 0;
             const int64_t ctx_hi = q + 10 < text_len ? q + 10 : text_len;
-            for (int64_t k = -5; k < 4 && !flag; ++k) {
-                const int64_t idx = q + k;
-                if (idx < ctx_lo || idx >= ctx_hi) continue;
-                const int64_t hi = run_hi[(size_t)idx] < ctx_hi ? run_hi[(size_t)idx] : ctx_hi;
-                const int64_t lo = run_lo[(size_t)idx] > ctx_lo ? run_lo[(size_t)idx] : ctx_lo;
-                flag = hi - lo >= 5;
+            const int64_t touch_lo = q - 5 > ctx_lo ? q - 5 : ctx_lo, touch_hi = q + 4 < ctx_hi ? q + 4 : ctx_hi;   // [touch_lo, touch_hi)
+            int64_t run_start = ctx_lo;
+            for (int64_t i = ctx_lo; i < ctx_hi && !flag; ++i) {
+                const bool last_of_run = i + 1 == ctx_hi || up(i + 1) != up(i);
+                if (last_of_run) {
+                    // the run [run_start, i + 1): long enough and sharing an index with the touched stretch
+                    if (i + 1 - run_start >= 5 && run_start < touch_hi && i + 1 > touch_lo) flag = true;
+                    run_start = i + 1;
+                }
             }
         }
         in_repeat[r] = flag ? 1 : 0;

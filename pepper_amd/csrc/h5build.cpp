@@ -64,6 +64,7 @@ struct Obj {
     bool vlen = false;                                        // variable-length UTF-8 strings: a scalar ((collection, object) below,
     uint32_t heap_collection = 0, heap_object = 0, heap_length = 0;   // compact layout) or an array of references at `addr`
     bool fixed_string = false;                                // numpy 'S<elem>' fields: null-padded ASCII, `elem` bytes each
+    bool is_float = false;                                    // IEEE little-endian float64 (elem == 8)
 };
 
 struct HeapCollection {                                       // a global heap collection being filled (GCOL, spec III.E)
@@ -266,6 +267,22 @@ struct pa_h5_builder {
         add(g, std::move(d));
     }
 
+    // float64 array, contiguous layout (what `file[path] = np.asarray(x, np.float64)` gives)
+    void float64_dataset(uint32_t g, const std::string& name, int rank, const uint64_t* dims, const double* data) {
+        Obj d;
+        d.name = name;
+        d.elem = 8;
+        d.is_float = true;
+        d.rank = (uint8_t)rank;
+        d.bytes = 8;
+        for (int k = 0; k < rank; ++k) {
+            d.dims[k] = dims[k];
+            d.bytes *= dims[k];
+        }
+        d.addr = d.bytes ? append(data, d.bytes) : UNDEF;
+        add(g, std::move(d));
+    }
+
     void row(uint32_t g, const char* name, uint8_t elem, bool is_signed, const void* data, uint64_t count) {
         dataset(g, name, elem, is_signed, 1, &count, data);
     }
@@ -291,7 +308,7 @@ struct pa_h5_builder {
 
     uint64_t dataset_header(const Obj& d) {
         const bool compact = d.addr == 0;
-        const uint16_t space = (uint16_t)(8 + 8 * d.rank), dtype = d.vlen ? 24 : (d.fixed_string ? 8 : 16), fill = 8;
+        const uint16_t space = (uint16_t)(8 + 8 * d.rank), dtype = (d.vlen || d.is_float) ? 24 : (d.fixed_string ? 8 : 16), fill = 8;
         const uint16_t layout = compact ? (uint16_t)((4 + d.bytes + 7) / 8 * 8) : 24;
         const uint32_t body = 4 * 8 + space + dtype + fill + layout;
         const uint64_t h = reserve(16 + body);
@@ -311,6 +328,11 @@ struct pa_h5_builder {
             // object index); base type = one-byte integer -- the bytes h5py writes for a Python str
             static const uint8_t vl[20] = {0x19, 0x01, 0x01, 0x00, 16, 0, 0, 0, 0x10, 0, 0, 0, 1, 0, 0, 0, 0, 0, 8, 0};
             std::memcpy(&meta[at], vl, sizeof vl);
+        } else if (d.is_float) {
+            // class 1 (floating point) v1, IEEE binary64 little-endian: mantissa normalisation "msb implied", sign at bit 63;
+            // properties: bit offset 0, precision 64, exponent at 52 (11 bits), mantissa at 0 (52 bits), bias 1023 (spec IV.A.2.d)
+            static const uint8_t f64[20] = {0x11, 0x20, 0x3f, 0x00, 8, 0, 0, 0, 0, 0, 64, 0, 52, 11, 0, 52, 0xff, 0x03, 0, 0};
+            std::memcpy(&meta[at], f64, sizeof f64);
         } else if (d.fixed_string) {
             meta[at] = 0x13;                                  // datatype v1, class 3 (string): null-padded, ASCII -- what h5py
             meta[at + 1] = 0x01;                              // writes for a numpy 'S' array
@@ -736,6 +758,43 @@ int pa_h5_builder_write_variant_summary(pa_h5_builder* b, const char* name, int3
     b->big_dataset(id, "candidate_frequency", 1, false, 2, d2, freqs);
     b->big_dataset(id, "images", 1, true, 3, d3, images);
     if (int rc = b->seal(summaries, id)) return rc;
+    if (b->out.size() >= (4u << 20)) return b->flush();
+    return 0;
+}
+
+int pa_h5_builder_write_prediction_batch(pa_h5_builder* b, const char* name, int32_t n, const char* contigs, int32_t contig_stride,
+                                         const int32_t* positions, const uint8_t* depths, const char* cand_blob,
+                                         const int64_t* cand_offsets, const uint8_t* freqs, const float* probs, int32_t n_classes) {
+    if (!b || !name || n < 0 || n_classes <= 0 || contig_stride <= 0 ||
+        (n > 0 && (!contigs || !positions || !depths || !cand_blob || !cand_offsets || !freqs || !probs)))
+        return fail("bad argument");
+    if (b->failed) return fail("the file has a failed write behind it");
+    if (!*name || std::strchr(name, '/')) return fail(std::string("bad batch name '") + name + "'");
+    const uint32_t predictions = b->group("predictions");
+    if (b->has_kid(predictions, name)) return fail(std::string("cannot create group 'predictions/") + name + "' (already exists)");
+    // contigs: fixed-width, null padded, as wide as the longest name of the batch (numpy 'S' array semantics)
+    size_t width = 1;
+    for (int32_t i = 0; i < n; ++i) width = std::max(width, strnlen(contigs + (size_t)i * contig_stride, (size_t)contig_stride));
+    if (width > 255) return fail("contig name longer than 255 bytes");
+    std::string names((size_t)n * width, '\0');
+    for (int32_t i = 0; i < n; ++i) {
+        const char* src = contigs + (size_t)i * contig_stride;
+        std::memcpy(&names[(size_t)i * width], src, strnlen(src, std::min(width, (size_t)contig_stride)));
+    }
+    std::vector<double> p64((size_t)n * n_classes);
+    for (size_t i = 0; i < p64.size(); ++i) p64[i] = (double)probs[i];
+    Obj g;
+    g.name = name;
+    g.group = true;
+    const uint32_t id = b->add(predictions, std::move(g));
+    const uint64_t d1[1] = {(uint64_t)n}, d2[2] = {(uint64_t)n, 1}, dp[2] = {(uint64_t)n, (uint64_t)n_classes};
+    b->fixed_strings(id, "contigs", (uint64_t)n, (uint32_t)width, names.data());
+    b->big_dataset(id, "positions", 4, true, 1, d1, positions);
+    b->big_dataset(id, "depths", 1, false, 1, d1, depths);
+    b->vlen_string_array(id, "candidates", 2, d2, cand_blob, cand_offsets, (uint64_t)n);
+    b->big_dataset(id, "candidate_frequency", 1, false, 2, d2, freqs);
+    b->float64_dataset(id, "base_prediction", 2, dp, p64.data());
+    if (int rc = b->seal(predictions, id)) return rc;
     if (b->out.size() >= (4u << 20)) return b->flush();
     return 0;
 }

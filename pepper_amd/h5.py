@@ -58,6 +58,8 @@ SYMBOLS = [
     ("pa_h5_builder_write_polish_image_regions", ctypes.c_int, [c_void_p, c_int32, c_char_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32] +
                                                                 [c_void_p] * 4),
     ("pa_h5_builder_write_variant_summary", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_char_p] + [c_void_p] * 6 + [c_int32, c_int32]),
+    ("pa_h5_builder_write_prediction_batch", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
+                                                            c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
     ("pa_h5_builder_close", ctypes.c_int, [c_void_p]),
     ("pa_h5_write_prediction_batch", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int32]),
@@ -144,6 +146,18 @@ class PredictionBuilder(object):
             self._h, n, seq_len, contigs.ctypes.data, contigs.dtype.itemsize, start.ctypes.data, end.ctypes.data,
             chunk.ctypes.data, new_region.ctypes.data, skip.ctypes.data, position.ctypes.data, index.ctypes.data,
             bases.ctypes.data, phred.ctypes.data))
+
+    def write_prediction_batch(self, group, contigs, positions, depths, cand_blob, cand_offsets, freqs, probs):
+        """File.write_prediction_batch's group (variant predictions/batch_<n>) through the append-only writer; group =
+        "predictions/<name>"."""
+        head, _, name = group.rpartition("/")
+        if head != "predictions":
+            raise H5Error("the append-only writer lays prediction batches out under predictions/: " + group)
+        n = len(positions)
+        blob = np.ascontiguousarray(cand_blob)
+        _check(self._lib.pa_h5_builder_write_prediction_batch(
+            self._h, name.encode(), n, contigs.ctypes.data, contigs.dtype.itemsize, positions.ctypes.data, depths.ctypes.data,
+            blob.ctypes.data, cand_offsets.ctypes.data, freqs.ctypes.data, probs.ctypes.data, probs.shape[1] if probs.ndim == 2 else 1))
 
     def write_polish_image_chunks(self, names, contig, region_start, region_end, chunk_id, images, labels, position, index):
         n, seq_len, features = images.shape

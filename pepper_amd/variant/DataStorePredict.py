@@ -5,6 +5,8 @@ write_prediction): predictions/batch_<n>/{contigs 'S', positions i32, depths u8,
 vlen-str, candidate_frequency u8, base_prediction float64 [B,3]} -- `np.float` in the reference
 is float64; the type_prediction dataset is commented out there and is not written here either.
 """
+import os
+
 import numpy as np
 
 from pepper_amd import h5
@@ -13,11 +15,24 @@ from pepper_amd import h5
 class DataStore(object):
     _prediction_path_ = 'predictions'
 
-    def __init__(self, filename, mode='r'):
+    def __init__(self, filename, mode='r', bulk=False):
+        """bulk=True (mode 'w'): the append-only writer (h5.PredictionBuilder: groups laid out as they come, the HDF5 metadata
+        written by close(); no libhdf5 call and no process-wide lock per batch) -- for writers that only use
+        write_prediction_arrays; PEPPER_AMD_H5_BUILDER=0 keeps libhdf5."""
         self.filename = filename
         self.mode = mode
-        self.file_handler = h5.File(self.filename, self.mode)
+        if bulk and mode == 'w' and os.environ.get("PEPPER_AMD_H5_BUILDER", "1") != "0":
+            self.file_handler = h5.PredictionBuilder(self.filename)
+        else:
+            self.file_handler = h5.File(self.filename, self.mode)
         self._written = set()
+
+    def abort(self):
+        """The run raised: publish nothing (the append-only writer removes its temporary file; a libhdf5 file is closed)."""
+        if hasattr(self.file_handler, "abort"):
+            self.file_handler.abort()
+        else:
+            self.file_handler.close()
 
     def close(self):
         self.file_handler.close()

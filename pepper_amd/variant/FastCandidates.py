@@ -297,7 +297,7 @@ def native_batch_arrays(options, rules, fasta_handler, first, n, positions, dept
     file_name, batch_key = where, ""
     text = np.frombuffer(blob, np.uint8)
     ends = np.flatnonzero(text == 0)
-    if len(ends) != n or np.isin(text, _LIST_BYTES).any():
+    if len(ends) != n or _LIST_LUT[text].any():
         return None
     starts = np.empty(n + 1, np.int64)
     starts[0] = 0
@@ -321,17 +321,17 @@ def native_batch_arrays(options, rules, fasta_handler, first, n, positions, dept
     row, ref_len, flags = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.uint8)
     offsets = np.empty(n + 1, np.int64)
     cap = len(blob) + n * (len(first) + 200)
-    lines = ctypes.create_string_buffer(cap)
+    lines = np.empty(cap, np.uint8)                       # (not zero-filled, and only the written part is copied out)
     m = h5.load().pa_candidates_select_format(
         ctypes.byref(rules), first, n, pos.ctypes.data, depth.ctypes.data, support.ctypes.data, pred.ctypes.data,
         letters.ctypes.data, rep.ctypes.data, blob, starts.ctypes.data, 1, row.ctypes.data, ref_len.ctypes.data,
-        flags.ctypes.data, lines, cap, offsets.ctypes.data)
+        flags.ctypes.data, ctypes.c_void_p(lines.ctypes.data), cap, offsets.ctypes.data)
     if m == -2:
         return None
     if m < 0:
         raise h5.H5Error(h5.load().pa_h5_last_error().decode())
-    raw_lines = lines.raw
     cut = offsets[:m + 1].tolist()
+    raw_lines = lines[:cut[m]].tobytes()
     row, flags = row[:m], flags[:m]
     return _Segment(contig, pos[row], ref_len[:m].copy(), (flags & 1).astype(bool), (flags & 2).astype(bool),
                     [raw_lines[cut[k]:cut[k + 1]] for k in range(m)],
@@ -339,6 +339,8 @@ def native_batch_arrays(options, rules, fasta_handler, first, n, positions, dept
 
 
 _LIST_BYTES = np.frombuffer(b" ,'\"[]\n", np.uint8)
+_LIST_LUT = np.zeros(256, bool)                              # the same set as a look-up (np.isin sorts per call)
+_LIST_LUT[_LIST_BYTES] = True
 
 
 def _python_batch(options, fasta_handler, file_name, batch_key, leftovers):

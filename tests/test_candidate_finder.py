@@ -481,3 +481,35 @@ def test_library_batches_equal_the_python_loops(tmp_path, monkeypatch):
         assert fc._native_batch(opts, fc._rules(opts), handler, pred, "batch_2") is None
         with pytest.raises(ZeroDivisionError):
             fc._python_batch(opts, handler, pred, "batch_2", [])
+
+
+def test_native_reference_flags_equal_the_array_form_on_random_windows():
+    """pa_candidates_reference_flags (per-position scan of the 20-base context) against _in_repeat_arrays (run tables over the
+    whole window): low-complexity text, lower case, windows that start at the contig's first base or later, positions at and
+    beyond both edges."""
+    import numpy as np
+    from types import SimpleNamespace
+    from pepper_amd import h5
+    from pepper_amd.variant.CandidateFinder import _in_repeat_arrays
+    rng = np.random.default_rng(23)
+    lib = h5.load()
+    for trial in range(60):
+        m = int(rng.integers(1, 400))
+        alphabet = "ACGT" if trial % 3 else "AC"
+        out = []
+        while len(out) < m:
+            out += [alphabet[int(rng.integers(len(alphabet)))]] * int(rng.integers(1, 9 if trial % 2 else 3))
+        text = "".join(out[:m])
+        if trial % 5 == 0:
+            text = text.lower()
+        if trial % 7 == 0:
+            text = text[:m // 2] + "N" * min(6, m - m // 2) + text[m // 2 + 6:]
+        lo = 0 if trial % 4 == 0 else int(rng.integers(0, 50))
+        positions = np.unique(np.concatenate([rng.integers(lo - 12, lo + m + 12, 200), [lo, lo + m - 1, lo + m, lo - 1, 0]])).astype(np.int64)
+        want_letters, want_flags = _in_repeat_arrays(SimpleNamespace(text=text, lo=lo), "c", positions)
+        letters, flags = np.empty(len(positions), np.uint8), np.empty(len(positions), np.uint8)
+        raw = text.encode("latin-1")
+        assert lib.pa_candidates_reference_flags(raw, len(raw), lo, len(positions), positions.ctypes.data, letters.ctypes.data,
+                                                 flags.ctypes.data) == 0
+        assert np.array_equal(letters, want_letters), trial
+        assert np.array_equal(flags.astype(bool), want_flags), (trial, positions[flags.astype(bool) != want_flags][:5])
