@@ -177,3 +177,24 @@ def test_native_merge_on_rows_no_pipeline_would_write(tmp_path, monkeypatch):
     with pytest.raises(KeyError):
         Stitch.small_chunk_stitch("c", [(bad, "c", 0, 10)])
     assert Stitch.small_chunk_stitch("c", []) == (-1, -1, "")
+
+
+def test_native_merge_takes_chunk_ids_in_string_order(tmp_path, monkeypatch):
+    """A region of twelve chunks: the reference iterates sorted(chunk ids) on STRINGS ("0", "1", "10", "11", "2", ...), and with
+    keys written by several chunks that order decides which label stays; the native merge goes chunk by chunk in that order."""
+    monkeypatch.delenv("PEPPER_AMD_STITCH_NUMPY", raising=False)
+    rng = np.random.default_rng(31)
+    pred = tmp_path / "pred"
+    pred.mkdir()
+    path = str(pred / "p.hdf")
+    with DataStore(path, "w") as store:
+        for start, end in ((0, 900), (700, 1600)):
+            for cid in range(12):
+                n = 150
+                pos = np.sort(rng.integers(start, end, n))
+                idx = rng.integers(0, 2, n)
+                order = np.lexsort((idx, pos))
+                store.write_prediction("ctg", start, end, cid, pos[order], idx[order], rng.integers(1, 5, n), np.zeros(n))
+    expect = dict_stitch([path], "ctg", 1)
+    out = perform_stitch(str(pred), str(tmp_path / "o"), 1)
+    assert open(out).read().splitlines()[1] == expect and len(expect) > 500
