@@ -185,6 +185,17 @@ int pa_h5_builder_write_prediction_batch(pa_h5_builder* b, const char* name, int
                                          const int64_t* cand_offsets, const uint8_t* freqs, const float* probs, int32_t n_classes);
 int pa_h5_builder_close(pa_h5_builder* b);
 
+/* One predictions/batch_<n> group of a variant prediction file (pepper_variant DataStorePredict.py:26-67) read in one call through
+ * the locator -- what the candidate finder does six h5py reads for (pepper_variant CandidateFinder.py:356-374).  load: 0 = the
+ * batch is held for this thread (n candidates, contigs as n x contig_width bytes null padded, the candidate strings as
+ * candidate_bytes bytes each followed by a NUL, n_classes probabilities per candidate), 1 = not a layout the locator reads
+ * (read the datasets through pa_h5_read / pa_h5_read_strings), -1 = error.  take copies the held batch out:
+ * contigs [n * contig_width], candidates [candidate_bytes], positions int32 [n], depths uint8 [n], freq uint8 [n],
+ * probs float64 [n * n_classes]. */
+int pa_h5_prediction_batch_load(pa_h5* f, const char* group, int64_t* n, int32_t* contig_width, int64_t* candidate_bytes,
+                                int32_t* n_classes);
+int pa_h5_prediction_batch_take(char* contigs, char* candidates, int32_t* positions, uint8_t* depths, uint8_t* freq, double* probs);
+
 /* How the polish chunks of this handle were read so far: `direct_chunks` had their image / position / index bytes copied
  * straight out of the mapped file (classic-format files of h5py or pa_h5_open mode 1 opened read-only: the locator in
  * hdf5io.cpp walks object header -> symbol table -> B-tree -> symbol node -> layout itself), `library_chunks` went through

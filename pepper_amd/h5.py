@@ -38,6 +38,8 @@ SYMBOLS = [
     ("pa_h5_write_vlen_strings", ctypes.c_int, [c_void_p, c_char_p, c_int32, P64, ctypes.POINTER(c_char_p)]),
     ("pa_h5_read_polish_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32]),
     ("pa_h5_read_stats", ctypes.c_int, [c_void_p, P64, P64]),
+    ("pa_h5_prediction_batch_load", ctypes.c_int, [c_void_p, c_char_p, P64, ctypes.POINTER(c_int32), P64, ctypes.POINTER(c_int32)]),
+    ("pa_h5_prediction_batch_take", ctypes.c_int, [c_void_p] * 6),
     ("pa_h5_read_polish_prediction_region", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                                            ctypes.POINTER(c_int32)]),
     ("pa_h5_write_polish_image_chunks", ctypes.c_int, [c_void_p, c_char_p, c_int32, c_int32, c_int32, c_char_p, c_int64, c_int64] +
@@ -411,6 +413,26 @@ class File(object):
                                                       positions.ctypes.data, depths.ctypes.data, cand_blob.ctypes.data,
                                                       cand_offsets.ctypes.data, freqs.ctypes.data, probs.ctypes.data,
                                                       probs.shape[1]))
+
+    def read_prediction_batch(self, group):        # (no libhdf5 call inside: no lock)
+        """One predictions/batch_<n> group in one call (pa_h5_prediction_batch_load / _take): (contigs uint8 [n, width] null
+        padded, candidate strings as bytes each followed by a NUL, positions int32 [n], depths uint8 [n], candidate_frequency
+        uint8 [n, 1], base_prediction float64 [n, classes]) -- or None when the file is not of a layout the locator reads (the
+        caller reads the datasets one by one then)."""
+        n, width, cand_bytes, classes = c_int64(), c_int32(), c_int64(), c_int32()
+        rc = self._lib.pa_h5_prediction_batch_load(self._h, group.encode(), ctypes.byref(n), ctypes.byref(width),
+                                                   ctypes.byref(cand_bytes), ctypes.byref(classes))
+        if rc == 1:
+            return None
+        _check(rc)
+        rows = n.value
+        contigs = np.empty((rows, max(1, width.value)), np.uint8)
+        cand = np.empty(max(1, cand_bytes.value), np.uint8)
+        positions, depths = np.empty(rows, np.int32), np.empty(rows, np.uint8)
+        freq, probs = np.empty((rows, 1), np.uint8), np.empty((rows, max(1, classes.value)), np.float64)
+        _check(self._lib.pa_h5_prediction_batch_take(contigs.ctypes.data, cand.ctypes.data, positions.ctypes.data, depths.ctypes.data,
+                                                     freq.ctypes.data, probs.ctypes.data))
+        return contigs, cand[:cand_bytes.value].tobytes(), positions, depths, freq, probs
 
     @_locked
     def read_strings_shaped(self, path):

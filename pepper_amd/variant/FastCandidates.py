@@ -275,6 +275,18 @@ def _native_batch_open(options, rules, fasta_handler, file_name, batch_key, file
     if not f.has_predictions:
         return _Segment("", np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, bool), np.zeros(0, bool), [])
     base = "predictions/" + batch_key + "/"
+    whole = f.read_prediction_batch(base[:-1])
+    if whole is not None:
+        # the six datasets in one call through the locator (files of this package's writers): the same conditions as below
+        contigs, blob, positions, depths, freq, pred = whole
+        n = len(positions)
+        if n == 0:
+            return _Segment("", np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, bool), np.zeros(0, bool), [])
+        if (contigs != contigs[0]).any():
+            return None
+        first = contigs[0].tobytes()
+        first = first[:first.index(b"\0")] if b"\0" in first else first
+        return native_batch_arrays(options, rules, fasta_handler, first, n, positions, depths, freq, pred, blob, file_name + "/" + batch_key)
     contig_shape, contig_blob = f.read_strings_shaped(base + "contigs")
     shape, blob = f.read_strings_shaped(base + "candidates")
     positions = f[base + "positions"]
@@ -376,7 +388,10 @@ def _parts(options, all_prediction_pair):
     threads = max(1, int(getattr(options, "threads", 1) or 1))
     pairs = list(all_prediction_pair)
     python_form = os.environ.get("PEPPER_AMD_CANDIDATES_PYTHON") == "1"
-    if threads == 1 or len(pairs) < (8 if python_form else 256) * threads or getattr(options, "fasta_handler_factory", None) is not None:
+    # (a batch read in one call and selected inside the library is ~0.4 ms: below ~2 000 batches one process is done before a pool
+    # of spawned workers has started)
+    if (threads == 1 or len(pairs) < (8 * threads if python_form else min(256 * threads, 2048)) or
+            getattr(options, "fasta_handler_factory", None) is not None):
         return [_part(options, pairs)]
     import sys
     from multiprocessing import get_context

@@ -55,6 +55,43 @@ def test_builder_batches_equal_libhdf5_batches(tmp_path):
             assert [c.decode() for c in np.asarray(b[base + "contigs"]).tolist()] == [c.decode() for c in batch[0].tolist()]
 
 
+def test_a_batch_read_in_one_call_equals_the_six_reads(tmp_path):
+    """File.read_prediction_batch (pa_h5_prediction_batch_load: the locator, variable-length strings out of the global heap
+    collections, float64 rows) against the dataset-by-dataset reads of libhdf5 -- on the append-only writer's file (where it must
+    succeed: that is the file the pipeline reads) and on libhdf5's (where it may answer None)."""
+    rng = np.random.default_rng(9)
+    batches = [_batch(rng, 512, "chr1"), _batch(rng, 300, "chr10_KI270_random"), _batch(rng, 1, "c")]
+    mixed = _batch(rng, 5, "chr2")
+    batches.append((np.array(["chr2", "chr2", "chr21_alt", "chr2", "a"], dtype='S'),) + mixed[1:])
+    for bulk in (True, False):
+        path = str(tmp_path / ("b%d.hdf" % bulk))
+        store = DataStore(path, mode='w', bulk=bulk)
+        for k, b in enumerate(batches):
+            store.write_prediction_arrays(k, *b[:7])
+        store.close()
+        with h5.File(path) as f:
+            for k in (2, 0, 1, 3, 1):                       # not in file order: the heap scan's cursor must not matter
+                base = "predictions/batch_%d" % k
+                got = f.read_prediction_batch(base)
+                if got is None:
+                    assert not bulk
+                    continue
+                contigs, blob, positions, depths, freq, probs = got
+                n = len(batches[k][1])
+                assert contigs.shape[0] == n and positions.dtype == np.int32 and probs.dtype == np.float64
+                shape, want_blob = f.read_strings_shaped(base + "/candidates")
+                assert blob == want_blob and tuple(shape) == (n, 1)
+                names = [bytes(row).rstrip(b"\0") for row in contigs]
+                assert names == [c for c in np.asarray(f[base + "/contigs"]).tolist()]
+                assert np.array_equal(positions, np.asarray(f[base + "/positions"])) and np.array_equal(depths, np.asarray(f[base + "/depths"]))
+                assert np.array_equal(freq, np.asarray(f[base + "/candidate_frequency"]))
+                assert np.array_equal(probs, np.asarray(f[base + "/base_prediction"]))
+            assert f.read_prediction_batch("predictions/batch_99") is None
+    # the pipeline's own file is read the fast way
+    with h5.File(str(tmp_path / "b1.hdf")) as f:
+        assert f.read_prediction_batch("predictions/batch_0") is not None
+
+
 def test_builder_store_is_published_by_close_only(tmp_path):
     import os
     path = str(tmp_path / "p.hdf")
