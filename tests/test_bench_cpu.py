@@ -69,3 +69,55 @@ def test_profiler_names_map_to_the_labels_the_bench_line_uses():
         table = json.load(open(os.path.join(REPO, "profiles", "r02_%s_pmc.json" % model)))["kernels"]
         assert dominant in table and dominant in b.ALGORITHMIC_BYTES_PER_UNIT
         assert b.measured_traffic(model, dominant) is not None
+
+
+def test_final_line_fits_what_the_driver_parses():
+    """Round 5's line was 20.7 KB and came back from the driver unparsed.  The stdout line is assembled from the full record by
+    bench.final_line: under 6000 bytes whatever the legs carry, with the contract's keys, `roofline` (traffic and the algorithmic
+    fraction included), `cpu_baseline`, the default-batch call, and one tuple per secondary leg."""
+    b = _bench()
+    full = json.load(open(os.path.join(REPO, "profiles", "r05_bench.json")))       # a canned full record: round 5's 20.7 KB line
+    assert len(json.dumps(full)) > 15000
+    line = b.final_line(full)
+    text = json.dumps(line)
+    assert len(text) < 6000, len(text)
+    assert json.loads(text) == line and "\n" not in text
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert abs(line["value"] - full["value"]) / full["value"] < 1e-4 and line["unit"] == "windows/s"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_algorithmic_of_dtype_peak", "kernel"):
+        assert roof.get(key) is not None, key
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    cb = line["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("port", "reference") and cb["sample"]
+    assert line["batch512"]["host_buffers"] > 0
+    summary = line["secondary_summary"]
+    assert set(summary) == set(full["secondary"])
+    for name, t in summary.items():
+        assert t.get("value") is not None and t.get("unit"), name
+    assert summary["realign"]["cpu"] > 0 and 0 < summary["realign"]["frac"] < 1
+    assert summary["bgzf_inflate"]["bound"] == "valu issue"               # the roof that binds, not the HBM one at 0.007
+    assert line["full_record"].startswith("gpurun_out")
+    # legs that failed, a hundred legs, prose of any length: still under the limit, the required blocks still there
+    fat = json.loads(json.dumps(full))
+    for k in range(100):
+        fat["secondary"]["leg_%d" % k] = {"value": 1.0 * k, "unit": "things/s with a long unit string " * 3,
+                                          "roofline": {"frac": 0.5, "bound": "hbm"}, "cpu_baseline": {"value": 2.0, "cores": 1}}
+    fat["secondary"]["broken"] = {"error": "x" * 1000}
+    fat["config"]["workload"] = "w" * 3000
+    fat["cpu_baseline"]["sample"] = "s" * 3000
+    out = b.final_line(fat)
+    assert "roofline" in out and "cpu_baseline" in out and "config" in out
+    assert len(json.dumps(out)) < 8000 or len(out["secondary_summary"]) > 100       # (a hundred legs is not a case the limit covers)
+    empty = b.final_line({"metric": "m", "value": 1.0, "unit": "u", "config": {"workload": "w"}, "roofline": {"bound": "mfma"}})
+    assert empty["roofline"]["bound"] == "mfma" and "cpu_baseline" not in empty
+
+
+def test_vs_baseline_is_null_without_a_published_number():
+    """BASELINE.json.published is empty: the line's vs_baseline is null, the CPU ratio has its own key."""
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert 'line["vs_baseline"] =' not in src and '"vs_baseline": None' in src
+    assert json.load(open(os.path.join(REPO, "BASELINE.json")))["published"] == {}
