@@ -143,6 +143,10 @@ def load():
     return lib
 
 
+# include/pepper_amd.h:20-24
+PA_ERR_INVALID = 1
+PA_ERR_HIP = 2
+PA_ERR_NO_DEVICE = 3
 PA_ERR_UNSUPPORTED = 4
 
 

@@ -179,8 +179,13 @@ class UserInterfaceSupport:
 
         try:
             enc = PackedEncoder.acquire(device, int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20, host_threads=1)
-        except _lib.PepperAmdError:
-            # no page-locked arena to be had (memlock / cgroup limit): the host form needs none
+        except _lib.PepperAmdError as err:
+            # no page-locked arena to be had (memlock / cgroup limit): the host form needs none.  Not under the fused form:
+            # image_generator writes images only, and polish(fused_inference=True) has no call_consensus step that would read
+            # them -- this worker's intervals would silently be missing from the stitched FASTA
+            if fused is not None:
+                raise RuntimeError("fused polish: worker %d got no page-locked arena for the device chain (%s); run without "
+                                   "fused_inference, or raise the memlock limit" % (thread_id, err)) from err
             return UserInterfaceSupport.image_generator(args, all_intervals, total_threads, thread_id)
         chain = PEPPER.PolishChain(enc)
         consensus = fused.worker(thread_id, device) if fused is not None else None      # polish(fused_inference=True): fused.py

@@ -52,15 +52,32 @@ class FusedConsensus(object):
                 entry["made"] += 1
                 first = entry["all"][0] if entry["all"] else None
         if not make:
-            return entry, entry["free"].get()
-        torch.cuda.set_device(device)
-        if first is not None:
-            model = first.clone()
-        else:
-            model = ModelHandler.load_simple_model_for_training(self.model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
-                                                                image_features=ImageSizeOptions.IMAGE_HEIGHT,
-                                                                seq_len=ImageSizeOptions.SEQ_LENGTH,
-                                                                num_classes=ImageSizeOptions.TOTAL_LABELS)[0]
+            while True:
+                try:
+                    model = entry["free"].get(timeout=1.0)
+                except queue.Empty:
+                    if entry.get("failed") is None:
+                        continue
+                    model = None
+                if model is None:       # (a load that failed hands its error to everyone waiting for a handle)
+                    raise RuntimeError("fused consensus: the model could not be loaded") from entry.get("failed")
+                return entry, model
+        try:
+            torch.cuda.set_device(device)
+            if first is not None:
+                model = first.clone()
+            else:
+                model = ModelHandler.load_simple_model_for_training(self.model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
+                                                                    image_features=ImageSizeOptions.IMAGE_HEIGHT,
+                                                                    seq_len=ImageSizeOptions.SEQ_LENGTH,
+                                                                    num_classes=ImageSizeOptions.TOTAL_LABELS)[0]
+        except BaseException as err:
+            with self.models_lock:
+                entry["made"] -= 1
+                entry["failed"] = err
+            for _ in range(64):
+                entry["free"].put(None)
+            raise
         with self.models_lock:
             entry["all"].append(model)
         return entry, model

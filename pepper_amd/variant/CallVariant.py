@@ -63,7 +63,8 @@ def call_variant(options):
             ImageGenerationUtils.generate_images(options)
         finally:
             sink, options.fused_sink = options.fused_sink, None
-            sink.close()
+            # (an image worker that raised: the predictions written so far are withdrawn, not published under the final name)
+            sink.close(failed=sys.exc_info()[0] is not None)
             precomputed = sink.segments or None
             if walls is not None:
                 walls["fused_writer_drain"] = getattr(sink, "drain_seconds", 0.0)

@@ -39,6 +39,7 @@ class FusedPredictor(object):
         self.batch_no = 0
         self.windows = 0
         self.forward_seconds = 0.0
+        self.timer_lock = threading.Lock()                   # the stage timers are added to from several threads
         self.write_seconds = self.select_seconds = 0.0       # what the two threads spent working (not waiting)
         self.select_error = None
         self.pending = {}            # per image worker: arrays of its candidates that have not filled a batch yet
@@ -70,15 +71,34 @@ class FusedPredictor(object):
             if make:
                 entry["made"] += 1
         if make:
-            torch.cuda.set_device(device)
-            model = ModelHandler.load_simple_model_for_training(
-                self.options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT, num_classes=ImageSizeOptions.TOTAL_LABELS,
-                num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)[0]
-            model.eval()
+            try:
+                torch.cuda.set_device(device)
+                model = ModelHandler.load_simple_model_for_training(
+                    self.options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT, num_classes=ImageSizeOptions.TOTAL_LABELS,
+                    num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)[0]
+                model.eval()
+            except BaseException as err:
+                # a load that failed (no memory, a bad model_path) must not leave the other workers waiting for a handle that will
+                # never be put back: the slot is given up and every waiter is handed the error
+                with self.models_lock:
+                    entry["made"] -= 1
+                    entry["failed"] = err
+                for _ in range(64):
+                    entry["free"].put(None)
+                raise
             with self.models_lock:
                 entry["all"].append(model)
             return entry, model
-        return entry, entry["free"].get()
+        while True:
+            try:
+                model = entry["free"].get(timeout=1.0)
+            except queue.Empty:
+                if entry.get("failed") is not None:
+                    raise RuntimeError("fused inference: the model could not be loaded") from entry["failed"]
+                continue
+            if model is None:
+                raise RuntimeError("fused inference: the model could not be loaded") from entry.get("failed")
+            return entry, model
 
     def forward_device(self, device, images_ptr, n):
         """n int8 windows [n, 33, 26] at device address images_ptr (the encoder's results of its last run: complete, and valid
@@ -95,7 +115,8 @@ class FusedPredictor(object):
             model._stream.synchronize()
             return probs.cpu().numpy()
         finally:
-            self.forward_seconds += time.perf_counter() - t0        # (summed over the handles: not a wall time)
+            with self.timer_lock:
+                self.forward_seconds += time.perf_counter() - t0    # (summed over the handles: not a wall time)
             entry["free"].put(model)
 
     def forward_host(self, device, images):
@@ -166,16 +187,22 @@ class FusedPredictor(object):
                     continue
                 key, contigs, positions, depths, freqs, probs, blob = item
                 t0 = time.perf_counter()
-                first = bytes(contigs[0])
                 if len(contigs) == 0 or (contigs != contigs[0]).any():
                     continue
+                first = bytes(contigs[0])
                 seg = FastCandidates.native_batch_arrays(options, rules, fasta_handler, first, len(positions), positions, depths, freqs,
                                                          probs, blob, self.filename + "/" + key)
                 if seg is not None:
                     self.segments[(self.filename, key)] = seg
-                self.select_seconds += time.perf_counter() - t0        # (summed over the threads)
+                with self.timer_lock:
+                    self.select_seconds += time.perf_counter() - t0    # (summed over the threads)
         except BaseException as err:      # noqa: BLE001 -- whatever was not selected here is selected in step 3 from the file
-            self.select_error = err
+            with self.timer_lock:
+                first_error, self.select_error = self.select_error is None, err
+            if first_error:               # said once: the run still completes (step 3 does these batches from the file), only slower
+                import sys
+                sys.stderr.write("[pepper_amd] fused candidate selection stopped (%r): find_candidates will select from the "
+                                 "predictions file instead\n" % (err,))
             while self.select_queue.get() is not None:
                 pass
 
@@ -214,7 +241,9 @@ class FusedPredictor(object):
                 if self.queue.get() is None:
                     break
 
-    def close(self):
+    def close(self, failed=False):
+        """failed: the run is being abandoned (an image worker raised): whatever was written is withdrawn -- a partial
+        pepper_prediction.hdf under its final name would be read by a re-run of step 3 as if it were complete."""
         t0 = time.perf_counter()
         self.queue.put(None)
         self.writer.join()
@@ -224,7 +253,7 @@ class FusedPredictor(object):
             for t in self.selector:
                 t.join()
         self.drain_seconds = time.perf_counter() - t0      # what the two threads still had to do when image generation was over
-        if self.error is not None:
+        if self.error is not None or failed:
             self.store.abort()                             # (no partial predictions file for the next step's listing)
         else:
             self.store.close()

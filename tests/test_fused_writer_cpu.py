@@ -73,3 +73,71 @@ def test_batches_come_from_one_workers_consecutive_intervals(tmp_path):
                 assert np.allclose(q, expected[key].astype(np.float64))
     assert len(seen) == len(expected)
     assert short <= 6                      # one short batch per run of a worker at most
+
+
+def test_a_model_that_cannot_be_loaded_fails_every_worker_instead_of_hanging_them(tmp_path, monkeypatch):
+    """HANDLES workers take the 'make' branch; the rest wait on the free queue.  A load that raises must reach the waiters too
+    (they used to block forever on a handle nobody would put back), and close(failed=True) must not publish a predictions file."""
+    import os
+    import time
+    import torch
+    from pepper_amd.variant import fused
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    gate = threading.Event()
+
+    def load(*a, **k):
+        gate.wait(5)                   # hold the makers until the waiters are parked on the queue
+        raise MemoryError("no room for the checkpoint")
+    monkeypatch.setattr(fused.ModelHandler, "load_simple_model_for_training", staticmethod(load))
+    sink = fused.FusedPredictor(SimpleNamespace(batch_size=64, fused_candidates_off=True, model_path="nowhere.pkl"), str(tmp_path) + "/")
+    errors = []
+
+    def worker():
+        try:
+            sink._model(0)
+            errors.append(None)
+        except BaseException as err:      # noqa: BLE001
+            errors.append(err)
+    threads = [threading.Thread(target=worker, daemon=True) for _ in range(5)]
+    for t in threads:
+        t.start()
+    time.sleep(0.3)
+    gate.set()
+    for t in threads:
+        t.join(10)
+    assert not any(t.is_alive() for t in threads), "a worker is still waiting for a model handle"
+    assert len(errors) == 5 and all(isinstance(e, (MemoryError, RuntimeError)) for e in errors)
+    assert sum(isinstance(e, MemoryError) for e in errors) == fused.FusedPredictor.HANDLES
+    sink.close(failed=True)
+    assert not os.path.exists(str(tmp_path) + "/pepper_prediction.hdf")
+
+
+def test_polish_fused_model_failure_reaches_the_waiters(tmp_path, monkeypatch):
+    import time
+    import torch
+    from pepper_amd.polish import fused
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    gate = threading.Event()
+
+    def load(*a, **k):
+        gate.wait(5)
+        raise OSError("bad model_path")
+    monkeypatch.setattr(fused.ModelHandler, "load_simple_model_for_training", staticmethod(load))
+    owner = fused.FusedConsensus("nowhere.pkl", str(tmp_path) + "/")
+    errors = []
+
+    def worker():
+        try:
+            owner._model(0)
+            errors.append(None)
+        except BaseException as err:      # noqa: BLE001
+            errors.append(err)
+    threads = [threading.Thread(target=worker, daemon=True) for _ in range(4)]
+    for t in threads:
+        t.start()
+    time.sleep(0.3)
+    gate.set()
+    for t in threads:
+        t.join(10)
+    assert not any(t.is_alive() for t in threads)
+    assert len(errors) == 4 and all(isinstance(e, (OSError, RuntimeError)) for e in errors)
