@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import pileup_utils as pu
+from conftest import need_reference_build
 
 
 def _same(a, b):
@@ -65,7 +66,7 @@ def libs():
 def test_restatement_equals_reference_build(libs, name):
     oracle, ref = libs
     if ref is None:
-        pytest.skip("oracle/_ref not built (no /root/reference here)")
+        need_reference_build("oracle/_ref")
     pile, params = _case(**CASES[name])
     a = pu.run_variant(oracle, pile, params)
     b = pu.run_variant(ref, pile, params, reference_impl=True)
@@ -76,7 +77,7 @@ def test_restatement_equals_reference_build(libs, name):
 def test_restatement_threshold_variants(libs):
     oracle, ref = libs
     if ref is None:
-        pytest.skip("oracle/_ref not built")
+        need_reference_build("oracle/_ref")
     pile, _ = _case(seed=11, ins_rate=0.03, del_rate=0.03)
     lo, hi = pile.region_start + 100, pile.region_end - 100
     for over in (dict(skip_indels=1), dict(min_snp_baseq=10, min_indel_baseq=10), dict(candidate_support_threshold=5),
@@ -110,7 +111,7 @@ def test_restatement_under_reference_presets(libs, preset, name):
     """HiFi / CLR / R10 image-generation thresholds (SetParameters.py:122-256) on quality-sensitive pileups."""
     oracle, ref = libs
     if ref is None:
-        pytest.skip("oracle/_ref not built")
+        need_reference_build("oracle/_ref")
     pile, params = preset_case(preset, name)
     a = pu.run_variant(oracle, pile, params)
     assert len(a["candidates"]) > 0
@@ -182,7 +183,7 @@ def _polish_case(seed, depth=45, region=1800, **kw):
 def test_polish_restatement_equals_reference_build(name):
     ref = pu.load_reference_polish_encoder()
     if ref is None:
-        pytest.skip("oracle/_ref not built (no /root/reference here)")
+        need_reference_build("oracle/_ref")
     oracle = pu.load_restatement()
     pile, start, end = _polish_case(**POLISH_CASES[name])
     img_o, pos_o = pu.run_polish_oracle(oracle, pile, start, end)

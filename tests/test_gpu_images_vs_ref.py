@@ -14,6 +14,7 @@ import pytest
 
 import bam_utils as bu
 import pileup_utils as pu
+from conftest import need_reference_build
 from pepper_amd import h5
 
 pytestmark = pytest.mark.gpu
@@ -174,7 +175,7 @@ def test_default_image_path_equals_the_reference_build_at_size(tmp_path, monkeyp
     from pepper_amd.variant.ImageGenerationUI import ImageGenerationUtils
     ref_lib = pu.load_reference_encoder()
     if ref_lib is None:
-        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+        need_reference_build("oracle/_ref/libref_variant_encoder.so")
     rng = np.random.default_rng(20260927)
     length_a, length_b = 231000, 31000
     draft_a, draft_b = rng.integers(0, 4, length_a).astype(np.uint8), rng.integers(0, 4, length_b).astype(np.uint8)
@@ -283,8 +284,9 @@ def test_sampled_intervals_of_a_bench_shaped_job_equal_the_reference_build(tmp_p
     from pepper_amd.variant.fasta import FASTA_handler
     ref_lib = pu.load_reference_encoder()
     tool = build.build_tools()
-    if ref_lib is None or tool is None:
-        pytest.skip("oracle/_ref or tools/synth_bam not available")
+    if ref_lib is None:
+        need_reference_build("oracle/_ref/libref_variant_encoder.so")
+    assert tool is not None, "tools/synth_bam did not build"
     work = str(tmp_path)
     info = json.loads(subprocess.run([tool, work, "8000000", "60", "77"], check=True, capture_output=True, text=True).stdout)
     bam, fa = os.path.join(work, "reads.bam"), os.path.join(work, "draft.fa")

@@ -424,6 +424,17 @@ def test_fused_polish_equals_the_three_step_run(tmp_path):
         assert np.array_equal(pa[key][2], pb[key][2]), key
         assert np.abs(pa[key][3].astype(int) - pb[key][3].astype(int)).max() <= 1
     assert fa_a == fa_b
+    # ... and ONE hop from the oracle: the fused run's bases / phred against models_np on the chunks that run wrote
+    names = sorted(ib)
+    labels, phred = models_np.polish_predict_chunks(sd, np.stack([ib[g] for g in names]), 128)
+    same_base = same_phred = total = 0
+    for g, want_b, want_p in zip(names, labels, phred):
+        contig, start, end, chunk = g.rsplit("_", 3)
+        got = pb[("%s-%s-%s" % (contig, start, end), chunk)]
+        same_base += int((got[2] == want_b).sum())
+        same_phred += int((np.abs(got[3].astype(int) - want_p.astype(int)) <= 1).sum())
+        total += len(want_b)
+    assert total >= 10000 and same_base > 0.999 * total and same_phred > 0.99 * total, (same_base, same_phred, total)
 
 
 def test_fused_call_variant_equals_the_three_step_run(tmp_path):
@@ -500,6 +511,23 @@ def test_fused_call_variant_equals_the_three_step_run(tmp_path):
     ia, ib = images(img_a), images(img_b)
     assert sorted(ia) == sorted(ib) and all(np.array_equal(ia[k][0], ib[k][0]) and np.array_equal(ia[k][1], ib[k][1]) for k in ia)
     _assert_same_vcfs(str(tmp_path / "fused"), str(tmp_path / "plain"))
+    # ... and ONE hop from the oracle: the fused run's base_prediction against models_np.variant_forward on the windows that run
+    # wrote (north_star: within 1e-4), candidate by candidate
+    checked = 0
+    for fn in sorted(os.listdir(img_b)):
+        with h5.File(os.path.join(img_b, fn)) as f:
+            for name in (f.keys("summaries") if "summaries" in f else []):
+                base = "summaries/" + name + "/"
+                windows = np.asarray(f[base + "images"])
+                if len(windows) == 0:
+                    continue
+                want = models_np.variant_forward(sd, windows)
+                contigs, pos, cand = f[base + "contigs"].tolist(), f[base + "positions"].tolist(), f[base + "candidates"].tolist()
+                for k in range(len(pos)):
+                    got = b[(contigs[k], pos[k], cand[k][0])][2]
+                    assert np.abs(np.asarray(got) - want[k]).max() < 1e-4, (name, k)
+                    checked += 1
+    assert checked == len(b)
 
 
 def _assert_same_vcfs(got_dir, want_dir):

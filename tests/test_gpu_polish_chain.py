@@ -12,6 +12,7 @@ import pytest
 
 import bam_utils as bu
 import pileup_utils as pu
+from conftest import need_reference_build
 from oracle import ssw
 from pepper_amd import h5
 
@@ -76,7 +77,7 @@ def test_chain_images_equal_the_reference_builds(tmp_path, monkeypatch):
     from pepper_amd.polish.ImageGenerationUI import UserInterfaceSupport
     ref_enc = pu.load_reference_polish_encoder()
     if ref_enc is None or not ssw.have_reference():
-        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+        need_reference_build("oracle/_ref (polish encoder, SSW)")
     low = dict(pos=2950, reverse=False, mapq=0, seq="ACGT" * 60, qual=np.full(240, 20, np.uint8), cigar=[(0, 240)])
     draft, reads, bam_path, fa_path = _dataset(tmp_path, 311, 6300, 330, (500, 3000), extra=[low])
     got = _make(bam_path, fa_path, str(tmp_path / "chain"), 1, True, monkeypatch)
@@ -122,8 +123,9 @@ def test_sampled_intervals_of_a_bench_shaped_job_equal_the_reference_builds(tmp_
     from pepper_amd.variant.fasta import FASTA_handler
     ref_enc = pu.load_reference_polish_encoder()
     tool = build.build_tools()
-    if ref_enc is None or not ssw.have_reference() or tool is None:
-        pytest.skip("oracle/_ref or tools/synth_bam not available")
+    if ref_enc is None or not ssw.have_reference():
+        need_reference_build("oracle/_ref (polish encoder, SSW)")
+    assert tool is not None, "tools/synth_bam did not build"
     work = str(tmp_path)
     info = json.loads(subprocess.run([tool, work, "2000000", "60", "78"], check=True, capture_output=True, text=True).stdout)
     bam, fa = os.path.join(work, "reads.bam"), os.path.join(work, "draft.fa")

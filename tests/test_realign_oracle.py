@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+from conftest import need_reference_build
 from oracle import ssw
 
 BASES = "ACGT"
@@ -38,9 +39,10 @@ def test_known_small_alignments():
     assert ssw.align("ACGT" * 10, "NNNNNNNN")[0] == 0
 
 
-@pytest.mark.skipif(not ssw.have_reference(), reason="oracle/_ref/libref_ssw.so not built (needs /root/reference)")
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_restatement_equals_reference_build_on_seeded_reads(seed):
+    if not ssw.have_reference():
+        need_reference_build("oracle/_ref/libref_ssw.so")
     rng = np.random.default_rng(seed)
     checked = wide = 0
     for it in range(220):
@@ -73,10 +75,11 @@ def test_restatement_equals_reference_build_on_seeded_reads(seed):
     assert checked == 220 and wide >= 10
 
 
-@pytest.mark.skipif(not ssw.have_reference(), reason="oracle/_ref/libref_ssw.so not built (needs /root/reference)")
 def test_restatement_equals_reference_build_on_low_complexity_sequences():
     """Repeats and homopolymers: equal-scoring cells everywhere, every tie rule matters (9000 further cases were
     compared offline, 0 differences)."""
+    if not ssw.have_reference():
+        need_reference_build("oracle/_ref/libref_ssw.so")
     rng = np.random.default_rng(9)
 
     def lowc(n):
