@@ -106,6 +106,19 @@ def self_spawn(args):
 
 COLLECTIVE_NOTE = "none (one rank)"
 BENCH_GROUP = None            # the RCCL process group when every rank could initialise it (dist_setup); None: the gloo default group
+RCCL_ATTEMPT_LEFT_BEHIND = False   # the RCCL attempt failed on some rank: a half-made communicator may exist here; leave without tearing it down
+
+
+def leave_group():
+    """The end of an N-rank run.  After an RCCL attempt that some rank failed, a communicator may be half made here (its creation
+    still blocked on a helper thread): tearing that down can block again, so the process leaves without it -- everything this rank
+    had to print is flushed first."""
+    import torch.distributed as dist
+    if RCCL_ATTEMPT_LEFT_BEHIND:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    dist.destroy_process_group()
 
 
 def dist_setup(args):
@@ -143,16 +156,24 @@ def dist_setup(args):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pepper_amd.parallel import agree_on_rccl
 
+    from pepper_amd.parallel import wait_bounded
+    from datetime import timedelta
+    probe_seconds = float(os.environ.get("PEPPER_AMD_RCCL_PROBE_SECONDS", 60))
+
     def try_rccl():
-        group = dist.new_group(backend="nccl", device_id=torch.device("cuda", device))
+        # (on agree_on_rccl's helper thread: the current device is per thread)
+        torch.cuda.set_device(device)
+        group = dist.new_group(backend="nccl", timeout=timedelta(seconds=probe_seconds), device_id=torch.device("cuda", device))
         probe = torch.ones(1, device=torch.device("cuda", device))
-        dist.all_reduce(probe, group=group)
-        torch.cuda.synchronize(device)
+        # no blocking wait and no device synchronize: a rank whose peers never enter polls until the deadline and then votes "failed"
+        wait_bounded(dist.all_reduce(probe, group=group, async_op=True), probe_seconds, "RCCL probe all-reduce")
         if int(probe.item()) != world:
             raise RuntimeError("RCCL all-reduce over %d ranks returned %d" % (world, int(probe.item())))
         return group
-    global BENCH_GROUP
-    BENCH_GROUP, failed, why = agree_on_rccl(world, try_rccl)
+    global BENCH_GROUP, RCCL_ATTEMPT_LEFT_BEHIND
+    # the whole attempt is bounded too (communicator creation can block as well): 1.5 x the probe's own deadline
+    BENCH_GROUP, failed, why = agree_on_rccl(world, try_rccl, timeout_s=1.5 * probe_seconds)
+    RCCL_ATTEMPT_LEFT_BEHIND = BENCH_GROUP is None and failed > 0
     if why:
         sys.stderr.write("[bench] rank %d: RCCL unusable (%s)\n" % (rank, why))
     one = torch.ones(1)
@@ -621,8 +642,7 @@ def encoder_bench(args):
         dt = float(tt.item())
     if rank != 0:
         if world > 1:
-            import torch.distributed as dist
-            dist.destroy_process_group()
+            leave_group()
         return
     avg = {k: float(np.mean([t[k] for t in times])) for k in times[0]}
     value = world * args.steps * stats["bases"] / dt
@@ -747,8 +767,7 @@ def encoder_bench(args):
         line["candidates_region0"] = {"device": len(out[0]["candidates"]), "cpu": run(*encoder_cpu.region_structs(regions[0]))}
     print(json.dumps(line))
     if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        leave_group()
 
 
 def polish_encoder_cpu_all_cores(seconds):
@@ -1472,8 +1491,7 @@ def main():
         wg_syn_bench(args, world, rank, device, ranks_seen, lib, handle, pool, unit_bytes, pool_n, host_call, sync)
         lib.pa_variant_destroy(handle)
         if world > 1:
-            import torch.distributed as dist
-            dist.destroy_process_group()
+            leave_group()
         return
     for k in range(args.warmup):
         step(k)
@@ -1629,8 +1647,7 @@ def main():
     else:
         lib.pa_polish_destroy(handle)
     if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        leave_group()
 
 
 if __name__ == "__main__":

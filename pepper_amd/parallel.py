@@ -76,14 +76,57 @@ def broadcast_numpy_state_dict(make_state_dict, shapes, src=0, device=None, grou
     return out
 
 
-def agree_on_rccl(world, try_rccl):
+class AttemptTimedOut(RuntimeError):
+    """bounded(): the call did not come back in time; its thread is still inside it."""
+
+
+def bounded(fn, timeout_s):
+    """fn() on a helper thread -> its result, or what it raised; AttemptTimedOut after timeout_s seconds, with the (daemon) thread
+    left where it is.  For calls that block inside a communication library with no deadline of their own -- a communicator
+    waiting for a peer that has already given up."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as err:      # noqa: BLE001
+            box["error"] = err
+    t = threading.Thread(target=run, name="bounded-attempt", daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        raise AttemptTimedOut("no answer within %.0f s" % timeout_s)
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
+def wait_bounded(work, timeout_s, what="collective"):
+    """Poll an async collective's completion (no blocking wait: a stuck device kernel cannot be waited out) -> None, or
+    AttemptTimedOut after timeout_s."""
+    import time
+    deadline = time.monotonic() + timeout_s
+    while not work.is_completed():
+        if time.monotonic() > deadline:
+            raise AttemptTimedOut("%s not complete after %.0f s" % (what, timeout_s))
+        time.sleep(0.005)
+    work.wait()             # (complete: this only hands over the result / raises what the collective raised)
+
+
+def agree_on_rccl(world, try_rccl, timeout_s=None):
     """All ranks decide TOGETHER whether the RCCL group is used: the default group is gloo (up wherever the rendezvous is),
     `try_rccl()` -- this rank's attempt to create the RCCL group and run a first collective on it, returning the group or raising
     -- runs on every rank, and the verdicts are summed over gloo.  -> (group or None, ranks that failed, this rank's reason).
-    A rank-local fallback (RCCL failed here, so re-initialise with gloo here) deadlocks the ranks where it did not fail."""
+    A rank-local fallback (RCCL failed here, so re-initialise with gloo here) deadlocks the ranks where it did not fail.
+
+    timeout_s bounds the attempt: RCCL coming up on seven ranks and throwing on the eighth leaves the seven INSIDE their first
+    collective (or inside communicator creation), waiting for a peer that is already on its way to the vote; without a bound
+    they sit there until the backend's watchdog fires, minutes later, and takes the process down with it.  With it the attempt
+    runs on a helper thread and a rank whose attempt has not answered in time votes "failed" like one whose attempt raised."""
     ok, why, group = 1.0, "", None
     try:
-        group = try_rccl()
+        group = bounded(try_rccl, timeout_s) if timeout_s else try_rccl()
     except Exception as err:        # noqa: BLE001 -- whatever the backend raises
         ok, why = 0.0, repr(err)[:160]
     verdict = torch.tensor([ok])

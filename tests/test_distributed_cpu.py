@@ -157,3 +157,73 @@ def test_ranks_agree_on_the_collective_backend(tmp_path, fail_on):
     got = [open(str(tmp_path / ("r%d" % r))).read().split() for r in range(2)]
     assert got[0][:2] == got[1][:2] == (["the-group", "0"] if not fail_on else ["None", str(len(fail_on))])
     assert [g[2] for g in got] == ["why" if r in fail_on else "-" for r in range(2)]
+
+
+def _blocked_worker(rank, world, port, out_dir):
+    """Rank 1's attempt raises before it enters the probe; rank 0 is INSIDE the probe all-reduce of a second group, waiting for
+    it -- the case the attempt's bound is for (the earlier test's failing rank raised and nobody blocked)."""
+    import os
+    import time
+    from datetime import timedelta
+    import torch
+    import torch.distributed as dist
+    from pepper_amd.parallel import agree_on_rccl, wait_bounded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    state = {}
+
+    def attempt():
+        group = dist.new_group(backend="gloo", timeout=timedelta(seconds=60))     # (both ranks get this far: creation is collective)
+        if rank == 1:
+            raise RuntimeError("the first collective failed on rank 1")
+        state["entered"] = time.monotonic()
+        wait_bounded(dist.all_reduce(torch.ones(1), group=group, async_op=True), 2.0, "probe all-reduce")
+        return group
+    t0 = time.monotonic()
+    group, failed, why = agree_on_rccl(world, attempt, timeout_s=30.0)
+    waited = time.monotonic() - t0
+    # the default group still works for both after the vote: the weight broadcast's stand-in
+    x = torch.tensor([float(rank + 1)])
+    dist.all_reduce(x)
+    with open(os.path.join(out_dir, "b%d" % rank), "w") as fh:
+        fh.write("%s %d %.2f %d %s" % (group, failed, waited, int(x.item()), why.replace(" ", "_") or "-"))
+    os._exit(0)              # (bench.py's leave_group: the abandoned group is not torn down)
+
+
+def test_a_rank_blocked_in_the_probe_is_released_by_the_bound(tmp_path):
+    port = _free_port()
+    mp.spawn(_blocked_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [open(str(tmp_path / ("b%d" % r))).read().split() for r in range(2)]
+    assert got[0][:2] == got[1][:2] == ["None", "2"]           # both attempts count as failed: one raised, one ran out of time
+    assert 1.5 < float(got[0][2]) < 15.0                       # rank 0 sat in the probe for its 2 s, not for the backend's minutes
+    assert got[0][3] == got[1][3] == "3"
+    assert "AttemptTimedOut" in got[0][4] and "rank_1" in got[1][4]
+
+
+def _stuck_worker(rank, world, port, out_dir):
+    """The attempt blocks somewhere that has no deadline at all (communicator creation): the outer bound of agree_on_rccl."""
+    import os
+    import threading
+    import time
+    import torch.distributed as dist
+    from pepper_amd.parallel import agree_on_rccl
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def attempt():
+        if rank == 0:
+            threading.Event().wait()          # for ever
+        return "the-group"
+    t0 = time.monotonic()
+    group, failed, why = agree_on_rccl(world, attempt, timeout_s=1.0)
+    with open(os.path.join(out_dir, "s%d" % rank), "w") as fh:
+        fh.write("%s %d %.2f" % (group, failed, time.monotonic() - t0))
+    dist.barrier()
+    os._exit(0)
+
+
+def test_an_attempt_that_never_returns_is_voted_failed(tmp_path):
+    port = _free_port()
+    mp.spawn(_stuck_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [open(str(tmp_path / ("s%d" % r))).read().split() for r in range(2)]
+    assert got[0][:2] == got[1][:2] == ["None", "1"] and float(got[0][2]) < 10.0
