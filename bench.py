@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the device-resident and batch-512 legs")
     ap.add_argument("--no-secondary", action="store_true",
                     help="variant only: skip the `secondary` block (polish, encoder and the two HDF5 -> HDF5 pipelines)")
+    ap.add_argument("--no-image-legs", action="store_true",
+                    help="N > 1: skip the per-rank image generation legs (variant generate_images and the polish chain on each rank's own "
+                         "synthetic BAM) that follow the timed model steps")
     ap.add_argument("--full-line", action="store_true",
                     help="print the whole record (tens of KB) as the stdout line instead of the compact one; the whole record is "
                          "always written to gpurun_out/bench_full.json")
@@ -1298,7 +1301,9 @@ def final_line(full, limit=LINE_LIMIT, full_record=FULL_RECORD):
     line["value"], line["ms_per_step"] = _sig(full.get("value"), 6), _sig(full.get("ms_per_step"), 6)
     line["config"] = {k: (short(cfg[k], 140) if isinstance(cfg[k], str) else cfg[k]) for k in
                       ("workload", "per_gpu_per_step", "distinct_units_per_gpu", "units", "device_pass", "h2d_d2h", "reference_hdf5_batch",
-                       "weights", "parallelism", "ranks_seen", "per_rank_seconds", "collective_backend", "per_rank_image_legs") if k in cfg}
+                       "weights", "parallelism", "ranks_seen", "per_rank_seconds", "collective_backend") if k in cfg}
+    if cfg.get("per_rank_image_legs"):
+        line["config"]["per_rank_image_legs"] = {k: v for k, v in cfg["per_rank_image_legs"].items() if k != "note"}
     roof = full.get("roofline") or {}
     line["roofline"] = {k: _sig(roof.get(k), 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                            "algorithmic_bytes_per_launch", "frac_algorithmic_of_dtype_peak",
@@ -1357,6 +1362,67 @@ def write_full_record(full, path=None):
     except OSError as e:
         sys.stderr.write("[bench] full record not written (%s)\n" % e)
         return False
+
+
+def rank_image_legs(rank, world, device):
+    """N > 1 only: every rank ALSO runs image generation -- variant generate_images and the polish chain's make_images -- on its own
+    synthetic BAM (its own shard: weak scaling, as the reference deals regions over processes, ImageGenerationUI.py:326-339) on its
+    own device, all ranks at once, with the box's usable CPUs dealt evenly over the ranks.  -> this rank's dict; rank 0 gathers
+    them.  The first 8-GPU run then measures region sharding of image generation, not only of the model."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from pepper_amd.hostinfo import usable_cpus
+    out = {"rank": rank, "device": device, "threads": max(1, usable_cpus() // world)}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    try:
+        st = os.statvfs(base)
+        if st.f_bavail * st.f_frsize < world * (3 << 30):
+            base = tempfile.gettempdir()
+    except OSError:
+        base = tempfile.gettempdir()
+    work = tempfile.mkdtemp(prefix="pepper_amd_rank%d_" % rank, dir=base)
+    barriers = 0                 # (of the two the ranks meet at: a rank whose leg failed still has to turn up at the rest)
+    try:
+        import bench_variant_images
+        from pepper_amd.polish.make_images import make_images
+        from pepper_amd.variant.ImageGenerationUI import ImageGenerationUtils
+        vdir, pdir = os.path.join(work, "v"), os.path.join(work, "p")
+        vbases = int(os.environ.get("PEPPER_AMD_BENCH_RANK_VARIANT_BASES", 16_000_000))
+        pbases = int(os.environ.get("PEPPER_AMD_BENCH_RANK_POLISH_BASES", 4_000_000))
+        bench_variant_images.make_fast(vdir, vbases, 60, 2027 + rank)
+        bench_variant_images.make_fast(pdir, pbases, 60, 3027 + rank)
+
+        def variant(tag):
+            o = bench_variant_images.options(vdir, os.path.join(vdir, tag), out["threads"], 100000, device=device)
+            ImageGenerationUtils.generate_images(o)
+            shutil.rmtree(os.path.join(vdir, tag), ignore_errors=True)
+
+        def polish(tag):
+            make_images(os.path.join(pdir, "reads.bam"), os.path.join(pdir, "draft.fa"), None, os.path.join(pdir, tag), out["threads"],
+                        device_ids=str(device))
+            shutil.rmtree(os.path.join(pdir, tag), ignore_errors=True)
+        variant("warm")
+        polish("warm")
+        import torch.distributed as dist
+        for key, fn, mb in (("make_images_mb_per_s", variant, vbases / 1e6), ("polish_make_images_mb_per_s", polish, pbases / 1e6)):
+            dist.barrier()
+            barriers += 1
+            t0 = time.perf_counter()
+            fn("timed")
+            dt = time.perf_counter() - t0
+            out[key], out[key.replace("mb_per_s", "seconds")] = round(mb / dt, 2), round(dt, 3)
+    except Exception as e:      # noqa: BLE001 -- the model line must not be lost to a failing image leg
+        out["error"] = repr(e)[:200]
+        try:                    # (the others are waiting at the barriers above)
+            import torch.distributed as dist
+            for _ in range(2 - barriers):
+                dist.barrier()
+        except Exception:       # noqa: BLE001
+            pass
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return out
 
 
 def timed_loop(fn, count, sync):
@@ -1520,6 +1586,25 @@ def main():
     prof = _lib.profile_dict(handle)
     _lib.check(lib.pa_profile_enable(handle, 0))
 
+    image_legs = None
+    if world > 1 and variant and not args.no_image_legs and not args.resident_only:
+        import torch.distributed as dist
+        mine = rank_image_legs(rank, world, device)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        image_legs = {"threads_per_rank": mine["threads"],
+                      "note": "every rank runs generate_images (variant) and make_images (polish chain) on its own synthetic BAM and its "
+                              "own device, all ranks at once; aggregate = all ranks' Mb / the slowest rank's seconds"}
+        for key, mb in (("make_images", "PEPPER_AMD_BENCH_RANK_VARIANT_BASES"), ("polish_make_images", "PEPPER_AMD_BENCH_RANK_POLISH_BASES")):
+            rates = [g.get(key + "_mb_per_s") for g in gathered]
+            secs = [g.get(key + "_seconds") for g in gathered]
+            image_legs[key + "_mb_per_s"] = rates
+            if all(r is not None for r in rates):
+                image_legs["aggregate_" + key + "_mb_per_s"] = round(sum(r * t for r, t in zip(rates, secs)) / max(secs), 2)
+        errs = [g["error"] for g in gathered if "error" in g]
+        if errs:
+            image_legs["errors"] = errs[:2]
+
     extras = {}
     if world == 1 and not args.no_extras and not args.resident_only:
         # (a) the same kernels on inputs already in HBM (round 1's figure): one device pass of `chunk` units, repeated
@@ -1587,7 +1672,7 @@ def main():
                        "weights": "seeded random init (pepper_amd.synthetic), fp32",
                        "parallelism": f"region-shard x{world}, one weight broadcast, no data-path collective",
                        "ranks_seen": ranks_seen, "per_rank_seconds": [round(x, 4) for x in per_rank_seconds],
-                       "collective_backend": COLLECTIVE_NOTE},
+                       "collective_backend": COLLECTIVE_NOTE, "per_rank_image_legs": image_legs},
             # achieved = ALGORITHMIC flops of the dominant kernel's launches / their HIP-event time; peak = the dense MFMA peak of the
             # datatype the MFMAs run in (f16: 2.5 PFLOP/s); frac = achieved / peak.  Each f32-accurate product costs three f16 MFMAs, so
             # the machine issues 3 x achieved: frac_of_dense_peak_issued says how busy the matrix cores are, frac how much useful work.

@@ -719,3 +719,63 @@ def test_polish_end_to_end_from_bam(tmp_path):
                 checked += 1
     assert checked >= 4
 
+
+
+def test_two_ranks_on_one_device_give_the_single_device_outputs(tmp_path):
+    """device_ids "0,0": what an N-GPU run does with its image workers (dealt over device_ids) and its inference callers (one
+    process per entry, predict_distributed_gpu's spawn leg; RunInference.py:101-116, ImageGenerationUI.py:326-339), on the one
+    device a test box has.  call_variant's five VCFs and polish's FASTA must be those of device_ids "0"."""
+    import glob
+    import bam_utils as bu
+    import pileup_utils as pu
+    from pepper_amd.polish.polish import polish
+    from pepper_amd.variant.CallVariant import call_variant
+    rng = np.random.default_rng(606)
+    ref = pu.random_reference(rng, 7000)
+    sites = {int(p): ("ACGT"[(("ACGT".index(ref[p]) + 1) % 4)], 0.5) for p in rng.choice(np.arange(200, 6800), 40, replace=False)}
+    indels = {900: ("I", "CA", 0.6), 2500: ("D", 2, 0.7), 5100: ("D", 9, 0.5)}
+    reads = pu.simulate_reads(rng, ref, 0, n_reads=520, read_len=(400, 1800), snp_sites=sites, indel_sites=indels)
+    reads = sorted([r for r in reads if not any(op in (3, 6) for op, _ in r["cigar"])], key=lambda r: r["pos"])
+    for i, r in enumerate(reads):
+        r["name"] = "q%d" % i
+    bam_path, fa_path = str(tmp_path / "in.bam"), str(tmp_path / "ref.fa")
+    bu.write_bam(bam_path, [("chr20", len(ref))], {0: reads}, flush_every=50)
+    with open(fa_path, "w") as fh:
+        fh.write(">chr20\n" + "\n".join(ref[i:i + 60] for i in range(0, len(ref), 60)) + "\n")
+    sd = synthetic.variant_state_dict(seed=94, gain=2.5)
+    model_path = str(tmp_path / "model.pkl")
+    torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in sd.items()}, hidden_size=128), model_path)
+
+    def options(out, device_ids):
+        return SimpleNamespace(
+            bam=bam_path, fasta=fa_path, region=None, region_size=1500, threads=4, train_mode=False,
+            use_hp_info=False, include_supplementary=False, output_dir=out,
+            min_mapq=1, min_snp_baseq=1, min_indel_baseq=1, snp_frequency=0.10, insert_frequency=0.15,
+            delete_frequency=0.15, min_coverage_threshold=3, snp_candidate_frequency_threshold=0.10,
+            indel_candidate_frequency_threshold=0.12, candidate_support_threshold=2, skip_indels=False,
+            downsample_rate=1.0,
+            model_path=model_path, batch_size=64, num_workers=0, gpu=True, device_ids=device_ids, callers_per_gpu=1,
+            quantized=False, dry=False, sample_name="SYN", allowed_multiallelics=4,
+            snp_p_value=0.1, insert_p_value=0.25, delete_p_value=0.25, snp_p_value_in_lc=0.1,
+            insert_p_value_in_lc=0.3, delete_p_value_in_lc=0.3, snp_q_cutoff=20, indel_q_cutoff=15,
+            snp_q_cutoff_in_lc=20, indel_q_cutoff_in_lc=10, report_snp_above_freq=0, report_indel_above_freq=0)
+    _, pred_one, totals_one = call_variant(options(str(tmp_path / "v_one"), "0"))
+    _, pred_two, totals_two = call_variant(options(str(tmp_path / "v_two"), "0,0"))
+    assert totals_one == totals_two and totals_one[0] > 20
+    assert sorted(os.listdir(pred_two)) == ["pepper_prediction_0.hdf", "pepper_prediction_1.hdf"]      # one file per caller
+    _assert_same_vcfs(str(tmp_path / "v_two"), str(tmp_path / "v_one"))
+
+    # polish: the same reads as a draft's pile
+    psd = synthetic.polish_state_dict(seed=19, gain=2.0)
+    pmodel = str(tmp_path / "polish.pkl")
+    torch.save(synthetic.checkpoint_dict({k: torch.from_numpy(v) for k, v in psd.items()}, hidden_size=128), pmodel)
+    texts = []
+    for name, device_ids in (("p_one", "0"), ("p_two", "0,0")):
+        out_dir = str(tmp_path / name) + "/"
+        polish(bam_path, fa_path, out_dir, 4, None, pmodel, 64, True, device_ids, 0)
+        fasta = glob.glob(out_dir + "*.fa")
+        assert len(fasta) == 1
+        texts.append(open(fasta[0]).read())
+        n_pred = len(glob.glob(out_dir + "predictions_*/*.hdf"))
+        assert n_pred == (1 if device_ids == "0" else 2), n_pred
+    assert texts[0] == texts[1] and texts[0].startswith(">chr20")
