@@ -46,6 +46,29 @@ def kernel_peak(label):
     return H2_MFMA_PEAK_TFLOPS if "_h2" in label else F32_MFMA_PEAK_TFLOPS
 
 
+def newest_profile(suffix):
+    """(path relative to the repository, round) of the committed profile profiles/rNN_<suffix> with the highest round, or (None, 0)."""
+    import glob
+    import re
+    best = (None, 0)
+    for path in glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_" + suffix)):
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        if m and int(m.group(1)) > best[1]:
+            best = (os.path.relpath(path, REPO), int(m.group(1)))
+    return best
+
+
+def counters_stale(profile_round, *sources):
+    """True when a kernel source the counters describe changed in a later round than the profile was taken in
+    (profiles/kernel_rounds.json, written from the history by tools/kernel_rounds.py -- the GPU box has no .git)."""
+    try:
+        with open(os.path.join(REPO, "profiles", "kernel_rounds.json")) as fh:
+            table = json.load(fh)["last_changed_in_round"]
+    except (OSError, KeyError, ValueError):
+        return None
+    return any(table.get(src, 0) > profile_round for src in sources)
+
+
 VARIANT_FLOP_PER_WINDOW = 2 * 80_664_064      # SURVEY.md 8(a) A8 / BASELINE.md section 2
 POLISH_FLOP_PER_WINDOW = 2 * 40_217_600       # per 100-step window (A12)
 POLISH_WINDOWS_PER_CHUNK = 19
@@ -344,10 +367,8 @@ def measured_traffic(model_kind, label):
     tools/pmc_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this file with --resident-only):
     FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16-byte-per-lane streaming reads, WRITE_SIZE as
     reported.  None where no pass is on file."""
-    for tag in ("r05", "r04", "r03", "r02"):
-        path = os.path.join(REPO, "profiles", f"{tag}_{model_kind}_pmc.json")
-        if os.path.exists(path):
-            break
+    rel, rnd = newest_profile(f"{model_kind}_pmc.json")
+    path = os.path.join(REPO, rel) if rel else ""
     try:
         with open(path) as fh:
             table = json.load(fh)
@@ -360,7 +381,8 @@ def measured_traffic(model_kind, label):
                 "mfma_busy_frac": k.get("mfma_busy_frac"),
                 "hbm_GBps_profiled": (total / (k["avg_us"] * 1e-6) / 1e9) if k.get("avg_us") else None,
                 "avg_us_profiled": k.get("avg_us"),
-                "source": os.path.relpath(path, REPO)}
+                "source": os.path.relpath(path, REPO), "round": rnd,
+                "stale": counters_stale(rnd, "rnn_h2.hip", "gemm_h2.hip", "mlp_h2.hip", "head.hip")}
     except Exception:
         return None
 
@@ -463,14 +485,18 @@ def realign_bench(args):
             "achieved": None, "frac": None, "traffic": None}
     try:
         ins = {}
-        for line in open(os.path.join(REPO, "profiles", "r05_realign_pmc.txt")):
+        src, src_round = newest_profile("realign_pmc.txt")
+        for line in open(os.path.join(REPO, src)):
             parts = line.split()
             if len(parts) >= 2 and parts[0].startswith("valu_wave_instructions_per_read"):
                 ins[parts[0]] = float(parts[1])
         per_read = ins["valu_wave_instructions_per_read_score"] + ins["valu_wave_instructions_per_read_band"]
         kernel_s = (ends + band) / args.steps * 1e-3
+        wall_s = dt / args.steps
         roof.update(achieved=per_read * n / kernel_s / 1e9, frac=per_read * n * 4.0 / (1024 * 2.4e9 * kernel_s),
-                    valu_wave_instructions_per_read=per_read, source="profiles/r05_realign_pmc.txt",
+                    frac_over="kernel time (the two kernels' HIP events)",
+                    frac_over_caller_wall=per_read * n * 4.0 / (1024 * 2.4e9 * wall_s),
+                    valu_wave_instructions_per_read=per_read, source=src, stale=counters_stale(src_round, "realign.hip"),
                     note="integer DP on the vector ALUs, neither HBM nor MFMA bound: achieved = the two kernels' vector instructions (counter "
                          "pass of this workload) over their HIP-event time; frac = the share of the chip's issue slots they fill")
     except (OSError, KeyError, ValueError):
@@ -499,14 +525,14 @@ HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md
 def encoder_traffic():
     """HBM bytes and instruction counts per launch of tile_count_kernel from the committed PMC passes (profiles/
     r04_encoder_variant_pmc.json, else r03)."""
-    path = os.path.join(REPO, "profiles", "r04_encoder_variant_pmc.json")
-    if not os.path.exists(path):
-        path = os.path.join(REPO, "profiles", "r03_encoder_variant_pmc.json")
+    rel, rnd = newest_profile("encoder_variant_pmc.json")
+    path = os.path.join(REPO, rel) if rel else ""
     try:
         with open(path) as fh:
             k = json.load(fh)["kernels"]["tile_count"]
         return {"bytes_per_launch": k["fetch_bytes_reported"] + k["write_bytes"], "fetch_bytes_reported": k["fetch_bytes_reported"],
-                "write_bytes": k["write_bytes"], "source": os.path.relpath(path, REPO),
+                "write_bytes": k["write_bytes"], "source": os.path.relpath(path, REPO), "round": rnd,
+                "stale": counters_stale(rnd, "encoder.hip", "encoder_common.h"),
                 "insts": {c: k.get(c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAIT_ANY",
                                                 "SQ_WAVE_CYCLES") if k.get(c) is not None},
                 "avg_us_profiled": k.get("avg_us"),
@@ -530,7 +556,7 @@ def encoder_issue_roof(traffic, launch_ms):
                 "lds_wave_instructions": ins.get("SQ_INSTS_LDS"), "cycles_per_valu_instruction": 4, "simd_cycles_available": simd_cycles,
                 "frac": 4.0 * valu / simd_cycles,
                 "wait_share_of_wave_cycles": (ins["SQ_WAIT_ANY"] / ins["SQ_WAVE_CYCLES"]) if ins.get("SQ_WAVE_CYCLES") else None,
-                "source": traffic["source"]}
+                "frac_over": "kernel time (tile_count_kernel's HIP events)", "source": traffic["source"], "stale": traffic.get("stale")}
     except Exception:
         return None
 
@@ -884,7 +910,7 @@ def polish_encoder_bench(args):
     print(json.dumps(line))
 
 
-def make_images_leg(scratch, level=1, tags=0, bases_default=64_000_000):
+def make_images_leg(scratch, level=1, tags=0, bases_default=64_000_000, quals=0):
     """generate_images (pepper_variant make_images / call_variant's first step) on a synthetic 64 Mb BAM at 60x written by
     tools/synth_bam: BAM + FASTA -> candidate image HDF5 files, Mb of reference per second with the stage times of the workers
     (tools/bench_variant_images.py).  Three runs over the same files, the median reported."""
@@ -902,7 +928,7 @@ def make_images_leg(scratch, level=1, tags=0, bases_default=64_000_000):
     try:
         from pepper_amd.hostinfo import usable_cpus
         threads = max(1, usable_cpus())
-        p = subprocess.run([sys.executable, tool, "make_fast", work, str(bases), "60", "2027", str(level), str(tags)], capture_output=True,
+        p = subprocess.run([sys.executable, tool, "make_fast", work, str(bases), "60", "2027", str(level), str(tags), str(quals)], capture_output=True,
                            text=True, timeout=600)
         if p.returncode != 0:
             return {"error": (p.stderr or "synth_bam failed").strip().splitlines()[-1][:300]}
@@ -965,7 +991,8 @@ def polish_make_images_leg(scratch):
         # x 4 cycles against the SIMD-cycles of the wall time
         try:
             ins = {}
-            for line in open(os.path.join(REPO, "profiles", "r05_polish_chain_pmc.txt")):
+            src, src_round = newest_profile("polish_chain_pmc.txt")
+            for line in open(os.path.join(REPO, src)):
                 parts = line.split()
                 if len(parts) >= 2 and parts[0] in ("valu_wave_instructions_per_read_score", "valu_wave_instructions_per_read_band"):
                     ins[parts[0]] = float(parts[1])
@@ -974,7 +1001,9 @@ def polish_make_images_leg(scratch):
             out["roofline"] = {"bound": "valu issue", "kernel": "sw_ends_pair_kernel + band_kernel", "unit": "G wave-instructions/s",
                                "achieved": per_read * mid["counts"]["realigned"] / mid["seconds"] / 1e9, "peak": 1024 * 2.4 / 4,
                                "frac": 4.0 * per_read * mid["counts"]["realigned"] / simd_cycles,
-                               "valu_wave_instructions_per_read": per_read, "source": "profiles/r05_polish_chain_pmc.txt"}
+                               "frac_over": "the job's wall time (all workers; what the chain could do at most is 1.0)",
+                               "valu_wave_instructions_per_read": per_read, "source": src,
+                               "stale": counters_stale(src_round, "realign.hip", "encoder_polish.hip")}
         except (OSError, KeyError, ValueError):
             pass
         return out
@@ -1085,6 +1114,9 @@ def secondary_block(args):
     lv6 = make_images_leg(scratch, level=6, tags=1, bases_default=32_000_000)
     out["make_images_level6"] = lv6 if "error" in lv6 else {k: lv6[k] for k in ("value", "unit", "seconds", "threads", "runs_mb_per_s", "data",
                                                                                   "stage_seconds_summed_over_workers", "synth_seconds")}
+    lvr = make_images_leg(scratch, level=6, tags=1, bases_default=32_000_000, quals=1)
+    out["make_images_realistic"] = lvr if "error" in lvr else {k: lvr[k] for k in ("value", "unit", "seconds", "threads", "runs_mb_per_s", "data",
+                                                                                     "stage_seconds_summed_over_workers", "synth_seconds")}
     out["polish_make_images"] = polish_make_images_leg(scratch)
     # the two top entry points as one job each (stage walls inside): 256 Mb at 30x for call_variant, 64 Mb at 60x for polish
     out["call_variant"] = e2e_leg("call_variant", scratch, 256_000_000, 30, 3, 24)
@@ -1095,48 +1127,56 @@ def secondary_block(args):
     out["polish_e2e_fused"] = e2e_leg("polish_fused", scratch, 64_000_000, 60, 2, 16)
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "8000000"], 300)
 
-    def inflate_roofline(d):
+    def inflate_roofline(d, profile="inflate_kernel_stats.txt"):
         """Two roofs of bgzf_inflate_kernel for the launch just timed: HBM (algorithmic bytes = compressed in + inflated out) and
-        vector instruction issue (SQ_INSTS_VALU of the committed PMC pass of the same workload x 4 cycles over the SIMD-cycles the
-        launch had).  The second one binds."""
-        roof = {"bound": "hbm", "kernel": "bgzf_inflate_kernel", "algorithmic_bytes_per_launch": d["compressed_bytes"] + d["inflated_bytes"],
-                "achieved": (d["compressed_bytes"] + d["inflated_bytes"]) / d["kernel_ms"] / 1e6, "peak": 8000.0, "unit": "GB/s", "traffic": None}
+        vector instruction issue (SQ_INSTS_VALU of the newest committed PMC pass of the same workload x 4 cycles over the SIMD-cycles
+        the launch had).  The second one binds.  Counters from a round before inflate.hip last changed are marked stale."""
+        roof = {"bound": "hbm", "kernel": "bgzf_inflate_kernel (inflate + the member's CRC-32 in its epilogue)",
+                "algorithmic_bytes_per_launch": d["compressed_bytes"] + d["inflated_bytes"],
+                "achieved": (d["compressed_bytes"] + d["inflated_bytes"]) / d["kernel_ms"] / 1e6, "peak": 8000.0, "unit": "GB/s", "traffic": None,
+                "frac_over": "kernel time (HIP events around the launch)"}
         roof["frac"] = roof["achieved"] / roof["peak"]
         try:
             ins = {}
-            path = os.path.join(REPO, "profiles", "r04_inflate_kernel_stats.txt")
+            src, src_round = newest_profile(profile)
+            path = os.path.join(REPO, src)
             for line in open(path):
                 parts = line.split()
                 if len(parts) >= 2 and (parts[0].startswith("SQ_") or parts[0] in ("FETCH_SIZE", "WRITE_SIZE")):
                     ins[parts[0]] = float(parts[1])
             members = next(int(line.split()[1]) for line in open(path) if line.startswith("inflate:"))
             scale = d["members"] / members                      # (the committed pass had this many members per launch)
+            stale = counters_stale(src_round, "inflate.hip")
             if "FETCH_SIZE" in ins and "WRITE_SIZE" in ins:      # KB per launch, each counter in its own pass (MI355X_MICROARCH.md)
                 roof["traffic"] = (ins["FETCH_SIZE"] + ins["WRITE_SIZE"]) * 1024.0 * scale
-                roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of profiles/r04_inflate_kernel_stats.txt: the writes are the inflated "
-                                        "bytes once; the fetches are 7x the compressed input -- every match byte is a byte-wide gather that "
-                                        "pulls a whole line, mostly of output this wavefront wrote moments ago")
+                roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
+                roof["fetch_over_compressed"] = ins["FETCH_SIZE"] * 1024.0 * scale / d["compressed_bytes"]
+                roof["traffic_note"] = ("FETCH_SIZE + WRITE_SIZE of %s: the writes are the inflated bytes once; the fetches are the "
+                                        "compressed input plus the match sources (byte-wide gathers that pull whole lines, mostly of "
+                                        "output this wavefront wrote moments ago) plus the epilogue's pass over the member for its CRC" % src)
             simd_cycles = 1024 * d["kernel_ms"] * 1e-3 * 2.4e9
             roof["issue"] = {"bound": "valu issue", "valu_wave_instructions": ins["SQ_INSTS_VALU"] * scale,
                              "salu_wave_instructions": ins["SQ_INSTS_SALU"] * scale, "lds_wave_instructions": ins["SQ_INSTS_LDS"] * scale,
                              "cycles_per_valu_instruction": 4, "simd_cycles_available": simd_cycles,
                              "frac": 4.0 * ins["SQ_INSTS_VALU"] * scale / simd_cycles,
                              "wait_share_of_wave_cycles": ins["SQ_WAIT_ANY"] / ins["SQ_WAVE_CYCLES"] if ins.get("SQ_WAVE_CYCLES") else None,
-                             "source": "profiles/r04_inflate_kernel_stats.txt"}
+                             "source": src, "stale": stale}
+            roof["stale"] = stale
         except Exception:       # noqa: BLE001
             roof["issue"] = None
         return roof
     out["bgzf_inflate"] = d if "error" in d else {
         "roofline": inflate_roofline(d),
         "value": d["device_GBps_inflated"], "unit": "GB/s of inflated bytes", "kernel": "bgzf_inflate_kernel", "kernel_ms": d["kernel_ms"],
+        "stale_counters": bool((inflate_roofline(d).get("stale"))),
         "members": d["members"], "compressed_bytes": d["compressed_bytes"], "inflated_bytes": d["inflated_bytes"],
         "cpu_zlib_one_core_GBps": d["zlib_one_core_GBps"], "identical_to_zlib": d["sample_identical"],
         "cpu_baseline": {"value": d.get("host_library_all_cores_GBps"), "unit": "GB/s of inflated bytes", "cores": d.get("host_cores"),
                          "kind": "port", "one_core": d.get("host_library_one_core_GBps"), "identical": d.get("identical_to_host_library"),
                          "sample": "all the members through pa_bgzf_inflate_host (libdeflate, htslib's inflate), one thread per usable CPU"},
         "note": "csrc/inflate.hip on the BGZF members of a synthetic 8 Mb / 60x BAM (tools/synth_bam, libdeflate level 1), inputs "
-                "resident, HIP events: one wavefront per member, 64 bit offsets decoded speculatively per step, then every member's "
-                "CRC-32 against its trailer (bgzf_crc_kernel, inside the timed region); bound by instruction "
+                "resident, HIP events: one wavefront per member, 64 bit offsets decoded speculatively per step, then the member's "
+                "CRC-32 against its trailer in the same wavefront's epilogue (one launch); bound by instruction "
                 "issue and the symbol-to-symbol dependency of DEFLATE, not by HBM (the bytes moved are compressed in + inflated out)"}
     # the members as samtools writes them: zlib level 6, NM / MD / RG aux data (longer matches, longer codes)
     d6 = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "4000000", "--level", "6", "--tags", "1"], 300)
@@ -1146,6 +1186,17 @@ def secondary_block(args):
         "identical_to_host_library": d6.get("identical_to_host_library"),
         "cpu_baseline": {"value": d6.get("host_library_all_cores_GBps"), "unit": "GB/s of inflated bytes", "cores": d6.get("host_cores"), "kind": "port"},
         "note": "the same kernels on a synthetic 4 Mb / 60x BAM written with zlib level 6 and NM / MD / RG aux data in every record"}
+    # ... and with quality strings that have run-length structure (binned plateaus, as a binning basecaller writes them): the members
+    # compress > 3 x instead of 1.5 x -- more output per consumed bit, the case a real BAM is closer to
+    dr = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "4000000", "--level", "6", "--tags", "1",
+                    "--quals", "1"], 300)
+    out["bgzf_inflate_realistic"] = dr if "error" in dr else {
+        "value": dr["device_GBps_inflated"], "unit": "GB/s of inflated bytes", "kernel_ms": dr["kernel_ms"], "members": dr["members"],
+        "compressed_bytes": dr["compressed_bytes"], "inflated_bytes": dr["inflated_bytes"],
+        "compression_ratio": round(dr["inflated_bytes"] / max(1, dr["compressed_bytes"]), 2), "identical_to_zlib": dr["sample_identical"],
+        "identical_to_host_library": dr.get("identical_to_host_library"),
+        "cpu_baseline": {"value": dr.get("host_library_all_cores_GBps"), "unit": "GB/s of inflated bytes", "cores": dr.get("host_cores"), "kind": "port"},
+        "note": "zlib level 6, NM / MD / RG aux data, run-length quality strings (tools/synth_bam quals = 1)"}
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_pipeline.py"), "--files", "16", "--windows", "524288", "--groups", "512",
                    "--workers", "0"] + extra, 600)
     out["run_inference_hdf5"] = d if "error" in d else {

@@ -113,7 +113,8 @@ int pa_encoder_stage_packed(pa_encoder* e, int32_t n_regions, const pa_packed_re
  * beneath sam_itr_next, bam_handler.cpp:341-372), and copied to host_out (NULL: not) for the host's record walk
  * (pa_bam_pack_inflated, whose data_off are offsets into exactly these bytes).  pa_encoder_stage_packed with arena = NULL then
  * takes the bytes where they are.  A malformed member fails the call (PA_ERR_INVALID, the member and the reason in
- * pa_last_error); the members' CRC32 is not verified, as in the host reader.  Timings: [10] the inflate kernel (HIP events),
+ * pa_last_error), and so does a member whose inflated bytes do not have the CRC-32 of its trailer (include/
+ * pepper_amd_io_device.h: checked when the trailer lies inside `comp`).  Timings: [10] the inflate kernel (HIP events),
  * [11] the whole call on the host clock (upload, kernel, download). */
 void* pa_encoder_host_span(pa_encoder* e, int64_t bytes);
 int pa_encoder_inflate_bgzf(pa_encoder* e, const uint8_t* comp, int64_t comp_bytes, int32_t n_blocks, const int64_t* comp_off,

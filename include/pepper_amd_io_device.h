@@ -4,12 +4,17 @@
  * sam_itr_next in /root/reference/pepper_variant/modules/cpp/bam_handler.cpp:341-372 (get_reads) and
  * /root/reference/pepper_hp/modules/src/dataio/bam_handler.cpp (the polisher's copy).  A BGZF file (SAM/BAM specification,
  * section 4.1) is a sequence of independent gzip members of at most 64 KiB of data each; one wavefront inflates one member
- * (RFC 1951: stored, fixed and dynamic blocks).  Like the host reader, the members' CRC32 is not verified; every structural
- * error of the stream fails the call (pa_last_error names the block and the reason).
+ * (RFC 1951: stored, fixed and dynamic blocks) and, as htslib's inflate_block does, checks the CRC-32 of the inflated bytes
+ * against the member's trailer.  Every structural error of the stream, and a CRC mismatch, fails the call (pa_last_error names
+ * the block and the reason).
  *
  * The caller describes the blocks: comp_off/comp_len = the raw DEFLATE bytes of block b inside `comp` (after the member's
  * header, before its CRC32/ISIZE trailer), out_off/out_len = where its ISIZE bytes go inside `out`.
  * pa_bam_read_span (include/pepper_amd_io.h) reads a stretch of a BAM file and fills exactly these tables.
+ * CRC contract: the 4 bytes at comp[comp_off[b] + comp_len[b] ..] are the member's CRC-32 (little endian) WHEN they lie inside
+ * `comp` (comp_off[b] + comp_len[b] + 4 <= comp_bytes) -- `comp` then holds whole members, as pa_bam_read_span leaves them.  A
+ * block whose DEFLATE bytes end less than 4 bytes before comp_bytes is inflated but not checked (the host reader does the same):
+ * a caller that hands over a bare DEFLATE stream puts it last, or appends its CRC-32.
  */
 #ifndef PEPPER_AMD_IO_DEVICE_H
 #define PEPPER_AMD_IO_DEVICE_H

@@ -1930,7 +1930,7 @@ int pa_encoder_inflate_bgzf(pa_encoder* e, const uint8_t* comp, int64_t comp_byt
     ENC_HIP(hipEventRecord(e->ev[10], st));
     pa::launch_bgzf_inflate(st, b.d_comp.as<uint8_t>(), reinterpret_cast<const int64_t*>(dm), reinterpret_cast<const int32_t*>(dm + nb * 16),
                             reinterpret_cast<const int64_t*>(dm + nb * 8), reinterpret_cast<const int32_t*>(dm + nb * 20),
-                            b.d_arena.as<uint8_t>(), reinterpret_cast<int32_t*>(dm + nb * 24), n_blocks);
+                            b.d_arena.as<uint8_t>(), reinterpret_cast<int32_t*>(dm + nb * 24), n_blocks, comp_bytes);
     ENC_HIP(hipGetLastError());
     ENC_HIP(hipEventRecord(e->ev[11], st));
     if (!mapped) ENC_HIP(hipMemcpyAsync(hm + nb * 24, dm + nb * 24, nb * 4, hipMemcpyDeviceToHost, st));

@@ -37,7 +37,7 @@
 //
 // Checks: over-subscribed code sets, codes without a symbol, distances beyond the produced output, output beyond the
 // block's ISIZE, a stored block's LEN/NLEN complement, input consumed beyond the block -> a non-zero status word per
-// block (the host call fails with the first one).  The member's CRC-32 is verified by bgzf_crc_kernel below (round 5).
+// block (the host call fails with the first one).  The member's CRC-32 is verified in the kernel's epilogue (wave_crc32).
 #include "../../include/pepper_amd.h"
 #include "../../include/pepper_amd_io_device.h"
 
@@ -75,6 +75,7 @@ struct Tables {
     uint16_t dist_sym[MAX_DIST];
     uint16_t cl_sym[20];
     int lit_count[16], dist_count[16], cl_count[16];
+    int lit_first[16], lit_index[16], dist_first[16], dist_index[16];     // per code length: the first canonical code, its symbol's place in *_sym
     uint8_t lens[MAX_LIT + MAX_DIST + 16];        // literal/length lengths, then the distance lengths
     uint8_t cl_lens[20];
     uint32_t ring[RING_WORDS];
@@ -192,21 +193,27 @@ PA_DEV uint32_t table_entry(TableFormat format, int sym, int len) {
 }
 
 template <TableFormat FORMAT, typename Entry>
-PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, Entry* table, int tbits) {
+PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, Entry* table, int tbits, int* first_of = nullptr,
+                        int* index_of = nullptr) {
     const int lane = threadIdx.x;
     if (lane < 16) count[lane] = 0;
     wave_order();
     for (int s = lane; s < n; s += 64) atomicAdd(&count[lens[s]], 1);
     wave_order();
     int offs[16];
-    int left = 1, total = 0;
+    int left = 1, total = 0, first = 0;
     bool ok = true;
     offs[0] = 0;
 #pragma unroll
     for (int len = 1; len < 16; ++len) {
         const int c = uni(count[len]);
         offs[len] = total;
+        if (first_of && lane == 0) {             // (what long_code() needs of the codes beyond the primary table)
+            first_of[len] = first;
+            index_of[len] = total;
+        }
         total += c;
+        first = (first + c) << 1;
         left = (left << 1) - c;
         if (left < 0) ok = false;
     }
@@ -289,14 +296,160 @@ PA_DEV int decode_canonical(uint32_t bits, const int* count, const uint16_t* sym
     return -1;
 }
 
+PA_DEV uint32_t load32(const uint8_t* p) {
+    typedef uint32_t __attribute__((aligned(1))) word_any;
+    return *reinterpret_cast<const word_any*>(p);
+}
+
+// ---- CRC-32 of every inflated member against its trailer --------------------------------------------------------------
+// htslib's inflate_block compares crc32() of the inflated block with the member's trailer and fails the read on a mismatch
+// (bgzf.c, under sam_itr_next: bam_handler.cpp:341-372); without it a flipped literal in the file is a silently different
+// base.  Round 5 did this in a second kernel (one wavefront per member, lane l on its own 1 KiB slice): a pass of its own over
+// bytes the inflate wavefront had just written, every load instruction touching 64 different cache lines -- +12 % on the leg at
+// 0.04 of HBM.  Now the wavefront that inflated the member checks it in its epilogue, in the LDS its Huffman tables no longer
+// need, with COALESCED loads: the member's 4-byte words are dealt round robin from the END (lane l: the words that end 4 (l +
+// 64 k) bytes before the member's end), so one load instruction reads 256 contiguous bytes.  A lane's words are 256 bytes
+// apart; between two of them its CRC state is advanced over the 252 bytes that belong to the other lanes -- which is linear in
+// the state, so "absorb a word, then advance 256 bytes" is ONE slice-by-4 style lookup in four tables built for a 256-byte
+// advance instead of a 4-byte one (IEEE 802.3 polynomial, reflected: 0xEDB88320; advancing a state over n zero bytes is a
+// multiplication by x^(8n) mod P, zlib's crc32_combine restated).  The lane's last word ends 4 l bytes before the end: one
+// multiplication by the constant x^(32 l) brings every lane's state to the member's end, where the 64 states are XORed.  The
+// initial state 0xFFFFFFFF and the (len mod 4) head bytes go to the lane that owns the first word.  ~6 k vector instructions
+// per member beside the inflate's ~700 k, no second launch, no second pass over HBM.
+constexpr uint32_t CRC_POLY = 0xEDB88320u;
+constexpr uint32_t crc_multmodp(uint32_t a, uint32_t b) {       // a * b mod P, bit 31 = x^0
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ CRC_POLY : b >> 1;
+    }
+    return p;
+}
+constexpr uint32_t crc_x2nmodp(uint64_t n, unsigned k) {          // x^(n * 2^k) mod P
+    uint32_t table = 1u << 30;                                    // x^1
+    for (unsigned i = 0; i < k; ++i) table = crc_multmodp(table, table);
+    uint32_t p = 1u << 31;                                        // x^0
+    while (n) {
+        if (n & 1) p = crc_multmodp(table, p);
+        n >>= 1;
+        table = crc_multmodp(table, table);
+    }
+    return p;
+}
+static_assert(crc_x2nmodp(0, 3) == 0x80000000u && crc_multmodp(0x80000000u, 0x12345678u) == 0x12345678u, "x^0 is the identity");
+
+constexpr int CRC_STRIDE = 256;                  // bytes between two words of one lane (64 lanes x 4 bytes)
+struct CrcConsts {
+    uint32_t bit[4][8];                          // bit[b][j] = x^(8 (CRC_STRIDE - b)) * (the state with only bit 7 - j of its low byte set)
+    uint32_t lane_shift[64];                     // x^(32 l): a state advanced over 4 l zero bytes
+};
+constexpr CrcConsts crc_consts() {
+    CrcConsts c{};
+    for (int b = 0; b < 4; ++b)
+        for (int j = 0; j < 8; ++j) c.bit[b][j] = crc_multmodp(crc_x2nmodp((uint64_t)(CRC_STRIDE - b), 3), 0x80u >> j);
+    for (int l = 0; l < 64; ++l) c.lane_shift[l] = crc_x2nmodp((uint64_t)(4 * l), 3);
+    return c;
+}
+__constant__ const CrcConsts CRC_CONSTS = crc_consts();
+
+struct CrcTables {
+    uint32_t adv[4][256];                        // adv[b][v]: the state v << 8 b advanced over CRC_STRIDE bytes
+    uint32_t one[256];                           // the state v advanced over one byte (the ordinary CRC-32 table)
+};
+
+__device__ __forceinline__ uint32_t crc_multmodp_dev(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+        p ^= (a & (0x80000000u >> i)) ? b : 0u;
+        b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);
+    }
+    return p;
+}
+
+// CRC-32 of data[0 .. len) by the calling wavefront (all 64 lanes call; the result is uniform).  `T` is LDS the wavefront
+// owns; its own earlier stores to `data` are complete (the caller waits for them).
+__device__ __forceinline__ uint32_t wave_crc32(const uint8_t* __restrict__ data, int len, CrcTables& T) {
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = (uint32_t)i;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+        T.one[i] = c;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            uint32_t e = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e ^= (i & (0x80 >> j)) ? CRC_CONSTS.bit[b][j] : 0u;
+            T.adv[b][i] = e;
+        }
+    }
+    wave_order();
+    const int nw = len >> 2, hb = len & 3;
+    const int owner = nw > 0 ? (nw - 1) & 63 : 0;            // the lane whose first word is the member's first whole word
+    uint32_t c = 0;
+    if (lane == owner) {
+        c = 0xFFFFFFFFu;
+        for (int i = 0; i < hb; ++i) c = T.one[(c ^ data[i]) & 0xffu] ^ (c >> 8);
+    }
+    if (lane < nw) {
+        const uint8_t* last = data + len - 4 * (lane + 1);      // this lane's last word; its k-th from the end lies CRC_STRIDE k in front
+        int k = (nw - 1 - lane) >> 6;
+        auto absorb = [&](uint32_t w) {
+            c ^= w;
+            c = T.adv[0][c & 0xffu] ^ T.adv[1][(c >> 8) & 0xffu] ^ T.adv[2][(c >> 16) & 0xffu] ^ T.adv[3][c >> 24];
+        };
+        for (; k >= 4; k -= 4) {                                 // four loads in flight in front of the dependent lookups
+            const uint32_t w0 = load32(last - (size_t)CRC_STRIDE * k), w1 = load32(last - (size_t)CRC_STRIDE * (k - 1));
+            const uint32_t w2 = load32(last - (size_t)CRC_STRIDE * (k - 2)), w3 = load32(last - (size_t)CRC_STRIDE * (k - 3));
+            absorb(w0);
+            absorb(w1);
+            absorb(w2);
+            absorb(w3);
+        }
+        for (; k >= 1; --k) absorb(load32(last - (size_t)CRC_STRIDE * k));
+        c ^= load32(last);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c = T.one[c & 0xffu] ^ (c >> 8);
+        c = crc_multmodp_dev(CRC_CONSTS.lane_shift[lane], c);   // over the 4 l bytes of the lanes behind this one
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c ^= (uint32_t)__shfl_xor((int)c, o, 64);
+    return c ^ 0xFFFFFFFFu;
+}
+
+// A code LONGER than the primary table, from uniform bits, all candidate lengths at once: lane j asks whether the first
+// min_len + j bits are a code of that length (canonical codes of length L are the L-bit values first[L] .. first[L] + count[L]
+// - 1; a smaller value continues a shorter code) -- the shortest length that says yes is the code.  Two LDS round trips instead
+// of decode_canonical's one per bit.  -> the symbol, *used = its length; -1: the bits are no code of the set.
+PA_DEV int long_code(uint32_t bits, const int* count, const uint16_t* syms, const int* first_of, const int* index_of, int min_len,
+                     int* used) {
+    const int j = threadIdx.x, L = min(min_len + j, 15);
+    const int code = (int)(__builtin_bitreverse32(bits) >> (32 - L));
+    const int rel = code - first_of[L];
+    const bool hit = j < 16 - min_len && (unsigned)rel < (unsigned)count[L];
+    const unsigned long long mask = __ballot(hit);
+    if (!mask) { *used = 0; return -1; }
+    const int w = __builtin_ctzll(mask);
+    const int sym = hit ? (int)syms[index_of[L] + rel] : 0;
+    *used = min_len + w;
+    return __builtin_amdgcn_readlane(sym, w);
+}
+
 // what a lane found at its bit offset: the symbol's total bits (code, extra bits, for a match also the distance's) | flags
 constexpr int F_MATCH = 64, F_END = 128, F_INVALID = 256;
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
                                                          const int32_t* __restrict__ comp_len, const int64_t* __restrict__ out_off,
                                                          const int32_t* __restrict__ out_len, uint8_t* out_base,
-                                                         int32_t* __restrict__ status, unsigned long long* dbg) {
-    __shared__ Tables T;
+                                                         int32_t* __restrict__ status, unsigned long long* dbg,
+                                                         int64_t comp_bytes) {
+    __shared__ union Lds { Tables t; CrcTables crc; } lds;      // (the CRC tables take the Huffman tables' place in the epilogue)
+    Tables& T = lds.t;
     int n_steps = 0, n_match = 0, n_fallback = 0, n_blocks_in = 0;      // statistics for PA_INFLATE_DEBUG
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
@@ -428,8 +581,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             for (int s = hlit + lane; s < 288; s += 64) T.lens[s] = 0;
         }
         wave_order();
-        if (!build_table<LITLEN>(T.lens, 288, T.lit_count, T.lit_sym, T.lit_table, LIT_BITS) ||
-            !build_table<DIST>(T.lens + 288, 32, T.dist_count, T.dist_sym, T.dist_table, DIST_BITS)) {
+        if (!build_table<LITLEN>(T.lens, 288, T.lit_count, T.lit_sym, T.lit_table, LIT_BITS, T.lit_first, T.lit_index) ||
+            !build_table<DIST>(T.lens + 288, 32, T.dist_count, T.dist_sym, T.dist_table, DIST_BITS, T.dist_first, T.dist_index)) {
             err = INF_OVERSUBSCRIBED;
             break;
         }
@@ -454,31 +607,72 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const int info_m = de == 0u ? F_INVALID : total_m;
             const int info_l = eb == 7 ? (len | F_END) : info_m;
             const int info_e = (e & 128u) ? info_l : len;
-            const int info = e == 0u ? F_INVALID : info_e;
+            int info = e == 0u ? F_INVALID : info_e;
             const int xlen = (int)__builtin_amdgcn_ubfe(lo, (uint32_t)len, (uint32_t)eb);
-            const int val = (e & 128u) ? (int)(e >> 8) + 3 + xlen : (int)(e >> 8);
-            const int dist = (int)(de >> 8) + (int)__builtin_amdgcn_ubfe(behind, (uint32_t)dlen, (uint32_t)deb);
+            int val = (e & 128u) ? (int)(e >> 8) + 3 + xlen : (int)(e >> 8);
+            int dist = (int)(de >> 8) + (int)__builtin_amdgcn_ubfe(behind, (uint32_t)dlen, (uint32_t)deb);
             // (eight scalar instructions per symbol, written out: the scalar unit is shared by the CU's four SIMDs and is the
             // unit this kernel keeps busiest -- the compiler's version of the loop took fourteen)
-            unsigned long long chain;
-            int k, f, stop = 0;
-            asm volatile("s_mov_b64 %[chain], 0\n\t"
-                         "s_mov_b32 %[k], 0\n"
-                         "1:\n\t"
-                         "v_readlane_b32 %[f], %[info], %[k]\n\t"
-                         "s_cmpk_gt_i32 %[f], 0x7f\n\t"
-                         "s_cbranch_scc1 2f\n\t"
-                         "s_bitset1_b64 %[chain], %[k]\n\t"
-                         "s_and_b32 %[f], %[f], 63\n\t"
-                         "s_add_i32 %[k], %[k], %[f]\n\t"
-                         "s_cmpk_lt_i32 %[k], 64\n\t"
-                         "s_cbranch_scc1 1b\n\t"
-                         "s_mov_b32 %[f], 0\n"
-                         "2:\n\t"
-                         : [chain] "=&s"(chain), [k] "=&s"(k), [f] "=&s"(f)
-                         : [info] "v"(info)
-                         : "scc");
-            if (k < 64) {                                   // the end-of-block code, or something the lanes could not decode
+            unsigned long long chain = 0;
+            int k = 0, f, stop = 0;
+            for (;;) {
+                asm volatile("1:\n\t"
+                             "v_readlane_b32 %[f], %[info], %[k]\n\t"
+                             "s_cmpk_gt_i32 %[f], 0x7f\n\t"
+                             "s_cbranch_scc1 2f\n\t"
+                             "s_bitset1_b64 %[chain], %[k]\n\t"
+                             "s_and_b32 %[f], %[f], 63\n\t"
+                             "s_add_i32 %[k], %[k], %[f]\n\t"
+                             "s_cmpk_lt_i32 %[k], 64\n\t"
+                             "s_cbranch_scc1 1b\n\t"
+                             "s_mov_b32 %[f], 0\n"
+                             "2:\n\t"
+                             : [chain] "+s"(chain), [k] "+s"(k), [f] "=&s"(f)
+                             : [info] "v"(info)
+                             : "scc");
+                if (k >= 64 || !(f & F_INVALID)) break;
+                // Offset k starts a symbol the lanes could not look up: a code longer than a primary table (7.7 % of the steps of a
+                // level-6 member; they used to end the step and take a bit-by-bit path).  Worked out here from the lane's own 64
+                // bits, written back into lane k, and the walk goes on from k.
+                ++n_fallback;
+                const uint32_t lo_k = (uint32_t)__builtin_amdgcn_readlane((int)lo, k), hi_k = (uint32_t)__builtin_amdgcn_readlane((int)hi, k);
+                uint32_t e_k = (uint32_t)uni((int)T.lit_table[lo_k & ((1u << LIT_BITS) - 1u)]);
+                if (e_k == 0u) {
+                    int used;
+                    const int sym = long_code(lo_k, T.lit_count, T.lit_sym, T.lit_first, T.lit_index, LIT_BITS + 1, &used);
+                    if (sym < 0) break;
+                    e_k = table_entry(LITLEN, sym, used);
+                    if (e_k == 0u) break;                              // (symbols 286 / 287: the per-symbol path names the error)
+                }
+                const int len_k = (int)(e_k & 15u), eb_k = (int)((e_k >> 4) & 7u);
+                int info_k, val_k, dist_k = 0;
+                if (!(e_k & 128u)) {
+                    info_k = len_k;
+                    val_k = (int)(e_k >> 8);
+                } else if (eb_k == 7) {
+                    info_k = len_k | F_END;
+                    val_k = 0;
+                } else {
+                    const uint32_t behind_k = __builtin_amdgcn_alignbit(hi_k, lo_k, (uint32_t)(len_k + eb_k));
+                    uint32_t de_k = (uint32_t)uni((int)T.dist_table[behind_k & ((1u << DIST_BITS) - 1u)]);
+                    if (de_k == 0u) {
+                        int used;
+                        const int ds = long_code(behind_k, T.dist_count, T.dist_sym, T.dist_first, T.dist_index, DIST_BITS + 1, &used);
+                        if (ds < 0) break;
+                        de_k = table_entry(DIST, ds, used);
+                        if (de_k == 0u) break;                         // (distance symbols 30 / 31)
+                    }
+                    const int dlen_k = (int)(de_k & 15u), deb_k = (int)((de_k >> 4) & 15u);
+                    info_k = (len_k + eb_k + dlen_k + deb_k) | F_MATCH;
+                    val_k = (int)(e_k >> 8) + 3 + (int)__builtin_amdgcn_ubfe(lo_k, (uint32_t)len_k, (uint32_t)eb_k);
+                    dist_k = (int)(de_k >> 8) + (int)__builtin_amdgcn_ubfe(behind_k, (uint32_t)dlen_k, (uint32_t)deb_k);
+                }
+                const bool here = lane == k;
+                info = here ? info_k : info;
+                val = here ? val_k : val;
+                dist = here ? dist_k : dist;
+            }
+            if (k < 64) {                                   // the end-of-block code, or something that is no code of the block's set
                 if (f & F_END) { chain |= 1ull << k; k += f & 63; stop = 1; }
                 else stop = 2;
             }
@@ -563,8 +757,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             if (stop == 1) more = false;
             else if (stop == 2) {
                 complete();
-                // a code longer than the primary table (or no code at all) at p: this one symbol from uniform bits
-                ++n_fallback;
+                // bits the walk could not resolve (no code of the set, an invalid symbol): this one symbol from uniform bits, which names
+                // the error
                 const uint64_t v = in.peek();
                 int used;
                 int s = decode_canonical((uint32_t)v, T.lit_count, T.lit_sym, &used);
@@ -614,6 +808,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     complete();
     if (!err && pos != olen) err = INF_OUTPUT;
     if (!err && in.p > (mis + clen) * 8) err = INF_INPUT;
+    // The member's CRC-32 against its trailer (the 4 bytes behind its DEFLATE bytes), by the wavefront that wrote it: as the host
+    // reader, a span that ends before the trailer is not checked (a caller that hands over bare DEFLATE streams).
+    // (the member's place in `comp` is read again here rather than kept in scalar registers through the symbol loop)
+    const int64_t trailer = *const_cast<const volatile int64_t*>(&comp_off[blk]) + *const_cast<const volatile int32_t*>(&comp_len[blk]);
+    if (!err && trailer + 4 <= comp_bytes) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): this wavefront's stores of the member have been taken by the memory system
+        wave_order();
+        const uint32_t crc = wave_crc32(out, olen, lds.crc);
+        const uint8_t* t = comp + trailer;
+        const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (crc != want) err = INF_CRC;
+    }
     if (lane == 0) status[blk] = err;
     if (dbg && lane == 0) {
         atomicAdd(&dbg[0], (unsigned long long)n_steps);
@@ -630,11 +836,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 // 4-byte load per record, the 32-byte core read beside it), then one wavefront per record sums the reference bases of its
 // operations.  What leaves the device is 40 bytes per record instead of the span.
 struct RecHdr { int64_t data_off; int32_t ref_id, pos, l_seq, n_cigar, flags, ref_len, state, block_size; };   // = pa_record_header
-
-PA_DEV uint32_t load32(const uint8_t* p) {
-    typedef uint32_t __attribute__((aligned(1))) word_any;
-    return *reinterpret_cast<const word_any*>(p);
-}
 
 // flags[0]: 1 a lane ran out of slots, 2 a record shorter than its core, 8 a lane's walk overshot the next entry (the entries
 // are not record starts);  flags[1]: 1 the span ends inside a record
@@ -742,117 +943,13 @@ void launch_record_walk(hipStream_t stream, const uint8_t* data, int64_t data_by
                        static_cast<const RecHdr*>(slots), counts, base, cap, n_entries, static_cast<RecHdr*>(out), (long long)out_cap);
 }
 
-// ---- CRC-32 of every inflated member against its trailer --------------------------------------------------------------
-// htslib's inflate_block compares crc32() of the inflated block with the member's trailer and fails the read on a mismatch
-// (bgzf.c, under sam_itr_next: bam_handler.cpp:341-372); without it a flipped literal in the file is a silently different
-// base.  One wavefront per member, after the inflate kernel: lane l takes the 1 KiB slice that ENDS 1 024 l bytes before
-// the member's end (slices aligned to the end: only the left-most one is short) through a slice-by-4 table built in LDS
-// (the IEEE 802.3 polynomial, reflected: 0xEDB88320), then the 64 slice CRCs are folded pairwise,
-//   crc(A || B) = crc(A) * x^(8 |B|) mod P  xor  crc(B)        (zlib's crc32_combine: multmodp / x2nmodp of crc32.c, restated)
-// where |B| is a whole number of slices at every level, so the six factors x^(8 * 1024 * 2^j) mod P are compile-time
-// constants.  ~4 k vector instructions per member beside the inflate kernel's ~700 k.
-namespace {
-
-constexpr uint32_t CRC_POLY = 0xEDB88320u;
-constexpr uint32_t crc_multmodp(uint32_t a, uint32_t b) {       // a * b mod P, bit 31 = x^0
-    uint32_t m = 1u << 31, p = 0;
-    for (;;) {
-        if (a & m) {
-            p ^= b;
-            if ((a & (m - 1)) == 0) break;
-        }
-        m >>= 1;
-        b = (b & 1) ? (b >> 1) ^ CRC_POLY : b >> 1;
-    }
-    return p;
-}
-constexpr uint32_t crc_x2nmodp(uint64_t n, unsigned k) {          // x^(n * 2^k) mod P
-    uint32_t table = 1u << 30;                                    // x^1
-    for (unsigned i = 0; i < k; ++i) table = crc_multmodp(table, table);
-    uint32_t p = 1u << 31;                                        // x^0
-    while (n) {
-        if (n & 1) p = crc_multmodp(table, p);
-        n >>= 1;
-        table = crc_multmodp(table, table);
-    }
-    return p;
-}
-constexpr int CRC_SLICE = 1024;
-struct CrcShift { uint32_t k[6]; };
-constexpr CrcShift crc_shifts() {
-    CrcShift s{};
-    for (int j = 0; j < 6; ++j) s.k[j] = crc_x2nmodp((uint64_t)CRC_SLICE << j, 3);      // x^(8 * 1024 * 2^j)
-    return s;
-}
-static_assert(crc_x2nmodp(0, 3) == 0x80000000u && crc_multmodp(0x80000000u, 0x12345678u) == 0x12345678u, "x^0 is the identity");
-
-__device__ __forceinline__ uint32_t crc_multmodp_dev(uint32_t a, uint32_t b) {
-    uint32_t p = 0;
-#pragma unroll 4
-    for (int i = 0; i < 32; ++i) {
-        p ^= (a & (0x80000000u >> i)) ? b : 0u;
-        b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);
-    }
-    return p;
-}
-
-__global__ __launch_bounds__(64) void bgzf_crc_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
-                                                      const int32_t* __restrict__ comp_len, const int64_t* __restrict__ out_off,
-                                                      const int32_t* __restrict__ out_len, const uint8_t* __restrict__ out,
-                                                      int32_t* __restrict__ status, CrcShift shifts) {
-    __shared__ uint32_t T[4][256];
-    const int blk = blockIdx.x, lane = threadIdx.x;
-    if (status[blk] != 0) return;                         // (the inflate kernel refused the member already)
-    for (int i = lane; i < 256; i += 64) {
-        uint32_t c = (uint32_t)i;
-        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
-        T[0][i] = c;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the wavefront's LDS writes are in order; this is for the compiler
-    asm volatile("" ::: "memory");
-    for (int t = 1; t < 4; ++t) {
-        for (int i = lane; i < 256; i += 64) { const uint32_t c = T[t - 1][i]; T[t][i] = (c >> 8) ^ T[0][c & 0xffu]; }
-        asm volatile("" ::: "memory");
-    }
-    const int len = out_len[blk];
-    const uint8_t* data = out + out_off[blk];
-    const int hi = len - CRC_SLICE * lane, lo = hi - CRC_SLICE > 0 ? hi - CRC_SLICE : 0;
-    uint32_t crc = 0;                                     // (the CRC-32 of no bytes)
-    if (hi > 0) {
-        uint32_t c = 0xFFFFFFFFu;
-        int i = lo;
-        for (; i < hi && ((size_t)(data + i) & 3u); ++i) c = T[0][(c ^ data[i]) & 0xffu] ^ (c >> 8);
-        for (; i + 4 <= hi; i += 4) {
-            c ^= *reinterpret_cast<const uint32_t*>(data + i);
-            c = T[3][c & 0xffu] ^ T[2][(c >> 8) & 0xffu] ^ T[1][(c >> 16) & 0xffu] ^ T[0][c >> 24];
-        }
-        for (; i < hi; ++i) c = T[0][(c ^ data[i]) & 0xffu] ^ (c >> 8);
-        crc = c ^ 0xFFFFFFFFu;
-    }
-    // lane l + 2^j holds the bytes in front of lane l's: fold towards lane 0
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const uint32_t left = (uint32_t)__shfl_down((int)crc, 1 << j, 64);
-        if ((lane & ((2 << j) - 1)) == 0) crc = crc_multmodp_dev(shifts.k[j], left) ^ crc;
-    }
-    if (lane == 0) {
-        const uint8_t* t = comp + comp_off[blk] + comp_len[blk];
-        const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-        if (crc != want) status[blk] = INF_CRC;
-    }
-}
-
-}  // namespace
-
 void launch_bgzf_inflate(hipStream_t stream, const uint8_t* comp, const int64_t* comp_off, const int32_t* comp_len,
                          const int64_t* out_off, const int32_t* out_len, uint8_t* out, int32_t* status, int n_blocks,
-                         unsigned long long* debug_counts) {
+                         int64_t comp_bytes, unsigned long long* debug_counts) {
     if (n_blocks <= 0) return;
+    // (one launch: inflate, then every member's CRC-32 against its trailer in the same wavefront's epilogue)
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
-                       status, debug_counts);
-    // every member's CRC-32 against its trailer (the 4 bytes behind its DEFLATE bytes: `comp` holds whole members)
-    constexpr CrcShift shifts = crc_shifts();
-    hipLaunchKernelGGL(bgzf_crc_kernel, dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out, status, shifts);
+                       status, debug_counts, comp_bytes);
 }
 
 const char* inflate_status_text(int32_t s) {
@@ -982,7 +1079,7 @@ int pa_inflater_inflate(pa_inflater* h, const uint8_t* comp, int64_t comp_bytes,
     INF_HIP(hipEventRecord(h->ev[0], h->stream));
     for (int r = 0; r < reps; ++r)
         pa::launch_bgzf_inflate(h->stream, static_cast<const uint8_t*>(h->d_comp), d_coff, d_clen, d_ooff, d_olen,
-                                static_cast<uint8_t*>(h->d_out), d_status, n_blocks, r == 0 ? d_dbg : nullptr);
+                                static_cast<uint8_t*>(h->d_out), d_status, n_blocks, comp_bytes, r == 0 ? d_dbg : nullptr);
     INF_HIP(hipGetLastError());
     INF_HIP(hipEventRecord(h->ev[1], h->stream));
     std::vector<int32_t> status(nb);

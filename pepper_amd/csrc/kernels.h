@@ -129,10 +129,12 @@ hipError_t launch_polish_finalize(const float* acc, uint8_t* labels, uint8_t* ph
                                   int C, int overlap, hipStream_t stream);
 
 // inflate.hip: one wavefront per BGZF block (tables of block b: comp_off/comp_len = its raw DEFLATE bytes in `comp`,
-// out_off/out_len = where its ISIZE bytes go in `out`); status[b] != 0 names the block's error (inflate_status_text)
+// out_off/out_len = where its ISIZE bytes go in `out`); status[b] != 0 names the block's error (inflate_status_text).
+// comp_bytes = the size of `comp`: a block whose 4-byte CRC-32 trailer (behind its DEFLATE bytes) lies inside it has its
+// inflated bytes checked against it by the same wavefront; one whose span ends at comp_bytes is not checked
 void launch_bgzf_inflate(hipStream_t stream, const uint8_t* comp, const int64_t* comp_off, const int32_t* comp_len,
                          const int64_t* out_off, const int32_t* out_len, uint8_t* out, int32_t* status, int n_blocks,
-                         unsigned long long* debug_counts = nullptr);
+                         int64_t comp_bytes, unsigned long long* debug_counts = nullptr);
 const char* inflate_status_text(int32_t s);
 // the BAM records of an inflated span (inflate.hip): entries = record starts (ascending; a lane follows the records from each
 // up to the next), slots [n_entries][cap] and out [<= n_entries * cap] of 40-byte pa_record_header, counts [n_entries],

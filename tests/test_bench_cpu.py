@@ -25,7 +25,9 @@ def test_help_and_contract_flags():
 def test_traffic_comes_from_the_committed_pmc_passes():
     b = _bench()
     t = b.measured_traffic("variant", "lstm_dec_h2_fused")
-    assert t is not None and t["source"] == os.path.join("profiles", "r05_variant_pmc.json")      # this round's passes
+    newest = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_variant_pmc.json"))[-1]
+    assert t is not None and t["source"] == os.path.join("profiles", newest) and t["round"] == int(newest[1:3])      # the newest passes
+    assert t["stale"] in (False, True)        # (True: a model kernel's source changed after the passes were taken)
     assert 0.5 < t["mfma_busy_frac"] < 1.0 and 100 < t["hbm_GBps_profiled"] < 8000               # the counters north_star names
     table = json.load(open(os.path.join(REPO, t["source"])))["kernels"]["lstm_dec_h2_fused"]
     assert t["bytes_per_launch"] == table["fetch_bytes_corrected"] + table["write_bytes"]
@@ -34,7 +36,8 @@ def test_traffic_comes_from_the_committed_pmc_passes():
     assert 0.95 * algorithmic < t["bytes_per_launch"] < 1.10 * algorithmic
     assert b.measured_traffic("variant", "no_such_kernel") is None
     e = b.encoder_traffic()                                  # the encoder line's traffic: this round's tile_count_kernel passes
-    assert e is not None and e["source"] == os.path.join("profiles", "r04_encoder_variant_pmc.json") and e["bytes_per_launch"] > 1e9
+    newest = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_encoder_variant_pmc.json"))[-1]
+    assert e is not None and e["source"] == os.path.join("profiles", newest) and e["bytes_per_launch"] > 1e9
     issue = b.encoder_issue_roof(e, e["avg_us_profiled"] * 1e-3)      # the roof that binds the encoder's kernel: instruction issue
     assert issue is not None and 0.3 < issue["frac"] < 1.0 and issue["valu_wave_instructions"] > 1e8
     for label in ("lstm_rec_h2_fused_in", "lstm_dec_h2_fused", "gemm_h2_linear_1", "gru_dec_h2_fused_dense", "gru_rec_h2_fused_in"):
@@ -121,3 +124,16 @@ def test_vs_baseline_is_null_without_a_published_number():
     src = open(os.path.join(REPO, "bench.py")).read()
     assert 'line["vs_baseline"] =' not in src and '"vs_baseline": None' in src
     assert json.load(open(os.path.join(REPO, "BASELINE.json")))["published"] == {}
+
+
+def test_counters_know_when_they_are_older_than_the_kernel():
+    """profiles/kernel_rounds.json (tools/kernel_rounds.py, from the history) says in which round each kernel source last changed;
+    counters_stale compares a profile's round with it -- the line marks a leg whose counters describe an earlier kernel."""
+    b = _bench()
+    table = json.load(open(os.path.join(REPO, "profiles", "kernel_rounds.json")))
+    assert table["current_round"] >= 6 and set(table["last_changed_in_round"]) >= {"inflate.hip", "realign.hip", "rnn_h2.hip", "encoder.hip"}
+    r = table["last_changed_in_round"]["inflate.hip"]
+    assert b.counters_stale(r - 1, "inflate.hip") is True and b.counters_stale(r, "inflate.hip") is False
+    assert b.counters_stale(99, "inflate.hip", "realign.hip") is False
+    path, rnd = b.newest_profile("variant_pmc.json")
+    assert path.startswith("profiles/r") and rnd >= 5 and b.newest_profile("no_such_profile.txt") == (None, 0)

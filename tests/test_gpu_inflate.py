@@ -121,6 +121,70 @@ def test_matches_that_read_what_was_just_written_under_load():
             assert inf.inflate(buf, table).tobytes() == want
 
 
+def _long_code_payloads(rng):
+    """Data whose Huffman codes run past the primary tables (10 bits literal/length, 8 bits distance): a geometric distribution
+    over 220 byte values (the rare ones get 11- to 15-bit codes), and fragments copied from a skewed choice of distances (most
+    near, a few far: the far distance symbols get 9- to 15-bit codes)."""
+    p = 0.93 ** np.arange(220)
+    skew = rng.choice(np.arange(220), 60000, p=p / p.sum()).astype(np.uint8)
+    yield bytes(skew), zlib.Z_HUFFMAN_ONLY
+    yield bytes(skew), zlib.Z_DEFAULT_STRATEGY
+    data = bytearray(rng.choice(np.arange(220), 20000, p=p / p.sum()).astype(np.uint8).tobytes())
+    while len(data) < 64000:
+        far = rng.random() < 0.03
+        dist = int(rng.integers(3000, min(len(data), 32000))) if far else int(rng.integers(4, 200))
+        n = int(rng.integers(3, 40))
+        at = len(data) - dist
+        data += data[at:at + n]
+        data += bytes(rng.choice(np.arange(220), int(rng.integers(0, 6)), p=p / p.sum()).astype(np.uint8))
+    yield bytes(data[:65000]), zlib.Z_DEFAULT_STRATEGY
+
+
+@pytest.mark.gpu
+def test_codes_longer_than_the_primary_tables():
+    """Symbols whose codes leave the primary tables are resolved inside the step (long_code in csrc/inflate.hip: all candidate
+    lengths at once) -- literals, lengths, the end-of-block code and distances; 600 members in one launch, levels 1 / 6 / 9,
+    bit-exact against zlib.  The kernel's own count of such symbols (PA_INFLATE_DEBUG) says the inputs do what they are for."""
+    rng = np.random.default_rng(14)
+    members, expect = [], []
+    for rep in range(200):
+        for data, strategy in _long_code_payloads(rng):
+            cut = int(rng.integers(1000, len(data)))
+            members.append(member(data[:cut], (1, 6, 9)[rep % 3], strategy, flush_at=(cut // 2,) if rep % 5 == 0 else ()))
+            expect.append(data[:cut])
+    inflate_and_compare(members, expect)
+    # the count, from a child process with the diagnostic switched on (it prints to stderr)
+    code = ("import sys, zlib, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_inflate as t; "
+            "rng = np.random.default_rng(14); ms = [t.member(d, 6, s) for d, s in t._long_code_payloads(rng)]; "
+            "buf = b''.join(ms); inf = t.DeviceInflater(); inf.inflate(buf, t.block_table(buf))" % (ROOT, os.path.join(ROOT, "tests")))
+    p = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PA_INFLATE_DEBUG="1"))
+    assert p.returncode == 0, p.stderr
+    line = [ln for ln in p.stderr.splitlines() if "long-code symbols" in ln][-1]
+    assert int(line.split(" matches, ")[1].split()[0]) > 1000, line
+
+
+@pytest.mark.gpu
+def test_crc_of_members_of_every_size_class():
+    """The epilogue's CRC deals a member's words over the lanes from its END, 256 bytes apart per lane: lengths around the
+    multiples of 4 (head bytes), of 256 (a lane's first word) and tiny members, at output offsets of every alignment -- each
+    passes with its true trailer and fails with a flipped one."""
+    rng = np.random.default_rng(15)
+    sizes = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 63, 64, 65, 252, 253, 254, 255, 256, 257, 258, 259, 260, 261, 511, 512, 513, 515,
+             1020, 1021, 1022, 1023, 1024, 1025, 1026, 1027, 16383, 16385, 65277, 65278, 65279, 65280]
+    datas = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in sizes]
+    with DeviceInflater() as inf:
+        for level in (0, 6):
+            members = [member(d, level) for d in datas]
+            buf = b"".join(members)
+            assert inf.inflate(buf, block_table(buf)).tobytes() == b"".join(datas)
+            for k in range(len(members)):
+                bad = bytearray(members[k])
+                bad[-5] ^= 0x40                                 # the trailer's CRC-32, highest byte
+                buf = b"".join(members[:k] + [bytes(bad)] + members[k + 1:])
+                with pytest.raises(_lib.PepperAmdError, match="BGZF block %d: CRC32" % k):
+                    inf.inflate(buf, block_table(buf))
+
+
 @pytest.mark.gpu
 def test_many_members_of_a_bam_file(tmp_path):
     """A whole synthetic BAM (tools/synth_bam: libdeflate's encoder, not zlib's) member by member."""
@@ -174,7 +238,7 @@ def test_malformed_members_fail_the_call():
 
 @pytest.mark.gpu
 def test_a_flipped_payload_bit_fails_the_members_crc():
-    """htslib's inflate_block compares crc32() of the inflated block with the member's trailer; so does the device (bgzf_crc_kernel):
+    """htslib's inflate_block compares crc32() of the inflated block with the member's trailer; so does the device (the inflate kernel's epilogue):
     a literal flipped inside a stored block, a flipped literal of a fixed-Huffman stream that still decodes, and a wrong
     trailer all inflate structurally and must fail the call -- in members of 1 byte, of 1 024 k +- 1 bytes (the slice edges of
     the fold) and of the maximum size; the untouched members pass."""

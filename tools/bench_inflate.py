@@ -32,11 +32,12 @@ def main():
     ap.add_argument("--bam", default=None)
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--tags", type=int, default=0)
+    ap.add_argument("--quals", type=int, default=0, help="1: quality strings with run-length structure (members compress > 3 x)")
     args = ap.parse_args()
     with tempfile.TemporaryDirectory() as tmp:
         bam = args.bam
         if bam is None:
-            subprocess.run([os.path.join(ROOT, "tools", "synth_bam"), tmp, str(args.genome), str(args.coverage), "11", "0", "1", str(args.level), str(args.tags)],
+            subprocess.run([os.path.join(ROOT, "tools", "synth_bam"), tmp, str(args.genome), str(args.coverage), "11", "0", "1", str(args.level), str(args.tags), str(args.quals)],
                            check=True, capture_output=True)
             bam = os.path.join(tmp, "reads.bam")
         raw = np.fromfile(bam, np.uint8)

@@ -1,7 +1,7 @@
 """Variant image generation rate: BAM + reference -> candidate image HDF5 (BAM reader, GPU summary encoder, HDF5 writer)
 through pepper_amd.variant.ImageGenerationUI.generate_images, the entry point of pepper_variant make_images / call_variant.
 
-  python tools/bench_variant_images.py make_fast <dir> [genome_bases=64000000] [coverage=60] [seed] [level=1] [tags=0]    synthetic data set
+  python tools/bench_variant_images.py make_fast <dir> [genome_bases=64000000] [coverage=60] [seed] [level=1] [tags=0] [quals=0]    synthetic data set
   python tools/bench_variant_images.py run <dir> [threads,threads,...] [region_size=100000]     GPU; one JSON line
 
 `run` reports, per thread count, the wall time, Mb of reference per second, aligned bases per second and the stage times
@@ -31,13 +31,14 @@ def options(data, out, threads, region_size=100000, **over):
     return o
 
 
-def make_fast(out, bases=64000000, coverage=60, seed=2027, level=1, tags=0):
-    """level 6, tags 1: zlib level 6 members and NM / MD / RG aux data in every record, as samtools writes a BAM."""
+def make_fast(out, bases=64000000, coverage=60, seed=2027, level=1, tags=0, quals=0):
+    """level 6, tags 1: zlib level 6 members and NM / MD / RG aux data in every record, as samtools writes a BAM; quals 1: quality
+    strings with run-length structure (binned plateaus), so that members compress > 3 x as a binning basecaller's BAM does."""
     from pepper_amd import build
     tool = build.build_tools()
     os.makedirs(out, exist_ok=True)
     t0 = time.perf_counter()
-    info = json.loads(subprocess.run([tool, out, str(int(bases)), str(coverage), str(int(seed)), "0", "1", str(int(level)), str(int(tags))],
+    info = json.loads(subprocess.run([tool, out, str(int(bases)), str(coverage), str(int(seed)), "0", "1", str(int(level)), str(int(tags)), str(int(quals))],
                                      check=True, capture_output=True, text=True).stdout)
     info["seconds"] = round(time.perf_counter() - t0, 2)
     with open(os.path.join(out, "synth.json"), "w") as fh:
@@ -69,13 +70,14 @@ def run(data, thread_counts=(16,), region_size=100000, warm=True):
     return {"metric": "variant make_images (generate_images): Mb of reference per second",
             "data": "synthetic BAM %.1f Mb at %.0fx, %d records, %.2f GB (tools/synth_bam, %s%s), intervals of %d" % (
                 mb, info["coverage"], info["records"], info["bam_bytes"] / 1e9, info.get("deflate", "level 1"),
-                ", NM/MD/RG tags" if info.get("aux_tags") else "", region_size),
+                (", NM/MD/RG tags" if info.get("aux_tags") else "") + (", run-length qualities" if "run-length" in info.get("quals", "") else ""),
+                region_size),
             "packed_reads": os.environ.get("PEPPER_AMD_PACKED_READS", "1") != "0", "runs": runs}
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "make_fast":
-        print(json.dumps(make_fast(sys.argv[2], *(float(a) for a in sys.argv[3:8]))))
+        print(json.dumps(make_fast(sys.argv[2], *(float(a) for a in sys.argv[3:9]))))
     else:
         counts = tuple(int(t) for t in sys.argv[3].split(",")) if len(sys.argv) > 3 else (16,)
         print(json.dumps(run(sys.argv[2], counts, int(sys.argv[4]) if len(sys.argv) > 4 else 100000)))

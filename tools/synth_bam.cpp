@@ -2,12 +2,14 @@
 // bench / profiling data for image generation (bench.py secondary.make_images, tools/bench_variant_images.py).
 // Not product code and not an oracle: the package's own BAM reader and the tests' Python writer define the format checks.
 //
-//   synth_bam <out_dir> <genome_bases> [coverage=60] [seed=2027] [threads=0 (all)] [contigs=1] [level=1] [tags=0]
+//   synth_bam <out_dir> <genome_bases> [coverage=60] [seed=2027] [threads=0 (all)] [contigs=1] [level=1] [tags=0] [quals=0]
 //
 // level: 1 = libdeflate level 1 (the fast default: what the data of rounds 3-4 was written with); 2..9 = zlib's deflate at that
 // level -- 6 is what samtools / htslib write (longer matches, longer codes: the blocks a real BAM holds).  tags = 1: every record
 // carries NM:i, an MD:Z string spelling out its mismatches and deletions, and RG:Z, as aligners write them (the aux data is a
-// fifth of a real record's bytes and compresses unlike the bases).
+// fifth of a real record's bytes and compresses unlike the bases).  quals = 1: quality strings with run-length structure (binned
+// values in plateaus, an ONT-like Q7 - Q30 histogram) instead of ~5 bits of entropy per base: members then compress 3-4 x, as the
+// BAMs of a binning basecaller do ("realistic" in bench.py's legs); quals = 0 is the harder case for the inflater per output byte.
 //
 // Reads as pepper_amd.synthetic.encoder_region models them (E-syn): 4-12 kb, an insert or a deletion of 1-5 bases every ~50
 // positions, 4 % substitutions, a heterozygous SNP site per ~1 kb and a systematic indel site per ~700 b carried by one of
@@ -72,7 +74,7 @@ struct Piece {
     int64_t n_bases = 0;
 };
 
-int g_level = 1, g_tags = 0;
+int g_level = 1, g_tags = 0, g_quals = 0;
 
 struct Deflater {
 #ifdef PA_HAVE_LIBDEFLATE
@@ -214,6 +216,24 @@ void make_piece(const Genome& g, int tid, int64_t lo, int64_t hi, double coverag
         if (g_tags) md_flush();
         const uint32_t l_seq = (uint32_t)bases.size();
         quals.resize(l_seq);
+        if (g_quals == 1) {
+            // qualities with run-length structure, as a basecaller that bins them writes (plateaus of one value a dozen bases long,
+            // the next plateau a step or two away, an occasional dip to a very low value inside a homopolymer-like stretch): the
+            // histogram is ONT-like (Q7 .. Q30, most mass around Q12 - Q22); deflate finds the runs, so a member of such records
+            // inflates to 3-4 x its size -- more output per consumed bit than the uniform qualities above give
+            static const uint8_t kBins[8] = {7, 10, 13, 16, 19, 22, 26, 30};
+            int bin = 2 + (int)rng.below(4);
+            for (uint32_t i = 0; i < l_seq;) {
+                uint64_t r = rng.next();
+                uint32_t run = 1 + (uint32_t)(r & 7) + (uint32_t)((r >> 3) & 7) + (uint32_t)((r >> 6) & 7);       // 1 .. 22, mean 11.5
+                const uint32_t kind = (uint32_t)((r >> 9) & 63);
+                uint8_t q = kBins[bin];
+                if (kind == 0) { q = (uint8_t)(2 + ((r >> 15) & 3)); run = 1 + (uint32_t)((r >> 17) & 3); }     // a dip
+                for (uint32_t j = 0; j < run && i < l_seq; ++j, ++i) quals[i] = q;
+                const int step = (int)((r >> 20) % 5) - 2;                                                       // -2 .. +2
+                bin = std::min(7, std::max(0, bin + step));
+            }
+        } else
         for (uint32_t i = 0; i < l_seq; i += 8) {
             uint64_t r = rng.next();
             for (uint32_t j = i; j < std::min(l_seq, i + 8); ++j, r >>= 8) {
@@ -289,6 +309,7 @@ int main(int argc, char** argv) {
     const int n_contigs = std::max(1, argc > 6 ? atoi(argv[6]) : 1);
     g_level = argc > 7 ? std::max(1, std::min(9, atoi(argv[7]))) : 1;
     g_tags = argc > 8 ? atoi(argv[8]) != 0 : 0;
+    g_quals = argc > 9 ? atoi(argv[9]) : 0;
     if (threads <= 0) threads = std::max(1u, std::thread::hardware_concurrency());
     if (FILE* fh = fopen("/sys/fs/cgroup/cpu.max", "r")) {       // a cgroup quota below the hardware's thread count
         char quota[32] = {0};
@@ -445,9 +466,9 @@ int main(int argc, char** argv) {
     }
     fclose(bai);
     printf("{\"records\": %lld, \"read_bases\": %lld, \"genome_bases\": %lld, \"coverage\": %.1f, \"bam_bytes\": %lld, \"threads\": %d, "
-           "\"deflate\": \"%s\", \"aux_tags\": %s}\n",
+           "\"deflate\": \"%s\", \"aux_tags\": %s, \"quals\": \"%s\"}\n",
            (long long)n_records, (long long)n_bases, (long long)total, (double)n_bases / (double)total, (long long)coff + 28, threads,
            g_level == 1 ? "libdeflate level 1 (zlib level 1 where libdeflate is absent)" : (std::string("zlib level ") + std::to_string(g_level)).c_str(),
-           g_tags ? "true" : "false");
+           g_tags ? "true" : "false", g_quals == 1 ? "run-length (binned plateaus, Q7-Q30)" : "~5 bits of entropy per base");
     return 0;
 }
