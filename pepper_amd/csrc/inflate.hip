@@ -231,22 +231,29 @@ PA_DEV bool build_table(const uint8_t* lens, int n, int* count, uint16_t* syms, 
         }
     }
     wave_order();
+    // The primary table, one entry per lane and pass: index t holds the code whose bits (first bit = bit 0 of t) t starts with.
+    // Per length L the canonical codes are the L-bit values first .. first + count - 1 (most significant bit first = the
+    // bit-reversed low L bits of t); the counts are uniform, so the walk over the lengths keeps (count, first, index) in scalar
+    // registers and every lane does compares only -- the per-lane loop over LDS reads of count[] this replaces was 10 dependent
+    // round trips per entry, 16 entries per lane, per block.
+    int cnt[16];
+#pragma unroll
+    for (int len = 1; len < 16; ++len) cnt[len] = uni(count[len]);
     for (int t = lane; t < (1 << tbits); t += 64) {
-        int code = 0, first = 0, index = 0;
-        Entry e = 0;
-#pragma unroll 1
-        for (int len = 1; len <= tbits; ++len) {
-            code |= (t >> (len - 1)) & 1;
-            const int c = count[len];
-            if (code - c < first) {
-                e = (Entry)table_entry(FORMAT, syms[index + (code - first)], len);
-                break;
+        const uint32_t rev = __builtin_bitreverse32((uint32_t)t);
+        int first = 0, index = 0, where = -1, hit_len = 0;
+#pragma unroll
+        for (int len = 1; len < 16; ++len) {
+            if (len <= tbits) {
+                const int rel = (int)(rev >> (32 - len)) - first;
+                const bool hit = where < 0 && (unsigned)rel < (unsigned)cnt[len];
+                where = hit ? index + rel : where;
+                hit_len = hit ? len : hit_len;
+                index += cnt[len];
+                first = (first + cnt[len]) << 1;
             }
-            index += c;
-            first = (first + c) << 1;
-            code <<= 1;
         }
-        table[t] = e;
+        table[t] = where >= 0 ? (Entry)table_entry(FORMAT, syms[where], hit_len) : (Entry)0;
     }
     wave_order();
     return true;
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const int info_e = (e & 128u) ? info_l : len;
             int info = e == 0u ? F_INVALID : info_e;
             const int xlen = (int)__builtin_amdgcn_ubfe(lo, (uint32_t)len, (uint32_t)eb);
-            int val = (e & 128u) ? (int)(e >> 8) + 3 + xlen : (int)(e >> 8);
+            int val = (int)(e >> 8) + ((e & 128u) ? 3 + xlen : 0);
             int dist = (int)(de >> 8) + (int)__builtin_amdgcn_ubfe(behind, (uint32_t)dlen, (uint32_t)deb);
             // (eight scalar instructions per symbol, written out: the scalar unit is shared by the CU's four SIMDs and is the
             // unit this kernel keeps busiest -- the compiler's version of the loop took fourteen)
