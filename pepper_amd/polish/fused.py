@@ -28,10 +28,11 @@ class _DeviceChunks(object):
 
 
 class FusedConsensus(object):
-    """One per polish() run: up to HANDLES model handles per device (a worker takes a free one for its pass) and, per worker, a
-    device buffer the chain's chunks are gathered in until a full-sized pass is worth launching (PASS_CHUNKS; the small-call
+    """One per polish() run: up to HANDLES model handles per device, a small pool of pass threads that run the model over full
+    gather buffers and write the predictions, and, per worker, two device buffers the chain's chunks are gathered in
+    (PASS_CHUNKS each: a pass worth launching; the small-call
     schedule of the step loops is several times slower per chunk)."""
-    PASS_CHUNKS = 4096
+    PASS_CHUNKS = int(os.environ.get("PEPPER_AMD_FUSED_PASS_CHUNKS", 4096))
     HANDLES = 2          # passes in flight per device (own stream and workspace each)
 
     def __init__(self, model_path, output_directory):
@@ -40,6 +41,10 @@ class FusedConsensus(object):
         self.models, self.models_lock = {}, threading.Lock()
         self.chunks = 0
         self.handles = max(1, int(os.environ.get("PEPPER_AMD_FUSED_HANDLES", self.HANDLES)))
+        # the threads that run the model passes and write their predictions (the image workers only gather chunks): a pass waits
+        # for a free handle of its device in _model, so a few threads more than handles keep every handle busy
+        from concurrent.futures import ThreadPoolExecutor
+        self.passes = ThreadPoolExecutor(max_workers=2 * self.handles + 2, thread_name_prefix="fused-consensus-pass")
 
     def _model(self, device):
         """(the device's entry, a free model handle of it): made on first use, at most `handles` of them."""
@@ -86,6 +91,7 @@ class FusedConsensus(object):
         return _Worker(self, thread_id, device)
 
     def close(self):
+        self.passes.shutdown(wait=True)
         for entry in self.models.values():
             for model in entry["all"]:
                 model.close()
@@ -93,17 +99,40 @@ class FusedConsensus(object):
 
 
 class _Worker(object):
+    """One image worker's side: TWO gather buffers.  A full one is handed to the owner's pass threads (model pass + prediction
+    write in the background) while the worker goes on filling the other with its next chain calls -- the worker waits only when
+    both are in flight.  (Until round 6 the worker ran the pass itself: sixteen workers queued for two model handles with their
+    chains idle, and fused polish was slower than the three steps it replaces.)"""
+
     def __init__(self, owner, thread_id, device):
         self.owner, self.device = owner, device
         self.seq, self.features = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
         torch.cuda.set_device(device)
-        self.buffer = torch.empty((owner.PASS_CHUNKS, self.seq, self.features), dtype=torch.uint8, device=torch.device("cuda", device))
-        self.position = np.empty((owner.PASS_CHUNKS, self.seq), np.int64)
-        self.index = np.empty((owner.PASS_CHUNKS, self.seq), np.int64)
-        self.meta = []                      # (contig, start, end, chunk id) per gathered chunk
+        n = owner.PASS_CHUNKS
+        self.sets = [{"buffer": torch.empty((n, self.seq, self.features), dtype=torch.uint8, device=torch.device("cuda", device)),
+                      "position": np.empty((n, self.seq), np.int64), "index": np.empty((n, self.seq), np.int64), "meta": [],
+                      "pending": None} for _ in range(2)]
+        self.cur = 0
         self.n = 0
         self.store = DataStore(owner.output_directory + "pepper_prediction_fused_" + str(thread_id) + ".hdf", mode='w')
+        self.store_lock = threading.Lock()          # (two passes of this worker may finish at the same time)
         self.failed = False
+
+    @property
+    def buffer(self):
+        return self.sets[self.cur]["buffer"]
+
+    @property
+    def position(self):
+        return self.sets[self.cur]["position"]
+
+    @property
+    def index(self):
+        return self.sets[self.cur]["index"]
+
+    @property
+    def meta(self):
+        return self.sets[self.cur]["meta"]
 
     def add(self, contig, starts, stops, chunk_counts, device_images, position, index):
         """The chunks of one chain call: device_images = their address on the device, position / index = numpy views of the
@@ -122,6 +151,7 @@ class _Worker(object):
             self.n += take
             at += take
             if self.n == self.owner.PASS_CHUNKS:
+                torch.cuda.current_stream().synchronize()      # (the pass thread reads the buffer on the model's stream)
                 self.flush()
         torch.cuda.current_stream().synchronize()              # (the chain overwrites its chunks in its next run)
 
@@ -137,29 +167,55 @@ class _Worker(object):
             self.meta.append((str(contig), int(start), int(end), int(cid)))
             self.n += 1
             if self.n == self.owner.PASS_CHUNKS:
+                torch.cuda.current_stream().synchronize()
                 self.flush()
 
-    def flush(self):
-        if self.n == 0:
-            return
+    def _wait(self, k):
+        pending, self.sets[k]["pending"] = self.sets[k]["pending"], None
+        if pending is not None:
+            pending.result()                 # (re-raises what the pass raised)
+
+    def _run_pass(self, k, n):
+        """On a pass thread: the model over the first n chunks of set k, then their predictions into this worker's file."""
+        st = self.sets[k]
         entry, model = self.owner._model(self.device)
         try:
             torch.cuda.set_device(self.device)
-            labels, phred = model.predict_chunks(self.buffer[:self.n])
+            labels, phred = model.predict_chunks(st["buffer"][:n])
             labels, phred = labels.cpu().numpy(), phred.cpu().numpy()
         finally:
             entry["free"].put(model)
-        meta = self.meta[:self.n]
+        meta = st["meta"][:n]
         contigs = np.array([m[0] for m in meta], dtype='S')
-        self.store.write_predictions_block(contigs, np.array([m[1] for m in meta], np.int64), np.array([m[2] for m in meta], np.int64),
-                                           np.array([m[3] for m in meta], np.int64), self.position[:self.n], self.index[:self.n], labels, phred)
-        self.owner.chunks += self.n
-        del self.meta[:self.n]
-        self.n = 0
+        with self.store_lock:
+            self.store.write_predictions_block(contigs, np.array([m[1] for m in meta], np.int64), np.array([m[2] for m in meta], np.int64),
+                                               np.array([m[3] for m in meta], np.int64), st["position"][:n], st["index"][:n], labels, phred)
+        with self.owner.models_lock:
+            self.owner.chunks += n
+        del st["meta"][:n]
+
+    def flush(self):
+        """Hand the current set to the pass threads and move to the other one (waiting for ITS pass, if that is still running)."""
+        if self.n == 0:
+            return
+        k, n = self.cur, self.n
+        self.sets[k]["pending"] = self.owner.passes.submit(self._run_pass, k, n)
+        self.cur, self.n = k ^ 1, 0
+        self._wait(self.cur)
 
     def close(self, failed=False):
         if failed:
+            for k in (0, 1):
+                try:
+                    self._wait(k)
+                except BaseException:      # noqa: BLE001 -- the run is being abandoned already
+                    pass
             self.store.abort()
             return
+        if self.n:
+            torch.cuda.set_device(self.device)
+            torch.cuda.current_stream().synchronize()
         self.flush()
+        for k in (0, 1):
+            self._wait(k)
         self.store.close()
