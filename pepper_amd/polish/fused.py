@@ -41,6 +41,7 @@ class FusedConsensus(object):
         self.models, self.models_lock = {}, threading.Lock()
         self.chunks = 0
         self.handles = max(1, int(os.environ.get("PEPPER_AMD_FUSED_HANDLES", self.HANDLES)))
+        self.stream_priority = int(os.environ.get("PEPPER_AMD_FUSED_STREAM_PRIORITY", -1))
         # the threads that run the model passes and write their predictions (the image workers only gather chunks): a pass waits
         # for a free handle of its device in _model, so a few threads more than handles keep every handle busy
         from concurrent.futures import ThreadPoolExecutor
@@ -72,10 +73,16 @@ class FusedConsensus(object):
             if first is not None:
                 model = first.clone()
             else:
-                model = ModelHandler.load_simple_model_for_training(self.model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
-                                                                    image_features=ImageSizeOptions.IMAGE_HEIGHT,
-                                                                    seq_len=ImageSizeOptions.SEQ_LENGTH,
-                                                                    num_classes=ImageSizeOptions.TOTAL_LABELS)[0]
+                loaded = ModelHandler.load_simple_model_for_training(self.model_path, input_channels=ImageSizeOptions.IMAGE_CHANNELS,
+                                                                     image_features=ImageSizeOptions.IMAGE_HEIGHT,
+                                                                     seq_len=ImageSizeOptions.SEQ_LENGTH,
+                                                                     num_classes=ImageSizeOptions.TOTAL_LABELS)[0]
+                # The passes' stream is one of the device's HIGH-PRIORITY queues: a pass is 19 windows x a few short kernels, and on
+                # an ordinary stream every one of them waits in a hardware queue it shares with an image worker's stream behind
+                # that worker's 10 ms alignment kernel (16 queues, ~20 streams) -- 3 500 launches x ~12 ms was the whole of what
+                # the fused form lost.  (The loader's signature is the reference's: the handle is re-made with the priority.)
+                model = loaded.clone(stream_priority=self.stream_priority)
+                loaded.close()
         except BaseException as err:
             with self.models_lock:
                 entry["made"] -= 1
@@ -114,6 +121,9 @@ class _Worker(object):
                       "pending": None} for _ in range(2)]
         self.cur = 0
         self.n = 0
+        # the gather copies run on this worker's own stream: the device's default stream is shared by every thread of the process,
+        # and a copy queued there waits behind whatever another thread made it wait for (a whole model pass)
+        self.copy_stream = torch.cuda.Stream(device=device)
         self.store = DataStore(owner.output_directory + "pepper_prediction_fused_" + str(thread_id) + ".hdf", mode='w')
         self.store_lock = threading.Lock()          # (two passes of this worker may finish at the same time)
         self.failed = False
@@ -144,16 +154,17 @@ class _Worker(object):
             take = min(total - at, self.owner.PASS_CHUNKS - self.n)
             src = torch.as_tensor(_DeviceChunks(device_images + at * self.seq * self.features, (take, self.seq, self.features)),
                                   device=torch.device("cuda", self.device))
-            self.buffer[self.n:self.n + take].copy_(src)
+            with torch.cuda.stream(self.copy_stream):
+                self.buffer[self.n:self.n + take].copy_(src)
             self.position[self.n:self.n + take] = position[at:at + take]
             self.index[self.n:self.n + take] = index[at:at + take]
             self.meta.extend(meta[at:at + take])
             self.n += take
             at += take
             if self.n == self.owner.PASS_CHUNKS:
-                torch.cuda.current_stream().synchronize()      # (the pass thread reads the buffer on the model's stream)
+                self.copy_stream.synchronize()                 # (the pass thread reads the buffer on the model's stream)
                 self.flush()
-        torch.cuda.current_stream().synchronize()              # (the chain overwrites its chunks in its next run)
+        self.copy_stream.synchronize()                         # (the chain overwrites its chunks in its next run)
 
     def add_host(self, region, images, positions, chunk_ids):
         """An interval that went through the host form (a pile beyond the reservoir cap, a span the packed reader refused): its
@@ -161,13 +172,14 @@ class _Worker(object):
         contig, start, end = region
         for image, pos, cid in zip(images, positions, chunk_ids):
             torch.cuda.set_device(self.device)
-            self.buffer[self.n].copy_(torch.from_numpy(np.ascontiguousarray(image, np.uint8)))
+            with torch.cuda.stream(self.copy_stream):
+                self.buffer[self.n].copy_(torch.from_numpy(np.ascontiguousarray(image, np.uint8)))
             pos = np.asarray(pos, np.int64).reshape(self.seq, 2)
             self.position[self.n], self.index[self.n] = pos[:, 0], pos[:, 1]
             self.meta.append((str(contig), int(start), int(end), int(cid)))
             self.n += 1
             if self.n == self.owner.PASS_CHUNKS:
-                torch.cuda.current_stream().synchronize()
+                self.copy_stream.synchronize()
                 self.flush()
 
     def _wait(self, k):
@@ -181,8 +193,9 @@ class _Worker(object):
         entry, model = self.owner._model(self.device)
         try:
             torch.cuda.set_device(self.device)
-            labels, phred = model.predict_chunks(st["buffer"][:n])
-            labels, phred = labels.cpu().numpy(), phred.cpu().numpy()
+            with torch.cuda.stream(model._stream):          # (this thread's "current stream": not the process-wide default one)
+                labels, phred = model.predict_chunks(st["buffer"][:n])
+                labels, phred = labels.cpu().numpy(), phred.cpu().numpy()
         finally:
             entry["free"].put(model)
         meta = st["meta"][:n]
@@ -214,7 +227,7 @@ class _Worker(object):
             return
         if self.n:
             torch.cuda.set_device(self.device)
-            torch.cuda.current_stream().synchronize()
+            self.copy_stream.synchronize()
         self.flush()
         for k in (0, 1):
             self._wait(k)

@@ -37,7 +37,9 @@ class TransducerGRU(object):
                                 TrainOptions.WINDOW_JUMP, ImageSizeOptions.SEQ_OVERLAP, self.device,
                                 self.max_chunk)
         names, data, numel, n, keep = _lib.marshal_state_dict(state_dict)
-        self._stream = torch.cuda.Stream(device=self.device)
+        # (priority -1: a stream of the device's high-priority queues -- a caller whose passes must not queue behind other
+        # streams' long kernels in a shared hardware queue, polish/fused.py)
+        self._stream = torch.cuda.Stream(device=self.device, priority=int(getattr(self, "stream_priority", 0)))
         handle = ctypes.c_void_p()
         _lib.check(lib.pa_polish_create(ctypes.byref(cfg), names, data, numel, n,
                                         ctypes.c_void_p(self._stream.cuda_stream), ctypes.byref(handle)))
@@ -45,11 +47,13 @@ class TransducerGRU(object):
         self._state = state_dict
         return self
 
-    def clone(self):
+    def clone(self, stream_priority=None):
         """A second, independent handle on the same weights (own stream, own staging buffers): what runs a second block on
-        the device while this one's pass is under way (pepper_amd/hostpipe.py polish_lanes)."""
+        the device while this one's pass is under way (pepper_amd/hostpipe.py polish_lanes).  stream_priority: 0 / -1 (high) for
+        the clone's stream; None: this object's."""
         other = TransducerGRU(1, self.image_features, self.num_layers, self.hidden_size, self.num_classes, device=self.device,
                               max_chunk=self.max_chunk)
+        other.stream_priority = int(getattr(self, "stream_priority", 0) if stream_priority is None else stream_priority)
         return other.load_state_dict(self._state)
 
     def eval(self):

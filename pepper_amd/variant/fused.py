@@ -73,9 +73,16 @@ class FusedPredictor(object):
         if make:
             try:
                 torch.cuda.set_device(device)
-                model = ModelHandler.load_simple_model_for_training(
-                    self.options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT, num_classes=ImageSizeOptions.TOTAL_LABELS,
-                    num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)[0]
+                # the forwards' stream is a high-priority one: on an ordinary stream each of a forward's kernels can sit in a hardware
+                # queue it shares with an image worker's stream behind that worker's encoder kernels (16 queues, ~20 streams)
+                from pepper_amd.variant.models import simple_model
+                simple_model.NEW_HANDLES.stream_priority = int(os.environ.get("PEPPER_AMD_FUSED_STREAM_PRIORITY", -1))
+                try:
+                    model = ModelHandler.load_simple_model_for_training(
+                        self.options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT, num_classes=ImageSizeOptions.TOTAL_LABELS,
+                        num_type_classes=ImageSizeOptions.TOTAL_TYPE_LABELS)[0]
+                finally:
+                    simple_model.NEW_HANDLES.stream_priority = 0
                 model.eval()
             except BaseException as err:
                 # a load that failed (no memory, a bad model_path) must not leave the other workers waiting for a handle that will
@@ -110,10 +117,11 @@ class FusedPredictor(object):
         t0 = time.perf_counter()
         try:
             torch.cuda.set_device(device)
-            probs = torch.empty((n, model.num_classes_type), dtype=torch.float32, device=torch.device("cuda", device))
-            _lib.check(lib.pa_variant_forward_device(model.handle, ctypes.c_void_p(images_ptr), n, probs.data_ptr(), None))
-            model._stream.synchronize()
-            return probs.cpu().numpy()
+            with torch.cuda.stream(model._stream):       # (allocation and the copy back on the forward's stream, not the process-wide default)
+                probs = torch.empty((n, model.num_classes_type), dtype=torch.float32, device=torch.device("cuda", device))
+                _lib.check(lib.pa_variant_forward_device(model.handle, ctypes.c_void_p(images_ptr), n, probs.data_ptr(), None))
+                model._stream.synchronize()
+                return probs.cpu().numpy()
         finally:
             with self.timer_lock:
                 self.forward_seconds += time.perf_counter() - t0    # (summed over the handles: not a wall time)

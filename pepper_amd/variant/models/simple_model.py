@@ -22,6 +22,12 @@ def _pinned_empty(shape, dtype):
         return torch.empty(shape, dtype=dtype)
 
 
+# Per thread: the priority of the stream a handle made on this thread gets (0; -1 = one of the device's high-priority queues).  The
+# loaders keep the reference's signatures, so a caller that wants its forwards not to queue behind other streams' long kernels in a
+# shared hardware queue (variant/fused.py) sets NEW_HANDLES.stream_priority around its load.
+import threading as _threading
+NEW_HANDLES = _threading.local()
+
 class TransducerGRU(object):
     def __init__(self, image_features, gru_layers, hidden_size, num_classes, num_classes_type,
                  bidirectional=True, device=None, max_chunk=0):
@@ -47,7 +53,7 @@ class TransducerGRU(object):
         cfg = _lib.VariantConfig(self.image_features, self.window, self.num_layers,
                                  self.num_classes_type, self.device, self.max_chunk)
         names, data, numel, n, keep = _lib.marshal_state_dict(state_dict)
-        self._stream = torch.cuda.Stream(device=self.device)
+        self._stream = torch.cuda.Stream(device=self.device, priority=int(getattr(NEW_HANDLES, "stream_priority", 0)))
         handle = ctypes.c_void_p()
         _lib.check(lib.pa_variant_create(ctypes.byref(cfg), names, data, numel, n,
                                          ctypes.c_void_p(self._stream.cuda_stream), ctypes.byref(handle)))
