@@ -2,11 +2,19 @@
 PEPPER_AMD_FUSED_POLISH=1).
 
 The reference's steps talk through files (/root/reference/pepper/modules/python/polish.py:94-117: make_images writes the image HDF5
-files, call_consensus reads them back).  Here an image-generation worker keeps the chunks the chain left on the device
-(pa_polish_chain_device_chunks), gathers a few thousand of them, and hands them to the polish model there
-(pa_polish_predict_device: the 19-window loop with hidden carry, labels and phred per position); both HDF5 stores are still
-written -- the image files by the workers as before, one prediction file per worker with the reference's layout
-(predictions/<contig>/<contig>-<start>-<end>/<chunk id>/...), which perform_stitch globs as it does the callers' files.
+files, call_consensus reads them back).  Here the image-generation workers copy the chunks the chain left on the device
+(pa_polish_chain_device_chunks) into ONE gather buffer per device, shared by all of them; every time it holds a full-sized pass
+(16 384 chunks) a background thread hands it to the polish model there (pa_polish_predict_device: the 19-window loop with hidden
+carry, labels and phred per position) and writes the predictions, while the workers go on filling the next buffer.  Both HDF5
+stores are still written -- the image files by the workers as before, the prediction files (one per pass thread) with the
+reference's layout (predictions/<contig>/<contig>-<start>-<end>/<chunk id>/...), which perform_stitch globs as it does the
+callers' files; an interval's chunks always travel in one pass, so a region group is never split over two files.
+
+Why one shared buffer: a pass is 19 windows x a few kernels whatever its size, and the step loops fill the chip only at 16 384
+chunks (128 rows per workgroup x 2 directions = 256 workgroups).  Round 5 gathered per worker (4 096 chunks, 64 workgroups) and
+ran the pass on the worker's own thread: sixteen workers queued for two model handles with their chains idle, 3 500 small
+launches each waited in a hardware queue behind some worker's 10 ms alignment kernel, and the fused form was slower than the
+three steps it replaces.
 """
 import os
 import queue
@@ -27,12 +35,121 @@ class _DeviceChunks(object):
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
 
 
+class _GatherSet(object):
+    """One pass worth of chunks on a device: the images there, their positions / indices and names on the host."""
+
+    def __init__(self, device, chunks, seq, features):
+        self.buffer = torch.empty((chunks, seq, features), dtype=torch.uint8, device=torch.device("cuda", device))
+        self.position = np.empty((chunks, seq), np.int64)
+        self.index = np.empty((chunks, seq), np.int64)
+        self.meta = [None] * chunks          # (contig, start, end, chunk id) per chunk
+        self.reserved = 0                    # chunks handed out to workers
+        self.done = 0                        # ... and filled in
+        self.sealed = False                  # no more reservations: the pass starts when done == reserved
+        self.busy = False                    # its pass is running
+
+
+class _Gather(object):
+    """The gather buffers of one device and the hand-over between the image workers (reserve / commit) and the pass threads."""
+    SETS = 3
+
+    def __init__(self, owner, device):
+        self.owner, self.device = owner, device
+        self.seq, self.features = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+        self.chunks = owner.PASS_CHUNKS
+        self.lock = threading.Condition()
+        self.sets = []                       # made on first use: the third only if the first two are both busy
+        self.cur = None
+        self.futures = []
+
+    def _free_set(self):
+        """(lock held) a set nobody is filling or running: an idle one, a new one while fewer than SETS exist, else wait."""
+        while True:
+            self.owner.check()
+            for st in self.sets:
+                if not st.busy and not st.sealed and st.reserved == 0:
+                    return st
+            if len(self.sets) < self.SETS:
+                torch.cuda.set_device(self.device)
+                st = _GatherSet(self.device, self.chunks, self.seq, self.features)
+                self.sets.append(st)
+                return st
+            self.lock.wait(0.5)
+
+    def reserve(self, n):
+        """Room for n chunks that must travel together (n <= PASS_CHUNKS) -> (set, offset).  A set that cannot take them is closed
+        short and the next one started."""
+        with self.lock:
+            if self.cur is not None and self.cur.reserved + n > self.chunks:
+                self._seal(self.cur)
+                self.cur = None
+            if self.cur is None:
+                self.cur = self._free_set()
+            st, at = self.cur, self.cur.reserved
+            st.reserved += n
+            return st, at
+
+    def commit(self, st, n):
+        with self.lock:
+            st.done += n
+            if st.sealed and st.done == st.reserved:
+                self._start(st)
+
+    def _seal(self, st):
+        st.sealed = True
+        if st.done == st.reserved:
+            self._start(st)
+
+    def _start(self, st):
+        if st.reserved == 0:
+            st.sealed = False
+            return
+        st.busy = True
+        self.futures.append(self.owner.passes.submit(self._run_pass, st))
+
+    def _run_pass(self, st):
+        """On a pass thread: the model over the set's chunks, their predictions into this thread's file, the set back to the workers."""
+        try:
+            n = st.reserved
+            entry, model = self.owner._model(self.device)
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(model._stream):          # (this thread's "current stream": not the process-wide default one)
+                    labels, phred = model.predict_chunks(st.buffer[:n])
+                    labels, phred = labels.cpu().numpy(), phred.cpu().numpy()
+            finally:
+                entry["free"].put(model)
+            meta = st.meta[:n]
+            contigs = np.array([m[0] for m in meta], dtype='S')
+            self.owner.store().write_predictions_block(contigs, np.array([m[1] for m in meta], np.int64), np.array([m[2] for m in meta], np.int64),
+                                                       np.array([m[3] for m in meta], np.int64), st.position[:n], st.index[:n], labels, phred)
+            with self.owner.models_lock:
+                self.owner.chunks += n
+                self.owner.passes_run += 1
+        except BaseException as err:      # noqa: BLE001 -- handed to the workers (check) and to close()
+            self.owner.fail(err)
+            raise
+        finally:
+            with self.lock:
+                st.reserved = st.done = 0
+                st.sealed = st.busy = False
+                self.lock.notify_all()
+
+    def finish(self):
+        """Every worker has finished: the last, short pass, then wait for all of them."""
+        with self.lock:
+            if self.cur is not None:
+                self._seal(self.cur)
+                self.cur = None
+            futures, self.futures = self.futures, []
+        for f in futures:
+            f.result()
+
+
 class FusedConsensus(object):
     """One per polish() run: up to HANDLES model handles per device, a small pool of pass threads that run the model over full
-    gather buffers and write the predictions, and, per worker, two device buffers the chain's chunks are gathered in
-    (PASS_CHUNKS each: a pass worth launching; the small-call
-    schedule of the step loops is several times slower per chunk)."""
-    PASS_CHUNKS = int(os.environ.get("PEPPER_AMD_FUSED_PASS_CHUNKS", 4096))
+    gather buffers and write the predictions, and per device the shared gather buffers (_Gather)."""
+    PASS_CHUNKS = int(os.environ.get("PEPPER_AMD_FUSED_PASS_CHUNKS", 16384))      # a pass that fills the chip (DESIGN.md 4.6e)
     HANDLES = 2          # passes in flight per device (own stream and workspace each)
 
     def __init__(self, model_path, output_directory):
@@ -40,12 +157,44 @@ class FusedConsensus(object):
         self.output_directory = output_directory
         self.models, self.models_lock = {}, threading.Lock()
         self.chunks = 0
+        self.passes_run = 0
         self.handles = max(1, int(os.environ.get("PEPPER_AMD_FUSED_HANDLES", self.HANDLES)))
         self.stream_priority = int(os.environ.get("PEPPER_AMD_FUSED_STREAM_PRIORITY", -1))
-        # the threads that run the model passes and write their predictions (the image workers only gather chunks): a pass waits
-        # for a free handle of its device in _model, so a few threads more than handles keep every handle busy
+        # the threads that run the model passes and write their predictions (the image workers only gather chunks)
         from concurrent.futures import ThreadPoolExecutor
-        self.passes = ThreadPoolExecutor(max_workers=2 * self.handles + 2, thread_name_prefix="fused-consensus-pass")
+        self.passes = ThreadPoolExecutor(max_workers=self.handles + 1, thread_name_prefix="fused-consensus-pass")
+        self.gathers = {}
+        self.stores, self._local = [], threading.local()
+        self.error = None
+        self.failed = False
+
+    # ---- errors ----
+    def fail(self, err):
+        with self.models_lock:
+            if self.error is None:
+                self.error = err
+
+    def check(self):
+        if self.error is not None:
+            raise RuntimeError("fused consensus: a model pass failed") from self.error
+
+    # ---- the prediction files: one per pass thread ----
+    def store(self):
+        st = getattr(self._local, "store", None)
+        if st is None:
+            with self.models_lock:
+                k = len(self.stores)
+                st = DataStore(self.output_directory + "pepper_prediction_fused_" + str(k) + ".hdf", mode='w')
+                self.stores.append(st)
+            self._local.store = st
+        return st
+
+    def gather(self, device):
+        with self.models_lock:
+            g = self.gathers.get(device)
+            if g is None:
+                g = self.gathers[device] = _Gather(self, device)
+            return g
 
     def _model(self, device):
         """(the device's entry, a free model handle of it): made on first use, at most `handles` of them."""
@@ -97,138 +246,104 @@ class FusedConsensus(object):
     def worker(self, thread_id, device):
         return _Worker(self, thread_id, device)
 
-    def close(self):
+    def close(self, failed=False):
+        """After make_images: the last pass, the files closed (or, after a failure anywhere, withdrawn), the handles released."""
+        failed = failed or self.failed or self.error is not None
+        err = self.error
+        try:
+            if not failed:
+                for g in list(self.gathers.values()):
+                    g.finish()
+        except BaseException as e:      # noqa: BLE001
+            failed, err = True, (err or e)
         self.passes.shutdown(wait=True)
+        for st in self.stores:
+            if failed:
+                st.abort()
+            else:
+                st.close()
         for entry in self.models.values():
             for model in entry["all"]:
                 model.close()
         self.models.clear()
+        self.gathers.clear()
+        if err is not None:
+            raise RuntimeError("fused consensus failed") from err
 
 
 class _Worker(object):
-    """One image worker's side: TWO gather buffers.  A full one is handed to the owner's pass threads (model pass + prediction
-    write in the background) while the worker goes on filling the other with its next chain calls -- the worker waits only when
-    both are in flight.  (Until round 6 the worker ran the pass itself: sixteen workers queued for two model handles with their
-    chains idle, and fused polish was slower than the three steps it replaces.)"""
+    """One image worker's side: copies its chain calls' chunks into the device's shared gather buffer."""
 
     def __init__(self, owner, thread_id, device):
         self.owner, self.device = owner, device
         self.seq, self.features = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
+        self.gather = owner.gather(device)
         torch.cuda.set_device(device)
-        n = owner.PASS_CHUNKS
-        self.sets = [{"buffer": torch.empty((n, self.seq, self.features), dtype=torch.uint8, device=torch.device("cuda", device)),
-                      "position": np.empty((n, self.seq), np.int64), "index": np.empty((n, self.seq), np.int64), "meta": [],
-                      "pending": None} for _ in range(2)]
-        self.cur = 0
-        self.n = 0
         # the gather copies run on this worker's own stream: the device's default stream is shared by every thread of the process,
         # and a copy queued there waits behind whatever another thread made it wait for (a whole model pass)
         self.copy_stream = torch.cuda.Stream(device=device)
-        self.store = DataStore(owner.output_directory + "pepper_prediction_fused_" + str(thread_id) + ".hdf", mode='w')
-        self.store_lock = threading.Lock()          # (two passes of this worker may finish at the same time)
-        self.failed = False
-
-    @property
-    def buffer(self):
-        return self.sets[self.cur]["buffer"]
-
-    @property
-    def position(self):
-        return self.sets[self.cur]["position"]
-
-    @property
-    def index(self):
-        return self.sets[self.cur]["index"]
-
-    @property
-    def meta(self):
-        return self.sets[self.cur]["meta"]
 
     def add(self, contig, starts, stops, chunk_counts, device_images, position, index):
         """The chunks of one chain call: device_images = their address on the device, position / index = numpy views of the
-        chain's page-locked copies ([total, seq] int64: copied here, the chain overwrites them in its next run)."""
-        meta = [(contig, int(a), int(b), cid) for a, b, c in zip(starts, stops, chunk_counts) for cid in range(int(c))]
-        total, at = len(meta), 0
+        chain's page-locked copies ([total, seq] int64: copied here, the chain overwrites them in its next run).  The chunks of an
+        interval stay together (one pass, one prediction file); a call's intervals are cut into pieces of at most a pass."""
+        counts = [int(c) for c in chunk_counts]
         torch.cuda.set_device(self.device)
-        while at < total:
-            take = min(total - at, self.owner.PASS_CHUNKS - self.n)
-            src = torch.as_tensor(_DeviceChunks(device_images + at * self.seq * self.features, (take, self.seq, self.features)),
-                                  device=torch.device("cuda", self.device))
-            with torch.cuda.stream(self.copy_stream):
-                self.buffer[self.n:self.n + take].copy_(src)
-            self.position[self.n:self.n + take] = position[at:at + take]
-            self.index[self.n:self.n + take] = index[at:at + take]
-            self.meta.extend(meta[at:at + take])
-            self.n += take
+        r0, at = 0, 0
+        while r0 < len(counts):
+            r1, take = r0, 0
+            while r1 < len(counts) and (take + counts[r1] <= self.gather.chunks or r1 == r0):
+                take += counts[r1]
+                r1 += 1
+            if take > self.gather.chunks:
+                raise RuntimeError("an interval of %d chunks does not fit a pass of %d" % (take, self.gather.chunks))
+            if take:
+                st, off = self.gather.reserve(take)
+                try:
+                    src = torch.as_tensor(_DeviceChunks(device_images + at * self.seq * self.features, (take, self.seq, self.features)),
+                                          device=torch.device("cuda", self.device))
+                    with torch.cuda.stream(self.copy_stream):
+                        st.buffer[off:off + take].copy_(src)
+                    st.position[off:off + take] = position[at:at + take]
+                    st.index[off:off + take] = index[at:at + take]
+                    k = off
+                    for r in range(r0, r1):
+                        a, b = int(starts[r]), int(stops[r])
+                        for cid in range(counts[r]):
+                            st.meta[k] = (contig, a, b, cid)
+                            k += 1
+                    self.copy_stream.synchronize()             # (the chain overwrites its chunks in its next run; the pass reads the set)
+                finally:
+                    self.gather.commit(st, take)
             at += take
-            if self.n == self.owner.PASS_CHUNKS:
-                self.copy_stream.synchronize()                 # (the pass thread reads the buffer on the model's stream)
-                self.flush()
-        self.copy_stream.synchronize()                         # (the chain overwrites its chunks in its next run)
+            r0 = r1
 
     def add_host(self, region, images, positions, chunk_ids):
         """An interval that went through the host form (a pile beyond the reservoir cap, a span the packed reader refused): its
         chunks as lists of [seq, features] uint8 arrays and [seq, 2] (position, index) arrays."""
         contig, start, end = region
-        for image, pos, cid in zip(images, positions, chunk_ids):
-            torch.cuda.set_device(self.device)
-            with torch.cuda.stream(self.copy_stream):
-                self.buffer[self.n].copy_(torch.from_numpy(np.ascontiguousarray(image, np.uint8)))
-            pos = np.asarray(pos, np.int64).reshape(self.seq, 2)
-            self.position[self.n], self.index[self.n] = pos[:, 0], pos[:, 1]
-            self.meta.append((str(contig), int(start), int(end), int(cid)))
-            self.n += 1
-            if self.n == self.owner.PASS_CHUNKS:
-                self.copy_stream.synchronize()
-                self.flush()
-
-    def _wait(self, k):
-        pending, self.sets[k]["pending"] = self.sets[k]["pending"], None
-        if pending is not None:
-            pending.result()                 # (re-raises what the pass raised)
-
-    def _run_pass(self, k, n):
-        """On a pass thread: the model over the first n chunks of set k, then their predictions into this worker's file."""
-        st = self.sets[k]
-        entry, model = self.owner._model(self.device)
+        n = len(images)
+        if n == 0:
+            return
+        torch.cuda.set_device(self.device)
+        st, off = self.gather.reserve(n)
         try:
-            torch.cuda.set_device(self.device)
-            with torch.cuda.stream(model._stream):          # (this thread's "current stream": not the process-wide default one)
-                labels, phred = model.predict_chunks(st["buffer"][:n])
-                labels, phred = labels.cpu().numpy(), phred.cpu().numpy()
+            block = np.ascontiguousarray(np.stack([np.asarray(im, np.uint8) for im in images]))
+            with torch.cuda.stream(self.copy_stream):
+                st.buffer[off:off + n].copy_(torch.from_numpy(block))
+            for k, (pos, cid) in enumerate(zip(positions, chunk_ids)):
+                pos = np.asarray(pos, np.int64).reshape(self.seq, 2)
+                st.position[off + k], st.index[off + k] = pos[:, 0], pos[:, 1]
+                st.meta[off + k] = (str(contig), int(start), int(end), int(cid))
+            self.copy_stream.synchronize()
         finally:
-            entry["free"].put(model)
-        meta = st["meta"][:n]
-        contigs = np.array([m[0] for m in meta], dtype='S')
-        with self.store_lock:
-            self.store.write_predictions_block(contigs, np.array([m[1] for m in meta], np.int64), np.array([m[2] for m in meta], np.int64),
-                                               np.array([m[3] for m in meta], np.int64), st["position"][:n], st["index"][:n], labels, phred)
-        with self.owner.models_lock:
-            self.owner.chunks += n
-        del st["meta"][:n]
+            self.gather.commit(st, n)
 
     def flush(self):
-        """Hand the current set to the pass threads and move to the other one (waiting for ITS pass, if that is still running)."""
-        if self.n == 0:
-            return
-        k, n = self.cur, self.n
-        self.sets[k]["pending"] = self.owner.passes.submit(self._run_pass, k, n)
-        self.cur, self.n = k ^ 1, 0
-        self._wait(self.cur)
+        """(kept for callers of the round-5 form: the passes start by themselves)"""
 
     def close(self, failed=False):
         if failed:
-            for k in (0, 1):
-                try:
-                    self._wait(k)
-                except BaseException:      # noqa: BLE001 -- the run is being abandoned already
-                    pass
-            self.store.abort()
-            return
-        if self.n:
-            torch.cuda.set_device(self.device)
-            self.copy_stream.synchronize()
-        self.flush()
-        for k in (0, 1):
-            self._wait(k)
-        self.store.close()
+            self.owner.failed = True
+        else:
+            self.owner.check()

@@ -11,13 +11,10 @@ import json,sys
 d=json.loads(sys.stdin.read()); print('$kind', '$*', d['value'], d['runs_seconds'], d['stage_walls'], {k:d['image_stage_seconds_summed_over_workers'].get(k) for k in ('chain','fused_consensus','chain_score_kernel','chain_band_kernel','fused_forward','hdf5','encode')})"
   rm -rf $S/$kind
 }
-run polish 64000000 60 A=1 | tee -a $O/fused_sweep2.txt
-run polish_fused 64000000 60 A=1 | tee -a $O/fused_sweep2.txt
-run polish_fused 64000000 60 PEPPER_AMD_FUSED_STREAM_PRIORITY=0 | tee -a $O/fused_sweep2.txt
-run polish_fused 64000000 60 PEPPER_AMD_FUSED_HANDLES=3 | tee -a $O/fused_sweep2.txt
-run polish_fused 64000000 60 PEPPER_AMD_FUSED_PASS_CHUNKS=8192 | tee -a $O/fused_sweep2.txt
-run polish_fused 64000000 60 PEPPER_AMD_FUSED_PASS_CHUNKS=2048 PEPPER_AMD_FUSED_HANDLES=4 | tee -a $O/fused_sweep2.txt
-run call_variant 256000000 30 A=1 | tee -a $O/fused_sweep2.txt
-run call_variant_fused 256000000 30 A=1 | tee -a $O/fused_sweep2.txt
-run call_variant_fused 256000000 30 PEPPER_AMD_FUSED_STREAM_PRIORITY=0 | tee -a $O/fused_sweep2.txt
+run polish 64000000 60 A=1 | tee -a $O/fused_sweep3.txt
+run polish_fused 64000000 60 A=1 | tee -a $O/fused_sweep3.txt
+run polish_fused 64000000 60 PEPPER_AMD_FUSED_STREAM_PRIORITY=0 | tee -a $O/fused_sweep3.txt
+run polish_fused 64000000 60 PEPPER_AMD_FUSED_HANDLES=1 | tee -a $O/fused_sweep3.txt
+run polish_fused 64000000 60 PEPPER_AMD_FUSED_HANDLES=3 | tee -a $O/fused_sweep3.txt
+run polish_fused 64000000 60 PEPPER_AMD_FUSED_PASS_CHUNKS=8192 | tee -a $O/fused_sweep3.txt
 rm -rf $S
