@@ -63,31 +63,37 @@ class _Gather(object):
         self.futures = []
 
     def _free_set(self):
-        """(lock held) a set nobody is filling or running: an idle one, a new one while fewer than SETS exist, else wait."""
-        while True:
-            self.owner.check()
-            for st in self.sets:
-                if not st.busy and not st.sealed and st.reserved == 0:
-                    return st
-            if len(self.sets) < self.SETS:
-                torch.cuda.set_device(self.device)
-                st = _GatherSet(self.device, self.chunks, self.seq, self.features)
-                self.sets.append(st)
+        """(lock held, never waits) a set nobody is filling or running: an idle one, a new one while fewer than SETS exist, else None."""
+        for st in self.sets:
+            if not st.busy and not st.sealed and st.reserved == 0:
                 return st
-            self.lock.wait(0.5)
+        if len(self.sets) < self.SETS:
+            torch.cuda.set_device(self.device)
+            st = _GatherSet(self.device, self.chunks, self.seq, self.features)
+            self.sets.append(st)
+            return st
+        return None
 
     def reserve(self, n):
         """Room for n chunks that must travel together (n <= PASS_CHUNKS) -> (set, offset).  A set that cannot take them is closed
-        short and the next one started."""
+        short and the next one started; when every set is being filled or run, the caller waits for a pass to finish.  (One loop
+        under one lock, re-reading `cur` after every wait: two workers that waited side by side must not each install a set of
+        their own -- the first one's would be left half filled for ever.)"""
         with self.lock:
-            if self.cur is not None and self.cur.reserved + n > self.chunks:
-                self._seal(self.cur)
-                self.cur = None
-            if self.cur is None:
-                self.cur = self._free_set()
-            st, at = self.cur, self.cur.reserved
-            st.reserved += n
-            return st, at
+            while True:
+                self.owner.check()
+                if self.cur is None:
+                    self.cur = self._free_set()
+                    if self.cur is None:
+                        self.lock.wait(0.5)
+                        continue
+                if self.cur.reserved + n > self.chunks:
+                    self._seal(self.cur)
+                    self.cur = None
+                    continue
+                st, at = self.cur, self.cur.reserved
+                st.reserved += n
+                return st, at
 
     def commit(self, st, n):
         with self.lock:
@@ -107,22 +113,25 @@ class _Gather(object):
         st.busy = True
         self.futures.append(self.owner.passes.submit(self._run_pass, st))
 
+    def _predict_and_write(self, st, n):
+        entry, model = self.owner._model(self.device)
+        try:
+            torch.cuda.set_device(self.device)
+            with torch.cuda.stream(model._stream):          # (this thread's "current stream": not the process-wide default one)
+                labels, phred = model.predict_chunks(st.buffer[:n])
+                labels, phred = labels.cpu().numpy(), phred.cpu().numpy()
+        finally:
+            entry["free"].put(model)
+        meta = st.meta[:n]
+        contigs = np.array([m[0] for m in meta], dtype='S')
+        self.owner.store().write_predictions_block(contigs, np.array([m[1] for m in meta], np.int64), np.array([m[2] for m in meta], np.int64),
+                                                   np.array([m[3] for m in meta], np.int64), st.position[:n], st.index[:n], labels, phred)
+
     def _run_pass(self, st):
         """On a pass thread: the model over the set's chunks, their predictions into this thread's file, the set back to the workers."""
         try:
             n = st.reserved
-            entry, model = self.owner._model(self.device)
-            try:
-                torch.cuda.set_device(self.device)
-                with torch.cuda.stream(model._stream):          # (this thread's "current stream": not the process-wide default one)
-                    labels, phred = model.predict_chunks(st.buffer[:n])
-                    labels, phred = labels.cpu().numpy(), phred.cpu().numpy()
-            finally:
-                entry["free"].put(model)
-            meta = st.meta[:n]
-            contigs = np.array([m[0] for m in meta], dtype='S')
-            self.owner.store().write_predictions_block(contigs, np.array([m[1] for m in meta], np.int64), np.array([m[2] for m in meta], np.int64),
-                                                       np.array([m[3] for m in meta], np.int64), st.position[:n], st.index[:n], labels, phred)
+            self._predict_and_write(st, n)
             with self.owner.models_lock:
                 self.owner.chunks += n
                 self.owner.passes_run += 1

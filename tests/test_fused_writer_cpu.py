@@ -141,3 +141,67 @@ def test_polish_fused_model_failure_reaches_the_waiters(tmp_path, monkeypatch):
         t.join(10)
     assert not any(t.is_alive() for t in threads)
     assert len(errors) == 4 and all(isinstance(e, (OSError, RuntimeError)) for e in errors)
+
+
+def test_polish_gather_hands_every_chunk_to_exactly_one_pass(monkeypatch):
+    """The fused polish's shared gather buffer (polish/fused.py _Gather) without a device: sixteen workers reserve / commit
+    pieces of 1 - 40 chunks against passes of 256, a pass takes a while (so that every set is busy and the workers wait side by
+    side -- the case that once left half-filled sets behind and hung the run); every chunk reaches exactly one pass, a piece is
+    never split over two passes, no pass is larger than a set, and finish() returns."""
+    import random
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    from pepper_amd.polish import fused
+
+    class FakeSet(object):
+        def __init__(self, device, chunks, seq, features):
+            self.meta = [None] * chunks
+            self.reserved = self.done = 0
+            self.sealed = self.busy = False
+    monkeypatch.setattr(fused, "_GatherSet", FakeSet)
+    monkeypatch.setattr(fused.torch.cuda, "set_device", lambda d: None)
+    seen, sizes, lock = [], [], threading.Lock()
+
+    class Gather(fused._Gather):
+        def _predict_and_write(self, st, n):
+            time.sleep(0.004)
+            with lock:
+                seen.extend(st.meta[:n])
+                sizes.append(n)
+    owner = SimpleNamespace(PASS_CHUNKS=256, passes=ThreadPoolExecutor(max_workers=3), models_lock=threading.Lock(), chunks=0,
+                            passes_run=0, error=None, check=lambda: None, fail=lambda err: None)
+    g = Gather(owner, 0)
+    pieces = {}
+
+    def worker(w):
+        rng = random.Random(w)
+        for k in range(120):
+            n = rng.randint(1, 40)
+            st, off = g.reserve(n)
+            for j in range(n):
+                st.meta[off + j] = (w, k, j)
+            if rng.random() < 0.3:
+                time.sleep(0.001)
+            g.commit(st, n)
+            pieces[(w, k)] = n
+    threads = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(16)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert not any(t.is_alive() for t in threads), "a worker is stuck in reserve()"
+    finisher = threading.Thread(target=g.finish, daemon=True)
+    finisher.start()
+    finisher.join(30)
+    assert not finisher.is_alive(), "finish() did not return"
+    owner.passes.shutdown(wait=True)
+    total = sum(pieces.values())
+    assert len(seen) == total == owner.chunks and len(set(seen)) == total
+    assert max(sizes) <= 256 and owner.passes_run == len(sizes)
+    # a piece's chunks are adjacent inside one pass
+    at = {m: i for i, m in enumerate(seen)}
+    bounds = np.cumsum([0] + sizes)
+    for (w, k), n in pieces.items():
+        idx = [at[(w, k, j)] for j in range(n)]
+        assert idx == list(range(idx[0], idx[0] + n))
+        assert np.searchsorted(bounds, idx[0], side="right") == np.searchsorted(bounds, idx[-1], side="right")

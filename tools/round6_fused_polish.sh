@@ -6,7 +6,7 @@ timeout 1200 python -m pytest tests/test_gpu_pipeline.py -m gpu -x -q -k "fused 
 S=/dev/shm/pe2e; mkdir -p $S
 run() { # kind, bases, coverage, env...
   kind=$1; bases=$2; cov=$3; shift 3
-  env "$@" timeout 900 python tools/bench_e2e.py $kind $S/$kind $bases $cov 2 2>/dev/null | tail -1 | python -c "
+  env "$@" timeout 150 python tools/bench_e2e.py $kind $S/$kind $bases $cov 2 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$kind', '$*', d['value'], d['runs_seconds'], d['stage_walls'], {k:d['image_stage_seconds_summed_over_workers'].get(k) for k in ('chain','fused_consensus','chain_score_kernel','chain_band_kernel','fused_forward','hdf5','encode')})"
   rm -rf $S/$kind
