@@ -266,6 +266,9 @@ class UserInterfaceSupport:
                     refused_at = None
                     for r0 in range(0, n_done, per_call):           # the chain over stretches of the resident span
                         r1 = min(n_done, r0 + per_call)
+                        if consensus is not None:
+                            consensus.settle()                       # (the copies of the last run's chunks: this run overwrites them)
+                            t0 = lap("fused_consensus", t0)
                         try:
                             _rows, _live, chunks = chain.run(list(zip(starts[r0:r1], stops[r0:r1])), windows[r0:r1], region_pairs[r0:r1 + 1],
                                                              counts, realign=True, resident=resident, chunk_size=seq_len,
@@ -282,13 +285,14 @@ class UserInterfaceSupport:
                                 mine["chain_" + key[:-3]] = mine.get("chain_" + key[:-3], 0.0) + v / 1e3
                             else:
                                 mine[key] = mine.get(key, 0) + v
-                        img, pos, idx = chain.chunk_pointers()
-                        output_hdf_file.write_regions(chr_name, starts[r0:r1], stops[r0:r1], chunks, seq_len, features, img, pos, idx)
-                        t0 = lap("hdf5", t0)
                         if consensus is not None and chain.n_chunks:
+                            # (first: the gather copy then runs on the device while this thread writes the image file)
                             _img, pos_v, idx_v = chain.chunk_arrays()
                             consensus.add(chr_name, starts[r0:r1], stops[r0:r1], chunks, chain.device_chunks(), pos_v, idx_v)
                             t0 = lap("fused_consensus", t0)
+                        img, pos, idx = chain.chunk_pointers()
+                        output_hdf_file.write_regions(chr_name, starts[r0:r1], stops[r0:r1], chunks, seq_len, features, img, pos, idx)
+                        t0 = lap("hdf5", t0)
                     if refused_at is not None:
                         deep = [r for r in deep if r < refused_at]
                     if len(deep):

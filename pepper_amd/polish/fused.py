@@ -51,7 +51,11 @@ class _GatherSet(object):
 
 class _Gather(object):
     """The gather buffers of one device and the hand-over between the image workers (reserve / commit) and the pass threads."""
-    SETS = 3
+    # Gather sets per device, made on demand: a worker that finds every set being filled or run gets a new one rather than
+    # waiting, up to this many (164 MB of device memory and 262 MB of host arrays each at 16 384 chunks).  The passes share the
+    # SIMDs with the alignment kernels and fall behind while the chains run; with room to gather ahead the workers never wait
+    # for them, and what is left of the passes runs at full speed once the chains are done.
+    SETS = max(2, int(os.environ.get("PEPPER_AMD_FUSED_GATHER_SETS", 6)))
 
     def __init__(self, owner, device):
         self.owner, self.device = owner, device
@@ -291,6 +295,7 @@ class _Worker(object):
         # the gather copies run on this worker's own stream: the device's default stream is shared by every thread of the process,
         # and a copy queued there waits behind whatever another thread made it wait for (a whole model pass)
         self.copy_stream = torch.cuda.Stream(device=device)
+        self.unsettled = []                  # (set, chunks) of copies under way
 
     def add(self, contig, starts, stops, chunk_counts, device_images, position, index):
         """The chunks of one chain call: device_images = their address on the device, position / index = numpy views of the
@@ -298,6 +303,7 @@ class _Worker(object):
         interval stay together (one pass, one prediction file); a call's intervals are cut into pieces of at most a pass."""
         counts = [int(c) for c in chunk_counts]
         torch.cuda.set_device(self.device)
+        self.settle()
         r0, at = 0, 0
         while r0 < len(counts):
             r1, take = r0, 0
@@ -321,11 +327,23 @@ class _Worker(object):
                         for cid in range(counts[r]):
                             st.meta[k] = (contig, a, b, cid)
                             k += 1
-                    self.copy_stream.synchronize()             # (the chain overwrites its chunks in its next run; the pass reads the set)
-                finally:
-                    self.gather.commit(st, take)
+                except BaseException:
+                    self.gather.commit(st, take)               # (the set must not wait for ever for this piece; the run fails anyway)
+                    raise
+                # The copy is NOT waited for here: it sits in a hardware queue behind whatever kernel of another worker shares
+                # that queue (~10-20 ms), time this worker spends better writing its image file and reading its next span.
+                # settle() -- called before the chain's next run, which overwrites the source -- waits and commits.
+                self.unsettled.append((st, take))
             at += take
             r0 = r1
+
+    def settle(self):
+        """Wait for the copies add() started and hand their pieces to the gather (before the chain's buffers are written again)."""
+        if self.unsettled:
+            self.copy_stream.synchronize()
+            pieces, self.unsettled = self.unsettled, []
+            for st, take in pieces:
+                self.gather.commit(st, take)
 
     def add_host(self, region, images, positions, chunk_ids):
         """An interval that went through the host form (a pile beyond the reservoir cap, a span the packed reader refused): its
@@ -335,6 +353,7 @@ class _Worker(object):
         if n == 0:
             return
         torch.cuda.set_device(self.device)
+        self.settle()
         st, off = self.gather.reserve(n)
         try:
             block = np.ascontiguousarray(np.stack([np.asarray(im, np.uint8) for im in images]))
@@ -352,6 +371,11 @@ class _Worker(object):
         """(kept for callers of the round-5 form: the passes start by themselves)"""
 
     def close(self, failed=False):
+        try:
+            self.settle()
+        except BaseException:      # noqa: BLE001
+            if not failed:
+                raise
         if failed:
             self.owner.failed = True
         else:
