@@ -178,7 +178,8 @@ class UserInterfaceSupport:
             return now
 
         try:
-            enc = PackedEncoder.acquire(device, int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20, host_threads=1)
+            enc = PackedEncoder.acquire(device, int(os.environ.get("PEPPER_AMD_ARENA_MB", 256)) << 20, host_threads=1,
+                                        torch_stream=fused is not None)
         except _lib.PepperAmdError as err:
             # no page-locked arena to be had (memlock / cgroup limit): the host form needs none.  Not under the fused form:
             # image_generator writes images only, and polish(fused_inference=True) has no call_consensus step that would read
@@ -188,7 +189,7 @@ class UserInterfaceSupport:
                                    "fused_inference, or raise the memlock limit" % (thread_id, err)) from err
             return UserInterfaceSupport.image_generator(args, all_intervals, total_threads, thread_id)
         chain = PEPPER.PolishChain(enc)
-        consensus = fused.worker(thread_id, device) if fused is not None else None      # polish(fused_inference=True): fused.py
+        consensus = fused.worker(thread_id, device, stream=enc.stream) if fused is not None else None      # polish(fused_inference=True): fused.py
         device_inflate = os.environ.get("PEPPER_AMD_DEVICE_INFLATE", "1") != "0"
         safe = AlingerOptions.ALIGNMENT_SAFE_BASES
         seq_len, features = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT

@@ -256,8 +256,8 @@ class FusedConsensus(object):
             entry["all"].append(model)
         return entry, model
 
-    def worker(self, thread_id, device):
-        return _Worker(self, thread_id, device)
+    def worker(self, thread_id, device, stream=None):
+        return _Worker(self, thread_id, device, stream)
 
     def close(self, failed=False):
         """After make_images: the last pass, the files closed (or, after a failure anywhere, withdrawn), the handles released."""
@@ -287,14 +287,16 @@ class FusedConsensus(object):
 class _Worker(object):
     """One image worker's side: copies its chain calls' chunks into the device's shared gather buffer."""
 
-    def __init__(self, owner, thread_id, device):
+    def __init__(self, owner, thread_id, device, stream=None):
         self.owner, self.device = owner, device
         self.seq, self.features = ImageSizeOptions.SEQ_LENGTH, ImageSizeOptions.IMAGE_HEIGHT
         self.gather = owner.gather(device)
         torch.cuda.set_device(device)
-        # the gather copies run on this worker's own stream: the device's default stream is shared by every thread of the process,
-        # and a copy queued there waits behind whatever another thread made it wait for (a whole model pass)
-        self.copy_stream = torch.cuda.Stream(device=device)
+        # The gather copies run on the worker's CHAIN stream (the encoder was made on a torch stream for this): queued behind the
+        # chain's own kernels, which have finished when add() is called, they start at once.  On the device's default stream --
+        # shared by every thread of the process -- a copy waits behind whatever another thread made that stream wait for (a whole
+        # model pass); on a stream of its own it waits behind the kernels of whichever other worker shares its hardware queue.
+        self.copy_stream = stream if stream is not None else torch.cuda.Stream(device=device)
         self.unsettled = []                  # (set, chunks) of copies under way
 
     def add(self, contig, starts, stops, chunk_counts, device_images, position, index):

@@ -268,19 +268,20 @@ class PackedEncoder(object):
     _idle_lock = __import__("threading").Lock()
 
     @classmethod
-    def acquire(cls, device=0, arena_bytes=192 << 20, host_threads=1):
+    def acquire(cls, device=0, arena_bytes=192 << 20, host_threads=1, torch_stream=False):
         """An encoder from the process-wide pool (or a new one): pinning a 256 MB arena and the first device allocations cost
         ~0.15 s per worker, which a long-running process pays once.  Under a memlock / cgroup limit the page-locked arena may
         not be had at that size: the request is halved down to 16 MB before the error is passed on (a smaller arena means
         fewer intervals per call, nothing else); the callers fall back to the host-clipped form when even that fails."""
         with cls._idle_lock:
             for k, enc in enumerate(cls._idle):
-                if enc.device == device and enc.arena is not None and enc.arena.nbytes <= arena_bytes and enc.arena.nbytes >= min(arena_bytes, 16 << 20):
+                if (enc.device == device and enc.arena is not None and enc.arena.nbytes <= arena_bytes and enc.arena.nbytes >= min(arena_bytes, 16 << 20)
+                        and (enc.stream is not None) == bool(torch_stream)):
                     return cls._idle.pop(k)
         size = arena_bytes
         while True:
             try:
-                return cls(device, size, host_threads=host_threads)
+                return cls(device, size, host_threads=host_threads, torch_stream=torch_stream)
             except _lib.PepperAmdError:
                 if size <= 16 << 20:
                     raise
@@ -290,12 +291,20 @@ class PackedEncoder(object):
         with self._idle_lock:
             self._idle.append(self)
 
-    def __init__(self, device=0, arena_bytes=192 << 20, max_reads=1 << 18, max_pairs=1 << 19, host_threads=0):
+    def __init__(self, device=0, arena_bytes=192 << 20, max_reads=1 << 18, max_pairs=1 << 19, host_threads=0, torch_stream=False):
         from pepper_amd.variant.bam import PACKED_READ
         self.lib = _lib.load()
         self.device = device
         self.enc = ctypes.c_void_p()
-        _lib.check(self.lib.pa_encoder_create(device, None, ctypes.byref(self.enc)))
+        # torch_stream: the encoder works on a stream torch made (self.stream) instead of one of its own, so that a caller can queue
+        # torch operations -- a copy of the results the encoder left on the device -- right behind the encoder's kernels, in the same
+        # hardware queue (polish/fused.py: a copy on any other stream waits behind whatever shares that stream's queue)
+        self.stream = None
+        if torch_stream:
+            import torch
+            self.stream = torch.cuda.Stream(device=device)
+        _lib.check(self.lib.pa_encoder_create(device, ctypes.c_void_p(self.stream.cuda_stream) if self.stream is not None else None,
+                                              ctypes.byref(self.enc)))
         _lib.check(self.lib.pa_encoder_set_host_threads(self.enc, host_threads))
         ptr = self.lib.pa_encoder_host_arena(self.enc, arena_bytes)
         if not ptr:
