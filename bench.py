@@ -104,6 +104,7 @@ def parse():
     ap.add_argument("--no-image-legs", action="store_true",
                     help="N > 1: skip the per-rank image generation legs (variant generate_images and the polish chain on each rank's own "
                          "synthetic BAM) that follow the timed model steps")
+    ap.add_argument("--legs", default="", help="secondary block: only these legs (comma separated names of the `secondary` keys)")
     ap.add_argument("--full-line", action="store_true",
                     help="print the whole record (tens of KB) as the stdout line instead of the compact one; the whole record is "
                          "always written to gpurun_out/bench_full.json")
@@ -1048,6 +1049,12 @@ def secondary_block(args):
     import subprocess
     me = os.path.abspath(__file__)
     out = {}
+    # --legs a,b: only those legs (development runs: one leg in the context the driver's run gives it -- a child of this process)
+    only = set(filter(None, (getattr(args, "legs", "") or "").split(",")))
+    SKIP = {"error": "skipped (--legs)"}
+
+    def want(name):
+        return not only or name in only
 
     def last_json(cmd, timeout, env=None):
         t0 = time.perf_counter()
@@ -1071,7 +1078,7 @@ def secondary_block(args):
         mid = good[len(good) // 2]
         mid["_runs"] = [round(g[key], 1) for g in good]
         return mid
-    d = median_of([sys.executable, me, "--model", "polish", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--full-line"], 300)
+    d = median_of([sys.executable, me, "--model", "polish", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--full-line"], 300) if want("polish") else SKIP
     out["polish"] = d if "error" in d else {
         "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"],
         "h2d_d2h": d["config"]["h2d_d2h"], "roofline": {k: d["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
@@ -1079,7 +1086,7 @@ def secondary_block(args):
                                                                                       "hbm_GBps") if k in d["roofline"]},
         "batch128": d.get("batch128"), "device_resident": (d.get("device_resident") or {}).get("value"),
         "runs": d["_runs"], "seconds": d["_seconds"]}
-    d = median_of([sys.executable, me, "--model", "encoder", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"], 300)
+    d = median_of([sys.executable, me, "--model", "encoder", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"], 300) if want("encoder") else SKIP
     out["encoder"] = d if "error" in d else {
         "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "regions_per_step": d["config"]["regions_per_gpu_per_step"],
         "aligned_bases_per_step": d["config"]["aligned_bases_per_step"], "candidates_per_step": d["config"]["candidates_per_step"],
@@ -1087,13 +1094,13 @@ def secondary_block(args):
                                                    "issue") if k in d["roofline"]},
         "host_buffers_one_call": d["host_buffers_one_call"]["value"], "packed_host_fed": d.get("packed_host_fed"),
         "runs": d["_runs"], "seconds": d["_seconds"]}
-    d = median_of([sys.executable, me, "--model", "polish-encoder", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"], 300)
+    d = median_of([sys.executable, me, "--model", "polish-encoder", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"], 300) if want("polish_encoder") else SKIP
     out["polish_encoder"] = d if "error" in d else {
         "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "regions_per_step": d["config"]["regions_per_step"],
         "aligned_bases_per_step": d["config"]["aligned_bases_per_step"], "rows_per_step": d["config"]["rows_per_step"],
         "roofline": {k: d["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")},
         "host_buffers_one_call": d["host_buffers_one_call"]["value"], "runs": d["_runs"], "seconds": d["_seconds"]}
-    d = median_of([sys.executable, me, "--model", "realign", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"], 300)
+    d = median_of([sys.executable, me, "--model", "realign", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"], 300) if want("realign") else SKIP
     out["realign"] = d if "error" in d else {
         "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"],
         "reads_per_s_4_worker_threads": d.get("reads_per_s_4_worker_threads"), "reads_per_s_one_region_call": d.get("reads_per_s_one_region_call"),
@@ -1108,24 +1115,24 @@ def secondary_block(args):
     except OSError:
         pass
     extra = ["--dir", scratch] if scratch else []
-    out["make_images"] = make_images_leg(scratch)
+    out["make_images"] = make_images_leg(scratch) if want("make_images") else SKIP
     # the same job on a BAM as samtools writes it: zlib level 6 members, NM / MD / RG aux data in every record (32 Mb: zlib level 6
     # writes the synthetic file at a tenth of libdeflate level 1's rate)
-    lv6 = make_images_leg(scratch, level=6, tags=1, bases_default=32_000_000)
+    lv6 = make_images_leg(scratch, level=6, tags=1, bases_default=32_000_000) if want("make_images_level6") else SKIP
     out["make_images_level6"] = lv6 if "error" in lv6 else {k: lv6[k] for k in ("value", "unit", "seconds", "threads", "runs_mb_per_s", "data",
                                                                                   "stage_seconds_summed_over_workers", "synth_seconds")}
-    lvr = make_images_leg(scratch, level=6, tags=1, bases_default=32_000_000, quals=1)
+    lvr = make_images_leg(scratch, level=6, tags=1, bases_default=32_000_000, quals=1) if want("make_images_realistic") else SKIP
     out["make_images_realistic"] = lvr if "error" in lvr else {k: lvr[k] for k in ("value", "unit", "seconds", "threads", "runs_mb_per_s", "data",
                                                                                      "stage_seconds_summed_over_workers", "synth_seconds")}
-    out["polish_make_images"] = polish_make_images_leg(scratch)
+    out["polish_make_images"] = polish_make_images_leg(scratch) if want("polish_make_images") else SKIP
     # the two top entry points as one job each (stage walls inside): 256 Mb at 30x for call_variant, 64 Mb at 60x for polish
-    out["call_variant"] = e2e_leg("call_variant", scratch, 256_000_000, 30, 3, 24)
+    out["call_variant"] = e2e_leg("call_variant", scratch, 256_000_000, 30, 3, 24) if want("call_variant") else SKIP
     # ... and with image generation and inference fused (options.fused_inference: the encoder's windows go to the model on the
     # device, candidate selection runs while the predictions are written; both HDF5 stores are still written)
-    out["call_variant_fused"] = e2e_leg("call_variant_fused", scratch, 256_000_000, 30, 3, 24)
-    out["polish_e2e"] = e2e_leg("polish", scratch, 64_000_000, 60, 2, 16)
-    out["polish_e2e_fused"] = e2e_leg("polish_fused", scratch, 64_000_000, 60, 2, 16)
-    d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "8000000"], 300)
+    out["call_variant_fused"] = e2e_leg("call_variant_fused", scratch, 256_000_000, 30, 3, 24) if want("call_variant_fused") else SKIP
+    out["polish_e2e"] = e2e_leg("polish", scratch, 64_000_000, 60, 2, 16) if want("polish_e2e") else SKIP
+    out["polish_e2e_fused"] = e2e_leg("polish_fused", scratch, 64_000_000, 60, 2, 16) if want("polish_e2e_fused") else SKIP
+    d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "8000000"], 300) if want("bgzf_inflate") else SKIP
 
     def inflate_roofline(d, profile="inflate_kernel_stats.txt"):
         """Two roofs of bgzf_inflate_kernel for the launch just timed: HBM (algorithmic bytes = compressed in + inflated out) and
@@ -1179,7 +1186,7 @@ def secondary_block(args):
                 "CRC-32 against its trailer in the same wavefront's epilogue (one launch); bound by instruction "
                 "issue and the symbol-to-symbol dependency of DEFLATE, not by HBM (the bytes moved are compressed in + inflated out)"}
     # the members as samtools writes them: zlib level 6, NM / MD / RG aux data (longer matches, longer codes)
-    d6 = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "4000000", "--level", "6", "--tags", "1"], 300)
+    d6 = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "4000000", "--level", "6", "--tags", "1"], 300) if want("bgzf_inflate_level6") else SKIP
     out["bgzf_inflate_level6"] = d6 if "error" in d6 else {
         "value": d6["device_GBps_inflated"], "unit": "GB/s of inflated bytes", "kernel_ms": d6["kernel_ms"], "members": d6["members"],
         "compressed_bytes": d6["compressed_bytes"], "inflated_bytes": d6["inflated_bytes"], "identical_to_zlib": d6["sample_identical"],
@@ -1189,7 +1196,7 @@ def secondary_block(args):
     # ... and with quality strings that have run-length structure (binned plateaus, as a binning basecaller writes them): the members
     # compress > 3 x instead of 1.5 x -- more output per consumed bit, the case a real BAM is closer to
     dr = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "4000000", "--level", "6", "--tags", "1",
-                    "--quals", "1"], 300)
+                    "--quals", "1"], 300) if want("bgzf_inflate_realistic") else SKIP
     out["bgzf_inflate_realistic"] = dr if "error" in dr else {
         "value": dr["device_GBps_inflated"], "unit": "GB/s of inflated bytes", "kernel_ms": dr["kernel_ms"], "members": dr["members"],
         "compressed_bytes": dr["compressed_bytes"], "inflated_bytes": dr["inflated_bytes"],
@@ -1198,7 +1205,7 @@ def secondary_block(args):
         "cpu_baseline": {"value": dr.get("host_library_all_cores_GBps"), "unit": "GB/s of inflated bytes", "cores": dr.get("host_cores"), "kind": "port"},
         "note": "zlib level 6, NM / MD / RG aux data, run-length quality strings (tools/synth_bam quals = 1)"}
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_pipeline.py"), "--files", "16", "--windows", "524288", "--groups", "512",
-                   "--workers", "0"] + extra, 600)
+                   "--workers", "0"] + extra, 600) if want("run_inference_hdf5") else SKIP
     out["run_inference_hdf5"] = d if "error" in d else {
         "value": d["windows_per_s"], "unit": "windows/s", "windows": d["windows"], "image_bytes": d["image_bytes"], "seconds": d["seconds"],
         "mode": d["mode"], "scratch": scratch or "system temporary directory",
@@ -1207,13 +1214,13 @@ def secondary_block(args):
     # three runs over the same files, the median reported: the job is 2-3 s of sixteen host CPUs' work beside the device passes and
     # its time varies by +-15 % from run to run on one box (profiles/r03_polish_pipeline_runs_ab.json)
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_polish_pipeline.py"), "--chunks", "524288", "--files", "64",
-                   "--workers", "0,0,0", "--median"] + extra, 900)
+                   "--workers", "0,0,0", "--median"] + extra, 900) if want("call_consensus_hdf5") else SKIP
     out["call_consensus_hdf5"] = d if "error" in d else {
         "value": d["chunks_per_s"], "unit": "chunks/s", "windows_per_s": d["windows_per_s"], "chunks": d["chunks"], "seconds": d["seconds"],
         "runs_chunks_per_s": d.get("runs_chunks_per_s"), "mode": d["mode"], "scratch": scratch or "system temporary directory",
         "note": "pepper_amd.polish.call_consensus.call_consensus: image HDF5 files -> predictions HDF5, start-up included (chunk reads "
                 "bypass libhdf5, prediction files laid out by h5build.cpp, blocks of several reader lanes per device pass)"}
-    return out
+    return {k: v for k, v in out.items() if not (isinstance(v, dict) and v.get("error") == SKIP["error"])}
 
 
 def wg_syn_bench(args, world, rank, device, ranks_seen, lib, handle, pool, unit_bytes, pool_n, host_call, sync):

@@ -172,7 +172,7 @@ class FusedConsensus(object):
         self.chunks = 0
         self.passes_run = 0
         self.handles = max(1, int(os.environ.get("PEPPER_AMD_FUSED_HANDLES", self.HANDLES)))
-        self.stream_priority = int(os.environ.get("PEPPER_AMD_FUSED_STREAM_PRIORITY", -1))
+        self.stream_priority = int(os.environ.get("PEPPER_AMD_FUSED_STREAM_PRIORITY", 0))
         # the threads that run the model passes and write their predictions (the image workers only gather chunks)
         from concurrent.futures import ThreadPoolExecutor
         self.passes = ThreadPoolExecutor(max_workers=self.handles + 1, thread_name_prefix="fused-consensus-pass")
@@ -239,12 +239,16 @@ class FusedConsensus(object):
                                                                      image_features=ImageSizeOptions.IMAGE_HEIGHT,
                                                                      seq_len=ImageSizeOptions.SEQ_LENGTH,
                                                                      num_classes=ImageSizeOptions.TOTAL_LABELS)[0]
-                # The passes' stream is one of the device's HIGH-PRIORITY queues: a pass is 19 windows x a few short kernels, and on
-                # an ordinary stream every one of them waits in a hardware queue it shares with an image worker's stream behind
-                # that worker's 10 ms alignment kernel (16 queues, ~20 streams) -- 3 500 launches x ~12 ms was the whole of what
-                # the fused form lost.  (The loader's signature is the reference's: the handle is re-made with the priority.)
-                model = loaded.clone(stream_priority=self.stream_priority)
-                loaded.close()
+                # PEPPER_AMD_FUSED_STREAM_PRIORITY=-1 puts the passes' stream on the device's high-priority queues.  Measured with
+                # full-sized passes: no gain (7.8 s either way on the 64 Mb job), and the extra hardware queues push a process that
+                # already drives sixteen past what the device keeps resident (docs/LEDGER_r05.md, "Late finding") -- inside
+                # bench.py's child process the fused run was 1.2 s slower with it.  Default 0.  (The loader's signature is the
+                # reference's, so the handle is re-made when a priority is asked for.)
+                if self.stream_priority:
+                    model = loaded.clone(stream_priority=self.stream_priority)
+                    loaded.close()
+                else:
+                    model = loaded
         except BaseException as err:
             with self.models_lock:
                 entry["made"] -= 1

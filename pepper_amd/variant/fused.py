@@ -73,10 +73,10 @@ class FusedPredictor(object):
         if make:
             try:
                 torch.cuda.set_device(device)
-                # the forwards' stream is a high-priority one: on an ordinary stream each of a forward's kernels can sit in a hardware
-                # queue it shares with an image worker's stream behind that worker's encoder kernels (16 queues, ~20 streams)
+                # PEPPER_AMD_FUSED_STREAM_PRIORITY=-1: the forwards' stream on the device's high-priority queues (default 0: measured no
+                # gain, and the extra hardware queues can push a sixteen-worker process past what the device keeps resident)
                 from pepper_amd.variant.models import simple_model
-                simple_model.NEW_HANDLES.stream_priority = int(os.environ.get("PEPPER_AMD_FUSED_STREAM_PRIORITY", -1))
+                simple_model.NEW_HANDLES.stream_priority = int(os.environ.get("PEPPER_AMD_FUSED_STREAM_PRIORITY", 0))
                 try:
                     model = ModelHandler.load_simple_model_for_training(
                         self.options.model_path, image_features=ImageSizeOptions.IMAGE_HEIGHT, num_classes=ImageSizeOptions.TOTAL_LABELS,
