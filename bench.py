@@ -888,6 +888,22 @@ def polish_encoder_bench(args):
                                   "note": "pa_polish_encoder_stage_batch + run + result copy per batch: gather into page-locked blocks, one "
                                           "H2D per array, kernels, one wait, D2H of the rows"},
     }
+    # The roof that binds polish_tile_kernel: 768 workgroups are ONE round of wavefronts (6 per SIMD), so the launch is as long as its
+    # slowest wavefront's dependent chain -- the issue share and the share of their cycles the wavefronts spend waiting say so
+    # (newest committed counter pass of this command, profiles/rNN_encoder_polish_pmc.json)
+    try:
+        src, src_round = newest_profile("encoder_polish_pmc.json")
+        with open(os.path.join(REPO, src)) as fh:
+            k = json.load(fh)["kernels"]["polish_tile"]
+        simd_cycles = 1024 * avg["tile_ms"] * 1e-3 * 2.4e9
+        line["roofline"]["issue"] = {
+            "bound": "latency of one round of wavefronts (valu issue beside it)", "valu_wave_instructions": k["SQ_INSTS_VALU"],
+            "salu_wave_instructions": k.get("SQ_INSTS_SALU"), "lds_wave_instructions": k.get("SQ_INSTS_LDS"), "waves": k.get("SQ_WAVES"),
+            "frac": 4.0 * k["SQ_INSTS_VALU"] / simd_cycles, "frac_over": "kernel time (polish_tile_kernel's HIP events)",
+            "wait_share_of_wave_cycles": (k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else None,
+            "source": src, "stale": counters_stale(src_round, "encoder_polish.hip", "encoder_common.h")}
+    except Exception:       # noqa: BLE001
+        pass
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(REPO, "oracle"))
         from oracle import encoder_cpu
@@ -1098,7 +1114,8 @@ def secondary_block(args):
     out["polish_encoder"] = d if "error" in d else {
         "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "regions_per_step": d["config"]["regions_per_step"],
         "aligned_bases_per_step": d["config"]["aligned_bases_per_step"], "rows_per_step": d["config"]["rows_per_step"],
-        "roofline": {k: d["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")},
+        "roofline": {k: d["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "issue")
+                     if k in d["roofline"]},
         "host_buffers_one_call": d["host_buffers_one_call"]["value"], "runs": d["_runs"], "seconds": d["_seconds"]}
     d = median_of([sys.executable, me, "--model", "realign", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"], 300) if want("realign") else SKIP
     out["realign"] = d if "error" in d else {
