@@ -55,6 +55,12 @@ def pytest_sessionstart(session):
     instead of skipping the tests that compare with it and staying green.  A CPU run in the build container (where
     /root/reference is) builds what is missing first -- `make -C oracle ref`, the same recipe __graft_entry__.build() runs; a
     GPU run never does (/root/reference does not exist on the GPU box: the libraries travel with the snapshot or the run is red)."""
+    # (the oracle's own C restatement: built by __graft_entry__.build(); a CPU run of a checkout that has not been built yet builds
+    # it here -- two g++ calls -- instead of failing in the first test that loads it)
+    if not _gpu_run(session.config) and not all(os.path.exists(os.path.join(REPO, "oracle", n))
+                                                 for n in ("libpileup_oracle.so", "libssw_oracle.so")):
+        import subprocess
+        subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle"), "restatement"], check=False)
     if os.environ.get("PEPPER_AMD_ALLOW_MISSING_REF"):
         return
     missing = missing_reference_builds()
