@@ -1193,7 +1193,7 @@ def secondary_block(args):
         "roofline": inflate_roofline(d),
         "value": d["device_GBps_inflated"], "unit": "GB/s of inflated bytes", "kernel": "bgzf_inflate_kernel", "kernel_ms": d["kernel_ms"],
         "stale_counters": bool((inflate_roofline(d).get("stale"))),
-        "members": d["members"], "compressed_bytes": d["compressed_bytes"], "inflated_bytes": d["inflated_bytes"],
+        "members": d["members"], "wave_slot_rounds": round(d["members"] / 6144.0, 2), "compressed_bytes": d["compressed_bytes"], "inflated_bytes": d["inflated_bytes"],
         "cpu_zlib_one_core_GBps": d["zlib_one_core_GBps"], "identical_to_zlib": d["sample_identical"],
         "cpu_baseline": {"value": d.get("host_library_all_cores_GBps"), "unit": "GB/s of inflated bytes", "cores": d.get("host_cores"),
                          "kind": "port", "one_core": d.get("host_library_one_core_GBps"), "identical": d.get("identical_to_host_library"),
@@ -1203,24 +1203,30 @@ def secondary_block(args):
                 "CRC-32 against its trailer in the same wavefront's epilogue (one launch); bound by instruction "
                 "issue and the symbol-to-symbol dependency of DEFLATE, not by HBM (the bytes moved are compressed in + inflated out)"}
     # the members as samtools writes them: zlib level 6, NM / MD / RG aux data (longer matches, longer codes)
-    d6 = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "4000000", "--level", "6", "--tags", "1"], 300) if want("bgzf_inflate_level6") else SKIP
+    # (the same 8 Mb genome as the level-1 leg: a launch is whole rounds of 6 144 wavefront slots, and the 4 Mb file rounds 1-5 used
+    # here -- 6 723 members, 1.09 rounds: a full round and a nearly empty one -- measured the tail, 32 GB/s, not the kernel, 40 GB/s:
+    # profiles/r06_inflate_waves_ab.txt has both sizes side by side)
+    d6 = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "8000000", "--level", "6", "--tags", "1"], 400) if want("bgzf_inflate_level6") else SKIP
     out["bgzf_inflate_level6"] = d6 if "error" in d6 else {
         "value": d6["device_GBps_inflated"], "unit": "GB/s of inflated bytes", "kernel_ms": d6["kernel_ms"], "members": d6["members"],
         "compressed_bytes": d6["compressed_bytes"], "inflated_bytes": d6["inflated_bytes"], "identical_to_zlib": d6["sample_identical"],
         "identical_to_host_library": d6.get("identical_to_host_library"),
         "cpu_baseline": {"value": d6.get("host_library_all_cores_GBps"), "unit": "GB/s of inflated bytes", "cores": d6.get("host_cores"), "kind": "port"},
-        "note": "the same kernels on a synthetic 4 Mb / 60x BAM written with zlib level 6 and NM / MD / RG aux data in every record"}
+        "wave_slot_rounds": round(d6["members"] / 6144.0, 2),
+        "note": "the same kernel on a synthetic 8 Mb / 60x BAM written with zlib level 6 and NM / MD / RG aux data in every record "
+                "(rounds 1-5: a 4 Mb file, 1.09 rounds of wavefront slots -- 32.3 GB/s on it today)"}
     # ... and with quality strings that have run-length structure (binned plateaus, as a binning basecaller writes them): the members
     # compress > 3 x instead of 1.5 x -- more output per consumed bit, the case a real BAM is closer to
-    dr = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "4000000", "--level", "6", "--tags", "1",
-                    "--quals", "1"], 300) if want("bgzf_inflate_realistic") else SKIP
+    dr = last_json([sys.executable, os.path.join(REPO, "tools", "bench_inflate.py"), "--genome", "8000000", "--level", "6", "--tags", "1",
+                    "--quals", "1"], 400) if want("bgzf_inflate_realistic") else SKIP
     out["bgzf_inflate_realistic"] = dr if "error" in dr else {
         "value": dr["device_GBps_inflated"], "unit": "GB/s of inflated bytes", "kernel_ms": dr["kernel_ms"], "members": dr["members"],
         "compressed_bytes": dr["compressed_bytes"], "inflated_bytes": dr["inflated_bytes"],
         "compression_ratio": round(dr["inflated_bytes"] / max(1, dr["compressed_bytes"]), 2), "identical_to_zlib": dr["sample_identical"],
         "identical_to_host_library": dr.get("identical_to_host_library"),
         "cpu_baseline": {"value": dr.get("host_library_all_cores_GBps"), "unit": "GB/s of inflated bytes", "cores": dr.get("host_cores"), "kind": "port"},
-        "note": "zlib level 6, NM / MD / RG aux data, run-length quality strings (tools/synth_bam quals = 1)"}
+        "wave_slot_rounds": round(dr["members"] / 6144.0, 2),
+        "note": "zlib level 6, NM / MD / RG aux data, run-length quality strings (tools/synth_bam quals = 1), 8 Mb / 60x"}
     d = last_json([sys.executable, os.path.join(REPO, "tools", "bench_pipeline.py"), "--files", "16", "--windows", "524288", "--groups", "512",
                    "--workers", "0"] + extra, 600) if want("run_inference_hdf5") else SKIP
     out["run_inference_hdf5"] = d if "error" in d else {

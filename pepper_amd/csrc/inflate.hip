@@ -450,7 +450,8 @@ PA_DEV int long_code(uint32_t bits, const int* count, const uint16_t* syms, cons
 // what a lane found at its bit offset: the symbol's total bits (code, extra bits, for a match also the distance's) | flags
 constexpr int F_MATCH = 64, F_END = 128, F_INVALID = 256;
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
+template <int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
                                                          const int32_t* __restrict__ comp_len, const int64_t* __restrict__ out_off,
                                                          const int32_t* __restrict__ out_len, uint8_t* out_base,
                                                          int32_t* __restrict__ status, unsigned long long* dbg,
@@ -955,8 +956,14 @@ void launch_bgzf_inflate(hipStream_t stream, const uint8_t* comp, const int64_t*
                          int64_t comp_bytes, unsigned long long* debug_counts) {
     if (n_blocks <= 0) return;
     // (one launch: inflate, then every member's CRC-32 against its trailer in the same wavefront's epilogue)
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
-                       status, debug_counts, comp_bytes);
+    // wavefronts per SIMD: 6 (80 registers, no spills) by default; PA_INFLATE_WAVES=7 takes the 72-register build (A/B runs)
+    static const int waves = [] { const char* v = getenv("PA_INFLATE_WAVES"); return v && atoi(v) == 7 ? 7 : 6; }();
+    if (waves == 7)
+        hipLaunchKernelGGL(bgzf_inflate_kernel<7>, dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
+                           status, debug_counts, comp_bytes);
+    else
+        hipLaunchKernelGGL(bgzf_inflate_kernel<6>, dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
+                           status, debug_counts, comp_bytes);
 }
 
 const char* inflate_status_text(int32_t s) {
