@@ -18,7 +18,7 @@ def _bench():
 
 def test_help_and_contract_flags():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--help"], capture_output=True, text=True, check=True).stdout
-    for flag in ("--gpus", "--steps", "--warmup", "--model", "--resident-only"):
+    for flag in ("--gpus", "--steps", "--warmup", "--model", "--resident-only", "--full-line", "--legs", "--no-image-legs"):
         assert flag in out
 
 
