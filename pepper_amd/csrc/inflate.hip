@@ -120,6 +120,8 @@ struct Stream {
     int loaded;
     uint32_t pre;               // per lane
     int p;                      // bit position of the next symbol, from `words`
+    int reach = 160;            // every read at or after p reaches at most this many bits further (lane 63's three words; 64 more
+                                // with a second window)
 
     PA_DEV uint32_t fetch(int c) const {
         const int i = c * 64 + (int)threadIdx.x;
@@ -135,9 +137,8 @@ struct Stream {
         pre = fetch(loaded);
         wave_order();
     }
-    // every read at or after p reaches at most 160 bits further (lane 63's three words)
     PA_DEV void ensure() {
-        while (((p + 160) >> 11) >= loaded) {
+        while (((p + reach) >> 11) >= loaded) {
             wave_order();
             ring[(loaded & 1) * 64 + threadIdx.x] = pre;
             ++loaded;
@@ -450,12 +451,24 @@ PA_DEV int long_code(uint32_t bits, const int* count, const uint16_t* syms, cons
 // what a lane found at its bit offset: the symbol's total bits (code, extra bits, for a match also the distance's) | flags
 constexpr int F_MATCH = 64, F_END = 128, F_INVALID = 256;
 
-template <int WAVES>
+// WIDE: a step looks at TWO windows of 64 bit offsets while the steps are small (the last one wrote at most `wide_below` bytes; both
+// windows' output must fit the step's 64 output lanes, else the second one is dropped and decoded again by the next step): the
+// lookups, the walk and the prefix sums run twice, everything per step -- the stream's window, the output placement, the gather, the
+// pending store -- once for twice the symbols.  Measured (profiles/r06_inflate_wide_ab.txt, counters beside it): the steps of the
+// level-1 bench members halve (60.3 M -> 32.8 M), vector instructions fall by 12 % (8.51 G -> 7.52 G per launch), scalar ones not
+// at all (7.57 G -> 7.55 G: they are per SYMBOL -- the walk -- not per step), time by 5.6 %: per-step work was a tenth of this
+// kernel.  What binds it is what the header says: the CU's one scalar unit (7.55 G instructions / 256 CUs = 0.78 of its issue slots
+// over the launch) beside the vector units at the same 0.78.
+constexpr int WIDE_BELOW = 48;
+#ifndef PA_INFLATE_WIDE_DEFAULT
+#define PA_INFLATE_WIDE_DEFAULT 1
+#endif
+template <int WAVES, bool WIDE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
                                                          const int32_t* __restrict__ comp_len, const int64_t* __restrict__ out_off,
                                                          const int32_t* __restrict__ out_len, uint8_t* out_base,
                                                          int32_t* __restrict__ status, unsigned long long* dbg,
-                                                         int64_t comp_bytes) {
+                                                         int64_t comp_bytes, int wide_below) {
     __shared__ union Lds { Tables t; CrcTables crc; } lds;      // (the CRC tables take the Huffman tables' place in the epilogue)
     Tables& T = lds.t;
     int n_steps = 0, n_match = 0, n_fallback = 0, n_blocks_in = 0;      // statistics for PA_INFLATE_DEBUG
@@ -475,6 +488,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 
     int pos = 0;                 // bytes written
     int err = INF_OK;
+    bool wide = WIDE;            // the next step takes two windows
+    in.reach = WIDE ? 224 : 160;
     // (A wavefront's vector memory operations reach its L1 in program order: a load issued after a store of the same
     // wavefront to the same bytes returns them -- the ordinary single-thread guarantee every in-place loop relies on; the
     // tests run every RLE-like pattern, where a match reads what the instruction before it wrote.)
@@ -601,108 +616,175 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         for (bool more = true; more && !err;) {
             ++n_steps;
             in.ensure();
-            const uint64_t bits = in.bits_at(in.p + lane);
-            const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
-            const uint32_t e = T.lit_table[lo & ((1u << LIT_BITS) - 1u)];
-            const int len = (int)(e & 15u), eb = (int)((e >> 4) & 7u);
-            // as if it were a length symbol: its extra bits, the distance code behind them, that code's extra bits
-            const uint32_t behind = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(len + eb));     // (at most 15 + 7 bits in)
-            const uint32_t de = T.dist_table[behind & ((1u << DIST_BITS) - 1u)];
-            const int dlen = (int)(de & 15u), deb = (int)((de >> 4) & 15u);
-            // Selects, not branches, and every select on ONE comparison: a lane mask is a scalar register pair, and combining
-            // two of them is work for the scalar unit -- the unit this kernel is bound by.
-            const int total_m = (len + eb + dlen + deb) | F_MATCH;
-            const int info_m = de == 0u ? F_INVALID : total_m;
-            const int info_l = eb == 7 ? (len | F_END) : info_m;
-            const int info_e = (e & 128u) ? info_l : len;
-            int info = e == 0u ? F_INVALID : info_e;
-            const int xlen = (int)__builtin_amdgcn_ubfe(lo, (uint32_t)len, (uint32_t)eb);
-            int val = (int)(e >> 8) + ((e & 128u) ? 3 + xlen : 0);
-            int dist = (int)(de >> 8) + (int)__builtin_amdgcn_ubfe(behind, (uint32_t)dlen, (uint32_t)deb);
-            // (eight scalar instructions per symbol, written out: the scalar unit is shared by the CU's four SIMDs and is the
-            // unit this kernel keeps busiest -- the compiler's version of the loop took fourteen)
-            unsigned long long chain = 0;
-            int k = 0, f, stop = 0;
-            for (;;) {
-                asm volatile("1:\n\t"
-                             "v_readlane_b32 %[f], %[info], %[k]\n\t"
-                             "s_cmpk_gt_i32 %[f], 0x7f\n\t"
-                             "s_cbranch_scc1 2f\n\t"
-                             "s_bitset1_b64 %[chain], %[k]\n\t"
-                             "s_and_b32 %[f], %[f], 63\n\t"
-                             "s_add_i32 %[k], %[k], %[f]\n\t"
-                             "s_cmpk_lt_i32 %[k], 64\n\t"
-                             "s_cbranch_scc1 1b\n\t"
-                             "s_mov_b32 %[f], 0\n"
-                             "2:\n\t"
-                             : [chain] "+s"(chain), [k] "+s"(k), [f] "=&s"(f)
-                             : [info] "v"(info)
-                             : "scc");
-                if (k >= 64 || !(f & F_INVALID)) break;
-                // Offset k starts a symbol the lanes could not look up: a code longer than a primary table (7.7 % of the steps of a
-                // level-6 member; they used to end the step and take a bit-by-bit path).  Worked out here from the lane's own 64
-                // bits, written back into lane k, and the walk goes on from k.
-                ++n_fallback;
-                const uint32_t lo_k = (uint32_t)__builtin_amdgcn_readlane((int)lo, k), hi_k = (uint32_t)__builtin_amdgcn_readlane((int)hi, k);
-                uint32_t e_k = (uint32_t)uni((int)T.lit_table[lo_k & ((1u << LIT_BITS) - 1u)]);
-                if (e_k == 0u) {
-                    int used;
-                    const int sym = long_code(lo_k, T.lit_count, T.lit_sym, T.lit_first, T.lit_index, LIT_BITS + 1, &used);
-                    if (sym < 0) break;
-                    e_k = table_entry(LITLEN, sym, used);
-                    if (e_k == 0u) break;                              // (symbols 286 / 287: the per-symbol path names the error)
-                }
-                const int len_k = (int)(e_k & 15u), eb_k = (int)((e_k >> 4) & 7u);
-                int info_k, val_k, dist_k = 0;
-                if (!(e_k & 128u)) {
-                    info_k = len_k;
-                    val_k = (int)(e_k >> 8);
-                } else if (eb_k == 7) {
-                    info_k = len_k | F_END;
-                    val_k = 0;
-                } else {
-                    const uint32_t behind_k = __builtin_amdgcn_alignbit(hi_k, lo_k, (uint32_t)(len_k + eb_k));
-                    uint32_t de_k = (uint32_t)uni((int)T.dist_table[behind_k & ((1u << DIST_BITS) - 1u)]);
-                    if (de_k == 0u) {
+            // what starts at a bit offset: the symbol's bits | flags, its literal / length, its distance
+            auto lookup = [&](uint32_t lo, uint32_t hi, int& info, int& val, int& dist) {
+                const uint32_t e = T.lit_table[lo & ((1u << LIT_BITS) - 1u)];
+                const int len = (int)(e & 15u), eb = (int)((e >> 4) & 7u);
+                // as if it were a length symbol: its extra bits, the distance code behind them, that code's extra bits
+                const uint32_t behind = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(len + eb));     // (at most 15 + 7 bits in)
+                const uint32_t de = T.dist_table[behind & ((1u << DIST_BITS) - 1u)];
+                const int dlen = (int)(de & 15u), deb = (int)((de >> 4) & 15u);
+                // Selects, not branches, and every select on ONE comparison: a lane mask is a scalar register pair, and combining
+                // two of them is work for the scalar unit -- the unit this kernel is bound by.
+                const int total_m = (len + eb + dlen + deb) | F_MATCH;
+                const int info_m = de == 0u ? F_INVALID : total_m;
+                const int info_l = eb == 7 ? (len | F_END) : info_m;
+                const int info_e = (e & 128u) ? info_l : len;
+                info = e == 0u ? F_INVALID : info_e;
+                const int xlen = (int)__builtin_amdgcn_ubfe(lo, (uint32_t)len, (uint32_t)eb);
+                val = (int)(e >> 8) + ((e & 128u) ? 3 + xlen : 0);
+                dist = (int)(de >> 8) + (int)__builtin_amdgcn_ubfe(behind, (uint32_t)dlen, (uint32_t)deb);
+            };
+            // Follow the symbols of a window of 64 bit offsets from offset k on (eight scalar instructions per symbol, written out:
+            // the scalar unit is shared by the CU's four SIMDs and is the unit this kernel keeps busiest -- the compiler's version of
+            // the loop took fourteen).  An offset whose code is longer than a primary table is worked out from the stream's bits at
+            // that offset (long_code: all candidate lengths at once), written into lane k, and the walk goes on.  Ends with k >= 64,
+            // or with f = what stopped it at offset k (the end-of-block code, or bits that are no code of the block's set).
+            auto walk = [&](int base, int& info, int& val, int& dist, unsigned long long& chain, int& k, int& f) {
+                for (;;) {
+                    asm volatile("1:\n\t"
+                                 "v_readlane_b32 %[f], %[info], %[k]\n\t"
+                                 "s_cmpk_gt_i32 %[f], 0x7f\n\t"
+                                 "s_cbranch_scc1 2f\n\t"
+                                 "s_bitset1_b64 %[chain], %[k]\n\t"
+                                 "s_and_b32 %[f], %[f], 63\n\t"
+                                 "s_add_i32 %[k], %[k], %[f]\n\t"
+                                 "s_cmpk_lt_i32 %[k], 64\n\t"
+                                 "s_cbranch_scc1 1b\n\t"
+                                 "s_mov_b32 %[f], 0\n"
+                                 "2:\n\t"
+                                 : [chain] "+s"(chain), [k] "+s"(k), [f] "=&s"(f)
+                                 : [info] "v"(info)
+                                 : "scc");
+                    if (k >= 64 || !(f & F_INVALID)) return;
+                    ++n_fallback;
+                    const uint64_t bits_k = in.bits_at(in.p + base + k);            // (uniform: every lane reads the same three words)
+                    const uint32_t lo_k = (uint32_t)uni((int)(uint32_t)bits_k), hi_k = (uint32_t)uni((int)(uint32_t)(bits_k >> 32));
+                    uint32_t e_k = (uint32_t)uni((int)T.lit_table[lo_k & ((1u << LIT_BITS) - 1u)]);
+                    if (e_k == 0u) {
                         int used;
-                        const int ds = long_code(behind_k, T.dist_count, T.dist_sym, T.dist_first, T.dist_index, DIST_BITS + 1, &used);
-                        if (ds < 0) break;
-                        de_k = table_entry(DIST, ds, used);
-                        if (de_k == 0u) break;                         // (distance symbols 30 / 31)
+                        const int sym = long_code(lo_k, T.lit_count, T.lit_sym, T.lit_first, T.lit_index, LIT_BITS + 1, &used);
+                        if (sym < 0) return;
+                        e_k = table_entry(LITLEN, sym, used);
+                        if (e_k == 0u) return;                             // (symbols 286 / 287: the per-symbol path names the error)
                     }
-                    const int dlen_k = (int)(de_k & 15u), deb_k = (int)((de_k >> 4) & 15u);
-                    info_k = (len_k + eb_k + dlen_k + deb_k) | F_MATCH;
-                    val_k = (int)(e_k >> 8) + 3 + (int)__builtin_amdgcn_ubfe(lo_k, (uint32_t)len_k, (uint32_t)eb_k);
-                    dist_k = (int)(de_k >> 8) + (int)__builtin_amdgcn_ubfe(behind_k, (uint32_t)dlen_k, (uint32_t)deb_k);
+                    const int len_k = (int)(e_k & 15u), eb_k = (int)((e_k >> 4) & 7u);
+                    int info_k, val_k, dist_k = 0;
+                    if (!(e_k & 128u)) {
+                        info_k = len_k;
+                        val_k = (int)(e_k >> 8);
+                    } else if (eb_k == 7) {
+                        info_k = len_k | F_END;
+                        val_k = 0;
+                    } else {
+                        const uint32_t behind_k = __builtin_amdgcn_alignbit(hi_k, lo_k, (uint32_t)(len_k + eb_k));
+                        uint32_t de_k = (uint32_t)uni((int)T.dist_table[behind_k & ((1u << DIST_BITS) - 1u)]);
+                        if (de_k == 0u) {
+                            int used;
+                            const int ds = long_code(behind_k, T.dist_count, T.dist_sym, T.dist_first, T.dist_index, DIST_BITS + 1, &used);
+                            if (ds < 0) return;
+                            de_k = table_entry(DIST, ds, used);
+                            if (de_k == 0u) return;                        // (distance symbols 30 / 31)
+                        }
+                        const int dlen_k = (int)(de_k & 15u), deb_k = (int)((de_k >> 4) & 15u);
+                        info_k = (len_k + eb_k + dlen_k + deb_k) | F_MATCH;
+                        val_k = (int)(e_k >> 8) + 3 + (int)__builtin_amdgcn_ubfe(lo_k, (uint32_t)len_k, (uint32_t)eb_k);
+                        dist_k = (int)(de_k >> 8) + (int)__builtin_amdgcn_ubfe(behind_k, (uint32_t)dlen_k, (uint32_t)deb_k);
+                    }
+                    const bool here = lane == k;
+                    info = here ? info_k : info;
+                    val = here ? val_k : val;
+                    dist = here ? dist_k : dist;
                 }
-                const bool here = lane == k;
-                info = here ? info_k : info;
-                val = here ? val_k : val;
-                dist = here ? dist_k : dist;
+            };
+            // what a lane is as a symbol of the step: 0 nothing (or the end code: it writes nothing), 1 a literal, 2 a match
+            auto kind_of = [&](unsigned long long chain, int info) {
+                const int on = (int)((chain >> lane) & 1ull);
+                return on ? (int)((0x021u >> (__builtin_amdgcn_ubfe((uint32_t)info, 6u, 2u) << 2)) & 3u) : 0;
+            };
+            // ---- window A: the 64 bit offsets from p; window B (WIDE, when the steps are small): the 64 behind them ----
+            int info, val, dist;
+            {
+                const uint64_t bits = in.bits_at(in.p + lane);
+                lookup((uint32_t)bits, (uint32_t)(bits >> 32), info, val, dist);
             }
+            int info_b = F_INVALID, val_b = 0, dist_b = 0;
+            const bool two = WIDE && wide;                  // (uniform)
+            if (two) {
+                const uint64_t bits = in.bits_at(in.p + 64 + lane);
+                lookup((uint32_t)bits, (uint32_t)(bits >> 32), info_b, val_b, dist_b);
+            }
+            unsigned long long chain = 0, chain_b = 0;
+            int k = 0, f, stop = 0;
+            walk(0, info, val, dist, chain, k, f);
             if (k < 64) {                                   // the end-of-block code, or something that is no code of the block's set
                 if (f & F_END) { chain |= 1ull << k; k += f & 63; stop = 1; }
                 else stop = 2;
             }
-            // what this lane is as a symbol of the step: 0 nothing (or the end code: it writes nothing), 1 a literal, 2 a match
-            const int on = (int)((chain >> lane) & 1ull);
-            const int kind = on ? (int)((0x021u >> (__builtin_amdgcn_ubfe((uint32_t)info, 6u, 2u) << 2)) & 3u) : 0;
+            int consumed = k, k_b = 0, stop_b = 0;
+            bool with_b = two && stop == 0;                 // (window A ran through: the next symbol starts at offset k - 64 of B)
+            if (with_b) {
+                k_b = k - 64;
+                walk(64, info_b, val_b, dist_b, chain_b, k_b, f);
+                if (k_b < 64) {
+                    if (f & F_END) { chain_b |= 1ull << k_b; k_b += f & 63; stop_b = 1; }
+                    else stop_b = 2;
+                }
+            }
+            const int kind = kind_of(chain, info);
             const bool is_lit = kind == 1, is_match = kind == 2;
             unsigned long long matches = __ballot(is_match);
             const unsigned long long lits = __ballot(is_lit);
+            int kind_b = 0, off_b = 0, produced_b = 0;
+            bool is_lit_b = false, is_match_b = false;
+            unsigned long long matches_b = 0, lits_b = 0;
+            if (with_b) {
+                kind_b = kind_of(chain_b, info_b);
+                is_lit_b = kind_b == 1;
+                is_match_b = kind_b == 2;
+                matches_b = __ballot(is_match_b);
+                lits_b = __ballot(is_lit_b);
+            }
             int off, produced;
-            if (matches == 0) {
+            if ((matches | matches_b) == 0) {
                 off = __popcll(lits & below);
                 produced = __popcll(lits);
+                if (with_b) {
+                    off_b = produced + __popcll(lits_b & below);
+                    produced_b = __popcll(lits_b);
+                }
             } else {
                 const int mine = is_lit ? 1 : (is_match ? val : 0);
                 const int incl = wave_scan_add(mine);
                 off = incl - mine;
                 produced = __builtin_amdgcn_readlane(incl, 63);
+                if (with_b) {
+                    const int mine_b = is_lit_b ? 1 : (is_match_b ? val_b : 0);
+                    const int incl_b = wave_scan_add(mine_b);
+                    off_b = produced + incl_b - mine_b;
+                    produced_b = __builtin_amdgcn_readlane(incl_b, 63);
+                }
             }
+            if (with_b && produced + produced_b > 64) {
+                // too much for one step's 64 output lanes: window B is dropped (its symbols are decoded again by the next step)
+                with_b = false;
+                matches_b = 0;
+                produced_b = 0;
+            }
+            if (with_b) {
+                consumed = 64 + k_b;
+                stop = stop_b;
+                produced += produced_b;
+            } else {
+                is_lit_b = is_match_b = false;
+                kind_b = 0;
+            }
+            if (WIDE) wide = produced <= wide_below;         // (the next step takes two windows while the steps stay small)
+            k = consumed;
             if (pos + produced > olen) { err = INF_OUTPUT; break; }
-            if (matches == 0) {
+            if ((matches | matches_b) == 0) {
                 if (is_lit) out[pos + off] = (uint8_t)val;            // (no read of memory: whatever is pending stays pending)
+                if (is_lit_b) out[pos + off_b] = (uint8_t)val_b;
             } else if (produced <= 64) {
                 // Every output byte of the step on its own lane: which symbol it belongs to (the symbols mark their first
                 // byte; a prefix maximum spreads the mark), then a literal's value or a match byte's source -- memory in front
@@ -710,11 +792,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 T.scratch[lane] = 0xff;
                 wave_order();
                 if (kind != 0) T.scratch[off] = (uint8_t)lane;
+                if (kind_b != 0) T.scratch[off_b] = (uint8_t)(64 + lane);
                 wave_order();
                 const int mark = T.scratch[lane];
                 const int packed = wave_scan_max(mark != 0xff ? (lane << 8 | mark) : -1);
                 const int start = packed >> 8;
-                const int word = __builtin_amdgcn_ds_bpermute((packed & 255) << 2, is_match ? (val | dist << 9 | 1 << 25) : val);
+                int word = __builtin_amdgcn_ds_bpermute((packed & 63) << 2, is_match ? (val | dist << 9 | 1 << 25) : val);
+                if (with_b) {
+                    const int word_b = __builtin_amdgcn_ds_bpermute((packed & 63) << 2, is_match_b ? (val_b | dist_b << 9 | 1 << 25) : val_b);
+                    word = (packed & 64) ? word_b : word;
+                }
                 const int mi = lane < produced ? (word >> 25) & 1 : 0;            // this byte comes from a match
                 const bool m = mi != 0;
                 const int sval = word & 511, d = (word >> 9) & 0xffff;
@@ -734,7 +821,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                         root = next;
                     }
                 }
-                n_match += __popcll(matches);
+                n_match += __popcll(matches) + __popcll(matches_b);
                 if (pend_n && __ballot((from_mem ? src : -1) >= pend_pos)) complete();
                 uint8_t b = 0;
                 if (from_mem) b = out[src];
@@ -746,7 +833,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 pend_pos = pos;
                 matches = 0;
             } else {
-                // a step of more than 64 bytes (long matches): the literals, then match by match in order
+                // a step of more than 64 bytes (long matches; window A alone): the literals, then match by match in order
                 complete();
                 if (is_lit) out[pos + off] = (uint8_t)val;
                 while (matches) {
@@ -956,14 +1043,15 @@ void launch_bgzf_inflate(hipStream_t stream, const uint8_t* comp, const int64_t*
                          int64_t comp_bytes, unsigned long long* debug_counts) {
     if (n_blocks <= 0) return;
     // (one launch: inflate, then every member's CRC-32 against its trailer in the same wavefront's epilogue)
-    // wavefronts per SIMD: 6 (80 registers, no spills) by default; PA_INFLATE_WAVES=7 takes the 72-register build (A/B runs)
-    static const int waves = [] { const char* v = getenv("PA_INFLATE_WAVES"); return v && atoi(v) == 7 ? 7 : 6; }();
-    if (waves == 7)
-        hipLaunchKernelGGL(bgzf_inflate_kernel<7>, dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
-                           status, debug_counts, comp_bytes);
+    // PA_INFLATE_WIDE=0 / 1: the one-window / two-window step (A/B runs; the default is what measured faster)
+    static const int wide = [] { const char* v = getenv("PA_INFLATE_WIDE"); return v ? atoi(v) != 0 : PA_INFLATE_WIDE_DEFAULT; }();
+    static const int below = [] { const char* v = getenv("PA_INFLATE_WIDE_BELOW"); return v ? atoi(v) : WIDE_BELOW; }();
+    if (wide)
+        hipLaunchKernelGGL((bgzf_inflate_kernel<6, true>), dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
+                           status, debug_counts, comp_bytes, below);
     else
-        hipLaunchKernelGGL(bgzf_inflate_kernel<6>, dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
-                           status, debug_counts, comp_bytes);
+        hipLaunchKernelGGL((bgzf_inflate_kernel<6, false>), dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
+                           status, debug_counts, comp_bytes, below);
 }
 
 const char* inflate_status_text(int32_t s) {

@@ -281,6 +281,22 @@ def test_a_flipped_payload_bit_fails_the_members_crc():
         assert inf.inflate(bytes(fixed), block_table(bytes(fixed))).tobytes() == text
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("wide,below", [("0", "48"), ("1", "1"), ("1", "64")])
+def test_every_case_in_the_other_step_forms(wide, below):
+    """PA_INFLATE_WIDE / PA_INFLATE_WIDE_BELOW pin the kernel's step form for a whole process (they are read once): every case of
+    this module through the one-window step, through the two-window step that falls back to one window after every step that wrote
+    more than a byte (the switch between the forms at every other step), and through the always-two-window step.  The default
+    (two windows while a step writes at most 48 bytes) is what the cases above ran."""
+    import sys
+    if os.environ.get("PEPPER_AMD_INFLATE_FORMS_CHILD") == "1":
+        pytest.skip("the child run itself")
+    env = dict(os.environ, PA_INFLATE_WIDE=wide, PA_INFLATE_WIDE_BELOW=below, PEPPER_AMD_INFLATE_FORMS_CHILD="1")
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, cwd=ROOT)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-2000:]
+
+
 def test_block_table_reads_the_member_headers():
     a, b = member(b"hello" * 100, 6), member(b"", 6, extra_subfield=True)
     comp_off, comp_len, out_off, out_len = block_table(a + b + EOF_MEMBER, base=10)
