@@ -448,8 +448,8 @@ PA_DEV int long_code(uint32_t bits, const int* count, const uint16_t* syms, cons
     return __builtin_amdgcn_readlane(sym, w);
 }
 
-// what a lane found at its bit offset: the symbol's total bits (code, extra bits, for a match also the distance's) | flags
-constexpr int F_MATCH = 64, F_END = 128, F_INVALID = 256;
+// what a lane found at its bit offset: the walk's advance (the symbol's total bits: code, extra bits, for a match also the distance's)
+constexpr int A_END = 64, A_INVALID = 128;      // (an ordinary symbol advances by its bits: at most 15 + 5 + 15 + 13 = 48)
 
 // WIDE: a step looks at TWO windows of 64 bit offsets while the steps are small (the last one wrote at most `wide_below` bytes; both
 // windows' output must fit the step's 64 output lanes, else the second one is dropped and decoded again by the next step): the
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             ++n_steps;
             in.ensure();
             // what starts at a bit offset: the symbol's bits | flags, its literal / length, its distance
-            auto lookup = [&](uint32_t lo, uint32_t hi, int& info, int& val, int& dist) {
+            auto lookup = [&](uint32_t lo, uint32_t hi, int& adv, int& kind, int& val, int& dist) {
                 const uint32_t e = T.lit_table[lo & ((1u << LIT_BITS) - 1u)];
                 const int len = (int)(e & 15u), eb = (int)((e >> 4) & 7u);
                 // as if it were a length symbol: its extra bits, the distance code behind them, that code's extra bits
@@ -626,11 +626,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 const int dlen = (int)(de & 15u), deb = (int)((de >> 4) & 15u);
                 // Selects, not branches, and every select on ONE comparison: a lane mask is a scalar register pair, and combining
                 // two of them is work for the scalar unit -- the unit this kernel is bound by.
-                const int total_m = (len + eb + dlen + deb) | F_MATCH;
-                const int info_m = de == 0u ? F_INVALID : total_m;
-                const int info_l = eb == 7 ? (len | F_END) : info_m;
-                const int info_e = (e & 128u) ? info_l : len;
-                info = e == 0u ? F_INVALID : info_e;
+                // adv: what the walk adds to its offset -- the symbol's bits (at most 48), A_END | its code length for the end-of-block
+                // code, A_INVALID for bits the tables do not hold: both of those end the walk by themselves (>= 64).  kind: 1 a
+                // literal, 2 a match, 0 neither.
+                const int total_m = len + eb + dlen + deb;
+                const int adv_m = de == 0u ? A_INVALID : total_m;
+                const int adv_l = eb == 7 ? (len | A_END) : adv_m;
+                const int adv_e = (e & 128u) ? adv_l : len;
+                adv = e == 0u ? A_INVALID : adv_e;
+                const int kind_l = adv_l < 64 ? 2 : 0;
+                const int kind_e = (e & 128u) ? kind_l : 1;
+                kind = e == 0u ? 0 : kind_e;
                 const int xlen = (int)__builtin_amdgcn_ubfe(lo, (uint32_t)len, (uint32_t)eb);
                 val = (int)(e >> 8) + ((e & 128u) ? 3 + xlen : 0);
                 dist = (int)(de >> 8) + (int)__builtin_amdgcn_ubfe(behind, (uint32_t)dlen, (uint32_t)deb);
@@ -640,23 +646,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             // the loop took fourteen).  An offset whose code is longer than a primary table is worked out from the stream's bits at
             // that offset (long_code: all candidate lengths at once), written into lane k, and the walk goes on.  Ends with k >= 64,
             // or with f = what stopped it at offset k (the end-of-block code, or bits that are no code of the block's set).
-            auto walk = [&](int base, int& info, int& val, int& dist, unsigned long long& chain, int& k, int& f) {
+            auto walk = [&](int base, int& adv, int& kind, int& val, int& dist, unsigned long long& chain, int& k, int& f) {
                 for (;;) {
+                    // four scalar instructions per symbol: the end-of-block code and undecodable bits carry an advance of 64 or more, so
+                    // ONE test ends the walk for them as for the window's end; which it was is sorted out behind the loop
                     asm volatile("1:\n\t"
-                                 "v_readlane_b32 %[f], %[info], %[k]\n\t"
-                                 "s_cmpk_gt_i32 %[f], 0x7f\n\t"
-                                 "s_cbranch_scc1 2f\n\t"
+                                 "v_readlane_b32 %[f], %[adv], %[k]\n\t"
                                  "s_bitset1_b64 %[chain], %[k]\n\t"
-                                 "s_and_b32 %[f], %[f], 63\n\t"
                                  "s_add_i32 %[k], %[k], %[f]\n\t"
                                  "s_cmpk_lt_i32 %[k], 64\n\t"
                                  "s_cbranch_scc1 1b\n\t"
-                                 "s_mov_b32 %[f], 0\n"
-                                 "2:\n\t"
                                  : [chain] "+s"(chain), [k] "+s"(k), [f] "=&s"(f)
-                                 : [info] "v"(info)
+                                 : [adv] "v"(adv)
                                  : "scc");
-                    if (k >= 64 || !(f & F_INVALID)) return;
+                    if (f < 64) return;                      // the window ran out behind an ordinary symbol: k >= 64
+                    k -= f;                                  // the offset of what stopped the walk; it is no symbol of the step
+                    chain &= ~(1ull << k);
+                    if (f < A_INVALID) return;               // the end-of-block code: f = A_END | its length
                     ++n_fallback;
                     const uint64_t bits_k = in.bits_at(in.p + base + k);            // (uniform: every lane reads the same three words)
                     const uint32_t lo_k = (uint32_t)uni((int)(uint32_t)bits_k), hi_k = (uint32_t)uni((int)(uint32_t)(bits_k >> 32));
@@ -669,12 +675,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                         if (e_k == 0u) return;                             // (symbols 286 / 287: the per-symbol path names the error)
                     }
                     const int len_k = (int)(e_k & 15u), eb_k = (int)((e_k >> 4) & 7u);
-                    int info_k, val_k, dist_k = 0;
+                    int adv_k, kind_k, val_k, dist_k = 0;
                     if (!(e_k & 128u)) {
-                        info_k = len_k;
+                        adv_k = len_k;
+                        kind_k = 1;
                         val_k = (int)(e_k >> 8);
                     } else if (eb_k == 7) {
-                        info_k = len_k | F_END;
+                        adv_k = len_k | A_END;
+                        kind_k = 0;
                         val_k = 0;
                     } else {
                         const uint32_t behind_k = __builtin_amdgcn_alignbit(hi_k, lo_k, (uint32_t)(len_k + eb_k));
@@ -687,51 +695,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                             if (de_k == 0u) return;                        // (distance symbols 30 / 31)
                         }
                         const int dlen_k = (int)(de_k & 15u), deb_k = (int)((de_k >> 4) & 15u);
-                        info_k = (len_k + eb_k + dlen_k + deb_k) | F_MATCH;
+                        adv_k = len_k + eb_k + dlen_k + deb_k;
+                        kind_k = 2;
                         val_k = (int)(e_k >> 8) + 3 + (int)__builtin_amdgcn_ubfe(lo_k, (uint32_t)len_k, (uint32_t)eb_k);
                         dist_k = (int)(de_k >> 8) + (int)__builtin_amdgcn_ubfe(behind_k, (uint32_t)dlen_k, (uint32_t)deb_k);
                     }
                     const bool here = lane == k;
-                    info = here ? info_k : info;
+                    adv = here ? adv_k : adv;
+                    kind = here ? kind_k : kind;
                     val = here ? val_k : val;
                     dist = here ? dist_k : dist;
                 }
             };
             // what a lane is as a symbol of the step: 0 nothing (or the end code: it writes nothing), 1 a literal, 2 a match
-            auto kind_of = [&](unsigned long long chain, int info) {
+            auto kind_of = [&](unsigned long long chain, int kind) {
                 const int on = (int)((chain >> lane) & 1ull);
-                return on ? (int)((0x021u >> (__builtin_amdgcn_ubfe((uint32_t)info, 6u, 2u) << 2)) & 3u) : 0;
+                return on ? kind : 0;
             };
             // ---- window A: the 64 bit offsets from p; window B (WIDE, when the steps are small): the 64 behind them ----
-            int info, val, dist;
+            int adv, kindv, val, dist;
             {
                 const uint64_t bits = in.bits_at(in.p + lane);
-                lookup((uint32_t)bits, (uint32_t)(bits >> 32), info, val, dist);
+                lookup((uint32_t)bits, (uint32_t)(bits >> 32), adv, kindv, val, dist);
             }
-            int info_b = F_INVALID, val_b = 0, dist_b = 0;
+            int adv_b = A_INVALID, kindv_b = 0, val_b = 0, dist_b = 0;
             const bool two = WIDE && wide;                  // (uniform)
             if (two) {
                 const uint64_t bits = in.bits_at(in.p + 64 + lane);
-                lookup((uint32_t)bits, (uint32_t)(bits >> 32), info_b, val_b, dist_b);
+                lookup((uint32_t)bits, (uint32_t)(bits >> 32), adv_b, kindv_b, val_b, dist_b);
             }
             unsigned long long chain = 0, chain_b = 0;
             int k = 0, f, stop = 0;
-            walk(0, info, val, dist, chain, k, f);
+            walk(0, adv, kindv, val, dist, chain, k, f);
             if (k < 64) {                                   // the end-of-block code, or something that is no code of the block's set
-                if (f & F_END) { chain |= 1ull << k; k += f & 63; stop = 1; }
+                if (f < A_INVALID) { k += f & 15; stop = 1; }
                 else stop = 2;
             }
             int consumed = k, k_b = 0, stop_b = 0;
             bool with_b = two && stop == 0;                 // (window A ran through: the next symbol starts at offset k - 64 of B)
             if (with_b) {
                 k_b = k - 64;
-                walk(64, info_b, val_b, dist_b, chain_b, k_b, f);
+                walk(64, adv_b, kindv_b, val_b, dist_b, chain_b, k_b, f);
                 if (k_b < 64) {
-                    if (f & F_END) { chain_b |= 1ull << k_b; k_b += f & 63; stop_b = 1; }
+                    if (f < A_INVALID) { k_b += f & 15; stop_b = 1; }
                     else stop_b = 2;
                 }
             }
-            const int kind = kind_of(chain, info);
+            const int kind = kind_of(chain, kindv);
             const bool is_lit = kind == 1, is_match = kind == 2;
             unsigned long long matches = __ballot(is_match);
             const unsigned long long lits = __ballot(is_lit);
@@ -739,7 +749,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             bool is_lit_b = false, is_match_b = false;
             unsigned long long matches_b = 0, lits_b = 0;
             if (with_b) {
-                kind_b = kind_of(chain_b, info_b);
+                kind_b = kind_of(chain_b, kindv_b);
                 is_lit_b = kind_b == 1;
                 is_match_b = kind_b == 2;
                 matches_b = __ballot(is_match_b);
