@@ -1183,6 +1183,8 @@ def secondary_block(args):
                              "salu_wave_instructions": ins["SQ_INSTS_SALU"] * scale, "lds_wave_instructions": ins["SQ_INSTS_LDS"] * scale,
                              "cycles_per_valu_instruction": 4, "simd_cycles_available": simd_cycles,
                              "frac": 4.0 * ins["SQ_INSTS_VALU"] * scale / simd_cycles,
+                             # the CU's ONE scalar unit (one instruction per cycle for its four SIMDs): the unit the symbol walk lives on
+                             "scalar_unit_frac": ins["SQ_INSTS_SALU"] * scale / (256 * d["kernel_ms"] * 1e-3 * 2.4e9),
                              "wait_share_of_wave_cycles": ins["SQ_WAIT_ANY"] / ins["SQ_WAVE_CYCLES"] if ins.get("SQ_WAVE_CYCLES") else None,
                              "source": src, "stale": stale}
             roof["stale"] = stale
