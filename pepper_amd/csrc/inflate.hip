@@ -61,6 +61,9 @@ namespace {
 constexpr int LIT_BITS = 10, DIST_BITS = 8, CL_BITS = 7;
 constexpr int MAX_LIT = 288, MAX_DIST = 32;
 constexpr int RING_WORDS = 128;                  // two chunks of 64 words of the compressed stream
+constexpr int RING_MIRROR = 8;                   // ... and its first words once more behind them: a read of up to 5 words from any word
+                                                 // of the ring is then five consecutive addresses (no wrap per word: two ds_read2 + one
+                                                 // ds_read from ONE address instead of five masked ones)
 
 enum InflateStatus : int32_t {
     INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_STORED_LEN = 2, INF_OVERSUBSCRIBED = 3, INF_NO_END_CODE = 4, INF_BAD_CODE = 5,
@@ -78,7 +81,7 @@ struct Tables {
     int lit_first[16], lit_index[16], dist_first[16], dist_index[16];     // per code length: the first canonical code, its symbol's place in *_sym
     uint8_t lens[MAX_LIT + MAX_DIST + 16];        // literal/length lengths, then the distance lengths
     uint8_t cl_lens[20];
-    uint32_t ring[RING_WORDS];
+    uint32_t ring[RING_WORDS + RING_MIRROR];
     uint8_t scratch[64];                          // per output byte of a step: the lane of the symbol that starts there
 };
 
@@ -123,6 +126,10 @@ struct Stream {
     int reach = 160;            // every read at or after p reaches at most this many bits further (lane 63's three words; 64 more
                                 // with a second window)
 
+    PA_DEV void store_chunk(int c, uint32_t v) {
+        ring[(c & 1) * 64 + threadIdx.x] = v;
+        if (!(c & 1) && threadIdx.x < RING_MIRROR) ring[RING_WORDS + threadIdx.x] = v;      // (the mirror of the ring's first words)
+    }
     PA_DEV uint32_t fetch(int c) const {
         const int i = c * 64 + (int)threadIdx.x;
         return i < n_words ? words[i] : 0u;
@@ -131,8 +138,8 @@ struct Stream {
         p = bit;
         const int c = bit >> 11;
         wave_order();
-        ring[(c & 1) * 64 + threadIdx.x] = fetch(c);
-        ring[((c + 1) & 1) * 64 + threadIdx.x] = fetch(c + 1);
+        store_chunk(c, fetch(c));
+        store_chunk(c + 1, fetch(c + 1));
         loaded = c + 2;
         pre = fetch(loaded);
         wave_order();
@@ -140,18 +147,27 @@ struct Stream {
     PA_DEV void ensure() {
         while (((p + reach) >> 11) >= loaded) {
             wave_order();
-            ring[(loaded & 1) * 64 + threadIdx.x] = pre;
+            store_chunk(loaded, pre);
             ++loaded;
             pre = fetch(loaded);
             wave_order();
         }
     }
-    // 64 bits from bit position q (the lane's own, or a uniform one)
+    // 64 bits from bit position q (the lane's own, or a uniform one): three consecutive words from the ring (its mirror makes them so)
     PA_DEV uint64_t bits_at(int q) const {
-        const int d = q >> 5, sh = q & 31;
-        const uint32_t w0 = ring[d & (RING_WORDS - 1)], w1 = ring[(d + 1) & (RING_WORDS - 1)], w2 = ring[(d + 2) & (RING_WORDS - 1)];
+        const int sh = q & 31;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ring) + ((q >> 3) & ((RING_WORDS - 1) << 2)));
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
         const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
         return ((uint64_t)hi << 32) | lo;
+    }
+    // ... and the 64 bits from q + 64 with them: five consecutive words
+    PA_DEV void bits2_at(int q, uint64_t& a, uint64_t& b) const {
+        const int sh = q & 31;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ring) + ((q >> 3) & ((RING_WORDS - 1) << 2)));
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+        a = ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+        b = ((uint64_t)__builtin_amdgcn_alignbit(w4, w3, sh) << 32) | __builtin_amdgcn_alignbit(w3, w2, sh);
     }
     PA_DEV uint64_t peek() {                    // uniform
         ensure();
@@ -714,15 +730,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             };
             // ---- window A: the 64 bit offsets from p; window B (WIDE, when the steps are small): the 64 behind them ----
             int adv, kindv, val, dist;
-            {
-                const uint64_t bits = in.bits_at(in.p + lane);
-                lookup((uint32_t)bits, (uint32_t)(bits >> 32), adv, kindv, val, dist);
-            }
             int adv_b = A_INVALID, kindv_b = 0, val_b = 0, dist_b = 0;
             const bool two = WIDE && wide;                  // (uniform)
             if (two) {
-                const uint64_t bits = in.bits_at(in.p + 64 + lane);
-                lookup((uint32_t)bits, (uint32_t)(bits >> 32), adv_b, kindv_b, val_b, dist_b);
+                uint64_t bits, bits_b;
+                in.bits2_at(in.p + lane, bits, bits_b);
+                lookup((uint32_t)bits, (uint32_t)(bits >> 32), adv, kindv, val, dist);
+                lookup((uint32_t)bits_b, (uint32_t)(bits_b >> 32), adv_b, kindv_b, val_b, dist_b);
+            } else {
+                const uint64_t bits = in.bits_at(in.p + lane);
+                lookup((uint32_t)bits, (uint32_t)(bits >> 32), adv, kindv, val, dist);
             }
             unsigned long long chain = 0, chain_b = 0;
             int k = 0, f, stop = 0;
