@@ -82,7 +82,8 @@ struct Tables {
     uint8_t lens[MAX_LIT + MAX_DIST + 16];        // literal/length lengths, then the distance lengths
     uint8_t cl_lens[20];
     uint32_t ring[RING_WORDS + RING_MIRROR];
-    uint8_t scratch[64];                          // per output byte of a step: the lane of the symbol that starts there
+    uint8_t scratch[128];                         // per output byte of a step: the lane of the symbol that starts there (+ 64 bytes
+                                                  // nobody reads: where the lanes that are no symbol write, so that no lane is masked)
 };
 
 PA_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -479,7 +480,9 @@ constexpr int WIDE_BELOW = 48;
 #ifndef PA_INFLATE_WIDE_DEFAULT
 #define PA_INFLATE_WIDE_DEFAULT 1
 #endif
-template <int WAVES, bool WIDE>
+// STATS: the step / match / long-code counts of PA_INFLATE_DEBUG (a handful of scalar instructions per step on the unit that binds the
+// kernel: compiled in only for the launches that ask for them).
+template <int WAVES, bool WIDE, bool STATS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const int64_t* __restrict__ comp_off,
                                                          const int32_t* __restrict__ comp_len, const int64_t* __restrict__ out_off,
                                                          const int32_t* __restrict__ out_len, uint8_t* out_base,
@@ -505,6 +508,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     int pos = 0;                 // bytes written
     int err = INF_OK;
     bool wide = WIDE;            // the next step takes two windows
+    int bad_dist = 0;            // per lane: a match of this member reached in front of it
     in.reach = WIDE ? 224 : 160;
     // (A wavefront's vector memory operations reach its L1 in program order: a load issued after a store of the same
     // wavefront to the same bytes returns them -- the ordinary single-thread guarantee every in-place loop relies on; the
@@ -524,13 +528,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     int pend_n = 0, pend_pos = 0;
     int pend_val = 0, pend_root = 0;
     uint8_t pend_byte = 0;
-    auto complete = [&]() {
-        if (pend_n) {
-            const int own = pend_val >= 0 ? pend_val : (int)pend_byte;
-            const int v = __builtin_amdgcn_ds_bpermute(pend_root << 2, own);
-            if (lane < pend_n) out[pend_pos + lane] = (uint8_t)v;
-            pend_n = 0;
-        }
+    auto complete = [&]() {          // (with nothing pending no lane stores: no test of pend_n on the scalar unit)
+        const int own = pend_val >= 0 ? pend_val : (int)pend_byte;
+        const int v = __builtin_amdgcn_ds_bpermute(pend_root << 2, own);
+        if (lane < pend_n) out[pend_pos + lane] = (uint8_t)v;
+        pend_n = 0;
     };
 
     bool last = olen == 0 && clen == 0;        // nothing at all: an empty member without a stream
@@ -628,9 +630,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         // ---- the symbols of the block: 64 bit offsets at a time ----
         // Lane k decodes whatever starts at bit p + k (most offsets are inside a symbol: their result is never looked at);
         // the symbols that do start in the window are found by following the lengths from offset 0.
-        ++n_blocks_in;
+        if (STATS) ++n_blocks_in;
         for (bool more = true; more && !err;) {
-            ++n_steps;
+            if (STATS) ++n_steps;
             in.ensure();
             // what starts at a bit offset: the symbol's bits | flags, its literal / length, its distance
             auto lookup = [&](uint32_t lo, uint32_t hi, int& adv, int& kind, int& val, int& dist) {
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     k -= f;                                  // the offset of what stopped the walk; it is no symbol of the step
                     chain &= ~(1ull << k);
                     if (f < A_INVALID) return;               // the end-of-block code: f = A_END | its length
-                    ++n_fallback;
+                    if (STATS) ++n_fallback;
                     const uint64_t bits_k = in.bits_at(in.p + base + k);            // (uniform: every lane reads the same three words)
                     const uint32_t lo_k = (uint32_t)uni((int)(uint32_t)bits_k), hi_k = (uint32_t)uni((int)(uint32_t)(bits_k >> 32));
                     uint32_t e_k = (uint32_t)uni((int)T.lit_table[lo_k & ((1u << LIT_BITS) - 1u)]);
@@ -818,8 +820,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 // of the step, or an earlier byte of this same step, followed back to a literal or a memory byte.
                 T.scratch[lane] = 0xff;
                 wave_order();
-                if (kind != 0) T.scratch[off] = (uint8_t)lane;
-                if (kind_b != 0) T.scratch[off_b] = (uint8_t)(64 + lane);
+                T.scratch[kind != 0 ? off : 64 + lane] = (uint8_t)lane;
+                T.scratch[kind_b != 0 ? off_b : 64 + lane] = (uint8_t)(64 + lane);
                 wave_order();
                 const int mark = T.scratch[lane];
                 const int packed = wave_scan_max(mark != 0xff ? (lane << 8 | mark) : -1);
@@ -832,13 +834,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 const int mi = lane < produced ? (word >> 25) & 1 : 0;            // this byte comes from a match
                 const bool m = mi != 0;
                 const int sval = word & 511, d = (word >> 9) & 0xffff;
-                if (__ballot((m ? d : 0) > pos + start)) { err = INF_DISTANCE; break; }
+                // (a distance that reaches in front of the member: remembered per lane and reported when the block ends -- one vector
+                // instruction here instead of a test and a branch on the scalar unit; the source is clamped into the member meanwhile)
+                bad_dist |= (m ? d : 0) > pos + start ? 1 : 0;
                 int rel = lane - start;
                 const bool wraps = (m ? d : 0x7fffffff) < sval;                  // distance < length: the source repeats
                 if (__ballot(wraps)) {
                     if (wraps) rel %= d;
                 }
-                const int src = pos + start - d + rel;
+                const int src = max(pos + start - d + rel, 0);
                 const bool in_step = (m ? src : -1) >= pos, from_mem = (m ? src : 0x7fffffff) < pos;
                 int root = in_step ? src - pos : lane;
                 if (__ballot(in_step)) {
@@ -848,10 +852,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                         root = next;
                     }
                 }
-                n_match += __popcll(matches) + __popcll(matches_b);
+                if (STATS) n_match += __popcll(matches) + __popcll(matches_b);
                 if (pend_n && __ballot((from_mem ? src : -1) >= pend_pos)) complete();
-                uint8_t b = 0;
-                if (from_mem) b = out[src];
+                const uint8_t b = out[from_mem ? src : 0];              // (every lane loads: the others the member's first byte, one line)
                 complete();                                            // the step before: its loads were issued a step ago
                 pend_byte = b;
                 pend_val = lane < produced ? (m ? -1 : sval) : -1;
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     const int mlen = __builtin_amdgcn_readlane(val, m), md = __builtin_amdgcn_readlane(dist, m);
                     const int dst = pos + __builtin_amdgcn_readlane(off, m);
                     if (md > dst) { err = INF_DISTANCE; break; }
-                    ++n_match;
+                    if (STATS) ++n_match;
                     copy_match(dst, mlen, md);
                 }
             }
@@ -926,6 +929,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 }
             }
         }
+        if (!err && __ballot(bad_dist != 0)) err = INF_DISTANCE;
     }
     complete();
     if (!err && pos != olen) err = INF_OUTPUT;
@@ -943,7 +947,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         if (crc != want) err = INF_CRC;
     }
     if (lane == 0) status[blk] = err;
-    if (dbg && lane == 0) {
+    if (STATS && dbg && lane == 0) {
         atomicAdd(&dbg[0], (unsigned long long)n_steps);
         atomicAdd(&dbg[1], (unsigned long long)n_match);
         atomicAdd(&dbg[2], (unsigned long long)n_fallback);
@@ -1073,12 +1077,17 @@ void launch_bgzf_inflate(hipStream_t stream, const uint8_t* comp, const int64_t*
     // PA_INFLATE_WIDE=0 / 1: the one-window / two-window step (A/B runs; the default is what measured faster)
     static const int wide = [] { const char* v = getenv("PA_INFLATE_WIDE"); return v ? atoi(v) != 0 : PA_INFLATE_WIDE_DEFAULT; }();
     static const int below = [] { const char* v = getenv("PA_INFLATE_WIDE_BELOW"); return v ? atoi(v) : WIDE_BELOW; }();
-    if (wide)
-        hipLaunchKernelGGL((bgzf_inflate_kernel<6, true>), dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
-                           status, debug_counts, comp_bytes, below);
-    else
-        hipLaunchKernelGGL((bgzf_inflate_kernel<6, false>), dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out,
-                           status, debug_counts, comp_bytes, below);
+#define PA_LAUNCH_INFLATE(W, S)                                                                                                        \
+    hipLaunchKernelGGL((bgzf_inflate_kernel<6, W, S>), dim3(n_blocks), dim3(64), 0, stream, comp, comp_off, comp_len, out_off, out_len, out, \
+                       status, debug_counts, comp_bytes, below)
+    if (debug_counts) {
+        if (wide) PA_LAUNCH_INFLATE(true, true);
+        else PA_LAUNCH_INFLATE(false, true);
+    } else {
+        if (wide) PA_LAUNCH_INFLATE(true, false);
+        else PA_LAUNCH_INFLATE(false, false);
+    }
+#undef PA_LAUNCH_INFLATE
 }
 
 const char* inflate_status_text(int32_t s) {
