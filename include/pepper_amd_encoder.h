@@ -221,7 +221,8 @@ int pa_polish_chain_chunks(pa_encoder* e, const uint8_t** images, const int64_t*
 int pa_polish_chain_device_chunks(pa_encoder* e, const uint8_t** images);
 /* Host-clock times of the last run in ms: [0] tables + upload + unpack launch, [1] re-aligner (its waits included) + apply,
  * [2] summary encoder (its wait included), [3] chunk kernel + download; HIP events: [5] score kernels, [6] band launches.
- * counts: [0] (read, region) pairs, [1] reads re-aligned, [2] CIGAR operations written, [3] summary rows. */
+ * counts: [0] (read, region) pairs, [1] reads re-aligned, [2] CIGAR operations written, [3] summary rows, [4] reads whose 8-bit
+ * score pass was proven to overflow from their BAM alignment and skipped (ssw.c:819-824 discards that pass's results). */
 int pa_polish_chain_last_timing(pa_encoder* e, double* ms, int32_t n_ms, int64_t* counts, int32_t n_counts);
 
 #ifdef __cplusplus

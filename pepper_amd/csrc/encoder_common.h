@@ -177,16 +177,18 @@ namespace pa_ra {
 // position - region start, region, flags) against window `region`: codes [window_off[region], + window_len[region]) of the
 // window text uploaded by this call.  Reads without READ_MAPQ_OK are not aligned (the summary skips them).  On return the
 // re-aligner's stream (the one it was created on) has been waited for once or more; the results are on the device: jobs (the kernels' table: state, ref_begin, ops_off,
-// n_ops per read) and the compacted operations (len << 4 | op).
+// n_ops per read) and the compacted operations (len << 4 | op).  d_cigar_op / d_cigar_len: the reads' clipped BAM alignments
+// (ReadRec.c0 / ncig; null: none) -- only used to prove that a read's 8-bit score pass overflows, which is then not run.
 struct DeviceResult {
     const void* jobs = nullptr;          // Job [n_reads] (realign.hip)
     const uint32_t* ops = nullptr;
     int64_t ops_written = 0;
     int32_t n_aligned = 0;
+    int32_t n_proven = 0;                // reads whose 8-bit score pass was proven to overflow from their BAM alignment and not run
 };
 int align_device(pa_realigner* r, const char* window_text, int64_t window_bytes, const int64_t* window_off,
                  const int32_t* window_len, int32_t n_windows, const pa_enc::ReadRec* d_reads, int32_t n_reads, const char* d_seq,
-                 int64_t seq_bytes, int32_t max_region_len, DeviceResult* out);
+                 int64_t seq_bytes, int32_t max_region_len, const int32_t* d_cigar_op, const int32_t* d_cigar_len, DeviceResult* out);
 // per read k with a new alignment: reads[k].row0 += ref_begin, its CIGAR = the operations decoded into cigar_op / cigar_len at
 // ops_base + ops_off ('=' and 'X' as MATCH when collapse_eqx), c0 / ncig pointing there
 int apply_device(pa_realigner* r, pa_enc::ReadRec* d_reads, int32_t n_reads, int32_t* cigar_op,

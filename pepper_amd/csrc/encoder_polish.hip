@@ -431,7 +431,7 @@ struct pa_polish_batch {
     int64_t n_chunks = 0;
     int32_t chunk_size = 0;
     double chain_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t chain_counts[4] = {0, 0, 0, 0};   // pairs, reads re-aligned, operations written, rows
+    int64_t chain_counts[5] = {0, 0, 0, 0, 0};   // pairs, reads re-aligned, operations written, rows, 8-bit passes proven away
 };
 
 void pa_polish_batch_free(pa_polish_batch* b) { delete b; }
@@ -895,10 +895,11 @@ int pa_polish_chain_run(pa_encoder* e, int32_t n_regions, const pa_packed_region
         }
         pa_ra::DeviceResult res;
         rc = pa_ra::align_device(e->realigner, text, window_bytes, woff.data(), wlen.data(), n_regions, u.reads, (int32_t)u.n_pairs, u.seq,
-                                 u.total_bases, max_L, &res);
+                                 u.total_bases, max_L, u.cigar_op, u.cigar_len, &res);
         if (rc != PA_OK) return rc;
         b.chain_counts[1] = res.n_aligned;
         b.chain_counts[2] = res.ops_written;
+        b.chain_counts[4] = res.n_proven;
         if (res.ops_written > u.extra_ops) return pa::set_error(PA_ERR_HIP, "polish chain: more re-aligned operations than the CIGAR arrays hold");
         (void)pa_realigner_last_timing(e->realigner, &b.chain_ms[5], &b.chain_ms[6], nullptr);
         rc = pa_ra::apply_device(e->realigner, u.reads, (int32_t)u.n_pairs, u.cigar_op, u.cigar_len, u.total_ops, 1);
@@ -989,7 +990,7 @@ int pa_polish_chain_device_chunks(pa_encoder* e, const uint8_t** images) {
 int pa_polish_chain_last_timing(pa_encoder* e, double* ms, int32_t n_ms, int64_t* counts, int32_t n_counts) {
     if (!e || n_ms < 0 || n_counts < 0) return pa::set_error(PA_ERR_INVALID, "null argument");
     for (int i = 0; ms && i < n_ms; ++i) ms[i] = (e->polish && i < 8) ? e->polish->chain_ms[i] : 0.0;
-    for (int i = 0; counts && i < n_counts; ++i) counts[i] = (e->polish && i < 4) ? e->polish->chain_counts[i] : 0;
+    for (int i = 0; counts && i < n_counts; ++i) counts[i] = (e->polish && i < 5) ? e->polish->chain_counts[i] : 0;
     return PA_OK;
 }
 

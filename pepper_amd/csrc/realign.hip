@@ -303,7 +303,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MAXN <= 20 ?
     PassOut f = {0, 0, 0, 0};
     int wide = 0, ref_begin = -1, read_begin = -1;
     const long long t_start = wall_clock64();
-    for (int pass = 0; pass < 3; ++pass) {
+    f.overflow = uni_value(J.wide) != 0;          // the job's builder has proven that the 8-bit pass overflows (overflow_proven): not run
+    for (int pass = f.overflow ? 1 : 0; pass < 3; ++pass) {
         if (pass == 1 && !f.overflow) continue;
         if (pass == 2 && !(f.score > 0 && f.ref >= 0)) continue;
         const bool rev = pass == 2;
@@ -549,9 +550,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void
     PassOut fa = {0, 0, 0, 0}, fb = {0, 0, 0, 0}, o1 = {0, 0, 0, 0}, o2 = {0, 0, 0, 0};
     int wide_a = 0, wide_b = 0, bad = 0;
     int rbeg_a = -1, qbeg_a = -1, rbeg_b = -1, qbeg_b = -1;
+    // a read whose 8-bit pass is proven to overflow (overflow_proven, by the job's builder) does not run it: the library throws that
+    // pass away whole (ssw.c:819-824); a pair of two such reads starts with the 16-bit segmentation
+    fa.overflow = uni(JA.wide) != 0;
+    fb.overflow = two && uni(JB.wide) != 0;
     for (int pass = 0; pass < 3; ++pass) {
         bool on_a, on_b;
-        if (pass == 0) { on_a = true; on_b = two; }
+        if (pass == 0) { on_a = !fa.overflow; on_b = two && !fb.overflow; }
         else if (pass == 1) { on_a = fa.overflow == 1; on_b = two && fb.overflow == 1; }
         else { on_a = fa.score > 0 && fa.ref >= 0; on_b = two && fb.score > 0 && fb.ref >= 0; }
         if (!on_a && !on_b) continue;
@@ -562,8 +567,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void
                            !on_b ? 0 : (rev ? fb.read + 1 : mb), (pass == 1 || (rev && wide_b)) ? 8 : 16, (rev && on_b) ? fb.score : -1};
         score_pass_pk<R>(snap, ha, hb, rev ? -1 : 1, rev ? -1 : 1, o1, o2);
         bad |= (on_a && o1.overflow == 2) | ((on_b && o2.overflow == 2) << 1);
-        if (pass == 0) { fa = o1; fb = o2; }
-        else if (pass == 1) {
+        if (pass == 0) {
+            if (on_a) fa = o1;
+            if (on_b) fb = o2;
+        } else if (pass == 1) {
             if (on_a) { fa = o1; wide_a = 1; }
             if (on_b) { fb = o2; wide_b = 1; }
         } else {
@@ -1230,7 +1237,7 @@ int pa_realigner_copy_cigars(pa_realigner* r, int32_t collapse_eqx, int64_t* cig
 // rounds of pa_realigner_align_windows afterwards.
 namespace {
 
-enum { DC_TOO_LONG = 0, DC_BAD = 1, DC_UNFINISHED = 2, DC_ERR = 3, DC_ALIGNED = 4, DC_N = 8 };     // int32 counters; [6..7] = dir bytes (u64)
+enum { DC_TOO_LONG = 0, DC_BAD = 1, DC_UNFINISHED = 2, DC_ERR = 3, DC_ALIGNED = 4, DC_PROVEN = 5, DC_N = 8 };     // int32 counters; [6..7] = dir bytes (u64)
 
 // one wave per read: its kept bases (text) -> codes at the same offsets
 __global__ __launch_bounds__(256) void codes_of_reads_kernel(const pa_enc::ReadRec* __restrict__ reads, int n_reads,
@@ -1245,9 +1252,55 @@ __global__ __launch_bounds__(256) void codes_of_reads_kernel(const pa_enc::ReadR
     }
 }
 
+// Does the 8-bit pass of this read overflow for certain?  (ssw.c:819-824: a running maximum >= 249 sends the read through the
+// 16-bit pass and the 8-bit pass's results are thrown away -- ~6 % of the score stage for nothing, on every long read.)  The BAM
+// alignment the read came with is a path through the matrix, and the pass's cell values are bounded from below along ANY path:
+//   diagonal  h(i, j) >= hs(i, j) >= h(i-1, j-1) + s(i, j)     (the cell's first term; s = +4 / -6)
+//   rows      h(i+k, j) >= h(i, j) - 8 - 2 (k - 1)             (the exact vertical chain ff, which no segment start resets)
+//   columns   hs(i, j+k) >= hs(i, j) - 8 - 2 (k - 1)           (E opens from hs: the library's segment-local value, so the bound
+//                                                                is carried for hs, and a row move leaves it at 0)
+// and every value is >= 0.  A path value >= 249 means a column maximum >= 249, which is the overflow; the walk stops there
+// (~75 bases into an ordinary read).  One thread per read: op codes M 0, I 1, D 2, N 3, S 4, = 7, X 8 as unpack_clip_kernel kept them
+// (the first kept operation is an M that starts at the read's first base and the window column the job starts at).
+__device__ bool overflow_proven(const int32_t* __restrict__ cigar_op, const int32_t* __restrict__ cigar_len, int c0, int ncig,
+                                const int8_t* __restrict__ read, int m, const int8_t* __restrict__ ref, int n) {
+    constexpr int LIMIT = 255 - BIAS;
+    if (S_MATCH * min(m, n) < LIMIT) return false;
+    int lh = 0, lhs = 0, i = 0, j = 0;                 // bounds of h and hs at the path's last cell (i - 1, j - 1)
+    for (int o = 0; o < ncig; ++o) {
+        const int op = cigar_op[c0 + o], len = cigar_len[c0 + o];
+        if (len <= 0) continue;
+        if (op == 0 || op == 7 || op == 8) {
+            const int k_end = min(len, min(m - i, n - j));
+            for (int k = 0; k < k_end; ++k) {
+                const int q = read[i + k], c = ref[j + k];
+                lh = max(lh + ((q == c && (unsigned)q < 4u) ? S_MATCH : -S_MIS), 0);
+                if (lh >= LIMIT) return true;
+            }
+            lhs = lh;
+            i += len; j += len;
+        } else if (op == 1 || op == 4) {
+            lh = max(lh - GO - (len - 1) * GE, 0);
+            lhs = 0;
+            i += len;
+        } else if (op == 2 || op == 3) {
+            lhs = max(lhs - GO - (len - 1) * GE, 0);
+            lh = lhs;
+            j += len;
+        } else {
+            lh = lhs = 0;                              // (nothing unpack_clip_kernel keeps; claim nothing)
+        }
+        if (i >= m || j >= n) break;
+    }
+    return false;
+}
+
+// cigar_op / cigar_len: the reads' clipped BAM alignments (ReadRec.c0 / ncig), or null: no read is proven
 __global__ __launch_bounds__(256) void jobs_of_reads_kernel(const pa_enc::ReadRec* __restrict__ reads, int n_reads,
                                                             const int64_t* __restrict__ window_off, const int32_t* __restrict__ window_len,
-                                                            Job* __restrict__ jobs, int* __restrict__ counters, int max_m) {
+                                                            Job* __restrict__ jobs, int* __restrict__ counters, int max_m,
+                                                            const int32_t* __restrict__ cigar_op, const int32_t* __restrict__ cigar_len,
+                                                            const int8_t* __restrict__ ref, const int8_t* __restrict__ seq) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n_reads) return;
     const pa_enc::ReadRec rd = reads[k];
@@ -1264,7 +1317,14 @@ __global__ __launch_bounds__(256) void jobs_of_reads_kernel(const pa_enc::ReadRe
         else {
             J.ref_off = (int32_t)(window_off[rd.region] + off);
             J.n = wl - off;
-            if (J.n > 0) J.state = ST_NEW;
+            if (J.n > 0) {
+                J.state = ST_NEW;
+                // (J.wide on the way in: the score kernels start this read with the 16-bit segmentation; on the way out it is what it was)
+                if (cigar_op && overflow_proven(cigar_op, cigar_len, rd.c0, rd.ncig, seq + rd.s0, rd.slen, ref + J.ref_off, J.n)) {
+                    J.wide = 1;
+                    atomicAdd(&counters[DC_PROVEN], 1);
+                }
+            }
         }
     }
     jobs[k] = J;
@@ -1397,7 +1457,7 @@ int band_rounds_host(pa_realigner* r, Job* dj, const int8_t* dref, const int8_t*
 
 int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window_bytes, const int64_t* window_off,
                         const int32_t* window_len, int32_t n_windows, const pa_enc::ReadRec* d_reads, int32_t n_reads, const char* d_seq,
-                        int64_t seq_bytes, int32_t max_region_len, DeviceResult* out) {
+                        int64_t seq_bytes, int32_t max_region_len, const int32_t* d_cigar_op, const int32_t* d_cigar_len, DeviceResult* out) {
     if (!r || !out || n_reads < 0 || n_windows < 0 || window_bytes < 0 || seq_bytes < 0 ||
         (n_reads > 0 && (!window_text || !window_off || !window_len || !d_reads || !d_seq || n_windows <= 0)))
         return pa::set_error(PA_ERR_INVALID, "null argument");
@@ -1454,15 +1514,20 @@ int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window
     if (window_bytes > 0)
         hipLaunchKernelGGL(to_codes_kernel, dim3((unsigned)((window_bytes + 255) / 256)), dim3(256), 0, st, dref, window_bytes);
     hipLaunchKernelGGL(codes_of_reads_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, d_reads, n_reads, d_seq, dseq);
-    hipLaunchKernelGGL(jobs_of_reads_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, d_reads, n_reads, d_woff, d_wlen, dj,
-                       d_ctr, max_m);
+    {
+        // PA_REALIGN_PROOF=0: every read runs its 8-bit pass (A/B runs and the test that holds the two forms to each other)
+        const char* v = getenv("PA_REALIGN_PROOF");
+        const bool proof = d_cigar_op && d_cigar_len && !(v && v[0] == '0');
+        hipLaunchKernelGGL(jobs_of_reads_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, d_reads, n_reads, d_woff, d_wlen, dj,
+                           d_ctr, max_m, proof ? d_cigar_op : nullptr, proof ? d_cigar_len : nullptr, dref, dseq);
+    }
     RA_HIP(hipEventRecord(r->ev[0], st));
     {
         // every instantiation over the whole table: a read runs in the narrowest register strip that holds it (two wavefronts per
         // SIMD up to 20 rows per lane); LDS for the rows beyond the widest strip
         const int rows = ((max_m + 15) / 16) * 16, R = (rows + 63) / 64;
         const size_t lds = rows > REG_ROWS ? (size_t)64 * R * 4 : 0;
-        static const char* mode = getenv("PA_REALIGN_SINGLE");                   // (as in pa_realigner_align_windows)
+        const char* mode = getenv("PA_REALIGN_SINGLE");                          // (as in pa_realigner_align_windows; read per call: tests flip it)
         const bool single = mode ? mode[0] == '1' : n_reads <= 2048;
         if (single) {
             hipLaunchKernelGGL(sw_ends_kernel<12>, dim3(n_reads), dim3(64), 0, st, dj, dref, dseq, 0, 12);
@@ -1512,6 +1577,7 @@ int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window
         return pa::set_error(PA_ERR_UNSUPPORTED, "read " + std::to_string(ctr[DC_TOO_LONG] - 1) + " keeps more than " + std::to_string(max_m) +
                                                      " bases of its region (take the host-fed form for this batch)");
     out->n_aligned = ctr[DC_ALIGNED];
+    out->n_proven = ctr[DC_PROVEN];
     // reads whose band left the first rows (ST_WIDER: from the layout or from the band kernel's doubling), and -- never, unless a
     // kernel is wrong -- a band that found nothing (ST_ERR): the table comes to the host and the remaining rounds run as in
     // pa_realigner_align_windows, with full rows

@@ -200,10 +200,11 @@ class PolishChain(object):
                 np.ctypeslib.as_array(ctypes.cast(idx, ctypes.POINTER(ctypes.c_int64)), shape=(n, c)))
 
     def timing(self):
-        ms, counts = np.zeros(8, np.float64), np.zeros(4, np.int64)
-        _lib.check(self.lib.pa_polish_chain_last_timing(self.packed.enc, ms.ctypes.data, 8, counts.ctypes.data, 4))
+        ms, counts = np.zeros(8, np.float64), np.zeros(5, np.int64)
+        _lib.check(self.lib.pa_polish_chain_last_timing(self.packed.enc, ms.ctypes.data, 8, counts.ctypes.data, 5))
         return dict(unpack_ms=ms[0], realign_ms=ms[1], encode_ms=ms[2], chunk_ms=ms[3], score_kernel_ms=ms[5], band_kernel_ms=ms[6],
-                    pairs=int(counts[0]), realigned=int(counts[1]), cigar_ops=int(counts[2]), rows=int(counts[3]))
+                    pairs=int(counts[0]), realigned=int(counts[1]), cigar_ops=int(counts[2]), rows=int(counts[3]),
+                    proven_overflows=int(counts[4]))
 
 
 _realigners = {}

@@ -200,6 +200,49 @@ def test_chain_host_packed_form_and_no_realignment(tmp_path, monkeypatch):
     enc.close()
 
 
+def test_proven_overflows_skip_the_8_bit_pass_and_change_nothing(tmp_path, monkeypatch):
+    """The job builder walks every read's BAM alignment and, where the path's score reaches 249, marks the read: its 8-bit score
+    pass (whose results ssw.c:819-824 throws away on overflow) is not run.  PA_REALIGN_PROOF=0 runs every pass: the same chunks,
+    byte for byte, in the one-read and in the two-reads-per-wavefront kernels; most long reads are proven, reads shorter than 63
+    bases never are.  (The comparisons with the reference's SSW build above run with the proof on: it is the default.)"""
+    from pepper_amd.polish import PEPPER
+    from pepper_amd.variant.PEPPER_VARIANT import PackedEncoder
+    from pepper_amd.variant.bam import BAM_handler
+    rng = np.random.default_rng(12)
+    short = [dict(pos=int(p), reverse=False, mapq=60, seq=None, qual=np.full(50, 20, np.uint8), cigar=[(0, 50)]) for p in (300, 1500, 2600)]
+    draft, reads, bam_path, fa_path = _dataset(tmp_path, 41, 3300, 260, (200, 2500))
+    for r in short:
+        r["seq"] = draft[r["pos"]:r["pos"] + 50]
+    reads = sorted(reads + short, key=lambda r: r["pos"])
+    for i, r in enumerate(reads):
+        r["name"] = "q%d" % i
+    bu.write_bam(bam_path, [("ctg1", len(draft))], {0: reads})
+    bam = BAM_handler(bam_path)
+    bounds = [(0, 1100), (900, 2100), (1900, 3100)]
+    windows = [draft[a:b + 21].encode() for a, b in bounds]
+    results = {}
+    for single in ("1", "0"):
+        monkeypatch.setenv("PA_REALIGN_SINGLE", single)
+        for proof in ("1", "0"):
+            monkeypatch.setenv("PA_REALIGN_PROOF", proof)
+            enc = PackedEncoder(0, 64 << 20, host_threads=1)
+            chain = PEPPER.PolishChain(enc)
+            n_done, region_pairs, counts = enc.pack(bam, "ctg1", [a for a, _ in bounds], [b for _, b in bounds], False, 0)
+            assert n_done == 3
+            rows, live, chunks = chain.run(bounds, windows, region_pairs, counts, realign=True)
+            t = chain.timing()
+            results[single, proof] = ([a.copy() for a in chain.chunk_arrays()], list(chunks), t["proven_overflows"], t["realigned"], t["pairs"])
+            enc.close()
+    for single in ("1", "0"):
+        on, off = results[single, "1"], results[single, "0"]
+        assert off[2] == 0 and on[2] > 0.6 * on[3] and on[2] <= on[4] - 3, (on[2:], off[2:])
+        assert on[1] == off[1] and on[3] == off[3]
+        for a, b in zip(on[0], off[0]):
+            assert np.array_equal(a, b)
+    for a, b in zip(results["1", "1"][0], results["0", "1"][0]):
+        assert np.array_equal(a, b)
+
+
 def test_chain_refuses_what_it_cannot_hold(tmp_path):
     """A read that keeps more bases of a region than a pair's slot (2 L + 64): PA_ERR_UNSUPPORTED, and image generation takes the
     host form for that run of intervals."""

@@ -43,7 +43,7 @@ def run(data, thread_counts=(8,), regions_per_call=None, warm=True):
         make_images(bam, fa, None, tmp, threads, stats=stages)
         dt = time.perf_counter() - t0
         size = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp))
-        counts = {k: int(stages.pop(k)) for k in ("pairs", "realigned", "cigar_ops", "rows") if k in stages}
+        counts = {k: int(stages.pop(k)) for k in ("pairs", "realigned", "cigar_ops", "rows", "proven_overflows") if k in stages}
         n_intervals = -(-info["genome_bases"] // 1000)
         runs.append({"threads": threads, "seconds": round(dt, 3), "mb_draft_per_s": round(mb / dt, 2),
                      "intervals_per_s": round(n_intervals / dt, 1), "reads_realigned_per_s": round(counts.get("realigned", 0) / dt, 1),
