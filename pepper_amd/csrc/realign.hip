@@ -525,9 +525,10 @@ __device__ __host__ inline int strip_of(int m) { return (((((m + 15) / 16) * 16)
 constexpr int pk_lds_bytes(int R) { return 2 * 64 * ((R + 3) & ~3) * 4; }
 template <int R, int W>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void sw_ends_pair_kernel(Job* __restrict__ jobs, const JobPair* __restrict__ pairs, const int* __restrict__ n_pairs,
-                                                          const int8_t* __restrict__ ref, const int8_t* __restrict__ seq, int r_lo, int r_hi) {
+                                                          const int8_t* __restrict__ ref, const int8_t* __restrict__ seq, int r_lo, int r_hi, int adaptive) {
     extern __shared__ uint32_t snap[];
-    if ((int)blockIdx.x >= *n_pairs) return;
+    if ((int)blockIdx.x >= n_pairs[0]) return;
+    if (adaptive && n_pairs[1] != R) return;          // (pair_jobs_kernel chose the strip size of this call on the device: one kernel of the ladder runs)
     const JobPair pr = pairs[blockIdx.x];
     Job& JA = jobs[pr.a];
     Job& JB = jobs[pr.b >= 0 ? pr.b : pr.a];
@@ -594,16 +595,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void
 // One launch per call (and a catch-all): the kernel of the strip size that holds the call's longest ordinary read takes every
 // pair up to that size -- shorter reads leave lanes idle, which costs less than the tail of a launch of their own (measured:
 // eight size-sorted launches 11.6 ms, one 7.7 ms for 8 000 reads) -- and the widest kernel takes what is longer.
-inline void launch_pair_kernels(hipStream_t st, int np, Job* dj, const JobPair* dp, const int* dn, const int8_t* dref, const int8_t* dseq, int need) {
-    int size = 24;
+// adaptive (the device-fed form, where the host knows only a bound of the reads' lengths): every size of the ladder up to that
+// bound is launched and all but one return at once -- the one pair_jobs_kernel found to be the smallest that holds the call's
+// longest read within the bound (pairs[0].b).  A step of the pass is R rows of instructions whatever the read's length: a
+// 1 220-base region's reads fit 20 rows per lane, the bound (region + 10 % + 16) asked for 22.
+constexpr int PAIR_LADDER[6] = {8, 12, 16, 18, 20, 22};
+__device__ constexpr int PAIR_LADDER_DEV[6] = {8, 12, 16, 18, 20, 22};
+inline int ladder_size(int need) {
+    for (int n : PAIR_LADDER) if (need <= n) return n;
+    return 24;
+}
+inline void launch_pair_kernels(hipStream_t st, int np, Job* dj, const JobPair* dp, const int* dn, const int8_t* dref, const int8_t* dseq, int need,
+                                bool adaptive = false) {
+    const int size = ladder_size(need);
 #define PA_PAIR_SIZE(N)                                                                                                                          \
-    if (need <= N && size == 24 && N < 24) {                                                                                                     \
-        size = N;                                                                                                                                \
-        hipLaunchKernelGGL((sw_ends_pair_kernel<N, (N <= 16 ? 3 : 2)>), dim3((unsigned)np), dim3(64), pk_lds_bytes(N), st, dj, dp, dn, dref, dseq, 0, N); \
-    }
+    if (adaptive ? N <= size : N == size)                                                                                                        \
+        hipLaunchKernelGGL((sw_ends_pair_kernel<N, (N <= 16 ? 3 : 2)>), dim3((unsigned)np), dim3(64), pk_lds_bytes(N), st, dj, dp, dn, dref, dseq, 0, N, adaptive ? 1 : 0);
     PA_PAIR_SIZE(8) PA_PAIR_SIZE(12) PA_PAIR_SIZE(16) PA_PAIR_SIZE(18) PA_PAIR_SIZE(20) PA_PAIR_SIZE(22)
 #undef PA_PAIR_SIZE
-    hipLaunchKernelGGL((sw_ends_pair_kernel<24, 2>), dim3((unsigned)np), dim3(64), pk_lds_bytes(24), st, dj, dp, dn, dref, dseq, size == 24 ? 0 : size, 24);
+    hipLaunchKernelGGL((sw_ends_pair_kernel<24, 2>), dim3((unsigned)np), dim3(64), pk_lds_bytes(24), st, dj, dp, dn, dref, dseq, size == 24 ? (adaptive ? 22 : 0) : size, 24, 0);
 }
 
 // inclusive prefix sum across the wavefront (same DPP pattern as wave_prefix_max)
@@ -1334,14 +1344,21 @@ __global__ __launch_bounds__(256) void jobs_of_reads_kernel(const pa_enc::ReadRe
 // a call has a few thousand reads): pairs[0].a = the number of pairs, pairs[1 ..] the pairs.  Reads beyond 24 rows per lane
 // stay out (the one-read kernel's LDS form takes them).
 __global__ __launch_bounds__(1024) void pair_jobs_kernel(const Job* __restrict__ jobs, int n_reads, int shift, int32_t* __restrict__ order,
-                                                         JobPair* __restrict__ pairs) {
+                                                         JobPair* __restrict__ pairs, int strip_cap) {
     __shared__ int hist[2048];
-    __shared__ int total;
+    __shared__ int total, longest;
     for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0;
+    if (threadIdx.x == 0) longest = 0;
     __syncthreads();
     auto key_of = [&](const Job& J) { const int k = J.n >> shift; return k < 2047 ? k : 2047; };
+    int mine = 0;                                 // the longest strip within the cap (what is longer goes to the widest kernel anyway)
     for (int k = threadIdx.x; k < n_reads; k += 1024)
-        if (jobs[k].state == ST_NEW && strip_of(jobs[k].m) <= 24) atomicAdd(&hist[key_of(jobs[k])], 1);
+        if (jobs[k].state == ST_NEW && strip_of(jobs[k].m) <= 24) {
+            atomicAdd(&hist[key_of(jobs[k])], 1);
+            const int st = strip_of(jobs[k].m);
+            if (st <= strip_cap && st > mine) mine = st;
+        }
+    if (mine) atomicMax(&longest, mine);
     __syncthreads();
     if (threadIdx.x == 0) {                       // exclusive scan of 2048 counters: a few microseconds
         int run = 0;
@@ -1353,7 +1370,11 @@ __global__ __launch_bounds__(1024) void pair_jobs_kernel(const Job* __restrict__
         if (jobs[k].state == ST_NEW && strip_of(jobs[k].m) <= 24) order[atomicAdd(&hist[key_of(jobs[k])], 1)] = k;
     __syncthreads();
     const int np = (total + 1) / 2;
-    if (threadIdx.x == 0) pairs[0] = JobPair{np, 0};
+    if (threadIdx.x == 0) {
+        int size = 24;                            // the ladder of launch_pair_kernels
+        for (int i = 5; i >= 0; --i) if (longest <= PAIR_LADDER_DEV[i]) size = PAIR_LADDER_DEV[i];
+        pairs[0] = JobPair{np, size};
+    }
     for (int i = threadIdx.x; i < np; i += 1024) pairs[i + 1] = JobPair{order[2 * i], 2 * i + 1 < total ? order[2 * i + 1] : -1};
 }
 
@@ -1541,12 +1562,17 @@ int pa_ra::align_device(pa_realigner* r, const char* window_text, int64_t window
             int shift = 0;
             while ((max_wl >> shift) >= 2047) ++shift;
             JobPair* dp = static_cast<JobPair*>(r->d_pairs.p);
-            hipLaunchKernelGGL(pair_jobs_kernel, dim3(1), dim3(1024), 0, st, dj, n_reads, shift, static_cast<int32_t*>(r->d_order.p), dp);
+            // (the reads' lengths are known on the device only: a region's ordinary read keeps its L aligned bases and some
+            // inserts; what is longer than L + L / 10 + 16 goes to the catch-all launch, and within that bound pair_jobs_kernel
+            // picks the strip size the call's longest read needs -- PA_REALIGN_ADAPT=0: the bound's size, as before round 6)
+            const int bound = strip_of(std::min(max_m, max_region_len + max_region_len / 10 + 16));
+            const char* av = getenv("PA_REALIGN_ADAPT");
+            const bool adaptive = !(av && av[0] == '0');
+            hipLaunchKernelGGL(pair_jobs_kernel, dim3(1), dim3(1024), 0, st, dj, n_reads, shift, static_cast<int32_t*>(r->d_order.p), dp,
+                               std::min(ladder_size(bound), 22));
             const int* dn = reinterpret_cast<const int*>(dp);
             const unsigned np = (unsigned)(n_reads + 1) / 2;
-            // (the reads' lengths are known on the device only: a region's ordinary read keeps its L aligned bases and some
-            // inserts; what is longer than L + L / 10 + 16 goes to the catch-all launch)
-            launch_pair_kernels(st, (int)np, dj, dp + 1, dn, dref, dseq, strip_of(std::min(max_m, max_region_len + max_region_len / 10 + 16)));
+            launch_pair_kernels(st, (int)np, dj, dp + 1, dn, dref, dseq, bound, adaptive);
             if (rows > REG_ROWS) hipLaunchKernelGGL(sw_ends_kernel<24>, dim3(n_reads), dim3(64), lds, st, dj, dref, dseq, 24, 1 << 30);
         }
         RA_HIP(hipGetLastError());

@@ -241,6 +241,18 @@ def test_proven_overflows_skip_the_8_bit_pass_and_change_nothing(tmp_path, monke
             assert np.array_equal(a, b)
     for a, b in zip(results["1", "1"][0], results["0", "1"][0]):
         assert np.array_equal(a, b)
+    # ... and the packed form again with the strip size of the call taken from the host's bound (PA_REALIGN_ADAPT=0) instead of
+    # chosen on the device from the reads' lengths
+    monkeypatch.setenv("PA_REALIGN_SINGLE", "0")
+    monkeypatch.setenv("PA_REALIGN_PROOF", "1")
+    monkeypatch.setenv("PA_REALIGN_ADAPT", "0")
+    enc = PackedEncoder(0, 64 << 20, host_threads=1)
+    chain = PEPPER.PolishChain(enc)
+    n_done, region_pairs, counts = enc.pack(bam, "ctg1", [a for a, _ in bounds], [b for _, b in bounds], False, 0)
+    chain.run(bounds, windows, region_pairs, counts, realign=True)
+    for a, b in zip(results["0", "1"][0], chain.chunk_arrays()):
+        assert np.array_equal(a, b)
+    enc.close()
 
 
 def test_chain_refuses_what_it_cannot_hold(tmp_path):
