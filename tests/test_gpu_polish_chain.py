@@ -28,7 +28,7 @@ def _dataset(tmp_path, seed, length, n_reads, read_len, deep_at=None, extra=()):
         a, b, n = deep_at
         more = pu.simulate_reads(rng, draft[a:b], a, n_reads=n, read_len=(120, 260), ins_rate=0.02, del_rate=0.02)
         reads += [r for r in more if not any(op in (3, 6) for op, _ in r["cigar"])]
-    reads += list(extra)
+    reads += list(extra(draft) if callable(extra) else extra)
     reads.sort(key=lambda r: r["pos"])
     for i, r in enumerate(reads):
         r["name"] = "q%d" % i
@@ -37,6 +37,58 @@ def _dataset(tmp_path, seed, length, n_reads, read_len, deep_at=None, extra=()):
     with open(fa_path, "w") as fh:
         fh.write(">ctg1\n" + draft + "\n")
     return draft, reads, bam_path, fa_path
+
+
+def _borderline_reads(draft):
+    """Reads around the 8-bit pass's overflow threshold (a running maximum of 249 = 63 matches): exact copies of 58 .. 70 draft
+    bases, the same with one substitution, and alignments whose path takes a row move next to a column move, a reference skip, N
+    bases -- the shapes the overflow proof's rules treat one by one."""
+    out = []
+
+    def read(pos, seq, cigar):
+        out.append(dict(pos=int(pos), reverse=False, mapq=60, seq=seq, qual=np.full(len(seq), 25, np.uint8), cigar=cigar))
+    flip = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    for k, n in enumerate(range(58, 71)):
+        p = 150 + 37 * k
+        read(p, draft[p:p + n], [(0, n)])
+        q = 1400 + 41 * k
+        seq = draft[q:q + n + 4]
+        read(q, seq[:30] + flip[seq[30]] + seq[31:], [(0, n + 4)])
+    p = 2300
+    read(p, draft[p:p + 40] + "ACG" + draft[p + 43:p + 120], [(0, 40), (1, 3), (2, 3), (0, 77)])          # rows, then columns
+    p = 2500
+    read(p, draft[p:p + 35] + draft[p + 40:p + 40 + 5] + "TTGCA" + draft[p + 45:p + 130], [(0, 35), (2, 5), (0, 5), (1, 5), (0, 85)])
+    p = 2900
+    read(p, draft[p:p + 20] + "N" * 3 + draft[p + 23:p + 100], [(0, 100)])                                   # N bases never match
+    p = 3100
+    read(p, "GGGTT" + draft[p:p + 90] + "ACACA", [(4, 5), (0, 90), (4, 5)])                                  # soft clips
+    return out
+
+
+def _path_bound_reaches_249(seq, cigar, window):
+    """The test's own statement of the overflow proof: lower bounds of the 8-bit pass's h and hs along the read's
+    clipped alignment -- +4 / -6 on the diagonal, 8 + 2 (k - 1) off for k rows (h only; hs falls to 0) or k columns (from hs)."""
+    h = hs = i = j = 0
+    for op, n in cigar:
+        if op in (0, 7, 8):
+            for k in range(min(n, len(seq) - i, len(window) - j)):
+                a, b = seq[i + k], window[j + k]
+                h = max(h + (4 if a == b and a in "ACGT" else -6), 0)
+                if h >= 249:
+                    return True
+            hs = h
+            i += n
+            j += n
+        elif op in (1, 4):
+            h, hs = max(h - 8 - 2 * (n - 1), 0), 0
+            i += n
+        elif op in (2, 3):
+            hs = max(hs - 8 - 2 * (n - 1), 0)
+            h = hs
+            j += n
+        if i >= len(seq) or j >= len(window):
+            break
+    return False
 
 
 def _groups(path):
@@ -79,7 +131,7 @@ def test_chain_images_equal_the_reference_builds(tmp_path, monkeypatch):
     if ref_enc is None or not ssw.have_reference():
         need_reference_build("oracle/_ref (polish encoder, SSW)")
     low = dict(pos=2950, reverse=False, mapq=0, seq="ACGT" * 60, qual=np.full(240, 20, np.uint8), cigar=[(0, 240)])
-    draft, reads, bam_path, fa_path = _dataset(tmp_path, 311, 6300, 330, (500, 3000), extra=[low])
+    draft, reads, bam_path, fa_path = _dataset(tmp_path, 311, 6300, 330, (500, 3000), extra=lambda d: [low] + _borderline_reads(d))
     got = _make(bam_path, fa_path, str(tmp_path / "chain"), 1, True, monkeypatch)
     _, intervals = UserInterfaceSupport.make_intervals([("ctg1", None)], fa_path)
     assert len(intervals) == 7
@@ -213,13 +265,14 @@ def test_proven_overflows_skip_the_8_bit_pass_and_change_nothing(tmp_path, monke
     draft, reads, bam_path, fa_path = _dataset(tmp_path, 41, 3300, 260, (200, 2500))
     for r in short:
         r["seq"] = draft[r["pos"]:r["pos"] + 50]
-    reads = sorted(reads + short, key=lambda r: r["pos"])
+    edge = [r for r in _borderline_reads(draft) if r["pos"] + 200 < len(draft)]
+    reads = sorted(reads + short + edge, key=lambda r: r["pos"])
     for i, r in enumerate(reads):
         r["name"] = "q%d" % i
     bu.write_bam(bam_path, [("ctg1", len(draft))], {0: reads})
     bam = BAM_handler(bam_path)
     bounds = [(0, 1100), (900, 2100), (1900, 3100)]
-    windows = [draft[a:b + 21].encode() for a, b in bounds]
+    windows = [draft[a:b + 20].encode() for a, b in bounds]
     results = {}
     for single in ("1", "0"):
         monkeypatch.setenv("PA_REALIGN_SINGLE", single)
@@ -241,6 +294,21 @@ def test_proven_overflows_skip_the_8_bit_pass_and_change_nothing(tmp_path, monke
             assert np.array_equal(a, b)
     for a, b in zip(results["1", "1"][0], results["0", "1"][0]):
         assert np.array_equal(a, b)
+    # which reads: the test's own walk over the clipped alignments marks exactly as many, and every read it marks scores >= 249 in the
+    # reference's SSW build (the bound holds for the 16-bit pass by the same rules) -- a claim the library's result contradicts
+    # would show here before it showed in an image
+    if ssw.have_reference():
+        marked = 0
+        for (a, b), window in zip(bounds, windows):
+            clipped = [r for r in bu.restated_get_reads(reads, a, b, False, 0) if r.get("mapq", 60) > 0 and r["pos"] >= a]
+            res = ssw.realign_reads(window.decode(), a, [r["pos"] for r in clipped], [r["seq"] for r in clipped], aligner=ssw.align_reference)
+            for r, (st, score, _p, _pe, _ops) in zip(clipped, res):
+                if _path_bound_reaches_249(r["seq"], r["cigar"], window.decode()[r["pos"] - a:]):
+                    marked += 1
+                    assert st == 1 and score >= 249, (r["pos"], score)
+        assert marked == results["1", "1"][2], (marked, results["1", "1"][2])
+    else:
+        need_reference_build("oracle/_ref (SSW)")
     # ... and the packed form again with the strip size of the call taken from the host's bound (PA_REALIGN_ADAPT=0) instead of
     # chosen on the device from the reads' lengths
     monkeypatch.setenv("PA_REALIGN_SINGLE", "0")
