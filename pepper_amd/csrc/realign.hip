@@ -599,11 +599,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) void
 // bound is launched and all but one return at once -- the one pair_jobs_kernel found to be the smallest that holds the call's
 // longest read within the bound (pairs[0].b).  A step of the pass is R rows of instructions whatever the read's length: a
 // 1 220-base region's reads fit 20 rows per lane, the bound (region + 10 % + 16) asked for 22.
-constexpr int PAIR_LADDER[6] = {8, 12, 16, 18, 20, 22};
-__device__ constexpr int PAIR_LADDER_DEV[6] = {8, 12, 16, 18, 20, 22};
-inline int ladder_size(int need) {
-    for (int n : PAIR_LADDER) if (need <= n) return n;
-    return 24;
+// the strip sizes the packed pass is instantiated for: the smallest that holds `need` rows per lane
+__host__ __device__ inline int ladder_size(int need) {
+    return need <= 8 ? 8 : need <= 12 ? 12 : need <= 16 ? 16 : need <= 18 ? 18 : need <= 20 ? 20 : need <= 22 ? 22 : 24;
 }
 inline void launch_pair_kernels(hipStream_t st, int np, Job* dj, const JobPair* dp, const int* dn, const int8_t* dref, const int8_t* dseq, int need,
                                 bool adaptive = false) {
@@ -1371,9 +1369,7 @@ __global__ __launch_bounds__(1024) void pair_jobs_kernel(const Job* __restrict__
     __syncthreads();
     const int np = (total + 1) / 2;
     if (threadIdx.x == 0) {
-        int size = 24;                            // the ladder of launch_pair_kernels
-        for (int i = 5; i >= 0; --i) if (longest <= PAIR_LADDER_DEV[i]) size = PAIR_LADDER_DEV[i];
-        pairs[0] = JobPair{np, size};
+        pairs[0] = JobPair{np, ladder_size(longest)};          // (longest <= strip_cap <= 22: a size of launch_pair_kernels' ladder)
     }
     for (int i = threadIdx.x; i < np; i += 1024) pairs[i + 1] = JobPair{order[2 * i], 2 * i + 1 < total ? order[2 * i + 1] : -1};
 }
